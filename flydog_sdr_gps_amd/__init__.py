@@ -1,0 +1,14 @@
+"""flydog_sdr_gps_amd -- MI355X (gfx950) implementation of the FlyDog_SDR_GPS DSP hot path.
+
+The product is the C-ABI library ``libkiwigpu.so`` (include/kiwigpu.h, sources in
+``csrc/``).  This package is the thin host side above it: a ctypes binding and a
+mirror of the reference's entry points for the path (gps/search.cpp
+SearchInit / Sample / Correlate).  There is no CPU fallback: without the built
+library and a gfx950 device, constructing a context raises.
+"""
+from ._lib import KiwiGpuError, Context, load_library, library_path  # noqa: F401
+from .acq import Searcher, AcqResult  # noqa: F401
+from . import sats, prn, synth  # noqa: F401
+
+__all__ = ["KiwiGpuError", "Context", "Searcher", "AcqResult", "load_library", "library_path",
+           "sats", "prn", "synth"]

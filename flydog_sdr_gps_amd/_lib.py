@@ -1,0 +1,157 @@
+"""ctypes binding of libkiwigpu.so (include/kiwigpu.h).  Fails loudly."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+ABI_VERSION = 1
+
+
+class KiwiGpuError(RuntimeError):
+    def __init__(self, status, where, text):
+        super().__init__("%s failed: %s (status %d)" % (where, text, status))
+        self.status = status
+
+
+def library_path():
+    return os.path.join(_HERE, "libkiwigpu.so")
+
+
+class AcqResultC(C.Structure):
+    _fields_ = [("snr", C.c_float), ("dop", C.c_int32), ("idx", C.c_int32), ("valid", C.c_int32)]
+
+
+class AcqCellC(C.Structure):
+    _fields_ = [("snr", C.c_float), ("max_pwr", C.c_float), ("tot_pwr", C.c_float),
+                ("idx", C.c_int32)]
+
+
+result_dtype = np.dtype([("snr", "<f4"), ("dop", "<i4"), ("idx", "<i4"), ("valid", "<i4")])
+cell_dtype = np.dtype([("snr", "<f4"), ("max_pwr", "<f4"), ("tot_pwr", "<f4"), ("idx", "<i4")])
+
+# name -> (restype, argtypes): every symbol include/kiwigpu.h declares
+_vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
+SYMBOLS = {
+    "kg_strerror": (C.c_char_p, [_i]),
+    "kg_last_error": (C.c_char_p, []),
+    "kg_abi_version": (_i, []),
+    "kg_ctx_create": (_i, [_i, _vp, C.POINTER(_vp)]),
+    "kg_ctx_destroy": (None, [_vp]),
+    "kg_ctx_sync": (_i, [_vp]),
+    "kg_ctx_poll": (_i, [_vp]),
+    "kg_ctx_stream": (_vp, [_vp]),
+    "kg_ctx_device_name": (_i, [_vp, C.c_char_p, _sz]),
+    "kg_ctx_num_cus": (_i, [_vp]),
+    "kg_timer_start": (_i, [_vp]),
+    "kg_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
+    "kg_acq_create": (_i, [_vp, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "kg_acq_destroy": (None, [_vp]),
+    "kg_acq_set_code": (_i, [_vp, _i, _vp, _i, _i, _i]),
+    "kg_acq_set_code_fft": (_i, [_vp, _i, _vp, _i]),
+    "kg_acq_get_code_fft": (_i, [_vp, _i, _vp]),
+    "kg_acq_sample_bits": (_i, [_vp, _i, _vp]),
+    "kg_acq_sample_bits_dev": (_i, [_vp, _i, _vp]),
+    "kg_acq_sample_iq16": (_i, [_vp, _i, _vp]),
+    "kg_acq_sample_iq16_dev": (_i, [_vp, _i, _vp]),
+    "kg_acq_set_data_fft": (_i, [_vp, _i, _vp]),
+    "kg_acq_get_data_fft": (_i, [_vp, _i, _vp]),
+    "kg_acq_get_data_td": (_i, [_vp, _i, _vp]),
+    "kg_acq_correlate_async": (_i, [_vp, _i, _vp, _i]),
+    "kg_acq_fetch": (_i, [_vp, _vp, _vp]),
+    "kg_acq_correlate": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
+    "kg_acq_results_dev": (_vp, [_vp]),
+}
+
+
+def load_library():
+    """dlopen libkiwigpu.so and bind every declared symbol.  No fallback."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise KiwiGpuError(-1, "load_library",
+                           "%s is not built (run `python -c 'import __graft_entry__ as g; "
+                           "g.build()'` or `make -C flydog_sdr_gps_amd/csrc`); there is no "
+                           "CPU fallback" % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.kg_abi_version() != ABI_VERSION:
+        raise KiwiGpuError(-2, "load_library", "ABI version mismatch")
+    _LIB = lib
+    return lib
+
+
+def check(status, where):
+    if status < 0:
+        lib = load_library()
+        text = lib.kg_last_error().decode() or lib.kg_strerror(status).decode()
+        raise KiwiGpuError(status, where, text)
+    return status
+
+
+def ptr(a):
+    """void* of a numpy array, or pass through an int device pointer."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One per GPU per process (kg_ctx).  stream: a hipStream_t handle (int), e.g.
+    torch.cuda.current_stream().cuda_stream, or None for a library-owned stream."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load_library()
+        h = C.c_void_p()
+        check(self.lib.kg_ctx_create(int(device), C.c_void_p(stream) if stream else None,
+                                     C.byref(h)), "kg_ctx_create")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.kg_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(self.lib.kg_ctx_sync(self.h), "kg_ctx_sync")
+
+    def poll(self):
+        return check(self.lib.kg_ctx_poll(self.h), "kg_ctx_poll") == 1
+
+    @property
+    def stream(self):
+        return self.lib.kg_ctx_stream(self.h)
+
+    @property
+    def name(self):
+        buf = C.create_string_buffer(256)
+        check(self.lib.kg_ctx_device_name(self.h, buf, 256), "kg_ctx_device_name")
+        return buf.value.decode()
+
+    @property
+    def num_cus(self):
+        return check(self.lib.kg_ctx_num_cus(self.h), "kg_ctx_num_cus")
+
+    def timer_start(self):
+        check(self.lib.kg_timer_start(self.h), "kg_timer_start")
+
+    def timer_stop(self):
+        ms = C.c_float()
+        check(self.lib.kg_timer_stop(self.h, C.byref(ms)), "kg_timer_stop")
+        return ms.value

@@ -1,0 +1,161 @@
+// kg_ctx.hip -- context, error text, stopwatch.
+#include "kg_common.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+
+void kg_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+const char *kg_last_error(void) { return g_err; }
+
+int kg_abi_version(void) { return KG_ABI_VERSION; }
+
+const char *kg_strerror(int s)
+{
+    switch (s) {
+    case KG_OK: return "ok";
+    case KG_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case KG_ERR_INVALID: return "invalid argument";
+    case KG_ERR_HIP: return "HIP runtime error";
+    case KG_ERR_NOMEM: return "out of memory";
+    case KG_ERR_STATE: return "call out of order";
+    default: return "unknown status";
+    }
+}
+
+static int make_table(float2 **d, int n)
+{
+    std::vector<float2> h(n);
+    for (int k = 0; k < n; k++) {
+        double a = 2.0 * M_PI * (double) k / (double) n;
+        h[k].x = (float) cos(a);
+        h[k].y = (float) sin(a);
+    }
+    // exact values on the axes
+    h[0] = make_float2(1.f, 0.f);
+    h[n / 4] = make_float2(0.f, 1.f);
+    h[n / 2] = make_float2(-1.f, 0.f);
+    h[3 * n / 4] = make_float2(0.f, -1.f);
+    KG_HIP(hipMalloc((void **) d, sizeof(float2) * n));
+    KG_HIP(hipMemcpy(*d, h.data(), sizeof(float2) * n, hipMemcpyHostToDevice));
+    return KG_OK;
+}
+
+int kg_ctx_create(int device, void *stream, kg_ctx **out)
+{
+    KG_REQUIRE(out != nullptr, KG_ERR_INVALID, "kg_ctx_create: out is null");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        kg_set_error("kg_ctx_create: no HIP device (%s); libkiwigpu has no CPU fallback",
+                     e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return KG_ERR_NO_DEVICE;
+    }
+    KG_REQUIRE(device >= 0 && device < ndev, KG_ERR_INVALID,
+               "kg_ctx_create: device %d out of range (0..%d)", device, ndev - 1);
+    hipDeviceProp_t prop;
+    KG_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        kg_set_error("kg_ctx_create: device %d is %s; this library is built for gfx950 only",
+                     device, prop.gcnArchName);
+        return KG_ERR_NO_DEVICE;
+    }
+    KG_HIP(hipSetDevice(device));
+    kg_ctx *c = (kg_ctx *) calloc(1, sizeof(kg_ctx));
+    KG_REQUIRE(c != nullptr, KG_ERR_NOMEM, "kg_ctx_create: calloc");
+    c->device = device;
+    c->num_cus = prop.multiProcessorCount;
+    snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
+    if (stream) {
+        c->stream = (hipStream_t) stream;
+        c->own_stream = false;
+    } else {
+        KG_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    KG_HIP(hipEventCreate(&c->ev_start));
+    KG_HIP(hipEventCreate(&c->ev_stop));
+    int rc;
+    if ((rc = make_table(&c->d_tab4096, 4096)) != KG_OK) return rc;
+    if ((rc = make_table(&c->d_tab16384, 16384)) != KG_OK) return rc;
+    if ((rc = make_table(&c->d_tab8192, 8192)) != KG_OK) return rc;
+    *out = c;
+    return KG_OK;
+}
+
+void kg_ctx_destroy(kg_ctx *c)
+{
+    if (!c) return;
+    (void) hipSetDevice(c->device);
+    (void) hipStreamSynchronize(c->stream);
+    (void) hipFree(c->d_tab4096);
+    (void) hipFree(c->d_tab16384);
+    (void) hipFree(c->d_tab8192);
+    (void) hipEventDestroy(c->ev_start);
+    (void) hipEventDestroy(c->ev_stop);
+    if (c->own_stream) (void) hipStreamDestroy(c->stream);
+    free(c);
+}
+
+int kg_ctx_sync(kg_ctx *c)
+{
+    int rc = kg_ctx_use(c);
+    if (rc) return rc;
+    KG_HIP(hipStreamSynchronize(c->stream));
+    return KG_OK;
+}
+
+int kg_ctx_poll(kg_ctx *c)
+{
+    int rc = kg_ctx_use(c);
+    if (rc) return rc;
+    hipError_t e = hipStreamQuery(c->stream);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) return 0;
+    kg_set_error("kg_ctx_poll: %s", hipGetErrorString(e));
+    return KG_ERR_HIP;
+}
+
+void *kg_ctx_stream(kg_ctx *c) { return c ? (void *) c->stream : nullptr; }
+
+int kg_ctx_device_name(kg_ctx *c, char *buf, size_t len)
+{
+    KG_REQUIRE(c && buf && len > 0, KG_ERR_INVALID, "kg_ctx_device_name: bad argument");
+    snprintf(buf, len, "%s", c->name);
+    return KG_OK;
+}
+
+int kg_ctx_num_cus(kg_ctx *c) { return c ? c->num_cus : KG_ERR_INVALID; }
+
+int kg_timer_start(kg_ctx *c)
+{
+    int rc = kg_ctx_use(c);
+    if (rc) return rc;
+    KG_HIP(hipEventRecord(c->ev_start, c->stream));
+    return KG_OK;
+}
+
+int kg_timer_stop(kg_ctx *c, float *ms)
+{
+    int rc = kg_ctx_use(c);
+    if (rc) return rc;
+    KG_REQUIRE(ms != nullptr, KG_ERR_INVALID, "kg_timer_stop: ms is null");
+    KG_HIP(hipEventRecord(c->ev_stop, c->stream));
+    KG_HIP(hipEventSynchronize(c->ev_stop));
+    KG_HIP(hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
+    return KG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,79 @@
+"""Seeded synthetic inputs for tests and bench.py.
+
+Pure input generators (numpy): nothing here is on the measured path.
+"""
+import numpy as np
+
+from . import prn as _prn
+from . import sats as _sats
+
+FS = 16.368e6     # gps/gps.h:43
+FC = 4.092e6      # gps/gps.h:42
+CPS = 1.023e6     # gps/gps.h:46
+NSAMPLES = 65536
+
+
+def _code_wave(chips, tau_chips, n):
+    """(1 - 2 c[floor(n * CPS/FS + tau) mod L]) over n samples."""
+    idx = np.floor(np.arange(n) * (CPS / FS) + tau_chips).astype(np.int64) % chips.size
+    return 1.0 - 2.0 * chips[idx].astype(np.float64)
+
+
+def gps_scene_bits(svs, seed, cn0_dbhz=45.0, n=NSAMPLES, boc_svs=()):
+    """Packed 1-bit real IF (the reference's sampler format, LSB first).
+
+    svs: list of (chips, tau_chips, doppler_hz, theta) with an optional 5th
+    element cn0 (dB-Hz).  x = sum A*code*cos(2 pi (FC+fd) n/FS + theta) + N(0,1);
+    bit = x < 0 (the reference maps bit 1 -> -1.0).  A = sqrt(4*10^(cn0/10)/FS)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    t = np.arange(n)
+    x = rng.standard_normal(n)
+    for sv in svs:
+        chips, tau, fd, theta = sv[:4]
+        cn0 = sv[4] if len(sv) > 4 else cn0_dbhz
+        boc = sv[5] if len(sv) > 5 else False
+        a = np.sqrt(4.0 * 10.0 ** (cn0 / 10.0) / FS)
+        code = _code_wave(chips, tau, n)
+        if boc:
+            sub = (np.arange(n) * (CPS / FS) + tau) % 1.0 >= 0.5
+            code = code * np.where(sub, -1.0, 1.0)
+        x = x + a * code * np.cos(2 * np.pi * (FC + fd) * t / FS + theta)
+    bits = (x < 0).astype(np.uint8)
+    return np.packbits(bits, bitorder="little")
+
+
+def gps_scene_iq16(svs, seed, cn0_dbhz=45.0, n=NSAMPLES, scale=2048.0):
+    """Complex int16 IF samples (i,q interleaved), round(scale*x) clipped.
+    x = sum A*code*exp(j(2 pi (FC+fd) n/FS + theta)) + CN(0,1)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    t = np.arange(n)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) / np.sqrt(2.0)
+    for sv in svs:
+        chips, tau, fd, theta = sv[:4]
+        cn0 = sv[4] if len(sv) > 4 else cn0_dbhz
+        a = np.sqrt(10.0 ** (cn0 / 10.0) / FS)
+        x = x + a * _code_wave(chips, tau, n) * np.exp(1j * (2 * np.pi * (FC + fd) * t / FS + theta))
+    iq = np.empty(2 * n, np.int16)
+    iq[0::2] = np.clip(np.rint(scale * x.real), -32768, 32767)
+    iq[1::2] = np.clip(np.rint(scale * x.imag), -32768, 32767)
+    return iq
+
+
+# BASELINE.json configs[1]: 8 SVs present out of the 32 Navstar PRNs searched
+CONFIG1_PRESENT = [(1, 300.5, 1500.0, 0.7), (3, 12.25, -2250.0, 1.9), (7, 911.0, 4400.0, 0.1),
+                   (11, 555.75, -4500.0, 2.8), (14, 71.5, 250.0, 4.0), (19, 1000.125, 3100.0, 5.5),
+                   (22, 640.0, -700.0, 3.3), (30, 222.625, -3300.0, 1.2)]
+
+
+def config1_iq16(seed=0x5EED0002, cn0_dbhz=47.0):
+    svs = []
+    for prn, tau, fd, th in CONFIG1_PRESENT:
+        _, t1, t2, _ = _sats.SATS[_sats.navstar_index(prn)]
+        svs.append((_prn.cacode(t1, t2), tau, fd, th))
+    return gps_scene_iq16(svs, seed, cn0_dbhz)
+
+
+def config0_bits(seed=0x5EED0001):
+    """BASELINE.json configs[0]: PRN1 at tau = 300.5 chips, +1500 Hz, theta 0.7, 45 dB-Hz."""
+    _, t1, t2, _ = _sats.SATS[0]
+    return gps_scene_bits([(_prn.cacode(t1, t2), 300.5, 1500.0, 0.7)], seed, 45.0)

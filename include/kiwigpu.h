@@ -1,0 +1,142 @@
+/*
+ * kiwigpu.h -- C ABI of libkiwigpu.so: the MI355X (gfx950) implementation of
+ * the FlyDog_SDR_GPS DSP hot path.
+ *
+ * The reference has no FFI seam for this path; the seam is function-level
+ * inside the kiwid process.  Every entry point below
+ * names the reference function(s) it replaces (file:line under the reference
+ * tree).  INTEGRATION.md shows the binding a maintainer adds on the reference
+ * side.
+ *
+ * Conventions
+ *   - plain C types only; complex data is interleaved float (re, im), the
+ *     layout of fftwf_complex / TYPECPX in the reference;
+ *   - every function returns KG_OK (0) or a negative kg_status; nothing throws;
+ *     kg_last_error() gives the text of the last failure on this thread;
+ *   - "_dev" variants take pointers to device (HBM) memory and only enqueue
+ *     work on the context's stream; the others take host memory, copy, and
+ *     (where they return results) synchronise;
+ *   - the library owns all device memory it allocates; callers keep ownership
+ *     of every buffer they pass in;
+ *   - there is NO CPU fallback: without a usable gfx950 device kg_ctx_create
+ *     fails with KG_ERR_NO_DEVICE.
+ *   - the reference runs this path from cooperative coroutines on one host
+ *     thread (support/coroutines.cpp); the async entry points plus kg_ctx_poll()
+ *     are meant to be called around its NextTask() yield points.
+ */
+#ifndef KIWIGPU_H
+#define KIWIGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KG_ABI_VERSION 1
+
+typedef enum {
+    KG_OK = 0,
+    KG_ERR_NO_DEVICE = -1,   /* no HIP device / not gfx950 / HIP runtime failure at init */
+    KG_ERR_INVALID = -2,     /* bad argument */
+    KG_ERR_HIP = -3,         /* a HIP call failed; see kg_last_error() */
+    KG_ERR_NOMEM = -4,
+    KG_ERR_STATE = -5        /* call out of order (e.g. correlate before a code was set) */
+} kg_status;
+
+const char *kg_strerror(int status);
+const char *kg_last_error(void);
+int kg_abi_version(void);
+
+/* ------------------------------------------------------------------------ */
+/* Context: one per GPU per process.                                         */
+/* ------------------------------------------------------------------------ */
+typedef struct kg_ctx kg_ctx;
+
+/* stream: a hipStream_t to enqueue on (e.g. the caller's or PyTorch's current
+ * stream), or NULL to let the library create its own non-blocking stream. */
+int kg_ctx_create(int device, void *stream, kg_ctx **out);
+void kg_ctx_destroy(kg_ctx *ctx);
+int kg_ctx_sync(kg_ctx *ctx);                 /* hipStreamSynchronize */
+int kg_ctx_poll(kg_ctx *ctx);                 /* 1 = stream idle, 0 = busy, <0 error */
+void *kg_ctx_stream(kg_ctx *ctx);             /* the hipStream_t in use */
+int kg_ctx_device_name(kg_ctx *ctx, char *buf, size_t len);
+int kg_ctx_num_cus(kg_ctx *ctx);
+
+/* HIP-event stopwatch on the context's stream (bench.py and C++ callers). */
+int kg_timer_start(kg_ctx *ctx);
+int kg_timer_stop(kg_ctx *ctx, float *elapsed_ms);    /* synchronises on the stop event */
+
+/* ------------------------------------------------------------------------ */
+/* GPS C/A + E1B parallel-code-phase acquisition.                            */
+/* Replaces gps/search.cpp: SearchInit() code tables (:183-350), Sample()    */
+/* (:382-449), Correlate() (:453-499).                                       */
+/* Fixed by the reference (gps/gps.h:62-73): NSAMPLES 65536, DECIM 4,        */
+/* FFT_LEN 16384.                                                            */
+/* ------------------------------------------------------------------------ */
+#define KG_ACQ_NSAMPLES 65536
+#define KG_ACQ_FFT_LEN  16384
+#define KG_ACQ_L1_LIMIT 4092      /* SAMPLE_RATE/1000*L1_CODE_PERIOD,  search.cpp:486 */
+#define KG_ACQ_E1B_LIMIT 16368    /* SAMPLE_RATE/1000*E1B_CODE_PERIOD, search.cpp:486 */
+
+typedef struct kg_acq kg_acq;
+
+/* Result of Correlate() for one SV.  valid == 0 means no Doppler bin had
+ * snr > 0 (all-zero or NaN input): the reference then leaves its out-pointers
+ * untouched and returns 0 (search.cpp:455,495). */
+typedef struct { float snr; int32_t dop; int32_t idx; int32_t valid; } kg_acq_result;
+
+/* One (SV, Doppler) cell of the search.cpp:465-496 loop. */
+typedef struct { float snr; float max_pwr; float tot_pwr; int32_t idx; } kg_acq_cell;
+
+/* max_sats: size of the code table (reference MAX_SATS = 64, gps.h:123).
+ * dop_lo..dop_hi: Doppler bins searched (reference -20..20, search.cpp:465).
+ * max_blocks: how many independent 65536-sample blocks ("receivers") can be
+ * resident and searched in one launch. */
+int kg_acq_create(kg_ctx *ctx, int max_sats, int dop_lo, int dop_hi, int max_blocks,
+                  kg_acq **out);
+void kg_acq_destroy(kg_acq *acq);
+
+/* SearchInit() per-SV body, run on the device: resample chips {0,1} at 16
+ * samples/chip over NSAMPLES, Bipolar, (boc: XOR BOC(1,1), search.cpp:317),
+ * 2x DecimateBy2float, forward FFT.  limit = peak-search window
+ * (KG_ACQ_L1_LIMIT / KG_ACQ_E1B_LIMIT). */
+int kg_acq_set_code(kg_acq *acq, int sat, const uint8_t *chips, int nchips, int boc,
+                    int limit);
+/* Upload a ready-made code spectrum (FFT_LEN complex, natural bin order), i.e.
+ * the first half of the reference's code[sat][] (search.cpp:54,283). */
+int kg_acq_set_code_fft(kg_acq *acq, int sat, const float *code_fft, int limit);
+int kg_acq_get_code_fft(kg_acq *acq, int sat, float *code_fft);      /* natural order */
+
+/* Sample(): packed 1-bit IF (8192 bytes, LSB first; verilog/gps/sampler.v) ->
+ * data spectrum of block `block`. */
+int kg_acq_sample_bits(kg_acq *acq, int block, const uint8_t *packed);
+int kg_acq_sample_bits_dev(kg_acq *acq, int block, const void *d_packed);
+/* Extension (BASELINE.json configs[1]): NSAMPLES complex int16 samples
+ * (i,q interleaved) at the FS/4 IF; mix by (-j)^n, then as Sample(). */
+int kg_acq_sample_iq16(kg_acq *acq, int block, const int16_t *iq);
+int kg_acq_sample_iq16_dev(kg_acq *acq, int block, const void *d_iq);
+/* Inject / read back Correlate()'s `data` argument (fwd_buf after Sample()),
+ * FFT_LEN complex in natural bin order. */
+int kg_acq_set_data_fft(kg_acq *acq, int block, const float *data_fft);
+int kg_acq_get_data_fft(kg_acq *acq, int block, float *data_fft);
+/* The FFT_LEN decimated time-domain samples Sample() feeds its FFT. */
+int kg_acq_get_data_td(kg_acq *acq, int block, float *td);
+
+/* Correlate() for nsats SVs x (dop_hi-dop_lo+1) bins x nblocks blocks
+ * (blocks 0..nblocks-1), one launch.  Enqueue only. */
+int kg_acq_correlate_async(kg_acq *acq, int nblocks, const int *sats, int nsats);
+/* Wait and copy out.  results[nblocks*nsats] (block-major), cells may be NULL
+ * or [nblocks*nsats*ndop]. */
+int kg_acq_fetch(kg_acq *acq, kg_acq_result *results, kg_acq_cell *cells);
+/* Convenience: async + fetch for one block. */
+int kg_acq_correlate(kg_acq *acq, int block_count, const int *sats, int nsats,
+                     kg_acq_result *results, kg_acq_cell *cells);
+/* Device pointer to the last launch's kg_acq_result array (for RCCL gathers). */
+void *kg_acq_results_dev(kg_acq *acq);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KIWIGPU_H */

@@ -1,0 +1,116 @@
+/*
+ * kiwi_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C restatement of the reference's algorithms for the hot path
+ * (flydog-sdr/FlyDog_SDR_GPS: gps/search.cpp, gps/cacode.h, gps/e1bcode.h,
+ * rx/rx_waterfall.cpp, rx/CuteSDR/fastfir.cpp, rx/data_pump.cpp).  Each
+ * function cites the reference file:line it follows.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * link or call anything in this directory.  The product (libkiwigpu.so) never
+ * does, and has no CPU fallback.
+ *
+ * PINNING STATUS
+ *   - PRN generators (ko_cacode): PINNED.  Checked against the reference's own
+ *     gps/cacode.h compiled in place (oracle/_ref, see oracle/Makefile) and
+ *     against the IS-GPS-200 first-10-chip known answers.
+ *   - E1B memory-code unpack (ko_e1b_from_hex): PINNED against the reference's
+ *     known answers at gps/search.cpp:295,302 (E01 0xf5d71, E02 0x96b85).
+ *   - Everything that goes through an FFT (code tables, Sample, Correlate,
+ *     waterfall, CFastFIR): PARITY UNPINNED.  The reference computes these with
+ *     FFTW3f, an un-vendored, un-pinned apt dependency (Makefile:365-366) that
+ *     is absent from this image, and its sources need the generated kiwi.gen.h;
+ *     the reference's path is therefore unbuildable here and the reference
+ *     holds no golden vectors for it.  The oracle FFT is
+ *     a double-precision radix-2 rounded to fp32 on store, cross-checked
+ *     against numpy.fft in tests/test_oracle.py.
+ */
+#ifndef KIWI_ORACLE_H
+#define KIWI_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float re, im; } ko_cpx;
+
+/* ---- constants pinned from the reference -------------------------------- */
+#define KO_NSAMPLES   65536      /* gps/gps.h:69-73  NSAMPLES = FS_I/BIN_SIZE          */
+#define KO_DECIM      4          /* gps/gps.h:62                                       */
+#define KO_FFT_LEN    16384      /* gps/gps.h:72     FFT_LEN = NSAMPLES/DECIM          */
+#define KO_NTAPS      31         /* gps/search.cpp:49                                  */
+#define KO_L1_CODELEN 1023       /* kiwi.config:266                                    */
+#define KO_E1B_CODELEN 4092      /* kiwi.config:270                                    */
+#define KO_SAMPLE_RATE 4092000   /* gps/gps.h:64     SAMPLE_RATE = FS_I/DECIM          */
+#define KO_DOP_LO     (-20)      /* gps/search.cpp:465  (int)(-5000/249.755859375)     */
+#define KO_DOP_HI     20
+
+/* ---- PRN generators ------------------------------------------------------ */
+/* gps/cacode.h:23-53.  t0,t1 <= 10: G2 tap pair; otherwise t1 is the 10-bit G2
+ * initial state (QZSS rows of gps/sats.cpp:74-84).  Writes 1023 chips {0,1}. */
+void ko_cacode(int t0, int t1, uint8_t *chips);
+
+/* gps/e1bcode.h:66-79: hex memory code -> 4092 chips, MSB-first per nibble.
+ * Returns 0, or -1 on a bad hex digit. */
+int ko_e1b_from_hex(const char *hex, uint8_t *chips);
+
+/* ---- FFT ------------------------------------------------------------------ */
+/* Unnormalised complex DFT, sign=-1 forward (FFTW_FORWARD), +1 backward.
+ * n is a power of two.  prec=1: double-precision arithmetic, fp32 on store
+ * (the parity oracle).  prec=0: fp32 arithmetic radix-4 Stockham (the "port"
+ * used for the CPU-baseline timing; what FFTW3f would do in spirit).
+ * Replaces fftwf_execute at gps/search.cpp:280,342,447,481,
+ * rx/rx_waterfall.cpp:1291, rx/CuteSDR/fastfir.cpp:274,304. */
+void ko_fft(int n, int sign, const ko_cpx *in, ko_cpx *out, int prec);
+
+/* ---- GPS acquisition ------------------------------------------------------ */
+/* gps/search.cpp:140-166 DecimateBy2float, in place.  buf must have room for
+ * size+KO_NTAPS elements (the tail is zero-filled first, :145).  Returns size/2. */
+int ko_decimate_by2_float(int size, ko_cpx *buf);
+
+/* gps/search.cpp:243-285 (boc=0) / :309-346 (boc=1): resample the chip
+ * sequence at CPS/FS = 1/16 chip per sample over NSAMPLES samples, Bipolar
+ * (0 -> +1, 1 -> -1), 2x DecimateBy2float, forward FFT.  *phase is the
+ * ca_phase / e1b_phase accumulator that persists across SVs (:206,:307).
+ * out receives FFT_LEN bins (the reference stores them twice, :283-284). */
+void ko_code_fft(const uint8_t *chips, int nchips, int boc, float *phase,
+                 ko_cpx *out, int prec);
+
+/* Same, stopping before the FFT: the FFT_LEN decimated replica samples. */
+void ko_code_replica(const uint8_t *chips, int nchips, int boc, float *phase,
+                     ko_cpx *out);
+
+/* gps/search.cpp:382-449 Sample(): 8192 bytes of 1-bit IF, LSB first ->
+ * XOR quadrature mix -> DecimateBy2binary -> DecimateBy2float -> forward FFT.
+ * out receives FFT_LEN bins.  If td != NULL it receives the FFT_LEN
+ * decimated time-domain samples (the FFT input). */
+void ko_sample_bits(const uint8_t *packed, ko_cpx *out, ko_cpx *td, int prec);
+
+/* Extension (BASELINE.json configs[1], "synthetic int16 IQ"): NSAMPLES complex
+ * int16 samples at the FC = FS/4 IF.  Mix = multiply by (-j)^n (exact), then
+ * the same two half-band stages and FFT as Sample(). */
+void ko_sample_iq16(const int16_t *iq, ko_cpx *out, ko_cpx *td, int prec);
+
+typedef struct { float snr; int dop; int idx; int valid; } ko_acq_result;
+typedef struct { float snr; float max_pwr; float tot_pwr; int idx; } ko_acq_cell;
+
+/* gps/search.cpp:453-499 Correlate().  code: FFT_LEN bins (natural order),
+ * data: FFT_LEN bins, limit = SAMPLE_RATE/1000*code_period_ms (4092 L1/QZSS,
+ * 16368 E1B; :486).  cells (may be NULL) receives one entry per Doppler bin.
+ * valid=0 reproduces "no snr > 0 seen, out-pointers untouched" (:495). */
+ko_acq_result ko_correlate(const ko_cpx *code, const ko_cpx *data, int limit,
+                           int dop_lo, int dop_hi, ko_acq_cell *cells, int prec);
+
+/* Many SVs: codes[nsv][FFT_LEN]; OpenMP-free pthread shard over SVs when
+ * nthreads > 1 (CPU baseline "T_all"). */
+void ko_correlate_many(const ko_cpx *codes, int nsv, const ko_cpx *data,
+                       const int *limits, int dop_lo, int dop_hi,
+                       ko_acq_result *out, ko_acq_cell *cells, int prec,
+                       int nthreads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

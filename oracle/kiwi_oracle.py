@@ -1,0 +1,174 @@
+"""ctypes front for the CPU ORACLE (oracle/libkiwi_oracle.so).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg; the product package (flydog_sdr_gps_amd) never
+imports this module.  See oracle/kiwi_oracle.h for what each entry point
+restates (reference file:line) and for the pinning status.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libkiwi_oracle.so")
+
+NSAMPLES = 65536
+FFT_LEN = 16384
+DECIM = 4
+NTAPS = 31
+L1_CODELEN = 1023
+E1B_CODELEN = 4092
+L1_LIMIT = 4092          # SAMPLE_RATE/1000 * L1_CODE_PERIOD, gps/search.cpp:486
+E1B_LIMIT = 16368        # SAMPLE_RATE/1000 * E1B_CODE_PERIOD
+DOP_LO, DOP_HI = -20, 20
+
+cpx = np.complex64
+
+
+class AcqResult(C.Structure):
+    _fields_ = [("snr", C.c_float), ("dop", C.c_int), ("idx", C.c_int), ("valid", C.c_int)]
+
+
+class AcqCell(C.Structure):
+    _fields_ = [("snr", C.c_float), ("max_pwr", C.c_float), ("tot_pwr", C.c_float),
+                ("idx", C.c_int)]
+
+
+cell_dtype = np.dtype([("snr", "<f4"), ("max_pwr", "<f4"), ("tot_pwr", "<f4"), ("idx", "<i4")])
+result_dtype = np.dtype([("snr", "<f4"), ("dop", "<i4"), ("idx", "<i4"), ("valid", "<i4")])
+
+
+def build(force=False):
+    """(Re)build libkiwi_oracle.so (and oracle/_ref when /root/reference exists)."""
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"],
+                              stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        vp = C.c_void_p
+        L.ko_cacode.argtypes = [C.c_int, C.c_int, vp]
+        L.ko_e1b_from_hex.argtypes = [C.c_char_p, vp]
+        L.ko_e1b_from_hex.restype = C.c_int
+        L.ko_fft.argtypes = [C.c_int, C.c_int, vp, vp, C.c_int]
+        L.ko_decimate_by2_float.argtypes = [C.c_int, vp]
+        L.ko_decimate_by2_float.restype = C.c_int
+        L.ko_code_fft.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), vp, C.c_int]
+        L.ko_code_replica.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), vp]
+        L.ko_sample_bits.argtypes = [vp, vp, vp, C.c_int]
+        L.ko_sample_iq16.argtypes = [vp, vp, vp, C.c_int]
+        L.ko_correlate.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+        L.ko_correlate.restype = AcqResult
+        L.ko_correlate_many.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp,
+                                        C.c_int, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def cacode(t0, t1):
+    out = np.zeros(L1_CODELEN, np.uint8)
+    lib().ko_cacode(int(t0), int(t1), _p(out))
+    return out
+
+
+def e1b_from_hex(hexstr):
+    out = np.zeros(E1B_CODELEN, np.uint8)
+    rc = lib().ko_e1b_from_hex(hexstr.encode("ascii"), _p(out))
+    if rc != 0:
+        raise ValueError("bad hex digit in E1B memory code")
+    return out
+
+
+def fft(x, sign=-1, prec=1):
+    x = np.ascontiguousarray(x, cpx)
+    out = np.empty_like(x)
+    lib().ko_fft(x.size, int(sign), _p(x), _p(out), int(prec))
+    return out
+
+
+def decimate_by2(x):
+    """DecimateBy2float on a copy; returns the size/2 outputs."""
+    x = np.asarray(x, cpx)
+    buf = np.zeros(x.size + NTAPS, cpx)
+    buf[:x.size] = x
+    n = lib().ko_decimate_by2_float(x.size, _p(buf))
+    return buf[:n].copy()
+
+
+def code_fft(chips, boc=False, prec=1, phase=0.0):
+    chips = np.ascontiguousarray(chips, np.uint8)
+    out = np.empty(FFT_LEN, cpx)
+    ph = C.c_float(phase)
+    lib().ko_code_fft(_p(chips), chips.size, int(bool(boc)), C.byref(ph), _p(out), int(prec))
+    return out
+
+
+def code_replica(chips, boc=False, phase=0.0):
+    chips = np.ascontiguousarray(chips, np.uint8)
+    out = np.empty(FFT_LEN, cpx)
+    ph = C.c_float(phase)
+    lib().ko_code_replica(_p(chips), chips.size, int(bool(boc)), C.byref(ph), _p(out))
+    return out, ph.value
+
+
+def sample_bits(packed, prec=1, want_td=False):
+    packed = np.ascontiguousarray(packed, np.uint8)
+    assert packed.size == NSAMPLES // 8
+    out = np.empty(FFT_LEN, cpx)
+    td = np.empty(FFT_LEN, cpx) if want_td else None
+    lib().ko_sample_bits(_p(packed), _p(out), _p(td) if want_td else None, int(prec))
+    return (out, td) if want_td else out
+
+
+def sample_iq16(iq, prec=1, want_td=False):
+    iq = np.ascontiguousarray(iq, np.int16).reshape(-1)
+    assert iq.size == 2 * NSAMPLES
+    out = np.empty(FFT_LEN, cpx)
+    td = np.empty(FFT_LEN, cpx) if want_td else None
+    lib().ko_sample_iq16(_p(iq), _p(out), _p(td) if want_td else None, int(prec))
+    return (out, td) if want_td else out
+
+
+def correlate(code, data, limit=L1_LIMIT, dop_lo=DOP_LO, dop_hi=DOP_HI, prec=1):
+    """-> (result dict, cells structured array[dop_hi-dop_lo+1])"""
+    code = np.ascontiguousarray(code, cpx)
+    data = np.ascontiguousarray(data, cpx)
+    cells = np.zeros(dop_hi - dop_lo + 1, cell_dtype)
+    r = lib().ko_correlate(_p(code), _p(data), int(limit), dop_lo, dop_hi, _p(cells), int(prec))
+    return dict(snr=r.snr, dop=r.dop, idx=r.idx, valid=r.valid), cells
+
+
+def correlate_many(codes, data, limits, dop_lo=DOP_LO, dop_hi=DOP_HI, prec=1, nthreads=1,
+                   want_cells=True):
+    codes = np.ascontiguousarray(codes, cpx)
+    data = np.ascontiguousarray(data, cpx)
+    nsv = codes.shape[0]
+    limits = np.ascontiguousarray(limits, np.int32)
+    nd = dop_hi - dop_lo + 1
+    out = np.zeros(nsv, result_dtype)
+    cells = np.zeros((nsv, nd), cell_dtype) if want_cells else None
+    lib().ko_correlate_many(_p(codes), nsv, _p(data), _p(limits), dop_lo, dop_hi, _p(out),
+                            _p(cells) if want_cells else None, int(prec), int(nthreads))
+    return out, cells
+
+
+def ref_cacode(t0, t1):
+    """Chips from the REFERENCE's own gps/cacode.h (oracle/_ref/cacode_ref), or None."""
+    exe = os.path.join(_HERE, "_ref", "cacode_ref")
+    if not os.path.exists(exe):
+        return None
+    s = subprocess.check_output([exe, str(t0), str(t1)]).decode().strip()
+    return np.frombuffer(s.encode(), np.uint8) - ord("0")

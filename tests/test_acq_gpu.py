@@ -1,0 +1,181 @@
+"""GPU parity: libkiwigpu acquisition (through the C ABI) vs the CPU oracle.
+
+Bars (BASELINE.json north_star): peak index / Doppler bin bit-exact; float
+results within 1e-5 relative (spectra: relative to the spectrum's max magnitude).
+"""
+import numpy as np
+import pytest
+
+from flydog_sdr_gps_amd import Searcher, prn, sats, synth
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+L1 = sats.L1_LIMIT
+
+
+def relmax(a, b):
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+@pytest.fixture(scope="module")
+def searcher(gpu_ctx):
+    s = Searcher(gpu_ctx, max_blocks=4)
+    yield s
+    s.close()
+
+
+@pytest.fixture(scope="module")
+def navstar_codes(searcher, oracle):
+    codes = {}
+    for sat in range(32):
+        _, t1, t2, _ = sats.SATS[sat]
+        chips = prn.cacode(t1, t2)
+        searcher.set_code(sat, chips)
+        codes[sat] = oracle.code_fft(chips)
+    return codes
+
+
+def test_code_table_matches_oracle(searcher, navstar_codes):
+    for sat in (0, 8, 31):
+        got = searcher.get_code_fft(sat)
+        assert relmax(got, navstar_codes[sat]) < RTOL
+
+
+def test_sample_bits_time_domain_bit_exact(searcher, oracle):
+    bits = synth.config0_bits()
+    searcher.sample(bits)
+    _, td = oracle.sample_bits(bits, want_td=True)
+    got = searcher.get_data_td()
+    # same operations in the same order, no FMA contraction on either side
+    assert np.array_equal(got.view(np.uint32), td.view(np.uint32))
+
+
+def test_sample_bits_spectrum(searcher, oracle):
+    bits = synth.config0_bits()
+    searcher.sample(bits)
+    want = oracle.sample_bits(bits)
+    assert relmax(searcher.get_data_fft(), want) < RTOL
+
+
+def test_sample_iq16(searcher, oracle):
+    iq = synth.config1_iq16()
+    searcher.sample_iq16(iq)
+    want, td = oracle.sample_iq16(iq, want_td=True)
+    assert np.array_equal(searcher.get_data_td().view(np.uint32), td.view(np.uint32))
+    assert relmax(searcher.get_data_fft(), want) < RTOL
+
+
+def check_cells(got_cells, want_cells):
+    assert np.array_equal(got_cells["idx"], want_cells["idx"])          # bit-exact peak index
+    np.testing.assert_allclose(got_cells["max_pwr"], want_cells["max_pwr"], rtol=RTOL)
+    np.testing.assert_allclose(got_cells["tot_pwr"], want_cells["tot_pwr"], rtol=RTOL)
+    np.testing.assert_allclose(got_cells["snr"], want_cells["snr"], rtol=2 * RTOL)
+
+
+def test_config0_prn1(searcher, navstar_codes, oracle):
+    """BASELINE.json configs[0]: PRN1 cold acquisition from 4 ms of 1-bit IF."""
+    bits = synth.config0_bits()
+    searcher.sample(bits)
+    res, cells = searcher.correlate_many([0])
+    data = oracle.sample_bits(bits)
+    want, wcells = oracle.correlate(navstar_codes[0], data)
+    r = res[0, 0]
+    assert (int(r["dop"]), int(r["idx"]), int(r["valid"])) == (want["dop"], want["idx"], 1)
+    assert abs(r["snr"] - want["snr"]) <= 2 * RTOL * want["snr"]
+    assert int(r["dop"]) == 6 and int(r["idx"]) == 1202           # injected +1500 Hz, 300.5 chips
+    check_cells(cells[0, 0], wcells)
+    # the SearchTask view: ca_shift *= DECIM
+    out = searcher.search([0], packed=bits)
+    assert out[0].lo_shift == 6 and out[0].ca_shift == 4808 and out[0].snr >= 16
+
+
+def test_config1_32sv_41bins(searcher, navstar_codes, oracle):
+    """BASELINE.json configs[1]: 32 SVs x 41 Doppler bins on int16 IQ."""
+    iq = synth.config1_iq16()
+    searcher.sample_iq16(iq)
+    svs = list(range(32))
+    res, cells = searcher.correlate_many(svs)
+    data = searcher.get_data_fft()          # same data spectrum on both sides
+    codes = np.stack([navstar_codes[s] for s in svs])
+    want, wcells = oracle.correlate_many(codes, data, [L1] * 32, nthreads=8)
+    assert np.array_equal(res[0]["dop"], want["dop"])
+    assert np.array_equal(res[0]["idx"], want["idx"])
+    assert np.array_equal(res[0]["valid"], want["valid"])
+    np.testing.assert_allclose(res[0]["snr"], want["snr"], rtol=2 * RTOL)
+    check_cells(cells[0], wcells)
+    found = {s + 1 for s in svs if res[0, s]["snr"] >= 16}
+    assert found == {p for p, *_ in synth.CONFIG1_PRESENT}
+    for p, tau, fd, _ in synth.CONFIG1_PRESENT:
+        r = res[0, p - 1]
+        assert int(r["dop"]) == int(round(fd / 249.755859375))
+        assert abs(int(r["idx"]) - tau * 4) <= 1
+
+
+def test_injected_spectrum_and_shifts(searcher, navstar_codes, oracle):
+    """Correlate() on a hand-made data spectrum: data = code shifted by d bins and
+    delayed -> the peak must come back at exactly (d, delay)."""
+    code = navstar_codes[4]
+    n = np.arange(16384)
+    for d, delay in ((-20, 0), (20, 4091), (0, 17), (-7, 2048), (13, 1)):
+        data = np.roll(code, d) * np.exp(-2j * np.pi * n * delay / 16384)
+        data = np.conj(np.conj(data))       # keep complex64
+        searcher.set_data_fft(data.astype(np.complex64))
+        res, cells = searcher.correlate_many([4])
+        want, wcells = oracle.correlate(code, data.astype(np.complex64))
+        assert (int(res[0, 0]["dop"]), int(res[0, 0]["idx"])) == (want["dop"], want["idx"])
+        check_cells(cells[0, 0], wcells)
+
+
+def test_all_zero_input_is_invalid(searcher, navstar_codes):
+    """search.cpp:455,495: snr = 0/0 is never > 0, so nothing is reported."""
+    searcher.set_data_fft(np.zeros(16384, np.complex64))
+    res, _ = searcher.correlate_many([0, 1])
+    assert np.all(res["valid"] == 0) and np.all(res["snr"] == 0)
+    out = searcher.search([0], lo_shift=3, ca_shift=44)
+    assert (out[0].lo_shift, out[0].ca_shift, out[0].valid) == (3, 44, 0)
+
+
+def test_multi_block_batch(searcher, navstar_codes, oracle):
+    """Several resident blocks ("receivers") searched in one launch."""
+    svs = [0, 2, 6, 10, 13, 18, 21, 29, 5]
+    datas = []
+    for b in range(3):
+        iq = synth.config1_iq16(seed=100 + b, cn0_dbhz=46.0 + b)
+        searcher.sample_iq16(iq, block=b)
+        datas.append(searcher.get_data_fft(b))
+    res, cells = searcher.correlate_many(svs, nblocks=3)
+    codes = np.stack([navstar_codes[s] for s in svs])
+    for b in range(3):
+        want, wcells = oracle.correlate_many(codes, datas[b], [L1] * len(svs), nthreads=8)
+        assert np.array_equal(res[b]["dop"], want["dop"])
+        assert np.array_equal(res[b]["idx"], want["idx"])
+        check_cells(cells[b], wcells)
+
+
+def test_custom_limit_and_narrow_doppler(gpu_ctx, oracle):
+    s = Searcher(gpu_ctx, max_sats=4, dop_lo=-3, dop_hi=5)
+    chips = prn.cacode(3, 7)
+    s.set_code(1, chips, limit=1000)
+    bits = synth.gps_scene_bits([(chips, 100.25, 700.0, 0.3)], seed=7)
+    s.sample(bits)
+    res, cells = s.correlate_many([1])
+    want, wcells = oracle.correlate(oracle.code_fft(chips), oracle.sample_bits(bits), limit=1000,
+                                    dop_lo=-3, dop_hi=5)
+    assert (int(res[0, 0]["dop"]), int(res[0, 0]["idx"])) == (want["dop"], want["idx"])
+    check_cells(cells[0, 0], wcells)
+    s.close()
+
+
+def test_error_paths(gpu_ctx):
+    from flydog_sdr_gps_amd import KiwiGpuError
+    s = Searcher(gpu_ctx, max_sats=4)
+    with pytest.raises(KiwiGpuError):
+        s.correlate_many([0])                 # no code set
+    with pytest.raises(KiwiGpuError):
+        s.set_code(9, prn.cacode(2, 6))       # sat out of range
+    with pytest.raises(KiwiGpuError):
+        s.set_code(0, np.full(1023, 2, np.uint8))
+    with pytest.raises(ValueError):
+        s.sample(np.zeros(10, np.uint8))
+    s.close()
