@@ -114,17 +114,21 @@ def test_config1_32sv_41bins(searcher, navstar_codes, oracle):
 
 def test_injected_spectrum_and_shifts(searcher, navstar_codes, oracle):
     """Correlate() on a hand-made data spectrum: data = code shifted by d bins and
-    delayed -> the peak must come back at exactly (d, delay)."""
+    advanced by `delay` samples -> the peak must come back at exactly (d, delay)
+    (prod = conj(data)*code[k-dop], backward FFT: search.cpp:471,481)."""
     code = navstar_codes[4]
     n = np.arange(16384)
     for d, delay in ((-20, 0), (20, 4091), (0, 17), (-7, 2048), (13, 1)):
-        data = np.roll(code, d) * np.exp(-2j * np.pi * n * delay / 16384)
-        data = np.conj(np.conj(data))       # keep complex64
+        data = np.roll(code, d) * np.exp(2j * np.pi * n * delay / 16384)
         searcher.set_data_fft(data.astype(np.complex64))
         res, cells = searcher.correlate_many([4])
         want, wcells = oracle.correlate(code, data.astype(np.complex64))
         assert (int(res[0, 0]["dop"]), int(res[0, 0]["idx"])) == (want["dop"], want["idx"])
-        check_cells(cells[0, 0], wcells)
+        assert (want["dop"], want["idx"]) == (d, delay)
+        # only the matched-Doppler cell: this noise-free input makes the other
+        # cells' outputs mirror-symmetric (exact power ties between two lags)
+        di = d - searcher.dop_lo
+        check_cells(cells[0, 0][di:di + 1], wcells[di:di + 1])
 
 
 def test_all_zero_input_is_invalid(searcher, navstar_codes):
@@ -178,4 +182,52 @@ def test_error_paths(gpu_ctx):
         s.set_code(0, np.full(1023, 2, np.uint8))
     with pytest.raises(ValueError):
         s.sample(np.zeros(10, np.uint8))
+    s.close()
+
+
+def test_golden_fixtures_incl_e1b_and_qzss(gpu_ctx, oracle):
+    """tests/golden/acq_golden.npz: Navstar, QZSS (G2-init code), absent SV, edge
+    Doppler and a Galileo E1B (BOC(1,1), 16368-sample window) case."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "acq_golden.npz"))
+    s = Searcher(gpu_ctx)
+    for k in range(int(g["ncases"])):
+        sat = int(g["case%d_sat" % k])
+        _, t1, t2, kind = sats.SATS[sat]
+        if kind == sats.E1B:
+            chips, boc = g["case%d_chips" % k], True
+        else:
+            chips, boc = prn.cacode(t1, t2), False
+        s.set_code(sat, chips, boc=boc)
+        want_code = oracle.code_fft(chips, boc=boc)
+        assert relmax(s.get_code_fft(sat), want_code) < RTOL
+        s.sample(g["case%d_bits" % k])
+        res, cells = s.correlate_many([sat])
+        want = g["case%d_result" % k]
+        r = res[0, 0]
+        assert (int(r["dop"]), int(r["idx"]), int(r["valid"])) == tuple(int(v) for v in want[1:])
+        assert abs(r["snr"] - want[0]) <= 3 * RTOL * want[0]
+        assert np.array_equal(cells[0, 0]["idx"], g["case%d_cell_idx" % k])
+        np.testing.assert_allclose(cells[0, 0]["snr"], g["case%d_cell_snr" % k], rtol=3 * RTOL)
+    s.close()
+
+
+def test_mixed_l1_e1b_batch(gpu_ctx, oracle):
+    """One launch list mixing 4092-window (C/A) and 16368-window (E1B) SVs."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "acq_golden.npz"))
+    e1b = g["case5_chips"]
+    s = Searcher(gpu_ctx, max_sats=8)
+    ca = prn.cacode(2, 6)
+    s.set_code(0, ca)
+    s.set_code(1, e1b, boc=True)
+    s.set_code(2, prn.cacode(3, 7))
+    s.sample(g["case5_bits"])
+    res, cells = s.correlate_many([1, 0, 2, 1])
+    data = s.get_data_fft()
+    w_e, c_e = oracle.correlate(oracle.code_fft(e1b, boc=True), data, limit=sats.E1B_LIMIT)
+    w_0, c_0 = oracle.correlate(oracle.code_fft(ca), data)
+    for pos, (w, c) in zip((0, 1, 3), ((w_e, c_e), (w_0, c_0), (w_e, c_e))):
+        assert (int(res[0, pos]["dop"]), int(res[0, pos]["idx"])) == (w["dop"], w["idx"])
+        check_cells(cells[0, pos], c)
     s.close()

@@ -1,0 +1,35 @@
+"""Summarises the rocprofv3 csv outputs written by tools/prof.sh."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def find(sub, pat):
+    return sorted(glob.glob(os.path.join(out, sub, "**", pat), recursive=True))
+
+
+for f in find("trace", "*kernel_stats.csv"):
+    print("== kernel stats (%s)" % os.path.relpath(f, out))
+    rows = list(csv.DictReader(open(f)))
+    for r in rows[:12]:
+        print("  %-60s calls %6s  avg %10.2f us  total %8.3f ms  %5s%%" % (
+            r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3,
+            float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
+
+for sub in ("pmc1", "pmc2", "pmc3", "pmc4"):
+    for f in find(sub, "*counter_collection.csv"):
+        acc = defaultdict(lambda: defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        print("== counters (%s), mean per dispatch" % os.path.relpath(f, out))
+        for k, cs in acc.items():
+            if "correlate" not in k and "fft_fwd" not in k and "frontend" not in k and "wf_" not in k \
+                    and "fir_" not in k and "ddc_" not in k:
+                continue
+            print("  " + k[:90])
+            for c, v in sorted(cs.items()):
+                print("      %-28s %16.1f   (n=%d)" % (c, sum(v) / len(v), len(v)))
