@@ -100,7 +100,7 @@ def main():
     stream = torch.cuda.current_stream(dev).cuda_stream
     ctx = Context(local_rank, stream)
     B = args.blocks
-    s = Searcher(ctx, max_blocks=B)
+    s = Searcher(ctx, max_blocks=2 * B)      # two sets of blocks, used alternately
     svs = list(range(NSV))
     chips_list = []
     for sat in svs:
@@ -111,13 +111,19 @@ def main():
     # each rank gets its own seeded blocks ("receivers"), resident in HBM
     blocks = shard.block_ids(rank, world, B)
     iq_host = [synth.config1_iq16(seed=0x5EED0002 + b) for b in blocks]
-    iq_dev = [torch.from_numpy(x).to(dev) for x in iq_host]
-    ptrs = [int(t.data_ptr()) for t in iq_dev]
+    iq_dev = torch.from_numpy(np.stack(iq_host)).to(dev)      # [B][2*65536] int16, resident
+    iq_ptr = int(iq_dev.data_ptr())
+
+    parity = [0]
 
     def step():
-        for b in range(B):
-            s.sample_iq16(ptrs[b], block=b)
-        s.correlate_async(svs, nblocks=B)
+        # Sample() of this step's blocks goes to the library's front-end stream and
+        # overlaps the previous step's Correlate() (other set of blocks); all of it
+        # is inside the timed region.
+        first = parity[0] * B
+        parity[0] ^= 1
+        s.sample_iq16_batch(iq_ptr, B, first_block=first)
+        s.correlate_async(svs, nblocks=B, first_block=first)
 
     def barrier():
         if distributed:

@@ -56,13 +56,17 @@ SYMBOLS = {
     "kg_acq_sample_bits_dev": (_i, [_vp, _i, _vp]),
     "kg_acq_sample_iq16": (_i, [_vp, _i, _vp]),
     "kg_acq_sample_iq16_dev": (_i, [_vp, _i, _vp]),
+    "kg_acq_sample_iq16_batch_dev": (_i, [_vp, _i, _i, _vp, _sz]),
     "kg_acq_set_data_fft": (_i, [_vp, _i, _vp]),
     "kg_acq_get_data_fft": (_i, [_vp, _i, _vp]),
     "kg_acq_get_data_td": (_i, [_vp, _i, _vp]),
     "kg_acq_correlate_async": (_i, [_vp, _i, _vp, _i]),
+    "kg_acq_correlate_blocks_async": (_i, [_vp, _i, _i, _vp, _i]),
     "kg_acq_fetch": (_i, [_vp, _vp, _vp]),
     "kg_acq_correlate": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
     "kg_acq_results_dev": (_vp, [_vp]),
+    "kg_acq_debug_fft_stamps": (_i, [_vp, _i, _vp, _i]),
+    "kg_acq_debug_corr_stamps": (_i, [_vp, _i, _vp, _i, _vp, _i]),
 }
 
 

@@ -115,6 +115,12 @@ class Searcher:
         check(self.lib.kg_acq_sample_iq16(self.h, block, ptr(iq)), "kg_acq_sample_iq16")
         self.ctx.sync()
 
+    def sample_iq16_batch(self, d_iq, nblocks, first_block=0, stride_bytes=4 * NSAMPLES):
+        """nblocks blocks from one device array (int pointer), one launch set."""
+        check(self.lib.kg_acq_sample_iq16_batch_dev(self.h, int(first_block), int(nblocks),
+                                                    ptr(int(d_iq)), int(stride_bytes)),
+              "kg_acq_sample_iq16_batch_dev")
+
     def set_data_fft(self, data_fft, block=0):
         data_fft = np.ascontiguousarray(data_fft, np.complex64)
         if data_fft.size != FFT_LEN:
@@ -132,10 +138,14 @@ class Searcher:
         return out
 
     # ---- Correlate ----------------------------------------------------------
-    def correlate_async(self, sats, nblocks=1):
+    def correlate_async(self, sats, nblocks=1, first_block=0):
+        """Enqueue Correlate() over blocks first_block..first_block+nblocks-1.  Alternating
+        first_block between two sets of blocks overlaps the next set's Sample() front end
+        (own stream) with this launch."""
         sats = np.ascontiguousarray(sats, np.int32)
-        check(self.lib.kg_acq_correlate_async(self.h, int(nblocks), ptr(sats), sats.size),
-              "kg_acq_correlate_async")
+        check(self.lib.kg_acq_correlate_blocks_async(self.h, int(first_block), int(nblocks),
+                                                     ptr(sats), sats.size),
+              "kg_acq_correlate_blocks_async")
         self._last = (int(nblocks), sats.size)
 
     def fetch(self, want_cells=True):
@@ -145,8 +155,8 @@ class Searcher:
         check(self.lib.kg_acq_fetch(self.h, ptr(res), ptr(cells)), "kg_acq_fetch")
         return res, cells
 
-    def correlate_many(self, sats, nblocks=1, want_cells=True):
-        self.correlate_async(sats, nblocks)
+    def correlate_many(self, sats, nblocks=1, want_cells=True, first_block=0):
+        self.correlate_async(sats, nblocks, first_block)
         return self.fetch(want_cells)
 
     def correlate(self, sat, block_data=None):

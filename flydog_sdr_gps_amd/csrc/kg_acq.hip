@@ -4,8 +4,14 @@
 // (:243-285, :309-346), Sample() (:382-449) and Correlate() (:453-499).
 //
 // Data layout in HBM (private to this file): every 16384-bin spectrum is kept
-// "residue-major": plane r (0..3) holds bins k = 4*k1 + r at position k1
-// (4 planes x 4096 float2 = 128 KiB).  The unnormalised backward transform of
+// "residue-major": plane r (0..3) holds bins k = 4*k1 + r.  Inside a plane,
+// element k1 = t + 256 j (the value thread t feeds into leg j of its first
+// radix-16) sits at row j>>1, column 2*(t + H) + (j&1): the two legs 2i, 2i+1
+// of one thread are adjacent, so a thread fetches its 16 inputs with eight
+// 16-byte loads that are contiguous across the wave.  Data planes have H = 0
+// (8 rows x 512 = 4096 float2); code planes carry a halo of H columns on both
+// sides of every row holding the wrapped neighbours, so the Doppler rotation
+// code[(k - dop) mod N] (:471) is a plain column offset with no wrap logic.  The unnormalised backward transform of
 // Correlate() only needs outputs n < 4092 (C/A) -- a quarter of the 16384 --
 // so it is computed as
 //      y[n] = sum_{k2=0..3} W_N^{n*k2} * IFFT_4096( X[4*k1 + k2] )[n],  n < 4096
@@ -43,9 +49,9 @@ __constant__ float c_hb_even[16] = {
 KG_DEV float bipolar(int bit) { return bit ? -1.0f : 1.0f; }      // search.cpp:62-66
 
 template <int SRC>
-KG_DEV f2 acq_source(const void *__restrict__ src, int i, int nchips, int boc)
+KG_DEV cf acq_source(const void *__restrict__ src, int i, int nchips, int boc)
 {
-    if (i >= NSAMPLES) return f2{0.f, 0.f};          // DecimateBy2float zero tail, :145
+    if (i >= NSAMPLES) return cf{0.f, 0.f};          // DecimateBy2float zero tail, :145
     if constexpr (SRC == SRC_BITS) {
         // search.cpp:408-423: LSB-first bits, lo_sin = {1,1,0,0}, lo_cos = {1,0,0,1},
         // lo_phase advances by exactly 1.0 per sample.  :168-175: 1 -> -1.0, 0 -> +1.0.
@@ -53,15 +59,15 @@ KG_DEV f2 acq_source(const void *__restrict__ src, int i, int nchips, int boc)
         const int bit = (p[i >> 3] >> (i & 7)) & 1;
         const int ph = i & 3;
         const int ls = ph < 2, lc = (ph == 0) | (ph == 3);
-        return f2{bipolar(bit ^ ls), bipolar(bit ^ lc)};
+        return cf{bipolar(bit ^ ls), bipolar(bit ^ lc)};
     } else if constexpr (SRC == SRC_IQ16) {
         const short2 v = ((const short2 *) src)[i];
         const float a = (float) v.x, b = (float) v.y;
         switch (i & 3) {                             // (a + jb) * (-j)^i
-        case 0:  return f2{a, b};
-        case 1:  return f2{b, -a};
-        case 2:  return f2{-a, -b};
-        default: return f2{-b, a};
+        case 0:  return cf{a, b};
+        case 1:  return cf{b, -a};
+        case 2:  return cf{-a, -b};
+        default: return cf{-b, a};
         }
     } else {
         // search.cpp:250-267 / :315-329 with ca_rate = 1/16 exactly: chip index
@@ -69,18 +75,18 @@ KG_DEV f2 acq_source(const void *__restrict__ src, int i, int nchips, int boc)
         const uint8_t *p = (const uint8_t *) src;
         const int chip = p[(i >> 4) % nchips];
         const int b11 = boc ? ((i & 15) >= 8) : 0;
-        return f2{bipolar(chip ^ b11), 0.f};
+        return cf{bipolar(chip ^ b11), 0.f};
     }
 }
 
 // One half-band output, reference accumulation order (search.cpp:148-158):
 // c0 term, then j = 2,4,..,30, then the centre tap.  Separate multiply and add.
-KG_DEV f2 hb_tap(const f2 *x)
+KG_DEV cf hb_tap(const float2 *x)
 {
-    f2 acc = x[0] * kg_splat(c_hb_even[0]);
+    cf acc = kg_scale(kg_ld(&x[0]), c_hb_even[0]);
 #pragma unroll
-    for (int j = 1; j < 16; j++) acc = acc + x[2 * j] * kg_splat(c_hb_even[j]);
-    acc = acc + x[(NTAPS - 1) / 2] * kg_splat(HB_CENTRE);
+    for (int j = 1; j < 16; j++) acc = acc + kg_scale(kg_ld(&x[2 * j]), c_hb_even[j]);
+    acc = acc + kg_scale(kg_ld(&x[(NTAPS - 1) / 2]), HB_CENTRE);
     return acc;
 }
 
@@ -91,57 +97,96 @@ KG_DEV f2 hb_tap(const f2 *x)
 template <int SRC>
 __global__ __launch_bounds__(256) void acq_frontend_kernel(const uint8_t *__restrict__ src,
                                                           size_t src_stride, int nchips, int boc,
-                                                          f2 *__restrict__ td)
+                                                          float2 *__restrict__ td)
 {
-    __shared__ f2 xs[FE_NX + 1];
-    __shared__ f2 y1[FE_NY1 + 1];
+    __shared__ float2 xs[FE_NX + 1];
+    __shared__ float2 y1[FE_NY1 + 1];
     const int tid = threadIdx.x;
     const int o0 = blockIdx.x * FE_TILE;
     const void *s = src + (size_t) blockIdx.y * src_stride;
-    for (int u = tid; u < FE_NX; u += 256) xs[u] = acq_source<SRC>(s, 4 * o0 + u, nchips, boc);
+    for (int u = tid; u < FE_NX; u += 256) kg_st(&xs[u], acq_source<SRC>(s, 4 * o0 + u, nchips, boc));
     __syncthreads();
-    for (int u = tid; u < FE_NY1; u += 256) y1[u] = hb_tap(&xs[2 * u]);
+    for (int u = tid; u < FE_NY1; u += 256) kg_st(&y1[u], hb_tap(&xs[2 * u]));
     __syncthreads();
-    td[(size_t) blockIdx.y * FFT_LEN + o0 + tid] = hb_tap(&y1[2 * tid]);
+    kg_st(&td[(size_t) blockIdx.y * FFT_LEN + o0 + tid], hb_tap(&y1[2 * tid]));
 }
 
 // ---------------------------------------------------------------------------
 // Forward 16384-point FFT, natural time order in -> residue-major spectrum out.
-// One 1024-thread workgroup per transform: group g (256 threads) transforms the
-// samples n = 4*n1 + g, then a radix-4 step with W_N^{-k*g} combines them.
+// Two launches (both latency-bound, so the work is spread over many CUs):
+//   acq_fft_sub_kernel      4 workgroups per transform; workgroup g transforms the
+//                           samples n = 4*n1 + g (4096 points) -> F_g in scratch
+//   acq_fft_combine_kernel  radix-4 across g with W_N^{-k*g}, writes the planes
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void acq_fft_fwd_kernel(const f2 *__restrict__ td,
-                                                          f2 *__restrict__ planes,
-                                                          size_t planes_stride,   // in f2
-                                                          const f2 *__restrict__ tab4096,
-                                                          const f2 *__restrict__ tab16384)
-{
-    extern __shared__ __attribute__((aligned(16))) f2 smem[];   // 4 x 4096
-    const int tid = threadIdx.x, g = tid >> 8, t = tid & 255;
-    const f2 *in = td + (size_t) blockIdx.x * FFT_LEN;
-    f2 *out = planes + (size_t) blockIdx.x * planes_stride;
-    f2 *tile = smem + g * SUB;
+#define STAMP(i)                                                                      \
+    do {                                                                              \
+        if (STAMPS) {                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                        \
+            if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0)               \
+                stamps[i] = __builtin_amdgcn_s_memrealtime();                         \
+            __builtin_amdgcn_sched_barrier(0);                                        \
+        }                                                                             \
+    } while (0)
 
+// STAMPS: diagnostic instantiation only (kg_acq_debug_fft_stamps); the product
+// launches the STAMPS = false kernels, in which no stamp code exists.
+template <bool STAMPS>
+__global__ __launch_bounds__(256) void acq_fft_sub_kernel(const float2 *__restrict__ td,
+                                                         float2 *__restrict__ scratch,   // [batch][4][4096]
+                                                         const float2 *__restrict__ tab4096,
+                                                         unsigned long long *__restrict__ stamps)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];   // 2 x 4096
+    const int t = threadIdx.x, g = blockIdx.x;
+    const float2 *in = td + (size_t) blockIdx.y * FFT_LEN;
+    float2 *out = scratch + ((size_t) blockIdx.y * 4 + g) * SUB;
+    STAMP(0);
+    cf x[16], y[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = kg_ld(&in[4 * (t + 256 * j) + g]);
     kg_tw4096 tw;
     kg_tw4096_load(tw, tab4096, t);
-    f2 x[16], y[16];
+    if (STAMPS) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    STAMP(1);
+    kg_subfft4096<-1>(x, y, smem, smem + SUB, tw, t);
+    STAMP(2);
 #pragma unroll
-    for (int j = 0; j < 16; j++) x[j] = in[4 * (t + 256 * j) + g];
-    kg_subfft4096<-1>(x, y, tile, tw, t);
-    __syncthreads();                                   // all pass-2 reads done
+    for (int m = 0; m < 16; m++) kg_st(&out[t + 256 * m], y[m]);       // F_g[k'] at k'
+    if (STAMPS) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    STAMP(3);
+}
+
+__global__ __launch_bounds__(256) void acq_fft_combine_kernel(const float2 *__restrict__ scratch,
+                                                             float2 *__restrict__ planes,
+                                                             size_t planes_stride,   // in float2
+                                                             const float2 *__restrict__ tab16384,
+                                                             int halo)               // H: 0 data, >0 code
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;      // k' < 4096
+    const float2 *f = scratch + (size_t) blockIdx.y * FFT_LEN;
+    float2 *out = planes + (size_t) blockIdx.y * planes_stride;
+    cf f0 = kg_ld(&f[k]), f1 = kg_ld(&f[SUB + k]), f2 = kg_ld(&f[2 * SUB + k]), f3 = kg_ld(&f[3 * SUB + k]);
+    f1 = kg_cmulc(f1, kg_ld(&tab16384[k]));            // W_N^{-k*n2}
+    f2 = kg_cmulc(f2, kg_ld(&tab16384[2 * k]));
+    f3 = kg_cmulc(f3, kg_ld(&tab16384[3 * k]));
+    kg_radix4<-1>(f0, f1, f2, f3);                     // X[k + 4096 q], q = 0..3
+    // bin k + 4096 q -> plane k & 3, element k1 = (k >> 2) + 1024 q = tt + 256 j
+    const int row = 2 * (256 + 2 * halo), plane = 8 * row;
+    float2 *o = out + (size_t) (k & 3) * plane;
+    const int tt = (k >> 2) & 255, j0 = k >> 10;       // j = j0 + 4 q
+    const cf fq[4] = {f0, f1, f2, f3};
 #pragma unroll
-    for (int m = 0; m < 16; m++) tile[t + 256 * m] = y[m];     // F_g[k'] at k'
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int k = tid + 1024 * u;                  // k' < 4096
-        f2 f0 = smem[k], f1 = smem[SUB + k], f2_ = smem[2 * SUB + k], f3 = smem[3 * SUB + k];
-        f1 = kg_cmulc(f1, tab16384[k]);                // W_N^{-k*n2}
-        f2_ = kg_cmulc(f2_, tab16384[2 * k]);
-        f3 = kg_cmulc(f3, tab16384[3 * k]);
-        kg_radix4<-1>(f0, f1, f2_, f3);                // X[k + 4096 q], q = 0..3
-        f2 *o = out + (size_t) (k & 3) * SUB + (k >> 2);
-        o[0] = f0; o[1024] = f1; o[2048] = f2_; o[3072] = f3;
+    for (int q = 0; q < 4; q++) {
+        const int j = j0 + 4 * q;
+        kg_st(&o[(j >> 1) * row + 2 * (tt + halo) + (j & 1)], fq[q]);
+        if (tt < halo) {                               // also the right halo of leg j-1
+            const int jj = (j - 1) & 15;
+            kg_st(&o[(jj >> 1) * row + 2 * (tt + 256 + halo) + (jj & 1)], fq[q]);
+        }
+        if (tt >= 256 - halo) {                        // and the left halo of leg j+1
+            const int jj = (j + 1) & 15;
+            kg_st(&o[(jj >> 1) * row + 2 * (tt - 256 + halo) + (jj & 1)], fq[q]);
+        }
     }
 }
 
@@ -149,98 +194,159 @@ __global__ __launch_bounds__(1024) void acq_fft_fwd_kernel(const f2 *__restrict_
 // Correlate(): one workgroup per (block, SV, Doppler) cell, persistent over a
 // cell list.  search.cpp:465-496.
 // ---------------------------------------------------------------------------
-struct acq_red { float p; int i; float s; };
+struct acq_red { float p; int i; float s; int pad; };
 
-// exp(+2 pi i k / 64): the wave-uniform part of the combine twiddle (scalar loads)
-__constant__ f2 c_w64[64] = {
-#define W64(k) {KG_W64[k][0], KG_W64[k][1]}
-    W64(0), W64(1), W64(2), W64(3), W64(4), W64(5), W64(6), W64(7),
-    W64(8), W64(9), W64(10), W64(11), W64(12), W64(13), W64(14), W64(15),
-    W64(16), W64(17), W64(18), W64(19), W64(20), W64(21), W64(22), W64(23),
-    W64(24), W64(25), W64(26), W64(27), W64(28), W64(29), W64(30), W64(31),
-    W64(32), W64(33), W64(34), W64(35), W64(36), W64(37), W64(38), W64(39),
-    W64(40), W64(41), W64(42), W64(43), W64(44), W64(45), W64(46), W64(47),
-    W64(48), W64(49), W64(50), W64(51), W64(52), W64(53), W64(54), W64(55),
-    W64(56), W64(57), W64(58), W64(59), W64(60), W64(61), W64(62), W64(63),
+#define ACQ_LDS_BYTES (2 * SUB * sizeof(float2) + 4 * sizeof(acq_red))
+
+// The wave-uniform half of the combine twiddle W_N^{n*k2}, n = t + 256 m:
+// W_N^{256 m k2} = W_64^{m k2} and, with m = 4a + b, = W_64^{4a k2} * W_64^{b k2}.
+// Row k2: { W_64^{k2}, W_64^{2 k2}, W_64^{3 k2}, W_64^{4 k2}, W_64^{8 k2}, W_64^{12 k2} }.
+#define W64(k) {KG_W64[(k) & 63][0], KG_W64[(k) & 63][1]}
+#define W64ROW(k2) { W64(1*k2), W64(2*k2), W64(3*k2), W64(4*k2), W64(8*k2), W64(12*k2), W64(0), W64(0) }
+__constant__ float2 c_comb6[4][8] = { W64ROW(0), W64ROW(1), W64ROW(2), W64ROW(3) };
+#undef W64ROW
 #undef W64
+
+// One (block, SV, Doppler) cell, prepared by the host (build_cell_table): the
+// kernel never divides or chases index lists.  32 bytes = one s_load_dwordx8.
+struct acq_cell_desc {
+    int data_off;     // float2 offset of the block's data spectrum
+    int code_off;     // float2 offset of the SV's code spectrum
+    int dop;          // Doppler bin
+    int limit;        // peak-search window (search.cpp:486)
+    int out;          // index into cells[]
+    int pad[3];
 };
 
-template <int NQ>
-__global__ __launch_bounds__(256, 2) void acq_correlate_kernel(
-    const f2 *__restrict__ data,      // [nblocks][4][4096]
-    const f2 *__restrict__ code,      // [max_sats][4][4096]
-    const f2 *__restrict__ tab4096, const f2 *__restrict__ tab16384,
-    const int *__restrict__ sats,     // [nsats]  SV id at each list position
-    const int *__restrict__ sel,      // [nsel]   list positions this launch handles
-    const int *__restrict__ limits,   // [max_sats]
-    int nsel, int nsats, int nblocks, int dop_lo, int ndop,
-    kg_acq_cell *__restrict__ cells)  // [nblocks][nsats][ndop]
+// Work item = (cell, k2): one 4096-point sub-transform.  The operands of the
+// NEXT item are loaded while the current one is transformed (PREFETCH).
+template <int NQ, bool PREFETCH, bool STAMPS = false>
+__global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
+    const float2 *__restrict__ data,  // [nblocks][4][4096]
+    const float2 *__restrict__ code,  // [max_sats][4][4096]
+    const float2 *__restrict__ tab4096, const float2 *__restrict__ tab16384,
+    const acq_cell_desc *__restrict__ table,   // cells grouped by XCD label
+    const int *__restrict__ xcd_start,         // [9] first cell of each group (+ end)
+    int halo,                                  // H of the code planes
+    kg_acq_cell *__restrict__ cells,           // [nblocks][nsats][ndop]
+    unsigned long long *__restrict__ stamps = nullptr)
 {
-    __shared__ __attribute__((aligned(16))) f2 tile[SUB];
-    __shared__ acq_red red[4];
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    float2 *tileA = smem, *tileB = smem + SUB;
+    acq_red *red = (acq_red *) (smem + 2 * SUB);
     const int t = threadIdx.x;
+    // diagnostics: one workgroup, thread 0, 16 stamps per (cell, k2) item
+    unsigned long long *st = (STAMPS && t == 0 && blockIdx.x == 8) ? stamps : nullptr;
+    if (STAMPS && st) { st[0] = __builtin_amdgcn_s_memtime(); st[1] = __builtin_amdgcn_s_memrealtime(); }
 
     kg_tw4096 tw;
     kg_tw4096_load(tw, tab4096, t);
 
-    // XCD-aware cell list: workgroups b and b+8 share an XCD (round-robin
-    // dispatch), so (block, SV) pair p is served only by workgroups with
-    // b % 8 == p % 8 and its code spectrum stays in one L2.  Speed only.
-    const int npairs = nblocks * nsel;
+    // XCD-aware: workgroups b and b+8 share an XCD (round-robin dispatch), so the
+    // cells of one (block, SV) pair -- one code spectrum -- all belong to one
+    // group and that spectrum stays in one L2.  Speed only, never correctness.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
-    const int np_x = xcd < npairs ? (npairs - xcd + 7) >> 3 : 0;
+    const int first = xcd_start[xcd], ncell = xcd_start[xcd + 1] - first;
+    const acq_cell_desc *tab = table + first;
 
-    for (int lc = slot; lc < np_x * ndop; lc += nslots) {
-        const int pi = lc / ndop, di = lc - pi * ndop;
-        const int p = xcd + 8 * pi;
-        const int blk = p / nsel, pos = sel[p - blk * nsel];
-        const int sat = sats[pos];
-        const int dop = dop_lo + di;
-        const int limit = limits[sat];
-        const f2 *dsp = data + (size_t) blk * FFT_LEN;
-        const f2 *csp = code + (size_t) sat * FFT_LEN;
+    // Operand fetch: eight 16-byte buffer loads per spectrum.  The descriptor
+    // (SGPRs) carries the plane base, soffset the row, voffset the lane column:
+    // no per-load VALU address arithmetic.
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const int rowb_c = 2 * (256 + 2 * halo) * (int) sizeof(float2);   // code row, bytes
+    const int plane_c = 8 * 2 * (256 + 2 * halo);                     // code plane, float2
+    cf d[16], c[16];
+    auto fetch = [&](int data_off, int code_off, int dop, int k2) {
+        const int s = k2 - dop;
+        const int q0 = s >> 2;                         // floor((k2 - dop) / 4)
+        const auto drs = __builtin_amdgcn_make_buffer_rsrc(
+            (void *) (data + data_off + k2 * SUB), 0, SUB * (int) sizeof(float2), 0x00020000);
+        const auto crs = __builtin_amdgcn_make_buffer_rsrc(
+            (void *) (code + code_off + (s & 3) * plane_c), 0, plane_c * (int) sizeof(float2), 0x00020000);
+        const int dvo = t * 16, cvo = (t + q0 + halo) * 16;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const u4 dv = __builtin_amdgcn_raw_buffer_load_b128(drs, dvo, i * 4096, 0);
+            const u4 cv = __builtin_amdgcn_raw_buffer_load_b128(crs, cvo, i * rowb_c, 0);
+            d[2 * i] = cf{__uint_as_float(dv[0]), __uint_as_float(dv[1])};
+            d[2 * i + 1] = cf{__uint_as_float(dv[2]), __uint_as_float(dv[3])};
+            c[2 * i] = cf{__uint_as_float(cv[0]), __uint_as_float(cv[1])};
+            c[2 * i + 1] = cf{__uint_as_float(cv[2]), __uint_as_float(cv[3])};
+        }
+    };
 
-        f2 acc[NQ][16];
-#pragma unroll
-        for (int q = 0; q < NQ; q++)
-#pragma unroll
-            for (int m = 0; m < 16; m++) acc[q][m] = f2{0.f, 0.f};
-        // rolled on purpose: an unrolled loop lets the compiler hoist all 128
-        // global loads to the top (>400 VGPRs) and quadruples the code size
+    if (slot >= ncell) return;
+    acq_cell_desc cur = tab[slot];
+    if (PREFETCH) fetch(cur.data_off, cur.code_off, cur.dop, 0);
+
+    int st_item = 0;
+    for (int lc = slot; lc < ncell; lc += nslots) {
+        const bool more = lc + nslots < ncell;
+        const acq_cell_desc nxt = tab[more ? lc + nslots : lc];   // one cell ahead
+        cf acc[NQ][16];
+        // rolled on purpose: unrolled (or with k2 a template constant) the
+        // register allocator spills 80+ VGPRs
 #pragma unroll 1
         for (int k2 = 0; k2 < 4; k2++) {
-            const int s = k2 - dop;
-            const f2 *dp = dsp + k2 * SUB;
-            const f2 *cp = csp + (s & 3) * SUB;
-            const int q0 = s >> 2;                     // floor((k2 - dop) / 4)
-            f2 x[16], y[16];
+            unsigned long long *sti = (STAMPS && st && st_item < 24) ? st + 16 + 16 * st_item : nullptr;
+            KG_STAMP(STAMPS, sti, 8);
+            if (!PREFETCH) fetch(cur.data_off, cur.code_off, cur.dop, k2);
+            const cf base = kg_ld(&tab16384[t * k2]);          // W_N^{t*k2}, used after the transform
+            cf x[16], y[16];
+            // conj(data) * code, simd_multiply_conjugate_ccc (support/simd.cpp:39-67)
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const int k1 = t + 256 * j;
-                const f2 d = dp[k1];
-                const f2 c = cp[(k1 + q0) & (SUB - 1)];
-                // conj(d) * c, simd_multiply_conjugate_ccc (support/simd.cpp:39-67)
-                x[j] = kg_cmulc(c, d);
+            for (int j = 0; j < 16; j++) x[j] = kg_cmulc(c[j], d[j]);
+            KG_STAMP(STAMPS, sti, 9);
+            if (PREFETCH && (k2 < 3 || more)) {        // one load site: (cur, k2+1) or (nxt, 0)
+                const bool same = k2 < 3;
+                fetch(same ? cur.data_off : nxt.data_off, same ? cur.code_off : nxt.code_off,
+                      same ? cur.dop : nxt.dop, (k2 + 1) & 3);
             }
-            kg_subfft4096<+1>(x, y, tile, tw, t);
-            // acc_q[n'] += y[n'] * W_N^{n'*k2} * j^{q*k2},  n' = t + 256 m, and
-            // W_N^{n'*k2} = W_N^{t*k2} * W_64^{m*k2} (per-thread base x uniform table)
-            const f2 base = tab16384[t * k2];
+            KG_STAMP(STAMPS, sti, 10);
+            kg_subfft4096_a<+1, STAMPS>(x, y, tileA, tileB, tw, t, sti);
+            // six wave-uniform constants (s_load), hidden behind pass 2
+            cf g[3], G[3];
 #pragma unroll
-            for (int m = 0; m < 16; m++) {
-                const f2 w = kg_cmul(base, c_w64[(m * k2) & 63]);
-                const f2 z = kg_cmul(y[m], w);
+            for (int i = 0; i < 3; i++) { g[i] = kg_ld(&c_comb6[k2][i]); G[i] = kg_ld(&c_comb6[k2][3 + i]); }
+            kg_subfft4096_b<+1, STAMPS>(x, y, tileB, tw, t, sti);
+            // acc_q[n'] += y[n'] * W_N^{n'*k2} * j^{q*k2},  n' = t + 256 m, m = 4a + b:
+            // W_N^{n'*k2} = (W_N^{t*k2} * W_64^{4a*k2}) * W_64^{b*k2}
+            if (k2 == 0) {
 #pragma unroll
-                for (int q = 0; q < NQ; q++) {
-                    const int r = (q * k2) & 3;        // j^(q*k2), wave-uniform
-                    f2 zq = (r & 1) ? f2{-z.y, z.x} : z;
-                    zq = (r & 2) ? -zq : zq;
-                    acc[q][m] = acc[q][m] + zq;
+                for (int q = 0; q < NQ; q++)
+#pragma unroll
+                    for (int m = 0; m < 16; m++) acc[q][m] = y[m];
+            } else {
+                cf B[4];
+                B[0] = base;
+#pragma unroll
+                for (int a = 1; a < 4; a++) B[a] = kg_cmul_s(base, G[a - 1]);
+#pragma unroll
+                for (int m = 0; m < 16; m++) {
+                    cf z = y[m];
+                    if ((m & 3) != 0) z = kg_cmul_s(z, g[(m & 3) - 1]);
+                    z = kg_cmul(z, B[m >> 2]);
+                    acc[0][m] = acc[0][m] + z;
+                    if constexpr (NQ == 4) {           // quarters 1..3: times j^(q*k2), wave-uniform
+                        if (k2 == 1) {
+                            acc[1][m] = kg_addj(acc[1][m], z); acc[2][m] = acc[2][m] - z;
+                            acc[3][m] = kg_subj(acc[3][m], z);
+                        } else if (k2 == 2) {
+                            acc[1][m] = acc[1][m] - z; acc[2][m] = acc[2][m] + z;
+                            acc[3][m] = acc[3][m] - z;
+                        } else {
+                            acc[1][m] = kg_subj(acc[1][m], z); acc[2][m] = acc[2][m] - z;
+                            acc[3][m] = kg_addj(acc[3][m], z);
+                        }
+                    }
                 }
             }
+            KG_STAMP(STAMPS, sti, 11);
+            if (STAMPS) st_item++;
         }
 
         // search.cpp:486-490: power, first maximum (strict >), running total
+        const int limit = cur.limit;
         float bp = 0.f, sum = 0.f;
         int bi = 0;
 #pragma unroll
@@ -248,55 +354,72 @@ __global__ __launch_bounds__(256, 2) void acq_correlate_kernel(
 #pragma unroll
             for (int m = 0; m < 16; m++) {
                 const int n = t + 256 * m + SUB * q;
-                const f2 v = acc[q][m];
+                const cf v = acc[q][m];
                 const float pw = v.x * v.x + v.y * v.y;
-                if (n < limit) {
-                    if (pw > bp) { bp = pw; bi = n; }
-                    sum += pw;
-                }
+                const bool in = n < limit, take = in & (pw > bp);
+                bp = take ? pw : bp; bi = take ? n : bi;
+                sum += in ? pw : 0.f;
             }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const float op = __shfl_xor(bp, off);
-            const int oi = __shfl_xor(bi, off);
-            const float os = __shfl_xor(sum, off);
-            if (op > bp || (op == bp && oi < bi)) { bp = op; bi = oi; }
-            sum += os;
+#define ACQ_RED_STEP(L)                                                               \
+        {                                                                                \
+            const float op = kg_xchg<L>(bp), os = kg_xchg<L>(sum);                       \
+            const int oi = kg_xchg<L>(bi);                                               \
+            const bool take = (op > bp) | ((op == bp) & (oi < bi));   /* branch-free */  \
+            bp = take ? op : bp; bi = take ? oi : bi;                                    \
+            sum += os;                                                                   \
         }
+        ACQ_RED_STEP(0) ACQ_RED_STEP(1) ACQ_RED_STEP(2) ACQ_RED_STEP(3) ACQ_RED_STEP(4) ACQ_RED_STEP(5)
+        // red[] was last read before this cell's eight barriers
         if ((t & 63) == 0) { red[t >> 6].p = bp; red[t >> 6].i = bi; red[t >> 6].s = sum; }
         __syncthreads();
-        if (t == 0) {
-            float mp = red[0].p, tot = red[0].s;
-            int mi = red[0].i;
-            for (int w = 1; w < 4; w++) {
-                if (red[w].p > mp || (red[w].p == mp && red[w].i < mi)) { mp = red[w].p; mi = red[w].i; }
-                tot += red[w].s;
+        if (t < 64) {                                  // lanes 0..3 of wave 0 merge the four waves
+            const acq_red r = red[t & 3];
+            bp = r.p; bi = r.i; sum = r.s;
+            ACQ_RED_STEP(0) ACQ_RED_STEP(1)
+            if (t == 0) {
+                const float ave = sum / (float) limit;     // :493
+                kg_acq_cell cc;
+                cc.snr = bp / ave;                         // :494
+                cc.max_pwr = bp; cc.tot_pwr = sum; cc.idx = bi;
+                cells[cur.out] = cc;
             }
-            const float ave = tot / (float) limit;     // :493
-            kg_acq_cell c;
-            c.snr = mp / ave;                          // :494
-            c.max_pwr = mp; c.tot_pwr = tot; c.idx = mi;
-            cells[((size_t) blk * nsats + pos) * ndop + di] = c;
         }
-        // red[] is rewritten only after the next cell's barriers
+#undef ACQ_RED_STEP
+        cur = nxt;
     }
+    if (STAMPS && st) { st[2] = __builtin_amdgcn_s_memtime(); st[3] = __builtin_amdgcn_s_memrealtime(); }
 }
 
-// search.cpp:455,495: best Doppler bin per (block, SV), strict > in ascending dop
-__global__ void acq_select_kernel(const kg_acq_cell *__restrict__ cells, int npairs, int dop_lo,
-                                  int ndop, kg_acq_result *__restrict__ out)
+// search.cpp:455,495: best Doppler bin per (block, SV): the serial scan keeps the
+// first bin (ascending dop) holding the maximum snr, and only if it is > 0.
+// One wave per pair; lane l scans bins l, l+64, ...
+__global__ __launch_bounds__(64) void acq_select_kernel(const kg_acq_cell *__restrict__ cells,
+                                                       int npairs, int dop_lo, int ndop,
+                                                       kg_acq_result *__restrict__ out)
 {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = blockIdx.x, lane = threadIdx.x;
     if (p >= npairs) return;
-    kg_acq_result r = {0.f, 0, 0, 0};
-    float max_snr = 0.f;
-    for (int di = 0; di < ndop; di++) {
+    float bs = 0.f;
+    int bd = 0x7fffffff, bidx = 0;
+    for (int di = lane; di < ndop; di += 64) {
         const kg_acq_cell c = cells[(size_t) p * ndop + di];
-        if (c.snr > max_snr) { max_snr = c.snr; r.dop = dop_lo + di; r.idx = c.idx; r.valid = 1; }
+        if (c.snr > bs) { bs = c.snr; bd = di; bidx = c.idx; }
     }
-    r.snr = max_snr;
-    out[p] = r;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float os = __shfl_xor(bs, off);
+        const int od = __shfl_xor(bd, off), oi = __shfl_xor(bidx, off);
+        if (os > bs || (os == bs && od < bd)) { bs = os; bd = od; bidx = oi; }
+    }
+    if (lane == 0) {
+        kg_acq_result r;
+        r.valid = bs > 0.f ? 1 : 0;
+        r.snr = r.valid ? bs : 0.f;
+        r.dop = r.valid ? dop_lo + bd : 0;
+        r.idx = r.valid ? bidx : 0;
+        out[p] = r;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -305,49 +428,81 @@ __global__ void acq_select_kernel(const kg_acq_cell *__restrict__ cells, int npa
 struct kg_acq {
     kg_ctx *ctx;
     int max_sats, dop_lo, dop_hi, ndop, max_blocks;
-    f2 *d_code;        // [max_sats][4][4096]
-    f2 *d_data;        // [max_blocks][4][4096]
-    f2 *d_td;          // [max_blocks][16384]  decimated time-domain samples per block
-    f2 *d_td_code;     // [16384]              same, for the code-table build
+    int halo;          // H of the code planes: covers every floor((k2 - dop) / 4)
+    size_t code_len;   // float2 per code spectrum (4 planes with halo)
+    float2 *d_code;        // [max_sats][4][4096]
+    float2 *d_data;        // [max_blocks][4][4096]
+    float2 *d_td;          // [max_blocks][16384]  decimated time-domain samples per block
+    float2 *d_td_code;     // [16384]              same, for the code-table build
+    float2 *d_fsub;        // [max_blocks][4][4096] sub-transforms awaiting the radix-4 combine
+    float2 *d_fsub_code;   // [4][4096]
     uint8_t *d_in;     // [max_blocks][NSAMPLES*4]    host-input staging
     uint8_t *d_chips;  // [E1B_CODELEN max]
     int *d_limits;     // [max_sats]
-    int *d_sats, *d_sel1, *d_sel4;
+    acq_cell_desc *d_table1, *d_table4;   // cell tables of the C/A and E1B launches
+    int *d_xcd1, *d_xcd4;                 // [9] group starts
+    size_t table_cap;
     kg_acq_cell *d_cells;
     kg_acq_result *d_results;
     std::vector<int> limits, code_set;
     std::vector<int> last_sats;
-    int last_nblocks, last_nsats, nsel1, nsel4;
+    int last_first, last_nblocks, last_nsats, nsel1, nsel4, table_nblocks;
+    // Sample() work runs on its own stream so that block b+1's front end overlaps
+    // block b's correlation; per-block events order the two streams.
+    hipStream_t fstream;
+    std::vector<hipEvent_t> ev_ready, ev_done;   // data spectrum written / last reader done
+    std::vector<char> has_ready, has_done;
     int grid1, grid4;
 };
 
 static const size_t IN_STRIDE = (size_t) NSAMPLES * 4;     // bytes per block of staging
 
-static void to_planes(const float *nat, std::vector<float2> &pl)
+// Host mirror of the plane layout (see the head of this file).
+static inline size_t plane_pos(int k1, int halo_col, int H)
 {
-    pl.resize(FFT_LEN);
-    for (int k = 0; k < FFT_LEN; k++)
-        pl[(size_t) (k & 3) * SUB + (k >> 2)] = make_float2(nat[2 * k], nat[2 * k + 1]);
+    const int t = k1 & 255, j = k1 >> 8, row = 2 * (256 + 2 * H);
+    return (size_t) (j >> 1) * row + 2 * (t + halo_col + H) + (j & 1);
 }
-static void from_planes(const std::vector<float2> &pl, float *nat)
+static inline size_t spec_len(int H) { return (size_t) 4 * 8 * 2 * (256 + 2 * H); }
+
+static void to_planes(const float *nat, std::vector<float2> &pl, int H)
 {
+    const size_t plane = spec_len(H) / 4;
+    pl.assign(spec_len(H), make_float2(0.f, 0.f));
     for (int k = 0; k < FFT_LEN; k++) {
-        const float2 v = pl[(size_t) (k & 3) * SUB + (k >> 2)];
+        const float2 v = make_float2(nat[2 * k], nat[2 * k + 1]);
+        const int k1 = k >> 2, t = k1 & 255, j = k1 >> 8;
+        float2 *p = pl.data() + (size_t) (k & 3) * plane;
+        p[plane_pos(k1, 0, H)] = v;
+        if (t < H) p[plane_pos(t + 256 * ((j - 1) & 15), 256, H)] = v;
+        if (t >= 256 - H) p[plane_pos(t + 256 * ((j + 1) & 15), -256, H)] = v;
+    }
+}
+static void from_planes(const std::vector<float2> &pl, float *nat, int H)
+{
+    const size_t plane = spec_len(H) / 4;
+    for (int k = 0; k < FFT_LEN; k++) {
+        const float2 v = pl[(size_t) (k & 3) * plane + plane_pos(k >> 2, 0, H)];
         nat[2 * k] = v.x; nat[2 * k + 1] = v.y;
     }
 }
 
 template <int SRC>
-static int launch_frontend(kg_acq *a, const uint8_t *d_src, size_t stride, int nbatch, int nchips,
-                           int boc, f2 *d_td, f2 *d_planes, size_t planes_stride)
+static int launch_frontend(kg_acq *a, hipStream_t st, const uint8_t *d_src, size_t stride, int nbatch,
+                           int nchips, int boc, float2 *d_td, float2 *d_scratch, float2 *d_planes,
+                           size_t planes_stride, int halo)
 {
     kg_ctx *c = a->ctx;
     hipLaunchKernelGGL(acq_frontend_kernel<SRC>, dim3(FFT_LEN / FE_TILE, nbatch), dim3(256), 0,
-                       c->stream, d_src, stride, nchips, boc, d_td);
+                       st, d_src, stride, nchips, boc, d_td);
     KG_HIP(hipGetLastError());
-    hipLaunchKernelGGL(acq_fft_fwd_kernel, dim3(nbatch), dim3(1024), 4 * SUB * sizeof(f2),
-                       c->stream, (const f2 *) d_td, d_planes, planes_stride,
-                       (const f2 *) c->d_tab4096, (const f2 *) c->d_tab16384);
+    hipLaunchKernelGGL(acq_fft_sub_kernel<false>, dim3(4, nbatch), dim3(256), 2 * SUB * sizeof(float2),
+                       st, (const float2 *) d_td, d_scratch, (const float2 *) c->d_tab4096,
+                       (unsigned long long *) nullptr);
+    KG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(acq_fft_combine_kernel, dim3(SUB / 256, nbatch), dim3(256), 0, st,
+                       (const float2 *) d_scratch, d_planes, planes_stride,
+                       (const float2 *) c->d_tab16384, halo);
     KG_HIP(hipGetLastError());
     return KG_OK;
 }
@@ -361,37 +516,59 @@ int kg_acq_create(kg_ctx *ctx, int max_sats, int dop_lo, int dop_hi, int max_blo
     KG_REQUIRE(out != nullptr, KG_ERR_INVALID, "kg_acq_create: out is null");
     *out = nullptr;
     KG_REQUIRE(max_sats >= 1 && max_sats <= 4096, KG_ERR_INVALID, "kg_acq_create: max_sats %d", max_sats);
-    KG_REQUIRE(dop_lo <= dop_hi && dop_lo > -FFT_LEN / 2 && dop_hi < FFT_LEN / 2, KG_ERR_INVALID,
-               "kg_acq_create: Doppler range %d..%d", dop_lo, dop_hi);
+    KG_REQUIRE(dop_lo <= dop_hi && dop_lo >= -1000 && dop_hi <= 1000, KG_ERR_INVALID,
+               "kg_acq_create: Doppler range %d..%d (supported: within -1000..1000)", dop_lo, dop_hi);
     KG_REQUIRE(max_blocks >= 1 && max_blocks <= 65535, KG_ERR_INVALID, "kg_acq_create: max_blocks %d",
                max_blocks);
     kg_acq *a = new (std::nothrow) kg_acq();
     KG_REQUIRE(a != nullptr, KG_ERR_NOMEM, "kg_acq_create: alloc");
     a->ctx = ctx; a->max_sats = max_sats; a->dop_lo = dop_lo; a->dop_hi = dop_hi;
     a->ndop = dop_hi - dop_lo + 1; a->max_blocks = max_blocks;
+    {
+        const int m = (dop_hi > -dop_lo ? dop_hi : -dop_lo);
+        a->halo = (m + 3) / 4 + 2;
+        a->code_len = spec_len(a->halo);
+    }
     a->limits.assign(max_sats, 0); a->code_set.assign(max_sats, 0);
-    a->last_nblocks = a->last_nsats = a->nsel1 = a->nsel4 = 0;
-    const size_t spec = sizeof(f2) * FFT_LEN;
-    KG_HIP(hipMalloc((void **) &a->d_code, spec * max_sats));
+    a->last_first = a->last_nblocks = a->last_nsats = a->nsel1 = a->nsel4 = a->table_nblocks = 0;
+    const size_t spec = sizeof(float2) * FFT_LEN;
+    KG_HIP(hipMalloc((void **) &a->d_code, sizeof(float2) * a->code_len * max_sats));
     KG_HIP(hipMalloc((void **) &a->d_data, spec * max_blocks));
     KG_HIP(hipMalloc((void **) &a->d_td, spec * max_blocks));
     KG_HIP(hipMalloc((void **) &a->d_td_code, spec));
+    KG_HIP(hipMalloc((void **) &a->d_fsub, spec * max_blocks));
+    KG_HIP(hipMalloc((void **) &a->d_fsub_code, spec));
     KG_HIP(hipMalloc((void **) &a->d_in, IN_STRIDE * max_blocks));
     KG_HIP(hipMalloc((void **) &a->d_chips, 8192));
     KG_HIP(hipMalloc((void **) &a->d_limits, sizeof(int) * max_sats));
-    KG_HIP(hipMalloc((void **) &a->d_sats, sizeof(int) * max_sats));
-    KG_HIP(hipMalloc((void **) &a->d_sel1, sizeof(int) * max_sats));
-    KG_HIP(hipMalloc((void **) &a->d_sel4, sizeof(int) * max_sats));
+    a->table_cap = (size_t) max_blocks * max_sats * a->ndop;
+    KG_HIP(hipMalloc((void **) &a->d_table1, sizeof(acq_cell_desc) * a->table_cap));
+    KG_HIP(hipMalloc((void **) &a->d_table4, sizeof(acq_cell_desc) * a->table_cap));
+    KG_HIP(hipMalloc((void **) &a->d_xcd1, sizeof(int) * 9));
+    KG_HIP(hipMalloc((void **) &a->d_xcd4, sizeof(int) * 9));
     KG_HIP(hipMalloc((void **) &a->d_cells, sizeof(kg_acq_cell) * (size_t) max_blocks * max_sats * a->ndop));
     KG_HIP(hipMalloc((void **) &a->d_results, sizeof(kg_acq_result) * (size_t) max_blocks * max_sats));
+    KG_HIP(hipStreamCreateWithFlags(&a->fstream, hipStreamNonBlocking));
+    a->ev_ready.resize(max_blocks); a->ev_done.resize(max_blocks);
+    a->has_ready.assign(max_blocks, 0); a->has_done.assign(max_blocks, 0);
+    for (int b = 0; b < max_blocks; b++) {
+        KG_HIP(hipEventCreateWithFlags(&a->ev_ready[b], hipEventDisableTiming));
+        KG_HIP(hipEventCreateWithFlags(&a->ev_done[b], hipEventDisableTiming));
+    }
     KG_HIP(hipMemset(a->d_limits, 0, sizeof(int) * max_sats));
     KG_HIP(hipMemset(a->d_data, 0, spec * max_blocks));
-    KG_HIP(hipFuncSetAttribute((const void *) acq_fft_fwd_kernel,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SUB * sizeof(f2)));
+    KG_HIP(hipFuncSetAttribute((const void *) acq_fft_sub_kernel<false>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SUB * sizeof(float2)));
+    KG_HIP(hipFuncSetAttribute((const void *) acq_fft_sub_kernel<true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SUB * sizeof(float2)));
     // persistent grid: resident workgroups per CU x CUs, rounded to a multiple of 8 (XCDs)
     int occ1 = 0, occ4 = 0;
-    KG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ1, acq_correlate_kernel<1>, 256, 0));
-    KG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ4, acq_correlate_kernel<4>, 256, 0));
+    KG_HIP(hipFuncSetAttribute((const void *) acq_correlate_kernel<1, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, ACQ_LDS_BYTES));
+    KG_HIP(hipFuncSetAttribute((const void *) acq_correlate_kernel<4, false>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, ACQ_LDS_BYTES));
+    KG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ1, acq_correlate_kernel<1, true>, 256, ACQ_LDS_BYTES));
+    KG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ4, acq_correlate_kernel<4, false>, 256, ACQ_LDS_BYTES));
     if (occ1 < 1) occ1 = 1;
     if (occ4 < 1) occ4 = 1;
     a->grid1 = (ctx->num_cus * occ1) & ~7;
@@ -406,11 +583,19 @@ void kg_acq_destroy(kg_acq *a)
 {
     if (!a) return;
     (void) hipSetDevice(a->ctx->device);
+    (void) hipStreamSynchronize(a->fstream);
     (void) hipStreamSynchronize(a->ctx->stream);
+    for (size_t b = 0; b < a->ev_ready.size(); b++) {
+        (void) hipEventDestroy(a->ev_ready[b]);
+        (void) hipEventDestroy(a->ev_done[b]);
+    }
+    (void) hipStreamDestroy(a->fstream);
     (void) hipFree(a->d_code); (void) hipFree(a->d_data); (void) hipFree(a->d_td);
     (void) hipFree(a->d_td_code);
+    (void) hipFree(a->d_fsub); (void) hipFree(a->d_fsub_code);
     (void) hipFree(a->d_in); (void) hipFree(a->d_chips); (void) hipFree(a->d_limits);
-    (void) hipFree(a->d_sats); (void) hipFree(a->d_sel1); (void) hipFree(a->d_sel4);
+    (void) hipFree(a->d_table1); (void) hipFree(a->d_table4);
+    (void) hipFree(a->d_xcd1); (void) hipFree(a->d_xcd4);
     (void) hipFree(a->d_cells); (void) hipFree(a->d_results);
     delete a;
 }
@@ -439,8 +624,8 @@ int kg_acq_set_code(kg_acq *a, int sat, const uint8_t *chips, int nchips, int bo
         KG_REQUIRE(chips[i] <= 1, KG_ERR_INVALID, "kg_acq_set_code: chips[%d] = %d is not 0/1", i, chips[i]);
     if ((rc = set_limit(a, sat, limit)) != KG_OK) return rc;
     KG_HIP(hipMemcpyAsync(a->d_chips, chips, nchips, hipMemcpyHostToDevice, a->ctx->stream));
-    rc = launch_frontend<SRC_CHIPS>(a, a->d_chips, 0, 1, nchips, boc ? 1 : 0, a->d_td_code,
-                                    a->d_code + (size_t) sat * FFT_LEN, FFT_LEN);
+    rc = launch_frontend<SRC_CHIPS>(a, a->ctx->stream, a->d_chips, 0, 1, nchips, boc ? 1 : 0, a->d_td_code, a->d_fsub_code,
+                                    a->d_code + (size_t) sat * a->code_len, a->code_len, a->halo);
     if (rc) return rc;
     KG_HIP(hipStreamSynchronize(a->ctx->stream));       // chips buffer is reused per call
     return KG_OK;
@@ -453,19 +638,20 @@ int kg_acq_set_code_fft(kg_acq *a, int sat, const float *code_fft, int limit)
     if (rc) return rc;
     if ((rc = set_limit(a, sat, limit)) != KG_OK) return rc;
     std::vector<float2> pl;
-    to_planes(code_fft, pl);
-    KG_HIP(hipMemcpyAsync(a->d_code + (size_t) sat * FFT_LEN, pl.data(), sizeof(f2) * FFT_LEN,
+    to_planes(code_fft, pl, a->halo);
+    KG_HIP(hipMemcpyAsync(a->d_code + (size_t) sat * a->code_len, pl.data(), sizeof(float2) * a->code_len,
                           hipMemcpyHostToDevice, a->ctx->stream));
     KG_HIP(hipStreamSynchronize(a->ctx->stream));
     return KG_OK;
 }
 
-static int get_planes(kg_acq *a, const f2 *d, float *nat)
+static int get_planes(kg_acq *a, const float2 *d, float *nat, int H)
 {
-    std::vector<float2> pl(FFT_LEN);
-    KG_HIP(hipMemcpyAsync(pl.data(), d, sizeof(f2) * FFT_LEN, hipMemcpyDeviceToHost, a->ctx->stream));
+    std::vector<float2> pl(spec_len(H));
+    KG_HIP(hipStreamSynchronize(a->fstream));
+    KG_HIP(hipMemcpyAsync(pl.data(), d, sizeof(float2) * pl.size(), hipMemcpyDeviceToHost, a->ctx->stream));
     KG_HIP(hipStreamSynchronize(a->ctx->stream));
-    from_planes(pl, nat);
+    from_planes(pl, nat, H);
     return KG_OK;
 }
 
@@ -476,7 +662,7 @@ int kg_acq_get_code_fft(kg_acq *a, int sat, float *code_fft)
     if (rc) return rc;
     KG_REQUIRE(sat >= 0 && sat < a->max_sats, KG_ERR_INVALID, "kg_acq_get_code_fft: sat %d", sat);
     KG_REQUIRE(a->code_set[sat], KG_ERR_STATE, "kg_acq_get_code_fft: no code set for sat %d", sat);
-    return get_planes(a, a->d_code + (size_t) sat * FFT_LEN, code_fft);
+    return get_planes(a, a->d_code + (size_t) sat * a->code_len, code_fft, a->halo);
 }
 
 static int check_block(kg_acq *a, int block, const void *p, const char *who)
@@ -487,12 +673,29 @@ static int check_block(kg_acq *a, int block, const void *p, const char *who)
     return kg_ctx_use(a->ctx);
 }
 
+// Front-stream bracket for everything that (re)writes block b's data spectrum.
+static int front_begin(kg_acq *a, int b)
+{
+    if (a->has_done[b]) KG_HIP(hipStreamWaitEvent(a->fstream, a->ev_done[b], 0));   // WAR
+    return KG_OK;
+}
+static int front_end(kg_acq *a, int b)
+{
+    KG_HIP(hipEventRecord(a->ev_ready[b], a->fstream));
+    a->has_ready[b] = 1;
+    return KG_OK;
+}
+
 int kg_acq_sample_bits_dev(kg_acq *a, int block, const void *d_packed)
 {
     int rc = check_block(a, block, d_packed, "kg_acq_sample_bits_dev");
     if (rc) return rc;
-    return launch_frontend<SRC_BITS>(a, (const uint8_t *) d_packed, 0, 1, 0, 0,
-                                     a->d_td + (size_t) block * FFT_LEN, a->d_data + (size_t) block * FFT_LEN, FFT_LEN);
+    if ((rc = front_begin(a, block)) != KG_OK) return rc;
+    rc = launch_frontend<SRC_BITS>(a, a->fstream, (const uint8_t *) d_packed, 0, 1, 0, 0,
+                                   a->d_td + (size_t) block * FFT_LEN, a->d_fsub + (size_t) block * FFT_LEN,
+                                   a->d_data + (size_t) block * FFT_LEN, FFT_LEN, 0);
+    if (rc) return rc;
+    return front_end(a, block);
 }
 
 int kg_acq_sample_bits(kg_acq *a, int block, const uint8_t *packed)
@@ -500,7 +703,7 @@ int kg_acq_sample_bits(kg_acq *a, int block, const uint8_t *packed)
     int rc = check_block(a, block, packed, "kg_acq_sample_bits");
     if (rc) return rc;
     uint8_t *stage = a->d_in + IN_STRIDE * block;
-    KG_HIP(hipMemcpyAsync(stage, packed, NSAMPLES / 8, hipMemcpyHostToDevice, a->ctx->stream));
+    KG_HIP(hipMemcpyAsync(stage, packed, NSAMPLES / 8, hipMemcpyHostToDevice, a->fstream));
     return kg_acq_sample_bits_dev(a, block, stage);
 }
 
@@ -509,8 +712,31 @@ int kg_acq_sample_iq16_dev(kg_acq *a, int block, const void *d_iq)
     int rc = check_block(a, block, d_iq, "kg_acq_sample_iq16_dev");
     if (rc) return rc;
     KG_REQUIRE(((uintptr_t) d_iq & 3) == 0, KG_ERR_INVALID, "kg_acq_sample_iq16_dev: pointer not 4-byte aligned");
-    return launch_frontend<SRC_IQ16>(a, (const uint8_t *) d_iq, 0, 1, 0, 0,
-                                     a->d_td + (size_t) block * FFT_LEN, a->d_data + (size_t) block * FFT_LEN, FFT_LEN);
+    if ((rc = front_begin(a, block)) != KG_OK) return rc;
+    rc = launch_frontend<SRC_IQ16>(a, a->fstream, (const uint8_t *) d_iq, 0, 1, 0, 0,
+                                   a->d_td + (size_t) block * FFT_LEN, a->d_fsub + (size_t) block * FFT_LEN,
+                                   a->d_data + (size_t) block * FFT_LEN, FFT_LEN, 0);
+    if (rc) return rc;
+    return front_end(a, block);
+}
+
+int kg_acq_sample_iq16_batch_dev(kg_acq *a, int first, int nblocks, const void *d_iq, size_t stride_bytes)
+{
+    int rc = check_block(a, first, d_iq, "kg_acq_sample_iq16_batch_dev");
+    if (rc) return rc;
+    KG_REQUIRE(nblocks >= 1 && first + nblocks <= a->max_blocks, KG_ERR_INVALID,
+               "kg_acq_sample_iq16_batch_dev: blocks %d..%d (max %d)", first, first + nblocks - 1, a->max_blocks);
+    KG_REQUIRE(((uintptr_t) d_iq & 3) == 0 && (stride_bytes & 3) == 0, KG_ERR_INVALID,
+               "kg_acq_sample_iq16_batch_dev: pointer/stride not 4-byte aligned");
+    for (int b = first; b < first + nblocks; b++)
+        if ((rc = front_begin(a, b)) != KG_OK) return rc;
+    rc = launch_frontend<SRC_IQ16>(a, a->fstream, (const uint8_t *) d_iq, stride_bytes, nblocks, 0, 0,
+                                   a->d_td + (size_t) first * FFT_LEN, a->d_fsub + (size_t) first * FFT_LEN,
+                                   a->d_data + (size_t) first * FFT_LEN, FFT_LEN, 0);
+    if (rc) return rc;
+    for (int b = first; b < first + nblocks; b++)
+        if ((rc = front_end(a, b)) != KG_OK) return rc;
+    return KG_OK;
 }
 
 int kg_acq_sample_iq16(kg_acq *a, int block, const int16_t *iq)
@@ -518,7 +744,7 @@ int kg_acq_sample_iq16(kg_acq *a, int block, const int16_t *iq)
     int rc = check_block(a, block, iq, "kg_acq_sample_iq16");
     if (rc) return rc;
     uint8_t *stage = a->d_in + IN_STRIDE * block;
-    KG_HIP(hipMemcpyAsync(stage, iq, (size_t) NSAMPLES * 4, hipMemcpyHostToDevice, a->ctx->stream));
+    KG_HIP(hipMemcpyAsync(stage, iq, (size_t) NSAMPLES * 4, hipMemcpyHostToDevice, a->fstream));
     return kg_acq_sample_iq16_dev(a, block, stage);
 }
 
@@ -527,10 +753,12 @@ int kg_acq_set_data_fft(kg_acq *a, int block, const float *data_fft)
     int rc = check_block(a, block, data_fft, "kg_acq_set_data_fft");
     if (rc) return rc;
     std::vector<float2> pl;
-    to_planes(data_fft, pl);
-    KG_HIP(hipMemcpyAsync(a->d_data + (size_t) block * FFT_LEN, pl.data(), sizeof(f2) * FFT_LEN,
-                          hipMemcpyHostToDevice, a->ctx->stream));
-    KG_HIP(hipStreamSynchronize(a->ctx->stream));
+    to_planes(data_fft, pl, 0);
+    if ((rc = front_begin(a, block)) != KG_OK) return rc;
+    KG_HIP(hipMemcpyAsync(a->d_data + (size_t) block * FFT_LEN, pl.data(), sizeof(float2) * FFT_LEN,
+                          hipMemcpyHostToDevice, a->fstream));
+    if ((rc = front_end(a, block)) != KG_OK) return rc;
+    KG_HIP(hipStreamSynchronize(a->fstream));
     return KG_OK;
 }
 
@@ -538,68 +766,113 @@ int kg_acq_get_data_fft(kg_acq *a, int block, float *data_fft)
 {
     int rc = check_block(a, block, data_fft, "kg_acq_get_data_fft");
     if (rc) return rc;
-    return get_planes(a, a->d_data + (size_t) block * FFT_LEN, data_fft);
+    return get_planes(a, a->d_data + (size_t) block * FFT_LEN, data_fft, 0);
 }
 
 int kg_acq_get_data_td(kg_acq *a, int block, float *td)
 {
     int rc = check_block(a, block, td, "kg_acq_get_data_td");
     if (rc) return rc;
-    KG_HIP(hipMemcpyAsync(td, a->d_td + (size_t) block * FFT_LEN, sizeof(f2) * FFT_LEN, hipMemcpyDeviceToHost, a->ctx->stream));
+    KG_HIP(hipStreamSynchronize(a->fstream));
+    KG_HIP(hipMemcpyAsync(td, a->d_td + (size_t) block * FFT_LEN, sizeof(float2) * FFT_LEN, hipMemcpyDeviceToHost, a->ctx->stream));
     KG_HIP(hipStreamSynchronize(a->ctx->stream));
     return KG_OK;
 }
 
-int kg_acq_correlate_async(kg_acq *a, int nblocks, const int *sats, int nsats)
+int kg_acq_correlate_blocks_async(kg_acq *a, int first, int nblocks, const int *sats, int nsats)
 {
     KG_REQUIRE(a && sats, KG_ERR_INVALID, "kg_acq_correlate_async: null argument");
     int rc = kg_ctx_use(a->ctx);
     if (rc) return rc;
-    KG_REQUIRE(nblocks >= 1 && nblocks <= a->max_blocks, KG_ERR_INVALID,
-               "kg_acq_correlate_async: nblocks %d (max %d)", nblocks, a->max_blocks);
+    KG_REQUIRE(nblocks >= 1 && first >= 0 && first + nblocks <= a->max_blocks, KG_ERR_INVALID,
+               "kg_acq_correlate_async: blocks %d..%d (max %d)", first, first + nblocks - 1,
+               a->max_blocks);
     KG_REQUIRE(nsats >= 1 && nsats <= a->max_sats, KG_ERR_INVALID,
                "kg_acq_correlate_async: nsats %d (max %d)", nsats, a->max_sats);
     hipStream_t st = a->ctx->stream;
-    bool same = (int) a->last_sats.size() == nsats;
+    // the tables hold block indices relative to `first` (the kernel gets data + first)
+    bool same = (int) a->last_sats.size() == nsats && a->table_nblocks == nblocks;
     for (int i = 0; same && i < nsats; i++) same = a->last_sats[i] == sats[i];
     if (!same) {
-        std::vector<int> s1, s4;
+        // (block, SV) pairs are dealt to the 8 XCD groups round-robin; a pair's
+        // ndop cells stay together.  Separate tables for the 4092-window (C/A)
+        // and the 16368-window (E1B) kernels.
+        std::vector<acq_cell_desc> tabs[2][8];
+        int np[2] = {0, 0};
+        a->nsel1 = a->nsel4 = 0;
         for (int i = 0; i < nsats; i++) {
             KG_REQUIRE(sats[i] >= 0 && sats[i] < a->max_sats, KG_ERR_INVALID,
                        "kg_acq_correlate_async: sats[%d] = %d out of range", i, sats[i]);
             KG_REQUIRE(a->code_set[sats[i]], KG_ERR_STATE,
                        "kg_acq_correlate_async: no code set for sat %d", sats[i]);
-            (a->limits[sats[i]] <= SUB ? s1 : s4).push_back(i);
+            (a->limits[sats[i]] <= SUB ? a->nsel1 : a->nsel4)++;
         }
-        // the previous launch may still be reading the lists
+        for (int blk = 0; blk < nblocks; blk++)
+            for (int i = 0; i < nsats; i++) {
+                const int sat = sats[i], w = a->limits[sat] <= SUB ? 0 : 1;
+                std::vector<acq_cell_desc> &v = tabs[w][np[w]++ & 7];
+                for (int di = 0; di < a->ndop; di++) {
+                    acq_cell_desc ds = {};
+                    ds.data_off = blk * FFT_LEN;
+                    ds.code_off = (int) (sat * a->code_len);
+                    ds.dop = a->dop_lo + di;
+                    ds.limit = a->limits[sat];
+                    ds.out = (blk * nsats + i) * a->ndop + di;
+                    v.push_back(ds);
+                }
+            }
+        // the previous launch may still be reading the tables
         KG_HIP(hipStreamSynchronize(st));
-        KG_HIP(hipMemcpy(a->d_sats, sats, sizeof(int) * nsats, hipMemcpyHostToDevice));
-        if (!s1.empty()) KG_HIP(hipMemcpy(a->d_sel1, s1.data(), sizeof(int) * s1.size(), hipMemcpyHostToDevice));
-        if (!s4.empty()) KG_HIP(hipMemcpy(a->d_sel4, s4.data(), sizeof(int) * s4.size(), hipMemcpyHostToDevice));
-        a->nsel1 = (int) s1.size(); a->nsel4 = (int) s4.size();
+        for (int w = 0; w < 2; w++) {
+            std::vector<acq_cell_desc> flat;
+            int starts[9];
+            for (int x = 0; x < 8; x++) {
+                starts[x] = (int) flat.size();
+                flat.insert(flat.end(), tabs[w][x].begin(), tabs[w][x].end());
+            }
+            starts[8] = (int) flat.size();
+            KG_HIP(hipMemcpy(w ? a->d_xcd4 : a->d_xcd1, starts, sizeof starts, hipMemcpyHostToDevice));
+            if (!flat.empty())
+                KG_HIP(hipMemcpy(w ? a->d_table4 : a->d_table1, flat.data(),
+                                 sizeof(acq_cell_desc) * flat.size(), hipMemcpyHostToDevice));
+        }
         a->last_sats.assign(sats, sats + nsats);
+        a->table_nblocks = nblocks;
     }
-    const f2 *t4 = (const f2 *) a->ctx->d_tab4096, *t16 = (const f2 *) a->ctx->d_tab16384;
+    for (int b = first; b < first + nblocks; b++)       // RAW: the blocks' front ends
+        if (a->has_ready[b]) KG_HIP(hipStreamWaitEvent(st, a->ev_ready[b], 0));
+    const float2 *t4 = a->ctx->d_tab4096, *t16 = a->ctx->d_tab16384;
     if (a->nsel1 > 0) {
-        hipLaunchKernelGGL(acq_correlate_kernel<1>, dim3(a->grid1), dim3(256), 0, st,
-                           (const f2 *) a->d_data, (const f2 *) a->d_code, t4, t16,
-                           (const int *) a->d_sats, (const int *) a->d_sel1, (const int *) a->d_limits,
-                           a->nsel1, nsats, nblocks, a->dop_lo, a->ndop, a->d_cells);
+        hipLaunchKernelGGL((acq_correlate_kernel<1, true>), dim3(a->grid1), dim3(256), ACQ_LDS_BYTES, st,
+                           (const float2 *) (a->d_data + (size_t) first * FFT_LEN),
+                           (const float2 *) a->d_code, t4, t16,
+                           (const acq_cell_desc *) a->d_table1, (const int *) a->d_xcd1, a->halo,
+                           a->d_cells, (unsigned long long *) nullptr);
         KG_HIP(hipGetLastError());
     }
     if (a->nsel4 > 0) {
-        hipLaunchKernelGGL(acq_correlate_kernel<4>, dim3(a->grid4), dim3(256), 0, st,
-                           (const f2 *) a->d_data, (const f2 *) a->d_code, t4, t16,
-                           (const int *) a->d_sats, (const int *) a->d_sel4, (const int *) a->d_limits,
-                           a->nsel4, nsats, nblocks, a->dop_lo, a->ndop, a->d_cells);
+        hipLaunchKernelGGL((acq_correlate_kernel<4, false>), dim3(a->grid4), dim3(256), ACQ_LDS_BYTES, st,
+                           (const float2 *) (a->d_data + (size_t) first * FFT_LEN),
+                           (const float2 *) a->d_code, t4, t16,
+                           (const acq_cell_desc *) a->d_table4, (const int *) a->d_xcd4, a->halo,
+                           a->d_cells, (unsigned long long *) nullptr);
         KG_HIP(hipGetLastError());
     }
     const int npairs = nblocks * nsats;
-    hipLaunchKernelGGL(acq_select_kernel, dim3((npairs + 63) / 64), dim3(64), 0, st,
+    hipLaunchKernelGGL(acq_select_kernel, dim3(npairs), dim3(64), 0, st,
                        (const kg_acq_cell *) a->d_cells, npairs, a->dop_lo, a->ndop, a->d_results);
     KG_HIP(hipGetLastError());
-    a->last_nblocks = nblocks; a->last_nsats = nsats;
+    for (int b = first; b < first + nblocks; b++) {
+        KG_HIP(hipEventRecord(a->ev_done[b], st));
+        a->has_done[b] = 1;
+    }
+    a->last_first = first; a->last_nblocks = nblocks; a->last_nsats = nsats;
     return KG_OK;
+}
+
+int kg_acq_correlate_async(kg_acq *a, int nblocks, const int *sats, int nsats)
+{
+    return kg_acq_correlate_blocks_async(a, 0, nblocks, sats, nsats);
 }
 
 int kg_acq_fetch(kg_acq *a, kg_acq_result *results, kg_acq_cell *cells)
@@ -626,5 +899,51 @@ int kg_acq_correlate(kg_acq *a, int nblocks, const int *sats, int nsats, kg_acq_
 }
 
 void *kg_acq_results_dev(kg_acq *a) { return a ? (void *) a->d_results : nullptr; }
+
+int kg_acq_debug_corr_stamps(kg_acq *a, int nblocks, const int *sats, int nsats,
+                             unsigned long long *stamps, int n)
+{
+    KG_REQUIRE(a && stamps && n >= 16 + 16 * 24, KG_ERR_INVALID, "kg_acq_debug_corr_stamps: need 400 slots");
+    int rc = kg_acq_correlate_async(a, nblocks, sats, nsats);      // builds the lists, warms up
+    if (rc) return rc;
+    KG_REQUIRE(a->nsel1 > 0, KG_ERR_STATE, "kg_acq_debug_corr_stamps: no C/A SV in the list");
+    hipStream_t st = a->ctx->stream;
+    unsigned long long *d = nullptr;
+    const size_t bytes = sizeof(unsigned long long) * (16 + 16 * 24);
+    KG_HIP(hipMalloc((void **) &d, bytes));
+    KG_HIP(hipMemset(d, 0, bytes));
+    KG_HIP(hipFuncSetAttribute((const void *) acq_correlate_kernel<1, true, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, ACQ_LDS_BYTES));
+    hipLaunchKernelGGL((acq_correlate_kernel<1, true, true>), dim3(a->grid1), dim3(256), ACQ_LDS_BYTES, st,
+                       (const float2 *) a->d_data, (const float2 *) a->d_code, a->ctx->d_tab4096,
+                       a->ctx->d_tab16384, (const acq_cell_desc *) a->d_table1,
+                       (const int *) a->d_xcd1, a->halo, a->d_cells, d);
+    KG_HIP(hipGetLastError());
+    KG_HIP(hipStreamSynchronize(st));
+    KG_HIP(hipMemcpy(stamps, d, bytes, hipMemcpyDeviceToHost));
+    KG_HIP(hipFree(d));
+    return KG_OK;
+}
+
+int kg_acq_debug_fft_stamps(kg_acq *a, int block, unsigned long long *stamps, int n)
+{
+    int rc = check_block(a, block, stamps, "kg_acq_debug_fft_stamps");
+    if (rc) return rc;
+    KG_REQUIRE(n >= 4, KG_ERR_INVALID, "kg_acq_debug_fft_stamps: need room for 4 stamps");
+    kg_ctx *c = a->ctx;
+    unsigned long long *d = nullptr;
+    KG_HIP(hipMalloc((void **) &d, 8 * sizeof(unsigned long long)));
+    KG_HIP(hipStreamSynchronize(a->fstream));
+    for (int rep = 0; rep < 3; rep++) {       // last repetition is the warm one
+        hipLaunchKernelGGL(acq_fft_sub_kernel<true>, dim3(4, 1), dim3(256), 2 * SUB * sizeof(float2),
+                           c->stream, (const float2 *) (a->d_td + (size_t) block * FFT_LEN),
+                           a->d_fsub + (size_t) block * FFT_LEN, (const float2 *) c->d_tab4096, d);
+        KG_HIP(hipGetLastError());
+        KG_HIP(hipStreamSynchronize(c->stream));
+    }
+    KG_HIP(hipMemcpy(stamps, d, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    KG_HIP(hipFree(d));
+    return KG_OK;
+}
 
 }  // extern "C"

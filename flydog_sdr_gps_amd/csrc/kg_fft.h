@@ -2,150 +2,295 @@
 //
 // 4096-point transform by one 256-thread group: 16 points per thread, three
 // radix-16 passes (Stockham autosort, natural order in -> natural order out),
-// two exchanges through a 32 KiB LDS tile.  The tile is XOR-swizzled
-// (P(e) = e ^ ((e >> 4) & 15)) so that every ds_write_b64 (16-lane groups,
-// 32 banks) and ds_read_b64 (32-lane groups, 64 banks) of the three passes is
-// bank-conflict free with no padding (checked exhaustively in
-// tools/proto_fft.py).
+// two exchanges through two 32 KiB LDS tiles used alternately, so one
+// workgroup barrier per exchange is enough (the tile being written was last
+// read two barriers ago).  The tiles are XOR-swizzled (P(e) = e ^ ((e>>4)&15)):
+// every ds_write_b64 (16-lane groups, 32 banks) and ds_read_b64 (32-lane
+// groups, 64 banks) of the three passes is bank-conflict free with no padding
+// (checked exhaustively in tools/proto_fft.py; SQ_LDS_BANK_CONFLICT = 0 on
+// hardware, profiles/).
+//
+// Arithmetic: a complex value is one 64-bit VGPR pair and every operation is a
+// packed v_pk_{add,mul,fma}_f32.  A wave issues one VALU instruction per four
+// cycles, a packed one keeps its SIMD-32 busy for all four, so a single wave
+// can saturate the SIMD -- which matters because the kernels built on this run
+// at two waves per SIMD.  hipcc folds broadcasts into op_sel but materialises
+// the swap-and-negate of a complex product / of a multiplication by +-j with
+// v_xor + v_mov; those two patterns are therefore written as inline asm with
+// op_sel / neg_lo / neg_hi modifiers (plain VALU: no manual wait states needed).
+// The library is built with -ffp-contract=off (every fused multiply-add is
+// explicit) and -fno-slp-vectorize.
 //
 // 16384 points = 4 x 4096 over the index residue mod 4 (callers combine the
 // four sub-transforms with a radix-4 step; see kg_acq.hip).
-//
-// The whole library is compiled with -ffp-contract=off: every fused
-// multiply-add below is explicit.
 #pragma once
 
 #include <hip/hip_runtime.h>
 #include "kg_tables.h"
 
-typedef float f2 __attribute__((ext_vector_type(2)));   // (re, im)
+typedef float cf __attribute__((ext_vector_type(2)));   // (re, im) = float2 = fftwf_complex
 
 #define KG_DEV __device__ __forceinline__
 
-KG_DEV f2 kg_splat(float v) { return f2{v, v}; }
+KG_DEV cf kg_scale(cf a, float s) { return a * cf{s, s}; }
+KG_DEV cf kg_ld(const float2 *p) { return *reinterpret_cast<const cf *>(p); }
+KG_DEV void kg_st(float2 *p, cf v) { *reinterpret_cast<cf *>(p) = v; }
 
-// a * w
-KG_DEV f2 kg_cmul(f2 a, f2 w)
+// a * w = (a.x w.x - a.y w.y, a.y w.x + a.x w.y)
+KG_DEV cf kg_cmul(cf a, cf w)
 {
-    f2 r = a * kg_splat(w.x);
-    return __builtin_elementwise_fma(f2{-a.y, a.x}, kg_splat(w.y), r);
+    cf r, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]"
+        : "=v"(d) : "v"(a), "v"(w), "v"(r));
+    return d;
 }
-// a * conj(w)
-KG_DEV f2 kg_cmulc(f2 a, f2 w)
+// a * conj(w) = (a.x w.x + a.y w.y, a.y w.x - a.x w.y)
+KG_DEV cf kg_cmulc(cf a, cf w)
 {
-    f2 r = a * kg_splat(w.x);
-    return __builtin_elementwise_fma(f2{a.y, -a.x}, kg_splat(w.y), r);
+    cf r, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]"
+        : "=v"(d) : "v"(a), "v"(w), "v"(r));
+    return d;
+}
+// the same with w wave-uniform (an SGPR pair: compile-time or s_load'ed constants)
+KG_DEV cf kg_cmul_s(cf a, cf w)
+{
+    cf r, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "s"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]"
+        : "=v"(d) : "v"(a), "s"(w), "v"(r));
+    return d;
+}
+KG_DEV cf kg_cmulc_s(cf a, cf w)
+{
+    cf r, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "s"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]"
+        : "=v"(d) : "v"(a), "s"(w), "v"(r));
+    return d;
+}
+// a + j b = (a.x - b.y, a.y + b.x)
+KG_DEV cf kg_addj(cf a, cf b)
+{
+    cf d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// a - j b = (a.x + b.y, a.y - b.x)
+KG_DEV cf kg_subj(cf a, cf b)
+{
+    cf d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
 }
 // a * w (SIGN > 0) or a * conj(w) (SIGN < 0): tables hold exp(+i...)
-template <int SIGN> KG_DEV f2 kg_twmul(f2 a, f2 w)
+template <int SIGN> KG_DEV cf kg_twmul(cf a, cf w)
 {
     return SIGN > 0 ? kg_cmul(a, w) : kg_cmulc(a, w);
 }
-// (SIGN*j) * a
-template <int SIGN> KG_DEV f2 kg_mulj(f2 a)
+template <int SIGN> KG_DEV cf kg_twmul_s(cf a, cf w)
 {
-    return SIGN > 0 ? f2{-a.y, a.x} : f2{a.y, -a.x};
+    return SIGN > 0 ? kg_cmul_s(a, w) : kg_cmulc_s(a, w);
 }
+// a + (SIGN*j) b,  a - (SIGN*j) b
+template <int SIGN> KG_DEV cf kg_add_sj(cf a, cf b) { return SIGN > 0 ? kg_addj(a, b) : kg_subj(a, b); }
+template <int SIGN> KG_DEV cf kg_sub_sj(cf a, cf b) { return SIGN > 0 ? kg_subj(a, b) : kg_addj(a, b); }
 
-// y_c = sum_a x_a (SIGN*j)^(a*c)
-template <int SIGN> KG_DEV void kg_radix4(f2 &x0, f2 &x1, f2 &x2, f2 &x3)
+// y_c = sum_a x_a (SIGN*j)^(a*c).  X2J: x2 still has to be multiplied by SIGN*j
+// (the W16^4 twiddle of the radix-16, folded into this butterfly's first adds).
+template <int SIGN, bool X2J = false> KG_DEV void kg_radix4(cf &x0, cf &x1, cf &x2, cf &x3)
 {
-    f2 s02 = x0 + x2, d02 = x0 - x2;
-    f2 s13 = x1 + x3, d13 = x1 - x3;
-    f2 jd = kg_mulj<SIGN>(d13);
+    const cf s02 = X2J ? kg_add_sj<SIGN>(x0, x2) : x0 + x2;
+    const cf d02 = X2J ? kg_sub_sj<SIGN>(x0, x2) : x0 - x2;
+    const cf s13 = x1 + x3, d13 = x1 - x3;
     x0 = s02 + s13;
-    x1 = d02 + jd;
+    x1 = kg_add_sj<SIGN>(d02, d13);
     x2 = s02 - s13;
-    x3 = d02 - jd;
+    x3 = kg_sub_sj<SIGN>(d02, d13);
 }
 
-template <int SIGN, int K> KG_DEV f2 kg_w16mul(f2 a)
+template <int SIGN, int K> KG_DEV cf kg_w16mul(cf a)
 {
-    if constexpr (K == 0) return a;
-    else if constexpr (K == 4) return kg_mulj<SIGN>(a);
-    else {
-        const f2 w = f2{KG_W16[K][0], KG_W16[K][1]};
-        return kg_twmul<SIGN>(a, w);
-    }
+    return kg_twmul_s<SIGN>(a, cf{KG_W16[K][0], KG_W16[K][1]});
 }
 
-// In: x[j].  Out: y[m] = sum_j x[j] * exp(SIGN*2*pi*i*j*m/16).
-template <int SIGN> KG_DEV void kg_radix16(f2 (&x)[16], f2 (&y)[16])
+// In: x[j].  Out: y[m] = sum_j x[j] * exp(SIGN*2*pi*i*j*m/16).   80 packed instructions.
+template <int SIGN> KG_DEV void kg_radix16(cf (&x)[16], cf (&y)[16])
 {
-    // stage 1: over a, for each b (j = 4a + b); result u_b[c] lands in x[4c + b]
+    // stage 1: over a, for each b (j = 4a + b); u_b[c] lands in x[4c + b]
 #pragma unroll
     for (int b = 0; b < 4; b++) kg_radix4<SIGN>(x[b], x[4 + b], x[8 + b], x[12 + b]);
-    // twiddle u_b[c] *= W16^(b*c)
+    // u_b[c] *= W16^(b*c)   (b*c = 4 is folded into stage 2)
     x[5]  = kg_w16mul<SIGN, 1>(x[5]);
     x[6]  = kg_w16mul<SIGN, 2>(x[6]);
     x[7]  = kg_w16mul<SIGN, 3>(x[7]);
     x[9]  = kg_w16mul<SIGN, 2>(x[9]);
-    x[10] = kg_w16mul<SIGN, 4>(x[10]);
     x[11] = kg_w16mul<SIGN, 6>(x[11]);
     x[13] = kg_w16mul<SIGN, 3>(x[13]);
     x[14] = kg_w16mul<SIGN, 6>(x[14]);
     x[15] = kg_w16mul<SIGN, 9>(x[15]);
     // stage 2: over b, for each c; Y[c + 4d] lands in x[4c + d]
-#pragma unroll
-    for (int c = 0; c < 4; c++) kg_radix4<SIGN>(x[4 * c], x[4 * c + 1], x[4 * c + 2], x[4 * c + 3]);
+    kg_radix4<SIGN>(x[0], x[1], x[2], x[3]);
+    kg_radix4<SIGN>(x[4], x[5], x[6], x[7]);
+    kg_radix4<SIGN, true>(x[8], x[9], x[10], x[11]);
+    kg_radix4<SIGN>(x[12], x[13], x[14], x[15]);
 #pragma unroll
     for (int m = 0; m < 16; m++) y[m] = x[4 * (m & 3) + (m >> 2)];
 }
 
-// Per-thread inter-pass twiddles of the 4096-point transform, thread t of 256:
-//   tw1[j-1] = exp(+2*pi*i * j*(t&15) / 256),  tw2[j-1] = exp(+2*pi*i * j*t / 4096)
-// taken from a table tab4096[k] = exp(+2*pi*i*k/4096) whose entries are the
-// fp32 roundings of double-precision values (host-built, HBM/L2 resident).
-struct kg_tw4096 {
-    f2 tw1[15];
-    f2 tw2[15];
-};
+// Inter-pass twiddles of the 4096-point transform for thread t of 256: pass 1
+// needs W256^(j*(t&15)), pass 2 W4096^(j*t), j = 1..15, all held in registers
+// (60 VGPRs) for the life of the kernel.  Values come from
+// tab4096[k] = exp(+2*pi*i*k/4096) (fp32 roundings of double-precision values,
+// host-built, L2 resident).
+struct kg_tw15 { cf w[15]; };
+struct kg_tw4096 { kg_tw15 p1, p2; };
 
-KG_DEV void kg_tw4096_load(kg_tw4096 &tw, const f2 *__restrict__ tab4096, int t)
+KG_DEV void kg_tw4096_load(kg_tw4096 &tw, const float2 *__restrict__ tab4096, int t)
 {
 #pragma unroll
     for (int j = 1; j < 16; j++) {
-        tw.tw1[j - 1] = tab4096[(j * (t & 15)) << 4];
-        tw.tw2[j - 1] = tab4096[j * t];
+        tw.p1.w[j - 1] = kg_ld(&tab4096[(j * (t & 15)) << 4]);
+        tw.p2.w[j - 1] = kg_ld(&tab4096[j * t]);
     }
 }
 
+template <int SIGN> KG_DEV void kg_twiddle16(cf (&x)[16], const kg_tw15 &w)
+{
+#pragma unroll
+    for (int j = 1; j < 16; j++) x[j] = kg_twmul<SIGN>(x[j], w.w[j - 1]);
+}
+
 // 4096-point transform of x (thread t holds X[t + 256 j], j = 0..15) by a
-// 256-thread group sharing the 4096-element LDS tile `lds`.
+// 256-thread group sharing two 4096-element LDS tiles.
 // Out: y[m] = sum_k X[k] exp(SIGN*2*pi*i*k*n/4096) at n = t + 256 m.
-// Contains four __syncthreads(): every thread of the workgroup must call it
-// (groups of a larger workgroup run it in lockstep on their own tiles).
-template <int SIGN>
-KG_DEV void kg_subfft4096(f2 (&x)[16], f2 (&y)[16], f2 *lds, const kg_tw4096 &tw, int t)
+// Two __syncthreads(): every thread of the workgroup must call it.  Back-to-back
+// calls need no barrier in between (tileA is rewritten two barriers after its
+// last read).
+// Diagnostic stamp (s_memtime, shader cycles): exists only in STAMPS instantiations.
+#define KG_STAMP(on, ptr, i)                                                          \
+    do {                                                                              \
+        if (on) {                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                        \
+            if ((ptr) != nullptr) (ptr)[i] = __builtin_amdgcn_s_memtime();            \
+            __builtin_amdgcn_sched_barrier(0);                                        \
+        }                                                                             \
+    } while (0)
+
+// First half: passes 0 and 1, ends after the second barrier.
+template <int SIGN, bool STAMPS = false>
+KG_DEV void kg_subfft4096_a(cf (&x)[16], cf (&y)[16], float2 *tileA, float2 *tileB,
+                            const kg_tw4096 &tw, int t, unsigned long long *st = nullptr)
 {
     const int tl = t & 15, th = t >> 4;
+    const int rd = t ^ (th & 15);          // P(t + 256 j) = 256 j + (t ^ ((t >> 4) & 15))
     // pass 0 (no twiddles): out index 16 t + m
     kg_radix16<SIGN>(x, y);
-    __syncthreads();                       // previous user of the tile is done reading
-    {
-        f2 *w = lds + 16 * t;
+    KG_STAMP(STAMPS, st, 0);
 #pragma unroll
-        for (int m = 0; m < 16; m++) w[m ^ tl] = y[m];
-    }
+    for (int m = 0; m < 16; m++) kg_st(&tileA[16 * t + (m ^ tl)], y[m]);
+    KG_STAMP(STAMPS, st, 1);
     __syncthreads();
-    const f2 *r = lds + (t ^ (th & 15));   // P(t + 256 j) = 256 j + (t ^ ((t >> 4) & 15))
+    KG_STAMP(STAMPS, st, 2);
 #pragma unroll
-    for (int j = 0; j < 16; j++) x[j] = r[256 * j];
-    __syncthreads();
+    for (int j = 0; j < 16; j++) x[j] = kg_ld(&tileA[rd + 256 * j]);
+    if (STAMPS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    KG_STAMP(STAMPS, st, 3);
     // pass 1: twiddle W256^(j*(t&15)), out index (t>>4)*256 + (t&15) + 16 m
-#pragma unroll
-    for (int j = 1; j < 16; j++) x[j] = kg_twmul<SIGN>(x[j], tw.tw1[j - 1]);
+    kg_twiddle16<SIGN>(x, tw.p1);
     kg_radix16<SIGN>(x, y);
-    {
-        f2 *w = lds + th * 256;
+    KG_STAMP(STAMPS, st, 4);
 #pragma unroll
-        for (int m = 0; m < 16; m++) w[16 * m + (tl ^ m)] = y[m];
-    }
+    for (int m = 0; m < 16; m++) kg_st(&tileB[th * 256 + 16 * m + (tl ^ m)], y[m]);
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 16; j++) x[j] = r[256 * j];
-    // pass 2: twiddle W4096^(j*t), out index t + 256 m (kept in registers)
-#pragma unroll
-    for (int j = 1; j < 16; j++) x[j] = kg_twmul<SIGN>(x[j], tw.tw2[j - 1]);
-    kg_radix16<SIGN>(x, y);
+    KG_STAMP(STAMPS, st, 5);
 }
+
+// Second half: pass 2; y[m] is the output at n = t + 256 m.
+template <int SIGN, bool STAMPS = false>
+KG_DEV void kg_subfft4096_b(cf (&x)[16], cf (&y)[16], const float2 *tileB,
+                            const kg_tw4096 &tw, int t, unsigned long long *st = nullptr)
+{
+    const int rd = t ^ ((t >> 4) & 15);
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = kg_ld(&tileB[rd + 256 * j]);
+    if (STAMPS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    KG_STAMP(STAMPS, st, 6);
+    // pass 2: twiddle W4096^(j*t), out index t + 256 m (kept in registers)
+    kg_twiddle16<SIGN>(x, tw.p2);
+    kg_radix16<SIGN>(x, y);
+    KG_STAMP(STAMPS, st, 7);
+}
+
+template <int SIGN, bool STAMPS = false>
+KG_DEV void kg_subfft4096(cf (&x)[16], cf (&y)[16], float2 *tileA, float2 *tileB,
+                          const kg_tw4096 &tw, int t, unsigned long long *st = nullptr)
+{
+    kg_subfft4096_a<SIGN, STAMPS>(x, y, tileA, tileB, tw, t, st);
+    kg_subfft4096_b<SIGN, STAMPS>(x, y, tileB, tw, t, st);
+}
+
+// The same transform for kernels that run it once per workgroup (forward FFT of
+// a sample block, code-table build): one tile, one rolled radix-16 body, the
+// twiddles fetched per pass instead of being held (half the registers).
+// Three __syncthreads(); several 256-thread groups of a larger workgroup may
+// run it in lockstep, each on its own tile.
+template <int SIGN>
+KG_DEV void kg_subfft4096_once(cf (&x)[16], cf (&y)[16], float2 *tile,
+                               const float2 *__restrict__ tab4096, int t)
+{
+    const int tl = t & 15, th = t >> 4;
+    const int rd = t ^ (th & 15);
+#pragma unroll 1
+    for (int p = 0; p < 3; p++) {
+        if (p > 0) {
+            const int e = (p == 1) ? (t & 15) << 4 : t;
+            kg_tw15 w;
+#pragma unroll
+            for (int j = 1; j < 16; j++) w.w[j - 1] = kg_ld(&tab4096[(j * e) & 4095]);
+#pragma unroll
+            for (int j = 0; j < 16; j++) x[j] = kg_ld(&tile[rd + 256 * j]);
+            __syncthreads();               // everyone has read before anyone rewrites the tile
+            kg_twiddle16<SIGN>(x, w);
+        }
+        kg_radix16<SIGN>(x, y);
+        if (p == 0) {
+#pragma unroll
+            for (int m = 0; m < 16; m++) kg_st(&tile[16 * t + (m ^ tl)], y[m]);
+            __syncthreads();
+        } else if (p == 1) {
+#pragma unroll
+            for (int m = 0; m < 16; m++) kg_st(&tile[th * 256 + 16 * m + (tl ^ m)], y[m]);
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Wave64 all-reduce steps without the LDS crossbar (ds_bpermute): quad_perm for
+// lane^1 and lane^2, row_half_mirror / row_mirror for the 8- and 16-lane
+// levels (the value is already uniform below that level), v_permlane16_swap /
+// v_permlane32_swap (gfx950) across rows and halves.
+// kg_xchg<L>(v): the partner's value at butterfly level L (0..5).
+// ---------------------------------------------------------------------------
+template <int L> KG_DEV unsigned kg_xchg_u(unsigned v)
+{
+    if constexpr (L == 0) return (unsigned) __builtin_amdgcn_mov_dpp((int) v, 0xB1, 0xF, 0xF, true);
+    else if constexpr (L == 1) return (unsigned) __builtin_amdgcn_mov_dpp((int) v, 0x4E, 0xF, 0xF, true);
+    else if constexpr (L == 2) return (unsigned) __builtin_amdgcn_mov_dpp((int) v, 0x141, 0xF, 0xF, true);
+    else if constexpr (L == 3) return (unsigned) __builtin_amdgcn_mov_dpp((int) v, 0x140, 0xF, 0xF, true);
+    else if constexpr (L == 4) {
+        // rows (r0,r1,r2,r3) -> .x = (r0,r0,r2,r2), .y = (r1,r1,r3,r3): partner = the other one
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        const bool odd_row = (threadIdx.x >> 4) & 1;
+        return odd_row ? r[0] : r[1];
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        const bool hi = (threadIdx.x >> 5) & 1;
+        return hi ? r[0] : r[1];
+    }
+}
+template <int L> KG_DEV float kg_xchg(float v) { return __uint_as_float(kg_xchg_u<L>(__float_as_uint(v))); }
+template <int L> KG_DEV int kg_xchg(int v) { return (int) kg_xchg_u<L>((unsigned) v); }

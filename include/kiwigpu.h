@@ -117,6 +117,10 @@ int kg_acq_sample_bits_dev(kg_acq *acq, int block, const void *d_packed);
  * (i,q interleaved) at the FS/4 IF; mix by (-j)^n, then as Sample(). */
 int kg_acq_sample_iq16(kg_acq *acq, int block, const int16_t *iq);
 int kg_acq_sample_iq16_dev(kg_acq *acq, int block, const void *d_iq);
+/* nblocks consecutive blocks from one device array, block b at d_iq + b*stride_bytes:
+ * one launch set for all of them. */
+int kg_acq_sample_iq16_batch_dev(kg_acq *acq, int first_block, int nblocks, const void *d_iq,
+                                 size_t stride_bytes);
 /* Inject / read back Correlate()'s `data` argument (fwd_buf after Sample()),
  * FFT_LEN complex in natural bin order. */
 int kg_acq_set_data_fft(kg_acq *acq, int block, const float *data_fft);
@@ -125,8 +129,15 @@ int kg_acq_get_data_fft(kg_acq *acq, int block, float *data_fft);
 int kg_acq_get_data_td(kg_acq *acq, int block, float *td);
 
 /* Correlate() for nsats SVs x (dop_hi-dop_lo+1) bins x nblocks blocks
- * (blocks 0..nblocks-1), one launch.  Enqueue only. */
+ * (blocks 0..nblocks-1), one launch.  Enqueue only.
+ * Stream model: the kg_acq_sample_* front end of a block runs on a stream of
+ * its own and is ordered against the Correlate() launches that read that block
+ * by events, so alternating between two sets of blocks (kg_acq_correlate_
+ * blocks_async with first = 0 / B) overlaps Sample() of the next set with
+ * Correlate() of the current one. */
 int kg_acq_correlate_async(kg_acq *acq, int nblocks, const int *sats, int nsats);
+int kg_acq_correlate_blocks_async(kg_acq *acq, int first_block, int nblocks, const int *sats,
+                                  int nsats);
 /* Wait and copy out.  results[nblocks*nsats] (block-major), cells may be NULL
  * or [nblocks*nsats*ndop]. */
 int kg_acq_fetch(kg_acq *acq, kg_acq_result *results, kg_acq_cell *cells);
@@ -135,6 +146,16 @@ int kg_acq_correlate(kg_acq *acq, int block_count, const int *sats, int nsats,
                      kg_acq_result *results, kg_acq_cell *cells);
 /* Device pointer to the last launch's kg_acq_result array (for RCCL gathers). */
 void *kg_acq_results_dev(kg_acq *acq);
+
+/* Diagnostics: re-runs the 4096-point stage of the forward FFT of `block` in a
+ * stamped build of the kernel and returns 4 s_memrealtime readings (100 MHz):
+ * start, inputs + twiddles loaded, transform done, results stored. */
+int kg_acq_debug_fft_stamps(kg_acq *acq, int block, unsigned long long *stamps, int n);
+/* Diagnostics: one Correlate() launch in a stamped build; stamps[0..3] = kernel
+ * start/end (s_memtime cycles, s_memrealtime 100 MHz) of one workgroup, then 16
+ * s_memtime readings per 4096-point work item (24 items).  n >= 400. */
+int kg_acq_debug_corr_stamps(kg_acq *acq, int nblocks, const int *sats, int nsats,
+                             unsigned long long *stamps, int n);
 
 #ifdef __cplusplus
 }

@@ -36,6 +36,19 @@ def navstar_codes(searcher, oracle):
     return codes
 
 
+@pytest.fixture(scope="module")
+def navstar_codes_for(oracle):
+    def make(searcher, sat_list):
+        out = []
+        for sat in sat_list:
+            _, t1, t2, _ = sats.SATS[sat]
+            chips = prn.cacode(t1, t2)
+            searcher.set_code(sat, chips)
+            out.append(oracle.code_fft(chips))
+        return np.stack(out)
+    return make
+
+
 def test_code_table_matches_oracle(searcher, navstar_codes):
     for sat in (0, 8, 31):
         got = searcher.get_code_fft(sat)
@@ -230,4 +243,31 @@ def test_mixed_l1_e1b_batch(gpu_ctx, oracle):
     for pos, (w, c) in zip((0, 1, 3), ((w_e, c_e), (w_0, c_0), (w_e, c_e))):
         assert (int(res[0, pos]["dop"]), int(res[0, pos]["idx"])) == (w["dop"], w["idx"])
         check_cells(cells[0, pos], c)
+    s.close()
+
+
+def test_two_block_sets_pipelined(gpu_ctx, navstar_codes_for, oracle):
+    """Alternating block sets: Sample() of set B overlaps Correlate() of set A on the
+    library's two streams; results must be those of the right block every time."""
+    s = Searcher(gpu_ctx, max_blocks=4)
+    svs = [0, 2, 6, 10, 13]
+    codes = navstar_codes_for(s, svs)
+    iqs = [synth.config1_iq16(seed=200 + i, cn0_dbhz=45.0 + i) for i in range(6)]
+    wants = []
+    for iq in iqs:
+        w, _ = oracle.correlate_many(codes, oracle.sample_iq16(iq), [L1] * len(svs), nthreads=4)
+        wants.append(w)
+    got = []
+    for step in range(3):                       # steps use blocks {0,1}, {2,3}, {0,1}
+        first = (step & 1) * 2
+        for b in range(2):
+            s.sample_iq16(iqs[2 * step + b], block=first + b)
+        res, _ = s.correlate_many(svs, nblocks=2, want_cells=False, first_block=first)
+        got.append(res.copy())
+    for step in range(3):
+        for b in range(2):
+            w = wants[2 * step + b]
+            assert np.array_equal(got[step][b]["dop"], w["dop"])
+            assert np.array_equal(got[step][b]["idx"], w["idx"])
+            np.testing.assert_allclose(got[step][b]["snr"], w["snr"], rtol=3 * RTOL)
     s.close()
