@@ -37,8 +37,9 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
 def cpu_baseline(iq, chips_list, budget_s=12.0):
-    """The CPU oracle (kind "port": fp32 FFT, all host cores, pthread shard over SVs)
-    timed on the same configs[1] workload, repeated for about budget_s seconds."""
+    """The CPU oracle (kind "port": fp32 FFT, all host cores, pthread shard over the
+    32 x 41 (SV, Doppler) cells) timed on the same configs[1] workload, repeated for
+    about budget_s seconds."""
     from oracle import kiwi_oracle as ko
     ko.lib()
     cores = os.cpu_count() or 1
@@ -64,7 +65,7 @@ def cpu_baseline(iq, chips_list, budget_s=12.0):
         "cores": cores,
         "kind": "port",
         "sample": "%d x the full configs[1] step (Sample + 32 SV x 41 bins), oracle fp32 "
-                  "FFT, %d threads over SVs, %.1f s" % (reps, cores, el),
+                  "FFT, %d threads over (SV, Doppler) cells, %.1f s" % (reps, cores, el),
         "single_thread_value": round(NSAMPLES / t1 / 1e6, 4),
     }
 

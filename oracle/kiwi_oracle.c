@@ -313,38 +313,44 @@ void ko_sample_iq16(const int16_t *iq, ko_cpx *out, ko_cpx *td, int prec)
     free(buf);
 }
 
+/* one (SV, Doppler) cell of the search.cpp:465-496 loop body */
+static ko_acq_cell correlate_cell(const ko_cpx *code, const ko_cpx *data, int limit, int dop,
+                                  ko_cpx *prod, ko_cpx *rev, int prec)
+{
+    const int N = KO_FFT_LEN;
+    float max_pwr = 0, tot_pwr = 0;                       /* :466 */
+    int max_pwr_i = 0, i;
+    for (i = 0; i < N; i++) {                             /* :471 = :473-477, simd.cpp:39-67 */
+        int j = (i - dop + N) % N;
+        prod[i].re = data[i].re * code[j].re + data[i].im * code[j].im;
+        prod[i].im = data[i].re * code[j].im - data[i].im * code[j].re;
+    }
+    ko_fft(N, +1, prod, rev, prec);                       /* :481 */
+    for (i = 0; i < limit; i++) {                         /* :486-490 */
+        const float pwr = rev[i].re * rev[i].re + rev[i].im * rev[i].im;
+        if (pwr > max_pwr) { max_pwr = pwr; max_pwr_i = i; }
+        tot_pwr += pwr;
+    }
+    ko_acq_cell c;
+    const float ave_pwr = tot_pwr / i;                    /* :493 */
+    c.snr = max_pwr / ave_pwr;                            /* :494 */ c.max_pwr = max_pwr; c.tot_pwr = tot_pwr; c.idx = max_pwr_i;
+    return c;
+}
+
 /* gps/search.cpp:453-499 */
 ko_acq_result ko_correlate(const ko_cpx *code, const ko_cpx *data, int limit,
                            int dop_lo, int dop_hi, ko_acq_cell *cells, int prec)
 {
-    const int N = KO_FFT_LEN;
-    ko_cpx *prod = (ko_cpx *) malloc(sizeof(ko_cpx) * N);
-    ko_cpx *rev = (ko_cpx *) malloc(sizeof(ko_cpx) * N);
+    ko_cpx *prod = (ko_cpx *) malloc(sizeof(ko_cpx) * KO_FFT_LEN);    /* rev_buf, :58,:454 */
+    ko_cpx *rev = (ko_cpx *) malloc(sizeof(ko_cpx) * KO_FFT_LEN);
     ko_acq_result r = {0.0f, 0, 0, 0};
     float max_snr = 0;                                    /* :455 */
-    int dop, i;
+    int dop;
     for (dop = dop_lo; dop <= dop_hi; dop++) {            /* :465 */
-        float max_pwr = 0, tot_pwr = 0;                   /* :466 */
-        int max_pwr_i = 0;
-        for (i = 0; i < N; i++) {                         /* :471 = :473-477, simd.cpp:39-67 */
-            int j = (i - dop + N) % N;
-            prod[i].re = data[i].re * code[j].re + data[i].im * code[j].im;
-            prod[i].im = data[i].re * code[j].im - data[i].im * code[j].re;
-        }
-        ko_fft(N, +1, prod, rev, prec);                   /* :481 */
-        for (i = 0; i < limit; i++) {                     /* :486-490 */
-            const float pwr = rev[i].re * rev[i].re + rev[i].im * rev[i].im;
-            if (pwr > max_pwr) { max_pwr = pwr; max_pwr_i = i; }
-            tot_pwr += pwr;
-        }
-        const float ave_pwr = tot_pwr / i;                /* :493 */
-        const float snr = max_pwr / ave_pwr;              /* :494 */
-        if (cells) {
-            ko_acq_cell *c = &cells[dop - dop_lo];
-            c->snr = snr; c->max_pwr = max_pwr; c->tot_pwr = tot_pwr; c->idx = max_pwr_i;
-        }
-        if (snr > max_snr) {                              /* :495 */
-            max_snr = snr; r.dop = dop; r.idx = max_pwr_i; r.valid = 1;
+        const ko_acq_cell c = correlate_cell(code, data, limit, dop, prod, rev, prec);
+        if (cells) cells[dop - dop_lo] = c;
+        if (c.snr > max_snr) {                            /* :495 */
+            max_snr = c.snr; r.dop = dop; r.idx = c.idx; r.valid = 1;
         }
     }
     r.snr = max_snr;                                      /* :498 */
@@ -354,17 +360,24 @@ ko_acq_result ko_correlate(const ko_cpx *code, const ko_cpx *data, int limit,
 
 typedef struct {
     const ko_cpx *codes, *data; const int *limits; int nsv, dop_lo, dop_hi, prec;
-    ko_acq_result *out; ko_acq_cell *cells; int tid, nthreads;
+    ko_acq_cell *cells; int tid, nthreads;
 } many_arg;
 
+/* threads take (SV, Doppler) cells round-robin: all host cores stay busy even
+ * when there are fewer SVs than cores (the CPU-baseline "T_all" figure) */
 static void *many_worker(void *p)
 {
     many_arg *a = (many_arg *) p;
-    int nd = a->dop_hi - a->dop_lo + 1, s;
-    for (s = a->tid; s < a->nsv; s += a->nthreads)
-        a->out[s] = ko_correlate(a->codes + (size_t) s * KO_FFT_LEN, a->data, a->limits[s],
-                                 a->dop_lo, a->dop_hi,
-                                 a->cells ? a->cells + (size_t) s * nd : NULL, a->prec);
+    const int nd = a->dop_hi - a->dop_lo + 1, ncell = a->nsv * nd;
+    ko_cpx *prod = (ko_cpx *) malloc(sizeof(ko_cpx) * KO_FFT_LEN);
+    ko_cpx *rev = (ko_cpx *) malloc(sizeof(ko_cpx) * KO_FFT_LEN);
+    int c;
+    for (c = a->tid; c < ncell; c += a->nthreads) {
+        const int s = c / nd, di = c - s * nd;
+        a->cells[c] = correlate_cell(a->codes + (size_t) s * KO_FFT_LEN, a->data, a->limits[s],
+                                     a->dop_lo + di, prod, rev, a->prec);
+    }
+    free(prod); free(rev);
     return NULL;
 }
 
@@ -373,16 +386,32 @@ void ko_correlate_many(const ko_cpx *codes, int nsv, const ko_cpx *data,
                        ko_acq_result *out, ko_acq_cell *cells, int prec,
                        int nthreads)
 {
+    const int nd = dop_hi - dop_lo + 1;
     if (nthreads < 1) nthreads = 1;
-    if (nthreads > 64) nthreads = 64;
+    if (nthreads > 1024) nthreads = 1024;
+    if (nthreads > nsv * nd) nthreads = nsv * nd;
     { const cpxd *d; const ko_cpx *f; twiddles(KO_FFT_LEN, +1, &d, &f); }  /* warm cache */
-    pthread_t th[64]; many_arg args[64];
-    int t;
+    ko_acq_cell *cl = cells ? cells : (ko_acq_cell *) malloc(sizeof(ko_acq_cell) * (size_t) nsv * nd);
+    pthread_t *th = (pthread_t *) malloc(sizeof(pthread_t) * nthreads);
+    many_arg *args = (many_arg *) malloc(sizeof(many_arg) * nthreads);
+    int t, s, di;
     for (t = 0; t < nthreads; t++) {
-        many_arg a = { codes, data, limits, nsv, dop_lo, dop_hi, prec, out, cells, t, nthreads };
+        many_arg a = { codes, data, limits, nsv, dop_lo, dop_hi, prec, cl, t, nthreads };
         args[t] = a;
         if (t > 0) pthread_create(&th[t], NULL, many_worker, &args[t]);
     }
     many_worker(&args[0]);
     for (t = 1; t < nthreads; t++) pthread_join(th[t], NULL);
+    for (s = 0; s < nsv; s++) {                           /* search.cpp:455,495 */
+        ko_acq_result r = {0.0f, 0, 0, 0};
+        float max_snr = 0;
+        for (di = 0; di < nd; di++) {
+            const ko_acq_cell *c = &cl[(size_t) s * nd + di];
+            if (c->snr > max_snr) { max_snr = c->snr; r.dop = dop_lo + di; r.idx = c->idx; r.valid = 1; }
+        }
+        r.snr = max_snr;
+        out[s] = r;
+    }
+    if (!cells) free(cl);
+    free(th); free(args);
 }
