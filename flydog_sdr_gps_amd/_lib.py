@@ -29,6 +29,13 @@ class AcqCellC(C.Structure):
                 ("idx", C.c_int32)]
 
 
+class WfChanCfgC(C.Structure):
+    _fields_ = [("zoom", C.c_int32), ("window_func", C.c_int32), ("interp", C.c_int32),
+                ("cic_comp", C.c_int32), ("overlapped", C.c_int32), ("fft_used", C.c_int32),
+                ("plot_width", C.c_int32), ("plot_width_clamped", C.c_int32),
+                ("fft_offset", C.c_float)]
+
+
 result_dtype = np.dtype([("snr", "<f4"), ("dop", "<i4"), ("idx", "<i4"), ("valid", "<i4")])
 cell_dtype = np.dtype([("snr", "<f4"), ("max_pwr", "<f4"), ("tot_pwr", "<f4"), ("idx", "<i4")])
 
@@ -65,6 +72,13 @@ SYMBOLS = {
     "kg_acq_fetch": (_i, [_vp, _vp, _vp]),
     "kg_acq_correlate": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
     "kg_acq_results_dev": (_vp, [_vp]),
+    "kg_wf_create": (_i, [_vp, _i, C.POINTER(_vp)]),
+    "kg_wf_destroy": (None, [_vp]),
+    "kg_wf_set_tables": (_i, [_vp, _vp, _vp]),
+    "kg_wf_set_channel": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "kg_wf_frames_dev": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "kg_wf_frames": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "kg_wf_debug_frame": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "kg_acq_debug_fft_stamps": (_i, [_vp, _i, _vp, _i]),
     "kg_acq_debug_corr_stamps": (_i, [_vp, _i, _vp, _i, _vp, _i]),
 }

@@ -1,0 +1,377 @@
+// kg_wf.hip -- waterfall frames on gfx950.
+//
+// Replaces, for a batch of (channel, frame) pairs, the reference's
+//   sample_wf() unpack + window          rx/rx_waterfall.cpp:1049-1066
+//   compute_frame(): 8192-point FFT      :1291
+//                    power (+ CIC comp)  :1303-1351
+//                    FFT-bin -> pixel    :1400-1473  (MAX / MIN / LAST / DROP / CMA)
+//                    dB, clamp, u8       :1489-1554
+// One 256-thread workgroup per frame, persistent over the frame list.
+//
+// FFT: 8192 = 2 x 4096 (samples n = 2*n1 + g); only bins k < fft_used <= 4096 are
+// ever looked at (:756-763), so the radix-2 combine is pruned to
+//     X[k] = F0[k] + W_8192^{-k} * F1[k],   k < 4096
+// and the two 4096-point transforms run back to back in the same two LDS tiles
+// (kg_fft.h).  The power spectrum goes through LDS once (16 KiB, reusing tile A)
+// to turn the strided per-thread bins into the contiguous runs the pixel stage
+// walks.
+//
+// Pixel stage: the reference walks bins in ascending order and restarts a
+// pixel whenever the mapped bin changes (:1458-1478).  The host turns its
+// fft2wf_map[] into (first bin, count) runs per pixel -- for the reference's
+// monotone maps that is the same partition, and a pixel that is never reached
+// keeps pwr_out = 0 exactly as after the reference's memset (:1385).  Each
+// thread then reduces four adjacent pixels, walking each run in ascending bin
+// order, so MAX/MIN/LAST/CMA reproduce the serial loop's result bit for bit.
+#include "kg_common.h"
+#include "kg_fft.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#define WF_NFFT  8192        // rx/rx_waterfall.h:61-62
+#define WF_WIDTH 1024        // rx/rx_waterfall.h:65
+#define SUB      4096
+
+enum { WF_MAX = 0, WF_MIN, WF_LAST, WF_DROP, WF_CMA };    // rx/rx_waterfall.h:116
+enum { WINF_BLACKMAN_HARRIS = 2 };                         // rx/rx_waterfall.h:162
+
+// Per-channel state in HBM (what compute_frame() reads from wf_inst_t).
+struct wf_chan_dev {
+    int zoom, window_func, interp, comp_on, dc, fft_used, limit, pwc;
+    float fft_offset;
+    int pad[3];
+    unsigned short first[WF_WIDTH];     // run of bins of each pixel (DROP: the sampled bin)
+    unsigned short count[WF_WIDTH];
+    float scale[WF_WIDTH], scale_div2[WF_WIDTH];
+};
+
+#define WF_LDS_BYTES (2 * SUB * sizeof(float2))
+
+template <bool TAPS>
+__global__ __launch_bounds__(256, 2) void wf_frame_kernel(
+    const short2 *__restrict__ iq,            // [nframes][8192] iq_t {i, q}
+    const int *__restrict__ chan_of,          // [nframes]
+    const wf_chan_dev *__restrict__ chans,
+    const float *__restrict__ windows,        // [4][8192]
+    const float *__restrict__ cic_comp,       // [8192]
+    const float2 *__restrict__ tab4096, const float2 *__restrict__ tab8192,
+    int nframes,
+    unsigned char *__restrict__ out,          // [nframes][1024]
+    float *__restrict__ tap_pwr, float *__restrict__ tap_pwr_out, float *__restrict__ tap_db)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    float2 *tileA = smem, *tileB = smem + SUB;
+    float *pwr = (float *) smem;              // [4096], reuses tile A after the transforms
+    const int t = threadIdx.x;
+
+    kg_tw4096 tw;
+    kg_tw4096_load(tw, tab4096, t);
+    cf wc[16];                                // W_8192^{k}, k = t + 256 m
+#pragma unroll
+    for (int m = 0; m < 16; m++) wc[m] = kg_ld(&tab8192[t + 256 * m]);
+
+    for (int f = blockIdx.x; f < nframes; f += gridDim.x) {
+        const wf_chan_dev *ch = chans + chan_of[f];
+        const int interp = ch->interp, dc = ch->dc, comp_on = ch->comp_on;
+        const short4 *src = (const short4 *) (iq + (size_t) f * WF_NFFT);
+        const float2 *win = (const float2 *) (windows + (size_t) ch->window_func * WF_NFFT);
+
+        // sample_wf(): fi = (float)(s2_t)i * window[sn]  (:1054-1061), samples 2*n1, 2*n1+1
+        cf xa[16], xb[16], y0[16], y1[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const short4 s = src[t + 256 * j];
+            const float2 w = win[t + 256 * j];
+            xa[j] = cf{(float) s.x * w.x, (float) s.y * w.x};
+            xb[j] = cf{(float) s.z * w.y, (float) s.w * w.y};
+        }
+        kg_subfft4096<-1>(xa, y0, tileA, tileB, tw, t);
+        kg_subfft4096<-1>(xb, y1, tileA, tileB, tw, t);
+        __syncthreads();                      // tile A is about to become pwr[]
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const int k = t + 256 * m;
+            const cf X = y0[m] + kg_cmulc(y1[m], wc[m]);
+            float re = X.x, im = X.y;
+            if (comp_on) { const float c = cic_comp[k]; re = re * c; im = im * c; }   // :1342
+            float p = re * re + im * im;                                                // :1345
+            if (k < dc) p = 0.f;                                                        // :1304
+            pwr[k] = p;
+            if (TAPS && k < ch->fft_used) tap_pwr[(size_t) f * SUB + k] = p;
+        }
+        __syncthreads();
+
+        // pixels 4t .. 4t+3
+        unsigned bytes = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int px = 4 * t + u;
+            const int first = ch->first[px], cnt = ch->count[px];
+            float p = 0.f;                    // memset(pwr_out, 0), :1385
+            int avgs = 0;
+            if (interp == WF_DROP) {
+                if (px < ch->pwc) p = pwr[first];                                       // :1418
+            } else if (cnt > 0) {
+                p = pwr[first]; avgs = 1;                                               // :1468-1475
+                for (int i = 1; i < cnt; i++) {
+                    const float q = pwr[first + i];
+                    switch (interp) {                                                   // :1461-1466
+                    case WF_CMA:  p += q; avgs++; break;
+                    case WF_MAX:  if (q > p) p = q; break;
+                    case WF_MIN:  if (q < p) p = q; break;
+                    default:      p = q; break;                                         // WF_LAST
+                    }
+                }
+            }
+            float scale = ch->scale[px];
+            if (interp == WF_CMA)                                                        // :1499-1500
+                scale = (avgs == 1) ? scale : ((avgs == 2) ? ch->scale_div2[px] : scale / (float) avgs);
+            // dB = 10.0 * log10f(p*scale + 1e-30F) + fft_offset: the product and sum in
+            // float, the 10.0* and + in double, one rounding to float (:1507)
+            const float arg = p * scale + 1e-30f;
+            const float l = (float) log10((double) arg);
+            float dB = (float) (10.0 * (double) l + (double) ch->fft_offset);
+            if (TAPS) { tap_pwr_out[(size_t) f * WF_WIDTH + px] = p; tap_db[(size_t) f * WF_WIDTH + px] = dB; }
+            unsigned b;
+            if (dB != dB) {
+                b = 0;                        // (u1_t)(int)NaN: an untouched CMA pixel (0 * inf)
+            } else {
+                if (dB > 0.f) dB = 0.f;                                                  // :1543
+                if (dB < -200.0f) dB = -200.0f;
+                dB = dB - 1.0f;
+                b = (unsigned) ((int) dB) & 0xffu;                                       // :1546
+            }
+            bytes |= b << (8 * u);
+        }
+        ((unsigned *) (out + (size_t) f * WF_WIDTH))[t] = bytes;
+        __syncthreads();                      // pwr[] (tile A) is rewritten by the next frame
+    }
+}
+
+// ---------------------------------------------------------------------------
+struct kg_wf {
+    kg_ctx *ctx;
+    int nchan;
+    wf_chan_dev *d_chans;
+    float *d_windows, *d_cic;
+    int *d_chan_of;  int chan_of_cap;
+    short2 *d_iq;    unsigned char *d_out;  int stage_cap;      // staging for host-buffer calls
+    float *d_tap_pwr, *d_tap_pwr_out, *d_tap_db;
+    std::vector<char> chan_set;
+    bool tables_set;
+    int grid;
+};
+
+extern "C" {
+
+int kg_wf_create(kg_ctx *ctx, int nchan, kg_wf **out)
+{
+    int rc = kg_ctx_use(ctx);
+    if (rc) return rc;
+    KG_REQUIRE(out != nullptr, KG_ERR_INVALID, "kg_wf_create: out is null");
+    *out = nullptr;
+    KG_REQUIRE(nchan >= 1 && nchan <= 65536, KG_ERR_INVALID, "kg_wf_create: nchan %d", nchan);
+    kg_wf *w = new (std::nothrow) kg_wf();
+    KG_REQUIRE(w != nullptr, KG_ERR_NOMEM, "kg_wf_create: alloc");
+    w->ctx = ctx; w->nchan = nchan; w->tables_set = false;
+    w->chan_set.assign(nchan, 0);
+    w->d_chan_of = nullptr; w->chan_of_cap = 0;
+    w->d_iq = nullptr; w->d_out = nullptr; w->stage_cap = 0;
+    w->d_tap_pwr = w->d_tap_pwr_out = w->d_tap_db = nullptr;
+    KG_HIP(hipMalloc((void **) &w->d_chans, sizeof(wf_chan_dev) * nchan));
+    KG_HIP(hipMalloc((void **) &w->d_windows, sizeof(float) * 4 * WF_NFFT));
+    KG_HIP(hipMalloc((void **) &w->d_cic, sizeof(float) * WF_NFFT));
+    KG_HIP(hipFuncSetAttribute((const void *) wf_frame_kernel<false>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS_BYTES));
+    KG_HIP(hipFuncSetAttribute((const void *) wf_frame_kernel<true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS_BYTES));
+    int occ = 0;
+    KG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, wf_frame_kernel<false>, 256, WF_LDS_BYTES));
+    if (occ < 1) occ = 1;
+    w->grid = ctx->num_cus * occ;
+    *out = w;
+    return KG_OK;
+}
+
+void kg_wf_destroy(kg_wf *w)
+{
+    if (!w) return;
+    (void) hipSetDevice(w->ctx->device);
+    (void) hipStreamSynchronize(w->ctx->stream);
+    (void) hipFree(w->d_chans); (void) hipFree(w->d_windows); (void) hipFree(w->d_cic);
+    (void) hipFree(w->d_chan_of); (void) hipFree(w->d_iq); (void) hipFree(w->d_out);
+    (void) hipFree(w->d_tap_pwr); (void) hipFree(w->d_tap_pwr_out); (void) hipFree(w->d_tap_db);
+    delete w;
+}
+
+int kg_wf_set_tables(kg_wf *w, const float *windows, const float *cic_comp)
+{
+    KG_REQUIRE(w && windows && cic_comp, KG_ERR_INVALID, "kg_wf_set_tables: null argument");
+    int rc = kg_ctx_use(w->ctx);
+    if (rc) return rc;
+    hipStream_t st = w->ctx->stream;
+    KG_HIP(hipMemcpyAsync(w->d_windows, windows, sizeof(float) * 4 * WF_NFFT, hipMemcpyHostToDevice, st));
+    KG_HIP(hipMemcpyAsync(w->d_cic, cic_comp, sizeof(float) * WF_NFFT, hipMemcpyHostToDevice, st));
+    KG_HIP(hipStreamSynchronize(st));
+    w->tables_set = true;
+    return KG_OK;
+}
+
+int kg_wf_set_channel(kg_wf *w, int ch, const kg_wf_chan_cfg *cfg, const uint16_t *fft2wf_map,
+                      const uint16_t *drop_sample, const float *fft_scale, const float *fft_scale_div2)
+{
+    KG_REQUIRE(w && cfg && fft2wf_map && drop_sample && fft_scale && fft_scale_div2, KG_ERR_INVALID,
+               "kg_wf_set_channel: null argument");
+    int rc = kg_ctx_use(w->ctx);
+    if (rc) return rc;
+    KG_REQUIRE(ch >= 0 && ch < w->nchan, KG_ERR_INVALID, "kg_wf_set_channel: channel %d (0..%d)", ch, w->nchan - 1);
+    KG_REQUIRE(cfg->fft_used >= 1 && cfg->fft_used <= SUB, KG_ERR_INVALID,
+               "kg_wf_set_channel: fft_used %d (1..%d)", cfg->fft_used, SUB);
+    KG_REQUIRE(cfg->window_func >= 0 && cfg->window_func < 4, KG_ERR_INVALID,
+               "kg_wf_set_channel: window_func %d", cfg->window_func);
+    KG_REQUIRE(cfg->interp >= WF_MAX && cfg->interp <= WF_CMA, KG_ERR_INVALID,
+               "kg_wf_set_channel: interp %d", cfg->interp);
+    KG_REQUIRE(cfg->plot_width_clamped >= 0 && cfg->plot_width_clamped <= WF_WIDTH, KG_ERR_INVALID,
+               "kg_wf_set_channel: plot_width_clamped %d", cfg->plot_width_clamped);
+    // the only branch of compute_frame() this library implements (:1400); the other
+    // one reads the map index as power (:1584-1592) and is unreachable for FlyDog
+    KG_REQUIRE(cfg->fft_used >= cfg->plot_width, KG_ERR_INVALID,
+               "kg_wf_set_channel: fft_used %d < plot_width %d is not supported", cfg->fft_used, cfg->plot_width);
+    static thread_local wf_chan_dev h;
+    memset(&h, 0, sizeof h);
+    h.zoom = cfg->zoom; h.window_func = cfg->window_func; h.interp = cfg->interp;
+    h.comp_on = (cfg->zoom > 1 && cfg->cic_comp && !cfg->overlapped) ? 1 : 0;        // :1324,:1335
+    h.dc = (cfg->zoom == 0 && cfg->window_func == WINF_BLACKMAN_HARRIS) ? 4 : 2;     // :1303
+    h.fft_used = cfg->fft_used; h.pwc = cfg->plot_width_clamped; h.fft_offset = cfg->fft_offset;
+    // fft_used_limit: the first bin that maps outside the plot (:1433-1447)
+    int limit = cfg->fft_used;
+    for (int i = 0; i < cfg->fft_used; i++)
+        if (fft2wf_map[i] >= WF_WIDTH) { limit = i; break; }
+    h.limit = limit;
+    if (cfg->interp == WF_DROP) {
+        for (int i = 0; i < cfg->plot_width_clamped; i++) {
+            KG_REQUIRE(drop_sample[i] < SUB, KG_ERR_INVALID, "kg_wf_set_channel: drop_sample[%d] = %d", i, drop_sample[i]);
+            h.first[i] = drop_sample[i]; h.count[i] = 1;
+        }
+    } else {
+        int i = 0;
+        while (i < limit) {                   // maximal runs of equal mapped bin
+            const int bin = fft2wf_map[i];
+            int j = i + 1;
+            while (j < limit && fft2wf_map[j] == bin) j++;
+            h.first[bin] = (unsigned short) i;      // a later run of the same bin restarts it (:1468)
+            h.count[bin] = (unsigned short) (j - i);
+            i = j;
+        }
+    }
+    memcpy(h.scale, fft_scale, sizeof h.scale);
+    memcpy(h.scale_div2, fft_scale_div2, sizeof h.scale_div2);
+    hipStream_t st = w->ctx->stream;
+    KG_HIP(hipStreamSynchronize(st));         // frames in flight may read the old record
+    KG_HIP(hipMemcpy(w->d_chans + ch, &h, sizeof h, hipMemcpyHostToDevice));
+    w->chan_set[ch] = 1;
+    return KG_OK;
+}
+
+static int wf_launch(kg_wf *w, int nframes, const int32_t *chan_of, const void *d_iq, void *d_out, bool taps)
+{
+    KG_REQUIRE(w->tables_set, KG_ERR_STATE, "kg_wf_frames: kg_wf_set_tables was not called");
+    KG_REQUIRE(nframes >= 1, KG_ERR_INVALID, "kg_wf_frames: nframes %d", nframes);
+    for (int f = 0; f < nframes; f++) {
+        KG_REQUIRE(chan_of[f] >= 0 && chan_of[f] < w->nchan, KG_ERR_INVALID,
+                   "kg_wf_frames: chan_of[%d] = %d out of range", f, chan_of[f]);
+        KG_REQUIRE(w->chan_set[chan_of[f]], KG_ERR_STATE, "kg_wf_frames: channel %d is not configured", chan_of[f]);
+    }
+    hipStream_t st = w->ctx->stream;
+    if (nframes > w->chan_of_cap) {
+        KG_HIP(hipStreamSynchronize(st));
+        (void) hipFree(w->d_chan_of);
+        KG_HIP(hipMalloc((void **) &w->d_chan_of, sizeof(int) * nframes));
+        w->chan_of_cap = nframes;
+    }
+    KG_HIP(hipMemcpyAsync(w->d_chan_of, chan_of, sizeof(int) * nframes, hipMemcpyHostToDevice, st));
+    const int grid = nframes < w->grid ? nframes : w->grid;
+    if (!taps) {
+        hipLaunchKernelGGL(wf_frame_kernel<false>, dim3(grid), dim3(256), WF_LDS_BYTES, st,
+                           (const short2 *) d_iq, (const int *) w->d_chan_of, (const wf_chan_dev *) w->d_chans,
+                           (const float *) w->d_windows, (const float *) w->d_cic,
+                           (const float2 *) w->ctx->d_tab4096, (const float2 *) w->ctx->d_tab8192, nframes,
+                           (unsigned char *) d_out, (float *) nullptr, (float *) nullptr, (float *) nullptr);
+    } else {
+        hipLaunchKernelGGL(wf_frame_kernel<true>, dim3(grid), dim3(256), WF_LDS_BYTES, st,
+                           (const short2 *) d_iq, (const int *) w->d_chan_of, (const wf_chan_dev *) w->d_chans,
+                           (const float *) w->d_windows, (const float *) w->d_cic,
+                           (const float2 *) w->ctx->d_tab4096, (const float2 *) w->ctx->d_tab8192, nframes,
+                           (unsigned char *) d_out, w->d_tap_pwr, w->d_tap_pwr_out, w->d_tap_db);
+    }
+    KG_HIP(hipGetLastError());
+    return KG_OK;
+}
+
+int kg_wf_frames_dev(kg_wf *w, int nframes, const int32_t *chan_of, const void *d_iq, void *d_out)
+{
+    KG_REQUIRE(w && chan_of && d_iq && d_out, KG_ERR_INVALID, "kg_wf_frames_dev: null argument");
+    int rc = kg_ctx_use(w->ctx);
+    if (rc) return rc;
+    KG_REQUIRE(((uintptr_t) d_iq & 7) == 0 && ((uintptr_t) d_out & 3) == 0, KG_ERR_INVALID,
+               "kg_wf_frames_dev: d_iq must be 8-byte and d_out 4-byte aligned");
+    return wf_launch(w, nframes, chan_of, d_iq, d_out, false);
+}
+
+static int wf_stage(kg_wf *w, int nframes)
+{
+    if (nframes > w->stage_cap) {
+        KG_HIP(hipStreamSynchronize(w->ctx->stream));
+        (void) hipFree(w->d_iq); (void) hipFree(w->d_out);
+        (void) hipFree(w->d_tap_pwr); (void) hipFree(w->d_tap_pwr_out); (void) hipFree(w->d_tap_db);
+        w->d_tap_pwr = w->d_tap_pwr_out = w->d_tap_db = nullptr;
+        KG_HIP(hipMalloc((void **) &w->d_iq, sizeof(short2) * WF_NFFT * (size_t) nframes));
+        KG_HIP(hipMalloc((void **) &w->d_out, (size_t) WF_WIDTH * nframes));
+        w->stage_cap = nframes;
+    }
+    return KG_OK;
+}
+
+int kg_wf_frames(kg_wf *w, int nframes, const int32_t *chan_of, const int16_t *iq, uint8_t *out)
+{
+    KG_REQUIRE(w && chan_of && iq && out, KG_ERR_INVALID, "kg_wf_frames: null argument");
+    int rc = kg_ctx_use(w->ctx);
+    if (rc) return rc;
+    KG_REQUIRE(nframes >= 1, KG_ERR_INVALID, "kg_wf_frames: nframes %d", nframes);
+    if ((rc = wf_stage(w, nframes)) != KG_OK) return rc;
+    hipStream_t st = w->ctx->stream;
+    KG_HIP(hipMemcpyAsync(w->d_iq, iq, sizeof(short2) * WF_NFFT * (size_t) nframes, hipMemcpyHostToDevice, st));
+    if ((rc = wf_launch(w, nframes, chan_of, w->d_iq, w->d_out, false)) != KG_OK) return rc;
+    KG_HIP(hipMemcpyAsync(out, w->d_out, (size_t) WF_WIDTH * nframes, hipMemcpyDeviceToHost, st));
+    KG_HIP(hipStreamSynchronize(st));
+    return KG_OK;
+}
+
+int kg_wf_debug_frame(kg_wf *w, int ch, const int16_t *iq, uint8_t *out, float *pwr, float *pwr_out, float *dB)
+{
+    KG_REQUIRE(w && iq && out && pwr && pwr_out && dB, KG_ERR_INVALID, "kg_wf_debug_frame: null argument");
+    int rc = kg_ctx_use(w->ctx);
+    if (rc) return rc;
+    if ((rc = wf_stage(w, 1)) != KG_OK) return rc;
+    hipStream_t st = w->ctx->stream;
+    if (!w->d_tap_pwr) {
+        KG_HIP(hipMalloc((void **) &w->d_tap_pwr, sizeof(float) * SUB * (size_t) w->stage_cap));
+        KG_HIP(hipMalloc((void **) &w->d_tap_pwr_out, sizeof(float) * WF_WIDTH * (size_t) w->stage_cap));
+        KG_HIP(hipMalloc((void **) &w->d_tap_db, sizeof(float) * WF_WIDTH * (size_t) w->stage_cap));
+    }
+    KG_HIP(hipMemsetAsync(w->d_tap_pwr, 0, sizeof(float) * SUB, st));
+    KG_HIP(hipMemcpyAsync(w->d_iq, iq, sizeof(short2) * WF_NFFT, hipMemcpyHostToDevice, st));
+    const int32_t c = ch;
+    if ((rc = wf_launch(w, 1, &c, w->d_iq, w->d_out, true)) != KG_OK) return rc;
+    KG_HIP(hipMemcpyAsync(out, w->d_out, WF_WIDTH, hipMemcpyDeviceToHost, st));
+    KG_HIP(hipMemcpyAsync(pwr, w->d_tap_pwr, sizeof(float) * SUB, hipMemcpyDeviceToHost, st));
+    KG_HIP(hipMemcpyAsync(pwr_out, w->d_tap_pwr_out, sizeof(float) * WF_WIDTH, hipMemcpyDeviceToHost, st));
+    KG_HIP(hipMemcpyAsync(dB, w->d_tap_db, sizeof(float) * WF_WIDTH, hipMemcpyDeviceToHost, st));
+    KG_HIP(hipStreamSynchronize(st));
+    return KG_OK;
+}
+
+}  // extern "C"

@@ -77,3 +77,18 @@ def config0_bits(seed=0x5EED0001):
     """BASELINE.json configs[0]: PRN1 at tau = 300.5 chips, +1500 Hz, theta 0.7, 45 dB-Hz."""
     _, t1, t2, _ = _sats.SATS[0]
     return gps_scene_bits([(_prn.cacode(t1, t2), 300.5, 1500.0, 0.7)], seed, 45.0)
+
+
+def wf_iq_frame(seed, tones=((0.05, -20.0), (0.21, -55.0), (0.33, -80.0)), noise_dbfs=-70.0,
+                n=8192):
+    """One waterfall DDC buffer: n complex int16 samples {i, q} (struct iq_t of
+    rx/rx_waterfall.cpp:95-97).  tones: (cycles per sample, dBFS); noise rms in dBFS."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    t = np.arange(n)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * (10.0 ** (noise_dbfs / 20.0) / np.sqrt(2))
+    for f, dbfs in tones:
+        x = x + 10.0 ** (dbfs / 20.0) * np.exp(2j * np.pi * (f * t + rng.random()))
+    iq = np.empty((n, 2), np.int16)
+    iq[:, 0] = np.clip(np.rint(32767.0 * x.real), -32768, 32767)
+    iq[:, 1] = np.clip(np.rint(32767.0 * x.imag), -32768, 32767)
+    return iq

@@ -147,6 +147,52 @@ int kg_acq_correlate(kg_acq *acq, int block_count, const int *sats, int nsats,
 /* Device pointer to the last launch's kg_acq_result array (for RCCL gathers). */
 void *kg_acq_results_dev(kg_acq *acq);
 
+/* ------------------------------------------------------------------------ */
+/* Waterfall frames.  Replaces, per (channel, frame): the unpack + window of   */
+/* sample_wf() (rx/rx_waterfall.cpp:1049-1066) and compute_frame()             */
+/* (:1275-1575: 8192-point FFT, power, CIC compensation, FFT-bin -> pixel      */
+/* reduce, dB, clamp, u8).  The tables and maps stay the caller's: they are    */
+/* the arrays c2s_waterfall_init() (:122-203) and the c2s_waterfall() loop     */
+/* (:775-928) already build, passed as they are.                               */
+/* ------------------------------------------------------------------------ */
+#define KG_WF_NFFT  8192      /* WF_C_NFFT = WF_C_NSAMPS, rx/rx_waterfall.h:61-62 */
+#define KG_WF_WIDTH 1024      /* WF_WIDTH, rx/rx_waterfall.h:65 */
+
+typedef struct kg_wf kg_wf;
+
+/* The scalar members of wf_inst_t (rx/rx_waterfall.h:118-157) compute_frame() reads. */
+typedef struct {
+    int32_t zoom;                 /* wf->zoom */
+    int32_t window_func;          /* WINF_WF_* 0..3, rx_waterfall.h:160-163 */
+    int32_t interp;               /* wf_interp_t: 0 MAX, 1 MIN, 2 LAST, 3 DROP, 4 CMA (rx_waterfall.h:116) */
+    int32_t cic_comp;             /* wf->cic_comp */
+    int32_t overlapped;           /* wf->overlapped_sampling */
+    int32_t fft_used;             /* 4096 at zoom 0, 2048 otherwise (:756-763) */
+    int32_t plot_width;           /* :772 */
+    int32_t plot_width_clamped;   /* :773 */
+    float fft_offset;             /* :898 */
+} kg_wf_chan_cfg;
+
+int kg_wf_create(kg_ctx *ctx, int nchan, kg_wf **out);
+void kg_wf_destroy(kg_wf *wf);
+/* wf_shmem_t.window_function[4][8192] and .CIC_comp[8192] (rx_waterfall.h:166-172) */
+int kg_wf_set_tables(kg_wf *wf, const float *window_function, const float *cic_comp);
+/* wf_inst_t.fft2wf_map[fft_used], .drop_sample[1024], .fft_scale[1024],
+ * .fft_scale_div2[1024] of channel ch.  Only the "FFT >= plot" case (:1400) is
+ * supported (fft_used >= plot_width), the only one reachable for FlyDog. */
+int kg_wf_set_channel(kg_wf *wf, int ch, const kg_wf_chan_cfg *cfg, const uint16_t *fft2wf_map,
+                      const uint16_t *drop_sample, const float *fft_scale,
+                      const float *fft_scale_div2);
+/* nframes frames; frame f belongs to channel chan_of[f] (host array), its input is
+ * iq[f][8192] {int16 i, int16 q} (struct iq_t, :95-97) and its output out[f][1024]
+ * bytes (wf_pkt_t.un.buf).  _dev: device pointers, enqueue only. */
+int kg_wf_frames_dev(kg_wf *wf, int nframes, const int32_t *chan_of, const void *d_iq, void *d_out);
+int kg_wf_frames(kg_wf *wf, int nframes, const int32_t *chan_of, const int16_t *iq, uint8_t *out);
+/* One frame with the intermediate arrays of compute_frame(): pwr[4096] (entries
+ * below fft_used are written), pwr_out[1024], dB[1024] (before the clamp). */
+int kg_wf_debug_frame(kg_wf *wf, int ch, const int16_t *iq, uint8_t *out, float *pwr,
+                      float *pwr_out, float *dB);
+
 /* Diagnostics: re-runs the 4096-point stage of the forward FFT of `block` in a
  * stamped build of the kernel and returns 4 s_memrealtime readings (100 MHz):
  * start, inputs + twiddles loaded, transform done, results stored. */

@@ -110,6 +110,40 @@ void ko_correlate_many(const ko_cpx *codes, int nsv, const ko_cpx *data,
                        ko_acq_result *out, ko_acq_cell *cells, int prec,
                        int nthreads);
 
+/* ---- waterfall (rx/rx_waterfall.cpp) ---------------------------------------- */
+#define KO_WF_NFFT  8192         /* rx/rx_waterfall.h:61-62 WF_C_NFFT = WF_C_NSAMPS */
+#define KO_WF_WIDTH 1024         /* rx/rx_waterfall.h:65 */
+enum { KO_WINF_HANNING = 0, KO_WINF_HAMMING = 1, KO_WINF_BLACKMAN_HARRIS = 2, KO_WINF_NONE = 3 };  /* rx_waterfall.h:160-163 */
+enum { KO_WF_MAX = 0, KO_WF_MIN, KO_WF_LAST, KO_WF_DROP, KO_WF_CMA };                             /* rx_waterfall.h:116 */
+
+typedef struct {
+    int zoom, decim, fft_used, plot_width, plot_width_clamped;
+    float start, fft_scale, fft_offset;
+    uint64_t i_offset;           /* 48-bit NCO phase increment */
+} ko_wf_params;
+
+typedef struct {
+    int zoom, window_func, interp, cic_comp, overlapped;
+    int fft_used, plot_width, plot_width_clamped;
+    const uint16_t *fft2wf_map;  /* [fft_used]  wf_inst_t.fft2wf_map  */
+    const uint16_t *drop_sample; /* [1024]      wf_inst_t.drop_sample */
+    const float *fft_scale, *fft_scale_div2;   /* [1024] */
+    float fft_offset;
+    const float *CIC_comp;       /* [8192] */
+} ko_wf_cfg;
+
+void ko_wf_window(int winf, float *window);                  /* c2s_waterfall_init :136-171 */
+void ko_wf_cic_comp(float *comp);                            /* c2s_waterfall_init :175-185 */
+void ko_wf_params_for(int zoom, float start, double adc_clock, double ui_srate,
+                      int spectral_inversion, ko_wf_params *out);
+void ko_wf_build_maps(int fft_used, int plot_width, int plot_width_clamped,
+                      int spectral_inversion, uint16_t *fft2wf_map, uint16_t *drop_sample);
+void ko_wf_window_iq(const int16_t *iq, const float *window, ko_cpx *out);   /* sample_wf :1049-1066 */
+/* compute_frame :1275-1575.  samps: 8192 windowed samples.  out: 1024 bytes.
+ * Optional taps: pwr[fft_used], pwr_out[1024], dB[1024] (before clamp). */
+void ko_wf_compute_frame(const ko_wf_cfg *wf, const ko_cpx *samps, uint8_t *out,
+                         float *pwr_dbg, float *pwr_out_dbg, float *dB_dbg, int prec);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,12 @@ def lib():
         L.ko_correlate.restype = AcqResult
         L.ko_correlate_many.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp,
                                         C.c_int, C.c_int]
+        L.ko_wf_window.argtypes = [C.c_int, vp]
+        L.ko_wf_cic_comp.argtypes = [vp]
+        L.ko_wf_params_for.argtypes = [C.c_int, C.c_float, C.c_double, C.c_double, C.c_int, vp]
+        L.ko_wf_build_maps.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+        L.ko_wf_window_iq.argtypes = [vp, vp, vp]
+        L.ko_wf_compute_frame.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int]
         _lib = L
     return _lib
 
@@ -163,6 +169,79 @@ def correlate_many(codes, data, limits, dop_lo=DOP_LO, dop_hi=DOP_HI, prec=1, nt
     lib().ko_correlate_many(_p(codes), nsv, _p(data), _p(limits), dop_lo, dop_hi, _p(out),
                             _p(cells) if want_cells else None, int(prec), int(nthreads))
     return out, cells
+
+
+# ---- waterfall -----------------------------------------------------------------
+WF_NFFT, WF_WIDTH = 8192, 1024
+
+
+class WfParams(C.Structure):
+    _fields_ = [("zoom", C.c_int), ("decim", C.c_int), ("fft_used", C.c_int),
+                ("plot_width", C.c_int), ("plot_width_clamped", C.c_int), ("start", C.c_float),
+                ("fft_scale", C.c_float), ("fft_offset", C.c_float), ("i_offset", C.c_uint64)]
+
+
+class WfCfg(C.Structure):
+    _fields_ = [("zoom", C.c_int), ("window_func", C.c_int), ("interp", C.c_int),
+                ("cic_comp", C.c_int), ("overlapped", C.c_int), ("fft_used", C.c_int),
+                ("plot_width", C.c_int), ("plot_width_clamped", C.c_int),
+                ("fft2wf_map", C.c_void_p), ("drop_sample", C.c_void_p),
+                ("fft_scale", C.c_void_p), ("fft_scale_div2", C.c_void_p),
+                ("fft_offset", C.c_float), ("CIC_comp", C.c_void_p)]
+
+
+def wf_window(winf):
+    out = np.empty(WF_NFFT, np.float32)
+    lib().ko_wf_window(int(winf), _p(out))
+    return out
+
+
+def wf_cic_comp():
+    out = np.empty(WF_NFFT, np.float32)
+    lib().ko_wf_cic_comp(_p(out))
+    return out
+
+
+def wf_params(zoom, start, adc_clock=125.0e6, ui_srate=32.0e6, spectral_inversion=False):
+    p = WfParams()
+    lib().ko_wf_params_for(int(zoom), float(start), float(adc_clock), float(ui_srate),
+                           int(bool(spectral_inversion)), C.byref(p))
+    return p
+
+
+def wf_build_maps(fft_used, plot_width, plot_width_clamped, spectral_inversion=False):
+    m = np.zeros(fft_used, np.uint16)
+    d = np.zeros(WF_WIDTH, np.uint16)
+    lib().ko_wf_build_maps(fft_used, plot_width, plot_width_clamped, int(bool(spectral_inversion)),
+                           _p(m), _p(d))
+    return m, d
+
+
+def wf_window_iq(iq, window):
+    iq = np.ascontiguousarray(iq, np.int16).reshape(-1)
+    window = np.ascontiguousarray(window, np.float32)
+    out = np.empty(WF_NFFT, cpx)
+    lib().ko_wf_window_iq(_p(iq), _p(window), _p(out))
+    return out
+
+
+def wf_compute_frame(samps, zoom, window_func, interp, cic_comp_on, overlapped, fft_used, plot_width,
+                     plot_width_clamped, fft2wf_map, drop_sample, fft_scale, fft_scale_div2,
+                     fft_offset, cic_table, prec=1):
+    """-> (out u8[1024], pwr[fft_used], pwr_out[1024], dB[1024])"""
+    samps = np.ascontiguousarray(samps, cpx)
+    keep = [np.ascontiguousarray(fft2wf_map, np.uint16), np.ascontiguousarray(drop_sample, np.uint16),
+            np.ascontiguousarray(fft_scale, np.float32), np.ascontiguousarray(fft_scale_div2, np.float32),
+            np.ascontiguousarray(cic_table, np.float32)]
+    cfg = WfCfg(zoom, window_func, interp, int(cic_comp_on), int(overlapped), fft_used, plot_width,
+                plot_width_clamped, keep[0].ctypes.data, keep[1].ctypes.data, keep[2].ctypes.data,
+                keep[3].ctypes.data, float(fft_offset), keep[4].ctypes.data)
+    out = np.empty(WF_WIDTH, np.uint8)
+    pwr = np.zeros(fft_used, np.float32)
+    pwr_out = np.empty(WF_WIDTH, np.float32)
+    dB = np.empty(WF_WIDTH, np.float32)
+    lib().ko_wf_compute_frame(C.byref(cfg), _p(samps), _p(out), _p(pwr), _p(pwr_out), _p(dB), int(prec))
+    return out, pwr, pwr_out, dB
 
 
 def ref_cacode(t0, t1):

@@ -224,3 +224,47 @@ def test_gloo_world2_gather(tmp_path):
                          timeout=240)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("ok") == 2
+
+
+# ---- waterfall host logic vs oracle -------------------------------------------
+def test_wf_tables_params_maps_match_oracle(oracle):
+    from flydog_sdr_gps_amd import wf
+    W = wf.window_functions()
+    for k in range(4):
+        assert np.array_equal(W[k], oracle.wf_window(k))
+    # sinc^-5 of a float-rounded sinc: numpy's sin/pow vs libm differ in the last ulps
+    assert np.allclose(wf.cic_comp_table(), oracle.wf_cic_comp(), rtol=2e-6, atol=0)
+    for z in range(15):
+        for inv in (False, True):
+            p = wf.WfParams.for_zoom(z, 3.0e5 * z + 17, spectral_inversion=inv)
+            q = oracle.wf_params(z, 3.0e5 * z + 17, spectral_inversion=inv)
+            assert (p.decim, p.fft_used, p.plot_width, p.plot_width_clamped, p.i_offset) == \
+                (q.decim, q.fft_used, q.plot_width, q.plot_width_clamped, q.i_offset)
+            assert np.float32(p.fft_scale) == np.float32(q.fft_scale)
+            m, d = wf.build_maps(p.fft_used, p.plot_width, p.plot_width_clamped, inv)
+            m2, d2 = oracle.wf_build_maps(q.fft_used, q.plot_width, q.plot_width_clamped, inv)
+            assert np.array_equal(m, m2) and np.array_equal(d, d2)
+    # FlyDog's plot widths never exceed the used FFT bins
+    for ui, width in ((32e6, 2000), (42e6, 1523), (52e6, 1230), (62e6, 1032)):
+        for z in (0, 1, 9):
+            p = wf.WfParams.for_zoom(z, 0, ui_srate=ui)
+            assert abs(p.plot_width - width) <= 1 and p.plot_width <= p.fft_used
+
+
+def test_wf_oracle_tone_lands_on_the_right_pixel(oracle):
+    """A tone at FFT bin b must light pixel plot_width*b/fft_used (:800)."""
+    from flydog_sdr_gps_amd import wf
+    p = wf.WfParams.for_zoom(3, 0.0)
+    m, d = wf.build_maps(p.fft_used, p.plot_width, p.plot_width_clamped)
+    t = np.arange(8192)
+    b = 300
+    iq = np.empty((8192, 2), np.int16)
+    iq[:, 0] = np.rint(8000 * np.cos(2 * np.pi * b * t / 8192))
+    iq[:, 1] = np.rint(8000 * np.sin(2 * np.pi * b * t / 8192))
+    samps = oracle.wf_window_iq(iq, wf.window_functions()[0])
+    sc = np.full(1024, p.fft_scale, np.float32)
+    out, pwr, pwr_out, dB = oracle.wf_compute_frame(samps, p.zoom, 0, wf.WF_MAX, 1, 0, p.fft_used,
+                                                    p.plot_width, p.plot_width_clamped, m, d, sc, sc / 2,
+                                                    p.fft_offset, wf.cic_comp_table())
+    assert int(np.argmax(pwr)) == b and int(np.argmax(out)) == p.plot_width * b // p.fft_used
+    assert out.min() >= 55
