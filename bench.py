@@ -70,14 +70,67 @@ def cpu_baseline(iq, chips_list, budget_s=12.0):
     }
 
 
+def bench_waterfall(args):
+    """Secondary workload (not the headline): waterfall frames, BASELINE configs[2]'s
+    14-channel zoom set, DDC output buffers (8192 int16 IQ per frame) resident in HBM.
+        python bench.py --workload waterfall [--frames F]"""
+    import torch
+    from flydog_sdr_gps_amd import Context, Waterfall, WfParams, synth, wf
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    ctx = Context(0, torch.cuda.current_stream(dev).cuda_stream)
+    zooms = [0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14]
+    w = Waterfall(ctx, nchan=len(zooms))
+    w.set_tables()
+    for ch, z in enumerate(zooms):
+        w.set_channel(ch, WfParams.for_zoom(z, 1.0e6 * ch), interp=wf.WF_CMA, cic_comp=True)
+    F = args.frames
+    nfr = F * len(zooms)
+    base = np.stack([synth.wf_iq_frame(seed=i) for i in range(32)])
+    iq = torch.from_numpy(base[np.arange(nfr) % 32].copy()).to(dev)
+    out = torch.empty((nfr, 1024), dtype=torch.uint8, device=dev)
+    chan_of = np.arange(nfr, dtype=np.int32) % len(zooms)
+    for _ in range(args.warmup):
+        w.frames_dev(chan_of, iq.data_ptr(), out.data_ptr())
+    torch.cuda.synchronize(dev)
+    ctx.timer_start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        w.frames_dev(chan_of, iq.data_ptr(), out.data_ptr())
+    kernel_ms = ctx.timer_stop() / args.steps
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    bytes_frame = 8192 * 4 + 1024          # int16 IQ in + u8 row out; tables are L2-resident
+    achieved = nfr * bytes_frame / (kernel_ms * 1e-3) / 1e9
+    print(json.dumps({
+        "metric": "waterfall IQ Msamples/s (window + 8192-pt FFT + pixel reduce + dB + u8)",
+        "value": round(nfr * 8192 * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "waterfall frames, 14 channels (zooms %s) x %d frames per step" % (zooms, F),
+                   "frames_per_step": nfr},
+        "roofline": {"bound": "hbm", "kernel": "wf_frame_kernel", "achieved": round(achieved, 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": None, "kernel_ms": round(kernel_ms, 5),
+                     "algorithmic_bytes_per_launch": nfr * bytes_frame},
+    }), flush=True)
+    w.close()
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="acq", choices=["acq", "waterfall"])
+    ap.add_argument("--frames", type=int, default=512, help="waterfall: frames per channel per step")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--blocks", type=int, default=1, help="independent 4 ms blocks per step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
+    if args.workload == "waterfall":
+        return bench_waterfall(args)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))

@@ -69,32 +69,54 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
 
     kg_tw4096 tw;
     kg_tw4096_load(tw, tab4096, t);
-    cf wc[16];                                // W_8192^{k}, k = t + 256 m
+    // combine twiddle W_8192^{k}, k = t + 256 m: W_8192^{t} (per thread) * W_32^{m} (immediate)
+    const cf wbase = kg_ld(&tab8192[t]);
+
+    short4 raw[16];
+    auto fetch = [&](int f) {
+        const short4 *src = (const short4 *) (iq + (size_t) f * WF_NFFT);
 #pragma unroll
-    for (int m = 0; m < 16; m++) wc[m] = kg_ld(&tab8192[t + 256 * m]);
+        for (int j = 0; j < 16; j++) raw[j] = src[t + 256 * j];
+    };
 
     for (int f = blockIdx.x; f < nframes; f += gridDim.x) {
         const wf_chan_dev *ch = chans + chan_of[f];
         const int interp = ch->interp, dc = ch->dc, comp_on = ch->comp_on;
-        const short4 *src = (const short4 *) (iq + (size_t) f * WF_NFFT);
         const float2 *win = (const float2 *) (windows + (size_t) ch->window_func * WF_NFFT);
 
         // sample_wf(): fi = (float)(s2_t)i * window[sn]  (:1054-1061), samples 2*n1, 2*n1+1
-        cf xa[16], xb[16], y0[16], y1[16];
+        fetch(f);
+        cf x[16], y0[16], y1[16];
+        float wodd[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-            const short4 s = src[t + 256 * j];
             const float2 w = win[t + 256 * j];
-            xa[j] = cf{(float) s.x * w.x, (float) s.y * w.x};
-            xb[j] = cf{(float) s.z * w.y, (float) s.w * w.y};
+            x[j] = cf{(float) raw[j].x * w.x, (float) raw[j].y * w.x};
+            wodd[j] = w.y;
         }
-        kg_subfft4096<-1>(xa, y0, tileA, tileB, tw, t);
-        kg_subfft4096<-1>(xb, y1, tileA, tileB, tw, t);
-        __syncthreads();                      // tile A is about to become pwr[]
+        kg_subfft4096<-1>(x, y0, tileA, tileB, tw, t);
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = cf{(float) raw[j].z * wodd[j], (float) raw[j].w * wodd[j]};
+        kg_subfft4096<-1>(x, y1, tileA, tileB, tw, t);
+        // (tile A, about to become pwr[], was last read before the second transform's
+        // second barrier)
+        // this thread's four pixels: run starts, run lengths, scales -- four vector loads
+        // issued here so that the combine / power stage hides them
+        const ushort4 pf = ((const ushort4 *) ch->first)[t];
+        const ushort4 pc = ((const ushort4 *) ch->count)[t];
+        const float4 ps = ((const float4 *) ch->scale)[t];
+        const float4 ps2 = ((const float4 *) ch->scale_div2)[t];
+        const int pfirst[4] = {pf.x, pf.y, pf.z, pf.w}, pcount[4] = {pc.x, pc.y, pc.z, pc.w};
+        const float pscale[4] = {ps.x, ps.y, ps.z, ps.w}, pscale2[4] = {ps2.x, ps2.y, ps2.z, ps2.w};
+        const int pwc = ch->pwc;
+        const float fft_offset = ch->fft_offset;
 #pragma unroll
         for (int m = 0; m < 16; m++) {
             const int k = t + 256 * m;
-            const cf X = y0[m] + kg_cmulc(y1[m], wc[m]);
+            cf z = y1[m];                     // * conj(W_32^m) * conj(W_8192^t)
+            if (m == 8) z = cf{z.y, -z.x};
+            else if (m != 0) z = kg_cmulc_s(z, cf{KG_W64[2 * m][0], KG_W64[2 * m][1]});
+            const cf X = y0[m] + kg_cmulc(z, wbase);
             float re = X.x, im = X.y;
             if (comp_on) { const float c = cic_comp[k]; re = re * c; im = im * c; }   // :1342
             float p = re * re + im * im;                                                // :1345
@@ -109,11 +131,11 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int px = 4 * t + u;
-            const int first = ch->first[px], cnt = ch->count[px];
+            const int first = pfirst[u], cnt = pcount[u];
             float p = 0.f;                    // memset(pwr_out, 0), :1385
             int avgs = 0;
             if (interp == WF_DROP) {
-                if (px < ch->pwc) p = pwr[first];                                       // :1418
+                if (px < pwc) p = pwr[first];                                           // :1418
             } else if (cnt > 0) {
                 p = pwr[first]; avgs = 1;                                               // :1468-1475
                 for (int i = 1; i < cnt; i++) {
@@ -126,14 +148,14 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
                     }
                 }
             }
-            float scale = ch->scale[px];
+            float scale = pscale[u];
             if (interp == WF_CMA)                                                        // :1499-1500
-                scale = (avgs == 1) ? scale : ((avgs == 2) ? ch->scale_div2[px] : scale / (float) avgs);
+                scale = (avgs == 1) ? scale : ((avgs == 2) ? pscale2[u] : scale / (float) avgs);
             // dB = 10.0 * log10f(p*scale + 1e-30F) + fft_offset: the product and sum in
             // float, the 10.0* and + in double, one rounding to float (:1507)
             const float arg = p * scale + 1e-30f;
-            const float l = (float) log10((double) arg);
-            float dB = (float) (10.0 * (double) l + (double) ch->fft_offset);
+            const float l = log10f(arg);
+            float dB = (float) (10.0 * (double) l + (double) fft_offset);
             if (TAPS) { tap_pwr_out[(size_t) f * WF_WIDTH + px] = p; tap_db[(size_t) f * WF_WIDTH + px] = dB; }
             unsigned b;
             if (dB != dB) {
