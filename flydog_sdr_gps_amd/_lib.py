@@ -52,6 +52,10 @@ SYMBOLS = {
     "kg_ctx_stream": (_vp, [_vp]),
     "kg_ctx_device_name": (_i, [_vp, C.c_char_p, _sz]),
     "kg_ctx_num_cus": (_i, [_vp]),
+    "kg_dev_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "kg_dev_free": (_i, [_vp, _vp]),
+    "kg_dev_upload": (_i, [_vp, _vp, _vp, _sz]),
+    "kg_dev_download": (_i, [_vp, _vp, _vp, _sz]),
     "kg_timer_start": (_i, [_vp]),
     "kg_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
     "kg_acq_create": (_i, [_vp, _i, _i, _i, _i, C.POINTER(_vp)]),
@@ -79,6 +83,13 @@ SYMBOLS = {
     "kg_wf_frames_dev": (_i, [_vp, _i, _vp, _vp, _vp]),
     "kg_wf_frames": (_i, [_vp, _i, _vp, _vp, _vp]),
     "kg_wf_debug_frame": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "kg_ddc_create": (_i, [_vp, _i, _sz, C.POINTER(_vp)]),
+    "kg_ddc_destroy": (None, [_vp]),
+    "kg_ddc_set_wf": (_i, [_vp, _i, C.c_uint64, _i]),
+    "kg_ddc_reset_wf": (_i, [_vp, _i]),
+    "kg_ddc_set_phase": (_i, [_vp, _i, C.c_uint64]),
+    "kg_ddc_wf_outputs": (C.c_long, [_vp, _i, _sz]),
+    "kg_ddc_wf_push_dev": (_i, [_vp, _vp, _sz, _vp, _i, _vp, _sz, _vp]),
     "kg_acq_debug_fft_stamps": (_i, [_vp, _i, _vp, _i]),
     "kg_acq_debug_corr_stamps": (_i, [_vp, _i, _vp, _i, _vp, _i]),
 }
@@ -165,6 +176,23 @@ class Context:
     @property
     def num_cus(self):
         return check(self.lib.kg_ctx_num_cus(self.h), "kg_ctx_num_cus")
+
+    # device memory without any other HIP runtime in the process
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        check(self.lib.kg_dev_alloc(self.h, int(nbytes), C.byref(p)), "kg_dev_alloc")
+        return p.value
+
+    def free(self, dptr):
+        check(self.lib.kg_dev_free(self.h, C.c_void_p(dptr)), "kg_dev_free")
+
+    def upload(self, dptr, host):
+        host = np.ascontiguousarray(host)
+        check(self.lib.kg_dev_upload(self.h, C.c_void_p(dptr), ptr(host), host.nbytes), "kg_dev_upload")
+
+    def download(self, dptr, host):
+        assert host.flags["C_CONTIGUOUS"]
+        check(self.lib.kg_dev_download(self.h, ptr(host), C.c_void_p(dptr), host.nbytes), "kg_dev_download")
 
     def timer_start(self):
         check(self.lib.kg_timer_start(self.h), "kg_timer_start")

@@ -139,6 +139,47 @@ int kg_ctx_device_name(kg_ctx *c, char *buf, size_t len)
 
 int kg_ctx_num_cus(kg_ctx *c) { return c ? c->num_cus : KG_ERR_INVALID; }
 
+int kg_dev_alloc(kg_ctx *c, size_t bytes, void **out)
+{
+    int rc = kg_ctx_use(c);
+    if (rc) return rc;
+    KG_REQUIRE(out != nullptr && bytes > 0, KG_ERR_INVALID, "kg_dev_alloc: bad argument");
+    *out = nullptr;
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipErrorOutOfMemory) { kg_set_error("kg_dev_alloc: out of device memory (%zu bytes)", bytes); return KG_ERR_NOMEM; }
+    KG_HIP(e);
+    return KG_OK;
+}
+
+int kg_dev_free(kg_ctx *c, void *p)
+{
+    int rc = kg_ctx_use(c);
+    if (rc) return rc;
+    KG_HIP(hipStreamSynchronize(c->stream));
+    KG_HIP(hipFree(p));
+    return KG_OK;
+}
+
+int kg_dev_upload(kg_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    int rc = kg_ctx_use(c);
+    if (rc) return rc;
+    KG_REQUIRE(dst && src, KG_ERR_INVALID, "kg_dev_upload: null argument");
+    KG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    KG_HIP(hipStreamSynchronize(c->stream));
+    return KG_OK;
+}
+
+int kg_dev_download(kg_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    int rc = kg_ctx_use(c);
+    if (rc) return rc;
+    KG_REQUIRE(dst && src, KG_ERR_INVALID, "kg_dev_download: null argument");
+    KG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    KG_HIP(hipStreamSynchronize(c->stream));
+    return KG_OK;
+}
+
 int kg_timer_start(kg_ctx *c)
 {
     int rc = kg_ctx_use(c);

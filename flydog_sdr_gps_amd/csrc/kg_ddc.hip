@@ -1,0 +1,564 @@
+// kg_ddc.hip -- the waterfall digital down-converter on gfx950.
+//
+// In the reference this is FPGA fabric, one instance per waterfall channel,
+// clocked at the ADC rate:  IQ_MIXER (verilog/rx/iq_mixer.v:5-67: 48-bit phase
+// accumulator, 15-bit sin/cos, 18x18 multiply, round to 24 bits)
+// -> cic_prune_var "wf1" x2 (verilog/rx/cic_prune_var.v + cic_wf1.vh: 5
+// integrators at the ADC rate, 89-bit wrapping accumulators, decimate by
+// R = 2^k <= 8192, 5 combs, Hogenauer-pruned widths 89/89/89/89/28 and
+// 23/22/21/20/20, rounded to 16 bits; R = 1 bypass) -> 16-bit IQ into the
+// 8192-sample buffer the host reads as iq_t (verilog/rx/waterfall_1cic.v:58-142).
+// The host programs it with CmdSetWFFreq / CmdSetWFDecim / CmdWFReset
+// (rx/rx_waterfall.cpp:466,507,1005).  Here the ADC stream lives in HBM and all
+// channels are computed from it.
+//
+// Bit-exactness target: a sequential restatement of the Verilog structure (the
+// tests' CPU model).  Frozen by us because the Xilinx DDS IP is closed: the sine
+// table, round(16383 cos/sin) addressed by phase bits 47:35, and no phase dither.
+//
+// Parallelisation.  The integrators are prefix sums over the whole stream and the
+// pruning (the 5th integrator accumulates floor(I4 / 2^61)) makes the output depend
+// on the exact wrapped value of I4 at every ADC sample, so time cannot simply be
+// cut into independent pieces.  The stream is cut into runs of L samples:
+//   A  every run integrates from a zero state  -> local end state e_r (4 x 128 bit)
+//   S  carry scan: c_{r+1} = T(L) c_r + e_r, where T(L) advances a state over L
+//      zero-input samples (binomial coefficients; validated in tools/ and the
+//      tests).  One wave per (channel, I/Q): lane-local sequential compose, a
+//      6-step wave scan with the affine combine, lane-local re-expansion.
+//   B  every run integrates again from its exact carried state, feeds the pruned
+//      5th integrator and records its value at every decimation strobe (relative
+//      to the run start) plus the run total
+//   S2 prefix sum of the run totals (mod 2^28)
+//   C  per output: absolute I5, the five pruned combs (a 6-tap dependency on
+//      earlier outputs only, so fully parallel), rounding, int16 store.
+// All arithmetic is modulo 2^128, which keeps the low 89 bits exact.
+#include "kg_common.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+struct u128 { u64 lo, hi; };
+
+#define DDC_DEV __device__ __forceinline__
+
+DDC_DEV u128 mk128(u64 lo, u64 hi) { u128 r; r.lo = lo; r.hi = hi; return r; }
+DDC_DEV u128 add128(u128 a, u128 b)
+{
+    u128 r;
+    r.lo = a.lo + b.lo;
+    r.hi = a.hi + b.hi + (r.lo < a.lo ? 1ull : 0ull);
+    return r;
+}
+DDC_DEV u128 mul128(u128 a, u128 b)          // modulo 2^128
+{
+    u128 r;
+    r.lo = a.lo * b.lo;
+    r.hi = __umul64hi(a.lo, b.lo) + a.lo * b.hi + a.hi * b.lo;
+    return r;
+}
+// j(j+1)/2 and j(j+1)(j+2)/6 exactly (j < 2^40), as 128-bit values
+DDC_DEV u128 binom2(u64 j)
+{
+    const u64 a = (j & 1) ? j : j / 2, b = (j & 1) ? (j + 1) / 2 : j + 1;
+    return mk128(a * b, __umul64hi(a, b));
+}
+DDC_DEV u128 binom3(u64 j)
+{
+    // of j, j+1, j+2 one is divisible by 3 and (another or the same) by 2
+    u64 f[3] = {j, j + 1, j + 2};
+    for (int i = 0; i < 3; i++) if (f[i] % 3 == 0) { f[i] /= 3; break; }
+    for (int i = 0; i < 3; i++) if ((f[i] & 1) == 0) { f[i] /= 2; break; }
+    const u128 ab = mk128(f[0] * f[1], __umul64hi(f[0], f[1]));
+    return mul128(ab, mk128(f[2], 0));
+}
+
+struct ddc_state4 { u128 i[4]; };            // integrators 1..4
+
+// advance a state over len zero-input samples
+DDC_DEV ddc_state4 ddc_T(u64 len, const ddc_state4 &s)
+{
+    const u128 L = mk128(len, 0), c2 = binom2(len), c3 = binom3(len);
+    ddc_state4 r;
+    r.i[0] = s.i[0];
+    r.i[1] = add128(s.i[1], mul128(L, s.i[0]));
+    r.i[2] = add128(add128(s.i[2], mul128(L, s.i[1])), mul128(c2, s.i[0]));
+    r.i[3] = add128(add128(add128(s.i[3], mul128(L, s.i[2])), mul128(c2, s.i[1])), mul128(c3, s.i[0]));
+    return r;
+}
+DDC_DEV ddc_state4 ddc_add(const ddc_state4 &a, const ddc_state4 &b)
+{
+    ddc_state4 r;
+    for (int k = 0; k < 4; k++) r.i[k] = add128(a.i[k], b.i[k]);
+    return r;
+}
+
+// Per-channel persistent state (HBM).
+struct ddc_chan {
+    u64 phase;            // 48-bit NCO accumulator: phase of the next sample
+    u64 phase_inc;        // CmdSetWFFreq (rx_waterfall.cpp:507)
+    int log2r;            // CmdSetWFDecim: R = 1 << log2r
+    u32 sample_no;        // decimation counter (cic_prune_var.v:65-80)
+    ddc_state4 integ[2];  // I, Q integrators 1..4
+    u32 integ5[2];        // 28-bit integrator 5
+    u32 hist[2][5];       // integrator-5 value at the last five strobes (what the comb registers hold)
+    int active;
+};
+
+// iq_mixer.v:27-51, IN_WIDTH 16, OUT_WIDTH 24: (prod >>> 11) + prod[10], prod = (adc<<2)*(dds<<3)
+DDC_DEV int mix24(int adc, int dds)
+{
+    const long long prod = (long long) (adc * 4) * (long long) (dds * 8);
+    return (int) ((prod >> 11) + ((prod >> 10) & 1));
+}
+
+#define DDC_THREADS 256
+
+// Passes A and B.  grid = (ceil(nruns / 256), nchan).
+template <bool PASS_B>
+__global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
+    const short *__restrict__ adc, long n, int L, int nruns,
+    const ddc_chan *__restrict__ chans, const int *__restrict__ chan_list,
+    const u32 *__restrict__ nco,              // [8192] {cos | sin << 16}
+    ddc_state4 *__restrict__ local,           // A: out [nlist][2][nruns];  B: in = carried states
+    u32 *__restrict__ c0rel,                  // B: relative I5 at strobes; entry li: I at c0off[li], Q right after
+    u32 *__restrict__ tau,                    // B: [nlist][2][nruns]
+    const long *__restrict__ c0off, const long *__restrict__ nouts,
+    short2 *__restrict__ out, long out_stride)   // R == 1 bypass writes the output directly (pass A)
+{
+    __shared__ u32 tab[8192];
+    for (int i = threadIdx.x; i < 8192; i += DDC_THREADS) tab[i] = nco[i];
+    __syncthreads();
+    const int li = blockIdx.y;
+    const ddc_chan ch = chans[chan_list[li]];
+    const int r = blockIdx.x * DDC_THREADS + threadIdx.x;
+    if (r >= nruns) return;
+    const long s0 = (long) r * L, s1 = (s0 + L < n) ? s0 + L : n;
+    const u64 M48 = (1ull << 48) - 1;
+    u64 ph = (ch.phase + (u64) s0 * ch.phase_inc) & M48;
+    const int log2r = ch.log2r;
+    const u64 Rm1 = (1ull << log2r) - 1;
+    const int shift = 65 - 5 * log2r;         // cic_prune_var.v:224-247
+
+    if (log2r == 0) {                         // R == 1 bypass: out = in[23 -: 16] (:289-297)
+        if (!PASS_B) {
+            for (long t = s0; t < s1; t++) {
+                const u32 e = tab[ph >> 35];
+                const int a = adc[t];
+                const int mi = mix24(a, (short) (e & 0xffff)), mq = mix24(a, (short) (e >> 16));
+                out[(long) li * out_stride + t] = make_short2((short) (mi >> 8), (short) (mq >> 8));
+                ph = (ph + ch.phase_inc) & M48;
+            }
+        }
+        return;
+    }
+
+    ddc_state4 SI, SQ;
+    if (PASS_B) {
+        SI = local[((long) li * 2 + 0) * nruns + r];
+        SQ = local[((long) li * 2 + 1) * nruns + r];
+    } else {
+        for (int k = 0; k < 4; k++) { SI.i[k] = mk128(0, 0); SQ.i[k] = mk128(0, 0); }
+    }
+    u32 i5i = 0, i5q = 0;
+    const u64 cnt0 = (u64) ch.sample_no + (u64) s0;      // samples since the counter was last zero
+    for (long t = s0; t < s1; t++) {
+        const u32 e = tab[ph >> 35];
+        const int a = adc[t];
+        const long long mi = mix24(a, (short) (e & 0xffff)), mq = mix24(a, (short) (e >> 16));
+        ph = (ph + ch.phase_inc) & M48;
+        // in = sign-extended m << shift, 128 bits
+        const u128 xi = mk128((u64) mi << shift, (u64) (shift ? mi >> (64 - shift) : mi >> 63));
+        const u128 xq = mk128((u64) mq << shift, (u64) (shift ? mq >> (64 - shift) : mq >> 63));
+        SI.i[0] = add128(SI.i[0], xi); SI.i[1] = add128(SI.i[1], SI.i[0]);
+        SI.i[2] = add128(SI.i[2], SI.i[1]); SI.i[3] = add128(SI.i[3], SI.i[2]);
+        SQ.i[0] = add128(SQ.i[0], xq); SQ.i[1] = add128(SQ.i[1], SQ.i[0]);
+        SQ.i[2] = add128(SQ.i[2], SQ.i[1]); SQ.i[3] = add128(SQ.i[3], SQ.i[2]);
+        if (PASS_B) {
+            // integrator 5 accumulates integrator4[88 -: 28] (cic_wf1.vh)
+            i5i = (i5i + (u32) ((SI.i[3].hi << 3) | (SI.i[3].lo >> 61))) & 0x0FFFFFFFu;
+            i5q = (i5q + (u32) ((SQ.i[3].hi << 3) | (SQ.i[3].lo >> 61))) & 0x0FFFFFFFu;
+            const u64 cnt = cnt0 + (u64) (t - s0) + 1;   // samples consumed including this one
+            if ((cnt & Rm1) == 0) {                       // strobe: sample_no == R - 1
+                const long o = (long) (cnt >> log2r) - 1;
+                c0rel[c0off[li] + o] = i5i;
+                c0rel[c0off[li] + nouts[li] + o] = i5q;
+            }
+        }
+    }
+    if (PASS_B) {
+        tau[((long) li * 2 + 0) * nruns + r] = i5i;
+        tau[((long) li * 2 + 1) * nruns + r] = i5q;
+    } else {
+        local[((long) li * 2 + 0) * nruns + r] = SI;
+        local[((long) li * 2 + 1) * nruns + r] = SQ;
+    }
+}
+
+// Carry scan of the integrator states and prefix sum of the run totals.
+// One wave per (channel, I/Q).  MODE 0: states (after pass A), MODE 1: tau (after pass B).
+DDC_DEV u64 shfl_up64(u64 v, int d)
+{
+    const u32 lo = __shfl_up((u32) v, d), hi = __shfl_up((u32) (v >> 32), d);
+    return ((u64) hi << 32) | lo;
+}
+DDC_DEV ddc_state4 shfl_up_state(const ddc_state4 &s, int d)
+{
+    ddc_state4 r;
+    for (int k = 0; k < 4; k++) { r.i[k].lo = shfl_up64(s.i[k].lo, d); r.i[k].hi = shfl_up64(s.i[k].hi, d); }
+    return r;
+}
+
+__global__ __launch_bounds__(64) void ddc_wf_scan_states_kernel(
+    ddc_state4 *__restrict__ local, long n, int L, int nruns, ddc_chan *__restrict__ chans,
+    const int *__restrict__ chan_list)
+{
+    const int li = blockIdx.x >> 1, comp = blockIdx.x & 1, lane = threadIdx.x;
+    ddc_chan *ch = chans + chan_list[li];
+    if (ch->log2r == 0) return;
+    ddc_state4 *st = local + ((long) li * 2 + comp) * nruns;
+    const int per = (nruns + 63) / 64;
+    const int r0 = lane * per, r1 = (r0 + per < nruns) ? r0 + per : nruns;
+    auto run_len = [&](int r) -> u64 { const long s0 = (long) r * L; return (u64) ((s0 + L < n ? s0 + L : n) - s0); };
+    // 1. lane-local composition
+    ddc_state4 acc; u64 len = 0;
+    for (int k = 0; k < 4; k++) acc.i[k] = mk128(0, 0);
+    for (int r = r0; r < r1; r++) { const u64 l = run_len(r); acc = ddc_add(ddc_T(l, acc), st[r]); len += l; }
+    // 2. inclusive wave scan: earlier lanes first
+    ddc_state4 inc = acc; u64 ilen = len;
+    for (int d = 1; d < 64; d <<= 1) {
+        const ddc_state4 a = shfl_up_state(inc, d);
+        const u64 alen = shfl_up64(ilen, d);
+        if (lane >= d) { inc = ddc_add(ddc_T(ilen, a), inc); ilen += alen; }
+    }
+    // exclusive prefix of this lane = inclusive of lane - 1, then the saved state in front
+    ddc_state4 exc = shfl_up_state(inc, 1); u64 elen = shfl_up64(ilen, 1);
+    if (lane == 0) { for (int k = 0; k < 4; k++) exc.i[k] = mk128(0, 0); elen = 0; }
+    ddc_state4 c = ddc_add(ddc_T(elen, ch->integ[comp]), exc);
+    // 3. per-run carried states
+    for (int r = r0; r < r1; r++) {
+        const ddc_state4 e = st[r];
+        st[r] = c;
+        c = ddc_add(ddc_T(run_len(r), c), e);
+    }
+    // the lane that owns the last run holds the end state
+    if (r1 == nruns && r0 < nruns) ch->integ[comp] = c;
+}
+
+__global__ __launch_bounds__(64) void ddc_wf_scan_tau_kernel(
+    u32 *__restrict__ tau, int nruns, ddc_chan *__restrict__ chans, const int *__restrict__ chan_list)
+{
+    const int li = blockIdx.x >> 1, comp = blockIdx.x & 1, lane = threadIdx.x;
+    ddc_chan *ch = chans + chan_list[li];
+    if (ch->log2r == 0) return;
+    u32 *tv = tau + ((long) li * 2 + comp) * nruns;
+    const int per = (nruns + 63) / 64;
+    const int r0 = lane * per, r1 = (r0 + per < nruns) ? r0 + per : nruns;
+    u32 acc = 0;
+    for (int r = r0; r < r1; r++) acc += tv[r];
+    u32 inc = acc;
+    for (int d = 1; d < 64; d <<= 1) { const u32 a = __shfl_up(inc, d); if (lane >= d) inc += a; }
+    u32 c = __shfl_up(inc, 1);
+    if (lane == 0) c = 0;
+    c = (c + ch->integ5[comp]) & 0x0FFFFFFFu;
+    for (int r = r0; r < r1; r++) { const u32 e = tv[r]; tv[r] = c; c = (c + e) & 0x0FFFFFFFu; }   // tv[r] = I5 at run start
+    if (r1 == nruns && r0 < nruns) ch->integ5[comp] = c;
+}
+
+// sign-extend the low `bits` bits
+DDC_DEV int sext32(int v, int bits) { return (v << (32 - bits)) >> (32 - bits); }
+
+// Combs + rounding, one thread per (channel, output).  cic_wf1.vh: comb widths
+// 23,22,21,20,20; their inputs drop 5,1,1,1,0 LSBs; out = comb5[19 -: 16] + comb5[3].
+__global__ __launch_bounds__(256) void ddc_wf_comb_kernel(
+    const u32 *__restrict__ c0rel, const u32 *__restrict__ i5start, int L, int nruns,
+    const long *__restrict__ c0off, const ddc_chan *__restrict__ chans, const int *__restrict__ chan_list, const long *__restrict__ nouts,
+    const u32 *__restrict__ cnt_before,       // [nlist] sample_no before this call
+    short2 *__restrict__ out, long out_stride, u32 *__restrict__ hist_out)   // [nlist][2][5]
+{
+    const int li = blockIdx.y;
+    const ddc_chan *ch = chans + chan_list[li];
+    const int log2r = ch->log2r;
+    if (log2r == 0) return;
+    const long nout = nouts[li];
+    const long o = (long) blockIdx.x * 256 + threadIdx.x;
+    if (o >= nout) return;
+    const u32 base = cnt_before[li];
+    short res[2];
+    for (int comp = 0; comp < 2; comp++) {
+        // absolute integrator-5 values at outputs o-5 .. o
+        int c0[6];
+        for (int d = 0; d < 6; d++) {
+            const long oo = o - 5 + d;
+            u32 v;
+            if (oo < 0) {
+                v = ch->hist[comp][5 + oo];   // strobes of earlier calls (zero after a reset)
+            } else {
+                const long g = ((oo + 1) << log2r) - 1 - (long) base;    // sample index of the strobe
+                const int run = (int) (g / L);
+                v = (c0rel[c0off[li] + comp * nout + oo] + i5start[((long) li * 2 + comp) * nruns + run]) & 0x0FFFFFFFu;
+            }
+            c0[d] = sext32((int) v, 28);
+            if (o == nout - 1 && d >= 1) hist_out[((long) li * 2 + comp) * 5 + (d - 1)] = v;
+        }
+        // comb k output at position d needs its input at d and d-1
+        const int W[5] = {23, 22, 21, 20, 20}, D[5] = {5, 1, 1, 1, 0};
+        int v[6];
+        for (int d = 0; d < 6; d++) v[d] = c0[d];
+        int cnt = 6;
+        for (int k = 0; k < 5; k++) {
+            int x[6];
+            for (int d = 0; d < cnt; d++) x[d] = sext32(v[d] >> D[k], W[k]);
+            for (int d = 1; d < cnt; d++) v[d - 1] = sext32(x[d] - x[d - 1], W[k]);
+            cnt--;
+        }
+        res[comp] = (short) ((v[0] >> 4) + ((v[0] >> 3) & 1));
+    }
+    out[(long) li * out_stride + o] = make_short2(res[0], res[1]);
+}
+
+// after a call: phase, counter, comb history
+__global__ void ddc_wf_finish_kernel(ddc_chan *__restrict__ chans, const int *__restrict__ chan_list, int nlist,
+                                     long n, const long *__restrict__ nouts, const u32 *__restrict__ hist_new)
+{
+    const int li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= nlist) return;
+    ddc_chan *ch = chans + chan_list[li];
+    const u64 M48 = (1ull << 48) - 1;
+    ch->phase = (ch->phase + (u64) n * ch->phase_inc) & M48;
+    if (ch->log2r == 0) return;
+    ch->sample_no = (u32) (((u64) ch->sample_no + (u64) n) & ((1ull << ch->log2r) - 1));
+    const long nout = nouts[li];
+    if (nout <= 0) return;
+    for (int comp = 0; comp < 2; comp++) {
+        u32 h[5];
+        for (int d = 0; d < 5; d++) {
+            // the last five strobes: fewer than five new ones keep part of the old history
+            const long back = 4 - d;             // 0 = most recent
+            if (back < nout) h[d] = hist_new[((long) li * 2 + comp) * 5 + d];
+            else h[d] = ch->hist[comp][d + nout];
+        }
+        for (int d = 0; d < 5; d++) ch->hist[comp][d] = h[d];
+    }
+}
+
+// ---------------------------------------------------------------------------
+struct kg_ddc {
+    kg_ctx *ctx;
+    int nchan;
+    long max_samples;
+    ddc_chan *d_chans;
+    std::vector<ddc_chan> h_chans;            // host mirror of the scalar fields
+    u32 *d_nco;
+    int *d_list; long *d_nouts, *d_c0off; u32 *d_cnt;
+    ddc_state4 *d_local; u32 *d_c0rel, *d_tau, *d_hist;
+    int max_runs; long c0_cap;
+};
+
+static const int DDC_RUN_MIN = 64, DDC_RUN_MAX = 8192, DDC_TARGET_RUNS = 8192;
+
+extern "C" {
+
+int kg_ddc_create(kg_ctx *ctx, int nchan, size_t max_samples, kg_ddc **out)
+{
+    int rc = kg_ctx_use(ctx);
+    if (rc) return rc;
+    KG_REQUIRE(out != nullptr, KG_ERR_INVALID, "kg_ddc_create: out is null");
+    *out = nullptr;
+    KG_REQUIRE(nchan >= 1 && nchan <= 4096, KG_ERR_INVALID, "kg_ddc_create: nchan %d", nchan);
+    KG_REQUIRE(max_samples >= 64 && max_samples <= ((size_t) 1 << 32), KG_ERR_INVALID,
+               "kg_ddc_create: max_samples %zu", max_samples);
+    kg_ddc *d = new (std::nothrow) kg_ddc();
+    KG_REQUIRE(d != nullptr, KG_ERR_NOMEM, "kg_ddc_create: alloc");
+    d->ctx = ctx; d->nchan = nchan; d->max_samples = (long) max_samples;
+    d->h_chans.assign(nchan, ddc_chan());
+    for (auto &c : d->h_chans) memset(&c, 0, sizeof c);
+    d->max_runs = (int) ((max_samples + DDC_RUN_MIN - 1) / DDC_RUN_MIN);
+    if (d->max_runs > DDC_TARGET_RUNS * 2) d->max_runs = DDC_TARGET_RUNS * 2;
+    d->c0_cap = 0; d->d_c0rel = nullptr;
+    KG_HIP(hipMalloc((void **) &d->d_chans, sizeof(ddc_chan) * nchan));
+    KG_HIP(hipMemset(d->d_chans, 0, sizeof(ddc_chan) * nchan));
+    KG_HIP(hipMalloc((void **) &d->d_nco, sizeof(u32) * 8192));
+    KG_HIP(hipMalloc((void **) &d->d_list, sizeof(int) * nchan));
+    KG_HIP(hipMalloc((void **) &d->d_nouts, sizeof(long) * nchan));
+    KG_HIP(hipMalloc((void **) &d->d_cnt, sizeof(u32) * nchan));
+    KG_HIP(hipMalloc((void **) &d->d_local, sizeof(ddc_state4) * 2 * (size_t) nchan * d->max_runs));
+    KG_HIP(hipMalloc((void **) &d->d_tau, sizeof(u32) * 2 * (size_t) nchan * d->max_runs));
+    KG_HIP(hipMalloc((void **) &d->d_c0off, sizeof(long) * nchan));
+    KG_HIP(hipMalloc((void **) &d->d_hist, sizeof(u32) * 10 * (size_t) nchan));
+    // NCO table (frozen by us; the Xilinx DDS IP is closed): round(16383 * cos/sin(2 pi a / 8192))
+    std::vector<u32> tab(8192);
+    for (int a = 0; a < 8192; a++) {
+        const double ph = 2.0 * M_PI * a / 8192.0;
+        const short c = (short) lrint(16383.0 * cos(ph)), s = (short) lrint(16383.0 * sin(ph));
+        tab[a] = (u32) (unsigned short) c | ((u32) (unsigned short) s << 16);
+    }
+    KG_HIP(hipMemcpy(d->d_nco, tab.data(), sizeof(u32) * 8192, hipMemcpyHostToDevice));
+    *out = d;
+    return KG_OK;
+}
+
+void kg_ddc_destroy(kg_ddc *d)
+{
+    if (!d) return;
+    (void) hipSetDevice(d->ctx->device);
+    (void) hipStreamSynchronize(d->ctx->stream);
+    (void) hipFree(d->d_chans); (void) hipFree(d->d_nco); (void) hipFree(d->d_list);
+    (void) hipFree(d->d_nouts); (void) hipFree(d->d_cnt); (void) hipFree(d->d_local);
+    (void) hipFree(d->d_tau); (void) hipFree(d->d_c0rel); (void) hipFree(d->d_hist);
+    (void) hipFree(d->d_c0off);
+    delete d;
+}
+
+static int ddc_upload(kg_ddc *d, int ch)
+{
+    hipStream_t st = d->ctx->stream;
+    KG_HIP(hipStreamSynchronize(st));
+    KG_HIP(hipMemcpy(d->d_chans + ch, &d->h_chans[ch], sizeof(ddc_chan), hipMemcpyHostToDevice));
+    return KG_OK;
+}
+
+int kg_ddc_set_wf(kg_ddc *d, int ch, uint64_t phase_inc, int decim)
+{
+    KG_REQUIRE(d != nullptr, KG_ERR_INVALID, "kg_ddc_set_wf: null argument");
+    int rc = kg_ctx_use(d->ctx);
+    if (rc) return rc;
+    KG_REQUIRE(ch >= 0 && ch < d->nchan, KG_ERR_INVALID, "kg_ddc_set_wf: channel %d (0..%d)", ch, d->nchan - 1);
+    int log2r = -1;
+    for (int k = 0; k <= 13; k++) if (decim == (1 << k)) log2r = k;
+    KG_REQUIRE(log2r >= 0, KG_ERR_INVALID, "kg_ddc_set_wf: decimation %d is not 1, 2, 4 .. 8192", decim);
+    // changing the rate or frequency resets the sampler, as sample_wf() does (CmdWFReset, :1005)
+    ddc_chan &c = d->h_chans[ch];
+    memset(&c, 0, sizeof c);
+    c.phase_inc = phase_inc & ((1ull << 48) - 1);
+    c.log2r = log2r;
+    c.active = 1;
+    return ddc_upload(d, ch);
+}
+
+int kg_ddc_reset_wf(kg_ddc *d, int ch)
+{
+    KG_REQUIRE(d != nullptr, KG_ERR_INVALID, "kg_ddc_reset_wf: null argument");
+    int rc = kg_ctx_use(d->ctx);
+    if (rc) return rc;
+    KG_REQUIRE(ch >= 0 && ch < d->nchan && d->h_chans[ch].active, KG_ERR_INVALID,
+               "kg_ddc_reset_wf: channel %d is not configured", ch);
+    // rst_wf_samp_wr (waterfall_1cic.v:47): CIC registers and the decimation counter; the NCO
+    // phase keeps running in the FPGA -- the device copy holds it, so read it back first
+    hipStream_t st = d->ctx->stream;
+    KG_HIP(hipStreamSynchronize(st));
+    ddc_chan cur;
+    KG_HIP(hipMemcpy(&cur, d->d_chans + ch, sizeof cur, hipMemcpyDeviceToHost));
+    ddc_chan &c = d->h_chans[ch];
+    const u64 inc = c.phase_inc; const int l2 = c.log2r;
+    memset(&c, 0, sizeof c);
+    c.phase = cur.phase; c.phase_inc = inc; c.log2r = l2; c.active = 1;
+    return ddc_upload(d, ch);
+}
+
+int kg_ddc_set_phase(kg_ddc *d, int ch, uint64_t phase)
+{
+    KG_REQUIRE(d != nullptr && ch >= 0 && ch < d->nchan && d->h_chans[ch].active, KG_ERR_INVALID,
+               "kg_ddc_set_phase: channel %d is not configured", ch);
+    int rc = kg_ctx_use(d->ctx);
+    if (rc) return rc;
+    hipStream_t st = d->ctx->stream;
+    KG_HIP(hipStreamSynchronize(st));
+    const u64 p = phase & ((1ull << 48) - 1);
+    KG_HIP(hipMemcpy(&d->d_chans[ch].phase, &p, sizeof p, hipMemcpyHostToDevice));
+    return KG_OK;
+}
+
+// Number of IQ pairs channel ch will produce for the next n samples.
+long kg_ddc_wf_outputs(kg_ddc *d, int ch, size_t n)
+{
+    if (!d || ch < 0 || ch >= d->nchan || !d->h_chans[ch].active) return KG_ERR_INVALID;
+    const ddc_chan &c = d->h_chans[ch];
+    return (long) (((u64) c.sample_no + (u64) n) >> c.log2r);
+}
+
+int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *chan_list, int nlist,
+                       void *d_out, size_t out_stride, int64_t *nouts)
+{
+    KG_REQUIRE(d && d_adc && chan_list && d_out, KG_ERR_INVALID, "kg_ddc_wf_push_dev: null argument");
+    int rc = kg_ctx_use(d->ctx);
+    if (rc) return rc;
+    KG_REQUIRE(n >= 1 && (long) n <= d->max_samples, KG_ERR_INVALID, "kg_ddc_wf_push_dev: n %zu (max %ld)", n, d->max_samples);
+    KG_REQUIRE(nlist >= 1 && nlist <= d->nchan, KG_ERR_INVALID, "kg_ddc_wf_push_dev: nlist %d", nlist);
+    KG_REQUIRE(((uintptr_t) d_adc & 1) == 0 && ((uintptr_t) d_out & 3) == 0, KG_ERR_INVALID,
+               "kg_ddc_wf_push_dev: misaligned pointer");
+    std::vector<long> h_nouts(nlist), h_off(nlist);
+    std::vector<u32> h_cnt(nlist);
+    long max_nout = 0, c0_need = 0;
+    for (int i = 0; i < nlist; i++) {
+        const int ch = chan_list[i];
+        KG_REQUIRE(ch >= 0 && ch < d->nchan && d->h_chans[ch].active, KG_ERR_STATE,
+                   "kg_ddc_wf_push_dev: channel %d is not configured", ch);
+        for (int j = 0; j < i; j++) KG_REQUIRE(chan_list[j] != ch, KG_ERR_INVALID, "kg_ddc_wf_push_dev: channel %d listed twice", ch);
+        const ddc_chan &c = d->h_chans[ch];
+        h_cnt[i] = c.sample_no;
+        h_nouts[i] = (long) (((u64) c.sample_no + (u64) n) >> c.log2r);
+        KG_REQUIRE((size_t) h_nouts[i] <= out_stride, KG_ERR_INVALID,
+                   "kg_ddc_wf_push_dev: out_stride %zu < %ld outputs of channel %d", out_stride, h_nouts[i], ch);
+        if (h_nouts[i] > max_nout) max_nout = h_nouts[i];
+        if (nouts) nouts[i] = h_nouts[i];
+        h_off[i] = c0_need;
+        if (c.log2r) c0_need += 2 * h_nouts[i];
+    }
+    hipStream_t st = d->ctx->stream;
+    if (c0_need > d->c0_cap) {
+        KG_HIP(hipStreamSynchronize(st));
+        (void) hipFree(d->d_c0rel);
+        KG_HIP(hipMalloc((void **) &d->d_c0rel, sizeof(u32) * (size_t) (c0_need + 16)));
+        d->c0_cap = c0_need;
+    }
+    // run length: a power of two between 64 and 8192, about 8192 runs per call
+    int L = DDC_RUN_MIN;
+    while (L < DDC_RUN_MAX && (long) ((n + L - 1) / L) > DDC_TARGET_RUNS) L <<= 1;
+    const int nruns = (int) ((n + L - 1) / L);
+    KG_REQUIRE(nruns <= d->max_runs, KG_ERR_INVALID, "kg_ddc_wf_push_dev: %d runs > %d", nruns, d->max_runs);
+    KG_HIP(hipMemcpyAsync(d->d_c0off, h_off.data(), sizeof(long) * nlist, hipMemcpyHostToDevice, st));
+    KG_HIP(hipMemcpyAsync(d->d_list, chan_list, sizeof(int) * nlist, hipMemcpyHostToDevice, st));
+    KG_HIP(hipMemcpyAsync(d->d_nouts, h_nouts.data(), sizeof(long) * nlist, hipMemcpyHostToDevice, st));
+    KG_HIP(hipMemcpyAsync(d->d_cnt, h_cnt.data(), sizeof(u32) * nlist, hipMemcpyHostToDevice, st));
+    KG_HIP(hipStreamSynchronize(st));         // the host vectors go out of scope
+    const dim3 grid((nruns + DDC_THREADS - 1) / DDC_THREADS, nlist);
+    hipLaunchKernelGGL(ddc_wf_run_kernel<false>, grid, dim3(DDC_THREADS), 0, st, (const short *) d_adc, (long) n, L,
+                       nruns, (const ddc_chan *) d->d_chans, (const int *) d->d_list, (const u32 *) d->d_nco,
+                       d->d_local, d->d_c0rel, d->d_tau, (const long *) d->d_c0off, (const long *) d->d_nouts,
+                       (short2 *) d_out, (long) out_stride);
+    KG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(ddc_wf_scan_states_kernel, dim3(2 * nlist), dim3(64), 0, st, d->d_local, (long) n, L, nruns,
+                       d->d_chans, (const int *) d->d_list);
+    KG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(ddc_wf_run_kernel<true>, grid, dim3(DDC_THREADS), 0, st, (const short *) d_adc, (long) n, L,
+                       nruns, (const ddc_chan *) d->d_chans, (const int *) d->d_list, (const u32 *) d->d_nco,
+                       d->d_local, d->d_c0rel, d->d_tau, (const long *) d->d_c0off, (const long *) d->d_nouts,
+                       (short2 *) d_out, (long) out_stride);
+    KG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(ddc_wf_scan_tau_kernel, dim3(2 * nlist), dim3(64), 0, st, d->d_tau, nruns, d->d_chans,
+                       (const int *) d->d_list);
+    KG_HIP(hipGetLastError());
+    if (max_nout > 0) {
+        hipLaunchKernelGGL(ddc_wf_comb_kernel, dim3((unsigned) ((max_nout + 255) / 256), nlist), dim3(256), 0, st,
+                           (const u32 *) d->d_c0rel, (const u32 *) d->d_tau, L, nruns, (const long *) d->d_c0off,
+                           (const ddc_chan *) d->d_chans, (const int *) d->d_list, (const long *) d->d_nouts,
+                           (const u32 *) d->d_cnt, (short2 *) d_out, (long) out_stride, d->d_hist);
+        KG_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(ddc_wf_finish_kernel, dim3((nlist + 63) / 64), dim3(64), 0, st, d->d_chans,
+                       (const int *) d->d_list, nlist, (long) n, (const long *) d->d_nouts, (const u32 *) d->d_hist);
+    KG_HIP(hipGetLastError());
+    // host mirror of the scalar state
+    for (int i = 0; i < nlist; i++) {
+        ddc_chan &c = d->h_chans[chan_list[i]];
+        if (c.log2r) c.sample_no = (u32) (((u64) c.sample_no + (u64) n) & ((1ull << c.log2r) - 1));
+    }
+    return KG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+"""Host-side mirror of the waterfall DDC control path over the C ABI.
+
+In the reference the DDC is FPGA fabric (verilog/rx/waterfall_1cic.v) driven by
+SPI commands from c2s_waterfall()/sample_wf() (rx/rx_waterfall.cpp):
+  spi_set(CmdSetWFDecim, rx_chan, decim)                 :466   ->  Ddc.set_wf(ch, inc, decim)
+  spi_set3(CmdSetWFFreq, rx_chan, i_offset hi32, lo16)   :507   ->  Ddc.set_wf(...)
+  spi_set(CmdWFReset, rx_chan, WF_SAMP_RD_RST|WR_RST..)  :1005  ->  Ddc.reset(ch)
+  spi_get_noduplex(CmdGetWFSamples, ...) x 9             :1036  ->  Ddc.push(adc) -> iq_t arrays
+push_dev() takes device pointers (from kg_dev_alloc or any HIP allocator).
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import Context, check, ptr
+
+
+class Ddc:
+    def __init__(self, ctx=None, nchan=4, max_samples=1 << 24, device=0):
+        self.ctx = ctx if ctx is not None else Context(device)
+        self.lib = self.ctx.lib
+        self.nchan, self.max_samples = nchan, max_samples
+        h = C.c_void_p()
+        check(self.lib.kg_ddc_create(self.ctx.h, int(nchan), int(max_samples), C.byref(h)),
+              "kg_ddc_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.kg_ddc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_wf(self, ch, phase_inc, decim):
+        check(self.lib.kg_ddc_set_wf(self.h, int(ch), int(phase_inc) & ((1 << 48) - 1), int(decim)),
+              "kg_ddc_set_wf")
+
+    def reset(self, ch):
+        check(self.lib.kg_ddc_reset_wf(self.h, int(ch)), "kg_ddc_reset_wf")
+
+    def set_phase(self, ch, phase):
+        check(self.lib.kg_ddc_set_phase(self.h, int(ch), int(phase) & ((1 << 48) - 1)),
+              "kg_ddc_set_phase")
+
+    def outputs(self, ch, n):
+        return check(self.lib.kg_ddc_wf_outputs(self.h, int(ch), int(n)), "kg_ddc_wf_outputs")
+
+    def push_dev(self, d_adc, n, chans, d_out, out_stride):
+        """Device pointers (ints).  Returns the per-channel output counts."""
+        chans = np.ascontiguousarray(chans, np.int32)
+        nouts = np.zeros(chans.size, np.int64)
+        check(self.lib.kg_ddc_wf_push_dev(self.h, ptr(int(d_adc)), int(n), ptr(chans), chans.size,
+                                          ptr(int(d_out)), int(out_stride), ptr(nouts)),
+              "kg_ddc_wf_push_dev")
+        return nouts
+
+    def push(self, adc, chans):
+        """Convenience for tests: host int16 array in, list of [nout, 2] int16 arrays out."""
+        adc = np.ascontiguousarray(adc, np.int16)
+        stride = max(int(self.outputs(c, adc.size)) for c in chans) + 1
+        d_adc = self.ctx.alloc(adc.nbytes)
+        d_out = self.ctx.alloc(len(chans) * stride * 4)
+        try:
+            self.ctx.upload(d_adc, adc)
+            nouts = self.push_dev(d_adc, adc.size, chans, d_out, stride)
+            host = np.zeros((len(chans), stride, 2), np.int16)
+            self.ctx.download(d_out, host)
+        finally:
+            self.ctx.free(d_adc)
+            self.ctx.free(d_out)
+        return [host[i, :int(nouts[i])].copy() for i in range(len(chans))]

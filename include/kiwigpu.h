@@ -64,6 +64,14 @@ void *kg_ctx_stream(kg_ctx *ctx);             /* the hipStream_t in use */
 int kg_ctx_device_name(kg_ctx *ctx, char *buf, size_t len);
 int kg_ctx_num_cus(kg_ctx *ctx);
 
+/* Device-memory helpers for callers that do not bring their own HIP runtime
+ * (the reference's host is plain C++): allocate / free HBM, blocking copies on
+ * the context's stream. */
+int kg_dev_alloc(kg_ctx *ctx, size_t bytes, void **out);
+int kg_dev_free(kg_ctx *ctx, void *ptr);
+int kg_dev_upload(kg_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int kg_dev_download(kg_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
 /* HIP-event stopwatch on the context's stream (bench.py and C++ callers). */
 int kg_timer_start(kg_ctx *ctx);
 int kg_timer_stop(kg_ctx *ctx, float *elapsed_ms);    /* synchronises on the stop event */
@@ -192,6 +200,35 @@ int kg_wf_frames(kg_wf *wf, int nframes, const int32_t *chan_of, const int16_t *
  * below fft_used are written), pwr_out[1024], dB[1024] (before the clamp). */
 int kg_wf_debug_frame(kg_wf *wf, int ch, const int16_t *iq, uint8_t *out, float *pwr,
                       float *pwr_out, float *dB);
+
+/* ------------------------------------------------------------------------ */
+/* Waterfall DDC.  In the reference this is FPGA fabric behind SPI commands:   */
+/* WATERFALL_1CIC (verilog/rx/waterfall_1cic.v:20-144) = IQ_MIXER (iq_mixer.v)  */
+/* + cic_prune_var "wf1" (cic_prune_var.v, cic_wf1.vh) + IQ_SAMPLER_8K_32B,     */
+/* programmed with CmdSetWFFreq / CmdSetWFDecim / CmdWFReset and read with      */
+/* CmdGetWFSamples (rx/rx_waterfall.cpp:466,507,1005,1036).  Here the ADC        */
+/* stream is an int16 array in HBM and every listed channel is computed from it. */
+/* ------------------------------------------------------------------------ */
+typedef struct kg_ddc kg_ddc;
+
+int kg_ddc_create(kg_ctx *ctx, int nchan, size_t max_samples, kg_ddc **out);
+void kg_ddc_destroy(kg_ddc *ddc);
+/* CmdSetWFFreq (48-bit phase increment, i_offset of rx_waterfall.cpp:498-507) and
+ * CmdSetWFDecim (R = 1, 2, 4 .. 8192).  Also resets the channel (phase = 0). */
+int kg_ddc_set_wf(kg_ddc *ddc, int ch, uint64_t phase_inc, int decim);
+/* CmdWFReset with WF_SAMP_WR_RST: zero the CIC registers and the decimation
+ * counter; the NCO phase keeps running. */
+int kg_ddc_reset_wf(kg_ddc *ddc, int ch);
+int kg_ddc_set_phase(kg_ddc *ddc, int ch, uint64_t phase);
+/* IQ pairs channel ch will produce for the next n ADC samples. */
+long kg_ddc_wf_outputs(kg_ddc *ddc, int ch, size_t n);
+/* Run n ADC samples (device int16 array) through the listed channels.  Channel
+ * chan_list[i] writes its IQ pairs {int16 i, int16 q} (struct iq_t) to
+ * d_out + i*out_stride (in pairs); nouts[i] (may be NULL) receives the count.
+ * State (NCO phase, CIC registers, decimation phase) carries over to the next
+ * call, so a stream may be pushed in pieces of any length.  Enqueue only. */
+int kg_ddc_wf_push_dev(kg_ddc *ddc, const void *d_adc, size_t n, const int32_t *chan_list,
+                       int nlist, void *d_out, size_t out_stride, int64_t *nouts);
 
 /* Diagnostics: re-runs the 4096-point stage of the forward FFT of `block` in a
  * stamped build of the kernel and returns 4 s_memrealtime readings (100 MHz):

@@ -144,6 +144,25 @@ void ko_wf_window_iq(const int16_t *iq, const float *window, ko_cpx *out);   /* 
 void ko_wf_compute_frame(const ko_wf_cfg *wf, const ko_cpx *samps, uint8_t *out,
                          float *pwr_dbg, float *pwr_out_dbg, float *dB_dbg, int prec);
 
+/* ---- waterfall DDC (verilog/rx: iq_mixer.v, cic_prune_var.v, cic_wf1.vh) ---- */
+typedef struct {
+    uint64_t integ[4][2];        /* integrators 1-4, 89 bits kept in 128 (lo, hi)  */
+    uint32_t integ5;             /* integrator 5, 28 bits                          */
+    int64_t comb_prev[5];        /* cic_comb.v prev_data of combs 1-5              */
+} ko_ddc_cic_state;
+
+typedef struct {
+    uint64_t phase;              /* 48-bit NCO accumulator (phase of the next sample) */
+    uint64_t n;                  /* samples consumed                                   */
+    uint32_t sample_no;          /* decimation counter, cic_prune_var.v:65-80          */
+    ko_ddc_cic_state cic[2];     /* I and Q                                            */
+} ko_ddc_wf_state;
+
+void ko_ddc_nco_table(int16_t *cos_tab, int16_t *sin_tab);     /* 8192 entries each */
+void ko_ddc_wf_reset(ko_ddc_wf_state *s);
+int ko_ddc_wf(ko_ddc_wf_state *s, const int16_t *adc, long n, uint64_t phase_inc, int log2r,
+              int16_t *out);
+
 #ifdef __cplusplus
 }
 #endif

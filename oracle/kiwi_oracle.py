@@ -244,6 +244,38 @@ def wf_compute_frame(samps, zoom, window_func, interp, cic_comp_on, overlapped, 
     return out, pwr, pwr_out, dB
 
 
+# ---- waterfall DDC ---------------------------------------------------------------
+class DdcCicState(C.Structure):
+    _fields_ = [("integ", (C.c_uint64 * 2) * 4), ("integ5", C.c_uint32),
+                ("comb_prev", C.c_int64 * 5)]
+
+
+class DdcWfState(C.Structure):
+    _fields_ = [("phase", C.c_uint64), ("n", C.c_uint64), ("sample_no", C.c_uint32),
+                ("cic", DdcCicState * 2)]
+
+
+def ddc_nco_table():
+    c = np.empty(8192, np.int16)
+    s = np.empty(8192, np.int16)
+    lib().ko_ddc_nco_table(_p(c), _p(s))
+    return c, s
+
+
+def ddc_wf(adc, phase_inc, log2r, state=None):
+    """-> (iq int16 [nout, 2], state).  state None = reset (rst_wf_samp_wr)."""
+    L = lib()
+    L.ko_ddc_wf.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_uint64, C.c_int, C.c_void_p]
+    L.ko_ddc_wf.restype = C.c_int
+    adc = np.ascontiguousarray(adc, np.int16)
+    if state is None:
+        state = DdcWfState()
+    out = np.empty((adc.size >> log2r) + 2, dtype=[("i", "<i2"), ("q", "<i2")])
+    n = L.ko_ddc_wf(C.byref(state), _p(adc), adc.size, C.c_uint64(phase_inc & ((1 << 48) - 1)),
+                    int(log2r), _p(out))
+    return out[:n].view(np.int16).reshape(n, 2).copy(), state
+
+
 def ref_cacode(t0, t1):
     """Chips from the REFERENCE's own gps/cacode.h (oracle/_ref/cacode_ref), or None."""
     exe = os.path.join(_HERE, "_ref", "cacode_ref")

@@ -268,3 +268,24 @@ def test_wf_oracle_tone_lands_on_the_right_pixel(oracle):
                                                     p.fft_offset, wf.cic_comp_table())
     assert int(np.argmax(pwr)) == b and int(np.argmax(out)) == p.plot_width * b // p.fft_used
     assert out.min() >= 55
+
+
+# ---- DDC oracle self-checks -----------------------------------------------------
+def test_ddc_oracle_gain_and_state_carry(oracle):
+    n = 1 << 16
+    t = np.arange(n)
+    adc = np.rint(20000 * np.cos(2 * np.pi * 0.111 * t + 0.3)).astype(np.int16)
+    inc = (-int(round(0.111 * 2 ** 48))) & ((1 << 48) - 1)
+    for log2r in (4, 9):
+        iq, _ = oracle.ddc_wf(adc, inc, log2r)
+        z = iq[8:, 0] + 1j * iq[8:, 1]
+        assert abs(np.abs(z).mean() / 20000 - 0.5) < 2e-3       # real tone -> half amplitude at DC
+        assert np.abs(z - z.mean()).std() < 1.0
+    whole, _ = oracle.ddc_wf(adc, inc, 6)
+    st, parts = None, []
+    for k in range(0, n, 7777):
+        p, st = oracle.ddc_wf(adc[k:k + 7777], inc, 6, st)
+        parts.append(p)
+    assert np.array_equal(np.concatenate(parts), whole)
+    c, s = oracle.ddc_nco_table()
+    assert c[0] == 16383 and s[2048] == 16383 and c[4096] == -16383 and abs(int(c[2048])) == 0
