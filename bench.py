@@ -119,9 +119,57 @@ def bench_waterfall(args):
     ctx.close()
 
 
+def bench_ddc(args):
+    """Secondary workload: BASELINE configs[2] -- 14 waterfall channels, NCO mix + CIC
+    decimate (+ 8192-pt FFT frames) on a synthetic 16-bit ADC stream resident in HBM.
+        python bench.py --workload ddc [--log2n 24]"""
+    import torch
+    from flydog_sdr_gps_amd import Context, Ddc, Waterfall, WfParams, wf
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    ctx = Context(0, torch.cuda.current_stream(dev).cuda_stream)
+    zooms = [0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14]
+    n = 1 << args.log2n
+    rng = np.random.Generator(np.random.PCG64(0x5EED0003))
+    t = np.arange(n, dtype=np.float64)
+    x = rng.normal(0, 10.0, n)
+    for f, a in ((0.0123, 3000.0), (0.071, 300.0), (0.2003, 30.0), (0.31, 3.0)):
+        x += a * np.cos(2 * np.pi * f * t)
+    adc = torch.from_numpy(np.clip(np.rint(x), -32768, 32767).astype(np.int16)).to(dev)
+    d = Ddc(ctx, nchan=len(zooms), max_samples=n)
+    chans = list(range(len(zooms)))
+    for ch, z in enumerate(zooms):
+        p = WfParams.for_zoom(z, 1.0e6 * ch, adc_clock=66.6666e6, ui_srate=30.0e6)
+        d.set_wf(ch, p.i_offset, p.decim)
+    stride = n + 1
+    out = torch.zeros((len(zooms), stride, 2), dtype=torch.int16, device=dev)
+    for _ in range(args.warmup):
+        d.push_dev(adc.data_ptr(), n, chans, out.data_ptr(), stride)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for _ in range(args.steps):
+        d.push_dev(adc.data_ptr(), n, chans, out.data_ptr(), stride)
+    ms = ctx.timer_stop() / args.steps
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    print(json.dumps({
+        "metric": "ADC Msamples/s ingested by the 14-channel waterfall DDC (NCO mix + CIC decimate)",
+        "value": round(n * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "dtype": "int128/int32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2] DDC: %d ADC samples, 14 channels, zooms %s" % (n, zooms)},
+        "gpu_ms_per_step": round(ms, 4),
+        "x_realtime_at_66.6MSps": round(n / (ms * 1e-3) / 66.6666e6, 1),
+    }), flush=True)
+    d.close()
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="acq", choices=["acq", "waterfall"])
+    ap.add_argument("--log2n", type=int, default=24, help="ddc: log2 of the ADC samples per step")
+    ap.add_argument("--workload", default="acq", choices=["acq", "waterfall", "ddc"])
     ap.add_argument("--frames", type=int, default=512, help="waterfall: frames per channel per step")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -131,6 +179,8 @@ def main():
     args = ap.parse_args()
     if args.workload == "waterfall":
         return bench_waterfall(args)
+    if args.workload == "ddc":
+        return bench_ddc(args)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))

@@ -79,6 +79,18 @@ DDC_DEV u128 binom3(u64 j)
 
 struct ddc_state4 { u128 i[4]; };            // integrators 1..4
 
+struct ddc_coef { u128 L, c2, c3; };
+DDC_DEV ddc_coef ddc_coef_for(u64 len) { ddc_coef c; c.L = mk128(len, 0); c.c2 = binom2(len); c.c3 = binom3(len); return c; }
+DDC_DEV ddc_state4 ddc_Tc(const ddc_coef &k, const ddc_state4 &s)
+{
+    ddc_state4 r;
+    r.i[0] = s.i[0];
+    r.i[1] = add128(s.i[1], mul128(k.L, s.i[0]));
+    r.i[2] = add128(add128(s.i[2], mul128(k.L, s.i[1])), mul128(k.c2, s.i[0]));
+    r.i[3] = add128(add128(add128(s.i[3], mul128(k.L, s.i[2])), mul128(k.c2, s.i[1])), mul128(k.c3, s.i[0]));
+    return r;
+}
+
 // advance a state over len zero-input samples
 DDC_DEV ddc_state4 ddc_T(u64 len, const ddc_state4 &s)
 {
@@ -110,10 +122,11 @@ struct ddc_chan {
 };
 
 // iq_mixer.v:27-51, IN_WIDTH 16, OUT_WIDTH 24: (prod >>> 11) + prod[10], prod = (adc<<2)*(dds<<3)
+// prod = 32 * adc * dds and |adc * dds| < 2^30, so in 32-bit arithmetic: (m >> 6) + bit 5 of m
 DDC_DEV int mix24(int adc, int dds)
 {
-    const long long prod = (long long) (adc * 4) * (long long) (dds * 8);
-    return (int) ((prod >> 11) + ((prod >> 10) & 1));
+    const int m = adc * dds;
+    return (m >> 6) + ((m >> 5) & 1);
 }
 
 #define DDC_THREADS 256
@@ -166,9 +179,22 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
     }
     u32 i5i = 0, i5q = 0;
     const u64 cnt0 = (u64) ch.sample_no + (u64) s0;      // samples since the counter was last zero
+    // the run is read 16 bytes (8 samples) at a time when it is aligned (L >= 64 always is)
+    const bool vec = (((uintptr_t) (adc + s0)) & 15) == 0;
+    short buf[8];
     for (long t = s0; t < s1; t++) {
+        const int w = (int) ((t - s0) & 7);
+        if (w == 0) {
+            if (vec && t + 8 <= s1) {
+                const int4 v = *(const int4 *) (adc + t);
+                buf[0] = (short) v.x; buf[1] = (short) (v.x >> 16); buf[2] = (short) v.y; buf[3] = (short) (v.y >> 16);
+                buf[4] = (short) v.z; buf[5] = (short) (v.z >> 16); buf[6] = (short) v.w; buf[7] = (short) (v.w >> 16);
+            } else {
+                for (int q = 0; q < 8; q++) buf[q] = (t + q < s1) ? adc[t + q] : (short) 0;
+            }
+        }
         const u32 e = tab[ph >> 35];
-        const int a = adc[t];
+        const int a = buf[w];
         const long long mi = mix24(a, (short) (e & 0xffff)), mq = mix24(a, (short) (e >> 16));
         ph = (ph + ch.phase_inc) & M48;
         // in = sign-extended m << shift, 128 bits
@@ -227,7 +253,12 @@ __global__ __launch_bounds__(64) void ddc_wf_scan_states_kernel(
     // 1. lane-local composition
     ddc_state4 acc; u64 len = 0;
     for (int k = 0; k < 4; k++) acc.i[k] = mk128(0, 0);
-    for (int r = r0; r < r1; r++) { const u64 l = run_len(r); acc = ddc_add(ddc_T(l, acc), st[r]); len += l; }
+    const ddc_coef kL = ddc_coef_for((u64) L);    // every run but possibly the last has length L
+    for (int r = r0; r < r1; r++) {
+        const u64 l = run_len(r);
+        acc = ddc_add(l == (u64) L ? ddc_Tc(kL, acc) : ddc_T(l, acc), st[r]);
+        len += l;
+    }
     // 2. inclusive wave scan: earlier lanes first
     ddc_state4 inc = acc; u64 ilen = len;
     for (int d = 1; d < 64; d <<= 1) {
@@ -243,7 +274,8 @@ __global__ __launch_bounds__(64) void ddc_wf_scan_states_kernel(
     for (int r = r0; r < r1; r++) {
         const ddc_state4 e = st[r];
         st[r] = c;
-        c = ddc_add(ddc_T(run_len(r), c), e);
+        const u64 l = run_len(r);
+        c = ddc_add(l == (u64) L ? ddc_Tc(kL, c) : ddc_T(l, c), e);
     }
     // the lane that owns the last run holds the end state
     if (r1 == nruns && r0 < nruns) ch->integ[comp] = c;
@@ -275,7 +307,7 @@ DDC_DEV int sext32(int v, int bits) { return (v << (32 - bits)) >> (32 - bits); 
 // Combs + rounding, one thread per (channel, output).  cic_wf1.vh: comb widths
 // 23,22,21,20,20; their inputs drop 5,1,1,1,0 LSBs; out = comb5[19 -: 16] + comb5[3].
 __global__ __launch_bounds__(256) void ddc_wf_comb_kernel(
-    const u32 *__restrict__ c0rel, const u32 *__restrict__ i5start, int L, int nruns,
+    const u32 *__restrict__ c0rel, const u32 *__restrict__ i5start, int log2L, int nruns,
     const long *__restrict__ c0off, const ddc_chan *__restrict__ chans, const int *__restrict__ chan_list, const long *__restrict__ nouts,
     const u32 *__restrict__ cnt_before,       // [nlist] sample_no before this call
     short2 *__restrict__ out, long out_stride, u32 *__restrict__ hist_out)   // [nlist][2][5]
@@ -299,7 +331,7 @@ __global__ __launch_bounds__(256) void ddc_wf_comb_kernel(
                 v = ch->hist[comp][5 + oo];   // strobes of earlier calls (zero after a reset)
             } else {
                 const long g = ((oo + 1) << log2r) - 1 - (long) base;    // sample index of the strobe
-                const int run = (int) (g / L);
+                const int run = (int) (g >> log2L);
                 v = (c0rel[c0off[li] + comp * nout + oo] + i5start[((long) li * 2 + comp) * nruns + run]) & 0x0FFFFFFFu;
             }
             c0[d] = sext32((int) v, 28);
@@ -520,6 +552,8 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
     int L = DDC_RUN_MIN;
     while (L < DDC_RUN_MAX && (long) ((n + L - 1) / L) > DDC_TARGET_RUNS) L <<= 1;
     const int nruns = (int) ((n + L - 1) / L);
+    int log2L = 0;
+    while ((1 << log2L) < L) log2L++;
     KG_REQUIRE(nruns <= d->max_runs, KG_ERR_INVALID, "kg_ddc_wf_push_dev: %d runs > %d", nruns, d->max_runs);
     KG_HIP(hipMemcpyAsync(d->d_c0off, h_off.data(), sizeof(long) * nlist, hipMemcpyHostToDevice, st));
     KG_HIP(hipMemcpyAsync(d->d_list, chan_list, sizeof(int) * nlist, hipMemcpyHostToDevice, st));
@@ -545,7 +579,7 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
     KG_HIP(hipGetLastError());
     if (max_nout > 0) {
         hipLaunchKernelGGL(ddc_wf_comb_kernel, dim3((unsigned) ((max_nout + 255) / 256), nlist), dim3(256), 0, st,
-                           (const u32 *) d->d_c0rel, (const u32 *) d->d_tau, L, nruns, (const long *) d->d_c0off,
+                           (const u32 *) d->d_c0rel, (const u32 *) d->d_tau, log2L, nruns, (const long *) d->d_c0off,
                            (const ddc_chan *) d->d_chans, (const int *) d->d_list, (const long *) d->d_nouts,
                            (const u32 *) d->d_cnt, (short2 *) d_out, (long) out_stride, d->d_hist);
         KG_HIP(hipGetLastError());
