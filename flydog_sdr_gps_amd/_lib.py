@@ -90,6 +90,16 @@ SYMBOLS = {
     "kg_ddc_set_phase": (_i, [_vp, _i, C.c_uint64]),
     "kg_ddc_wf_outputs": (C.c_long, [_vp, _i, _sz]),
     "kg_ddc_wf_push_dev": (_i, [_vp, _vp, _sz, _vp, _i, _vp, _sz, _vp]),
+    "kg_dpump_unpack_dev": (_i, [_vp, _vp, _i, _i, _vp, C.c_float, C.c_float, C.c_float, _i, _vp, _sz]),
+    "kg_fir_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "kg_fir_destroy": (None, [_vp]),
+    "kg_fir_setup": (_i, [_vp, _i, C.c_float, C.c_float, C.c_float, C.c_float, _i, _i, _i]),
+    "kg_fir_set_coef": (_i, [_vp, _i, _vp]),
+    "kg_fir_get_coef": (_i, [_vp, _i, _vp]),
+    "kg_fir_reset": (_i, [_vp, _i]),
+    "kg_fir_pos": (_i, [_vp, _i]),
+    "kg_fir_process": (_i, [_vp, _i, _vp, _i, _vp]),
+    "kg_fir_process_dev": (_i, [_vp, _vp, _i, _vp, _sz, _i, _vp, _sz, _vp]),
     "kg_acq_debug_fft_stamps": (_i, [_vp, _i, _vp, _i]),
     "kg_acq_debug_corr_stamps": (_i, [_vp, _i, _vp, _i, _vp, _i]),
 }

@@ -230,6 +230,50 @@ long kg_ddc_wf_outputs(kg_ddc *ddc, int ch, size_t n);
 int kg_ddc_wf_push_dev(kg_ddc *ddc, const void *d_adc, size_t n, const int32_t *chan_list,
                        int nlist, void *d_out, size_t out_stride, int64_t *nouts);
 
+/* ------------------------------------------------------------------------ */
+/* Audio front: data-pump unpack and the CFastFIR passband filter.             */
+/* ------------------------------------------------------------------------ */
+/* snd_service() unpack (rx/data_pump.cpp:145-208): nsamps * nchans rx_iq_t records
+ * {u16 i, u16 q, u8 q3, u8 i3} (rx/data_pump.h:27-30), sample-major / channel-minor,
+ * -> out[ch][nsamps] TYPECPX: re = q*rescale + DC_offset_I, im = i*rescale +
+ * DC_offset_Q (I and Q as given when spectral_inversion).  enabled[ch] == 0 leaves
+ * that channel's output untouched (rx_channels[ch].data_enabled).  Device buffers;
+ * enabled is a host array.  Synchronous. */
+int kg_dpump_unpack_dev(kg_ctx *ctx, const void *d_raw, int nsamps, int nchans,
+                        const uint8_t *enabled, float rescale, float dc_i, float dc_q,
+                        int spectral_inversion, void *d_out, size_t out_stride);
+
+#define KG_FIR_FFT_SIZE 1024      /* CONV_FFT_SIZE, rx/CuteSDR/cuteSDR.h:12 */
+#define KG_FIR_OUT      512       /* FASTFIR_OUTBUF_SIZE, rx/CuteSDR/cuteSDR.h:14 */
+
+typedef struct kg_fir kg_fir;      /* the m_PassbandFIR[MAX_RX_CHANS] array, rx/rx_sound.cpp:150 */
+
+/* max_in: the largest InLength of one ProcessData call. */
+int kg_fir_create(kg_ctx *ctx, int nchan, int max_in, kg_fir **out);
+void kg_fir_destroy(kg_fir *fir);
+/* CFastFIR::SetupParameters(instance, FLoCut, FHiCut, Offset, SampleRate)
+ * (rx/CuteSDR/fastfir.cpp:171-232) with the window of SetupWindowFunction
+ * (:102-146; window_func < 0 = Blackman-Nuttall) and SetupCICFilter (:148-158;
+ * snd_rate_3ch selects the :70-71 constants).  Taps are designed on the host in
+ * the reference's float arithmetic, transformed on the device.  Returns 1 when the
+ * sanity check (:193-200) rejects the parameters and the old filter stays. */
+int kg_fir_setup(kg_fir *fir, int ch, float FLoCut, float FHiCut, float Offset, float SampleRate,
+                 int window_func, int do_cic_comp, int snd_rate_3ch);
+/* Or hand over the reference's own m_pFilterCoef_CIC[1024] (complex float). */
+int kg_fir_set_coef(kg_fir *fir, int ch, const float *coef_fft);
+int kg_fir_get_coef(kg_fir *fir, int ch, float *coef_fft);
+int kg_fir_reset(kg_fir *fir, int ch);
+int kg_fir_pos(kg_fir *fir, int ch);                        /* CFastFIR::FirPos(), fastfir.h:33 */
+/* CFastFIR::ProcessData(rx_chan, InLength, In, Out) (fastfir.cpp:241-324), host
+ * buffers: returns the number of complex samples written to out (0 or a multiple
+ * of 512), or a negative status. */
+int kg_fir_process(kg_fir *fir, int ch, const float *in, int n, float *out);
+/* The same for a list of channels at once, device buffers: channel chans[i] takes
+ * n samples from d_in + i*in_stride and writes nout[i] samples to d_out + i*out_stride
+ * (strides in complex samples).  Enqueue only. */
+int kg_fir_process_dev(kg_fir *fir, const int32_t *chans, int nch, const void *d_in,
+                       size_t in_stride, int n, void *d_out, size_t out_stride, int32_t *nout);
+
 /* Diagnostics: re-runs the 4096-point stage of the forward FFT of `block` in a
  * stamped build of the kernel and returns 4 s_memrealtime readings (100 MHz):
  * start, inputs + twiddles loaded, transform done, results stored. */

@@ -144,6 +144,28 @@ void ko_wf_window_iq(const int16_t *iq, const float *window, ko_cpx *out);   /* 
 void ko_wf_compute_frame(const ko_wf_cfg *wf, const ko_cpx *samps, uint8_t *out,
                          float *pwr_dbg, float *pwr_out_dbg, float *dB_dbg, int prec);
 
+/* ---- audio front: data_pump unpack, CFastFIR ---------------------------------- */
+#define KO_FIR_FFT_SIZE 1024     /* CONV_FFT_SIZE, rx/CuteSDR/cuteSDR.h:12 */
+#define KO_FIR_SIZE     513      /* CONV_FIR_SIZE, rx/CuteSDR/fastfir.h:20 */
+
+typedef struct {
+    int in_pos;                  /* m_InBufInPos                       */
+    ko_cpx buf[KO_FIR_FFT_SIZE]; /* m_pFFTBuf                          */
+    ko_cpx overlap[KO_FIR_SIZE]; /* m_pFFTOverlapBuf                   */
+} ko_fir_state;
+
+float ko_dpump_rescale(int use_cicf);
+void ko_dpump_unpack(const uint8_t *raw, int nsamps, int nchans, const uint8_t *enabled,
+                     float rescale, float dc_i, float dc_q, int spectral_inversion,
+                     ko_cpx *out, int out_stride);
+void ko_fir_cic_coeffs(int snd_rate_3ch, float *cic);
+void ko_fir_window(int window_func, float *tbl);
+int ko_fir_design(float FLoCut, float FHiCut, float Offset, float SampleRate, const float *window,
+                  int do_cic_comp, const float *cic_coeffs, ko_cpx *coef, ko_cpx *coef_cic,
+                  ko_cpx *time_coef, int prec);
+void ko_fir_reset(ko_fir_state *s);
+int ko_fir_process(ko_fir_state *s, const ko_cpx *coef_cic, const ko_cpx *in, int n, ko_cpx *out, int prec);
+
 /* ---- waterfall DDC (verilog/rx: iq_mixer.v, cic_prune_var.v, cic_wf1.vh) ---- */
 typedef struct {
     uint64_t integ[4][2];        /* integrators 1-4, 89 bits kept in 128 (lo, hi)  */

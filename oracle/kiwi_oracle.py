@@ -244,6 +244,80 @@ def wf_compute_frame(samps, zoom, window_func, interp, cic_comp_on, overlapped, 
     return out, pwr, pwr_out, dB
 
 
+# ---- audio front ------------------------------------------------------------------
+FIR_FFT_SIZE, FIR_SIZE = 1024, 513
+
+
+class FirState(C.Structure):
+    _fields_ = [("in_pos", C.c_int), ("buf", C.c_float * (2 * 1024)), ("overlap", C.c_float * (2 * 513))]
+
+
+def dpump_rescale(use_cicf=True):
+    L = lib()
+    L.ko_dpump_rescale.restype = C.c_float
+    L.ko_dpump_rescale.argtypes = [C.c_int]
+    return L.ko_dpump_rescale(int(use_cicf))
+
+
+def dpump_unpack(raw, nsamps, nchans, enabled=None, rescale=None, dc_i=0.0, dc_q=0.0,
+                 spectral_inversion=False):
+    L = lib()
+    L.ko_dpump_unpack.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float,
+                                  C.c_float, C.c_int, C.c_void_p, C.c_int]
+    raw = np.ascontiguousarray(raw, np.uint8)
+    en = np.ones(nchans, np.uint8) if enabled is None else np.ascontiguousarray(enabled, np.uint8)
+    out = np.zeros((nchans, nsamps), cpx)
+    L.ko_dpump_unpack(_p(raw), nsamps, nchans, _p(en), dpump_rescale() if rescale is None else rescale,
+                      dc_i, dc_q, int(bool(spectral_inversion)), _p(out), nsamps)
+    return out
+
+
+def fir_cic_coeffs(snd_rate_3ch=False):
+    out = np.empty(FIR_FFT_SIZE, np.float32)
+    L = lib(); L.ko_fir_cic_coeffs.argtypes = [C.c_int, C.c_void_p]
+    L.ko_fir_cic_coeffs(int(snd_rate_3ch), _p(out))
+    return out
+
+
+def fir_window(window_func=-1):
+    out = np.empty(FIR_SIZE, np.float32)
+    L = lib(); L.ko_fir_window.argtypes = [C.c_int, C.c_void_p]
+    L.ko_fir_window(int(window_func), _p(out))
+    return out
+
+
+def fir_design(lo, hi, offset, fs, window=None, do_cic_comp=False, cic=None, prec=1):
+    """-> (coef[1024], coef_cic[1024], time_coef[1024]) or None when rejected (:193-200)."""
+    L = lib()
+    L.ko_fir_design.argtypes = [C.c_float] * 4 + [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p, C.c_void_p, C.c_int]
+    L.ko_fir_design.restype = C.c_int
+    window = fir_window() if window is None else np.ascontiguousarray(window, np.float32)
+    cic = fir_cic_coeffs() if cic is None else np.ascontiguousarray(cic, np.float32)
+    coef, coef_cic, tcoef = (np.empty(FIR_FFT_SIZE, cpx) for _ in range(3))
+    rc = L.ko_fir_design(lo, hi, offset, fs, _p(window), int(do_cic_comp), _p(cic), _p(coef),
+                         _p(coef_cic), _p(tcoef), int(prec))
+    return None if rc else (coef, coef_cic, tcoef)
+
+
+def fir_new_state():
+    L = lib(); L.ko_fir_reset.argtypes = [C.c_void_p]
+    st = FirState()
+    L.ko_fir_reset(C.byref(st))
+    return st
+
+
+def fir_process(state, coef_cic, x, prec=1):
+    L = lib()
+    L.ko_fir_process.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    L.ko_fir_process.restype = C.c_int
+    x = np.ascontiguousarray(x, cpx)
+    coef_cic = np.ascontiguousarray(coef_cic, cpx)
+    out = np.empty(x.size + 1024, cpx)
+    n = L.ko_fir_process(C.byref(state), _p(coef_cic), _p(x), x.size, _p(out), int(prec))
+    return out[:n].copy(), state.in_pos - (FIR_SIZE - 1)          # FirPos(), fastfir.h:33
+
+
 # ---- waterfall DDC ---------------------------------------------------------------
 class DdcCicState(C.Structure):
     _fields_ = [("integ", (C.c_uint64 * 2) * 4), ("integ5", C.c_uint32),

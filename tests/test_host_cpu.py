@@ -289,3 +289,38 @@ def test_ddc_oracle_gain_and_state_carry(oracle):
     assert np.array_equal(np.concatenate(parts), whole)
     c, s = oracle.ddc_nco_table()
     assert c[0] == 16383 and s[2048] == 16383 and c[4096] == -16383 and abs(int(c[2048])) == 0
+
+
+# ---- audio front oracle self-checks ----------------------------------------------
+def test_fir_oracle_is_a_linear_convolution_and_counts_like_the_reference(oracle):
+    coef, coef_cic, tc = oracle.fir_design(300.0, 2700.0, 0.0, 12000.0)
+    assert np.array_equal(coef, coef_cic)                        # CIC compensation off (VAL_CICF_DECIM_BY_2 == 2)
+    f = np.fft.fftfreq(1024, 1 / 12000.0)
+    H = np.abs(coef) * 1024
+    assert abs(H[(f > 700) & (f < 2300)].mean() - 1) < 1e-3 and H[(f < 0) | (f > 3300)].max() < 1e-4
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(170 * 7) + 1j * rng.standard_normal(170 * 7)).astype(np.complex64)
+    st, sizes, pos = oracle.fir_new_state(), [], []
+    for k in range(7):
+        o, p = oracle.fir_process(st, coef_cic, x[170 * k:170 * (k + 1)])
+        sizes.append(o.size)
+        pos.append(p)
+    assert sizes == [0, 0, 0, 512, 0, 0, 512] and pos == [170, 340, 510, 168, 338, 508, 166]
+    y, _ = oracle.fir_process(oracle.fir_new_state(), coef_cic, x)
+    ref = np.convolve(x, tc[:513] * 1024)[:y.size]
+    assert np.abs(y - ref).max() / np.abs(ref).max() < 1e-6
+    assert oracle.fir_design(2700.0, 300.0, 0.0, 12000.0) is None
+    on = oracle.fir_design(300.0, 2700.0, 0.0, 12000.0, do_cic_comp=True)
+    assert not np.array_equal(on[0], on[1])
+
+
+def test_unpack_oracle_sign_extension_and_swap(oracle):
+    from flydog_sdr_gps_amd import snd
+    raw = snd.pack_rx_iq([[-1, 2 ** 23 - 1]], [[-2 ** 23, 5]])
+    r = np.float32(oracle.dpump_rescale())
+    out = oracle.dpump_unpack(raw, 1, 2)
+    assert out[0, 0] == np.complex64(complex(np.float32(-2 ** 23) * r, np.float32(-1) * r))      # re = q, im = i
+    assert out[1, 0] == np.complex64(complex(np.float32(5) * r, np.float32(2 ** 23 - 1) * r))
+    inv = oracle.dpump_unpack(raw, 1, 2, spectral_inversion=True)
+    assert inv[0, 0] == np.complex64(complex(np.float32(-1) * r, np.float32(-2 ** 23) * r))
+    assert abs(float(r) - 2 ** -8 * 10 ** 0.225) < 1e-9 and np.float32(snd.RESCALE) == r

@@ -1,0 +1,145 @@
+"""GPU parity: data-pump unpack (bit-exact) and CFastFIR (<= 1e-5 of the output's max)
+through the C ABI vs the oracle's restatement of rx/data_pump.cpp / rx/CuteSDR/fastfir.cpp."""
+import numpy as np
+import pytest
+
+from flydog_sdr_gps_amd import FastFir, snd
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+def relmax(a, b):
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+def test_unpack_bit_exact(gpu_ctx, oracle):
+    rng = np.random.default_rng(4)
+    for nsamps, nchans in ((170, 4), (85, 8), (48, 14), (226, 3)):        # config.h:40, main.cpp:400
+        i24 = rng.integers(-2 ** 23, 2 ** 23, (nsamps, nchans))
+        q24 = rng.integers(-2 ** 23, 2 ** 23, (nsamps, nchans))
+        i24[0, 0], q24[0, 0], i24[1, 0], q24[1, 0] = -2 ** 23, 2 ** 23 - 1, -1, 0
+        raw = snd.pack_rx_iq(i24, q24)
+        for inv in (False, True):
+            en = np.ones(nchans, np.uint8)
+            en[nchans - 1] = 0                                              # data_enabled = false
+            got = snd.unpack(gpu_ctx, raw, nsamps, nchans, enabled=en, dc_i=0.25, dc_q=-1.5,
+                             spectral_inversion=inv)
+            want = oracle.dpump_unpack(raw, nsamps, nchans, enabled=en, dc_i=0.25, dc_q=-1.5,
+                                       spectral_inversion=inv)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+            assert np.all(got[nchans - 1] == 0)
+    assert np.float32(snd.RESCALE) == np.float32(oracle.dpump_rescale())
+    x = snd.unpack(gpu_ctx, snd.pack_rx_iq([[5]], [[-7]]), 1, 1)
+    assert x[0, 0] == np.complex64(complex(np.float32(-7) * np.float32(snd.RESCALE), np.float32(5) * np.float32(snd.RESCALE)))
+
+
+@pytest.fixture(scope="module")
+def fir(gpu_ctx):
+    f = FastFir(gpu_ctx, nchan=8, max_in=4096)
+    yield f
+    f.close()
+
+
+@pytest.mark.parametrize("lo,hi,off,fs,win,cic", [
+    (300.0, 2700.0, 0.0, 12000.0, -1, False),          # USB
+    (-2700.0, -300.0, 0.0, 12000.0, -1, False),        # LSB
+    (-4900.0, 4900.0, 0.0, 12000.0, 3, True),          # AM wide, Hanning, CIC compensation on
+    (-200.0, 200.0, 500.0, 20250.0, 4, False),         # CW with offset, 20.25 kHz mode, Hamming
+])
+def test_setup_matches_oracle(fir, oracle, lo, hi, off, fs, win, cic):
+    assert fir.setup(0, lo, hi, off, fs, window_func=win, do_cic_comp=cic)
+    coef, coef_cic, _ = oracle.fir_design(lo, hi, off, fs, window=oracle.fir_window(win), do_cic_comp=cic)
+    assert relmax(fir.get_coef(0), coef_cic) < RTOL
+
+
+def test_setup_rejects_like_the_reference(fir):
+    assert fir.setup(1, 300.0, 2700.0, 0.0, 12000.0)
+    before = fir.get_coef(1)
+    assert not fir.setup(1, 2700.0, 300.0, 0.0, 12000.0)        # lo >= hi   (fastfir.cpp:193)
+    assert not fir.setup(1, 300.0, 6000.0, 0.0, 12000.0)        # hi >= fs/2 (:197)
+    assert np.array_equal(fir.get_coef(1), before)
+
+
+def test_process_170_sample_buffers(fir, oracle):
+    """The 4-channel data pump hands over 170 samples at a time: outputs appear as
+    0,0,0,512,0,0,512 and FirPos() runs 170,340,510,168,... (rx_sound.cpp:604-613)."""
+    fir.setup(2, 300.0, 2700.0, 0.0, 12000.0)
+    fir.reset(2)
+    _, coef_cic, _ = oracle.fir_design(300.0, 2700.0, 0.0, 12000.0)
+    st = oracle.fir_new_state()
+    rng = np.random.default_rng(9)
+    x = ((rng.standard_normal(170 * 13) + 1j * rng.standard_normal(170 * 13)) * 3000).astype(np.complex64)
+    got_pos, want_pos = [], []
+    for k in range(13):
+        seg = x[170 * k:170 * (k + 1)]
+        got = fir.process(2, seg)
+        want, pos = oracle.fir_process(st, coef_cic, seg)
+        assert got.size == want.size
+        if want.size:
+            assert relmax(got, want) < RTOL
+        got_pos.append(fir.pos(2))
+        want_pos.append(pos)
+    assert got_pos == want_pos and got_pos[:4] == [170, 340, 510, 168]
+
+
+def test_process_many_blocks_and_odd_lengths(fir, oracle):
+    fir.setup(3, -2700.0, -300.0, 0.0, 12000.0)
+    fir.reset(3)
+    _, coef_cic, tc = oracle.fir_design(-2700.0, -300.0, 0.0, 12000.0)
+    st = oracle.fir_new_state()
+    rng = np.random.default_rng(10)
+    x = ((rng.standard_normal(9000) + 1j * rng.standard_normal(9000)) * 100).astype(np.complex64)
+    pos, outs, wants = 0, [], []
+    for n in (1, 511, 512, 513, 4096, 7, 1024, 2336):
+        seg = x[pos:pos + n]
+        pos += n
+        outs.append(fir.process(3, seg))
+        wants.append(oracle.fir_process(st, coef_cic, seg)[0])
+    got, want = np.concatenate(outs), np.concatenate(wants)
+    assert got.size == want.size == (9000 // 512) * 512
+    assert relmax(got, want) < RTOL
+    # and it IS the linear convolution with the 513 designed taps
+    lin = np.convolve(x.astype(np.complex128), tc[:513].astype(np.complex128) * 1024)[:got.size]
+    assert relmax(got, lin) < 3e-6
+
+
+def test_batched_channels_device_buffers(gpu_ctx, oracle):
+    """8 channels with different passbands, one call per 512-sample hop."""
+    nch, n = 8, 1536
+    f = FastFir(gpu_ctx, nchan=nch, max_in=n)
+    rng = np.random.default_rng(11)
+    x = ((rng.standard_normal((nch, n)) + 1j * rng.standard_normal((nch, n))) * 500).astype(np.complex64)
+    coefs = []
+    for ch in range(nch):
+        lo = 100.0 + 50 * ch
+        f.setup(ch, lo, lo + 2400.0, 0.0, 12000.0)
+        coefs.append(oracle.fir_design(lo, lo + 2400.0, 0.0, 12000.0)[1])
+    d_in = gpu_ctx.alloc(x.nbytes)
+    out = np.zeros((nch, n), np.complex64)
+    d_out = gpu_ctx.alloc(out.nbytes)
+    gpu_ctx.upload(d_in, x)
+    nout = f.process_dev(list(range(nch)), d_in, n, n, d_out, n)
+    gpu_ctx.sync()
+    gpu_ctx.download(d_out, out)
+    assert np.all(nout == 1536)
+    for ch in range(nch):
+        want, _ = oracle.fir_process(oracle.fir_new_state(), coefs[ch], x[ch])
+        assert relmax(out[ch, :1536], want) < RTOL
+    gpu_ctx.free(d_in)
+    gpu_ctx.free(d_out)
+    f.close()
+
+
+def test_fir_error_paths(gpu_ctx):
+    from flydog_sdr_gps_amd import KiwiGpuError
+    f = FastFir(gpu_ctx, nchan=2, max_in=100)
+    with pytest.raises(KiwiGpuError):
+        f.process(0, np.zeros(10, np.complex64))          # no filter set
+    f.setup(0, 300.0, 2700.0, 0.0, 12000.0)
+    with pytest.raises(KiwiGpuError):
+        f.process(0, np.zeros(101, np.complex64))         # longer than max_in
+    with pytest.raises(KiwiGpuError):
+        f.setup(2, 300.0, 2700.0, 0.0, 12000.0)
+    assert f.process(0, np.zeros(0, np.complex64)).size == 0
+    f.close()

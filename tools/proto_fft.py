@@ -96,3 +96,41 @@ print("p0 write", all(wr_ok(16 * t + m) for m in range(16)))
 print("p1 read ", all(rd_ok(t + 256 * j) for j in range(16)))
 print("p1 write", all(wr_ok((t >> 4) * 256 + (t & 15) + 16 * m) for m in range(16)))
 assert len(set(P(np.arange(M)))) == M
+
+# ---- 1024 = 16 * 16 * 4 by one wave (64 threads x 16 points), kg_snd.hip -------------
+def fft1024_wave(xin, sign):
+    N, t = 1024, np.arange(64)
+    A = np.zeros(N, complex); B = np.zeros(N, complex)
+    x = np.stack([xin[t + 64 * j] for j in range(16)])
+    y = dft16(x, sign)
+    for m in range(16): A[16 * t + m] = y[m]
+    x = np.stack([A[t + 64 * j] for j in range(16)])
+    for j in range(16): x[j] = x[j] * np.exp(sign * 2j * np.pi * j * (t & 15) / 256)
+    y = dft16(x, sign)
+    for m in range(16): B[(t >> 4) * 256 + (t & 15) + 16 * m] = y[m]
+    out = np.zeros(N, complex)
+    W4 = np.exp(sign * 2j * np.pi * np.outer(np.arange(4), np.arange(4)) / 4)
+    held = {}
+    for u in range(4):
+        b = t + 64 * u
+        x = np.stack([B[b + 256 * j] * np.exp(sign * 2j * np.pi * j * b / 1024) for j in range(4)])
+        y = np.tensordot(W4, x, axes=(1, 0))
+        for m in range(4):
+            out[b + 256 * m] = y[m]
+            held[(u, m)] = b + 256 * m
+    # the positions a thread ends with are exactly the t + 64 j it starts the next transform with
+    for (u, m), pos in held.items():
+        assert np.array_equal(pos, t + 64 * (u + 4 * m))
+    return out
+
+x = rng.standard_normal(1024) + 1j * rng.standard_normal(1024)
+for sign in (+1, -1):
+    ref = np.fft.ifft(x) * 1024 if sign > 0 else np.fft.fft(x)
+    print("fft1024 sign", sign, np.abs(fft1024_wave(x, sign) - ref).max() / np.abs(ref).max())
+tt = np.arange(64)
+def rd_ok64(e): return all(len(set(P(e[g:g+32]) % 32)) == 32 for g in (0, 32))
+def wr_ok64(e): return all(len(set(P(e[g:g+16]) % 16)) == 16 for g in range(0, 64, 16))
+print("1024 p0 write", all(wr_ok64(16 * tt + m) for m in range(16)),
+      "p1 read", all(rd_ok64(tt + 64 * j) for j in range(16)),
+      "p1 write", all(wr_ok64((tt >> 4) * 256 + (tt & 15) + 16 * m) for m in range(16)),
+      "p2 read", all(rd_ok64(tt + 64 * u + 256 * j) for u in range(4) for j in range(4)))
