@@ -9,9 +9,9 @@ library and a gfx950 device, constructing a context raises.
 from ._lib import KiwiGpuError, Context, load_library, library_path  # noqa: F401
 from .acq import Searcher, AcqResult  # noqa: F401
 from .wf import Waterfall, WfParams  # noqa: F401
-from .ddc import Ddc  # noqa: F401
+from .ddc import Ddc, RxDdc  # noqa: F401
 from .snd import FastFir  # noqa: F401
 from . import sats, prn, synth, shard, wf, snd  # noqa: F401
 
-__all__ = ["KiwiGpuError", "Context", "Searcher", "AcqResult", "Waterfall", "WfParams", "Ddc", "FastFir",
+__all__ = ["KiwiGpuError", "Context", "Searcher", "AcqResult", "Waterfall", "WfParams", "Ddc", "RxDdc", "FastFir",
            "load_library", "library_path", "sats", "prn", "synth", "shard", "wf"]

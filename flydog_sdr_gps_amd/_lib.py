@@ -90,6 +90,12 @@ SYMBOLS = {
     "kg_ddc_set_phase": (_i, [_vp, _i, C.c_uint64]),
     "kg_ddc_wf_outputs": (C.c_long, [_vp, _i, _sz]),
     "kg_ddc_wf_push_dev": (_i, [_vp, _vp, _sz, _vp, _i, _vp, _sz, _vp]),
+    "kg_rxddc_create": (_i, [_vp, _i, _sz, C.POINTER(_vp)]),
+    "kg_rxddc_destroy": (None, [_vp]),
+    "kg_rxddc_set_freq": (_i, [_vp, _i, C.c_uint64]),
+    "kg_rxddc_reset": (_i, [_vp, _i]),
+    "kg_rxddc_outputs": (C.c_long, [_vp, _i, _sz]),
+    "kg_rxddc_push_dev": (_i, [_vp, _vp, _sz, _vp, _i, _vp, _sz, _vp]),
     "kg_dpump_unpack_dev": (_i, [_vp, _vp, _i, _i, _vp, C.c_float, C.c_float, C.c_float, _i, _vp, _sz]),
     "kg_fir_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
     "kg_fir_destroy": (None, [_vp]),

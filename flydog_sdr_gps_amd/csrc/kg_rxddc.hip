@@ -1,0 +1,487 @@
+// kg_rxddc.hip -- the audio digital down-converter on gfx950.
+//
+// In the reference this is FPGA fabric, one RX instance per audio channel
+// (verilog/rx/rx.v:22-178), clocked at the ADC rate:
+//   IQ_MIXER, OUT_WIDTH = RX1_BITS = 22                       (iq_mixer.v)
+//   cic_prune_var "rx1": N = 3, R = RX1_STD_DECIM = 1736      (kiwi.config:104)
+//        55-bit accumulators, integrators 55/55/26 (the third takes [54 -: 26]),
+//        combs 22/21/20 dropping 4/1/1 LSBs, out = comb3[19 -: 18] + comb3[1]
+//   cic_prune_var "rx2": N = 5, R = RX2_STD_DECIM = 3, 26 bits, out = comb5[25 -: 24] + comb5[1]
+//   fir_iq: 65 symmetric taps, 18-bit coefficients, 42-bit accumulator,
+//        out = acc[41 -: 24], every second output kept          (fir_iq.sv)
+//   output words {i[15:0]}, {q[15:0]}, {i[23:16], q[23:16]} (rx.v:172) = rx_iq_t
+// Total decimation 1736 * 3 * 2 = 10416 (RX_DECIM_4CH, kiwi.config:141).
+// The host sets the NCO with CmdSetRXFreq (rx/rx_sound_cmd.cpp:41-51) and reads
+// the records with CmdGetRX (rx/data_pump.cpp:101).
+//
+// Parallelisation: the rx1 integrators run at the ADC rate and its third one is
+// pruned (it accumulates integrator2[54 -: 26]), so -- as in kg_ddc.hip -- the
+// stream is cut into runs, run-local states are combined by an exact carry scan
+// (c1' = c1 + e1, c2' = c2 + L*c1 + e2, modulo 2^64 which keeps the low 55 bits
+// exact), the runs are integrated again from their exact states, and a prefix sum
+// of run totals gives the pruned integrator.  Everything after rx1 runs at 72 kHz
+// and is unpruned linear arithmetic in wrapping registers, i.e. exactly an FIR:
+// rx2 is the 11-tap (1 + z + z^2)^5 at stride 3 modulo 2^26, fir_iq the 65-tap
+// filter at stride 2 modulo 2^42 -- computed directly per output sample.
+#include "kg_common.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+#define RX_R1 1736
+#define RX_R2 3
+#define RX_HIST 256          // rx1 outputs kept from earlier calls (a final output spans 203 of them)
+#define RX_THREADS 256
+
+// fir_iq.sv:91-123, default (rx4 / rx8) table, taps[0..32] as 18-bit two's complement
+__constant__ int c_cicf_taps[33] = {
+    0x00071, 0x3ffae, 0x3ff5b, 0x00029, 0x000f6, 0x0002a, 0x3fea6, 0x3ff32, 0x001aa, 0x001dc, 0x3fe5a,
+    0x3fcae, 0x000fb, 0x00503, 0x000a7, 0x3f96f, 0x3fc85, 0x0076b, 0x00793, 0x3f927, 0x3f33f, 0x00401,
+    0x01296, 0x00227, 0x3e7b0, 0x3f2dd, 0x01caf, 0x0200e, 0x3e310, 0x3bb4f, 0x00c0e, 0x0aeac, 0x1036e,
+};
+// (1 + z + z^2)^5
+__constant__ int c_box3_5[11] = {1, 5, 15, 30, 45, 51, 45, 30, 15, 5, 1};
+
+struct rx_chan {
+    u64 phase, phase_inc;
+    u32 cnt1;                 // rx1 decimation counter
+    u64 i1[2], i2[2];         // rx1 integrators 1, 2 (55 bits, kept modulo 2^64)
+    u32 i3[2];                // rx1 integrator 3 (26 bits)
+    u32 hist3[2][3];          // integrator-3 values at the last three strobes (rx1 comb registers)
+    u64 n1;                   // rx1 outputs produced since reset
+    int active;
+};
+
+#define RX_DEV __device__ __forceinline__
+
+RX_DEV int mix22(int adc, int dds)            // iq_mixer.v:43-51 with OUT_WIDTH 22: (m >> 8) + bit 7
+{
+    const int m = adc * dds;
+    return (m >> 8) + ((m >> 7) & 1);
+}
+RX_DEV int sx(int v, int bits) { return (v << (32 - bits)) >> (32 - bits); }
+RX_DEV long long sx64(long long v, int bits) { return (v << (64 - bits)) >> (64 - bits); }
+
+// passes A and B of rx1.  grid = (ceil(nruns / 256), nlist)
+template <bool PASS_B>
+__global__ __launch_bounds__(RX_THREADS) void rx1_run_kernel(
+    const short *__restrict__ adc, long n, int L, int nruns, const rx_chan *__restrict__ chans,
+    const int *__restrict__ chan_list, const u32 *__restrict__ nco,
+    u64 *__restrict__ st,                     // [nlist][2 comp][2 integ][nruns]: A out, B in (carried)
+    u32 *__restrict__ c0rel, u32 *__restrict__ tau, long max_out)
+{
+    __shared__ u32 tab[8192];
+    for (int i = threadIdx.x; i < 8192; i += RX_THREADS) tab[i] = nco[i];
+    __syncthreads();
+    const int li = blockIdx.y;
+    const rx_chan ch = chans[chan_list[li]];
+    const int r = blockIdx.x * RX_THREADS + threadIdx.x;
+    if (r >= nruns) return;
+    const long s0 = (long) r * L, s1 = (s0 + L < n) ? s0 + L : n;
+    const u64 M48 = (1ull << 48) - 1;
+    u64 ph = (ch.phase + (u64) s0 * ch.phase_inc) & M48;
+    u64 a1i = 0, a2i = 0, a1q = 0, a2q = 0;
+    u64 *base = st + (long) li * 4 * nruns;
+    if (PASS_B) { a1i = base[0 * nruns + r]; a2i = base[1 * nruns + r]; a1q = base[2 * nruns + r]; a2q = base[3 * nruns + r]; }
+    u32 i3i = 0, i3q = 0;
+    const u64 c0 = (u64) ch.cnt1 + (u64) s0;
+    u32 k = (u32) (c0 % RX_R1);               // decimation counter at the run start
+    long o = (long) (c0 / RX_R1);             // strobes of this call before the run
+    const bool vec = (((uintptr_t) (adc + s0)) & 15) == 0;
+    short buf[8];
+    for (long t = s0; t < s1; t++) {
+        const int w = (int) ((t - s0) & 7);
+        if (w == 0) {
+            if (vec && t + 8 <= s1) {
+                const int4 v = *(const int4 *) (adc + t);
+                buf[0] = (short) v.x; buf[1] = (short) (v.x >> 16); buf[2] = (short) v.y; buf[3] = (short) (v.y >> 16);
+                buf[4] = (short) v.z; buf[5] = (short) (v.z >> 16); buf[6] = (short) v.w; buf[7] = (short) (v.w >> 16);
+            } else {
+                for (int q = 0; q < 8; q++) buf[q] = (t + q < s1) ? adc[t + q] : (short) 0;
+            }
+        }
+        const u32 e = tab[ph >> 35];
+        const int a = buf[w];
+        const long long mi = mix22(a, (short) (e & 0xffff)), mq = mix22(a, (short) (e >> 16));
+        ph = (ph + ch.phase_inc) & M48;
+        a1i += (u64) mi; a2i += a1i;
+        a1q += (u64) mq; a2q += a1q;
+        if (PASS_B) {
+            i3i = (i3i + (u32) (a2i >> 29)) & 0x03FFFFFFu;      // integrator2[54 -: 26]
+            i3q = (i3q + (u32) (a2q >> 29)) & 0x03FFFFFFu;
+            if (++k == RX_R1) {
+                k = 0;
+                c0rel[((long) li * 2 + 0) * max_out + o] = i3i;
+                c0rel[((long) li * 2 + 1) * max_out + o] = i3q;
+                o++;
+            }
+        }
+    }
+    if (PASS_B) {
+        tau[((long) li * 2 + 0) * nruns + r] = i3i;
+        tau[((long) li * 2 + 1) * nruns + r] = i3q;
+    } else {
+        base[0 * nruns + r] = a1i; base[1 * nruns + r] = a2i; base[2 * nruns + r] = a1q; base[3 * nruns + r] = a2q;
+    }
+}
+
+RX_DEV u64 rx_shfl_up64(u64 v, int d)
+{
+    const u32 lo = __shfl_up((u32) v, d), hi = __shfl_up((u32) (v >> 32), d);
+    return ((u64) hi << 32) | lo;
+}
+
+// carry scan of (i1, i2) per (channel, comp): one wave each
+__global__ __launch_bounds__(64) void rx1_scan_kernel(u64 *__restrict__ st, long n, int L, int nruns,
+                                                     rx_chan *__restrict__ chans, const int *__restrict__ chan_list)
+{
+    const int li = blockIdx.x >> 1, comp = blockIdx.x & 1, lane = threadIdx.x;
+    rx_chan *ch = chans + chan_list[li];
+    u64 *e1 = st + ((long) li * 4 + 2 * comp) * nruns, *e2 = e1 + nruns;
+    const int per = (nruns + 63) / 64;
+    const int r0 = lane * per, r1 = (r0 + per < nruns) ? r0 + per : nruns;
+    auto run_len = [&](int r) -> u64 { const long s0 = (long) r * L; return (u64) ((s0 + L < n ? s0 + L : n) - s0); };
+    u64 a1 = 0, a2 = 0, len = 0;
+    for (int r = r0; r < r1; r++) { const u64 l = run_len(r); a2 = a2 + l * a1 + e2[r]; a1 = a1 + e1[r]; len += l; }
+    u64 i1 = a1, i2 = a2, ilen = len;
+    for (int d = 1; d < 64; d <<= 1) {
+        const u64 p1 = rx_shfl_up64(i1, d), p2 = rx_shfl_up64(i2, d), pl = rx_shfl_up64(ilen, d);
+        if (lane >= d) { i2 = p2 + ilen * p1 + i2; i1 = p1 + i1; ilen += pl; }
+    }
+    u64 x1 = rx_shfl_up64(i1, 1), x2 = rx_shfl_up64(i2, 1), xl = rx_shfl_up64(ilen, 1);
+    if (lane == 0) { x1 = 0; x2 = 0; xl = 0; }
+    u64 c1 = ch->i1[comp] + x1, c2 = ch->i2[comp] + xl * ch->i1[comp] + x2;
+    for (int r = r0; r < r1; r++) {
+        const u64 l = run_len(r), f1 = e1[r], f2 = e2[r];
+        e1[r] = c1; e2[r] = c2;
+        c2 = c2 + l * c1 + f2; c1 = c1 + f1;
+    }
+    if (r1 == nruns && r0 < nruns) { ch->i1[comp] = c1; ch->i2[comp] = c2; }
+}
+
+__global__ __launch_bounds__(64) void rx1_scan_tau_kernel(u32 *__restrict__ tau, int nruns, rx_chan *__restrict__ chans,
+                                                         const int *__restrict__ chan_list)
+{
+    const int li = blockIdx.x >> 1, comp = blockIdx.x & 1, lane = threadIdx.x;
+    rx_chan *ch = chans + chan_list[li];
+    u32 *tv = tau + ((long) li * 2 + comp) * nruns;
+    const int per = (nruns + 63) / 64;
+    const int r0 = lane * per, r1 = (r0 + per < nruns) ? r0 + per : nruns;
+    u32 acc = 0;
+    for (int r = r0; r < r1; r++) acc += tv[r];
+    u32 inc = acc;
+    for (int d = 1; d < 64; d <<= 1) { const u32 a = __shfl_up(inc, d); if (lane >= d) inc += a; }
+    u32 c = __shfl_up(inc, 1);
+    if (lane == 0) c = 0;
+    c = (c + ch->i3[comp]) & 0x03FFFFFFu;
+    for (int r = r0; r < r1; r++) { const u32 e = tv[r]; tv[r] = c; c = (c + e) & 0x03FFFFFFu; }
+    if (r1 == nruns && r0 < nruns) ch->i3[comp] = c;
+}
+
+// rx1 combs + rounding -> 18-bit samples appended behind the channel's history.
+// one thread per (list entry, output)
+__global__ __launch_bounds__(256) void rx1_comb_kernel(
+    const u32 *__restrict__ c0rel, const u32 *__restrict__ i3start, int L, int nruns, long max_out,
+    const rx_chan *__restrict__ chans, const int *__restrict__ chan_list, const long *__restrict__ nouts,
+    const u32 *__restrict__ cnt_before, int *__restrict__ c1buf, long c1_stride, u32 *__restrict__ hist_out)
+{
+    const int li = blockIdx.y;
+    const rx_chan *ch = chans + chan_list[li];
+    const long nout = nouts[li];
+    const long o = (long) blockIdx.x * 256 + threadIdx.x;
+    if (o >= nout) return;
+    const u32 base = cnt_before[li];
+    for (int comp = 0; comp < 2; comp++) {
+        int c0[4];
+        for (int d = 0; d < 4; d++) {
+            const long oo = o - 3 + d;
+            u32 v;
+            if (oo < 0) v = ch->hist3[comp][3 + oo];
+            else {
+                const long g = (oo + 1) * RX_R1 - 1 - (long) base;      // sample index of the strobe
+                v = (c0rel[((long) li * 2 + comp) * max_out + oo] + i3start[((long) li * 2 + comp) * nruns + (int) (g / L)]) & 0x03FFFFFFu;
+            }
+            c0[d] = sx((int) v, 26);
+            if (o == nout - 1 && d >= 1) hist_out[((long) li * 2 + comp) * 3 + (d - 1)] = v;
+        }
+        const int W[3] = {22, 21, 20}, D[3] = {4, 1, 1};
+        int v[4] = {c0[0], c0[1], c0[2], c0[3]};
+        int cnt = 4;
+        for (int k = 0; k < 3; k++) {
+            int x[4];
+            for (int d = 0; d < cnt; d++) x[d] = sx(v[d] >> D[k], W[k]);
+            for (int d = 1; d < cnt; d++) v[d - 1] = sx(x[d] - x[d - 1], W[k]);
+            cnt--;
+        }
+        c1buf[((long) chan_list[li] * 2 + comp) * c1_stride + RX_HIST + o] = sx((v[0] >> 2) + ((v[0] >> 1) & 1), 18);
+    }
+}
+
+// rx2 + fir_iq + record packing: one thread per (list entry, final output)
+__global__ __launch_bounds__(128) void rx2_fir_kernel(
+    const int *__restrict__ c1buf, long c1_stride, const int *__restrict__ chan_list,
+    const long *__restrict__ n1_before,       // rx1 outputs produced before this call
+    const long *__restrict__ q_first, const int *__restrict__ nfinal,
+    unsigned short *__restrict__ out, long out_stride /* records */)
+{
+    const int li = blockIdx.y, ch = chan_list[li];
+    const int qi = blockIdx.x * 128 + threadIdx.x;
+    if (qi >= nfinal[li]) return;
+    const long q = q_first[li] + qi;          // absolute final-output index since reset
+    const long nb = n1_before[li];
+    int y[2];
+    for (int comp = 0; comp < 2; comp++) {
+        const int *c1 = c1buf + ((long) ch * 2 + comp) * c1_stride + RX_HIST;    // c1[j - nb] = absolute rx1 output j
+        long long acc = 0;
+        const long nn = 2 * q + 1;            // fir_iq input index of this output
+        for (int k = 0; k < 65; k++) {
+            const long p = nn - k;            // rx2 output index
+            int v2 = 0;
+            if (p >= 0) {
+                int s = 0;                    // rx2: sum h[m] c1[3p + 2 - m] modulo 2^26, then round to 24 bits
+                for (int m = 0; m < 11; m++) {
+                    const long j = 3 * p + 2 - m;
+                    if (j >= 0) s += c_box3_5[m] * c1[j - nb];
+                }
+                s = sx(s, 26);
+                v2 = sx((s >> 2) + ((s >> 1) & 1), 24);
+            }
+            const int coef = sx(c_cicf_taps[k <= 32 ? k : 64 - k], 18);
+            acc = sx64(acc + (long long) v2 * coef, 42);
+        }
+        y[comp] = sx((int) (acc >> 18), 24);
+    }
+    unsigned short *o = out + ((long) li * out_stride + qi) * 3;
+    o[0] = (unsigned short) y[0];
+    o[1] = (unsigned short) y[1];
+    o[2] = (unsigned short) (((y[1] >> 16) & 0xff) | (((y[0] >> 16) & 0xff) << 8));    // q3 | i3 << 8
+}
+
+// keep the last RX_HIST rx1 outputs, update counters / comb history / phase
+__global__ __launch_bounds__(RX_HIST) void rx_finish_kernel(rx_chan *__restrict__ chans, const int *__restrict__ chan_list,
+                                                           long n, const long *__restrict__ nouts,
+                                                           const u32 *__restrict__ hist_new, int *__restrict__ c1buf,
+                                                           long c1_stride)
+{
+    const int li = blockIdx.x, t = threadIdx.x;
+    rx_chan *ch = chans + chan_list[li];
+    const long nout = nouts[li];
+    for (int comp = 0; comp < 2; comp++) {
+        int *b = c1buf + ((long) chan_list[li] * 2 + comp) * c1_stride;
+        const int v = b[nout + t];            // the last RX_HIST entries of [history | new]
+        __syncthreads();
+        b[t] = v;
+        __syncthreads();
+    }
+    if (t == 0) {
+        const u64 M48 = (1ull << 48) - 1;
+        ch->phase = (ch->phase + (u64) n * ch->phase_inc) & M48;
+        ch->cnt1 = (u32) (((u64) ch->cnt1 + (u64) n) % RX_R1);
+        ch->n1 += (u64) nout;
+        if (nout > 0)
+            for (int comp = 0; comp < 2; comp++)
+                for (int d = 0; d < 3; d++) ch->hist3[comp][d] = hist_new[((long) li * 2 + comp) * 3 + d];
+    }
+}
+
+// ---------------------------------------------------------------------------
+struct kg_rxddc {
+    kg_ctx *ctx;
+    int nchan; long max_samples;
+    rx_chan *d_chans; std::vector<rx_chan> h;
+    u32 *d_nco;
+    int *d_list, *d_nfinal; long *d_nouts, *d_n1b, *d_qfirst; u32 *d_cnt;
+    u64 *d_st; u32 *d_c0rel, *d_tau, *d_hist;
+    int *d_c1buf; long c1_stride;
+    int max_runs; long max_out;
+};
+
+extern "C" {
+
+int kg_rxddc_create(kg_ctx *ctx, int nchan, size_t max_samples, kg_rxddc **out)
+{
+    int rc = kg_ctx_use(ctx);
+    if (rc) return rc;
+    KG_REQUIRE(out != nullptr, KG_ERR_INVALID, "kg_rxddc_create: out is null");
+    *out = nullptr;
+    KG_REQUIRE(nchan >= 1 && nchan <= 4096, KG_ERR_INVALID, "kg_rxddc_create: nchan %d", nchan);
+    KG_REQUIRE(max_samples >= 64 && max_samples <= ((size_t) 1 << 32), KG_ERR_INVALID, "kg_rxddc_create: max_samples %zu", max_samples);
+    kg_rxddc *d = new (std::nothrow) kg_rxddc();
+    KG_REQUIRE(d != nullptr, KG_ERR_NOMEM, "kg_rxddc_create: alloc");
+    d->ctx = ctx; d->nchan = nchan; d->max_samples = (long) max_samples;
+    d->h.assign(nchan, rx_chan());
+    for (auto &c : d->h) memset(&c, 0, sizeof c);
+    d->max_runs = (int) ((max_samples + 63) / 64);
+    if (d->max_runs > 16384) d->max_runs = 16384;
+    d->max_out = (long) (max_samples / RX_R1) + 2;
+    d->c1_stride = RX_HIST + d->max_out + RX_HIST;
+    KG_HIP(hipMalloc((void **) &d->d_chans, sizeof(rx_chan) * nchan));
+    KG_HIP(hipMemset(d->d_chans, 0, sizeof(rx_chan) * nchan));
+    KG_HIP(hipMalloc((void **) &d->d_nco, sizeof(u32) * 8192));
+    KG_HIP(hipMalloc((void **) &d->d_list, sizeof(int) * nchan));
+    KG_HIP(hipMalloc((void **) &d->d_nfinal, sizeof(int) * nchan));
+    KG_HIP(hipMalloc((void **) &d->d_nouts, sizeof(long) * nchan));
+    KG_HIP(hipMalloc((void **) &d->d_n1b, sizeof(long) * nchan));
+    KG_HIP(hipMalloc((void **) &d->d_qfirst, sizeof(long) * nchan));
+    KG_HIP(hipMalloc((void **) &d->d_cnt, sizeof(u32) * nchan));
+    KG_HIP(hipMalloc((void **) &d->d_st, sizeof(u64) * 4 * (size_t) nchan * d->max_runs));
+    KG_HIP(hipMalloc((void **) &d->d_tau, sizeof(u32) * 2 * (size_t) nchan * d->max_runs));
+    KG_HIP(hipMalloc((void **) &d->d_c0rel, sizeof(u32) * 2 * (size_t) nchan * d->max_out));
+    KG_HIP(hipMalloc((void **) &d->d_hist, sizeof(u32) * 6 * (size_t) nchan));
+    KG_HIP(hipMalloc((void **) &d->d_c1buf, sizeof(int) * 2 * (size_t) nchan * d->c1_stride));
+    KG_HIP(hipMemset(d->d_c1buf, 0, sizeof(int) * 2 * (size_t) nchan * d->c1_stride));
+    std::vector<u32> tab(8192);
+    for (int a = 0; a < 8192; a++) {
+        const double ph = 2.0 * M_PI * a / 8192.0;
+        const short c = (short) lrint(16383.0 * cos(ph)), s = (short) lrint(16383.0 * sin(ph));
+        tab[a] = (u32) (unsigned short) c | ((u32) (unsigned short) s << 16);
+    }
+    KG_HIP(hipMemcpy(d->d_nco, tab.data(), sizeof(u32) * 8192, hipMemcpyHostToDevice));
+    *out = d;
+    return KG_OK;
+}
+
+void kg_rxddc_destroy(kg_rxddc *d)
+{
+    if (!d) return;
+    (void) hipSetDevice(d->ctx->device);
+    (void) hipStreamSynchronize(d->ctx->stream);
+    (void) hipFree(d->d_chans); (void) hipFree(d->d_nco); (void) hipFree(d->d_list); (void) hipFree(d->d_nfinal);
+    (void) hipFree(d->d_nouts); (void) hipFree(d->d_n1b); (void) hipFree(d->d_qfirst); (void) hipFree(d->d_cnt);
+    (void) hipFree(d->d_st); (void) hipFree(d->d_tau); (void) hipFree(d->d_c0rel); (void) hipFree(d->d_hist);
+    (void) hipFree(d->d_c1buf);
+    delete d;
+}
+
+// CmdSetRXFreq (rx_sound_cmd.cpp:41-51: i_phase = round(f / adc_clk * 2^48)).  The FPGA keeps
+// its filters running when the frequency changes; so does this: only the increment changes.
+int kg_rxddc_set_freq(kg_rxddc *d, int ch, uint64_t phase_inc)
+{
+    KG_REQUIRE(d != nullptr, KG_ERR_INVALID, "kg_rxddc_set_freq: null argument");
+    int rc = kg_ctx_use(d->ctx);
+    if (rc) return rc;
+    KG_REQUIRE(ch >= 0 && ch < d->nchan, KG_ERR_INVALID, "kg_rxddc_set_freq: channel %d (0..%d)", ch, d->nchan - 1);
+    hipStream_t st = d->ctx->stream;
+    KG_HIP(hipStreamSynchronize(st));
+    const u64 inc = phase_inc & ((1ull << 48) - 1);
+    const int one = 1;
+    d->h[ch].phase_inc = inc; d->h[ch].active = 1;
+    KG_HIP(hipMemcpy(&d->d_chans[ch].phase_inc, &inc, sizeof inc, hipMemcpyHostToDevice));
+    KG_HIP(hipMemcpy(&d->d_chans[ch].active, &one, sizeof one, hipMemcpyHostToDevice));
+    return KG_OK;
+}
+
+// power-on state: all registers zero, phase zero
+int kg_rxddc_reset(kg_rxddc *d, int ch)
+{
+    KG_REQUIRE(d != nullptr && ch >= 0 && ch < d->nchan, KG_ERR_INVALID, "kg_rxddc_reset: channel %d", ch);
+    int rc = kg_ctx_use(d->ctx);
+    if (rc) return rc;
+    hipStream_t st = d->ctx->stream;
+    KG_HIP(hipStreamSynchronize(st));
+    rx_chan &c = d->h[ch];
+    const u64 inc = c.phase_inc; const int act = c.active;
+    memset(&c, 0, sizeof c);
+    c.phase_inc = inc; c.active = act;
+    KG_HIP(hipMemcpy(d->d_chans + ch, &c, sizeof c, hipMemcpyHostToDevice));
+    KG_HIP(hipMemset(d->d_c1buf + (size_t) ch * 2 * d->c1_stride, 0, sizeof(int) * 2 * d->c1_stride));
+    return KG_OK;
+}
+
+// rx_iq_t records channel ch will produce for the next n ADC samples
+long kg_rxddc_outputs(kg_rxddc *d, int ch, size_t n)
+{
+    if (!d || ch < 0 || ch >= d->nchan || !d->h[ch].active) return KG_ERR_INVALID;
+    const rx_chan &c = d->h[ch];
+    const u64 n1_after = c.n1 + ((u64) c.cnt1 + (u64) n) / RX_R1;
+    // final output q needs fir input 2q + 1, i.e. rx2 output 2q + 1, i.e. rx1 outputs up to 3 (2q + 1) + 2
+    auto finals = [](u64 n1) -> u64 { return n1 < 6 ? 0 : (n1 - 6) / 6 + 1; };   // largest q + 1 with 6 q + 5 < n1
+    return (long) (finals(n1_after) - finals(c.n1));
+}
+
+int kg_rxddc_push_dev(kg_rxddc *d, const void *d_adc, size_t n, const int32_t *chan_list, int nlist,
+                      void *d_out, size_t out_stride, int32_t *nouts)
+{
+    KG_REQUIRE(d && d_adc && chan_list && d_out, KG_ERR_INVALID, "kg_rxddc_push_dev: null argument");
+    int rc = kg_ctx_use(d->ctx);
+    if (rc) return rc;
+    KG_REQUIRE(n >= 1 && (long) n <= d->max_samples, KG_ERR_INVALID, "kg_rxddc_push_dev: n %zu (max %ld)", n, d->max_samples);
+    KG_REQUIRE(nlist >= 1 && nlist <= d->nchan, KG_ERR_INVALID, "kg_rxddc_push_dev: nlist %d", nlist);
+    KG_REQUIRE(((uintptr_t) d_adc & 1) == 0 && ((uintptr_t) d_out & 1) == 0, KG_ERR_INVALID, "kg_rxddc_push_dev: misaligned pointer");
+    auto finals = [](u64 n1) -> u64 { return n1 < 6 ? 0 : (n1 - 6) / 6 + 1; };
+    std::vector<long> h_nouts(nlist), h_n1b(nlist), h_qfirst(nlist);
+    std::vector<int> h_nfinal(nlist);
+    std::vector<u32> h_cnt(nlist);
+    long max_n1 = 0; int max_final = 0;
+    for (int i = 0; i < nlist; i++) {
+        const int ch = chan_list[i];
+        KG_REQUIRE(ch >= 0 && ch < d->nchan && d->h[ch].active, KG_ERR_STATE, "kg_rxddc_push_dev: channel %d has no frequency set", ch);
+        for (int j = 0; j < i; j++) KG_REQUIRE(chan_list[j] != ch, KG_ERR_INVALID, "kg_rxddc_push_dev: channel %d listed twice", ch);
+        const rx_chan &c = d->h[ch];
+        h_cnt[i] = c.cnt1;
+        h_nouts[i] = (long) (((u64) c.cnt1 + (u64) n) / RX_R1);
+        h_n1b[i] = (long) c.n1;
+        h_qfirst[i] = (long) finals(c.n1);
+        h_nfinal[i] = (int) (finals(c.n1 + (u64) h_nouts[i]) - finals(c.n1));
+        KG_REQUIRE((size_t) h_nfinal[i] <= out_stride, KG_ERR_INVALID, "kg_rxddc_push_dev: out_stride %zu < %d records", out_stride, h_nfinal[i]);
+        if (h_nouts[i] > max_n1) max_n1 = h_nouts[i];
+        if (h_nfinal[i] > max_final) max_final = h_nfinal[i];
+        if (nouts) nouts[i] = h_nfinal[i];
+    }
+    int L = 64;
+    while (L < 8192 && (long) ((n + L - 1) / L) > 8192) L <<= 1;
+    const int nruns = (int) ((n + L - 1) / L);
+    KG_REQUIRE(nruns <= d->max_runs, KG_ERR_INVALID, "kg_rxddc_push_dev: %d runs > %d", nruns, d->max_runs);
+    hipStream_t st = d->ctx->stream;
+    KG_HIP(hipMemcpyAsync(d->d_list, chan_list, sizeof(int) * nlist, hipMemcpyHostToDevice, st));
+    KG_HIP(hipMemcpyAsync(d->d_nouts, h_nouts.data(), sizeof(long) * nlist, hipMemcpyHostToDevice, st));
+    KG_HIP(hipMemcpyAsync(d->d_n1b, h_n1b.data(), sizeof(long) * nlist, hipMemcpyHostToDevice, st));
+    KG_HIP(hipMemcpyAsync(d->d_qfirst, h_qfirst.data(), sizeof(long) * nlist, hipMemcpyHostToDevice, st));
+    KG_HIP(hipMemcpyAsync(d->d_nfinal, h_nfinal.data(), sizeof(int) * nlist, hipMemcpyHostToDevice, st));
+    KG_HIP(hipMemcpyAsync(d->d_cnt, h_cnt.data(), sizeof(u32) * nlist, hipMemcpyHostToDevice, st));
+    KG_HIP(hipStreamSynchronize(st));
+    const dim3 grid((nruns + RX_THREADS - 1) / RX_THREADS, nlist);
+    hipLaunchKernelGGL(rx1_run_kernel<false>, grid, dim3(RX_THREADS), 0, st, (const short *) d_adc, (long) n, L, nruns,
+                       (const rx_chan *) d->d_chans, (const int *) d->d_list, (const u32 *) d->d_nco, d->d_st,
+                       d->d_c0rel, d->d_tau, d->max_out);
+    KG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(rx1_scan_kernel, dim3(2 * nlist), dim3(64), 0, st, d->d_st, (long) n, L, nruns, d->d_chans,
+                       (const int *) d->d_list);
+    KG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(rx1_run_kernel<true>, grid, dim3(RX_THREADS), 0, st, (const short *) d_adc, (long) n, L, nruns,
+                       (const rx_chan *) d->d_chans, (const int *) d->d_list, (const u32 *) d->d_nco, d->d_st,
+                       d->d_c0rel, d->d_tau, d->max_out);
+    KG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(rx1_scan_tau_kernel, dim3(2 * nlist), dim3(64), 0, st, d->d_tau, nruns, d->d_chans,
+                       (const int *) d->d_list);
+    KG_HIP(hipGetLastError());
+    if (max_n1 > 0) {
+        hipLaunchKernelGGL(rx1_comb_kernel, dim3((unsigned) ((max_n1 + 255) / 256), nlist), dim3(256), 0, st,
+                           (const u32 *) d->d_c0rel, (const u32 *) d->d_tau, L, nruns, d->max_out,
+                           (const rx_chan *) d->d_chans, (const int *) d->d_list, (const long *) d->d_nouts,
+                           (const u32 *) d->d_cnt, d->d_c1buf, d->c1_stride, d->d_hist);
+        KG_HIP(hipGetLastError());
+    }
+    if (max_final > 0) {
+        hipLaunchKernelGGL(rx2_fir_kernel, dim3((max_final + 127) / 128, nlist), dim3(128), 0, st,
+                           (const int *) d->d_c1buf, d->c1_stride, (const int *) d->d_list, (const long *) d->d_n1b,
+                           (const long *) d->d_qfirst, (const int *) d->d_nfinal, (unsigned short *) d_out, (long) out_stride);
+        KG_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(rx_finish_kernel, dim3(nlist), dim3(RX_HIST), 0, st, d->d_chans, (const int *) d->d_list, (long) n,
+                       (const long *) d->d_nouts, (const u32 *) d->d_hist, d->d_c1buf, d->c1_stride);
+    KG_HIP(hipGetLastError());
+    for (int i = 0; i < nlist; i++) {
+        rx_chan &c = d->h[chan_list[i]];
+        c.cnt1 = (u32) (((u64) c.cnt1 + (u64) n) % RX_R1);
+        c.n1 += (u64) h_nouts[i];
+    }
+    return KG_OK;
+}
+
+}  // extern "C"

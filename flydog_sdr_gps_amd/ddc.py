@@ -74,3 +74,70 @@ class Ddc:
             self.ctx.free(d_adc)
             self.ctx.free(d_out)
         return [host[i, :int(nouts[i])].copy() for i in range(len(chans))]
+
+
+RX_DECIM = 1736 * 3 * 2      # RX_DECIM_4CH (kiwi.config:141): RX1_STD_DECIM * RX2_STD_DECIM * CICF_DECIM_BY_2
+
+
+def rx_phase_inc(freq_hz, adc_clock=125.0e6):
+    """rx_sound_set_freq (rx/rx_sound_cmd.cpp:41-51): i_phase = (u64) round(f / adc_clk * 2^48)."""
+    return int(round(freq_hz / adc_clock * 2.0 ** 48)) & ((1 << 48) - 1)
+
+
+class RxDdc:
+    """The per-channel audio DDC (verilog/rx/rx.v) for nchan channels (kg_rxddc):
+    CmdSetRXFreq -> set_freq(ch, inc);  CmdGetRX -> push(adc) -> rx_iq_t records."""
+
+    def __init__(self, ctx=None, nchan=4, max_samples=1 << 24, device=0):
+        self.ctx = ctx if ctx is not None else Context(device)
+        self.lib = self.ctx.lib
+        self.nchan, self.max_samples = nchan, max_samples
+        h = C.c_void_p()
+        check(self.lib.kg_rxddc_create(self.ctx.h, int(nchan), int(max_samples), C.byref(h)),
+              "kg_rxddc_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.kg_rxddc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_freq(self, ch, phase_inc):
+        check(self.lib.kg_rxddc_set_freq(self.h, int(ch), int(phase_inc) & ((1 << 48) - 1)),
+              "kg_rxddc_set_freq")
+
+    def reset(self, ch):
+        check(self.lib.kg_rxddc_reset(self.h, int(ch)), "kg_rxddc_reset")
+
+    def outputs(self, ch, n):
+        return check(self.lib.kg_rxddc_outputs(self.h, int(ch), int(n)), "kg_rxddc_outputs")
+
+    def push_dev(self, d_adc, n, chans, d_out, out_stride):
+        chans = np.ascontiguousarray(chans, np.int32)
+        nouts = np.zeros(chans.size, np.int32)
+        check(self.lib.kg_rxddc_push_dev(self.h, ptr(int(d_adc)), int(n), ptr(chans), chans.size,
+                                         ptr(int(d_out)), int(out_stride), ptr(nouts)),
+              "kg_rxddc_push_dev")
+        return nouts
+
+    def push(self, adc, chans):
+        """Host int16 array in; per channel the rx_iq_t bytes (uint8[nout*6]) out."""
+        adc = np.ascontiguousarray(adc, np.int16)
+        stride = max(int(self.outputs(c, adc.size)) for c in chans) + 1
+        d_adc = self.ctx.alloc(adc.nbytes)
+        d_out = self.ctx.alloc(len(chans) * stride * 6)
+        try:
+            self.ctx.upload(d_adc, adc)
+            nouts = self.push_dev(d_adc, adc.size, chans, d_out, stride)
+            host = np.zeros((len(chans), stride * 6), np.uint8)
+            self.ctx.download(d_out, host)
+        finally:
+            self.ctx.free(d_adc)
+            self.ctx.free(d_out)
+        return [host[i, :6 * int(nouts[i])].copy() for i in range(len(chans))]

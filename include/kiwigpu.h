@@ -231,6 +231,29 @@ int kg_ddc_wf_push_dev(kg_ddc *ddc, const void *d_adc, size_t n, const int32_t *
                        int nlist, void *d_out, size_t out_stride, int64_t *nouts);
 
 /* ------------------------------------------------------------------------ */
+/* Audio DDC.  In the reference: one RX instance per audio channel in FPGA      */
+/* fabric (verilog/rx/rx.v:22-178): IQ_MIXER (22 bits) -> CIC N=3 R=1736 ->      */
+/* CIC N=5 R=3 -> 65-tap CICF /2 (fir_iq.sv) -> 24-bit IQ at ADC/10416, read as  */
+/* rx_iq_t records with CmdGetRX (rx/data_pump.cpp:101) after the NCO was set    */
+/* with CmdSetRXFreq (rx/rx_sound_cmd.cpp:41-51).                                */
+/* ------------------------------------------------------------------------ */
+typedef struct kg_rxddc kg_rxddc;
+
+int kg_rxddc_create(kg_ctx *ctx, int nchan, size_t max_samples, kg_rxddc **out);
+void kg_rxddc_destroy(kg_rxddc *ddc);
+/* CmdSetRXFreq: 48-bit phase increment i_phase = round(f / adc_clk * 2^48).  The
+ * filters keep running across a retune, as in the FPGA. */
+int kg_rxddc_set_freq(kg_rxddc *ddc, int ch, uint64_t phase_inc);
+int kg_rxddc_reset(kg_rxddc *ddc, int ch);                 /* power-on state */
+long kg_rxddc_outputs(kg_rxddc *ddc, int ch, size_t n);     /* records the next n samples yield */
+/* n ADC samples (device int16 array) through the listed channels: channel
+ * chan_list[i] writes nouts[i] rx_iq_t records {u16 i, u16 q, u8 q3, u8 i3}
+ * (rx/data_pump.h:27-30) to d_out + i*out_stride records.  State carries over
+ * between calls.  Enqueue only. */
+int kg_rxddc_push_dev(kg_rxddc *ddc, const void *d_adc, size_t n, const int32_t *chan_list,
+                      int nlist, void *d_out, size_t out_stride, int32_t *nouts);
+
+/* ------------------------------------------------------------------------ */
 /* Audio front: data-pump unpack and the CFastFIR passband filter.             */
 /* ------------------------------------------------------------------------ */
 /* snd_service() unpack (rx/data_pump.cpp:145-208): nsamps * nchans rx_iq_t records

@@ -185,6 +185,23 @@ void ko_ddc_wf_reset(ko_ddc_wf_state *s);
 int ko_ddc_wf(ko_ddc_wf_state *s, const int16_t *adc, long n, uint64_t phase_inc, int log2r,
               int16_t *out);
 
+/* ---- audio DDC (verilog/rx/rx.v, cic_rx1/rx2, fir_iq.sv) ------------------------ */
+typedef struct {
+    uint64_t phase;              /* 48-bit NCO accumulator                            */
+    uint32_t cnt1, cnt2;         /* decimation counters of rx1 (R 1736) and rx2 (R 3) */
+    int decim_by_2;              /* fir_iq.sv decim_by_2 toggle                       */
+    uint64_t i1[2], i2[2];       /* rx1 integrators 1, 2 (55 bits)                    */
+    uint32_t i3[2];              /* rx1 integrator 3 (26 bits)                        */
+    int64_t comb1_prev[2][3];    /* rx1 comb registers                                */
+    int64_t j[2][5];             /* rx2 integrators (26 bits)                         */
+    int64_t comb2_prev[2][5];    /* rx2 comb registers                                */
+    int32_t fir_buf[2][65];      /* fir_iq bufI / bufQ, [0] newest                    */
+} ko_ddc_rx_state;
+
+extern const int32_t ko_cicf_taps65[33];
+void ko_ddc_rx_reset(ko_ddc_rx_state *s);
+int ko_ddc_rx(ko_ddc_rx_state *s, const int16_t *adc, long n, uint64_t phase_inc, uint8_t *out);
+
 #ifdef __cplusplus
 }
 #endif

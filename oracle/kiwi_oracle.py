@@ -350,6 +350,29 @@ def ddc_wf(adc, phase_inc, log2r, state=None):
     return out[:n].view(np.int16).reshape(n, 2).copy(), state
 
 
+class DdcRxState(C.Structure):
+    _fields_ = [("phase", C.c_uint64), ("cnt1", C.c_uint32), ("cnt2", C.c_uint32), ("decim_by_2", C.c_int),
+                ("i1", C.c_uint64 * 2), ("i2", C.c_uint64 * 2), ("i3", C.c_uint32 * 2),
+                ("comb1_prev", (C.c_int64 * 3) * 2), ("j", (C.c_int64 * 5) * 2),
+                ("comb2_prev", (C.c_int64 * 5) * 2), ("fir_buf", (C.c_int32 * 65) * 2)]
+
+
+RX_DECIM = 1736 * 3 * 2          # RX_DECIM_4CH, kiwi.config:141
+
+
+def ddc_rx(adc, phase_inc, state=None):
+    """-> (rx_iq_t bytes uint8[nout*6], state)."""
+    L = lib()
+    L.ko_ddc_rx.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_uint64, C.c_void_p]
+    L.ko_ddc_rx.restype = C.c_int
+    adc = np.ascontiguousarray(adc, np.int16)
+    if state is None:
+        state = DdcRxState()
+    out = np.zeros((adc.size // RX_DECIM + 2) * 6, np.uint8)
+    n = L.ko_ddc_rx(C.byref(state), _p(adc), adc.size, C.c_uint64(phase_inc & ((1 << 48) - 1)), _p(out))
+    return out[:6 * n].copy(), state
+
+
 def ref_cacode(t0, t1):
     """Chips from the REFERENCE's own gps/cacode.h (oracle/_ref/cacode_ref), or None."""
     exe = os.path.join(_HERE, "_ref", "cacode_ref")

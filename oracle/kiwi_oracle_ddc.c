@@ -117,3 +117,111 @@ int ko_ddc_wf(ko_ddc_wf_state *s, const int16_t *adc, long n, uint64_t phase_inc
     }
     return nout;
 }
+
+/* ======================================================================== */
+/* Audio DDC: verilog/rx/rx.v:22-178                                         */
+/*   IQ_MIXER (OUT_WIDTH = RX1_BITS = 22)                                    */
+/*   -> cic_prune_var "rx1": N = 3, R = RX1_STD_DECIM = 1736 (kiwi.config:104)*/
+/*   -> cic_prune_var "rx2": N = 5, R = RX2_STD_DECIM = 3, 18 -> 24 bits      */
+/*   -> fir_iq (verilog/rx/fir_iq.sv): 65 taps, 18-bit coefficients, /2      */
+/*   -> 3-word output mux {i[15:0]},{q[15:0]},{i[23:16],q[23:16]} (rx.v:172) */
+/* rx1 widths for R = 1736 are those verilog/rx/cic_gen.c emits for that R    */
+/* (acc 55 bits, integrators 55/55/26 with the third taking */
+/* [54 -: 26], combs 22/21/20 dropping 4/1/1 LSBs, out = comb3[19 -: 18] +     */
+/* comb3[1]); the checked-in cic_rx1_12k.vh is the stale R = 926 variant of    */
+/* the same structure.  rx2: cic_rx2_12k.vh (26 bits throughout, out =        */
+/* comb5[25 -: 24] + comb5[1]).  SELF-REFERENTIAL like the waterfall DDC.      */
+/* ======================================================================== */
+
+/* fir_iq.sv:91-123, the default (rx4/rx8) table: taps[0..32], symmetric */
+const int32_t ko_cicf_taps65[33] = {
+    0x00071, 0x3ffae, 0x3ff5b, 0x00029, 0x000f6, 0x0002a, 0x3fea6, 0x3ff32, 0x001aa, 0x001dc, 0x3fe5a,
+    0x3fcae, 0x000fb, 0x00503, 0x000a7, 0x3f96f, 0x3fc85, 0x0076b, 0x00793, 0x3f927, 0x3f33f, 0x00401,
+    0x01296, 0x00227, 0x3e7b0, 0x3f2dd, 0x01caf, 0x0200e, 0x3e310, 0x3bb4f, 0x00c0e, 0x0aeac, 0x1036e,
+};
+
+static inline int32_t mix22(int16_t adc, int16_t dds)     /* iq_mixer.v:43-51, OUT_WIDTH 22 */
+{
+    const int64_t prod = (int64_t) ((int32_t) adc * 4) * (int64_t) ((int32_t) dds * 8);
+    return (int32_t) ((prod >> 13) + ((prod >> 12) & 1));
+}
+
+void ko_ddc_rx_reset(ko_ddc_rx_state *s)
+{
+    memset(s, 0, sizeof *s);
+}
+
+/* One audio channel over n ADC samples.  out: rx_iq_t records (6 bytes each).
+ * Returns the number of records written. */
+int ko_ddc_rx(ko_ddc_rx_state *s, const int16_t *adc, long n, uint64_t phase_inc, uint8_t *out)
+{
+    nco_init();
+    const uint64_t M48 = (1ULL << 48) - 1, M55 = (1ULL << 55) - 1;
+    const int R1 = 1736, R2 = 3;
+    int nout = 0;
+    for (long t = 0; t < n; t++) {
+        const int a = (int) (s->phase >> 35);
+        const int32_t m[2] = { mix22(adc[t], nco_cos[a]), mix22(adc[t], nco_sin[a]) };
+        s->phase = (s->phase + phase_inc) & M48;
+        const int strobe1 = (s->cnt1 == (uint32_t) (R1 - 1));
+        s->cnt1 = strobe1 ? 0 : s->cnt1 + 1;
+        int32_t c1[2] = {0, 0};
+        for (int c = 0; c < 2; c++) {
+            /* rx1: integrators 55, 55, 26 bits */
+            s->i1[c] = (s->i1[c] + (uint64_t) (int64_t) m[c]) & M55;
+            s->i2[c] = (s->i2[c] + s->i1[c]) & M55;
+            s->i3[c] = (s->i3[c] + (uint32_t) (s->i2[c] >> 29)) & 0x03FFFFFF;      /* [54 -: 26] */
+            if (strobe1) {
+                static const int W[3] = {22, 21, 20}, D[3] = {4, 1, 1};
+                int64_t v = sext(s->i3[c], 26);
+                for (int k = 0; k < 3; k++) {
+                    const int64_t x = sext((uint64_t) (v >> D[k]), W[k]);
+                    const int64_t y = sext((uint64_t) (x - s->comb1_prev[c][k]), W[k]);
+                    s->comb1_prev[c][k] = x;
+                    v = y;
+                }
+                c1[c] = (int32_t) sext((uint64_t) ((v >> 2) + ((v >> 1) & 1)), 18);   /* comb3[19 -: 18] + comb3[1] */
+            }
+        }
+        if (!strobe1) continue;
+        /* rx2: N = 5, R = 3, 26-bit registers, no pruning */
+        const int strobe2 = (s->cnt2 == (uint32_t) (R2 - 1));
+        s->cnt2 = strobe2 ? 0 : s->cnt2 + 1;
+        int32_t c2[2] = {0, 0};
+        for (int c = 0; c < 2; c++) {
+            int64_t v = c1[c];
+            for (int k = 0; k < 5; k++) { s->j[c][k] = sext((uint64_t) (s->j[c][k] + v), 26); v = s->j[c][k]; }
+            if (strobe2) {
+                for (int k = 0; k < 5; k++) {
+                    const int64_t y = sext((uint64_t) (v - s->comb2_prev[c][k]), 26);
+                    s->comb2_prev[c][k] = v;
+                    v = y;
+                }
+                c2[c] = (int32_t) sext((uint64_t) ((v >> 2) + ((v >> 1) & 1)), 24);   /* comb5[25 -: 24] + comb5[1] */
+            }
+        }
+        if (!strobe2) continue;
+        /* fir_iq: shift register, 65 symmetric taps, 42-bit accumulator, out = acc[41 -: 24],
+         * an output on every second input (decim_by_2 starts at 0, fir_iq.sv:125-170) */
+        int32_t y[2];
+        for (int c = 0; c < 2; c++) {
+            memmove(&s->fir_buf[c][1], &s->fir_buf[c][0], sizeof(int32_t) * 64);
+            s->fir_buf[c][0] = c2[c];
+            int64_t acc = 0;
+            for (int k = 0; k < 65; k++) {
+                const int32_t coef = (int32_t) sext((uint64_t) ko_cicf_taps65[k <= 32 ? k : 64 - k], 18);
+                acc = sext((uint64_t) (acc + (int64_t) s->fir_buf[c][k] * coef), 42);
+            }
+            y[c] = (int32_t) sext((uint64_t) (acc >> 18), 24);
+        }
+        const int emit = s->decim_by_2;
+        s->decim_by_2 ^= 1;
+        if (!emit) continue;
+        /* rx.v:172 words -> rx_iq_t {u16 i, u16 q, u8 q3, u8 i3} (rx/data_pump.h:27-30) */
+        uint8_t *o = out + 6 * (size_t) nout++;
+        o[0] = (uint8_t) y[0]; o[1] = (uint8_t) (y[0] >> 8);
+        o[2] = (uint8_t) y[1]; o[3] = (uint8_t) (y[1] >> 8);
+        o[4] = (uint8_t) (y[1] >> 16); o[5] = (uint8_t) (y[0] >> 16);
+    }
+    return nout;
+}
