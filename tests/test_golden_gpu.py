@@ -1,0 +1,56 @@
+"""GPU results vs the committed fixtures of tests/golden/ (made by tools/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from flydog_sdr_gps_amd import Ddc, FastFir, RxDdc, Waterfall, WfParams, snd, wf
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_wf_rows(gpu_ctx):
+    g = np.load(os.path.join(GOLD, "wf_golden.npz"))
+    w = Waterfall(gpu_ctx, nchan=1)
+    w.set_tables(wf.window_functions(), g["cic_comp"])
+    for k in range(int(g["ncases"])):
+        zoom, start, interp, winf, cic, inv = g["case%d_cfg" % k]
+        p = WfParams.for_zoom(int(zoom), float(start), spectral_inversion=bool(inv))
+        w.set_channel(0, p, interp=int(interp), window_func=int(winf), cic_comp=bool(cic), spectral_inversion=bool(inv))
+        row, _, pwr_out, dB = w.debug_frame(0, g["case%d_iq" % k])
+        want, want_dB = g["case%d_row" % k], g["case%d_dB" % k]
+        assert np.abs(pwr_out - g["case%d_pwr_out" % k]).max() <= 1e-5 * g["case%d_pwr_out" % k].max()
+        diff = np.nonzero(row != want)[0]
+        assert diff.size <= 8
+        for i in diff:                                      # one LSB at an (int) truncation edge
+            assert abs(int(row[i]) - int(want[i])) == 1 and abs(want_dB[i] - np.rint(want_dB[i])) < 2e-3
+    w.close()
+
+
+def test_unpack_fir_ddc(gpu_ctx):
+    g = np.load(os.path.join(GOLD, "snd_golden.npz"))
+    got = snd.unpack(gpu_ctx, g["raw"], 8, 4, dc_i=0.5, dc_q=-0.25)
+    assert np.array_equal(got.view(np.uint32), g["unpack_normal"].view(np.uint32))
+    got = snd.unpack(gpu_ctx, g["raw"], 8, 4, dc_i=0.5, dc_q=-0.25, spectral_inversion=True)
+    assert np.array_equal(got.view(np.uint32), g["unpack_inverted"].view(np.uint32))
+    f = FastFir(gpu_ctx, nchan=1, max_in=256)
+    f.set_coef(0, g["fir_coef"])                            # the reference's own m_pFilterCoef_CIC path
+    outs, pos = [], []
+    for k in range(7):
+        outs.append(f.process(0, g["fir_in"][170 * k:170 * (k + 1)]))
+        pos.append(f.pos(0))
+    y = np.concatenate(outs)
+    assert pos == list(g["fir_pos"]) and y.size == g["fir_out"].size
+    assert np.abs(y - g["fir_out"]).max() <= 1e-5 * np.abs(g["fir_out"]).max()
+    f.close()
+    d = np.load(os.path.join(GOLD, "ddc_golden.npz"))
+    for l2 in (0, 4, 11):
+        e = Ddc(gpu_ctx, nchan=1, max_samples=d["adc"].size)
+        e.set_wf(0, int(d["inc"]), 1 << l2)
+        assert np.array_equal(e.push(d["adc"], [0])[0], d["wf_r%d" % l2])
+        e.close()
+    r = RxDdc(gpu_ctx, nchan=1, max_samples=d["adc_rx"].size)
+    r.set_freq(0, int(d["inc_rx"]))
+    assert np.array_equal(r.push(d["adc_rx"], [0])[0], d["rx_records"])
+    r.close()

@@ -324,3 +324,41 @@ def test_unpack_oracle_sign_extension_and_swap(oracle):
     inv = oracle.dpump_unpack(raw, 1, 2, spectral_inversion=True)
     assert inv[0, 0] == np.complex64(complex(np.float32(-1) * r, np.float32(-2 ** 23) * r))
     assert abs(float(r) - 2 ** -8 * 10 ** 0.225) < 1e-9 and np.float32(snd.RESCALE) == r
+
+
+# ---- committed fixtures for the waterfall / audio / DDC rows ----------------------------
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_golden_wf_oracle(oracle):
+    from flydog_sdr_gps_amd import wf
+    g = np.load(os.path.join(GOLD, "wf_golden.npz"))
+    W = wf.window_functions()
+    for k in range(int(g["ncases"])):
+        zoom, start, interp, winf, cic, inv = g["case%d_cfg" % k]
+        p = wf.WfParams.for_zoom(int(zoom), float(start), spectral_inversion=bool(inv))
+        m, d = wf.build_maps(p.fft_used, p.plot_width, p.plot_width_clamped, bool(inv))
+        sc = np.full(1024, p.fft_scale, np.float32)
+        row, _, pwr_out, dB = oracle.wf_compute_frame(
+            oracle.wf_window_iq(g["case%d_iq" % k], W[int(winf)]), p.zoom, int(winf), int(interp), int(cic), 0,
+            p.fft_used, p.plot_width, p.plot_width_clamped, m, d, sc, (sc / np.float32(2)).astype(np.float32),
+            p.fft_offset, g["cic_comp"])
+        assert np.array_equal(row, g["case%d_row" % k])
+        assert np.array_equal(pwr_out, g["case%d_pwr_out" % k])
+
+
+def test_golden_snd_and_ddc_oracle(oracle):
+    g = np.load(os.path.join(GOLD, "snd_golden.npz"))
+    assert np.array_equal(oracle.dpump_unpack(g["raw"], 8, 4, dc_i=0.5, dc_q=-0.25), g["unpack_normal"])
+    assert np.array_equal(oracle.dpump_unpack(g["raw"], 8, 4, dc_i=0.5, dc_q=-0.25, spectral_inversion=True),
+                          g["unpack_inverted"])
+    st, outs, pos = oracle.fir_new_state(), [], []
+    for k in range(7):
+        o, p = oracle.fir_process(st, g["fir_coef"], g["fir_in"][170 * k:170 * (k + 1)])
+        outs.append(o)
+        pos.append(p)
+    assert np.array_equal(np.concatenate(outs), g["fir_out"]) and pos == list(g["fir_pos"])
+    d = np.load(os.path.join(GOLD, "ddc_golden.npz"))
+    for l2 in (0, 4, 11):
+        assert np.array_equal(oracle.ddc_wf(d["adc"], int(d["inc"]), l2)[0], d["wf_r%d" % l2])
+    assert np.array_equal(oracle.ddc_rx(d["adc_rx"], int(d["inc_rx"]))[0], d["rx_records"])

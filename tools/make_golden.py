@@ -71,3 +71,63 @@ for k, (sat, bits, chips, r, cells) in enumerate(cases):
     out["case%d_cell_snr" % k] = cells["snr"]
 np.savez_compressed(os.path.join(GOLD, "acq_golden.npz"), **out)
 print("wrote", GOLD)
+
+# ---------------------------------------------------------------------------------
+# waterfall / audio front / DDC fixtures (same status: oracle outputs, regression pins)
+# ---------------------------------------------------------------------------------
+from flydog_sdr_gps_amd import wf, snd          # noqa: E402
+
+tables = (wf.window_functions(), wf.cic_comp_table())
+out = {"cic_comp": tables[1]}
+cases_wf = [(0, 0.0, wf.WF_CMA, wf.WINF_HANNING, True, False),
+            (3, 2.0e6, wf.WF_MAX, wf.WINF_BLACKMAN_HARRIS, True, False),
+            (10, 9.0e6, wf.WF_DROP, wf.WINF_HANNING, True, True)]
+out["ncases"] = len(cases_wf)
+for k, (zoom, start, interp, winf, cic, inv) in enumerate(cases_wf):
+    p = wf.WfParams.for_zoom(zoom, start, spectral_inversion=inv)
+    m, d = wf.build_maps(p.fft_used, p.plot_width, p.plot_width_clamped, inv)
+    iq = synth.wf_iq_frame(seed=4000 + k, tones=((0.05, -50.0), (0.21, -60.0)), noise_dbfs=-45.0)
+    sc = np.full(1024, p.fft_scale, np.float32)
+    row, pwr, pwr_out, dB = ko.wf_compute_frame(ko.wf_window_iq(iq, tables[0][winf]), p.zoom, winf, interp, cic,
+                                                False, p.fft_used, p.plot_width, p.plot_width_clamped, m, d, sc,
+                                                (sc / np.float32(2)).astype(np.float32), p.fft_offset, tables[1])
+    out["case%d_cfg" % k] = np.array([zoom, start, interp, winf, int(cic), int(inv)], np.float64)
+    out["case%d_iq" % k] = iq
+    out["case%d_row" % k] = row
+    out["case%d_dB" % k] = dB
+    out["case%d_pwr_out" % k] = pwr_out
+    print("wf case %d: z%d row min/max %d/%d" % (k, zoom, row.min(), row.max()))
+np.savez_compressed(os.path.join(GOLD, "wf_golden.npz"), **out)
+
+rng = np.random.default_rng(0x5EED0A)
+i24 = rng.integers(-2 ** 23, 2 ** 23, (8, 4)); q24 = rng.integers(-2 ** 23, 2 ** 23, (8, 4))
+i24[0, 0], q24[0, 0], i24[1, 1], q24[1, 1] = -2 ** 23, 2 ** 23 - 1, -1, -2
+raw = snd.pack_rx_iq(i24, q24)
+coef, coef_cic, tcoef = ko.fir_design(300.0, 2700.0, 0.0, 12000.0)
+x = ((rng.standard_normal(170 * 7) + 1j * rng.standard_normal(170 * 7)) * 2000).astype(np.complex64)
+st, outs, pos = ko.fir_new_state(), [], []
+for k in range(7):
+    o, pp = ko.fir_process(st, coef_cic, x[170 * k:170 * (k + 1)])
+    outs.append(o); pos.append(pp)
+np.savez_compressed(os.path.join(GOLD, "snd_golden.npz"), raw=raw,
+                    unpack_normal=ko.dpump_unpack(raw, 8, 4, dc_i=0.5, dc_q=-0.25),
+                    unpack_inverted=ko.dpump_unpack(raw, 8, 4, dc_i=0.5, dc_q=-0.25, spectral_inversion=True),
+                    fir_coef=coef_cic, fir_in=x, fir_out=np.concatenate(outs), fir_pos=np.array(pos))
+print("snd: fir outputs", sum(o.size for o in outs), "pos", pos)
+
+t = np.arange(1 << 15)
+adc = np.clip(np.rint(9000 * np.cos(2 * np.pi * 0.0123 * t) + 700 * np.cos(2 * np.pi * 0.201 * t + 1)
+                      + rng.normal(0, 40, t.size)), -32768, 32767).astype(np.int16)
+inc = (-int(round((0.0123 + 2.0 ** -22) * 2 ** 48))) & ((1 << 48) - 1)
+dd = {"adc": adc, "inc": np.uint64(inc)}
+for l2 in (0, 4, 11):
+    dd["wf_r%d" % l2] = ko.ddc_wf(adc, inc, l2)[0]
+n_rx = 10416 * 5
+t = np.arange(n_rx)
+adc_rx = np.clip(np.rint(15000 * np.cos(2 * np.pi * (0.0371 + 900 / 125e6) * t) + rng.normal(0, 30, n_rx)), -32768, 32767).astype(np.int16)
+inc_rx = int(round(0.0371 * 2 ** 48)) & ((1 << 48) - 1)
+dd["adc_rx"] = adc_rx
+dd["inc_rx"] = np.uint64(inc_rx)
+dd["rx_records"] = ko.ddc_rx(adc_rx, inc_rx)[0]
+np.savez_compressed(os.path.join(GOLD, "ddc_golden.npz"), **dd)
+print("ddc: wf outputs", {k: v.shape for k, v in dd.items() if k.startswith("wf_")}, "rx records", dd["rx_records"].size // 6)
