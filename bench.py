@@ -5,7 +5,8 @@ Workload (BASELINE.json configs[1]): 32 GPS L1 C/A SVs x 41 Doppler bins, 4 ms
 coherent FFT correlation on synthetic int16 IQ (65536 samples @ 16.368 MS/s),
 the sample block already resident in HBM.  One step = Sample() front end
 (mix, 2x half-band /2, 16384-pt FFT) + Correlate() for all 32 SVs x 41 bins +
-best-bin selection, for --blocks independent sample blocks (default 1).
+best-bin selection, for --blocks independent 4 ms sample blocks (default 8: a
+32 ms batch of the IQ stream per step; --blocks 1 is the single-block latency case).
 
 Metric: IQ Msamples/s ingested = blocks * 65536 * steps * n_gpus / seconds.
 Multi-GPU (weak scaling): every rank searches its own resident block(s); there
@@ -36,36 +37,71 @@ BYTES_PER_CELL = 2 * FFT_LEN * 8 + 16
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def usable_cores():
+    """Host threads this process can really run at once: the affinity mask, capped by the
+    cgroup CPU quota (os.cpu_count() reports the machine, not the container)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                       # cgroup v2
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:      # cgroup v1
+                quota = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if quota > 0:
+                n = min(n, max(1, int(quota / period + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(iq, chips_list, budget_s=12.0):
-    """The CPU oracle (kind "port": fp32 FFT, all host cores, pthread shard over the
-    32 x 41 (SV, Doppler) cells) timed on the same configs[1] workload, repeated for
-    about budget_s seconds."""
+    """The CPU oracle (kind "port": fp32 FFT) timed on the same configs[1] workload: every
+    host thread runs whole single-threaded steps (Sample + 32 SV x 41 bins) on its own,
+    back to back for about budget_s seconds -- independent blocks, like the GPU's batch,
+    and no per-call thread start-up in the timed loop (ctypes drops the GIL in the calls)."""
+    import threading
     from oracle import kiwi_oracle as ko
     ko.lib()
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     codes = np.stack([ko.code_fft(c, prec=0) for c in chips_list])
     limits = [4092] * len(chips_list)
-    ko.correlate_many(codes[:cores], ko.sample_iq16(iq, prec=0), limits[:cores], prec=0,
-                      nthreads=cores, want_cells=False)          # warm-up
-    reps, t0 = 0, time.perf_counter()
-    while True:
+
+    def one_step():
         data = ko.sample_iq16(iq, prec=0)
-        ko.correlate_many(codes, data, limits, prec=0, nthreads=cores, want_cells=False)
-        reps += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s:
-            break
+        ko.correlate_many(codes, data, limits, prec=0, nthreads=1, want_cells=False)
+
     t1_0 = time.perf_counter()
-    data = ko.sample_iq16(iq, prec=0)
-    ko.correlate_many(codes[:4], data, limits[:4], prec=0, nthreads=1, want_cells=False)
-    t1 = (time.perf_counter() - t1_0) * (len(chips_list) / 4.0)
+    one_step()                                                    # warm-up + single-thread figure
+    t1 = time.perf_counter() - t1_0
+    done = [0] * cores
+    deadline = time.perf_counter() + budget_s
+
+    def worker(k):
+        while time.perf_counter() < deadline:
+            one_step()
+            done[k] += 1
+
+    t0 = time.perf_counter()
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(cores)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    el = time.perf_counter() - t0
+    reps = sum(done)
     return {
         "value": round(reps * NSAMPLES / el / 1e6, 4),
         "unit": "Msamples/s",
         "cores": cores,
+        "machine_cpus": os.cpu_count(),
         "kind": "port",
-        "sample": "%d x the full configs[1] step (Sample + 32 SV x 41 bins), oracle fp32 "
-                  "FFT, %d threads over (SV, Doppler) cells, %.1f s" % (reps, cores, el),
+        "sample": "%d x the full configs[1] block (Sample + 32 SV x 41 bins), oracle fp32 FFT, "
+                  "%d threads each running whole blocks, %.1f s" % (reps, cores, el),
         "single_thread_value": round(NSAMPLES / t1 / 1e6, 4),
     }
 
@@ -166,6 +202,20 @@ def bench_ddc(args):
     ctx.close()
 
 
+def measured_traffic(workload, units):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/hbm_traffic.json, written from tools/prof.sh output: FETCH_SIZE x2 on gfx950
+    + WRITE_SIZE, separate --pmc runs of this same command).  A bench run cannot read
+    counters itself; None when no measurement exists for this configuration."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as f:
+            tab = json.load(f)
+        return tab[workload][str(units)]["bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log2n", type=int, default=24, help="ddc: log2 of the ADC samples per step")
@@ -174,7 +224,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--blocks", type=int, default=1, help="independent 4 ms blocks per step")
+    ap.add_argument("--blocks", type=int, default=8, help="independent 4 ms blocks per step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
     if args.workload == "waterfall":
@@ -221,9 +271,9 @@ def main():
     parity = [0]
 
     def step():
-        # Sample() of this step's blocks goes to the library's front-end stream and
-        # overlaps the previous step's Correlate() (other set of blocks); all of it
-        # is inside the timed region.
+        # Sample() then Correlate() of this step's blocks, in order on one stream (two sets
+        # of blocks alternate so that consecutive steps never touch the same spectra); all
+        # of it is inside the timed region.
         first = parity[0] * B
         parity[0] ^= 1
         s.sample_iq16_batch(iq_ptr, B, first_block=first)
@@ -240,6 +290,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_enqueued = time.perf_counter() - t0      # host side only: diagnostic, not the metric
     barrier()
     elapsed = time.perf_counter() - t0
     if distributed:
@@ -299,7 +350,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": measured_traffic("acq", B),
                 "kernel_ms": round(kernel_ms, 5),
                 "algorithmic_bytes_per_launch": cells * BYTES_PER_CELL,
                 "note": "algorithmic bytes = 262160 B per (SV,Doppler) cell (SURVEY 8d); the "
@@ -307,6 +358,7 @@ def main():
                         "this can exceed the HBM peak; the kernel is fp32-VALU/LDS bound",
             },
             "found_prns": found,
+            "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 5),
         }
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(iq_host[0], chips_list)

@@ -447,11 +447,16 @@ struct kg_acq {
     std::vector<int> limits, code_set;
     std::vector<int> last_sats;
     int last_first, last_nblocks, last_nsats, nsel1, nsel4, table_nblocks;
-    // Sample() work runs on its own stream so that block b+1's front end overlaps
-    // block b's correlation; per-block events order the two streams.
+    // Stream of the Sample() work: the context's stream, or (opt-in) a second one ordered
+    // against it by events.
     hipStream_t fstream;
+    bool own_fstream;
     std::vector<hipEvent_t> ev_ready, ev_done;   // data spectrum written / last reader done
-    std::vector<char> has_ready, has_done;
+    // Block b is covered by events ev_ready[ready_of[b]] / ev_done[done_of[b]] (-1: none yet).
+    // A batch call records ONE event for all its blocks: every record and every cross-stream
+    // wait is a packet the command processor handles between two kernels (8 blocks per
+    // call: 358 -> 288 us per step when the per-block events went away).
+    std::vector<int> ready_of, done_of;
     int grid1, grid4;
 };
 
@@ -548,9 +553,20 @@ int kg_acq_create(kg_ctx *ctx, int max_sats, int dop_lo, int dop_hi, int max_blo
     KG_HIP(hipMalloc((void **) &a->d_xcd4, sizeof(int) * 9));
     KG_HIP(hipMalloc((void **) &a->d_cells, sizeof(kg_acq_cell) * (size_t) max_blocks * max_sats * a->ndop));
     KG_HIP(hipMalloc((void **) &a->d_results, sizeof(kg_acq_result) * (size_t) max_blocks * max_sats));
-    KG_HIP(hipStreamCreateWithFlags(&a->fstream, hipStreamNonBlocking));
+    {
+        // Sample() and Correlate() run in order on the context's stream.  A second stream
+        // (KIWIGPU_ACQ_FRONT_STREAM=1) lets block b+1's front end overlap block b's
+        // correlation: 60 instead of 65 us per 1-block step on MI355X, but when the front-end
+        // kernels are dispatched together with the persistent correlator the latter can
+        // spend its first pass at one workgroup per CU (16 blocks per step: 887 us against
+        // 528 us in order; profiles/r01_streams.txt), so the overlap is opt-in.
+        const char *e = getenv("KIWIGPU_ACQ_FRONT_STREAM");
+        a->own_fstream = e && e[0] == '1';
+        if (a->own_fstream) KG_HIP(hipStreamCreateWithFlags(&a->fstream, hipStreamNonBlocking));
+        else a->fstream = ctx->stream;
+    }
     a->ev_ready.resize(max_blocks); a->ev_done.resize(max_blocks);
-    a->has_ready.assign(max_blocks, 0); a->has_done.assign(max_blocks, 0);
+    a->ready_of.assign(max_blocks, -1); a->done_of.assign(max_blocks, -1);
     for (int b = 0; b < max_blocks; b++) {
         KG_HIP(hipEventCreateWithFlags(&a->ev_ready[b], hipEventDisableTiming));
         KG_HIP(hipEventCreateWithFlags(&a->ev_done[b], hipEventDisableTiming));
@@ -589,7 +605,7 @@ void kg_acq_destroy(kg_acq *a)
         (void) hipEventDestroy(a->ev_ready[b]);
         (void) hipEventDestroy(a->ev_done[b]);
     }
-    (void) hipStreamDestroy(a->fstream);
+    if (a->own_fstream) (void) hipStreamDestroy(a->fstream);
     (void) hipFree(a->d_code); (void) hipFree(a->d_data); (void) hipFree(a->d_td);
     (void) hipFree(a->d_td_code);
     (void) hipFree(a->d_fsub); (void) hipFree(a->d_fsub_code);
@@ -673,16 +689,30 @@ static int check_block(kg_acq *a, int block, const void *p, const char *who)
     return kg_ctx_use(a->ctx);
 }
 
-// Front-stream bracket for everything that (re)writes block b's data spectrum.
-static int front_begin(kg_acq *a, int b)
+// Front-stream bracket for everything that (re)writes the data spectra of blocks
+// b .. b+n-1.  Events are only ever re-recorded on the same stream, so waiting on a shared
+// event that has since been recorded again waits for later work, never for less.
+static int wait_once(hipStream_t st, const std::vector<hipEvent_t> &ev, const std::vector<int> &of, int b, int n)
 {
-    if (a->has_done[b]) KG_HIP(hipStreamWaitEvent(a->fstream, a->ev_done[b], 0));   // WAR
+    for (int i = b; i < b + n; i++) {
+        const int e = of[i];
+        if (e < 0) continue;
+        bool seen = false;
+        for (int k = b; k < i && !seen; k++) seen = of[k] == e;
+        if (!seen) KG_HIP(hipStreamWaitEvent(st, ev[e], 0));
+    }
     return KG_OK;
 }
-static int front_end(kg_acq *a, int b)
+static int front_begin(kg_acq *a, int b, int n = 1)
 {
+    if (!a->own_fstream) return KG_OK;                                     // same stream: in order anyway
+    return wait_once(a->fstream, a->ev_done, a->done_of, b, n);           // WAR
+}
+static int front_end(kg_acq *a, int b, int n = 1)
+{
+    if (!a->own_fstream) return KG_OK;
     KG_HIP(hipEventRecord(a->ev_ready[b], a->fstream));
-    a->has_ready[b] = 1;
+    for (int i = b; i < b + n; i++) a->ready_of[i] = b;
     return KG_OK;
 }
 
@@ -728,15 +758,12 @@ int kg_acq_sample_iq16_batch_dev(kg_acq *a, int first, int nblocks, const void *
                "kg_acq_sample_iq16_batch_dev: blocks %d..%d (max %d)", first, first + nblocks - 1, a->max_blocks);
     KG_REQUIRE(((uintptr_t) d_iq & 3) == 0 && (stride_bytes & 3) == 0, KG_ERR_INVALID,
                "kg_acq_sample_iq16_batch_dev: pointer/stride not 4-byte aligned");
-    for (int b = first; b < first + nblocks; b++)
-        if ((rc = front_begin(a, b)) != KG_OK) return rc;
+    if ((rc = front_begin(a, first, nblocks)) != KG_OK) return rc;
     rc = launch_frontend<SRC_IQ16>(a, a->fstream, (const uint8_t *) d_iq, stride_bytes, nblocks, 0, 0,
                                    a->d_td + (size_t) first * FFT_LEN, a->d_fsub + (size_t) first * FFT_LEN,
                                    a->d_data + (size_t) first * FFT_LEN, FFT_LEN, 0);
     if (rc) return rc;
-    for (int b = first; b < first + nblocks; b++)
-        if ((rc = front_end(a, b)) != KG_OK) return rc;
-    return KG_OK;
+    return front_end(a, first, nblocks);
 }
 
 int kg_acq_sample_iq16(kg_acq *a, int block, const int16_t *iq)
@@ -839,8 +866,7 @@ int kg_acq_correlate_blocks_async(kg_acq *a, int first, int nblocks, const int *
         a->last_sats.assign(sats, sats + nsats);
         a->table_nblocks = nblocks;
     }
-    for (int b = first; b < first + nblocks; b++)       // RAW: the blocks' front ends
-        if (a->has_ready[b]) KG_HIP(hipStreamWaitEvent(st, a->ev_ready[b], 0));
+    if (a->own_fstream && (rc = wait_once(st, a->ev_ready, a->ready_of, first, nblocks)) != KG_OK) return rc;   // RAW
     const float2 *t4 = a->ctx->d_tab4096, *t16 = a->ctx->d_tab16384;
     if (a->nsel1 > 0) {
         hipLaunchKernelGGL((acq_correlate_kernel<1, true>), dim3(a->grid1), dim3(256), ACQ_LDS_BYTES, st,
@@ -862,9 +888,9 @@ int kg_acq_correlate_blocks_async(kg_acq *a, int first, int nblocks, const int *
     hipLaunchKernelGGL(acq_select_kernel, dim3(npairs), dim3(64), 0, st,
                        (const kg_acq_cell *) a->d_cells, npairs, a->dop_lo, a->ndop, a->d_results);
     KG_HIP(hipGetLastError());
-    for (int b = first; b < first + nblocks; b++) {
-        KG_HIP(hipEventRecord(a->ev_done[b], st));
-        a->has_done[b] = 1;
+    if (a->own_fstream) {
+        KG_HIP(hipEventRecord(a->ev_done[first], st));
+        for (int b = first; b < first + nblocks; b++) a->done_of[b] = first;
     }
     a->last_first = first; a->last_nblocks = nblocks; a->last_nsats = nsats;
     return KG_OK;
