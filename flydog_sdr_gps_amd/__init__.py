@@ -11,7 +11,8 @@ from .acq import Searcher, AcqResult  # noqa: F401
 from .wf import Waterfall, WfParams  # noqa: F401
 from .ddc import Ddc, RxDdc  # noqa: F401
 from .snd import FastFir  # noqa: F401
-from . import sats, prn, synth, shard, wf, snd  # noqa: F401
+from .post import Post  # noqa: F401
+from . import sats, prn, synth, shard, wf, snd, post  # noqa: F401
 
-__all__ = ["KiwiGpuError", "Context", "Searcher", "AcqResult", "Waterfall", "WfParams", "Ddc", "RxDdc", "FastFir",
+__all__ = ["KiwiGpuError", "Context", "Searcher", "AcqResult", "Waterfall", "WfParams", "Ddc", "RxDdc", "FastFir", "Post",
            "load_library", "library_path", "sats", "prn", "synth", "shard", "wf"]

@@ -17,7 +17,8 @@ class KiwiGpuError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "libkiwigpu.so")
+    """The in-tree build; KIWIGPU_LIBRARY names another build of the same ABI (experiments)."""
+    return os.environ.get("KIWIGPU_LIBRARY") or os.path.join(_HERE, "libkiwigpu.so")
 
 
 class AcqResultC(C.Structure):
@@ -106,6 +107,15 @@ SYMBOLS = {
     "kg_fir_pos": (_i, [_vp, _i]),
     "kg_fir_process": (_i, [_vp, _i, _vp, _i, _vp]),
     "kg_fir_process_dev": (_i, [_vp, _vp, _i, _vp, _sz, _i, _vp, _sz, _vp]),
+    "kg_post_create": (_i, [_vp, _i, C.POINTER(_vp)]),
+    "kg_post_destroy": (None, [_vp]),
+    "kg_post_set_agc": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, C.c_float]),
+    "kg_post_agc_delay": (_i, [_vp, _i]),
+    "kg_post_set_smeter": (_i, [_vp, _i, C.c_float]),
+    "kg_post_set_mode": (_i, [_vp, _i, _i]),
+    "kg_post_reset": (_i, [_vp, _i]),
+    "kg_post_process_dev": (_i, [_vp, _vp, _i, _vp, _sz, _i, _vp, _vp, _vp, _sz]),
+    "kg_post_smeter": (_i, [_vp, _vp, _i, _vp, _vp]),
     "kg_acq_debug_fft_stamps": (_i, [_vp, _i, _vp, _i]),
     "kg_acq_debug_corr_stamps": (_i, [_vp, _i, _vp, _i, _vp, _i]),
 }

@@ -297,6 +297,53 @@ int kg_fir_process(kg_fir *fir, int ch, const float *in, int n, float *out);
 int kg_fir_process_dev(kg_fir *fir, const int32_t *chans, int nch, const void *d_in,
                        size_t in_stride, int n, void *d_out, size_t out_stride, int32_t *nout);
 
+/* ---------------------------------------------------------------------------
+ * What consumes the CFastFIR output in c2s_sound(), per receiver channel
+ * (SURVEY.md 8(f) rank 1): S-meter (rx/rx_sound.cpp:248-250, 676-696), the m_Agc[]
+ * array (rx/rx_sound.cpp:152; rx/CuteSDR/agc.cpp) and the AM / NBFM detectors
+ * (rx/rx_sound.cpp:766-783, 845-881).  One object holds these for nchan receivers;
+ * kg_post_process_dev() runs a batch of channels in one launch (one wavefront per
+ * channel: the recursions are sequential per channel, parallel across channels).
+ * ------------------------------------------------------------------------- */
+typedef struct kg_post kg_post;
+
+enum {                      /* what follows the S-meter for a channel (the `switch (s->mode)` of :763-900) */
+    KG_POST_IQ   = 0,       /* MODE_IQ/DRM: CAgc complex -> complex (rx_sound.cpp:1096-1100)       -> d_agc   */
+    KG_POST_SSB  = 1,       /* MODE_USB/USN/LSB/LSN/CW/CWN: CAgc complex -> mono16 (:893)          -> d_s16   */
+    KG_POST_AM   = 2,       /* MODE_AM/AMN: CAgc, envelope, DC-removal IIR (:766-783)              -> d_demod */
+    KG_POST_NBFM = 3        /* MODE_NBFM/NNFM: CAgc, fmdemod_quadri + clipper (:845-881)           -> d_demod */
+};
+
+#define KG_POST_MAX_SAMPLES 1024  /* per call and channel; c2s_sound() hands over ns_out = 512 */
+
+int kg_post_create(kg_ctx *ctx, int nchan, kg_post **out);
+void kg_post_destroy(kg_post *post);
+/* CAgc::SetParameters(AgcOn, UseHang, Threshold, ManualGain, SlopeFactor, Decay, SampleRate)
+ * (agc.cpp:98-163): returns at once when nothing changed; a new sample rate clears the
+ * delay line, the magnitude window and the averagers.  Constants are computed on the
+ * host with the reference's float/double expressions.  A fresh object is in the state
+ * the reference reaches after its first call with a new sample rate. */
+int kg_post_set_agc(kg_post *post, int chan, int agc_on, int use_hang, int threshold, int manual_gain,
+                    int slope_factor, int decay, float sample_rate);
+int kg_post_agc_delay(kg_post *post, int chan);           /* CAgc::GetDelaySamples(), agc.h:27 */
+/* sMeterAlpha = 1 - expf(-1 / (frate * ATTACK_TIMECONST)) (rx_sound.cpp:248-249) */
+int kg_post_set_smeter(kg_post *post, int chan, float frate);
+int kg_post_set_mode(kg_post *post, int chan, int mode);
+/* A new connection on the channel: sMeterAvg_dB = 0, z1 = 0 (rx_sound.cpp:244,250),
+ * conn->last_sample = 0.  The AGC object persists across connections, as m_Agc[] does. */
+int kg_post_reset(kg_post *post, int chan);
+/* One pass over nsamps FIR output samples of each listed channel (d_fir + i*in_stride,
+ * complex float).  Outputs (any may be NULL) at row i*out_stride of d_s16 (int16),
+ * d_demod (float), d_agc (complex float), by the channel's mode.  Float -> mono16 is
+ * the reference's (TYPEMONO16) cast: truncation; outside the int16 range (undefined in
+ * C) the low 16 bits of the int32 conversion, as x86 does.  Enqueue only. */
+int kg_post_process_dev(kg_post *post, const int32_t *chans, int nch, const void *d_fir, size_t in_stride,
+                        int nsamps, void *d_s16, void *d_demod, void *d_agc, size_t out_stride);
+/* S-meter state after the last pass: avg_dB[i] = sMeterAvg_dB, and (taps != NULL)
+ * taps[2i], taps[2i+1] = the values receive_S_meter() is handed at j == 0 and j == ns_out/2
+ * (rx_sound.cpp:693), all before S_meter_cal is added.  Synchronises the stream. */
+int kg_post_smeter(kg_post *post, const int32_t *chans, int nch, float *avg_dB, float *taps);
+
 /* Diagnostics: re-runs the 4096-point stage of the forward FFT of `block` in a
  * stamped build of the kernel and returns 4 s_memrealtime readings (100 MHz):
  * start, inputs + twiddles loaded, transform done, results stored. */

@@ -28,6 +28,7 @@
 #ifndef KIWI_ORACLE_H
 #define KIWI_ORACLE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -201,6 +202,29 @@ typedef struct {
 extern const int32_t ko_cicf_taps65[33];
 void ko_ddc_rx_reset(ko_ddc_rx_state *s);
 int ko_ddc_rx(ko_ddc_rx_state *s, const int16_t *adc, long n, uint64_t phase_inc, uint8_t *out);
+
+/* ---- part 6: S-meter, CAgc, AM / NBFM detectors (kiwi_oracle_post.c) ---- */
+#define KO_AGC_MAX_DELAY_BUF 2048        /* agc.h:16 */
+typedef struct {                          /* agc.h:30-64 */
+    int agc_on, use_hang, threshold, manual_gain, decay;
+    float slope_factor, sample_rate;
+    float manual_agc_gain, decay_ave, attack_ave;
+    float attack_rise_alpha, attack_fall_alpha, decay_rise_alpha, decay_fall_alpha;
+    float fixed_gain, knee, gain_slope, peak;
+    int sig_delay_ptr, mag_buf_pos, delay_samples, window_samples, hang_time, hang_timer;
+    ko_cpx sig_delay_buf[KO_AGC_MAX_DELAY_BUF];
+    float mag_buf[KO_AGC_MAX_DELAY_BUF];
+} ko_agc_state;
+size_t ko_agc_state_size(void);
+void ko_agc_init(ko_agc_state *s);
+void ko_agc_set_parameters(ko_agc_state *s, int agc_on, int use_hang, int threshold, int manual_gain,
+                           int slope_factor, int decay, float sample_rate);
+void ko_agc_process_cpx(ko_agc_state *s, int n, const ko_cpx *in, ko_cpx *out);
+void ko_agc_process_s16(ko_agc_state *s, int n, const ko_cpx *in, int16_t *out);
+float ko_smeter_alpha(float frate);
+float ko_smeter_process(float avg_dB, float alpha, int n, const ko_cpx *in, float *tap);
+void ko_am_detect(double *z1, int n, const ko_cpx *agc, float *demod);
+void ko_nbfm_detect(ko_cpx *last, int n, const ko_cpx *agc, float *demod);
 
 #ifdef __cplusplus
 }

@@ -318,6 +318,71 @@ def fir_process(state, coef_cic, x, prec=1):
     return out[:n].copy(), state.in_pos - (FIR_SIZE - 1)          # FirPos(), fastfir.h:33
 
 
+# ---- S-meter, CAgc, AM / NBFM detectors (kiwi_oracle_post.c) -----------------------
+class Agc:
+    """One CAgc instance (agc.cpp).  State lives in an opaque buffer of ko_agc_state_size()."""
+
+    def __init__(self):
+        L = lib()
+        L.ko_agc_state_size.restype = C.c_size_t
+        self._buf = C.create_string_buffer(L.ko_agc_state_size())
+        L.ko_agc_init(self._buf)
+
+    def set_parameters(self, agc_on, use_hang, threshold, manual_gain, slope, decay, sample_rate):
+        L = lib()
+        L.ko_agc_set_parameters.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_float]
+        L.ko_agc_set_parameters(self._buf, int(agc_on), int(use_hang), int(threshold), int(manual_gain),
+                                int(slope), int(decay), float(sample_rate))
+
+    def process_cpx(self, x):
+        x = np.ascontiguousarray(x, cpx)
+        out = np.empty(x.size, cpx)
+        lib().ko_agc_process_cpx(self._buf, C.c_int(x.size), _p(x), _p(out))
+        return out
+
+    def process_s16(self, x):
+        x = np.ascontiguousarray(x, cpx)
+        out = np.empty(x.size, np.int16)
+        lib().ko_agc_process_s16(self._buf, C.c_int(x.size), _p(x), _p(out))
+        return out
+
+
+def smeter_alpha(frate):
+    L = lib()
+    L.ko_smeter_alpha.argtypes = [C.c_float]
+    L.ko_smeter_alpha.restype = C.c_float
+    return float(L.ko_smeter_alpha(float(frate)))
+
+
+def smeter_process(avg_dB, alpha, x):
+    """-> (new average, (value at j == 0, value at j == n/2))"""
+    L = lib()
+    L.ko_smeter_process.argtypes = [C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+    L.ko_smeter_process.restype = C.c_float
+    x = np.ascontiguousarray(x, cpx)
+    tap = np.zeros(2, np.float32)
+    avg = L.ko_smeter_process(float(avg_dB), float(alpha), x.size, _p(x), _p(tap))
+    return float(avg), (float(tap[0]), float(tap[1]))
+
+
+def am_detect(z1, agc):
+    """-> (demod float32[n], new z1)"""
+    agc = np.ascontiguousarray(agc, cpx)
+    z = C.c_double(z1)
+    out = np.empty(agc.size, np.float32)
+    lib().ko_am_detect(C.byref(z), C.c_int(agc.size), _p(agc), _p(out))
+    return out, z.value
+
+
+def nbfm_detect(last, agc):
+    """last = (re, im) of conn->last_sample -> (demod float32[n], new last)"""
+    agc = np.ascontiguousarray(agc, cpx)
+    l = np.array([complex(last[0], last[1])], cpx)
+    out = np.empty(agc.size, np.float32)
+    lib().ko_nbfm_detect(_p(l), C.c_int(agc.size), _p(agc), _p(out))
+    return out, (float(l[0].real), float(l[0].imag))
+
+
 # ---- waterfall DDC ---------------------------------------------------------------
 class DdcCicState(C.Structure):
     _fields_ = [("integ", (C.c_uint64 * 2) * 4), ("integ5", C.c_uint32),

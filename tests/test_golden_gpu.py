@@ -54,3 +54,35 @@ def test_unpack_fir_ddc(gpu_ctx):
     r.set_freq(0, int(d["inc_rx"]))
     assert np.array_equal(r.push(d["adc_rx"], [0])[0], d["rx_records"])
     r.close()
+
+
+def test_post_golden(gpu_ctx):
+    """S-meter / CAgc / detectors against the committed oracle outputs (tests/golden/post_golden.npz);
+    bars as in tests/test_post_gpu.py."""
+    from flydog_sdr_gps_amd import Post, post
+    g = np.load(os.path.join(GOLD, "post_golden.npz"))
+    x, n = g["x"], g["x"].size
+    P = Post(gpu_ctx, nchan=9)
+    try:
+        for k, args in enumerate(g["agc_args"]):
+            for m, mode in enumerate((post.MODE_SSB, post.MODE_AM, post.MODE_NBFM)):
+                ch = 3 * k + m
+                P.set_agc(ch, *[int(v) for v in args], float(g["rate"]))
+                P.set_smeter(ch, float(g["rate"])); P.set_mode(ch, mode); P.reset(ch)
+        outs = [P.process(np.arange(9), np.tile(x[i:i + 512], (9, 1))) for i in range(0, n, 512)]
+        s16 = np.concatenate([o[0] for o in outs], axis=1)
+        dem = np.concatenate([o[1] for o in outs], axis=1)
+        agc = np.concatenate([o[2] for o in outs], axis=1)
+        for k in range(3):
+            want = g["agc_cpx_%d" % k]
+            d = np.abs(s16[3 * k].astype(int) - g["agc_s16_%d" % k].astype(int))
+            assert d.max() <= 1 and (d == 0).mean() >= 0.99
+            for ch in (3 * k + 1, 3 * k + 2):
+                assert np.abs(agc[ch] - want).max() <= 1e-5 * np.abs(want).max()
+            zmax = 100.0 * float(np.abs(want).max())
+            assert np.abs(dem[3 * k + 1] - g["am_%d" % k]).max() <= 4 * float(np.spacing(np.float32(zmax))) + 1e-5 * np.abs(g["am_%d" % k]).max()
+            assert np.abs(dem[3 * k + 2] - g["nbfm_%d" % k]).max() <= 2e-5 * 8192
+        avg, taps = P.smeter([0])
+        assert abs(avg[0] - g["smeter"][1]) <= 1e-4 and np.abs(taps[0] - g["smeter"][2:]).max() <= 1e-4
+    finally:
+        P.close()

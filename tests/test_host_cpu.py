@@ -362,3 +362,87 @@ def test_golden_snd_and_ddc_oracle(oracle):
     for l2 in (0, 4, 11):
         assert np.array_equal(oracle.ddc_wf(d["adc"], int(d["inc"]), l2)[0], d["wf_r%d" % l2])
     assert np.array_equal(oracle.ddc_rx(d["adc_rx"], int(d["inc_rx"]))[0], d["rx_records"])
+
+
+def test_golden_post_oracle(oracle):
+    """tests/golden/post_golden.npz (tools/make_golden.py) against the oracle built here.  The
+    fixture holds libm results (log10f, powf) of the image it was made on, so floats are
+    compared to 1e-6 of their scale rather than bit for bit."""
+    g = np.load(os.path.join(GOLD, "post_golden.npz"))
+    x, n = g["x"], g["x"].size
+    for k, args in enumerate(g["agc_args"]):
+        a, b = oracle.Agc(), oracle.Agc()
+        a.set_parameters(*[int(v) for v in args], float(g["rate"]))
+        b.set_parameters(*[int(v) for v in args], float(g["rate"]))
+        cp = np.concatenate([a.process_cpx(x[i:i + 512]) for i in range(0, n, 512)])
+        s16 = np.concatenate([b.process_s16(x[i:i + 512]) for i in range(0, n, 512)])
+        assert np.abs(cp - g["agc_cpx_%d" % k]).max() <= 1e-6 * np.abs(cp).max()
+        assert np.abs(s16.astype(int) - g["agc_s16_%d" % k].astype(int)).max() <= 1
+        am = oracle.am_detect(0.0, g["agc_cpx_%d" % k])[0]
+        fm = oracle.nbfm_detect((0.0, 0.0), g["agc_cpx_%d" % k])[0]
+        assert np.array_equal(am, g["am_%d" % k]) and np.array_equal(fm, g["nbfm_%d" % k])   # no libm inside
+    al = oracle.smeter_alpha(12000.0)
+    avg = 0.0
+    for i in range(0, n, 512):
+        avg, taps = oracle.smeter_process(avg, al, x[i:i + 512])
+    assert np.allclose([al, avg, taps[0], taps[1]], g["smeter"], rtol=1e-6, atol=1e-5)
+
+
+def test_post_oracle_known_answers(oracle):
+    """Closed forms for the restatement of agc.cpp / rx_sound.cpp:676-881 (no reference vectors
+    exist for these): steady-state AGC level, delay, manual gain, S-meter level, detectors."""
+    t = np.arange(8192)
+    for amp in (300.0, 20000.0):
+        a = oracle.Agc()
+        a.set_parameters(True, False, -130, 50, 0, 100, 12000.0)
+        x = (amp * np.exp(2j * np.pi * 0.05 * t)).astype(np.complex64)
+        y = a.process_cpx(x)
+        assert np.allclose(np.abs(y[-256:]), 0.7 * 32767, rtol=2e-3)               # AGC_OUTSCALE, slope 0
+        assert np.abs(np.angle(y[-256:] * np.conj(x[-256 - 180:-180]))).max() < 1e-3   # 12000 * .015 samples late
+        avg, _ = oracle.smeter_process(0.0, oracle.smeter_alpha(12000.0), x)
+        assert abs(avg - 10 * np.log10(amp * amp / 8191.0 ** 2)) < 1e-2
+    m = oracle.Agc()
+    m.set_parameters(False, False, -100, 80, 6, 1000, 12000.0)
+    x = (1000 * np.exp(2j * np.pi * 0.01 * t)).astype(np.complex64)
+    y = m.process_cpx(x)
+    assert np.allclose(y, np.float32(32767.0 * 10 ** -1.0) * x, rtol=1e-6)
+    fm, last = oracle.nbfm_detect((0.0, 0.0), y)
+    k = 0.340447550238101026565118445432744920253753662109375
+    assert np.allclose(fm[1:], 32767 * k * np.sin(2 * np.pi * 0.01), rtol=1e-3) and last == (float(y[-1].real), float(y[-1].imag))
+    assert np.all(np.abs(oracle.nbfm_detect((0.0, 0.0), (1000 * np.exp(2j * np.pi * 0.2 * t)).astype(np.complex64))[0][1:]) == 8192)
+    am, z1 = oracle.am_detect(0.0, np.full(4096, 100 + 0j, np.complex64))
+    assert am[0] == 100 and abs(am[-1]) < 1e-3 and abs(z1 - 100 / (1 - 0.99)) < 0.1
+    assert np.array_equal(oracle.Agc().process_s16(np.zeros(4, np.complex64)), np.zeros(4, np.int16))
+
+
+def test_agc_peak_is_the_window_maximum():
+    """The GPU path computes m_Peak as a sliding-window maximum instead of the reference's
+    running maximum with rescans (agc.cpp:193-210).  Both bookkeepings, restated here on plain
+    floats, give the same sequence for any input >= -8 -- including ties, decays where the
+    maximum leaves the window at every step, and the initial fill of -16."""
+    rng = np.random.default_rng(2)
+    for W in (1, 2, 7, 216):
+        for kind in range(4):
+            n = 1500
+            if kind == 0:
+                m = rng.uniform(-8, 0, n)
+            elif kind == 1:
+                m = np.linspace(-0.5, -7.5, n)                           # strictly falling
+            elif kind == 2:
+                m = rng.integers(-8, 0, n).astype(float)                 # many exact ties
+            else:
+                m = np.where(np.arange(n) % 500 < 250, -8.0, -2.0)
+            m = m.astype(np.float32)
+            buf, pos, peak, ref = np.full(W, -16.0, np.float32), 0, np.float32(-16.0), []
+            for v in m:                                                   # the reference's bookkeeping
+                tmp = buf[pos]
+                buf[pos] = v
+                pos = 0 if pos + 1 >= W else pos + 1
+                if v > peak:
+                    peak = v
+                elif tmp == peak:
+                    peak = max(np.float32(-8.0), buf.max())
+                ref.append(peak)
+            hist = np.concatenate([np.full(W, -16.0, np.float32), m])
+            win = np.array([hist[j + 1:j + 1 + W].max() for j in range(n)])   # the GPU's formulation
+            assert np.array_equal(np.array(ref, np.float32), win)

@@ -1,0 +1,237 @@
+"""GPU parity of the S-meter / CAgc / AM / NBFM row (kg_post) through the C ABI against the
+oracle's restatement of rx/CuteSDR/agc.cpp and rx/rx_sound.cpp:676-881.
+
+Bars.  The arithmetic is float with double intermediates, identical on both sides except for
+log10f / powf (device libm vs host libm, <= 2 ulp each), so:
+  complex AGC output      <= 1e-5 of the largest output magnitude (north_star float bar)
+  mono16 AGC output       |diff| <= 1 LSB (a truncating cast of a value that moved by ~1e-7), and
+                          at least 99 % of the samples identical
+  S-meter average         <= 1e-4 dB absolute
+  AM detector output      <= 4 float steps of the IIR state z (z ~ 100 x the envelope: that step IS
+                          the resolution of the reference's own output)
+  NBFM detector output    <= 1e-5 of full scale (8192, the clipper), + 1e-5 relative
+"""
+import numpy as np
+import pytest
+
+from flydog_sdr_gps_amd import Post, post
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+def tone(n, amp, f, rng, noise=20.0, start=0):
+    t = np.arange(start, start + n)
+    x = amp * np.exp(2j * np.pi * f * t) + rng.normal(0, noise, n) + 1j * rng.normal(0, noise, n)
+    return x.astype(np.complex64)
+
+
+def signals(n, rng):
+    """A set of envelopes that exercise the window-maximum bookkeeping: steady, steps up and down,
+    slow exponential decay (the maximum leaves the window at every sample), exact repeats
+    (ties), silence."""
+    t = np.arange(n)
+    out = []
+    out.append(tone(n, 3000.0, 0.05, rng))
+    step = np.where((t // 700) % 2 == 0, 200.0, 9000.0)
+    out.append((step * np.exp(2j * np.pi * 0.031 * t)).astype(np.complex64))
+    out.append((12000.0 * np.exp(-t / 900.0) * np.exp(2j * np.pi * 0.11 * t)).astype(np.complex64))
+    out.append(np.tile(np.array([100 + 50j, -100 + 50j, 100 - 50j, 30 + 1j], np.complex64), n // 4 + 1)[:n])
+    z = tone(n, 5000.0, 0.02, rng)
+    z[n // 3: n // 3 + 600] = 0
+    out.append(z)
+    am = 4000.0 * (1 + 0.6 * np.sin(2 * np.pi * t / 37.0))
+    out.append((am * np.exp(2j * np.pi * 0.07 * t) + rng.normal(0, 5, n)).astype(np.complex64))
+    ph = 2 * np.pi * np.cumsum(0.04 + 0.03 * np.sin(2 * np.pi * t / 50.0))
+    out.append((6000.0 * np.exp(1j * ph)).astype(np.complex64))
+    out.append(np.zeros(n, np.complex64))
+    return out
+
+
+PARAMS = [   # agc_on, hang, threshold, manual_gain, slope, decay, rate
+    (True, False, -100, 50, 6, 1000, 12000.0),      # the web client's defaults for SSB
+    (True, True, -90, 50, 3, 500, 12000.0),         # hang timer
+    (True, False, -130, 50, 0, 100, 20250.0),       # fast decay, 20.25 kHz mode
+    (False, False, -100, 60, 6, 1000, 12000.0),     # manual gain
+    (True, True, -60, 50, 10, 2000, 12000.0),       # high knee: fixed-gain branch most of the time
+]
+
+
+def run_oracle(oracle, prm, mode, blocks, smeter_rate):
+    a = oracle.Agc()
+    a.set_parameters(*prm)
+    alpha = oracle.smeter_alpha(smeter_rate)
+    avg, z1, last = 0.0, 0.0, (0.0, 0.0)
+    outs, taps = [], None
+    for x in blocks:
+        avg, taps = oracle.smeter_process(avg, alpha, x)
+        if mode == post.MODE_SSB:
+            outs.append(a.process_s16(x))
+        else:
+            y = a.process_cpx(x)
+            if mode == post.MODE_AM:
+                d, z1 = oracle.am_detect(z1, y)
+                outs.append((y, d))
+            elif mode == post.MODE_NBFM:
+                d, last = oracle.nbfm_detect(last, y)
+                outs.append((y, d))
+            else:
+                outs.append((y, None))
+    return outs, avg, taps, z1
+
+
+def check_cpx(got, want):
+    scale = max(float(np.abs(want).max()), 1e-30)
+    assert float(np.abs(got - want).max()) <= RTOL * scale
+
+
+def check_s16(got, want):
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 1, "mono16 differs by %d" % d.max()
+    assert (d == 0).mean() >= 0.99
+
+
+@pytest.mark.parametrize("mode", [post.MODE_SSB, post.MODE_IQ, post.MODE_AM, post.MODE_NBFM])
+def test_batch_of_channels_matches_oracle(gpu_ctx, oracle, mode):
+    """len(signals) x len(PARAMS) channels in one launch per 512-sample block, 6 blocks in a row
+    (state carried on the device), every channel against its own oracle instance."""
+    rng = np.random.default_rng(11 + mode)
+    nblk, n = 6, 512
+    sigs = signals(nblk * n, rng)
+    combos = [(s, p) for s in range(len(sigs)) for p in range(len(PARAMS))]
+    P = Post(gpu_ctx, nchan=len(combos))
+    try:
+        for ch, (s, p) in enumerate(combos):
+            P.set_agc(ch, *PARAMS[p])
+            P.set_smeter(ch, PARAMS[p][6])
+            P.set_mode(ch, mode)
+            P.reset(ch)
+        chans = np.arange(len(combos), dtype=np.int32)
+        got = []
+        for b in range(nblk):
+            x = np.stack([sigs[s][b * n:(b + 1) * n] for s, _ in combos])
+            got.append(P.process(chans, x))
+        avg, taps = P.smeter(chans)
+        for ch, (s, p) in enumerate(combos):
+            blocks = [sigs[s][b * n:(b + 1) * n] for b in range(nblk)]
+            want, wavg, wtaps, wz1 = run_oracle(oracle, PARAMS[p], mode, blocks, PARAMS[p][6])
+            assert abs(float(avg[ch]) - wavg) <= 1e-4, (ch, avg[ch], wavg)
+            assert abs(float(taps[ch, 0]) - wtaps[0]) <= 1e-4 and abs(float(taps[ch, 1]) - wtaps[1]) <= 1e-4
+            for b in range(nblk):
+                s16, demod, agc = (a[ch] for a in got[b])
+                if mode == post.MODE_SSB:
+                    check_s16(s16, want[b])
+                    continue
+                wy, wd = want[b]
+                check_cpx(agc, wy)
+                if mode == post.MODE_AM:
+                    zstep = np.spacing(np.float32(max(abs(wz1), 1.0)))
+                    assert float(np.abs(demod - wd).max()) <= 4 * float(zstep) + 1e-5 * float(np.abs(wd).max())
+                elif mode == post.MODE_NBFM:
+                    assert float(np.abs(demod - wd).max()) <= 1e-5 * 8192 + 1e-5 * float(np.abs(wd).max())
+    finally:
+        P.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 171, 512, 1000, 1024])
+def test_block_lengths_and_continuity(gpu_ctx, oracle, n):
+    """Any call length gives the same stream as the oracle fed the same pieces, including calls
+    shorter than the delay line and the magnitude window."""
+    rng = np.random.default_rng(n)
+    total = 3000
+    x = signals(total, rng)[1] + tone(total, 50.0, 0.2, rng)
+    P = Post(gpu_ctx, nchan=2)
+    try:
+        P.set_agc(1, *PARAMS[1]); P.set_smeter(1, 12000.0); P.set_mode(1, post.MODE_IQ); P.reset(1)
+        a = oracle.Agc(); a.set_parameters(*PARAMS[1])
+        pos = 0
+        calls = 0
+        while pos < total and calls < 40:
+            m = min(n, total - pos)
+            _, _, agc = P.process([1], x[pos:pos + m][None, :])
+            check_cpx(agc[0], a.process_cpx(x[pos:pos + m]))
+            pos += m
+            calls += 1
+        assert P.agc_delay(1) == int(np.float32(12000.0) * .015) == 180
+    finally:
+        P.close()
+
+
+def test_set_parameters_semantics(gpu_ctx, oracle):
+    """agc.cpp:101-131: identical arguments change nothing; a new decay keeps the delay line and
+    the averagers; a new sample rate clears them; switching AGC off freezes its state."""
+    rng = np.random.default_rng(5)
+    x = tone(4 * 512, 2500.0, 0.03, rng)
+    P = Post(gpu_ctx, nchan=1)
+    a = oracle.Agc()
+    try:
+        P.set_mode(0, post.MODE_IQ)
+        steps = [
+            (True, False, -100, 50, 6, 1000, 12000.0),
+            (True, False, -100, 50, 6, 1000, 12000.0),     # no change
+            (True, False, -100, 50, 6, 250, 12000.0),      # decay only
+            (False, False, -100, 70, 6, 250, 12000.0),     # manual
+            (True, True, -100, 70, 6, 250, 12000.0),       # back on, state as it was left
+            (True, True, -100, 70, 6, 250, 20250.0),       # rate change: cleared
+        ]
+        for k, prm in enumerate(steps):
+            P.set_agc(0, *prm)
+            a.set_parameters(*prm)
+            blk = x[(k % 4) * 512:(k % 4) * 512 + 512]
+            _, _, agc = P.process([0], blk[None, :])
+            check_cpx(agc[0], a.process_cpx(blk))
+    finally:
+        P.close()
+
+
+def test_known_answers(gpu_ctx):
+    """Closed forms that need no oracle: above the knee with slope 0 a steady tone leaves the AGC at
+    0.7 x 32767 whatever its level, delayed by GetDelaySamples(); manual gain is a plain factor;
+    the S-meter settles at 10 log10(P / 8191^2); the NBFM detector of a tone at f is
+    32767 K sin(2 pi f / fs); the AM detector of a steady carrier decays to 0."""
+    n, nblk = 1024, 8
+    t = np.arange(n * nblk)
+    P = Post(gpu_ctx, nchan=4)
+    try:
+        for ch, amp in enumerate((300.0, 20000.0)):
+            P.set_agc(ch, True, False, -130, 50, 0, 100, 12000.0)
+            P.set_smeter(ch, 12000.0); P.set_mode(ch, post.MODE_IQ); P.reset(ch)
+        P.set_agc(2, False, False, -100, 80, 6, 1000, 12000.0); P.set_mode(2, post.MODE_NBFM); P.reset(2)
+        P.set_agc(3, False, False, -100, 100, 6, 1000, 12000.0); P.set_mode(3, post.MODE_AM); P.reset(3)
+        x = np.stack([300.0 * np.exp(2j * np.pi * 0.05 * t), 20000.0 * np.exp(2j * np.pi * 0.05 * t),
+                      1000.0 * np.exp(2j * np.pi * 0.01 * t), 0.25 * np.exp(2j * np.pi * 0.02 * t)]).astype(np.complex64)
+        for b in range(nblk):
+            s16, demod, agc = P.process([0, 1, 2, 3], x[:, b * n:(b + 1) * n])
+        for ch in (0, 1):
+            assert np.allclose(np.abs(agc[ch][-256:]), 0.7 * 32767, rtol=2e-3)
+            want = x[ch, (nblk - 1) * n - 180:nblk * n - 180]
+            ph = np.angle(agc[ch][-256:] * np.conj(want[-256:]))
+            assert np.abs(ph).max() < 1e-3
+        avg, _ = P.smeter([0, 1])
+        for ch, amp in enumerate((300.0, 20000.0)):
+            assert abs(avg[ch] - 10 * np.log10(amp * amp / 8191.0 ** 2)) < 1e-2
+        g = 32767.0 * 10 ** (-(100 - 80) / 20.0)
+        assert np.allclose(agc[2], g * x[2, -n:], rtol=1e-5)
+        k = 0.340447550238101026565118445432744920253753662109375
+        assert np.allclose(demod[2][1:], 32767 * k * np.sin(2 * np.pi * 0.01), rtol=1e-3)
+        assert np.abs(demod[3][-256:]).max() < 1e-2 * 32767 * 0.25 + 1.0
+    finally:
+        P.close()
+
+
+def test_argument_errors(gpu_ctx):
+    from flydog_sdr_gps_amd import KiwiGpuError
+    P = Post(gpu_ctx, nchan=2)
+    try:
+        with pytest.raises(KiwiGpuError):
+            P.set_agc(2, True, False, -100, 50, 6, 1000, 12000.0)          # channel out of range
+        with pytest.raises(KiwiGpuError):
+            P.set_agc(0, True, False, -100, 50, 6, 1000, 200000.0)         # window > MAX_DELAY_BUF
+        with pytest.raises(KiwiGpuError):
+            P.set_mode(0, 9)
+        with pytest.raises(KiwiGpuError):
+            P.process([0, 0], np.zeros((2, 16), np.complex64))             # listed twice
+        with pytest.raises(KiwiGpuError):
+            P.process([0], np.zeros((1, 1025), np.complex64))              # > KG_POST_MAX_SAMPLES
+    finally:
+        P.close()

@@ -131,3 +131,27 @@ dd["inc_rx"] = np.uint64(inc_rx)
 dd["rx_records"] = ko.ddc_rx(adc_rx, inc_rx)[0]
 np.savez_compressed(os.path.join(GOLD, "ddc_golden.npz"), **dd)
 print("ddc: wf outputs", {k: v.shape for k, v in dd.items() if k.startswith("wf_")}, "rx records", dd["rx_records"].size // 6)
+
+# ---- S-meter / CAgc / detectors (kiwi_oracle_post.c) ----------------------------------
+rng = np.random.default_rng(0x5EED0B)
+n = 4 * 512
+t = np.arange(n)
+env = np.where((t // 600) % 2 == 0, 400.0, 7000.0) * np.exp(-(t % 600) / 500.0)
+xp = (env * np.exp(2j * np.pi * 0.043 * t) + rng.normal(0, 8, n) + 1j * rng.normal(0, 8, n)).astype(np.complex64)
+pg = {"x": xp, "agc_args": np.array([[1, 0, -100, 50, 6, 1000], [1, 1, -90, 50, 3, 500], [0, 0, -100, 60, 6, 1000]]),
+      "rate": np.float32(12000.0)}
+for k, args in enumerate(pg["agc_args"]):
+    a = ko.Agc(); a.set_parameters(*[int(v) for v in args], 12000.0)
+    b = ko.Agc(); b.set_parameters(*[int(v) for v in args], 12000.0)
+    cp = np.concatenate([a.process_cpx(xp[i:i + 512]) for i in range(0, n, 512)])
+    pg["agc_cpx_%d" % k] = cp
+    pg["agc_s16_%d" % k] = np.concatenate([b.process_s16(xp[i:i + 512]) for i in range(0, n, 512)])
+    pg["am_%d" % k] = ko.am_detect(0.0, cp)[0]
+    pg["nbfm_%d" % k] = ko.nbfm_detect((0.0, 0.0), cp)[0]
+al = ko.smeter_alpha(12000.0)
+avg, taps = 0.0, None
+for i in range(0, n, 512):
+    avg, taps = ko.smeter_process(avg, al, xp[i:i + 512])
+pg["smeter"] = np.array([al, avg, taps[0], taps[1]], np.float32)
+np.savez_compressed(os.path.join(GOLD, "post_golden.npz"), **pg)
+print("post: smeter", pg["smeter"], "agc |out| max", [float(np.abs(pg["agc_cpx_%d" % k]).max()) for k in range(3)])
