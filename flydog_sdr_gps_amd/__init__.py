@@ -12,7 +12,8 @@ from .wf import Waterfall, WfParams  # noqa: F401
 from .ddc import Ddc, RxDdc  # noqa: F401
 from .snd import FastFir  # noqa: F401
 from .post import Post  # noqa: F401
-from . import sats, prn, synth, shard, wf, snd, post  # noqa: F401
+from .wire import Adpcm  # noqa: F401
+from . import sats, prn, synth, shard, wf, snd, post, wire  # noqa: F401
 
-__all__ = ["KiwiGpuError", "Context", "Searcher", "AcqResult", "Waterfall", "WfParams", "Ddc", "RxDdc", "FastFir", "Post",
+__all__ = ["KiwiGpuError", "Context", "Searcher", "AcqResult", "Waterfall", "WfParams", "Ddc", "RxDdc", "FastFir", "Post", "Adpcm",
            "load_library", "library_path", "sats", "prn", "synth", "shard", "wf"]

@@ -116,6 +116,14 @@ SYMBOLS = {
     "kg_post_reset": (_i, [_vp, _i]),
     "kg_post_process_dev": (_i, [_vp, _vp, _i, _vp, _sz, _i, _vp, _vp, _vp, _sz]),
     "kg_post_smeter": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "kg_adpcm_create": (_i, [_vp, _i, C.POINTER(_vp)]),
+    "kg_adpcm_destroy": (None, [_vp]),
+    "kg_adpcm_set_state": (_i, [_vp, _i, _i, _i]),
+    "kg_adpcm_get_state": (_i, [_vp, _i, _vp, _vp]),
+    "kg_adpcm_encode_dev": (_i, [_vp, _vp, _i, _vp, _sz, _i, _vp, _sz]),
+    "kg_snd_payload_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _vp, _sz]),
+    "kg_snd_header": (None, [C.c_uint8, C.c_uint32, C.c_float, _vp]),
+    "kg_wf_packets_dev": (_i, [_vp, _vp, _sz, _i, _vp, _vp, _sz, _vp]),
     "kg_acq_debug_fft_stamps": (_i, [_vp, _i, _vp, _i]),
     "kg_acq_debug_corr_stamps": (_i, [_vp, _i, _vp, _i, _vp, _i]),
 }

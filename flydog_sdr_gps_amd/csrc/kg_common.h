@@ -39,7 +39,14 @@ struct kg_ctx {
     float2 *d_tab4096;    // exp(+2 pi i k / 4096),  k < 4096
     float2 *d_tab16384;   // exp(+2 pi i k / 16384), k < 16384
     float2 *d_tab8192;    // exp(+2 pi i k / 8192),  k < 8192
+    // small per-call tables (descriptor lists) of entry points that own no object
+    void *d_scratch;
+    size_t scratch_bytes;
 };
+
+// Device scratch of at least `bytes`, filled from `src` before returning (synchronous: the
+// previous user of the scratch is drained first).  Valid until the next call on this context.
+int kg_ctx_scratch_upload(kg_ctx *ctx, const void *src, size_t bytes, void **d_out);
 
 // Make ctx's device current on the calling thread.
 static inline int kg_ctx_use(kg_ctx *ctx)

@@ -15,6 +15,22 @@ void kg_set_error(const char *fmt, ...)
     va_end(ap);
 }
 
+int kg_ctx_scratch_upload(kg_ctx *c, const void *src, size_t bytes, void **d_out)
+{
+    KG_REQUIRE(c && src && d_out && bytes > 0, KG_ERR_INVALID, "kg_ctx_scratch_upload: bad argument");
+    KG_HIP(hipStreamSynchronize(c->stream));
+    if (bytes > c->scratch_bytes) {
+        if (c->d_scratch) KG_HIP(hipFree(c->d_scratch));
+        c->d_scratch = nullptr; c->scratch_bytes = 0;
+        const size_t cap = bytes < 4096 ? 4096 : bytes;
+        KG_HIP(hipMalloc(&c->d_scratch, cap));
+        c->scratch_bytes = cap;
+    }
+    KG_HIP(hipMemcpy(c->d_scratch, src, bytes, hipMemcpyHostToDevice));
+    *d_out = c->d_scratch;
+    return KG_OK;
+}
+
 extern "C" {
 
 const char *kg_last_error(void) { return g_err; }
@@ -103,6 +119,7 @@ void kg_ctx_destroy(kg_ctx *c)
     (void) hipFree(c->d_tab4096);
     (void) hipFree(c->d_tab16384);
     (void) hipFree(c->d_tab8192);
+    if (c->d_scratch) (void) hipFree(c->d_scratch);
     (void) hipEventDestroy(c->ev_start);
     (void) hipEventDestroy(c->ev_stop);
     if (c->own_stream) (void) hipStreamDestroy(c->stream);

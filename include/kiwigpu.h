@@ -344,6 +344,51 @@ int kg_post_process_dev(kg_post *post, const int32_t *chans, int nch, const void
  * (rx_sound.cpp:693), all before S_meter_cal is added.  Synchronises the stream. */
 int kg_post_smeter(kg_post *post, const int32_t *chans, int nch, float *avg_dB, float *taps);
 
+/* ---------------------------------------------------------------------------
+ * Wire formats: the IMA ADPCM coder of rx/csdr/ima_adpcm.cpp
+ * as c2s_sound() and compute_frame() use it, the waterfall packet and the sound packet
+ * header, so that what leaves the GPU is byte-compatible with the web client.
+ * Integer work: bit-exact.
+ * ------------------------------------------------------------------------- */
+typedef struct kg_adpcm kg_adpcm;   /* the per-connection `ima_adpcm_state_t adpcm_snd` (rx/rx_sound.h) of nchan channels */
+
+int kg_adpcm_create(kg_ctx *ctx, int nchan, kg_adpcm **out);
+void kg_adpcm_destroy(kg_adpcm *a);
+/* memset(&s->adpcm_snd, 0, ...) is set_state(chan, 0, 0); get_state() is what the
+ * "MSG audio_adpcm_state=%d,%d" message carries (rx/rx_sound.cpp:1314): index, previousValue. */
+int kg_adpcm_set_state(kg_adpcm *a, int chan, int index, int previous);
+int kg_adpcm_get_state(kg_adpcm *a, int chan, int *index, int *previous);
+/* encode_ima_adpcm_i16_e8(out_samps_s2, bp_real_u1, ns_out, &s->adpcm_snd) (ima_adpcm.cpp:185-197,
+ * rx/rx_sound.cpp:1122) for a list of channels: row i of d_s16 (int16, in_stride samples apart)
+ * -> nsamps/2 bytes at d_out + i*out_stride (bytes).  nsamps even.  Enqueue only. */
+int kg_adpcm_encode_dev(kg_adpcm *a, const int32_t *chans, int nch, const void *d_s16, size_t in_stride,
+                        int nsamps, void *d_out, size_t out_stride);
+/* The uncompressed payload (rx/rx_sound.cpp:1126-1140): int16 rows copied as they are
+ * (little_endian != 0) or byte-swapped to network order.  Enqueue only. */
+int kg_snd_payload_dev(kg_ctx *ctx, const void *d_s16, size_t in_stride, int nch, int nsamps,
+                       int little_endian, void *d_out, size_t out_stride);
+/* The 10 header bytes of snd_pkt_real_t (rx/rx_sound.h:42-48; rx/rx_sound.cpp:252,
+ * 1219-1254): "SND", flags, seq little-endian, S-meter clamped to -127 .. 3.4 dBm and sent
+ * big-endian in 0.1 dB steps above -127.  Host only. */
+void kg_snd_header(uint8_t flags, uint32_t seq, float smeter_dBm, uint8_t *h);
+
+#define KG_WF_ADPCM_PAD 10                          /* ADPCM_PAD, rx/rx_waterfall.h:83 */
+#define KG_WF_PKT_HDR   16                          /* id4, x_bin_server, flags_x_zoom_server, seq */
+#define KG_WF_PKT_MAX   (KG_WF_PKT_HDR + KG_WF_ADPCM_PAD + 1024)   /* sizeof(wf_pkt_t) */
+typedef struct {
+    uint32_t x_bin_server;          /* wf->start or wf->prev_start (rx_waterfall.cpp:1603-1616) */
+    uint32_t zoom;                  /* wf->zoom or wf->prev_zoom; WF_FLAGS_COMPRESSION is added here */
+    uint32_t seq;                   /* wf->snd_seq (:1635) */
+    int32_t use_compression;
+} kg_wf_pkt_info;
+/* wf_pkt_t for nrows waterfall rows (1024 u8 each, row_stride bytes apart, as
+ * kg_wf_frames_dev leaves them): header + either the row or, compressed, the 10 pad bytes
+ * (copies of the first pixel) and the row through encode_ima_adpcm_u8_e8 with a fresh state
+ * (rx_waterfall.cpp:1622-1631).  Packet i starts at d_pkts + i*pkt_stride (>= KG_WF_PKT_MAX);
+ * pkt_bytes[i] (host) = what goes on the wire: 16 + wf->out_bytes.  Enqueue only. */
+int kg_wf_packets_dev(kg_ctx *ctx, const void *d_rows, size_t row_stride, int nrows,
+                      const kg_wf_pkt_info *info, void *d_pkts, size_t pkt_stride, int32_t *pkt_bytes);
+
 /* Diagnostics: re-runs the 4096-point stage of the forward FFT of `block` in a
  * stamped build of the kernel and returns 4 s_memrealtime readings (100 MHz):
  * start, inputs + twiddles loaded, transform done, results stored. */

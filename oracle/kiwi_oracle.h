@@ -226,6 +226,19 @@ float ko_smeter_process(float avg_dB, float alpha, int n, const ko_cpx *in, floa
 void ko_am_detect(double *z1, int n, const ko_cpx *agc, float *demod);
 void ko_nbfm_detect(ko_cpx *last, int n, const ko_cpx *agc, float *demod);
 
+/* ---- part 7: wire formats (kiwi_oracle_wire.c) ---- */
+#define KO_WF_WIDTH 1024                 /* rx_waterfall.h:64 */
+#define KO_WF_ADPCM_PAD 10               /* rx_waterfall.h:83 */
+typedef struct { int index, previous; } ko_adpcm_state;      /* ima_adpcm.h: index, previousValue */
+const int *ko_adpcm_step_table(void);
+void ko_adpcm_encode_i16(const int16_t *in, uint8_t *out, int n, ko_adpcm_state *s);
+void ko_adpcm_encode_u8(const uint8_t *in, uint8_t *out, int n, ko_adpcm_state *s);
+void ko_adpcm_decode_i16(const uint8_t *in, int16_t *out, int nbytes, ko_adpcm_state *s);
+void ko_adpcm_decode_u8(const uint8_t *in, uint8_t *out, int nbytes, ko_adpcm_state *s);
+int ko_wf_packet(const uint8_t *row, uint32_t x_bin_server, uint32_t zoom, uint32_t seq, int use_compression,
+                 uint8_t *pkt);
+void ko_snd_header(uint8_t flags, uint32_t seq, float smeter_dBm, uint8_t *h);
+
 #ifdef __cplusplus
 }
 #endif

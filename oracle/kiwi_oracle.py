@@ -383,6 +383,69 @@ def nbfm_detect(last, agc):
     return out, (float(l[0].real), float(l[0].imag))
 
 
+# ---- wire formats (kiwi_oracle_wire.c) ----------------------------------------------
+class AdpcmState(C.Structure):
+    _fields_ = [("index", C.c_int), ("previous", C.c_int)]
+
+
+def adpcm_encode_i16(x, state=None):
+    """encode_ima_adpcm_i16_e8 -> (bytes uint8[n/2], state)"""
+    st = state if state is not None else AdpcmState(0, 0)
+    x = np.ascontiguousarray(x, np.int16)
+    out = np.empty(x.size // 2, np.uint8)
+    lib().ko_adpcm_encode_i16(_p(x), _p(out), C.c_int(x.size), C.byref(st))
+    return out, st
+
+
+def adpcm_encode_u8(x, state=None):
+    st = state if state is not None else AdpcmState(0, 0)
+    x = np.ascontiguousarray(x, np.uint8)
+    out = np.empty(x.size // 2, np.uint8)
+    lib().ko_adpcm_encode_u8(_p(x), _p(out), C.c_int(x.size), C.byref(st))
+    return out, st
+
+
+def adpcm_decode_i16(b, state=None):
+    st = state if state is not None else AdpcmState(0, 0)
+    b = np.ascontiguousarray(b, np.uint8)
+    out = np.empty(b.size * 2, np.int16)
+    lib().ko_adpcm_decode_i16(_p(b), _p(out), C.c_int(b.size), C.byref(st))
+    return out, st
+
+
+def adpcm_decode_u8(b, state=None):
+    st = state if state is not None else AdpcmState(0, 0)
+    b = np.ascontiguousarray(b, np.uint8)
+    out = np.empty(b.size * 2, np.uint8)
+    lib().ko_adpcm_decode_u8(_p(b), _p(out), C.c_int(b.size), C.byref(st))
+    return out, st
+
+
+def adpcm_step_table():
+    L = lib()
+    L.ko_adpcm_step_table.restype = C.POINTER(C.c_int * 89)
+    return np.array(L.ko_adpcm_step_table().contents[:], np.int32)
+
+
+def wf_packet(row, x_bin_server, zoom, seq, use_compression):
+    L = lib()
+    L.ko_wf_packet.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+    L.ko_wf_packet.restype = C.c_int
+    row = np.ascontiguousarray(row, np.uint8)
+    assert row.size == 1024
+    pkt = np.zeros(16 + 1034, np.uint8)
+    n = L.ko_wf_packet(_p(row), int(x_bin_server), int(zoom), int(seq), int(bool(use_compression)), _p(pkt))
+    return pkt[:n].copy()
+
+
+def snd_header(flags, seq, smeter_dBm):
+    L = lib()
+    L.ko_snd_header.argtypes = [C.c_uint8, C.c_uint32, C.c_float, C.c_void_p]
+    h = np.zeros(10, np.uint8)
+    L.ko_snd_header(int(flags), int(seq) & 0xFFFFFFFF, float(smeter_dBm), _p(h))
+    return h
+
+
 # ---- waterfall DDC ---------------------------------------------------------------
 class DdcCicState(C.Structure):
     _fields_ = [("integ", (C.c_uint64 * 2) * 4), ("integ5", C.c_uint32),

@@ -86,3 +86,18 @@ def test_post_golden(gpu_ctx):
         assert abs(avg[0] - g["smeter"][1]) <= 1e-4 and np.abs(taps[0] - g["smeter"][2:]).max() <= 1e-4
     finally:
         P.close()
+
+
+def test_wire_golden(gpu_ctx):
+    """ADPCM sound coder, waterfall packets and the sound header against tests/golden/wire_golden.npz."""
+    from flydog_sdr_gps_amd import Adpcm, wire
+    g = np.load(os.path.join(GOLD, "wire_golden.npz"))
+    A = Adpcm(gpu_ctx, nchan=1)
+    try:
+        enc = [A.encode([0], g["audio"][None, i:i + 512])[0] for i in range(0, g["audio"].size, 512)]
+        assert np.array_equal(np.concatenate(enc), g["adpcm"]) and list(A.get_state(0)) == list(g["adpcm_state"])
+    finally:
+        A.close()
+    pk = wire.wf_packets(gpu_ctx, np.stack([g["row"], g["row"]]), [(123456, 7, 4242, True), (123456, 7, 4242, False)])
+    assert np.array_equal(pk[0], g["pkt_compressed"]) and np.array_equal(pk[1], g["pkt_raw"])
+    assert np.array_equal(wire.snd_header(gpu_ctx, 0x10, 4242, -87.31), g["snd_header"])

@@ -446,3 +446,55 @@ def test_agc_peak_is_the_window_maximum():
             hist = np.concatenate([np.full(W, -16.0, np.float32), m])
             win = np.array([hist[j + 1:j + 1 + W].max() for j in range(n)])   # the GPU's formulation
             assert np.array_equal(np.array(ref, np.float32), win)
+
+
+def test_adpcm_oracle_pinned_against_audioop(oracle):
+    """The oracle's restatement of rx/csdr/ima_adpcm.cpp against CPython's audioop (the CWI IMA
+    ADPCM codec the reference file descends from), an independent implementation: same codes,
+    same decoder output, same final state.  The reference packs the FIRST sample of a pair into
+    the LOW nibble (ima_adpcm.cpp:192-193); audioop packs it into the high one."""
+    audioop = pytest.importorskip("audioop")
+    rng = np.random.default_rng(6)
+    t = np.arange(6000)
+    for x in (rng.normal(0, 9000, 6000), 20000 * np.sin(t / 7.0), np.where((t // 50) % 2, 32767, -32768),
+              np.zeros(6000), rng.integers(-2, 3, 6000)):
+        x = np.clip(np.rint(x), -32768, 32767).astype(np.int16)
+        got, st = oracle.adpcm_encode_i16(x)
+        ab, ast = audioop.lin2adpcm(x.tobytes(), 2, None)
+        ab = np.frombuffer(ab, np.uint8)
+        assert np.array_equal(got, ((ab >> 4) | (ab << 4)) & 0xFF)
+        assert (st.previous, st.index) == ast
+        dec, dst = oracle.adpcm_decode_i16(got)
+        assert np.array_equal(dec, np.frombuffer(audioop.adpcm2lin(ab.tobytes(), 2, None)[0], np.int16))
+        assert (dst.index, dst.previous) == (st.index, st.previous) and dec[-1] == st.previous
+    tab = oracle.adpcm_step_table()
+    assert tab[0] == 7 and tab[88] == 32767 and np.all(np.diff(tab) > 0)
+    assert np.all(np.abs(tab[1:] / tab[:-1] - 1.1) < 0.15)             # the specification's ~1.1 ratio
+
+
+def test_wire_oracle_properties_and_golden(oracle):
+    g = np.load(os.path.join(GOLD, "wire_golden.npz"))
+    st, enc = None, []
+    for i in range(0, g["audio"].size, 512):
+        e, st = oracle.adpcm_encode_i16(g["audio"][i:i + 512], st)
+        enc.append(e)
+    assert np.array_equal(np.concatenate(enc), g["adpcm"]) and [st.index, st.previous] == list(g["adpcm_state"])
+    pc, pr = oracle.wf_packet(g["row"], 123456, 7, 4242, True), oracle.wf_packet(g["row"], 123456, 7, 4242, False)
+    assert np.array_equal(pc, g["pkt_compressed"]) and np.array_equal(pr, g["pkt_raw"])
+    assert pc.size == 16 + 517 and pr.size == 16 + 1024 and np.array_equal(pr[16:], g["row"])
+    assert bytes(pc[:4]) == b"W/F " and int.from_bytes(bytes(pc[4:8]), "little") == 123456
+    assert int.from_bytes(bytes(pc[8:12]), "little") == 7 | 0x10000 and int.from_bytes(bytes(pr[8:12]), "little") == 7
+    assert int.from_bytes(bytes(pc[12:16]), "little") == 4242
+    # what the client decodes: 10 pad pixels then the row, within the coder's tracking error,
+    # never outside 0..255; the u8 coder is the i16 coder wherever its predictor stays in 0..255
+    dec, _ = oracle.adpcm_decode_u8(pc[16:])
+    assert dec.size == 1034 and np.abs(dec[10:].astype(int) - g["row"].astype(int)).mean() < 6
+    smooth = (128 + 40 * np.sin(np.arange(512) / 20.0)).astype(np.uint8)
+    e8, _ = oracle.adpcm_encode_u8(smooth)
+    e16, _ = oracle.adpcm_encode_i16(smooth.astype(np.int16))
+    assert np.array_equal(e8, e16)
+    assert np.array_equal(oracle.snd_header(0x10, 4242, -87.31), g["snd_header"])
+    h = oracle.snd_header(0xFF, 0xA1B2C3D4, 55.0)
+    assert bytes(h[:3]) == b"SND" and h[3] == 0xFF and list(h[4:8]) == [0xD4, 0xC3, 0xB2, 0xA1]
+    assert (int(h[8]) << 8 | int(h[9])) == int((np.float32(3.4) + 127.0) * 10)
+    assert list(oracle.snd_header(0, 0, -500.0)[8:]) == [0, 0]

@@ -155,3 +155,20 @@ for i in range(0, n, 512):
 pg["smeter"] = np.array([al, avg, taps[0], taps[1]], np.float32)
 np.savez_compressed(os.path.join(GOLD, "post_golden.npz"), **pg)
 print("post: smeter", pg["smeter"], "agc |out| max", [float(np.abs(pg["agc_cpx_%d" % k]).max()) for k in range(3)])
+
+# ---- wire formats (kiwi_oracle_wire.c) ------------------------------------------------
+rng = np.random.default_rng(0x5EED0C)
+t = np.arange(2048)
+aud = np.clip(np.rint(7000 * np.sin(2 * np.pi * 0.011 * t) * (1 + 0.8 * np.sin(2 * np.pi * t / 400.0))
+                      + rng.normal(0, 500, t.size)), -32768, 32767).astype(np.int16)
+st, enc = None, []
+for i in range(0, aud.size, 512):
+    e, st = ko.adpcm_encode_i16(aud[i:i + 512], st)
+    enc.append(e)
+row = np.clip(110 + 70 * np.sin(np.arange(1024) / 11.0) + rng.normal(0, 9, 1024), 0, 255).astype(np.uint8)
+np.savez_compressed(os.path.join(GOLD, "wire_golden.npz"), audio=aud, adpcm=np.concatenate(enc),
+                    adpcm_state=np.array([st.index, st.previous]), row=row,
+                    pkt_compressed=ko.wf_packet(row, 123456, 7, 4242, True),
+                    pkt_raw=ko.wf_packet(row, 123456, 7, 4242, False),
+                    snd_header=ko.snd_header(0x10, 4242, -87.31))
+print("wire: adpcm bytes", sum(e.size for e in enc), "state", (st.index, st.previous))
