@@ -13,7 +13,8 @@ from .ddc import Ddc, RxDdc  # noqa: F401
 from .snd import FastFir  # noqa: F401
 from .post import Post  # noqa: F401
 from .wire import Adpcm  # noqa: F401
-from . import sats, prn, synth, shard, wf, snd, post, wire  # noqa: F401
+from .handoff import Aperture, chan_start  # noqa: F401
+from . import sats, prn, synth, shard, wf, snd, post, wire, handoff  # noqa: F401
 
-__all__ = ["KiwiGpuError", "Context", "Searcher", "AcqResult", "Waterfall", "WfParams", "Ddc", "RxDdc", "FastFir", "Post", "Adpcm",
+__all__ = ["KiwiGpuError", "Context", "Searcher", "AcqResult", "Waterfall", "WfParams", "Ddc", "RxDdc", "FastFir", "Post", "Adpcm", "Aperture", "chan_start",
            "load_library", "library_path", "sats", "prn", "synth", "shard", "wf"]

@@ -389,6 +389,44 @@ typedef struct {
 int kg_wf_packets_dev(kg_ctx *ctx, const void *d_rows, size_t row_stride, int nrows,
                       const kg_wf_pkt_info *info, void *d_pkts, size_t pkt_stride, int32_t *pkt_bytes);
 
+/* ---------------------------------------------------------------------------
+ * Hand-off: what turns the path's results into the reference's
+ * own programming.
+ * ------------------------------------------------------------------------- */
+typedef struct {
+    double lo_dop, ca_dop;          /* Hz: Doppler from the FFT bin shift, and of the code rate */
+    uint32_t lo_rate, ca_rate;      /* CmdSetRateLO / CmdSetRateCG words */
+    uint32_t ca_pause;              /* CmdPause takes ca_pause - 1 when ca_pause != 0 */
+    int32_t code_creep;             /* samples */
+} kg_chan_start;
+/* The arithmetic of CHANNEL::Start(sat, t_sample, lo_shift, ca_shift, snr)
+ * (gps/channel.cpp:281-311) for a kg_acq_result: lo_shift = result.dop, ca_shift =
+ * result.idx * DECIM (gps/search.cpp:575), secs = (timer_us() - t_sample) / 1e6.
+ * Host only, double arithmetic as in the reference. */
+void kg_acq_chan_start(int is_e1b, int lo_shift, int ca_shift, double secs, kg_chan_start *out);
+
+typedef struct kg_aper kg_aper;     /* wf_inst_t::avg_pwr[APER_PWR_LEN] of nchan waterfalls (rx/rx_waterfall.h:154) */
+enum { KG_APER_IIR = 0, KG_APER_MMA = 1, KG_APER_EMA = 2 };      /* aper_algo_t, rx/rx_waterfall.h:113 */
+typedef struct {
+    int32_t algo;                   /* KG_APER_*; a single-shot request is MMA with param 8 (:1192-1195) */
+    float param;                    /* wf->aper_param */
+    int32_t clear;                  /* wf->avg_clear: load the averages from this row (:1183-1188) */
+    int32_t audio_fft;              /* rx_chan >= wf_chans: pixels 256..767 only (:1180-1181) */
+} kg_aper_cfg;
+int kg_aper_create(kg_ctx *ctx, int nchan, kg_aper **out);
+void kg_aper_destroy(kg_aper *a);
+/* The averaging half of aperture_auto() (rx/rx_waterfall.cpp:1183-1222) for row i of d_rows
+ * (1024 u8 pixels, row_stride apart) and channel chans[i]; pixels go through dB_wire_to_dBm()
+ * with waterfall_cal (rx/rx_util.cpp:905-912).  Enqueue only. */
+int kg_aper_update_dev(kg_aper *a, const int32_t *chans, int nrows, const void *d_rows, size_t row_stride,
+                       const kg_aper_cfg *cfg, int waterfall_cal);
+/* The reporting half (:1233-1272): signal = highest 5 dB band present (at least -80), noise =
+ * the most populated band (the lowest of equals); bands <= -190 are masked areas; no band
+ * at all gives -110 / -120.  Averages must lie within -190 .. 1000 dBm.  Synchronises. */
+int kg_aper_report(kg_aper *a, const int32_t *chans, int n, const int32_t *audio_fft, int32_t *signal,
+                   int32_t *noise);
+int kg_aper_get(kg_aper *a, int chan, float *avg_pwr);            /* 1024 floats */
+
 /* Diagnostics: re-runs the 4096-point stage of the forward FFT of `block` in a
  * stamped build of the kernel and returns 4 s_memrealtime readings (100 MHz):
  * start, inputs + twiddles loaded, transform done, results stored. */

@@ -239,6 +239,17 @@ int ko_wf_packet(const uint8_t *row, uint32_t x_bin_server, uint32_t zoom, uint3
                  uint8_t *pkt);
 void ko_snd_header(uint8_t flags, uint32_t seq, float smeter_dBm, uint8_t *h);
 
+/* ---- part 8: acquisition hand-off arithmetic, waterfall autoscale (kiwi_oracle_handoff.c) ---- */
+typedef struct {
+    double lo_dop, ca_dop;
+    uint32_t lo_rate, ca_rate, ca_pause;
+    int32_t code_creep;
+} ko_chan_start_out;
+void ko_chan_start(int is_e1b, int lo_shift, int ca_shift, double secs, ko_chan_start_out *o);
+void ko_aper_update(float *avg_pwr, const uint8_t *bp, int algo, float param, int clear, int start, int stop,
+                    int waterfall_cal);
+void ko_aper_report(const float *avg_pwr, int start, int stop, int *signal, int *noise);
+
 #ifdef __cplusplus
 }
 #endif

@@ -446,6 +446,37 @@ def snd_header(flags, seq, smeter_dBm):
     return h
 
 
+# ---- hand-off arithmetic, waterfall autoscale (kiwi_oracle_handoff.c) ----------------
+class ChanStart(C.Structure):
+    _fields_ = [("lo_dop", C.c_double), ("ca_dop", C.c_double), ("lo_rate", C.c_uint32), ("ca_rate", C.c_uint32),
+                ("ca_pause", C.c_uint32), ("code_creep", C.c_int32)]
+
+
+def chan_start(is_e1b, lo_shift, ca_shift, secs):
+    L = lib()
+    L.ko_chan_start.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]
+    o = ChanStart()
+    L.ko_chan_start(int(bool(is_e1b)), int(lo_shift), int(ca_shift), float(secs), C.byref(o))
+    return o
+
+
+def aper_update(avg_pwr, row, algo, param, clear=False, start=0, stop=1024, waterfall_cal=-13):
+    L = lib()
+    L.ko_aper_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]
+    avg = np.ascontiguousarray(avg_pwr, np.float32).copy()
+    row = np.ascontiguousarray(row, np.uint8)
+    L.ko_aper_update(_p(avg), _p(row), int(algo), float(param), int(bool(clear)), int(start), int(stop),
+                     int(waterfall_cal))
+    return avg
+
+
+def aper_report(avg_pwr, start=0, stop=1024):
+    avg = np.ascontiguousarray(avg_pwr, np.float32)
+    s, n = C.c_int(), C.c_int()
+    lib().ko_aper_report(_p(avg), C.c_int(start), C.c_int(stop), C.byref(s), C.byref(n))
+    return s.value, n.value
+
+
 # ---- waterfall DDC ---------------------------------------------------------------
 class DdcCicState(C.Structure):
     _fields_ = [("integ", (C.c_uint64 * 2) * 4), ("integ5", C.c_uint32),

@@ -498,3 +498,27 @@ def test_wire_oracle_properties_and_golden(oracle):
     assert bytes(h[:3]) == b"SND" and h[3] == 0xFF and list(h[4:8]) == [0xD4, 0xC3, 0xB2, 0xA1]
     assert (int(h[8]) << 8 | int(h[9])) == int((np.float32(3.4) + 127.0) * 10)
     assert list(oracle.snd_header(0, 0, -500.0)[8:]) == [0, 0]
+
+
+def test_handoff_oracle_known_answers(oracle):
+    """gps/channel.cpp:281-311 and rx/rx_waterfall.cpp:1173-1273 restated: closed-form cases."""
+    o = oracle.chan_start(False, 0, 1000, 0.5)
+    assert (o.lo_rate, o.ca_rate, o.ca_pause, o.code_creep) == (0x40000000, 0x10000000, 16368 - 1000, 0)   # FC/FS = 1/4, CPS/FS = 1/16
+    o = oracle.chan_start(False, 8, 0, 2.0)                        # +8 bins of FS/65536 Hz
+    lo_dop = 8 * 16368000 / 65536.0
+    assert o.lo_dop == lo_dop and abs(o.ca_dop - lo_dop / 1540.0) < 1e-9            # L1 = 1540 x the chip rate
+    assert o.lo_rate == int((4.092e6 + lo_dop) / 16.368e6 * 2 ** 32)
+    assert o.code_creep == round(lo_dop / 1540.0 * 2.0 / 1.023e6 * 16.368e6) and o.ca_pause == 16368 - o.code_creep
+    assert oracle.chan_start(True, 0, 65000, 0.0).ca_pause == 4 * 16368 - 65000
+    flat = np.full(1024, 150, np.uint8)                            # -105 + cal(-13) = -118 dBm
+    avg = oracle.aper_update(np.zeros(1024, np.float32), flat, 1, 8.0, clear=True)
+    assert np.all(avg == -118) and oracle.aper_report(avg) == (-80, -120)
+    step = flat.copy(); step[:] = 230                              # -38 dBm
+    assert np.allclose(oracle.aper_update(avg, step, 1, 8.0), (-118 * 7 - 38) / 8.0)             # MMA
+    assert np.allclose(oracle.aper_update(avg, step, 2, 4.0), -118 + 80 / 4.0)                   # EMA
+    assert np.allclose(oracle.aper_update(avg, step, 0, 2.5), -118 + 80 * 0.01)                  # IIR: gain floor
+    avg[100] = -17.0
+    assert oracle.aper_report(avg) == (-20, -120) and oracle.aper_report(avg, 256, 768) == (-80, -120)
+    assert oracle.aper_report(np.full(1024, -200, np.float32)) == (-80, -120)                    # all masked: -110 -> -80
+    half = np.concatenate([np.full(512, -113, np.float32), np.full(512, -103, np.float32)])
+    assert oracle.aper_report(half) == (-80, -115)                                               # tie -> lower band
