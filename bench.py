@@ -35,6 +35,7 @@ NDOP = 41
 # code spectrum read once (2 * N * 8 B) + a 16-byte result.
 BYTES_PER_CELL = 2 * FFT_LEN * 8 + 16
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+FLOPS_PER_CELL = 4 * 5 * 4096 * 12 + 6 * FFT_LEN + 3 * 4096 * 10
 
 
 def usable_cores():
@@ -236,7 +237,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    # KIWIGPU_BENCH_FORCE_DIST=1 takes the process-group path with one rank as well (used to
+    # exercise init / barrier / all_reduce / all_gather over RCCL on a single-GPU box)
+    distributed = world > 1 or os.environ.get("KIWIGPU_BENCH_FORCE_DIST") == "1"
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -356,6 +359,16 @@ def main():
                 "note": "algorithmic bytes = 262160 B per (SV,Doppler) cell (SURVEY 8d); the "
                         "spectra are shared between cells and served from L2/Infinity Cache, so "
                         "this can exceed the HBM peak; the kernel is fp32-VALU/LDS bound",
+            },
+            # What actually bounds the kernel: fp32 vector arithmetic.  Nominal
+            # FFT arithmetic of one cell = four 4096-point sub-transforms (5 N log2 N) + the
+            # 16384 conj-multiplies (6) + three twiddled accumulations of 4096 points (8 + 2);
+            # peak = 157.3 TFLOP/s fp32 vector (MI355X_MICROARCH.md).  Supplementary to `roofline`.
+            "valu": {
+                "flops_per_cell": FLOPS_PER_CELL,
+                "achieved_tflops": round(cells * FLOPS_PER_CELL / (kernel_ms * 1e-3) / 1e12, 2),
+                "peak_tflops": 157.3,
+                "frac": round(cells * FLOPS_PER_CELL / (kernel_ms * 1e-3) / 1e12 / 157.3, 4),
             },
             "found_prns": found,
             "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 5),
