@@ -96,3 +96,51 @@ def test_audio_chain_adc_to_packet(gpu_ctx, oracle):
             assert 3000 < np.abs(tail).max() < 32767
     finally:
         d.close(); fir.close(); P.close(); A.close()
+
+
+def test_waterfall_chain_adc_to_packet(gpu_ctx, oracle):
+    """ADC stream -> waterfall DDC (zoom 4: R = 16) -> 8192-sample frame -> u8 row -> autoscale
+    averages -> wf_pkt_t, each stage against the oracle fed the GPU's own upstream output; the
+    carrier that went in sits at its pixel in the decoded packet."""
+    from flydog_sdr_gps_amd import Aperture, Ddc, Waterfall, WfParams, handoff, wf
+    from tests.test_wf_gpu import check_row, db_bound, oracle_frame
+    zoom, start_hz, ui_srate = 4, 6.0e6, 30.0e6
+    hz_per_start = ui_srate / (1024 << 14)                         # rx_waterfall.cpp:262: `start` counts these
+    p = WfParams.for_zoom(zoom, start_hz / hz_per_start, adc_clock=66.6666e6, ui_srate=ui_srate)
+    assert p.decim == 8
+    n = 8192 * p.decim + 4096
+    t = np.arange(n)
+    f_sig = p.start * hz_per_start + 0.3 * ui_srate / (1 << zoom)  # 30 % into the displayed span
+    rng = np.random.default_rng(4)
+    adc = np.rint(6000 * np.cos(2 * np.pi * f_sig / 66.6666e6 * t) + rng.normal(0, 20, n)).astype(np.int16)
+
+    d = Ddc(gpu_ctx, nchan=1, max_samples=n)
+    W = Waterfall(gpu_ctx, nchan=1)
+    A = Aperture(gpu_ctx, nchan=1)
+    tables = (wf.window_functions(), wf.cic_comp_table())
+    try:
+        d.set_wf(0, p.i_offset, p.decim)
+        iq = d.push(adc, [0])[0][:8192]                              # stage 1: bit-exact
+        want_iq = oracle.ddc_wf(adc, p.i_offset, int(np.log2(p.decim)))[0][:8192]
+        assert np.array_equal(iq, want_iq)
+
+        W.set_tables(*tables)                                         # stage 2: the frame
+        W.set_channel(0, p, interp=wf.WF_MAX, window_func=wf.WINF_HANNING, cic_comp=True)
+        row = W.frames([0], iq[None])[0]
+        w_out, _, w_pwr_out, w_dB = oracle_frame(oracle, tables, iq, p, wf.WF_MAX, wf.WINF_HANNING, True, False, False)
+        check_row(row, w_out, w_dB, db_bound(w_pwr_out))
+
+        A.update([0], row[None], [(handoff.MMA, 8.0, True, False)])   # stage 3: autoscale, exact
+        assert np.array_equal(A.get(0), oracle.aper_update(np.zeros(1024, np.float32), row, handoff.MMA, 8.0, True))
+        sig, noise = A.report([0])
+        assert (int(sig[0]), int(noise[0])) == oracle.aper_report(A.get(0))
+
+        from flydog_sdr_gps_amd import wire                           # stage 4: the packet, bit-exact
+        pk = wire.wf_packets(gpu_ctx, row[None], [(int(p.start), zoom, 9, True)])[0]
+        assert np.array_equal(pk, oracle.wf_packet(row, int(p.start), zoom, 9, True))
+        dec, _ = oracle.adpcm_decode_u8(pk[16:])
+        peak = int(np.argmax(dec[10:].astype(int)))
+        assert abs(peak - 0.3 * 1024) <= 2, peak
+        assert sig[0] > noise[0] + 30
+    finally:
+        d.close(); W.close(); A.close()
