@@ -437,6 +437,12 @@ struct kg_acq {
     float2 *d_fsub;        // [max_blocks][4][4096] sub-transforms awaiting the radix-4 combine
     float2 *d_fsub_code;   // [4][4096]
     uint8_t *d_in;     // [max_blocks][NSAMPLES*4]    host-input staging
+    // Host-buffer Sample() calls return before the copy has run ("enqueue only"), so the
+    // caller's samples are first copied into one of a few pinned slots; a slot is reused
+    // once the event recorded behind its copy has fired.
+    uint8_t *h_pin[4];
+    hipEvent_t ev_pin[4];
+    int pin_next;
     uint8_t *d_chips;  // [E1B_CODELEN max]
     int *d_limits;     // [max_sats]
     acq_cell_desc *d_table1, *d_table4;   // cell tables of the C/A and E1B launches
@@ -544,6 +550,11 @@ int kg_acq_create(kg_ctx *ctx, int max_sats, int dop_lo, int dop_hi, int max_blo
     KG_HIP(hipMalloc((void **) &a->d_fsub, spec * max_blocks));
     KG_HIP(hipMalloc((void **) &a->d_fsub_code, spec));
     KG_HIP(hipMalloc((void **) &a->d_in, IN_STRIDE * max_blocks));
+    for (int k = 0; k < 4; k++) {
+        KG_HIP(hipHostMalloc((void **) &a->h_pin[k], IN_STRIDE, hipHostMallocDefault));
+        KG_HIP(hipEventCreateWithFlags(&a->ev_pin[k], hipEventDisableTiming));
+    }
+    a->pin_next = 0;
     KG_HIP(hipMalloc((void **) &a->d_chips, 8192));
     KG_HIP(hipMalloc((void **) &a->d_limits, sizeof(int) * max_sats));
     a->table_cap = (size_t) max_blocks * max_sats * a->ndop;
@@ -610,6 +621,7 @@ void kg_acq_destroy(kg_acq *a)
     (void) hipFree(a->d_td_code);
     (void) hipFree(a->d_fsub); (void) hipFree(a->d_fsub_code);
     (void) hipFree(a->d_in); (void) hipFree(a->d_chips); (void) hipFree(a->d_limits);
+    for (int k = 0; k < 4; k++) { (void) hipHostFree(a->h_pin[k]); (void) hipEventDestroy(a->ev_pin[k]); }
     (void) hipFree(a->d_table1); (void) hipFree(a->d_table4);
     (void) hipFree(a->d_xcd1); (void) hipFree(a->d_xcd4);
     (void) hipFree(a->d_cells); (void) hipFree(a->d_results);
@@ -689,6 +701,18 @@ static int check_block(kg_acq *a, int block, const void *p, const char *who)
     return kg_ctx_use(a->ctx);
 }
 
+// Caller's host samples -> the block's device staging area, through a pinned slot.
+static int stage_host_block(kg_acq *a, uint8_t *d_stage, const void *src, size_t bytes)
+{
+    const int k = a->pin_next;
+    a->pin_next = (k + 1) & 3;
+    KG_HIP(hipEventSynchronize(a->ev_pin[k]));           // never-recorded events are complete
+    memcpy(a->h_pin[k], src, bytes);
+    KG_HIP(hipMemcpyAsync(d_stage, a->h_pin[k], bytes, hipMemcpyHostToDevice, a->fstream));
+    KG_HIP(hipEventRecord(a->ev_pin[k], a->fstream));
+    return KG_OK;
+}
+
 // Front-stream bracket for everything that (re)writes the data spectra of blocks
 // b .. b+n-1.  Events are only ever re-recorded on the same stream, so waiting on a shared
 // event that has since been recorded again waits for later work, never for less.
@@ -733,7 +757,7 @@ int kg_acq_sample_bits(kg_acq *a, int block, const uint8_t *packed)
     int rc = check_block(a, block, packed, "kg_acq_sample_bits");
     if (rc) return rc;
     uint8_t *stage = a->d_in + IN_STRIDE * block;
-    KG_HIP(hipMemcpyAsync(stage, packed, NSAMPLES / 8, hipMemcpyHostToDevice, a->fstream));
+    if ((rc = stage_host_block(a, stage, packed, NSAMPLES / 8))) return rc;
     return kg_acq_sample_bits_dev(a, block, stage);
 }
 
@@ -771,7 +795,7 @@ int kg_acq_sample_iq16(kg_acq *a, int block, const int16_t *iq)
     int rc = check_block(a, block, iq, "kg_acq_sample_iq16");
     if (rc) return rc;
     uint8_t *stage = a->d_in + IN_STRIDE * block;
-    KG_HIP(hipMemcpyAsync(stage, iq, (size_t) NSAMPLES * 4, hipMemcpyHostToDevice, a->fstream));
+    if ((rc = stage_host_block(a, stage, iq, (size_t) NSAMPLES * 4))) return rc;
     return kg_acq_sample_iq16_dev(a, block, stage);
 }
 

@@ -180,6 +180,7 @@ struct kg_wf {
     wf_chan_dev *d_chans;
     float *d_windows, *d_cic;
     int *d_chan_of;  int chan_of_cap;
+    std::vector<int> chan_of;            // what d_chan_of holds
     short2 *d_iq;    unsigned char *d_out;  int stage_cap;      // staging for host-buffer calls
     float *d_tap_pwr, *d_tap_pwr_out, *d_tap_db;
     std::vector<char> chan_set;
@@ -311,10 +312,17 @@ static int wf_launch(kg_wf *w, int nframes, const int32_t *chan_of, const void *
     if (nframes > w->chan_of_cap) {
         KG_HIP(hipStreamSynchronize(st));
         (void) hipFree(w->d_chan_of);
+        w->chan_of.clear();
         KG_HIP(hipMalloc((void **) &w->d_chan_of, sizeof(int) * nframes));
         w->chan_of_cap = nframes;
     }
-    KG_HIP(hipMemcpyAsync(w->d_chan_of, chan_of, sizeof(int) * nframes, hipMemcpyHostToDevice, st));
+    // chan_of is the caller's and this entry point only enqueues: keep a copy, upload it
+    // synchronously, and only when it differs from what the device already holds
+    if ((int) w->chan_of.size() != nframes || memcmp(w->chan_of.data(), chan_of, sizeof(int) * nframes) != 0) {
+        KG_HIP(hipStreamSynchronize(st));      // an earlier launch may still read the old list
+        w->chan_of.assign(chan_of, chan_of + nframes);
+        KG_HIP(hipMemcpy(w->d_chan_of, w->chan_of.data(), sizeof(int) * nframes, hipMemcpyHostToDevice));
+    }
     const int grid = nframes < w->grid ? nframes : w->grid;
     if (!taps) {
         hipLaunchKernelGGL(wf_frame_kernel<false>, dim3(grid), dim3(256), WF_LDS_BYTES, st,
