@@ -124,6 +124,7 @@ SYMBOLS = {
     "kg_snd_payload_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _vp, _sz]),
     "kg_snd_header": (None, [C.c_uint8, C.c_uint32, C.c_float, _vp]),
     "kg_wf_packets_dev": (_i, [_vp, _vp, _sz, _i, _vp, _vp, _sz, _vp]),
+    "kg_fir_process_taps_dev": (_i, [_vp, _vp, _i, _vp, _sz, _i, _vp, _sz, _vp, _vp, _vp, _sz]),
     "kg_acq_chan_start": (None, [_i, _i, _i, C.c_double, _vp]),
     "kg_aper_create": (_i, [_vp, _i, C.POINTER(_vp)]),
     "kg_aper_destroy": (None, [_vp]),

@@ -124,10 +124,14 @@ KG_DEV void fir_fft1024(cf (&x)[16], float2 *tile, const fir_tw &tw, int t)
 
 // One wave per (list entry, block).  in: per-channel history buffers
 // [512 old | new samples...]; block b reads [512 b, 512 b + 1024).
+// TAPS: also store the extension taps of fastfir.cpp:278-302 (either pointer may be null):
+// pre = forward spectrum x m_CIC, post = the filtered spectrum, 1024 points per block.
+template <bool TAPS>
 __global__ __launch_bounds__(64 * FIR_WAVES) void fir_block_kernel(
     const float2 *__restrict__ hist, long hist_stride, const int *__restrict__ chan_list,
     const int *__restrict__ nblk, const float2 *__restrict__ coef,     // [nchan][1024]
-    const float2 *__restrict__ tab4096, float2 *__restrict__ out, long out_stride, int max_blk)
+    const float2 *__restrict__ tab4096, float2 *__restrict__ out, long out_stride, int max_blk,
+    const float *__restrict__ cic, float2 *__restrict__ tap_pre, float2 *__restrict__ tap_post, long tap_stride)
 {
     __shared__ __attribute__((aligned(16))) float2 tiles[FIR_WAVES][FIR_FFT];
     const int w = threadIdx.x >> 6, t = threadIdx.x & 63;
@@ -143,8 +147,18 @@ __global__ __launch_bounds__(64 * FIR_WAVES) void fir_block_kernel(
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = kg_ld(&src[t + 64 * j]);
     fir_fft1024<-1, false>(x, tile, tw, t);                            // fastfir.cpp:274
+    if (TAPS && tap_pre) {                                             // simd_multiply_cfc, :280-283
+        float2 *p = tap_pre + (long) li * tap_stride + (long) FIR_FFT * blk;
+#pragma unroll
+        for (int j = 0; j < 16; j++) { const float c = cic[t + 64 * j]; kg_st(&p[t + 64 * j], cf{x[j].x * c, x[j].y * c}); }
+    }
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = kg_cmul(x[j], kg_ld(&cf_[t + 64 * j]));    // simd_multiply_ccc, :293
+    if (TAPS && tap_post) {                                            // :299-302
+        float2 *p = tap_post + (long) li * tap_stride + (long) FIR_FFT * blk;
+#pragma unroll
+        for (int j = 0; j < 16; j++) kg_st(&p[t + 64 * j], x[j]);
+    }
     fir_fft1024<+1, true>(x, tile, tw, t);                             // :304
     float2 *dst = out + (long) li * out_stride + (long) FIR_OUT * blk;
 #pragma unroll
@@ -270,6 +284,9 @@ int kg_fir_create(kg_ctx *ctx, int nchan, int max_in, kg_fir **out)
     KG_HIP(hipMalloc((void **) &f->d_coef, sizeof(float2) * FIR_FFT * (size_t) nchan));
     KG_HIP(hipMalloc((void **) &f->d_taps, sizeof(float2) * FIR_FFT));
     KG_HIP(hipMalloc((void **) &f->d_cic, sizeof(float) * FIR_FFT));
+    fir_cic_table(0, f->cic);                                          // the constructor's m_CIC, fastfir.cpp:61-79
+    f->cic_3ch = 0;
+    KG_HIP(hipMemcpy(f->d_cic, f->cic, sizeof f->cic, hipMemcpyHostToDevice));
     KG_HIP(hipMalloc((void **) &f->d_list, sizeof(int) * nchan));
     KG_HIP(hipMalloc((void **) &f->d_fill, sizeof(int) * nchan));
     KG_HIP(hipMalloc((void **) &f->d_nblk, sizeof(int) * nchan));
@@ -381,8 +398,25 @@ int kg_fir_pos(kg_fir *f, int ch)                 // FirPos(), fastfir.h:33
     return f->fill[ch];
 }
 
+static int fir_process_impl(kg_fir *f, const int32_t *chans, int nch, const void *d_in, size_t in_stride, int n,
+                            void *d_out, size_t out_stride, int32_t *nout, void *d_pre, void *d_post, size_t tap_stride);
+
 int kg_fir_process_dev(kg_fir *f, const int32_t *chans, int nch, const void *d_in, size_t in_stride, int n,
                        void *d_out, size_t out_stride, int32_t *nout)
+{
+    return fir_process_impl(f, chans, nch, d_in, in_stride, n, d_out, out_stride, nout, nullptr, nullptr, 0);
+}
+
+int kg_fir_process_taps_dev(kg_fir *f, const int32_t *chans, int nch, const void *d_in, size_t in_stride, int n,
+                            void *d_out, size_t out_stride, int32_t *nout, void *d_pre, void *d_post, size_t tap_stride)
+{
+    return fir_process_impl(f, chans, nch, d_in, in_stride, n, d_out, out_stride, nout, d_pre, d_post, tap_stride);
+}
+
+}  // extern "C"
+
+static int fir_process_impl(kg_fir *f, const int32_t *chans, int nch, const void *d_in, size_t in_stride, int n,
+                            void *d_out, size_t out_stride, int32_t *nout, void *d_pre, void *d_post, size_t tap_stride)
 {
     KG_REQUIRE(f && chans && d_in && d_out, KG_ERR_INVALID, "kg_fir_process_dev: null argument");
     int rc = kg_ctx_use(f->ctx);
@@ -402,6 +436,8 @@ int kg_fir_process_dev(kg_fir *f, const int32_t *chans, int nch, const void *d_i
         h_rem[i] = tot % FIR_OUT;
         KG_REQUIRE((size_t) h_nblk[i] * FIR_OUT <= out_stride || h_nblk[i] == 0, KG_ERR_INVALID,
                    "kg_fir_process_dev: out_stride %zu < %d outputs", out_stride, h_nblk[i] * FIR_OUT);
+        KG_REQUIRE(!(d_pre || d_post) || (size_t) h_nblk[i] * FIR_FFT <= tap_stride, KG_ERR_INVALID,
+                   "kg_fir_process_taps_dev: tap_stride %zu < %d blocks of 1024", tap_stride, h_nblk[i]);
         if (h_nblk[i] > max_blk) max_blk = h_nblk[i];
         if (nout) nout[i] = h_nblk[i] * FIR_OUT;
     }
@@ -416,10 +452,18 @@ int kg_fir_process_dev(kg_fir *f, const int32_t *chans, int nch, const void *d_i
                        (long) in_stride, (const int *) f->d_list, (const int *) f->d_fill, n, f->d_hist, f->hist_stride);
     KG_HIP(hipGetLastError());
     if (max_blk > 0) {
-        hipLaunchKernelGGL(fir_block_kernel, dim3((max_blk + FIR_WAVES - 1) / FIR_WAVES, nch), dim3(64 * FIR_WAVES), 0, st,
-                           (const float2 *) f->d_hist, f->hist_stride, (const int *) f->d_list, (const int *) f->d_nblk,
-                           (const float2 *) f->d_coef, (const float2 *) f->ctx->d_tab4096, (float2 *) d_out,
-                           (long) out_stride, max_blk);
+        const dim3 grid((max_blk + FIR_WAVES - 1) / FIR_WAVES, nch);
+        if (d_pre || d_post)
+            hipLaunchKernelGGL(fir_block_kernel<true>, grid, dim3(64 * FIR_WAVES), 0, st,
+                               (const float2 *) f->d_hist, f->hist_stride, (const int *) f->d_list, (const int *) f->d_nblk,
+                               (const float2 *) f->d_coef, (const float2 *) f->ctx->d_tab4096, (float2 *) d_out,
+                               (long) out_stride, max_blk, (const float *) f->d_cic, (float2 *) d_pre, (float2 *) d_post,
+                               (long) tap_stride);
+        else
+            hipLaunchKernelGGL(fir_block_kernel<false>, grid, dim3(64 * FIR_WAVES), 0, st,
+                               (const float2 *) f->d_hist, f->hist_stride, (const int *) f->d_list, (const int *) f->d_nblk,
+                               (const float2 *) f->d_coef, (const float2 *) f->ctx->d_tab4096, (float2 *) d_out,
+                               (long) out_stride, max_blk, (const float *) nullptr, (float2 *) nullptr, (float2 *) nullptr, 0L);
         KG_HIP(hipGetLastError());
         hipLaunchKernelGGL(fir_shift_kernel, dim3(nch), dim3(1024), 0, st, f->d_hist, f->hist_stride,
                            (const int *) f->d_list, (const int *) f->d_nblk, (const int *) f->d_rem);
@@ -428,6 +472,8 @@ int kg_fir_process_dev(kg_fir *f, const int32_t *chans, int nch, const void *d_i
     for (int i = 0; i < nch; i++) f->fill[chans[i]] = h_rem[i];
     return KG_OK;
 }
+
+extern "C" {
 
 // CFastFIR::ProcessData(rx_chan, InLength, In, Out) with host buffers: returns the
 // number of samples written to out (0 or a multiple of 512), or a negative status.

@@ -112,3 +112,31 @@ class FastFir:
                                           int(n), ptr(int(d_out)), int(out_stride), ptr(nout)),
               "kg_fir_process_dev")
         return nout
+
+    def process_taps(self, ch, x):
+        """ProcessData with its extension taps (fastfir.cpp:278-302), host arrays:
+        -> (out, pre [nblk, 1024], post [nblk, 1024])"""
+        x = np.ascontiguousarray(x, np.complex64)
+        maxblk = x.size // 512 + 2
+        ctx = self.ctx
+        d_in, d_out = ctx.alloc(max(x.nbytes, 8)), ctx.alloc((x.size + 512) * 8)
+        d_pre, d_post = ctx.alloc(maxblk * 1024 * 8), ctx.alloc(maxblk * 1024 * 8)
+        try:
+            ctx.upload(d_in, x)
+            chans = np.array([ch], np.int32)
+            nout = np.zeros(1, np.int32)
+            check(self.lib.kg_fir_process_taps_dev(self.h, ptr(chans), 1, ptr(int(d_in)), x.size, x.size,
+                                                   ptr(int(d_out)), x.size + 512, ptr(nout), ptr(int(d_pre)),
+                                                   ptr(int(d_post)), maxblk * 1024), "kg_fir_process_taps_dev")
+            ctx.sync()
+            n = int(nout[0])
+            out = np.zeros(max(n, 1), np.complex64)
+            pre, post = np.zeros((maxblk, 1024), np.complex64), np.zeros((maxblk, 1024), np.complex64)
+            if n:
+                ctx.download(d_out, out[:n])
+                ctx.download(d_pre, pre)
+                ctx.download(d_post, post)
+        finally:
+            for d in (d_in, d_out, d_pre, d_post):
+                ctx.free(d)
+        return out[:n].copy(), pre[:n // 512].copy(), post[:n // 512].copy()

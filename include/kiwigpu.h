@@ -427,6 +427,19 @@ int kg_aper_report(kg_aper *a, const int32_t *chans, int n, const int32_t *audio
                    int32_t *noise);
 int kg_aper_get(kg_aper *a, int chan, float *avg_pwr);            /* 1024 floats */
 
+/* kg_fir_process_dev plus the extension taps of ProcessData (SURVEY.md 8(f) rank 4;
+ * rx/CuteSDR/fastfir.cpp:278-302): for block b of list entry i, 1024 complex floats at
+ * d_pre / d_post + i*tap_stride + b*1024 (either may be NULL): pre = the forward spectrum
+ * times the CIC compensation table (what receive_FFT(PRE_FILTERED) is handed), post = the
+ * filtered spectrum (receive_FFT(POST_FILTERED), specAF_FFT).  A PRE_FILTERED extension that
+ * edits the buffer (the `buf_modified` path, :286-290) is not supported on this path.  The
+ * other taps of c2s_sound() are plain buffers of this API: receive_iq_pre_fir = the unpack
+ * output, receive_iq_pre_agc = the FIR output (an iq_buf_t ring when d_out walks
+ * [N_DPBUF][512]), receive_iq_post_agc / receive_real / receive_S_meter = kg_post outputs. */
+int kg_fir_process_taps_dev(kg_fir *fir, const int32_t *chans, int nch, const void *d_in, size_t in_stride, int n,
+                            void *d_out, size_t out_stride, int32_t *nout, void *d_pre, void *d_post,
+                            size_t tap_stride);
+
 /* Diagnostics: re-runs the 4096-point stage of the forward FFT of `block` in a
  * stamped build of the kernel and returns 4 s_memrealtime readings (100 MHz):
  * start, inputs + twiddles loaded, transform done, results stored. */

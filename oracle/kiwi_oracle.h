@@ -166,6 +166,8 @@ int ko_fir_design(float FLoCut, float FHiCut, float Offset, float SampleRate, co
                   ko_cpx *time_coef, int prec);
 void ko_fir_reset(ko_fir_state *s);
 int ko_fir_process(ko_fir_state *s, const ko_cpx *coef_cic, const ko_cpx *in, int n, ko_cpx *out, int prec);
+int ko_fir_process_taps(ko_fir_state *s, const ko_cpx *coef_cic, const float *cic, const ko_cpx *in, int n,
+                        ko_cpx *out, int prec, ko_cpx *pre, ko_cpx *post);
 
 /* ---- waterfall DDC (verilog/rx: iq_mixer.v, cic_prune_var.v, cic_wf1.vh) ---- */
 typedef struct {

@@ -477,6 +477,23 @@ def aper_report(avg_pwr, start=0, stop=1024):
     return s.value, n.value
 
 
+def fir_process_taps(state, coef_cic, cic, x, prec=1):
+    """-> (out, FirPos, pre [nblk, 1024], post [nblk, 1024]): ProcessData with its extension taps"""
+    L = lib()
+    L.ko_fir_process_taps.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                      C.c_void_p, C.c_void_p]
+    L.ko_fir_process_taps.restype = C.c_int
+    x = np.ascontiguousarray(x, cpx)
+    coef_cic = np.ascontiguousarray(coef_cic, cpx)
+    cic = np.ascontiguousarray(cic, np.float32)
+    out = np.empty(x.size + 1024, cpx)
+    maxblk = x.size // 512 + 2
+    pre, post = np.zeros((maxblk, 1024), cpx), np.zeros((maxblk, 1024), cpx)
+    n = L.ko_fir_process_taps(C.byref(state), _p(coef_cic), _p(cic), _p(x), x.size, _p(out), int(prec), _p(pre), _p(post))
+    nblk = n // 512
+    return out[:n].copy(), state.in_pos - (FIR_SIZE - 1), pre[:nblk].copy(), post[:nblk].copy()
+
+
 # ---- waterfall DDC ---------------------------------------------------------------
 class DdcCicState(C.Structure):
     _fields_ = [("integ", (C.c_uint64 * 2) * 4), ("integ5", C.c_uint32),

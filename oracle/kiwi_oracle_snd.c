@@ -128,7 +128,17 @@ void ko_fir_reset(ko_fir_state *s)
  * of samples written to out (a multiple of 512). */
 int ko_fir_process(ko_fir_state *s, const ko_cpx *coef_cic, const ko_cpx *in, int n, ko_cpx *out, int prec)
 {
-    int outpos = 0;
+    return ko_fir_process_taps(s, coef_cic, NULL, in, n, out, prec, NULL, NULL);
+}
+
+/* The same with the extension taps of fastfir.cpp:278-302: per 1024-point block, pre = forward
+ * spectrum x m_CIC (simd_multiply_cfc, :280-283: what receive_FFT(PRE_FILTERED) is handed) and
+ * post = the filtered spectrum (:299-302: receive_FFT(POST_FILTERED) / specAF_FFT).  An
+ * extension that edits the PRE buffer (buf_modified, :286-290) is outside this restatement. */
+int ko_fir_process_taps(ko_fir_state *s, const ko_cpx *coef_cic, const float *cic, const ko_cpx *in, int n,
+                        ko_cpx *out, int prec, ko_cpx *pre, ko_cpx *post)
+{
+    int outpos = 0, blk = 0;
     ko_cpx tmp[FFT_SIZE];
     for (int i = 0; i < n; i++) {
         int j = s->in_pos - (FFT_SIZE - FIR_SIZE + 1);
@@ -136,11 +146,18 @@ int ko_fir_process(ko_fir_state *s, const ko_cpx *coef_cic, const ko_cpx *in, in
         s->buf[s->in_pos++] = in[i];
         if (s->in_pos >= FFT_SIZE) {
             ko_fft(FFT_SIZE, -1, s->buf, tmp, prec);                  /* :274 */
+            if (pre && cic)
+                for (int k = 0; k < FFT_SIZE; k++) {                  /* simd_multiply_cfc :280-283 */
+                    pre[(size_t) blk * FFT_SIZE + k].re = tmp[k].re * cic[k];
+                    pre[(size_t) blk * FFT_SIZE + k].im = tmp[k].im * cic[k];
+                }
             for (int k = 0; k < FFT_SIZE; k++) {                      /* simd_multiply_ccc :293 */
                 const float ar = coef_cic[k].re, ai = coef_cic[k].im, br = tmp[k].re, bi = tmp[k].im;
                 s->buf[k].re = ar * br - ai * bi;
                 s->buf[k].im = ar * bi + ai * br;
             }
+            if (post) memcpy(post + (size_t) blk * FFT_SIZE, s->buf, sizeof(ko_cpx) * FFT_SIZE);   /* :299-302 */
+            blk++;
             ko_fft(FFT_SIZE, +1, s->buf, tmp, prec);                  /* :304 */
             if (out) for (j = FIR_SIZE - 1; j < FFT_SIZE; j++) out[outpos++] = tmp[j];   /* :307-310 */
             for (j = 0; j < FIR_SIZE - 1; j++) s->buf[j] = s->overlap[j];                /* :313-316 */

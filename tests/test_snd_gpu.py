@@ -143,3 +143,37 @@ def test_fir_error_paths(gpu_ctx):
         f.setup(2, 300.0, 2700.0, 0.0, 12000.0)
     assert f.process(0, np.zeros(0, np.complex64)).size == 0
     f.close()
+
+
+def test_extension_fft_taps(gpu_ctx, oracle):
+    """The PRE_FILTERED / POST_FILTERED spectra ProcessData hands to extensions and to the audio
+    spectrum (fastfir.cpp:278-302), per 1024-point block, against the oracle; outputs unchanged
+    by asking for the taps."""
+    rng = np.random.default_rng(12)
+    f = FastFir(gpu_ctx, nchan=2, max_in=4096)
+    try:
+        for do_cic, snd3 in ((False, False), (True, True)):
+            f.setup(1, -2700.0, -300.0, 0.0, 12000.0, do_cic_comp=do_cic, snd_rate_3ch=snd3)
+            f.reset(1)
+            cic = oracle.fir_cic_coeffs(snd3)
+            coef = f.get_coef(1)
+            st = oracle.fir_new_state()
+            for n in (170, 170, 170, 170, 1500, 7, 2048):
+                x = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 3000).astype(np.complex64)
+                out, pre, post = f.process_taps(1, x)
+                w_out, _, w_pre, w_post = oracle.fir_process_taps(st, coef, cic, x, prec=0)
+                assert out.size == w_out.size and pre.shape == w_pre.shape == post.shape == w_post.shape
+                if out.size:
+                    assert relmax(out, w_out) <= RTOL
+                    assert relmax(pre, w_pre) <= RTOL and relmax(post, w_post) <= RTOL
+                    # the taps are what the output is made of (the reverse plan is unnormalised, :304)
+                    assert np.allclose(1024 * np.fft.ifft(post[-1])[512:], out[-512:], rtol=0, atol=2e-4 * np.abs(out).max())
+        # the plain entry point and the tapped one give identical outputs
+        f.reset(1)
+        g = FastFir(gpu_ctx, nchan=1, max_in=4096)
+        g.set_coef(0, f.get_coef(1))
+        x = ((rng.standard_normal(2048) + 1j * rng.standard_normal(2048)) * 100).astype(np.complex64)
+        assert np.array_equal(g.process(0, x), f.process_taps(1, x)[0])
+        g.close()
+    finally:
+        f.close()
