@@ -203,6 +203,137 @@ def bench_ddc(args):
     ctx.close()
 
 
+def bench_receivers(args):
+    """BASELINE configs[3]: a batch of virtual receivers per GPU (weak scaling over ranks), each
+    with a waterfall and an audio path, fed from one ADC block resident in HBM per step:
+      waterfall: NCO mix + CIC decimate -> 8192-sample frame -> u8 row -> wf_pkt_t (ADPCM)
+      audio:     NCO mix + CIC/CIC/CICF decimate -> rx_iq_t -> unpack -> CFastFIR -> S-meter +
+                 CAgc (mono16) -> IMA ADPCM
+        python bench.py --workload receivers [--receivers 128] [--log2n 22] [--gpus N via torch.distributed.run]"""
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+        local_rank = 0
+    dev = torch.device("cuda", local_rank)
+    from flydog_sdr_gps_amd import Adpcm, Context, Ddc, FastFir, Post, RxDdc, Waterfall, WfParams, post, snd, wf, wire
+    from flydog_sdr_gps_amd.ddc import RX_DECIM, rx_phase_inc
+    ctx = Context(local_rank, torch.cuda.current_stream(dev).cuda_stream)
+    NR, n = args.receivers, 1 << args.log2n
+    assert n >= 512 * 8192, "--log2n >= 22: every step must complete a waterfall frame at zoom 10"
+    adc_clock, ui_srate = 66.6666e6, 30.0e6
+    rng = np.random.Generator(np.random.PCG64(0x5EED0004 + rank))
+    t = np.arange(n, dtype=np.float64)
+    x = rng.normal(0, 10.0, n)
+    for f, a in ((0.0123, 3000.0), (0.071, 300.0), (0.2003, 30.0), (0.31, 3.0)):
+        x += a * np.cos(2 * np.pi * f * t)
+    adc = torch.from_numpy(np.clip(np.rint(x), -32768, 32767).astype(np.int16)).to(dev)
+    chans = list(range(NR))
+
+    d = Ddc(ctx, nchan=NR, max_samples=n)
+    W = Waterfall(ctx, nchan=NR)
+    W.set_tables()
+    hz_per_start = ui_srate / (1024 << 14)
+    params = []
+    for ch in range(NR):
+        z = 1 + ch % 10
+        p = WfParams.for_zoom(z, (1.0e6 + 0.2e6 * (ch % 97)) / hz_per_start, adc_clock=adc_clock, ui_srate=ui_srate)
+        params.append(p)
+        d.set_wf(ch, p.i_offset, p.decim)
+        W.set_channel(ch, p, interp=wf.WF_MAX, window_func=wf.WINF_HANNING, cic_comp=True)
+    rx = RxDdc(ctx, nchan=NR, max_samples=n)
+    nrec_max = n // RX_DECIM + 2
+    fir = FastFir(ctx, nchan=NR, max_in=nrec_max)
+    P = Post(ctx, nchan=NR)
+    A = Adpcm(ctx, nchan=NR)
+    fs = adc_clock / RX_DECIM
+    for ch in range(NR):
+        rx.set_freq(ch, rx_phase_inc(0.0123 * adc_clock - 1000.0 - 10.0 * ch, adc_clock))
+        fir.setup(ch, 300.0, 2700.0, 0.0, fs)
+        P.set_agc(ch, True, False, -100, 50, 6, 1000, fs)
+        P.set_smeter(ch, fs); P.set_mode(ch, post.MODE_SSB); P.reset(ch)
+
+    wf_stride = n + 1
+    wf_iq = torch.zeros((NR, wf_stride, 2), dtype=torch.int16, device=dev)
+    frames = torch.zeros((NR, 8192, 2), dtype=torch.int16, device=dev)
+    rows = torch.zeros((NR, 1024), dtype=torch.uint8, device=dev)
+    pkts = torch.zeros((NR, wire.WF_PKT_MAX), dtype=torch.uint8, device=dev)
+    raw = torch.zeros((NR, nrec_max * 6), dtype=torch.uint8, device=dev)
+    xin = torch.zeros((NR, nrec_max, 2), dtype=torch.float32, device=dev)
+    firo = torch.zeros((NR, 1024, 2), dtype=torch.float32, device=dev)
+    s16 = torch.zeros((NR, 512), dtype=torch.int16, device=dev)
+    pay = torch.zeros((NR, 256), dtype=torch.uint8, device=dev)
+    infos = [(int(params[ch].start), params[ch].zoom, 0, True) for ch in range(NR)]
+    counts = {"frames": 0, "audio_blocks": 0}
+
+    def step():
+        nw = d.push_dev(adc.data_ptr(), n, chans, wf_iq.data_ptr(), wf_stride)
+        assert int(nw.min()) >= 8192
+        frames.copy_(wf_iq[:, :8192])                       # the frame each receiver's waterfall takes this step
+        W.frames_dev(chans, frames.data_ptr(), rows.data_ptr())
+        wire.wf_packets_dev(ctx, rows.data_ptr(), 1024, infos, pkts.data_ptr())
+        counts["frames"] += NR
+        nr = rx.push_dev(adc.data_ptr(), n, chans, raw.data_ptr(), nrec_max)
+        nrec = int(nr.min())
+        assert nrec == int(nr.max())
+        snd.unpack_rows_dev(ctx, raw.data_ptr(), nrec_max, nrec, NR, xin.data_ptr(), nrec_max)
+        nout = fir.process_dev(chans, xin.data_ptr(), nrec_max, nrec, firo.data_ptr(), 1024)
+        if int(nout[0]) == 512:
+            P.process_dev(chans, firo.data_ptr(), 1024, 512, s16.data_ptr(), 0, 0, 512)
+            A.encode_dev(chans, s16.data_ptr(), 512, 512, pay.data_ptr(), 256)
+            counts["audio_blocks"] += NR
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    counts["frames"] = counts["audio_blocks"] = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    # sanity: the strongest carrier is in the band of every waterfall row and audio came out
+    assert int(rows.max()) > 100 and counts["audio_blocks"] > 0 and int(pay.to(torch.int32).abs().sum()) > 0
+    if rank == 0:
+        step_s = elapsed / args.steps
+        print(json.dumps({
+            "metric": "receiver x ADC Msamples/s ingested (waterfall + audio chain per virtual receiver)",
+            "value": round(n * NR * world / step_s / 1e6, 1), "unit": "Msamples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int128/int64/f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[3]: %d virtual receivers per GPU x %d GPU(s), %d-sample 16-bit ADC "
+                                   "block @66.67 MS/s resident in HBM per step; per receiver a waterfall channel "
+                                   "(zooms 1..10) and an SSB audio channel" % (NR, world, n),
+                       "receivers_per_gpu": NR, "adc_samples_per_step": n,
+                       "parallelism": "receivers sharded over ranks, no data-path collective"},
+            "adc_ms_per_step": round(n / adc_clock * 1e3, 3),
+            "x_realtime_all_receivers": round(n / adc_clock / step_s, 2),
+            "waterfall_frames_per_s": round(counts["frames"] * world / elapsed, 1),
+            "audio_blocks_per_s": round(counts["audio_blocks"] * world / elapsed, 1),
+        }), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def measured_traffic(workload, units):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes
     (profiles/hbm_traffic.json, written from tools/prof.sh output: FETCH_SIZE x2 on gfx950
@@ -219,8 +350,9 @@ def measured_traffic(workload, units):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--log2n", type=int, default=24, help="ddc: log2 of the ADC samples per step")
-    ap.add_argument("--workload", default="acq", choices=["acq", "waterfall", "ddc"])
+    ap.add_argument("--log2n", type=int, default=None, help="ddc / receivers: log2 of the ADC samples per step (24 / 22)")
+    ap.add_argument("--receivers", type=int, default=128, help="receivers: virtual receivers per GPU")
+    ap.add_argument("--workload", default="acq", choices=["acq", "waterfall", "ddc", "receivers"])
     ap.add_argument("--frames", type=int, default=512, help="waterfall: frames per channel per step")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -228,10 +360,14 @@ def main():
     ap.add_argument("--blocks", type=int, default=8, help="independent 4 ms blocks per step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
+    if args.log2n is None:
+        args.log2n = 22 if args.workload == "receivers" else 24
     if args.workload == "waterfall":
         return bench_waterfall(args)
     if args.workload == "ddc":
         return bench_ddc(args)
+    if args.workload == "receivers":
+        return bench_receivers(args)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))

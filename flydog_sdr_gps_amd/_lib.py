@@ -98,6 +98,7 @@ SYMBOLS = {
     "kg_rxddc_outputs": (C.c_long, [_vp, _i, _sz]),
     "kg_rxddc_push_dev": (_i, [_vp, _vp, _sz, _vp, _i, _vp, _sz, _vp]),
     "kg_dpump_unpack_dev": (_i, [_vp, _vp, _i, _i, _vp, C.c_float, C.c_float, C.c_float, _i, _vp, _sz]),
+    "kg_dpump_unpack_rows_dev": (_i, [_vp, _vp, _sz, _i, _i, _vp, C.c_float, C.c_float, C.c_float, _i, _vp, _sz]),
     "kg_fir_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
     "kg_fir_destroy": (None, [_vp]),
     "kg_fir_setup": (_i, [_vp, _i, C.c_float, C.c_float, C.c_float, C.c_float, _i, _i, _i]),

@@ -37,13 +37,15 @@
 // data pump unpack: rx_iq_t {u16 i, u16 q, u8 q3, u8 i3} (data_pump.h:27-30),
 // sample-major, channel-minor -> out[ch][sample] TYPECPX
 // ---------------------------------------------------------------------------
-__global__ void snd_unpack_kernel(const unsigned short *__restrict__ raw, int nsamps, int nchans,
+// raw_stride 0: the SPI layout, record (j, ch) at j * nchans + ch; otherwise one row of
+// records per channel, raw_stride records apart (what kg_rxddc_push_dev writes)
+__global__ void snd_unpack_kernel(const unsigned short *__restrict__ raw, long raw_stride, int nsamps, int nchans,
                                   const unsigned char *__restrict__ enabled, float rescale, float dc_i,
                                   float dc_q, int inversion, float2 *__restrict__ out, long out_stride)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x, ch = blockIdx.y;
     if (j >= nsamps || !enabled[ch]) return;
-    const unsigned short *p = raw + ((long) j * nchans + ch) * 3;
+    const unsigned short *p = raw + (raw_stride ? (long) ch * raw_stride + j : (long) j * nchans + ch) * 3;
     const unsigned lo_i = p[0], lo_q = p[1], hi = p[2];        // hi = q3 | i3 << 8
     const unsigned q3 = hi & 0xff, i3 = hi >> 8;
     // S24_8_16(h8, l16), types.h:44
@@ -500,25 +502,42 @@ int kg_fir_process(kg_fir *f, int ch, const float *in, int n, float *out)
 }
 
 // snd_service() unpack (data_pump.cpp:145-208), device buffers.
-int kg_dpump_unpack_dev(kg_ctx *ctx, const void *d_raw, int nsamps, int nchans, const uint8_t *enabled,
-                        float rescale, float dc_i, float dc_q, int spectral_inversion, void *d_out,
-                        size_t out_stride)
+static int unpack_impl(kg_ctx *ctx, const void *d_raw, size_t raw_stride, int nsamps, int nchans, const uint8_t *enabled,
+                       float rescale, float dc_i, float dc_q, int spectral_inversion, void *d_out, size_t out_stride)
 {
     int rc = kg_ctx_use(ctx);
     if (rc) return rc;
     KG_REQUIRE(d_raw && d_out && enabled, KG_ERR_INVALID, "kg_dpump_unpack_dev: null argument");
     KG_REQUIRE(nsamps >= 1 && nchans >= 1 && nchans <= 65535, KG_ERR_INVALID, "kg_dpump_unpack_dev: %d samples x %d channels", nsamps, nchans);
     KG_REQUIRE(((uintptr_t) d_raw & 1) == 0 && ((uintptr_t) d_out & 7) == 0, KG_ERR_INVALID, "kg_dpump_unpack_dev: misaligned pointer");
-    unsigned char *d_en = nullptr;
-    KG_HIP(hipMalloc((void **) &d_en, nchans));
-    KG_HIP(hipMemcpy(d_en, enabled, nchans, hipMemcpyHostToDevice));
+    KG_REQUIRE(out_stride >= (size_t) nsamps && (raw_stride == 0 || raw_stride >= (size_t) nsamps), KG_ERR_INVALID,
+               "kg_dpump_unpack_dev: stride smaller than nsamps");
+    void *d_en = nullptr;
+    if ((rc = kg_ctx_scratch_upload(ctx, enabled, nchans, &d_en))) return rc;
     hipLaunchKernelGGL(snd_unpack_kernel, dim3((nsamps + 255) / 256, nchans), dim3(256), 0, ctx->stream,
-                       (const unsigned short *) d_raw, nsamps, nchans, (const unsigned char *) d_en, rescale, dc_i,
-                       dc_q, spectral_inversion ? 1 : 0, (float2 *) d_out, (long) out_stride);
+                       (const unsigned short *) d_raw, (long) raw_stride, nsamps, nchans, (const unsigned char *) d_en,
+                       rescale, dc_i, dc_q, spectral_inversion ? 1 : 0, (float2 *) d_out, (long) out_stride);
     KG_HIP(hipGetLastError());
-    KG_HIP(hipStreamSynchronize(ctx->stream));
-    KG_HIP(hipFree(d_en));
     return KG_OK;
+}
+
+int kg_dpump_unpack_dev(kg_ctx *ctx, const void *d_raw, int nsamps, int nchans, const uint8_t *enabled,
+                        float rescale, float dc_i, float dc_q, int spectral_inversion, void *d_out,
+                        size_t out_stride)
+{
+    int rc = unpack_impl(ctx, d_raw, 0, nsamps, nchans, enabled, rescale, dc_i, dc_q, spectral_inversion, d_out, out_stride);
+    if (rc) return rc;
+    KG_HIP(hipStreamSynchronize(ctx->stream));           // documented as synchronous
+    return KG_OK;
+}
+
+int kg_dpump_unpack_rows_dev(kg_ctx *ctx, const void *d_raw, size_t raw_stride, int nsamps, int nchans,
+                             const uint8_t *enabled, float rescale, float dc_i, float dc_q, int spectral_inversion,
+                             void *d_out, size_t out_stride)
+{
+    KG_REQUIRE(raw_stride >= 1, KG_ERR_INVALID, "kg_dpump_unpack_rows_dev: raw_stride 0");
+    return unpack_impl(ctx, d_raw, raw_stride, nsamps, nchans, enabled, rescale, dc_i, dc_q, spectral_inversion, d_out,
+                       out_stride);
 }
 
 }  // extern "C"

@@ -54,6 +54,15 @@ def unpack(ctx, raw, nsamps, nchans, enabled=None, rescale=RESCALE, dc_i=0.0, dc
     return host
 
 
+def unpack_rows_dev(ctx, d_raw, raw_stride, nsamps, nchans, d_out, out_stride, enabled=None, rescale=RESCALE,
+                    dc_i=0.0, dc_q=0.0, spectral_inversion=False):
+    """Device buffers; records one row per channel (kg_rxddc_push_dev's layout).  Enqueue only."""
+    en = np.ones(nchans, np.uint8) if enabled is None else np.ascontiguousarray(enabled, np.uint8)
+    check(ctx.lib.kg_dpump_unpack_rows_dev(ctx.h, C.c_void_p(int(d_raw)), int(raw_stride), int(nsamps), int(nchans),
+                                           ptr(en), rescale, dc_i, dc_q, int(bool(spectral_inversion)),
+                                           C.c_void_p(int(d_out)), int(out_stride)), "kg_dpump_unpack_rows_dev")
+
+
 class FastFir:
     """The m_PassbandFIR[] array of rx/rx_sound.cpp:150 on the GPU (kg_fir)."""
 

@@ -266,6 +266,12 @@ int kg_dpump_unpack_dev(kg_ctx *ctx, const void *d_raw, int nsamps, int nchans,
                         const uint8_t *enabled, float rescale, float dc_i, float dc_q,
                         int spectral_inversion, void *d_out, size_t out_stride);
 
+/* The same unpack for records stored one row per channel, raw_stride records apart: the
+ * layout kg_rxddc_push_dev writes (many receivers, no SPI interleave).  Enqueue only. */
+int kg_dpump_unpack_rows_dev(kg_ctx *ctx, const void *d_raw, size_t raw_stride, int nsamps, int nchans,
+                             const uint8_t *enabled, float rescale, float dc_i, float dc_q,
+                             int spectral_inversion, void *d_out, size_t out_stride);
+
 #define KG_FIR_FFT_SIZE 1024      /* CONV_FFT_SIZE, rx/CuteSDR/cuteSDR.h:12 */
 #define KG_FIR_OUT      512       /* FASTFIR_OUTBUF_SIZE, rx/CuteSDR/cuteSDR.h:14 */
 
