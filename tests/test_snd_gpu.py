@@ -177,3 +177,29 @@ def test_extension_fft_taps(gpu_ctx, oracle):
         g.close()
     finally:
         f.close()
+
+
+def test_unpack_rows_layout_bit_exact(gpu_ctx, oracle):
+    """kg_dpump_unpack_rows_dev: the same arithmetic on records stored one row per channel (the
+    layout the audio DDC writes) -- equal to the SPI-layout unpack of the same records."""
+    rng = np.random.default_rng(9)
+    nsamps, nchans, stride = 173, 5, 200
+    i24 = rng.integers(-2 ** 23, 2 ** 23, (nsamps, nchans))
+    q24 = rng.integers(-2 ** 23, 2 ** 23, (nsamps, nchans))
+    spi = snd.pack_rx_iq(i24, q24)                                    # [nsamps][nchans][6]
+    rows = np.zeros((nchans, stride, 6), np.uint8)
+    rows[:, :nsamps] = spi.reshape(nsamps, nchans, 6).transpose(1, 0, 2)
+    en = np.array([1, 1, 0, 1, 1], np.uint8)
+    out = np.zeros((nchans, nsamps), np.complex64)
+    d_raw, d_out = gpu_ctx.alloc(rows.nbytes), gpu_ctx.alloc(out.nbytes)
+    try:
+        gpu_ctx.upload(d_raw, rows)
+        gpu_ctx.upload(d_out, out)
+        snd.unpack_rows_dev(gpu_ctx, d_raw, stride, nsamps, nchans, d_out, nsamps, enabled=en, dc_i=1.5, dc_q=-2.0)
+        gpu_ctx.sync()
+        gpu_ctx.download(d_out, out)
+    finally:
+        gpu_ctx.free(d_raw)
+        gpu_ctx.free(d_out)
+    want = oracle.dpump_unpack(spi, nsamps, nchans, enabled=en, dc_i=1.5, dc_q=-2.0)
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32)) and np.all(out[2] == 0)
