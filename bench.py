@@ -509,7 +509,7 @@ def main():
             "found_prns": found,
             "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 5),
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:                  # the CPU leg runs at N = 1 only
             out["cpu_baseline"] = cpu_baseline(iq_host[0], chips_list)
             out["speedup_vs_cpu_all_cores"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
