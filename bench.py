@@ -5,8 +5,8 @@ Workload (BASELINE.json configs[1]): 32 GPS L1 C/A SVs x 41 Doppler bins, 4 ms
 coherent FFT correlation on synthetic int16 IQ (65536 samples @ 16.368 MS/s),
 the sample block already resident in HBM.  One step = Sample() front end
 (mix, 2x half-band /2, 16384-pt FFT) + Correlate() for all 32 SVs x 41 bins +
-best-bin selection, for --blocks independent 4 ms sample blocks (default 8: a
-32 ms batch of the IQ stream per step; --blocks 1 is the single-block latency case).
+best-bin selection, for --blocks independent 4 ms sample blocks (default 32: a
+128 ms / 8 MiB batch of the IQ stream per step; --blocks 1 is the single-block latency case).
 
 Metric: IQ Msamples/s ingested = blocks * 65536 * steps * n_gpus / seconds.
 Multi-GPU (weak scaling): every rank searches its own resident block(s); there
@@ -357,7 +357,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--blocks", type=int, default=8, help="independent 4 ms blocks per step")
+    ap.add_argument("--blocks", type=int, default=32, help="independent 4 ms blocks per step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
     if args.log2n is None:
