@@ -57,6 +57,7 @@ SYMBOLS = {
     "kg_dev_free": (_i, [_vp, _vp]),
     "kg_dev_upload": (_i, [_vp, _vp, _vp, _sz]),
     "kg_dev_download": (_i, [_vp, _vp, _vp, _sz]),
+    "kg_dev_mem_info": (_i, [_vp, _vp, _vp]),
     "kg_timer_start": (_i, [_vp]),
     "kg_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
     "kg_acq_create": (_i, [_vp, _i, _i, _i, _i, C.POINTER(_vp)]),
@@ -235,6 +236,12 @@ class Context:
     def download(self, dptr, host):
         assert host.flags["C_CONTIGUOUS"]
         check(self.lib.kg_dev_download(self.h, ptr(host), C.c_void_p(dptr), host.nbytes), "kg_dev_download")
+
+    def mem_info(self):
+        """-> (free bytes, total bytes) of the device"""
+        f, t = C.c_size_t(), C.c_size_t()
+        check(self.lib.kg_dev_mem_info(self.h, C.byref(f), C.byref(t)), "kg_dev_mem_info")
+        return f.value, t.value
 
     def timer_start(self):
         check(self.lib.kg_timer_start(self.h), "kg_timer_start")

@@ -197,6 +197,16 @@ int kg_dev_download(kg_ctx *c, void *dst, const void *src, size_t bytes)
     return KG_OK;
 }
 
+int kg_dev_mem_info(kg_ctx *c, size_t *free_bytes, size_t *total_bytes)
+{
+    int rc = kg_ctx_use(c);
+    if (rc) return rc;
+    KG_REQUIRE(free_bytes && total_bytes, KG_ERR_INVALID, "kg_dev_mem_info: null argument");
+    KG_HIP(hipStreamSynchronize(c->stream));
+    KG_HIP(hipMemGetInfo(free_bytes, total_bytes));
+    return KG_OK;
+}
+
 int kg_timer_start(kg_ctx *c)
 {
     int rc = kg_ctx_use(c);

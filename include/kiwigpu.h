@@ -71,6 +71,8 @@ int kg_dev_alloc(kg_ctx *ctx, size_t bytes, void **out);
 int kg_dev_free(kg_ctx *ctx, void *ptr);
 int kg_dev_upload(kg_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int kg_dev_download(kg_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+/* hipMemGetInfo of the context's device (lifecycle tests, capacity planning). */
+int kg_dev_mem_info(kg_ctx *ctx, size_t *free_bytes, size_t *total_bytes);
 
 /* HIP-event stopwatch on the context's stream (bench.py and C++ callers). */
 int kg_timer_start(kg_ctx *ctx);
