@@ -306,41 +306,48 @@ DDC_DEV int sext32(int v, int bits) { return (v << (32 - bits)) >> (32 - bits); 
 
 // Combs + rounding, one thread per (channel, output).  cic_wf1.vh: comb widths
 // 23,22,21,20,20; their inputs drop 5,1,1,1,0 LSBs; out = comb5[19 -: 16] + comb5[3].
+// Channels decimate differently, so the grid is flat: workgroup w belongs to the list entry
+// li with wg_start[li] <= w < wg_start[li + 1] (bypass channels own none).  A workgroup first
+// puts the absolute integrator-5 values of its 256 outputs and the five before them in LDS.
 __global__ __launch_bounds__(256) void ddc_wf_comb_kernel(
     const u32 *__restrict__ c0rel, const u32 *__restrict__ i5start, int log2L, int nruns,
     const long *__restrict__ c0off, const ddc_chan *__restrict__ chans, const int *__restrict__ chan_list, const long *__restrict__ nouts,
     const u32 *__restrict__ cnt_before,       // [nlist] sample_no before this call
+    const int *__restrict__ wg_start, int nlist,
     short2 *__restrict__ out, long out_stride, u32 *__restrict__ hist_out)   // [nlist][2][5]
 {
-    const int li = blockIdx.y;
+    __shared__ int s_c0[2][256 + 5];
+    int lo = 0, hi = nlist;                   // wg_start[lo] <= blockIdx.x < wg_start[hi]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int) blockIdx.x >= wg_start[mid]) lo = mid; else hi = mid; }
+    const int li = lo, t = threadIdx.x;
     const ddc_chan *ch = chans + chan_list[li];
     const int log2r = ch->log2r;
-    if (log2r == 0) return;
     const long nout = nouts[li];
-    const long o = (long) blockIdx.x * 256 + threadIdx.x;
-    if (o >= nout) return;
+    const long o0 = (long) (blockIdx.x - wg_start[li]) * 256;
     const u32 base = cnt_before[li];
+    for (int e = t; e < 2 * (256 + 5); e += 256) {
+        const int comp = e >= 256 + 5, d = comp ? e - (256 + 5) : e;
+        const long oo = o0 - 5 + d;
+        u32 v = 0;
+        if (oo < 0) {
+            v = ch->hist[comp][5 + oo];       // strobes of earlier calls (zero after a reset)
+        } else if (oo < nout) {
+            const long g = ((oo + 1) << log2r) - 1 - (long) base;    // sample index of the strobe
+            const int run = (int) (g >> log2L);
+            v = (c0rel[c0off[li] + comp * nout + oo] + i5start[((long) li * 2 + comp) * nruns + run]) & 0x0FFFFFFFu;
+            if (oo >= nout - 5) hist_out[((long) li * 2 + comp) * 5 + (int) (oo - (nout - 5))] = v;
+        }
+        s_c0[comp][d] = sext32((int) v, 28);
+    }
+    __syncthreads();
+    const long o = o0 + t;
+    if (o >= nout) return;
     short res[2];
     for (int comp = 0; comp < 2; comp++) {
-        // absolute integrator-5 values at outputs o-5 .. o
-        int c0[6];
-        for (int d = 0; d < 6; d++) {
-            const long oo = o - 5 + d;
-            u32 v;
-            if (oo < 0) {
-                v = ch->hist[comp][5 + oo];   // strobes of earlier calls (zero after a reset)
-            } else {
-                const long g = ((oo + 1) << log2r) - 1 - (long) base;    // sample index of the strobe
-                const int run = (int) (g >> log2L);
-                v = (c0rel[c0off[li] + comp * nout + oo] + i5start[((long) li * 2 + comp) * nruns + run]) & 0x0FFFFFFFu;
-            }
-            c0[d] = sext32((int) v, 28);
-            if (o == nout - 1 && d >= 1) hist_out[((long) li * 2 + comp) * 5 + (d - 1)] = v;
-        }
         // comb k output at position d needs its input at d and d-1
         const int W[5] = {23, 22, 21, 20, 20}, D[5] = {5, 1, 1, 1, 0};
         int v[6];
-        for (int d = 0; d < 6; d++) v[d] = c0[d];
+        for (int d = 0; d < 6; d++) v[d] = s_c0[comp][t + d];
         int cnt = 6;
         for (int k = 0; k < 5; k++) {
             int x[6];
@@ -387,6 +394,7 @@ struct kg_ddc {
     std::vector<ddc_chan> h_chans;            // host mirror of the scalar fields
     u32 *d_nco;
     int *d_list; long *d_nouts, *d_c0off; u32 *d_cnt;
+    int *d_wgoff;                 // [nchan + 1] first comb workgroup of every list entry
     ddc_state4 *d_local; u32 *d_c0rel, *d_tau, *d_hist;
     int max_runs; long c0_cap;
 };
@@ -418,6 +426,7 @@ int kg_ddc_create(kg_ctx *ctx, int nchan, size_t max_samples, kg_ddc **out)
     KG_HIP(hipMalloc((void **) &d->d_list, sizeof(int) * nchan));
     KG_HIP(hipMalloc((void **) &d->d_nouts, sizeof(long) * nchan));
     KG_HIP(hipMalloc((void **) &d->d_cnt, sizeof(u32) * nchan));
+    KG_HIP(hipMalloc((void **) &d->d_wgoff, sizeof(int) * (nchan + 1)));
     KG_HIP(hipMalloc((void **) &d->d_local, sizeof(ddc_state4) * 2 * (size_t) nchan * d->max_runs));
     KG_HIP(hipMalloc((void **) &d->d_tau, sizeof(u32) * 2 * (size_t) nchan * d->max_runs));
     KG_HIP(hipMalloc((void **) &d->d_c0off, sizeof(long) * nchan));
@@ -440,7 +449,7 @@ void kg_ddc_destroy(kg_ddc *d)
     (void) hipSetDevice(d->ctx->device);
     (void) hipStreamSynchronize(d->ctx->stream);
     (void) hipFree(d->d_chans); (void) hipFree(d->d_nco); (void) hipFree(d->d_list);
-    (void) hipFree(d->d_nouts); (void) hipFree(d->d_cnt); (void) hipFree(d->d_local);
+    (void) hipFree(d->d_nouts); (void) hipFree(d->d_cnt); (void) hipFree(d->d_wgoff); (void) hipFree(d->d_local);
     (void) hipFree(d->d_tau); (void) hipFree(d->d_c0rel); (void) hipFree(d->d_hist);
     (void) hipFree(d->d_c0off);
     delete d;
@@ -525,7 +534,8 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
                "kg_ddc_wf_push_dev: misaligned pointer");
     std::vector<long> h_nouts(nlist), h_off(nlist);
     std::vector<u32> h_cnt(nlist);
-    long max_nout = 0, c0_need = 0;
+    std::vector<int> h_wg(nlist + 1);
+    long max_nout = 0, c0_need = 0, comb_wgs = 0;
     for (int i = 0; i < nlist; i++) {
         const int ch = chan_list[i];
         KG_REQUIRE(ch >= 0 && ch < d->nchan && d->h_chans[ch].active, KG_ERR_STATE,
@@ -540,7 +550,11 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
         if (nouts) nouts[i] = h_nouts[i];
         h_off[i] = c0_need;
         if (c.log2r) c0_need += 2 * h_nouts[i];
+        h_wg[i] = (int) comb_wgs;
+        if (c.log2r) comb_wgs += (h_nouts[i] + 255) / 256;
     }
+    h_wg[nlist] = (int) comb_wgs;
+    KG_REQUIRE(comb_wgs < (1l << 31), KG_ERR_INVALID, "kg_ddc_wf_push_dev: too many outputs in one call");
     hipStream_t st = d->ctx->stream;
     if (c0_need > d->c0_cap) {
         KG_HIP(hipStreamSynchronize(st));
@@ -569,6 +583,7 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
     KG_HIP(hipMemcpyAsync(d->d_list, chan_list, sizeof(int) * nlist, hipMemcpyHostToDevice, st));
     KG_HIP(hipMemcpyAsync(d->d_nouts, h_nouts.data(), sizeof(long) * nlist, hipMemcpyHostToDevice, st));
     KG_HIP(hipMemcpyAsync(d->d_cnt, h_cnt.data(), sizeof(u32) * nlist, hipMemcpyHostToDevice, st));
+    KG_HIP(hipMemcpyAsync(d->d_wgoff, h_wg.data(), sizeof(int) * (nlist + 1), hipMemcpyHostToDevice, st));
     KG_HIP(hipStreamSynchronize(st));         // the host vectors go out of scope
     const dim3 grid((nruns + DDC_THREADS - 1) / DDC_THREADS, nlist);
     hipLaunchKernelGGL(ddc_wf_run_kernel<false>, grid, dim3(DDC_THREADS), 0, st, (const short *) d_adc, (long) n, L,
@@ -587,11 +602,12 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
     hipLaunchKernelGGL(ddc_wf_scan_tau_kernel, dim3(2 * nlist), dim3(64), 0, st, d->d_tau, nruns, d->d_chans,
                        (const int *) d->d_list);
     KG_HIP(hipGetLastError());
-    if (max_nout > 0) {
-        hipLaunchKernelGGL(ddc_wf_comb_kernel, dim3((unsigned) ((max_nout + 255) / 256), nlist), dim3(256), 0, st,
+    if (comb_wgs > 0) {
+        hipLaunchKernelGGL(ddc_wf_comb_kernel, dim3((unsigned) comb_wgs), dim3(256), 0, st,
                            (const u32 *) d->d_c0rel, (const u32 *) d->d_tau, log2L, nruns, (const long *) d->d_c0off,
                            (const ddc_chan *) d->d_chans, (const int *) d->d_list, (const long *) d->d_nouts,
-                           (const u32 *) d->d_cnt, (short2 *) d_out, (long) out_stride, d->d_hist);
+                           (const u32 *) d->d_cnt, (const int *) d->d_wgoff, nlist, (short2 *) d_out, (long) out_stride,
+                           d->d_hist);
         KG_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(ddc_wf_finish_kernel, dim3((nlist + 63) / 64), dim3(64), 0, st, d->d_chans,
