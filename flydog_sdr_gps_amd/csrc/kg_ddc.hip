@@ -239,16 +239,23 @@ DDC_DEV ddc_state4 shfl_up_state(const ddc_state4 &s, int d)
     return r;
 }
 
-__global__ __launch_bounds__(64) void ddc_wf_scan_states_kernel(
+#define DDC_SCAN_WAVES 8
+__global__ __launch_bounds__(64 * DDC_SCAN_WAVES) void ddc_wf_scan_states_kernel(
     ddc_state4 *__restrict__ local, long n, int L, int nruns, ddc_chan *__restrict__ chans,
     const int *__restrict__ chan_list)
 {
-    const int li = blockIdx.x >> 1, comp = blockIdx.x & 1, lane = threadIdx.x;
+    // One workgroup of eight waves per (channel, I/Q): lane-local composition of a chunk of
+    // runs, inclusive scan inside each wave, the eight wave totals folded through LDS, then
+    // every lane walks its chunk again from its exact start state.
+    __shared__ ddc_state4 w_state[DDC_SCAN_WAVES];
+    __shared__ u64 w_len[DDC_SCAN_WAVES];
+    const int li = blockIdx.x >> 1, comp = blockIdx.x & 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = threadIdx.x;
     ddc_chan *ch = chans + chan_list[li];
     if (ch->log2r == 0) return;
     ddc_state4 *st = local + ((long) li * 2 + comp) * nruns;
-    const int per = (nruns + 63) / 64;
-    const int r0 = lane * per, r1 = (r0 + per < nruns) ? r0 + per : nruns;
+    const int per = (nruns + 64 * DDC_SCAN_WAVES - 1) / (64 * DDC_SCAN_WAVES);
+    const int r0 = gl * per < nruns ? gl * per : nruns, r1 = (r0 + per < nruns) ? r0 + per : nruns;
     auto run_len = [&](int r) -> u64 { const long s0 = (long) r * L; return (u64) ((s0 + L < n ? s0 + L : n) - s0); };
     // 1. lane-local composition
     ddc_state4 acc; u64 len = 0;
@@ -266,10 +273,16 @@ __global__ __launch_bounds__(64) void ddc_wf_scan_states_kernel(
         const u64 alen = shfl_up64(ilen, d);
         if (lane >= d) { inc = ddc_add(ddc_T(ilen, a), inc); ilen += alen; }
     }
-    // exclusive prefix of this lane = inclusive of lane - 1, then the saved state in front
+    if (lane == 63) { w_state[wave] = inc; w_len[wave] = ilen; }
+    __syncthreads();
+    // state at the start of this wave's first run: the saved state advanced through the earlier waves
+    ddc_state4 ws = ch->integ[comp];
+    for (int w = 0; w < wave; w++) ws = ddc_add(ddc_T(w_len[w], ws), w_state[w]);
+    __syncthreads();                              // every wave has read the saved state
+    // exclusive prefix of this lane inside its wave = inclusive of lane - 1
     ddc_state4 exc = shfl_up_state(inc, 1); u64 elen = shfl_up64(ilen, 1);
     if (lane == 0) { for (int k = 0; k < 4; k++) exc.i[k] = mk128(0, 0); elen = 0; }
-    ddc_state4 c = ddc_add(ddc_T(elen, ch->integ[comp]), exc);
+    ddc_state4 c = ddc_add(ddc_T(elen, ws), exc);
     // 3. per-run carried states
     for (int r = r0; r < r1; r++) {
         const ddc_state4 e = st[r];
@@ -591,7 +604,7 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
                        d->d_local, d->d_c0rel, d->d_tau, (const long *) d->d_c0off, (const long *) d->d_nouts,
                        (short2 *) d_out, (long) out_stride);
     KG_HIP(hipGetLastError());
-    hipLaunchKernelGGL(ddc_wf_scan_states_kernel, dim3(2 * nlist), dim3(64), 0, st, d->d_local, (long) n, L, nruns,
+    hipLaunchKernelGGL(ddc_wf_scan_states_kernel, dim3(2 * nlist), dim3(64 * DDC_SCAN_WAVES), 0, st, d->d_local, (long) n, L, nruns,
                        d->d_chans, (const int *) d->d_list);
     KG_HIP(hipGetLastError());
     hipLaunchKernelGGL(ddc_wf_run_kernel<true>, grid, dim3(DDC_THREADS), 0, st, (const short *) d_adc, (long) n, L,
