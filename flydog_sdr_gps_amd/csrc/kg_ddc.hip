@@ -170,31 +170,85 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
         return;
     }
 
+    const u64 cnt0 = (u64) ch.sample_no + (u64) s0;      // samples since the counter was last zero
+    const long lI = ((long) li * 2 + 0) * nruns + r, lQ = ((long) li * 2 + 1) * nruns + r;
+    u32 i5i = 0, i5q = 0;
+    u32 c = (u32) (cnt0 & Rm1);                           // decimation counter, sample_no
+    long o = (long) (cnt0 >> log2r);                      // index of the next strobe's output
+    u32 *c0i = c0rel + c0off[li], *c0q = c0i + nouts[li];
+    // eight samples per round from one 16-byte load (runs start 128-byte aligned relative to
+    // the block; an unaligned block or the ragged end of the last run go sample by sample)
+    auto samples8 = [&](long t, short (&buf)[8]) {
+        if ((((uintptr_t) (adc + t)) & 15) == 0 && t + 8 <= s1) {
+            const int4 v = *(const int4 *) (adc + t);
+            buf[0] = (short) v.x; buf[1] = (short) (v.x >> 16); buf[2] = (short) v.y; buf[3] = (short) (v.y >> 16);
+            buf[4] = (short) v.z; buf[5] = (short) (v.z >> 16); buf[6] = (short) v.w; buf[7] = (short) (v.w >> 16);
+        } else {
+            for (int q = 0; q < 8; q++) buf[q] = (t + q < s1) ? adc[t + q] : (short) 0;
+        }
+    };
+
+    if (log2r <= 8) {
+        // Narrow path.  The integrator inputs are m << shift, so bits [shift-1:0] of every
+        // integrator stay zero, and nothing above bit 88 is ever read (integrator 5 takes
+        // [88 -: 28]): for R <= 256 the live bits [88:shift] are 24 + 5 log2 R <= 64 bits, kept
+        // here as (state >> shift) mod 2^64.  Same values as the 128-bit path, half the adds.
+        const int sh5 = 5 * log2r - 4;                    // 61 - shift
+        u64 I[4], Q[4];
+        if (PASS_B) {
+            const ddc_state4 a = local[lI], b = local[lQ];
+            for (int k = 0; k < 4; k++) {
+                I[k] = (a.i[k].lo >> shift) | (a.i[k].hi << (64 - shift));
+                Q[k] = (b.i[k].lo >> shift) | (b.i[k].hi << (64 - shift));
+            }
+        } else {
+            for (int k = 0; k < 4; k++) I[k] = Q[k] = 0;
+        }
+        auto step = [&](int a) {
+            const u32 e = tab[ph >> 35];
+            const long long mi = mix24(a, (short) (e & 0xffff)), mq = mix24(a, (short) (e >> 16));
+            ph = (ph + ch.phase_inc) & M48;
+            I[0] += (u64) mi; I[1] += I[0]; I[2] += I[1]; I[3] += I[2];
+            Q[0] += (u64) mq; Q[1] += Q[0]; Q[2] += Q[1]; Q[3] += Q[2];
+            if (PASS_B) {
+                i5i = (i5i + (u32) (I[3] >> sh5)) & 0x0FFFFFFFu;      // integrator4[88 -: 28] (cic_wf1.vh)
+                i5q = (i5q + (u32) (Q[3] >> sh5)) & 0x0FFFFFFFu;
+                c = (c + 1) & (u32) Rm1;
+                if (c == 0) { c0i[o] = i5i; c0q[o] = i5q; o++; }      // strobe: sample_no was R - 1
+            }
+        };
+        long t = s0;
+        for (; t + 8 <= s1; t += 8) {                     // whole groups, no per-sample masking
+            short buf[8];
+            samples8(t, buf);
+#pragma unroll
+            for (int w = 0; w < 8; w++) step(buf[w]);
+        }
+        for (; t < s1; t++) step(adc[t]);                 // ragged end of the block's last run
+        if (PASS_B) {
+            tau[lI] = i5i;
+            tau[lQ] = i5q;
+        } else {
+            ddc_state4 a, b;
+            for (int k = 0; k < 4; k++) {
+                a.i[k] = mk128(I[k] << shift, I[k] >> (64 - shift));
+                b.i[k] = mk128(Q[k] << shift, Q[k] >> (64 - shift));
+            }
+            local[lI] = a;
+            local[lQ] = b;
+        }
+        return;
+    }
+
     ddc_state4 SI, SQ;
     if (PASS_B) {
-        SI = local[((long) li * 2 + 0) * nruns + r];
-        SQ = local[((long) li * 2 + 1) * nruns + r];
+        SI = local[lI];
+        SQ = local[lQ];
     } else {
         for (int k = 0; k < 4; k++) { SI.i[k] = mk128(0, 0); SQ.i[k] = mk128(0, 0); }
     }
-    u32 i5i = 0, i5q = 0;
-    const u64 cnt0 = (u64) ch.sample_no + (u64) s0;      // samples since the counter was last zero
-    // the run is read 16 bytes (8 samples) at a time when it is aligned (L >= 64 always is)
-    const bool vec = (((uintptr_t) (adc + s0)) & 15) == 0;
-    short buf[8];
-    for (long t = s0; t < s1; t++) {
-        const int w = (int) ((t - s0) & 7);
-        if (w == 0) {
-            if (vec && t + 8 <= s1) {
-                const int4 v = *(const int4 *) (adc + t);
-                buf[0] = (short) v.x; buf[1] = (short) (v.x >> 16); buf[2] = (short) v.y; buf[3] = (short) (v.y >> 16);
-                buf[4] = (short) v.z; buf[5] = (short) (v.z >> 16); buf[6] = (short) v.w; buf[7] = (short) (v.w >> 16);
-            } else {
-                for (int q = 0; q < 8; q++) buf[q] = (t + q < s1) ? adc[t + q] : (short) 0;
-            }
-        }
+    auto step = [&](int a) {
         const u32 e = tab[ph >> 35];
-        const int a = buf[w];
         const long long mi = mix24(a, (short) (e & 0xffff)), mq = mix24(a, (short) (e >> 16));
         ph = (ph + ch.phase_inc) & M48;
         // in = sign-extended m << shift, 128 bits
@@ -208,20 +262,24 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
             // integrator 5 accumulates integrator4[88 -: 28] (cic_wf1.vh)
             i5i = (i5i + (u32) ((SI.i[3].hi << 3) | (SI.i[3].lo >> 61))) & 0x0FFFFFFFu;
             i5q = (i5q + (u32) ((SQ.i[3].hi << 3) | (SQ.i[3].lo >> 61))) & 0x0FFFFFFFu;
-            const u64 cnt = cnt0 + (u64) (t - s0) + 1;   // samples consumed including this one
-            if ((cnt & Rm1) == 0) {                       // strobe: sample_no == R - 1
-                const long o = (long) (cnt >> log2r) - 1;
-                c0rel[c0off[li] + o] = i5i;
-                c0rel[c0off[li] + nouts[li] + o] = i5q;
-            }
+            c = (c + 1) & (u32) Rm1;
+            if (c == 0) { c0i[o] = i5i; c0q[o] = i5q; o++; }          // strobe: sample_no was R - 1
         }
+    };
+    long t = s0;
+    for (; t + 8 <= s1; t += 8) {
+        short buf[8];
+        samples8(t, buf);
+#pragma unroll
+        for (int w = 0; w < 8; w++) step(buf[w]);
     }
+    for (; t < s1; t++) step(adc[t]);
     if (PASS_B) {
-        tau[((long) li * 2 + 0) * nruns + r] = i5i;
-        tau[((long) li * 2 + 1) * nruns + r] = i5q;
+        tau[lI] = i5i;
+        tau[lQ] = i5q;
     } else {
-        local[((long) li * 2 + 0) * nruns + r] = SI;
-        local[((long) li * 2 + 1) * nruns + r] = SQ;
+        local[lI] = SI;
+        local[lQ] = SQ;
     }
 }
 
