@@ -92,21 +92,9 @@ __global__ __launch_bounds__(RX_THREADS) void rx1_run_kernel(
     const u64 c0 = (u64) ch.cnt1 + (u64) s0;
     u32 k = (u32) (c0 % RX_R1);               // decimation counter at the run start
     long o = (long) (c0 / RX_R1);             // strobes of this call before the run
-    const bool vec = (((uintptr_t) (adc + s0)) & 15) == 0;
-    short buf[8];
-    for (long t = s0; t < s1; t++) {
-        const int w = (int) ((t - s0) & 7);
-        if (w == 0) {
-            if (vec && t + 8 <= s1) {
-                const int4 v = *(const int4 *) (adc + t);
-                buf[0] = (short) v.x; buf[1] = (short) (v.x >> 16); buf[2] = (short) v.y; buf[3] = (short) (v.y >> 16);
-                buf[4] = (short) v.z; buf[5] = (short) (v.z >> 16); buf[6] = (short) v.w; buf[7] = (short) (v.w >> 16);
-            } else {
-                for (int q = 0; q < 8; q++) buf[q] = (t + q < s1) ? adc[t + q] : (short) 0;
-            }
-        }
+    u32 *c0i = c0rel + ((long) li * 2 + 0) * max_out, *c0q = c0rel + ((long) li * 2 + 1) * max_out;
+    auto step = [&](int a) {
         const u32 e = tab[ph >> 35];
-        const int a = buf[w];
         const long long mi = mix22(a, (short) (e & 0xffff)), mq = mix22(a, (short) (e >> 16));
         ph = (ph + ch.phase_inc) & M48;
         a1i += (u64) mi; a2i += a1i;
@@ -116,12 +104,22 @@ __global__ __launch_bounds__(RX_THREADS) void rx1_run_kernel(
             i3q = (i3q + (u32) (a2q >> 29)) & 0x03FFFFFFu;
             if (++k == RX_R1) {
                 k = 0;
-                c0rel[((long) li * 2 + 0) * max_out + o] = i3i;
-                c0rel[((long) li * 2 + 1) * max_out + o] = i3q;
+                c0i[o] = i3i;
+                c0q[o] = i3q;
                 o++;
             }
         }
+    };
+    // whole groups of eight samples from one 16-byte load, the ragged end sample by sample
+    long t = s0;
+    if ((((uintptr_t) (adc + s0)) & 15) == 0) {
+        for (; t + 8 <= s1; t += 8) {
+            const int4 v = *(const int4 *) (adc + t);
+            step((short) v.x); step((short) (v.x >> 16)); step((short) v.y); step((short) (v.y >> 16));
+            step((short) v.z); step((short) (v.z >> 16)); step((short) v.w); step((short) (v.w >> 16));
+        }
     }
+    for (; t < s1; t++) step(adc[t]);
     if (PASS_B) {
         tau[((long) li * 2 + 0) * nruns + r] = i3i;
         tau[((long) li * 2 + 1) * nruns + r] = i3q;
