@@ -135,6 +135,7 @@ __global__ __launch_bounds__(64 * FIR_WAVES) void fir_block_kernel(
     const float2 *__restrict__ tab4096, float2 *__restrict__ out, long out_stride, int max_blk,
     const float *__restrict__ cic, float2 *__restrict__ tap_pre, float2 *__restrict__ tap_post, long tap_stride)
 {
+    (void) max_blk;                           // the grid is sized from it; rows check their own nblk
     __shared__ __attribute__((aligned(16))) float2 tiles[FIR_WAVES][FIR_FFT];
     const int w = threadIdx.x >> 6, t = threadIdx.x & 63;
     const int li = blockIdx.y, blk = blockIdx.x * FIR_WAVES + w;
