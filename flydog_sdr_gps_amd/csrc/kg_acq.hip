@@ -592,10 +592,10 @@ int kg_acq_create(kg_ctx *ctx, int max_sats, int dop_lo, int dop_hi, int max_blo
     int occ1 = 0, occ4 = 0;
     KG_HIP(hipFuncSetAttribute((const void *) acq_correlate_kernel<1, true>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, ACQ_LDS_BYTES));
-    KG_HIP(hipFuncSetAttribute((const void *) acq_correlate_kernel<4, false>,
+    KG_HIP(hipFuncSetAttribute((const void *) acq_correlate_kernel<4, true>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, ACQ_LDS_BYTES));
     KG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ1, acq_correlate_kernel<1, true>, 256, ACQ_LDS_BYTES));
-    KG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ4, acq_correlate_kernel<4, false>, 256, ACQ_LDS_BYTES));
+    KG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ4, acq_correlate_kernel<4, true>, 256, ACQ_LDS_BYTES));
     if (occ1 < 1) occ1 = 1;
     if (occ4 < 1) occ4 = 1;
     a->grid1 = (ctx->num_cus * occ1) & ~7;
@@ -901,7 +901,7 @@ int kg_acq_correlate_blocks_async(kg_acq *a, int first, int nblocks, const int *
         KG_HIP(hipGetLastError());
     }
     if (a->nsel4 > 0) {
-        hipLaunchKernelGGL((acq_correlate_kernel<4, false>), dim3(a->grid4), dim3(256), ACQ_LDS_BYTES, st,
+        hipLaunchKernelGGL((acq_correlate_kernel<4, true>), dim3(a->grid4), dim3(256), ACQ_LDS_BYTES, st,
                            (const float2 *) (a->d_data + (size_t) first * FFT_LEN),
                            (const float2 *) a->d_code, t4, t16,
                            (const acq_cell_desc *) a->d_table4, (const int *) a->d_xcd4, a->halo,
