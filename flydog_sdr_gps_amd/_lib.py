@@ -69,6 +69,7 @@ SYMBOLS = {
     "kg_acq_sample_bits_dev": (_i, [_vp, _i, _vp]),
     "kg_acq_sample_iq16": (_i, [_vp, _i, _vp]),
     "kg_acq_sample_iq16_dev": (_i, [_vp, _i, _vp]),
+    "kg_acq_sample_iq16_batch": (_i, [_vp, _i, _i, _vp, _sz]),
     "kg_acq_sample_iq16_batch_dev": (_i, [_vp, _i, _i, _vp, _sz]),
     "kg_acq_set_data_fft": (_i, [_vp, _i, _vp]),
     "kg_acq_get_data_fft": (_i, [_vp, _i, _vp]),

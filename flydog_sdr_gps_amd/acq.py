@@ -115,6 +115,14 @@ class Searcher:
         check(self.lib.kg_acq_sample_iq16(self.h, block, ptr(iq)), "kg_acq_sample_iq16")
         self.ctx.sync()
 
+    def sample_iq16_host_batch(self, iq, first_block=0):
+        """iq: int16 [nblocks, 2 * 65536] in host memory -> data spectra of blocks first_block .. (one
+        transfer, one front-end launch; the array may be reused as soon as the call returns)."""
+        iq = np.ascontiguousarray(iq, np.int16)
+        iq = iq.reshape(-1, 2 * NSAMPLES)
+        check(self.lib.kg_acq_sample_iq16_batch(self.h, int(first_block), iq.shape[0], ptr(iq), NSAMPLES),
+              "kg_acq_sample_iq16_batch")
+
     def sample_iq16_batch(self, d_iq, nblocks, first_block=0, stride_bytes=4 * NSAMPLES):
         """nblocks blocks from one device array (int pointer), one launch set."""
         check(self.lib.kg_acq_sample_iq16_batch_dev(self.h, int(first_block), int(nblocks),

@@ -443,6 +443,11 @@ struct kg_acq {
     uint8_t *h_pin[4];
     hipEvent_t ev_pin[4];
     int pin_next;
+    // batch calls: one pinned region for all blocks of the call, grown on demand
+    uint8_t *h_batch; size_t batch_cap; hipEvent_t ev_batch;
+    // its transfer runs on a copy-only stream so that it overlaps the previous batch's
+    // correlation: ev_batch = transfer done, ev_in_free = the staging area has been consumed
+    hipStream_t cstream; hipEvent_t ev_in_free; bool in_free_set;
     uint8_t *d_chips;  // [E1B_CODELEN max]
     int *d_limits;     // [max_sats]
     acq_cell_desc *d_table1, *d_table4;   // cell tables of the C/A and E1B launches
@@ -555,6 +560,11 @@ int kg_acq_create(kg_ctx *ctx, int max_sats, int dop_lo, int dop_hi, int max_blo
         KG_HIP(hipEventCreateWithFlags(&a->ev_pin[k], hipEventDisableTiming));
     }
     a->pin_next = 0;
+    a->h_batch = nullptr; a->batch_cap = 0;
+    KG_HIP(hipEventCreateWithFlags(&a->ev_batch, hipEventDisableTiming));
+    KG_HIP(hipEventCreateWithFlags(&a->ev_in_free, hipEventDisableTiming));
+    KG_HIP(hipStreamCreateWithFlags(&a->cstream, hipStreamNonBlocking));
+    a->in_free_set = false;
     KG_HIP(hipMalloc((void **) &a->d_chips, 8192));
     KG_HIP(hipMalloc((void **) &a->d_limits, sizeof(int) * max_sats));
     a->table_cap = (size_t) max_blocks * max_sats * a->ndop;
@@ -622,6 +632,9 @@ void kg_acq_destroy(kg_acq *a)
     (void) hipFree(a->d_fsub); (void) hipFree(a->d_fsub_code);
     (void) hipFree(a->d_in); (void) hipFree(a->d_chips); (void) hipFree(a->d_limits);
     for (int k = 0; k < 4; k++) { (void) hipHostFree(a->h_pin[k]); (void) hipEventDestroy(a->ev_pin[k]); }
+    if (a->h_batch) (void) hipHostFree(a->h_batch);
+    (void) hipEventDestroy(a->ev_batch); (void) hipEventDestroy(a->ev_in_free);
+    (void) hipStreamSynchronize(a->cstream); (void) hipStreamDestroy(a->cstream);
     (void) hipFree(a->d_table1); (void) hipFree(a->d_table4);
     (void) hipFree(a->d_xcd1); (void) hipFree(a->d_xcd4);
     (void) hipFree(a->d_cells); (void) hipFree(a->d_results);
@@ -788,6 +801,37 @@ int kg_acq_sample_iq16_batch_dev(kg_acq *a, int first, int nblocks, const void *
                                    a->d_data + (size_t) first * FFT_LEN, FFT_LEN, 0);
     if (rc) return rc;
     return front_end(a, first, nblocks);
+}
+
+int kg_acq_sample_iq16_batch(kg_acq *a, int first, int nblocks, const int16_t *iq, size_t stride_samples)
+{
+    int rc = check_block(a, first, iq, "kg_acq_sample_iq16_batch");
+    if (rc) return rc;
+    KG_REQUIRE(nblocks >= 1 && first + nblocks <= a->max_blocks, KG_ERR_INVALID,
+               "kg_acq_sample_iq16_batch: blocks %d..%d (max %d)", first, first + nblocks - 1, a->max_blocks);
+    KG_REQUIRE(stride_samples >= (size_t) NSAMPLES, KG_ERR_INVALID, "kg_acq_sample_iq16_batch: stride %zu < %d samples",
+               stride_samples, NSAMPLES);
+    const size_t bytes = IN_STRIDE * (size_t) nblocks;
+    KG_HIP(hipEventSynchronize(a->ev_batch));            // the previous batch has left the pinned region
+    if (bytes > a->batch_cap) {
+        if (a->h_batch) KG_HIP(hipHostFree(a->h_batch));
+        a->h_batch = nullptr; a->batch_cap = 0;
+        KG_HIP(hipHostMalloc((void **) &a->h_batch, bytes, hipHostMallocDefault));
+        a->batch_cap = bytes;
+    }
+    for (int b = 0; b < nblocks; b++)
+        memcpy(a->h_batch + IN_STRIDE * b, iq + 2 * stride_samples * b, IN_STRIDE);
+    uint8_t *stage = a->d_in + IN_STRIDE * first;
+    // copy stream: after the front end that last read the staging area; front-end stream: after the copy
+    if (a->in_free_set) KG_HIP(hipStreamWaitEvent(a->cstream, a->ev_in_free, 0));
+    KG_HIP(hipMemcpyAsync(stage, a->h_batch, bytes, hipMemcpyHostToDevice, a->cstream));
+    KG_HIP(hipEventRecord(a->ev_batch, a->cstream));
+    KG_HIP(hipStreamWaitEvent(a->fstream, a->ev_batch, 0));
+    rc = kg_acq_sample_iq16_batch_dev(a, first, nblocks, stage, IN_STRIDE);
+    if (rc) return rc;
+    KG_HIP(hipEventRecord(a->ev_in_free, a->fstream));
+    a->in_free_set = true;
+    return KG_OK;
 }
 
 int kg_acq_sample_iq16(kg_acq *a, int block, const int16_t *iq)

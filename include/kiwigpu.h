@@ -131,6 +131,10 @@ int kg_acq_sample_iq16_dev(kg_acq *acq, int block, const void *d_iq);
  * one launch set for all of them. */
 int kg_acq_sample_iq16_batch_dev(kg_acq *acq, int first_block, int nblocks, const void *d_iq,
                                  size_t stride_bytes);
+/* The same for nblocks blocks in host memory, stride_samples complex samples apart: copied
+ * into the library's pinned staging region before the call returns, one transfer and one
+ * front-end launch for the batch. */
+int kg_acq_sample_iq16_batch(kg_acq *acq, int first, int nblocks, const int16_t *iq, size_t stride_samples);
 /* Inject / read back Correlate()'s `data` argument (fwd_buf after Sample()),
  * FFT_LEN complex in natural bin order. */
 int kg_acq_set_data_fft(kg_acq *acq, int block, const float *data_fft);

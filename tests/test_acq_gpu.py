@@ -271,3 +271,20 @@ def test_two_block_sets_pipelined(gpu_ctx, navstar_codes_for, oracle):
             assert np.array_equal(got[step][b]["idx"], w["idx"])
             np.testing.assert_allclose(got[step][b]["snr"], w["snr"], rtol=3 * RTOL)
     s.close()
+
+
+def test_host_batch_sample_equals_per_block(gpu_ctx):
+    """kg_acq_sample_iq16_batch (host buffers, one transfer per batch) gives the spectra the
+    per-block host entry point gives, and the caller's array may be overwritten at once."""
+    s = Searcher(gpu_ctx, max_blocks=6)
+    try:
+        blocks = np.stack([synth.config1_iq16(seed=77 + b) for b in range(3)])
+        s.sample_iq16_host_batch(blocks, first_block=3)
+        keep = blocks.copy()
+        blocks[:] = 0                                   # "enqueue only": the library has its own copy
+        for b in range(3):
+            s.sample_iq16(keep[b], block=b)
+        for b in range(3):
+            assert np.array_equal(s.get_data_fft(block=b).view(np.uint32), s.get_data_fft(block=3 + b).view(np.uint32))
+    finally:
+        s.close()

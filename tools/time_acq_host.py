@@ -39,4 +39,24 @@ for name, fn, arg, nsamp in (("int16 IQ, 256 KiB/block", s.sample_iq16, iq, 6553
     t_pipe = (time.perf_counter() - t0) / n
     print("%-26s synchronous %6.1f us/block = %6.1f Msamples/s;  8 in flight %6.1f us/block = %6.1f Msamples/s"
           % (name, t_sync * 1e6, nsamp / t_sync / 1e6, t_pipe * 1e6, nsamp / t_pipe / 1e6))
+for B in (8, 32):
+    s2 = Searcher(ctx, max_blocks=2 * B)
+    for sat in svs:
+        _, t1, t2, _ = sats.SATS[sat]
+        s2.set_code(sat, prn.cacode(t1, t2))
+    batch = np.stack([synth.config1_iq16(seed=0x5EED0002 + b) for b in range(B)])
+    for _ in range(2):
+        s2.sample_iq16_host_batch(batch, 0); s2.correlate_async(svs, nblocks=B); s2.fetch(want_cells=False)
+    n = 40
+    t0 = time.perf_counter()
+    par = 0
+    for i in range(n):
+        s2.sample_iq16_host_batch(batch, par * B)
+        s2.correlate_async(svs, nblocks=B, first_block=par * B)
+        par ^= 1
+    ctx.sync()
+    t = (time.perf_counter() - t0) / n
+    print("int16 IQ host batches of %2d blocks: %7.1f us/batch = %6.1f us/block = %6.1f Msamples/s"
+          % (B, t * 1e6, t * 1e6 / B, B * 65536 / t / 1e6))
+    s2.close()
 s.close()
