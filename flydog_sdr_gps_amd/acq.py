@@ -147,9 +147,7 @@ class Searcher:
 
     # ---- Correlate ----------------------------------------------------------
     def correlate_async(self, sats, nblocks=1, first_block=0):
-        """Enqueue Correlate() over blocks first_block..first_block+nblocks-1.  Alternating
-        first_block between two sets of blocks overlaps the next set's Sample() front end
-        (own stream) with this launch."""
+        """Enqueue Correlate() over blocks first_block..first_block+nblocks-1."""
         sats = np.ascontiguousarray(sats, np.int32)
         check(self.lib.kg_acq_correlate_blocks_async(self.h, int(first_block), int(nblocks),
                                                      ptr(sats), sats.size),

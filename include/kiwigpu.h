@@ -144,11 +144,8 @@ int kg_acq_get_data_td(kg_acq *acq, int block, float *td);
 
 /* Correlate() for nsats SVs x (dop_hi-dop_lo+1) bins x nblocks blocks
  * (blocks 0..nblocks-1), one launch.  Enqueue only.
- * Stream model: the kg_acq_sample_* front end of a block runs on a stream of
- * its own and is ordered against the Correlate() launches that read that block
- * by events, so alternating between two sets of blocks (kg_acq_correlate_
- * blocks_async with first = 0 / B) overlaps Sample() of the next set with
- * Correlate() of the current one. */
+ * Stream model: Sample() and Correlate() run in order on the context's stream
+ * (a second stream for Sample() is an opt-in experiment). */
 int kg_acq_correlate_async(kg_acq *acq, int nblocks, const int *sats, int nsats);
 int kg_acq_correlate_blocks_async(kg_acq *acq, int first_block, int nblocks, const int *sats,
                                   int nsats);
