@@ -141,7 +141,7 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
     u32 *__restrict__ c0rel,                  // B: relative I5 at strobes; entry li: I at c0off[li], Q right after
     u32 *__restrict__ tau,                    // B: [nlist][2][nruns]
     const long *__restrict__ c0off, const long *__restrict__ nouts,
-    short2 *__restrict__ out, long out_stride)   // R == 1 bypass writes the output directly (pass A)
+    short2 *__restrict__ out, long out_stride)   // (unused: the R == 1 bypass has its own kernel)
 {
     __shared__ u32 tab[8192];
     for (int i = threadIdx.x; i < 8192; i += DDC_THREADS) tab[i] = nco[i];
@@ -157,18 +157,7 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
     const u64 Rm1 = (1ull << log2r) - 1;
     const int shift = 65 - 5 * log2r;         // cic_prune_var.v:224-247
 
-    if (log2r == 0) {                         // R == 1 bypass: out = in[23 -: 16] (:289-297)
-        if (!PASS_B) {
-            for (long t = s0; t < s1; t++) {
-                const u32 e = tab[ph >> 35];
-                const int a = adc[t];
-                const int mi = mix24(a, (short) (e & 0xffff)), mq = mix24(a, (short) (e >> 16));
-                out[(long) li * out_stride + t] = make_short2((short) (mi >> 8), (short) (mq >> 8));
-                ph = (ph + ch.phase_inc) & M48;
-            }
-        }
-        return;
-    }
+    if (log2r == 0) return;                   // R == 1 bypass: ddc_wf_bypass_kernel
 
     const u64 cnt0 = (u64) ch.sample_no + (u64) s0;      // samples since the counter was last zero
     const long lI = ((long) li * 2 + 0) * nruns + r, lQ = ((long) li * 2 + 1) * nruns + r;
@@ -280,6 +269,50 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
     } else {
         local[lI] = SI;
         local[lQ] = SQ;
+    }
+}
+
+// R == 1 bypass (cic_prune_var.v:289-297): out = mixer output [23 -: 16], no filter state at all,
+// so it is sample-parallel: eight samples per thread from one 16-byte load, two 16-byte stores.
+__global__ __launch_bounds__(256) void ddc_wf_bypass_kernel(
+    const short *__restrict__ adc, long n, const ddc_chan *__restrict__ chans, const int *__restrict__ chan_list,
+    const int *__restrict__ bypass_list,      // list entries with R == 1
+    const u32 *__restrict__ nco, short2 *__restrict__ out, long out_stride)
+{
+    __shared__ u32 tab[8192];
+    for (int i = threadIdx.x; i < 8192; i += 256) tab[i] = nco[i];
+    __syncthreads();
+    const int li = bypass_list[blockIdx.y];
+    const ddc_chan ch = chans[chan_list[li]];
+    const u64 M48 = (1ull << 48) - 1;
+    const long t0 = ((long) blockIdx.x * 256 + threadIdx.x) * 8;
+    if (t0 >= n) return;
+    u64 ph = (ch.phase + (u64) t0 * ch.phase_inc) & M48;
+    short2 *o = out + (long) li * out_stride + t0;
+    short a[8];
+    const bool full = t0 + 8 <= n;
+    if (full && (((uintptr_t) (adc + t0)) & 15) == 0) {
+        const int4 v = *(const int4 *) (adc + t0);
+        a[0] = (short) v.x; a[1] = (short) (v.x >> 16); a[2] = (short) v.y; a[3] = (short) (v.y >> 16);
+        a[4] = (short) v.z; a[5] = (short) (v.z >> 16); a[6] = (short) v.w; a[7] = (short) (v.w >> 16);
+    } else {
+        for (int q = 0; q < 8; q++) a[q] = (t0 + q < n) ? adc[t0 + q] : (short) 0;
+    }
+    short2 r[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const u32 e = tab[ph >> 35];
+        const int mi = mix24(a[q], (short) (e & 0xffff)), mq = mix24(a[q], (short) (e >> 16));
+        r[q] = make_short2((short) (mi >> 8), (short) (mq >> 8));
+        ph = (ph + ch.phase_inc) & M48;
+    }
+    if (full && (((uintptr_t) o) & 15) == 0) {
+        int4 w0, w1;
+        w0.x = *(int *) &r[0]; w0.y = *(int *) &r[1]; w0.z = *(int *) &r[2]; w0.w = *(int *) &r[3];
+        w1.x = *(int *) &r[4]; w1.y = *(int *) &r[5]; w1.z = *(int *) &r[6]; w1.w = *(int *) &r[7];
+        ((int4 *) o)[0] = w0; ((int4 *) o)[1] = w1;
+    } else {
+        for (int q = 0; q < 8; q++) if (t0 + q < n) o[q] = r[q];
     }
 }
 
@@ -466,6 +499,7 @@ struct kg_ddc {
     u32 *d_nco;
     int *d_list; long *d_nouts, *d_c0off; u32 *d_cnt;
     int *d_wgoff;                 // [nchan + 1] first comb workgroup of every list entry
+    int *d_bypass;                // [nchan] list entries with R == 1
     ddc_state4 *d_local; u32 *d_c0rel, *d_tau, *d_hist;
     int max_runs; long c0_cap;
 };
@@ -498,6 +532,7 @@ int kg_ddc_create(kg_ctx *ctx, int nchan, size_t max_samples, kg_ddc **out)
     KG_HIP(hipMalloc((void **) &d->d_nouts, sizeof(long) * nchan));
     KG_HIP(hipMalloc((void **) &d->d_cnt, sizeof(u32) * nchan));
     KG_HIP(hipMalloc((void **) &d->d_wgoff, sizeof(int) * (nchan + 1)));
+    KG_HIP(hipMalloc((void **) &d->d_bypass, sizeof(int) * nchan));
     KG_HIP(hipMalloc((void **) &d->d_local, sizeof(ddc_state4) * 2 * (size_t) nchan * d->max_runs));
     KG_HIP(hipMalloc((void **) &d->d_tau, sizeof(u32) * 2 * (size_t) nchan * d->max_runs));
     KG_HIP(hipMalloc((void **) &d->d_c0off, sizeof(long) * nchan));
@@ -520,7 +555,7 @@ void kg_ddc_destroy(kg_ddc *d)
     (void) hipSetDevice(d->ctx->device);
     (void) hipStreamSynchronize(d->ctx->stream);
     (void) hipFree(d->d_chans); (void) hipFree(d->d_nco); (void) hipFree(d->d_list);
-    (void) hipFree(d->d_nouts); (void) hipFree(d->d_cnt); (void) hipFree(d->d_wgoff); (void) hipFree(d->d_local);
+    (void) hipFree(d->d_nouts); (void) hipFree(d->d_cnt); (void) hipFree(d->d_wgoff); (void) hipFree(d->d_bypass); (void) hipFree(d->d_local);
     (void) hipFree(d->d_tau); (void) hipFree(d->d_c0rel); (void) hipFree(d->d_hist);
     (void) hipFree(d->d_c0off);
     delete d;
@@ -605,7 +640,7 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
                "kg_ddc_wf_push_dev: misaligned pointer");
     std::vector<long> h_nouts(nlist), h_off(nlist);
     std::vector<u32> h_cnt(nlist);
-    std::vector<int> h_wg(nlist + 1);
+    std::vector<int> h_wg(nlist + 1), h_bypass;
     long max_nout = 0, c0_need = 0, comb_wgs = 0;
     for (int i = 0; i < nlist; i++) {
         const int ch = chan_list[i];
@@ -623,6 +658,7 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
         if (c.log2r) c0_need += 2 * h_nouts[i];
         h_wg[i] = (int) comb_wgs;
         if (c.log2r) comb_wgs += (h_nouts[i] + 255) / 256;
+        else h_bypass.push_back(i);
     }
     h_wg[nlist] = (int) comb_wgs;
     KG_REQUIRE(comb_wgs < (1l << 31), KG_ERR_INVALID, "kg_ddc_wf_push_dev: too many outputs in one call");
@@ -655,7 +691,15 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
     KG_HIP(hipMemcpyAsync(d->d_nouts, h_nouts.data(), sizeof(long) * nlist, hipMemcpyHostToDevice, st));
     KG_HIP(hipMemcpyAsync(d->d_cnt, h_cnt.data(), sizeof(u32) * nlist, hipMemcpyHostToDevice, st));
     KG_HIP(hipMemcpyAsync(d->d_wgoff, h_wg.data(), sizeof(int) * (nlist + 1), hipMemcpyHostToDevice, st));
+    if (!h_bypass.empty())
+        KG_HIP(hipMemcpyAsync(d->d_bypass, h_bypass.data(), sizeof(int) * h_bypass.size(), hipMemcpyHostToDevice, st));
     KG_HIP(hipStreamSynchronize(st));         // the host vectors go out of scope
+    if (!h_bypass.empty()) {
+        hipLaunchKernelGGL(ddc_wf_bypass_kernel, dim3((unsigned) ((n + 2047) / 2048), (unsigned) h_bypass.size()), dim3(256),
+                           0, st, (const short *) d_adc, (long) n, (const ddc_chan *) d->d_chans, (const int *) d->d_list,
+                           (const int *) d->d_bypass, (const u32 *) d->d_nco, (short2 *) d_out, (long) out_stride);
+        KG_HIP(hipGetLastError());
+    }
     const dim3 grid((nruns + DDC_THREADS - 1) / DDC_THREADS, nlist);
     hipLaunchKernelGGL(ddc_wf_run_kernel<false>, grid, dim3(DDC_THREADS), 0, st, (const short *) d_adc, (long) n, L,
                        nruns, (const ddc_chan *) d->d_chans, (const int *) d->d_list, (const u32 *) d->d_nco,
