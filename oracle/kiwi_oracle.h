@@ -204,6 +204,7 @@ typedef struct {
 extern const int32_t ko_cicf_taps65[33];
 void ko_ddc_rx_reset(ko_ddc_rx_state *s);
 int ko_ddc_rx(ko_ddc_rx_state *s, const int16_t *adc, long n, uint64_t phase_inc, uint8_t *out);
+int ko_ddc_shape(int which, int r, int *o);      /* 0 wf1, 1 rx1 (decimation r), 2 rx2 */
 
 /* ---- part 6: S-meter, CAgc, AM / NBFM detectors (kiwi_oracle_post.c) ---- */
 #define KO_AGC_MAX_DELAY_BUF 2048        /* agc.h:16 */

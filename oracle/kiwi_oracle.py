@@ -318,6 +318,13 @@ def fir_process(state, coef_cic, x, prec=1):
     return out[:n].copy(), state.in_pos - (FIR_SIZE - 1)          # FirPos(), fastfir.h:33
 
 
+def ddc_shape(which, r=0):
+    """Structural constants of the pruned CICs as the oracle uses them (see ko_ddc_shape)."""
+    o = (C.c_int * 64)()
+    n = lib().ko_ddc_shape(C.c_int(which), C.c_int(r), o)
+    return list(o[:n])
+
+
 # ---- S-meter, CAgc, AM / NBFM detectors (kiwi_oracle_post.c) -----------------------
 class Agc:
     """One CAgc instance (agc.cpp).  State lives in an opaque buffer of ko_agc_state_size()."""

@@ -20,6 +20,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* comb widths / input truncations of cic_wf1.vh and cic_rx1_*.vh (see ko_ddc_shape below) */
+static const int WF1_COMB_W[5] = {23, 22, 21, 20, 20}, WF1_COMB_D[5] = {5, 1, 1, 1, 0};
+static const int RX1_COMB_W[3] = {22, 21, 20}, RX1_COMB_D[3] = {4, 1, 1};
+
 typedef unsigned __int128 u128;
 
 static int16_t nco_cos[8192], nco_sin[8192];
@@ -100,8 +104,7 @@ int ko_ddc_wf(ko_ddc_wf_state *s, const int16_t *adc, long n, uint64_t phase_inc
             q->integ5 = (q->integ5 + t28) & 0x0FFFFFFF;                 /* 28-bit integrator 5 */
             if (strobe) {
                 /* combs, cic_wf1.vh: widths 23,22,21,20,20; inputs drop 5,1,1,1,0 LSBs */
-                static const int W[5] = {23, 22, 21, 20, 20};
-                static const int D[5] = {5, 1, 1, 1, 0};
+                const int *W = WF1_COMB_W, *D = WF1_COMB_D;
                 int64_t v = sext(q->integ5, 28);
                 for (int k = 0; k < 5; k++) {
                     const int64_t x = sext((uint64_t) (v >> D[k]), W[k]);   /* in_data of comb k */
@@ -116,6 +119,51 @@ int ko_ddc_wf(ko_ddc_wf_state *s, const int16_t *adc, long n, uint64_t phase_inc
         if (strobe || log2r == 0) nout++;
     }
     return nout;
+}
+
+/* The structural constants of the three pruned CICs, in one place: the code above and below
+ * reads them, and tests/test_host_cpu.py compares them with the reference's generated
+ * verilog/rx/cic_*.vh when the reference tree is present (that pins register widths,
+ * truncations and the output rounding slice; the arithmetic around them stays a restatement).
+ * Layout of ko_ddc_shape(): [0] N, [1] input bits, [2] output bits, then N integrator widths,
+ * N comb widths, N comb input truncations, [..] out_msb, out_width, round_bit. */
+static int hogenauer_acc_bits(int n, int r, int bin)          /* cic_gen.c: Bin + ceil(N log2 R) */
+{
+    int growth = 0;
+    double v = 1.0;
+    /* smallest g with 2^g >= R^N */
+    double rn = 1.0;
+    for (int i = 0; i < n; i++) rn *= (double) r;
+    while (v < rn) { v *= 2.0; growth++; }
+    return bin + growth;
+}
+
+int ko_ddc_shape(int which, int r, int *o)
+{
+    int k = 0;
+    if (which == 0) {                          /* wf1: cic_wf1.vh, N = 5, R up to 8192, 24 -> 16 bits */
+        const int acc = hogenauer_acc_bits(5, 8192, 24);
+        o[k++] = 5; o[k++] = 24; o[k++] = 16;
+        for (int i = 0; i < 4; i++) o[k++] = acc;
+        o[k++] = 28;
+        for (int i = 0; i < 5; i++) o[k++] = WF1_COMB_W[i];
+        for (int i = 0; i < 5; i++) o[k++] = WF1_COMB_D[i];
+        o[k++] = 19; o[k++] = 16; o[k++] = 3;
+    } else if (which == 1) {                   /* rx1: cic_rx1_*.vh structure for decimation r, N = 3, 22 -> 18 bits */
+        const int acc = hogenauer_acc_bits(3, r, 22);
+        o[k++] = 3; o[k++] = 22; o[k++] = 18;
+        o[k++] = acc; o[k++] = acc; o[k++] = 26;
+        for (int i = 0; i < 3; i++) o[k++] = RX1_COMB_W[i];
+        for (int i = 0; i < 3; i++) o[k++] = RX1_COMB_D[i];
+        o[k++] = 19; o[k++] = 18; o[k++] = 1;
+    } else {                                   /* rx2: cic_rx2_12k.vh, N = 5, R = 3, 18 -> 24 bits, unpruned */
+        o[k++] = 5; o[k++] = 18; o[k++] = 24;
+        for (int i = 0; i < 5; i++) o[k++] = 26;
+        for (int i = 0; i < 5; i++) o[k++] = 26;
+        for (int i = 0; i < 5; i++) o[k++] = 0;
+        o[k++] = 25; o[k++] = 24; o[k++] = 1;
+    }
+    return k;
 }
 
 /* ======================================================================== */
@@ -172,7 +220,7 @@ int ko_ddc_rx(ko_ddc_rx_state *s, const int16_t *adc, long n, uint64_t phase_inc
             s->i2[c] = (s->i2[c] + s->i1[c]) & M55;
             s->i3[c] = (s->i3[c] + (uint32_t) (s->i2[c] >> 29)) & 0x03FFFFFF;      /* [54 -: 26] */
             if (strobe1) {
-                static const int W[3] = {22, 21, 20}, D[3] = {4, 1, 1};
+                const int *W = RX1_COMB_W, *D = RX1_COMB_D;
                 int64_t v = sext(s->i3[c], 26);
                 for (int k = 0; k < 3; k++) {
                     const int64_t x = sext((uint64_t) (v >> D[k]), W[k]);

@@ -522,3 +522,59 @@ def test_handoff_oracle_known_answers(oracle):
     assert oracle.aper_report(np.full(1024, -200, np.float32)) == (-80, -120)                    # all masked: -110 -> -80
     half = np.concatenate([np.full(512, -113, np.float32), np.full(512, -103, np.float32)])
     assert oracle.aper_report(half) == (-80, -115)                                               # tie -> lower band
+
+
+def _parse_cic_vh(path):
+    """Structural constants of a generated verilog/rx/cic_*.vh: (N, R, Bin, Bout, integrator widths,
+    comb widths, comb input truncations, (out msb, out width, rounding bit))."""
+    import re
+    txt = open(path).read()
+    n, r, bin_, bout = (int(v) for v in re.search(r"N=(\d+) R=(\d+) M=1 Bin=(\d+) Bout=(\d+)", txt).groups())
+    integ = [int(w) for w in re.findall(r"cic_integrator #\(\.WIDTH\((\d+)\)\)", txt)]
+    comb = [int(w) for w in re.findall(r"cic_comb #\(\.WIDTH\((\d+)\)\)", txt)]
+    trunc = []
+    for blk in re.findall(r"cic_comb #.*?\);", txt, flags=re.S):
+        src_w = re.search(r"\.in_data\((\w+)\[(\d+) -:(\d+)\]\)", blk)
+        decl = re.search(r"wire signed \[(\d+):0\] %s;" % src_w.group(1), txt)
+        trunc.append(int(decl.group(1)) + 1 - int(src_w.group(3)))      # declared width - bits taken
+    m = re.search(r"assign out = comb\d_data\[(\d+) -:(\d+)\] \+ comb\d_data\[(\d+)\];", txt)
+    return n, r, bin_, bout, integ, comb, trunc, tuple(int(v) for v in m.groups())
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/verilog/rx"), reason="reference tree not present")
+def test_ddc_oracle_shapes_pinned_against_reference_verilog(oracle):
+    """The DDC oracle has no executable reference (FPGA fabric), but its structural constants do:
+    the register widths, comb truncations and output rounding slices it uses must be the ones in
+    the reference's generated CIC headers.  The checked-in cic_rx1_12k.vh was generated for
+    R = 926 (kiwi.config now says 1736): same structure, and the accumulator width follows
+    cic_gen.c's Bin + ceil(N log2 R) for either R."""
+    ref = "/root/reference/verilog/rx/"
+    n, r, bin_, bout, integ, comb, trunc, out = _parse_cic_vh(ref + "cic_wf1.vh")
+    assert (n, r, bin_, bout) == (5, 8192, 24, 16)
+    assert oracle.ddc_shape(0) == [n, bin_, bout] + integ + comb + trunc + list(out)
+    n, r, bin_, bout, integ, comb, trunc, out = _parse_cic_vh(ref + "cic_rx1_12k.vh")
+    assert oracle.ddc_shape(1, r) == [n, bin_, bout] + integ + comb + trunc + list(out)
+    want = oracle.ddc_shape(1, 1736)                       # RX1_STD_DECIM today
+    assert want[3:6] == [22 + int(np.ceil(3 * np.log2(1736))), 22 + int(np.ceil(3 * np.log2(1736))), 26] == [55, 55, 26]
+    assert want[6:] == oracle.ddc_shape(1, r)[6:]          # combs and rounding do not depend on R
+    n, r, bin_, bout, integ, comb, trunc, out = _parse_cic_vh(ref + "cic_rx2_12k.vh")
+    assert (n, r) == (5, 3)
+    assert oracle.ddc_shape(2) == [n, bin_, bout] + integ + comb + trunc + list(out)
+
+
+@pytest.mark.skipif(not os.path.isfile("/root/reference/verilog/rx/fir_iq.sv"), reason="reference tree not present")
+def test_cicf_taps_pinned_against_reference_verilog(oracle):
+    """The 65-tap CICF of the audio DDC: the oracle's (and, through the bit-exact GPU tests, the
+    library's) 33 stored coefficients are the table of verilog/rx/fir_iq.sv (default branch,
+    N=5 R=3), whose DC gain is 2^17 to within a few LSBs (the acc[41 -: 24] slice divides by 2^18
+    after the /2 decimation)."""
+    import ctypes as C
+    import re
+    txt = open("/root/reference/verilog/rx/fir_iq.sv").read()
+    branch = txt[txt.index("end else begin // N=5,R=3"):]
+    taps = [int(h, 16) for _, h in re.findall(r"assign taps\[\s*(\d+)\]\s*=\s*COEFF'\('sh([0-9a-fA-F]+)\);", branch)][:33]
+    L = oracle.lib()
+    mine = list((C.c_int32 * 33).in_dll(L, "ko_cicf_taps65"))
+    assert len(taps) == 33 and mine == taps
+    signed = [t - (1 << 18) if t & (1 << 17) else t for t in taps]
+    assert abs(2 * sum(signed[:32]) + signed[32] - 2 ** 17) <= 8
