@@ -578,3 +578,23 @@ def test_cicf_taps_pinned_against_reference_verilog(oracle):
     assert len(taps) == 33 and mine == taps
     signed = [t - (1 << 18) if t & (1 << 17) else t for t in taps]
     assert abs(2 * sum(signed[:32]) + signed[32] - 2 ** 17) <= 8
+
+
+@pytest.mark.skipif(not os.path.isfile("/root/reference/gps/sats.cpp"), reason="reference tree not present")
+def test_sats_table_pinned_against_reference():
+    """sats.SATS is the host mirror of Sats[] (gps/sats.cpp:25-142): the active rows (comments
+    stripped), in order, with the QZSS G2 initial states read as the octal literals they are."""
+    import re
+    from flydog_sdr_gps_amd import sats
+    txt = open("/root/reference/gps/sats.cpp").read()
+    body = txt[txt.index("SATELLITE Sats[] = {"):]
+    body = body[:body.index("{-1}")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)          # the SBAS block is commented out
+    body = re.sub(r"//[^\n]*", "", body)
+    rows = re.findall(r"\{\s*(\d+)\s*,\s*(\d+)\s*,\s*(\d+)\s*,\s*(\w+)\s*\}", body)
+    ref = []
+    for prn_, t1, t2, kind in rows:
+        lit = lambda v: int(v, 8) if len(v) > 1 and v[0] == "0" else int(v)      # C literal: leading 0 = octal
+        ref.append((int(prn_), lit(t1), lit(t2), kind))
+    assert ref == [tuple(r) for r in sats.SATS]
+    assert len(ref) == 32 + 4 + 23 and len(ref) <= sats.MAX_SATS
