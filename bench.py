@@ -149,7 +149,7 @@ def bench_waterfall(args):
                    "frames_per_step": nfr},
         "roofline": {"bound": "hbm", "kernel": "wf_frame_kernel", "achieved": round(achieved, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": None, "kernel_ms": round(kernel_ms, 5),
+                     "traffic": measured_traffic("waterfall", nfr), "kernel_ms": round(kernel_ms, 5),
                      "algorithmic_bytes_per_launch": nfr * bytes_frame},
     }), flush=True)
     w.close()
