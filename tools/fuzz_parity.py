@@ -1,0 +1,166 @@
+"""Randomised differential soak: many random configurations of every stateful module through the
+C ABI against the oracle (bit-exact where the module is integer, the module's bar otherwise).
+usage: python tools/fuzz_parity.py [seconds per module] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from flydog_sdr_gps_amd import Adpcm, Context, Ddc, FastFir, Post, RxDdc, post, snd, wire   # noqa: E402
+from flydog_sdr_gps_amd.ddc import RX_DECIM   # noqa: E402
+from oracle import kiwi_oracle as ko          # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+ctx = Context(0)
+fails = 0
+
+
+def adc_block(n):
+    t = np.arange(n)
+    x = rng.normal(0, rng.uniform(1, 3000), n)
+    for _ in range(int(rng.integers(0, 4))):
+        x += rng.uniform(10, 12000) * np.cos(2 * np.pi * rng.uniform(0, 0.5) * t + rng.uniform(0, 6))
+    if rng.random() < 0.1:
+        x[:] = rng.choice([-32768, 32767, 0])
+    return np.clip(np.rint(x), -32768, 32767).astype(np.int16)
+
+
+def soak(name, trial):
+    global fails
+    t0, n = time.time(), 0
+    while time.time() - t0 < budget:
+        try:
+            trial()
+        except AssertionError as e:
+            fails += 1
+            print("FAIL %s trial %d: %s" % (name, n, e))
+            if fails > 5:
+                sys.exit(1)
+        n += 1
+    print("%-10s %5d trials ok" % (name, n))
+
+
+def trial_wfddc():
+    nch = int(rng.integers(1, 5))
+    d = Ddc(ctx, nchan=nch, max_samples=1 << 17)
+    incs = [int(rng.integers(0, 1 << 48)) for _ in range(nch)]
+    l2 = [int(rng.integers(0, 14)) for _ in range(nch)]
+    states = [None] * nch
+    for ch in range(nch):
+        d.set_wf(ch, incs[ch], 1 << l2[ch])
+    for _ in range(int(rng.integers(1, 4))):
+        n = int(rng.integers(1, 1 << 16))
+        adc = adc_block(n)
+        got = d.push(adc, list(range(nch)))
+        for ch in range(nch):
+            want, states[ch] = ko.ddc_wf(adc, incs[ch], l2[ch], states[ch])
+            assert np.array_equal(got[ch], want), ("wf ddc", l2[ch], n)
+    d.close()
+
+
+def trial_rxddc():
+    nch = int(rng.integers(1, 4))
+    d = RxDdc(ctx, nchan=nch, max_samples=1 << 17)
+    incs = [int(rng.integers(0, 1 << 48)) for _ in range(nch)]
+    states = [None] * nch
+    for ch in range(nch):
+        d.set_freq(ch, incs[ch])
+    for _ in range(int(rng.integers(1, 4))):
+        n = int(rng.integers(1, 6 * RX_DECIM))
+        adc = adc_block(n)
+        got = d.push(adc, list(range(nch)))
+        for ch in range(nch):
+            want, states[ch] = ko.ddc_rx(adc, incs[ch], states[ch])
+            assert np.array_equal(got[ch], want), ("rx ddc", n)
+    d.close()
+
+
+def trial_fir():
+    f = FastFir(ctx, nchan=1, max_in=4096)
+    lo = float(rng.uniform(-5000, 4000))
+    hi = float(lo + rng.uniform(100, 5000))
+    if not f.setup(0, lo, min(hi, 5900.0), float(rng.uniform(-200, 200)), 12000.0, window_func=int(rng.integers(-1, 5)),
+                   do_cic_comp=bool(rng.integers(0, 2))):
+        f.close()
+        return
+    coef = f.get_coef(0)
+    st = ko.fir_new_state()
+    scale = 0.0
+    for _ in range(int(rng.integers(2, 8))):
+        n = int(rng.integers(1, 1500))
+        x = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * rng.uniform(1, 20000)).astype(np.complex64)
+        scale = max(scale, float(np.abs(x).max()))
+        got = f.process(0, x)
+        want, pos = ko.fir_process(st, coef, x, prec=0)
+        assert got.size == want.size and f.pos(0) == pos, "fir sizes"
+        if got.size:
+            # 1e-5 of the block's maximum, but not below the fp32 rounding of what went through the
+            # transform: a block that is mostly start-up zeros or stop-band content is tiny next to
+            # its input (observed: errors ~1e-7 of the input amplitude, outputs 0.2 % of it)
+            bar = 1e-5 * max(float(np.abs(want).max()), 0.05 * scale)
+            assert np.abs(got - want).max() <= bar, ("fir values", float(np.abs(got - want).max()), bar)
+    f.close()
+
+
+def trial_post():
+    P = Post(ctx, nchan=1)
+    a = ko.Agc()
+    mode = int(rng.integers(0, 4))
+    P.set_mode(0, mode)
+    P.set_smeter(0, 12000.0)
+    P.reset(0)
+    avg, alpha, z1, last = 0.0, ko.smeter_alpha(12000.0), 0.0, (0.0, 0.0)
+    for _ in range(int(rng.integers(1, 6))):
+        prm = (bool(rng.integers(0, 5)), bool(rng.integers(0, 2)), int(rng.integers(-130, -20)), int(rng.integers(0, 90)),
+               int(rng.integers(0, 11)), int(rng.choice([20, 100, 500, 1000, 5000])), float(rng.choice([12000.0, 20250.0])))
+        P.set_agc(0, *prm)
+        a.set_parameters(*prm)
+        n = int(rng.integers(1, 1025))
+        t = np.arange(n)
+        env = rng.uniform(1, 20000) * np.exp(-t / rng.uniform(50, 5000)) if rng.random() < 0.5 else np.full(n, rng.uniform(0, 9000))
+        x = (env * np.exp(2j * np.pi * rng.uniform(-0.4, 0.4) * t) + rng.normal(0, rng.uniform(0, 50), n)).astype(np.complex64)
+        s16, demod, agc = P.process([0], x[None, :])
+        avg, _ = ko.smeter_process(avg, alpha, x)
+        if mode == post.MODE_SSB:
+            want = a.process_s16(x)
+            dl = np.abs(s16[0].astype(int) - want.astype(int))
+            assert dl.max() <= 1 or np.abs(want).max() > 30000, ("post s16", dl.max())
+        else:
+            want = a.process_cpx(x)
+            assert np.abs(agc[0] - want).max() <= 2e-5 * max(np.abs(want).max(), 1e-20), "post cpx"
+            if mode == post.MODE_AM:
+                wd, z1 = ko.am_detect(z1, want)
+            elif mode == post.MODE_NBFM:
+                wd, last = ko.nbfm_detect(last, want)
+                assert np.abs(demod[0] - wd).max() <= 2e-5 * 8192 + 2e-5 * np.abs(wd).max() + 1e-3, "post nbfm"
+        got_avg, _ = P.smeter([0])
+        assert abs(float(got_avg[0]) - avg) <= 2e-4, ("smeter", got_avg[0], avg)
+    P.close()
+
+
+def trial_wire():
+    nch = int(rng.integers(1, 6))
+    A = Adpcm(ctx, nchan=nch)
+    sts = [None] * nch
+    for _ in range(int(rng.integers(1, 4))):
+        n = 2 * int(rng.integers(1, 600))
+        x = np.clip(np.rint(rng.normal(0, rng.uniform(1, 20000), (nch, n))), -32768, 32767).astype(np.int16)
+        got = A.encode(list(range(nch)), x)
+        for ch in range(nch):
+            want, sts[ch] = ko.adpcm_encode_i16(x[ch], sts[ch])
+            assert np.array_equal(got[ch], want), "adpcm"
+    A.close()
+    rows = rng.integers(0, 256, (3, 1024)).astype(np.uint8)
+    infos = [(int(rng.integers(0, 1 << 31)), int(rng.integers(0, 15)), int(rng.integers(0, 1 << 31)), bool(rng.integers(0, 2)))
+             for _ in range(3)]
+    for r, p in enumerate(wire.wf_packets(ctx, rows, infos)):
+        assert np.array_equal(p, ko.wf_packet(rows[r], *infos[r])), "wf packet"
+
+
+for name, fn in (("wf ddc", trial_wfddc), ("rx ddc", trial_rxddc), ("fastfir", trial_fir), ("post", trial_post), ("wire", trial_wire)):
+    soak(name, fn)
+print("failures:", fails)
+sys.exit(1 if fails else 0)
