@@ -8,7 +8,8 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from flydog_sdr_gps_amd import Adpcm, Context, Ddc, FastFir, Post, RxDdc, post, snd, wire   # noqa: E402
+from flydog_sdr_gps_amd import (Adpcm, Context, Ddc, FastFir, Post, RxDdc, Searcher, post, prn, sats, snd, synth,   # noqa: E402
+                                wire)
 from flydog_sdr_gps_amd.ddc import RX_DECIM   # noqa: E402
 from oracle import kiwi_oracle as ko          # noqa: E402
 
@@ -160,7 +161,39 @@ def trial_wire():
         assert np.array_equal(p, ko.wf_packet(rows[r], *infos[r])), "wf packet"
 
 
-for name, fn in (("wf ddc", trial_wfddc), ("rx ddc", trial_rxddc), ("fastfir", trial_fir), ("post", trial_post), ("wire", trial_wire)):
+_acq = {}
+
+
+def trial_acq():
+    """One SV on one block of 1-bit IF: a PRN injected at a random code phase / Doppler / C/N0 (or
+    absent); the GPU's (valid, Doppler bin, index) must be the oracle's, snr within 2e-5."""
+    if not _acq:
+        _acq["s"] = Searcher(ctx, max_blocks=1)
+        _acq["chips"] = {}
+    s = _acq["s"]
+    sat = int(rng.integers(0, 36))
+    if sat not in _acq["chips"]:
+        _, t1, t2, _ = sats.SATS[sat]
+        _acq["chips"][sat] = prn.cacode(t1, t2)
+        s.set_code(sat, _acq["chips"][sat])
+    chips = _acq["chips"][sat]
+    present = rng.random() < 0.85
+    other = prn.cacode(*sats.SATS[(sat + 7) % 32][1:3])
+    scene = [(chips if present else other, float(rng.uniform(0, 1023)), float(rng.uniform(-5000, 5000)), float(rng.uniform(0, 6.28)))]
+    bits = synth.gps_scene_bits(scene, int(rng.integers(0, 1 << 31)), float(rng.uniform(38, 50)))
+    s.sample(bits, block=0)
+    got, _ = s.correlate_many([sat], nblocks=1, want_cells=False)
+    g = got[0, 0]
+    res = ko.correlate(ko.code_fft(chips, prec=1), ko.sample_bits(bits, prec=1))
+    w_snr, w_dop, w_idx, w_valid = (res[0][k] for k in ("snr", "dop", "idx", "valid"))
+    if w_snr >= 20:                                     # a detection: everything must agree
+        assert (int(g["valid"]), int(g["dop"]), int(g["idx"])) == (int(w_valid), int(w_dop), int(w_idx)), ("acq", g, res[0])
+        assert abs(float(g["snr"]) - w_snr) <= 2e-5 * w_snr, ("acq snr", g["snr"], w_snr)
+    else:                                               # noise: the maximum may sit on a near-tie; the level must agree
+        assert abs(float(g["snr"]) - w_snr) <= 1e-3 * max(w_snr, 1.0), ("acq noise snr", g["snr"], w_snr)
+
+
+for name, fn in (("acq", trial_acq), ("wf ddc", trial_wfddc), ("rx ddc", trial_rxddc), ("fastfir", trial_fir), ("post", trial_post), ("wire", trial_wire)):
     soak(name, fn)
 print("failures:", fails)
 sys.exit(1 if fails else 0)
