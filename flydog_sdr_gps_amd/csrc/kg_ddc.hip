@@ -130,6 +130,8 @@ DDC_DEV int mix24(int adc, int dds)
 }
 
 #define DDC_THREADS 256
+#define DDC_STAGE_ROW 17          // words per lane row of a staging tile: 16 strobes + 1 (odd stride: conflict-free)
+#define DDC_STAGE_BYTES ((DDC_THREADS / 64) * 2 * 64 * DDC_STAGE_ROW * 4)
 
 // Passes A and B.  grid = (ceil(nruns / 256), nchan).
 template <bool PASS_B>
@@ -141,12 +143,14 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
     u32 *__restrict__ c0rel,                  // B: relative I5 at strobes; entry li: I at c0off[li], Q right after
     u32 *__restrict__ tau,                    // B: [nlist][2][nruns]
     const long *__restrict__ c0off, const long *__restrict__ nouts,
-    short2 *__restrict__ out, long out_stride)   // (unused: the R == 1 bypass has its own kernel)
+    const int *__restrict__ sel,              // list entries this launch covers (null: all, in order)
+    int stage_bytes)                          // pass B, R <= 8: dynamic LDS for the strobe staging tiles, else 0
 {
     __shared__ u32 tab[8192];
+    extern __shared__ u32 stage_lds[];        // [waves][2][64][DDC_STAGE_ROW] when stage_bytes != 0
     for (int i = threadIdx.x; i < 8192; i += DDC_THREADS) tab[i] = nco[i];
     __syncthreads();
-    const int li = blockIdx.y;
+    const int li = sel ? sel[blockIdx.y] : (int) blockIdx.y;
     const ddc_chan ch = chans[chan_list[li]];
     const int r = blockIdx.x * DDC_THREADS + threadIdx.x;
     if (r >= nruns) return;
@@ -212,6 +216,62 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
         // of a group leave as ONE 16-byte (8-byte) store per component instead of scattered
         // 4-byte ones (every lane works on a different run, so each store is its own transaction:
         // at R = 2 the scalar stores made pass B 13 times slower than pass A).
+        // R <= 8, pass B: every lane of a wave works on a different run, so a strobe store touches 64
+        // different lines.  With staging tiles the wave collects 16 strobes per run in LDS
+        // (lane rows of 17 words: conflict-free) and flushes them transposed: four lanes write
+        // one run's 64 bytes, a store instruction writes 16 whole lines.  Needs the regular case:
+        // a full wave of full runs aligned to the decimation, 16 | strobes per run, 16-byte
+        // aligned staging rows; anything else takes the paths below.
+        if (PASS_B && stage_bytes && log2r <= 3) {
+            const int lane = threadIdx.x & 63, K = L >> log2r;
+            const bool ok = c == 0 && (s1 - s0) == L && (K & 15) == 0 && (o & 3) == 0 &&
+                            ((uintptr_t) c0i & 15) == 0 && ((uintptr_t) c0q & 15) == 0;
+            if (__popcll(__ballot(ok)) == 64) {
+                u32 *tI = stage_lds + (threadIdx.x >> 6) * (2 * 64 * DDC_STAGE_ROW), *tQ = tI + 64 * DDC_STAGE_ROW;
+                // output index of the wave's first run (lane 0); lane l's run starts l * K later
+                const long o_wave = ((long) __shfl((int) (o >> 32), 0) << 32) | (unsigned) __shfl((int) o, 0);
+                int kcol = 0;
+                long kdone = 0;                                           // strobes of this run already flushed
+                for (; t + 8 <= s1; t += 8) {
+                    short buf[8];
+                    samples8(t, buf);
+#pragma unroll
+                    for (int w = 0; w < 8; w++) {
+                        const u32 e = tab[ph >> 35];
+                        const long long mi = mix24(buf[w], (short) (e & 0xffff)), mq = mix24(buf[w], (short) (e >> 16));
+                        ph = (ph + ch.phase_inc) & M48;
+                        I[0] += (u64) mi; I[1] += I[0]; I[2] += I[1]; I[3] += I[2];
+                        Q[0] += (u64) mq; Q[1] += Q[0]; Q[2] += Q[1]; Q[3] += Q[2];
+                        i5i = (i5i + (u32) (I[3] >> sh5)) & 0x0FFFFFFFu;
+                        i5q = (i5q + (u32) (Q[3] >> sh5)) & 0x0FFFFFFFu;
+                        if (((w + 1) & (int) Rm1) == 0) {                 // strobe (the group starts aligned)
+                            tI[lane * DDC_STAGE_ROW + kcol] = i5i;
+                            tQ[lane * DDC_STAGE_ROW + kcol] = i5q;
+                            kcol++;
+                        }
+                    }
+                    if (kcol == 16) {                                      // wave-uniform
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int rl = q * 16 + (lane >> 2), col = (lane & 3) * 4;
+                            const u32 *ri = tI + rl * DDC_STAGE_ROW + col, *rq = tQ + rl * DDC_STAGE_ROW + col;
+                            const uint4 vi = make_uint4(ri[0], ri[1], ri[2], ri[3]);
+                            const uint4 vq = make_uint4(rq[0], rq[1], rq[2], rq[3]);
+                            const long dst = o_wave + (long) rl * K + kdone + col;
+                            *(uint4 *) (c0i + dst) = vi;
+                            *(uint4 *) (c0q + dst) = vq;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        kdone += 16;
+                        kcol = 0;
+                    }
+                }
+                o += K;                                                    // all K strobes of the run are out
+            }
+        }
         if (PASS_B && log2r <= 2 && c == 0 && (o & 3) == 0 && ((uintptr_t) c0i & 15) == 0 && ((uintptr_t) c0q & 15) == 0) {
             auto quiet = [&](int a) {                     // step() without the strobe store
                 const u32 e = tab[ph >> 35];
@@ -540,6 +600,7 @@ struct kg_ddc {
     int *d_list; long *d_nouts, *d_c0off; u32 *d_cnt;
     int *d_wgoff;                 // [nchan + 1] first comb workgroup of every list entry
     int *d_bypass;                // [nchan] list entries with R == 1
+    int *d_sel;                   // [3][nchan] list entries: R > 1 | 2 <= R <= 8 (staged pass B) | R > 8
     ddc_state4 *d_local; u32 *d_c0rel, *d_tau, *d_hist;
     int max_runs; long c0_cap;
 };
@@ -573,6 +634,9 @@ int kg_ddc_create(kg_ctx *ctx, int nchan, size_t max_samples, kg_ddc **out)
     KG_HIP(hipMalloc((void **) &d->d_cnt, sizeof(u32) * nchan));
     KG_HIP(hipMalloc((void **) &d->d_wgoff, sizeof(int) * (nchan + 1)));
     KG_HIP(hipMalloc((void **) &d->d_bypass, sizeof(int) * nchan));
+    KG_HIP(hipMalloc((void **) &d->d_sel, sizeof(int) * 3 * nchan));
+    KG_HIP(hipFuncSetAttribute((const void *) ddc_wf_run_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               DDC_STAGE_BYTES));
     KG_HIP(hipMalloc((void **) &d->d_local, sizeof(ddc_state4) * 2 * (size_t) nchan * d->max_runs));
     KG_HIP(hipMalloc((void **) &d->d_tau, sizeof(u32) * 2 * (size_t) nchan * d->max_runs));
     KG_HIP(hipMalloc((void **) &d->d_c0off, sizeof(long) * nchan));
@@ -595,7 +659,7 @@ void kg_ddc_destroy(kg_ddc *d)
     (void) hipSetDevice(d->ctx->device);
     (void) hipStreamSynchronize(d->ctx->stream);
     (void) hipFree(d->d_chans); (void) hipFree(d->d_nco); (void) hipFree(d->d_list);
-    (void) hipFree(d->d_nouts); (void) hipFree(d->d_cnt); (void) hipFree(d->d_wgoff); (void) hipFree(d->d_bypass); (void) hipFree(d->d_local);
+    (void) hipFree(d->d_nouts); (void) hipFree(d->d_cnt); (void) hipFree(d->d_wgoff); (void) hipFree(d->d_bypass); (void) hipFree(d->d_sel); (void) hipFree(d->d_local);
     (void) hipFree(d->d_tau); (void) hipFree(d->d_c0rel); (void) hipFree(d->d_hist);
     (void) hipFree(d->d_c0off);
     delete d;
@@ -680,7 +744,7 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
                "kg_ddc_wf_push_dev: misaligned pointer");
     std::vector<long> h_nouts(nlist), h_off(nlist);
     std::vector<u32> h_cnt(nlist);
-    std::vector<int> h_wg(nlist + 1), h_bypass;
+    std::vector<int> h_wg(nlist + 1), h_bypass, h_run, h_small, h_rest;
     long max_nout = 0, c0_need = 0, comb_wgs = 0;
     for (int i = 0; i < nlist; i++) {
         const int ch = chan_list[i];
@@ -699,6 +763,7 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
         h_wg[i] = (int) comb_wgs;
         if (c.log2r) comb_wgs += (h_nouts[i] + 255) / 256;
         else h_bypass.push_back(i);
+        if (c.log2r) { h_run.push_back(i); (c.log2r <= 3 ? h_small : h_rest).push_back(i); }
     }
     h_wg[nlist] = (int) comb_wgs;
     KG_REQUIRE(comb_wgs < (1l << 31), KG_ERR_INVALID, "kg_ddc_wf_push_dev: too many outputs in one call");
@@ -733,6 +798,12 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
     KG_HIP(hipMemcpyAsync(d->d_wgoff, h_wg.data(), sizeof(int) * (nlist + 1), hipMemcpyHostToDevice, st));
     if (!h_bypass.empty())
         KG_HIP(hipMemcpyAsync(d->d_bypass, h_bypass.data(), sizeof(int) * h_bypass.size(), hipMemcpyHostToDevice, st));
+    if (!h_run.empty())
+        KG_HIP(hipMemcpyAsync(d->d_sel, h_run.data(), sizeof(int) * h_run.size(), hipMemcpyHostToDevice, st));
+    if (!h_small.empty())
+        KG_HIP(hipMemcpyAsync(d->d_sel + d->nchan, h_small.data(), sizeof(int) * h_small.size(), hipMemcpyHostToDevice, st));
+    if (!h_rest.empty())
+        KG_HIP(hipMemcpyAsync(d->d_sel + 2 * d->nchan, h_rest.data(), sizeof(int) * h_rest.size(), hipMemcpyHostToDevice, st));
     KG_HIP(hipStreamSynchronize(st));         // the host vectors go out of scope
     if (!h_bypass.empty()) {
         hipLaunchKernelGGL(ddc_wf_bypass_kernel, dim3((unsigned) ((n + 2047) / 2048), (unsigned) h_bypass.size()), dim3(256),
@@ -740,20 +811,41 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
                            (const int *) d->d_bypass, (const u32 *) d->d_nco, (short2 *) d_out, (long) out_stride);
         KG_HIP(hipGetLastError());
     }
-    const dim3 grid((nruns + DDC_THREADS - 1) / DDC_THREADS, nlist);
-    hipLaunchKernelGGL(ddc_wf_run_kernel<false>, grid, dim3(DDC_THREADS), 0, st, (const short *) d_adc, (long) n, L,
-                       nruns, (const ddc_chan *) d->d_chans, (const int *) d->d_list, (const u32 *) d->d_nco,
-                       d->d_local, d->d_c0rel, d->d_tau, (const long *) d->d_c0off, (const long *) d->d_nouts,
-                       (short2 *) d_out, (long) out_stride);
-    KG_HIP(hipGetLastError());
+    const unsigned gx = (unsigned) ((nruns + DDC_THREADS - 1) / DDC_THREADS);
+    if (!h_run.empty()) {
+        hipLaunchKernelGGL(ddc_wf_run_kernel<false>, dim3(gx, (unsigned) h_run.size()), dim3(DDC_THREADS), 0, st,
+                           (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, (const int *) d->d_list,
+                           (const u32 *) d->d_nco, d->d_local, d->d_c0rel, d->d_tau, (const long *) d->d_c0off,
+                           (const long *) d->d_nouts, (const int *) d->d_sel, 0);
+        KG_HIP(hipGetLastError());
+    }
     hipLaunchKernelGGL(ddc_wf_scan_states_kernel, dim3(2 * nlist), dim3(64 * DDC_SCAN_WAVES), 0, st, d->d_local, (long) n, L, nruns,
                        d->d_chans, (const int *) d->d_list);
     KG_HIP(hipGetLastError());
-    hipLaunchKernelGGL(ddc_wf_run_kernel<true>, grid, dim3(DDC_THREADS), 0, st, (const short *) d_adc, (long) n, L,
-                       nruns, (const ddc_chan *) d->d_chans, (const int *) d->d_list, (const u32 *) d->d_nco,
-                       d->d_local, d->d_c0rel, d->d_tau, (const long *) d->d_c0off, (const long *) d->d_nouts,
-                       (short2 *) d_out, (long) out_stride);
-    KG_HIP(hipGetLastError());
+    // Pass B.  The staged strobe flush (R <= 8) needs 34 KiB more LDS, hence its own launch; that
+    // only pays when those channels fill the GPU by themselves (two waves per SIMD), otherwise
+    // splitting the launch costs more than the scattered stores (14-channel set: 3 such channels).
+    const bool staged = (long) h_small.size() * nruns >= (long) d->ctx->num_cus * 4 * 2 * 64;
+    if (staged) {
+        hipLaunchKernelGGL(ddc_wf_run_kernel<true>, dim3(gx, (unsigned) h_small.size()), dim3(DDC_THREADS), DDC_STAGE_BYTES, st,
+                           (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, (const int *) d->d_list,
+                           (const u32 *) d->d_nco, d->d_local, d->d_c0rel, d->d_tau, (const long *) d->d_c0off,
+                           (const long *) d->d_nouts, (const int *) d->d_sel + d->nchan, DDC_STAGE_BYTES);
+        KG_HIP(hipGetLastError());
+        if (!h_rest.empty()) {
+            hipLaunchKernelGGL(ddc_wf_run_kernel<true>, dim3(gx, (unsigned) h_rest.size()), dim3(DDC_THREADS), 0, st,
+                               (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, (const int *) d->d_list,
+                               (const u32 *) d->d_nco, d->d_local, d->d_c0rel, d->d_tau, (const long *) d->d_c0off,
+                               (const long *) d->d_nouts, (const int *) d->d_sel + 2 * d->nchan, 0);
+            KG_HIP(hipGetLastError());
+        }
+    } else if (!h_run.empty()) {
+        hipLaunchKernelGGL(ddc_wf_run_kernel<true>, dim3(gx, (unsigned) h_run.size()), dim3(DDC_THREADS), 0, st,
+                           (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, (const int *) d->d_list,
+                           (const u32 *) d->d_nco, d->d_local, d->d_c0rel, d->d_tau, (const long *) d->d_c0off,
+                           (const long *) d->d_nouts, (const int *) d->d_sel, 0);
+        KG_HIP(hipGetLastError());
+    }
     hipLaunchKernelGGL(ddc_wf_scan_tau_kernel, dim3(2 * nlist), dim3(64), 0, st, d->d_tau, nruns, d->d_chans,
                        (const int *) d->d_list);
     KG_HIP(hipGetLastError());

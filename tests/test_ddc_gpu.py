@@ -202,3 +202,28 @@ def test_rx_ddc_feeds_the_unpack_and_fir(gpu_ctx, oracle):
     assert np.mean(np.abs(y2[512:]) ** 2) < 1e-4 * p_in
     d.close()
     f.close()
+
+
+def test_many_small_decimations_take_the_staged_strobe_path(gpu_ctx, oracle):
+    """26 channels, 24 of them with R = 2, 4, 8, on 2^20 + 37 samples (8193 runs of 128): 24 x 8193
+    runs >= two waves per SIMD, so pass B uses its LDS-staged, transposed strobe stores for them
+    (the last, short run of each channel and the second push -- decimation counter no longer
+    aligned -- take the plain path).  Bit-exact per channel, state carried."""
+    rng = np.random.default_rng(31)
+    l2 = [1, 2, 3] * 8 + [4, 6]
+    nch = len(l2)
+    incs = [int(rng.integers(0, 1 << 48)) for _ in range(nch)]
+    d = Ddc(gpu_ctx, nchan=nch, max_samples=(1 << 20) + 64)
+    try:
+        for ch in range(nch):
+            d.set_wf(ch, incs[ch], 1 << l2[ch])
+        states = [None] * nch
+        for n in ((1 << 20) + 37, (1 << 19) + 5):
+            t = np.arange(n)
+            adc = np.clip(np.rint(9000 * np.cos(2 * np.pi * 0.0123 * t) + rng.normal(0, 200, n)), -32768, 32767).astype(np.int16)
+            got = d.push(adc, list(range(nch)))
+            for ch in range(nch):
+                want, states[ch] = oracle.ddc_wf(adc, incs[ch], l2[ch], states[ch])
+                assert np.array_equal(got[ch], want), (ch, l2[ch], n)
+    finally:
+        d.close()
