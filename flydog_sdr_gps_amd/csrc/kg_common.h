@@ -42,7 +42,23 @@ struct kg_ctx {
     // small per-call tables (descriptor lists) of entry points that own no object
     void *d_scratch;
     size_t scratch_bytes;
+    // Staging ring for the small per-call tables of the enqueue-only entry points (channel lists,
+    // per-channel counts): KG_RING_SLOTS pinned host slots and as many device slots.  A call copies
+    // its table into the next host slot and enqueues the transfer to the matching device slot; the
+    // kernels it then enqueues read the device slot.  A slot comes round again KG_RING_SLOTS uploads
+    // later and waits (normally not at all) for the event recorded half a ring after its last use.
+    unsigned char *h_ring, *d_ring;
+    hipEvent_t ring_ev[32];
+    unsigned long ring_next;
 };
+
+#define KG_RING_SLOTS 32
+#define KG_RING_SLOT_BYTES ((size_t) 512 * 1024)
+
+// A device copy of src[0..bytes) for kernels enqueued on ctx->stream after this call (and before
+// KG_RING_SLOTS / 2 further kg_ctx_stage calls).  Does not synchronise the stream in steady state.
+// Tables larger than a slot take the synchronous scratch buffer.
+int kg_ctx_stage(kg_ctx *ctx, const void *src, size_t bytes, void **d_out);
 
 // Device scratch of at least `bytes`, filled from `src` before returning (synchronous: the
 // previous user of the scratch is drained first).  Valid until the next call on this context.

@@ -31,6 +31,30 @@ int kg_ctx_scratch_upload(kg_ctx *c, const void *src, size_t bytes, void **d_out
     return KG_OK;
 }
 
+int kg_ctx_stage(kg_ctx *c, const void *src, size_t bytes, void **d_out)
+{
+    KG_REQUIRE(c && src && d_out && bytes > 0, KG_ERR_INVALID, "kg_ctx_stage: bad argument");
+    if (bytes > KG_RING_SLOT_BYTES) return kg_ctx_scratch_upload(c, src, bytes, d_out);
+    if (!c->h_ring) {
+        KG_HIP(hipHostMalloc((void **) &c->h_ring, KG_RING_SLOTS * KG_RING_SLOT_BYTES, hipHostMallocDefault));
+        KG_HIP(hipMalloc((void **) &c->d_ring, KG_RING_SLOTS * KG_RING_SLOT_BYTES));
+        for (int i = 0; i < KG_RING_SLOTS; i++) KG_HIP(hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming));
+        c->ring_next = 0;
+    }
+    const unsigned long j = c->ring_next++;
+    const int slot = (int) (j % KG_RING_SLOTS);
+    // The slot was last used by upload j - SLOTS; its consumers were enqueued before upload
+    // j - SLOTS/2 was made (no call makes that many uploads before launching), and the event of
+    // that upload was recorded in front of it.
+    if (j >= KG_RING_SLOTS) KG_HIP(hipEventSynchronize(c->ring_ev[(j - KG_RING_SLOTS / 2) % KG_RING_SLOTS]));
+    KG_HIP(hipEventRecord(c->ring_ev[slot], c->stream));
+    unsigned char *h = c->h_ring + (size_t) slot * KG_RING_SLOT_BYTES, *d = c->d_ring + (size_t) slot * KG_RING_SLOT_BYTES;
+    memcpy(h, src, bytes);
+    KG_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+    *d_out = d;
+    return KG_OK;
+}
+
 extern "C" {
 
 const char *kg_last_error(void) { return g_err; }
@@ -120,6 +144,10 @@ void kg_ctx_destroy(kg_ctx *c)
     (void) hipFree(c->d_tab16384);
     (void) hipFree(c->d_tab8192);
     if (c->d_scratch) (void) hipFree(c->d_scratch);
+    if (c->h_ring) {
+        (void) hipHostFree(c->h_ring); (void) hipFree(c->d_ring);
+        for (int i = 0; i < KG_RING_SLOTS; i++) (void) hipEventDestroy(c->ring_ev[i]);
+    }
     (void) hipEventDestroy(c->ev_start);
     (void) hipEventDestroy(c->ev_stop);
     if (c->own_stream) (void) hipStreamDestroy(c->stream);

@@ -597,10 +597,6 @@ struct kg_ddc {
     ddc_chan *d_chans;
     std::vector<ddc_chan> h_chans;            // host mirror of the scalar fields
     u32 *d_nco;
-    int *d_list; long *d_nouts, *d_c0off; u32 *d_cnt;
-    int *d_wgoff;                 // [nchan + 1] first comb workgroup of every list entry
-    int *d_bypass;                // [nchan] list entries with R == 1
-    int *d_sel;                   // [3][nchan] list entries: R > 1 | 2 <= R <= 8 (staged pass B) | R > 8
     ddc_state4 *d_local; u32 *d_c0rel, *d_tau, *d_hist;
     int max_runs; long c0_cap;
 };
@@ -629,17 +625,10 @@ int kg_ddc_create(kg_ctx *ctx, int nchan, size_t max_samples, kg_ddc **out)
     KG_HIP(hipMalloc((void **) &d->d_chans, sizeof(ddc_chan) * nchan));
     KG_HIP(hipMemset(d->d_chans, 0, sizeof(ddc_chan) * nchan));
     KG_HIP(hipMalloc((void **) &d->d_nco, sizeof(u32) * 8192));
-    KG_HIP(hipMalloc((void **) &d->d_list, sizeof(int) * nchan));
-    KG_HIP(hipMalloc((void **) &d->d_nouts, sizeof(long) * nchan));
-    KG_HIP(hipMalloc((void **) &d->d_cnt, sizeof(u32) * nchan));
-    KG_HIP(hipMalloc((void **) &d->d_wgoff, sizeof(int) * (nchan + 1)));
-    KG_HIP(hipMalloc((void **) &d->d_bypass, sizeof(int) * nchan));
-    KG_HIP(hipMalloc((void **) &d->d_sel, sizeof(int) * 3 * nchan));
     KG_HIP(hipFuncSetAttribute((const void *) ddc_wf_run_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                DDC_STAGE_BYTES));
     KG_HIP(hipMalloc((void **) &d->d_local, sizeof(ddc_state4) * 2 * (size_t) nchan * d->max_runs));
     KG_HIP(hipMalloc((void **) &d->d_tau, sizeof(u32) * 2 * (size_t) nchan * d->max_runs));
-    KG_HIP(hipMalloc((void **) &d->d_c0off, sizeof(long) * nchan));
     KG_HIP(hipMalloc((void **) &d->d_hist, sizeof(u32) * 10 * (size_t) nchan));
     // NCO table (frozen by us; the Xilinx DDS IP is closed): round(16383 * cos/sin(2 pi a / 8192))
     std::vector<u32> tab(8192);
@@ -658,10 +647,10 @@ void kg_ddc_destroy(kg_ddc *d)
     if (!d) return;
     (void) hipSetDevice(d->ctx->device);
     (void) hipStreamSynchronize(d->ctx->stream);
-    (void) hipFree(d->d_chans); (void) hipFree(d->d_nco); (void) hipFree(d->d_list);
-    (void) hipFree(d->d_nouts); (void) hipFree(d->d_cnt); (void) hipFree(d->d_wgoff); (void) hipFree(d->d_bypass); (void) hipFree(d->d_sel); (void) hipFree(d->d_local);
+    (void) hipFree(d->d_chans); (void) hipFree(d->d_nco); 
+    (void) hipFree(d->d_local);
     (void) hipFree(d->d_tau); (void) hipFree(d->d_c0rel); (void) hipFree(d->d_hist);
-    (void) hipFree(d->d_c0off);
+    
     delete d;
 }
 
@@ -791,36 +780,48 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
     int log2L = 0;
     while ((1 << log2L) < L) log2L++;
     KG_REQUIRE(nruns <= d->max_runs, KG_ERR_INVALID, "kg_ddc_wf_push_dev: %d runs > %d", nruns, d->max_runs);
-    KG_HIP(hipMemcpyAsync(d->d_c0off, h_off.data(), sizeof(long) * nlist, hipMemcpyHostToDevice, st));
-    KG_HIP(hipMemcpyAsync(d->d_list, chan_list, sizeof(int) * nlist, hipMemcpyHostToDevice, st));
-    KG_HIP(hipMemcpyAsync(d->d_nouts, h_nouts.data(), sizeof(long) * nlist, hipMemcpyHostToDevice, st));
-    KG_HIP(hipMemcpyAsync(d->d_cnt, h_cnt.data(), sizeof(u32) * nlist, hipMemcpyHostToDevice, st));
-    KG_HIP(hipMemcpyAsync(d->d_wgoff, h_wg.data(), sizeof(int) * (nlist + 1), hipMemcpyHostToDevice, st));
-    if (!h_bypass.empty())
-        KG_HIP(hipMemcpyAsync(d->d_bypass, h_bypass.data(), sizeof(int) * h_bypass.size(), hipMemcpyHostToDevice, st));
-    if (!h_run.empty())
-        KG_HIP(hipMemcpyAsync(d->d_sel, h_run.data(), sizeof(int) * h_run.size(), hipMemcpyHostToDevice, st));
-    if (!h_small.empty())
-        KG_HIP(hipMemcpyAsync(d->d_sel + d->nchan, h_small.data(), sizeof(int) * h_small.size(), hipMemcpyHostToDevice, st));
-    if (!h_rest.empty())
-        KG_HIP(hipMemcpyAsync(d->d_sel + 2 * d->nchan, h_rest.data(), sizeof(int) * h_rest.size(), hipMemcpyHostToDevice, st));
-    KG_HIP(hipStreamSynchronize(st));         // the host vectors go out of scope
+    // The per-call tables go through the context's staging ring in one piece: no stream
+    // synchronisation, and the previous call's kernels keep their own copy.
+    const long *s_c0off, *s_nouts; const int *s_list, *s_wgoff, *s_bypass, *s_selrun, *s_selsmall, *s_selrest; const u32 *s_cnt;
+    {
+        std::vector<unsigned char> pack;
+        auto put = [&](const void *src, size_t bytes) -> size_t {
+            const size_t at = (pack.size() + 15) & ~(size_t) 15;
+            pack.resize(at + bytes);
+            if (bytes) memcpy(pack.data() + at, src, bytes);
+            return at;
+        };
+        const size_t o_off = put(h_off.data(), sizeof(long) * nlist), o_nouts = put(h_nouts.data(), sizeof(long) * nlist);
+        const size_t o_list = put(chan_list, sizeof(int) * nlist), o_cnt = put(h_cnt.data(), sizeof(u32) * nlist);
+        const size_t o_wg = put(h_wg.data(), sizeof(int) * (nlist + 1));
+        const size_t o_by = put(h_bypass.data(), sizeof(int) * h_bypass.size());
+        const size_t o_run = put(h_run.data(), sizeof(int) * h_run.size());
+        const size_t o_small = put(h_small.data(), sizeof(int) * h_small.size());
+        const size_t o_rest = put(h_rest.data(), sizeof(int) * h_rest.size());
+        void *base = nullptr;
+        if ((rc = kg_ctx_stage(d->ctx, pack.data(), pack.size(), &base))) return rc;
+        const unsigned char *b = (const unsigned char *) base;
+        s_c0off = (const long *) (b + o_off); s_nouts = (const long *) (b + o_nouts);
+        s_list = (const int *) (b + o_list); s_cnt = (const u32 *) (b + o_cnt); s_wgoff = (const int *) (b + o_wg);
+        s_bypass = (const int *) (b + o_by); s_selrun = (const int *) (b + o_run);
+        s_selsmall = (const int *) (b + o_small); s_selrest = (const int *) (b + o_rest);
+    }
     if (!h_bypass.empty()) {
         hipLaunchKernelGGL(ddc_wf_bypass_kernel, dim3((unsigned) ((n + 2047) / 2048), (unsigned) h_bypass.size()), dim3(256),
-                           0, st, (const short *) d_adc, (long) n, (const ddc_chan *) d->d_chans, (const int *) d->d_list,
-                           (const int *) d->d_bypass, (const u32 *) d->d_nco, (short2 *) d_out, (long) out_stride);
+                           0, st, (const short *) d_adc, (long) n, (const ddc_chan *) d->d_chans, s_list,
+                           s_bypass, (const u32 *) d->d_nco, (short2 *) d_out, (long) out_stride);
         KG_HIP(hipGetLastError());
     }
     const unsigned gx = (unsigned) ((nruns + DDC_THREADS - 1) / DDC_THREADS);
     if (!h_run.empty()) {
         hipLaunchKernelGGL(ddc_wf_run_kernel<false>, dim3(gx, (unsigned) h_run.size()), dim3(DDC_THREADS), 0, st,
-                           (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, (const int *) d->d_list,
-                           (const u32 *) d->d_nco, d->d_local, d->d_c0rel, d->d_tau, (const long *) d->d_c0off,
-                           (const long *) d->d_nouts, (const int *) d->d_sel, 0);
+                           (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, s_list,
+                           (const u32 *) d->d_nco, d->d_local, d->d_c0rel, d->d_tau, s_c0off,
+                           s_nouts, s_selrun, 0);
         KG_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(ddc_wf_scan_states_kernel, dim3(2 * nlist), dim3(64 * DDC_SCAN_WAVES), 0, st, d->d_local, (long) n, L, nruns,
-                       d->d_chans, (const int *) d->d_list);
+                       d->d_chans, s_list);
     KG_HIP(hipGetLastError());
     // Pass B.  The staged strobe flush (R <= 8) needs 34 KiB more LDS, hence its own launch; that
     // only pays when those channels fill the GPU by themselves (two waves per SIMD), otherwise
@@ -828,37 +829,37 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
     const bool staged = (long) h_small.size() * nruns >= (long) d->ctx->num_cus * 4 * 2 * 64;
     if (staged) {
         hipLaunchKernelGGL(ddc_wf_run_kernel<true>, dim3(gx, (unsigned) h_small.size()), dim3(DDC_THREADS), DDC_STAGE_BYTES, st,
-                           (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, (const int *) d->d_list,
-                           (const u32 *) d->d_nco, d->d_local, d->d_c0rel, d->d_tau, (const long *) d->d_c0off,
-                           (const long *) d->d_nouts, (const int *) d->d_sel + d->nchan, DDC_STAGE_BYTES);
+                           (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, s_list,
+                           (const u32 *) d->d_nco, d->d_local, d->d_c0rel, d->d_tau, s_c0off,
+                           s_nouts, s_selsmall, DDC_STAGE_BYTES);
         KG_HIP(hipGetLastError());
         if (!h_rest.empty()) {
             hipLaunchKernelGGL(ddc_wf_run_kernel<true>, dim3(gx, (unsigned) h_rest.size()), dim3(DDC_THREADS), 0, st,
-                               (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, (const int *) d->d_list,
-                               (const u32 *) d->d_nco, d->d_local, d->d_c0rel, d->d_tau, (const long *) d->d_c0off,
-                               (const long *) d->d_nouts, (const int *) d->d_sel + 2 * d->nchan, 0);
+                               (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, s_list,
+                               (const u32 *) d->d_nco, d->d_local, d->d_c0rel, d->d_tau, s_c0off,
+                               s_nouts, s_selrest, 0);
             KG_HIP(hipGetLastError());
         }
     } else if (!h_run.empty()) {
         hipLaunchKernelGGL(ddc_wf_run_kernel<true>, dim3(gx, (unsigned) h_run.size()), dim3(DDC_THREADS), 0, st,
-                           (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, (const int *) d->d_list,
-                           (const u32 *) d->d_nco, d->d_local, d->d_c0rel, d->d_tau, (const long *) d->d_c0off,
-                           (const long *) d->d_nouts, (const int *) d->d_sel, 0);
+                           (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, s_list,
+                           (const u32 *) d->d_nco, d->d_local, d->d_c0rel, d->d_tau, s_c0off,
+                           s_nouts, s_selrun, 0);
         KG_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(ddc_wf_scan_tau_kernel, dim3(2 * nlist), dim3(64), 0, st, d->d_tau, nruns, d->d_chans,
-                       (const int *) d->d_list);
+                       s_list);
     KG_HIP(hipGetLastError());
     if (comb_wgs > 0) {
         hipLaunchKernelGGL(ddc_wf_comb_kernel, dim3((unsigned) comb_wgs), dim3(256), 0, st,
-                           (const u32 *) d->d_c0rel, (const u32 *) d->d_tau, log2L, nruns, (const long *) d->d_c0off,
-                           (const ddc_chan *) d->d_chans, (const int *) d->d_list, (const long *) d->d_nouts,
-                           (const u32 *) d->d_cnt, (const int *) d->d_wgoff, nlist, (short2 *) d_out, (long) out_stride,
+                           (const u32 *) d->d_c0rel, (const u32 *) d->d_tau, log2L, nruns, s_c0off,
+                           (const ddc_chan *) d->d_chans, s_list, s_nouts,
+                           s_cnt, s_wgoff, nlist, (short2 *) d_out, (long) out_stride,
                            d->d_hist);
         KG_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(ddc_wf_finish_kernel, dim3((nlist + 63) / 64), dim3(64), 0, st, d->d_chans,
-                       (const int *) d->d_list, nlist, (long) n, (const long *) d->d_nouts, (const u32 *) d->d_hist);
+                       s_list, nlist, (long) n, s_nouts, (const u32 *) d->d_hist);
     KG_HIP(hipGetLastError());
     // host mirror of the scalar state
     for (int i = 0; i < nlist; i++) {

@@ -150,7 +150,7 @@ int kg_aper_update_dev(kg_aper *a, const int32_t *chans, int nrows, const void *
         h[i].start = cfg[i].audio_fft ? 256 : 0; h[i].stop = cfg[i].audio_fft ? 768 : APER_LEN;
     }
     void *d_cfg = nullptr;
-    if ((rc = kg_ctx_scratch_upload(a->ctx, h.data(), sizeof(aper_row_cfg) * nrows, &d_cfg))) return rc;
+    if ((rc = kg_ctx_stage(a->ctx, h.data(), sizeof(aper_row_cfg) * nrows, &d_cfg))) return rc;
     hipLaunchKernelGGL(aper_update_kernel, dim3(APER_LEN / 256, nrows), dim3(256), 0, a->ctx->stream, a->d_avg,
                        (const unsigned char *) d_rows, row_stride, (const aper_row_cfg *) d_cfg, waterfall_cal);
     KG_HIP(hipGetLastError());

@@ -241,8 +241,6 @@ struct kg_post {
     post_chan *d_chan;
     float2 *d_ring_in;
     float *d_ring_mag;
-    int *d_list;
-    std::vector<int> list;               // what d_list holds
     std::vector<post_chan> h_chan;       // parameters only; the state lives on the device
     std::vector<post_host> h_args;
 };
@@ -293,7 +291,6 @@ int kg_post_create(kg_ctx *ctx, int nchan, kg_post **out)
     KG_HIP(hipMalloc((void **) &p->d_chan, sizeof(post_chan) * nchan));
     KG_HIP(hipMalloc((void **) &p->d_ring_in, sizeof(float2) * POST_CIRC * (size_t) nchan));
     KG_HIP(hipMalloc((void **) &p->d_ring_mag, sizeof(float) * POST_CIRC * (size_t) nchan));
-    KG_HIP(hipMalloc((void **) &p->d_list, sizeof(int) * nchan));
     post_chan z;
     memset(&z, 0, sizeof z);
     z.agc_on = 1;                                   // CAgc::CAgc(), agc.cpp:77-86
@@ -317,7 +314,7 @@ void kg_post_destroy(kg_post *p)
     if (!p) return;
     (void) hipSetDevice(p->ctx->device);
     (void) hipStreamSynchronize(p->ctx->stream);
-    (void) hipFree(p->d_chan); (void) hipFree(p->d_ring_in); (void) hipFree(p->d_ring_mag); (void) hipFree(p->d_list);
+    (void) hipFree(p->d_chan); (void) hipFree(p->d_ring_in); (void) hipFree(p->d_ring_mag);
     delete p;
 }
 
@@ -433,13 +430,10 @@ int kg_post_process_dev(kg_post *p, const int32_t *chans, int nch, const void *d
         seen[chans[i]] = 1;
     }
     hipStream_t st = p->ctx->stream;
-    if ((int) p->list.size() != nch || memcmp(p->list.data(), chans, sizeof(int) * nch) != 0) {
-        KG_HIP(hipStreamSynchronize(st));      // an earlier launch may still read the old list
-        p->list.assign(chans, chans + nch);
-        KG_HIP(hipMemcpy(p->d_list, p->list.data(), sizeof(int) * nch, hipMemcpyHostToDevice));
-    }
+    void *d_list = nullptr;
+    if ((rc = kg_ctx_stage(p->ctx, chans, sizeof(int) * nch, &d_list))) return rc;
     hipLaunchKernelGGL(post_kernel, dim3(nch), dim3(64), 0, st, p->d_chan, p->d_ring_in, p->d_ring_mag,
-                       (const int *) p->d_list, (const float2 *) d_fir, in_stride, nsamps,
+                       (const int *) d_list, (const float2 *) d_fir, in_stride, nsamps,
                        (short *) d_s16, (float *) d_demod, (float2 *) d_agc, out_stride);
     KG_HIP(hipGetLastError());
     return KG_OK;

@@ -293,7 +293,6 @@ struct kg_rxddc {
     int nchan; long max_samples;
     rx_chan *d_chans; std::vector<rx_chan> h;
     u32 *d_nco;
-    int *d_list, *d_nfinal; long *d_nouts, *d_n1b, *d_qfirst; u32 *d_cnt;
     u64 *d_st; u32 *d_c0rel, *d_tau, *d_hist;
     int *d_c1buf; long c1_stride;
     int max_runs; long max_out;
@@ -321,12 +320,6 @@ int kg_rxddc_create(kg_ctx *ctx, int nchan, size_t max_samples, kg_rxddc **out)
     KG_HIP(hipMalloc((void **) &d->d_chans, sizeof(rx_chan) * nchan));
     KG_HIP(hipMemset(d->d_chans, 0, sizeof(rx_chan) * nchan));
     KG_HIP(hipMalloc((void **) &d->d_nco, sizeof(u32) * 8192));
-    KG_HIP(hipMalloc((void **) &d->d_list, sizeof(int) * nchan));
-    KG_HIP(hipMalloc((void **) &d->d_nfinal, sizeof(int) * nchan));
-    KG_HIP(hipMalloc((void **) &d->d_nouts, sizeof(long) * nchan));
-    KG_HIP(hipMalloc((void **) &d->d_n1b, sizeof(long) * nchan));
-    KG_HIP(hipMalloc((void **) &d->d_qfirst, sizeof(long) * nchan));
-    KG_HIP(hipMalloc((void **) &d->d_cnt, sizeof(u32) * nchan));
     KG_HIP(hipMalloc((void **) &d->d_st, sizeof(u64) * 4 * (size_t) nchan * d->max_runs));
     KG_HIP(hipMalloc((void **) &d->d_tau, sizeof(u32) * 2 * (size_t) nchan * d->max_runs));
     KG_HIP(hipMalloc((void **) &d->d_c0rel, sizeof(u32) * 2 * (size_t) nchan * d->max_out));
@@ -349,8 +342,8 @@ void kg_rxddc_destroy(kg_rxddc *d)
     if (!d) return;
     (void) hipSetDevice(d->ctx->device);
     (void) hipStreamSynchronize(d->ctx->stream);
-    (void) hipFree(d->d_chans); (void) hipFree(d->d_nco); (void) hipFree(d->d_list); (void) hipFree(d->d_nfinal);
-    (void) hipFree(d->d_nouts); (void) hipFree(d->d_n1b); (void) hipFree(d->d_qfirst); (void) hipFree(d->d_cnt);
+    (void) hipFree(d->d_chans); (void) hipFree(d->d_nco); 
+    
     (void) hipFree(d->d_st); (void) hipFree(d->d_tau); (void) hipFree(d->d_c0rel); (void) hipFree(d->d_hist);
     (void) hipFree(d->d_c1buf);
     delete d;
@@ -436,43 +429,55 @@ int kg_rxddc_push_dev(kg_rxddc *d, const void *d_adc, size_t n, const int32_t *c
     const int nruns = (int) ((n + L - 1) / L);
     KG_REQUIRE(nruns <= d->max_runs, KG_ERR_INVALID, "kg_rxddc_push_dev: %d runs > %d", nruns, d->max_runs);
     hipStream_t st = d->ctx->stream;
-    KG_HIP(hipMemcpyAsync(d->d_list, chan_list, sizeof(int) * nlist, hipMemcpyHostToDevice, st));
-    KG_HIP(hipMemcpyAsync(d->d_nouts, h_nouts.data(), sizeof(long) * nlist, hipMemcpyHostToDevice, st));
-    KG_HIP(hipMemcpyAsync(d->d_n1b, h_n1b.data(), sizeof(long) * nlist, hipMemcpyHostToDevice, st));
-    KG_HIP(hipMemcpyAsync(d->d_qfirst, h_qfirst.data(), sizeof(long) * nlist, hipMemcpyHostToDevice, st));
-    KG_HIP(hipMemcpyAsync(d->d_nfinal, h_nfinal.data(), sizeof(int) * nlist, hipMemcpyHostToDevice, st));
-    KG_HIP(hipMemcpyAsync(d->d_cnt, h_cnt.data(), sizeof(u32) * nlist, hipMemcpyHostToDevice, st));
-    KG_HIP(hipStreamSynchronize(st));
+    // per-call tables through the context's staging ring (no stream synchronisation)
+    const int *s_list, *s_nfinal; const long *s_nouts, *s_n1b, *s_qfirst; const u32 *s_cnt;
+    {
+        std::vector<unsigned char> pack;
+        auto put = [&](const void *src, size_t bytes) -> size_t {
+            const size_t at = (pack.size() + 15) & ~(size_t) 15;
+            pack.resize(at + bytes);
+            memcpy(pack.data() + at, src, bytes);
+            return at;
+        };
+        const size_t o_list = put(chan_list, sizeof(int) * nlist), o_nouts = put(h_nouts.data(), sizeof(long) * nlist);
+        const size_t o_n1b = put(h_n1b.data(), sizeof(long) * nlist), o_qf = put(h_qfirst.data(), sizeof(long) * nlist);
+        const size_t o_nf = put(h_nfinal.data(), sizeof(int) * nlist), o_cnt = put(h_cnt.data(), sizeof(u32) * nlist);
+        void *base = nullptr;
+        if ((rc = kg_ctx_stage(d->ctx, pack.data(), pack.size(), &base))) return rc;
+        const unsigned char *b = (const unsigned char *) base;
+        s_list = (const int *) (b + o_list); s_nouts = (const long *) (b + o_nouts); s_n1b = (const long *) (b + o_n1b);
+        s_qfirst = (const long *) (b + o_qf); s_nfinal = (const int *) (b + o_nf); s_cnt = (const u32 *) (b + o_cnt);
+    }
     const dim3 grid((nruns + RX_THREADS - 1) / RX_THREADS, nlist);
     hipLaunchKernelGGL(rx1_run_kernel<false>, grid, dim3(RX_THREADS), 0, st, (const short *) d_adc, (long) n, L, nruns,
-                       (const rx_chan *) d->d_chans, (const int *) d->d_list, (const u32 *) d->d_nco, d->d_st,
+                       (const rx_chan *) d->d_chans, s_list, (const u32 *) d->d_nco, d->d_st,
                        d->d_c0rel, d->d_tau, d->max_out);
     KG_HIP(hipGetLastError());
     hipLaunchKernelGGL(rx1_scan_kernel, dim3(2 * nlist), dim3(64), 0, st, d->d_st, (long) n, L, nruns, d->d_chans,
-                       (const int *) d->d_list);
+                       s_list);
     KG_HIP(hipGetLastError());
     hipLaunchKernelGGL(rx1_run_kernel<true>, grid, dim3(RX_THREADS), 0, st, (const short *) d_adc, (long) n, L, nruns,
-                       (const rx_chan *) d->d_chans, (const int *) d->d_list, (const u32 *) d->d_nco, d->d_st,
+                       (const rx_chan *) d->d_chans, s_list, (const u32 *) d->d_nco, d->d_st,
                        d->d_c0rel, d->d_tau, d->max_out);
     KG_HIP(hipGetLastError());
     hipLaunchKernelGGL(rx1_scan_tau_kernel, dim3(2 * nlist), dim3(64), 0, st, d->d_tau, nruns, d->d_chans,
-                       (const int *) d->d_list);
+                       s_list);
     KG_HIP(hipGetLastError());
     if (max_n1 > 0) {
         hipLaunchKernelGGL(rx1_comb_kernel, dim3((unsigned) ((max_n1 + 255) / 256), nlist), dim3(256), 0, st,
                            (const u32 *) d->d_c0rel, (const u32 *) d->d_tau, L, nruns, d->max_out,
-                           (const rx_chan *) d->d_chans, (const int *) d->d_list, (const long *) d->d_nouts,
-                           (const u32 *) d->d_cnt, d->d_c1buf, d->c1_stride, d->d_hist);
+                           (const rx_chan *) d->d_chans, s_list, s_nouts,
+                           s_cnt, d->d_c1buf, d->c1_stride, d->d_hist);
         KG_HIP(hipGetLastError());
     }
     if (max_final > 0) {
         hipLaunchKernelGGL(rx2_fir_kernel, dim3((max_final + 127) / 128, nlist), dim3(128), 0, st,
-                           (const int *) d->d_c1buf, d->c1_stride, (const int *) d->d_list, (const long *) d->d_n1b,
-                           (const long *) d->d_qfirst, (const int *) d->d_nfinal, (unsigned short *) d_out, (long) out_stride);
+                           (const int *) d->d_c1buf, d->c1_stride, s_list, s_n1b,
+                           s_qfirst, s_nfinal, (unsigned short *) d_out, (long) out_stride);
         KG_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(rx_finish_kernel, dim3(nlist), dim3(RX_HIST), 0, st, d->d_chans, (const int *) d->d_list, (long) n,
-                       (const long *) d->d_nouts, (const u32 *) d->d_hist, d->d_c1buf, d->c1_stride);
+    hipLaunchKernelGGL(rx_finish_kernel, dim3(nlist), dim3(RX_HIST), 0, st, d->d_chans, s_list, (long) n,
+                       s_nouts, (const u32 *) d->d_hist, d->d_c1buf, d->c1_stride);
     KG_HIP(hipGetLastError());
     for (int i = 0; i < nlist; i++) {
         rx_chan &c = d->h[chan_list[i]];

@@ -226,7 +226,6 @@ struct kg_fir {
     long hist_stride;
     float2 *d_hist, *d_coef, *d_taps, *d_stage_in, *d_stage_out;
     float *d_cic;
-    int *d_list, *d_fill, *d_nblk, *d_rem;
     std::vector<int> fill;                    // pending new samples per channel = FirPos()
     std::vector<char> coef_set;
     // host copies of the design tables (SetupWindowFunction / constructor)
@@ -290,10 +289,6 @@ int kg_fir_create(kg_ctx *ctx, int nchan, int max_in, kg_fir **out)
     fir_cic_table(0, f->cic);                                          // the constructor's m_CIC, fastfir.cpp:61-79
     f->cic_3ch = 0;
     KG_HIP(hipMemcpy(f->d_cic, f->cic, sizeof f->cic, hipMemcpyHostToDevice));
-    KG_HIP(hipMalloc((void **) &f->d_list, sizeof(int) * nchan));
-    KG_HIP(hipMalloc((void **) &f->d_fill, sizeof(int) * nchan));
-    KG_HIP(hipMalloc((void **) &f->d_nblk, sizeof(int) * nchan));
-    KG_HIP(hipMalloc((void **) &f->d_rem, sizeof(int) * nchan));
     *out = f;
     return KG_OK;
 }
@@ -304,7 +299,7 @@ void kg_fir_destroy(kg_fir *f)
     (void) hipSetDevice(f->ctx->device);
     (void) hipStreamSynchronize(f->ctx->stream);
     (void) hipFree(f->d_hist); (void) hipFree(f->d_coef); (void) hipFree(f->d_taps); (void) hipFree(f->d_cic);
-    (void) hipFree(f->d_list); (void) hipFree(f->d_fill); (void) hipFree(f->d_nblk); (void) hipFree(f->d_rem);
+    
     (void) hipFree(f->d_stage_in); (void) hipFree(f->d_stage_out);
     delete f;
 }
@@ -446,30 +441,37 @@ static int fir_process_impl(kg_fir *f, const int32_t *chans, int nch, const void
     }
     if (n == 0) return KG_OK;
     hipStream_t st = f->ctx->stream;
-    KG_HIP(hipMemcpyAsync(f->d_list, chans, sizeof(int) * nch, hipMemcpyHostToDevice, st));
-    KG_HIP(hipMemcpyAsync(f->d_fill, h_fill.data(), sizeof(int) * nch, hipMemcpyHostToDevice, st));
-    KG_HIP(hipMemcpyAsync(f->d_nblk, h_nblk.data(), sizeof(int) * nch, hipMemcpyHostToDevice, st));
-    KG_HIP(hipMemcpyAsync(f->d_rem, h_rem.data(), sizeof(int) * nch, hipMemcpyHostToDevice, st));
-    KG_HIP(hipStreamSynchronize(st));         // the host vectors go out of scope
+    // per-call tables through the context's staging ring (no stream synchronisation)
+    const int *s_list, *s_fill, *s_nblk, *s_rem;
+    {
+        std::vector<int> pack(4 * (size_t) nch);
+        memcpy(pack.data(), chans, sizeof(int) * nch);
+        memcpy(pack.data() + nch, h_fill.data(), sizeof(int) * nch);
+        memcpy(pack.data() + 2 * nch, h_nblk.data(), sizeof(int) * nch);
+        memcpy(pack.data() + 3 * nch, h_rem.data(), sizeof(int) * nch);
+        void *base = nullptr;
+        if ((rc = kg_ctx_stage(f->ctx, pack.data(), sizeof(int) * pack.size(), &base))) return rc;
+        s_list = (const int *) base; s_fill = s_list + nch; s_nblk = s_list + 2 * nch; s_rem = s_list + 3 * nch;
+    }
     hipLaunchKernelGGL(fir_append_kernel, dim3((n + 255) / 256, nch), dim3(256), 0, st, (const float2 *) d_in,
-                       (long) in_stride, (const int *) f->d_list, (const int *) f->d_fill, n, f->d_hist, f->hist_stride);
+                       (long) in_stride, s_list, s_fill, n, f->d_hist, f->hist_stride);
     KG_HIP(hipGetLastError());
     if (max_blk > 0) {
         const dim3 grid((max_blk + FIR_WAVES - 1) / FIR_WAVES, nch);
         if (d_pre || d_post)
             hipLaunchKernelGGL(fir_block_kernel<true>, grid, dim3(64 * FIR_WAVES), 0, st,
-                               (const float2 *) f->d_hist, f->hist_stride, (const int *) f->d_list, (const int *) f->d_nblk,
+                               (const float2 *) f->d_hist, f->hist_stride, s_list, s_nblk,
                                (const float2 *) f->d_coef, (const float2 *) f->ctx->d_tab4096, (float2 *) d_out,
                                (long) out_stride, max_blk, (const float *) f->d_cic, (float2 *) d_pre, (float2 *) d_post,
                                (long) tap_stride);
         else
             hipLaunchKernelGGL(fir_block_kernel<false>, grid, dim3(64 * FIR_WAVES), 0, st,
-                               (const float2 *) f->d_hist, f->hist_stride, (const int *) f->d_list, (const int *) f->d_nblk,
+                               (const float2 *) f->d_hist, f->hist_stride, s_list, s_nblk,
                                (const float2 *) f->d_coef, (const float2 *) f->ctx->d_tab4096, (float2 *) d_out,
                                (long) out_stride, max_blk, (const float *) nullptr, (float2 *) nullptr, (float2 *) nullptr, 0L);
         KG_HIP(hipGetLastError());
         hipLaunchKernelGGL(fir_shift_kernel, dim3(nch), dim3(1024), 0, st, f->d_hist, f->hist_stride,
-                           (const int *) f->d_list, (const int *) f->d_nblk, (const int *) f->d_rem);
+                           s_list, s_nblk, s_rem);
         KG_HIP(hipGetLastError());
     }
     for (int i = 0; i < nch; i++) f->fill[chans[i]] = h_rem[i];
@@ -514,7 +516,7 @@ static int unpack_impl(kg_ctx *ctx, const void *d_raw, size_t raw_stride, int ns
     KG_REQUIRE(out_stride >= (size_t) nsamps && (raw_stride == 0 || raw_stride >= (size_t) nsamps), KG_ERR_INVALID,
                "kg_dpump_unpack_dev: stride smaller than nsamps");
     void *d_en = nullptr;
-    if ((rc = kg_ctx_scratch_upload(ctx, enabled, nchans, &d_en))) return rc;
+    if ((rc = kg_ctx_stage(ctx, enabled, nchans, &d_en))) return rc;
     hipLaunchKernelGGL(snd_unpack_kernel, dim3((nsamps + 255) / 256, nchans), dim3(256), 0, ctx->stream,
                        (const unsigned short *) d_raw, (long) raw_stride, nsamps, nchans, (const unsigned char *) d_en,
                        rescale, dc_i, dc_q, spectral_inversion ? 1 : 0, (float2 *) d_out, (long) out_stride);

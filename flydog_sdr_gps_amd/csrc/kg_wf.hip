@@ -179,8 +179,6 @@ struct kg_wf {
     int nchan;
     wf_chan_dev *d_chans;
     float *d_windows, *d_cic;
-    int *d_chan_of;  int chan_of_cap;
-    std::vector<int> chan_of;            // what d_chan_of holds
     short2 *d_iq;    unsigned char *d_out;  int stage_cap;      // staging for host-buffer calls
     float *d_tap_pwr, *d_tap_pwr_out, *d_tap_db;
     std::vector<char> chan_set;
@@ -201,7 +199,6 @@ int kg_wf_create(kg_ctx *ctx, int nchan, kg_wf **out)
     KG_REQUIRE(w != nullptr, KG_ERR_NOMEM, "kg_wf_create: alloc");
     w->ctx = ctx; w->nchan = nchan; w->tables_set = false;
     w->chan_set.assign(nchan, 0);
-    w->d_chan_of = nullptr; w->chan_of_cap = 0;
     w->d_iq = nullptr; w->d_out = nullptr; w->stage_cap = 0;
     w->d_tap_pwr = w->d_tap_pwr_out = w->d_tap_db = nullptr;
     KG_HIP(hipMalloc((void **) &w->d_chans, sizeof(wf_chan_dev) * nchan));
@@ -225,7 +222,7 @@ void kg_wf_destroy(kg_wf *w)
     (void) hipSetDevice(w->ctx->device);
     (void) hipStreamSynchronize(w->ctx->stream);
     (void) hipFree(w->d_chans); (void) hipFree(w->d_windows); (void) hipFree(w->d_cic);
-    (void) hipFree(w->d_chan_of); (void) hipFree(w->d_iq); (void) hipFree(w->d_out);
+    (void) hipFree(w->d_iq); (void) hipFree(w->d_out);
     (void) hipFree(w->d_tap_pwr); (void) hipFree(w->d_tap_pwr_out); (void) hipFree(w->d_tap_db);
     delete w;
 }
@@ -309,30 +306,21 @@ static int wf_launch(kg_wf *w, int nframes, const int32_t *chan_of, const void *
         KG_REQUIRE(w->chan_set[chan_of[f]], KG_ERR_STATE, "kg_wf_frames: channel %d is not configured", chan_of[f]);
     }
     hipStream_t st = w->ctx->stream;
-    if (nframes > w->chan_of_cap) {
-        KG_HIP(hipStreamSynchronize(st));
-        (void) hipFree(w->d_chan_of);
-        w->chan_of.clear();
-        KG_HIP(hipMalloc((void **) &w->d_chan_of, sizeof(int) * nframes));
-        w->chan_of_cap = nframes;
-    }
-    // chan_of is the caller's and this entry point only enqueues: keep a copy, upload it
-    // synchronously, and only when it differs from what the device already holds
-    if ((int) w->chan_of.size() != nframes || memcmp(w->chan_of.data(), chan_of, sizeof(int) * nframes) != 0) {
-        KG_HIP(hipStreamSynchronize(st));      // an earlier launch may still read the old list
-        w->chan_of.assign(chan_of, chan_of + nframes);
-        KG_HIP(hipMemcpy(w->d_chan_of, w->chan_of.data(), sizeof(int) * nframes, hipMemcpyHostToDevice));
+    void *d_chan_of = nullptr;                 // chan_of is the caller's: staged copy, no stream synchronisation
+    {
+        int rc = kg_ctx_stage(w->ctx, chan_of, sizeof(int) * nframes, &d_chan_of);
+        if (rc) return rc;
     }
     const int grid = nframes < w->grid ? nframes : w->grid;
     if (!taps) {
         hipLaunchKernelGGL(wf_frame_kernel<false>, dim3(grid), dim3(256), WF_LDS_BYTES, st,
-                           (const short2 *) d_iq, (const int *) w->d_chan_of, (const wf_chan_dev *) w->d_chans,
+                           (const short2 *) d_iq, (const int *) d_chan_of, (const wf_chan_dev *) w->d_chans,
                            (const float *) w->d_windows, (const float *) w->d_cic,
                            (const float2 *) w->ctx->d_tab4096, (const float2 *) w->ctx->d_tab8192, nframes,
                            (unsigned char *) d_out, (float *) nullptr, (float *) nullptr, (float *) nullptr);
     } else {
         hipLaunchKernelGGL(wf_frame_kernel<true>, dim3(grid), dim3(256), WF_LDS_BYTES, st,
-                           (const short2 *) d_iq, (const int *) w->d_chan_of, (const wf_chan_dev *) w->d_chans,
+                           (const short2 *) d_iq, (const int *) d_chan_of, (const wf_chan_dev *) w->d_chans,
                            (const float *) w->d_windows, (const float *) w->d_cic,
                            (const float2 *) w->ctx->d_tab4096, (const float2 *) w->ctx->d_tab8192, nframes,
                            (unsigned char *) d_out, w->d_tap_pwr, w->d_tap_pwr_out, w->d_tap_db);

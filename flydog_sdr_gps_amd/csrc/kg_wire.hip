@@ -137,8 +137,6 @@ struct kg_adpcm {
     kg_ctx *ctx;
     int nchan;
     adpcm_state *d_state;
-    int *d_list;
-    std::vector<int> list;
 };
 
 extern "C" {
@@ -155,7 +153,6 @@ int kg_adpcm_create(kg_ctx *ctx, int nchan, kg_adpcm **out)
     a->ctx = ctx; a->nchan = nchan;
     KG_HIP(hipMalloc((void **) &a->d_state, sizeof(adpcm_state) * nchan));
     KG_HIP(hipMemset(a->d_state, 0, sizeof(adpcm_state) * nchan));
-    KG_HIP(hipMalloc((void **) &a->d_list, sizeof(int) * nchan));
     *out = a;
     return KG_OK;
 }
@@ -165,7 +162,7 @@ void kg_adpcm_destroy(kg_adpcm *a)
     if (!a) return;
     (void) hipSetDevice(a->ctx->device);
     (void) hipStreamSynchronize(a->ctx->stream);
-    (void) hipFree(a->d_state); (void) hipFree(a->d_list);
+    (void) hipFree(a->d_state);
     delete a;
 }
 
@@ -214,12 +211,9 @@ int kg_adpcm_encode_dev(kg_adpcm *a, const int32_t *chans, int nch, const void *
         seen[chans[i]] = 1;
     }
     hipStream_t st = a->ctx->stream;
-    if ((int) a->list.size() != nch || memcmp(a->list.data(), chans, sizeof(int) * nch) != 0) {
-        KG_HIP(hipStreamSynchronize(st));
-        a->list.assign(chans, chans + nch);
-        KG_HIP(hipMemcpy(a->d_list, a->list.data(), sizeof(int) * nch, hipMemcpyHostToDevice));
-    }
-    hipLaunchKernelGGL(adpcm_snd_kernel, dim3((nch + 63) / 64), dim3(64), 0, st, a->d_state, (const int *) a->d_list,
+    void *d_list = nullptr;
+    if ((rc = kg_ctx_stage(a->ctx, chans, sizeof(int) * nch, &d_list))) return rc;
+    hipLaunchKernelGGL(adpcm_snd_kernel, dim3((nch + 63) / 64), dim3(64), 0, st, a->d_state, (const int *) d_list,
                        nch, (const short *) d_s16, in_stride, nsamps, (unsigned char *) d_out, out_stride);
     KG_HIP(hipGetLastError());
     return KG_OK;
@@ -270,7 +264,7 @@ int kg_wf_packets_dev(kg_ctx *ctx, const void *d_rows, size_t row_stride, int nr
         pkt_bytes[i] = KG_WF_PKT_HDR + (info[i].use_compression ? (KG_WF_ADPCM_PAD + 1024) / 2 : 1024);
     }
     void *d_info = nullptr;
-    if ((rc = kg_ctx_scratch_upload(ctx, h.data(), sizeof(wf_pkt_dev_info) * nrows, &d_info))) return rc;
+    if ((rc = kg_ctx_stage(ctx, h.data(), sizeof(wf_pkt_dev_info) * nrows, &d_info))) return rc;
     hipLaunchKernelGGL(wf_packet_kernel, dim3(nrows), dim3(64), 0, ctx->stream, (const unsigned char *) d_rows,
                        row_stride, (const wf_pkt_dev_info *) d_info, (unsigned char *) d_pkts, pkt_stride);
     KG_HIP(hipGetLastError());

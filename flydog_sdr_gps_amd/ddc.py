@@ -27,7 +27,8 @@ class Ddc:
 
     def close(self):
         if getattr(self, "h", None):
-            self.lib.kg_ddc_destroy(self.h)
+            if getattr(self.ctx, "h", None):          # an object must not outlive its context
+                self.lib.kg_ddc_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -99,7 +100,8 @@ class RxDdc:
 
     def close(self):
         if getattr(self, "h", None):
-            self.lib.kg_rxddc_destroy(self.h)
+            if getattr(self.ctx, "h", None):          # an object must not outlive its context
+                self.lib.kg_rxddc_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -76,7 +76,8 @@ class FastFir:
 
     def close(self):
         if getattr(self, "h", None):
-            self.lib.kg_fir_destroy(self.h)
+            if getattr(self.ctx, "h", None):          # an object must not outlive its context
+                self.lib.kg_fir_destroy(self.h)
             self.h = None
 
     def __del__(self):

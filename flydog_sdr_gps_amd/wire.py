@@ -39,7 +39,8 @@ class Adpcm:
 
     def close(self):
         if getattr(self, "h", None):
-            self.lib.kg_adpcm_destroy(self.h)
+            if getattr(self.ctx, "h", None):          # an object must not outlive its context
+                self.lib.kg_adpcm_destroy(self.h)
             self.h = None
 
     def __del__(self):

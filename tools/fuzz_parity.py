@@ -196,4 +196,7 @@ def trial_acq():
 for name, fn in (("acq", trial_acq), ("wf ddc", trial_wfddc), ("rx ddc", trial_rxddc), ("fastfir", trial_fir), ("post", trial_post), ("wire", trial_wire)):
     soak(name, fn)
 print("failures:", fails)
+if _acq:
+    _acq["s"].close()
+ctx.close()
 sys.exit(1 if fails else 0)
