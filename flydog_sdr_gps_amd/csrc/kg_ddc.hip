@@ -181,7 +181,10 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
         }
     };
 
-    if (log2r <= 8) {
+    // Pass A always starts from zero: over a run of at most 1024 samples the integrators hold plain
+    // sums below 2^23 * 1024^4 / 24 < 2^59, so 64 bits are exact for every R (stored sign-extended).
+    const bool short_zero_run = !PASS_B && L <= 1024;
+    if (log2r <= 8 || short_zero_run) {
         // Narrow path.  The integrator inputs are m << shift, so bits [shift-1:0] of every
         // integrator stay zero, and nothing above bit 88 is ever read (integrator 5 takes
         // [88 -: 28]): for R <= 256 the live bits [88:shift] are 24 + 5 log2 R <= 64 bits, kept
@@ -320,8 +323,12 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
         } else {
             ddc_state4 a, b;
             for (int k = 0; k < 4; k++) {
-                a.i[k] = mk128(I[k] << shift, I[k] >> (64 - shift));
-                b.i[k] = mk128(Q[k] << shift, Q[k] >> (64 - shift));
+                // R <= 256: bits above 88 are never read, a logical shift will do; wider R (zero-state
+                // sums): the value is signed and must be extended through bit 88
+                const u64 hi_i = log2r <= 8 ? I[k] >> (64 - shift) : (u64) ((long long) I[k] >> (shift ? 64 - shift : 63));
+                const u64 hi_q = log2r <= 8 ? Q[k] >> (64 - shift) : (u64) ((long long) Q[k] >> (shift ? 64 - shift : 63));
+                a.i[k] = mk128(I[k] << shift, hi_i);
+                b.i[k] = mk128(Q[k] << shift, hi_q);
             }
             local[lI] = a;
             local[lQ] = b;
