@@ -47,6 +47,7 @@ SYMBOLS = {
     "kg_last_error": (C.c_char_p, []),
     "kg_abi_version": (_i, []),
     "kg_ctx_create": (_i, [_i, _vp, C.POINTER(_vp)]),
+    "kg_ctx_create_on_stream": (_i, [_i, _vp, C.POINTER(_vp)]),
     "kg_ctx_destroy": (None, [_vp]),
     "kg_ctx_sync": (_i, [_vp]),
     "kg_ctx_poll": (_i, [_vp]),
@@ -61,6 +62,9 @@ SYMBOLS = {
     "kg_timer_start": (_i, [_vp]),
     "kg_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
     "kg_acq_create": (_i, [_vp, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "kg_acq_create_shape": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "kg_acq_nsamples": (_i, [_vp]),
+    "kg_acq_fft_len": (_i, [_vp]),
     "kg_acq_destroy": (None, [_vp]),
     "kg_acq_set_code": (_i, [_vp, _i, _vp, _i, _i, _i]),
     "kg_acq_set_code_fft": (_i, [_vp, _i, _vp, _i]),
@@ -180,13 +184,17 @@ def ptr(a):
 
 class Context:
     """One per GPU per process (kg_ctx).  stream: a hipStream_t handle (int), e.g.
-    torch.cuda.current_stream().cuda_stream, or None for a library-owned stream."""
+    torch.cuda.current_stream().cuda_stream -- 0 is HIP's legacy default stream and is used
+    as such -- or None for a library-owned non-blocking stream."""
 
     def __init__(self, device=0, stream=None):
         self.lib = load_library()
         h = C.c_void_p()
-        check(self.lib.kg_ctx_create(int(device), C.c_void_p(stream) if stream else None,
-                                     C.byref(h)), "kg_ctx_create")
+        if stream is None:
+            check(self.lib.kg_ctx_create(int(device), None, C.byref(h)), "kg_ctx_create")
+        else:
+            check(self.lib.kg_ctx_create_on_stream(int(device), C.c_void_p(int(stream)), C.byref(h)),
+                  "kg_ctx_create_on_stream")
         self.h = h
         self.device = device
 

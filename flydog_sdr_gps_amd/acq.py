@@ -22,6 +22,11 @@ NSAMPLES = 65536      # gps/gps.h:73
 FFT_LEN = 16384       # gps/gps.h:72
 DECIM = 4             # gps/gps.h:62
 BIN_SIZE = 249.755859375   # Hz, gps/gps.h:69
+# BASELINE.json configs[4]: 10 ms coherent (163680 samples at FS), 65536-point transforms,
+# Doppler bin SAMPLE_RATE / 65536 = 62.44 Hz, 256 bins = -128..127 (KG_ACQ10_* in kiwigpu.h)
+NSAMPLES_10MS = 163680
+FFT_LEN_10MS = 65536
+BIN_SIZE_10MS = 4.092e6 / 65536
 DOP_LO, DOP_HI = -20, 20   # gps/search.cpp:465
 MIN_SIG = 16               # gps/gps.h:60
 
@@ -32,15 +37,20 @@ class Searcher:
     """GPU acquisition engine for one device (kg_acq)."""
 
     def __init__(self, ctx=None, max_sats=_sats.MAX_SATS, dop_lo=DOP_LO, dop_hi=DOP_HI,
-                 max_blocks=1, device=0):
+                 max_blocks=1, device=0, nsamples=NSAMPLES, fft_len=FFT_LEN):
         self.ctx = ctx if ctx is not None else Context(device)
         self.lib = self.ctx.lib
         self.max_sats, self.dop_lo, self.dop_hi = max_sats, dop_lo, dop_hi
         self.ndop = dop_hi - dop_lo + 1
         self.max_blocks = max_blocks
+        self.nsamples, self.fft_len = int(nsamples), int(fft_len)
         h = C.c_void_p()
-        check(self.lib.kg_acq_create(self.ctx.h, max_sats, dop_lo, dop_hi, max_blocks,
-                                     C.byref(h)), "kg_acq_create")
+        if (self.nsamples, self.fft_len) == (NSAMPLES, FFT_LEN):
+            check(self.lib.kg_acq_create(self.ctx.h, max_sats, dop_lo, dop_hi, max_blocks,
+                                         C.byref(h)), "kg_acq_create")
+        else:
+            check(self.lib.kg_acq_create_shape(self.ctx.h, max_sats, dop_lo, dop_hi, max_blocks,
+                                               self.nsamples, self.fft_len, C.byref(h)), "kg_acq_create_shape")
         self.h = h
         self._last = (0, 0)
 
@@ -66,13 +76,13 @@ class Searcher:
 
     def set_code_fft(self, sat, code_fft, limit=_sats.L1_LIMIT):
         code_fft = np.ascontiguousarray(code_fft, np.complex64)
-        if code_fft.size != FFT_LEN:
-            raise ValueError("code_fft must hold %d bins" % FFT_LEN)
+        if code_fft.size != self.fft_len:
+            raise ValueError("code_fft must hold %d bins" % self.fft_len)
         check(self.lib.kg_acq_set_code_fft(self.h, int(sat), ptr(code_fft), int(limit)),
               "kg_acq_set_code_fft")
 
     def get_code_fft(self, sat):
-        out = np.empty(FFT_LEN, np.complex64)
+        out = np.empty(self.fft_len, np.complex64)
         check(self.lib.kg_acq_get_code_fft(self.h, int(sat), ptr(out)), "kg_acq_get_code_fft")
         return out
 
@@ -93,26 +103,26 @@ class Searcher:
 
     # ---- Sample -------------------------------------------------------------
     def sample(self, packed, block=0):
-        """8192 bytes of packed 1-bit IF -> data spectrum of `block` (Sample())."""
+        """nsamples / 8 (8192) bytes of packed 1-bit IF -> data spectrum of `block` (Sample())."""
         if isinstance(packed, int):
             check(self.lib.kg_acq_sample_bits_dev(self.h, block, ptr(packed)),
                   "kg_acq_sample_bits_dev")
             return
         packed = np.ascontiguousarray(packed, np.uint8)
-        if packed.size != NSAMPLES // 8:
-            raise ValueError("need %d bytes of packed samples" % (NSAMPLES // 8))
+        if packed.size != self.nsamples // 8:
+            raise ValueError("need %d bytes of packed samples" % (self.nsamples // 8))
         check(self.lib.kg_acq_sample_bits(self.h, block, ptr(packed)), "kg_acq_sample_bits")
         self.ctx.sync()      # the host buffer may be released by the caller
 
     def sample_iq16(self, iq, block=0):
-        """65536 complex int16 samples at the FS/4 IF (extension), host array or device ptr."""
+        """nsamples (65536) complex int16 samples at the FS/4 IF (extension), host array or device ptr."""
         if isinstance(iq, int):
             check(self.lib.kg_acq_sample_iq16_dev(self.h, block, ptr(iq)),
                   "kg_acq_sample_iq16_dev")
             return
         iq = np.ascontiguousarray(iq, np.int16).reshape(-1)
-        if iq.size != 2 * NSAMPLES:
-            raise ValueError("need %d int16 values" % (2 * NSAMPLES))
+        if iq.size != 2 * self.nsamples:
+            raise ValueError("need %d int16 values" % (2 * self.nsamples))
         check(self.lib.kg_acq_sample_iq16(self.h, block, ptr(iq)), "kg_acq_sample_iq16")
         self.ctx.sync()
 
@@ -120,29 +130,31 @@ class Searcher:
         """iq: int16 [nblocks, 2 * 65536] in host memory -> data spectra of blocks first_block .. (one
         transfer, one front-end launch; the array may be reused as soon as the call returns)."""
         iq = np.ascontiguousarray(iq, np.int16)
-        iq = iq.reshape(-1, 2 * NSAMPLES)
-        check(self.lib.kg_acq_sample_iq16_batch(self.h, int(first_block), iq.shape[0], ptr(iq), NSAMPLES),
+        iq = iq.reshape(-1, 2 * self.nsamples)
+        check(self.lib.kg_acq_sample_iq16_batch(self.h, int(first_block), iq.shape[0], ptr(iq), self.nsamples),
               "kg_acq_sample_iq16_batch")
 
-    def sample_iq16_batch(self, d_iq, nblocks, first_block=0, stride_bytes=4 * NSAMPLES):
+    def sample_iq16_batch(self, d_iq, nblocks, first_block=0, stride_bytes=None):
         """nblocks blocks from one device array (int pointer), one launch set."""
+        if stride_bytes is None:
+            stride_bytes = 4 * self.nsamples
         check(self.lib.kg_acq_sample_iq16_batch_dev(self.h, int(first_block), int(nblocks),
                                                     ptr(int(d_iq)), int(stride_bytes)),
               "kg_acq_sample_iq16_batch_dev")
 
     def set_data_fft(self, data_fft, block=0):
         data_fft = np.ascontiguousarray(data_fft, np.complex64)
-        if data_fft.size != FFT_LEN:
-            raise ValueError("data_fft must hold %d bins" % FFT_LEN)
+        if data_fft.size != self.fft_len:
+            raise ValueError("data_fft must hold %d bins" % self.fft_len)
         check(self.lib.kg_acq_set_data_fft(self.h, block, ptr(data_fft)), "kg_acq_set_data_fft")
 
     def get_data_fft(self, block=0):
-        out = np.empty(FFT_LEN, np.complex64)
+        out = np.empty(self.fft_len, np.complex64)
         check(self.lib.kg_acq_get_data_fft(self.h, block, ptr(out)), "kg_acq_get_data_fft")
         return out
 
     def get_data_td(self, block=0):
-        out = np.empty(FFT_LEN, np.complex64)
+        out = np.empty(self.fft_len, np.complex64)
         check(self.lib.kg_acq_get_data_td(self.h, block, ptr(out)), "kg_acq_get_data_td")
         return out
 

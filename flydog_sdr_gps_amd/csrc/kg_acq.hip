@@ -3,8 +3,15 @@
 // Replaces gps/search.cpp of the reference: the SearchInit() code-table build
 // (:243-285, :309-346), Sample() (:382-449) and Correlate() (:453-499).
 //
-// Data layout in HBM (private to this file): every 16384-bin spectrum is kept
-// "residue-major": plane r (0..3) holds bins k = 4*k1 + r.  Inside a plane,
+// Shape.  The reference is one fixed shape (gps/gps.h:62-73): NSAMPLES 65536 input
+// samples, DECIM 4, FFT_LEN N = 16384.  Here the shape is a property of the kg_acq
+// object: `nsamples` input samples carry signal (the rest of the 4*N-sample array is
+// zero, as DecimateBy2float's zero tail, :145), N = P * 4096 with P = 4 (reference)
+// or P = 16 (BASELINE configs[4]: 10 ms coherent = 163680 samples, N = 65536).  The
+// text below is written for P = 4; for P = 16 read "16 planes / 16 sub-transforms".
+//
+// Data layout in HBM (private to this file): every N-bin spectrum is kept
+// "residue-major": plane r (0..P-1) holds bins k = P*k1 + r.  Inside a plane,
 // element k1 = t + 256 j (the value thread t feeds into leg j of its first
 // radix-16) sits at row j>>1, column 2*(t + H) + (j&1): the two legs 2i, 2i+1
 // of one thread are adjacent, so a thread fetches its 16 inputs with eight
@@ -24,13 +31,13 @@
 #include "kg_common.h"
 #include "kg_fft.h"
 
+#include <math.h>
 #include <stdlib.h>
 #include <vector>
 
-#define NSAMPLES KG_ACQ_NSAMPLES
-#define FFT_LEN  KG_ACQ_FFT_LEN
-#define SUB      4096                 // FFT_LEN / 4
+#define SUB      4096                 // points per sub-transform: N / P
 #define NTAPS    31                   // gps/search.cpp:49
+#define DECIM    4                    // gps/gps.h:62
 
 // ---------------------------------------------------------------------------
 // Front end: mix -> half-band /2 -> half-band /2   (Sample() / SearchInit())
@@ -49,9 +56,9 @@ __constant__ float c_hb_even[16] = {
 KG_DEV float bipolar(int bit) { return bit ? -1.0f : 1.0f; }      // search.cpp:62-66
 
 template <int SRC>
-KG_DEV cf acq_source(const void *__restrict__ src, int i, int nchips, int boc)
+KG_DEV cf acq_source(const void *__restrict__ src, int i, int nvalid, int nchips, int boc)
 {
-    if (i >= NSAMPLES) return cf{0.f, 0.f};          // DecimateBy2float zero tail, :145
+    if (i >= nvalid) return cf{0.f, 0.f};            // DecimateBy2float zero tail, :145
     if constexpr (SRC == SRC_BITS) {
         // search.cpp:408-423: LSB-first bits, lo_sin = {1,1,0,0}, lo_cos = {1,0,0,1},
         // lo_phase advances by exactly 1.0 per sample.  :168-175: 1 -> -1.0, 0 -> +1.0.
@@ -96,27 +103,28 @@ KG_DEV cf hb_tap(const float2 *x)
 
 template <int SRC>
 __global__ __launch_bounds__(256) void acq_frontend_kernel(const uint8_t *__restrict__ src,
-                                                          size_t src_stride, int nchips, int boc,
-                                                          float2 *__restrict__ td)
+                                                          size_t src_stride, int nvalid, int nchips, int boc,
+                                                          float2 *__restrict__ td, int fft_len)
 {
     __shared__ float2 xs[FE_NX + 1];
     __shared__ float2 y1[FE_NY1 + 1];
     const int tid = threadIdx.x;
     const int o0 = blockIdx.x * FE_TILE;
     const void *s = src + (size_t) blockIdx.y * src_stride;
-    for (int u = tid; u < FE_NX; u += 256) kg_st(&xs[u], acq_source<SRC>(s, 4 * o0 + u, nchips, boc));
+    for (int u = tid; u < FE_NX; u += 256) kg_st(&xs[u], acq_source<SRC>(s, 4 * o0 + u, nvalid, nchips, boc));
     __syncthreads();
     for (int u = tid; u < FE_NY1; u += 256) kg_st(&y1[u], hb_tap(&xs[2 * u]));
     __syncthreads();
-    kg_st(&td[(size_t) blockIdx.y * FFT_LEN + o0 + tid], hb_tap(&y1[2 * tid]));
+    kg_st(&td[(size_t) blockIdx.y * fft_len + o0 + tid], hb_tap(&y1[2 * tid]));
 }
 
 // ---------------------------------------------------------------------------
-// Forward 16384-point FFT, natural time order in -> residue-major spectrum out.
-// Two launches (both latency-bound, so the work is spread over many CUs):
-//   acq_fft_sub_kernel      4 workgroups per transform; workgroup g transforms the
-//                           samples n = 4*n1 + g (4096 points) -> F_g in scratch
-//   acq_fft_combine_kernel  radix-4 across g with W_N^{-k*g}, writes the planes
+// Forward N-point FFT (N = P * 4096), natural time order in -> residue-major
+// spectrum out.  Two launches (both latency-bound, so the work is spread over
+// many CUs):
+//   acq_fft_sub_kernel      P workgroups per transform; workgroup g transforms the
+//                           samples n = P*n1 + g (4096 points) -> F_g in scratch
+//   acq_fft_combine_kernel  radix-P across g with W_N^{-k*g}, writes the planes
 // ---------------------------------------------------------------------------
 #define STAMP(i)                                                                      \
     do {                                                                              \
@@ -132,18 +140,18 @@ __global__ __launch_bounds__(256) void acq_frontend_kernel(const uint8_t *__rest
 // launches the STAMPS = false kernels, in which no stamp code exists.
 template <bool STAMPS>
 __global__ __launch_bounds__(256) void acq_fft_sub_kernel(const float2 *__restrict__ td,
-                                                         float2 *__restrict__ scratch,   // [batch][4][4096]
-                                                         const float2 *__restrict__ tab4096,
+                                                         float2 *__restrict__ scratch,   // [batch][P][4096]
+                                                         const float2 *__restrict__ tab4096, int P,
                                                          unsigned long long *__restrict__ stamps)
 {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];   // 2 x 4096
     const int t = threadIdx.x, g = blockIdx.x;
-    const float2 *in = td + (size_t) blockIdx.y * FFT_LEN;
-    float2 *out = scratch + ((size_t) blockIdx.y * 4 + g) * SUB;
+    const float2 *in = td + (size_t) blockIdx.y * P * SUB;
+    float2 *out = scratch + ((size_t) blockIdx.y * P + g) * SUB;
     STAMP(0);
     cf x[16], y[16];
 #pragma unroll
-    for (int j = 0; j < 16; j++) x[j] = kg_ld(&in[4 * (t + 256 * j) + g]);
+    for (int j = 0; j < 16; j++) x[j] = kg_ld(&in[P * (t + 256 * j) + g]);
     kg_tw4096 tw;
     kg_tw4096_load(tw, tab4096, t);
     if (STAMPS) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -156,28 +164,37 @@ __global__ __launch_bounds__(256) void acq_fft_sub_kernel(const float2 *__restri
     STAMP(3);
 }
 
+template <int P>
 __global__ __launch_bounds__(256) void acq_fft_combine_kernel(const float2 *__restrict__ scratch,
                                                              float2 *__restrict__ planes,
                                                              size_t planes_stride,   // in float2
-                                                             const float2 *__restrict__ tab16384,
+                                                             const float2 *__restrict__ tabN,
                                                              int halo)               // H: 0 data, >0 code
 {
+    static_assert(P == 4 || P == 16, "N = 16384 or 65536");
     const int k = blockIdx.x * 256 + threadIdx.x;      // k' < 4096
-    const float2 *f = scratch + (size_t) blockIdx.y * FFT_LEN;
+    const float2 *f = scratch + (size_t) blockIdx.y * (P * SUB);
     float2 *out = planes + (size_t) blockIdx.y * planes_stride;
-    cf f0 = kg_ld(&f[k]), f1 = kg_ld(&f[SUB + k]), f2 = kg_ld(&f[2 * SUB + k]), f3 = kg_ld(&f[3 * SUB + k]);
-    f1 = kg_cmulc(f1, kg_ld(&tab16384[k]));            // W_N^{-k*n2}
-    f2 = kg_cmulc(f2, kg_ld(&tab16384[2 * k]));
-    f3 = kg_cmulc(f3, kg_ld(&tab16384[3 * k]));
-    kg_radix4<-1>(f0, f1, f2, f3);                     // X[k + 4096 q], q = 0..3
-    // bin k + 4096 q -> plane k & 3, element k1 = (k >> 2) + 1024 q = tt + 256 j
-    const int row = 2 * (256 + 2 * halo), plane = 8 * row;
-    float2 *o = out + (size_t) (k & 3) * plane;
-    const int tt = (k >> 2) & 255, j0 = k >> 10;       // j = j0 + 4 q
-    const cf fq[4] = {f0, f1, f2, f3};
+    cf v[P];
+    v[0] = kg_ld(&f[k]);
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int j = j0 + 4 * q;
+    for (int g = 1; g < P; g++) v[g] = kg_cmulc(kg_ld(&f[g * SUB + k]), kg_ld(&tabN[g * k]));   // W_N^{-k*g}
+    // X[k + 4096 q], q = 0..P-1
+    cf fq[P];
+    if constexpr (P == 4) {
+        kg_radix4<-1>(v[0], v[1], v[2], v[3]);
+#pragma unroll
+        for (int q = 0; q < 4; q++) fq[q] = v[q];
+    } else {
+        kg_radix16<-1>(v, fq);
+    }
+    // bin k + 4096 q -> plane k & (P-1), element k1 = k / P + (4096 / P) q = tt + 256 j
+    const int row = 2 * (256 + 2 * halo), plane = 8 * row;
+    float2 *o = out + (size_t) (k & (P - 1)) * plane;
+#pragma unroll
+    for (int q = 0; q < P; q++) {
+        const int k1 = k / P + (SUB / P) * q;
+        const int tt = k1 & 255, j = k1 >> 8;
         kg_st(&o[(j >> 1) * row + 2 * (tt + halo) + (j & 1)], fq[q]);
         if (tt < halo) {                               // also the right halo of leg j-1
             const int jj = (j - 1) & 15;
@@ -198,39 +215,50 @@ struct acq_red { float p; int i; float s; int pad; };
 
 #define ACQ_LDS_BYTES (2 * SUB * sizeof(float2) + 4 * sizeof(acq_red))
 
-// The wave-uniform half of the combine twiddle W_N^{n*k2}, n = t + 256 m:
-// W_N^{256 m k2} = W_64^{m k2} and, with m = 4a + b, = W_64^{4a k2} * W_64^{b k2}.
-// Row k2: { W_64^{k2}, W_64^{2 k2}, W_64^{3 k2}, W_64^{4 k2}, W_64^{8 k2}, W_64^{12 k2} }.
-#define W64(k) {KG_W64[(k) & 63][0], KG_W64[(k) & 63][1]}
-#define W64ROW(k2) { W64(1*k2), W64(2*k2), W64(3*k2), W64(4*k2), W64(8*k2), W64(12*k2), W64(0), W64(0) }
-__constant__ float2 c_comb6[4][8] = { W64ROW(0), W64ROW(1), W64ROW(2), W64ROW(3) };
-#undef W64ROW
-#undef W64
-
-// One (block, SV, Doppler) cell, prepared by the host (build_cell_table): the
-// kernel never divides or chases index lists.  32 bytes = one s_load_dwordx8.
-struct acq_cell_desc {
+// One (block, SV) pair, prepared by the host: 16 bytes = one s_load_dwordx4.  The
+// cells of a launch are the pairs x the Doppler bins; the kernel walks (pair, bin)
+// with two additions per step (no division, no index lists).
+struct acq_pair_desc {
     int data_off;     // float2 offset of the block's data spectrum
     int code_off;     // float2 offset of the SV's code spectrum
-    int dop;          // Doppler bin
     int limit;        // peak-search window (search.cpp:486)
-    int out;          // index into cells[]
-    int pad[3];
+    int out;          // index of the pair's first cell in cells[]
+};
+
+struct acq_cell_desc { int data_off, code_off, dop, limit, out; };
+
+// Launch constants (kernarg): the Doppler range and how a persistent workgroup steps
+// through its XCD group's cells (cell = pair_in_group * ndop + bin).
+struct acq_walk {
+    int npairs;       // pairs in this launch's table
+    int ndop, dop_lo;
+    int step_pairs;   // nslots / ndop
+    int step_bins;    // nslots % ndop
 };
 
 // Work item = (cell, k2): one 4096-point sub-transform.  The operands of the
 // NEXT item are loaded while the current one is transformed (PREFETCH).
-template <int NQ, bool PREFETCH, bool STAMPS = false>
+//
+// Wave-uniform constants of the combine twiddle W_N^{n*k2}, n = t + 256 m:
+// W_N^{256 m k2} = W_R^{m k2} with R = N / 256 and, with m = 4a + b,
+// = W_R^{4a k2} * W_R^{b k2}.  comb[k2] = { W_R^{k2}, W_R^{2 k2}, W_R^{3 k2},
+// W_R^{4 k2}, W_R^{8 k2}, W_R^{12 k2}, -, - } (host-built, fp32 roundings of double
+// values); quart[k2][q] = W_P^{q k2}: the factor of output quarter q (NQ = 4).
+template <int P, int NQ, bool PREFETCH, bool STAMPS = false>
 __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
-    const float2 *__restrict__ data,  // [nblocks][4][4096]
-    const float2 *__restrict__ code,  // [max_sats][4][4096]
-    const float2 *__restrict__ tab4096, const float2 *__restrict__ tab16384,
-    const acq_cell_desc *__restrict__ table,   // cells grouped by XCD label
-    const int *__restrict__ xcd_start,         // [9] first cell of each group (+ end)
+    const float2 *__restrict__ data,  // [nblocks][P][4096]
+    const float2 *__restrict__ code,  // [max_sats][P][8 rows][2 (256 + 2 H)]
+    const float2 *__restrict__ tab4096, const float2 *__restrict__ tabN,
+    const float2 *__restrict__ comb,           // [P][8]
+    const float2 *__restrict__ quart,          // [P][4]
+    const acq_pair_desc *__restrict__ pairs,   // pair p belongs to XCD group p & 7
+    acq_walk walk,
     int halo,                                  // H of the code planes
     kg_acq_cell *__restrict__ cells,           // [nblocks][nsats][ndop]
     unsigned long long *__restrict__ stamps = nullptr)
 {
+    static_assert(P == 4 || P == 16, "N = 16384 or 65536");
+    constexpr int LOGP = P == 4 ? 2 : 4;
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     float2 *tileA = smem, *tileB = smem + SUB;
     acq_red *red = (acq_red *) (smem + 2 * SUB);
@@ -245,9 +273,9 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
     // XCD-aware: workgroups b and b+8 share an XCD (round-robin dispatch), so the
     // cells of one (block, SV) pair -- one code spectrum -- all belong to one
     // group and that spectrum stays in one L2.  Speed only, never correctness.
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
-    const int first = xcd_start[xcd], ncell = xcd_start[xcd + 1] - first;
-    const acq_cell_desc *tab = table + first;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int gpairs = (walk.npairs - xcd + 7) >> 3;           // pairs xcd, xcd + 8, ...
+    const int ndop = walk.ndop;
 
     // Operand fetch: eight 16-byte buffer loads per spectrum.  The descriptor
     // (SGPRs) carries the plane base, soffset the row, voffset the lane column:
@@ -258,11 +286,11 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
     cf d[16], c[16];
     auto fetch = [&](int data_off, int code_off, int dop, int k2) {
         const int s = k2 - dop;
-        const int q0 = s >> 2;                         // floor((k2 - dop) / 4)
+        const int q0 = s >> LOGP;                      // floor((k2 - dop) / P)
         const auto drs = __builtin_amdgcn_make_buffer_rsrc(
             (void *) (data + data_off + k2 * SUB), 0, SUB * (int) sizeof(float2), 0x00020000);
         const auto crs = __builtin_amdgcn_make_buffer_rsrc(
-            (void *) (code + code_off + (s & 3) * plane_c), 0, plane_c * (int) sizeof(float2), 0x00020000);
+            (void *) (code + code_off + (s & (P - 1)) * plane_c), 0, plane_c * (int) sizeof(float2), 0x00020000);
         const int dvo = t * 16, cvo = (t + q0 + halo) * 16;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -274,43 +302,57 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
             c[2 * i + 1] = cf{__uint_as_float(cv[2]), __uint_as_float(cv[3])};
         }
     };
+    // (pair in group, bin) -> descriptor; one s_load_dwordx4
+    auto describe = [&](int pg, int di) {
+        const acq_pair_desc pd = pairs[(pg << 3) + xcd];
+        return acq_cell_desc{pd.data_off, pd.code_off, walk.dop_lo + di, pd.limit, pd.out + di};
+    };
 
-    if (slot >= ncell) return;
-    acq_cell_desc cur = tab[slot];
+    int pg = slot / ndop, di = slot - pg * ndop;       // once per workgroup
+    if (pg >= gpairs) return;
+    acq_cell_desc cur = describe(pg, di);
     if (PREFETCH) fetch(cur.data_off, cur.code_off, cur.dop, 0);
 
     int st_item = 0;
-    for (int lc = slot; lc < ncell; lc += nslots) {
-        const bool more = lc + nslots < ncell;
-        const acq_cell_desc nxt = tab[more ? lc + nslots : lc];   // one cell ahead
+    for (;;) {
+        // one cell ahead
+        int npg = pg + walk.step_pairs, ndi = di + walk.step_bins;
+        if (ndi >= ndop) { ndi -= ndop; npg++; }
+        const bool more = npg < gpairs;
+        const acq_cell_desc nxt = describe(more ? npg : pg, more ? ndi : di);
         cf acc[NQ][16];
         // rolled on purpose: unrolled (or with k2 a template constant) the
         // register allocator spills 80+ VGPRs
 #pragma unroll 1
-        for (int k2 = 0; k2 < 4; k2++) {
+        for (int k2 = 0; k2 < P; k2++) {
             unsigned long long *sti = (STAMPS && st && st_item < 24) ? st + 16 + 16 * st_item : nullptr;
             KG_STAMP(STAMPS, sti, 8);
             if (!PREFETCH) fetch(cur.data_off, cur.code_off, cur.dop, k2);
-            const cf base = kg_ld(&tab16384[t * k2]);          // W_N^{t*k2}, used after the transform
+            const cf base = kg_ld(&tabN[t * k2]);              // W_N^{t*k2}, used after the transform
             cf x[16], y[16];
             // conj(data) * code, simd_multiply_conjugate_ccc (support/simd.cpp:39-67)
 #pragma unroll
             for (int j = 0; j < 16; j++) x[j] = kg_cmulc(c[j], d[j]);
             KG_STAMP(STAMPS, sti, 9);
-            if (PREFETCH && (k2 < 3 || more)) {        // one load site: (cur, k2+1) or (nxt, 0)
-                const bool same = k2 < 3;
+            if (PREFETCH && (k2 < P - 1 || more)) {    // one load site: (cur, k2+1) or (nxt, 0)
+                const bool same = k2 < P - 1;
                 fetch(same ? cur.data_off : nxt.data_off, same ? cur.code_off : nxt.code_off,
-                      same ? cur.dop : nxt.dop, (k2 + 1) & 3);
+                      same ? cur.dop : nxt.dop, (k2 + 1) & (P - 1));
             }
             KG_STAMP(STAMPS, sti, 10);
             kg_subfft4096_a<+1, STAMPS>(x, y, tileA, tileB, tw, t, sti);
-            // six wave-uniform constants (s_load), hidden behind pass 2
-            cf g[3], G[3];
+            // wave-uniform constants (s_load), hidden behind pass 2
+            cf g[3], G[3], Q[3];
+            (void) Q;
 #pragma unroll
-            for (int i = 0; i < 3; i++) { g[i] = kg_ld(&c_comb6[k2][i]); G[i] = kg_ld(&c_comb6[k2][3 + i]); }
+            for (int i = 0; i < 3; i++) { g[i] = kg_ld(&comb[8 * k2 + i]); G[i] = kg_ld(&comb[8 * k2 + 3 + i]); }
+            if constexpr (NQ == 4 && P != 4) {
+#pragma unroll
+                for (int q = 1; q < 4; q++) Q[q - 1] = kg_ld(&quart[4 * k2 + q]);
+            }
             kg_subfft4096_b<+1, STAMPS>(x, y, tileB, tw, t, sti);
-            // acc_q[n'] += y[n'] * W_N^{n'*k2} * j^{q*k2},  n' = t + 256 m, m = 4a + b:
-            // W_N^{n'*k2} = (W_N^{t*k2} * W_64^{4a*k2}) * W_64^{b*k2}
+            // acc_q[n'] += y[n'] * W_N^{n'*k2} * W_P^{q*k2},  n' = t + 256 m, m = 4a + b:
+            // W_N^{n'*k2} = (W_N^{t*k2} * W_R^{4a*k2}) * W_R^{b*k2}
             if (k2 == 0) {
 #pragma unroll
                 for (int q = 0; q < NQ; q++)
@@ -327,7 +369,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
                     if ((m & 3) != 0) z = kg_cmul_s(z, g[(m & 3) - 1]);
                     z = kg_cmul(z, B[m >> 2]);
                     acc[0][m] = acc[0][m] + z;
-                    if constexpr (NQ == 4) {           // quarters 1..3: times j^(q*k2), wave-uniform
+                    if constexpr (NQ == 4 && P == 4) {    // quarters 1..3: times j^(q*k2), wave-uniform
                         if (k2 == 1) {
                             acc[1][m] = kg_addj(acc[1][m], z); acc[2][m] = acc[2][m] - z;
                             acc[3][m] = kg_subj(acc[3][m], z);
@@ -338,6 +380,9 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
                             acc[1][m] = kg_subj(acc[1][m], z); acc[2][m] = acc[2][m] - z;
                             acc[3][m] = kg_addj(acc[3][m], z);
                         }
+                    } else if constexpr (NQ == 4) {       // times W_16^(q*k2), wave-uniform
+#pragma unroll
+                        for (int q = 1; q < 4; q++) acc[q][m] = acc[q][m] + kg_cmul_s(z, Q[q - 1]);
                     }
                 }
             }
@@ -370,7 +415,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
             sum += os;                                                                   \
         }
         ACQ_RED_STEP(0) ACQ_RED_STEP(1) ACQ_RED_STEP(2) ACQ_RED_STEP(3) ACQ_RED_STEP(4) ACQ_RED_STEP(5)
-        // red[] was last read before this cell's eight barriers
+        // red[] was last read before this cell's barriers
         if ((t & 63) == 0) { red[t >> 6].p = bp; red[t >> 6].i = bi; red[t >> 6].s = sum; }
         __syncthreads();
         if (t < 64) {                                  // lanes 0..3 of wave 0 merge the four waves
@@ -386,7 +431,8 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
             }
         }
 #undef ACQ_RED_STEP
-        cur = nxt;
+        if (!more) break;
+        cur = nxt; pg = npg; di = ndi;
     }
     if (STAMPS && st) { st[2] = __builtin_amdgcn_s_memtime(); st[3] = __builtin_amdgcn_s_memrealtime(); }
 }
@@ -428,15 +474,24 @@ __global__ __launch_bounds__(64) void acq_select_kernel(const kg_acq_cell *__res
 struct kg_acq {
     kg_ctx *ctx;
     int max_sats, dop_lo, dop_hi, ndop, max_blocks;
-    int halo;          // H of the code planes: covers every floor((k2 - dop) / 4)
-    size_t code_len;   // float2 per code spectrum (4 planes with halo)
-    float2 *d_code;        // [max_sats][4][4096]
-    float2 *d_data;        // [max_blocks][4][4096]
-    float2 *d_td;          // [max_blocks][16384]  decimated time-domain samples per block
-    float2 *d_td_code;     // [16384]              same, for the code-table build
-    float2 *d_fsub;        // [max_blocks][4][4096] sub-transforms awaiting the radix-4 combine
-    float2 *d_fsub_code;   // [4][4096]
-    uint8_t *d_in;     // [max_blocks][NSAMPLES*4]    host-input staging
+    // shape (see the head of this file)
+    int nsamples;      // input samples per block that carry signal (<= 4 * fft_len)
+    int fft_len;       // N
+    int P;             // N / 4096: 4 or 16
+    size_t in_stride;  // bytes of one block of int16 IQ staging: nsamples * 4
+    int halo;          // H of the code planes: covers every floor((k2 - dop) / P)
+    size_t code_len;   // float2 per code spectrum (P planes with halo)
+    float2 *d_tabN;        // exp(+2 pi i k / N); the context's table for N = 16384
+    bool own_tabN;
+    float2 *d_comb;        // [P][8]  combine constants (acq_correlate_kernel)
+    float2 *d_quart;       // [P][4]
+    float2 *d_code;        // [max_sats][P planes with halo]
+    float2 *d_data;        // [max_blocks][P][4096]
+    float2 *d_td;          // [max_blocks][N]  decimated time-domain samples per block
+    float2 *d_td_code;     // [N]              same, for the code-table build
+    float2 *d_fsub;        // [max_blocks][P][4096] sub-transforms awaiting the radix-P combine
+    float2 *d_fsub_code;   // [P][4096]
+    uint8_t *d_in;     // [max_blocks][in_stride]    host-input staging
     // Host-buffer Sample() calls return before the copy has run ("enqueue only"), so the
     // caller's samples are first copied into one of a few pinned slots; a slot is reused
     // once the event recorded behind its copy has fired.
@@ -449,15 +504,15 @@ struct kg_acq {
     // correlation: ev_batch = transfer done, ev_in_free = the staging area has been consumed
     hipStream_t cstream; hipEvent_t ev_in_free; bool in_free_set;
     uint8_t *d_chips;  // [E1B_CODELEN max]
-    int *d_limits;     // [max_sats]
-    acq_cell_desc *d_table1, *d_table4;   // cell tables of the C/A and E1B launches
-    int *d_xcd1, *d_xcd4;                 // [9] group starts
-    size_t table_cap;
     kg_acq_cell *d_cells;
     kg_acq_result *d_results;
     std::vector<int> limits, code_set;
+    // The (block, SV) pair tables of the last launch live in a slot of the context's staging
+    // ring; they are reused while the SV list is unchanged and the slot has not come round.
     std::vector<int> last_sats;
-    int last_first, last_nblocks, last_nsats, nsel1, nsel4, table_nblocks;
+    const acq_pair_desc *d_pairs1, *d_pairs4;   // 4092-window (C/A) and 16368-window (E1B) launches
+    unsigned long pairs_seq;                    // ring position when they were staged
+    int last_first, last_nblocks, last_nsats, np1, np4, table_nblocks;
     // Stream of the Sample() work: the context's stream, or (opt-in) a second one ordered
     // against it by events.
     hipStream_t fstream;
@@ -471,107 +526,124 @@ struct kg_acq {
     int grid1, grid4;
 };
 
-static const size_t IN_STRIDE = (size_t) NSAMPLES * 4;     // bytes per block of staging
-
 // Host mirror of the plane layout (see the head of this file).
 static inline size_t plane_pos(int k1, int halo_col, int H)
 {
     const int t = k1 & 255, j = k1 >> 8, row = 2 * (256 + 2 * H);
     return (size_t) (j >> 1) * row + 2 * (t + halo_col + H) + (j & 1);
 }
-static inline size_t spec_len(int H) { return (size_t) 4 * 8 * 2 * (256 + 2 * H); }
+static inline size_t spec_len(int P, int H) { return (size_t) P * 8 * 2 * (256 + 2 * H); }
 
-static void to_planes(const float *nat, std::vector<float2> &pl, int H)
+static void to_planes(const float *nat, std::vector<float2> &pl, int P, int H)
 {
-    const size_t plane = spec_len(H) / 4;
-    pl.assign(spec_len(H), make_float2(0.f, 0.f));
-    for (int k = 0; k < FFT_LEN; k++) {
+    const size_t plane = spec_len(P, H) / P;
+    pl.assign(spec_len(P, H), make_float2(0.f, 0.f));
+    for (int k = 0; k < P * SUB; k++) {
         const float2 v = make_float2(nat[2 * k], nat[2 * k + 1]);
-        const int k1 = k >> 2, t = k1 & 255, j = k1 >> 8;
-        float2 *p = pl.data() + (size_t) (k & 3) * plane;
+        const int k1 = k / P, t = k1 & 255, j = k1 >> 8;
+        float2 *p = pl.data() + (size_t) (k % P) * plane;
         p[plane_pos(k1, 0, H)] = v;
         if (t < H) p[plane_pos(t + 256 * ((j - 1) & 15), 256, H)] = v;
         if (t >= 256 - H) p[plane_pos(t + 256 * ((j + 1) & 15), -256, H)] = v;
     }
 }
-static void from_planes(const std::vector<float2> &pl, float *nat, int H)
+static void from_planes(const std::vector<float2> &pl, float *nat, int P, int H)
 {
-    const size_t plane = spec_len(H) / 4;
-    for (int k = 0; k < FFT_LEN; k++) {
-        const float2 v = pl[(size_t) (k & 3) * plane + plane_pos(k >> 2, 0, H)];
+    const size_t plane = spec_len(P, H) / P;
+    for (int k = 0; k < P * SUB; k++) {
+        const float2 v = pl[(size_t) (k % P) * plane + plane_pos(k / P, 0, H)];
         nat[2 * k] = v.x; nat[2 * k + 1] = v.y;
     }
 }
 
+// exp(+2 pi i k / n) in double, rounded to fp32, exact on the axes (as kg_ctx's tables).
+static float2 unit_root(long k, long n)
+{
+    k %= n;
+    if (k < 0) k += n;
+    if (k == 0) return make_float2(1.f, 0.f);
+    if (4 * k == n) return make_float2(0.f, 1.f);
+    if (2 * k == n) return make_float2(-1.f, 0.f);
+    if (4 * k == 3 * n) return make_float2(0.f, -1.f);
+    const double a = 2.0 * M_PI * (double) k / (double) n;
+    return make_float2((float) cos(a), (float) sin(a));
+}
+
 template <int SRC>
 static int launch_frontend(kg_acq *a, hipStream_t st, const uint8_t *d_src, size_t stride, int nbatch,
-                           int nchips, int boc, float2 *d_td, float2 *d_scratch, float2 *d_planes,
-                           size_t planes_stride, int halo)
+                           int nvalid, int nchips, int boc, float2 *d_td, float2 *d_scratch,
+                           float2 *d_planes, size_t planes_stride, int halo)
 {
     kg_ctx *c = a->ctx;
-    hipLaunchKernelGGL(acq_frontend_kernel<SRC>, dim3(FFT_LEN / FE_TILE, nbatch), dim3(256), 0,
-                       st, d_src, stride, nchips, boc, d_td);
+    hipLaunchKernelGGL(acq_frontend_kernel<SRC>, dim3(a->fft_len / FE_TILE, nbatch), dim3(256), 0,
+                       st, d_src, stride, nvalid, nchips, boc, d_td, a->fft_len);
     KG_HIP(hipGetLastError());
-    hipLaunchKernelGGL(acq_fft_sub_kernel<false>, dim3(4, nbatch), dim3(256), 2 * SUB * sizeof(float2),
-                       st, (const float2 *) d_td, d_scratch, (const float2 *) c->d_tab4096,
+    hipLaunchKernelGGL(acq_fft_sub_kernel<false>, dim3(a->P, nbatch), dim3(256), 2 * SUB * sizeof(float2),
+                       st, (const float2 *) d_td, d_scratch, (const float2 *) c->d_tab4096, a->P,
                        (unsigned long long *) nullptr);
     KG_HIP(hipGetLastError());
-    hipLaunchKernelGGL(acq_fft_combine_kernel, dim3(SUB / 256, nbatch), dim3(256), 0, st,
-                       (const float2 *) d_scratch, d_planes, planes_stride,
-                       (const float2 *) c->d_tab16384, halo);
+    if (a->P == 4)
+        hipLaunchKernelGGL(acq_fft_combine_kernel<4>, dim3(SUB / 256, nbatch), dim3(256), 0, st,
+                           (const float2 *) d_scratch, d_planes, planes_stride,
+                           (const float2 *) a->d_tabN, halo);
+    else
+        hipLaunchKernelGGL(acq_fft_combine_kernel<16>, dim3(SUB / 256, nbatch), dim3(256), 0, st,
+                           (const float2 *) d_scratch, d_planes, planes_stride,
+                           (const float2 *) a->d_tabN, halo);
     KG_HIP(hipGetLastError());
     return KG_OK;
 }
 
-extern "C" {
-
-int kg_acq_create(kg_ctx *ctx, int max_sats, int dop_lo, int dop_hi, int max_blocks, kg_acq **out)
+static int acq_init(kg_acq *a)
 {
-    int rc = kg_ctx_use(ctx);
-    if (rc) return rc;
-    KG_REQUIRE(out != nullptr, KG_ERR_INVALID, "kg_acq_create: out is null");
-    *out = nullptr;
-    KG_REQUIRE(max_sats >= 1 && max_sats <= 4096, KG_ERR_INVALID, "kg_acq_create: max_sats %d", max_sats);
-    KG_REQUIRE(dop_lo <= dop_hi && dop_lo >= -1000 && dop_hi <= 1000, KG_ERR_INVALID,
-               "kg_acq_create: Doppler range %d..%d (supported: within -1000..1000)", dop_lo, dop_hi);
-    KG_REQUIRE(max_blocks >= 1 && max_blocks <= 65535, KG_ERR_INVALID, "kg_acq_create: max_blocks %d",
-               max_blocks);
-    kg_acq *a = new (std::nothrow) kg_acq();
-    KG_REQUIRE(a != nullptr, KG_ERR_NOMEM, "kg_acq_create: alloc");
-    a->ctx = ctx; a->max_sats = max_sats; a->dop_lo = dop_lo; a->dop_hi = dop_hi;
-    a->ndop = dop_hi - dop_lo + 1; a->max_blocks = max_blocks;
+    kg_ctx *ctx = a->ctx;
+    const int max_sats = a->max_sats, max_blocks = a->max_blocks, N = a->fft_len, P = a->P;
     {
-        const int m = (dop_hi > -dop_lo ? dop_hi : -dop_lo);
-        a->halo = (m + 3) / 4 + 2;
-        a->code_len = spec_len(a->halo);
+        const int m = (a->dop_hi > -a->dop_lo ? a->dop_hi : -a->dop_lo);
+        a->halo = (m + P - 1) / P + 2;
+        a->code_len = spec_len(P, a->halo);
     }
     a->limits.assign(max_sats, 0); a->code_set.assign(max_sats, 0);
-    a->last_first = a->last_nblocks = a->last_nsats = a->nsel1 = a->nsel4 = a->table_nblocks = 0;
-    const size_t spec = sizeof(float2) * FFT_LEN;
+    a->last_first = a->last_nblocks = a->last_nsats = a->np1 = a->np4 = a->table_nblocks = 0;
+    a->d_pairs1 = a->d_pairs4 = nullptr; a->pairs_seq = 0;
+    a->in_stride = (size_t) a->nsamples * 4;
+    const size_t spec = sizeof(float2) * N;
+    if (N == 16384) { a->d_tabN = ctx->d_tab16384; a->own_tabN = false; }
+    else {
+        std::vector<float2> h(N);
+        for (int k = 0; k < N; k++) h[k] = unit_root(k, N);
+        KG_HIP(hipMalloc((void **) &a->d_tabN, spec));
+        a->own_tabN = true;
+        KG_HIP(hipMemcpy(a->d_tabN, h.data(), spec, hipMemcpyHostToDevice));
+    }
+    {
+        const long R = N / 256;
+        std::vector<float2> comb(P * 8, make_float2(1.f, 0.f)), quart(P * 4);
+        static const int mult[6] = {1, 2, 3, 4, 8, 12};
+        for (int k2 = 0; k2 < P; k2++) {
+            for (int i = 0; i < 6; i++) comb[8 * k2 + i] = unit_root((long) mult[i] * k2, R);
+            for (int q = 0; q < 4; q++) quart[4 * k2 + q] = unit_root((long) q * k2, P);
+        }
+        KG_HIP(hipMalloc((void **) &a->d_comb, sizeof(float2) * comb.size()));
+        KG_HIP(hipMalloc((void **) &a->d_quart, sizeof(float2) * quart.size()));
+        KG_HIP(hipMemcpy(a->d_comb, comb.data(), sizeof(float2) * comb.size(), hipMemcpyHostToDevice));
+        KG_HIP(hipMemcpy(a->d_quart, quart.data(), sizeof(float2) * quart.size(), hipMemcpyHostToDevice));
+    }
     KG_HIP(hipMalloc((void **) &a->d_code, sizeof(float2) * a->code_len * max_sats));
     KG_HIP(hipMalloc((void **) &a->d_data, spec * max_blocks));
     KG_HIP(hipMalloc((void **) &a->d_td, spec * max_blocks));
     KG_HIP(hipMalloc((void **) &a->d_td_code, spec));
     KG_HIP(hipMalloc((void **) &a->d_fsub, spec * max_blocks));
     KG_HIP(hipMalloc((void **) &a->d_fsub_code, spec));
-    KG_HIP(hipMalloc((void **) &a->d_in, IN_STRIDE * max_blocks));
+    KG_HIP(hipMalloc((void **) &a->d_in, a->in_stride * max_blocks));
     for (int k = 0; k < 4; k++) {
-        KG_HIP(hipHostMalloc((void **) &a->h_pin[k], IN_STRIDE, hipHostMallocDefault));
+        KG_HIP(hipHostMalloc((void **) &a->h_pin[k], a->in_stride, hipHostMallocDefault));
         KG_HIP(hipEventCreateWithFlags(&a->ev_pin[k], hipEventDisableTiming));
     }
-    a->pin_next = 0;
-    a->h_batch = nullptr; a->batch_cap = 0;
     KG_HIP(hipEventCreateWithFlags(&a->ev_batch, hipEventDisableTiming));
     KG_HIP(hipEventCreateWithFlags(&a->ev_in_free, hipEventDisableTiming));
     KG_HIP(hipStreamCreateWithFlags(&a->cstream, hipStreamNonBlocking));
-    a->in_free_set = false;
     KG_HIP(hipMalloc((void **) &a->d_chips, 8192));
-    KG_HIP(hipMalloc((void **) &a->d_limits, sizeof(int) * max_sats));
-    a->table_cap = (size_t) max_blocks * max_sats * a->ndop;
-    KG_HIP(hipMalloc((void **) &a->d_table1, sizeof(acq_cell_desc) * a->table_cap));
-    KG_HIP(hipMalloc((void **) &a->d_table4, sizeof(acq_cell_desc) * a->table_cap));
-    KG_HIP(hipMalloc((void **) &a->d_xcd1, sizeof(int) * 9));
-    KG_HIP(hipMalloc((void **) &a->d_xcd4, sizeof(int) * 9));
     KG_HIP(hipMalloc((void **) &a->d_cells, sizeof(kg_acq_cell) * (size_t) max_blocks * max_sats * a->ndop));
     KG_HIP(hipMalloc((void **) &a->d_results, sizeof(kg_acq_result) * (size_t) max_blocks * max_sats));
     {
@@ -582,17 +654,20 @@ int kg_acq_create(kg_ctx *ctx, int max_sats, int dop_lo, int dop_hi, int max_blo
         // spend its first pass at one workgroup per CU (16 blocks per step: 887 us against
         // 528 us in order; profiles/r01_streams.txt), so the overlap is opt-in.
         const char *e = getenv("KIWIGPU_ACQ_FRONT_STREAM");
-        a->own_fstream = e && e[0] == '1';
-        if (a->own_fstream) KG_HIP(hipStreamCreateWithFlags(&a->fstream, hipStreamNonBlocking));
-        else a->fstream = ctx->stream;
+        if (e && e[0] == '1') {
+            KG_HIP(hipStreamCreateWithFlags(&a->fstream, hipStreamNonBlocking));
+            a->own_fstream = true;
+        }
     }
-    a->ev_ready.resize(max_blocks); a->ev_done.resize(max_blocks);
     a->ready_of.assign(max_blocks, -1); a->done_of.assign(max_blocks, -1);
+    a->ev_ready.reserve(max_blocks); a->ev_done.reserve(max_blocks);
     for (int b = 0; b < max_blocks; b++) {
-        KG_HIP(hipEventCreateWithFlags(&a->ev_ready[b], hipEventDisableTiming));
-        KG_HIP(hipEventCreateWithFlags(&a->ev_done[b], hipEventDisableTiming));
+        hipEvent_t e1, e2;
+        KG_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+        a->ev_ready.push_back(e1);
+        KG_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+        a->ev_done.push_back(e2);
     }
-    KG_HIP(hipMemset(a->d_limits, 0, sizeof(int) * max_sats));
     KG_HIP(hipMemset(a->d_data, 0, spec * max_blocks));
     KG_HIP(hipFuncSetAttribute((const void *) acq_fft_sub_kernel<false>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SUB * sizeof(float2)));
@@ -600,43 +675,89 @@ int kg_acq_create(kg_ctx *ctx, int max_sats, int dop_lo, int dop_hi, int max_blo
                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SUB * sizeof(float2)));
     // persistent grid: resident workgroups per CU x CUs, rounded to a multiple of 8 (XCDs)
     int occ1 = 0, occ4 = 0;
-    KG_HIP(hipFuncSetAttribute((const void *) acq_correlate_kernel<1, true>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, ACQ_LDS_BYTES));
-    KG_HIP(hipFuncSetAttribute((const void *) acq_correlate_kernel<4, true>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, ACQ_LDS_BYTES));
-    KG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ1, acq_correlate_kernel<1, true>, 256, ACQ_LDS_BYTES));
-    KG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ4, acq_correlate_kernel<4, true>, 256, ACQ_LDS_BYTES));
+#define ACQ_SETUP(PP)                                                                                          \
+    KG_HIP(hipFuncSetAttribute((const void *) acq_correlate_kernel<PP, 1, true>,                              \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, ACQ_LDS_BYTES));                   \
+    KG_HIP(hipFuncSetAttribute((const void *) acq_correlate_kernel<PP, 4, true>,                              \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, ACQ_LDS_BYTES));                   \
+    KG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ1, acq_correlate_kernel<PP, 1, true>, 256,        \
+                                                        ACQ_LDS_BYTES));                                      \
+    KG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ4, acq_correlate_kernel<PP, 4, true>, 256,        \
+                                                        ACQ_LDS_BYTES));
+    if (P == 4) { ACQ_SETUP(4) } else { ACQ_SETUP(16) }
+#undef ACQ_SETUP
     if (occ1 < 1) occ1 = 1;
     if (occ4 < 1) occ4 = 1;
     a->grid1 = (ctx->num_cus * occ1) & ~7;
     a->grid4 = (ctx->num_cus * occ4) & ~7;
     if (a->grid1 < 8) a->grid1 = 8;
     if (a->grid4 < 8) a->grid4 = 8;
+    return KG_OK;
+}
+
+extern "C" {
+
+int kg_acq_create_shape(kg_ctx *ctx, int max_sats, int dop_lo, int dop_hi, int max_blocks, int nsamples,
+                        int fft_len, kg_acq **out)
+{
+    int rc = kg_ctx_use(ctx);
+    if (rc) return rc;
+    KG_REQUIRE(out != nullptr, KG_ERR_INVALID, "kg_acq_create: out is null");
+    *out = nullptr;
+    KG_REQUIRE(max_sats >= 1 && max_sats <= 4096, KG_ERR_INVALID, "kg_acq_create: max_sats %d", max_sats);
+    KG_REQUIRE(dop_lo <= dop_hi && dop_lo >= -1000 && dop_hi <= 1000, KG_ERR_INVALID,
+               "kg_acq_create: Doppler range %d..%d (supported: within -1000..1000)", dop_lo, dop_hi);
+    KG_REQUIRE(max_blocks >= 1 && max_blocks <= 65535, KG_ERR_INVALID, "kg_acq_create: max_blocks %d",
+               max_blocks);
+    KG_REQUIRE(fft_len == 16384 || fft_len == 65536, KG_ERR_INVALID,
+               "kg_acq_create: fft_len %d (supported: 16384, 65536)", fft_len);
+    KG_REQUIRE(nsamples >= 8 && nsamples <= DECIM * fft_len && nsamples % 8 == 0, KG_ERR_INVALID,
+               "kg_acq_create: nsamples %d (a multiple of 8, at most %d)", nsamples, DECIM * fft_len);
+    KG_REQUIRE((size_t) max_blocks * fft_len < ((size_t) 1 << 31), KG_ERR_INVALID,
+               "kg_acq_create: max_blocks %d x fft_len %d exceeds the 2^31-element offset range", max_blocks, fft_len);
+    kg_acq *a = new (std::nothrow) kg_acq();       // value-initialised: every pointer null
+    KG_REQUIRE(a != nullptr, KG_ERR_NOMEM, "kg_acq_create: alloc");
+    a->ctx = ctx; a->max_sats = max_sats; a->dop_lo = dop_lo; a->dop_hi = dop_hi;
+    a->ndop = dop_hi - dop_lo + 1; a->max_blocks = max_blocks;
+    a->nsamples = nsamples; a->fft_len = fft_len; a->P = fft_len / SUB;
+    a->fstream = ctx->stream;
+    rc = acq_init(a);
+    if (rc != KG_OK) { kg_acq_destroy(a); return rc; }     // frees whatever was allocated
     *out = a;
     return KG_OK;
 }
+
+int kg_acq_create(kg_ctx *ctx, int max_sats, int dop_lo, int dop_hi, int max_blocks, kg_acq **out)
+{
+    return kg_acq_create_shape(ctx, max_sats, dop_lo, dop_hi, max_blocks, KG_ACQ_NSAMPLES, KG_ACQ_FFT_LEN, out);
+}
+
+int kg_acq_nsamples(kg_acq *a) { return a ? a->nsamples : KG_ERR_INVALID; }
+int kg_acq_fft_len(kg_acq *a) { return a ? a->fft_len : KG_ERR_INVALID; }
 
 void kg_acq_destroy(kg_acq *a)
 {
     if (!a) return;
     (void) hipSetDevice(a->ctx->device);
-    (void) hipStreamSynchronize(a->fstream);
+    if (a->fstream) (void) hipStreamSynchronize(a->fstream);
     (void) hipStreamSynchronize(a->ctx->stream);
-    for (size_t b = 0; b < a->ev_ready.size(); b++) {
-        (void) hipEventDestroy(a->ev_ready[b]);
-        (void) hipEventDestroy(a->ev_done[b]);
-    }
+    for (size_t b = 0; b < a->ev_ready.size(); b++) (void) hipEventDestroy(a->ev_ready[b]);
+    for (size_t b = 0; b < a->ev_done.size(); b++) (void) hipEventDestroy(a->ev_done[b]);
     if (a->own_fstream) (void) hipStreamDestroy(a->fstream);
+    if (a->own_tabN) (void) hipFree(a->d_tabN);
+    (void) hipFree(a->d_comb); (void) hipFree(a->d_quart);          // hipFree(nullptr) is a no-op
     (void) hipFree(a->d_code); (void) hipFree(a->d_data); (void) hipFree(a->d_td);
     (void) hipFree(a->d_td_code);
     (void) hipFree(a->d_fsub); (void) hipFree(a->d_fsub_code);
-    (void) hipFree(a->d_in); (void) hipFree(a->d_chips); (void) hipFree(a->d_limits);
-    for (int k = 0; k < 4; k++) { (void) hipHostFree(a->h_pin[k]); (void) hipEventDestroy(a->ev_pin[k]); }
+    (void) hipFree(a->d_in); (void) hipFree(a->d_chips);
+    for (int k = 0; k < 4; k++) {
+        if (a->h_pin[k]) (void) hipHostFree(a->h_pin[k]);
+        if (a->ev_pin[k]) (void) hipEventDestroy(a->ev_pin[k]);
+    }
     if (a->h_batch) (void) hipHostFree(a->h_batch);
-    (void) hipEventDestroy(a->ev_batch); (void) hipEventDestroy(a->ev_in_free);
-    (void) hipStreamSynchronize(a->cstream); (void) hipStreamDestroy(a->cstream);
-    (void) hipFree(a->d_table1); (void) hipFree(a->d_table4);
-    (void) hipFree(a->d_xcd1); (void) hipFree(a->d_xcd4);
+    if (a->ev_batch) (void) hipEventDestroy(a->ev_batch);
+    if (a->ev_in_free) (void) hipEventDestroy(a->ev_in_free);
+    if (a->cstream) { (void) hipStreamSynchronize(a->cstream); (void) hipStreamDestroy(a->cstream); }
     (void) hipFree(a->d_cells); (void) hipFree(a->d_results);
     delete a;
 }
@@ -645,13 +766,11 @@ static int set_limit(kg_acq *a, int sat, int limit)
 {
     KG_REQUIRE(sat >= 0 && sat < a->max_sats, KG_ERR_INVALID, "sat %d out of range (0..%d)", sat,
                a->max_sats - 1);
-    KG_REQUIRE(limit >= 1 && limit <= FFT_LEN, KG_ERR_INVALID, "limit %d out of range (1..%d)", limit,
-               FFT_LEN);
+    KG_REQUIRE(limit >= 1 && limit <= 4 * SUB, KG_ERR_INVALID, "limit %d out of range (1..%d)", limit,
+               4 * SUB);
     a->limits[sat] = limit;
     a->code_set[sat] = 1;
-    a->last_sats.clear();        // force the selection lists to be rebuilt
-    KG_HIP(hipMemcpyAsync(a->d_limits + sat, &a->limits[sat], sizeof(int), hipMemcpyHostToDevice,
-                          a->ctx->stream));
+    a->last_sats.clear();        // force the pair tables to be rebuilt
     return KG_OK;
 }
 
@@ -665,8 +784,10 @@ int kg_acq_set_code(kg_acq *a, int sat, const uint8_t *chips, int nchips, int bo
         KG_REQUIRE(chips[i] <= 1, KG_ERR_INVALID, "kg_acq_set_code: chips[%d] = %d is not 0/1", i, chips[i]);
     if ((rc = set_limit(a, sat, limit)) != KG_OK) return rc;
     KG_HIP(hipMemcpyAsync(a->d_chips, chips, nchips, hipMemcpyHostToDevice, a->ctx->stream));
-    rc = launch_frontend<SRC_CHIPS>(a, a->ctx->stream, a->d_chips, 0, 1, nchips, boc ? 1 : 0, a->d_td_code, a->d_fsub_code,
-                                    a->d_code + (size_t) sat * a->code_len, a->code_len, a->halo);
+    // the replica covers all DECIM * N samples, as the reference's covers NSAMPLES (:250)
+    rc = launch_frontend<SRC_CHIPS>(a, a->ctx->stream, a->d_chips, 0, 1, DECIM * a->fft_len, nchips, boc ? 1 : 0,
+                                    a->d_td_code, a->d_fsub_code, a->d_code + (size_t) sat * a->code_len,
+                                    a->code_len, a->halo);
     if (rc) return rc;
     KG_HIP(hipStreamSynchronize(a->ctx->stream));       // chips buffer is reused per call
     return KG_OK;
@@ -679,7 +800,7 @@ int kg_acq_set_code_fft(kg_acq *a, int sat, const float *code_fft, int limit)
     if (rc) return rc;
     if ((rc = set_limit(a, sat, limit)) != KG_OK) return rc;
     std::vector<float2> pl;
-    to_planes(code_fft, pl, a->halo);
+    to_planes(code_fft, pl, a->P, a->halo);
     KG_HIP(hipMemcpyAsync(a->d_code + (size_t) sat * a->code_len, pl.data(), sizeof(float2) * a->code_len,
                           hipMemcpyHostToDevice, a->ctx->stream));
     KG_HIP(hipStreamSynchronize(a->ctx->stream));
@@ -688,11 +809,11 @@ int kg_acq_set_code_fft(kg_acq *a, int sat, const float *code_fft, int limit)
 
 static int get_planes(kg_acq *a, const float2 *d, float *nat, int H)
 {
-    std::vector<float2> pl(spec_len(H));
+    std::vector<float2> pl(spec_len(a->P, H));
     KG_HIP(hipStreamSynchronize(a->fstream));
     KG_HIP(hipMemcpyAsync(pl.data(), d, sizeof(float2) * pl.size(), hipMemcpyDeviceToHost, a->ctx->stream));
     KG_HIP(hipStreamSynchronize(a->ctx->stream));
-    from_planes(pl, nat, H);
+    from_planes(pl, nat, a->P, H);
     return KG_OK;
 }
 
@@ -725,6 +846,13 @@ static int stage_host_block(kg_acq *a, uint8_t *d_stage, const void *src, size_t
     KG_HIP(hipEventRecord(a->ev_pin[k], a->fstream));
     return KG_OK;
 }
+// Behind every front end that read d_in: the next batch copy (on cstream) waits for it.
+static int staging_consumed(kg_acq *a)
+{
+    KG_HIP(hipEventRecord(a->ev_in_free, a->fstream));
+    a->in_free_set = true;
+    return KG_OK;
+}
 
 // Front-stream bracket for everything that (re)writes the data spectra of blocks
 // b .. b+n-1.  Events are only ever re-recorded on the same stream, so waiting on a shared
@@ -753,25 +881,37 @@ static int front_end(kg_acq *a, int b, int n = 1)
     return KG_OK;
 }
 
+}  // extern "C"
+
+template <int SRC>
+static int sample_dev(kg_acq *a, int first, int nblocks, const void *d_src, size_t stride)
+{
+    int rc;
+    if ((rc = front_begin(a, first, nblocks)) != KG_OK) return rc;
+    const size_t off = (size_t) first * a->fft_len;
+    rc = launch_frontend<SRC>(a, a->fstream, (const uint8_t *) d_src, stride, nblocks, a->nsamples, 0, 0,
+                              a->d_td + off, a->d_fsub + off, a->d_data + off, a->fft_len, 0);
+    if (rc) return rc;
+    return front_end(a, first, nblocks);
+}
+
+extern "C" {
+
 int kg_acq_sample_bits_dev(kg_acq *a, int block, const void *d_packed)
 {
     int rc = check_block(a, block, d_packed, "kg_acq_sample_bits_dev");
     if (rc) return rc;
-    if ((rc = front_begin(a, block)) != KG_OK) return rc;
-    rc = launch_frontend<SRC_BITS>(a, a->fstream, (const uint8_t *) d_packed, 0, 1, 0, 0,
-                                   a->d_td + (size_t) block * FFT_LEN, a->d_fsub + (size_t) block * FFT_LEN,
-                                   a->d_data + (size_t) block * FFT_LEN, FFT_LEN, 0);
-    if (rc) return rc;
-    return front_end(a, block);
+    return sample_dev<SRC_BITS>(a, block, 1, d_packed, 0);
 }
 
 int kg_acq_sample_bits(kg_acq *a, int block, const uint8_t *packed)
 {
     int rc = check_block(a, block, packed, "kg_acq_sample_bits");
     if (rc) return rc;
-    uint8_t *stage = a->d_in + IN_STRIDE * block;
-    if ((rc = stage_host_block(a, stage, packed, NSAMPLES / 8))) return rc;
-    return kg_acq_sample_bits_dev(a, block, stage);
+    uint8_t *stage = a->d_in + a->in_stride * block;
+    if ((rc = stage_host_block(a, stage, packed, (size_t) a->nsamples / 8))) return rc;
+    if ((rc = sample_dev<SRC_BITS>(a, block, 1, stage, 0)) != KG_OK) return rc;
+    return staging_consumed(a);
 }
 
 int kg_acq_sample_iq16_dev(kg_acq *a, int block, const void *d_iq)
@@ -779,12 +919,7 @@ int kg_acq_sample_iq16_dev(kg_acq *a, int block, const void *d_iq)
     int rc = check_block(a, block, d_iq, "kg_acq_sample_iq16_dev");
     if (rc) return rc;
     KG_REQUIRE(((uintptr_t) d_iq & 3) == 0, KG_ERR_INVALID, "kg_acq_sample_iq16_dev: pointer not 4-byte aligned");
-    if ((rc = front_begin(a, block)) != KG_OK) return rc;
-    rc = launch_frontend<SRC_IQ16>(a, a->fstream, (const uint8_t *) d_iq, 0, 1, 0, 0,
-                                   a->d_td + (size_t) block * FFT_LEN, a->d_fsub + (size_t) block * FFT_LEN,
-                                   a->d_data + (size_t) block * FFT_LEN, FFT_LEN, 0);
-    if (rc) return rc;
-    return front_end(a, block);
+    return sample_dev<SRC_IQ16>(a, block, 1, d_iq, 0);
 }
 
 int kg_acq_sample_iq16_batch_dev(kg_acq *a, int first, int nblocks, const void *d_iq, size_t stride_bytes)
@@ -795,12 +930,7 @@ int kg_acq_sample_iq16_batch_dev(kg_acq *a, int first, int nblocks, const void *
                "kg_acq_sample_iq16_batch_dev: blocks %d..%d (max %d)", first, first + nblocks - 1, a->max_blocks);
     KG_REQUIRE(((uintptr_t) d_iq & 3) == 0 && (stride_bytes & 3) == 0, KG_ERR_INVALID,
                "kg_acq_sample_iq16_batch_dev: pointer/stride not 4-byte aligned");
-    if ((rc = front_begin(a, first, nblocks)) != KG_OK) return rc;
-    rc = launch_frontend<SRC_IQ16>(a, a->fstream, (const uint8_t *) d_iq, stride_bytes, nblocks, 0, 0,
-                                   a->d_td + (size_t) first * FFT_LEN, a->d_fsub + (size_t) first * FFT_LEN,
-                                   a->d_data + (size_t) first * FFT_LEN, FFT_LEN, 0);
-    if (rc) return rc;
-    return front_end(a, first, nblocks);
+    return sample_dev<SRC_IQ16>(a, first, nblocks, d_iq, stride_bytes);
 }
 
 int kg_acq_sample_iq16_batch(kg_acq *a, int first, int nblocks, const int16_t *iq, size_t stride_samples)
@@ -809,9 +939,9 @@ int kg_acq_sample_iq16_batch(kg_acq *a, int first, int nblocks, const int16_t *i
     if (rc) return rc;
     KG_REQUIRE(nblocks >= 1 && first + nblocks <= a->max_blocks, KG_ERR_INVALID,
                "kg_acq_sample_iq16_batch: blocks %d..%d (max %d)", first, first + nblocks - 1, a->max_blocks);
-    KG_REQUIRE(stride_samples >= (size_t) NSAMPLES, KG_ERR_INVALID, "kg_acq_sample_iq16_batch: stride %zu < %d samples",
-               stride_samples, NSAMPLES);
-    const size_t bytes = IN_STRIDE * (size_t) nblocks;
+    KG_REQUIRE(stride_samples >= (size_t) a->nsamples, KG_ERR_INVALID, "kg_acq_sample_iq16_batch: stride %zu < %d samples",
+               stride_samples, a->nsamples);
+    const size_t bytes = a->in_stride * (size_t) nblocks;
     KG_HIP(hipEventSynchronize(a->ev_batch));            // the previous batch has left the pinned region
     if (bytes > a->batch_cap) {
         if (a->h_batch) KG_HIP(hipHostFree(a->h_batch));
@@ -820,27 +950,26 @@ int kg_acq_sample_iq16_batch(kg_acq *a, int first, int nblocks, const int16_t *i
         a->batch_cap = bytes;
     }
     for (int b = 0; b < nblocks; b++)
-        memcpy(a->h_batch + IN_STRIDE * b, iq + 2 * stride_samples * b, IN_STRIDE);
-    uint8_t *stage = a->d_in + IN_STRIDE * first;
+        memcpy(a->h_batch + a->in_stride * b, iq + 2 * stride_samples * b, a->in_stride);
+    uint8_t *stage = a->d_in + a->in_stride * first;
     // copy stream: after the front end that last read the staging area; front-end stream: after the copy
     if (a->in_free_set) KG_HIP(hipStreamWaitEvent(a->cstream, a->ev_in_free, 0));
     KG_HIP(hipMemcpyAsync(stage, a->h_batch, bytes, hipMemcpyHostToDevice, a->cstream));
     KG_HIP(hipEventRecord(a->ev_batch, a->cstream));
     KG_HIP(hipStreamWaitEvent(a->fstream, a->ev_batch, 0));
-    rc = kg_acq_sample_iq16_batch_dev(a, first, nblocks, stage, IN_STRIDE);
+    rc = sample_dev<SRC_IQ16>(a, first, nblocks, stage, a->in_stride);
     if (rc) return rc;
-    KG_HIP(hipEventRecord(a->ev_in_free, a->fstream));
-    a->in_free_set = true;
-    return KG_OK;
+    return staging_consumed(a);
 }
 
 int kg_acq_sample_iq16(kg_acq *a, int block, const int16_t *iq)
 {
     int rc = check_block(a, block, iq, "kg_acq_sample_iq16");
     if (rc) return rc;
-    uint8_t *stage = a->d_in + IN_STRIDE * block;
-    if ((rc = stage_host_block(a, stage, iq, (size_t) NSAMPLES * 4))) return rc;
-    return kg_acq_sample_iq16_dev(a, block, stage);
+    uint8_t *stage = a->d_in + a->in_stride * block;
+    if ((rc = stage_host_block(a, stage, iq, a->in_stride))) return rc;
+    if ((rc = sample_dev<SRC_IQ16>(a, block, 1, stage, 0)) != KG_OK) return rc;
+    return staging_consumed(a);
 }
 
 int kg_acq_set_data_fft(kg_acq *a, int block, const float *data_fft)
@@ -848,9 +977,9 @@ int kg_acq_set_data_fft(kg_acq *a, int block, const float *data_fft)
     int rc = check_block(a, block, data_fft, "kg_acq_set_data_fft");
     if (rc) return rc;
     std::vector<float2> pl;
-    to_planes(data_fft, pl, 0);
+    to_planes(data_fft, pl, a->P, 0);
     if ((rc = front_begin(a, block)) != KG_OK) return rc;
-    KG_HIP(hipMemcpyAsync(a->d_data + (size_t) block * FFT_LEN, pl.data(), sizeof(float2) * FFT_LEN,
+    KG_HIP(hipMemcpyAsync(a->d_data + (size_t) block * a->fft_len, pl.data(), sizeof(float2) * a->fft_len,
                           hipMemcpyHostToDevice, a->fstream));
     if ((rc = front_end(a, block)) != KG_OK) return rc;
     KG_HIP(hipStreamSynchronize(a->fstream));
@@ -861,7 +990,7 @@ int kg_acq_get_data_fft(kg_acq *a, int block, float *data_fft)
 {
     int rc = check_block(a, block, data_fft, "kg_acq_get_data_fft");
     if (rc) return rc;
-    return get_planes(a, a->d_data + (size_t) block * FFT_LEN, data_fft, 0);
+    return get_planes(a, a->d_data + (size_t) block * a->fft_len, data_fft, 0);
 }
 
 int kg_acq_get_data_td(kg_acq *a, int block, float *td)
@@ -869,10 +998,28 @@ int kg_acq_get_data_td(kg_acq *a, int block, float *td)
     int rc = check_block(a, block, td, "kg_acq_get_data_td");
     if (rc) return rc;
     KG_HIP(hipStreamSynchronize(a->fstream));
-    KG_HIP(hipMemcpyAsync(td, a->d_td + (size_t) block * FFT_LEN, sizeof(float2) * FFT_LEN, hipMemcpyDeviceToHost, a->ctx->stream));
+    KG_HIP(hipMemcpyAsync(td, a->d_td + (size_t) block * a->fft_len, sizeof(float2) * a->fft_len,
+                          hipMemcpyDeviceToHost, a->ctx->stream));
     KG_HIP(hipStreamSynchronize(a->ctx->stream));
     return KG_OK;
 }
+
+}  // extern "C"
+
+template <int P, int NQ, bool STAMPS>
+static void launch_correlate(kg_acq *a, hipStream_t st, int first, const acq_pair_desc *d_pairs, int npairs,
+                             unsigned long long *d_stamps)
+{
+    const int grid = NQ == 1 ? a->grid1 : a->grid4, nslots = grid >> 3;
+    const acq_walk w = {npairs, a->ndop, a->dop_lo, nslots / a->ndop, nslots % a->ndop};
+    hipLaunchKernelGGL((acq_correlate_kernel<P, NQ, true, STAMPS>), dim3(grid), dim3(256), ACQ_LDS_BYTES, st,
+                       (const float2 *) (a->d_data + (size_t) first * a->fft_len), (const float2 *) a->d_code,
+                       (const float2 *) a->ctx->d_tab4096, (const float2 *) a->d_tabN,
+                       (const float2 *) a->d_comb, (const float2 *) a->d_quart, d_pairs, w, a->halo,
+                       a->d_cells, d_stamps);
+}
+
+extern "C" {
 
 int kg_acq_correlate_blocks_async(kg_acq *a, int first, int nblocks, const int *sats, int nsats)
 {
@@ -885,71 +1032,56 @@ int kg_acq_correlate_blocks_async(kg_acq *a, int first, int nblocks, const int *
     KG_REQUIRE(nsats >= 1 && nsats <= a->max_sats, KG_ERR_INVALID,
                "kg_acq_correlate_async: nsats %d (max %d)", nsats, a->max_sats);
     hipStream_t st = a->ctx->stream;
-    // the tables hold block indices relative to `first` (the kernel gets data + first)
-    bool same = (int) a->last_sats.size() == nsats && a->table_nblocks == nblocks;
+    // The tables hold block indices relative to `first` (the kernel gets data + first).  They are
+    // reused while the SV list is the same and the ring slot they were staged in is still theirs
+    // (fewer than half a ring of uploads since); otherwise they are staged again -- a memcpy into
+    // pinned memory and an enqueued transfer, never a stream synchronisation (the per-SV calling
+    // pattern of the reference's SearchTask loop changes the list on every call).
+    bool same = (int) a->last_sats.size() == nsats && a->table_nblocks == nblocks &&
+                a->ctx->ring_next - a->pairs_seq < KG_RING_SLOTS / 2;
     for (int i = 0; same && i < nsats; i++) same = a->last_sats[i] == sats[i];
     if (!same) {
-        // (block, SV) pairs are dealt to the 8 XCD groups round-robin; a pair's
-        // ndop cells stay together.  Separate tables for the 4092-window (C/A)
-        // and the 16368-window (E1B) kernels.
-        std::vector<acq_cell_desc> tabs[2][8];
-        int np[2] = {0, 0};
-        a->nsel1 = a->nsel4 = 0;
+        // (block, SV) pairs are dealt to the 8 XCD groups round-robin (pair p -> group p & 7); a
+        // pair's ndop cells stay together.  Separate tables for the 4092-window (C/A) and the
+        // 16368-window (E1B) kernels, staged as one upload: [pairs1 | pairs4].
         for (int i = 0; i < nsats; i++) {
             KG_REQUIRE(sats[i] >= 0 && sats[i] < a->max_sats, KG_ERR_INVALID,
                        "kg_acq_correlate_async: sats[%d] = %d out of range", i, sats[i]);
             KG_REQUIRE(a->code_set[sats[i]], KG_ERR_STATE,
                        "kg_acq_correlate_async: no code set for sat %d", sats[i]);
-            (a->limits[sats[i]] <= SUB ? a->nsel1 : a->nsel4)++;
         }
+        std::vector<acq_pair_desc> tab[2];
         for (int blk = 0; blk < nblocks; blk++)
             for (int i = 0; i < nsats; i++) {
-                const int sat = sats[i], w = a->limits[sat] <= SUB ? 0 : 1;
-                std::vector<acq_cell_desc> &v = tabs[w][np[w]++ & 7];
-                for (int di = 0; di < a->ndop; di++) {
-                    acq_cell_desc ds = {};
-                    ds.data_off = blk * FFT_LEN;
-                    ds.code_off = (int) (sat * a->code_len);
-                    ds.dop = a->dop_lo + di;
-                    ds.limit = a->limits[sat];
-                    ds.out = (blk * nsats + i) * a->ndop + di;
-                    v.push_back(ds);
-                }
+                const int sat = sats[i];
+                acq_pair_desc pd;
+                pd.data_off = blk * a->fft_len;
+                pd.code_off = (int) (sat * a->code_len);
+                pd.limit = a->limits[sat];
+                pd.out = (blk * nsats + i) * a->ndop;
+                tab[a->limits[sat] <= SUB ? 0 : 1].push_back(pd);
             }
-        // the previous launch may still be reading the tables
-        KG_HIP(hipStreamSynchronize(st));
-        for (int w = 0; w < 2; w++) {
-            std::vector<acq_cell_desc> flat;
-            int starts[9];
-            for (int x = 0; x < 8; x++) {
-                starts[x] = (int) flat.size();
-                flat.insert(flat.end(), tabs[w][x].begin(), tabs[w][x].end());
-            }
-            starts[8] = (int) flat.size();
-            KG_HIP(hipMemcpy(w ? a->d_xcd4 : a->d_xcd1, starts, sizeof starts, hipMemcpyHostToDevice));
-            if (!flat.empty())
-                KG_HIP(hipMemcpy(w ? a->d_table4 : a->d_table1, flat.data(),
-                                 sizeof(acq_cell_desc) * flat.size(), hipMemcpyHostToDevice));
-        }
+        a->np1 = (int) tab[0].size(); a->np4 = (int) tab[1].size();
+        tab[0].insert(tab[0].end(), tab[1].begin(), tab[1].end());
+        void *d = nullptr;
+        if ((rc = kg_ctx_stage(a->ctx, tab[0].data(), sizeof(acq_pair_desc) * tab[0].size(), &d)) != KG_OK) return rc;
+        a->d_pairs1 = (const acq_pair_desc *) d;
+        a->d_pairs4 = a->d_pairs1 + a->np1;
+        a->pairs_seq = a->ctx->ring_next;
         a->last_sats.assign(sats, sats + nsats);
         a->table_nblocks = nblocks;
+        // a table too large for a ring slot went through the context's scratch: never reused
+        if (sizeof(acq_pair_desc) * tab[0].size() > KG_RING_SLOT_BYTES) a->last_sats.clear();
     }
     if (a->own_fstream && (rc = wait_once(st, a->ev_ready, a->ready_of, first, nblocks)) != KG_OK) return rc;   // RAW
-    const float2 *t4 = a->ctx->d_tab4096, *t16 = a->ctx->d_tab16384;
-    if (a->nsel1 > 0) {
-        hipLaunchKernelGGL((acq_correlate_kernel<1, true>), dim3(a->grid1), dim3(256), ACQ_LDS_BYTES, st,
-                           (const float2 *) (a->d_data + (size_t) first * FFT_LEN),
-                           (const float2 *) a->d_code, t4, t16,
-                           (const acq_cell_desc *) a->d_table1, (const int *) a->d_xcd1, a->halo,
-                           a->d_cells, (unsigned long long *) nullptr);
+    if (a->np1 > 0) {
+        if (a->P == 4) launch_correlate<4, 1, false>(a, st, first, a->d_pairs1, a->np1, nullptr);
+        else launch_correlate<16, 1, false>(a, st, first, a->d_pairs1, a->np1, nullptr);
         KG_HIP(hipGetLastError());
     }
-    if (a->nsel4 > 0) {
-        hipLaunchKernelGGL((acq_correlate_kernel<4, true>), dim3(a->grid4), dim3(256), ACQ_LDS_BYTES, st,
-                           (const float2 *) (a->d_data + (size_t) first * FFT_LEN),
-                           (const float2 *) a->d_code, t4, t16,
-                           (const acq_cell_desc *) a->d_table4, (const int *) a->d_xcd4, a->halo,
-                           a->d_cells, (unsigned long long *) nullptr);
+    if (a->np4 > 0) {
+        if (a->P == 4) launch_correlate<4, 4, false>(a, st, first, a->d_pairs4, a->np4, nullptr);
+        else launch_correlate<16, 4, false>(a, st, first, a->d_pairs4, a->np4, nullptr);
         KG_HIP(hipGetLastError());
     }
     const int npairs = nblocks * nsats;
@@ -1000,18 +1132,21 @@ int kg_acq_debug_corr_stamps(kg_acq *a, int nblocks, const int *sats, int nsats,
     KG_REQUIRE(a && stamps && n >= 16 + 16 * 24, KG_ERR_INVALID, "kg_acq_debug_corr_stamps: need 400 slots");
     int rc = kg_acq_correlate_async(a, nblocks, sats, nsats);      // builds the lists, warms up
     if (rc) return rc;
-    KG_REQUIRE(a->nsel1 > 0, KG_ERR_STATE, "kg_acq_debug_corr_stamps: no C/A SV in the list");
+    KG_REQUIRE(a->np1 > 0, KG_ERR_STATE, "kg_acq_debug_corr_stamps: no C/A SV in the list");
     hipStream_t st = a->ctx->stream;
     unsigned long long *d = nullptr;
     const size_t bytes = sizeof(unsigned long long) * (16 + 16 * 24);
     KG_HIP(hipMalloc((void **) &d, bytes));
     KG_HIP(hipMemset(d, 0, bytes));
-    KG_HIP(hipFuncSetAttribute((const void *) acq_correlate_kernel<1, true, true>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, ACQ_LDS_BYTES));
-    hipLaunchKernelGGL((acq_correlate_kernel<1, true, true>), dim3(a->grid1), dim3(256), ACQ_LDS_BYTES, st,
-                       (const float2 *) a->d_data, (const float2 *) a->d_code, a->ctx->d_tab4096,
-                       a->ctx->d_tab16384, (const acq_cell_desc *) a->d_table1,
-                       (const int *) a->d_xcd1, a->halo, a->d_cells, d);
+    if (a->P == 4) {
+        KG_HIP(hipFuncSetAttribute((const void *) acq_correlate_kernel<4, 1, true, true>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, ACQ_LDS_BYTES));
+        launch_correlate<4, 1, true>(a, st, 0, a->d_pairs1, a->np1, d);
+    } else {
+        KG_HIP(hipFuncSetAttribute((const void *) acq_correlate_kernel<16, 1, true, true>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, ACQ_LDS_BYTES));
+        launch_correlate<16, 1, true>(a, st, 0, a->d_pairs1, a->np1, d);
+    }
     KG_HIP(hipGetLastError());
     KG_HIP(hipStreamSynchronize(st));
     KG_HIP(hipMemcpy(stamps, d, bytes, hipMemcpyDeviceToHost));
@@ -1029,9 +1164,9 @@ int kg_acq_debug_fft_stamps(kg_acq *a, int block, unsigned long long *stamps, in
     KG_HIP(hipMalloc((void **) &d, 8 * sizeof(unsigned long long)));
     KG_HIP(hipStreamSynchronize(a->fstream));
     for (int rep = 0; rep < 3; rep++) {       // last repetition is the warm one
-        hipLaunchKernelGGL(acq_fft_sub_kernel<true>, dim3(4, 1), dim3(256), 2 * SUB * sizeof(float2),
-                           c->stream, (const float2 *) (a->d_td + (size_t) block * FFT_LEN),
-                           a->d_fsub + (size_t) block * FFT_LEN, (const float2 *) c->d_tab4096, d);
+        hipLaunchKernelGGL(acq_fft_sub_kernel<true>, dim3(a->P, 1), dim3(256), 2 * SUB * sizeof(float2),
+                           c->stream, (const float2 *) (a->d_td + (size_t) block * a->fft_len),
+                           a->d_fsub + (size_t) block * a->fft_len, (const float2 *) c->d_tab4096, a->P, d);
         KG_HIP(hipGetLastError());
         KG_HIP(hipStreamSynchronize(c->stream));
     }

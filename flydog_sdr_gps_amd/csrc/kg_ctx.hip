@@ -92,7 +92,7 @@ static int make_table(float2 **d, int n)
     return KG_OK;
 }
 
-int kg_ctx_create(int device, void *stream, kg_ctx **out)
+static int ctx_create(int device, void *stream, bool use_given, kg_ctx **out)
 {
     KG_REQUIRE(out != nullptr, KG_ERR_INVALID, "kg_ctx_create: out is null");
     *out = nullptr;
@@ -118,7 +118,7 @@ int kg_ctx_create(int device, void *stream, kg_ctx **out)
     c->device = device;
     c->num_cus = prop.multiProcessorCount;
     snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
-    if (stream) {
+    if (use_given) {
         c->stream = (hipStream_t) stream;
         c->own_stream = false;
     } else {
@@ -128,11 +128,21 @@ int kg_ctx_create(int device, void *stream, kg_ctx **out)
     KG_HIP(hipEventCreate(&c->ev_start));
     KG_HIP(hipEventCreate(&c->ev_stop));
     int rc;
-    if ((rc = make_table(&c->d_tab4096, 4096)) != KG_OK) return rc;
-    if ((rc = make_table(&c->d_tab16384, 16384)) != KG_OK) return rc;
-    if ((rc = make_table(&c->d_tab8192, 8192)) != KG_OK) return rc;
+    if ((rc = make_table(&c->d_tab4096, 4096)) != KG_OK) { kg_ctx_destroy(c); return rc; }
+    if ((rc = make_table(&c->d_tab16384, 16384)) != KG_OK) { kg_ctx_destroy(c); return rc; }
+    if ((rc = make_table(&c->d_tab8192, 8192)) != KG_OK) { kg_ctx_destroy(c); return rc; }
     *out = c;
     return KG_OK;
+}
+
+int kg_ctx_create(int device, void *stream, kg_ctx **out)
+{
+    return ctx_create(device, stream, stream != nullptr, out);
+}
+
+int kg_ctx_create_on_stream(int device, void *stream, kg_ctx **out)
+{
+    return ctx_create(device, stream, true, out);
 }
 
 void kg_ctx_destroy(kg_ctx *c)

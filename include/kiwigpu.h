@@ -57,6 +57,10 @@ typedef struct kg_ctx kg_ctx;
 /* stream: a hipStream_t to enqueue on (e.g. the caller's or PyTorch's current
  * stream), or NULL to let the library create its own non-blocking stream. */
 int kg_ctx_create(int device, void *stream, kg_ctx **out);
+/* The same, but `stream` is always taken as given: NULL here means HIP's legacy default
+ * ("null") stream, which is what torch.cuda.current_stream().cuda_stream is (0) when no
+ * other stream was selected.  The library never destroys a caller's stream. */
+int kg_ctx_create_on_stream(int device, void *stream, kg_ctx **out);
 void kg_ctx_destroy(kg_ctx *ctx);
 int kg_ctx_sync(kg_ctx *ctx);                 /* hipStreamSynchronize */
 int kg_ctx_poll(kg_ctx *ctx);                 /* 1 = stream idle, 0 = busy, <0 error */
@@ -82,11 +86,20 @@ int kg_timer_stop(kg_ctx *ctx, float *elapsed_ms);    /* synchronises on the sto
 /* GPS C/A + E1B parallel-code-phase acquisition.                            */
 /* Replaces gps/search.cpp: SearchInit() code tables (:183-350), Sample()    */
 /* (:382-449), Correlate() (:453-499).                                       */
-/* Fixed by the reference (gps/gps.h:62-73): NSAMPLES 65536, DECIM 4,        */
-/* FFT_LEN 16384.                                                            */
+/* The reference's shape (gps/gps.h:62-73): NSAMPLES 65536, DECIM 4,          */
+/* FFT_LEN 16384 -- what kg_acq_create() builds.  kg_acq_create_shape() builds */
+/* the same algorithm for a longer coherent interval (BASELINE.json           */
+/* configs[4]); every size below then reads kg_acq_nsamples() / kg_acq_fft_len() */
+/* in place of the two constants.                                             */
 /* ------------------------------------------------------------------------ */
 #define KG_ACQ_NSAMPLES 65536
 #define KG_ACQ_FFT_LEN  16384
+#define KG_ACQ_DECIM    4         /* gps/gps.h:62 */
+/* BASELINE.json configs[4]: 10 ms coherent at FS = 16.368 MHz, zero-padded to a
+ * 65536-point transform at SAMPLE_RATE = FS/DECIM = 4.092 MHz.  One Doppler bin is
+ * SAMPLE_RATE / FFT_LEN = 62.44 Hz there (249.76 Hz in the reference shape). */
+#define KG_ACQ10_NSAMPLES 163680
+#define KG_ACQ10_FFT_LEN  65536
 #define KG_ACQ_L1_LIMIT 4092      /* SAMPLE_RATE/1000*L1_CODE_PERIOD,  search.cpp:486 */
 #define KG_ACQ_E1B_LIMIT 16368    /* SAMPLE_RATE/1000*E1B_CODE_PERIOD, search.cpp:486 */
 
@@ -106,6 +119,17 @@ typedef struct { float snr; float max_pwr; float tot_pwr; int32_t idx; } kg_acq_
  * resident and searched in one launch. */
 int kg_acq_create(kg_ctx *ctx, int max_sats, int dop_lo, int dop_hi, int max_blocks,
                   kg_acq **out);
+/* The same engine for another shape of the same algorithm: a sample block holds
+ * `nsamples` input samples at FS (a multiple of 8, at most DECIM * fft_len; the rest of
+ * the DECIM * fft_len array Sample() decimates is zero, as DecimateBy2float's tail is,
+ * search.cpp:145), the transforms are fft_len points (16384 or 65536), the code replica
+ * covers all DECIM * fft_len samples as the reference's covers NSAMPLES (:250), a Doppler
+ * bin is one bin of that transform, the peak-search windows stay 4092 / 16368.
+ * kg_acq_create() == kg_acq_create_shape(.., KG_ACQ_NSAMPLES, KG_ACQ_FFT_LEN, ..). */
+int kg_acq_create_shape(kg_ctx *ctx, int max_sats, int dop_lo, int dop_hi, int max_blocks,
+                        int nsamples, int fft_len, kg_acq **out);
+int kg_acq_nsamples(kg_acq *acq);
+int kg_acq_fft_len(kg_acq *acq);
 void kg_acq_destroy(kg_acq *acq);
 
 /* SearchInit() per-SV body, run on the device: resample chips {0,1} at 16
@@ -143,7 +167,9 @@ int kg_acq_get_data_fft(kg_acq *acq, int block, float *data_fft);
 int kg_acq_get_data_td(kg_acq *acq, int block, float *td);
 
 /* Correlate() for nsats SVs x (dop_hi-dop_lo+1) bins x nblocks blocks
- * (blocks 0..nblocks-1), one launch.  Enqueue only.
+ * (blocks 0..nblocks-1), one launch.  Enqueue only: the call never waits for the
+ * stream, also when the SV list differs from the previous call's (the reference's
+ * SearchTask loop asks for one SV at a time).
  * Stream model: Sample() and Correlate() run in order on the context's stream
  * (a second stream for Sample() is an opt-in experiment). */
 int kg_acq_correlate_async(kg_acq *acq, int nblocks, const int *sats, int nsats);

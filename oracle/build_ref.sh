@@ -1,0 +1,68 @@
+#!/bin/bash
+# Builds oracle/_ref/: the pieces of the reference that compile from their own sources, each
+# compiled where it lies under $REFERENCE (nothing is copied into the repo; _ref/ is git-ignored
+# and holds binaries and generated files only).  Test infrastructure, run in the build container;
+# the GPU box uses the prebuilt files.
+#
+#   1. the reference's own eCPU assembler (e_cpu/asm/*.cpp) is compiled and run, in a temporary
+#      directory, on the reference's kiwi.config / *.asm  ->  _ref/gen/kiwi.gen.h (the generated
+#      header most reference translation units include);
+#   2. against the reference's headers + that kiwi.gen.h:
+#        cacode_ref    gps/cacode.h                      (C/A generator)
+#        e1b_ref       gps/e1bcode.h                     (the 50 Galileo E1-B memory codes)
+#        gpsconst_ref  gps/gps.h, kiwi.h, kiwi.gen.h     (the constants the oracle hard-pins)
+#        agc_ref       rx/CuteSDR/agc.cpp                (CAgc)
+#        adpcm_ref     rx/csdr/ima_adpcm.cpp             (IMA ADPCM coder/decoder)
+#        cic_gen_ref   verilog/rx/cic_gen.c              (Hogenauer pruning generator; its .vh
+#                                                         output for every CIC instance -> _ref/cic/)
+#
+# NOT built, and why (no stand-ins are written for missing headers or libraries):
+#   gps/search.cpp, rx/rx_waterfall.cpp, rx/CuteSDR/fastfir.cpp, support/simd.cpp  need <fftw3.h>
+#     (FFTW3f is un-vendored and absent from this image);
+#   gps/channel.cpp (CHANNEL::Start), rx/rx_sound.cpp, rx/data_pump.cpp  do not link without the
+#     SPI / task / timer runtime (spi_set, timer_us, TaskSleepMsec, ...).
+set -e
+REFERENCE=${REFERENCE:-/root/reference}
+HERE=$(cd "$(dirname "$0")" && pwd)
+OUT=$HERE/_ref
+CXX=${CXX:-g++}
+CC=${CC:-gcc}
+if [ ! -f "$REFERENCE/gps/cacode.h" ]; then
+    echo "reference tree absent: using prebuilt oracle/_ref/ if any"
+    exit 0
+fi
+mkdir -p "$OUT/gen" "$OUT/cic"
+
+# ---- 1. kiwi.gen.h from the reference's own assembler
+W=$(mktemp -d /tmp/kiwiref.XXXXXX)
+trap 'rm -rf "$W"' EXIT
+mkdir -p "$W/e_cpu" "$W/verilog" "$W/gen"
+# the assembler reads ./kiwi.asm, ./*.config, ../kiwi.config and writes ../verilog/*.vh: give it a
+# scratch directory of that shape (temporary, deleted on exit)
+cp "$REFERENCE"/e_cpu/*.asm "$REFERENCE"/e_cpu/*.config "$W/e_cpu/"
+cp "$REFERENCE/kiwi.config" "$W/"
+$CXX -I"$REFERENCE/e_cpu" -I"$REFERENCE/e_cpu/asm" -I"$REFERENCE" -D_GNU_SOURCE -w \
+    "$REFERENCE"/e_cpu/asm/*.cpp -o "$W/asm"
+(cd "$W/e_cpu" && "$W/asm" -o "$W/gen" > "$W/asm.log" 2>&1) || { cat "$W/asm.log"; exit 1; }
+cp "$W/gen/kiwi.gen.h" "$W/gen/other.gen.h" "$OUT/gen/"
+
+# ---- 2. the buildable pieces, in place
+R=$REFERENCE
+INC="-I$R -I$R/gps -I$R/rx -I$R/rx/CuteSDR -I$R/rx/csdr -I$R/rx/kiwi -I$R/rx/wdsp -I$R/rx/Teensy \
+ -I$R/support -I$R/platform/common -I$R/platform/beaglebone -I$R/arch/sitara -I$R/init -I$R/net \
+ -I$R/web -I$R/dev -I$R/ui -I$R/extensions -I$R/pkgs -I$R/pkgs/mongoose -I$R/pkgs/jsmn \
+ -I$R/pkgs/sha256 -I$OUT/gen"
+# the defines the reference's Makefile passes for a BeagleBone build (Makefile, Makefile.comp.inc)
+DEF="-std=gnu++11 -DKIWI -DKIWISDR -DHOST -DDEBIAN_VERSION=11 -DVERSION_MAJ=1 -DVERSION_MIN=663 \
+ -DARCH_CPU=x86 -DCPU_AM3359 -DPLATFORM_beaglebone_black"
+# -ffp-contract=off: x86-64 gcc does not contract by default at -O2 without -march flags; stated
+# so that the AGC's float/double expressions are evaluated operation by operation
+OPT="-O2 -ffp-contract=off -w"
+$CXX -O2 -I$R/gps -o "$OUT/cacode_ref" "$HERE/ref/ref_cacode_main.cpp"
+$CXX $OPT $DEF $INC -o "$OUT/e1b_ref" "$HERE/ref/ref_e1b_main.cpp"
+$CXX $OPT $DEF $INC -o "$OUT/gpsconst_ref" "$HERE/ref/ref_gpsconst_main.cpp"
+$CXX $OPT $DEF $INC -o "$OUT/agc_ref" "$HERE/ref/ref_agc_main.cpp" "$R/rx/CuteSDR/agc.cpp" -lm
+$CXX $OPT $DEF $INC -o "$OUT/adpcm_ref" "$HERE/ref/ref_adpcm_main.cpp" "$R/rx/csdr/ima_adpcm.cpp"
+$CC -O1 -w -DKIWISDR -I"$OUT/gen" "$R/verilog/rx/cic_gen.c" -lm -o "$OUT/cic_gen_ref"
+(cd "$OUT/cic" && "$OUT/cic_gen_ref" > cic_gen.log 2>&1)
+echo "built oracle/_ref: cacode_ref e1b_ref gpsconst_ref agc_ref adpcm_ref cic_gen_ref (+ gen/kiwi.gen.h, cic/*.vh) from $REFERENCE"

@@ -214,14 +214,16 @@ int ko_decimate_by2_float(int size, ko_cpx *buf)
 }
 
 /* gps/search.cpp:250-267 (boc=0) and :315-329 (boc=1), then :269-276 */
-void ko_code_replica(const uint8_t *chips, int nchips, int boc, float *phase,
-                     ko_cpx *out)
+void ko_code_replica_n(const uint8_t *chips, int nchips, int boc, float *phase,
+                       ko_cpx *out, int fft_len)
 {
-    ko_cpx *buf = (ko_cpx *) malloc(sizeof(ko_cpx) * (KO_NSAMPLES + 2 * KO_NTAPS));
+    /* the replica covers NSAMPLES = DECIM * FFT_LEN samples (:250; gps/gps.h:72-73) */
+    const int nsamples = KO_DECIM * fft_len;
+    ko_cpx *buf = (ko_cpx *) malloc(sizeof(ko_cpx) * ((size_t) nsamples + 2 * KO_NTAPS));
     const float rate = (float) (1.023e6 / 16.368e6);     /* CPS/FS, :205,:306 */
     float ph = *phase;
     int codep = 0, i, n;
-    for (i = 0; i < KO_NSAMPLES; i++) {
+    for (i = 0; i < nsamples; i++) {
         float chip;
         if (!boc) {
             chip = bipolar(chips[codep]);                 /* :252 */
@@ -244,42 +246,55 @@ void ko_code_replica(const uint8_t *chips, int nchips, int boc, float *phase,
         buf[i].re = chip; buf[i].im = 0;
     }
     *phase = ph;
-    n = KO_NSAMPLES;
+    n = nsamples;
     for (i = KO_DECIM; i > 1; i >>= 1) n = ko_decimate_by2_float(n, buf);   /* :273-275 */
-    memcpy(out, buf, sizeof(ko_cpx) * KO_FFT_LEN);
+    memcpy(out, buf, sizeof(ko_cpx) * fft_len);
     free(buf);
+}
+
+void ko_code_replica(const uint8_t *chips, int nchips, int boc, float *phase, ko_cpx *out)
+{
+    ko_code_replica_n(chips, nchips, boc, phase, out, KO_FFT_LEN);
+}
+
+void ko_code_fft_n(const uint8_t *chips, int nchips, int boc, float *phase,
+                   ko_cpx *out, int prec, int fft_len)
+{
+    ko_cpx *td = (ko_cpx *) malloc(sizeof(ko_cpx) * fft_len);
+    ko_code_replica_n(chips, nchips, boc, phase, td, fft_len);
+    ko_fft(fft_len, -1, td, out, prec);                   /* :280 / :342 */
+    free(td);
 }
 
 void ko_code_fft(const uint8_t *chips, int nchips, int boc, float *phase,
                  ko_cpx *out, int prec)
 {
-    ko_cpx *td = (ko_cpx *) malloc(sizeof(ko_cpx) * KO_FFT_LEN);
-    ko_code_replica(chips, nchips, boc, phase, td);
-    ko_fft(KO_FFT_LEN, -1, td, out, prec);                /* :280 / :342 */
-    free(td);
+    ko_code_fft_n(chips, nchips, boc, phase, out, prec, KO_FFT_LEN);
 }
 
-static void finish_sample(ko_cpx *buf, ko_cpx *out, ko_cpx *td, int prec)
+/* buf holds DECIM * fft_len samples, zero from `nsamples` on (the reference's block is full:
+ * nsamples == DECIM * fft_len) */
+static void finish_sample(ko_cpx *buf, ko_cpx *out, ko_cpx *td, int prec, int fft_len)
 {
-    int n = KO_NSAMPLES, i;
+    int n = KO_DECIM * fft_len, i;
     /* DecimateBy2binary's float stage + DecimateBy2float, :437-442 */
     for (i = KO_DECIM; i > 1; i >>= 1) n = ko_decimate_by2_float(n, buf);
-    if (td) memcpy(td, buf, sizeof(ko_cpx) * KO_FFT_LEN);
-    ko_fft(KO_FFT_LEN, -1, buf, out, prec);               /* :447 */
+    if (td) memcpy(td, buf, sizeof(ko_cpx) * fft_len);
+    ko_fft(fft_len, -1, buf, out, prec);                  /* :447 */
 }
 
 /* gps/search.cpp:382-449 */
-void ko_sample_bits(const uint8_t *packed, ko_cpx *out, ko_cpx *td, int prec)
+void ko_sample_bits_n(const uint8_t *packed, ko_cpx *out, ko_cpx *td, int prec, int nsamples, int fft_len)
 {
     static const int lo_sin[4] = {1, 1, 0, 0};            /* :383 */
     static const int lo_cos[4] = {1, 0, 0, 1};            /* :384 */
     const float lo_rate = (float) (4 * 4.092e6 / 16.368e6);     /* :386 */
-    ko_cpx *buf = (ko_cpx *) malloc(sizeof(ko_cpx) * (KO_NSAMPLES + 2 * KO_NTAPS));
+    ko_cpx *buf = (ko_cpx *) calloc((size_t) KO_DECIM * fft_len + 2 * KO_NTAPS, sizeof(ko_cpx));
     float lo_phase = 0;
     int i = 0, j = 0, b;
-    while (i < KO_NSAMPLES) {
+    while (i < nsamples) {
         uint8_t byte = packed[j++];                       /* :408 */
-        for (b = 0; b < 8 && i < KO_NSAMPLES; ++b, ++i, byte >>= 1) {
+        for (b = 0; b < 8 && i < nsamples; ++b, ++i, byte >>= 1) {
             const int bit = byte & 1;                     /* :411 LSB first */
             int bi = bit ^ lo_sin[(int) lo_phase];        /* :419 */
             int bq = bit ^ lo_cos[(int) lo_phase];        /* :420 */
@@ -292,15 +307,20 @@ void ko_sample_bits(const uint8_t *packed, ko_cpx *out, ko_cpx *td, int prec)
             buf[i].im = bipolar(fq >= 0);
         }
     }
-    finish_sample(buf, out, td, prec);
+    finish_sample(buf, out, td, prec, fft_len);
     free(buf);
 }
 
-void ko_sample_iq16(const int16_t *iq, ko_cpx *out, ko_cpx *td, int prec)
+void ko_sample_bits(const uint8_t *packed, ko_cpx *out, ko_cpx *td, int prec)
 {
-    ko_cpx *buf = (ko_cpx *) malloc(sizeof(ko_cpx) * (KO_NSAMPLES + 2 * KO_NTAPS));
+    ko_sample_bits_n(packed, out, td, prec, KO_NSAMPLES, KO_FFT_LEN);
+}
+
+void ko_sample_iq16_n(const int16_t *iq, ko_cpx *out, ko_cpx *td, int prec, int nsamples, int fft_len)
+{
+    ko_cpx *buf = (ko_cpx *) calloc((size_t) KO_DECIM * fft_len + 2 * KO_NTAPS, sizeof(ko_cpx));
     int i;
-    for (i = 0; i < KO_NSAMPLES; i++) {
+    for (i = 0; i < nsamples; i++) {
         float a = (float) iq[2 * i], b = (float) iq[2 * i + 1];
         switch (i & 3) {                                  /* (a+jb)*(-j)^i */
         case 0:  buf[i].re =  a; buf[i].im =  b; break;
@@ -309,19 +329,23 @@ void ko_sample_iq16(const int16_t *iq, ko_cpx *out, ko_cpx *td, int prec)
         default: buf[i].re = -b; buf[i].im =  a; break;
         }
     }
-    finish_sample(buf, out, td, prec);
+    finish_sample(buf, out, td, prec, fft_len);
     free(buf);
+}
+
+void ko_sample_iq16(const int16_t *iq, ko_cpx *out, ko_cpx *td, int prec)
+{
+    ko_sample_iq16_n(iq, out, td, prec, KO_NSAMPLES, KO_FFT_LEN);
 }
 
 /* one (SV, Doppler) cell of the search.cpp:465-496 loop body */
 static ko_acq_cell correlate_cell(const ko_cpx *code, const ko_cpx *data, int limit, int dop,
-                                  ko_cpx *prod, ko_cpx *rev, int prec)
+                                  ko_cpx *prod, ko_cpx *rev, int prec, int N)
 {
-    const int N = KO_FFT_LEN;
     float max_pwr = 0, tot_pwr = 0;                       /* :466 */
     int max_pwr_i = 0, i;
     for (i = 0; i < N; i++) {                             /* :471 = :473-477, simd.cpp:39-67 */
-        int j = (i - dop + N) % N;
+        int j = ((i - dop) % N + N) % N;
         prod[i].re = data[i].re * code[j].re + data[i].im * code[j].im;
         prod[i].im = data[i].re * code[j].im - data[i].im * code[j].re;
     }
@@ -338,16 +362,16 @@ static ko_acq_cell correlate_cell(const ko_cpx *code, const ko_cpx *data, int li
 }
 
 /* gps/search.cpp:453-499 */
-ko_acq_result ko_correlate(const ko_cpx *code, const ko_cpx *data, int limit,
-                           int dop_lo, int dop_hi, ko_acq_cell *cells, int prec)
+ko_acq_result ko_correlate_n(const ko_cpx *code, const ko_cpx *data, int limit,
+                             int dop_lo, int dop_hi, ko_acq_cell *cells, int prec, int fft_len)
 {
-    ko_cpx *prod = (ko_cpx *) malloc(sizeof(ko_cpx) * KO_FFT_LEN);    /* rev_buf, :58,:454 */
-    ko_cpx *rev = (ko_cpx *) malloc(sizeof(ko_cpx) * KO_FFT_LEN);
+    ko_cpx *prod = (ko_cpx *) malloc(sizeof(ko_cpx) * fft_len);       /* rev_buf, :58,:454 */
+    ko_cpx *rev = (ko_cpx *) malloc(sizeof(ko_cpx) * fft_len);
     ko_acq_result r = {0.0f, 0, 0, 0};
     float max_snr = 0;                                    /* :455 */
     int dop;
     for (dop = dop_lo; dop <= dop_hi; dop++) {            /* :465 */
-        const ko_acq_cell c = correlate_cell(code, data, limit, dop, prod, rev, prec);
+        const ko_acq_cell c = correlate_cell(code, data, limit, dop, prod, rev, prec, fft_len);
         if (cells) cells[dop - dop_lo] = c;
         if (c.snr > max_snr) {                            /* :495 */
             max_snr = c.snr; r.dop = dop; r.idx = c.idx; r.valid = 1;
@@ -358,9 +382,15 @@ ko_acq_result ko_correlate(const ko_cpx *code, const ko_cpx *data, int limit,
     return r;
 }
 
+ko_acq_result ko_correlate(const ko_cpx *code, const ko_cpx *data, int limit,
+                           int dop_lo, int dop_hi, ko_acq_cell *cells, int prec)
+{
+    return ko_correlate_n(code, data, limit, dop_lo, dop_hi, cells, prec, KO_FFT_LEN);
+}
+
 typedef struct {
     const ko_cpx *codes, *data; const int *limits; int nsv, dop_lo, dop_hi, prec;
-    ko_acq_cell *cells; int tid, nthreads;
+    ko_acq_cell *cells; int tid, nthreads, fft_len;
 } many_arg;
 
 /* threads take (SV, Doppler) cells round-robin: all host cores stay busy even
@@ -369,34 +399,34 @@ static void *many_worker(void *p)
 {
     many_arg *a = (many_arg *) p;
     const int nd = a->dop_hi - a->dop_lo + 1, ncell = a->nsv * nd;
-    ko_cpx *prod = (ko_cpx *) malloc(sizeof(ko_cpx) * KO_FFT_LEN);
-    ko_cpx *rev = (ko_cpx *) malloc(sizeof(ko_cpx) * KO_FFT_LEN);
+    ko_cpx *prod = (ko_cpx *) malloc(sizeof(ko_cpx) * a->fft_len);
+    ko_cpx *rev = (ko_cpx *) malloc(sizeof(ko_cpx) * a->fft_len);
     int c;
     for (c = a->tid; c < ncell; c += a->nthreads) {
         const int s = c / nd, di = c - s * nd;
-        a->cells[c] = correlate_cell(a->codes + (size_t) s * KO_FFT_LEN, a->data, a->limits[s],
-                                     a->dop_lo + di, prod, rev, a->prec);
+        a->cells[c] = correlate_cell(a->codes + (size_t) s * a->fft_len, a->data, a->limits[s],
+                                     a->dop_lo + di, prod, rev, a->prec, a->fft_len);
     }
     free(prod); free(rev);
     return NULL;
 }
 
-void ko_correlate_many(const ko_cpx *codes, int nsv, const ko_cpx *data,
-                       const int *limits, int dop_lo, int dop_hi,
-                       ko_acq_result *out, ko_acq_cell *cells, int prec,
-                       int nthreads)
+void ko_correlate_many_n(const ko_cpx *codes, int nsv, const ko_cpx *data,
+                         const int *limits, int dop_lo, int dop_hi,
+                         ko_acq_result *out, ko_acq_cell *cells, int prec,
+                         int nthreads, int fft_len)
 {
     const int nd = dop_hi - dop_lo + 1;
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 1024) nthreads = 1024;
     if (nthreads > nsv * nd) nthreads = nsv * nd;
-    { const cpxd *d; const ko_cpx *f; twiddles(KO_FFT_LEN, +1, &d, &f); }  /* warm cache */
+    { const cpxd *d; const ko_cpx *f; twiddles(fft_len, +1, &d, &f); }     /* warm cache */
     ko_acq_cell *cl = cells ? cells : (ko_acq_cell *) malloc(sizeof(ko_acq_cell) * (size_t) nsv * nd);
     pthread_t *th = (pthread_t *) malloc(sizeof(pthread_t) * nthreads);
     many_arg *args = (many_arg *) malloc(sizeof(many_arg) * nthreads);
     int t, s, di;
     for (t = 0; t < nthreads; t++) {
-        many_arg a = { codes, data, limits, nsv, dop_lo, dop_hi, prec, cl, t, nthreads };
+        many_arg a = { codes, data, limits, nsv, dop_lo, dop_hi, prec, cl, t, nthreads, fft_len };
         args[t] = a;
         if (t > 0) pthread_create(&th[t], NULL, many_worker, &args[t]);
     }
@@ -414,4 +444,12 @@ void ko_correlate_many(const ko_cpx *codes, int nsv, const ko_cpx *data,
     }
     if (!cells) free(cl);
     free(th); free(args);
+}
+
+void ko_correlate_many(const ko_cpx *codes, int nsv, const ko_cpx *data,
+                       const int *limits, int dop_lo, int dop_hi,
+                       ko_acq_result *out, ko_acq_cell *cells, int prec,
+                       int nthreads)
+{
+    ko_correlate_many_n(codes, nsv, data, limits, dop_lo, dop_hi, out, cells, prec, nthreads, KO_FFT_LEN);
 }

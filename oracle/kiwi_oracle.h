@@ -111,6 +111,24 @@ void ko_correlate_many(const ko_cpx *codes, int nsv, const ko_cpx *data,
                        ko_acq_result *out, ko_acq_cell *cells, int prec,
                        int nthreads);
 
+/* ---- the same acquisition functions for another shape (BASELINE.json configs[4]) ----
+ * The reference is one shape: NSAMPLES = 65536 = DECIM * FFT_LEN (gps/gps.h:62-73).  The _n
+ * forms restate the same loops with FFT_LEN = fft_len (a power of two) and a sample block of
+ * `nsamples` <= DECIM * fft_len input samples followed by zeros (what DecimateBy2float's
+ * zero tail, search.cpp:145, already is for the last taps); the code replica covers all
+ * DECIM * fft_len samples as the reference's covers NSAMPLES (:250).  configs[4]: nsamples =
+ * 163680 (10 ms at FS), fft_len = 65536.  An extension beyond the reference: PARITY UNPINNED
+ * by nature; the un-suffixed functions are these with (65536, 16384). */
+void ko_code_replica_n(const uint8_t *chips, int nchips, int boc, float *phase, ko_cpx *out, int fft_len);
+void ko_code_fft_n(const uint8_t *chips, int nchips, int boc, float *phase, ko_cpx *out, int prec, int fft_len);
+void ko_sample_bits_n(const uint8_t *packed, ko_cpx *out, ko_cpx *td, int prec, int nsamples, int fft_len);
+void ko_sample_iq16_n(const int16_t *iq, ko_cpx *out, ko_cpx *td, int prec, int nsamples, int fft_len);
+ko_acq_result ko_correlate_n(const ko_cpx *code, const ko_cpx *data, int limit, int dop_lo, int dop_hi,
+                             ko_acq_cell *cells, int prec, int fft_len);
+void ko_correlate_many_n(const ko_cpx *codes, int nsv, const ko_cpx *data, const int *limits, int dop_lo,
+                         int dop_hi, ko_acq_result *out, ko_acq_cell *cells, int prec, int nthreads,
+                         int fft_len);
+
 /* ---- waterfall (rx/rx_waterfall.cpp) ---------------------------------------- */
 #define KO_WF_NFFT  8192         /* rx/rx_waterfall.h:61-62 WF_C_NFFT = WF_C_NSAMPS */
 #define KO_WF_WIDTH 1024         /* rx/rx_waterfall.h:65 */
@@ -220,6 +238,7 @@ typedef struct {                          /* agc.h:30-64 */
 } ko_agc_state;
 size_t ko_agc_state_size(void);
 void ko_agc_init(ko_agc_state *s);
+int ko_agc_delay(const ko_agc_state *s);                  /* CAgc::GetDelaySamples(), agc.h:27 */
 void ko_agc_set_parameters(ko_agc_state *s, int agc_on, int use_hang, int threshold, int manual_gain,
                            int slope_factor, int decay, float sample_rate);
 void ko_agc_process_cpx(ko_agc_state *s, int n, const ko_cpx *in, ko_cpx *out);

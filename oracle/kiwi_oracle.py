@@ -70,6 +70,14 @@ def lib():
         L.ko_correlate.restype = AcqResult
         L.ko_correlate_many.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp,
                                         C.c_int, C.c_int]
+        L.ko_code_fft_n.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), vp, C.c_int, C.c_int]
+        L.ko_code_replica_n.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), vp, C.c_int]
+        L.ko_sample_bits_n.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int]
+        L.ko_sample_iq16_n.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int]
+        L.ko_correlate_n.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int]
+        L.ko_correlate_n.restype = AcqResult
+        L.ko_correlate_many_n.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp,
+                                          C.c_int, C.c_int, C.c_int]
         L.ko_wf_window.argtypes = [C.c_int, vp]
         L.ko_wf_cic_comp.argtypes = [vp]
         L.ko_wf_params_for.argtypes = [C.c_int, C.c_float, C.c_double, C.c_double, C.c_int, vp]
@@ -114,46 +122,55 @@ def decimate_by2(x):
     return buf[:n].copy()
 
 
-def code_fft(chips, boc=False, prec=1, phase=0.0):
+# Shape arguments (nsamples, fft_len): the reference's (65536, 16384) by default; the _n entry
+# points restate the same loops for BASELINE configs[4]'s (163680, 65536).
+NSAMPLES_10MS, FFT_LEN_10MS = 163680, 65536
+
+
+def code_fft(chips, boc=False, prec=1, phase=0.0, fft_len=FFT_LEN):
     chips = np.ascontiguousarray(chips, np.uint8)
-    out = np.empty(FFT_LEN, cpx)
+    out = np.empty(fft_len, cpx)
     ph = C.c_float(phase)
-    lib().ko_code_fft(_p(chips), chips.size, int(bool(boc)), C.byref(ph), _p(out), int(prec))
+    lib().ko_code_fft_n(_p(chips), chips.size, int(bool(boc)), C.byref(ph), _p(out), int(prec), int(fft_len))
     return out
 
 
-def code_replica(chips, boc=False, phase=0.0):
+def code_replica(chips, boc=False, phase=0.0, fft_len=FFT_LEN):
     chips = np.ascontiguousarray(chips, np.uint8)
-    out = np.empty(FFT_LEN, cpx)
+    out = np.empty(fft_len, cpx)
     ph = C.c_float(phase)
-    lib().ko_code_replica(_p(chips), chips.size, int(bool(boc)), C.byref(ph), _p(out))
+    lib().ko_code_replica_n(_p(chips), chips.size, int(bool(boc)), C.byref(ph), _p(out), int(fft_len))
     return out, ph.value
 
 
-def sample_bits(packed, prec=1, want_td=False):
+def sample_bits(packed, prec=1, want_td=False, nsamples=NSAMPLES, fft_len=FFT_LEN):
     packed = np.ascontiguousarray(packed, np.uint8)
-    assert packed.size == NSAMPLES // 8
-    out = np.empty(FFT_LEN, cpx)
-    td = np.empty(FFT_LEN, cpx) if want_td else None
-    lib().ko_sample_bits(_p(packed), _p(out), _p(td) if want_td else None, int(prec))
+    assert packed.size == nsamples // 8 and nsamples <= DECIM * fft_len
+    out = np.empty(fft_len, cpx)
+    td = np.empty(fft_len, cpx) if want_td else None
+    lib().ko_sample_bits_n(_p(packed), _p(out), _p(td) if want_td else None, int(prec), int(nsamples),
+                           int(fft_len))
     return (out, td) if want_td else out
 
 
-def sample_iq16(iq, prec=1, want_td=False):
+def sample_iq16(iq, prec=1, want_td=False, nsamples=NSAMPLES, fft_len=FFT_LEN):
     iq = np.ascontiguousarray(iq, np.int16).reshape(-1)
-    assert iq.size == 2 * NSAMPLES
-    out = np.empty(FFT_LEN, cpx)
-    td = np.empty(FFT_LEN, cpx) if want_td else None
-    lib().ko_sample_iq16(_p(iq), _p(out), _p(td) if want_td else None, int(prec))
+    assert iq.size == 2 * nsamples and nsamples <= DECIM * fft_len
+    out = np.empty(fft_len, cpx)
+    td = np.empty(fft_len, cpx) if want_td else None
+    lib().ko_sample_iq16_n(_p(iq), _p(out), _p(td) if want_td else None, int(prec), int(nsamples),
+                           int(fft_len))
     return (out, td) if want_td else out
 
 
 def correlate(code, data, limit=L1_LIMIT, dop_lo=DOP_LO, dop_hi=DOP_HI, prec=1):
-    """-> (result dict, cells structured array[dop_hi-dop_lo+1])"""
+    """-> (result dict, cells structured array[dop_hi-dop_lo+1]); the transform length is code.size"""
     code = np.ascontiguousarray(code, cpx)
     data = np.ascontiguousarray(data, cpx)
+    assert code.size == data.size
     cells = np.zeros(dop_hi - dop_lo + 1, cell_dtype)
-    r = lib().ko_correlate(_p(code), _p(data), int(limit), dop_lo, dop_hi, _p(cells), int(prec))
+    r = lib().ko_correlate_n(_p(code), _p(data), int(limit), dop_lo, dop_hi, _p(cells), int(prec),
+                             int(code.size))
     return dict(snr=r.snr, dop=r.dop, idx=r.idx, valid=r.valid), cells
 
 
@@ -162,12 +179,13 @@ def correlate_many(codes, data, limits, dop_lo=DOP_LO, dop_hi=DOP_HI, prec=1, nt
     codes = np.ascontiguousarray(codes, cpx)
     data = np.ascontiguousarray(data, cpx)
     nsv = codes.shape[0]
+    assert codes.shape[1] == data.size
     limits = np.ascontiguousarray(limits, np.int32)
     nd = dop_hi - dop_lo + 1
     out = np.zeros(nsv, result_dtype)
     cells = np.zeros((nsv, nd), cell_dtype) if want_cells else None
-    lib().ko_correlate_many(_p(codes), nsv, _p(data), _p(limits), dop_lo, dop_hi, _p(out),
-                            _p(cells) if want_cells else None, int(prec), int(nthreads))
+    lib().ko_correlate_many_n(_p(codes), nsv, _p(data), _p(limits), dop_lo, dop_hi, _p(out),
+                              _p(cells) if want_cells else None, int(prec), int(nthreads), int(data.size))
     return out, cells
 
 
@@ -340,6 +358,9 @@ class Agc:
         L.ko_agc_set_parameters.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_float]
         L.ko_agc_set_parameters(self._buf, int(agc_on), int(use_hang), int(threshold), int(manual_gain),
                                 int(slope), int(decay), float(sample_rate))
+
+    def delay(self):
+        return int(lib().ko_agc_delay(self._buf))
 
     def process_cpx(self, x):
         x = np.ascontiguousarray(x, cpx)

@@ -9,9 +9,12 @@
  * TYPEREAL is float (datatypes.h:18,46); literals such as 1.0, 0.5, 10.0, 1e-16 are
  * double, so the reference's expressions mix float and double and round to float on
  * assignment.  Every expression below keeps the operand types of the line it cites.
- * PARITY UNPINNED: agc.h includes kiwi.h -> kiwi.gen.h (generated, absent), so the
- * reference's own object cannot be built here, and the reference holds no vectors for
- * these functions.  Transcendentals are this host's libm (log10f, powf, expf).
+ * CAgc: PINNED -- rx/CuteSDR/agc.cpp is built from its own source against the kiwi.gen.h the
+ * reference's assembler generates (oracle/build_ref.sh) and tests/golden/agc_ref.npz holds its
+ * outputs; tests/test_ref_pins_cpu.py requires this restatement to reproduce them bit for bit.
+ * S-meter and the AM / NBFM detectors live inside c2s_sound() (rx/rx_sound.cpp), which does not
+ * link without the task / SPI runtime: PARITY UNPINNED.  Transcendentals are this host's libm
+ * (log10f, powf, expf).
  */
 #include "kiwi_oracle.h"
 
@@ -29,6 +32,7 @@
 #define MAX_MANUAL_AMPLITUDE 32767.0    /* :67 */
 
 size_t ko_agc_state_size(void) { return sizeof(ko_agc_state); }
+int ko_agc_delay(const ko_agc_state *s) { return s->delay_samples; }     /* GetDelaySamples(), agc.h:27 */
 
 /* agc.cpp:77-86.  The reference leaves the dynamic state (averagers, buffers) unset
  * until the first SetParameters() with a sample rate other than 100.0; the oracle

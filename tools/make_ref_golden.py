@@ -1,0 +1,161 @@
+"""Generates tests/golden/*_ref.* from the REFERENCE ITSELF (run in the build container, where
+/root/reference is mounted and `make -C oracle` has built oracle/_ref/ from the reference's own
+sources, see oracle/build_ref.sh).  What is committed is data: inputs made here from fixed seeds and
+the outputs the reference's code produced for them.
+
+  e1b_ref.npz     the 50 Galileo E1-B memory codes: the ICD hex strings (data table of
+                  gps/e1bcode.h) and the chips E1BCODE(prn) of that header produces
+  consts_ref.json the constants of gps/gps.h, kiwi.h and the generated kiwi.gen.h
+  cic_ref.json    register widths / truncations / output slices verilog/rx/cic_gen.c emits for every
+                  CIC instance of kiwi.config (rx1 std + wide, rx2 std + wide, wf1)
+  agc_ref.npz     CAgc (rx/CuteSDR/agc.cpp): SetParameters / ProcessData scripts, inputs, outputs
+  adpcm_ref.npz   rx/csdr/ima_adpcm.cpp: i16 and u8 coder + decoder, inputs, outputs, end states
+"""
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref")
+GOLD = os.path.join(ROOT, "tests", "golden")
+REFERENCE = os.environ.get("REFERENCE", "/root/reference")
+
+
+def run(args, stdin=None):
+    p = subprocess.run(args, input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+    return p.stdout, p.stderr
+
+
+# ---- E1B ----------------------------------------------------------------------------------
+out, _ = run([os.path.join(REF, "e1b_ref")])
+chips = np.zeros((50, 4092), np.uint8)
+for line in out.decode().splitlines():
+    prn, bits = line.split()
+    chips[int(prn) - 1] = np.frombuffer(bits.encode(), np.uint8) - ord("0")
+hexes = re.findall(r'"([0-9A-F]{1023})"', open(os.path.join(REFERENCE, "gps", "e1bcode.h")).read())
+assert len(hexes) == 50
+np.savez_compressed(os.path.join(GOLD, "e1b_ref.npz"), chips_packed=np.packbits(chips, axis=1),
+                    hex=np.array(hexes))
+print("e1b_ref.npz: 50 codes, E01 first 20 chips 0x%x" % int("".join(map(str, chips[0, :20])), 2))
+
+# ---- constants ----------------------------------------------------------------------------
+out, _ = run([os.path.join(REF, "gpsconst_ref")])
+consts = json.loads(out.decode())
+consts.pop("_")
+json.dump(consts, open(os.path.join(GOLD, "consts_ref.json"), "w"), indent=1, sort_keys=True)
+print("consts_ref.json: %d constants" % len(consts))
+
+# ---- CIC shapes ---------------------------------------------------------------------------
+cic = {}
+for name in ("cic_rx1_12k", "cic_rx1_20k", "cic_rx2_12k", "cic_rx2_20k", "cic_wf1"):
+    text = open(os.path.join(REF, "cic", name + ".vh")).read()
+    m = re.search(r"N=(\d+) R=(\d+) M=1 Bin=(\d+) Bout=(\d+)", text)
+    n, r, bin_, bout = map(int, m.groups())
+    acc = int(re.search(r"acc_max (\d+)", text).group(1))
+    integ = [int(h) + 1 for h in re.findall(r"wire signed \[(\d+):0\] integrator[1-9]\d*_data", text)]
+    comb = [int(h) + 1 for h in re.findall(r"wire signed \[(\d+):0\] comb[1-9]\d*_data", text)]
+    comb0 = int(re.search(r"wire signed \[(\d+):0\] comb0_data", text).group(1)) + 1
+    trunc = [int(t) for t in re.findall(r"// trunc (\d+) bits", text)]
+    # "out = combN[hi -: w] + combN[round_bit]", or without the rounding term when nothing is dropped
+    o = re.search(r"assign out = comb(\d+)_data\[(\d+) -:(\d+)\](?: \+ comb\d+_data\[(\d+)\])?", text)
+    cic[name] = {"N": n, "R": r, "Bin": bin_, "Bout": bout, "acc": acc, "integrators": integ,
+                 "comb0": comb0, "combs": comb, "trunc": trunc,
+                 "out": [int(x) if x is not None else -1 for x in o.groups()]}
+json.dump(cic, open(os.path.join(GOLD, "cic_ref.json"), "w"), indent=1, sort_keys=True)
+for k, v in cic.items():
+    print("cic_ref.json:", k, v)
+
+# ---- CAgc ---------------------------------------------------------------------------------
+rng = np.random.Generator(np.random.PCG64(0x5EED00A6))
+
+
+def envelope(kind, n):
+    t = np.arange(n)
+    if kind == "steps":
+        e = np.where((t // 700) % 2 == 0, 3000.0, 30.0)
+    elif kind == "decay":
+        e = 20000.0 * np.exp(-t / 900.0) + 5.0
+    elif kind == "silence":
+        e = np.where(t < n // 3, 800.0, 0.0)
+    elif kind == "ties":
+        e = np.full(n, 1000.0)
+    else:
+        e = 10.0 ** rng.uniform(0.5, 4.3, n)
+    ph = np.cumsum(rng.uniform(0.1, 0.5, n))
+    x = e * np.exp(1j * ph) + (0 if kind == "ties" else 1) * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    return x.astype(np.complex64)
+
+
+scenarios = [
+    # (name, script lines; C/M lengths consume the input in order)
+    ("agc_slow_cpx_steps", "steps", ["P 1 0 -100 50 6 1000 12000", "D"] + ["C 512"] * 4),
+    ("agc_fast_s16_decay", "decay", ["P 1 0 -90 50 4 250 12000"] + ["M 512"] * 4),
+    ("agc_hang_s16_steps", "steps", ["P 1 1 -100 50 6 500 12000", "D"] + ["M 512"] * 4),
+    ("manual_gain_cpx", "noise", ["P 0 0 -100 70 6 1000 12000"] + ["C 512"] * 2),
+    ("wide_rate_s16_silence", "silence", ["P 1 0 -100 50 6 1000 20250", "D"] + ["M 512"] * 4),
+    ("retune_sequence", "noise", ["P 1 0 -100 50 6 1000 12000", "C 512", "P 1 0 -100 50 6 1000 12000", "C 300",
+                                  "P 1 0 -80 50 2 100 12000", "C 212", "P 0 0 -80 35 2 100 12000", "M 512",
+                                  "P 1 1 -110 35 10 2000 20250", "D", "M 512", "C 1"]),
+    ("exact_ties_cpx", "ties", ["P 1 0 -100 50 6 1000 12000"] + ["C 512"] * 2),
+]
+agc = {}
+with tempfile.TemporaryDirectory() as tmp:
+    for name, kind, script in scenarios:
+        n = sum(int(l.split()[1]) for l in script if l[0] in "CM")
+        x = envelope(kind, n)
+        open(os.path.join(tmp, "s.txt"), "w").write("\n".join(script) + "\n")
+        x.tofile(os.path.join(tmp, "in.bin"))
+        run([os.path.join(REF, "agc_ref"), os.path.join(tmp, "s.txt"), os.path.join(tmp, "in.bin"),
+             os.path.join(tmp, "out.bin")])
+        y = np.fromfile(os.path.join(tmp, "out.bin"), np.float32)
+        agc[name + "_script"] = np.array(script)
+        agc[name + "_in"] = x
+        agc[name + "_out"] = y
+        print("agc_ref.npz: %-24s %5d samples in, %5d floats out" % (name, n, y.size))
+agc["names"] = np.array([s[0] for s in scenarios])
+np.savez_compressed(os.path.join(GOLD, "agc_ref.npz"), **agc)
+
+# ---- IMA ADPCM ------------------------------------------------------------------------------
+rng = np.random.Generator(np.random.PCG64(0x5EED00AD))
+t = np.arange(4096)
+sig = np.concatenate([
+    8000.0 * np.sin(2 * np.pi * 0.013 * t) + 200.0 * rng.standard_normal(t.size),
+    np.where((t // 37) % 2 == 0, 32767.0, -32768.0),           # full-scale square wave
+    np.zeros(t.size),                                            # silence
+    rng.integers(-32768, 32768, t.size).astype(np.float64),     # white, full range
+]).round().clip(-32768, 32767).astype(np.int16)
+ad = {"i16_in": sig}
+enc, err = run([os.path.join(REF, "adpcm_ref"), "enc_i16", "0", "0", "512"], sig.tobytes())
+ad["i16_enc"] = np.frombuffer(enc, np.uint8)
+ad["i16_enc_state"] = np.array([int(v) for v in err.split()], np.int32)
+dec, err = run([os.path.join(REF, "adpcm_ref"), "dec_i16", "0", "0", "256"], enc)
+ad["i16_dec"] = np.frombuffer(dec, np.int16)
+ad["i16_dec_state"] = np.array([int(v) for v in err.split()], np.int32)
+# resumed state (the audio_adpcm_state message), odd block length
+enc2, err = run([os.path.join(REF, "adpcm_ref"), "enc_i16", "37", "-1234", "170"], sig[:3400].tobytes())
+ad["i16_enc_resumed"] = np.frombuffer(enc2, np.uint8)
+ad["i16_enc_resumed_state"] = np.array([int(v) for v in err.split()], np.int32)
+rows = np.stack([
+    np.clip(120 + 60 * np.sin(2 * np.pi * np.arange(1024) / 200.0) + rng.normal(0, 8, 1024), 0, 255),
+    rng.integers(0, 256, 1024).astype(np.float64),
+    np.full(1024, 55.0),
+    np.where(np.arange(1024) % 2 == 0, 255.0, 0.0),
+]).round().astype(np.uint8)
+ad["u8_rows"] = rows
+u8enc, u8dec = [], []
+for r in rows:
+    # compute_frame(): 10 pad bytes (copies of the first pixel) + the row, fresh state per row
+    padded = np.concatenate([np.full(10, r[0], np.uint8), r])
+    e, _ = run([os.path.join(REF, "adpcm_ref"), "enc_u8", "0", "0", "1034"], padded.tobytes())
+    u8enc.append(np.frombuffer(e, np.uint8))
+    d, _ = run([os.path.join(REF, "adpcm_ref"), "dec_u8", "0", "0", "517"], e)
+    u8dec.append(np.frombuffer(d, np.uint8))
+ad["u8_enc"] = np.stack(u8enc)
+ad["u8_dec"] = np.stack(u8dec)
+np.savez_compressed(os.path.join(GOLD, "adpcm_ref.npz"), **ad)
+print("adpcm_ref.npz: %d int16 samples, %d rows; end state %s" % (sig.size, rows.shape[0], ad["i16_enc_state"]))
