@@ -50,9 +50,14 @@ def gps_scene_iq16(svs, seed, cn0_dbhz=45.0, n=NSAMPLES, scale=2048.0):
     x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) / np.sqrt(2.0)
     for sv in svs:
         chips, tau, fd, theta = sv[:4]
-        cn0 = sv[4] if len(sv) > 4 else cn0_dbhz
+        cn0 = sv[4] if len(sv) > 4 and sv[4] is not None else cn0_dbhz
+        boc = sv[5] if len(sv) > 5 else False
         a = np.sqrt(10.0 ** (cn0 / 10.0) / FS)
-        x = x + a * _code_wave(chips, tau, n) * np.exp(1j * (2 * np.pi * (FC + fd) * t / FS + theta))
+        code = _code_wave(chips, tau, n)
+        if boc:                                       # BOC(1,1): second half of every chip inverted
+            sub = (np.arange(n) * (CPS / FS) + tau) % 1.0 >= 0.5
+            code = code * np.where(sub, -1.0, 1.0)
+        x = x + a * code * np.exp(1j * (2 * np.pi * (FC + fd) * t / FS + theta))
     iq = np.empty(2 * n, np.int16)
     iq[0::2] = np.clip(np.rint(scale * x.real), -32768, 32767)
     iq[1::2] = np.clip(np.rint(scale * x.imag), -32768, 32767)
@@ -77,6 +82,47 @@ def config0_bits(seed=0x5EED0001):
     """BASELINE.json configs[0]: PRN1 at tau = 300.5 chips, +1500 Hz, theta 0.7, 45 dB-Hz."""
     _, t1, t2, _ = _sats.SATS[0]
     return gps_scene_bits([(_prn.cacode(t1, t2), 300.5, 1500.0, 0.7)], seed, 45.0)
+
+
+# BASELINE.json configs[4]: joint L1 C/A (+ QZSS) and Galileo E1B search on a 10 ms block
+# (163680 samples at FS), 65536-point transforms, Doppler bin 4.092e6 / 65536 = 62.44 Hz.
+NSAMPLES_10MS = 163680
+BIN_10MS = 4.092e6 / 65536
+# (index into sats.SATS, code phase in chips, Doppler in Hz, carrier phase, C/N0 dB-Hz)
+CONFIG4_PRESENT = [(0, 300.5, 1500.0, 0.7, 41.0), (6, 911.0, 7300.0, 0.1, 40.0), (13, 71.5, -250.0, 4.0, 39.0),
+                   (21, 640.0, -7800.0, 3.3, 42.0), (29, 222.625, -3300.0, 1.2, 40.0),
+                   (32, 800.5, 2600.0, 1.0, 41.0),                     # QZSS 194
+                   (37, 1500.25, 3900.0, 2.2, 42.0), (45, 3333.5, -5100.0, 5.0, 43.0),   # E1B E03, E13
+                   (58, 12.0, 60.0, 0.3, 42.0)]                        # E1B E36
+
+
+def e1b_chips_fixture(path=None):
+    """{prn: chips uint8[4092]} from tests/golden/e1b_ref.npz: the 50 Galileo E1-B memory codes as the
+    reference's own gps/e1bcode.h produced them (tools/make_ref_golden.py).  Input data for tests
+    and bench.py; in a deployment the caller hands over its own table."""
+    import os
+    if path is None:
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                            "e1b_ref.npz")
+    g = np.load(path)
+    chips = np.unpackbits(g["chips_packed"], axis=1)[:, :4092]
+    return {i + 1: chips[i].copy() for i in range(chips.shape[0])}
+
+
+def all_sv_codes(e1b=None):
+    """[(chips, boc)] for every row of sats.SATS (36 C/A + QZSS rows, 23 E1B rows)."""
+    e1b = e1b if e1b is not None else e1b_chips_fixture()
+    out = []
+    for prn, t1, t2, kind in _sats.SATS:
+        out.append((e1b[prn], True) if kind == _sats.E1B else (_prn.cacode(t1, t2), False))
+    return out
+
+
+def config4_iq16(seed=0x5EED0005, codes=None, present=CONFIG4_PRESENT):
+    """One 10 ms block of complex int16 IF samples holding the SVs of CONFIG4_PRESENT."""
+    codes = codes if codes is not None else all_sv_codes()
+    svs = [(codes[sat][0], tau, fd, th, cn0, codes[sat][1]) for sat, tau, fd, th, cn0 in present]
+    return gps_scene_iq16(svs, seed, n=NSAMPLES_10MS)
 
 
 def wf_iq_frame(seed, tones=((0.05, -20.0), (0.21, -55.0), (0.33, -80.0)), noise_dbfs=-70.0,

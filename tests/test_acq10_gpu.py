@@ -1,0 +1,150 @@
+"""GPU parity for BASELINE.json configs[4]: joint GPS L1 C/A (+ QZSS) and Galileo E1B acquisition,
+10 ms coherent (163680 samples at FS), 65536-point transforms, 256 Doppler bins (-128..127 at
+62.44 Hz), all 59 SVs of the satellite table.  An extension beyond the reference (which is one
+shape: 4 ms / 16384 points / 41 bins): the checker is the oracle's `_n` restatement of the same
+loops at the larger shape, end to end from the int16 samples (never the GPU's own spectra).
+
+Bars: decimated samples bit-exact; spectra <= 1e-5 of the spectrum's max; every (SV, bin) cell's
+peak index identical, max/total power <= 1e-5, snr <= 2e-5; winners identical."""
+import os
+
+import numpy as np
+import pytest
+
+from flydog_sdr_gps_amd import Searcher, acq, sats, synth
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+N10, FFT10 = acq.NSAMPLES_10MS, acq.FFT_LEN_10MS
+DOP_LO, DOP_HI = -128, 127
+
+
+def relmax(a, b):
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+@pytest.fixture(scope="module")
+def codes():
+    return synth.all_sv_codes()
+
+
+@pytest.fixture(scope="module")
+def searcher10(gpu_ctx, codes):
+    s = Searcher(gpu_ctx, dop_lo=DOP_LO, dop_hi=DOP_HI, max_blocks=2, nsamples=N10, fft_len=FFT10)
+    for sat, (chips, boc) in enumerate(codes):
+        s.set_code(sat, chips, boc=boc)
+    yield s
+    s.close()
+
+
+@pytest.fixture(scope="module")
+def oracle_codes(oracle, codes):
+    return np.stack([oracle.code_fft(chips, boc=boc, fft_len=FFT10) for chips, boc in codes])
+
+
+def test_shape_accessors_and_rejections(gpu_ctx, searcher10):
+    from flydog_sdr_gps_amd import KiwiGpuError
+    assert searcher10.lib.kg_acq_nsamples(searcher10.h) == N10
+    assert searcher10.lib.kg_acq_fft_len(searcher10.h) == FFT10
+    with pytest.raises(KiwiGpuError):
+        Searcher(gpu_ctx, nsamples=N10, fft_len=32768)          # only 16384 and 65536 exist
+    with pytest.raises(KiwiGpuError):
+        Searcher(gpu_ctx, nsamples=4 * 65536 + 8, fft_len=FFT10)
+    with pytest.raises(ValueError):
+        searcher10.sample_iq16(np.zeros(2 * 65536, np.int16))    # a 4 ms block is the wrong size here
+
+
+def test_code_tables_65536(searcher10, oracle_codes):
+    for sat in (0, 31, 32, 35, 36, 58):          # Navstar, QZSS, E1B (BOC)
+        assert relmax(searcher10.get_code_fft(sat), oracle_codes[sat]) < RTOL
+
+
+def test_sample_10ms_iq16_and_bits(searcher10, oracle, codes):
+    iq = synth.config4_iq16(codes=codes)
+    searcher10.sample_iq16(iq)
+    want, td = oracle.sample_iq16(iq, want_td=True, nsamples=N10, fft_len=FFT10)
+    got_td = searcher10.get_data_td()
+    assert np.array_equal(got_td.view(np.uint32), td.view(np.uint32))
+    assert np.all(got_td[N10 // 4 + 32:] == 0)                   # the zero padding
+    assert relmax(searcher10.get_data_fft(), want) < RTOL
+    chips, _ = codes[0]
+    bits = synth.gps_scene_bits([(chips, 100.25, 700.0, 0.3)], seed=7, n=N10)
+    assert bits.size == N10 // 8
+    searcher10.sample(bits, block=1)
+    want, td = oracle.sample_bits(bits, want_td=True, nsamples=N10, fft_len=FFT10)
+    assert np.array_equal(searcher10.get_data_td(1).view(np.uint32), td.view(np.uint32))
+    assert relmax(searcher10.get_data_fft(1), want) < RTOL
+    res, _ = searcher10.correlate_many([0], first_block=1)
+    w, _ = oracle.correlate(oracle.code_fft(chips, fft_len=FFT10), want, dop_lo=DOP_LO, dop_hi=DOP_HI)
+    assert (int(res[0, 0]["dop"]), int(res[0, 0]["idx"])) == (w["dop"], w["idx"]) == (11, 401)
+
+
+def test_config4_all_59_svs_256_bins(searcher10, oracle, codes, oracle_codes):
+    """Every one of the 59 x 256 = 15104 cells against the oracle chain run from the samples."""
+    iq = synth.config4_iq16(codes=codes)
+    searcher10.sample_iq16(iq)
+    svs = list(range(len(codes)))
+    res, cells = searcher10.correlate_many(svs)
+    data = oracle.sample_iq16(iq, nsamples=N10, fft_len=FFT10)
+    limits = [sats.E1B_LIMIT if boc else sats.L1_LIMIT for _, boc in codes]
+    want, wcells = oracle.correlate_many(oracle_codes, data, limits, dop_lo=DOP_LO, dop_hi=DOP_HI,
+                                         nthreads=max(1, len(os.sched_getaffinity(0))))
+    np.testing.assert_allclose(cells[0]["max_pwr"], wcells["max_pwr"], rtol=RTOL)
+    np.testing.assert_allclose(cells[0]["tot_pwr"], wcells["tot_pwr"], rtol=RTOL)
+    np.testing.assert_allclose(cells[0]["snr"], wcells["snr"], rtol=2 * RTOL)
+    assert np.array_equal(cells[0]["idx"], wcells["idx"])            # bit-exact peak index, all cells
+    assert np.array_equal(res[0]["dop"], want["dop"])
+    assert np.array_equal(res[0]["idx"], want["idx"])
+    assert np.array_equal(res[0]["valid"], want["valid"])
+    np.testing.assert_allclose(res[0]["snr"], want["snr"], rtol=2 * RTOL)
+    found = {s for s in svs if res[0, s]["snr"] >= acq.MIN_SIG}
+    assert found == {p[0] for p in synth.CONFIG4_PRESENT}
+    for sat, tau, fd, _, _ in synth.CONFIG4_PRESENT:
+        r = res[0, sat]
+        assert abs(int(r["dop"]) - fd / synth.BIN_10MS) <= 1.0
+        assert abs(int(r["idx"]) - tau * 4) <= 1
+
+
+def test_injected_spectrum_and_shift_edges_65536(searcher10, oracle_codes, oracle):
+    """data = code shifted by d bins and advanced by `delay` samples -> the peak comes back at
+    exactly (d, delay): the Doppler-bin edges, the 4096-sample quarter edges of the E1B window,
+    the plane wrap (d = +-16 k)."""
+    n = np.arange(FFT10)
+    for sat, cases in ((4, ((-128, 0), (127, 4091), (16, 17), (-16, 2048), (-1, 1))),
+                       (40, ((-128, 16367), (127, 4096), (0, 8191), (33, 12288), (-47, 4095)))):
+        code = oracle_codes[sat]
+        limit = sats.E1B_LIMIT if sat >= 36 else sats.L1_LIMIT
+        for d, delay in cases:
+            data = (np.roll(code, d) * np.exp(2j * np.pi * n * delay / FFT10)).astype(np.complex64)
+            searcher10.set_data_fft(data)
+            res, cells = searcher10.correlate_many([sat])
+            assert (int(res[0, 0]["dop"]), int(res[0, 0]["idx"])) == (d, delay)
+            w, wcells = oracle.correlate(code, data, limit=limit, dop_lo=d, dop_hi=d)
+            assert (w["dop"], w["idx"]) == (d, delay)
+            np.testing.assert_allclose(cells[0, 0]["max_pwr"][d - DOP_LO], wcells["max_pwr"][0], rtol=RTOL)
+            np.testing.assert_allclose(cells[0, 0]["tot_pwr"][d - DOP_LO], wcells["tot_pwr"][0], rtol=RTOL)
+
+
+def test_two_blocks_per_sv_calls_and_zero_input(searcher10, oracle, codes, oracle_codes):
+    """Two resident 10 ms blocks in one launch; then the reference's calling pattern -- one SV per
+    Correlate() call, the list changing every time (no call may disturb another's tables)."""
+    iqs = [synth.config4_iq16(seed=900 + b, codes=codes) for b in range(2)]
+    for b in range(2):
+        searcher10.sample_iq16(iqs[b], block=b)
+    svs = [0, 36, 21, 45, 5]
+    res, _ = searcher10.correlate_many(svs, nblocks=2, want_cells=False)
+    limits = [sats.E1B_LIMIT if codes[s][1] else sats.L1_LIMIT for s in svs]
+    for b in range(2):
+        data = oracle.sample_iq16(iqs[b], nsamples=N10, fft_len=FFT10)
+        want, _ = oracle.correlate_many(oracle_codes[svs], data, limits, dop_lo=DOP_LO, dop_hi=DOP_HI,
+                                        nthreads=max(1, len(os.sched_getaffinity(0))), want_cells=False)
+        assert np.array_equal(res[b]["dop"], want["dop"]) and np.array_equal(res[b]["idx"], want["idx"])
+        np.testing.assert_allclose(res[b]["snr"], want["snr"], rtol=2 * RTOL)
+        if b == 0:
+            for k, sv in enumerate(svs):                       # per-SV calls, block 0
+                one, _ = searcher10.correlate_many([sv], want_cells=False)
+                assert (one[0, 0]["dop"], one[0, 0]["idx"]) == (want["dop"][k], want["idx"][k])
+    searcher10.set_data_fft(np.zeros(FFT10, np.complex64))
+    res, _ = searcher10.correlate_many([0, 36])
+    assert np.all(res["valid"] == 0) and np.all(res["snr"] == 0)

@@ -109,7 +109,7 @@ def test_config1_32sv_41bins(searcher, navstar_codes, oracle):
     searcher.sample_iq16(iq)
     svs = list(range(32))
     res, cells = searcher.correlate_many(svs)
-    data = searcher.get_data_fft()          # same data spectrum on both sides
+    data = oracle.sample_iq16(iq)           # the oracle chain end to end, from the int16 samples
     codes = np.stack([navstar_codes[s] for s in svs])
     want, wcells = oracle.correlate_many(codes, data, [L1] * 32, nthreads=8)
     assert np.array_equal(res[0]["dop"], want["dop"])
