@@ -1,28 +1,42 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the MI355X acquisition hot path.
+"""bench.py -- the headline benchmark of the MI355X DSP hot path (BASELINE.json's metric:
+"IQ Msamples/s ingested (waterfall + GPS acq)").
 
-Workload (BASELINE.json configs[1]): 32 GPS L1 C/A SVs x 41 Doppler bins, 4 ms
-coherent FFT correlation on synthetic int16 IQ (65536 samples @ 16.368 MS/s),
-the sample block already resident in HBM.  One step = Sample() front end
-(mix, 2x half-band /2, 16384-pt FFT) + Correlate() for all 32 SVs x 41 bins +
-best-bin selection, for --blocks independent 4 ms sample blocks (default 32: a
-128 ms / 8 MiB batch of the IQ stream per step; --blocks 1 is the single-block latency case).
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload W] [--no-cpu]
 
-Metric: IQ Msamples/s ingested = blocks * 65536 * steps * n_gpus / seconds.
-Multi-GPU (weak scaling): every rank searches its own resident block(s); there
-is no data-path collective; results are all-gathered over RCCL
-after the timed region.
+With --gpus N > 1 (and no WORLD_SIZE in the environment) this process only LAUNCHES: it starts N
+rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, one per GPU), relays
+rank 0's JSON line and exits with the first non-zero return code.  It never touches the GPU or
+imports torch itself.  Started by `python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N`, it is a rank; --gpus must then equal WORLD_SIZE.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--blocks B] [--no-cpu]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+Workloads (all inputs synthetic, seeded, resident in HBM before the timed region):
+  acq        BASELINE configs[1]: 32 GPS L1 C/A SVs x 41 Doppler bins, 4 ms coherent FFT correlate
+             on int16 IQ; a step = Sample() front end + Correlate() + best-bin selection for
+             --blocks independent 4 ms blocks (default 32).           <- `value` of the line
+  wf14       BASELINE configs[2], frame half: 14 waterfall channels, window + 8192-point FFT +
+             power + pixel reduce + dB + u8 on DDC output buffers; the input is sized past the
+             256 MiB Infinity Cache so that the HBM figure is an HBM figure.
+  ddc14      BASELINE configs[2], DDC half: NCO mix + 5-stage pruned CIC for the 14 channels on a
+             16-bit ADC stream.
+  all        (default) the three above; ONE JSON line whose top level is `acq` (metric, value,
+             roofline, cpu_baseline) and whose "workloads" object holds every workload's own
+             value, step times, roofline and cpu_baseline.
+  acq10ms    BASELINE configs[4]: joint L1 C/A + QZSS + Galileo E1B, 10 ms coherent (65536-point
+             transforms), 256 Doppler bins, all 59 SVs.
+  receivers  BASELINE configs[3]: --receivers virtual receivers per GPU (waterfall + audio chain).
+  waterfall / ddc   the old names of wf14 / ddc14 as single lines.
+
+Multi-GPU (weak scaling): every rank works on its own resident units (sample blocks / frames /
+receivers); no data-path collective; the tiny acquisition results are all-gathered
+over RCCL after the timed region.  `value` = units of all ranks / max-over-ranks time.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -31,11 +45,103 @@ NSAMPLES = 65536
 FFT_LEN = 16384
 NSV = 32
 NDOP = 41
-# algorithmic bytes of one (SV, Doppler) cell = data spectrum +
-# code spectrum read once (2 * N * 8 B) + a 16-byte result.
-BYTES_PER_CELL = 2 * FFT_LEN * 8 + 16
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
-FLOPS_PER_CELL = 4 * 5 * 4096 * 12 + 6 * FFT_LEN + 3 * 4096 * 10
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured achievable)
+VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak (MI355X_MICROARCH.md)
+INT_PEAK_TOPS = 78.6         # 256 CUs x 4 SIMD-32 x 32 lanes x 2.4 GHz: one 32-bit integer op per lane per clock
+ZOOMS14 = [0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14]      # BASELINE configs[2]
+
+
+# ------------------------------------------------------------------------------------------------
+# Launcher: `python bench.py --gpus N` starts N ranks.  Runs before anything imports torch.
+# ------------------------------------------------------------------------------------------------
+def launch_ranks(n, argv):
+    import socket
+    with socket.socket() as s:                     # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else None, text=True))
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:                                    # a rank failed: stop the others (exact PIDs)
+            rc = bad[0]
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.05)
+    out0 = procs[0].stdout.read() or ""            # one JSON line: far below the pipe buffer
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if rc != 0:
+        sys.stderr.write("bench.py: a rank exited with status %d\n" % rc)
+    return rc
+
+
+class Dist:
+    """The process-group side of a rank (RCCL on GPUs; gloo for the CPU launcher test)."""
+
+    def __init__(self, backend="nccl"):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        # KIWIGPU_BENCH_FORCE_DIST=1 takes the process-group path with one rank as well
+        self.on = self.world > 1 or os.environ.get("KIWIGPU_BENCH_FORCE_DIST") == "1"
+        self.backend = backend
+        self.dev = None
+        if backend == "nccl":
+            import torch
+            ndev = torch.cuda.device_count()       # does not initialise the GPU
+            if self.local_rank >= ndev:
+                sys.stderr.write("bench.py: rank %d needs GPU %d but this node has %d\n"
+                                 % (self.rank, self.local_rank, ndev))
+                sys.exit(3)
+            torch.cuda.set_device(self.local_rank)
+            self.dev = torch.device("cuda", self.local_rank)
+        if self.on:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group("gloo")
+
+    def barrier(self):
+        if self.on:
+            import torch.distributed as dist
+            dist.barrier()
+        if self.dev is not None:
+            import torch
+            torch.cuda.synchronize(self.dev)       # every stream of the device
+
+    def max_over_ranks(self, seconds):
+        if not self.on:
+            return seconds
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([seconds], dtype=torch.float64, device=self.dev if self.dev is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.on:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
 
 
 def usable_cores():
@@ -60,31 +166,21 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(iq, chips_list, budget_s=12.0):
-    """The CPU oracle (kind "port": fp32 FFT) timed on the same configs[1] workload: every
-    host thread runs whole single-threaded steps (Sample + 32 SV x 41 bins) on its own,
-    back to back for about budget_s seconds -- independent blocks, like the GPU's batch,
-    and no per-call thread start-up in the timed loop (ctypes drops the GIL in the calls)."""
+def cpu_threads(one_unit, budget_s):
+    """Every usable host thread runs whole single-threaded units back to back for about budget_s
+    seconds (independent units, like the GPU's batch; ctypes drops the GIL inside the oracle).
+    -> (units done, seconds, cores, seconds of one unit on one thread)"""
     import threading
-    from oracle import kiwi_oracle as ko
-    ko.lib()
     cores = usable_cores()
-    codes = np.stack([ko.code_fft(c, prec=0) for c in chips_list])
-    limits = [4092] * len(chips_list)
-
-    def one_step():
-        data = ko.sample_iq16(iq, prec=0)
-        ko.correlate_many(codes, data, limits, prec=0, nthreads=1, want_cells=False)
-
-    t1_0 = time.perf_counter()
-    one_step()                                                    # warm-up + single-thread figure
-    t1 = time.perf_counter() - t1_0
+    t0 = time.perf_counter()
+    one_unit()                                                    # warm-up + single-thread figure
+    t1 = time.perf_counter() - t0
     done = [0] * cores
     deadline = time.perf_counter() + budget_s
 
     def worker(k):
         while time.perf_counter() < deadline:
-            one_step()
+            one_unit()
             done[k] += 1
 
     t0 = time.perf_counter()
@@ -93,155 +189,405 @@ def cpu_baseline(iq, chips_list, budget_s=12.0):
         th.start()
     for th in threads:
         th.join()
-    el = time.perf_counter() - t0
-    reps = sum(done)
-    return {
-        "value": round(reps * NSAMPLES / el / 1e6, 4),
+    return sum(done), time.perf_counter() - t0, cores, t1
+
+
+def measured_traffic(workload, units):
+    """HBM bytes per launch of the workload's dominant kernel from the committed PMC passes
+    (profiles/hbm_traffic.json, written from tools/prof.sh output: 2 x FETCH_SIZE + WRITE_SIZE,
+    separate --pmc runs of this same command, as MI355X_MICROARCH.md's HBM section prescribes).
+    A bench run cannot read counters itself: -> (bytes or None, where the number comes from)."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as f:
+            tab = json.load(f)
+        e = tab[workload][str(units)]
+        return e["bytes_per_launch"], "committed profile: %s" % e.get("source", tab.get("_source", "profiles/hbm_traffic.json"))
+    except (OSError, KeyError, ValueError):
+        return None, "no committed PMC pass for this configuration"
+
+
+def timed_steps(dist, step, steps, warmup):
+    """W untimed steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides, max
+    over ranks; then the same K steps once more with a device event between steps for the spread
+    (not part of the headline time).  -> (seconds, host enqueue seconds, spread dict)"""
+    import torch
+    for _ in range(warmup):
+        step()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    t_enq = time.perf_counter() - t0
+    dist.barrier()
+    elapsed = dist.max_over_ranks(time.perf_counter() - t0)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    ev[0].record()
+    for i in range(steps):
+        step()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    dts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+    spread = {"min": round(dts[0], 5), "median": round(dts[len(dts) // 2], 5), "max": round(dts[-1], 5),
+              "how": "device events between the steps of a second, untimed pass of K steps"}
+    return elapsed, t_enq, spread
+
+
+# ------------------------------------------------------------------------------------------------
+# GPS acquisition: configs[1] (4 ms) and configs[4] (10 ms)
+# ------------------------------------------------------------------------------------------------
+def acq_flops_per_cell(P, limit_quarters):
+    """Nominal FFT arithmetic of one (SV, Doppler) cell: P 4096-point sub-transforms at 5 N log2 N,
+    the N conj-multiplies (6 flops), P - 1 twiddled accumulations of 4096 points per output quarter
+    (8 + 2 flops)."""
+    return P * 5 * 4096 * 12 + 6 * P * 4096 + (P - 1) * 4096 * 10 * limit_quarters
+
+
+def run_acq(args, dist, ten_ms=False):
+    import numpy as np
+    import torch
+    from flydog_sdr_gps_amd import Context, Searcher, acq, prn, sats, shard, synth
+    dev = dist.dev
+    ctx = Context(dist.local_rank, torch.cuda.current_stream(dev).cuda_stream)
+    if ten_ms:
+        B = args.blocks or 2
+        nsamples, fft_len, dop_lo, dop_hi = acq.NSAMPLES_10MS, acq.FFT_LEN_10MS, -128, 127
+        codes = synth.all_sv_codes()
+        svs = list(range(len(codes)))
+        make_block = lambda b: synth.config4_iq16(seed=0x5EED0005 + b, codes=codes)     # noqa: E731
+    else:
+        B = args.blocks or 32
+        nsamples, fft_len, dop_lo, dop_hi = NSAMPLES, FFT_LEN, -20, 20
+        codes = [(prn.cacode(sats.SATS[s][1], sats.SATS[s][2]), False) for s in range(NSV)]
+        svs = list(range(NSV))
+        make_block = lambda b: synth.config1_iq16(seed=0x5EED0002 + b)                  # noqa: E731
+    ndop, P = dop_hi - dop_lo + 1, fft_len // 4096
+    s = Searcher(ctx, dop_lo=dop_lo, dop_hi=dop_hi, max_blocks=2 * B, nsamples=nsamples, fft_len=fft_len)
+    for sat, (chips, boc) in enumerate(codes):
+        s.set_code(sat, chips, boc=boc)
+    # each rank gets its own seeded blocks ("receivers"), resident in HBM
+    blocks = shard.block_ids(dist.rank, dist.world, B)
+    iq_host = [make_block(b) for b in blocks]
+    iq_dev = torch.from_numpy(np.stack(iq_host)).to(dev)          # [B][2*nsamples] int16, resident
+    iq_ptr = int(iq_dev.data_ptr())
+    parity = [0]
+
+    def step():
+        # Sample() then Correlate() of this step's blocks, in order on one stream (two sets of
+        # blocks alternate so that consecutive steps never touch the same spectra)
+        first = parity[0] * B
+        parity[0] ^= 1
+        s.sample_iq16_batch(iq_ptr, B, first_block=first)
+        s.correlate_async(svs, nblocks=B, first_block=first)
+
+    elapsed, t_enq, spread = timed_steps(dist, step, args.steps, args.warmup)
+
+    # dominant kernel alone: Correlate() launches back to back, HIP events on its own stream
+    kreps = max(10, min(args.steps, 200))
+    for _ in range(3):
+        s.correlate_async(svs, nblocks=B)
+    torch.cuda.synchronize(dev)
+    ctx.timer_start()
+    for _ in range(kreps):
+        s.correlate_async(svs, nblocks=B)
+    kernel_ms = ctx.timer_stop() / kreps
+
+    res, _ = s.fetch(want_cells=False)
+    found = sorted(int(sv) for sv in svs if res[0, sv]["snr"] >= acq.MIN_SIG)
+    if dist.on and dist.backend == "nccl":
+        gathered = shard.gather_results(res, dev)       # RCCL all_gather of the tiny result arrays
+        assert gathered.shape[0] == dist.world * B
+    expect = sorted(p[0] for p in synth.CONFIG4_PRESENT) if ten_ms else \
+        sorted(p - 1 for p, *_ in synth.CONFIG1_PRESENT)
+    assert found == expect, "acquisition result wrong: %s != %s" % (found, expect)
+
+    n1 = sum(1 for _, boc in codes if not boc)
+    n4 = len(codes) - n1
+    flops_launch = B * ndop * (n1 * acq_flops_per_cell(P, 1) + n4 * acq_flops_per_cell(P, 4))
+    cells = B * len(svs) * ndop
+    bytes_cell = 2 * fft_len * 8 + 16                  # SURVEY.md 8(d): both spectra once + the result
+    traffic, source = measured_traffic("acq10ms" if ten_ms else "acq", B)
+    tfl = flops_launch / (kernel_ms * 1e-3) / 1e12
+    out = {
+        "metric": "IQ Msamples/s ingested (GPS acq: Sample + %d SV x %d Doppler Correlate)" % (len(svs), ndop),
+        "value": round(float(B) * nsamples * args.steps * dist.world / elapsed / 1e6, 3),
         "unit": "Msamples/s",
-        "cores": cores,
-        "machine_cpus": os.cpu_count(),
-        "kind": "port",
-        "sample": "%d x the full configs[1] block (Sample + 32 SV x 41 bins), oracle fp32 FFT, "
-                  "%d threads each running whole blocks, %.1f s" % (reps, cores, el),
-        "single_thread_value": round(NSAMPLES / t1 / 1e6, 4),
+        "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+        "step_ms_spread": spread,
+        "dtype": "f32",
+        "config": {
+            "workload": ("BASELINE configs[4]: GPS L1 C/A + QZSS + Galileo E1B joint acquisition, 10 ms coherent "
+                         "(163680 samples @16.368 MS/s -> 65536-point transforms), 256 Doppler bins of 62.44 Hz, "
+                         "59 SVs (36 C/A, 23 E1B), synthetic int16 IQ resident in HBM") if ten_ms else
+                        ("BASELINE configs[1]: 32 GPS L1 C/A SVs x 41 Doppler bins, 4 ms coherent FFT correlate, "
+                         "synthetic int16 IQ @16.368 MS/s resident in HBM"),
+            "blocks_per_step_per_gpu": B, "samples_per_block": nsamples, "cells_per_step_per_gpu": cells,
+            "parallelism": "replicated codes, sample blocks sharded over %d GPU(s), no data-path collective" % dist.world,
+        },
+        # What bounds the correlator (DESIGN.md section 4): fp32 vector arithmetic -- every operand is
+        # served from L2, the kernel cannot be HBM-bound.  achieved = nominal FFT flops / HIP-event time.
+        "roofline": {
+            "bound": "valu", "kernel": "acq_correlate_kernel<%d,1>%s" % (P, " + <%d,4>" % P if n4 else ""),
+            "achieved": round(tfl, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tfl / VALU_PEAK_TFLOPS, 4),
+            "traffic": traffic, "traffic_source": source,
+            "kernel_ms": round(kernel_ms, 5), "flops_per_launch": flops_launch,
+        },
+        # Secondary: SURVEY 8(d)'s per-cell byte model and, where a PMC pass exists, measured HBM bytes.
+        "hbm": {
+            "algorithmic_bytes_per_launch": cells * bytes_cell,
+            "algorithmic_GBps": round(cells * bytes_cell / (kernel_ms * 1e-3) / 1e9, 1),
+            "measured_GBps": None if traffic is None else round(traffic / (kernel_ms * 1e-3) / 1e9, 1),
+            "peak": HBM_PEAK_GBS,
+            "frac_measured": None if traffic is None else round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "note": "the spectra are shared between cells and served from L2 / Infinity Cache: the algorithmic "
+                    "figure is not HBM traffic and may exceed the HBM peak",
+        },
+        "found_svs": found,
+        "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 5),
+    }
+    if not args.no_cpu and dist.world == 1 and dist.rank == 0:
+        out["cpu_baseline"] = cpu_acq(iq_host[0], codes, nsamples, fft_len, dop_lo, dop_hi, args.cpu_seconds)
+        out["speedup_vs_cpu_all_cores"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+    s.close()
+    ctx.close()
+    return out
+
+
+def cpu_acq(iq, codes, nsamples, fft_len, dop_lo, dop_hi, budget_s):
+    """The CPU oracle (kind "port": scalar fp32 radix-4 FFT in place of FFTW3f, which is absent from
+    this image) on the same workload: Sample() + Correlate() for every SV and bin of one block."""
+    import numpy as np
+    from oracle import kiwi_oracle as ko
+    ko.lib()
+    spectra = np.stack([ko.code_fft(c, boc=b, prec=0, fft_len=fft_len) for c, b in codes])
+    limits = [ko.E1B_LIMIT if b else ko.L1_LIMIT for _, b in codes]
+    ndop = dop_hi - dop_lo + 1
+    if fft_len == FFT_LEN:
+        def unit():
+            data = ko.sample_iq16(iq, prec=0)
+            ko.correlate_many(spectra, data, limits, prec=0, nthreads=1, want_cells=False)
+        samples_per_unit, what = nsamples, "the full configs[1] block (Sample + 32 SV x 41 bins)"
+    else:
+        # a bounded slice of the 59 x 256 cells: Sample() + 2 SVs (one C/A, one E1B) x 256 bins
+        sub = [0, len(codes) - 1]
+        frac = len(sub) / len(codes)
+
+        def unit():
+            data = ko.sample_iq16(iq, prec=0, nsamples=nsamples, fft_len=fft_len)
+            ko.correlate_many(spectra[sub], data, [limits[i] for i in sub], dop_lo=dop_lo, dop_hi=dop_hi,
+                              prec=0, nthreads=1, want_cells=False)
+        samples_per_unit = nsamples * frac
+        what = "Sample + 2 of the 59 SVs x %d bins of one configs[4] block (scaled by 2/59)" % ndop
+    reps, el, cores, t1 = cpu_threads(unit, budget_s)
+    return {
+        "value": round(reps * samples_per_unit / el / 1e6, 5), "unit": "Msamples/s", "cores": cores,
+        "machine_cpus": os.cpu_count(), "kind": "port",
+        "sample": "%d x %s, oracle fp32 FFT, %d threads each running whole units, %.1f s" % (reps, what, cores, el),
+        "single_thread_value": round(samples_per_unit / t1 / 1e6, 5),
+        "port_vs_reference": "FFTW3f is unavailable here; a tuned FFTW build is estimated 2-4x faster than this "
+                             "scalar port, so divide the speed-up by up to 4 for a fair reference build",
     }
 
 
-def bench_waterfall(args):
-    """Secondary workload (not the headline): waterfall frames, BASELINE configs[2]'s
-    14-channel zoom set, DDC output buffers (8192 int16 IQ per frame) resident in HBM.
-        python bench.py --workload waterfall [--frames F]"""
+# ------------------------------------------------------------------------------------------------
+# Waterfall frames (configs[2], frame half)
+# ------------------------------------------------------------------------------------------------
+def run_wf14(args, dist):
+    import numpy as np
     import torch
     from flydog_sdr_gps_amd import Context, Waterfall, WfParams, synth, wf
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
-    ctx = Context(0, torch.cuda.current_stream(dev).cuda_stream)
-    zooms = [0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14]
+    dev = dist.dev
+    ctx = Context(dist.local_rank, torch.cuda.current_stream(dev).cuda_stream)
+    zooms = ZOOMS14
     w = Waterfall(ctx, nchan=len(zooms))
-    w.set_tables()
+    tables = (wf.window_functions(), wf.cic_comp_table())
+    w.set_tables(*tables)
+    params = []
     for ch, z in enumerate(zooms):
-        w.set_channel(ch, WfParams.for_zoom(z, 1.0e6 * ch), interp=wf.WF_CMA, cic_comp=True)
-    F = args.frames
+        p = WfParams.for_zoom(z, 1.0e6 * ch)
+        params.append(p)
+        w.set_channel(ch, p, interp=wf.WF_CMA, cic_comp=True)
+    F = args.frames                                   # frames per channel per step
     nfr = F * len(zooms)
-    base = np.stack([synth.wf_iq_frame(seed=i) for i in range(32)])
-    iq = torch.from_numpy(base[np.arange(nfr) % 32].copy()).to(dev)
+    base = np.stack([synth.wf_iq_frame(seed=i + 1000 * dist.rank) for i in range(32)])
+    # distinct frames all the way (a rolled copy per repetition): 8192 x 4 B each, the whole input
+    # must not fit the 256 MiB Infinity Cache or FETCH_SIZE would count MALL hits
+    iq = torch.from_numpy(base).to(dev)
+    reps = (nfr + 31) // 32
+    iq = torch.cat([torch.roll(iq, shifts=7 * r + 1, dims=1) for r in range(reps)])[:nfr].contiguous()
     out = torch.empty((nfr, 1024), dtype=torch.uint8, device=dev)
     chan_of = np.arange(nfr, dtype=np.int32) % len(zooms)
-    for _ in range(args.warmup):
+
+    def step():
         w.frames_dev(chan_of, iq.data_ptr(), out.data_ptr())
+
+    steps = max(5, args.steps // 4)
+    elapsed, t_enq, spread = timed_steps(dist, step, steps, max(2, args.warmup // 4))
     torch.cuda.synchronize(dev)
     ctx.timer_start()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        w.frames_dev(chan_of, iq.data_ptr(), out.data_ptr())
-    kernel_ms = ctx.timer_stop() / args.steps
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    bytes_frame = 8192 * 4 + 1024          # int16 IQ in + u8 row out; tables are L2-resident
+    for _ in range(steps):
+        step()
+    kernel_ms = ctx.timer_stop() / steps
+    assert int(out.max()) > 100
+    bytes_frame = 8192 * 4 + 1024          # int16 IQ in + u8 row out; window/maps are L2-resident (SURVEY 8d)
     achieved = nfr * bytes_frame / (kernel_ms * 1e-3) / 1e9
-    print(json.dumps({
-        "metric": "waterfall IQ Msamples/s (window + 8192-pt FFT + pixel reduce + dB + u8)",
-        "value": round(nfr * 8192 * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s",
-        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "waterfall frames, 14 channels (zooms %s) x %d frames per step" % (zooms, F),
-                   "frames_per_step": nfr},
+    traffic, source = measured_traffic("wf14", nfr)
+    res = {
+        "metric": "waterfall IQ Msamples/s (window + 8192-pt FFT + power + pixel reduce + dB + u8)",
+        "value": round(nfr * 8192.0 * steps * dist.world / elapsed / 1e6, 1), "unit": "Msamples/s",
+        "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 5), "step_ms_spread": spread, "dtype": "f32",
+        "config": {"workload": "BASELINE configs[2] frames: 14 channels (zooms %s) x %d frames per step, "
+                               "%.0f MiB of int16 IQ per step (past the 256 MiB Infinity Cache)"
+                               % (zooms, F, nfr * 32768 / 2 ** 20), "frames_per_step": nfr},
         "roofline": {"bound": "hbm", "kernel": "wf_frame_kernel", "achieved": round(achieved, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": measured_traffic("waterfall", nfr), "kernel_ms": round(kernel_ms, 5),
+                     "traffic": traffic, "traffic_source": source, "kernel_ms": round(kernel_ms, 5),
                      "algorithmic_bytes_per_launch": nfr * bytes_frame},
-    }), flush=True)
+    }
+    if not args.no_cpu and dist.world == 1 and dist.rank == 0:
+        from oracle import kiwi_oracle as ko
+        ko.lib()
+        maps = [wf.build_maps(p.fft_used, p.plot_width, p.plot_width_clamped, False) for p in params]
+        scales = [np.full(1024, p.fft_scale, np.float32) for p in params]
+        k = [0]
+
+        def unit():                                   # one frame of each of the 14 channels
+            for ch, p in enumerate(params):
+                f = base[(k[0] + ch) % 32]
+                samps = ko.wf_window_iq(f, tables[0][wf.WINF_HANNING])
+                ko.wf_compute_frame(samps, p.zoom, wf.WINF_HANNING, wf.WF_CMA, True, False, p.fft_used,
+                                    p.plot_width, p.plot_width_clamped, maps[ch][0], maps[ch][1], scales[ch],
+                                    (scales[ch] / np.float32(2)).astype(np.float32), p.fft_offset, tables[1], prec=0)
+            k[0] += 1
+        reps_done, el, cores, t1 = cpu_threads(unit, args.cpu_seconds)
+        res["cpu_baseline"] = {
+            "value": round(reps_done * 14 * 8192 / el / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "%d x (one frame of each of the 14 channels: sample_wf window + compute_frame), oracle fp32 "
+                      "FFT, %d threads, %.1f s" % (reps_done, cores, el),
+            "single_thread_value": round(14 * 8192 / t1 / 1e6, 4)}
+        res["speedup_vs_cpu_all_cores"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
     w.close()
     ctx.close()
+    return res
 
 
-def bench_ddc(args):
-    """Secondary workload: BASELINE configs[2] -- 14 waterfall channels, NCO mix + CIC
-    decimate (+ 8192-pt FFT frames) on a synthetic 16-bit ADC stream resident in HBM.
-        python bench.py --workload ddc [--log2n 24]"""
-    import torch
-    from flydog_sdr_gps_amd import Context, Ddc, Waterfall, WfParams, wf
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
-    ctx = Context(0, torch.cuda.current_stream(dev).cuda_stream)
-    zooms = [0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14]
-    n = 1 << args.log2n
-    rng = np.random.Generator(np.random.PCG64(0x5EED0003))
+# ------------------------------------------------------------------------------------------------
+# Waterfall DDC (configs[2], DDC half)
+# ------------------------------------------------------------------------------------------------
+def adc_block(n, seed):
+    import numpy as np
+    rng = np.random.Generator(np.random.PCG64(seed))
     t = np.arange(n, dtype=np.float64)
     x = rng.normal(0, 10.0, n)
     for f, a in ((0.0123, 3000.0), (0.071, 300.0), (0.2003, 30.0), (0.31, 3.0)):
         x += a * np.cos(2 * np.pi * f * t)
-    adc = torch.from_numpy(np.clip(np.rint(x), -32768, 32767).astype(np.int16)).to(dev)
+    return np.clip(np.rint(x), -32768, 32767).astype(np.int16)
+
+
+def run_ddc14(args, dist):
+    import numpy as np
+    import torch
+    from flydog_sdr_gps_amd import Context, Ddc, WfParams
+    dev = dist.dev
+    ctx = Context(dist.local_rank, torch.cuda.current_stream(dev).cuda_stream)
+    zooms = ZOOMS14
+    n = 1 << args.log2n
+    adc_host = adc_block(n, 0x5EED0003)               # the same stream on every rank (configs[2]/[3])
+    adc = torch.from_numpy(adc_host).to(dev)
     d = Ddc(ctx, nchan=len(zooms), max_samples=n)
     chans = list(range(len(zooms)))
+    prm = []
     for ch, z in enumerate(zooms):
         p = WfParams.for_zoom(z, 1.0e6 * ch, adc_clock=66.6666e6, ui_srate=30.0e6)
+        prm.append(p)
         d.set_wf(ch, p.i_offset, p.decim)
     stride = n + 1
     out = torch.zeros((len(zooms), stride, 2), dtype=torch.int16, device=dev)
-    for _ in range(args.warmup):
+
+    def step():
         d.push_dev(adc.data_ptr(), n, chans, out.data_ptr(), stride)
+
+    steps = max(5, args.steps // 4)
+    elapsed, t_enq, spread = timed_steps(dist, step, steps, max(2, args.warmup // 4))
     torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
     ctx.timer_start()
-    for _ in range(args.steps):
-        d.push_dev(adc.data_ptr(), n, chans, out.data_ptr(), stride)
-    ms = ctx.timer_stop() / args.steps
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    print(json.dumps({
-        "metric": "ADC Msamples/s ingested by the 14-channel waterfall DDC (NCO mix + CIC decimate)",
-        "value": round(n * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s", "n_gpus": 1,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True, "dtype": "int128/int32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[2] DDC: %d ADC samples, 14 channels, zooms %s" % (n, zooms)},
-        "gpu_ms_per_step": round(ms, 4),
-        "x_realtime_at_66.6MSps": round(n / (ms * 1e-3) / 66.6666e6, 1),
-    }), flush=True)
+    for _ in range(steps):
+        step()
+    gpu_ms = ctx.timer_stop() / steps
+    # Integer work per ADC sample and channel, counted in 32-bit operations on the algorithm (not on
+    # the kernels): NCO phase add (48 bit: 2) + 2 table reads + 2 multiplies + 2 roundings (4) = 10;
+    # five integrators on I and Q, the first four 89 bits wide (3 words) and the fifth 28 (1): 2 x 13 = 26;
+    # the combs and the output rounding run at 1/R and are left out.
+    ops_sample_chan = 36
+    tops = n * len(zooms) * ops_sample_chan / (gpu_ms * 1e-3) / 1e12
+    out_bytes = sum((n // p.decim) * 4 for p in prm)
+    res = {
+        "metric": "ADC Msamples/s ingested by the 14-channel waterfall DDC (NCO mix + pruned 5-stage CIC)",
+        "value": round(float(n) * steps * dist.world / elapsed / 1e6, 1), "unit": "Msamples/s",
+        "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 5), "step_ms_spread": spread,
+        "dtype": "int128/int64/int32",
+        "config": {"workload": "BASELINE configs[2] DDC: %d ADC samples per step, 14 channels, zooms %s" % (n, zooms),
+                   "adc_samples_per_step": n},
+        "x_realtime_at_66.6MSps": round(n / (gpu_ms * 1e-3) / 66.6666e6, 1),
+        # integer-VALU bound by arithmetic intensity (SURVEY 8d's caveat): 2 bytes in per ADC sample for
+        # 14 x 36 integer operations
+        "roofline": {"bound": "valu", "kernel": "ddc_wf passes A + scan + B + comb (whole step)",
+                     "achieved": round(tops, 3), "peak": INT_PEAK_TOPS, "unit": "Tiop/s",
+                     "frac": round(tops / INT_PEAK_TOPS, 4), "traffic": None,
+                     "traffic_source": "not profiled: HBM traffic is the 2 B/sample ADC block + the decimated outputs",
+                     "kernel_ms": round(gpu_ms, 5), "int_ops_per_sample_per_channel": ops_sample_chan},
+        "hbm": {"algorithmic_bytes_per_step": 2 * n + out_bytes,
+                "algorithmic_GBps": round((2 * n + out_bytes) / (gpu_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS},
+    }
+    if not args.no_cpu and dist.world == 1 and dist.rank == 0:
+        from oracle import kiwi_oracle as ko
+        ko.lib()
+        m = 1 << 18                                      # a bounded piece of the same stream
+        piece = adc_host[:m]
+        log2r = [int(np.log2(p.decim)) for p in prm]
+
+        def unit():                                      # all 14 channels over the piece
+            for ch, p in enumerate(prm):
+                ko.ddc_wf(piece, p.i_offset, log2r[ch])
+        reps_done, el, cores, t1 = cpu_threads(unit, args.cpu_seconds)
+        res["cpu_baseline"] = {
+            "value": round(reps_done * m / el / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "%d x (2^18 ADC samples through the 14 channels), the oracle's sequential Verilog-structured "
+                      "model (the reference has no CPU DDC: it is FPGA fabric), %d threads, %.1f s" % (reps_done, cores, el),
+            "single_thread_value": round(m / t1 / 1e6, 4)}
+        res["speedup_vs_cpu_all_cores"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
     d.close()
     ctx.close()
+    return res
 
 
-def bench_receivers(args):
-    """BASELINE configs[3]: a batch of virtual receivers per GPU (weak scaling over ranks), each
-    with a waterfall and an audio path, fed from one ADC block resident in HBM per step:
+# ------------------------------------------------------------------------------------------------
+# configs[3]: virtual receivers
+# ------------------------------------------------------------------------------------------------
+def run_receivers(args, dist):
+    """A batch of virtual receivers per GPU (weak scaling over ranks), each with a waterfall and an
+    audio path, fed from one ADC block resident in HBM per step:
       waterfall: NCO mix + CIC decimate -> 8192-sample frame -> u8 row -> wf_pkt_t (ADPCM)
       audio:     NCO mix + CIC/CIC/CICF decimate -> rx_iq_t -> unpack -> CFastFIR -> S-meter +
-                 CAgc (mono16) -> IMA ADPCM
-        python bench.py --workload receivers [--receivers 128] [--log2n 22] [--gpus N via torch.distributed.run]"""
+                 CAgc (mono16) -> IMA ADPCM"""
+    import numpy as np
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
-    if distributed:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-        local_rank = 0
-    dev = torch.device("cuda", local_rank)
+    dev = dist.dev
     from flydog_sdr_gps_amd import Adpcm, Context, Ddc, FastFir, Post, RxDdc, Waterfall, WfParams, post, snd, wf, wire
     from flydog_sdr_gps_amd.ddc import RX_DECIM, rx_phase_inc
     # the waterfall chain and the audio chain of a receiver are independent: one context (= one
     # stream) each, so the short latency-bound kernels of one hide under the DDC passes of the other
     two = os.environ.get("KIWIGPU_BENCH_ONE_STREAM") != "1"
-    ctx = Context(local_rank, torch.cuda.current_stream(dev).cuda_stream)
+    ctx = Context(dist.local_rank, torch.cuda.current_stream(dev).cuda_stream)
     side = torch.cuda.Stream(device=dev) if two else None
-    ctx_au = Context(local_rank, side.cuda_stream) if two else ctx
+    ctx_au = Context(dist.local_rank, side.cuda_stream) if two else ctx
     NR, n = args.receivers, 1 << args.log2n
     assert n >= 512 * 8192, "--log2n >= 22: every step must complete a waterfall frame at zoom 10"
     adc_clock, ui_srate = 66.6666e6, 30.0e6
-    rng = np.random.Generator(np.random.PCG64(0x5EED0004 + rank))
-    t = np.arange(n, dtype=np.float64)
-    x = rng.normal(0, 10.0, n)
-    for f, a in ((0.0123, 3000.0), (0.071, 300.0), (0.2003, 30.0), (0.31, 3.0)):
-        x += a * np.cos(2 * np.pi * f * t)
-    adc = torch.from_numpy(np.clip(np.rint(x), -32768, 32767).astype(np.int16)).to(dev)
+    adc = torch.from_numpy(adc_block(n, 0x5EED0004)).to(dev)      # every GPU sees the SAME stream (configs[3])
     chans = list(range(NR))
+    first_rx = dist.rank * NR                                      # this rank's slice of the receiver set
 
     d = Ddc(ctx, nchan=NR, max_samples=n)
     W = Waterfall(ctx, nchan=NR)
@@ -249,8 +595,9 @@ def bench_receivers(args):
     hz_per_start = ui_srate / (1024 << 14)
     params = []
     for ch in range(NR):
-        z = 1 + ch % 10
-        p = WfParams.for_zoom(z, (1.0e6 + 0.2e6 * (ch % 97)) / hz_per_start, adc_clock=adc_clock, ui_srate=ui_srate)
+        k = first_rx + ch
+        z = 1 + k % 10
+        p = WfParams.for_zoom(z, (1.0e6 + 0.2e6 * (k % 97)) / hz_per_start, adc_clock=adc_clock, ui_srate=ui_srate)
         params.append(p)
         d.set_wf(ch, p.i_offset, p.decim)
         W.set_channel(ch, p, interp=wf.WF_MAX, window_func=wf.WINF_HANNING, cic_comp=True)
@@ -261,7 +608,7 @@ def bench_receivers(args):
     A = Adpcm(ctx_au, nchan=NR)
     fs = adc_clock / RX_DECIM
     for ch in range(NR):
-        rx.set_freq(ch, rx_phase_inc(0.0123 * adc_clock - 1000.0 - 10.0 * ch, adc_clock))
+        rx.set_freq(ch, rx_phase_inc(0.0123 * adc_clock - 1000.0 - 10.0 * (first_rx + ch), adc_clock))
         fir.setup(ch, 300.0, 2700.0, 0.0, fs)
         P.set_agc(ch, True, False, -100, 50, 6, 1000, fs)
         P.set_smeter(ch, fs); P.set_mode(ch, post.MODE_SSB); P.reset(ch)
@@ -280,16 +627,6 @@ def bench_receivers(args):
     counts = {"frames": 0, "audio_blocks": 0}
     torch.cuda.synchronize(dev)                              # buffers exist before the side stream touches them
 
-    def step():
-        # audio chain first: its calls only enqueue on the side stream
-        audio()
-        nw = d.push_dev(adc.data_ptr(), n, chans, wf_iq.data_ptr(), wf_stride)
-        assert int(nw.min()) >= 8192
-        frames.copy_(wf_iq[:, :8192])                       # the frame each receiver's waterfall takes this step
-        W.frames_dev(chans, frames.data_ptr(), rows.data_ptr())
-        wire.wf_packets_dev(ctx, rows.data_ptr(), 1024, infos, pkts.data_ptr())
-        counts["frames"] += NR
-
     def audio():
         nr = rx.push_dev(adc.data_ptr(), n, chans, raw.data_ptr(), nrec_max)
         nrec = int(nr.min())
@@ -301,233 +638,111 @@ def bench_receivers(args):
             A.encode_dev(chans, s16.data_ptr(), 512, 512, pay.data_ptr(), 256)
             counts["audio_blocks"] += NR
 
-    def barrier():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize(dev)                         # all streams of the device
+    def step():
+        audio()                                              # only enqueues, on the side stream
+        nw = d.push_dev(adc.data_ptr(), n, chans, wf_iq.data_ptr(), wf_stride)
+        assert int(nw.min()) >= 8192
+        frames.copy_(wf_iq[:, :8192])                       # the frame each receiver's waterfall takes this step
+        W.frames_dev(chans, frames.data_ptr(), rows.data_ptr())
+        wire.wf_packets_dev(ctx, rows.data_ptr(), 1024, infos, pkts.data_ptr())
+        counts["frames"] += NR
 
     for _ in range(args.warmup):
         step()
-    barrier()
+    dist.barrier()
     counts["frames"] = counts["audio_blocks"] = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    dist.barrier()
+    elapsed = dist.max_over_ranks(time.perf_counter() - t0)
     # sanity: the strongest carrier is in the band of every waterfall row and audio came out
     assert int(rows.max()) > 100 and counts["audio_blocks"] > 0 and int(pay.to(torch.int32).abs().sum()) > 0
-    if rank == 0:
-        step_s = elapsed / args.steps
-        print(json.dumps({
-            "metric": "receiver x ADC Msamples/s ingested (waterfall + audio chain per virtual receiver)",
-            "value": round(n * NR * world / step_s / 1e6, 1), "unit": "Msamples/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int128/int64/f32",
-            "data": "synthetic",
-            "config": {"workload": "BASELINE configs[3]: %d virtual receivers per GPU x %d GPU(s), %d-sample 16-bit ADC "
-                                   "block @66.67 MS/s resident in HBM per step; per receiver a waterfall channel "
-                                   "(zooms 1..10) and an SSB audio channel" % (NR, world, n),
-                       "receivers_per_gpu": NR, "adc_samples_per_step": n,
-                       "parallelism": "receivers sharded over ranks, no data-path collective"},
-            "adc_ms_per_step": round(n / adc_clock * 1e3, 3),
-            "x_realtime_all_receivers": round(n / adc_clock / step_s, 2),
-            "waterfall_frames_per_s": round(counts["frames"] * world / elapsed, 1),
-            "audio_blocks_per_s": round(counts["audio_blocks"] * world / elapsed, 1),
-        }), flush=True)
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+    step_s = elapsed / args.steps
+    world = dist.world
+    return {
+        "metric": "receiver x ADC Msamples/s ingested (waterfall + audio chain per virtual receiver)",
+        "value": round(n * NR * world / step_s / 1e6, 1), "unit": "Msamples/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int128/int64/f32",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE configs[3]: %d virtual receivers per GPU x %d GPU(s), one %d-sample 16-bit ADC "
+                               "block @66.67 MS/s (the same stream on every GPU) resident in HBM per step; per receiver a "
+                               "waterfall channel (zooms 1..10) and an SSB audio channel" % (NR, world, n),
+                   "receivers_per_gpu": NR, "adc_samples_per_step": n,
+                   "parallelism": "receivers sharded over ranks, no data-path collective"},
+        "adc_ms_per_step": round(n / adc_clock * 1e3, 3),
+        "x_realtime_all_receivers": round(n / adc_clock / step_s, 2),
+        "waterfall_frames_per_s": round(counts["frames"] * world / elapsed, 1),
+        "audio_blocks_per_s": round(counts["audio_blocks"] * world / elapsed, 1),
+    }
 
 
-def measured_traffic(workload, units):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/hbm_traffic.json, written from tools/prof.sh output: FETCH_SIZE x2 on gfx950
-    + WRITE_SIZE, separate --pmc runs of this same command).  A bench run cannot read
-    counters itself; None when no measurement exists for this configuration."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")
-    try:
-        with open(path) as f:
-            tab = json.load(f)
-        return tab[workload][str(units)]["bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+def run_stub(args, dist):
+    """Launcher / rendezvous self-test without a GPU (tests/test_host_cpu.py): gloo process group,
+    barrier, max-over-ranks, one line from rank 0."""
+    dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (dist.rank + 1))
+    dist.barrier()
+    el = dist.max_over_ranks(time.perf_counter() - t0)
+    return {"metric": "launcher self-test", "value": round(dist.world / el, 3), "unit": "ranks/s",
+            "config": {"workload": "stub (no GPU)"}, "dtype": "none"}
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--log2n", type=int, default=None, help="ddc / receivers: log2 of the ADC samples per step (24 / 22)")
-    ap.add_argument("--receivers", type=int, default=128, help="receivers: virtual receivers per GPU")
-    ap.add_argument("--workload", default="acq", choices=["acq", "waterfall", "ddc", "receivers"])
-    ap.add_argument("--frames", type=int, default=512, help="waterfall: frames per channel per step")
+    ap.add_argument("--workload", default="all",
+                    choices=["all", "acq", "acq10ms", "wf14", "ddc14", "waterfall", "ddc", "receivers", "stub"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--blocks", type=int, default=32, help="independent 4 ms blocks per step")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--blocks", type=int, default=None, help="acq: independent sample blocks per step (32; acq10ms: 2)")
+    ap.add_argument("--frames", type=int, default=2048, help="wf14: frames per channel per step (2048 = 896 MiB of input)")
+    ap.add_argument("--log2n", type=int, default=None, help="ddc14 / receivers: log2 of the ADC samples per step (24 / 22)")
+    ap.add_argument("--receivers", type=int, default=128, help="receivers: virtual receivers per GPU")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     args = ap.parse_args()
     if args.log2n is None:
         args.log2n = 22 if args.workload == "receivers" else 24
-    if args.workload == "waterfall":
-        return bench_waterfall(args)
-    if args.workload == "ddc":
-        return bench_ddc(args)
-    if args.workload == "receivers":
-        return bench_receivers(args)
+    args.workload = {"waterfall": "wf14", "ddc": "ddc14"}.get(args.workload, args.workload)
 
-    import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    # KIWIGPU_BENCH_FORCE_DIST=1 takes the process-group path with one rank as well (used to
-    # exercise init / barrier / all_reduce / all_gather over RCCL on a single-GPU box)
-    distributed = world > 1 or os.environ.get("KIWIGPU_BENCH_FORCE_DIST") == "1"
-    if distributed:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))      # the parent never touches the GPU
+    if world_env is not None and int(world_env) != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%s\n" % (args.gpus, world_env))
+        sys.exit(2)
+
+    dist = Dist("gloo" if args.workload == "stub" else "nccl")
+    common = {"n_gpus": dist.world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+              "scaling": "weak", "vs_baseline": None, "data": "synthetic"}
+    if args.workload == "stub":
+        line = dict(run_stub(args, dist), **common)
+    elif args.workload == "receivers":
+        line = run_receivers(args, dist)
+    elif args.workload in ("acq", "acq10ms", "wf14", "ddc14"):
+        fn = {"acq": lambda: run_acq(args, dist), "acq10ms": lambda: run_acq(args, dist, ten_ms=True),
+              "wf14": lambda: run_wf14(args, dist), "ddc14": lambda: run_ddc14(args, dist)}[args.workload]
+        r = fn()
+        line = dict(r, **common)
+        line["steps"] = r.get("steps", args.steps)
     else:
-        torch.cuda.set_device(0)
-        local_rank = 0
-    dev = torch.device("cuda", local_rank)
-
-    from flydog_sdr_gps_amd import Context, Searcher, prn, sats, synth
-    from flydog_sdr_gps_amd import shard
-
-    # run on torch's current stream so torch.cuda.Event / synchronize see the work
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    ctx = Context(local_rank, stream)
-    B = args.blocks
-    s = Searcher(ctx, max_blocks=2 * B)      # two sets of blocks, used alternately
-    svs = list(range(NSV))
-    chips_list = []
-    for sat in svs:
-        _, t1, t2, _ = sats.SATS[sat]
-        chips_list.append(prn.cacode(t1, t2))
-        s.set_code(sat, chips_list[-1])
-
-    # each rank gets its own seeded blocks ("receivers"), resident in HBM
-    blocks = shard.block_ids(rank, world, B)
-    iq_host = [synth.config1_iq16(seed=0x5EED0002 + b) for b in blocks]
-    iq_dev = torch.from_numpy(np.stack(iq_host)).to(dev)      # [B][2*65536] int16, resident
-    iq_ptr = int(iq_dev.data_ptr())
-
-    parity = [0]
-
-    def step():
-        # Sample() then Correlate() of this step's blocks, in order on one stream (two sets
-        # of blocks alternate so that consecutive steps never touch the same spectra); all
-        # of it is inside the timed region.
-        first = parity[0] * B
-        parity[0] ^= 1
-        s.sample_iq16_batch(iq_ptr, B, first_block=first)
-        s.correlate_async(svs, nblocks=B, first_block=first)
-
-    def barrier():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    t_enqueued = time.perf_counter() - t0      # host side only: diagnostic, not the metric
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    # dominant kernel alone: Correlate() launches back to back, HIP events on its stream
-    kreps = max(20, min(args.steps, 200))
-    for _ in range(3):
-        s.correlate_async(svs, nblocks=B)
-    torch.cuda.synchronize(dev)
-    ctx.timer_start()
-    for _ in range(kreps):
-        s.correlate_async(svs, nblocks=B)
-    kernel_ms = ctx.timer_stop() / kreps
-
-    res, _ = s.fetch(want_cells=False)
-    found = sorted(int(sv) + 1 for sv in svs if res[0, sv]["snr"] >= 16)
-    if distributed:
-        gathered = shard.gather_results(res, dev)       # RCCL all_gather of the tiny result arrays
-        assert gathered.shape[0] == world * B
-    if rank == 0:
-        expect = sorted(p for p, *_ in synth.CONFIG1_PRESENT)
-        assert found == expect, "acquisition result wrong: %s != %s" % (found, expect)
-
-    if rank == 0:
-        total_samples = float(B) * NSAMPLES * args.steps * world
-        cells = B * NSV * NDOP
-        achieved = cells * BYTES_PER_CELL / (kernel_ms * 1e-3) / 1e9
-        out = {
-            "metric": "IQ Msamples/s ingested (GPS acq: Sample + 32 SV x 41 Doppler Correlate)",
-            "value": round(total_samples / elapsed / 1e6, 3),
-            "unit": "Msamples/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": "BASELINE configs[1]: 32 GPS L1 C/A SVs x 41 Doppler bins, 4 ms "
-                            "coherent FFT correlate, synthetic int16 IQ @16.368 MS/s resident in HBM",
-                "blocks_per_step_per_gpu": B,
-                "samples_per_block": NSAMPLES,
-                "cells_per_step_per_gpu": cells,
-                "parallelism": "replicated codes, sample blocks sharded over %d GPU(s), "
-                               "no data-path collective" % world,
-            },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "acq_correlate_kernel<1>",
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": measured_traffic("acq", B),
-                "kernel_ms": round(kernel_ms, 5),
-                "algorithmic_bytes_per_launch": cells * BYTES_PER_CELL,
-                "note": "algorithmic bytes = 262160 B per (SV,Doppler) cell (SURVEY 8d); the "
-                        "spectra are shared between cells and served from L2/Infinity Cache, so "
-                        "this can exceed the HBM peak; the kernel is fp32-VALU/LDS bound",
-            },
-            # What actually bounds the kernel (DESIGN.md section 4): fp32 vector arithmetic.  Nominal
-            # FFT arithmetic of one cell = four 4096-point sub-transforms (5 N log2 N) + the
-            # 16384 conj-multiplies (6) + three twiddled accumulations of 4096 points (8 + 2);
-            # peak = 157.3 TFLOP/s fp32 vector (MI355X_MICROARCH.md).  Supplementary to `roofline`.
-            "valu": {
-                "flops_per_cell": FLOPS_PER_CELL,
-                "achieved_tflops": round(cells * FLOPS_PER_CELL / (kernel_ms * 1e-3) / 1e12, 2),
-                "peak_tflops": 157.3,
-                "frac": round(cells * FLOPS_PER_CELL / (kernel_ms * 1e-3) / 1e12 / 157.3, 4),
-            },
-            "found_prns": found,
-            "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 5),
-        }
-        if not args.no_cpu and world == 1:                  # the CPU leg runs at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(iq_host[0], chips_list)
-            out["speedup_vs_cpu_all_cores"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(out), flush=True)
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
-    s.close()
-    ctx.close()
+        import torch
+        a = run_acq(args, dist)
+        torch.cuda.empty_cache()
+        w = run_wf14(args, dist)
+        torch.cuda.empty_cache()
+        d = run_ddc14(args, dist)
+        line = dict(a, **common)
+        line["metric"] = "IQ Msamples/s ingested (waterfall + GPS acq); value = GPS acq, BASELINE configs[1]"
+        line["workloads"] = {"acq": {k: a[k] for k in a if k not in ("metric", "config")},
+                             "wf14": w, "ddc14": d}
+        line["config"]["also_in_this_line"] = "workloads.wf14 and workloads.ddc14: BASELINE configs[2]"
+    if dist.rank == 0:
+        print(json.dumps(line), flush=True)
+    dist.close()
 
 
 if __name__ == "__main__":

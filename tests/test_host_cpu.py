@@ -226,6 +226,39 @@ def test_gloo_world2_gather(tmp_path):
     assert out.stdout.count("ok") == 2
 
 
+def test_bench_gpus_flag_launches_ranks():
+    """`python bench.py --gpus N` (the driver's command line) must START N ranks: the parent spawns
+    them before touching torch or the GPU, relays rank 0's line and propagates failures.  Driven here
+    with the GPU-free stub workload over gloo."""
+    import json
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, bench, "--gpus", "2", "--workload", "stub"], env=env,
+                         capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # ONE line, from rank 0
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["higher_is_better"] is True
+    # a rank started by torchrun with another world size than --gpus refuses to run
+    out = subprocess.run([sys.executable, bench, "--gpus", "2", "--workload", "stub"],
+                         env=dict(env, WORLD_SIZE="3", RANK="0"), capture_output=True, text=True, timeout=60)
+    assert out.returncode == 2 and "WORLD_SIZE" in out.stderr
+    # no GPUs here: every GPU workload fails cleanly, the failure reaches the caller's exit status
+    out = subprocess.run([sys.executable, bench, "--gpus", "2", "--workload", "acq", "--steps", "1"], env=env,
+                         capture_output=True, text=True, timeout=240)
+    if not _have_gpu_count(2):
+        assert out.returncode != 0 and "needs GPU" in out.stderr
+
+
+def _have_gpu_count(n):
+    try:
+        import torch
+        return torch.cuda.device_count() >= n
+    except Exception:
+        return False
+
+
 # ---- waterfall host logic vs oracle -------------------------------------------
 def test_wf_tables_params_maps_match_oracle(oracle):
     from flydog_sdr_gps_amd import wf
