@@ -293,7 +293,8 @@ def run_acq(args, dist, ten_ms=False):
     kernel_ms = ctx.timer_stop() / kreps
 
     res, _ = s.fetch(want_cells=False)
-    found = sorted(int(sv) for sv in svs if res[0, sv]["snr"] >= acq.MIN_SIG)
+    min_sig = synth.MIN_SIG_10MS if ten_ms else acq.MIN_SIG
+    found = sorted(int(sv) for sv in svs if res[0, sv]["snr"] >= min_sig)
     if dist.on and dist.backend == "nccl":
         gathered = shard.gather_results(res, dev)       # RCCL all_gather of the tiny result arrays
         assert gathered.shape[0] == dist.world * B

@@ -88,6 +88,10 @@ def config0_bits(seed=0x5EED0001):
 # (163680 samples at FS), 65536-point transforms, Doppler bin 4.092e6 / 65536 = 62.44 Hz.
 NSAMPLES_10MS = 163680
 BIN_10MS = 4.092e6 / 65536
+# Detection threshold for this shape.  The reference's MIN_SIG = 16 (gps/gps.h:60) is sized for its
+# 41 x 4092 trials per SV; 256 bins x 4092 (E1B: 16368) lags are 1.0 M (4.2 M) trials, whose noise
+# maximum alone is ln(trials) + a few = 14..19 in units of the mean power.
+MIN_SIG_10MS = 30.0
 # (index into sats.SATS, code phase in chips, Doppler in Hz, carrier phase, C/N0 dB-Hz)
 CONFIG4_PRESENT = [(0, 300.5, 1500.0, 0.7, 41.0), (6, 911.0, 7300.0, 0.1, 40.0), (13, 71.5, -250.0, 4.0, 39.0),
                    (21, 640.0, -7800.0, 3.3, 42.0), (29, 222.625, -3300.0, 1.2, 40.0),

@@ -98,8 +98,11 @@ def test_config4_all_59_svs_256_bins(searcher10, oracle, codes, oracle_codes):
     assert np.array_equal(res[0]["idx"], want["idx"])
     assert np.array_equal(res[0]["valid"], want["valid"])
     np.testing.assert_allclose(res[0]["snr"], want["snr"], rtol=2 * RTOL)
-    found = {s for s in svs if res[0, s]["snr"] >= acq.MIN_SIG}
+    # MIN_SIG = 16 is the reference's threshold for 41 x 4092 trials per SV; with 256 x 4092
+    # (16368 for E1B) trials the noise maximum alone reaches 14..19, so this shape needs its own
+    found = {s for s in svs if res[0, s]["snr"] >= synth.MIN_SIG_10MS}
     assert found == {p[0] for p in synth.CONFIG4_PRESENT}
+    assert max(res[0, s]["snr"] for s in svs if s not in found) < 24.0
     for sat, tau, fd, _, _ in synth.CONFIG4_PRESENT:
         r = res[0, sat]
         assert abs(int(r["dop"]) - fd / synth.BIN_10MS) <= 1.0
