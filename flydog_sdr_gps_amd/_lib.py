@@ -98,6 +98,8 @@ SYMBOLS = {
     "kg_ddc_wf_outputs": (C.c_long, [_vp, _i, _sz]),
     "kg_ddc_wf_push_dev": (_i, [_vp, _vp, _sz, _vp, _i, _vp, _sz, _vp]),
     "kg_rxddc_create": (_i, [_vp, _i, _sz, C.POINTER(_vp)]),
+    "kg_rxddc_create_mode": (_i, [_vp, _i, _sz, _i, C.POINTER(_vp)]),
+    "kg_rxddc_decim": (_i, [_vp]),
     "kg_rxddc_destroy": (None, [_vp]),
     "kg_rxddc_set_freq": (_i, [_vp, _i, C.c_uint64]),
     "kg_rxddc_reset": (_i, [_vp, _i]),

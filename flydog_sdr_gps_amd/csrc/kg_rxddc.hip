@@ -10,7 +10,9 @@
 //   fir_iq: 65 symmetric taps, 18-bit coefficients, 42-bit accumulator,
 //        out = acc[41 -: 24], every second output kept          (fir_iq.sv)
 //   output words {i[15:0]}, {q[15:0]}, {i[23:16], q[23:16]} (rx.v:172) = rx_iq_t
-// Total decimation 1736 * 3 * 2 = 10416 (RX_DECIM_4CH, kiwi.config:141).
+// Total decimation 1736 * 3 * 2 = 10416 (RX_DECIM_4CH, kiwi.config:141).  That is the rx4 / rx8
+// instance (KG_RXDDC_STD); the rx3 "wide" instance (1543 * 2 * 2 = 6172, RX_DECIM_3CH) and the rx14
+// instance (17-tap CICF) are the same structure with the parameters of rx_mode below.
 // The host sets the NCO with CmdSetRXFreq (rx/rx_sound_cmd.cpp:41-51) and reads
 // the records with CmdGetRX (rx/data_pump.cpp:101).
 //
@@ -33,19 +35,43 @@
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
-#define RX_R1 1736
-#define RX_R2 3
 #define RX_HIST 256          // rx1 outputs kept from earlier calls (a final output spans 203 of them)
 #define RX_THREADS 256
 
-// fir_iq.sv:91-123, default (rx4 / rx8) table, taps[0..32] as 18-bit two's complement
-__constant__ int c_cicf_taps[33] = {
-    0x00071, 0x3ffae, 0x3ff5b, 0x00029, 0x000f6, 0x0002a, 0x3fea6, 0x3ff32, 0x001aa, 0x001dc, 0x3fe5a,
-    0x3fcae, 0x000fb, 0x00503, 0x000a7, 0x3f96f, 0x3fc85, 0x0076b, 0x00793, 0x3f927, 0x3f33f, 0x00401,
-    0x01296, 0x00227, 0x3e7b0, 0x3f2dd, 0x01caf, 0x0200e, 0x3e310, 0x3bb4f, 0x00c0e, 0x0aeac, 0x1036e,
+// The three RX instances the reference builds (kiwi.config:101-105, fir_iq.sv:39-123); the widths
+// are what verilog/rx/cic_gen.c emits for those decimations (tests/golden/cic_ref.json):
+//   KG_RXDDC_STD   rx4 / rx8: rx1 R 1736 (acc 55: third integrator takes [54 -: 26]), rx2 R 3 (26 bits,
+//                  out = comb5[25 -: 24] + comb5[1]), 65-tap CICF
+//   KG_RXDDC_WIDE  rx3: rx1 R 1543 (acc 54: [53 -: 26]), rx2 R 2 (24 bits, out = comb5[23 -: 24], no
+//                  rounding), the 65-tap RX_CFG == 3 CICF
+//   KG_RXDDC_RX14  rx14: the std CICs, the 17-tap RX_CFG == 14 CICF
+struct rx_mode {
+    int r1, r2;
+    int sh3;          // acc width - 26: what the third rx1 integrator drops
+    int w2, round2;   // rx2 register width; 1: out = (v >> 2) + ((v >> 1) & 1), 0: out = v
+    int ntaps;        // CICF taps (65 / 17)
+    int nbox;         // taps of (1 + z + .. + z^(r2-1))^5 = 5 (r2 - 1) + 1
+    int tapset;       // row of c_cicf_taps / c_box
 };
-// (1 + z + z^2)^5
-__constant__ int c_box3_5[11] = {1, 5, 15, 30, 45, 51, 45, 30, 15, 5, 1};
+static const rx_mode RX_MODES[3] = {
+    {1736, 3, 29, 26, 1, 65, 11, 0},
+    {1543, 2, 28, 24, 0, 65, 6, 1},
+    {1736, 3, 29, 26, 1, 17, 11, 2},
+};
+
+// fir_iq.sv:91-123 (default: rx4 / rx8), :45-77 (RX_CFG == 3), :79-88 (RX_CFG == 14): taps[0..(NTAPS-1)/2]
+// as 18-bit two's complement
+__constant__ int c_cicf_taps[3][33] = {
+    {0x00071, 0x3ffae, 0x3ff5b, 0x00029, 0x000f6, 0x0002a, 0x3fea6, 0x3ff32, 0x001aa, 0x001dc, 0x3fe5a,
+     0x3fcae, 0x000fb, 0x00503, 0x000a7, 0x3f96f, 0x3fc85, 0x0076b, 0x00793, 0x3f927, 0x3f33f, 0x00401,
+     0x01296, 0x00227, 0x3e7b0, 0x3f2dd, 0x01caf, 0x0200e, 0x3e310, 0x3bb4f, 0x00c0e, 0x0aeac, 0x1036e},
+    {0x0005f, 0x3ffa4, 0x3ff6c, 0x0003c, 0x000e6, 0x0000a, 0x3feb1, 0x3ff63, 0x001ad, 0x00199, 0x3fe3e,
+     0x3fcfe, 0x0013d, 0x004b1, 0x00036, 0x3f9b3, 0x3fd2b, 0x0074d, 0x006b9, 0x3f904, 0x3f444, 0x00481,
+     0x01177, 0x00126, 0x3e8ca, 0x3f490, 0x01bd5, 0x01d5a, 0x3e30e, 0x3bf82, 0x00f77, 0x0ac26, 0x0fd54},
+    {0x001dd, 0x001dd, 0x001dd, 0x3f290, 0x3ee98, 0x006e8, 0x04205, 0x084ab, 0x0a235},
+};
+// (1 + z + z^2)^5 and (1 + z)^5
+__constant__ int c_box[3][11] = {{1, 5, 15, 30, 45, 51, 45, 30, 15, 5, 1}, {1, 5, 10, 10, 5, 1}, {1, 5, 15, 30, 45, 51, 45, 30, 15, 5, 1}};
 
 struct rx_chan {
     u64 phase, phase_inc;
@@ -73,8 +99,10 @@ __global__ __launch_bounds__(RX_THREADS) void rx1_run_kernel(
     const short *__restrict__ adc, long n, int L, int nruns, const rx_chan *__restrict__ chans,
     const int *__restrict__ chan_list, const u32 *__restrict__ nco,
     u64 *__restrict__ st,                     // [nlist][2 comp][2 integ][nruns]: A out, B in (carried)
-    u32 *__restrict__ c0rel, u32 *__restrict__ tau, long max_out)
+    u32 *__restrict__ c0rel, u32 *__restrict__ tau, long max_out, rx_mode md)
 {
+    const u32 RX_R1 = (u32) md.r1;
+    const int SH3 = md.sh3;
     __shared__ u32 tab[8192];
     for (int i = threadIdx.x; i < 8192; i += RX_THREADS) tab[i] = nco[i];
     __syncthreads();
@@ -100,8 +128,8 @@ __global__ __launch_bounds__(RX_THREADS) void rx1_run_kernel(
         a1i += (u64) mi; a2i += a1i;
         a1q += (u64) mq; a2q += a1q;
         if (PASS_B) {
-            i3i = (i3i + (u32) (a2i >> 29)) & 0x03FFFFFFu;      // integrator2[54 -: 26]
-            i3q = (i3q + (u32) (a2q >> 29)) & 0x03FFFFFFu;
+            i3i = (i3i + (u32) (a2i >> SH3)) & 0x03FFFFFFu;     // integrator2[acc-1 -: 26]
+            i3q = (i3q + (u32) (a2q >> SH3)) & 0x03FFFFFFu;
             if (++k == RX_R1) {
                 k = 0;
                 c0i[o] = i3i;
@@ -186,7 +214,8 @@ __global__ __launch_bounds__(64) void rx1_scan_tau_kernel(u32 *__restrict__ tau,
 __global__ __launch_bounds__(256) void rx1_comb_kernel(
     const u32 *__restrict__ c0rel, const u32 *__restrict__ i3start, int L, int nruns, long max_out,
     const rx_chan *__restrict__ chans, const int *__restrict__ chan_list, const long *__restrict__ nouts,
-    const u32 *__restrict__ cnt_before, int *__restrict__ c1buf, long c1_stride, u32 *__restrict__ hist_out)
+    const u32 *__restrict__ cnt_before, int *__restrict__ c1buf, long c1_stride, u32 *__restrict__ hist_out,
+    int RX_R1)
 {
     const int li = blockIdx.y;
     const rx_chan *ch = chans + chan_list[li];
@@ -225,7 +254,7 @@ __global__ __launch_bounds__(128) void rx2_fir_kernel(
     const int *__restrict__ c1buf, long c1_stride, const int *__restrict__ chan_list,
     const long *__restrict__ n1_before,       // rx1 outputs produced before this call
     const long *__restrict__ q_first, const int *__restrict__ nfinal,
-    unsigned short *__restrict__ out, long out_stride /* records */)
+    unsigned short *__restrict__ out, long out_stride /* records */, rx_mode md)
 {
     const int li = blockIdx.y, ch = chan_list[li];
     const int qi = blockIdx.x * 128 + threadIdx.x;
@@ -237,19 +266,20 @@ __global__ __launch_bounds__(128) void rx2_fir_kernel(
         const int *c1 = c1buf + ((long) ch * 2 + comp) * c1_stride + RX_HIST;    // c1[j - nb] = absolute rx1 output j
         long long acc = 0;
         const long nn = 2 * q + 1;            // fir_iq input index of this output
-        for (int k = 0; k < 65; k++) {
+        const int half = (md.ntaps - 1) >> 1;
+        for (int k = 0; k < md.ntaps; k++) {
             const long p = nn - k;            // rx2 output index
             int v2 = 0;
             if (p >= 0) {
-                int s = 0;                    // rx2: sum h[m] c1[3p + 2 - m] modulo 2^26, then round to 24 bits
-                for (int m = 0; m < 11; m++) {
-                    const long j = 3 * p + 2 - m;
-                    if (j >= 0) s += c_box3_5[m] * c1[j - nb];
+                int s = 0;                    // rx2: sum h[m] c1[r2 p + r2 - 1 - m] modulo 2^w2, then to 24 bits
+                for (int m = 0; m < md.nbox; m++) {
+                    const long j = md.r2 * p + md.r2 - 1 - m;
+                    if (j >= 0) s += c_box[md.tapset][m] * c1[j - nb];
                 }
-                s = sx(s, 26);
-                v2 = sx((s >> 2) + ((s >> 1) & 1), 24);
+                s = sx(s, md.w2);
+                v2 = md.round2 ? sx((s >> 2) + ((s >> 1) & 1), 24) : sx(s, 24);
             }
-            const int coef = sx(c_cicf_taps[k <= 32 ? k : 64 - k], 18);
+            const int coef = sx(c_cicf_taps[md.tapset][k <= half ? k : md.ntaps - 1 - k], 18);
             acc = sx64(acc + (long long) v2 * coef, 42);
         }
         y[comp] = sx((int) (acc >> 18), 24);
@@ -264,7 +294,7 @@ __global__ __launch_bounds__(128) void rx2_fir_kernel(
 __global__ __launch_bounds__(RX_HIST) void rx_finish_kernel(rx_chan *__restrict__ chans, const int *__restrict__ chan_list,
                                                            long n, const long *__restrict__ nouts,
                                                            const u32 *__restrict__ hist_new, int *__restrict__ c1buf,
-                                                           long c1_stride)
+                                                           long c1_stride, int RX_R1)
 {
     const int li = blockIdx.x, t = threadIdx.x;
     rx_chan *ch = chans + chan_list[li];
@@ -290,6 +320,7 @@ __global__ __launch_bounds__(RX_HIST) void rx_finish_kernel(rx_chan *__restrict_
 // ---------------------------------------------------------------------------
 struct kg_rxddc {
     kg_ctx *ctx;
+    rx_mode md;
     int nchan; long max_samples;
     rx_chan *d_chans; std::vector<rx_chan> h;
     u32 *d_nco;
@@ -302,15 +333,26 @@ extern "C" {
 
 int kg_rxddc_create(kg_ctx *ctx, int nchan, size_t max_samples, kg_rxddc **out)
 {
+    return kg_rxddc_create_mode(ctx, nchan, max_samples, KG_RXDDC_STD, out);
+}
+
+int kg_rxddc_decim(kg_rxddc *d) { return d ? d->md.r1 * d->md.r2 * 2 : KG_ERR_INVALID; }
+
+int kg_rxddc_create_mode(kg_ctx *ctx, int nchan, size_t max_samples, int mode, kg_rxddc **out)
+{
     int rc = kg_ctx_use(ctx);
     if (rc) return rc;
     KG_REQUIRE(out != nullptr, KG_ERR_INVALID, "kg_rxddc_create: out is null");
     *out = nullptr;
+    KG_REQUIRE(mode == KG_RXDDC_STD || mode == KG_RXDDC_WIDE || mode == KG_RXDDC_RX14, KG_ERR_INVALID,
+               "kg_rxddc_create_mode: mode %d", mode);
     KG_REQUIRE(nchan >= 1 && nchan <= 4096, KG_ERR_INVALID, "kg_rxddc_create: nchan %d", nchan);
     KG_REQUIRE(max_samples >= 64 && max_samples <= ((size_t) 1 << 32), KG_ERR_INVALID, "kg_rxddc_create: max_samples %zu", max_samples);
     kg_rxddc *d = new (std::nothrow) kg_rxddc();
     KG_REQUIRE(d != nullptr, KG_ERR_NOMEM, "kg_rxddc_create: alloc");
     d->ctx = ctx; d->nchan = nchan; d->max_samples = (long) max_samples;
+    d->md = RX_MODES[mode];
+    const int RX_R1 = d->md.r1;
     d->h.assign(nchan, rx_chan());
     for (auto &c : d->h) memset(&c, 0, sizeof c);
     d->max_runs = (int) ((max_samples + 63) / 64);
@@ -389,9 +431,10 @@ long kg_rxddc_outputs(kg_rxddc *d, int ch, size_t n)
 {
     if (!d || ch < 0 || ch >= d->nchan || !d->h[ch].active) return KG_ERR_INVALID;
     const rx_chan &c = d->h[ch];
+    const u64 RX_R1 = (u64) d->md.r1, two_r2 = 2 * (u64) d->md.r2;
     const u64 n1_after = c.n1 + ((u64) c.cnt1 + (u64) n) / RX_R1;
-    // final output q needs fir input 2q + 1, i.e. rx2 output 2q + 1, i.e. rx1 outputs up to 3 (2q + 1) + 2
-    auto finals = [](u64 n1) -> u64 { return n1 < 6 ? 0 : (n1 - 6) / 6 + 1; };   // largest q + 1 with 6 q + 5 < n1
+    // final output q needs fir input 2q + 1, i.e. rx2 output 2q + 1, i.e. rx1 outputs up to r2 (2q + 1) + r2 - 1
+    auto finals = [two_r2](u64 n1) -> u64 { return n1 < two_r2 ? 0 : (n1 - two_r2) / two_r2 + 1; };   // #q with 2 r2 q + 2 r2 - 1 < n1
     return (long) (finals(n1_after) - finals(c.n1));
 }
 
@@ -404,7 +447,8 @@ int kg_rxddc_push_dev(kg_rxddc *d, const void *d_adc, size_t n, const int32_t *c
     KG_REQUIRE(n >= 1 && (long) n <= d->max_samples, KG_ERR_INVALID, "kg_rxddc_push_dev: n %zu (max %ld)", n, d->max_samples);
     KG_REQUIRE(nlist >= 1 && nlist <= d->nchan, KG_ERR_INVALID, "kg_rxddc_push_dev: nlist %d", nlist);
     KG_REQUIRE(((uintptr_t) d_adc & 1) == 0 && ((uintptr_t) d_out & 1) == 0, KG_ERR_INVALID, "kg_rxddc_push_dev: misaligned pointer");
-    auto finals = [](u64 n1) -> u64 { return n1 < 6 ? 0 : (n1 - 6) / 6 + 1; };
+    const u64 RX_R1 = (u64) d->md.r1, two_r2 = 2 * (u64) d->md.r2;
+    auto finals = [two_r2](u64 n1) -> u64 { return n1 < two_r2 ? 0 : (n1 - two_r2) / two_r2 + 1; };
     std::vector<long> h_nouts(nlist), h_n1b(nlist), h_qfirst(nlist);
     std::vector<int> h_nfinal(nlist);
     std::vector<u32> h_cnt(nlist);
@@ -451,14 +495,14 @@ int kg_rxddc_push_dev(kg_rxddc *d, const void *d_adc, size_t n, const int32_t *c
     const dim3 grid((nruns + RX_THREADS - 1) / RX_THREADS, nlist);
     hipLaunchKernelGGL(rx1_run_kernel<false>, grid, dim3(RX_THREADS), 0, st, (const short *) d_adc, (long) n, L, nruns,
                        (const rx_chan *) d->d_chans, s_list, (const u32 *) d->d_nco, d->d_st,
-                       d->d_c0rel, d->d_tau, d->max_out);
+                       d->d_c0rel, d->d_tau, d->max_out, d->md);
     KG_HIP(hipGetLastError());
     hipLaunchKernelGGL(rx1_scan_kernel, dim3(2 * nlist), dim3(64), 0, st, d->d_st, (long) n, L, nruns, d->d_chans,
                        s_list);
     KG_HIP(hipGetLastError());
     hipLaunchKernelGGL(rx1_run_kernel<true>, grid, dim3(RX_THREADS), 0, st, (const short *) d_adc, (long) n, L, nruns,
                        (const rx_chan *) d->d_chans, s_list, (const u32 *) d->d_nco, d->d_st,
-                       d->d_c0rel, d->d_tau, d->max_out);
+                       d->d_c0rel, d->d_tau, d->max_out, d->md);
     KG_HIP(hipGetLastError());
     hipLaunchKernelGGL(rx1_scan_tau_kernel, dim3(2 * nlist), dim3(64), 0, st, d->d_tau, nruns, d->d_chans,
                        s_list);
@@ -467,17 +511,17 @@ int kg_rxddc_push_dev(kg_rxddc *d, const void *d_adc, size_t n, const int32_t *c
         hipLaunchKernelGGL(rx1_comb_kernel, dim3((unsigned) ((max_n1 + 255) / 256), nlist), dim3(256), 0, st,
                            (const u32 *) d->d_c0rel, (const u32 *) d->d_tau, L, nruns, d->max_out,
                            (const rx_chan *) d->d_chans, s_list, s_nouts,
-                           s_cnt, d->d_c1buf, d->c1_stride, d->d_hist);
+                           s_cnt, d->d_c1buf, d->c1_stride, d->d_hist, d->md.r1);
         KG_HIP(hipGetLastError());
     }
     if (max_final > 0) {
         hipLaunchKernelGGL(rx2_fir_kernel, dim3((max_final + 127) / 128, nlist), dim3(128), 0, st,
                            (const int *) d->d_c1buf, d->c1_stride, s_list, s_n1b,
-                           s_qfirst, s_nfinal, (unsigned short *) d_out, (long) out_stride);
+                           s_qfirst, s_nfinal, (unsigned short *) d_out, (long) out_stride, d->md);
         KG_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(rx_finish_kernel, dim3(nlist), dim3(RX_HIST), 0, st, d->d_chans, s_list, (long) n,
-                       s_nouts, (const u32 *) d->d_hist, d->d_c1buf, d->c1_stride);
+                       s_nouts, (const u32 *) d->d_hist, d->d_c1buf, d->c1_stride, d->md.r1);
     KG_HIP(hipGetLastError());
     for (int i = 0; i < nlist; i++) {
         rx_chan &c = d->h[chan_list[i]];

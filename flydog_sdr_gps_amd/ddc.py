@@ -78,6 +78,9 @@ class Ddc:
 
 
 RX_DECIM = 1736 * 3 * 2      # RX_DECIM_4CH (kiwi.config:141): RX1_STD_DECIM * RX2_STD_DECIM * CICF_DECIM_BY_2
+RX_DECIM_WIDE = 1543 * 2 * 2   # RX_DECIM_3CH (kiwi.config:140): the rx3 / 20.25 kHz instance
+# the RX instances the reference builds (KG_RXDDC_* in kiwigpu.h): rx4 / rx8, rx3, rx14
+RX_STD, RX_WIDE, RX_14 = 0, 1, 2
 
 
 def rx_phase_inc(freq_hz, adc_clock=125.0e6):
@@ -89,14 +92,15 @@ class RxDdc:
     """The per-channel audio DDC (verilog/rx/rx.v) for nchan channels (kg_rxddc):
     CmdSetRXFreq -> set_freq(ch, inc);  CmdGetRX -> push(adc) -> rx_iq_t records."""
 
-    def __init__(self, ctx=None, nchan=4, max_samples=1 << 24, device=0):
+    def __init__(self, ctx=None, nchan=4, max_samples=1 << 24, device=0, mode=RX_STD):
         self.ctx = ctx if ctx is not None else Context(device)
         self.lib = self.ctx.lib
-        self.nchan, self.max_samples = nchan, max_samples
+        self.nchan, self.max_samples, self.mode = nchan, max_samples, int(mode)
         h = C.c_void_p()
-        check(self.lib.kg_rxddc_create(self.ctx.h, int(nchan), int(max_samples), C.byref(h)),
-              "kg_rxddc_create")
+        check(self.lib.kg_rxddc_create_mode(self.ctx.h, int(nchan), int(max_samples), int(mode), C.byref(h)),
+              "kg_rxddc_create_mode")
         self.h = h
+        self.decim = check(self.lib.kg_rxddc_decim(h), "kg_rxddc_decim")
 
     def close(self):
         if getattr(self, "h", None):

@@ -262,13 +262,22 @@ int kg_ddc_wf_push_dev(kg_ddc *ddc, const void *d_adc, size_t n, const int32_t *
 /* ------------------------------------------------------------------------ */
 /* Audio DDC.  In the reference: one RX instance per audio channel in FPGA      */
 /* fabric (verilog/rx/rx.v:22-178): IQ_MIXER (22 bits) -> CIC N=3 R=1736 ->      */
-/* CIC N=5 R=3 -> 65-tap CICF /2 (fir_iq.sv) -> 24-bit IQ at ADC/10416, read as  */
+/* CIC N=5 R=3 -> 65-tap CICF /2 (fir_iq.sv) -> 24-bit IQ at ADC/10416 (the rx4 / */
+/* rx8 instance; rx3 and rx14: kg_rxddc_create_mode), read as                     */
 /* rx_iq_t records with CmdGetRX (rx/data_pump.cpp:101) after the NCO was set    */
 /* with CmdSetRXFreq (rx/rx_sound_cmd.cpp:41-51).                                */
 /* ------------------------------------------------------------------------ */
 typedef struct kg_rxddc kg_rxddc;
 
-int kg_rxddc_create(kg_ctx *ctx, int nchan, size_t max_samples, kg_rxddc **out);
+int kg_rxddc_create(kg_ctx *ctx, int nchan, size_t max_samples, kg_rxddc **out);   /* KG_RXDDC_STD */
+/* The RX instances the reference builds, selected by its RX_CFG (kiwi.config:101-105, 140-143;
+ * verilog/rx/fir_iq.sv:39-123; register widths as verilog/rx/cic_gen.c emits them):
+ *   KG_RXDDC_STD   rx4 / rx8: CIC 1736 -> CIC 3 -> 65-tap CICF / 2 = ADC / 10416 (12 kHz class)
+ *   KG_RXDDC_WIDE  rx3:       CIC 1543 -> CIC 2 -> 65-tap CICF (RX_CFG == 3 taps) / 2 = ADC / 6172 (20.25 kHz)
+ *   KG_RXDDC_RX14  rx14:      CIC 1736 -> CIC 3 -> 17-tap CICF (RX_CFG == 14 taps) / 2 = ADC / 10416 */
+enum { KG_RXDDC_STD = 0, KG_RXDDC_WIDE = 1, KG_RXDDC_RX14 = 2 };
+int kg_rxddc_create_mode(kg_ctx *ctx, int nchan, size_t max_samples, int mode, kg_rxddc **out);
+int kg_rxddc_decim(kg_rxddc *ddc);                          /* ADC samples per output record */
 void kg_rxddc_destroy(kg_rxddc *ddc);
 /* CmdSetRXFreq: 48-bit phase increment i_phase = round(f / adc_clk * 2^48).  The
  * filters keep running across a retune, as in the FPGA. */

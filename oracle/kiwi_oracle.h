@@ -219,10 +219,16 @@ typedef struct {
     int32_t fir_buf[2][65];      /* fir_iq bufI / bufQ, [0] newest                    */
 } ko_ddc_rx_state;
 
-extern const int32_t ko_cicf_taps65[33];
 void ko_ddc_rx_reset(ko_ddc_rx_state *s);
 int ko_ddc_rx(ko_ddc_rx_state *s, const int16_t *adc, long n, uint64_t phase_inc, uint8_t *out);
-int ko_ddc_shape(int which, int r, int *o);      /* 0 wf1, 1 rx1 (decimation r), 2 rx2 */
+/* The same for each RX instance the reference builds (kiwi.config:101-105, fir_iq.sv:39-123):
+ * KO_RX_STD rx4 / rx8 (1736 x 3 x 2, 65 taps), KO_RX_WIDE rx3 (1543 x 2 x 2, the RX_CFG == 3 taps),
+ * KO_RX_14 rx14 (1736 x 3 x 2, the 17-tap RX_CFG == 14 filter). */
+enum { KO_RX_STD = 0, KO_RX_WIDE = 1, KO_RX_14 = 2 };
+int ko_ddc_rx_mode(ko_ddc_rx_state *s, const int16_t *adc, long n, uint64_t phase_inc, uint8_t *out, int mode);
+int ko_ddc_rx_decim(int mode);                   /* total decimation: 10416 / 6172 / 10416 */
+extern const int32_t ko_cicf_taps65[33], ko_cicf_taps65_wide[33], ko_cicf_taps17[9];
+int ko_ddc_shape(int which, int r, int *o);      /* 0 wf1, 1 rx1 (decimation r), 2 rx2, 3 rx2 wide */
 
 /* ---- part 6: S-meter, CAgc, AM / NBFM detectors (kiwi_oracle_post.c) ---- */
 #define KO_AGC_MAX_DELAY_BUF 2048        /* agc.h:16 */

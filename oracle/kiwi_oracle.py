@@ -564,16 +564,24 @@ class DdcRxState(C.Structure):
 RX_DECIM = 1736 * 3 * 2          # RX_DECIM_4CH, kiwi.config:141
 
 
-def ddc_rx(adc, phase_inc, state=None):
+RX_STD, RX_WIDE, RX_14 = 0, 1, 2     # the RX instances of kiwi.config / fir_iq.sv (KO_RX_*)
+
+
+def ddc_rx_decim(mode=RX_STD):
+    return int(lib().ko_ddc_rx_decim(int(mode)))
+
+
+def ddc_rx(adc, phase_inc, state=None, mode=RX_STD):
     """-> (rx_iq_t bytes uint8[nout*6], state)."""
     L = lib()
-    L.ko_ddc_rx.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_uint64, C.c_void_p]
-    L.ko_ddc_rx.restype = C.c_int
+    L.ko_ddc_rx_mode.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_uint64, C.c_void_p, C.c_int]
+    L.ko_ddc_rx_mode.restype = C.c_int
     adc = np.ascontiguousarray(adc, np.int16)
     if state is None:
         state = DdcRxState()
-    out = np.zeros((adc.size // RX_DECIM + 2) * 6, np.uint8)
-    n = L.ko_ddc_rx(C.byref(state), _p(adc), adc.size, C.c_uint64(phase_inc & ((1 << 48) - 1)), _p(out))
+    out = np.zeros((adc.size // ddc_rx_decim(mode) + 2) * 6, np.uint8)
+    n = L.ko_ddc_rx_mode(C.byref(state), _p(adc), adc.size, C.c_uint64(phase_inc & ((1 << 48) - 1)), _p(out),
+                         int(mode))
     return out[:6 * n].copy(), state
 
 

@@ -156,6 +156,12 @@ int ko_ddc_shape(int which, int r, int *o)
         for (int i = 0; i < 3; i++) o[k++] = RX1_COMB_W[i];
         for (int i = 0; i < 3; i++) o[k++] = RX1_COMB_D[i];
         o[k++] = 19; o[k++] = 18; o[k++] = 1;
+    } else if (which == 3) {                   /* rx2 wide: cic_rx2_20k.vh, N = 5, R = 2, 24 bits, no rounding */
+        o[k++] = 5; o[k++] = 18; o[k++] = 24;
+        for (int i = 0; i < 5; i++) o[k++] = 24;
+        for (int i = 0; i < 5; i++) o[k++] = 24;
+        for (int i = 0; i < 5; i++) o[k++] = 0;
+        o[k++] = 23; o[k++] = 24; o[k++] = -1;
     } else {                                   /* rx2: cic_rx2_12k.vh, N = 5, R = 3, 18 -> 24 bits, unpruned */
         o[k++] = 5; o[k++] = 18; o[k++] = 24;
         for (int i = 0; i < 5; i++) o[k++] = 26;
@@ -199,13 +205,40 @@ void ko_ddc_rx_reset(ko_ddc_rx_state *s)
     memset(s, 0, sizeof *s);
 }
 
+/* fir_iq.sv:45-77, the RX_CFG == 3 table (wide: "N=5,R=2,M=1, cutoff at 8 kHz") */
+const int32_t ko_cicf_taps65_wide[33] = {
+    0x0005f, 0x3ffa4, 0x3ff6c, 0x0003c, 0x000e6, 0x0000a, 0x3feb1, 0x3ff63, 0x001ad, 0x00199, 0x3fe3e,
+    0x3fcfe, 0x0013d, 0x004b1, 0x00036, 0x3f9b3, 0x3fd2b, 0x0074d, 0x006b9, 0x3f904, 0x3f444, 0x00481,
+    0x01177, 0x00126, 0x3e8ca, 0x3f490, 0x01bd5, 0x01d5a, 0x3e30e, 0x3bf82, 0x00f77, 0x0ac26, 0x0fd54,
+};
+/* fir_iq.sv:79-88, the RX_CFG == 14 table (17 taps) */
+const int32_t ko_cicf_taps17[9] = {
+    0x001dd, 0x001dd, 0x001dd, 0x3f290, 0x3ee98, 0x006e8, 0x04205, 0x084ab, 0x0a235,
+};
+
+/* The three RX instances kiwi.config / fir_iq.sv build (KO_RX_STD: rx4 / rx8, RX_CFG 4 and 8;
+ * KO_RX_WIDE: rx3, RX_CFG 3, the 20.25 kHz mode; KO_RX_14: rx14, RX_CFG 14).  rx1 / rx2 widths are
+ * what verilog/rx/cic_gen.c emits for the decimations of kiwi.config:101-105 -- pinned by
+ * tests/golden/cic_ref.json, which holds cic_gen.c's own output (tests/test_ref_pins_cpu.py):
+ *   std / rx14: rx1 R 1736, acc 55, third integrator [54 -: 26]; rx2 R 3, 26 bits, out [25 -: 24] + [1]
+ *   wide:       rx1 R 1543, acc 54, third integrator [53 -: 26]; rx2 R 2, 24 bits, out [23 -: 24] */
+typedef struct { int r1, r2, acc1, w2, round2, ntaps; const int32_t *taps; } rx_mode;
+static const rx_mode RX_MODES[3] = {
+    { 1736, 3, 55, 26, 1, 65, ko_cicf_taps65 },
+    { 1543, 2, 54, 24, 0, 65, ko_cicf_taps65_wide },
+    { 1736, 3, 55, 26, 1, 17, ko_cicf_taps17 },
+};
+
+int ko_ddc_rx_decim(int mode) { return RX_MODES[mode].r1 * RX_MODES[mode].r2 * 2; }
+
 /* One audio channel over n ADC samples.  out: rx_iq_t records (6 bytes each).
  * Returns the number of records written. */
-int ko_ddc_rx(ko_ddc_rx_state *s, const int16_t *adc, long n, uint64_t phase_inc, uint8_t *out)
+int ko_ddc_rx_mode(ko_ddc_rx_state *s, const int16_t *adc, long n, uint64_t phase_inc, uint8_t *out, int mode)
 {
     nco_init();
-    const uint64_t M48 = (1ULL << 48) - 1, M55 = (1ULL << 55) - 1;
-    const int R1 = 1736, R2 = 3;
+    const rx_mode *md = &RX_MODES[mode];
+    const uint64_t M48 = (1ULL << 48) - 1, MACC = (1ULL << md->acc1) - 1;
+    const int R1 = md->r1, R2 = md->r2, SH3 = md->acc1 - 26, W2 = md->w2, NT = md->ntaps;
     int nout = 0;
     for (long t = 0; t < n; t++) {
         const int a = (int) (s->phase >> 35);
@@ -215,10 +248,10 @@ int ko_ddc_rx(ko_ddc_rx_state *s, const int16_t *adc, long n, uint64_t phase_inc
         s->cnt1 = strobe1 ? 0 : s->cnt1 + 1;
         int32_t c1[2] = {0, 0};
         for (int c = 0; c < 2; c++) {
-            /* rx1: integrators 55, 55, 26 bits */
-            s->i1[c] = (s->i1[c] + (uint64_t) (int64_t) m[c]) & M55;
-            s->i2[c] = (s->i2[c] + s->i1[c]) & M55;
-            s->i3[c] = (s->i3[c] + (uint32_t) (s->i2[c] >> 29)) & 0x03FFFFFF;      /* [54 -: 26] */
+            /* rx1: integrators acc, acc, 26 bits */
+            s->i1[c] = (s->i1[c] + (uint64_t) (int64_t) m[c]) & MACC;
+            s->i2[c] = (s->i2[c] + s->i1[c]) & MACC;
+            s->i3[c] = (s->i3[c] + (uint32_t) (s->i2[c] >> SH3)) & 0x03FFFFFF;     /* [acc-1 -: 26] */
             if (strobe1) {
                 const int *W = RX1_COMB_W, *D = RX1_COMB_D;
                 int64_t v = sext(s->i3[c], 26);
@@ -232,32 +265,33 @@ int ko_ddc_rx(ko_ddc_rx_state *s, const int16_t *adc, long n, uint64_t phase_inc
             }
         }
         if (!strobe1) continue;
-        /* rx2: N = 5, R = 3, 26-bit registers, no pruning */
+        /* rx2: N = 5, R = R2, W2-bit registers, no pruning */
         const int strobe2 = (s->cnt2 == (uint32_t) (R2 - 1));
         s->cnt2 = strobe2 ? 0 : s->cnt2 + 1;
         int32_t c2[2] = {0, 0};
         for (int c = 0; c < 2; c++) {
             int64_t v = c1[c];
-            for (int k = 0; k < 5; k++) { s->j[c][k] = sext((uint64_t) (s->j[c][k] + v), 26); v = s->j[c][k]; }
+            for (int k = 0; k < 5; k++) { s->j[c][k] = sext((uint64_t) (s->j[c][k] + v), W2); v = s->j[c][k]; }
             if (strobe2) {
                 for (int k = 0; k < 5; k++) {
-                    const int64_t y = sext((uint64_t) (v - s->comb2_prev[c][k]), 26);
+                    const int64_t y = sext((uint64_t) (v - s->comb2_prev[c][k]), W2);
                     s->comb2_prev[c][k] = v;
                     v = y;
                 }
-                c2[c] = (int32_t) sext((uint64_t) ((v >> 2) + ((v >> 1) & 1)), 24);   /* comb5[25 -: 24] + comb5[1] */
+                c2[c] = md->round2 ? (int32_t) sext((uint64_t) ((v >> 2) + ((v >> 1) & 1)), 24)   /* comb5[25 -: 24] + comb5[1] */
+                                   : (int32_t) sext((uint64_t) v, 24);                             /* comb5[23 -: 24] */
             }
         }
         if (!strobe2) continue;
-        /* fir_iq: shift register, 65 symmetric taps, 42-bit accumulator, out = acc[41 -: 24],
+        /* fir_iq: shift register, NT symmetric taps, 42-bit accumulator, out = acc[41 -: 24],
          * an output on every second input (decim_by_2 starts at 0, fir_iq.sv:125-170) */
         int32_t y[2];
         for (int c = 0; c < 2; c++) {
-            memmove(&s->fir_buf[c][1], &s->fir_buf[c][0], sizeof(int32_t) * 64);
+            memmove(&s->fir_buf[c][1], &s->fir_buf[c][0], sizeof(int32_t) * (NT - 1));
             s->fir_buf[c][0] = c2[c];
             int64_t acc = 0;
-            for (int k = 0; k < 65; k++) {
-                const int32_t coef = (int32_t) sext((uint64_t) ko_cicf_taps65[k <= 32 ? k : 64 - k], 18);
+            for (int k = 0; k < NT; k++) {
+                const int32_t coef = (int32_t) sext((uint64_t) md->taps[k <= (NT - 1) / 2 ? k : NT - 1 - k], 18);
                 acc = sext((uint64_t) (acc + (int64_t) s->fir_buf[c][k] * coef), 42);
             }
             y[c] = (int32_t) sext((uint64_t) (acc >> 18), 24);
@@ -272,4 +306,9 @@ int ko_ddc_rx(ko_ddc_rx_state *s, const int16_t *adc, long n, uint64_t phase_inc
         o[4] = (uint8_t) (y[1] >> 16); o[5] = (uint8_t) (y[0] >> 16);
     }
     return nout;
+}
+
+int ko_ddc_rx(ko_ddc_rx_state *s, const int16_t *adc, long n, uint64_t phase_inc, uint8_t *out)
+{
+    return ko_ddc_rx_mode(s, adc, n, phase_inc, out, KO_RX_STD);
 }

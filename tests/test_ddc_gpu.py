@@ -227,3 +227,58 @@ def test_many_small_decimations_take_the_staged_strobe_path(gpu_ctx, oracle):
                 assert np.array_equal(got[ch], want), (ch, l2[ch], n)
     finally:
         d.close()
+
+
+# ---- the other RX instances: rx3 (wide, 20.25 kHz) and rx14 (17-tap CICF) ----------------------
+from flydog_sdr_gps_amd.ddc import RX_14, RX_DECIM_WIDE, RX_STD, RX_WIDE   # noqa: E402
+
+
+@pytest.mark.parametrize("mode", [RX_WIDE, RX_14, RX_STD])
+def test_rx_ddc_instances_bit_exact_ragged_retune_multichannel(gpu_ctx, oracle, mode):
+    """kiwi.config:101-105 / fir_iq.sv:39-123: 1543 x 2 x 2 with the RX_CFG == 3 taps, and 1736 x 3 x 2
+    with the 17-tap RX_CFG == 14 filter, bit-exact against the sequential oracle for ragged pushes,
+    a mid-stream retune, several channels and a reset."""
+    decim = {RX_STD: RX_DECIM, RX_WIDE: RX_DECIM_WIDE, RX_14: RX_DECIM}[mode]
+    nch, n = 5, decim * 36 + 777
+    adc = adc_stream(n, seed=31 + mode, tones=((0.0912, 14000.0), (0.0912 + 3000 / 125e6, 1500.0), (0.27, 6000.0)))
+    d = RxDdc(gpu_ctx, nchan=nch, max_samples=n, mode=mode)
+    assert d.decim == decim == oracle.ddc_rx_decim(mode)
+    incs = [(-rx_phase_inc((0.0912 + 2e-6 * ch) * 125e6)) & ((1 << 48) - 1) for ch in range(nch)]
+    inc2 = (-rx_phase_inc(0.0912 * 125e6 + 2200)) & ((1 << 48) - 1)
+    for ch in range(nch):
+        d.set_freq(ch, incs[ch])
+    chans = list(range(nch))
+    sts, parts, wants, pos = [None] * nch, [[] for _ in chans], [[] for _ in chans], 0
+    for k, step in enumerate((1, decim - 1, decim, 2 * decim + 1, 63, 100003, 5, n)):
+        if pos >= n:
+            break
+        if k == 4:
+            d.set_freq(2, inc2)                       # retune one channel: its filters keep running
+            incs[2] = inc2
+        seg = adc[pos:pos + step]
+        pos += len(seg)
+        got = d.push(seg, chans)
+        for ch in chans:
+            w, sts[ch] = oracle.ddc_rx(seg, incs[ch], sts[ch], mode=mode)
+            parts[ch].append(got[ch])
+            wants[ch].append(w)
+    for ch in chans:
+        g, w = np.concatenate(parts[ch]), np.concatenate(wants[ch])
+        assert g.size == w.size and g.size >= 6 * 35, (ch, g.size, w.size)
+        assert np.array_equal(g, w), (mode, ch)
+    d.reset(1)
+    d.set_freq(1, incs[1])
+    again = d.push(adc[:decim * 20], [1])[0]
+    assert np.array_equal(again, oracle.ddc_rx(adc[:decim * 20], incs[1], mode=mode)[0])
+    d.close()
+
+
+def test_rx_ddc_wide_mode_differs_and_rejects_bad_mode(gpu_ctx):
+    from flydog_sdr_gps_amd import KiwiGpuError
+    with pytest.raises(KiwiGpuError):
+        RxDdc(gpu_ctx, nchan=1, max_samples=1 << 16, mode=7)
+    d = RxDdc(gpu_ctx, nchan=1, max_samples=1 << 20, mode=RX_WIDE)
+    assert d.outputs(0, RX_DECIM_WIDE * 10) < 0            # no frequency set yet
+    d.set_freq(0, 12345)
+    assert d.outputs(0, RX_DECIM_WIDE * 10) == 10           # one record per 6172 ADC samples
+    d.close()

@@ -129,3 +129,56 @@ def test_adpcm_oracle_matches_reference_ima_adpcm_cpp(oracle):
         # and the packet builder puts exactly these bytes behind its 16-byte header
         pkt = oracle.wf_packet(r, 1234, 5, 77, True)
         assert np.array_equal(pkt[16:], want_e)
+
+
+def test_cic_shapes_match_reference_cic_gen_c(oracle):
+    """verilog/rx/cic_gen.c, compiled from its own source and run with the reference's kiwi.gen.h,
+    emits the register widths, truncations and output slices of every CIC instance (cic_ref.json holds
+    its output).  The DDC oracle -- and through it the HIP kernels -- must use exactly these, for the
+    std (1736 / 3) AND the wide (1543 / 2) decimations and for the waterfall CIC."""
+    c = json.load(open(os.path.join(GOLD, "cic_ref.json")))
+
+    def flat(e):
+        n = e["N"]
+        integ, combs = e["integrators"], e["combs"]
+        trunc = e["trunc"]                       # N integrator inputs, N comb inputs, the output
+        comb_drop = trunc[n:2 * n]
+        return [n, e["Bin"], e["Bout"]] + integ + combs + comb_drop + e["out"][1:]
+
+    wf1 = c["cic_wf1"]
+    assert (wf1["N"], wf1["R"], wf1["acc"]) == (5, 8192, 89)
+    assert oracle.ddc_shape(0) == flat(wf1)
+    for name, which, r in (("cic_rx1_12k", 1, 1736), ("cic_rx1_20k", 1, 1543)):
+        e = c[name]
+        assert e["R"] == r and e["integrators"][:2] == [e["acc"], e["acc"]]
+        assert oracle.ddc_shape(which, r) == flat(e), name
+        assert e["trunc"][2] == e["acc"] - 26                # what the third integrator drops
+    assert oracle.ddc_shape(2) == flat(c["cic_rx2_12k"]) and c["cic_rx2_12k"]["R"] == 3
+    assert oracle.ddc_shape(3) == flat(c["cic_rx2_20k"]) and c["cic_rx2_20k"]["R"] == 2
+    k = json.load(open(os.path.join(GOLD, "consts_ref.json")))
+    assert (k["RX1_STD_DECIM"], k["RX2_STD_DECIM"], k["RX1_WIDE_DECIM"], k["RX2_WIDE_DECIM"]) == (1736, 3, 1543, 2)
+    assert oracle.ddc_rx_decim(oracle.RX_STD) == 1736 * 3 * 2 and oracle.ddc_rx_decim(oracle.RX_WIDE) == 1543 * 2 * 2
+
+
+@pytest.mark.skipif(not os.path.isfile("/root/reference/verilog/rx/fir_iq.sv"), reason="reference tree not present")
+def test_all_three_cicf_tap_sets_match_fir_iq_sv(oracle):
+    """fir_iq.sv:45-123: the RX_CFG == 3, RX_CFG == 14 and default coefficient tables."""
+    import ctypes as C
+    import re
+    text = open("/root/reference/verilog/rx/fir_iq.sv").read()
+    # the three `assign taps[..] = COEFF'('sh.....)` runs, in file order: RX_CFG == 3, == 14, default
+    allt = [(int(i), int(h, 16)) for i, h in
+            re.findall(r"assign taps\[\s*(\d+)\]\s*=\s*COEFF'\('sh([0-9a-f]{5})\)", text)]
+    sets, cur = [], []
+    for i, v in allt:
+        if i == 0 and cur:
+            sets.append(cur)
+            cur = []
+        cur.append(v)
+    sets.append(cur)
+    assert [len(x) for x in sets] == [33, 9, 33]
+    L = oracle.lib()
+    for name, n, want in (("ko_cicf_taps65_wide", 33, sets[0]), ("ko_cicf_taps17", 9, sets[1]),
+                          ("ko_cicf_taps65", 33, sets[2])):
+        got = list((C.c_int32 * n).in_dll(L, name))
+        assert got == want[:n] and len(want) >= n, name
