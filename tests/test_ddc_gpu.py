@@ -278,7 +278,8 @@ def test_rx_ddc_wide_mode_differs_and_rejects_bad_mode(gpu_ctx):
     with pytest.raises(KiwiGpuError):
         RxDdc(gpu_ctx, nchan=1, max_samples=1 << 16, mode=7)
     d = RxDdc(gpu_ctx, nchan=1, max_samples=1 << 20, mode=RX_WIDE)
-    assert d.outputs(0, RX_DECIM_WIDE * 10) < 0            # no frequency set yet
+    with pytest.raises(KiwiGpuError):
+        d.outputs(0, RX_DECIM_WIDE * 10)                    # no frequency set yet
     d.set_freq(0, 12345)
     assert d.outputs(0, RX_DECIM_WIDE * 10) == 10           # one record per 6172 ADC samples
     d.close()
