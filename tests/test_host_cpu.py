@@ -631,3 +631,18 @@ def test_sats_table_pinned_against_reference():
         ref.append((int(prn_), lit(t1), lit(t2), kind))
     assert ref == [tuple(r) for r in sats.SATS]
     assert len(ref) == 32 + 4 + 23 and len(ref) <= sats.MAX_SATS
+
+
+def test_cpp_example_builds_against_the_header_and_fails_loudly_without_a_gpu(tmp_path):
+    """examples/search_dropin.cpp: a C++11 translation unit that includes only include/kiwigpu.h, links
+    libkiwigpu.so and runs the SearchInit / Sample / Correlate / ChanStart sequence.  Here (no GPU) it
+    must build, start, and stop at kg_ctx_create with the no-device error -- no CPU fallback."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "examples")])
+    exe = os.path.join(ROOT, "examples", "search_dropin")
+    f = tmp_path / "bits.bin"
+    f.write_bytes(bytes(8192))
+    out = subprocess.run([exe, str(f)], capture_output=True, text=True, timeout=120)
+    if _have_gpu_count(1):
+        assert out.returncode == 0
+    else:
+        assert out.returncode == 1 and "no HIP device" in out.stderr and "no CPU fallback" in out.stderr

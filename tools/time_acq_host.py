@@ -39,6 +39,25 @@ for name, fn, arg, nsamp in (("int16 IQ, 256 KiB/block", s.sample_iq16, iq, 6553
     t_pipe = (time.perf_counter() - t0) / n
     print("%-26s synchronous %6.1f us/block = %6.1f Msamples/s;  8 in flight %6.1f us/block = %6.1f Msamples/s"
           % (name, t_sync * 1e6, nsamp / t_sync / 1e6, t_pipe * 1e6, nsamp / t_pipe / 1e6))
+# The reference's own calling pattern (gps/search.cpp:571-575): ONE SV per Correlate() call, the SV list
+# changing on every call.  Per call: enqueue (pair table staged through the ring, no stream sync),
+# poll until idle (where the reference's coroutine yields), fetch the 16-byte result.
+s.sample(bits, block=0)
+ctx.sync()
+lat, enq = [], []
+for rep in range(20):
+    for sv in svs:
+        t0 = time.perf_counter()
+        s.correlate_async([sv], nblocks=1)
+        t1 = time.perf_counter()
+        while not ctx.poll():
+            pass
+        s.fetch(want_cells=False)
+        lat.append(time.perf_counter() - t0)
+        enq.append(t1 - t0)
+lat.sort(); enq.sort()
+print("one SV per Correlate() call (41 cells): %6.1f us median, %6.1f us min per call; host enqueue %5.1f us median "
+      "(never waits for the stream)" % (lat[len(lat) // 2] * 1e6, lat[0] * 1e6, enq[len(enq) // 2] * 1e6))
 for B in (8, 32):
     s2 = Searcher(ctx, max_blocks=2 * B)
     for sat in svs:
