@@ -244,7 +244,7 @@ struct acq_walk {
 // = W_R^{4a k2} * W_R^{b k2}.  comb[k2] = { W_R^{k2}, W_R^{2 k2}, W_R^{3 k2},
 // W_R^{4 k2}, W_R^{8 k2}, W_R^{12 k2}, -, - } (host-built, fp32 roundings of double
 // values); quart[k2][q] = W_P^{q k2}: the factor of output quarter q (NQ = 4).
-template <int P, int NQ, bool PREFETCH, bool STAMPS = false>
+template <int P, int NQ, bool PREFETCH, bool STAMPS = false>   // PREFETCH: always true (kept in the names)
 __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
     const float2 *__restrict__ data,  // [nblocks][P][4096]
     const float2 *__restrict__ code,  // [max_sats][P][8 rows][2 (256 + 2 H)]
@@ -266,9 +266,24 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
     // diagnostics: one workgroup, thread 0, 16 stamps per (cell, k2) item
     unsigned long long *st = (STAMPS && t == 0 && blockIdx.x == 8) ? stamps : nullptr;
     if (STAMPS && st) { st[0] = __builtin_amdgcn_s_memtime(); st[1] = __builtin_amdgcn_s_memrealtime(); }
+    // diagnostics: every workgroup's start / end (100 MHz), XCC id and cell count at stamps[512 + 4 b ..]
+    unsigned long long *wgt = (STAMPS && t == 0) ? stamps + 512 + 4 * blockIdx.x : nullptr;
+    int wg_cells = 0;
+    if (STAMPS && wgt) {
+        wgt[0] = __builtin_amdgcn_s_memrealtime();
+        wgt[2] = (unsigned long long) __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID, all 32 bits
+    }
 
     kg_tw4096 tw;
     kg_tw4096_load(tw, tab4096, t);
+    // W_N^{t*k2}, the lane half of the combine twiddle, from registers: W_N^{t*b} (b = 1..3) and,
+    // for P = 16, W_N^{4*t*a} (a = 1..3); no per-item vector load, whose s_waitcnt would also drain
+    // the operand prefetch of the next item
+    cf wb[3], wa[3];
+#pragma unroll
+    for (int i = 1; i < 4; i++) { wb[i - 1] = kg_ld(&tabN[t * i]); wa[i - 1] = kg_ld(&tabN[(4 * t * i) & (P * SUB - 1)]); }
+    (void) wa;
+    auto sel3 = [](const cf (&w)[3], int i) { return i == 1 ? w[0] : (i == 2 ? w[1] : w[2]); };
 
     // XCD-aware: workgroups b and b+8 share an XCD (round-robin dispatch), so the
     // cells of one (block, SV) pair -- one code spectrum -- all belong to one
@@ -311,7 +326,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
     int pg = slot / ndop, di = slot - pg * ndop;       // once per workgroup
     if (pg >= gpairs) return;
     acq_cell_desc cur = describe(pg, di);
-    if (PREFETCH) fetch(cur.data_off, cur.code_off, cur.dop, 0);
+    fetch(cur.data_off, cur.code_off, cur.dop, 0);
 
     int st_item = 0;
     for (;;) {
@@ -327,14 +342,23 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
         for (int k2 = 0; k2 < P; k2++) {
             unsigned long long *sti = (STAMPS && st && st_item < 24) ? st + 16 + 16 * st_item : nullptr;
             KG_STAMP(STAMPS, sti, 8);
-            if (!PREFETCH) fetch(cur.data_off, cur.code_off, cur.dop, k2);
-            const cf base = kg_ld(&tabN[t * k2]);              // W_N^{t*k2}, used after the transform
+            cf base;                                           // W_N^{t*k2}, used after the transform
+            if constexpr (P == 4) base = sel3(wb, k2);
+            else {
+                const int ka = k2 >> 2, kb = k2 & 3;
+                const cf A = sel3(wa, ka), Bv = sel3(wb, kb);
+                base = ka == 0 ? Bv : (kb == 0 ? A : kg_cmul(A, Bv));
+            }
             cf x[16], y[16];
             // conj(data) * code, simd_multiply_conjugate_ccc (support/simd.cpp:39-67)
 #pragma unroll
-            for (int j = 0; j < 16; j++) x[j] = kg_cmulc(c[j], d[j]);
+            for (int j = 0; j < 16; j += 4) {
+                x[j] = c[j]; x[j + 1] = c[j + 1]; x[j + 2] = c[j + 2]; x[j + 3] = c[j + 3];
+                kg_cmul4v<true>(x[j], x[j + 1], x[j + 2], x[j + 3], d[j], d[j + 1], d[j + 2], d[j + 3]);
+            }
             KG_STAMP(STAMPS, sti, 9);
-            if (PREFETCH && (k2 < P - 1 || more)) {    // one load site: (cur, k2+1) or (nxt, 0)
+            {   // one load site, never skipped (the very last item re-reads its own cell: harmless), so
+                // that the compiler's wait counts stay exact across the loop
                 const bool same = k2 < P - 1;
                 fetch(same ? cur.data_off : nxt.data_off, same ? cur.code_off : nxt.code_off,
                       same ? cur.dop : nxt.dop, (k2 + 1) & (P - 1));
@@ -363,6 +387,24 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
                 B[0] = base;
 #pragma unroll
                 for (int a = 1; a < 4; a++) B[a] = kg_cmul_s(base, G[a - 1]);
+                if constexpr (NQ == 1) {
+                    // acc[m] += y[m] * C[m], C[4a + b] = B[a] * g[b]: the twiddles are combined first
+                    // (wave-uniform factors), the products accumulate through fused multiply-adds
+#pragma unroll
+                    for (int a = 0; a < 4; a++) {
+                        cf C1 = B[a], C2 = B[a], C3 = B[a], C0 = B[a];
+                        {
+                            cf r1, r2, r3;
+                            asm(KG_MUL_("%3", "%0", "%6") KG_MUL_("%4", "%1", "%7") KG_MUL_("%5", "%2", "%8")
+                                KG_FMA_("%0", "%6", "%3", "neg_lo:[0,1,0]") KG_FMA_("%1", "%7", "%4", "neg_lo:[0,1,0]")
+                                KG_FMA_("%2", "%8", "%5", "neg_lo:[0,1,0]")
+                                : "+v"(C1), "+v"(C2), "+v"(C3), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                                : "s"(g[0]), "s"(g[1]), "s"(g[2]));
+                        }
+                        kg_cmac4v(acc[0][4 * a], acc[0][4 * a + 1], acc[0][4 * a + 2], acc[0][4 * a + 3],
+                                  y[4 * a], y[4 * a + 1], y[4 * a + 2], y[4 * a + 3], C0, C1, C2, C3);
+                    }
+                } else
 #pragma unroll
                 for (int m = 0; m < 16; m++) {
                     cf z = y[m];
@@ -431,10 +473,12 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
             }
         }
 #undef ACQ_RED_STEP
+        if (STAMPS) wg_cells++;
         if (!more) break;
         cur = nxt; pg = npg; di = ndi;
     }
     if (STAMPS && st) { st[2] = __builtin_amdgcn_s_memtime(); st[3] = __builtin_amdgcn_s_memrealtime(); }
+    if (STAMPS && wgt) { wgt[1] = __builtin_amdgcn_s_memrealtime(); wgt[3] = (unsigned long long) wg_cells; }
 }
 
 // search.cpp:455,495: best Doppler bin per (block, SV): the serial scan keeps the
@@ -1129,13 +1173,14 @@ void *kg_acq_results_dev(kg_acq *a) { return a ? (void *) a->d_results : nullptr
 int kg_acq_debug_corr_stamps(kg_acq *a, int nblocks, const int *sats, int nsats,
                              unsigned long long *stamps, int n)
 {
-    KG_REQUIRE(a && stamps && n >= 16 + 16 * 24, KG_ERR_INVALID, "kg_acq_debug_corr_stamps: need 400 slots");
+    KG_REQUIRE(a && stamps && n >= 512 + 4 * 1024, KG_ERR_INVALID, "kg_acq_debug_corr_stamps: need 4608 slots");
     int rc = kg_acq_correlate_async(a, nblocks, sats, nsats);      // builds the lists, warms up
     if (rc) return rc;
     KG_REQUIRE(a->np1 > 0, KG_ERR_STATE, "kg_acq_debug_corr_stamps: no C/A SV in the list");
     hipStream_t st = a->ctx->stream;
     unsigned long long *d = nullptr;
-    const size_t bytes = sizeof(unsigned long long) * (16 + 16 * 24);
+    const size_t bytes = sizeof(unsigned long long) * (512 + 4 * 1024);
+    KG_REQUIRE(a->grid1 <= 1024, KG_ERR_STATE, "kg_acq_debug_corr_stamps: grid %d", a->grid1);
     KG_HIP(hipMalloc((void **) &d, bytes));
     KG_HIP(hipMemset(d, 0, bytes));
     if (a->P == 4) {

@@ -98,6 +98,79 @@ template <int SIGN> KG_DEV cf kg_twmul_s(cf a, cf w)
 template <int SIGN> KG_DEV cf kg_add_sj(cf a, cf b) { return SIGN > 0 ? kg_addj(a, b) : kg_subj(a, b); }
 template <int SIGN> KG_DEV cf kg_sub_sj(cf a, cf b) { return SIGN > 0 ? kg_subj(a, b) : kg_addj(a, b); }
 
+// ---------------------------------------------------------------------------
+// Batched complex products.  hipcc puts one wait state (s_nop) between an inline-asm definition and
+// the instruction that reads it (it cannot see that the asm is not a partial-register write), and a
+// product's multiply feeds its fused multiply-add directly: 85 of the 451 vector instructions of a
+// correlator item were followed by an s_nop and a dependent issue.  These blocks hold four independent
+// products each -- the four multiplies, then the four multiply-adds -- so neither happens.
+// a_i <- a_i * w_i (CONJ = false) or a_i * conj(w_i) (CONJ = true), in place.
+// ---------------------------------------------------------------------------
+#define KG_MUL_(r, a, w) "v_pk_mul_f32 " r ", " a ", " w " op_sel_hi:[1,0]\n\t"
+#define KG_FMA_(a, w, r, neg) "v_pk_fma_f32 " a ", " a ", " w ", " r " op_sel:[1,1,0] op_sel_hi:[0,1,1] " neg "\n\t"
+
+template <bool CONJ> KG_DEV void kg_cmul4v(cf &a0, cf &a1, cf &a2, cf &a3, cf w0, cf w1, cf w2, cf w3)
+{
+    cf r0, r1, r2, r3;
+    if constexpr (!CONJ)
+        asm(KG_MUL_("%4", "%0", "%8") KG_MUL_("%5", "%1", "%9") KG_MUL_("%6", "%2", "%10") KG_MUL_("%7", "%3", "%11")
+            KG_FMA_("%0", "%8", "%4", "neg_lo:[0,1,0]") KG_FMA_("%1", "%9", "%5", "neg_lo:[0,1,0]")
+            KG_FMA_("%2", "%10", "%6", "neg_lo:[0,1,0]") KG_FMA_("%3", "%11", "%7", "neg_lo:[0,1,0]")
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+            : "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+    else
+        asm(KG_MUL_("%4", "%0", "%8") KG_MUL_("%5", "%1", "%9") KG_MUL_("%6", "%2", "%10") KG_MUL_("%7", "%3", "%11")
+            KG_FMA_("%0", "%8", "%4", "neg_hi:[0,1,0]") KG_FMA_("%1", "%9", "%5", "neg_hi:[0,1,0]")
+            KG_FMA_("%2", "%10", "%6", "neg_hi:[0,1,0]") KG_FMA_("%3", "%11", "%7", "neg_hi:[0,1,0]")
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+            : "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+}
+// the same with wave-uniform w_i (SGPR pairs)
+template <bool CONJ> KG_DEV void kg_cmul4s(cf &a0, cf &a1, cf &a2, cf &a3, cf w0, cf w1, cf w2, cf w3)
+{
+    cf r0, r1, r2, r3;
+    if constexpr (!CONJ)
+        asm(KG_MUL_("%4", "%0", "%8") KG_MUL_("%5", "%1", "%9") KG_MUL_("%6", "%2", "%10") KG_MUL_("%7", "%3", "%11")
+            KG_FMA_("%0", "%8", "%4", "neg_lo:[0,1,0]") KG_FMA_("%1", "%9", "%5", "neg_lo:[0,1,0]")
+            KG_FMA_("%2", "%10", "%6", "neg_lo:[0,1,0]") KG_FMA_("%3", "%11", "%7", "neg_lo:[0,1,0]")
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+            : "s"(w0), "s"(w1), "s"(w2), "s"(w3));
+    else
+        asm(KG_MUL_("%4", "%0", "%8") KG_MUL_("%5", "%1", "%9") KG_MUL_("%6", "%2", "%10") KG_MUL_("%7", "%3", "%11")
+            KG_FMA_("%0", "%8", "%4", "neg_hi:[0,1,0]") KG_FMA_("%1", "%9", "%5", "neg_hi:[0,1,0]")
+            KG_FMA_("%2", "%10", "%6", "neg_hi:[0,1,0]") KG_FMA_("%3", "%11", "%7", "neg_hi:[0,1,0]")
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+            : "s"(w0), "s"(w1), "s"(w2), "s"(w3));
+}
+// three products (the last group of the fifteen inter-pass twiddles)
+template <bool CONJ> KG_DEV void kg_cmul3v(cf &a0, cf &a1, cf &a2, cf w0, cf w1, cf w2)
+{
+    cf r0, r1, r2;
+    if constexpr (!CONJ)
+        asm(KG_MUL_("%3", "%0", "%6") KG_MUL_("%4", "%1", "%7") KG_MUL_("%5", "%2", "%8")
+            KG_FMA_("%0", "%6", "%3", "neg_lo:[0,1,0]") KG_FMA_("%1", "%7", "%4", "neg_lo:[0,1,0]")
+            KG_FMA_("%2", "%8", "%5", "neg_lo:[0,1,0]")
+            : "+v"(a0), "+v"(a1), "+v"(a2), "=&v"(r0), "=&v"(r1), "=&v"(r2) : "v"(w0), "v"(w1), "v"(w2));
+    else
+        asm(KG_MUL_("%3", "%0", "%6") KG_MUL_("%4", "%1", "%7") KG_MUL_("%5", "%2", "%8")
+            KG_FMA_("%0", "%6", "%3", "neg_hi:[0,1,0]") KG_FMA_("%1", "%7", "%4", "neg_hi:[0,1,0]")
+            KG_FMA_("%2", "%8", "%5", "neg_hi:[0,1,0]")
+            : "+v"(a0), "+v"(a1), "+v"(a2), "=&v"(r0), "=&v"(r1), "=&v"(r2) : "v"(w0), "v"(w1), "v"(w2));
+}
+// acc_i += y_i * w_i for four points: two fused multiply-adds per point (first the x halves, then the
+// y halves), nothing reads the register written by the previous instruction
+KG_DEV void kg_cmac4v(cf &c0, cf &c1, cf &c2, cf &c3, cf y0, cf y1, cf y2, cf y3, cf w0, cf w1, cf w2, cf w3)
+{
+#define KG_MAC1_(c, y, w) "v_pk_fma_f32 " c ", " y ", " w ", " c " op_sel_hi:[0,1,1]\n\t"
+#define KG_MAC2_(c, y, w) "v_pk_fma_f32 " c ", " y ", " w ", " c " op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+    asm(KG_MAC1_("%0", "%4", "%8") KG_MAC1_("%1", "%5", "%9") KG_MAC1_("%2", "%6", "%10") KG_MAC1_("%3", "%7", "%11")
+        KG_MAC2_("%0", "%4", "%8") KG_MAC2_("%1", "%5", "%9") KG_MAC2_("%2", "%6", "%10") KG_MAC2_("%3", "%7", "%11")
+        : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+        : "v"(y0), "v"(y1), "v"(y2), "v"(y3), "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+#undef KG_MAC1_
+#undef KG_MAC2_
+}
+
 // y_c = sum_a x_a (SIGN*j)^(a*c).  X2J: x2 still has to be multiplied by SIGN*j
 // (the W16^4 twiddle of the radix-16, folded into this butterfly's first adds).
 template <int SIGN, bool X2J = false> KG_DEV void kg_radix4(cf &x0, cf &x1, cf &x2, cf &x3)
@@ -117,20 +190,17 @@ template <int SIGN, int K> KG_DEV cf kg_w16mul(cf a)
 }
 
 // In: x[j].  Out: y[m] = sum_j x[j] * exp(SIGN*2*pi*i*j*m/16).   80 packed instructions.
+// (kg_w16mul: the single-product form of the internal twiddles, kept for the one-wave transforms.)
 template <int SIGN> KG_DEV void kg_radix16(cf (&x)[16], cf (&y)[16])
 {
     // stage 1: over a, for each b (j = 4a + b); u_b[c] lands in x[4c + b]
 #pragma unroll
     for (int b = 0; b < 4; b++) kg_radix4<SIGN>(x[b], x[4 + b], x[8 + b], x[12 + b]);
     // u_b[c] *= W16^(b*c)   (b*c = 4 is folded into stage 2)
-    x[5]  = kg_w16mul<SIGN, 1>(x[5]);
-    x[6]  = kg_w16mul<SIGN, 2>(x[6]);
-    x[7]  = kg_w16mul<SIGN, 3>(x[7]);
-    x[9]  = kg_w16mul<SIGN, 2>(x[9]);
-    x[11] = kg_w16mul<SIGN, 6>(x[11]);
-    x[13] = kg_w16mul<SIGN, 3>(x[13]);
-    x[14] = kg_w16mul<SIGN, 6>(x[14]);
-    x[15] = kg_w16mul<SIGN, 9>(x[15]);
+#define KG_W16C(K) cf{KG_W16[K][0], KG_W16[K][1]}
+    kg_cmul4s<(SIGN < 0)>(x[5], x[6], x[7], x[9], KG_W16C(1), KG_W16C(2), KG_W16C(3), KG_W16C(2));
+    kg_cmul4s<(SIGN < 0)>(x[11], x[13], x[14], x[15], KG_W16C(6), KG_W16C(3), KG_W16C(6), KG_W16C(9));
+#undef KG_W16C
     // stage 2: over b, for each c; Y[c + 4d] lands in x[4c + d]
     kg_radix4<SIGN>(x[0], x[1], x[2], x[3]);
     kg_radix4<SIGN>(x[4], x[5], x[6], x[7]);
@@ -159,8 +229,10 @@ KG_DEV void kg_tw4096_load(kg_tw4096 &tw, const float2 *__restrict__ tab4096, in
 
 template <int SIGN> KG_DEV void kg_twiddle16(cf (&x)[16], const kg_tw15 &w)
 {
-#pragma unroll
-    for (int j = 1; j < 16; j++) x[j] = kg_twmul<SIGN>(x[j], w.w[j - 1]);
+    kg_cmul4v<(SIGN < 0)>(x[1], x[2], x[3], x[4], w.w[0], w.w[1], w.w[2], w.w[3]);
+    kg_cmul4v<(SIGN < 0)>(x[5], x[6], x[7], x[8], w.w[4], w.w[5], w.w[6], w.w[7]);
+    kg_cmul4v<(SIGN < 0)>(x[9], x[10], x[11], x[12], w.w[8], w.w[9], w.w[10], w.w[11]);
+    kg_cmul3v<(SIGN < 0)>(x[13], x[14], x[15], w.w[12], w.w[13], w.w[14]);
 }
 
 // 4096-point transform of x (thread t holds X[t + 256 j], j = 0..15) by a

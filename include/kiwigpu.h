@@ -490,7 +490,9 @@ int kg_fir_process_taps_dev(kg_fir *fir, const int32_t *chans, int nch, const vo
 int kg_acq_debug_fft_stamps(kg_acq *acq, int block, unsigned long long *stamps, int n);
 /* Diagnostics: one Correlate() launch in a stamped build; stamps[0..3] = kernel
  * start/end (s_memtime cycles, s_memrealtime 100 MHz) of one workgroup, then 16
- * s_memtime readings per 4096-point work item (24 items).  n >= 400. */
+ * s_memtime readings per 4096-point work item (24 items) from stamps[16]; from stamps[512],
+ * four values per workgroup b: start, end (s_memrealtime), XCC id register, cells done.
+ * n >= 4608. */
 int kg_acq_debug_corr_stamps(kg_acq *acq, int nblocks, const int *sats, int nsats,
                              unsigned long long *stamps, int n);
 

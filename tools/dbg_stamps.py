@@ -19,7 +19,7 @@ from flydog_sdr_gps_amd import prn, sats
 for sat in range(32):
     s.set_code(sat, prn.cacode(sats.SATS[sat][1], sats.SATS[sat][2]))
 svs = np.arange(32, dtype=np.int32)
-cs = np.zeros(16 + 16 * 24, np.uint64)
+cs = np.zeros(512 + 4 * 1024, np.uint64)
 check(s.lib.kg_acq_debug_corr_stamps(s.h, 1, ptr(svs), 32, ptr(cs), cs.size), "corr stamps")
 cyc, rt = int(cs[2] - cs[0]), int(cs[3] - cs[1]) * 10
 print("correlator WG life: %d cycles, %d ns -> clock %.2f GHz" % (cyc, rt, cyc / max(rt, 1)))
