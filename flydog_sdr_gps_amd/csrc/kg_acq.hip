@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void acq_fft_combine_kernel(const float2 *__re
 // ---------------------------------------------------------------------------
 struct acq_red { float p; int i; float s; int pad; };
 
-#define ACQ_LDS_BYTES (2 * SUB * sizeof(float2) + 4 * sizeof(acq_red))
+#define ACQ_LDS_BYTES (2 * SUB * sizeof(float2) + 4 * sizeof(acq_red) + 16)     // + the claimed cell index
 
 // One (block, SV) pair, prepared by the host: 16 bytes = one s_load_dwordx4.  The
 // cells of a launch are the pairs x the Doppler bins; the kernel walks (pair, bin)
@@ -227,13 +227,15 @@ struct acq_pair_desc {
 
 struct acq_cell_desc { int data_off, code_off, dop, limit, out; };
 
-// Launch constants (kernarg): the Doppler range and how a persistent workgroup steps
-// through its XCD group's cells (cell = pair_in_group * ndop + bin).
+// Launch constants (kernarg).  The cells of XCD group x are (pair x + 8 pg, bin di) in the order
+// cell = pg * ndop + di.  A persistent workgroup takes cells `slot` and `slot + nslots` and then
+// claims one more at a time from the group's counter (an agent-scope atomic): the two workgroups
+// of a CU do not run at the same speed -- the older one wins the vector-issue arbitration (810 us
+// against 1036 us for the same 82 cells, profiles/r02_acq_wg_life.txt) -- so a static split leaves
+// every CU half empty for the last fifth of the launch.
 struct acq_walk {
     int npairs;       // pairs in this launch's table
     int ndop, dop_lo;
-    int step_pairs;   // nslots / ndop
-    int step_bins;    // nslots % ndop
 };
 
 // Work item = (cell, k2): one 4096-point sub-transform.  The operands of the
@@ -252,6 +254,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
     const float2 *__restrict__ comb,           // [P][8]
     const float2 *__restrict__ quart,          // [P][4]
     const acq_pair_desc *__restrict__ pairs,   // pair p belongs to XCD group p & 7
+    int *__restrict__ claim,                   // [8] per-group cell counters, zero at launch
     acq_walk walk,
     int halo,                                  // H of the code planes
     kg_acq_cell *__restrict__ cells,           // [nblocks][nsats][ndop]
@@ -262,6 +265,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     float2 *tileA = smem, *tileB = smem + SUB;
     acq_red *red = (acq_red *) (smem + 2 * SUB);
+    volatile int *red_claim = (volatile int *) (red + 4);
     const int t = threadIdx.x;
     // diagnostics: one workgroup, thread 0, 16 stamps per (cell, k2) item
     unsigned long long *st = (STAMPS && t == 0 && blockIdx.x == 8) ? stamps : nullptr;
@@ -288,9 +292,9 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
     // XCD-aware: workgroups b and b+8 share an XCD (round-robin dispatch), so the
     // cells of one (block, SV) pair -- one code spectrum -- all belong to one
     // group and that spectrum stays in one L2.  Speed only, never correctness.
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
     const int gpairs = (walk.npairs - xcd + 7) >> 3;           // pairs xcd, xcd + 8, ...
-    const int ndop = walk.ndop;
+    const int ndop = walk.ndop, ncell = gpairs * ndop;
 
     // Operand fetch: eight 16-byte buffer loads per spectrum.  The descriptor
     // (SGPRs) carries the plane base, soffset the row, voffset the lane column:
@@ -299,42 +303,53 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
     const int rowb_c = 2 * (256 + 2 * halo) * (int) sizeof(float2);   // code row, bytes
     const int plane_c = 8 * 2 * (256 + 2 * halo);                     // code plane, float2
     cf d[16], c[16];
-    auto fetch = [&](int data_off, int code_off, int dop, int k2) {
+    // fetch() = prepare the two buffer descriptors (SALU) + rows 0..7; fetch_rows() issues the loads of
+    // rows r0 .. r0+n-1 (one data and one code load per row) so that they can be spread
+    struct acq_rsrc { __amdgpu_buffer_rsrc_t drs, crs; int dvo, cvo; };
+    auto fetch_prepare = [&](int data_off, int code_off, int dop, int k2) {
         const int s = k2 - dop;
         const int q0 = s >> LOGP;                      // floor((k2 - dop) / P)
-        const auto drs = __builtin_amdgcn_make_buffer_rsrc(
+        acq_rsrc r;
+        r.drs = __builtin_amdgcn_make_buffer_rsrc(
             (void *) (data + data_off + k2 * SUB), 0, SUB * (int) sizeof(float2), 0x00020000);
-        const auto crs = __builtin_amdgcn_make_buffer_rsrc(
+        r.crs = __builtin_amdgcn_make_buffer_rsrc(
             (void *) (code + code_off + (s & (P - 1)) * plane_c), 0, plane_c * (int) sizeof(float2), 0x00020000);
-        const int dvo = t * 16, cvo = (t + q0 + halo) * 16;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const u4 dv = __builtin_amdgcn_raw_buffer_load_b128(drs, dvo, i * 4096, 0);
-            const u4 cv = __builtin_amdgcn_raw_buffer_load_b128(crs, cvo, i * rowb_c, 0);
-            d[2 * i] = cf{__uint_as_float(dv[0]), __uint_as_float(dv[1])};
-            d[2 * i + 1] = cf{__uint_as_float(dv[2]), __uint_as_float(dv[3])};
-            c[2 * i] = cf{__uint_as_float(cv[0]), __uint_as_float(cv[1])};
-            c[2 * i + 1] = cf{__uint_as_float(cv[2]), __uint_as_float(cv[3])};
-        }
+        r.dvo = t * 16; r.cvo = (t + q0 + halo) * 16;
+        return r;
     };
-    // (pair in group, bin) -> descriptor; one s_load_dwordx4
-    auto describe = [&](int pg, int di) {
+    auto fetch_row = [&](const acq_rsrc &r, int i) {
+        const u4 dv = __builtin_amdgcn_raw_buffer_load_b128(r.drs, r.dvo, i * 4096, 0);
+        const u4 cv = __builtin_amdgcn_raw_buffer_load_b128(r.crs, r.cvo, i * rowb_c, 0);
+        d[2 * i] = cf{__uint_as_float(dv[0]), __uint_as_float(dv[1])};
+        d[2 * i + 1] = cf{__uint_as_float(dv[2]), __uint_as_float(dv[3])};
+        c[2 * i] = cf{__uint_as_float(cv[0]), __uint_as_float(cv[1])};
+        c[2 * i + 1] = cf{__uint_as_float(cv[2]), __uint_as_float(cv[3])};
+    };
+    auto fetch = [&](int data_off, int code_off, int dop, int k2) {
+        const acq_rsrc r = fetch_prepare(data_off, code_off, dop, k2);
+#pragma unroll
+        for (int i = 0; i < 8; i++) fetch_row(r, i);
+    };
+    // cell index -> descriptor: one (uniform) division, one s_load_dwordx4
+    auto describe = [&](int idx) {
+        const int pg = idx / ndop, di = idx - pg * ndop;
         const acq_pair_desc pd = pairs[(pg << 3) + xcd];
         return acq_cell_desc{pd.data_off, pd.code_off, walk.dop_lo + di, pd.limit, pd.out + di};
     };
 
-    int pg = slot / ndop, di = slot - pg * ndop;       // once per workgroup
-    if (pg >= gpairs) return;
-    acq_cell_desc cur = describe(pg, di);
+    int cur_idx = slot, nxt_idx = slot + nslots;
+    if (cur_idx >= ncell) return;
+    acq_cell_desc cur = describe(cur_idx);
     fetch(cur.data_off, cur.code_off, cur.dop, 0);
 
     int st_item = 0;
     for (;;) {
-        // one cell ahead
-        int npg = pg + walk.step_pairs, ndi = di + walk.step_bins;
-        if (ndi >= ndop) { ndi -= ndop; npg++; }
-        const bool more = npg < gpairs;
-        const acq_cell_desc nxt = describe(more ? npg : pg, more ? ndi : di);
+        // one cell ahead; the cell after that is claimed now and its index crosses the workgroup
+        // through LDS at this cell's last barrier
+        const bool more = nxt_idx < ncell;
+        const acq_cell_desc nxt = describe(more ? nxt_idx : cur_idx);
+        int claimed = 0;
+        if (t == 0) claimed = 2 * nslots + __hip_atomic_fetch_add(&claim[xcd], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         cf acc[NQ][16];
         // rolled on purpose: unrolled (or with k2 a template constant) the
         // register allocator spills 80+ VGPRs
@@ -350,21 +365,35 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
                 base = ka == 0 ? Bv : (kb == 0 ? A : kg_cmul(A, Bv));
             }
             cf x[16], y[16];
+            // The operands of the next item -- (cur, k2+1) or (nxt, 0); the very last item re-reads its own
+            // cell, harmless, so that there is ONE load site that is never skipped -- are fetched row by
+            // row between the arithmetic groups of this item: a row's registers are free as soon as its
+            // products are formed, and sixteen 1 KiB loads issued back to back queue behind each other in
+            // the texture addresser for several hundred cycles.
+            const bool same = k2 < P - 1;
+            const acq_rsrc nr = fetch_prepare(same ? cur.data_off : nxt.data_off, same ? cur.code_off : nxt.code_off,
+                                              same ? cur.dop : nxt.dop, (k2 + 1) & (P - 1));
             // conj(data) * code, simd_multiply_conjugate_ccc (support/simd.cpp:39-67)
 #pragma unroll
             for (int j = 0; j < 16; j += 4) {
                 x[j] = c[j]; x[j + 1] = c[j + 1]; x[j + 2] = c[j + 2]; x[j + 3] = c[j + 3];
                 kg_cmul4v<true>(x[j], x[j + 1], x[j + 2], x[j + 3], d[j], d[j + 1], d[j + 2], d[j + 3]);
-            }
-            KG_STAMP(STAMPS, sti, 9);
-            {   // one load site, never skipped (the very last item re-reads its own cell: harmless), so
-                // that the compiler's wait counts stay exact across the loop
-                const bool same = k2 < P - 1;
-                fetch(same ? cur.data_off : nxt.data_off, same ? cur.code_off : nxt.code_off,
-                      same ? cur.dop : nxt.dop, (k2 + 1) & (P - 1));
+                if (STAMPS && j == 12) KG_STAMP(STAMPS, sti, 9);
+                if (j >= 4) { kg_pin(); fetch_row(nr, j / 4 - 1); kg_pin(); }     // rows 0..2 (registers of the batch before)
             }
             KG_STAMP(STAMPS, sti, 10);
-            kg_subfft4096_a<+1, STAMPS>(x, y, tileA, tileB, tw, t, sti);
+            if constexpr (STAMPS) {
+                kg_pin(); fetch_row(nr, 3); fetch_row(nr, 4); fetch_row(nr, 5); fetch_row(nr, 6); fetch_row(nr, 7); kg_pin();
+                kg_subfft4096_a<+1, STAMPS>(x, y, tileA, tileB, tw, t, sti);
+            } else {
+                // rows 3..7 between the first-stage groups of pass 0
+                kg_subfft4096_a_spread<+1>(x, y, tileA, tileB, tw, t, [&](int s) {
+                    kg_pin();
+                    fetch_row(nr, 3 + s);
+                    if (s == 3) fetch_row(nr, 7);
+                    kg_pin();
+                });
+            }
             // wave-uniform constants (s_load), hidden behind pass 2
             cf g[3], G[3], Q[3];
             (void) Q;
@@ -459,7 +488,11 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
         ACQ_RED_STEP(0) ACQ_RED_STEP(1) ACQ_RED_STEP(2) ACQ_RED_STEP(3) ACQ_RED_STEP(4) ACQ_RED_STEP(5)
         // red[] was last read before this cell's barriers
         if ((t & 63) == 0) { red[t >> 6].p = bp; red[t >> 6].i = bi; red[t >> 6].s = sum; }
+        if (t == 0) *red_claim = claimed;
         __syncthreads();
+        // (rewritten only after eight more barriers; readfirstlane: the index must stay wave-uniform, or
+        // every buffer load below turns into a waterfall loop over its descriptor)
+        const int nn_idx = __builtin_amdgcn_readfirstlane(*red_claim);
         if (t < 64) {                                  // lanes 0..3 of wave 0 merge the four waves
             const acq_red r = red[t & 3];
             bp = r.p; bi = r.i; sum = r.s;
@@ -475,7 +508,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
 #undef ACQ_RED_STEP
         if (STAMPS) wg_cells++;
         if (!more) break;
-        cur = nxt; pg = npg; di = ndi;
+        cur = nxt; cur_idx = nxt_idx; nxt_idx = nn_idx;
     }
     if (STAMPS && st) { st[2] = __builtin_amdgcn_s_memtime(); st[3] = __builtin_amdgcn_s_memrealtime(); }
     if (STAMPS && wgt) { wgt[1] = __builtin_amdgcn_s_memrealtime(); wgt[3] = (unsigned long long) wg_cells; }
@@ -486,9 +519,10 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
 // One wave per pair; lane l scans bins l, l+64, ...
 __global__ __launch_bounds__(64) void acq_select_kernel(const kg_acq_cell *__restrict__ cells,
                                                        int npairs, int dop_lo, int ndop,
-                                                       kg_acq_result *__restrict__ out)
+                                                       kg_acq_result *__restrict__ out, int *__restrict__ claim)
 {
     const int p = blockIdx.x, lane = threadIdx.x;
+    if (p == 0 && lane < 16) claim[lane] = 0;          // the correlators' cell counters, for the next launch
     if (p >= npairs) return;
     float bs = 0.f;
     int bd = 0x7fffffff, bidx = 0;
@@ -550,6 +584,7 @@ struct kg_acq {
     uint8_t *d_chips;  // [E1B_CODELEN max]
     kg_acq_cell *d_cells;
     kg_acq_result *d_results;
+    int *d_claim;      // [16] cell counters of the C/A ([0..8)) and E1B ([8..16)) launches; zero between launches
     std::vector<int> limits, code_set;
     // The (block, SV) pair tables of the last launch live in a slot of the context's staging
     // ring; they are reused while the SV list is unchanged and the slot has not come round.
@@ -690,6 +725,8 @@ static int acq_init(kg_acq *a)
     KG_HIP(hipMalloc((void **) &a->d_chips, 8192));
     KG_HIP(hipMalloc((void **) &a->d_cells, sizeof(kg_acq_cell) * (size_t) max_blocks * max_sats * a->ndop));
     KG_HIP(hipMalloc((void **) &a->d_results, sizeof(kg_acq_result) * (size_t) max_blocks * max_sats));
+    KG_HIP(hipMalloc((void **) &a->d_claim, sizeof(int) * 16));
+    KG_HIP(hipMemset(a->d_claim, 0, sizeof(int) * 16));
     {
         // Sample() and Correlate() run in order on the context's stream.  A second stream
         // (KIWIGPU_ACQ_FRONT_STREAM=1) lets block b+1's front end overlap block b's
@@ -802,7 +839,7 @@ void kg_acq_destroy(kg_acq *a)
     if (a->ev_batch) (void) hipEventDestroy(a->ev_batch);
     if (a->ev_in_free) (void) hipEventDestroy(a->ev_in_free);
     if (a->cstream) { (void) hipStreamSynchronize(a->cstream); (void) hipStreamDestroy(a->cstream); }
-    (void) hipFree(a->d_cells); (void) hipFree(a->d_results);
+    (void) hipFree(a->d_cells); (void) hipFree(a->d_results); (void) hipFree(a->d_claim);
     delete a;
 }
 
@@ -1054,13 +1091,13 @@ template <int P, int NQ, bool STAMPS>
 static void launch_correlate(kg_acq *a, hipStream_t st, int first, const acq_pair_desc *d_pairs, int npairs,
                              unsigned long long *d_stamps)
 {
-    const int grid = NQ == 1 ? a->grid1 : a->grid4, nslots = grid >> 3;
-    const acq_walk w = {npairs, a->ndop, a->dop_lo, nslots / a->ndop, nslots % a->ndop};
+    const int grid = NQ == 1 ? a->grid1 : a->grid4;
+    const acq_walk w = {npairs, a->ndop, a->dop_lo};
     hipLaunchKernelGGL((acq_correlate_kernel<P, NQ, true, STAMPS>), dim3(grid), dim3(256), ACQ_LDS_BYTES, st,
                        (const float2 *) (a->d_data + (size_t) first * a->fft_len), (const float2 *) a->d_code,
                        (const float2 *) a->ctx->d_tab4096, (const float2 *) a->d_tabN,
-                       (const float2 *) a->d_comb, (const float2 *) a->d_quart, d_pairs, w, a->halo,
-                       a->d_cells, d_stamps);
+                       (const float2 *) a->d_comb, (const float2 *) a->d_quart, d_pairs,
+                       a->d_claim + (NQ == 1 ? 0 : 8), w, a->halo, a->d_cells, d_stamps);
 }
 
 extern "C" {
@@ -1130,7 +1167,7 @@ int kg_acq_correlate_blocks_async(kg_acq *a, int first, int nblocks, const int *
     }
     const int npairs = nblocks * nsats;
     hipLaunchKernelGGL(acq_select_kernel, dim3(npairs), dim3(64), 0, st,
-                       (const kg_acq_cell *) a->d_cells, npairs, a->dop_lo, a->ndop, a->d_results);
+                       (const kg_acq_cell *) a->d_cells, npairs, a->dop_lo, a->ndop, a->d_results, a->d_claim);
     KG_HIP(hipGetLastError());
     if (a->own_fstream) {
         KG_HIP(hipEventRecord(a->ev_done[first], st));
@@ -1183,6 +1220,7 @@ int kg_acq_debug_corr_stamps(kg_acq *a, int nblocks, const int *sats, int nsats,
     KG_REQUIRE(a->grid1 <= 1024, KG_ERR_STATE, "kg_acq_debug_corr_stamps: grid %d", a->grid1);
     KG_HIP(hipMalloc((void **) &d, bytes));
     KG_HIP(hipMemset(d, 0, bytes));
+    KG_HIP(hipMemsetAsync(a->d_claim, 0, sizeof(int) * 16, st));
     if (a->P == 4) {
         KG_HIP(hipFuncSetAttribute((const void *) acq_correlate_kernel<4, 1, true, true>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, ACQ_LDS_BYTES));
@@ -1193,6 +1231,7 @@ int kg_acq_debug_corr_stamps(kg_acq *a, int nblocks, const int *sats, int nsats,
         launch_correlate<16, 1, true>(a, st, 0, a->d_pairs1, a->np1, d);
     }
     KG_HIP(hipGetLastError());
+    KG_HIP(hipMemsetAsync(a->d_claim, 0, sizeof(int) * 16, st));
     KG_HIP(hipStreamSynchronize(st));
     KG_HIP(hipMemcpy(stamps, d, bytes, hipMemcpyDeviceToHost));
     KG_HIP(hipFree(d));

@@ -173,15 +173,28 @@ KG_DEV void kg_cmac4v(cf &c0, cf &c1, cf &c2, cf &c3, cf y0, cf y1, cf y2, cf y3
 
 // y_c = sum_a x_a (SIGN*j)^(a*c).  X2J: x2 still has to be multiplied by SIGN*j
 // (the W16^4 twiddle of the radix-16, folded into this butterfly's first adds).
+// (p, q) = (a + (SIGN*j) b, a - (SIGN*j) b) in one block: two inline-asm definitions that the next
+// instruction reads would each cost a wait state
+template <int SIGN> KG_DEV void kg_addsub_sj(cf &p, cf &q, cf a, cf b)
+{
+    if constexpr (SIGN > 0)
+        asm("v_pk_add_f32 %0, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+            "v_pk_add_f32 %1, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]"
+            : "=&v"(p), "=v"(q) : "v"(a), "v"(b));
+    else
+        asm("v_pk_add_f32 %0, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %1, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]"
+            : "=&v"(p), "=v"(q) : "v"(a), "v"(b));
+}
 template <int SIGN, bool X2J = false> KG_DEV void kg_radix4(cf &x0, cf &x1, cf &x2, cf &x3)
 {
-    const cf s02 = X2J ? kg_add_sj<SIGN>(x0, x2) : x0 + x2;
-    const cf d02 = X2J ? kg_sub_sj<SIGN>(x0, x2) : x0 - x2;
+    cf s02, d02;
+    if constexpr (X2J) kg_addsub_sj<SIGN>(s02, d02, x0, x2);
+    else { s02 = x0 + x2; d02 = x0 - x2; }
     const cf s13 = x1 + x3, d13 = x1 - x3;
     x0 = s02 + s13;
-    x1 = kg_add_sj<SIGN>(d02, d13);
     x2 = s02 - s13;
-    x3 = kg_sub_sj<SIGN>(d02, d13);
+    kg_addsub_sj<SIGN>(x1, x3, d02, d13);
 }
 
 template <int SIGN, int K> KG_DEV cf kg_w16mul(cf a)
@@ -208,6 +221,34 @@ template <int SIGN> KG_DEV void kg_radix16(cf (&x)[16], cf (&y)[16])
     kg_radix4<SIGN>(x[12], x[13], x[14], x[15]);
 #pragma unroll
     for (int m = 0; m < 16; m++) y[m] = x[4 * (m & 3) + (m >> 2)];
+}
+
+// The same butterfly with a hook after each of its eight radix-4 groups (s = 0..3: the first stage,
+// s = 4..7: the second, after which y[s-4], y[s], y[s+4], y[s+8] are final).  Callers use the hooks
+// to issue memory instructions between the groups (operand loads of the next item, the LDS stores of
+// finished outputs), fenced with kg_pin() so that they stay spread through the arithmetic instead of
+// queueing as one burst behind it.
+#define kg_pin() __builtin_amdgcn_sched_barrier(0)
+template <int SIGN, class H> KG_DEV void kg_radix16_h(cf (&x)[16], cf (&y)[16], H hook)
+{
+#pragma unroll
+    for (int b = 0; b < 4; b++) { kg_radix4<SIGN>(x[b], x[4 + b], x[8 + b], x[12 + b]); hook(b); }
+#define KG_W16C(K) cf{KG_W16[K][0], KG_W16[K][1]}
+    kg_radix4<SIGN>(x[0], x[1], x[2], x[3]);
+    y[0] = x[0]; y[4] = x[1]; y[8] = x[2]; y[12] = x[3];
+    hook(4);
+    kg_cmul4s<(SIGN < 0)>(x[5], x[6], x[7], x[9], KG_W16C(1), KG_W16C(2), KG_W16C(3), KG_W16C(2));
+    kg_radix4<SIGN>(x[4], x[5], x[6], x[7]);
+    y[1] = x[4]; y[5] = x[5]; y[9] = x[6]; y[13] = x[7];
+    hook(5);
+    kg_cmul4s<(SIGN < 0)>(x[11], x[13], x[14], x[15], KG_W16C(6), KG_W16C(3), KG_W16C(6), KG_W16C(9));
+    kg_radix4<SIGN, true>(x[8], x[9], x[10], x[11]);
+    y[2] = x[8]; y[6] = x[9]; y[10] = x[10]; y[14] = x[11];
+    hook(6);
+    kg_radix4<SIGN>(x[12], x[13], x[14], x[15]);
+    y[3] = x[12]; y[7] = x[13]; y[11] = x[14]; y[15] = x[15];
+    hook(7);
+#undef KG_W16C
 }
 
 // Inter-pass twiddles of the 4096-point transform for thread t of 256: pass 1
@@ -294,6 +335,38 @@ KG_DEV void kg_subfft4096_b(cf (&x)[16], cf (&y)[16], const float2 *tileB,
     kg_twiddle16<SIGN>(x, tw.p2);
     kg_radix16<SIGN>(x, y);
     KG_STAMP(STAMPS, st, 7);
+}
+
+// kg_subfft4096_a with the LDS stores of each pass issued group by group as the outputs become
+// final, and a caller hook h0(s), s = 0..3, between the first-stage groups of pass 0.
+template <int SIGN, class H0>
+KG_DEV void kg_subfft4096_a_spread(cf (&x)[16], cf (&y)[16], float2 *tileA, float2 *tileB,
+                                   const kg_tw4096 &tw, int t, H0 h0)
+{
+    const int tl = t & 15, th = t >> 4;
+    const int rd = t ^ (th & 15);
+    kg_radix16_h<SIGN>(x, y, [&](int s) {
+        if (s < 4) h0(s);
+        else {
+            kg_pin();
+#pragma unroll
+            for (int m = s - 4; m < 16; m += 4) kg_st(&tileA[16 * t + (m ^ tl)], y[m]);
+            kg_pin();
+        }
+    });
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = kg_ld(&tileA[rd + 256 * j]);
+    kg_twiddle16<SIGN>(x, tw.p1);
+    kg_radix16_h<SIGN>(x, y, [&](int s) {
+        if (s >= 4) {
+            kg_pin();
+#pragma unroll
+            for (int m = s - 4; m < 16; m += 4) kg_st(&tileB[th * 256 + 16 * m + (tl ^ m)], y[m]);
+            kg_pin();
+        }
+    });
+    __syncthreads();
 }
 
 template <int SIGN, bool STAMPS = false>
