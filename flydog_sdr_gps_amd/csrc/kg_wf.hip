@@ -72,31 +72,60 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
     // combine twiddle W_8192^{k}, k = t + 256 m: W_8192^{t} (per thread) * W_32^{m} (immediate)
     const cf wbase = kg_ld(&tab8192[t]);
 
-    short4 raw[16];
-    auto fetch = [&](int f) {
-        const short4 *src = (const short4 *) (iq + (size_t) f * WF_NFFT);
+    // A frame is read in two passes of sixteen 4-byte loads per thread: the even samples (n = 2*n1) for
+    // the first 4096-point transform, then the odd ones -- the same 128-byte lines, by then in L2 -- for
+    // the second, into the same sixteen registers; and once the second transform's inputs are formed
+    // the next frame's even samples land there while the rest of this frame is computed.  The frame
+    // fetch is the kernel's one HBM access: at the top of the loop its whole latency was exposed.
+    int raw[16];
+    auto fetch = [&](int f, int g) {
+        const int *src = (const int *) (iq + (size_t) f * WF_NFFT) + g;
 #pragma unroll
-        for (int j = 0; j < 16; j++) raw[j] = src[t + 256 * j];
+        for (int j = 0; j < 16; j++) raw[j] = src[2 * (t + 256 * j)];
+    };
+    // window values of this thread's sixteen samples of parity g (4-byte loads, L1 / L2 hits)
+    float wv[16];
+    auto fetch_window = [&](const float *win, int g) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) wv[j] = win[2 * (t + 256 * j) + g];
+    };
+    auto windowed = [&](cf (&x)[16]) {
+        // sample_wf(): fi = (float)(s2_t)i * window[sn]  (:1054-1061)
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            x[j] = cf{(float) (short) (raw[j] & 0xffff) * wv[j], (float) (short) (raw[j] >> 16) * wv[j]};
     };
 
+    // Everything a frame needs first -- its channel number, that channel's window, its even samples
+    // and their window values -- is requested while the previous frame is still being computed, so a
+    // frame starts with its first transform instead of a chain of three dependent memory round trips
+    // (chan_of[f] -> the channel record -> window and samples).
+    if ((int) blockIdx.x >= nframes) return;
+    int cid = chan_of[blockIdx.x];
+    fetch(blockIdx.x, 0);
+    fetch_window(windows + (size_t) chans[cid].window_func * WF_NFFT, 0);
     for (int f = blockIdx.x; f < nframes; f += gridDim.x) {
-        const wf_chan_dev *ch = chans + chan_of[f];
+        const wf_chan_dev *ch = chans + cid;
         const int interp = ch->interp, dc = ch->dc, comp_on = ch->comp_on;
-        const float2 *win = (const float2 *) (windows + (size_t) ch->window_func * WF_NFFT);
+        const float *win = windows + (size_t) ch->window_func * WF_NFFT;
+        const int fn = f + gridDim.x;
+        const bool more = fn < nframes;
+        const int cid_next = chan_of[more ? fn : f];
+        const int wfn_next = chans[cid_next].window_func;
 
-        // sample_wf(): fi = (float)(s2_t)i * window[sn]  (:1054-1061), samples 2*n1, 2*n1+1
-        fetch(f);
         cf x[16], y0[16], y1[16];
-        float wodd[16];
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const float2 w = win[t + 256 * j];
-            x[j] = cf{(float) raw[j].x * w.x, (float) raw[j].y * w.x};
-            wodd[j] = w.y;
-        }
+        windowed(x);
+        fetch(f, 1);
+        fetch_window(win, 1);
         kg_subfft4096<-1>(x, y0, tileA, tileB, tw, t);
+        windowed(x);
+        if (more) fetch(fn, 0);
+        // CIC compensation factors of this thread's sixteen bins, fetched here in one batch and used
+        // after the transform (one load + wait per bin inside the power loop cost sixteen exposed L2
+        // round trips per frame); 1.0f where the frame is not compensated: x * 1.0f is exact
+        float cicv[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) x[j] = cf{(float) raw[j].z * wodd[j], (float) raw[j].w * wodd[j]};
+        for (int m = 0; m < 16; m++) cicv[m] = cic_comp[comp_on ? t + 256 * m : 0];
         kg_subfft4096<-1>(x, y1, tileA, tileB, tw, t);
         // (tile A, about to become pwr[], was last read before the second transform's
         // second barrier)
@@ -110,47 +139,80 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
         const float pscale[4] = {ps.x, ps.y, ps.z, ps.w}, pscale2[4] = {ps2.x, ps2.y, ps2.z, ps2.w};
         const int pwc = ch->pwc;
         const float fft_offset = ch->fft_offset;
+        // X[k] = F0[k] + F1[k] * conj(W_8192^t) * conj(W_32^m), k = t + 256 m: the two factors applied to
+        // all sixteen bins in blocks of four products (kg_fft.h), then the sum
+#pragma unroll
+        for (int m = 0; m < 16; m += 4) kg_cmul4v<true>(y1[m], y1[m + 1], y1[m + 2], y1[m + 3], wbase, wbase, wbase, wbase);
+#define WF_W32(m) cf{KG_W64[2 * (m)][0], KG_W64[2 * (m)][1]}
+        kg_cmul4s<true>(y1[0], y1[1], y1[2], y1[3], WF_W32(0), WF_W32(1), WF_W32(2), WF_W32(3));
+        kg_cmul4s<true>(y1[4], y1[5], y1[6], y1[7], WF_W32(4), WF_W32(5), WF_W32(6), WF_W32(7));
+        kg_cmul4s<true>(y1[8], y1[9], y1[10], y1[11], WF_W32(8), WF_W32(9), WF_W32(10), WF_W32(11));
+        kg_cmul4s<true>(y1[12], y1[13], y1[14], y1[15], WF_W32(12), WF_W32(13), WF_W32(14), WF_W32(15));
+#undef WF_W32
 #pragma unroll
         for (int m = 0; m < 16; m++) {
             const int k = t + 256 * m;
-            cf z = y1[m];                     // * conj(W_32^m) * conj(W_8192^t)
-            if (m == 8) z = cf{z.y, -z.x};
-            else if (m != 0) z = kg_cmulc_s(z, cf{KG_W64[2 * m][0], KG_W64[2 * m][1]});
-            const cf X = y0[m] + kg_cmulc(z, wbase);
-            float re = X.x, im = X.y;
-            if (comp_on) { const float c = cic_comp[k]; re = re * c; im = im * c; }   // :1342
-            float p = re * re + im * im;                                                // :1345
+            cf X = y0[m] + y1[m];
+            X = X * cf{cicv[m], cicv[m]};     // re *= CIC_comp[k], im *= CIC_comp[k] (:1342); 1.0f when off: exact
+            const cf sq = X * X;
+            float p = sq.x + sq.y;                                                      // re*re + im*im, :1345
             if (k < dc) p = 0.f;                                                        // :1304
             pwr[k] = p;
             if (TAPS && k < ch->fft_used) tap_pwr[(size_t) f * SUB + k] = p;
         }
         __syncthreads();
+        // the next frame's first window values arrive during the pixel stage
+        fetch_window(windows + (size_t) wfn_next * WF_NFFT, 0);
+        cid = cid_next;
 
-        // pixels 4t .. 4t+3
+        // pixels 4t .. 4t+3.  The interpolation mode is the frame's (wave-uniform); the run lengths
+        // differ per pixel, so the walk goes to the longest run of the wave with the shorter ones
+        // predicated: no divergent loops, the four pixels of a thread advance together, and every
+        // pixel still sees its bins in ascending order (same result as the serial :1458-1478 loop).
+        float pp[4] = {0.f, 0.f, 0.f, 0.f};   // memset(pwr_out, 0), :1385
+        int avgs[4] = {0, 0, 0, 0};
+        if (interp == WF_DROP) {
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (4 * t + u < pwc) pp[u] = pwr[pfirst[u]];                            // :1418
+        } else {
+            int cmax = max(max(pcount[0], pcount[1]), max(pcount[2], pcount[3]));
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) cmax = max(cmax, __shfl_xor(cmax, off));
+            cmax = __builtin_amdgcn_readfirstlane(cmax);
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (pcount[u] > 0) { pp[u] = pwr[pfirst[u]]; avgs[u] = 1; }            // :1468-1475
+            int plast[4];                     // last bin of each run (the run's first bin when it is empty)
+#pragma unroll
+            for (int u = 0; u < 4; u++) plast[u] = pfirst[u] + max(pcount[u] - 1, 0);
+            auto walk = [&](auto upd) {
+                for (int i = 1; i < cmax; i++) {
+                    float q[4];               // four unconditional LDS reads (index clamped into the run), one wait
+#pragma unroll
+                    for (int u = 0; u < 4; u++) q[u] = pwr[min(pfirst[u] + i, plast[u])];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) pp[u] = (i < pcount[u]) ? upd(pp[u], q[u]) : pp[u];
+                }
+            };
+            switch (interp) {                                                           // :1461-1466
+            case WF_CMA:  walk([](float p, float q) { return p + q; });
+#pragma unroll
+                          for (int u = 0; u < 4; u++) avgs[u] = pcount[u];
+                          break;
+            case WF_MAX:  walk([](float p, float q) { return q > p ? q : p; }); break;
+            case WF_MIN:  walk([](float p, float q) { return q < p ? q : p; }); break;
+            default:      walk([](float, float q) { return q; }); break;               // WF_LAST
+            }
+        }
         unsigned bytes = 0;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int px = 4 * t + u;
-            const int first = pfirst[u], cnt = pcount[u];
-            float p = 0.f;                    // memset(pwr_out, 0), :1385
-            int avgs = 0;
-            if (interp == WF_DROP) {
-                if (px < pwc) p = pwr[first];                                           // :1418
-            } else if (cnt > 0) {
-                p = pwr[first]; avgs = 1;                                               // :1468-1475
-                for (int i = 1; i < cnt; i++) {
-                    const float q = pwr[first + i];
-                    switch (interp) {                                                   // :1461-1466
-                    case WF_CMA:  p += q; avgs++; break;
-                    case WF_MAX:  if (q > p) p = q; break;
-                    case WF_MIN:  if (q < p) p = q; break;
-                    default:      p = q; break;                                         // WF_LAST
-                    }
-                }
-            }
+            const float p = pp[u];
             float scale = pscale[u];
             if (interp == WF_CMA)                                                        // :1499-1500
-                scale = (avgs == 1) ? scale : ((avgs == 2) ? pscale2[u] : scale / (float) avgs);
+                scale = (avgs[u] == 1) ? scale : ((avgs[u] == 2) ? pscale2[u] : scale / (float) avgs[u]);
             // dB = 10.0 * log10f(p*scale + 1e-30F) + fft_offset: the product and sum in
             // float, the 10.0* and + in double, one rounding to float (:1507)
             const float arg = p * scale + 1e-30f;
