@@ -48,7 +48,7 @@ struct wf_chan_dev {
     float scale[WF_WIDTH], scale_div2[WF_WIDTH];
 };
 
-#define WF_LDS_BYTES (2 * SUB * sizeof(float2))
+#define WF_LDS_BYTES (2 * SUB * sizeof(float2) + 16)       // + the claimed frame index
 
 template <bool TAPS>
 __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
@@ -60,11 +60,13 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
     const float2 *__restrict__ tab4096, const float2 *__restrict__ tab8192,
     int nframes,
     unsigned char *__restrict__ out,          // [nframes][1024]
+    int *__restrict__ claim,                  // [2]: frames handed out beyond the first two per workgroup; workgroups done
     float *__restrict__ tap_pwr, float *__restrict__ tap_pwr_out, float *__restrict__ tap_db)
 {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     float2 *tileA = smem, *tileB = smem + SUB;
     float *pwr = (float *) smem;              // [4096], reuses tile A after the transforms
+    volatile int *lds_claim = (volatile int *) (smem + 2 * SUB);
     const int t = threadIdx.x;
 
     kg_tw4096 tw;
@@ -100,18 +102,24 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
     // and their window values -- is requested while the previous frame is still being computed, so a
     // frame starts with its first transform instead of a chain of three dependent memory round trips
     // (chan_of[f] -> the channel record -> window and samples).
-    if ((int) blockIdx.x >= nframes) return;
-    int cid = chan_of[blockIdx.x];
-    fetch(blockIdx.x, 0);
+    // Frames are handed out dynamically after the first two of a workgroup (frame b and b + grid): the
+    // two workgroups of a CU do not run at the same speed (the older one wins the vector-issue
+    // arbitration), so equal static shares leave CUs half empty at the end.  The frame after next is
+    // claimed at the top of a frame and crosses the workgroup through LDS at the power-stage barrier.
+    // The last workgroup to leave resets the two counters for the next launch.
+    int f = blockIdx.x, fn = blockIdx.x + gridDim.x;
+    int cid = chan_of[f];                     // grid <= nframes: every workgroup has a first frame
+    fetch(f, 0);
     fetch_window(windows + (size_t) chans[cid].window_func * WF_NFFT, 0);
-    for (int f = blockIdx.x; f < nframes; f += gridDim.x) {
+    for (;;) {
         const wf_chan_dev *ch = chans + cid;
         const int interp = ch->interp, dc = ch->dc, comp_on = ch->comp_on;
         const float *win = windows + (size_t) ch->window_func * WF_NFFT;
-        const int fn = f + gridDim.x;
         const bool more = fn < nframes;
         const int cid_next = chan_of[more ? fn : f];
         const int wfn_next = chans[cid_next].window_func;
+        int claimed = 0;
+        if (t == 0) claimed = 2 * gridDim.x + __hip_atomic_fetch_add(&claim[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
         cf x[16], y0[16], y1[16];
         windowed(x);
@@ -160,7 +168,9 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
             pwr[k] = p;
             if (TAPS && k < ch->fft_used) tap_pwr[(size_t) f * SUB + k] = p;
         }
+        if (t == 0) *lds_claim = claimed;
         __syncthreads();
+        const int fnn = __builtin_amdgcn_readfirstlane(*lds_claim);    // wave-uniform; rewritten after >= 6 barriers
         // the next frame's first window values arrive during the pixel stage
         fetch_window(windows + (size_t) wfn_next * WF_NFFT, 0);
         cid = cid_next;
@@ -232,6 +242,15 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
         }
         ((unsigned *) (out + (size_t) f * WF_WIDTH))[t] = bytes;
         __syncthreads();                      // pwr[] (tile A) is rewritten by the next frame
+        if (!more) break;
+        f = fn; fn = fnn;
+    }
+    if (t == 0) {
+        const int done = __hip_atomic_fetch_add(&claim[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == (int) gridDim.x - 1) {    // every other workgroup has made its last claim
+            __hip_atomic_store(&claim[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&claim[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -243,6 +262,7 @@ struct kg_wf {
     float *d_windows, *d_cic;
     short2 *d_iq;    unsigned char *d_out;  int stage_cap;      // staging for host-buffer calls
     float *d_tap_pwr, *d_tap_pwr_out, *d_tap_db;
+    int *d_claim;                             // wf_frame_kernel's two counters, zero between launches
     std::vector<char> chan_set;
     bool tables_set;
     int grid;
@@ -266,6 +286,8 @@ int kg_wf_create(kg_ctx *ctx, int nchan, kg_wf **out)
     KG_HIP(hipMalloc((void **) &w->d_chans, sizeof(wf_chan_dev) * nchan));
     KG_HIP(hipMalloc((void **) &w->d_windows, sizeof(float) * 4 * WF_NFFT));
     KG_HIP(hipMalloc((void **) &w->d_cic, sizeof(float) * WF_NFFT));
+    KG_HIP(hipMalloc((void **) &w->d_claim, sizeof(int) * 2));
+    KG_HIP(hipMemset(w->d_claim, 0, sizeof(int) * 2));
     KG_HIP(hipFuncSetAttribute((const void *) wf_frame_kernel<false>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS_BYTES));
     KG_HIP(hipFuncSetAttribute((const void *) wf_frame_kernel<true>,
@@ -283,7 +305,7 @@ void kg_wf_destroy(kg_wf *w)
     if (!w) return;
     (void) hipSetDevice(w->ctx->device);
     (void) hipStreamSynchronize(w->ctx->stream);
-    (void) hipFree(w->d_chans); (void) hipFree(w->d_windows); (void) hipFree(w->d_cic);
+    (void) hipFree(w->d_chans); (void) hipFree(w->d_windows); (void) hipFree(w->d_cic); (void) hipFree(w->d_claim);
     (void) hipFree(w->d_iq); (void) hipFree(w->d_out);
     (void) hipFree(w->d_tap_pwr); (void) hipFree(w->d_tap_pwr_out); (void) hipFree(w->d_tap_db);
     delete w;
@@ -379,13 +401,13 @@ static int wf_launch(kg_wf *w, int nframes, const int32_t *chan_of, const void *
                            (const short2 *) d_iq, (const int *) d_chan_of, (const wf_chan_dev *) w->d_chans,
                            (const float *) w->d_windows, (const float *) w->d_cic,
                            (const float2 *) w->ctx->d_tab4096, (const float2 *) w->ctx->d_tab8192, nframes,
-                           (unsigned char *) d_out, (float *) nullptr, (float *) nullptr, (float *) nullptr);
+                           (unsigned char *) d_out, w->d_claim, (float *) nullptr, (float *) nullptr, (float *) nullptr);
     } else {
         hipLaunchKernelGGL(wf_frame_kernel<true>, dim3(grid), dim3(256), WF_LDS_BYTES, st,
                            (const short2 *) d_iq, (const int *) d_chan_of, (const wf_chan_dev *) w->d_chans,
                            (const float *) w->d_windows, (const float *) w->d_cic,
                            (const float2 *) w->ctx->d_tab4096, (const float2 *) w->ctx->d_tab8192, nframes,
-                           (unsigned char *) d_out, w->d_tap_pwr, w->d_tap_pwr_out, w->d_tap_db);
+                           (unsigned char *) d_out, w->d_claim, w->d_tap_pwr, w->d_tap_pwr_out, w->d_tap_db);
     }
     KG_HIP(hipGetLastError());
     return KG_OK;
