@@ -134,6 +134,10 @@ SYMBOLS = {
     "kg_snd_header": (None, [C.c_uint8, C.c_uint32, C.c_float, _vp]),
     "kg_wf_packets_dev": (_i, [_vp, _vp, _sz, _i, _vp, _vp, _sz, _vp]),
     "kg_fir_process_taps_dev": (_i, [_vp, _vp, _i, _vp, _sz, _i, _vp, _sz, _vp, _vp, _vp, _sz]),
+    "kg_fir_refilter_dev": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp, _sz]),
+    "kg_fir_set_coef_plain": (_i, [_vp, _i, _vp]),
+    "kg_snd_gps_begin": (None, [_vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "kg_snd_gps_stamp": (None, [_vp, _i, _i, _i, _i, _i, C.c_double, C.c_double, C.c_uint64, _vp]),
     "kg_acq_chan_start": (None, [_i, _i, _i, C.c_double, _vp]),
     "kg_aper_create": (_i, [_vp, _i, C.POINTER(_vp)]),
     "kg_aper_destroy": (None, [_vp]),

@@ -133,7 +133,8 @@ __global__ __launch_bounds__(64 * FIR_WAVES) void fir_block_kernel(
     const float2 *__restrict__ hist, long hist_stride, const int *__restrict__ chan_list,
     const int *__restrict__ nblk, const float2 *__restrict__ coef,     // [nchan][1024]
     const float2 *__restrict__ tab4096, float2 *__restrict__ out, long out_stride, int max_blk,
-    const float *__restrict__ cic, float2 *__restrict__ tap_pre, float2 *__restrict__ tap_post, long tap_stride)
+    const float *__restrict__ cic, const int *__restrict__ cic_on,     // m_CIC = the table where do_CIC_comp, else 1.0 (:156)
+    float2 *__restrict__ tap_pre, float2 *__restrict__ tap_post, long tap_stride)
 {
     (void) max_blk;                           // the grid is sized from it; rows check their own nblk
     __shared__ __attribute__((aligned(16))) float2 tiles[FIR_WAVES][FIR_FFT];
@@ -153,7 +154,9 @@ __global__ __launch_bounds__(64 * FIR_WAVES) void fir_block_kernel(
     if (TAPS && tap_pre) {                                             // simd_multiply_cfc, :280-283
         float2 *p = tap_pre + (long) li * tap_stride + (long) FIR_FFT * blk;
 #pragma unroll
-        for (int j = 0; j < 16; j++) { const float c = cic[t + 64 * j]; kg_st(&p[t + 64 * j], cf{x[j].x * c, x[j].y * c}); }
+        const bool on = cic_on[ch] != 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) { const float c = on ? cic[t + 64 * j] : 1.0f; kg_st(&p[t + 64 * j], cf{x[j].x * c, x[j].y * c}); }
     }
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = kg_cmul(x[j], kg_ld(&cf_[t + 64 * j]));    // simd_multiply_ccc, :293
@@ -166,6 +169,35 @@ __global__ __launch_bounds__(64 * FIR_WAVES) void fir_block_kernel(
     float2 *dst = out + (long) li * out_stride + (long) FIR_OUT * blk;
 #pragma unroll
     for (int u = 0; u < 4; u++) {                                      // keep outputs 512..1023 (:307-310)
+        kg_st(&dst[t + 64 * u], x[u + 8]);
+        kg_st(&dst[t + 64 * u + 256], x[u + 12]);
+    }
+}
+
+// The `buf_modified` path of ProcessData (fastfir.cpp:286-290): a PRE_FILTERED spectrum the caller has
+// edited is multiplied by m_pFilterCoef (no CIC compensation: the edited buffer already carries it),
+// transformed back, samples 512..1023 kept.  One wave per (list entry, block).
+__global__ __launch_bounds__(64 * FIR_WAVES) void fir_refilter_kernel(
+    const float2 *__restrict__ pre, long tap_stride, const int *__restrict__ chan_list, const int *__restrict__ nblk,
+    const float2 *__restrict__ coef0,          // [nchan][1024] m_pFilterCoef
+    const float2 *__restrict__ tab4096, float2 *__restrict__ out, long out_stride)
+{
+    __shared__ __attribute__((aligned(16))) float2 tiles[FIR_WAVES][FIR_FFT];
+    const int w = threadIdx.x >> 6, t = threadIdx.x & 63;
+    const int li = blockIdx.y, blk = blockIdx.x * FIR_WAVES + w;
+    if (blk >= nblk[li]) return;
+    float2 *tile = tiles[w];
+    fir_tw tw;
+    fir_tw_load(tw, tab4096, t);
+    const float2 *src = pre + (long) li * tap_stride + (long) FIR_FFT * blk;
+    const float2 *cf_ = coef0 + (long) chan_list[li] * FIR_FFT;
+    cf x[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = kg_cmul(kg_ld(&cf_[t + 64 * j]), kg_ld(&src[t + 64 * j]));   // simd_multiply_ccc, :287-290
+    fir_fft1024<+1, true>(x, tile, tw, t);                             // :304
+    float2 *dst = out + (long) li * out_stride + (long) FIR_OUT * blk;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {                                      // outputs 512..1023 (:307-310)
         kg_st(&dst[t + 64 * u], x[u + 8]);
         kg_st(&dst[t + 64 * u + 256], x[u + 12]);
     }
@@ -224,8 +256,9 @@ struct kg_fir {
     kg_ctx *ctx;
     int nchan, max_in;
     long hist_stride;
-    float2 *d_hist, *d_coef, *d_taps, *d_stage_in, *d_stage_out;
+    float2 *d_hist, *d_coef, *d_coef0, *d_taps, *d_stage_in, *d_stage_out;   // d_coef0: m_pFilterCoef (no CIC compensation)
     float *d_cic;
+    int *d_cic_on;                            // per channel: m_do_CIC_comp (SetupCICFilter, fastfir.cpp:148-158)
     std::vector<int> fill;                    // pending new samples per channel = FirPos()
     std::vector<char> coef_set;
     // host copies of the design tables (SetupWindowFunction / constructor)
@@ -284,8 +317,11 @@ int kg_fir_create(kg_ctx *ctx, int nchan, int max_in, kg_fir **out)
     KG_HIP(hipMalloc((void **) &f->d_hist, sizeof(float2) * f->hist_stride * nchan));
     KG_HIP(hipMemset(f->d_hist, 0, sizeof(float2) * f->hist_stride * nchan));   // m_pFFTBuf[] = 0, :61-66
     KG_HIP(hipMalloc((void **) &f->d_coef, sizeof(float2) * FIR_FFT * (size_t) nchan));
+    KG_HIP(hipMalloc((void **) &f->d_coef0, sizeof(float2) * FIR_FFT * (size_t) nchan));
     KG_HIP(hipMalloc((void **) &f->d_taps, sizeof(float2) * FIR_FFT));
     KG_HIP(hipMalloc((void **) &f->d_cic, sizeof(float) * FIR_FFT));
+    KG_HIP(hipMalloc((void **) &f->d_cic_on, sizeof(int) * nchan));
+    KG_HIP(hipMemset(f->d_cic_on, 0, sizeof(int) * nchan));
     fir_cic_table(0, f->cic);                                          // the constructor's m_CIC, fastfir.cpp:61-79
     f->cic_3ch = 0;
     KG_HIP(hipMemcpy(f->d_cic, f->cic, sizeof f->cic, hipMemcpyHostToDevice));
@@ -298,7 +334,7 @@ void kg_fir_destroy(kg_fir *f)
     if (!f) return;
     (void) hipSetDevice(f->ctx->device);
     (void) hipStreamSynchronize(f->ctx->stream);
-    (void) hipFree(f->d_hist); (void) hipFree(f->d_coef); (void) hipFree(f->d_taps); (void) hipFree(f->d_cic);
+    (void) hipFree(f->d_hist); (void) hipFree(f->d_coef); (void) hipFree(f->d_coef0); (void) hipFree(f->d_taps); (void) hipFree(f->d_cic); (void) hipFree(f->d_cic_on);
     
     (void) hipFree(f->d_stage_in); (void) hipFree(f->d_stage_out);
     delete f;
@@ -319,7 +355,20 @@ int kg_fir_set_coef(kg_fir *f, int ch, const float *coef_fft)
     hipStream_t st = f->ctx->stream;
     KG_HIP(hipStreamSynchronize(st));
     KG_HIP(hipMemcpy(f->d_coef + (size_t) ch * FIR_FFT, coef_fft, sizeof(float2) * FIR_FFT, hipMemcpyHostToDevice));
+    KG_HIP(hipMemcpy(f->d_coef0 + (size_t) ch * FIR_FFT, coef_fft, sizeof(float2) * FIR_FFT, hipMemcpyHostToDevice));
+    const int off = 0;                        // m_CIC[] = 1.0: FlyDog builds with m_do_CIC_comp false (fastfir.cpp:94)
+    KG_HIP(hipMemcpy(f->d_cic_on + ch, &off, sizeof off, hipMemcpyHostToDevice));
     f->coef_set[ch] = 1;
+    return KG_OK;
+}
+
+int kg_fir_set_coef_plain(kg_fir *f, int ch, const float *coef_fft)
+{
+    int rc = fir_chan_ok(f, ch, "kg_fir_set_coef_plain");
+    if (rc) return rc;
+    KG_REQUIRE(coef_fft != nullptr, KG_ERR_INVALID, "kg_fir_set_coef_plain: null argument");
+    KG_HIP(hipStreamSynchronize(f->ctx->stream));
+    KG_HIP(hipMemcpy(f->d_coef0 + (size_t) ch * FIR_FFT, coef_fft, sizeof(float2) * FIR_FFT, hipMemcpyHostToDevice));
     return KG_OK;
 }
 
@@ -375,7 +424,12 @@ int kg_fir_setup(kg_fir *f, int ch, float FLoCut, float FHiCut, float Offset, fl
                        do_cic_comp ? (const float *) f->d_cic : (const float *) nullptr,
                        (const float2 *) f->ctx->d_tab4096, f->d_coef + (size_t) ch * FIR_FFT);
     KG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(fir_coef_fft_kernel, dim3(1), dim3(64), 0, st, (const float2 *) f->d_taps, (const float *) nullptr,
+                       (const float2 *) f->ctx->d_tab4096, f->d_coef0 + (size_t) ch * FIR_FFT);      // m_pFilterCoef, :229
+    KG_HIP(hipGetLastError());
     KG_HIP(hipStreamSynchronize(st));
+    const int cic_on = do_cic_comp ? 1 : 0;
+    KG_HIP(hipMemcpy(f->d_cic_on + ch, &cic_on, sizeof cic_on, hipMemcpyHostToDevice));
     f->coef_set[ch] = 1;
     return KG_OK;
 }
@@ -409,6 +463,35 @@ int kg_fir_process_taps_dev(kg_fir *f, const int32_t *chans, int nch, const void
                             void *d_out, size_t out_stride, int32_t *nout, void *d_pre, void *d_post, size_t tap_stride)
 {
     return fir_process_impl(f, chans, nch, d_in, in_stride, n, d_out, out_stride, nout, d_pre, d_post, tap_stride);
+}
+
+int kg_fir_refilter_dev(kg_fir *f, const int32_t *chans, int nch, const int32_t *nblk, const void *d_pre,
+                        size_t tap_stride, void *d_out, size_t out_stride)
+{
+    KG_REQUIRE(f && chans && nblk && d_pre && d_out, KG_ERR_INVALID, "kg_fir_refilter_dev: null argument");
+    int rc = kg_ctx_use(f->ctx);
+    if (rc) return rc;
+    KG_REQUIRE(nch >= 1 && nch <= f->nchan, KG_ERR_INVALID, "kg_fir_refilter_dev: nch %d", nch);
+    int max_blk = 0;
+    for (int i = 0; i < nch; i++) {
+        KG_REQUIRE(chans[i] >= 0 && chans[i] < f->nchan && f->coef_set[chans[i]], KG_ERR_STATE,
+                   "kg_fir_refilter_dev: channel %d has no filter", chans[i]);
+        KG_REQUIRE(nblk[i] >= 0 && (size_t) nblk[i] * FIR_FFT <= tap_stride && (size_t) nblk[i] * FIR_OUT <= out_stride,
+                   KG_ERR_INVALID, "kg_fir_refilter_dev: %d blocks do not fit the strides", nblk[i]);
+        if (nblk[i] > max_blk) max_blk = nblk[i];
+    }
+    if (max_blk == 0) return KG_OK;
+    std::vector<int> pack(2 * (size_t) nch);
+    memcpy(pack.data(), chans, sizeof(int) * nch);
+    memcpy(pack.data() + nch, nblk, sizeof(int) * nch);
+    void *base = nullptr;
+    if ((rc = kg_ctx_stage(f->ctx, pack.data(), sizeof(int) * pack.size(), &base))) return rc;
+    const int *s_list = (const int *) base, *s_nblk = s_list + nch;
+    hipLaunchKernelGGL(fir_refilter_kernel, dim3((max_blk + FIR_WAVES - 1) / FIR_WAVES, nch), dim3(64 * FIR_WAVES), 0,
+                       f->ctx->stream, (const float2 *) d_pre, (long) tap_stride, s_list, s_nblk,
+                       (const float2 *) f->d_coef0, (const float2 *) f->ctx->d_tab4096, (float2 *) d_out, (long) out_stride);
+    KG_HIP(hipGetLastError());
+    return KG_OK;
 }
 
 }  // extern "C"
@@ -462,13 +545,13 @@ static int fir_process_impl(kg_fir *f, const int32_t *chans, int nch, const void
             hipLaunchKernelGGL(fir_block_kernel<true>, grid, dim3(64 * FIR_WAVES), 0, st,
                                (const float2 *) f->d_hist, f->hist_stride, s_list, s_nblk,
                                (const float2 *) f->d_coef, (const float2 *) f->ctx->d_tab4096, (float2 *) d_out,
-                               (long) out_stride, max_blk, (const float *) f->d_cic, (float2 *) d_pre, (float2 *) d_post,
+                               (long) out_stride, max_blk, (const float *) f->d_cic, (const int *) f->d_cic_on, (float2 *) d_pre, (float2 *) d_post,
                                (long) tap_stride);
         else
             hipLaunchKernelGGL(fir_block_kernel<false>, grid, dim3(64 * FIR_WAVES), 0, st,
                                (const float2 *) f->d_hist, f->hist_stride, s_list, s_nblk,
                                (const float2 *) f->d_coef, (const float2 *) f->ctx->d_tab4096, (float2 *) d_out,
-                               (long) out_stride, max_blk, (const float *) nullptr, (float2 *) nullptr, (float2 *) nullptr, 0L);
+                               (long) out_stride, max_blk, (const float *) nullptr, (const int *) nullptr, (float2 *) nullptr, (float2 *) nullptr, 0L);
         KG_HIP(hipGetLastError());
         hipLaunchKernelGGL(fir_shift_kernel, dim3(nch), dim3(1024), 0, st, f->d_hist, f->hist_stride,
                            s_list, s_nblk, s_rem);

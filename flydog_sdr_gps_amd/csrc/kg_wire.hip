@@ -6,6 +6,8 @@
 // stream, the streams of a launch in parallel.  Integer arithmetic, bit-exact.
 #include "kg_common.h"
 
+#include <math.h>
+
 #include <stdlib.h>
 #include <new>
 #include <vector>
@@ -245,6 +247,32 @@ void kg_snd_header(uint8_t flags, uint32_t seq, float smeter_dBm, uint8_t *h)
     h[3] = flags;
     h[4] = (uint8_t) seq; h[5] = (uint8_t) (seq >> 8); h[6] = (uint8_t) (seq >> 16); h[7] = (uint8_t) (seq >> 24);
     h[8] = (uint8_t) (sm >> 8); h[9] = (uint8_t) sm;             // SET_BE_U16
+}
+
+static const double GPS_WEEK_SEC = 7 * 24 * 3600.0;             // rx/rx_sound.cpp:93
+
+void kg_snd_gps_begin(kg_gps_state *s, double clk_gps_secs, double dticks, double adc_clock_base,
+                      double gps_delay, double gps_delay2)
+{
+    if (!s) return;                                             // rx/rx_sound.cpp:557
+    s->gpssec = fmod(GPS_WEEK_SEC + clk_gps_secs + (dticks / adc_clock_base) - gps_delay + gps_delay2, GPS_WEEK_SEC);
+}
+
+void kg_snd_gps_stamp(kg_gps_state *s, int norm_nrx_samps, int fir_pos, int agc_on, int agc_delay,
+                      int rx_decim, double adc_clock_base, double clk_gps_secs, uint64_t clk_ticks,
+                      kg_iq_stamp *out)
+{
+    if (!s || !out) return;
+    int sample_filter_delays = norm_nrx_samps - fir_pos;        // :638 (1) delay in the FIR filter
+    if (agc_on) sample_filter_delays -= agc_delay;              // :640-641 (2) delay in the AGC
+    s->gpssec = fmod(GPS_WEEK_SEC + s->gpssec + (rx_decim * sample_filter_delays / adc_clock_base), GPS_WEEK_SEC);   // :652
+    memset(out, 0, sizeof *out);
+    out->gpssec = (uint32_t) s->last_gpssec;                    // :654
+    out->gpsnsec = s->gps_init ? (uint32_t) (1e9 * (s->last_gpssec - out->gpssec)) : 0;    // :655
+    const double dt_to_pos_sol = s->last_gpssec - clk_gps_secs; // :656
+    out->last_gps_solution = s->gps_init ? ((clk_ticks == 0) ? 255 : (uint8_t) (dt_to_pos_sol < 252.0 ? dt_to_pos_sol : 252.0)) : 0;   // :658
+    if (!s->gps_init) s->gps_init = 1;                          // :659
+    s->last_gpssec = s->gpssec;                                 // :661
 }
 
 int kg_wf_packets_dev(kg_ctx *ctx, const void *d_rows, size_t row_stride, int nrows, const kg_wf_pkt_info *info,

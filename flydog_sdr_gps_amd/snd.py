@@ -150,3 +150,38 @@ class FastFir:
             for d in (d_in, d_out, d_pre, d_post):
                 ctx.free(d)
         return out[:n].copy(), pre[:n // 512].copy(), post[:n // 512].copy()
+
+    def process_taps_edit(self, ch, x, edit):
+        """ProcessData when a PRE_FILTERED extension rewrites the spectrum it is handed (`buf_modified`,
+        fastfir.cpp:286-290): process with taps, apply edit(pre) -> edited blocks (host callable standing in
+        for the extension's device code), filter the edited blocks again.  -> (out, pre, edited)"""
+        x = np.ascontiguousarray(x, np.complex64)
+        maxblk = x.size // 512 + 2
+        ctx = self.ctx
+        d_in, d_out = ctx.alloc(max(x.nbytes, 8)), ctx.alloc((x.size + 512) * 8)
+        d_pre = ctx.alloc(maxblk * 1024 * 8)
+        try:
+            ctx.upload(d_in, x)
+            chans = np.array([ch], np.int32)
+            nout = np.zeros(1, np.int32)
+            check(self.lib.kg_fir_process_taps_dev(self.h, ptr(chans), 1, ptr(int(d_in)), x.size, x.size,
+                                                   ptr(int(d_out)), x.size + 512, ptr(nout), ptr(int(d_pre)), None,
+                                                   maxblk * 1024), "kg_fir_process_taps_dev")
+            ctx.sync()
+            n = int(nout[0])
+            nblk = np.array([n // 512], np.int32)
+            pre = np.zeros((maxblk, 1024), np.complex64)
+            ctx.download(d_pre, pre)
+            edited = pre.copy()
+            edited[:n // 512] = edit(pre[:n // 512])
+            ctx.upload(d_pre, edited)
+            check(self.lib.kg_fir_refilter_dev(self.h, ptr(chans), 1, ptr(nblk), ptr(int(d_pre)), maxblk * 1024,
+                                               ptr(int(d_out)), x.size + 512), "kg_fir_refilter_dev")
+            ctx.sync()
+            out = np.zeros(max(n, 1), np.complex64)
+            if n:
+                ctx.download(d_out, out[:n])
+        finally:
+            for d in (d_in, d_out, d_pre):
+                ctx.free(d)
+        return out[:n].copy(), pre[:n // 512].copy(), edited[:n // 512].copy()

@@ -130,3 +130,26 @@ def wf_packets(ctx, rows, infos):
         ctx.free(d_rows)
         ctx.free(d_pk)
     return [pk[i, :nb[i]].copy() for i in range(len(infos))]
+
+
+class GpsState(C.Structure):
+    """snd_t::gpssec, last_gpssec, gps_init (rx/rx_sound.h:120-122) of one sound connection."""
+    _fields_ = [("gpssec", C.c_double), ("last_gpssec", C.c_double), ("gps_init", C.c_int32), ("pad", C.c_int32)]
+
+
+class IqStamp(C.Structure):
+    _fields_ = [("gpssec", C.c_uint32), ("gpsnsec", C.c_uint32), ("last_gps_solution", C.c_uint8), ("pad", C.c_uint8 * 3)]
+
+
+def gps_begin(lib, st, clk_gps_secs, dticks, adc_clock_base, gps_delay, gps_delay2):
+    """rx/rx_sound.cpp:557, once per data-pump buffer (host arithmetic in libkiwigpu)."""
+    lib.kg_snd_gps_begin(C.byref(st), float(clk_gps_secs), float(dticks), float(adc_clock_base), float(gps_delay),
+                         float(gps_delay2))
+
+
+def gps_stamp(lib, st, norm_nrx_samps, fir_pos, agc_on, agc_delay, rx_decim, adc_clock_base, clk_gps_secs, clk_ticks):
+    """rx/rx_sound.cpp:636-661, once per FIR output block -> (gpssec, gpsnsec, last_gps_solution)"""
+    o = IqStamp()
+    lib.kg_snd_gps_stamp(C.byref(st), int(norm_nrx_samps), int(fir_pos), int(bool(agc_on)), int(agc_delay),
+                         int(rx_decim), float(adc_clock_base), float(clk_gps_secs), int(clk_ticks), C.byref(o))
+    return o.gpssec, o.gpsnsec, o.last_gps_solution

@@ -326,7 +326,8 @@ void kg_fir_destroy(kg_fir *fir);
  * sanity check (:193-200) rejects the parameters and the old filter stays. */
 int kg_fir_setup(kg_fir *fir, int ch, float FLoCut, float FHiCut, float Offset, float SampleRate,
                  int window_func, int do_cic_comp, int snd_rate_3ch);
-/* Or hand over the reference's own m_pFilterCoef_CIC[1024] (complex float). */
+/* Or hand over the reference's own m_pFilterCoef_CIC[1024] (complex float); the channel's m_CIC[] is
+ * then 1.0 (m_do_CIC_comp false, what FlyDog builds: fastfir.cpp:94). */
 int kg_fir_set_coef(kg_fir *fir, int ch, const float *coef_fft);
 int kg_fir_get_coef(kg_fir *fir, int ch, float *coef_fft);
 int kg_fir_reset(kg_fir *fir, int ch);
@@ -416,6 +417,24 @@ int kg_snd_payload_dev(kg_ctx *ctx, const void *d_s16, size_t in_stride, int nch
  * big-endian in 0.1 dB steps above -127.  Host only. */
 void kg_snd_header(uint8_t flags, uint32_t seq, float smeter_dBm, uint8_t *h);
 
+/* The GPS time stamp of snd_pkt_iq_t (rx/rx_sound.h:61-64), host arithmetic as c2s_sound() does it.
+ * State per sound connection (snd_t::gpssec, last_gpssec, gps_init, rx/rx_sound.h:120-122). */
+typedef struct { double gpssec, last_gpssec; int32_t gps_init; int32_t pad; } kg_gps_state;
+typedef struct { uint32_t gpssec, gpsnsec; uint8_t last_gps_solution; uint8_t pad[3]; } kg_iq_stamp;
+/* rx/rx_sound.cpp:557, once per data-pump buffer: gpssec = fmod(week + clk.gps_secs + dticks /
+ * clk.adc_clock_base - gps_delay + gps_delay2, week); dticks = the buffer's 48-bit tick count minus
+ * clk.ticks. */
+void kg_snd_gps_begin(kg_gps_state *s, double clk_gps_secs, double dticks, double adc_clock_base,
+                      double gps_delay, double gps_delay2);
+/* rx/rx_sound.cpp:636-661, once per 512-sample FIR output block: the FIR delay (norm_nrx_samps -
+ * fir_pos, fir_pos = kg_fir_pos() before the block) and the AGC delay (kg_post_agc_delay(), when the
+ * AGC is on) are taken off, the header carries the PREVIOUS block's time (last_gpssec), and
+ * last_gps_solution = 255 without a clock solution (clk_ticks == 0), else min(252, seconds since it),
+ * 0 on the first block of a connection. */
+void kg_snd_gps_stamp(kg_gps_state *s, int norm_nrx_samps, int fir_pos, int agc_on, int agc_delay,
+                      int rx_decim, double adc_clock_base, double clk_gps_secs, uint64_t clk_ticks,
+                      kg_iq_stamp *out);
+
 #define KG_WF_ADPCM_PAD 10                          /* ADPCM_PAD, rx/rx_waterfall.h:83 */
 #define KG_WF_PKT_HDR   16                          /* id4, x_bin_server, flags_x_zoom_server, seq */
 #define KG_WF_PKT_MAX   (KG_WF_PKT_HDR + KG_WF_ADPCM_PAD + 1024)   /* sizeof(wf_pkt_t) */
@@ -483,6 +502,19 @@ int kg_aper_get(kg_aper *a, int chan, float *avg_pwr);            /* 1024 floats
 int kg_fir_process_taps_dev(kg_fir *fir, const int32_t *chans, int nch, const void *d_in, size_t in_stride, int n,
                             void *d_out, size_t out_stride, int32_t *nout, void *d_pre, void *d_post,
                             size_t tap_stride);
+
+/* A PRE_FILTERED extension that EDITS the spectrum it is handed (`buf_modified`, fastfir.cpp:286-290):
+ * after kg_fir_process_taps_dev() delivered d_pre, the caller rewrites those 1024-point blocks on the
+ * device and calls this.  Block b (b < nblk[i]) of list entry i is filtered again as the reference
+ * filters a modified buffer -- m_pFilterCoef (the coefficients WITHOUT the CIC compensation) times the
+ * edited block, backward transform, samples 512..1023 -- into d_out + i*out_stride + 512 b, replacing
+ * what kg_fir_process_taps_dev wrote there.  The un-compensated coefficients are those kg_fir_setup
+ * designed, or what kg_fir_set_coef_plain handed over.  Enqueue only. */
+int kg_fir_refilter_dev(kg_fir *fir, const int32_t *chans, int nch, const int32_t *nblk, const void *d_pre,
+                        size_t tap_stride, void *d_out, size_t out_stride);
+/* m_pFilterCoef[1024] (complex float) for kg_fir_refilter_dev when kg_fir_set_coef supplied
+ * m_pFilterCoef_CIC; kg_fir_set_coef alone uses the same array for both. */
+int kg_fir_set_coef_plain(kg_fir *fir, int ch, const float *coef_fft);
 
 /* Diagnostics: re-runs the 4096-point stage of the forward FFT of `block` in a
  * stamped build of the kernel and returns 4 s_memrealtime readings (100 MHz):

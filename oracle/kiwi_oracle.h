@@ -278,6 +278,14 @@ void ko_aper_update(float *avg_pwr, const uint8_t *bp, int algo, float param, in
                     int waterfall_cal);
 void ko_aper_report(const float *avg_pwr, int start, int stop, int *signal, int *noise);
 
+/* GPS time stamp of the IQ sound packet (rx/rx_sound.cpp:557, :636-661) */
+typedef struct { double gpssec, last_gpssec; int gps_init; int pad; } ko_gps_state;
+void ko_snd_gps_begin(ko_gps_state *s, double clk_gps_secs, double dticks, double adc_clock_base,
+                      double gps_delay, double gps_delay2);
+void ko_snd_gps_stamp(ko_gps_state *s, int norm_nrx_samps, int fir_pos, int agc_on, int agc_delay, int rx_decim,
+                      double adc_clock_base, double clk_gps_secs, uint64_t clk_ticks, uint32_t *gpssec,
+                      uint32_t *gpsnsec, uint8_t *last_gps_solution);
+
 #ifdef __cplusplus
 }
 #endif

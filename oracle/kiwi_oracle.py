@@ -474,6 +474,25 @@ def snd_header(flags, seq, smeter_dBm):
     return h
 
 
+class GpsState(C.Structure):
+    _fields_ = [("gpssec", C.c_double), ("last_gpssec", C.c_double), ("gps_init", C.c_int), ("pad", C.c_int)]
+
+
+def gps_begin(st, clk_gps_secs, dticks, adc_clock_base, gps_delay, gps_delay2):
+    L = lib()
+    L.ko_snd_gps_begin.argtypes = [C.c_void_p] + [C.c_double] * 5
+    L.ko_snd_gps_begin(C.byref(st), clk_gps_secs, dticks, adc_clock_base, gps_delay, gps_delay2)
+
+
+def gps_stamp(st, norm_nrx_samps, fir_pos, agc_on, agc_delay, rx_decim, adc_clock_base, clk_gps_secs, clk_ticks):
+    L = lib()
+    L.ko_snd_gps_stamp.argtypes = [C.c_void_p] + [C.c_int] * 5 + [C.c_double, C.c_double, C.c_uint64] + [C.c_void_p] * 3
+    a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint8()
+    L.ko_snd_gps_stamp(C.byref(st), norm_nrx_samps, fir_pos, int(bool(agc_on)), agc_delay, rx_decim, adc_clock_base,
+                       clk_gps_secs, clk_ticks, C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
 # ---- hand-off arithmetic, waterfall autoscale (kiwi_oracle_handoff.c) ----------------
 class ChanStart(C.Structure):
     _fields_ = [("lo_dop", C.c_double), ("ca_dop", C.c_double), ("lo_rate", C.c_uint32), ("ca_rate", C.c_uint32),

@@ -15,6 +15,8 @@
  */
 #include "kiwi_oracle.h"
 
+#include <math.h>
+
 #include <string.h>
 
 static const int index_adjust[16] = { -1, -1, -1, -1, 2, 4, 6, 8, -1, -1, -1, -1, 2, 4, 6, 8 };   /* :89-94 */
@@ -144,4 +146,27 @@ void ko_snd_header(uint8_t flags, uint32_t seq, float smeter_dBm, uint8_t *h)
     h[3] = flags;
     put_le32(h + 4, seq);                                      /* :1252 SET_LE_U32 */
     h[8] = sm >> 8; h[9] = sm & 0xff;                          /* :1226 SET_BE_U16 */
+}
+
+/* The GPS time stamp of snd_pkt_iq_t: rx/rx_sound.cpp:557 (per data-pump buffer) and :636-661 (per FIR
+ * output block).  Pure double arithmetic on host values. */
+static const double KO_GPS_WEEK_SEC = 7 * 24 * 3600.0;         /* :93 */
+void ko_snd_gps_begin(ko_gps_state *s, double clk_gps_secs, double dticks, double adc_clock_base,
+                      double gps_delay, double gps_delay2)
+{
+    s->gpssec = fmod(KO_GPS_WEEK_SEC + clk_gps_secs + (dticks / adc_clock_base) - gps_delay + gps_delay2, KO_GPS_WEEK_SEC);
+}
+void ko_snd_gps_stamp(ko_gps_state *s, int norm_nrx_samps, int fir_pos, int agc_on, int agc_delay, int rx_decim,
+                      double adc_clock_base, double clk_gps_secs, uint64_t clk_ticks, uint32_t *gpssec,
+                      uint32_t *gpsnsec, uint8_t *last_gps_solution)
+{
+    int sample_filter_delays = norm_nrx_samps - fir_pos;       /* :638 */
+    if (agc_on) sample_filter_delays -= agc_delay;             /* :640-641 */
+    s->gpssec = fmod(KO_GPS_WEEK_SEC + s->gpssec + (rx_decim * sample_filter_delays / adc_clock_base), KO_GPS_WEEK_SEC);
+    *gpssec = (uint32_t) s->last_gpssec;                       /* :654 */
+    *gpsnsec = s->gps_init ? (uint32_t) (1e9 * (s->last_gpssec - *gpssec)) : 0;
+    const double dt_to_pos_sol = s->last_gpssec - clk_gps_secs;
+    *last_gps_solution = s->gps_init ? ((clk_ticks == 0) ? 255 : (uint8_t) (dt_to_pos_sol < 252.0 ? dt_to_pos_sol : 252.0)) : 0;
+    if (!s->gps_init) s->gps_init = 1;
+    s->last_gpssec = s->gpssec;
 }

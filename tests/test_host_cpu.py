@@ -646,3 +646,31 @@ def test_cpp_example_builds_against_the_header_and_fails_loudly_without_a_gpu(tm
         assert out.returncode == 0
     else:
         assert out.returncode == 1 and "no HIP device" in out.stderr and "no CPU fallback" in out.stderr
+
+
+def test_gps_timestamp_host_arithmetic_matches_oracle(oracle):
+    """kg_snd_gps_begin / kg_snd_gps_stamp (host functions of libkiwigpu: rx/rx_sound.cpp:557, :636-661)
+    against the oracle's restatement over a simulated stream: 170-sample data-pump buffers, the FIR's
+    fir_pos sequence, AGC on and off, a week wrap, no clock solution, the first block of a connection."""
+    from flydog_sdr_gps_amd import load_library, wire
+    lib = load_library()
+    rng = np.random.Generator(np.random.PCG64(5))
+    for agc_on, clk_ticks, t0 in ((1, 123456, 1000.25), (0, 0, 604799.5), (1, 99, 3.0e5)):
+        g, k = wire.GpsState(), oracle.GpsState()
+        fir_pos, clk_gps = 0, t0 - 20.0
+        adc, decim, nrx = 66.6666e6 + 13.7, 5555, 170
+        dticks = 0.0
+        for buf in range(60):
+            dticks += decim * nrx + float(rng.integers(-2, 3))
+            wire.gps_begin(lib, g, clk_gps, dticks + 20.0 * adc, adc, 28926.838 / adc, 1e-7)
+            oracle.gps_begin(k, clk_gps, dticks + 20.0 * adc, adc, 28926.838 / adc, 1e-7)
+            assert g.gpssec == k.gpssec
+            fir_pos += nrx
+            if fir_pos >= 512:                       # ProcessData emitted a block
+                got = wire.gps_stamp(lib, g, 85, fir_pos - nrx, agc_on, 180, decim, adc, clk_gps, clk_ticks)
+                want = oracle.gps_stamp(k, 85, fir_pos - nrx, agc_on, 180, decim, adc, clk_gps, clk_ticks)
+                assert got == want and (g.gpssec, g.last_gpssec, g.gps_init) == (k.gpssec, k.last_gpssec, k.gps_init)
+                if clk_ticks == 0 and buf > 10:
+                    assert got[2] == 255
+                fir_pos -= 512
+        assert 0.0 <= g.gpssec < 7 * 24 * 3600.0

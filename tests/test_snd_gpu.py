@@ -155,7 +155,8 @@ def test_extension_fft_taps(gpu_ctx, oracle):
         for do_cic, snd3 in ((False, False), (True, True)):
             f.setup(1, -2700.0, -300.0, 0.0, 12000.0, do_cic_comp=do_cic, snd_rate_3ch=snd3)
             f.reset(1)
-            cic = oracle.fir_cic_coeffs(snd3)
+            # m_CIC[] = the compensation table only where do_CIC_comp, else 1.0 (SetupCICFilter, fastfir.cpp:156)
+            cic = oracle.fir_cic_coeffs(snd3) if do_cic else np.ones(1024, np.float32)
             coef = f.get_coef(1)
             st = oracle.fir_new_state()
             for n in (170, 170, 170, 170, 1500, 7, 2048):
@@ -203,3 +204,39 @@ def test_unpack_rows_layout_bit_exact(gpu_ctx, oracle):
         gpu_ctx.free(d_out)
     want = oracle.dpump_unpack(spi, nsamps, nchans, enabled=en, dc_i=1.5, dc_q=-2.0)
     assert np.array_equal(out.view(np.uint32), want.view(np.uint32)) and np.all(out[2] == 0)
+
+
+def test_pre_filtered_extension_that_edits_the_spectrum(gpu_ctx, oracle):
+    """fastfir.cpp:286-290 (`buf_modified`): the extension is handed the CIC-compensated forward
+    spectrum, rewrites it, and the block is then filtered with m_pFilterCoef (no CIC factor) instead of
+    m_pFilterCoef_CIC.  Editing nothing must reproduce the normal output exactly when the filter has no
+    CIC compensation; a notch edit must equal the oracle's backward transform of coef x edited."""
+    from flydog_sdr_gps_amd import FastFir
+    rng = np.random.Generator(np.random.PCG64(77))
+    x = (rng.standard_normal(2048) + 1j * rng.standard_normal(2048)).astype(np.complex64) * 1000
+    for do_cic in (False, True):
+        f = FastFir(gpu_ctx, nchan=2, max_in=4096)
+        f.setup(1, -2700.0, -300.0, 0.0, 12000.0, do_cic_comp=do_cic)
+        coef, coef_cic, _ = oracle.fir_design(-2700.0, -300.0, 0.0, 12000.0, do_cic_comp=do_cic, prec=0)
+
+        def notch(pre):
+            e = pre.copy()
+            e[:, 900:930] = 0                      # the extension removes a band
+            e[:, 5] *= 2.0
+            return e
+
+        out, pre, edited = f.process_taps_edit(1, x, notch)
+        assert out.size == 2048 - 512 + 512 * 0 or out.size % 512 == 0
+        nblk = out.size // 512
+        assert nblk >= 3
+        for b in range(nblk):
+            want = oracle.fft(coef * edited[b], sign=+1, prec=1)[512:]
+            scale = np.abs(want).max()
+            assert np.abs(out[512 * b:512 * (b + 1)] - want).max() <= 2e-5 * scale, (do_cic, b)
+        # the identity edit: m_pFilterCoef x (FFT x CIC) == m_pFilterCoef_CIC x FFT up to rounding
+        f.reset(1)
+        ident, _, _ = f.process_taps_edit(1, x, lambda p: p)
+        f.reset(1)
+        normal = f.process(1, x)
+        assert np.abs(ident - normal).max() <= 2e-5 * np.abs(normal).max()
+        f.close()
