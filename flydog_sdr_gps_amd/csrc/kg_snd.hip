@@ -153,7 +153,6 @@ __global__ __launch_bounds__(64 * FIR_WAVES) void fir_block_kernel(
     fir_fft1024<-1, false>(x, tile, tw, t);                            // fastfir.cpp:274
     if (TAPS && tap_pre) {                                             // simd_multiply_cfc, :280-283
         float2 *p = tap_pre + (long) li * tap_stride + (long) FIR_FFT * blk;
-#pragma unroll
         const bool on = cic_on[ch] != 0;
 #pragma unroll
         for (int j = 0; j < 16; j++) { const float c = on ? cic[t + 64 * j] : 1.0f; kg_st(&p[t + 64 * j], cf{x[j].x * c, x[j].y * c}); }
