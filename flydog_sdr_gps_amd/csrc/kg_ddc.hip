@@ -767,6 +767,7 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
     if (c0_need > d->c0_cap) {
         KG_HIP(hipStreamSynchronize(st));
         (void) hipFree(d->d_c0rel);
+        d->d_c0rel = nullptr; d->c0_cap = 0;  // nothing dangles if the allocation below fails
         KG_HIP(hipMalloc((void **) &d->d_c0rel, sizeof(u32) * (size_t) (c0_need + 16)));
         d->c0_cap = c0_need;
     }
