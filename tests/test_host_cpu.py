@@ -674,3 +674,13 @@ def test_gps_timestamp_host_arithmetic_matches_oracle(oracle):
                     assert got[2] == 255
                 fir_pos -= 512
         assert 0.0 <= g.gpssec < 7 * 24 * 3600.0
+
+
+def test_oracle_is_clean_under_asan_and_ubsan():
+    """The GPU box cannot run sanitizers; the oracle can: oracle/asan_main.c walks every family of its
+    entry points (both acquisition shapes, waterfall, FIR, both DDCs and the three RX instances, AGC and
+    detectors, wire formats, hand-off, GPS stamp) under -fsanitize=address,undefined."""
+    out = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "asan-run"], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "asan driver ok" in out.stdout and "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr
