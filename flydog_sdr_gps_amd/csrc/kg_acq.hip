@@ -433,27 +433,45 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
                         kg_cmac4v(acc[0][4 * a], acc[0][4 * a + 1], acc[0][4 * a + 2], acc[0][4 * a + 3],
                                   y[4 * a], y[4 * a + 1], y[4 * a + 2], y[4 * a + 3], C0, C1, C2, C3);
                     }
-                } else
+                } else {
+                    // four output quarters: z[m] = y[m] * C[m] once, then acc_q[m] += z[m] * W_P^(q*k2)
 #pragma unroll
-                for (int m = 0; m < 16; m++) {
-                    cf z = y[m];
-                    if ((m & 3) != 0) z = kg_cmul_s(z, g[(m & 3) - 1]);
-                    z = kg_cmul(z, B[m >> 2]);
-                    acc[0][m] = acc[0][m] + z;
-                    if constexpr (NQ == 4 && P == 4) {    // quarters 1..3: times j^(q*k2), wave-uniform
-                        if (k2 == 1) {
-                            acc[1][m] = kg_addj(acc[1][m], z); acc[2][m] = acc[2][m] - z;
-                            acc[3][m] = kg_subj(acc[3][m], z);
-                        } else if (k2 == 2) {
-                            acc[1][m] = acc[1][m] - z; acc[2][m] = acc[2][m] + z;
-                            acc[3][m] = acc[3][m] - z;
-                        } else {
-                            acc[1][m] = kg_subj(acc[1][m], z); acc[2][m] = acc[2][m] - z;
-                            acc[3][m] = kg_addj(acc[3][m], z);
+                    for (int a = 0; a < 4; a++) {
+                        cf C1 = B[a], C2 = B[a], C3 = B[a], C0 = B[a];
+                        {
+                            cf r1, r2, r3;
+                            asm(KG_MUL_("%3", "%0", "%6") KG_MUL_("%4", "%1", "%7") KG_MUL_("%5", "%2", "%8")
+                                KG_FMA_("%0", "%6", "%3", "neg_lo:[0,1,0]") KG_FMA_("%1", "%7", "%4", "neg_lo:[0,1,0]")
+                                KG_FMA_("%2", "%8", "%5", "neg_lo:[0,1,0]")
+                                : "+v"(C1), "+v"(C2), "+v"(C3), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                                : "s"(g[0]), "s"(g[1]), "s"(g[2]));
                         }
-                    } else if constexpr (NQ == 4) {       // times W_16^(q*k2), wave-uniform
+                        cf z0 = y[4 * a], z1 = y[4 * a + 1], z2 = y[4 * a + 2], z3 = y[4 * a + 3];
+                        kg_cmul4v<false>(z0, z1, z2, z3, C0, C1, C2, C3);
+                        const cf z[4] = {z0, z1, z2, z3};
 #pragma unroll
-                        for (int q = 1; q < 4; q++) acc[q][m] = acc[q][m] + kg_cmul_s(z, Q[q - 1]);
+                        for (int b = 0; b < 4; b++) {
+                            const int m = 4 * a + b;
+                            acc[0][m] = acc[0][m] + z[b];
+                            if constexpr (P == 4) {            // quarters 1..3: times j^(q*k2), wave-uniform
+                                if (k2 == 1) {
+                                    acc[1][m] = kg_addj(acc[1][m], z[b]); acc[2][m] = acc[2][m] - z[b];
+                                    acc[3][m] = kg_subj(acc[3][m], z[b]);
+                                } else if (k2 == 2) {
+                                    acc[1][m] = acc[1][m] - z[b]; acc[2][m] = acc[2][m] + z[b];
+                                    acc[3][m] = acc[3][m] - z[b];
+                                } else {
+                                    acc[1][m] = kg_subj(acc[1][m], z[b]); acc[2][m] = acc[2][m] - z[b];
+                                    acc[3][m] = kg_addj(acc[3][m], z[b]);
+                                }
+                            }
+                        }
+                        if constexpr (P != 4) {                // times W_16^(q*k2), wave-uniform
+#pragma unroll
+                            for (int q = 1; q < 4; q++)
+                                kg_cmac4s(acc[q][4 * a], acc[q][4 * a + 1], acc[q][4 * a + 2], acc[q][4 * a + 3],
+                                          z0, z1, z2, z3, Q[q - 1]);
+                        }
                     }
                 }
             }

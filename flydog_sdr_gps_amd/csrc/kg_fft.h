@@ -167,9 +167,17 @@ KG_DEV void kg_cmac4v(cf &c0, cf &c1, cf &c2, cf &c3, cf y0, cf y1, cf y2, cf y3
         KG_MAC2_("%0", "%4", "%8") KG_MAC2_("%1", "%5", "%9") KG_MAC2_("%2", "%6", "%10") KG_MAC2_("%3", "%7", "%11")
         : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
         : "v"(y0), "v"(y1), "v"(y2), "v"(y3), "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+}
+// the same with one wave-uniform factor w (an SGPR pair) for all four points
+KG_DEV void kg_cmac4s(cf &c0, cf &c1, cf &c2, cf &c3, cf y0, cf y1, cf y2, cf y3, cf w)
+{
+    asm(KG_MAC1_("%0", "%4", "%8") KG_MAC1_("%1", "%5", "%8") KG_MAC1_("%2", "%6", "%8") KG_MAC1_("%3", "%7", "%8")
+        KG_MAC2_("%0", "%4", "%8") KG_MAC2_("%1", "%5", "%8") KG_MAC2_("%2", "%6", "%8") KG_MAC2_("%3", "%7", "%8")
+        : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+        : "v"(y0), "v"(y1), "v"(y2), "v"(y3), "s"(w));
+}
 #undef KG_MAC1_
 #undef KG_MAC2_
-}
 
 // y_c = sum_a x_a (SIGN*j)^(a*c).  X2J: x2 still has to be multiplied by SIGN*j
 // (the W16^4 twiddle of the radix-16, folded into this butterfly's first adds).
