@@ -216,13 +216,15 @@ def timed_steps(dist, step, steps, warmup):
     import torch
     for _ in range(warmup):
         step()
-    dist.barrier()
+    dist.barrier()                                   # barrier, then synchronize
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     t_enq = time.perf_counter() - t0
-    dist.barrier()
-    elapsed = dist.max_over_ranks(time.perf_counter() - t0)
+    torch.cuda.synchronize()                         # this rank's K steps are done ...
+    local = time.perf_counter() - t0
+    dist.barrier()                                   # ... every rank's are: the slowest rank's time counts
+    elapsed = dist.max_over_ranks(local)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     ev[0].record()
     for i in range(steps):
@@ -663,8 +665,10 @@ def run_receivers(args, dist):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    torch.cuda.synchronize(dev)                      # both streams of this rank
+    local = time.perf_counter() - t0
     dist.barrier()
-    elapsed = dist.max_over_ranks(time.perf_counter() - t0)
+    elapsed = dist.max_over_ranks(local)
     # sanity: the strongest carrier is in the band of every waterfall row and audio came out
     assert int(rows.max()) > 100 and counts["audio_blocks"] > 0 and int(pay.to(torch.int32).abs().sum()) > 0
     step_s = elapsed / args.steps
