@@ -787,6 +787,10 @@ static int acq_init(kg_acq *a)
 #undef ACQ_SETUP
     if (occ1 < 1) occ1 = 1;
     if (occ4 < 1) occ4 = 1;
+    if (const char *e = getenv("KIWIGPU_ACQ_WGS_PER_CU")) {      // experiments: fewer resident workgroups per CU
+        const int v = atoi(e);
+        if (v >= 1 && v < occ1) occ1 = v;
+    }
     a->grid1 = (ctx->num_cus * occ1) & ~7;
     a->grid4 = (ctx->num_cus * occ4) & ~7;
     if (a->grid1 < 8) a->grid1 = 8;
