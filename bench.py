@@ -580,87 +580,112 @@ def run_ddc14(args, dist):
 # ------------------------------------------------------------------------------------------------
 # configs[3]: virtual receivers
 # ------------------------------------------------------------------------------------------------
-def run_receivers(args, dist):
-    """A batch of virtual receivers per GPU (weak scaling over ranks), each with a waterfall and an
-    audio path, fed from one ADC block resident in HBM per step:
+class ReceiverBank:
+    """NR virtual receivers on one GPU, each with a waterfall and an audio path, fed from one ADC
+    block resident in HBM per step (receiver k of the whole job = first_rx + local index):
       waterfall: NCO mix + CIC decimate -> 8192-sample frame -> u8 row -> wf_pkt_t (ADPCM)
       audio:     NCO mix + CIC/CIC/CICF decimate -> rx_iq_t -> unpack -> CFastFIR -> S-meter +
-                 CAgc (mono16) -> IMA ADPCM"""
-    import numpy as np
-    import torch
-    dev = dist.dev
-    from flydog_sdr_gps_amd import Adpcm, Context, Ddc, FastFir, Post, RxDdc, Waterfall, WfParams, post, snd, wf, wire
-    from flydog_sdr_gps_amd.ddc import RX_DECIM, rx_phase_inc
-    # the waterfall chain and the audio chain of a receiver are independent: one context (= one
-    # stream) each, so the short latency-bound kernels of one hide under the DDC passes of the other
-    two = os.environ.get("KIWIGPU_BENCH_ONE_STREAM") != "1"
-    ctx = Context(dist.local_rank, torch.cuda.current_stream(dev).cuda_stream)
-    side = torch.cuda.Stream(device=dev) if two else None
-    ctx_au = Context(dist.local_rank, side.cuda_stream) if two else ctx
-    NR, n = args.receivers, 1 << args.log2n
-    assert n >= 512 * 8192, "--log2n >= 22: every step must complete a waterfall frame at zoom 10"
-    adc_clock, ui_srate = 66.6666e6, 30.0e6
-    adc = torch.from_numpy(adc_block(n, 0x5EED0004)).to(dev)      # every GPU sees the SAME stream (configs[3])
-    chans = list(range(NR))
-    first_rx = dist.rank * NR                                      # this rank's slice of the receiver set
+                 CAgc (mono16) -> IMA ADPCM
+    tests/test_receivers_gpu.py steps the same object and checks every stage of every receiver
+    against the oracle."""
+    ADC_CLOCK, UI_SRATE = 66.6666e6, 30.0e6
 
-    d = Ddc(ctx, nchan=NR, max_samples=n)
-    W = Waterfall(ctx, nchan=NR)
-    W.set_tables()
-    hz_per_start = ui_srate / (1024 << 14)
-    params = []
-    for ch in range(NR):
-        k = first_rx + ch
-        z = 1 + k % 10
-        p = WfParams.for_zoom(z, (1.0e6 + 0.2e6 * (k % 97)) / hz_per_start, adc_clock=adc_clock, ui_srate=ui_srate)
-        params.append(p)
-        d.set_wf(ch, p.i_offset, p.decim)
-        W.set_channel(ch, p, interp=wf.WF_MAX, window_func=wf.WINF_HANNING, cic_comp=True)
-    rx = RxDdc(ctx_au, nchan=NR, max_samples=n)
-    nrec_max = n // RX_DECIM + 2
-    fir = FastFir(ctx_au, nchan=NR, max_in=nrec_max)
-    P = Post(ctx_au, nchan=NR)
-    A = Adpcm(ctx_au, nchan=NR)
-    fs = adc_clock / RX_DECIM
-    for ch in range(NR):
-        rx.set_freq(ch, rx_phase_inc(0.0123 * adc_clock - 1000.0 - 10.0 * (first_rx + ch), adc_clock))
-        fir.setup(ch, 300.0, 2700.0, 0.0, fs)
-        P.set_agc(ch, True, False, -100, 50, 6, 1000, fs)
-        P.set_smeter(ch, fs); P.set_mode(ch, post.MODE_SSB); P.reset(ch)
+    def __init__(self, local_rank, dev, NR, n, first_rx, two_streams=True):
+        import torch
+        from flydog_sdr_gps_amd import Adpcm, Context, Ddc, FastFir, Post, RxDdc, Waterfall, WfParams, post, wf, wire
+        from flydog_sdr_gps_amd.ddc import RX_DECIM, rx_phase_inc
+        assert n >= 512 * 8192, "--log2n >= 22: every step must complete a waterfall frame at zoom 10"
+        self.dev, self.NR, self.n, self.first_rx = dev, NR, n, first_rx
+        # the waterfall chain and the audio chain of a receiver are independent: one context (= one
+        # stream) each, so the short latency-bound kernels of one hide under the DDC passes of the other
+        self.ctx = ctx = Context(local_rank, torch.cuda.current_stream(dev).cuda_stream)
+        self.side = torch.cuda.Stream(device=dev) if two_streams else None
+        self.ctx_au = ctx_au = Context(local_rank, self.side.cuda_stream) if two_streams else ctx
+        self.adc_host = adc_block(n, 0x5EED0004)                      # every GPU sees the SAME stream (configs[3])
+        self.adc = torch.from_numpy(self.adc_host).to(dev)
+        self.chans = list(range(NR))
 
-    wf_stride = n + 1
-    wf_iq = torch.zeros((NR, wf_stride, 2), dtype=torch.int16, device=dev)
-    frames = torch.zeros((NR, 8192, 2), dtype=torch.int16, device=dev)
-    rows = torch.zeros((NR, 1024), dtype=torch.uint8, device=dev)
-    pkts = torch.zeros((NR, wire.WF_PKT_MAX), dtype=torch.uint8, device=dev)
-    raw = torch.zeros((NR, nrec_max * 6), dtype=torch.uint8, device=dev)
-    xin = torch.zeros((NR, nrec_max, 2), dtype=torch.float32, device=dev)
-    firo = torch.zeros((NR, 1024, 2), dtype=torch.float32, device=dev)
-    s16 = torch.zeros((NR, 512), dtype=torch.int16, device=dev)
-    pay = torch.zeros((NR, 256), dtype=torch.uint8, device=dev)
-    infos = [(int(params[ch].start), params[ch].zoom, 0, True) for ch in range(NR)]
-    counts = {"frames": 0, "audio_blocks": 0}
-    torch.cuda.synchronize(dev)                              # buffers exist before the side stream touches them
+        self.d = d = Ddc(ctx, nchan=NR, max_samples=n)
+        self.W = W = Waterfall(ctx, nchan=NR)
+        W.set_tables()
+        hz_per_start = self.UI_SRATE / (1024 << 14)
+        self.params = []
+        for ch in range(NR):
+            k = first_rx + ch
+            z = 1 + k % 10
+            p = WfParams.for_zoom(z, (1.0e6 + 0.2e6 * (k % 97)) / hz_per_start, adc_clock=self.ADC_CLOCK, ui_srate=self.UI_SRATE)
+            self.params.append(p)
+            d.set_wf(ch, p.i_offset, p.decim)
+            W.set_channel(ch, p, interp=wf.WF_MAX, window_func=wf.WINF_HANNING, cic_comp=True)
+        self.rx = RxDdc(ctx_au, nchan=NR, max_samples=n)
+        self.nrec_max = nrec_max = n // RX_DECIM + 2
+        self.fir = FastFir(ctx_au, nchan=NR, max_in=nrec_max)
+        self.P = Post(ctx_au, nchan=NR)
+        self.A = Adpcm(ctx_au, nchan=NR)
+        self.fs = fs = self.ADC_CLOCK / RX_DECIM
+        self.rx_inc = []
+        for ch in range(NR):
+            self.rx_inc.append(rx_phase_inc(0.0123 * self.ADC_CLOCK - 1000.0 - 10.0 * (first_rx + ch), self.ADC_CLOCK))
+            self.rx.set_freq(ch, self.rx_inc[ch])
+            self.fir.setup(ch, 300.0, 2700.0, 0.0, fs)
+            self.P.set_agc(ch, True, False, -100, 50, 6, 1000, fs)
+            self.P.set_smeter(ch, fs); self.P.set_mode(ch, post.MODE_SSB); self.P.reset(ch)
 
-    def audio():
-        nr = rx.push_dev(adc.data_ptr(), n, chans, raw.data_ptr(), nrec_max)
+        self.wf_stride = n + 1
+        self.wf_iq = torch.zeros((NR, self.wf_stride, 2), dtype=torch.int16, device=dev)
+        self.frames = torch.zeros((NR, 8192, 2), dtype=torch.int16, device=dev)
+        self.rows = torch.zeros((NR, 1024), dtype=torch.uint8, device=dev)
+        self.pkts = torch.zeros((NR, wire.WF_PKT_MAX), dtype=torch.uint8, device=dev)
+        self.raw = torch.zeros((NR, nrec_max * 6), dtype=torch.uint8, device=dev)
+        self.xin = torch.zeros((NR, nrec_max, 2), dtype=torch.float32, device=dev)
+        self.firo = torch.zeros((NR, 1024, 2), dtype=torch.float32, device=dev)
+        self.s16 = torch.zeros((NR, 512), dtype=torch.int16, device=dev)
+        self.pay = torch.zeros((NR, 256), dtype=torch.uint8, device=dev)
+        self.infos = [(int(self.params[ch].start), self.params[ch].zoom, 0, True) for ch in range(NR)]
+        self.counts = {"frames": 0, "audio_blocks": 0}
+        self.last = {}                                                # what the last step produced (counts per stage)
+        torch.cuda.synchronize(dev)                                   # buffers exist before the side stream touches them
+
+    def audio(self):
+        from flydog_sdr_gps_amd import snd
+        NR, chans, nrec_max = self.NR, self.chans, self.nrec_max
+        nr = self.rx.push_dev(self.adc.data_ptr(), self.n, chans, self.raw.data_ptr(), nrec_max)
         nrec = int(nr.min())
         assert nrec == int(nr.max())
-        snd.unpack_rows_dev(ctx_au, raw.data_ptr(), nrec_max, nrec, NR, xin.data_ptr(), nrec_max)
-        nout = fir.process_dev(chans, xin.data_ptr(), nrec_max, nrec, firo.data_ptr(), 1024)
+        snd.unpack_rows_dev(self.ctx_au, self.raw.data_ptr(), nrec_max, nrec, NR, self.xin.data_ptr(), nrec_max)
+        nout = self.fir.process_dev(chans, self.xin.data_ptr(), nrec_max, nrec, self.firo.data_ptr(), 1024)
+        self.last.update(nrec=nrec, nout=int(nout[0]))
+        assert int(nout.min()) == int(nout.max())
         if int(nout[0]) == 512:
-            P.process_dev(chans, firo.data_ptr(), 1024, 512, s16.data_ptr(), 0, 0, 512)
-            A.encode_dev(chans, s16.data_ptr(), 512, 512, pay.data_ptr(), 256)
-            counts["audio_blocks"] += NR
+            self.P.process_dev(chans, self.firo.data_ptr(), 1024, 512, self.s16.data_ptr(), 0, 0, 512)
+            self.A.encode_dev(chans, self.s16.data_ptr(), 512, 512, self.pay.data_ptr(), 256)
+            self.counts["audio_blocks"] += NR
 
-    def step():
-        audio()                                              # only enqueues, on the side stream
-        nw = d.push_dev(adc.data_ptr(), n, chans, wf_iq.data_ptr(), wf_stride)
+    def step(self):
+        from flydog_sdr_gps_amd import wire
+        self.audio()                                         # only enqueues, on the side stream
+        nw = self.d.push_dev(self.adc.data_ptr(), self.n, self.chans, self.wf_iq.data_ptr(), self.wf_stride)
         assert int(nw.min()) >= 8192
-        frames.copy_(wf_iq[:, :8192])                       # the frame each receiver's waterfall takes this step
-        W.frames_dev(chans, frames.data_ptr(), rows.data_ptr())
-        wire.wf_packets_dev(ctx, rows.data_ptr(), 1024, infos, pkts.data_ptr())
-        counts["frames"] += NR
+        self.last["nw"] = nw
+        self.frames.copy_(self.wf_iq[:, :8192])             # the frame each receiver's waterfall takes this step
+        self.W.frames_dev(self.chans, self.frames.data_ptr(), self.rows.data_ptr())
+        wire.wf_packets_dev(self.ctx, self.rows.data_ptr(), 1024, self.infos, self.pkts.data_ptr())
+        self.counts["frames"] += self.NR
+
+    def close(self):
+        for o in (self.d, self.W, self.rx, self.fir, self.P, self.A):
+            o.close()
+
+
+def run_receivers(args, dist):
+    """BASELINE configs[3]: a ReceiverBank per GPU (weak scaling over ranks)."""
+    import torch
+    dev = dist.dev
+    two = os.environ.get("KIWIGPU_BENCH_ONE_STREAM") != "1"
+    NR, n = args.receivers, 1 << args.log2n
+    adc_clock = ReceiverBank.ADC_CLOCK
+    bank = ReceiverBank(dist.local_rank, dev, NR, n, dist.rank * NR, two)   # this rank's slice of the receiver set
+    step, counts, rows, pay = bank.step, bank.counts, bank.rows, bank.pay
 
     for _ in range(args.warmup):
         step()

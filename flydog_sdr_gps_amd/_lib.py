@@ -149,6 +149,21 @@ SYMBOLS = {
 }
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels carry their own libamdhip64 / libhsa-runtime64.  Two HIP runtimes in one
+    process cannot both own the GPU: whichever initialises second reports "No HIP GPUs are
+    available" (measured on the MI355X box: libkiwigpu.so first, then torch.zeros(device="cuda")
+    fails; torch first, both work, because libkiwigpu.so's NEEDED libamdhip64 then resolves to the
+    copy torch has mapped).  So when torch is installed it is imported BEFORE libkiwigpu.so is
+    opened.  A host without torch uses the system runtime; KIWIGPU_NO_TORCH_PRELOAD=1 skips this."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("KIWIGPU_NO_TORCH_PRELOAD") == "1":
+        return
+    import importlib.util
+    if importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401
+
+
 def load_library():
     """dlopen libkiwigpu.so and bind every declared symbol.  No fallback."""
     global _LIB
@@ -160,6 +175,7 @@ def load_library():
                            "%s is not built (run `python -c 'import __graft_entry__ as g; "
                            "g.build()'` or `make -C flydog_sdr_gps_amd/csrc`); there is no "
                            "CPU fallback" % path)
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
