@@ -194,11 +194,75 @@ def cpu_threads(one_unit, budget_s):
     return sum(done), time.perf_counter() - t0, cores, t1
 
 
+LIVE_TRAFFIC = {}            # workload -> (bytes per launch, source), filled by live_traffic_passes()
+TRAFFIC_KERNELS = {"acq": ("acq_correlate_kernel<4, 1,",), "acq59": ("acq_correlate_kernel<4, 1,", "acq_correlate_kernel<4, 4,"),
+                   "acq10ms": ("acq_correlate_kernel<16, 1,", "acq_correlate_kernel<16, 4,"), "wf14": ("wf_frame_kernel",)}
+
+
+def under_profiler():
+    return any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+
+
+def live_traffic_passes(args):
+    """HBM bytes per launch of each workload's dominant kernel(s), measured NOW: before this process
+    touches the GPU it runs this same file as a child under `rocprofv3 --pmc` -- one pass for
+    FETCH_SIZE, one for WRITE_SIZE (separate passes, nothing but the counter: MI355X_MICROARCH.md's
+    HBM section) -- on the same per-launch configuration, a few steps each.  bytes = (2 x FETCH_SIZE
+    + WRITE_SIZE) KB: gfx950 tallies its 128-byte read requests as 64.  Any failure (no rocprofv3,
+    already under a profiler, a pass timing out) leaves LIVE_TRAFFIC without the entry and the line
+    falls back to the committed figure, saying so."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if shutil.which("rocprofv3") is None or under_profiler():
+        return
+    wls = ["acq", "wf14"] if args.workload == "all" else [args.workload]
+    for wl in wls:
+        keys = TRAFFIC_KERNELS.get(wl)
+        if keys is None:
+            continue
+        child = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", "4", "--warmup", "1",
+                 "--no-cpu", "--no-live-traffic", "--frames", str(args.frames)]
+        if args.blocks is not None:
+            child += ["--blocks", str(args.blocks)]
+        mean = {}
+        tmp = tempfile.mkdtemp(prefix="kiwigpu_pmc_")
+        try:
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                d = os.path.join(tmp, counter)
+                cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child
+                env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+                r = subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+                if r.returncode != 0:
+                    raise RuntimeError("pass failed")
+                per = {k: [] for k in keys}
+                for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                    with open(f) as fh:
+                        for row in csv.DictReader(fh):
+                            if row["Counter_Name"] != counter:
+                                continue
+                            for k in keys:
+                                if k in row["Kernel_Name"]:
+                                    per[k].append(float(row["Counter_Value"]))
+                if any(not v for v in per.values()):
+                    raise RuntimeError("kernel not seen")
+                mean[counter] = sum(sum(v) / len(v) for v in per.values())       # KB per launch, all parts
+            LIVE_TRAFFIC[wl] = (int((2 * mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024),
+                                "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run "
+                                "(2 x %.1f KB + %.1f KB per launch)" % (mean["FETCH_SIZE"], mean["WRITE_SIZE"]))
+        except Exception as e:                                    # noqa: BLE001 -- fall back, and say so
+            sys.stderr.write("bench.py: live PMC pass for %s not available (%s)\n" % (wl, e))
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+
+
 def measured_traffic(workload, units):
-    """HBM bytes per launch of the workload's dominant kernel from the committed PMC passes
-    (profiles/hbm_traffic.json, written from tools/prof.sh output: 2 x FETCH_SIZE + WRITE_SIZE,
-    separate --pmc runs of this same command, as MI355X_MICROARCH.md's HBM section prescribes).
-    A bench run cannot read counters itself: -> (bytes or None, where the number comes from)."""
+    """HBM bytes per launch of the workload's dominant kernel: the live PMC child passes of this
+    run (live_traffic_passes) when they ran, else the committed passes (profiles/hbm_traffic.json,
+    written from tools/prof.sh output the same way).  -> (bytes or None, where the number comes from)"""
+    if workload in LIVE_TRAFFIC:
+        return LIVE_TRAFFIC[workload]
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         with open(path) as f:
@@ -745,6 +809,8 @@ def main():
     ap.add_argument("--receivers", type=int, default=128, help="receivers: virtual receivers per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="skip the rocprofv3 --pmc child passes; roofline.traffic then comes from profiles/hbm_traffic.json")
     args = ap.parse_args()
     if args.log2n is None:
         args.log2n = 22 if args.workload == "receivers" else 24
@@ -757,6 +823,8 @@ def main():
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%s\n" % (args.gpus, world_env))
         sys.exit(2)
 
+    if world_env is None and args.gpus == 1 and not args.no_live_traffic:
+        live_traffic_passes(args)                            # children; this process has not touched the GPU yet
     dist = Dist("gloo" if args.workload == "stub" else "nccl")
     common = {"n_gpus": dist.world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
               "scaling": "weak", "vs_baseline": None, "data": "synthetic"}
