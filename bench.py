@@ -233,9 +233,16 @@ def live_traffic_passes(args):
                 d = os.path.join(tmp, counter)
                 cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child
                 env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
-                r = subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
-                if r.returncode != 0:
-                    raise RuntimeError("pass failed")
+                p = subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                     start_new_session=True)     # its own process group: a stuck pass is ended whole
+                try:
+                    rc = p.wait(timeout=240)
+                except subprocess.TimeoutExpired:
+                    os.killpg(p.pid, 9)
+                    p.wait()
+                    raise RuntimeError("pass timed out")
+                if rc != 0:
+                    raise RuntimeError("pass failed, status %d" % rc)
                 per = {k: [] for k in keys}
                 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                     with open(f) as fh:
