@@ -60,6 +60,14 @@ struct kg_ctx {
 // Tables larger than a slot take the synchronous scratch buffer.
 int kg_ctx_stage(kg_ctx *ctx, const void *src, size_t bytes, void **d_out);
 
+// The same for a table that is usually the SAME from call to call (a channel list, the frame ->
+// channel map of a batch): the owner keeps a kg_stage_cache; an unchanged table (memcmp with the
+// host copy) costs no transfer at all, a changed one goes through the ring and, in stream order, into
+// the cache's own device buffer (kernels still reading the old contents were enqueued before it).
+struct kg_stage_cache { unsigned char *host; void *dev; size_t cap, bytes; };
+int kg_ctx_stage_cached(kg_ctx *ctx, kg_stage_cache *sc, const void *src, size_t bytes, void **d_out);
+void kg_stage_cache_free(kg_stage_cache *sc);       // the caller has drained the stream
+
 // Device scratch of at least `bytes`, filled from `src` before returning (synchronous: the
 // previous user of the scratch is drained first).  Valid until the next call on this context.
 int kg_ctx_scratch_upload(kg_ctx *ctx, const void *src, size_t bytes, void **d_out);

@@ -55,6 +55,39 @@ int kg_ctx_stage(kg_ctx *c, const void *src, size_t bytes, void **d_out)
     return KG_OK;
 }
 
+int kg_ctx_stage_cached(kg_ctx *c, kg_stage_cache *sc, const void *src, size_t bytes, void **d_out)
+{
+    KG_REQUIRE(c && sc && src && d_out && bytes > 0, KG_ERR_INVALID, "kg_ctx_stage_cached: bad argument");
+    if (sc->dev && sc->bytes == bytes && memcmp(sc->host, src, bytes) == 0) { *d_out = sc->dev; return KG_OK; }
+    if (bytes > sc->cap) {                      // grows rarely: drain, then replace both copies
+        KG_HIP(hipStreamSynchronize(c->stream));
+        if (sc->dev) KG_HIP(hipFree(sc->dev));
+        free(sc->host);
+        sc->dev = nullptr; sc->host = nullptr; sc->cap = sc->bytes = 0;
+        const size_t cap = bytes < 4096 ? 4096 : bytes + bytes / 2;
+        sc->host = (unsigned char *) malloc(cap);
+        KG_REQUIRE(sc->host != nullptr, KG_ERR_NOMEM, "kg_ctx_stage_cached: %zu host bytes", cap);
+        KG_HIP(hipMalloc(&sc->dev, cap));
+        sc->cap = cap;
+    }
+    void *d = nullptr;
+    const int rc = kg_ctx_stage(c, src, bytes, &d);
+    if (rc) { sc->bytes = 0; return rc; }
+    KG_HIP(hipMemcpyAsync(sc->dev, d, bytes, hipMemcpyDeviceToDevice, c->stream));
+    memcpy(sc->host, src, bytes);
+    sc->bytes = bytes;
+    *d_out = d;                                 // this call reads the ring copy; later calls the cache
+    return KG_OK;
+}
+
+void kg_stage_cache_free(kg_stage_cache *sc)
+{
+    if (!sc) return;
+    if (sc->dev) (void) hipFree(sc->dev);
+    free(sc->host);
+    sc->dev = nullptr; sc->host = nullptr; sc->cap = sc->bytes = 0;
+}
+
 extern "C" {
 
 const char *kg_last_error(void) { return g_err; }

@@ -35,6 +35,10 @@ typedef float cf __attribute__((ext_vector_type(2)));   // (re, im) = float2 = f
 KG_DEV cf kg_scale(cf a, float s) { return a * cf{s, s}; }
 KG_DEV cf kg_ld(const float2 *p) { return *reinterpret_cast<const cf *>(p); }
 KG_DEV void kg_st(float2 *p, cf v) { *reinterpret_cast<cf *>(p) = v; }
+// LDS tile read: one ds_read_b64 per element.  Left alone, hipcc pairs two of them into a
+// ds_read2st64_b64, which occupies the LDS for 8 cycles against 2 + 2 (MI355X_MICROARCH.md, LDS table);
+// the volatile LDS-address-space access keeps them apart (-1.6 % correlator, -1.8 % waterfall frames).
+KG_DEV cf kg_ld_tile(const float2 *p) { return *(const volatile cf __attribute__((address_space(3))) *) p; }
 
 // a * w = (a.x w.x - a.y w.y, a.y w.x + a.x w.y)
 KG_DEV cf kg_cmul(cf a, cf w)
@@ -316,7 +320,7 @@ KG_DEV void kg_subfft4096_a(cf (&x)[16], cf (&y)[16], float2 *tileA, float2 *til
     __syncthreads();
     KG_STAMP(STAMPS, st, 2);
 #pragma unroll
-    for (int j = 0; j < 16; j++) x[j] = kg_ld(&tileA[rd + 256 * j]);
+    for (int j = 0; j < 16; j++) x[j] = kg_ld_tile(&tileA[rd + 256 * j]);
     if (STAMPS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     KG_STAMP(STAMPS, st, 3);
     // pass 1: twiddle W256^(j*(t&15)), out index (t>>4)*256 + (t&15) + 16 m
@@ -336,7 +340,7 @@ KG_DEV void kg_subfft4096_b(cf (&x)[16], cf (&y)[16], const float2 *tileB,
 {
     const int rd = t ^ ((t >> 4) & 15);
 #pragma unroll
-    for (int j = 0; j < 16; j++) x[j] = kg_ld(&tileB[rd + 256 * j]);
+    for (int j = 0; j < 16; j++) x[j] = kg_ld_tile(&tileB[rd + 256 * j]);
     if (STAMPS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     KG_STAMP(STAMPS, st, 6);
     // pass 2: twiddle W4096^(j*t), out index t + 256 m (kept in registers)
@@ -364,7 +368,7 @@ KG_DEV void kg_subfft4096_a_spread(cf (&x)[16], cf (&y)[16], float2 *tileA, floa
     });
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 16; j++) x[j] = kg_ld(&tileA[rd + 256 * j]);
+    for (int j = 0; j < 16; j++) x[j] = kg_ld_tile(&tileA[rd + 256 * j]);
     kg_twiddle16<SIGN>(x, tw.p1);
     kg_radix16_h<SIGN>(x, y, [&](int s) {
         if (s >= 4) {

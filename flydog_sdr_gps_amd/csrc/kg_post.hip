@@ -243,6 +243,7 @@ struct kg_post {
     float *d_ring_mag;
     std::vector<post_chan> h_chan;       // parameters only; the state lives on the device
     std::vector<post_host> h_args;
+    kg_stage_cache list_cache = {};      // the channel list of the last process call
 };
 
 static int post_check(kg_post *p, int ch, const char *who)
@@ -315,6 +316,7 @@ void kg_post_destroy(kg_post *p)
     (void) hipSetDevice(p->ctx->device);
     (void) hipStreamSynchronize(p->ctx->stream);
     (void) hipFree(p->d_chan); (void) hipFree(p->d_ring_in); (void) hipFree(p->d_ring_mag);
+    kg_stage_cache_free(&p->list_cache);
     delete p;
 }
 
@@ -431,7 +433,7 @@ int kg_post_process_dev(kg_post *p, const int32_t *chans, int nch, const void *d
     }
     hipStream_t st = p->ctx->stream;
     void *d_list = nullptr;
-    if ((rc = kg_ctx_stage(p->ctx, chans, sizeof(int) * nch, &d_list))) return rc;
+    if ((rc = kg_ctx_stage_cached(p->ctx, &p->list_cache, chans, sizeof(int) * nch, &d_list))) return rc;
     hipLaunchKernelGGL(post_kernel, dim3(nch), dim3(64), 0, st, p->d_chan, p->d_ring_in, p->d_ring_mag,
                        (const int *) d_list, (const float2 *) d_fir, in_stride, nsamps,
                        (short *) d_s16, (float *) d_demod, (float2 *) d_agc, out_stride);

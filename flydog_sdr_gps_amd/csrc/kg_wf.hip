@@ -261,6 +261,7 @@ struct kg_wf {
     wf_chan_dev *d_chans;
     float *d_windows, *d_cic;
     short2 *d_iq;    unsigned char *d_out;  int stage_cap;      // staging for host-buffer calls
+    kg_stage_cache chan_of_cache;          // the frame -> channel map of the last batch (usually unchanged)
     float *d_tap_pwr, *d_tap_pwr_out, *d_tap_db;
     int *d_claim;                             // wf_frame_kernel's two counters, zero between launches
     std::vector<char> chan_set;
@@ -308,6 +309,7 @@ void kg_wf_destroy(kg_wf *w)
     (void) hipFree(w->d_chans); (void) hipFree(w->d_windows); (void) hipFree(w->d_cic); (void) hipFree(w->d_claim);
     (void) hipFree(w->d_iq); (void) hipFree(w->d_out);
     (void) hipFree(w->d_tap_pwr); (void) hipFree(w->d_tap_pwr_out); (void) hipFree(w->d_tap_db);
+    kg_stage_cache_free(&w->chan_of_cache);
     delete w;
 }
 
@@ -392,7 +394,7 @@ static int wf_launch(kg_wf *w, int nframes, const int32_t *chan_of, const void *
     hipStream_t st = w->ctx->stream;
     void *d_chan_of = nullptr;                 // chan_of is the caller's: staged copy, no stream synchronisation
     {
-        int rc = kg_ctx_stage(w->ctx, chan_of, sizeof(int) * nframes, &d_chan_of);
+        int rc = kg_ctx_stage_cached(w->ctx, &w->chan_of_cache, chan_of, sizeof(int) * nframes, &d_chan_of);
         if (rc) return rc;
     }
     const int grid = nframes < w->grid ? nframes : w->grid;

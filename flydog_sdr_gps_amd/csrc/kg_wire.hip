@@ -139,6 +139,7 @@ struct kg_adpcm {
     kg_ctx *ctx;
     int nchan;
     adpcm_state *d_state;
+    kg_stage_cache list_cache;           // the channel list of the last encode call
 };
 
 extern "C" {
@@ -165,6 +166,7 @@ void kg_adpcm_destroy(kg_adpcm *a)
     (void) hipSetDevice(a->ctx->device);
     (void) hipStreamSynchronize(a->ctx->stream);
     (void) hipFree(a->d_state);
+    kg_stage_cache_free(&a->list_cache);
     delete a;
 }
 
@@ -214,7 +216,7 @@ int kg_adpcm_encode_dev(kg_adpcm *a, const int32_t *chans, int nch, const void *
     }
     hipStream_t st = a->ctx->stream;
     void *d_list = nullptr;
-    if ((rc = kg_ctx_stage(a->ctx, chans, sizeof(int) * nch, &d_list))) return rc;
+    if ((rc = kg_ctx_stage_cached(a->ctx, &a->list_cache, chans, sizeof(int) * nch, &d_list))) return rc;
     hipLaunchKernelGGL(adpcm_snd_kernel, dim3((nch + 63) / 64), dim3(64), 0, st, a->d_state, (const int *) d_list,
                        nch, (const short *) d_s16, in_stride, nsamps, (unsigned char *) d_out, out_stride);
     KG_HIP(hipGetLastError());

@@ -133,6 +133,32 @@ def test_batch_of_channels_matches_oracle(gpu_ctx, oracle, mode):
         P.close()
 
 
+def test_channel_list_changing_between_calls(gpu_ctx, oracle):
+    """The channel list of a process call is kept on the device while it does not change; every call
+    must still use its own list (same, permuted, shorter, longer, first again), each channel's AGC
+    state carried through the calls that include it."""
+    rng = np.random.default_rng(31)
+    nch, n = 7, 256
+    sig = signals(16 * n, rng)[0]
+    P = Post(gpu_ctx, nchan=nch)
+    agcs = [oracle.Agc() for _ in range(nch)]
+    pos = [0] * nch
+    try:
+        for ch in range(nch):
+            P.set_agc(ch, *PARAMS[ch % len(PARAMS)])
+            agcs[ch].set_parameters(*PARAMS[ch % len(PARAMS)])
+            P.set_smeter(ch, PARAMS[0][6]); P.set_mode(ch, post.MODE_SSB); P.reset(ch)
+        lists = [[0, 1, 2], [0, 1, 2], [2, 1, 0], [4, 3], list(range(nch)), [0, 1, 2], [6]]
+        for k, chans in enumerate(lists):
+            x = np.stack([sig[pos[ch]:pos[ch] + n] * np.float32(1 + ch) for ch in chans])
+            s16 = P.process(np.asarray(chans, np.int32), x)[0]
+            for r, ch in enumerate(chans):
+                check_s16(s16[r], agcs[ch].process_s16(x[r]))
+                pos[ch] += n
+    finally:
+        P.close()
+
+
 @pytest.mark.parametrize("n", [1, 2, 63, 171, 512, 1000, 1024])
 def test_block_lengths_and_continuity(gpu_ctx, oracle, n):
     """Any call length gives the same stream as the oracle fed the same pieces, including calls

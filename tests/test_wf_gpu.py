@@ -176,6 +176,32 @@ def test_batch_of_frames_over_mixed_channels(engine, oracle, tables):
         check_row(out[k], w_out, w_dB, db_bound(w_po))
 
 
+def test_channel_map_changing_between_calls(engine, oracle, tables):
+    """The frame -> channel map of a batch is kept on the device while it does not change
+    (kg_stage_cache): same map again, a permuted one of the same length, a longer one, the first one
+    again -- every call must use ITS map."""
+    zooms = [0, 3, 7, 10]
+    ps = []
+    for ch, z in enumerate(zooms):
+        p = WfParams.for_zoom(z, 1.0e6 * ch)
+        ps.append(p)
+        engine.set_channel(ch, p, interp=wf.WF_MAX, window_func=wf.WINF_HANNING, cic_comp=True)
+    iqs = [synth.wf_iq_frame(seed=500 + i) for i in range(12)]
+    want = {}
+
+    def ref(ch, i):
+        if (ch, i) not in want:
+            want[(ch, i)] = oracle_frame(oracle, tables, iqs[i], ps[ch], wf.WF_MAX, wf.WINF_HANNING, True, False, False)
+        return want[(ch, i)]
+
+    maps = [[0, 1, 2, 3], [0, 1, 2, 3], [3, 2, 1, 0], [1, 1, 0, 2], list(range(4)) * 3, [0, 1, 2, 3], [2]]
+    for m in maps:
+        out = engine.frames(m, np.stack(iqs[:len(m)]))
+        for k, ch in enumerate(m):
+            w_out, _, w_po, w_dB = ref(ch, k)
+            check_row(out[k], w_out, w_dB, db_bound(w_po))
+
+
 def test_wf_error_paths(gpu_ctx, tables):
     from flydog_sdr_gps_amd import KiwiGpuError
     w = Waterfall(gpu_ctx, nchan=2)

@@ -45,6 +45,28 @@ def test_sound_adpcm_many_channels_bit_exact(gpu_ctx, oracle):
         A.close()
 
 
+def test_sound_adpcm_channel_list_changing_between_calls(gpu_ctx, oracle):
+    """The channel list of an encode call is kept on the device while it does not change; every
+    call must still use its own list: same, permuted, shorter, longer, first again."""
+    rng = np.random.default_rng(22)
+    nch, n = 9, 256
+    A = Adpcm(gpu_ctx, nchan=nch)
+    st = [None] * nch
+    try:
+        lists = [[0, 1, 2, 3], [0, 1, 2, 3], [3, 2, 1, 0], [5, 4], list(range(nch)), [0, 1, 2, 3], [8]]
+        for k, chans in enumerate(lists):
+            x = np.stack([audio(n, rng, (ch + k) % 5) for ch in chans])
+            got = A.encode(np.asarray(chans, np.int32), x)
+            for r, ch in enumerate(chans):
+                want, st[ch] = oracle.adpcm_encode_i16(x[r], st[ch])
+                assert np.array_equal(got[r], want), (k, ch)
+        for ch in range(nch):
+            want = (st[ch].index, st[ch].previous) if st[ch] is not None else (0, 0)
+            assert A.get_state(ch) == want
+    finally:
+        A.close()
+
+
 @pytest.mark.parametrize("n", [2, 6, 170, 512, 2048])
 def test_sound_adpcm_lengths_and_state(gpu_ctx, oracle, n):
     rng = np.random.default_rng(n)
