@@ -325,6 +325,16 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
         c[2 * i] = cf{__uint_as_float(cv[0]), __uint_as_float(cv[1])};
         c[2 * i + 1] = cf{__uint_as_float(cv[2]), __uint_as_float(cv[3])};
     };
+    auto fetch_drow = [&](const acq_rsrc &r, int i) {
+        const u4 dv = __builtin_amdgcn_raw_buffer_load_b128(r.drs, r.dvo, i * 4096, 0);
+        d[2 * i] = cf{__uint_as_float(dv[0]), __uint_as_float(dv[1])};
+        d[2 * i + 1] = cf{__uint_as_float(dv[2]), __uint_as_float(dv[3])};
+    };
+    auto fetch_crow = [&](const acq_rsrc &r, int i) {
+        const u4 cv = __builtin_amdgcn_raw_buffer_load_b128(r.crs, r.cvo, i * rowb_c, 0);
+        c[2 * i] = cf{__uint_as_float(cv[0]), __uint_as_float(cv[1])};
+        c[2 * i + 1] = cf{__uint_as_float(cv[2]), __uint_as_float(cv[3])};
+    };
     auto fetch = [&](int data_off, int code_off, int dop, int k2) {
         const acq_rsrc r = fetch_prepare(data_off, code_off, dop, k2);
 #pragma unroll
@@ -351,6 +361,110 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
         int claimed = 0;
         if (t == 0) claimed = 2 * nslots + __hip_atomic_fetch_add(&claim[xcd], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         cf acc[NQ][16];
+        // The twiddle-accumulate of item k2 is DEFERRED into item k2+1's exchanges, where a wave otherwise
+        // only waits (slots: behind the stores before a barrier, or after it while the tile reads are in
+        // flight).  yprev holds the deferred item's transform; for NQ == 1 (256 registers, two workgroups per
+        // CU) the code rows of the next item are fetched during pass 2 to make room, the data rows keep their
+        // place in the conjugate product and pass 0.  NQ == 4 runs one workgroup per CU -- nothing else
+        // fills its waits; slots {0,0,1,1} measured best for it (<4,4> 1.67 -> 1.53 ms on the acq59 workload).
+        cf yprev[16], pbase = cf{0.f, 0.f}, pg[3], pG[3], pQ[3];
+        (void) pQ;
+        // acc[4a + b] (+)= yv[4a + b] * (bs * W_R^{4a kp}) * W_R^{b kp} for a in [a0, a1): C[4a + b] = B[a] * g[b]
+        // is formed first (wave-uniform factors), the products accumulate through fused multiply-adds
+        auto accumulate = [&](const cf (&yv)[16], int kp, cf bs, const cf (&g)[3], const cf (&G)[3],
+                              const cf (&Q)[3], int a0, int a1) {
+            (void) Q;
+            if (kp == 0) {
+#pragma unroll
+                for (int q = 0; q < NQ; q++)
+#pragma unroll
+                    for (int a = 0; a < 4; a++)
+                        if (a >= a0 && a < a1) {
+#pragma unroll
+                            for (int b4 = 0; b4 < 4; b4++) acc[q][4 * a + b4] = yv[4 * a + b4];
+                        }
+                return;
+            }
+            // B[a] = bs * W_R^{4a kp}: the three products in one block (kg_fft.h, batched products)
+            cf B1 = bs, B2 = bs, B3 = bs;
+            {
+                cf r1, r2, r3;
+                asm(KG_MUL_("%3", "%0", "%6") KG_MUL_("%4", "%1", "%7") KG_MUL_("%5", "%2", "%8")
+                    KG_FMA_("%0", "%6", "%3", "neg_lo:[0,1,0]") KG_FMA_("%1", "%7", "%4", "neg_lo:[0,1,0]")
+                    KG_FMA_("%2", "%8", "%5", "neg_lo:[0,1,0]")
+                    : "+v"(B1), "+v"(B2), "+v"(B3), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                    : "s"(G[0]), "s"(G[1]), "s"(G[2]));
+            }
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                if (a < a0 || a >= a1) continue;
+                const cf Ba = a == 0 ? bs : (a == 1 ? B1 : (a == 2 ? B2 : B3));
+                cf C1 = Ba, C2 = Ba, C3 = Ba, C0 = Ba;
+                {
+                    cf r1, r2, r3;
+                    asm(KG_MUL_("%3", "%0", "%6") KG_MUL_("%4", "%1", "%7") KG_MUL_("%5", "%2", "%8")
+                        KG_FMA_("%0", "%6", "%3", "neg_lo:[0,1,0]") KG_FMA_("%1", "%7", "%4", "neg_lo:[0,1,0]")
+                        KG_FMA_("%2", "%8", "%5", "neg_lo:[0,1,0]")
+                        : "+v"(C1), "+v"(C2), "+v"(C3), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                        : "s"(g[0]), "s"(g[1]), "s"(g[2]));
+                }
+                if constexpr (NQ == 1) {
+                    kg_cmac4v(acc[0][4 * a], acc[0][4 * a + 1], acc[0][4 * a + 2], acc[0][4 * a + 3],
+                              yv[4 * a], yv[4 * a + 1], yv[4 * a + 2], yv[4 * a + 3], C0, C1, C2, C3);
+                } else {
+                    // four output quarters: z[m] = y[m] * C[m] once, then acc_q[m] += z[m] * W_P^(q*kp)
+                    cf z0 = yv[4 * a], z1 = yv[4 * a + 1], z2 = yv[4 * a + 2], z3 = yv[4 * a + 3];
+                    kg_cmul4v<false>(z0, z1, z2, z3, C0, C1, C2, C3);
+                    const cf z[4] = {z0, z1, z2, z3};
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const int m = 4 * a + b;
+                        acc[0][m] = acc[0][m] + z[b];
+                        if constexpr (P == 4) {            // quarters 1..3: times j^(q*kp), wave-uniform
+                            if (kp == 1) {
+                                acc[1][m] = kg_addj(acc[1][m], z[b]); acc[2][m] = acc[2][m] - z[b];
+                                acc[3][m] = kg_subj(acc[3][m], z[b]);
+                            } else if (kp == 2) {
+                                acc[1][m] = acc[1][m] - z[b]; acc[2][m] = acc[2][m] + z[b];
+                                acc[3][m] = acc[3][m] - z[b];
+                            } else {
+                                acc[1][m] = kg_subj(acc[1][m], z[b]); acc[2][m] = acc[2][m] - z[b];
+                                acc[3][m] = kg_addj(acc[3][m], z[b]);
+                            }
+                        }
+                    }
+                    if constexpr (P != 4) {                // times W_16^(q*kp), wave-uniform
+#pragma unroll
+                        for (int q = 1; q < 4; q++)
+                            kg_cmac4s(acc[q][4 * a], acc[q][4 * a + 1], acc[q][4 * a + 2], acc[q][4 * a + 3],
+                                      z0, z1, z2, z3, Q[q - 1]);
+                    }
+                }
+            }
+        };
+        // where the four quarters (a = 0..3) of the deferred accumulate go: slot 0 = behind the pass-0 stores,
+        // before barrier 1; 1 = after barrier 1, pass-1 tile reads in flight; 2 = behind the pass-1 stores,
+        // before barrier 2; 3 = after barrier 2, pass-2 tile reads in flight
+#ifndef KG_DEFER_PLACE
+#define KG_DEFER_PLACE {1, 1, 1, 1}
+#endif
+#ifndef KG_DEFER_PLACE4
+#define KG_DEFER_PLACE4 {0, 0, 1, 1}
+#endif
+        auto deferred = [&](int slot, int k2) {
+            constexpr int place1[4] = KG_DEFER_PLACE, place4[4] = KG_DEFER_PLACE4;
+            if (k2 > 0) {
+                kg_pin();
+                int a0 = 4, a1 = 0;                            // the run of quarters placed in this slot
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+                    if ((NQ == 1 ? place1[a] : place4[a]) == slot) { a0 = a < a0 ? a : a0; a1 = a + 1; }
+                if (a0 < a1) accumulate(yprev, k2 - 1, pbase, pg, pG, pQ, a0, a1);
+                kg_pin();
+            }
+        };
+        const int tl = t & 15, th = t >> 4;
+        const int rd = t ^ (th & 15);              // P(t + 256 j) = 256 j + (t ^ ((t >> 4) & 15)), kg_fft.h
         // rolled on purpose: unrolled (or with k2 a template constant) the
         // register allocator spills 80+ VGPRs
 #pragma unroll 1
@@ -379,21 +493,50 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
                 x[j] = c[j]; x[j + 1] = c[j + 1]; x[j + 2] = c[j + 2]; x[j + 3] = c[j + 3];
                 kg_cmul4v<true>(x[j], x[j + 1], x[j + 2], x[j + 3], d[j], d[j + 1], d[j + 2], d[j + 3]);
                 if (STAMPS && j == 12) KG_STAMP(STAMPS, sti, 9);
-                if (j >= 4) { kg_pin(); fetch_row(nr, j / 4 - 1); kg_pin(); }     // rows 0..2 (registers of the batch before)
+                if (j >= 4) {                                   // rows 0..2 (registers of the batch before)
+                    kg_pin();
+                    if constexpr (NQ == 1) fetch_drow(nr, j / 4 - 1); else fetch_row(nr, j / 4 - 1);
+                    kg_pin();
+                }
             }
             KG_STAMP(STAMPS, sti, 10);
-            if constexpr (STAMPS) {
-                kg_pin(); fetch_row(nr, 3); fetch_row(nr, 4); fetch_row(nr, 5); fetch_row(nr, 6); fetch_row(nr, 7); kg_pin();
-                kg_subfft4096_a<+1, STAMPS>(x, y, tileA, tileB, tw, t, sti);
-            } else {
-                // rows 3..7 between the first-stage groups of pass 0
-                kg_subfft4096_a_spread<+1>(x, y, tileA, tileB, tw, t, [&](int s) {
+            // pass 0 (no twiddles), out index 16 t + m: rows 3..7 between its first-stage groups, the LDS
+            // stores group by group as the outputs become final
+            kg_radix16_h<+1>(x, y, [&](int s) {
+                kg_pin();
+                if (s < 4) {
+                    if constexpr (NQ == 1) { fetch_drow(nr, 3 + s); if (s == 3) fetch_drow(nr, 7); }
+                    else { fetch_row(nr, 3 + s); if (s == 3) fetch_row(nr, 7); }
+                } else {
+#pragma unroll
+                    for (int m = s - 4; m < 16; m += 4) kg_st(&tileA[16 * t + (m ^ tl)], y[m]);
+                }
+                kg_pin();
+            });
+            KG_STAMP(STAMPS, sti, 0);
+            deferred(0, k2);
+            KG_STAMP(STAMPS, sti, 1);
+            __syncthreads();
+            KG_STAMP(STAMPS, sti, 2);
+#pragma unroll
+            for (int j = 0; j < 16; j++) x[j] = kg_ld_tile(&tileA[rd + 256 * j]);
+            deferred(1, k2);
+            if (STAMPS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            KG_STAMP(STAMPS, sti, 3);
+            // pass 1: twiddle W256^(j*(t&15)), out index (t>>4)*256 + (t&15) + 16 m
+            kg_twiddle16<+1>(x, tw.p1);
+            kg_radix16_h<+1>(x, y, [&](int s) {
+                if (s >= 4) {
                     kg_pin();
-                    fetch_row(nr, 3 + s);
-                    if (s == 3) fetch_row(nr, 7);
+#pragma unroll
+                    for (int m = s - 4; m < 16; m += 4) kg_st(&tileB[th * 256 + 16 * m + (tl ^ m)], y[m]);
                     kg_pin();
-                });
-            }
+                }
+            });
+            KG_STAMP(STAMPS, sti, 4);
+            deferred(2, k2);
+            __syncthreads();
+            KG_STAMP(STAMPS, sti, 5);
             // wave-uniform constants (s_load), hidden behind pass 2
             cf g[3], G[3], Q[3];
             (void) Q;
@@ -403,81 +546,31 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
 #pragma unroll
                 for (int q = 1; q < 4; q++) Q[q - 1] = kg_ld(&quart[4 * k2 + q]);
             }
-            kg_subfft4096_b<+1, STAMPS>(x, y, tileB, tw, t, sti);
-            // acc_q[n'] += y[n'] * W_N^{n'*k2} * W_P^{q*k2},  n' = t + 256 m, m = 4a + b:
-            // W_N^{n'*k2} = (W_N^{t*k2} * W_R^{4a*k2}) * W_R^{b*k2}
-            if (k2 == 0) {
 #pragma unroll
-                for (int q = 0; q < NQ; q++)
-#pragma unroll
-                    for (int m = 0; m < 16; m++) acc[q][m] = y[m];
-            } else {
-                cf B[4];
-                B[0] = base;
-#pragma unroll
-                for (int a = 1; a < 4; a++) B[a] = kg_cmul_s(base, G[a - 1]);
+            for (int j = 0; j < 16; j++) x[j] = kg_ld_tile(&tileB[rd + 256 * j]);
+            deferred(3, k2);
+            if (STAMPS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            KG_STAMP(STAMPS, sti, 6);
+            // pass 2: twiddle W4096^(j*t), out index t + 256 m (kept in registers)
+            kg_twiddle16<+1>(x, tw.p2);
+            // (NQ == 1: the next item's code rows, two per first-stage group)
+            kg_radix16_h<+1>(x, yprev, [&](int s) {
                 if constexpr (NQ == 1) {
-                    // acc[m] += y[m] * C[m], C[4a + b] = B[a] * g[b]: the twiddles are combined first
-                    // (wave-uniform factors), the products accumulate through fused multiply-adds
-#pragma unroll
-                    for (int a = 0; a < 4; a++) {
-                        cf C1 = B[a], C2 = B[a], C3 = B[a], C0 = B[a];
-                        {
-                            cf r1, r2, r3;
-                            asm(KG_MUL_("%3", "%0", "%6") KG_MUL_("%4", "%1", "%7") KG_MUL_("%5", "%2", "%8")
-                                KG_FMA_("%0", "%6", "%3", "neg_lo:[0,1,0]") KG_FMA_("%1", "%7", "%4", "neg_lo:[0,1,0]")
-                                KG_FMA_("%2", "%8", "%5", "neg_lo:[0,1,0]")
-                                : "+v"(C1), "+v"(C2), "+v"(C3), "=&v"(r1), "=&v"(r2), "=&v"(r3)
-                                : "s"(g[0]), "s"(g[1]), "s"(g[2]));
-                        }
-                        kg_cmac4v(acc[0][4 * a], acc[0][4 * a + 1], acc[0][4 * a + 2], acc[0][4 * a + 3],
-                                  y[4 * a], y[4 * a + 1], y[4 * a + 2], y[4 * a + 3], C0, C1, C2, C3);
-                    }
-                } else {
-                    // four output quarters: z[m] = y[m] * C[m] once, then acc_q[m] += z[m] * W_P^(q*k2)
-#pragma unroll
-                    for (int a = 0; a < 4; a++) {
-                        cf C1 = B[a], C2 = B[a], C3 = B[a], C0 = B[a];
-                        {
-                            cf r1, r2, r3;
-                            asm(KG_MUL_("%3", "%0", "%6") KG_MUL_("%4", "%1", "%7") KG_MUL_("%5", "%2", "%8")
-                                KG_FMA_("%0", "%6", "%3", "neg_lo:[0,1,0]") KG_FMA_("%1", "%7", "%4", "neg_lo:[0,1,0]")
-                                KG_FMA_("%2", "%8", "%5", "neg_lo:[0,1,0]")
-                                : "+v"(C1), "+v"(C2), "+v"(C3), "=&v"(r1), "=&v"(r2), "=&v"(r3)
-                                : "s"(g[0]), "s"(g[1]), "s"(g[2]));
-                        }
-                        cf z0 = y[4 * a], z1 = y[4 * a + 1], z2 = y[4 * a + 2], z3 = y[4 * a + 3];
-                        kg_cmul4v<false>(z0, z1, z2, z3, C0, C1, C2, C3);
-                        const cf z[4] = {z0, z1, z2, z3};
-#pragma unroll
-                        for (int b = 0; b < 4; b++) {
-                            const int m = 4 * a + b;
-                            acc[0][m] = acc[0][m] + z[b];
-                            if constexpr (P == 4) {            // quarters 1..3: times j^(q*k2), wave-uniform
-                                if (k2 == 1) {
-                                    acc[1][m] = kg_addj(acc[1][m], z[b]); acc[2][m] = acc[2][m] - z[b];
-                                    acc[3][m] = kg_subj(acc[3][m], z[b]);
-                                } else if (k2 == 2) {
-                                    acc[1][m] = acc[1][m] - z[b]; acc[2][m] = acc[2][m] + z[b];
-                                    acc[3][m] = acc[3][m] - z[b];
-                                } else {
-                                    acc[1][m] = kg_subj(acc[1][m], z[b]); acc[2][m] = acc[2][m] - z[b];
-                                    acc[3][m] = kg_addj(acc[3][m], z[b]);
-                                }
-                            }
-                        }
-                        if constexpr (P != 4) {                // times W_16^(q*k2), wave-uniform
-#pragma unroll
-                            for (int q = 1; q < 4; q++)
-                                kg_cmac4s(acc[q][4 * a], acc[q][4 * a + 1], acc[q][4 * a + 2], acc[q][4 * a + 3],
-                                          z0, z1, z2, z3, Q[q - 1]);
-                        }
-                    }
+                    if (s < 4) { kg_pin(); fetch_crow(nr, 2 * s); fetch_crow(nr, 2 * s + 1); kg_pin(); }
                 }
+            });
+            pbase = base;
+#pragma unroll
+            for (int i = 0; i < 3; i++) { pg[i] = g[i]; pG[i] = G[i]; }
+            if constexpr (NQ == 4 && P != 4) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) pQ[i] = Q[i];
             }
+            KG_STAMP(STAMPS, sti, 7);
             KG_STAMP(STAMPS, sti, 11);
             if (STAMPS) st_item++;
         }
+        accumulate(yprev, P - 1, pbase, pg, pG, pQ, 0, 4);     // the cell's last item
 
         // search.cpp:486-490: power, first maximum (strict >), running total
         const int limit = cur.limit;
