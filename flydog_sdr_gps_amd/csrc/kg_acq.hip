@@ -386,28 +386,15 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
                 return;
             }
             // B[a] = bs * W_R^{4a kp}: the three products in one block (kg_fft.h, batched products)
-            cf B1 = bs, B2 = bs, B3 = bs;
-            {
-                cf r1, r2, r3;
-                asm(KG_MUL_("%3", "%0", "%6") KG_MUL_("%4", "%1", "%7") KG_MUL_("%5", "%2", "%8")
-                    KG_FMA_("%0", "%6", "%3", "neg_lo:[0,1,0]") KG_FMA_("%1", "%7", "%4", "neg_lo:[0,1,0]")
-                    KG_FMA_("%2", "%8", "%5", "neg_lo:[0,1,0]")
-                    : "+v"(B1), "+v"(B2), "+v"(B3), "=&v"(r1), "=&v"(r2), "=&v"(r3)
-                    : "s"(G[0]), "s"(G[1]), "s"(G[2]));
-            }
+            cf B1, B2, B3;
+            kg_cmul1x3s(B1, B2, B3, bs, G[0], G[1], G[2]);
 #pragma unroll
             for (int a = 0; a < 4; a++) {
                 if (a < a0 || a >= a1) continue;
                 const cf Ba = a == 0 ? bs : (a == 1 ? B1 : (a == 2 ? B2 : B3));
-                cf C1 = Ba, C2 = Ba, C3 = Ba, C0 = Ba;
-                {
-                    cf r1, r2, r3;
-                    asm(KG_MUL_("%3", "%0", "%6") KG_MUL_("%4", "%1", "%7") KG_MUL_("%5", "%2", "%8")
-                        KG_FMA_("%0", "%6", "%3", "neg_lo:[0,1,0]") KG_FMA_("%1", "%7", "%4", "neg_lo:[0,1,0]")
-                        KG_FMA_("%2", "%8", "%5", "neg_lo:[0,1,0]")
-                        : "+v"(C1), "+v"(C2), "+v"(C3), "=&v"(r1), "=&v"(r2), "=&v"(r3)
-                        : "s"(g[0]), "s"(g[1]), "s"(g[2]));
-                }
+                const cf C0 = Ba;
+                cf C1, C2, C3;
+                kg_cmul1x3s(C1, C2, C3, Ba, g[0], g[1], g[2]);
                 if constexpr (NQ == 1) {
                     kg_cmac4v(acc[0][4 * a], acc[0][4 * a + 1], acc[0][4 * a + 2], acc[0][4 * a + 3],
                               yv[4 * a], yv[4 * a + 1], yv[4 * a + 2], yv[4 * a + 3], C0, C1, C2, C3);
@@ -573,19 +560,44 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
         accumulate(yprev, P - 1, pbase, pg, pG, pQ, 0, 4);     // the cell's last item
 
         // search.cpp:486-490: power, first maximum (strict >), running total
-        const int limit = cur.limit;
+        // Row r = m + 16 q holds n = t + 256 r.  `limit` is wave-uniform, so a row lies wholly inside the
+        // window (256 (r + 1) <= limit: a scalar test; all but the last row or two) or needs the per-lane
+        // test; the row number, not n, is tracked as the position of the maximum (an inline constant).
+        const int limit = cur.limit, full_rows = limit >> 8;
         float bp = 0.f, sum = 0.f;
         int bi = 0;
-#pragma unroll
-        for (int q = 0; q < NQ; q++) {
+        if constexpr (NQ == 1) {
+            int br = 0;
 #pragma unroll
             for (int m = 0; m < 16; m++) {
-                const int n = t + 256 * m + SUB * q;
-                const cf v = acc[q][m];
-                const float pw = v.x * v.x + v.y * v.y;
-                const bool in = n < limit, take = in & (pw > bp);
-                bp = take ? pw : bp; bi = take ? n : bi;
-                sum += in ? pw : 0.f;
+                const cf v = acc[0][m];
+                const cf sq = v * v;
+                const float pw = sq.x + sq.y;
+                if (m < full_rows) {
+                    const bool take = pw > bp;
+                    bp = take ? pw : bp; br = take ? m : br;
+                    sum += pw;
+                } else {
+                    const bool in = t + 256 * m < limit, take = in & (pw > bp);
+                    bp = take ? pw : bp; br = take ? m : br;
+                    sum += in ? pw : 0.f;
+                }
+            }
+            bi = t + 256 * br;
+        } else {
+            // (one workgroup per CU: the straight masked scan measured faster here than a test per row or
+            // per output quarter, 1.53 against 1.64 ms for <4,4> on the acq59 workload)
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+#pragma unroll
+                for (int m = 0; m < 16; m++) {
+                    const int n = t + 256 * m + SUB * q;
+                    const cf v = acc[q][m];
+                    const float pw = v.x * v.x + v.y * v.y;
+                    const bool in = n < limit, take = in & (pw > bp);
+                    bp = take ? pw : bp; bi = take ? n : bi;
+                    sum += in ? pw : 0.f;
+                }
             }
         }
 #define ACQ_RED_STEP(L)                                                               \

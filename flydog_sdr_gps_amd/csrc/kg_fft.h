@@ -113,6 +113,17 @@ template <int SIGN> KG_DEV cf kg_sub_sj(cf a, cf b) { return SIGN > 0 ? kg_subj(
 #define KG_MUL_(r, a, w) "v_pk_mul_f32 " r ", " a ", " w " op_sel_hi:[1,0]\n\t"
 #define KG_FMA_(a, w, r, neg) "v_pk_fma_f32 " a ", " a ", " w ", " r " op_sel:[1,1,0] op_sel_hi:[0,1,1] " neg "\n\t"
 
+// o_i = a * w_i for one a and three wave-uniform w_i, NOT in place (the in-place blocks need a copy of a
+// per product when a is used again: 15 v_mov_b64 per correlator item went on that)
+#define KG_FMA3_(o, a, w, neg) "v_pk_fma_f32 " o ", " a ", " w ", " o " op_sel:[1,1,0] op_sel_hi:[0,1,1] " neg "\n\t"
+KG_DEV void kg_cmul1x3s(cf &o0, cf &o1, cf &o2, cf a, cf w0, cf w1, cf w2)
+{
+    asm(KG_MUL_("%0", "%3", "%4") KG_MUL_("%1", "%3", "%5") KG_MUL_("%2", "%3", "%6")
+        KG_FMA3_("%0", "%3", "%4", "neg_lo:[0,1,0]") KG_FMA3_("%1", "%3", "%5", "neg_lo:[0,1,0]")
+        KG_FMA3_("%2", "%3", "%6", "neg_lo:[0,1,0]")
+        : "=&v"(o0), "=&v"(o1), "=&v"(o2) : "v"(a), "s"(w0), "s"(w1), "s"(w2));
+}
+
 template <bool CONJ> KG_DEV void kg_cmul4v(cf &a0, cf &a1, cf &a2, cf &a3, cf w0, cf w1, cf w2, cf w3)
 {
     cf r0, r1, r2, r3;
