@@ -608,9 +608,14 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
             bp = take ? op : bp; bi = take ? oi : bi;                                    \
             sum += os;                                                                   \
         }
-        ACQ_RED_STEP(0) ACQ_RED_STEP(1) ACQ_RED_STEP(2) ACQ_RED_STEP(3) ACQ_RED_STEP(4) ACQ_RED_STEP(5)
-        // red[] was last read before this cell's barriers
-        if ((t & 63) == 0) { red[t >> 6].p = bp; red[t >> 6].i = bi; red[t >> 6].s = sum; }
+        // the wave's maximum, the lowest n holding it (what one strict-> scan in ascending n finds), the total
+        {
+            float wmax = bp, wsum = sum;
+            kg_wave_max_sum(wmax, wsum);
+            const int wn = kg_wave_min(bp == wmax ? bi : 0x7fffffff);
+            // red[] was last read before this cell's barriers
+            if ((t & 63) == 0) { red[t >> 6].p = wmax; red[t >> 6].i = wn; red[t >> 6].s = wsum; }
+        }
         if (t == 0) *red_claim = claimed;
         __syncthreads();
         // (rewritten only after eight more barriers; readfirstlane: the index must stay wave-uniform, or

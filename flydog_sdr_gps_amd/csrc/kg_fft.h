@@ -462,3 +462,32 @@ template <int L> KG_DEV unsigned kg_xchg_u(unsigned v)
 }
 template <int L> KG_DEV float kg_xchg(float v) { return __uint_as_float(kg_xchg_u<L>(__float_as_uint(v))); }
 template <int L> KG_DEV int kg_xchg(int v) { return (int) kg_xchg_u<L>((unsigned) v); }
+
+// ---------------------------------------------------------------------------
+// Wave64 reductions to a wave-uniform value: four butterfly levels inside each row of 16, then
+// row_bcast15 (rows 1, 3 take in the row below) and row_bcast31 (rows 2, 3 take in lanes 0..31): row 3
+// holds the result, v_readlane 63 makes it scalar.  Every level is ONE instruction -- the combining
+// operation with a DPP operand -- where hipcc emits copy + v_mov_dpp + canonicalise + operation (and a
+// v_permlane*_swap butterfly needs a dozen instructions for the two cross-row levels).  A DPP operand
+// must have been written at least two wait states earlier: the maximum and the sum are reduced
+// together, interleaved, with one s_nop between levels.
+// ---------------------------------------------------------------------------
+#define KG_DPP_LEVELS_(OP2)                                                              \
+    OP2("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") OP2("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf") \
+    OP2("row_half_mirror row_mask:0xf bank_mask:0xf") OP2("row_mirror row_mask:0xf bank_mask:0xf")             \
+    OP2("row_bcast:15 row_mask:0xa bank_mask:0xf") OP2("row_bcast:31 row_mask:0xc bank_mask:0xf")
+KG_DEV void kg_wave_max_sum(float &mx, float &sm)        // -> both wave-uniform
+{
+#define KG_OP2_(ctl) "v_max_f32_dpp %0, %0, %0 " ctl "\n\tv_add_f32_dpp %1, %1, %1 " ctl "\n\ts_nop 0\n\t"
+    asm("s_nop 1\n\t" KG_DPP_LEVELS_(KG_OP2_) : "+v"(mx), "+v"(sm));
+#undef KG_OP2_
+    mx = __uint_as_float((unsigned) __builtin_amdgcn_readlane((int) __float_as_uint(mx), 63));
+    sm = __uint_as_float((unsigned) __builtin_amdgcn_readlane((int) __float_as_uint(sm), 63));
+}
+KG_DEV int kg_wave_min(int x)
+{
+#define KG_OP2_(ctl) "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 " ctl "\n\t"
+    asm(KG_DPP_LEVELS_(KG_OP2_) : "+v"(x));
+#undef KG_OP2_
+    return __builtin_amdgcn_readlane(x, 63);
+}
