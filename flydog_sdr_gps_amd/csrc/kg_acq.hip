@@ -541,11 +541,12 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
             // pass 2: twiddle W4096^(j*t), out index t + 256 m (kept in registers)
             kg_twiddle16<+1>(x, tw.p2);
             // (NQ == 1: the next item's code rows, two per first-stage group)
-            kg_radix16_h<+1>(x, yprev, [&](int s) {
+            auto crows = [&](int s) {
                 if constexpr (NQ == 1) {
                     if (s < 4) { kg_pin(); fetch_crow(nr, 2 * s); fetch_crow(nr, 2 * s + 1); kg_pin(); }
                 }
-            });
+            };
+            kg_radix16_h<+1>(x, yprev, crows);
             pbase = base;
 #pragma unroll
             for (int i = 0; i < 3; i++) { pg[i] = g[i]; pG[i] = G[i]; }

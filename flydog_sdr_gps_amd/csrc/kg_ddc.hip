@@ -380,7 +380,7 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
 }
 
 // R == 1 bypass (cic_prune_var.v:289-297): out = mixer output [23 -: 16], no filter state at all,
-// so it is sample-parallel: eight samples per thread from one 16-byte load, two 16-byte stores.
+// so it is sample-parallel: two lane-contiguous groups of four samples per thread.
 __global__ __launch_bounds__(256) void ddc_wf_bypass_kernel(
     const short *__restrict__ adc, long n, const ddc_chan *__restrict__ chans, const int *__restrict__ chan_list,
     const int *__restrict__ bypass_list,      // list entries with R == 1
@@ -392,34 +392,43 @@ __global__ __launch_bounds__(256) void ddc_wf_bypass_kernel(
     const int li = bypass_list[blockIdx.y];
     const ddc_chan ch = chans[chan_list[li]];
     const u64 M48 = (1ull << 48) - 1;
-    const long t0 = ((long) blockIdx.x * 256 + threadIdx.x) * 8;
-    if (t0 >= n) return;
-    u64 ph = (ch.phase + (u64) t0 * ch.phase_inc) & M48;
-    short2 *o = out + (long) li * out_stride + t0;
-    short a[8];
-    const bool full = t0 + 8 <= n;
-    if (full && (((uintptr_t) (adc + t0)) & 15) == 0) {
-        const int4 v = *(const int4 *) (adc + t0);
-        a[0] = (short) v.x; a[1] = (short) (v.x >> 16); a[2] = (short) v.y; a[3] = (short) (v.y >> 16);
-        a[4] = (short) v.z; a[5] = (short) (v.z >> 16); a[6] = (short) v.w; a[7] = (short) (v.w >> 16);
-    } else {
-        for (int q = 0; q < 8; q++) a[q] = (t0 + q < n) ? adc[t0 + q] : (short) 0;
-    }
-    short2 r[8];
+    // persistent over the 2048-sample blocks of the channel: the 32 KiB table is staged once per
+    // workgroup, not once per 8 KiB of output
+    const long nblk = (n + 2047) / 2048;
+    for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        // two groups of four samples per thread, lane-contiguous: a wave's 8-byte loads cover 512
+        // contiguous bytes and its 16-byte stores 1 KiB of whole lines (eight consecutive samples per
+        // thread made every store instruction touch sixteen half-written lines)
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const u32 e = tab[ph >> 35];
-        const int mi = mix24(a[q], (short) (e & 0xffff)), mq = mix24(a[q], (short) (e >> 16));
-        r[q] = make_short2((short) (mi >> 8), (short) (mq >> 8));
-        ph = (ph + ch.phase_inc) & M48;
-    }
-    if (full && (((uintptr_t) o) & 15) == 0) {
-        int4 w0, w1;
-        w0.x = *(int *) &r[0]; w0.y = *(int *) &r[1]; w0.z = *(int *) &r[2]; w0.w = *(int *) &r[3];
-        w1.x = *(int *) &r[4]; w1.y = *(int *) &r[5]; w1.z = *(int *) &r[6]; w1.w = *(int *) &r[7];
-        ((int4 *) o)[0] = w0; ((int4 *) o)[1] = w1;
-    } else {
-        for (int q = 0; q < 8; q++) if (t0 + q < n) o[q] = r[q];
+        for (int g = 0; g < 2; g++) {
+            const long t0 = blk * 2048 + g * 1024 + 4 * (long) threadIdx.x;
+            if (t0 >= n) continue;
+            u64 ph = (ch.phase + (u64) t0 * ch.phase_inc) & M48;
+            short2 *o = out + (long) li * out_stride + t0;
+            short a[4];
+            const bool full = t0 + 4 <= n;
+            if (full && (((uintptr_t) (adc + t0)) & 7) == 0) {
+                const int2 v = *(const int2 *) (adc + t0);
+                a[0] = (short) v.x; a[1] = (short) (v.x >> 16); a[2] = (short) v.y; a[3] = (short) (v.y >> 16);
+            } else {
+                for (int q = 0; q < 4; q++) a[q] = (t0 + q < n) ? adc[t0 + q] : (short) 0;
+            }
+            short2 r[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const u32 e = tab[ph >> 35];
+                const int mi = mix24(a[q], (short) (e & 0xffff)), mq = mix24(a[q], (short) (e >> 16));
+                r[q] = make_short2((short) (mi >> 8), (short) (mq >> 8));
+                ph = (ph + ch.phase_inc) & M48;
+            }
+            if (full && (((uintptr_t) o) & 15) == 0) {
+                int4 w0;
+                w0.x = *(int *) &r[0]; w0.y = *(int *) &r[1]; w0.z = *(int *) &r[2]; w0.w = *(int *) &r[3];
+                *(int4 *) o = w0;
+            } else {
+                for (int q = 0; q < 4; q++) if (t0 + q < n) o[q] = r[q];
+            }
+        }
     }
 }
 
@@ -815,7 +824,8 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
         s_selsmall = (const int *) (b + o_small); s_selrest = (const int *) (b + o_rest);
     }
     if (!h_bypass.empty()) {
-        hipLaunchKernelGGL(ddc_wf_bypass_kernel, dim3((unsigned) ((n + 2047) / 2048), (unsigned) h_bypass.size()), dim3(256),
+        const long nblk_by = (n + 2047) / 2048, cap_by = (long) d->ctx->num_cus * 4;   // LDS: 32 KiB each, 4 per CU
+        hipLaunchKernelGGL(ddc_wf_bypass_kernel, dim3((unsigned) (nblk_by < cap_by ? nblk_by : cap_by), (unsigned) h_bypass.size()), dim3(256),
                            0, st, (const short *) d_adc, (long) n, (const ddc_chan *) d->d_chans, s_list,
                            s_bypass, (const u32 *) d->d_nco, (short2 *) d_out, (long) out_stride);
         KG_HIP(hipGetLastError());

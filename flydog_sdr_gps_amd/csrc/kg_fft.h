@@ -484,6 +484,13 @@ KG_DEV void kg_wave_max_sum(float &mx, float &sm)        // -> both wave-uniform
     mx = __uint_as_float((unsigned) __builtin_amdgcn_readlane((int) __float_as_uint(mx), 63));
     sm = __uint_as_float((unsigned) __builtin_amdgcn_readlane((int) __float_as_uint(sm), 63));
 }
+KG_DEV int kg_wave_max(int x)
+{
+#define KG_OP2_(ctl) "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 " ctl "\n\t"
+    asm(KG_DPP_LEVELS_(KG_OP2_) : "+v"(x));
+#undef KG_OP2_
+    return __builtin_amdgcn_readlane(x, 63);
+}
 KG_DEV int kg_wave_min(int x)
 {
 #define KG_OP2_(ctl) "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 " ctl "\n\t"

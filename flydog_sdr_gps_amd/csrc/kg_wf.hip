@@ -186,10 +186,8 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
             for (int u = 0; u < 4; u++)
                 if (4 * t + u < pwc) pp[u] = pwr[pfirst[u]];                            // :1418
         } else {
-            int cmax = max(max(pcount[0], pcount[1]), max(pcount[2], pcount[3]));
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) cmax = max(cmax, __shfl_xor(cmax, off));
-            cmax = __builtin_amdgcn_readfirstlane(cmax);
+            // (DPP reduce: six dependent ds_bpermute round trips per frame otherwise)
+            const int cmax = kg_wave_max(max(max(pcount[0], pcount[1]), max(pcount[2], pcount[3])));
 #pragma unroll
             for (int u = 0; u < 4; u++)
                 if (pcount[u] > 0) { pp[u] = pwr[pfirst[u]]; avgs[u] = 1; }            // :1468-1475

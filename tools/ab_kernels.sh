@@ -10,7 +10,7 @@ for v in "$@"; do
   echo "== $v"
   python3 - "$f" <<'PY'
 import csv, sys
-for r in list(csv.DictReader(open(sys.argv[1])))[:4]:
+for r in list(csv.DictReader(open(sys.argv[1])))[:8]:
     print("  %-48s calls %5s avg %10.2f us" % (r["Name"][:48], r["Calls"], float(r["AverageNs"]) / 1e3))
 PY
 done
