@@ -69,12 +69,12 @@ DDC_DEV u128 binom2(u64 j)
 }
 DDC_DEV u128 binom3(u64 j)
 {
-    // of j, j+1, j+2 one is divisible by 3 and (another or the same) by 2
-    u64 f[3] = {j, j + 1, j + 2};
-    for (int i = 0; i < 3; i++) if (f[i] % 3 == 0) { f[i] /= 3; break; }
-    for (int i = 0; i < 3; i++) if ((f[i] & 1) == 0) { f[i] /= 2; break; }
-    const u128 ab = mk128(f[0] * f[1], __umul64hi(f[0], f[1]));
-    return mul128(ab, mk128(f[2], 0));
+    // j (j+1) (j+2) < 2^120 is even and a multiple of 3: halve it, then divide by 3 exactly =
+    // multiply by the inverse of 3 modulo 2^128 (no 64-bit division: that is a software loop here)
+    const u128 ab = mk128(j * (j + 1), __umul64hi(j, j + 1));
+    u128 p = mul128(ab, mk128(j + 2, 0));
+    p.lo = (p.lo >> 1) | (p.hi << 63); p.hi >>= 1;
+    return mul128(p, mk128(0xAAAAAAAAAAAAAAABull, 0xAAAAAAAAAAAAAAAAull));
 }
 
 struct ddc_state4 { u128 i[4]; };            // integrators 1..4
@@ -439,6 +439,17 @@ DDC_DEV u64 shfl_up64(u64 v, int d)
     const u32 lo = __shfl_up((u32) v, d), hi = __shfl_up((u32) (v >> 32), d);
     return ((u64) hi << 32) | lo;
 }
+DDC_DEV u64 shfl64(u64 v, int src)
+{
+    const u32 lo = __shfl((u32) v, src), hi = __shfl((u32) (v >> 32), src);
+    return ((u64) hi << 32) | lo;
+}
+DDC_DEV ddc_state4 shfl_state(const ddc_state4 &s, int src)
+{
+    ddc_state4 r;
+    for (int k = 0; k < 4; k++) { r.i[k].lo = shfl64(s.i[k].lo, src); r.i[k].hi = shfl64(s.i[k].hi, src); }
+    return r;
+}
 DDC_DEV ddc_state4 shfl_up_state(const ddc_state4 &s, int d)
 {
     ddc_state4 r;
@@ -447,23 +458,59 @@ DDC_DEV ddc_state4 shfl_up_state(const ddc_state4 &s, int d)
 }
 
 #define DDC_SCAN_WAVES 8
+#define DDC_SCAN_MAX_CHUNKS 16
+// Ordered fold of the affine maps held by lanes 0 .. 2^LOG - 1 (lane order = time order; a lane with
+// len = 0 and e = 0 is the identity): log steps of the inclusive scan instead of a serial chain of
+// 128-bit multiply-adds.  -> the fold of lanes 0 .. lane (every lane of the group must call it)
+template <int LOG> DDC_DEV void ddc_fold_lanes(ddc_state4 &e, u64 &len, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < (1 << LOG); d <<= 1) {
+        const ddc_state4 a = shfl_up_state(e, d);
+        const u64 alen = shfl_up64(len, d);
+        if (lane >= d) { e = ddc_add(ddc_T(len, a), e); len += alen; }
+    }
+}
+// What a chunk of runs does to the integrator state: state_out = T(len) state_in + e.  Published by the
+// workgroup that owns the chunk for the workgroups of the later chunks of the same (channel, I/Q).
+struct ddc_chunk_agg { ddc_state4 e; u64 len; u32 epoch; u32 pad; };
+
+// Carry scan of the integrator states.  A (channel, I/Q) pair's runs are cut into `nchunk` chunks, one
+// workgroup of eight waves each: lane-local composition of a few runs, inclusive scan inside each wave,
+// the eight wave totals folded through LDS -> the chunk's aggregate, published in global memory; the
+// start state of the chunk = the saved state advanced through the aggregates of the chunks before it
+// (waited for one by one; every workgroup publishes before it waits, and workgroups take their chunk
+// numbers from a ticket counter in the order they start, so whoever is waited for is already running);
+// then every lane walks its runs again from its exact start state.  (One workgroup per pair took 120 us
+// for 16 384 runs -- 28 workgroups on 256 CUs, each lane composing 32 runs of 128-bit multiply-adds twice.)
 __global__ __launch_bounds__(64 * DDC_SCAN_WAVES) void ddc_wf_scan_states_kernel(
     ddc_state4 *__restrict__ local, long n, int L, int nruns, ddc_chan *__restrict__ chans,
-    const int *__restrict__ chan_list)
+    const int *__restrict__ chan_list, int npairs, int nchunk, ddc_chunk_agg *__restrict__ aggs,
+    u32 *__restrict__ ticket, u32 ticket_base, u32 epoch)
 {
-    // One workgroup of eight waves per (channel, I/Q): lane-local composition of a chunk of
-    // runs, inclusive scan inside each wave, the eight wave totals folded through LDS, then
-    // every lane walks its chunk again from its exact start state.
     __shared__ ddc_state4 w_state[DDC_SCAN_WAVES];
     __shared__ u64 w_len[DDC_SCAN_WAVES];
-    const int li = blockIdx.x >> 1, comp = blockIdx.x & 1;
+    __shared__ ddc_state4 s_start;
+    __shared__ u32 s_id;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = threadIdx.x;
+    if (gl == 0) s_id = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ticket_base;
+    __syncthreads();
+    const int id = (int) s_id, g = id / npairs, pair = id - g * npairs;     // chunk-major: chunk 0 of every pair first
+    const int li = pair >> 1, comp = pair & 1;
     ddc_chan *ch = chans + chan_list[li];
-    if (ch->log2r == 0) return;
+    if (ch->log2r == 0) return;                   // (the whole pair: nobody waits for a bypass channel)
     ddc_state4 *st = local + ((long) li * 2 + comp) * nruns;
-    const int per = (nruns + 64 * DDC_SCAN_WAVES - 1) / (64 * DDC_SCAN_WAVES);
-    const int r0 = gl * per < nruns ? gl * per : nruns, r1 = (r0 + per < nruns) ? r0 + per : nruns;
+    ddc_chunk_agg *agg = aggs + (long) pair * DDC_SCAN_MAX_CHUNKS;
+    const int cper = (nruns + nchunk - 1) / nchunk;
+    const int c0 = g * cper < nruns ? g * cper : nruns, c1 = c0 + cper < nruns ? c0 + cper : nruns;
+    const int per = (c1 - c0 + 64 * DDC_SCAN_WAVES - 1) / (64 * DDC_SCAN_WAVES);
+    const int r0 = c0 + gl * per < c1 ? c0 + gl * per : c1, r1 = (r0 + per < c1) ? r0 + per : c1;
     auto run_len = [&](int r) -> u64 { const long s0 = (long) r * L; return (u64) ((s0 + L < n ? s0 + L : n) - s0); };
+    // the saved state is read before anything is published: the last chunk rewrites it at the end, after
+    // it has seen every other chunk's aggregate
+    ddc_state4 saved;
+    for (int k = 0; k < 4; k++) saved.i[k] = mk128(0, 0);
+    if (gl == 0) saved = ch->integ[comp];
     // 1. lane-local composition
     ddc_state4 acc; u64 len = 0;
     for (int k = 0; k < 4; k++) acc.i[k] = mk128(0, 0);
@@ -482,15 +529,48 @@ __global__ __launch_bounds__(64 * DDC_SCAN_WAVES) void ddc_wf_scan_states_kernel
     }
     if (lane == 63) { w_state[wave] = inc; w_len[wave] = ilen; }
     __syncthreads();
-    // state at the start of this wave's first run: the saved state advanced through the earlier waves
-    ddc_state4 ws = ch->integ[comp];
-    for (int w = 0; w < wave; w++) ws = ddc_add(ddc_T(w_len[w], ws), w_state[w]);
-    __syncthreads();                              // every wave has read the saved state
+    // 3. the chunk's aggregate out, the aggregates of the earlier chunks in: wave 0, one lane per wave
+    // total / per earlier chunk, folded in log steps
+    if (wave == 0) {
+        ddc_state4 e; u64 l = 0;
+        for (int k = 0; k < 4; k++) e.i[k] = mk128(0, 0);
+        if (lane < DDC_SCAN_WAVES) { e = w_state[lane]; l = w_len[lane]; }
+        ddc_fold_lanes<3>(e, l, lane);
+        if (lane == DDC_SCAN_WAVES - 1 && g + 1 < nchunk) {
+            agg[g].e = e; agg[g].len = l;
+            __hip_atomic_store(&agg[g].epoch, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        for (int k = 0; k < 4; k++) e.i[k] = mk128(0, 0);
+        l = 0;
+        if (lane < g) {
+            while (__hip_atomic_load(&agg[lane].epoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+                __builtin_amdgcn_s_sleep(2);
+            for (int k = 0; k < 4; k++) {          // past the acquire: loads that do not come from a stale line
+                e.i[k].lo = __hip_atomic_load(&agg[lane].e.i[k].lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                e.i[k].hi = __hip_atomic_load(&agg[lane].e.i[k].hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            l = __hip_atomic_load(&agg[lane].len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ddc_fold_lanes<4>(e, l, lane);             // DDC_SCAN_MAX_CHUNKS = 16 lanes
+        const ddc_state4 sv = shfl_state(saved, 0);
+        if (lane == DDC_SCAN_MAX_CHUNKS - 1) s_start = ddc_add(ddc_T(l, sv), e);
+    }
+    __syncthreads();
+    // state at the start of this wave's first run: the chunk's start advanced through the earlier waves
+    ddc_state4 ws;
+    {
+        ddc_state4 e; u64 l = 0;
+        for (int k = 0; k < 4; k++) e.i[k] = mk128(0, 0);
+        if (lane < wave) { e = w_state[lane]; l = w_len[lane]; }
+        ddc_fold_lanes<3>(e, l, lane);
+        e = shfl_state(e, DDC_SCAN_WAVES - 1); l = shfl64(l, DDC_SCAN_WAVES - 1);
+        ws = ddc_add(ddc_T(l, s_start), e);
+    }
     // exclusive prefix of this lane inside its wave = inclusive of lane - 1
     ddc_state4 exc = shfl_up_state(inc, 1); u64 elen = shfl_up64(ilen, 1);
     if (lane == 0) { for (int k = 0; k < 4; k++) exc.i[k] = mk128(0, 0); elen = 0; }
     ddc_state4 c = ddc_add(ddc_T(elen, ws), exc);
-    // 3. per-run carried states
+    // 4. per-run carried states
     for (int r = r0; r < r1; r++) {
         const ddc_state4 e = st[r];
         st[r] = c;
@@ -501,22 +581,29 @@ __global__ __launch_bounds__(64 * DDC_SCAN_WAVES) void ddc_wf_scan_states_kernel
     if (r1 == nruns && r0 < nruns) ch->integ[comp] = c;
 }
 
-__global__ __launch_bounds__(64) void ddc_wf_scan_tau_kernel(
+// Prefix sum of the runs' integrator-5 totals: one workgroup of eight waves per (channel, I/Q).
+__global__ __launch_bounds__(64 * DDC_SCAN_WAVES) void ddc_wf_scan_tau_kernel(
     u32 *__restrict__ tau, int nruns, ddc_chan *__restrict__ chans, const int *__restrict__ chan_list)
 {
-    const int li = blockIdx.x >> 1, comp = blockIdx.x & 1, lane = threadIdx.x;
+    __shared__ u32 w_tot[DDC_SCAN_WAVES];
+    const int li = blockIdx.x >> 1, comp = blockIdx.x & 1, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = threadIdx.x;
     ddc_chan *ch = chans + chan_list[li];
     if (ch->log2r == 0) return;
     u32 *tv = tau + ((long) li * 2 + comp) * nruns;
-    const int per = (nruns + 63) / 64;
-    const int r0 = lane * per, r1 = (r0 + per < nruns) ? r0 + per : nruns;
+    const int per = (nruns + 64 * DDC_SCAN_WAVES - 1) / (64 * DDC_SCAN_WAVES);
+    const int r0 = gl * per < nruns ? gl * per : nruns, r1 = (r0 + per < nruns) ? r0 + per : nruns;
     u32 acc = 0;
     for (int r = r0; r < r1; r++) acc += tv[r];
     u32 inc = acc;
     for (int d = 1; d < 64; d <<= 1) { const u32 a = __shfl_up(inc, d); if (lane >= d) inc += a; }
+    if (lane == 63) w_tot[wave] = inc;
     u32 c = __shfl_up(inc, 1);
     if (lane == 0) c = 0;
-    c = (c + ch->integ5[comp]) & 0x0FFFFFFFu;
+    __syncthreads();
+    const u32 i5 = ch->integ5[comp];
+    __syncthreads();                              // every wave has read the saved value
+    for (int w = 0; w < wave; w++) c += w_tot[w];
+    c = (c + i5) & 0x0FFFFFFFu;
     for (int r = r0; r < r1; r++) { const u32 e = tv[r]; tv[r] = c; c = (c + e) & 0x0FFFFFFFu; }   // tv[r] = I5 at run start
     if (r1 == nruns && r0 < nruns) ch->integ5[comp] = c;
 }
@@ -615,6 +702,7 @@ struct kg_ddc {
     u32 *d_nco;
     ddc_state4 *d_local; u32 *d_c0rel, *d_tau, *d_hist;
     int max_runs; long c0_cap;
+    ddc_chunk_agg *d_aggs; u32 *d_ticket; u32 ticket_base, epoch;     // chunked state scan
 };
 
 static const int DDC_RUN_MIN = 64, DDC_RUN_MAX = 8192, DDC_TARGET_RUNS = 8192;
@@ -646,6 +734,11 @@ int kg_ddc_create(kg_ctx *ctx, int nchan, size_t max_samples, kg_ddc **out)
     KG_HIP(hipMalloc((void **) &d->d_local, sizeof(ddc_state4) * 2 * (size_t) nchan * d->max_runs));
     KG_HIP(hipMalloc((void **) &d->d_tau, sizeof(u32) * 2 * (size_t) nchan * d->max_runs));
     KG_HIP(hipMalloc((void **) &d->d_hist, sizeof(u32) * 10 * (size_t) nchan));
+    KG_HIP(hipMalloc((void **) &d->d_aggs, sizeof(ddc_chunk_agg) * 2 * (size_t) nchan * DDC_SCAN_MAX_CHUNKS));
+    KG_HIP(hipMemset(d->d_aggs, 0, sizeof(ddc_chunk_agg) * 2 * (size_t) nchan * DDC_SCAN_MAX_CHUNKS));
+    KG_HIP(hipMalloc((void **) &d->d_ticket, sizeof(u32)));
+    KG_HIP(hipMemset(d->d_ticket, 0, sizeof(u32)));
+    d->ticket_base = 0; d->epoch = 0;
     // NCO table (frozen by us; the Xilinx DDS IP is closed): round(16383 * cos/sin(2 pi a / 8192))
     std::vector<u32> tab(8192);
     for (int a = 0; a < 8192; a++) {
@@ -666,6 +759,7 @@ void kg_ddc_destroy(kg_ddc *d)
     (void) hipFree(d->d_chans); (void) hipFree(d->d_nco); 
     (void) hipFree(d->d_local);
     (void) hipFree(d->d_tau); (void) hipFree(d->d_c0rel); (void) hipFree(d->d_hist);
+    (void) hipFree(d->d_aggs); (void) hipFree(d->d_ticket);
     
     delete d;
 }
@@ -838,8 +932,20 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
                            s_nouts, s_selrun, 0);
         KG_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(ddc_wf_scan_states_kernel, dim3(2 * nlist), dim3(64 * DDC_SCAN_WAVES), 0, st, d->d_local, (long) n, L, nruns,
-                       d->d_chans, s_list);
+    {
+        // chunks per (channel, I/Q): as many as keep every chunk at least a workgroup's worth of runs and
+        // the whole grid resident at once
+        const int npairs = 2 * nlist;
+        int nchunk = (d->ctx->num_cus * 2) / npairs;
+        if (nchunk > DDC_SCAN_MAX_CHUNKS) nchunk = DDC_SCAN_MAX_CHUNKS;
+        while (nchunk > 1 && nruns / nchunk < 64 * DDC_SCAN_WAVES) nchunk--;
+        if (nchunk < 1) nchunk = 1;
+        d->epoch++;
+        hipLaunchKernelGGL(ddc_wf_scan_states_kernel, dim3((unsigned) (npairs * nchunk)), dim3(64 * DDC_SCAN_WAVES), 0, st,
+                           d->d_local, (long) n, L, nruns, d->d_chans, s_list, npairs, nchunk, d->d_aggs, d->d_ticket,
+                           d->ticket_base, d->epoch);
+        d->ticket_base += (u32) (npairs * nchunk);
+    }
     KG_HIP(hipGetLastError());
     // Pass B.  The staged strobe flush (R <= 8) needs 34 KiB more LDS, hence its own launch; that
     // only pays when those channels fill the GPU by themselves (two waves per SIMD), otherwise
@@ -865,7 +971,7 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
                            s_nouts, s_selrun, 0);
         KG_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(ddc_wf_scan_tau_kernel, dim3(2 * nlist), dim3(64), 0, st, d->d_tau, nruns, d->d_chans,
+    hipLaunchKernelGGL(ddc_wf_scan_tau_kernel, dim3(2 * nlist), dim3(64 * DDC_SCAN_WAVES), 0, st, d->d_tau, nruns, d->d_chans,
                        s_list);
     KG_HIP(hipGetLastError());
     if (comb_wgs > 0) {
