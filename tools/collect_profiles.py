@@ -1,0 +1,67 @@
+"""Copies the judged summaries of a tools/prof_round.sh run from gpurun_out/<tag>_* into profiles/r02_*
+and rewrites profiles/hbm_traffic.json from their PMC passes (2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes).
+usage: python tools/collect_profiles.py <tag> [round-prefix, default r02]"""
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+tag = sys.argv[1]
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+go, pr = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
+
+
+def first(pat):
+    f = sorted(glob.glob(pat, recursive=True))
+    return f[0] if f else None
+
+
+for wl in ("acq", "acq59", "acq10ms", "wf14", "ddc14", "receivers"):
+    ks = first(os.path.join(go, "%s_%s" % (tag, wl), "trace", "**", "*kernel_stats.csv"))
+    if ks:
+        shutil.copy(ks, os.path.join(pr, "%s_%s_kernel_stats.csv" % (rnd, wl)))
+    sm = os.path.join(go, "%s_%s.summary.txt" % (tag, wl))
+    if os.path.isfile(sm):
+        shutil.copy(sm, os.path.join(pr, "%s_%s_summary.txt" % (rnd, wl)))
+
+
+def counters(wl, kernel_sub):
+    """mean per dispatch of the named counters for the kernel whose name contains kernel_sub"""
+    text = open(os.path.join(pr, "%s_%s_summary.txt" % (rnd, wl))).read()
+    out = {}
+    for block in re.split(r"\n  (?=\S)", text):
+        if kernel_sub not in block.split("\n")[0]:
+            continue
+        for m in re.finditer(r"^\s+(\w+)\s+([0-9.]+)\s+\(n=", block, re.M):
+            out.setdefault(m.group(1), float(m.group(2)))
+    return out
+
+
+def entry(wl, sub, label):
+    c = counters(wl, sub)
+    return {"kernel": label, "fetch_size_kb": c["FETCH_SIZE"], "write_size_kb": c["WRITE_SIZE"],
+            "bytes_per_launch": int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024),
+            "tcc_hit": c.get("TCC_HIT_sum"), "tcc_miss": c.get("TCC_MISS_sum"),
+            "source": "profiles/%s_%s_summary.txt" % (rnd, wl)}
+
+
+tab = {"_how": "tools/prof_round.sh on MI355X: separate rocprofv3 --pmc passes of bench.py (pass 3: FETCH_SIZE; pass 4: "
+               "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum), mean per dispatch; bytes = 2 x FETCH_SIZE KB (gfx950 tallies "
+               "128-byte read requests at 64 B, MI355X_MICROARCH.md HBM section) + WRITE_SIZE KB.  bench.py measures "
+               "the same live (live_traffic_passes); this table is its fallback",
+       "_source": "profiles/%s_*_summary.txt" % rnd}
+tab["acq"] = {"32": entry("acq", "acq_correlate_kernel<4, 1,", "acq_correlate_kernel<4, 1, true, false>")}
+tab["wf14"] = {"28672": entry("wf14", "wf_frame_kernel", "wf_frame_kernel<false>")}
+p1 = entry("acq10ms", "acq_correlate_kernel<16, 1,", "acq_correlate_kernel<16, 1, true, false>")
+p4 = entry("acq10ms", "acq_correlate_kernel<16, 4,", "acq_correlate_kernel<16, 4, true, false>")
+tab["acq10ms"] = {"2": {"kernel": "acq_correlate_kernel<16,1> + <16,4>",
+                        "bytes_per_launch": p1["bytes_per_launch"] + p4["bytes_per_launch"], "parts": [p1, p4]}}
+q1 = entry("acq59", "acq_correlate_kernel<4, 1,", "acq_correlate_kernel<4, 1, true, false>")
+q4 = entry("acq59", "acq_correlate_kernel<4, 4,", "acq_correlate_kernel<4, 4, true, false>")
+tab["acq59"] = {"32": {"kernel": "acq_correlate_kernel<4,1> + <4,4>",
+                       "bytes_per_launch": q1["bytes_per_launch"] + q4["bytes_per_launch"], "parts": [q1, q4]}}
+json.dump(tab, open(os.path.join(pr, "hbm_traffic.json"), "w"), indent=1)
+print(json.dumps({k: (v if k.startswith("_") else {kk: vv.get("bytes_per_launch") for kk, vv in v.items()}) for k, v in tab.items()}, indent=1))

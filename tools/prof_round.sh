@@ -4,7 +4,7 @@
 tag=$1
 export TMPDIR=/tmp
 for wl in acq acq59 acq10ms wf14; do
-  extra="--steps 40"; [ $wl = acq10ms ] && extra="--steps 8 --warmup 2"
+  extra="--steps 40"; [ $wl = acq10ms ] && extra="--steps 8 --warmup 2"; [ $wl = wf14 ] && extra="--steps 400 --warmup 40"
   tools/prof.sh ${tag}_$wl --workload $wl $extra > gpurun_out/${tag}_$wl.summary.txt 2>&1
   echo "== $wl"; grep -E "calls" gpurun_out/${tag}_$wl.summary.txt | head -6
 done
