@@ -940,13 +940,14 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
         if (nchunk > DDC_SCAN_MAX_CHUNKS) nchunk = DDC_SCAN_MAX_CHUNKS;
         while (nchunk > 1 && nruns / nchunk < 64 * DDC_SCAN_WAVES) nchunk--;
         if (nchunk < 1) nchunk = 1;
-        d->epoch++;
         hipLaunchKernelGGL(ddc_wf_scan_states_kernel, dim3((unsigned) (npairs * nchunk)), dim3(64 * DDC_SCAN_WAVES), 0, st,
                            d->d_local, (long) n, L, nruns, d->d_chans, s_list, npairs, nchunk, d->d_aggs, d->d_ticket,
-                           d->ticket_base, d->epoch);
+                           d->ticket_base, d->epoch + 1);
+        KG_HIP(hipGetLastError());
+        // only a launch that was accepted advances the ticket counter and publishes under the new epoch
+        d->epoch++;
         d->ticket_base += (u32) (npairs * nchunk);
     }
-    KG_HIP(hipGetLastError());
     // Pass B.  The staged strobe flush (R <= 8) needs 34 KiB more LDS, hence its own launch; that
     // only pays when those channels fill the GPU by themselves (two waves per SIMD), otherwise
     // splitting the launch costs more than the scattered stores (14-channel set: 3 such channels).

@@ -57,6 +57,29 @@ def test_pieces_of_any_length_carry_state(gpu_ctx, oracle):
         d.close()
 
 
+def test_long_blocks_take_the_chunked_state_scan(gpu_ctx, oracle):
+    """2^21 samples in two unequal pushes: 8192+ runs per channel, so the integrator carry scan of a
+    (channel, I/Q) pair is cut into the maximum number of chunks across workgroups (look-back through
+    published aggregates), with the state carried from the first push into the second; R = 1 rides
+    along on the bypass kernel's persistent loop."""
+    n = 1 << 21
+    adc = adc_stream(n, seed=77, tones=((0.0123, 9000.0), (0.31, 1500.0)))
+    chans = [(inc_for(0.0123 + 2.0 ** -20), 6), (inc_for(0.31), 12), (inc_for(0.05), 0)]
+    d = Ddc(gpu_ctx, nchan=len(chans), max_samples=n)
+    try:
+        for ch, (inc, log2r) in enumerate(chans):
+            d.set_wf(ch, inc, 1 << log2r)
+        cut = (1 << 20) + 12345
+        a = d.push(adc[:cut], list(range(len(chans))))
+        b = d.push(adc[cut:], list(range(len(chans))))
+        for ch, (inc, log2r) in enumerate(chans):
+            want, _ = oracle.ddc_wf(adc, inc, log2r)
+            got = np.concatenate([a[ch], b[ch]])
+            assert got.shape == want.shape and np.array_equal(got, want), ch
+    finally:
+        d.close()
+
+
 def test_reset_restarts_cic_but_not_phase(gpu_ctx, oracle):
     n = 50_000
     adc = adc_stream(2 * n, seed=5)
