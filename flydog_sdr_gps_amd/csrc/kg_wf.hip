@@ -294,6 +294,10 @@ int kg_wf_create(kg_ctx *ctx, int nchan, kg_wf **out)
     int occ = 0;
     KG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, wf_frame_kernel<false>, 256, WF_LDS_BYTES));
     if (occ < 1) occ = 1;
+    if (const char *e = getenv("KIWIGPU_WF_WGS_PER_CU")) {      // experiment: fewer workgroups per CU
+        const int v = atoi(e);
+        if (v >= 1 && v < occ) occ = v;
+    }
     w->grid = ctx->num_cus * occ;
     *out = w;
     return KG_OK;
