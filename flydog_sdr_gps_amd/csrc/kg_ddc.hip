@@ -703,6 +703,7 @@ struct kg_ddc {
     ddc_state4 *d_local; u32 *d_c0rel, *d_tau, *d_hist;
     int max_runs; long c0_cap;
     ddc_chunk_agg *d_aggs; u32 *d_ticket; u32 ticket_base, epoch;     // chunked state scan
+    hipStream_t side; hipEvent_t ev_fork, ev_join;                   // pass B of the small decimations beside the rest
 };
 
 static const int DDC_RUN_MIN = 64, DDC_RUN_MAX = 8192, DDC_TARGET_RUNS = 8192;
@@ -760,6 +761,7 @@ void kg_ddc_destroy(kg_ddc *d)
     (void) hipFree(d->d_local);
     (void) hipFree(d->d_tau); (void) hipFree(d->d_c0rel); (void) hipFree(d->d_hist);
     (void) hipFree(d->d_aggs); (void) hipFree(d->d_ticket);
+    if (d->side) { (void) hipStreamSynchronize(d->side); (void) hipEventDestroy(d->ev_fork); (void) hipEventDestroy(d->ev_join); (void) hipStreamDestroy(d->side); }
     
     delete d;
 }
@@ -948,11 +950,37 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
         d->epoch++;
         d->ticket_base += (u32) (npairs * nchunk);
     }
-    // Pass B.  The staged strobe flush (R <= 8) needs 34 KiB more LDS, hence its own launch; that
-    // only pays when those channels fill the GPU by themselves (two waves per SIMD), otherwise
-    // splitting the launch costs more than the scattered stores (14-channel set: 3 such channels).
-    const bool staged = (long) h_small.size() * nruns >= (long) d->ctx->num_cus * 4 * 2 * 64;
-    if (staged) {
+    // Pass B.  The staged strobe flush (R <= 8) needs 34 KiB more LDS, hence its own launch.  Neither
+    // launch fills the GPU by itself (a lane walks a whole run: 64 workgroups per channel), so when both
+    // kinds of channel are present the staged launch runs beside the other one on a second stream of the
+    // object (fork after the state scan, join before the run-total prefix); with only small decimations
+    // it pays once those channels fill the GPU by themselves, otherwise the scattered stores are cheaper
+    // than the smaller grid.
+    bool staged = (long) h_small.size() * nruns >= (long) d->ctx->num_cus * 4 * 2 * 64;
+    bool beside = !h_small.empty() && !h_rest.empty();
+    if (const char *e = getenv("KIWIGPU_DDC_STAGED")) staged = atoi(e) != 0 && !h_small.empty();
+    if (const char *e = getenv("KIWIGPU_DDC_SIDE")) beside = beside && atoi(e) != 0;
+    if (beside) {
+        if (!d->side) {
+            KG_HIP(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
+            KG_HIP(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
+            KG_HIP(hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming));
+        }
+        KG_HIP(hipEventRecord(d->ev_fork, st));
+        KG_HIP(hipStreamWaitEvent(d->side, d->ev_fork, 0));
+        hipLaunchKernelGGL(ddc_wf_run_kernel<true>, dim3(gx, (unsigned) h_small.size()), dim3(DDC_THREADS), DDC_STAGE_BYTES, d->side,
+                           (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, s_list,
+                           (const u32 *) d->d_nco, d->d_local, d->d_c0rel, d->d_tau, s_c0off,
+                           s_nouts, s_selsmall, DDC_STAGE_BYTES);
+        KG_HIP(hipGetLastError());
+        KG_HIP(hipEventRecord(d->ev_join, d->side));
+        hipLaunchKernelGGL(ddc_wf_run_kernel<true>, dim3(gx, (unsigned) h_rest.size()), dim3(DDC_THREADS), 0, st,
+                           (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, s_list,
+                           (const u32 *) d->d_nco, d->d_local, d->d_c0rel, d->d_tau, s_c0off,
+                           s_nouts, s_selrest, 0);
+        KG_HIP(hipGetLastError());
+        KG_HIP(hipStreamWaitEvent(st, d->ev_join, 0));
+    } else if (staged) {
         hipLaunchKernelGGL(ddc_wf_run_kernel<true>, dim3(gx, (unsigned) h_small.size()), dim3(DDC_THREADS), DDC_STAGE_BYTES, st,
                            (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, s_list,
                            (const u32 *) d->d_nco, d->d_local, d->d_c0rel, d->d_tau, s_c0off,
