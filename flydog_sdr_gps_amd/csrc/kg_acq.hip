@@ -440,13 +440,13 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
 #endif
         auto deferred = [&](int slot, int k2) {
             constexpr int place1[4] = KG_DEFER_PLACE, place4[4] = KG_DEFER_PLACE4;
-            if (k2 > 0) {
-                kg_pin();
-                int a0 = 4, a1 = 0;                            // the run of quarters placed in this slot
+            int a0 = 4, a1 = 0;                                // the run of quarters placed in this slot
 #pragma unroll
-                for (int a = 0; a < 4; a++)
-                    if ((NQ == 1 ? place1[a] : place4[a]) == slot) { a0 = a < a0 ? a : a0; a1 = a + 1; }
-                if (a0 < a1) accumulate(yprev, k2 - 1, pbase, pg, pG, pQ, a0, a1);
+            for (int a = 0; a < 4; a++)
+                if ((NQ == 1 ? place1[a] : place4[a]) == slot) { a0 = a < a0 ? a : a0; a1 = a + 1; }
+            if (a0 < a1 && k2 > 0) {                           // (an empty slot leaves nothing behind, not even the test)
+                kg_pin();
+                accumulate(yprev, k2 - 1, pbase, pg, pG, pQ, a0, a1);
                 kg_pin();
             }
         };
