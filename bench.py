@@ -530,6 +530,12 @@ def run_wf14(args, dist):
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": traffic, "traffic_source": source, "kernel_ms": round(kernel_ms, 5),
                      "algorithmic_bytes_per_launch": nfr * bytes_frame},
+        # the other roof, for scale: nominal flops of the 8192-point transform (5 N log2 N) per frame against
+        # the fp32 vector peak; the kernel issues 1239 vector instructions per wave and frame, 600 of them
+        # the two 4096-point transforms, so its vector floor (0.25 ms) is above its HBM floor
+        "valu": {"nominal_flops_per_launch": nfr * 5 * 8192 * 13,
+                 "achieved_TFLOPs": round(nfr * 5 * 8192 * 13 / (kernel_ms * 1e-3) / 1e12, 2), "peak": VALU_PEAK_TFLOPS,
+                 "frac": round(nfr * 5 * 8192 * 13 / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)},
     }
     if not args.no_cpu and dist.world == 1 and dist.rank == 0:
         from oracle import kiwi_oracle as ko
