@@ -144,6 +144,31 @@ def test_injected_spectrum_and_shifts(searcher, navstar_codes, oracle):
         check_cells(cells[0, 0][di:di + 1], wcells[di:di + 1])
 
 
+def test_exact_ties_go_to_the_first_lag_and_the_first_bin(gpu_ctx, oracle):
+    """search.cpp:486-495: both scans are strict `>`, so of equal maxima the FIRST one wins -- the lowest
+    lag inside a cell, the lowest Doppler bin among cells.  A product spectrum that is a single DC bin
+    transforms to the same value at every lag, exactly (every butterfly adds zeros, the only non-zero
+    input of each pass has twiddle 1): every lag of every cell ties, across lanes, waves and the
+    workgroup merge of the reduction, and every cell's snr is exactly 1."""
+    s = Searcher(gpu_ctx, max_sats=2)
+    try:
+        n = s.fft_len
+        code = np.ones(n, np.complex64)
+        data = np.zeros(n, np.complex64)
+        data[0] = 3 + 4j
+        s.set_data_fft(data)
+        for limit in (sats.L1_LIMIT, sats.E1B_LIMIT, 1000):      # one accumulator, four (all 16368 lags), a short window
+            s.set_code_fft(0, code, limit=limit)
+            res, cells = s.correlate_many([0])
+            want, wcells = oracle.correlate(code, data, limit=limit)
+            assert np.all(wcells["idx"] == 0) and np.all(wcells["snr"] == 1.0) and (want["dop"], want["idx"]) == (s.dop_lo, 0)
+            assert np.all(cells[0, 0]["idx"] == 0), limit
+            assert np.all(cells[0, 0]["max_pwr"] == 25.0) and np.all(cells[0, 0]["snr"] == 1.0), limit
+            assert (int(res[0, 0]["dop"]), int(res[0, 0]["idx"]), int(res[0, 0]["valid"])) == (s.dop_lo, 0, 1)
+    finally:
+        s.close()
+
+
 def test_all_zero_input_is_invalid(searcher, navstar_codes):
     """search.cpp:455,495: snr = 0/0 is never > 0, so nothing is reported."""
     searcher.set_data_fft(np.zeros(16384, np.complex64))
