@@ -209,6 +209,29 @@ def test_custom_limit_and_narrow_doppler(gpu_ctx, oracle):
     s.close()
 
 
+@pytest.mark.parametrize("limit", [1, 255, 256, 257, 3839, 3840, 3841, 4095, 4096, 4097, 8191, 12288, 16367, 16384])
+def test_search_window_boundaries(gpu_ctx, oracle, limit):
+    """The peak-search window (search.cpp:486 `limit`) on and around the 256-lag rows of the cell-end scan
+    (rows wholly inside the window skip the per-lane test) and around 4096, where the four-accumulator
+    correlator takes over: every cell's first maximum and totals against the oracle, with the true peak
+    both inside and outside the window."""
+    s = Searcher(gpu_ctx, max_sats=2, dop_lo=-4, dop_hi=4)
+    try:
+        chips = prn.cacode(2, 6)
+        s.set_code(0, chips, limit=limit)
+        for delay in (100.25, 900.5):           # code delay in chips: lag 401 / 3602 of the 4.092 MS/s grid
+            bits = synth.gps_scene_bits([(chips, delay, 0.0, 0.5)], seed=int(delay))
+            s.sample(bits)
+            res, cells = s.correlate_many([0])
+            want, wcells = oracle.correlate(oracle.code_fft(chips), oracle.sample_bits(bits), limit=limit,
+                                            dop_lo=-4, dop_hi=4)
+            assert (int(res[0, 0]["dop"]), int(res[0, 0]["idx"])) == (want["dop"], want["idx"]), (limit, delay)
+            check_cells(cells[0, 0], wcells)
+            assert np.all(cells[0, 0]["idx"] < limit)
+    finally:
+        s.close()
+
+
 def test_error_paths(gpu_ctx):
     from flydog_sdr_gps_amd import KiwiGpuError
     s = Searcher(gpu_ctx, max_sats=4)
