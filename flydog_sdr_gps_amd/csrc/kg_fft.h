@@ -400,6 +400,39 @@ KG_DEV void kg_subfft4096(cf (&x)[16], cf (&y)[16], float2 *tileA, float2 *tileB
     kg_subfft4096_b<SIGN, STAMPS>(x, y, tileB, tw, t, st);
 }
 
+// kg_subfft4096 with the pass-1 twiddles W256^(j (t & 15)) read from a 240-entry LDS table
+// (tw1[(j - 1) 16 + (t & 15)], filled by kg_tw1_fill) instead of 30 registers: for kernels that need
+// those registers for something that saves global loads (kg_wf.hip).
+KG_DEV void kg_tw1_fill(float2 *tw1, const float2 *__restrict__ tab4096, int t)
+{
+    if (t < 240) kg_st(&tw1[t], kg_ld(&tab4096[(((t >> 4) + 1) * (t & 15)) << 4]));
+}
+template <int SIGN>
+KG_DEV void kg_subfft4096_l(cf (&x)[16], cf (&y)[16], float2 *tileA, float2 *tileB, const float2 *tw1,
+                            const kg_tw15 &p2, int t)
+{
+    const int tl = t & 15, th = t >> 4;
+    const int rd = t ^ (th & 15);
+    kg_radix16<SIGN>(x, y);
+#pragma unroll
+    for (int m = 0; m < 16; m++) kg_st(&tileA[16 * t + (m ^ tl)], y[m]);
+    __syncthreads();
+    kg_tw15 w1;
+#pragma unroll
+    for (int j = 1; j < 16; j++) w1.w[j - 1] = kg_ld_tile(&tw1[(j - 1) * 16 + tl]);
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = kg_ld_tile(&tileA[rd + 256 * j]);
+    kg_twiddle16<SIGN>(x, w1);
+    kg_radix16<SIGN>(x, y);
+#pragma unroll
+    for (int m = 0; m < 16; m++) kg_st(&tileB[th * 256 + 16 * m + (tl ^ m)], y[m]);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = kg_ld_tile(&tileB[rd + 256 * j]);
+    kg_twiddle16<SIGN>(x, p2);
+    kg_radix16<SIGN>(x, y);
+}
+
 // The same transform for kernels that run it once per workgroup (forward FFT of
 // a sample block, code-table build): one tile, one rolled radix-16 body, the
 // twiddles fetched per pass instead of being held (half the registers).

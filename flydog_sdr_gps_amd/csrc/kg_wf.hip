@@ -48,7 +48,7 @@ struct wf_chan_dev {
     float scale[WF_WIDTH], scale_div2[WF_WIDTH];
 };
 
-#define WF_LDS_BYTES (2 * SUB * sizeof(float2) + 16)       // + the claimed frame index
+#define WF_LDS_BYTES (2 * SUB * sizeof(float2) + 240 * sizeof(float2) + 16)       // + pass-1 twiddles + the claimed frame index
 
 template <bool TAPS>
 __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
@@ -66,11 +66,16 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     float2 *tileA = smem, *tileB = smem + SUB;
     float *pwr = (float *) smem;              // [4096], reuses tile A after the transforms
-    volatile int *lds_claim = (volatile int *) (smem + 2 * SUB);
+    float2 *tw1 = smem + 2 * SUB;
+    volatile int *lds_claim = (volatile int *) (tw1 + 240);
     const int t = threadIdx.x;
 
-    kg_tw4096 tw;
-    kg_tw4096_load(tw, tab4096, t);
+    // pass-1 twiddles from an LDS table, pass-2 twiddles in registers: the 30 registers saved hold the
+    // second parity of the frame and of the window (8-byte loads: 32 fewer load instructions per frame)
+    kg_tw1_fill(tw1, tab4096, t);
+    kg_tw15 p2;
+#pragma unroll
+    for (int j = 1; j < 16; j++) p2.w[j - 1] = kg_ld(&tab4096[j * t]);
     // combine twiddle W_8192^{k}, k = t + 256 m: W_8192^{t} (per thread) * W_32^{m} (immediate)
     const cf wbase = kg_ld(&tab8192[t]);
 
@@ -79,23 +84,26 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
     // the second, into the same sixteen registers; and once the second transform's inputs are formed
     // the next frame's even samples land there while the rest of this frame is computed.  The frame
     // fetch is the kernel's one HBM access: at the top of the loop its whole latency was exposed.
-    int raw[16];
-    auto fetch = [&](int f, int g) {
-        const int *src = (const int *) (iq + (size_t) f * WF_NFFT) + g;
+    int2 raw[16];
+    auto fetch = [&](int f) {
+        const int2 *src = (const int2 *) (iq + (size_t) f * WF_NFFT);
 #pragma unroll
-        for (int j = 0; j < 16; j++) raw[j] = src[2 * (t + 256 * j)];
+        for (int j = 0; j < 16; j++) raw[j] = src[t + 256 * j];         // samples 2 n1 (even) and 2 n1 + 1 (odd), n1 = t + 256 j
     };
-    // window values of this thread's sixteen samples of parity g (4-byte loads, L1 / L2 hits)
-    float wv[16];
-    auto fetch_window = [&](const float *win, int g) {
+    // window values of this thread's thirty-two samples (8-byte loads, L1 / L2 hits)
+    float2 wv[16];
+    auto fetch_window = [&](const float *win) {
 #pragma unroll
-        for (int j = 0; j < 16; j++) wv[j] = win[2 * (t + 256 * j) + g];
+        for (int j = 0; j < 16; j++) wv[j] = ((const float2 *) win)[t + 256 * j];
     };
-    auto windowed = [&](cf (&x)[16]) {
+    auto windowed = [&](cf (&x)[16], int g) {
         // sample_wf(): fi = (float)(s2_t)i * window[sn]  (:1054-1061)
 #pragma unroll
-        for (int j = 0; j < 16; j++)
-            x[j] = cf{(float) (short) (raw[j] & 0xffff) * wv[j], (float) (short) (raw[j] >> 16) * wv[j]};
+        for (int j = 0; j < 16; j++) {
+            const int r = g ? raw[j].y : raw[j].x;
+            const float w = g ? wv[j].y : wv[j].x;
+            x[j] = cf{(float) (short) (r & 0xffff) * w, (float) (short) (r >> 16) * w};
+        }
     };
 
     // Everything a frame needs first -- its channel number, that channel's window, its even samples
@@ -109,12 +117,11 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
     // The last workgroup to leave resets the two counters for the next launch.
     int f = blockIdx.x, fn = blockIdx.x + gridDim.x;
     int cid = chan_of[f];                     // grid <= nframes: every workgroup has a first frame
-    fetch(f, 0);
-    fetch_window(windows + (size_t) chans[cid].window_func * WF_NFFT, 0);
+    fetch(f);
+    fetch_window(windows + (size_t) chans[cid].window_func * WF_NFFT);
     for (;;) {
         const wf_chan_dev *ch = chans + cid;
         const int interp = ch->interp, dc = ch->dc, comp_on = ch->comp_on;
-        const float *win = windows + (size_t) ch->window_func * WF_NFFT;
         const bool more = fn < nframes;
         const int cid_next = chan_of[more ? fn : f];
         const int wfn_next = chans[cid_next].window_func;
@@ -122,19 +129,20 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
         if (t == 0) claimed = 2 * gridDim.x + __hip_atomic_fetch_add(&claim[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
         cf x[16], y0[16], y1[16];
-        windowed(x);
-        fetch(f, 1);
-        fetch_window(win, 1);
-        kg_subfft4096<-1>(x, y0, tileA, tileB, tw, t);
-        windowed(x);
-        if (more) fetch(fn, 0);
+        windowed(x, 0);
+        kg_subfft4096_l<-1>(x, y0, tileA, tileB, tw1, p2, t);
+        windowed(x, 1);
+        if (more) fetch(fn);                  // the next frame, both parities, into the registers just consumed
         // CIC compensation factors of this thread's sixteen bins, fetched here in one batch and used
         // after the transform (one load + wait per bin inside the power loop cost sixteen exposed L2
-        // round trips per frame); 1.0f where the frame is not compensated: x * 1.0f is exact
+        // round trips per frame)
+        // (a per-thread-contiguous copy of the table, four 16-byte loads, measured slower: 0.434 against 0.427 ms)
+        // (1.0f = CIC_comp[0] where the frame is not compensated: x * 1.0f is exact; a branch that skips
+        // those loads measured 20 % SLOWER -- it splits the block the scheduler interleaves)
         float cicv[16];
 #pragma unroll
         for (int m = 0; m < 16; m++) cicv[m] = cic_comp[comp_on ? t + 256 * m : 0];
-        kg_subfft4096<-1>(x, y1, tileA, tileB, tw, t);
+        kg_subfft4096_l<-1>(x, y1, tileA, tileB, tw1, p2, t);
         // (tile A, about to become pwr[], was last read before the second transform's
         // second barrier)
         // this thread's four pixels: run starts, run lengths, scales -- four vector loads
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
         __syncthreads();
         const int fnn = __builtin_amdgcn_readfirstlane(*lds_claim);    // wave-uniform; rewritten after >= 6 barriers
         // the next frame's first window values arrive during the pixel stage
-        fetch_window(windows + (size_t) wfn_next * WF_NFFT, 0);
+        fetch_window(windows + (size_t) wfn_next * WF_NFFT);
         cid = cid_next;
 
         // pixels 4t .. 4t+3.  The interpolation mode is the frame's (wave-uniform); the run lengths
