@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
     const int *__restrict__ chan_of,          // [nframes]
     const wf_chan_dev *__restrict__ chans,
     const float *__restrict__ windows,        // [4][8192]
-    const float *__restrict__ cic_comp,       // [8192]
+    const float *__restrict__ cic_comp,       // [8192], kg_wf_set_tables' order: pairs of bins, then 4096 x 1.0f
     const float2 *__restrict__ tab4096, const float2 *__restrict__ tab8192,
     int nframes,
     unsigned char *__restrict__ out,          // [nframes][1024]
@@ -140,8 +140,11 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
         // (1.0f = CIC_comp[0] where the frame is not compensated: x * 1.0f is exact; a branch that skips
         // those loads measured 20 % SLOWER -- it splits the block the scheduler interleaves)
         float cicv[16];
+        {
+            const float2 *cp = (const float2 *) cic_comp + (comp_on ? 0 : 2048) + t;
 #pragma unroll
-        for (int m = 0; m < 16; m++) cicv[m] = cic_comp[comp_on ? t + 256 * m : 0];
+            for (int i = 0; i < 8; i++) { const float2 v = cp[256 * i]; cicv[2 * i] = v.x; cicv[2 * i + 1] = v.y; }
+        }
         kg_subfft4096_l<-1>(x, y1, tileA, tileB, tw1, p2, t);
         // (tile A, about to become pwr[], was last read before the second transform's
         // second barrier)
@@ -330,7 +333,15 @@ int kg_wf_set_tables(kg_wf *w, const float *windows, const float *cic_comp)
     if (rc) return rc;
     hipStream_t st = w->ctx->stream;
     KG_HIP(hipMemcpyAsync(w->d_windows, windows, sizeof(float) * 4 * WF_NFFT, hipMemcpyHostToDevice, st));
-    KG_HIP(hipMemcpyAsync(w->d_cic, cic_comp, sizeof(float) * WF_NFFT, hipMemcpyHostToDevice, st));
+    // device copy in the frame kernel's own order: the factors of bins t + 256 m and t + 256 (m + 1), m
+    // even, are adjacent at (m / 2) 512 + 2 t: eight lane-contiguous 8-byte loads per frame instead of
+    // sixteen 4-byte ones.  Entries 4096.. hold 1.0f: an uncompensated frame reads those (x * 1.0f is exact).
+    {
+        std::vector<float> tr(WF_NFFT, 1.0f);
+        for (int t = 0; t < 256; t++)
+            for (int m = 0; m < 16; m++) tr[(m >> 1) * 512 + 2 * t + (m & 1)] = cic_comp[t + 256 * m];
+        KG_HIP(hipMemcpy(w->d_cic, tr.data(), sizeof(float) * WF_NFFT, hipMemcpyHostToDevice));
+    }
     KG_HIP(hipStreamSynchronize(st));
     w->tables_set = true;
     return KG_OK;
