@@ -126,7 +126,7 @@ struct ddc_chan {
 DDC_DEV int mix24(int adc, int dds)
 {
     const int m = adc * dds;
-    return (m >> 6) + ((m >> 5) & 1);
+    return (m + 32) >> 6;                     // = (m >> 6) + bit 5 of m, one instruction fewer (|m| < 2^30)
 }
 
 #define DDC_THREADS 256

@@ -88,7 +88,7 @@ struct rx_chan {
 RX_DEV int mix22(int adc, int dds)            // iq_mixer.v:43-51 with OUT_WIDTH 22: (m >> 8) + bit 7
 {
     const int m = adc * dds;
-    return (m >> 8) + ((m >> 7) & 1);
+    return (m + 128) >> 8;                    // = (m >> 8) + bit 7 of m (|m| < 2^30)
 }
 RX_DEV int sx(int v, int bits) { return (v << (32 - bits)) >> (32 - bits); }
 RX_DEV long long sx64(long long v, int bits) { return (v << (64 - bits)) >> (64 - bits); }
