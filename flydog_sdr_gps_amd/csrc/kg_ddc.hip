@@ -155,8 +155,9 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
     const int r = blockIdx.x * DDC_THREADS + threadIdx.x;
     if (r >= nruns) return;
     const long s0 = (long) r * L, s1 = (s0 + L < n) ? s0 + L : n;
-    const u64 M48 = (1ull << 48) - 1;
-    u64 ph = (ch.phase + (u64) s0 * ch.phase_inc) & M48;
+    // the 48-bit accumulator sits in the TOP bits of a 64-bit register: it wraps by itself (no mask per sample)
+    u64 ph = (ch.phase + (u64) s0 * ch.phase_inc) << 16;
+    const u64 inc16 = ch.phase_inc << 16;
     const int log2r = ch.log2r;
     const u64 Rm1 = (1ull << log2r) - 1;
     const int shift = 65 - 5 * log2r;         // cic_prune_var.v:224-247
@@ -201,9 +202,9 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
             for (int k = 0; k < 4; k++) I[k] = Q[k] = 0;
         }
         auto step = [&](int a) {
-            const u32 e = tab[ph >> 35];
+            const u32 e = tab[ph >> 51];
             const long long mi = mix24(a, (short) (e & 0xffff)), mq = mix24(a, (short) (e >> 16));
-            ph = (ph + ch.phase_inc) & M48;
+            ph += inc16;
             I[0] += (u64) mi; I[1] += I[0]; I[2] += I[1]; I[3] += I[2];
             Q[0] += (u64) mq; Q[1] += Q[0]; Q[2] += Q[1]; Q[3] += Q[2];
             if (PASS_B) {
@@ -240,9 +241,9 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
                     samples8(t, buf);
 #pragma unroll
                     for (int w = 0; w < 8; w++) {
-                        const u32 e = tab[ph >> 35];
+                        const u32 e = tab[ph >> 51];
                         const long long mi = mix24(buf[w], (short) (e & 0xffff)), mq = mix24(buf[w], (short) (e >> 16));
-                        ph = (ph + ch.phase_inc) & M48;
+                        ph += inc16;
                         I[0] += (u64) mi; I[1] += I[0]; I[2] += I[1]; I[3] += I[2];
                         Q[0] += (u64) mq; Q[1] += Q[0]; Q[2] += Q[1]; Q[3] += Q[2];
                         i5i = (i5i + (u32) (I[3] >> sh5)) & 0x0FFFFFFFu;
@@ -277,9 +278,9 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
         }
         if (PASS_B && log2r <= 2 && c == 0 && (o & 3) == 0 && ((uintptr_t) c0i & 15) == 0 && ((uintptr_t) c0q & 15) == 0) {
             auto quiet = [&](int a) {                     // step() without the strobe store
-                const u32 e = tab[ph >> 35];
+                const u32 e = tab[ph >> 51];
                 const long long mi = mix24(a, (short) (e & 0xffff)), mq = mix24(a, (short) (e >> 16));
-                ph = (ph + ch.phase_inc) & M48;
+                ph += inc16;
                 I[0] += (u64) mi; I[1] += I[0]; I[2] += I[1]; I[3] += I[2];
                 Q[0] += (u64) mq; Q[1] += Q[0]; Q[2] += Q[1]; Q[3] += Q[2];
                 i5i = (i5i + (u32) (I[3] >> sh5)) & 0x0FFFFFFFu;
@@ -344,9 +345,9 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
         for (int k = 0; k < 4; k++) { SI.i[k] = mk128(0, 0); SQ.i[k] = mk128(0, 0); }
     }
     auto step = [&](int a) {
-        const u32 e = tab[ph >> 35];
+        const u32 e = tab[ph >> 51];
         const long long mi = mix24(a, (short) (e & 0xffff)), mq = mix24(a, (short) (e >> 16));
-        ph = (ph + ch.phase_inc) & M48;
+        ph += inc16;
         // in = sign-extended m << shift, 128 bits
         const u128 xi = mk128((u64) mi << shift, (u64) (shift ? mi >> (64 - shift) : mi >> 63));
         const u128 xq = mk128((u64) mq << shift, (u64) (shift ? mq >> (64 - shift) : mq >> 63));
@@ -391,7 +392,6 @@ __global__ __launch_bounds__(256) void ddc_wf_bypass_kernel(
     __syncthreads();
     const int li = bypass_list[blockIdx.y];
     const ddc_chan ch = chans[chan_list[li]];
-    const u64 M48 = (1ull << 48) - 1;
     // persistent over the 2048-sample blocks of the channel: the 32 KiB table is staged once per
     // workgroup, not once per 8 KiB of output
     const long nblk = (n + 2047) / 2048;
@@ -403,7 +403,8 @@ __global__ __launch_bounds__(256) void ddc_wf_bypass_kernel(
         for (int g = 0; g < 2; g++) {
             const long t0 = blk * 2048 + g * 1024 + 4 * (long) threadIdx.x;
             if (t0 >= n) continue;
-            u64 ph = (ch.phase + (u64) t0 * ch.phase_inc) & M48;
+            u64 ph = (ch.phase + (u64) t0 * ch.phase_inc) << 16;    // top-aligned: wraps by itself
+            const u64 inc16 = ch.phase_inc << 16;
             short2 *o = out + (long) li * out_stride + t0;
             short a[4];
             const bool full = t0 + 4 <= n;
@@ -416,10 +417,10 @@ __global__ __launch_bounds__(256) void ddc_wf_bypass_kernel(
             short2 r[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const u32 e = tab[ph >> 35];
+                const u32 e = tab[ph >> 51];
                 const int mi = mix24(a[q], (short) (e & 0xffff)), mq = mix24(a[q], (short) (e >> 16));
                 r[q] = make_short2((short) (mi >> 8), (short) (mq >> 8));
-                ph = (ph + ch.phase_inc) & M48;
+                ph += inc16;
             }
             if (full && (((uintptr_t) o) & 15) == 0) {
                 int4 w0;

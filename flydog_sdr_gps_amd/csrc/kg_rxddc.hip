@@ -111,8 +111,9 @@ __global__ __launch_bounds__(RX_THREADS) void rx1_run_kernel(
     const int r = blockIdx.x * RX_THREADS + threadIdx.x;
     if (r >= nruns) return;
     const long s0 = (long) r * L, s1 = (s0 + L < n) ? s0 + L : n;
-    const u64 M48 = (1ull << 48) - 1;
-    u64 ph = (ch.phase + (u64) s0 * ch.phase_inc) & M48;
+    // the 48-bit accumulator sits in the TOP bits of a 64-bit register: it wraps by itself (no mask per sample)
+    u64 ph = (ch.phase + (u64) s0 * ch.phase_inc) << 16;
+    const u64 inc16 = ch.phase_inc << 16;
     u64 a1i = 0, a2i = 0, a1q = 0, a2q = 0;
     u64 *base = st + (long) li * 4 * nruns;
     if (PASS_B) { a1i = base[0 * nruns + r]; a2i = base[1 * nruns + r]; a1q = base[2 * nruns + r]; a2q = base[3 * nruns + r]; }
@@ -122,9 +123,9 @@ __global__ __launch_bounds__(RX_THREADS) void rx1_run_kernel(
     long o = (long) (c0 / RX_R1);             // strobes of this call before the run
     u32 *c0i = c0rel + ((long) li * 2 + 0) * max_out, *c0q = c0rel + ((long) li * 2 + 1) * max_out;
     auto step = [&](int a) {
-        const u32 e = tab[ph >> 35];
+        const u32 e = tab[ph >> 51];
         const long long mi = mix22(a, (short) (e & 0xffff)), mq = mix22(a, (short) (e >> 16));
-        ph = (ph + ch.phase_inc) & M48;
+        ph += inc16;
         a1i += (u64) mi; a2i += a1i;
         a1q += (u64) mq; a2q += a1q;
         if (PASS_B) {
