@@ -1050,13 +1050,31 @@ static int check_block(kg_acq *a, int block, const void *p, const char *who)
 }
 
 // Caller's host samples -> the block's device staging area, through a pinned slot.
+// One block's input, pinned host memory -> its staging slot in HBM: read by a kernel (the pinned buffer is
+// mapped into the device's address space), 16 bytes per lane.  An enqueued hipMemcpyAsync of this size
+// costs 250 us more under the HIP runtime PyTorch 2.10 bundles (ROCm 7.0) than under the system's 7.2
+// (`tools/time_acq_host.py`, synchronous int16 IQ: 374 against 128 us per block); a kernel costs the
+// same under both.
+__global__ __launch_bounds__(256) void acq_stage_copy_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
+{
+    const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+
 static int stage_host_block(kg_acq *a, uint8_t *d_stage, const void *src, size_t bytes)
 {
     const int k = a->pin_next;
     a->pin_next = (k + 1) & 3;
     KG_HIP(hipEventSynchronize(a->ev_pin[k]));           // never-recorded events are complete
     memcpy(a->h_pin[k], src, bytes);
-    KG_HIP(hipMemcpyAsync(d_stage, a->h_pin[k], bytes, hipMemcpyHostToDevice, a->fstream));
+    if ((bytes & 15) == 0 && bytes >= 65536) {
+        const size_t n16 = bytes / 16;
+        hipLaunchKernelGGL(acq_stage_copy_kernel, dim3((unsigned) ((n16 + 255) / 256)), dim3(256), 0, a->fstream,
+                           (const uint4 *) a->h_pin[k], (uint4 *) d_stage, n16);
+        KG_HIP(hipGetLastError());
+    } else {
+        KG_HIP(hipMemcpyAsync(d_stage, a->h_pin[k], bytes, hipMemcpyHostToDevice, a->fstream));
+    }
     KG_HIP(hipEventRecord(a->ev_pin[k], a->fstream));
     return KG_OK;
 }
