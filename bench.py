@@ -280,13 +280,31 @@ def measured_traffic(workload, units):
         return None, "no committed PMC pass for this configuration"
 
 
+PREROLL_S = 0.12
+
+
+def preroll(step, warmup):
+    """The W untimed warm-up steps, then more untimed ones until about PREROLL_S seconds of work have run:
+    an MI355X that has been idle reaches its steady clock only after tens of milliseconds of load (measured
+    on the correlator: 0.96 ms per launch at the start, 0.84 after 20 launches, 0.80 after 60), and a short
+    timed region would otherwise average that ramp.  Never part of the timed region."""
+    import torch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(max(1, warmup)):
+        step()
+    torch.cuda.synchronize()
+    est = max((time.perf_counter() - t0) / max(1, warmup), 1e-5)
+    for _ in range(min(4000, int(PREROLL_S / est))):
+        step()
+
+
 def timed_steps(dist, step, steps, warmup):
     """W untimed steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides, max
     over ranks; then the same K steps once more with a device event between steps for the spread
     (not part of the headline time).  -> (seconds, host enqueue seconds, spread dict)"""
     import torch
-    for _ in range(warmup):
-        step()
+    preroll(step, warmup)
     dist.barrier()                                   # barrier, then synchronize
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -764,8 +782,7 @@ def run_receivers(args, dist):
     bank = ReceiverBank(dist.local_rank, dev, NR, n, dist.rank * NR, two)   # this rank's slice of the receiver set
     step, counts, rows, pay = bank.step, bank.counts, bank.rows, bank.pay
 
-    for _ in range(args.warmup):
-        step()
+    preroll(step, args.warmup)
     dist.barrier()
     counts["frames"] = counts["audio_blocks"] = 0
     t0 = time.perf_counter()
@@ -839,7 +856,7 @@ def main():
     if world_env is None and args.gpus == 1 and not args.no_live_traffic:
         live_traffic_passes(args)                            # children; this process has not touched the GPU yet
     dist = Dist("gloo" if args.workload == "stub" else "nccl")
-    common = {"n_gpus": dist.world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+    common = {"n_gpus": dist.world, "steps": args.steps, "warmup": args.warmup, "preroll_s": PREROLL_S, "higher_is_better": True,
               "scaling": "weak", "vs_baseline": None, "data": "synthetic"}
     if args.workload == "stub":
         line = dict(run_stub(args, dist), **common)
