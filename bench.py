@@ -284,18 +284,23 @@ PREROLL_S = 0.12
 
 
 def preroll(step, warmup):
-    """The W untimed warm-up steps, then more untimed ones until about PREROLL_S seconds of work have run:
-    an MI355X that has been idle reaches its steady clock only after tens of milliseconds of load (measured
-    on the correlator: 0.96 ms per launch at the start, 0.84 after 20 launches, 0.80 after 60), and a short
-    timed region would otherwise average that ramp.  Never part of the timed region."""
+    """The W untimed warm-up steps, then more untimed ones until about PREROLL_S seconds of work have run
+    (at least 64 steps): an MI355X that has been idle reaches its steady clock only after tens of
+    milliseconds of load (measured on the correlator: 0.96 ms per launch at the start, 0.84 after 20
+    launches, 0.80 after 60), and the library's staging ring comes round for the first time at its 33rd
+    upload -- the HIP runtime's first blocking event wait costs the host 30 ms once per process.  A short
+    timed region would otherwise hold both.  Never part of the timed region."""
     import torch
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
     for _ in range(max(1, warmup)):
         step()
+    torch.cuda.synchronize()                         # one-time costs (code load, lazy allocations) are behind us
+    probe = max(4, min(warmup, 16))
+    t0 = time.perf_counter()
+    for _ in range(probe):
+        step()
     torch.cuda.synchronize()
-    est = max((time.perf_counter() - t0) / max(1, warmup), 1e-5)
-    for _ in range(min(4000, int(PREROLL_S / est))):
+    est = max((time.perf_counter() - t0) / probe, 1e-5)
+    for _ in range(min(4000, max(64, int(PREROLL_S / est)))):
         step()
 
 
