@@ -287,9 +287,9 @@ def preroll(step, warmup):
     """The W untimed warm-up steps, then more untimed ones until about PREROLL_S seconds of work have run
     (at least 64 steps): an MI355X that has been idle reaches its steady clock only after tens of
     milliseconds of load (measured on the correlator: 0.96 ms per launch at the start, 0.84 after 20
-    launches, 0.80 after 60), and the library's staging ring comes round for the first time at its 33rd
-    upload -- the HIP runtime's first blocking event wait costs the host 30 ms once per process.  A short
-    timed region would otherwise hold both.  Never part of the timed region."""
+    launches, 0.80 after 60), and the first time two streams of a process depend on each other (the DDC's
+    side stream) the HIP runtime stalls the GPU side for 30-50 ms, once per process, some thirty calls
+    in.  A short timed region would otherwise hold both.  Never part of the timed region."""
     import torch
     for _ in range(max(1, warmup)):
         step()
