@@ -169,7 +169,7 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
     u32 i5i = 0, i5q = 0;
     u32 c = (u32) (cnt0 & Rm1);                           // decimation counter, sample_no
     long o = (long) (cnt0 >> log2r);                      // index of the next strobe's output
-    u32 *c0i = c0rel + c0off[li], *c0q = c0i + nouts[li];
+    u32 *c0i = c0rel + c0off[li], *c0q = c0i + ((nouts[li] + 3) & ~3l);      // planes start 16-byte aligned
     // eight samples per round from one 16-byte load (runs start 128-byte aligned relative to
     // the block; an unaligned block or the ragged end of the last run go sample by sample)
     auto samples8 = [&](long t, short (&buf)[8]) {
@@ -612,11 +612,15 @@ __global__ __launch_bounds__(64 * DDC_SCAN_WAVES) void ddc_wf_scan_tau_kernel(
 // sign-extend the low `bits` bits
 DDC_DEV int sext32(int v, int bits) { return (v << (32 - bits)) >> (32 - bits); }
 
-// Combs + rounding, one thread per (channel, output).  cic_wf1.vh: comb widths
+// Combs + rounding, four consecutive outputs per thread.  cic_wf1.vh: comb widths
 // 23,22,21,20,20; their inputs drop 5,1,1,1,0 LSBs; out = comb5[19 -: 16] + comb5[3].
 // Channels decimate differently, so the grid is flat: workgroup w belongs to the list entry
 // li with wg_start[li] <= w < wg_start[li + 1] (bypass channels own none).  A workgroup first
-// puts the absolute integrator-5 values of its 256 outputs and the five before them in LDS.
+// puts the absolute integrator-5 values of its 1024 outputs and the five before them in LDS
+// (16-byte loads of the run-relative values: the I and Q planes of a channel start 16-byte aligned),
+// then every thread runs the five combs over a nine-value window: 30 differences for four outputs
+// where one output per thread took 15 each, and a quarter of the load and store instructions.
+#define DDC_COMB_TILE 1024
 __global__ __launch_bounds__(256) void ddc_wf_comb_kernel(
     const u32 *__restrict__ c0rel, const u32 *__restrict__ i5start, int log2L, int nruns,
     const long *__restrict__ c0off, const ddc_chan *__restrict__ chans, const int *__restrict__ chan_list, const long *__restrict__ nouts,
@@ -624,48 +628,76 @@ __global__ __launch_bounds__(256) void ddc_wf_comb_kernel(
     const int *__restrict__ wg_start, int nlist,
     short2 *__restrict__ out, long out_stride, u32 *__restrict__ hist_out)   // [nlist][2][5]
 {
-    __shared__ int s_c0[2][256 + 5];
+    __shared__ int s_c0[2][DDC_COMB_TILE + 8];       // [d]: output o0 - 8 + d (three unused slots keep 16-byte rows)
     int lo = 0, hi = nlist;                   // wg_start[lo] <= blockIdx.x < wg_start[hi]
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int) blockIdx.x >= wg_start[mid]) lo = mid; else hi = mid; }
     const int li = lo, t = threadIdx.x;
     const ddc_chan *ch = chans + chan_list[li];
     const int log2r = ch->log2r;
-    const long nout = nouts[li];
-    const long o0 = (long) (blockIdx.x - wg_start[li]) * 256;
+    const long nout = nouts[li], plane = (nout + 3) & ~3l;
+    const long o0 = (long) (blockIdx.x - wg_start[li]) * DDC_COMB_TILE;
     const u32 base = cnt_before[li];
-    for (int e = t; e < 2 * (256 + 5); e += 256) {
-        const int comp = e >= 256 + 5, d = comp ? e - (256 + 5) : e;
-        const long oo = o0 - 5 + d;
-        u32 v = 0;
-        if (oo < 0) {
-            v = ch->hist[comp][5 + oo];       // strobes of earlier calls (zero after a reset)
-        } else if (oo < nout) {
-            const long g = ((oo + 1) << log2r) - 1 - (long) base;    // sample index of the strobe
-            const int run = (int) (g >> log2L);
-            v = (c0rel[c0off[li] + comp * nout + oo] + i5start[((long) li * 2 + comp) * nruns + run]) & 0x0FFFFFFFu;
-            if (oo >= nout - 5) hist_out[((long) li * 2 + comp) * 5 + (int) (oo - (nout - 5))] = v;
+    auto absolute = [&](int comp, long oo, u32 rel) -> u32 {
+        const long g = ((oo + 1) << log2r) - 1 - (long) base;    // sample index of the strobe
+        const int run = (int) (g >> log2L);
+        return (rel + i5start[((long) li * 2 + comp) * nruns + run]) & 0x0FFFFFFFu;
+    };
+#pragma unroll
+    for (int comp = 0; comp < 2; comp++) {
+        const u32 *src = c0rel + c0off[li] + comp * plane;
+        // the four outputs of this thread
+        const long oo = o0 + 4 * t;
+        u32 v[4] = {0, 0, 0, 0};
+        if (oo + 4 <= nout) {
+            const uint4 q = *(const uint4 *) (src + oo);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+            for (int k = 0; k < 4; k++) if (oo + k < nout) v[k] = src[oo + k];
         }
-        s_c0[comp][d] = sext32((int) v, 28);
+        for (int k = 0; k < 4; k++) {
+            u32 a = 0;
+            if (oo + k < nout) {
+                a = absolute(comp, oo + k, v[k]);
+                if (oo + k >= nout - 5) hist_out[((long) li * 2 + comp) * 5 + (int) (oo + k - (nout - 5))] = a;
+            }
+            s_c0[comp][8 + 4 * t + k] = sext32((int) a, 28);
+        }
+        // the five outputs before the tile: strobes of earlier calls (zero after a reset) or earlier tiles
+        if (t < 5) {
+            const long pb = o0 - 5 + t;
+            const u32 a = pb < 0 ? ch->hist[comp][5 + pb] : absolute(comp, pb, src[pb]);
+            s_c0[comp][3 + t] = sext32((int) a, 28);
+        }
     }
     __syncthreads();
-    const long o = o0 + t;
-    if (o >= nout) return;
-    short res[2];
-    for (int comp = 0; comp < 2; comp++) {
-        // comb k output at position d needs its input at d and d-1
-        const int W[5] = {23, 22, 21, 20, 20}, D[5] = {5, 1, 1, 1, 0};
-        int v[6];
-        for (int d = 0; d < 6; d++) v[d] = s_c0[comp][t + d];
-        int cnt = 6;
-        for (int k = 0; k < 5; k++) {
-            int x[6];
-            for (int d = 0; d < cnt; d++) x[d] = sext32(v[d] >> D[k], W[k]);
-            for (int d = 1; d < cnt; d++) v[d - 1] = sext32(x[d] - x[d - 1], W[k]);
-            cnt--;
+    const long o = o0 + 4 * t;
+    short res[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    if (o < nout) {
+        for (int comp = 0; comp < 2; comp++) {
+            // comb k output at position d needs its input at d and d-1
+            const int W[5] = {23, 22, 21, 20, 20}, D[5] = {5, 1, 1, 1, 0};
+            int v[9];
+            for (int d = 0; d < 9; d++) v[d] = s_c0[comp][3 + 4 * t + d];
+            int cnt = 9;
+            for (int k = 0; k < 5; k++) {
+                int x[9];
+                for (int d = 0; d < cnt; d++) x[d] = sext32(v[d] >> D[k], W[k]);
+                for (int d = 1; d < cnt; d++) v[d - 1] = sext32(x[d] - x[d - 1], W[k]);
+                cnt--;
+            }
+            for (int k = 0; k < 4; k++) res[comp][k] = (short) ((v[k] >> 4) + ((v[k] >> 3) & 1));
         }
-        res[comp] = (short) ((v[0] >> 4) + ((v[0] >> 3) & 1));
     }
-    out[(long) li * out_stride + o] = make_short2(res[0], res[1]);
+    // out through LDS, so that the stores are lane-contiguous whatever the alignment of the caller's rows
+    __syncthreads();                          // every thread has read its window
+    int *s_out = &s_c0[0][0];
+    for (int k = 0; k < 4; k++) s_out[4 * t + k] = (int) ((unsigned short) res[0][k] | ((unsigned) (unsigned short) res[1][k] << 16));
+    __syncthreads();
+    short2 *dst = out + (long) li * out_stride + o0;
+    for (int k = 0; k < 4; k++) {
+        const int e = t + 256 * k;
+        if (o0 + e < nout) { const int w = s_out[e]; dst[e] = make_short2((short) (w & 0xffff), (short) (w >> 16)); }
+    }
 }
 
 // after a call: phase, counter, comb history
@@ -861,9 +893,9 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
         if (h_nouts[i] > max_nout) max_nout = h_nouts[i];
         if (nouts) nouts[i] = h_nouts[i];
         h_off[i] = c0_need;
-        if (c.log2r) c0_need += 2 * h_nouts[i];
+        if (c.log2r) c0_need += 2 * ((h_nouts[i] + 3) & ~3l);             // I and Q planes, each a multiple of 16 bytes
         h_wg[i] = (int) comb_wgs;
-        if (c.log2r) comb_wgs += (h_nouts[i] + 255) / 256;
+        if (c.log2r) comb_wgs += (h_nouts[i] + DDC_COMB_TILE - 1) / DDC_COMB_TILE;
         else h_bypass.push_back(i);
         if (c.log2r) { h_run.push_back(i); (c.log2r <= 3 ? h_small : h_rest).push_back(i); }
     }
