@@ -701,6 +701,17 @@ class ReceiverBank:
         self.ctx = ctx = Context(local_rank, torch.cuda.current_stream(dev).cuda_stream)
         self.side = torch.cuda.Stream(device=dev) if two_streams else None
         self.ctx_au = ctx_au = Context(local_rank, self.side.cuda_stream) if two_streams else ctx
+        # the tails of both chains are sequential per-channel recurrences (ADPCM of the waterfall row; CAgc and
+        # ADPCM of the audio block: one lane per channel, 100-140 us each whatever the load): on streams of
+        # their own they no longer stand between a chain's DDC of this step and of the next one
+        self.tails = two_streams and os.environ.get("KIWIGPU_BENCH_TAIL_STREAMS") != "0"
+        self.s_pk = torch.cuda.Stream(device=dev) if self.tails else None
+        self.s_tail = torch.cuda.Stream(device=dev) if self.tails else None
+        self.ctx_pk = Context(local_rank, self.s_pk.cuda_stream) if self.tails else ctx
+        self.ctx_tail = Context(local_rank, self.s_tail.cuda_stream) if self.tails else ctx_au
+        self.main = torch.cuda.current_stream(dev)
+        self.ev_frames, self.ev_pk, self.ev_fir, self.ev_tail = (torch.cuda.Event() for _ in range(4))
+        self.pk_pending = self.tail_pending = False
         self.adc_host = adc_block(n, 0x5EED0004)                      # every GPU sees the SAME stream (configs[3])
         self.adc = torch.from_numpy(self.adc_host).to(dev)
         self.chans = list(range(NR))
@@ -720,8 +731,8 @@ class ReceiverBank:
         self.rx = RxDdc(ctx_au, nchan=NR, max_samples=n)
         self.nrec_max = nrec_max = n // RX_DECIM + 2
         self.fir = FastFir(ctx_au, nchan=NR, max_in=nrec_max)
-        self.P = Post(ctx_au, nchan=NR)
-        self.A = Adpcm(ctx_au, nchan=NR)
+        self.P = Post(self.ctx_tail, nchan=NR)
+        self.A = Adpcm(self.ctx_tail, nchan=NR)
         self.fs = fs = self.ADC_CLOCK / RX_DECIM
         self.rx_inc = []
         for ch in range(NR):
@@ -753,12 +764,21 @@ class ReceiverBank:
         nrec = int(nr.min())
         assert nrec == int(nr.max())
         snd.unpack_rows_dev(self.ctx_au, self.raw.data_ptr(), nrec_max, nrec, NR, self.xin.data_ptr(), nrec_max)
+        if self.tails and self.tail_pending:
+            self.side.wait_event(self.ev_tail)               # the tail of the step before has read firo
+            self.tail_pending = False
         nout = self.fir.process_dev(chans, self.xin.data_ptr(), nrec_max, nrec, self.firo.data_ptr(), 1024)
         self.last.update(nrec=nrec, nout=int(nout[0]))
         assert int(nout.min()) == int(nout.max())
         if int(nout[0]) == 512:
+            if self.tails:
+                self.ev_fir.record(self.side)
+                self.s_tail.wait_event(self.ev_fir)
             self.P.process_dev(chans, self.firo.data_ptr(), 1024, 512, self.s16.data_ptr(), 0, 0, 512)
             self.A.encode_dev(chans, self.s16.data_ptr(), 512, 512, self.pay.data_ptr(), 256)
+            if self.tails:
+                self.ev_tail.record(self.s_tail)
+                self.tail_pending = True
             self.counts["audio_blocks"] += NR
 
     def step(self):
@@ -768,8 +788,17 @@ class ReceiverBank:
         assert int(nw.min()) >= 8192
         self.last["nw"] = nw
         self.frames.copy_(self.wf_iq[:, :8192])             # the frame each receiver's waterfall takes this step
+        if self.tails and self.pk_pending:
+            self.main.wait_event(self.ev_pk)                 # the packets of the step before have read rows
+            self.pk_pending = False
         self.W.frames_dev(self.chans, self.frames.data_ptr(), self.rows.data_ptr())
-        wire.wf_packets_dev(self.ctx, self.rows.data_ptr(), 1024, self.infos, self.pkts.data_ptr())
+        if self.tails:
+            self.ev_frames.record(self.main)
+            self.s_pk.wait_event(self.ev_frames)
+        wire.wf_packets_dev(self.ctx_pk, self.rows.data_ptr(), 1024, self.infos, self.pkts.data_ptr())
+        if self.tails:
+            self.ev_pk.record(self.s_pk)
+            self.pk_pending = True
         self.counts["frames"] += self.NR
 
     def close(self):
