@@ -952,10 +952,30 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
         s_bypass = (const int *) (b + o_by); s_selrun = (const int *) (b + o_run);
         s_selsmall = (const int *) (b + o_small); s_selrest = (const int *) (b + o_rest);
     }
+    // The object's second stream: work that does not depend on the pass A -> scan -> pass B chain runs beside
+    // it -- the R = 1 bypass channels (no filter state at all) from the start, pass B of the R <= 8 channels
+    // (below) -- and joins before the call's last kernels.  KIWIGPU_DDC_SIDE=0: everything in line.
+    bool side_on = true, side_used = false;
+    if (const char *e = getenv("KIWIGPU_DDC_SIDE")) side_on = atoi(e) != 0;
+    auto side_ready = [&]() -> int {
+        if (!d->side) {
+            KG_HIP(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
+            KG_HIP(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
+            KG_HIP(hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming));
+        }
+        return KG_OK;
+    };
     if (!h_bypass.empty()) {
+        hipStream_t bst = st;
+        if (side_on && !h_run.empty()) {
+            if ((rc = side_ready())) return rc;
+            KG_HIP(hipEventRecord(d->ev_fork, st));                  // behind the staged tables
+            KG_HIP(hipStreamWaitEvent(d->side, d->ev_fork, 0));
+            bst = d->side; side_used = true;
+        }
         const long nblk_by = (n + 2047) / 2048, cap_by = (long) d->ctx->num_cus * 4;   // LDS: 32 KiB each, 4 per CU
         hipLaunchKernelGGL(ddc_wf_bypass_kernel, dim3((unsigned) (nblk_by < cap_by ? nblk_by : cap_by), (unsigned) h_bypass.size()), dim3(256),
-                           0, st, (const short *) d_adc, (long) n, (const ddc_chan *) d->d_chans, s_list,
+                           0, bst, (const short *) d_adc, (long) n, (const ddc_chan *) d->d_chans, s_list,
                            s_bypass, (const u32 *) d->d_nco, (short2 *) d_out, (long) out_stride);
         KG_HIP(hipGetLastError());
     }
@@ -990,15 +1010,11 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
     // it pays once those channels fill the GPU by themselves, otherwise the scattered stores are cheaper
     // than the smaller grid.
     bool staged = (long) h_small.size() * nruns >= (long) d->ctx->num_cus * 4 * 2 * 64;
-    bool beside = !h_small.empty() && !h_rest.empty();
+    const bool beside = side_on && !h_small.empty() && !h_rest.empty();
     if (const char *e = getenv("KIWIGPU_DDC_STAGED")) staged = atoi(e) != 0 && !h_small.empty();
-    if (const char *e = getenv("KIWIGPU_DDC_SIDE")) beside = beside && atoi(e) != 0;
     if (beside) {
-        if (!d->side) {
-            KG_HIP(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
-            KG_HIP(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
-            KG_HIP(hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming));
-        }
+        if ((rc = side_ready())) return rc;
+        side_used = true;
         KG_HIP(hipEventRecord(d->ev_fork, st));
         KG_HIP(hipStreamWaitEvent(d->side, d->ev_fork, 0));
         hipLaunchKernelGGL(ddc_wf_run_kernel<true>, dim3(gx, (unsigned) h_small.size()), dim3(DDC_THREADS), DDC_STAGE_BYTES, d->side,
@@ -1006,13 +1022,11 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
                            (const u32 *) d->d_nco, d->d_local, d->d_c0rel, d->d_tau, s_c0off,
                            s_nouts, s_selsmall, DDC_STAGE_BYTES);
         KG_HIP(hipGetLastError());
-        KG_HIP(hipEventRecord(d->ev_join, d->side));
         hipLaunchKernelGGL(ddc_wf_run_kernel<true>, dim3(gx, (unsigned) h_rest.size()), dim3(DDC_THREADS), 0, st,
                            (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, s_list,
                            (const u32 *) d->d_nco, d->d_local, d->d_c0rel, d->d_tau, s_c0off,
                            s_nouts, s_selrest, 0);
         KG_HIP(hipGetLastError());
-        KG_HIP(hipStreamWaitEvent(st, d->ev_join, 0));
     } else if (staged) {
         hipLaunchKernelGGL(ddc_wf_run_kernel<true>, dim3(gx, (unsigned) h_small.size()), dim3(DDC_THREADS), DDC_STAGE_BYTES, st,
                            (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, s_list,
@@ -1032,6 +1046,10 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
                            (const u32 *) d->d_nco, d->d_local, d->d_c0rel, d->d_tau, s_c0off,
                            s_nouts, s_selrun, 0);
         KG_HIP(hipGetLastError());
+    }
+    if (side_used) {                              // everything the second stream did is behind this point of the first
+        KG_HIP(hipEventRecord(d->ev_join, d->side));
+        KG_HIP(hipStreamWaitEvent(st, d->ev_join, 0));
     }
     hipLaunchKernelGGL(ddc_wf_scan_tau_kernel, dim3(2 * nlist), dim3(64 * DDC_SCAN_WAVES), 0, st, d->d_tau, nruns, d->d_chans,
                        s_list);
