@@ -46,14 +46,15 @@ def soak(name, trial):
 
 def trial_wfddc():
     nch = int(rng.integers(1, 5))
-    d = Ddc(ctx, nchan=nch, max_samples=1 << 17)
+    big = rng.random() < 0.15                        # long blocks: the carry scan cut into chunks across workgroups
+    d = Ddc(ctx, nchan=nch, max_samples=1 << (20 if big else 17))
     incs = [int(rng.integers(0, 1 << 48)) for _ in range(nch)]
     l2 = [int(rng.integers(0, 14)) for _ in range(nch)]
     states = [None] * nch
     for ch in range(nch):
         d.set_wf(ch, incs[ch], 1 << l2[ch])
     for _ in range(int(rng.integers(1, 4))):
-        n = int(rng.integers(1, 1 << 16))
+        n = int(rng.integers(1 << 17, 1 << 20)) if big else int(rng.integers(1, 1 << 16))
         adc = adc_block(n)
         got = d.push(adc, list(range(nch)))
         for ch in range(nch):
