@@ -194,10 +194,46 @@ def trial_acq():
         assert abs(float(g["snr"]) - w_snr) <= 1e-3 * max(w_snr, 1.0), ("acq noise snr", g["snr"], w_snr)
 
 
-for name, fn in (("acq", trial_acq), ("wf ddc", trial_wfddc), ("rx ddc", trial_rxddc), ("fastfir", trial_fir), ("post", trial_post), ("wire", trial_wire)):
+_wf = {}
+
+
+def trial_wf():
+    """Waterfall frames: random zoom / start / interpolation / window / CIC compensation / inversion on
+    random frames, batched over a random frame -> channel map (the device copy of the map is cached)."""
+    from flydog_sdr_gps_amd import Waterfall, WfParams, wf
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tests.test_wf_gpu import check_row, db_bound, oracle_frame
+    if not _wf:
+        _wf["tables"] = (wf.window_functions(), wf.cic_comp_table())
+        _wf["w"] = Waterfall(ctx, nchan=6)
+        _wf["w"].set_tables(*_wf["tables"])
+    w, tables = _wf["w"], _wf["tables"]
+    cfg = []
+    for ch in range(6):
+        zoom = int(rng.integers(0, 15))
+        inv = bool(rng.integers(0, 2))
+        p = WfParams.for_zoom(zoom, float(rng.uniform(0, 2.0e7)), spectral_inversion=inv)
+        interp = int(rng.choice([wf.WF_MAX, wf.WF_MIN, wf.WF_LAST, wf.WF_DROP, wf.WF_CMA]))
+        win = int(rng.integers(0, 4))
+        comp = bool(rng.integers(0, 2))
+        w.set_channel(ch, p, interp=interp, window_func=win, cic_comp=comp, spectral_inversion=inv)
+        cfg.append((p, interp, win, comp, inv))
+    nfr = int(rng.integers(1, 9))
+    chan_of = [int(c) for c in rng.integers(0, 6, nfr)]
+    iqs = [synth.wf_iq_frame(seed=int(rng.integers(0, 1 << 30)), noise_dbfs=float(rng.uniform(-70, -20))) for _ in range(nfr)]
+    out = w.frames(chan_of, np.stack(iqs))
+    for k, ch in enumerate(chan_of):
+        p, interp, win, comp, inv = cfg[ch]
+        w_out, _, w_po, w_dB = oracle_frame(ko, tables, iqs[k], p, interp, win, comp, False, inv)
+        check_row(out[k], w_out, w_dB, db_bound(w_po))
+
+
+for name, fn in (("acq", trial_acq), ("wf ddc", trial_wfddc), ("rx ddc", trial_rxddc), ("fastfir", trial_fir), ("post", trial_post), ("wire", trial_wire), ("wf frames", trial_wf)):
     soak(name, fn)
 print("failures:", fails)
 if _acq:
     _acq["s"].close()
+if _wf:
+    _wf["w"].close()
 ctx.close()
 sys.exit(1 if fails else 0)
