@@ -19,14 +19,18 @@ Workloads (all inputs synthetic, seeded, resident in HBM before the timed region
              256 MiB Infinity Cache so that the HBM figure is an HBM figure.
   ddc14      BASELINE configs[2], DDC half: NCO mix + 5-stage pruned CIC for the 14 channels on a
              16-bit ADC stream.
-  all        (default) the three above; ONE JSON line whose top level is `acq` (metric, value,
+  cfg2_chain BASELINE configs[2] end to end: 2^24 ADC samples -> the 14 DDC channels -> every
+             8192-sample frame those complete (~8190, read where the DDC left them) -> rows, one step
+             (the loop of rx/rx_waterfall.cpp:930-939 at 100 % duty).
+  receivers  BASELINE configs[3]: --receivers virtual receivers per GPU (waterfall + audio chain).
+  acq10ms    BASELINE configs[4]: joint L1 C/A + QZSS + Galileo E1B, 10 ms coherent (65536-point
+             transforms), 256 Doppler bins, all 59 SVs.  --shard sv: ONE block, the SV list split
+             over the ranks (strong scaling), results all-gathered and merged.
+  all        (default) the six above; ONE JSON line whose top level is `acq` (metric, value,
              roofline, cpu_baseline) and whose "workloads" object holds every workload's own
-             value, step times, roofline and cpu_baseline.
+             value, step times, roofline (traffic measured live) and cpu_baseline.
   acq59      the 4 ms shape with the reference's whole SV list (36 C/A + QZSS, 23 E1B): profiles the
              four-accumulator (16368-sample window) correlator beside the C/A one.
-  acq10ms    BASELINE configs[4]: joint L1 C/A + QZSS + Galileo E1B, 10 ms coherent (65536-point
-             transforms), 256 Doppler bins, all 59 SVs.
-  receivers  BASELINE configs[3]: --receivers virtual receivers per GPU (waterfall + audio chain).
   waterfall / ddc   the old names of wf14 / ddc14 as single lines.
 
 Multi-GPU (weak scaling): every rank works on its own resident units (sample blocks / frames /
@@ -194,80 +198,162 @@ def cpu_threads(one_unit, budget_s):
     return sum(done), time.perf_counter() - t0, cores, t1
 
 
-LIVE_TRAFFIC = {}            # workload -> (bytes per launch, source), filled by live_traffic_passes()
-TRAFFIC_KERNELS = {"acq": ("acq_correlate_kernel<4, 1,",), "acq59": ("acq_correlate_kernel<4, 1,", "acq_correlate_kernel<4, 4,"),
-                   "acq10ms": ("acq_correlate_kernel<16, 1,", "acq_correlate_kernel<16, 4,"), "wf14": ("wf_frame_kernel",)}
+# ------------------------------------------------------------------------------------------------
+# HBM traffic, measured by the run that prints it
+# ------------------------------------------------------------------------------------------------
+ALL_WORKLOADS = ["acq", "wf14", "ddc14", "cfg2_chain", "receivers", "acq10ms"]     # the default line, in run order
+PMC_WORKLOADS = ALL_WORKLOADS + ["acq59"]
+PMC_STEPS = 4                # steps inside a workload's marked window of a counter pass
+LIVE_TRAFFIC = {}            # workload -> (bytes, source), filled by live_traffic_passes()
+# What `traffic` is per workload: the named (dominant) kernels per launch -- the same unit as roofline.achieved --
+# or, for the workloads whose roofline is the whole step, every kernel dispatched in a step.
+TRAFFIC_KERNELS = {"acq": ("acq_correlate_kernel<4, 1,",),
+                   "acq59": ("acq_correlate_kernel<4, 1,", "acq_correlate_kernel<4, 4,"),
+                   "acq10ms": ("acq_correlate_kernel<16, 1,", "acq_correlate_kernel<16, 4,"),
+                   "wf14": ("wf_frame_kernel",),
+                   "ddc14": None, "cfg2_chain": None, "receivers": None}
+
+
+def pmc_tag(workload):
+    """Grid size (in workgroups) of the kg_ctx_mark() kernel that opens a workload's window; + 1 closes it."""
+    return 100 + 2 * PMC_WORKLOADS.index(workload)
+
+
+def pmc_window(ctx, workload, step, sync):
+    """Counter-pass mode (--pmc-child): two untimed steps, then PMC_STEPS steps between two marker kernels.
+    `rocprofv3 --pmc` rows carry neither timestamps nor user markers, so the parent attributes rows to
+    this window by dispatch order (kg_ctx_mark, include/kiwigpu.h)."""
+    for _ in range(2):
+        step()
+    sync()
+    ctx.mark(pmc_tag(workload))
+    for _ in range(PMC_STEPS):
+        step()
+    sync()                                           # every stream of the step has been enqueued AND has run
+    ctx.mark(pmc_tag(workload) + 1)
+    sync()
+    return {"pmc_child": workload}
 
 
 def under_profiler():
     return any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
 
 
-def live_traffic_passes(args):
-    """HBM bytes per launch of each workload's dominant kernel(s), measured NOW: before this process
-    touches the GPU it runs this same file as a child under `rocprofv3 --pmc` -- one pass for
-    FETCH_SIZE, one for WRITE_SIZE (separate passes, nothing but the counter: MI355X_MICROARCH.md's
-    HBM section) -- on the same per-launch configuration, a few steps each.  bytes = (2 x FETCH_SIZE
-    + WRITE_SIZE) KB: gfx950 tallies its 128-byte read requests as 64.  Any failure (no rocprofv3,
-    already under a profiler, a pass timing out) leaves LIVE_TRAFFIC without the entry and the line
-    falls back to the committed figure, saying so."""
+def parse_counter_rows(files, counter):
+    """counter_collection.csv files -> rows [(dispatch id, kernel name, workgroups, value)] in dispatch order."""
     import csv
+    rows = []
+    for f in files:
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row["Counter_Name"] != counter:
+                    continue
+                wg = max(1, int(float(row.get("Workgroup_Size", "64") or 64)))
+                rows.append((int(row["Dispatch_Id"]), row["Kernel_Name"], int(float(row["Grid_Size"])) // wg,
+                             float(row["Counter_Value"])))
+    rows.sort()
+    return rows
+
+
+def window_traffic(rows, workload):
+    """KB of the workload's marked window: -> (per launch of the dominant kernels | per step of all kernels,
+    {kernel: KB per step} of the largest contributors)."""
+    tag, inside, win = pmc_tag(workload), False, []
+    for _, name, groups, val in rows:
+        if "kg_mark_kernel" in name:
+            if groups == tag:
+                inside, win = True, []
+            elif groups == tag + 1 and inside:
+                inside = False
+                break
+            continue
+        if inside:
+            win.append((name, val))
+    if inside or not win:
+        raise RuntimeError("window of %s not found" % workload)
+    per = {}
+    for name, val in win:
+        per.setdefault(name, []).append(val)
+    keys = TRAFFIC_KERNELS[workload]
+    by_step = {k: sum(v) / PMC_STEPS for k, v in per.items()}
+    top = dict(sorted(by_step.items(), key=lambda kv: -kv[1])[:4])
+    if keys is None:
+        return sum(by_step.values()), top
+    tot = 0.0
+    for k in keys:
+        vals = [v for name, vs in per.items() if k in name for v in vs]
+        if not vals:
+            raise RuntimeError("kernel %s not seen" % k)
+        tot += sum(vals) / len(vals)
+    return tot, top
+
+
+def live_traffic_passes(args):
+    """HBM bytes of each workload, measured NOW: before this process touches the GPU it runs this same file
+    as a child under `rocprofv3 --pmc` -- ONE pass for FETCH_SIZE, one for WRITE_SIZE (separate passes,
+    nothing but the counter: MI355X_MICROARCH.md's HBM section), each running EVERY workload of this run on
+    its own per-launch configuration, PMC_STEPS steps between two marker kernels.  bytes = (2 x FETCH_SIZE +
+    WRITE_SIZE) KB: gfx950 tallies its 128-byte read requests as 64.  Any failure (no rocprofv3, already
+    under a profiler, a pass timing out) leaves LIVE_TRAFFIC without the entry and the line falls back to
+    the committed figure, saying so."""
     import glob
     import shutil
     import tempfile
     if shutil.which("rocprofv3") is None or under_profiler():
         return
-    wls = ["acq", "wf14"] if args.workload == "all" else [args.workload]
-    for wl in wls:
-        keys = TRAFFIC_KERNELS.get(wl)
-        if keys is None:
-            continue
-        child = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", "4", "--warmup", "1",
-                 "--no-cpu", "--no-live-traffic", "--frames", str(args.frames)]
-        if args.blocks is not None:
-            child += ["--blocks", str(args.blocks)]
-        mean = {}
-        tmp = tempfile.mkdtemp(prefix="kiwigpu_pmc_")
-        try:
-            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-                d = os.path.join(tmp, counter)
-                cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child
-                env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
-                p = subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
-                                     start_new_session=True)     # its own process group: a stuck pass is ended whole
+    wls = [w for w in (ALL_WORKLOADS if args.workload == "all" else [args.workload]) if w in TRAFFIC_KERNELS]
+    if not wls:
+        return
+    child = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--pmc-child",
+             "--no-cpu", "--no-live-traffic", "--frames", str(args.frames), "--receivers", str(args.receivers)]
+    if args.blocks is not None:
+        child += ["--blocks", str(args.blocks)]
+    if args.log2n_given:
+        child += ["--log2n", str(args.log2n)]
+    kb = {}
+    tmp = tempfile.mkdtemp(prefix="kiwigpu_pmc_")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child
+            env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+            p = subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                 start_new_session=True)     # its own process group: a stuck pass is ended whole
+            try:
+                rc = p.wait(timeout=300)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, 9)
+                p.wait()
+                raise RuntimeError("pass timed out")
+            if rc != 0:
+                raise RuntimeError("pass failed, status %d" % rc)
+            rows = parse_counter_rows(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), counter)
+            for wl in wls:
                 try:
-                    rc = p.wait(timeout=240)
-                except subprocess.TimeoutExpired:
-                    os.killpg(p.pid, 9)
-                    p.wait()
-                    raise RuntimeError("pass timed out")
-                if rc != 0:
-                    raise RuntimeError("pass failed, status %d" % rc)
-                per = {k: [] for k in keys}
-                for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                    with open(f) as fh:
-                        for row in csv.DictReader(fh):
-                            if row["Counter_Name"] != counter:
-                                continue
-                            for k in keys:
-                                if k in row["Kernel_Name"]:
-                                    per[k].append(float(row["Counter_Value"]))
-                if any(not v for v in per.values()):
-                    raise RuntimeError("kernel not seen")
-                mean[counter] = sum(sum(v) / len(v) for v in per.values())       # KB per launch, all parts
-            LIVE_TRAFFIC[wl] = (int((2 * mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024),
-                                "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run "
-                                "(2 x %.1f KB + %.1f KB per launch)" % (mean["FETCH_SIZE"], mean["WRITE_SIZE"]))
-        except Exception as e:                                    # noqa: BLE001 -- fall back, and say so
-            sys.stderr.write("bench.py: live PMC pass for %s not available (%s)\n" % (wl, e))
-        finally:
-            shutil.rmtree(tmp, ignore_errors=True)
+                    kb.setdefault(wl, {})[counter] = window_traffic(rows, wl)
+                except RuntimeError as e:
+                    sys.stderr.write("bench.py: live PMC figure for %s not available (%s)\n" % (wl, e))
+        for wl in wls:
+            if len(kb.get(wl, {})) != 2:
+                continue
+            (fk, ftop), (wk, wtop) = kb[wl]["FETCH_SIZE"], kb[wl]["WRITE_SIZE"]
+            what = "per launch of the dominant kernel(s)" if TRAFFIC_KERNELS[wl] else "per step, every kernel of the step"
+            LIVE_TRAFFIC[wl] = (int((2 * fk + wk) * 1024),
+                                "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run, %s "
+                                "(2 x %.1f KB + %.1f KB)" % (what, fk, wk),
+                                {k: int((2 * ftop.get(k, 0.0) + wtop.get(k, 0.0)) * 1024)
+                                 for k in list(ftop)[:3]})
+    except Exception as e:                                    # noqa: BLE001 -- fall back, and say so
+        sys.stderr.write("bench.py: live PMC passes not available (%s)\n" % e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def measured_traffic(workload, units):
-    """HBM bytes per launch of the workload's dominant kernel: the live PMC child passes of this
-    run (live_traffic_passes) when they ran, else the committed passes (profiles/hbm_traffic.json,
-    written from tools/prof.sh output the same way).  -> (bytes or None, where the number comes from)"""
+    """HBM bytes of the workload (per launch of its dominant kernels, or per step: TRAFFIC_KERNELS): the live
+    PMC child passes of this run (live_traffic_passes) when they ran, else the committed passes
+    (profiles/hbm_traffic.json, written the same way).  -> (bytes or None, where the number comes from,
+    {kernel: bytes per step} of the largest contributors or None)"""
     if workload in LIVE_TRAFFIC:
         return LIVE_TRAFFIC[workload]
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -275,9 +361,24 @@ def measured_traffic(workload, units):
         with open(path) as f:
             tab = json.load(f)
         e = tab[workload][str(units)]
-        return e["bytes_per_launch"], "committed profile: %s" % e.get("source", tab.get("_source", "profiles/hbm_traffic.json"))
+        return (e["bytes_per_launch"], "committed profile: %s" % e.get("source", tab.get("_source", "profiles/hbm_traffic.json")),
+                None)
     except (OSError, KeyError, ValueError):
-        return None, "no committed PMC pass for this configuration"
+        return None, "no live PMC pass and no committed one for this configuration", None
+
+
+def event_spread(launch, reps):
+    """Per-launch duration of `launch` (one enqueue on torch's current stream, which the contexts of the bench
+    share): a device event between back-to-back launches.  -> (min, median) in ms"""
+    import torch
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ev[0].record()
+    for i in range(reps):
+        launch()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    dts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(reps))
+    return round(dts[0], 5), round(dts[len(dts) // 2], 5)
 
 
 PREROLL_S = 0.12
@@ -341,37 +442,56 @@ def acq_flops_per_cell(P, limit_quarters):
     return P * 5 * 4096 * 12 + 6 * P * 4096 + (P - 1) * 4096 * 10 * limit_quarters
 
 
+class DevBytes:
+    """A device buffer as torch sees it (zero copy): torch.as_tensor(DevBytes(ptr, n), device=...)."""
+
+    def __init__(self, dptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(dptr), False), "version": 2}
+
+
 def run_acq(args, dist, ten_ms=False, all_svs=False):
     import numpy as np
     import torch
     from flydog_sdr_gps_amd import Context, Searcher, acq, prn, sats, shard, synth
+    from flydog_sdr_gps_amd._lib import result_dtype
+    from tests.fixtures import e1b_chips
     dev = dist.dev
     ctx = Context(dist.local_rank, torch.cuda.current_stream(dev).cuda_stream)
+    wl = "acq10ms" if ten_ms else ("acq59" if all_svs else "acq")
+    shard_sv = ten_ms and args.shard == "sv"
     if ten_ms:
-        B = args.blocks or 2
+        B = args.blocks or (1 if shard_sv else 2)
         nsamples, fft_len, dop_lo, dop_hi = acq.NSAMPLES_10MS, acq.FFT_LEN_10MS, -128, 127
-        codes = synth.all_sv_codes()
-        svs = list(range(len(codes)))
-        make_block = lambda b: synth.config4_iq16(seed=0x5EED0005 + b, codes=codes)     # noqa: E731
+        codes = synth.all_sv_codes(e1b_chips())
+        make_block = lambda b: synth.config4_iq16(codes, seed=0x5EED0005 + b)            # noqa: E731
     else:
         B = args.blocks or 32
         nsamples, fft_len, dop_lo, dop_hi = NSAMPLES, FFT_LEN, -20, 20
         # all_svs: the reference's whole Sats[] list (36 C/A + QZSS rows and the 23 E1B rows, whose
         # 16368-sample window takes the four-accumulator kernel) on the configs[1] blocks
-        codes = synth.all_sv_codes() if all_svs else \
+        codes = synth.all_sv_codes(e1b_chips()) if all_svs else \
             [(prn.cacode(sats.SATS[s][1], sats.SATS[s][2]), False) for s in range(NSV)]
-        svs = list(range(len(codes)))
         make_block = lambda b: synth.config1_iq16(seed=0x5EED0002 + b)                  # noqa: E731
+    nsv_all = len(codes)
+    # --shard sv (SURVEY.md 8e, first bullet; gps/search.cpp:512-604 is the loop being partitioned): every rank
+    # holds the SAME block(s) and searches its contiguous share of the SV list
+    sv_lo, sv_hi = shard.split_units(nsv_all, dist.world)[dist.rank] if shard_sv else (0, nsv_all)
+    svs = list(range(sv_lo, sv_hi))
     ndop, P = dop_hi - dop_lo + 1, fft_len // 4096
     s = Searcher(ctx, dop_lo=dop_lo, dop_hi=dop_hi, max_blocks=2 * B, nsamples=nsamples, fft_len=fft_len)
-    for sat, (chips, boc) in enumerate(codes):
-        s.set_code(sat, chips, boc=boc)
-    # each rank gets its own seeded blocks ("receivers"), resident in HBM
-    blocks = shard.block_ids(dist.rank, dist.world, B)
+    for sat in svs:
+        s.set_code(sat, codes[sat][0], boc=codes[sat][1])
+    # each rank gets its own seeded blocks ("receivers"), resident in HBM; --shard sv: every rank the same ones
+    blocks = list(range(B)) if shard_sv else shard.block_ids(dist.rank, dist.world, B)
     iq_host = [make_block(b) for b in blocks]
     iq_dev = torch.from_numpy(np.stack(iq_host)).to(dev)          # [B][2*nsamples] int16, resident
     iq_ptr = int(iq_dev.data_ptr())
     parity = [0]
+    nsv_max = max(hi - lo for lo, hi in shard.split_units(nsv_all, dist.world)) if shard_sv else len(svs)
+    rbytes = B * nsv_max * result_dtype.itemsize
+    if shard_sv and dist.on and dist.backend == "nccl":
+        res_dev = torch.as_tensor(DevBytes(s.results_dev(), rbytes), device=dev)     # the library's result array, zero copy
+        gathered_dev = torch.empty(dist.world * rbytes, dtype=torch.uint8, device=dev)
 
     def step():
         # Sample() then Correlate() of this step's blocks, in order on one stream (two sets of
@@ -380,7 +500,16 @@ def run_acq(args, dist, ten_ms=False, all_svs=False):
         parity[0] ^= 1
         s.sample_iq16_batch(iq_ptr, B, first_block=first)
         s.correlate_async(svs, nblocks=B, first_block=first)
+        if shard_sv and dist.on and dist.backend == "nccl":
+            # the exchange step of the SV-sharded search: every rank's winners to every rank (RCCL, 16 B per
+            # (block, SV)); the merge is shard.merge_sv_shards on the host after the timed region
+            import torch.distributed as tdist
+            tdist.all_gather_into_tensor(gathered_dev, res_dev)
 
+    if args.pmc_child:
+        out = pmc_window(ctx, wl, step, lambda: torch.cuda.synchronize(dev))
+        s.close(); ctx.close()
+        return out
     elapsed, t_enq, spread = timed_steps(dist, step, args.steps, args.warmup)
 
     # dominant kernel alone: Correlate() launches back to back, HIP events on its own stream
@@ -392,12 +521,21 @@ def run_acq(args, dist, ten_ms=False, all_svs=False):
     for _ in range(kreps):
         s.correlate_async(svs, nblocks=B)
     kernel_ms = ctx.timer_stop() / kreps
+    k_min, k_med = event_spread(lambda: s.correlate_async(svs, nblocks=B), kreps)
 
     res, _ = s.fetch(want_cells=False)
+    if shard_sv:
+        if dist.on and dist.backend == "nccl":
+            parts = gathered_dev.cpu().numpy().view(result_dtype).reshape(dist.world, -1)
+        else:
+            parts = res.reshape(1, -1)
+        res = shard.merge_sv_shards(parts, B, shard.split_units(nsv_all, dist.world))       # [B][59]
+        assert res.shape == (B, nsv_all)
     # (E1B rows: 41 x 16368 trials per SV put the noise maximum close to the reference's MIN_SIG = 16)
     min_sig = synth.MIN_SIG_10MS if ten_ms else (24.0 if all_svs else acq.MIN_SIG)
-    found = sorted(int(sv) for sv in svs if res[0, sv]["snr"] >= min_sig)
-    if dist.on and dist.backend == "nccl":
+    res_svs = list(range(nsv_all)) if shard_sv else svs
+    found = sorted(int(sv) for i, sv in enumerate(res_svs) if res[0, i]["snr"] >= min_sig)
+    if dist.on and dist.backend == "nccl" and not shard_sv:
         gathered = shard.gather_results(res, dev)       # RCCL all_gather of the tiny result arrays
         assert gathered.shape[0] == dist.world * B
     expect = sorted(p[0] for p in synth.CONFIG4_PRESENT) if ten_ms else \
@@ -408,16 +546,17 @@ def run_acq(args, dist, ten_ms=False, all_svs=False):
     if dist.rank == 0 and not all_svs:
         assert found == expect, "acquisition result wrong: %s != %s" % (found, expect)
 
-    n1 = sum(1 for _, boc in codes if not boc)
-    n4 = len(codes) - n1
+    n1 = sum(1 for sat in svs if not codes[sat][1])
+    n4 = len(svs) - n1
     flops_launch = B * ndop * (n1 * acq_flops_per_cell(P, 1) + n4 * acq_flops_per_cell(P, 4))
     cells = B * len(svs) * ndop
     bytes_cell = 2 * fft_len * 8 + 16                  # both spectra once + the result
-    traffic, source = measured_traffic("acq10ms" if ten_ms else "acq", B)
+    traffic, source, _ = measured_traffic(wl, B)
     tfl = flops_launch / (kernel_ms * 1e-3) / 1e12
     out = {
-        "metric": "IQ Msamples/s ingested (GPS acq: Sample + %d SV x %d Doppler Correlate)" % (len(svs), ndop),
-        "value": round(float(B) * nsamples * args.steps * dist.world / elapsed / 1e6, 3),
+        "metric": "IQ Msamples/s ingested (GPS acq: Sample + %d SV x %d Doppler Correlate)" % (nsv_all, ndop),
+        # weak scaling: every rank its own blocks; --shard sv (strong): the same B blocks, searched once by all ranks
+        "value": round(float(B) * nsamples * args.steps * (1 if shard_sv else dist.world) / elapsed / 1e6, 3),
         "unit": "Msamples/s",
         "ms_per_step": round(elapsed / args.steps * 1e3, 5),
         "step_ms_spread": spread,
@@ -431,7 +570,9 @@ def run_acq(args, dist, ten_ms=False, all_svs=False):
                          ("BASELINE configs[1]: 32 GPS L1 C/A SVs x 41 Doppler bins, 4 ms coherent FFT correlate, "
                           "synthetic int16 IQ @16.368 MS/s resident in HBM")),
             "blocks_per_step_per_gpu": B, "samples_per_block": nsamples, "cells_per_step_per_gpu": cells,
-            "parallelism": "replicated codes, sample blocks sharded over %d GPU(s), no data-path collective" % dist.world,
+            "parallelism": ("--shard sv: the same %d block(s) on every GPU, the %d SVs split over %d GPU(s) (this rank: %d..%d), "
+                            "winners all-gathered over RCCL every step" % (B, nsv_all, dist.world, sv_lo, sv_hi - 1)) if shard_sv else
+                           "replicated codes, sample blocks sharded over %d GPU(s), no data-path collective" % dist.world,
         },
         # What bounds the correlator: fp32 vector arithmetic -- every operand is
         # served from L2, the kernel cannot be HBM-bound.  achieved = nominal FFT flops / HIP-event time.
@@ -440,7 +581,8 @@ def run_acq(args, dist, ten_ms=False, all_svs=False):
             "achieved": round(tfl, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tfl / VALU_PEAK_TFLOPS, 4),
             "traffic": traffic, "traffic_source": source,
-            "kernel_ms": round(kernel_ms, 5), "flops_per_launch": flops_launch,
+            "kernel_ms": round(kernel_ms, 5), "kernel_ms_min": k_min, "kernel_ms_median": k_med,
+            "flops_per_launch": flops_launch,
         },
         # Secondary: SURVEY 8(d)'s per-cell byte model and, where a PMC pass exists, measured HBM bytes.
         "hbm": {
@@ -455,48 +597,236 @@ def run_acq(args, dist, ten_ms=False, all_svs=False):
         "found_svs": found,
         "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 5),
     }
+    if shard_sv:
+        out["scaling"] = "strong"
+    if dist.world == 1 and dist.rank == 0 and not shard_sv:
+        # SURVEY 8(d)'s "ingested" variant: the blocks start in HOST memory (one pinned transfer per batch on the copy
+        # stream) and the winners end there; two batches in flight.  Never `value`.
+        host = np.ascontiguousarray(np.stack(iq_host))
+        reps = max(6, min(40, args.steps))
+        for _ in range(2):
+            s.sample_iq16_host_batch(host, 0); s.correlate_async(svs, nblocks=B); s.fetch(want_cells=False)
+        t0 = time.perf_counter()
+        par = 0
+        for _ in range(reps):
+            s.sample_iq16_host_batch(host, par * B)
+            s.correlate_async(svs, nblocks=B, first_block=par * B)
+            par ^= 1
+        s.fetch(want_cells=False)                            # waits for the stream, copies the last batch's winners out
+        t_host = (time.perf_counter() - t0) / reps
+        out["ingest_pcie_Msps"] = round(B * nsamples / t_host / 1e6, 1)
+        out["ingest_pcie_note"] = ("host int16 IQ in (%d blocks per pinned batch transfer, two batches in flight), winners "
+                                   "fetched to the host: %.1f us per block" % (B, t_host / B * 1e6))
     if not args.no_cpu and dist.world == 1 and dist.rank == 0:
         out["cpu_baseline"] = cpu_acq(iq_host[0], codes, nsamples, fft_len, dop_lo, dop_hi, args.cpu_seconds)
         out["speedup_vs_cpu_all_cores"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        if wl in POCKETFFT:
+            out["cpu_baseline_pocketfft"] = POCKETFFT[wl]
+            if POCKETFFT[wl].get("value"):
+                out["speedup_vs_cpu_pocketfft"] = round(out["value"] / POCKETFFT[wl]["value"], 1)
     s.close()
     ctx.close()
     return out
 
 
+def cpu_rate(one_unit, budget_s):
+    """units per second of `one_unit` on all usable host threads (cpu_threads) -> (rate, cores, single-thread seconds)"""
+    reps, el, cores, t1 = cpu_threads(one_unit, budget_s)
+    return max(reps, 1) / el if reps else 1.0 / t1, cores, t1
+
+
 def cpu_acq(iq, codes, nsamples, fft_len, dop_lo, dop_hi, budget_s):
     """The CPU oracle (kind "port": scalar fp32 radix-4 FFT in place of FFTW3f, which is absent from
-    this image) on the same workload: Sample() + Correlate() for every SV and bin of one block."""
+    this image; built for this machine's CPU when gcc is present, native_oracle()) on the same workload:
+    Sample() + Correlate() for every SV and bin of one block."""
     import numpy as np
     from oracle import kiwi_oracle as ko
     ko.lib()
     spectra = np.stack([ko.code_fft(c, boc=b, prec=0, fft_len=fft_len) for c, b in codes])
     limits = [ko.E1B_LIMIT if b else ko.L1_LIMIT for _, b in codes]
     ndop = dop_hi - dop_lo + 1
-    if fft_len == FFT_LEN:
+    if fft_len == FFT_LEN and not any(b for _, b in codes):
         def unit():
             data = ko.sample_iq16(iq, prec=0)
             ko.correlate_many(spectra, data, limits, prec=0, nthreads=1, want_cells=False)
-        samples_per_unit, what = nsamples, "the full configs[1] block (Sample + 32 SV x 41 bins)"
+        reps, el, cores, t1 = cpu_threads(unit, budget_s)
+        value, single = reps * nsamples / el / 1e6, nsamples / t1 / 1e6
+        what = "%d x the full configs[1] block (Sample + %d SV x %d bins)" % (reps, len(codes), ndop)
     else:
-        # a bounded slice of the 59 x 256 cells: Sample() + 2 SVs (one C/A, one E1B) x 256 bins
-        sub = [0, len(codes) - 1]
-        frac = len(sub) / len(codes)
+        # The real mix, leg by leg: Sample() once per block, then one Correlate() per SV -- n_ca C/A SVs (4092-lag
+        # peak search) and n_e1b E1B SVs (16368 lags).  Each leg is timed on all cores; a block on all cores takes
+        # 1 / r_sample + n_ca / r_ca + n_e1b / r_e1b.
+        ca = next(i for i, (_, b) in enumerate(codes) if not b)
+        e1b = next(i for i, (_, b) in enumerate(codes) if b)
+        n_e1b = sum(1 for _, b in codes if b)
+        n_ca = len(codes) - n_e1b
+        data0 = ko.sample_iq16(iq, prec=0, nsamples=nsamples, fft_len=fft_len)
 
-        def unit():
-            data = ko.sample_iq16(iq, prec=0, nsamples=nsamples, fft_len=fft_len)
-            ko.correlate_many(spectra[sub], data, [limits[i] for i in sub], dop_lo=dop_lo, dop_hi=dop_hi,
-                              prec=0, nthreads=1, want_cells=False)
-        samples_per_unit = nsamples * frac
-        what = "Sample + 2 of the 59 SVs x %d bins of one configs[4] block (scaled by 2/59)" % ndop
-    reps, el, cores, t1 = cpu_threads(unit, budget_s)
+        def corr(i):
+            return lambda: ko.correlate_many(spectra[[i]], data0, [limits[i]], dop_lo=dop_lo, dop_hi=dop_hi,
+                                             prec=0, nthreads=1, want_cells=False)
+        r_s, cores, t_s = cpu_rate(lambda: ko.sample_iq16(iq, prec=0, nsamples=nsamples, fft_len=fft_len), budget_s / 6)
+        r_ca, _, t_ca = cpu_rate(corr(ca), budget_s / 3)
+        r_e1b, _, t_e1b = cpu_rate(corr(e1b), budget_s / 2)
+        value = nsamples / (1.0 / r_s + n_ca / r_ca + n_e1b / r_e1b) / 1e6
+        single = nsamples / (t_s + n_ca * t_ca + n_e1b * t_e1b) / 1e6
+        what = ("legs timed separately and combined as t_sample + %d t_ca + %d t_e1b (one SV x %d bins each: C/A %.3f s, "
+                "E1B %.3f s, Sample %.4f s on one thread)" % (n_ca, n_e1b, ndop, t_ca, t_e1b, t_s))
+        el = budget_s
     return {
-        "value": round(reps * samples_per_unit / el / 1e6, 5), "unit": "Msamples/s", "cores": cores,
+        "value": round(value, 5), "unit": "Msamples/s", "cores": cores,
         "machine_cpus": os.cpu_count(), "kind": "port",
-        "sample": "%d x %s, oracle fp32 FFT, %d threads each running whole units, %.1f s" % (reps, what, cores, el),
-        "single_thread_value": round(samples_per_unit / t1 / 1e6, 5),
-        "port_vs_reference": "FFTW3f is unavailable here; a tuned FFTW build is estimated 2-4x faster than this "
-                             "scalar port, so divide the speed-up by up to 4 for a fair reference build",
+        "sample": "%s, oracle fp32 FFT (%s), %d threads each running whole units, ~%.0f s" % (what, native_oracle_note(), cores, el),
+        "single_thread_value": round(single, 5),
+        "port_vs_reference": "FFTW3f is unavailable here; cpu_baseline_pocketfft times the same work with the tuned FFT "
+                             "that IS in the image (scipy.fft / pocketfft)",
     }
+
+
+POCKETFFT = {}               # workload -> cpu_baseline_pocketfft object, filled by pocketfft_legs() BEFORE the GPU is touched
+_PF = {}                     # what the forked workers of a leg run (inherited through fork, never pickled)
+
+
+def _pf_worker(budget):
+    fn = _PF["unit"]
+    fn()                                              # warm-up in this process (plans, page faults)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        fn()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget:
+            return n, el
+
+
+def pf_rate(unit, budget_s):
+    """units per second of `unit` with one forked worker PROCESS per usable core (many small numpy calls: threads
+    would serialise on the interpreter lock).  Only ever called before this process has initialised the GPU."""
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    cores = usable_cores()
+    _PF["unit"] = unit
+    with ProcessPoolExecutor(cores, mp_context=mp.get_context("fork")) as pool:
+        got = list(pool.map(_pf_worker, [budget_s] * cores))
+    return sum(n / el for n, el in got), cores
+
+
+def cpu_acq_pocketfft(iq, codes, nsamples, fft_len, dop_lo, dop_hi, budget_s):
+    """The same Sample() FFT + Correlate() work with an independent tuned FFT (scipy.fft = pocketfft, complex64,
+    eight Doppler bins per batched call so that the working set stays in L2, one SV per host process): what the FFT
+    library that IS in this image does with this loop on these cores.  Not a parity oracle; its winner is compared
+    with the oracle's as a sanity flag only."""
+    import numpy as np
+    import scipy.fft as sf
+    from numpy.lib.stride_tricks import as_strided
+    from oracle import kiwi_oracle as ko
+    ko.lib()
+    N, ndop = fft_len, dop_hi - dop_lo + 1
+    _, td = ko.sample_iq16(iq, prec=0, want_td=True, nsamples=nsamples, fft_len=fft_len)   # mix + 2 half-bands: not FFT work
+    td = np.ascontiguousarray(td, np.complex64)
+    i_ca = next(i for i, (_, b) in enumerate(codes) if not b)
+    i_e1b = next((i for i, (_, b) in enumerate(codes) if b), i_ca)
+    code_td = [np.ascontiguousarray(ko.code_replica(codes[i][0], boc=codes[i][1], fft_len=fft_len)[0], np.complex64)
+               for i in (i_ca, i_e1b)]
+    chunk = 8
+
+    def one_sv(which, limit):
+        dconj = np.conj(sf.fft(td))                                  # Sample()'s transform
+        cspec = sf.fft(code_td[which])                               # (SearchInit's; cheap beside the 41 / 256 inverse ones)
+        c3 = np.concatenate([cspec, cspec, cspec])                   # code[(k - dop) mod N] = c3[N + k - dop]: a strided view, no copy
+        best = (0.0, 0, 0)
+        for d0 in range(dop_lo, dop_hi + 1, chunk):
+            nd = min(chunk, dop_hi + 1 - d0)
+            v = as_strided(c3[N - d0:], shape=(nd, N), strides=(-c3.strides[0], c3.strides[0]), writeable=False)
+            y = sf.ifft(dconj * v, axis=1, norm="forward")[:, :limit]                   # unnormalised backward transform
+            pw = y.real * y.real + y.imag * y.imag
+            i = pw.argmax(axis=1)
+            mx = pw[np.arange(nd), i]
+            snr = mx / (pw.sum(axis=1) / limit)
+            j = int(snr.argmax())
+            if snr[j] > best[0]:
+                best = (float(snr[j]), d0 + j, int(i[j]))
+        return best
+
+    n_e1b = sum(1 for _, b in codes if b)
+    n_ca = len(codes) - n_e1b
+    legs = [(0, ko.L1_LIMIT, n_ca)] + ([(1, ko.E1B_LIMIT, n_e1b)] if n_e1b else [])
+    t_block, notes, cores = 0.0, [], 1
+    for which, limit, count in legs:
+        rate, cores = pf_rate(lambda: one_sv(which, limit), budget_s / len(legs))
+        t_block += count / rate
+        notes.append("%s: %.4f s per SV x %d bins on all cores" % ("E1B" if which else "C/A", 1.0 / rate, ndop))
+    got = one_sv(0, ko.L1_LIMIT)
+    want, _ = ko.correlate(ko.code_fft(codes[i_ca][0], prec=0, fft_len=fft_len),
+                           ko.sample_iq16(iq, prec=0, nsamples=nsamples, fft_len=fft_len), dop_lo=dop_lo, dop_hi=dop_hi, prec=0)
+    return {"value": round(nsamples / t_block / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "independent tuned FFT",
+            "sample": "scipy.fft (pocketfft) complex64 + numpy, one SV per process, %d processes, 8 Doppler bins per batched call; "
+                      "%s; block time = sum of count x per-SV time; Sample()'s mix + decimation left out (0.2 %% of the work)"
+                      % (cores, "; ".join(notes)),
+            "agrees_with_oracle": bool(got[1] == want["dop"] and got[2] == want["idx"])}
+
+
+def pocketfft_legs(args):
+    """cpu_baseline_pocketfft of the workloads of this run that go through an FFT, measured with forked worker
+    processes -- hence BEFORE this process initialises the GPU (a fork of a process that holds a HIP context is
+    not something to rely on).  Inputs are the workloads' own (same seeds)."""
+    import numpy as np
+    from flydog_sdr_gps_amd import WfParams, acq, prn, sats, synth, wf
+    from tests.fixtures import e1b_chips
+    wls = ALL_WORKLOADS if args.workload == "all" else [args.workload]
+    budget = args.cpu_seconds / 2
+    try:
+        import scipy.fft  # noqa: F401
+    except ImportError as e:
+        for wl in wls:
+            POCKETFFT[wl] = {"value": None, "note": "scipy.fft unavailable: %s" % e}
+        return
+    if "acq" in wls:
+        codes = [(prn.cacode(sats.SATS[s][1], sats.SATS[s][2]), False) for s in range(NSV)]
+        POCKETFFT["acq"] = cpu_acq_pocketfft(synth.config1_iq16(seed=0x5EED0002), codes, NSAMPLES, FFT_LEN, -20, 20, budget)
+    if "acq10ms" in wls:
+        codes = synth.all_sv_codes(e1b_chips())
+        POCKETFFT["acq10ms"] = cpu_acq_pocketfft(synth.config4_iq16(codes, seed=0x5EED0005), codes, acq.NSAMPLES_10MS,
+                                                  acq.FFT_LEN_10MS, -128, 127, 2 * budget)
+    if "wf14" in wls:
+        params = [WfParams.for_zoom(z, 1.0e6 * ch) for ch, z in enumerate(ZOOMS14)]
+        maps = [wf.build_maps(p.fft_used, p.plot_width, p.plot_width_clamped, False) for p in params]
+        base = np.stack([synth.wf_iq_frame(seed=i) for i in range(32)])
+        POCKETFFT["wf14"] = cpu_wf_pocketfft(base, params, (wf.window_functions(), wf.cic_comp_table()), maps, budget)
+
+
+_NATIVE = {}
+
+
+def native_oracle():
+    """The oracle built for THIS machine's CPU (-O3 -march=native) when gcc is here: the shipped
+    libkiwi_oracle.so is built for the x86-64-v3 baseline because it travels between machines.  Selected
+    through KIWI_ORACLE_LIBRARY before the oracle is first loaded; any failure keeps the shipped build."""
+    if _NATIVE:
+        return
+    _NATIVE["note"] = "shipped -march=x86-64-v3 build"
+    if os.environ.get("KIWI_ORACLE_LIBRARY"):
+        _NATIVE["note"] = "KIWI_ORACLE_LIBRARY=%s" % os.environ["KIWI_ORACLE_LIBRARY"]
+        return
+    import glob
+    import shutil
+    import tempfile
+    if shutil.which("gcc") is None:
+        return
+    d = tempfile.mkdtemp(prefix="kiwi_oracle_native_")
+    out = os.path.join(d, "libkiwi_oracle_native.so")
+    srcs = [os.path.join(ROOT, "oracle", "kiwi_oracle.c")] + sorted(glob.glob(os.path.join(ROOT, "oracle", "kiwi_oracle_*.c")))
+    cmd = ["gcc", "-O3", "-march=native", "-ffp-contract=off", "-fPIC", "-std=gnu11", "-shared", "-o", out] + srcs + ["-lm", "-lpthread"]
+    try:
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+        os.environ["KIWI_ORACLE_LIBRARY"] = out
+        _NATIVE["note"] = "built here with -O3 -march=native"
+    except (OSError, subprocess.SubprocessError):
+        pass
+
+
+def native_oracle_note():
+    return _NATIVE.get("note", "shipped -march=x86-64-v3 build")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -531,6 +861,10 @@ def run_wf14(args, dist):
     def step():
         w.frames_dev(chan_of, iq.data_ptr(), out.data_ptr())
 
+    if args.pmc_child:
+        res = pmc_window(ctx, "wf14", step, lambda: torch.cuda.synchronize(dev))
+        w.close(); ctx.close()
+        return res
     steps = max(5, args.steps)                      # (a quarter of them left the post-synchronize clock ramp, ~1 ms, in the average)
     elapsed, t_enq, spread = timed_steps(dist, step, steps, max(2, args.warmup))
     torch.cuda.synchronize(dev)
@@ -538,10 +872,11 @@ def run_wf14(args, dist):
     for _ in range(steps):
         step()
     kernel_ms = ctx.timer_stop() / steps
+    k_min, k_med = event_spread(step, steps)
     assert int(out.max()) > 100
     bytes_frame = 8192 * 4 + 1024          # int16 IQ in + u8 row out; window/maps are L2-resident
     achieved = nfr * bytes_frame / (kernel_ms * 1e-3) / 1e9
-    traffic, source = measured_traffic("wf14", nfr)
+    traffic, source, _ = measured_traffic("wf14", nfr)
     res = {
         "metric": "waterfall IQ Msamples/s (window + 8192-pt FFT + power + pixel reduce + dB + u8)",
         "value": round(nfr * 8192.0 * steps * dist.world / elapsed / 1e6, 1), "unit": "Msamples/s",
@@ -552,6 +887,7 @@ def run_wf14(args, dist):
         "roofline": {"bound": "hbm", "kernel": "wf_frame_kernel", "achieved": round(achieved, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": traffic, "traffic_source": source, "kernel_ms": round(kernel_ms, 5),
+                     "kernel_ms_min": k_min, "kernel_ms_median": k_med,
                      "algorithmic_bytes_per_launch": nfr * bytes_frame},
         # the other roof, for scale: nominal flops of the 8192-point transform (5 N log2 N) per frame against
         # the fp32 vector peak; the kernel issues 1239 vector instructions per wave and frame, 600 of them
@@ -582,15 +918,73 @@ def run_wf14(args, dist):
                       "FFT, %d threads, %.1f s" % (reps_done, cores, el),
             "single_thread_value": round(14 * 8192 / t1 / 1e6, 4)}
         res["speedup_vs_cpu_all_cores"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
+        if "wf14" in POCKETFFT:
+            res["cpu_baseline_pocketfft"] = POCKETFFT["wf14"]
+            if POCKETFFT["wf14"].get("value"):
+                res["speedup_vs_cpu_pocketfft"] = round(res["value"] / POCKETFFT["wf14"]["value"], 1)
     w.close()
     ctx.close()
     return res
 
 
+def wf_rows_numpy(iq, p, window, cic, fmap, comp_on):
+    """compute_frame() for a batch of frames of ONE channel, vectorised (WF_CMA, the bench's mode): window,
+    scipy.fft, CIC compensation, power, per-pixel mean over the mapped bins, dB, u8.  iq: int16 [F][8192][2]."""
+    import numpy as np
+    import scipy.fft as sf
+    x = iq[..., 0].astype(np.float32) * window + 1j * (iq[..., 1].astype(np.float32) * window)
+    X = sf.fft(x.astype(np.complex64), axis=1)[:, :p.fft_used]
+    if comp_on:
+        X = X * cic[:p.fft_used]
+    pw = X.real * X.real + X.imag * X.imag
+    pw[:, :2] = 0.0
+    m = np.asarray(fmap[:p.fft_used], np.int64)
+    limit = int(np.argmax(m >= 1024)) if (m >= 1024).any() else p.fft_used
+    starts = np.flatnonzero(np.r_[True, m[1:limit] != m[:limit - 1]])
+    sums = np.add.reduceat(pw[:, :limit], starts, axis=1)
+    counts = np.diff(np.r_[starts, limit]).astype(np.float32)
+    rows = np.zeros((iq.shape[0], 1024), np.float32)
+    rows[:, m[starts]] = sums / counts
+    with np.errstate(divide="ignore"):
+        dB = 10.0 * np.log10(rows * np.float32(p.fft_scale) + np.float32(1e-30)) + p.fft_offset
+    return (np.clip(dB, -200.0, 0.0) - 1.0).astype(np.int32).astype(np.uint8)
+
+
+def cpu_wf_pocketfft(base, params, tables, maps, budget_s):
+    """The waterfall frame work with scipy.fft (pocketfft) and numpy, one chunk of 32 frames per call, one worker
+    process per core (pf_rate: before the GPU is touched)."""
+    from flydog_sdr_gps_amd import wf
+    win, cic = tables[0][wf.WINF_HANNING], tables[1]
+    k = [0]
+
+    def chunk():                                     # 32 frames of the next channel in turn
+        i = k[0] % len(params)
+        k[0] += 1
+        p = params[i]
+        return wf_rows_numpy(base, p, win, cic, maps[i][0], p.zoom > 1)
+    rate, cores = pf_rate(chunk, budget_s)
+    return {"value": round(rate * base.shape[0] * 8192 / 1e6, 3), "unit": "Msamples/s", "cores": cores,
+            "kind": "independent tuned FFT",
+            "sample": "chunks of %d frames (channels in turn), scipy.fft complex64 + numpy (window, power, CIC compensation, "
+                      "per-pixel mean, dB, u8), one chunk per call, %d worker processes, %.1f s" % (base.shape[0], cores, budget_s)}
+
+
 # ------------------------------------------------------------------------------------------------
 # Waterfall DDC (configs[2], DDC half)
 # ------------------------------------------------------------------------------------------------
+_ADC_CACHE = {}
+
+
 def adc_block(n, seed):
+    """n samples of the synthetic 16-bit ADC stream (the same call returns the same array: ddc14 and
+    cfg2_chain share theirs)."""
+    if (n, seed) not in _ADC_CACHE:
+        _ADC_CACHE.clear()
+        _ADC_CACHE[(n, seed)] = _adc_block(n, seed)
+    return _ADC_CACHE[(n, seed)]
+
+
+def _adc_block(n, seed):
     import numpy as np
     rng = np.random.Generator(np.random.PCG64(seed))
     t = np.arange(n, dtype=np.float64)
@@ -623,6 +1017,10 @@ def run_ddc14(args, dist):
     def step():
         d.push_dev(adc.data_ptr(), n, chans, out.data_ptr(), stride)
 
+    if args.pmc_child:
+        res = pmc_window(ctx, "ddc14", step, lambda: torch.cuda.synchronize(dev))
+        d.close(); ctx.close()
+        return res
     steps = max(5, args.steps)                      # (a quarter of them left the post-synchronize clock ramp, ~1 ms, in the average)
     elapsed, t_enq, spread = timed_steps(dist, step, steps, max(2, args.warmup))
     torch.cuda.synchronize(dev)
@@ -630,6 +1028,8 @@ def run_ddc14(args, dist):
     for _ in range(steps):
         step()
     gpu_ms = ctx.timer_stop() / steps
+    k_min, k_med = event_spread(step, steps)
+    traffic, source, top = measured_traffic("ddc14", n)
     # Integer work per ADC sample and channel, counted in 32-bit operations on the algorithm (not on
     # the kernels): NCO phase add (48 bit: 2) + 2 table reads + 2 multiplies + 2 roundings (4) = 10;
     # five integrators on I and Q, the first four 89 bits wide (3 words) and the fifth 28 (1): 2 x 13 = 26;
@@ -649,11 +1049,14 @@ def run_ddc14(args, dist):
         # 14 x 36 integer operations
         "roofline": {"bound": "valu", "kernel": "ddc_wf passes A + scan + B + comb (whole step)",
                      "achieved": round(tops, 3), "peak": INT_PEAK_TOPS, "unit": "Tiop/s",
-                     "frac": round(tops / INT_PEAK_TOPS, 4), "traffic": None,
-                     "traffic_source": "not profiled: HBM traffic is the 2 B/sample ADC block + the decimated outputs",
-                     "kernel_ms": round(gpu_ms, 5), "int_ops_per_sample_per_channel": ops_sample_chan},
+                     "frac": round(tops / INT_PEAK_TOPS, 4), "traffic": traffic, "traffic_source": source,
+                     "traffic_top_kernels": top,
+                     "kernel_ms": round(gpu_ms, 5), "kernel_ms_min": k_min, "kernel_ms_median": k_med,
+                     "int_ops_per_sample_per_channel": ops_sample_chan},
         "hbm": {"algorithmic_bytes_per_step": 2 * n + out_bytes,
-                "algorithmic_GBps": round((2 * n + out_bytes) / (gpu_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS},
+                "algorithmic_GBps": round((2 * n + out_bytes) / (gpu_ms * 1e-3) / 1e9, 1),
+                "measured_GBps": None if traffic is None else round(traffic / (gpu_ms * 1e-3) / 1e9, 1),
+                "peak": HBM_PEAK_GBS},
     }
     if not args.no_cpu and dist.world == 1 and dist.rank == 0:
         from oracle import kiwi_oracle as ko
@@ -673,6 +1076,159 @@ def run_ddc14(args, dist):
             "single_thread_value": round(m / t1 / 1e6, 4)}
         res["speedup_vs_cpu_all_cores"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
     d.close()
+    ctx.close()
+    return res
+
+
+# ------------------------------------------------------------------------------------------------
+# configs[2] end to end: ADC stream -> 14 DDC channels -> the frames those complete -> rows
+# ------------------------------------------------------------------------------------------------
+def run_cfg2_chain(args, dist):
+    """One step = 2^log2n ADC samples through kg_ddc_wf_push_dev on the 14 zooms, then every 8192-sample frame the
+    channels have completed (read in place from the DDC's per-channel rows, kg_wf_frames_at_dev) through
+    kg_wf_frames: what rx/rx_waterfall.cpp:930-939 loops over (sample_wf + compute_frame), at 100 % duty.  The
+    zoom-14 channel (R = 8192) yields 2048 samples per 2^24-sample step: its row fills over four steps and its
+    frame is taken on the fourth."""
+    import numpy as np
+    import torch
+    from flydog_sdr_gps_amd import Context, Ddc, Waterfall, WfParams, wf
+    dev = dist.dev
+    ctx = Context(dist.local_rank, torch.cuda.current_stream(dev).cuda_stream)
+    zooms = ZOOMS14
+    n = 1 << args.log2n
+    adc_host = adc_block(n, 0x5EED0003)
+    adc = torch.from_numpy(adc_host).to(dev)
+    C14 = len(zooms)
+    d = Ddc(ctx, nchan=C14, max_samples=n)
+    w = Waterfall(ctx, nchan=C14)
+    tables = (wf.window_functions(), wf.cic_comp_table())
+    w.set_tables(*tables)
+    chans = list(range(C14))
+    prm = []
+    for ch, z in enumerate(zooms):
+        p = WfParams.for_zoom(z, 1.0e6 * ch, adc_clock=66.6666e6, ui_srate=30.0e6)
+        prm.append(p)
+        d.set_wf(ch, p.i_offset, p.decim)
+        w.set_channel(ch, p, interp=wf.WF_CMA, cic_comp=True)
+    nout = [n // p.decim for p in prm]
+    assert all(n % p.decim == 0 for p in prm)
+    frac = sorted(set(x for x in nout if x < 8192))
+    assert len(frac) <= 1 and all(8192 % x == 0 for x in frac), "one fractional class of channels per step"
+    cyc = 8192 // frac[0] if frac else 1                   # steps per frame of the slowest channel
+    q = frac[0] if frac else 0
+    stride = n + 8192                                      # pairs between channel rows: room for the (k % cyc) q shift
+    wf_iq = torch.zeros((C14, stride, 2), dtype=torch.int16, device=dev)
+    # frame tables of the cyc kinds of step: in step k every channel's new samples start q (k % cyc) pairs into its row
+    tabs = []
+    for k in range(cyc):
+        co, fo = [], []
+        for ch in range(C14):
+            if nout[ch] >= 8192:
+                for f in range(nout[ch] // 8192):
+                    co.append(ch); fo.append(ch * stride + q * k + 8192 * f)
+            elif k == cyc - 1:
+                co.append(ch); fo.append(ch * stride)
+        tabs.append((np.asarray(co, np.int32), np.asarray(fo, np.uint64)))
+    rows = torch.zeros((max(len(t[0]) for t in tabs), 1024), dtype=torch.uint8, device=dev)
+    kstep = [0]
+    base_ptr = wf_iq.data_ptr()
+
+    def ddc_part(k):
+        d.push_dev(adc.data_ptr(), n, chans, base_ptr + 4 * q * k, stride)
+
+    def frames_part(k):
+        w.frames_dev(tabs[k][0], base_ptr, rows.data_ptr(), frame_off=tabs[k][1])
+
+    def step():
+        k = kstep[0] % cyc
+        kstep[0] += 1
+        ddc_part(k)
+        frames_part(k)
+
+    if args.pmc_child:
+        res = pmc_window(ctx, "cfg2_chain", step, lambda: torch.cuda.synchronize(dev))
+        d.close(); w.close(); ctx.close()
+        return res
+    steps = max(2 * cyc, (args.steps + cyc - 1) // cyc * cyc)          # whole cycles
+    elapsed, t_enq, spread = timed_steps(dist, step, steps, max(cyc, args.warmup // cyc * cyc))
+    torch.cuda.synchronize(dev)
+    assert kstep[0] % cyc == 0
+    ctx.timer_start()
+    for _ in range(steps):
+        step()
+    gpu_ms = ctx.timer_stop() / steps
+    k_min, k_med = event_spread(step, steps)
+    ctx.timer_start()
+    for i in range(steps):
+        ddc_part(i % cyc)
+    ddc_ms = ctx.timer_stop() / steps
+    ctx.timer_start()
+    for i in range(steps):
+        frames_part(i % cyc)
+    frames_ms = ctx.timer_stop() / steps
+    assert int(rows.max()) > 100
+    frames_per_step = sum(len(t[0]) for t in tabs) / cyc
+    ops_sample_chan = 36                                   # run_ddc14's count: NCO + mixer + five integrators per sample and channel
+    tops = n * C14 * ops_sample_chan / (gpu_ms * 1e-3) / 1e12
+    out_bytes = sum(4 * x for x in nout)
+    alg_bytes = 2 * n + out_bytes + frames_per_step * (8192 * 4 + 1024)   # ADC in, DDC rows out, frames back in, u8 rows out
+    traffic, source, top = measured_traffic("cfg2_chain", n)
+    res = {
+        "metric": "ADC Msamples/s ingested by the 14-channel waterfall end to end (DDC -> frames -> rows)",
+        "value": round(float(n) * steps * dist.world / elapsed / 1e6, 1), "unit": "Msamples/s",
+        "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 5), "step_ms_spread": spread,
+        "dtype": "int128/int64/int32 + f32",
+        "config": {"workload": "BASELINE configs[2] end to end: %d ADC samples per step -> 14 DDC channels (zooms %s) -> "
+                               "the %.2f frames per step those complete -> window + 8192-pt FFT + power + pixels + dB + u8 rows"
+                               % (n, zooms, frames_per_step),
+                   "adc_samples_per_step": n, "frames_per_step": frames_per_step},
+        "x_realtime_at_66.6MSps": round(n / (gpu_ms * 1e-3) / 66.6666e6, 1),
+        "frames_per_s": round(frames_per_step * steps * dist.world / elapsed, 1),
+        # the step is the DDC's integer work (ddc14's roof) plus a quarter as much frame time; the numerator counts the
+        # DDC's operations only, so `frac` is a lower bound on the vector units' use over the step
+        "roofline": {"bound": "valu", "kernel": "whole step: ddc_wf passes + wf_frame_kernel",
+                     "achieved": round(tops, 3), "peak": INT_PEAK_TOPS, "unit": "Tiop/s", "frac": round(tops / INT_PEAK_TOPS, 4),
+                     "traffic": traffic, "traffic_source": source, "traffic_top_kernels": top,
+                     "kernel_ms": round(gpu_ms, 5), "kernel_ms_min": k_min, "kernel_ms_median": k_med,
+                     "ddc_ms_alone": round(ddc_ms, 5), "frames_ms_alone": round(frames_ms, 5),
+                     "int_ops_per_sample_per_channel": ops_sample_chan,
+                     "frames_nominal_TFLOPs": round(frames_per_step * 5 * 8192 * 13 / (gpu_ms * 1e-3) / 1e12, 3)},
+        "hbm": {"algorithmic_bytes_per_step": int(alg_bytes),
+                "algorithmic_GBps": round(alg_bytes / (gpu_ms * 1e-3) / 1e9, 1),
+                "measured_GBps": None if traffic is None else round(traffic / (gpu_ms * 1e-3) / 1e9, 1),
+                "peak": HBM_PEAK_GBS},
+    }
+    if not args.no_cpu and dist.world == 1 and dist.rank == 0:
+        from oracle import kiwi_oracle as ko
+        ko.lib()
+        m = 1 << 20                                      # a bounded piece of the same stream
+        piece = adc_host[:m]
+        log2r = [int(np.log2(p.decim)) for p in prm]
+        maps = [wf.build_maps(p.fft_used, p.plot_width, p.plot_width_clamped, False) for p in prm]
+        scales = [np.full(1024, p.fft_scale, np.float32) for p in prm]
+        done_frames = [0]
+
+        def unit():                                      # 2^20 ADC samples: 14 DDC channels, then every complete frame
+            nf = 0
+            for ch, p in enumerate(prm):
+                iq, _ = ko.ddc_wf(piece, p.i_offset, log2r[ch])
+                for f in range(iq.shape[0] // 8192):
+                    samps = ko.wf_window_iq(iq[8192 * f:8192 * (f + 1)], tables[0][wf.WINF_HANNING])
+                    ko.wf_compute_frame(samps, p.zoom, wf.WINF_HANNING, wf.WF_CMA, True, False, p.fft_used,
+                                        p.plot_width, p.plot_width_clamped, maps[ch][0], maps[ch][1], scales[ch],
+                                        (scales[ch] / np.float32(2)).astype(np.float32), p.fft_offset, tables[1], prec=0)
+                    nf += 1
+            done_frames[0] = nf
+        reps_done, el, cores, t1 = cpu_threads(unit, args.cpu_seconds)
+        res["cpu_baseline"] = {
+            "value": round(max(reps_done, 1) * m / el / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "%d x (2^20 ADC samples through the oracle's 14 DDC channels, then sample_wf window + compute_frame of the "
+                      "%d complete frames they hold; the whole step holds %.1f per 2^20), %d threads, %.1f s"
+                      % (reps_done, done_frames[0], frames_per_step * m / n, cores, el),
+            "single_thread_value": round(m / t1 / 1e6, 4)}
+        res["speedup_vs_cpu_all_cores"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
+    d.close()
+    w.close()
     ctx.close()
     return res
 
@@ -808,6 +1364,7 @@ class ReceiverBank:
 
 def run_receivers(args, dist):
     """BASELINE configs[3]: a ReceiverBank per GPU (weak scaling over ranks)."""
+    import numpy as np
     import torch
     dev = dist.dev
     two = os.environ.get("KIWIGPU_BENCH_ONE_STREAM") != "1"
@@ -816,24 +1373,46 @@ def run_receivers(args, dist):
     bank = ReceiverBank(dist.local_rank, dev, NR, n, dist.rank * NR, two)   # this rank's slice of the receiver set
     step, counts, rows, pay = bank.step, bank.counts, bank.rows, bank.pay
 
+    if args.pmc_child:
+        res = pmc_window(bank.ctx, "receivers", step, lambda: torch.cuda.synchronize(dev))
+        bank.close()
+        return res
     preroll(step, args.warmup)
     dist.barrier()
     counts["frames"] = counts["audio_blocks"] = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize(dev)                      # both streams of this rank
+    torch.cuda.synchronize(dev)                      # every stream of this rank
     local = time.perf_counter() - t0
     dist.barrier()
     elapsed = dist.max_over_ranks(local)
     # sanity: the strongest carrier is in the band of every waterfall row and audio came out
     assert int(rows.max()) > 100 and counts["audio_blocks"] > 0 and int(pay.to(torch.int32).abs().sum()) > 0
+    frames_total, audio_total = counts["frames"], counts["audio_blocks"]
     step_s = elapsed / args.steps
     world = dist.world
-    return {
+    # per-step device time (all four streams) from events on the main stream around whole steps
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    torch.cuda.synchronize(dev)
+    ev[0].record()
+    for i in range(args.steps):
+        step()
+        ev[i + 1].record()
+    torch.cuda.synchronize(dev)
+    dts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps))
+    # Integer work per ADC sample and receiver, counted on the algorithm: the waterfall DDC's 36 (run_ddc14) + the audio
+    # DDC's NCO / mixer (10) and rx1's three integrators on I and Q (55, 55 and 26 bits: 2 + 2 + 1 words, x 2 = 10);
+    # everything behind the first decimation (rx2, CICF, CFastFIR, CAgc, frames, coders) runs at <= 1 / 1543 of the rate.
+    ops = 36 + 20
+    tops = n * NR * ops / step_s / 1e12
+    traffic, source, top = measured_traffic("receivers", NR)
+    res = {
         "metric": "receiver x ADC Msamples/s ingested (waterfall + audio chain per virtual receiver)",
         "value": round(n * NR * world / step_s / 1e6, 1), "unit": "Msamples/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 4),
+        "step_ms_spread": {"min": round(dts[0], 5), "median": round(dts[len(dts) // 2], 5), "max": round(dts[-1], 5),
+                           "how": "main-stream device events around the steps of a second, untimed pass"},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int128/int64/f32",
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[3]: %d virtual receivers per GPU x %d GPU(s), one %d-sample 16-bit ADC "
@@ -843,9 +1422,63 @@ def run_receivers(args, dist):
                    "parallelism": "receivers sharded over ranks, no data-path collective"},
         "adc_ms_per_step": round(n / adc_clock * 1e3, 3),
         "x_realtime_all_receivers": round(n / adc_clock / step_s, 2),
-        "waterfall_frames_per_s": round(counts["frames"] * world / elapsed, 1),
-        "audio_blocks_per_s": round(counts["audio_blocks"] * world / elapsed, 1),
+        "waterfall_frames_per_s": round(frames_total * world / elapsed, 1),
+        "audio_blocks_per_s": round(audio_total * world / elapsed, 1),
+        "roofline": {"bound": "valu", "kernel": "whole step (both DDCs' run passes dominate; four streams)",
+                     "achieved": round(tops, 3), "peak": INT_PEAK_TOPS, "unit": "Tiop/s", "frac": round(tops / INT_PEAK_TOPS, 4),
+                     "traffic": traffic, "traffic_source": source, "traffic_top_kernels": top,
+                     "kernel_ms": round(step_s * 1e3, 5), "kernel_ms_min": round(dts[0], 5),
+                     "kernel_ms_median": round(dts[len(dts) // 2], 5), "int_ops_per_sample_per_receiver": ops},
+        "hbm": {"measured_GBps": None if traffic is None else round(traffic / step_s / 1e9, 1), "peak": HBM_PEAK_GBS},
     }
+    if not args.no_cpu and dist.world == 1 and dist.rank == 0:
+        res["cpu_baseline"] = cpu_receivers(bank, args.cpu_seconds)
+        res["speedup_vs_cpu_all_cores"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
+    bank.close()
+    return res
+
+
+def cpu_receivers(bank, budget_s):
+    """The oracle on whole receivers of the same bank: one unit = one receiver's complete step (waterfall DDC -> frame ->
+    row -> wf_pkt_t; audio DDC -> rx_iq_t -> unpack -> CFastFIR -> CAgc mono16 -> ADPCM) on the bank's ADC block."""
+    import numpy as np
+    from flydog_sdr_gps_amd import wf
+    from oracle import kiwi_oracle as ko
+    ko.lib()
+    adc, n = bank.adc_host, bank.n
+    tables = (wf.window_functions(), wf.cic_comp_table())
+    coef = ko.fir_design(300.0, 2700.0, 0.0, bank.fs, prec=0)[1]
+    k = [0]
+    import threading
+    lock = threading.Lock()
+
+    def unit():
+        with lock:
+            ch = k[0] % bank.NR
+            k[0] += 1
+        p = bank.params[ch]
+        iq, _ = ko.ddc_wf(adc, p.i_offset, int(np.log2(p.decim)))
+        fmap, drop = wf.build_maps(p.fft_used, p.plot_width, p.plot_width_clamped, False)
+        scale = np.full(1024, p.fft_scale, np.float32)
+        samps = ko.wf_window_iq(iq[:8192], tables[0][wf.WINF_HANNING])
+        row = ko.wf_compute_frame(samps, p.zoom, wf.WINF_HANNING, wf.WF_MAX, True, False, p.fft_used, p.plot_width,
+                                  p.plot_width_clamped, fmap, drop, scale, (scale / np.float32(2)).astype(np.float32),
+                                  p.fft_offset, tables[1], prec=0)[0]
+        ko.wf_packet(row, int(p.start), p.zoom, 0, True)
+        raw, _ = ko.ddc_rx(adc, bank.rx_inc[ch])
+        nrec = raw.size // 6
+        x = ko.dpump_unpack(raw, nrec, 1)[0]
+        y, _ = ko.fir_process(ko.fir_new_state(), coef, x, prec=0)
+        if y.size:
+            agc = ko.Agc()
+            agc.set_parameters(True, False, -100, 50, 6, 1000, bank.fs)
+            ko.adpcm_encode_i16(agc.process_s16(y[:512]))
+    reps, el, cores, t1 = cpu_threads(unit, budget_s)
+    return {"value": round(reps * n / el / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "%d x (one virtual receiver over the step's %d ADC samples: both chains, every stage; the DDCs are the "
+                      "oracle's sequential Verilog-structured models -- in the reference they are FPGA fabric), %d threads, %.1f s"
+                      % (reps, n, cores, el),
+            "single_thread_value": round(n / t1 / 1e6, 4)}
 
 
 def run_stub(args, dist):
@@ -856,28 +1489,64 @@ def run_stub(args, dist):
     time.sleep(0.01 * (dist.rank + 1))
     dist.barrier()
     el = dist.max_over_ranks(time.perf_counter() - t0)
-    return {"metric": "launcher self-test", "value": round(dist.world / el, 3), "unit": "ranks/s",
-            "config": {"workload": "stub (no GPU)"}, "dtype": "none"}
+    out = {"metric": "launcher self-test", "value": round(dist.world / el, 3), "unit": "ranks/s",
+           "config": {"workload": "stub (no GPU)"}, "dtype": "none"}
+    if args.shard == "sv":
+        # the --shard sv exchange of run_acq without a GPU: every rank fabricates the winners of ITS share of the 59 SVs
+        # (a pure function of block and SV), all ranks gather (gloo), the merge must give the unsharded table
+        import numpy as np
+        import torch
+        import torch.distributed as tdist
+        from flydog_sdr_gps_amd import shard
+        from flydog_sdr_gps_amd._lib import result_dtype
+        B, nsv = 2, 59
+        ranges = shard.split_units(nsv, dist.world)
+
+        def fake(b, sv):
+            return (16.0 + sv + 0.25 * b, sv - 30, (97 * sv + b) % 4092, 1)
+        full = np.array([[fake(b, sv) for sv in range(nsv)] for b in range(B)], result_dtype)
+        lo, hi = ranges[dist.rank]
+        nmax = max(h - l for l, h in ranges)
+        mine = np.zeros(B * nmax, result_dtype)                 # the library's result array: [B][this rank's SVs], then slack
+        mine[:B * (hi - lo)] = full[:, lo:hi].reshape(-1)
+        raw = torch.from_numpy(mine.view(np.uint8).copy())
+        if dist.on:
+            outs = [torch.empty_like(raw) for _ in range(dist.world)]
+            tdist.all_gather(outs, raw)
+            parts = np.stack([o.numpy().view(result_dtype) for o in outs])
+        else:
+            parts = mine.reshape(1, -1)
+        merged = shard.merge_sv_shards(parts, B, ranges)
+        assert merged.shape == (B, nsv) and np.array_equal(merged, full), "sv-sharded merge differs from the unsharded table"
+        out["shard_sv"] = {"world": dist.world, "ranges": ranges, "merged_equals_unsharded": True}
+        out["scaling"] = "strong"
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="all",
-                    choices=["all", "acq", "acq59", "acq10ms", "wf14", "ddc14", "waterfall", "ddc", "receivers", "stub"])
+                    choices=["all", "acq", "acq59", "acq10ms", "wf14", "ddc14", "cfg2_chain", "waterfall", "ddc", "receivers", "stub"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--blocks", type=int, default=None, help="acq: independent sample blocks per step (32; acq10ms: 2)")
     ap.add_argument("--frames", type=int, default=2048, help="wf14: frames per channel per step (2048 = 896 MiB of input)")
-    ap.add_argument("--log2n", type=int, default=None, help="ddc14 / receivers: log2 of the ADC samples per step (24 / 22)")
+    ap.add_argument("--log2n", type=int, default=None, help="ddc14 / cfg2_chain / receivers: log2 of the ADC samples per step (24 / 24 / 22)")
     ap.add_argument("--receivers", type=int, default=128, help="receivers: virtual receivers per GPU")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each cpu_baseline leg")
+    ap.add_argument("--shard", choices=["blocks", "sv"], default="blocks",
+                    help="acq10ms: what the ranks share out -- their own blocks (weak scaling, default) or the SVs of the "
+                         "same block (strong scaling, results all-gathered over RCCL every step)")
+    ap.add_argument("--cpu-seconds", type=float, default=None, help="budget of each cpu_baseline leg (10; `all`: 4)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="skip the rocprofv3 --pmc child passes; roofline.traffic then comes from profiles/hbm_traffic.json")
+    ap.add_argument("--pmc-child", action="store_true",
+                    help="(internal) counter-pass mode: a few steps of every workload between marker kernels, no timing")
     args = ap.parse_args()
-    if args.log2n is None:
-        args.log2n = 22 if args.workload == "receivers" else 24
+    args.log2n_given = args.log2n is not None
+    if args.cpu_seconds is None:
+        args.cpu_seconds = 4.0 if args.workload == "all" else 10.0
     args.workload = {"waterfall": "wf14", "ddc": "ddc14"}.get(args.workload, args.workload)
 
     world_env = os.environ.get("WORLD_SIZE")
@@ -887,34 +1556,57 @@ def main():
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%s\n" % (args.gpus, world_env))
         sys.exit(2)
 
-    if world_env is None and args.gpus == 1 and not args.no_live_traffic:
+    if world_env is None and args.gpus == 1 and not args.no_live_traffic and not args.pmc_child and args.workload != "stub":
         live_traffic_passes(args)                            # children; this process has not touched the GPU yet
+    if not args.no_cpu and not args.pmc_child and args.workload != "stub" and (world_env is None or int(world_env) == 1):
+        native_oracle()                                      # before anything loads the oracle
+        pocketfft_legs(args)                                 # forked workers: before this process touches the GPU
     dist = Dist("gloo" if args.workload == "stub" else "nccl")
     common = {"n_gpus": dist.world, "steps": args.steps, "warmup": args.warmup, "preroll_s": PREROLL_S, "higher_is_better": True,
               "scaling": "weak", "vs_baseline": None, "data": "synthetic"}
-    if args.workload == "stub":
-        line = dict(run_stub(args, dist), **common)
-    elif args.workload == "receivers":
-        line = run_receivers(args, dist)
-    elif args.workload in ("acq", "acq59", "acq10ms", "wf14", "ddc14"):
-        fn = {"acq": lambda: run_acq(args, dist), "acq10ms": lambda: run_acq(args, dist, ten_ms=True),
-              "acq59": lambda: run_acq(args, dist, all_svs=True),
-              "wf14": lambda: run_wf14(args, dist), "ddc14": lambda: run_ddc14(args, dist)}[args.workload]
+
+    def log2n_for(wl):
+        return args.log2n if args.log2n_given else (22 if wl == "receivers" else 24)
+
+    def run(wl):
+        import copy
+        a = copy.copy(args)
+        a.log2n = log2n_for(wl)
+        if args.workload == "all" and wl == "acq10ms":
+            a.steps, a.warmup = min(args.steps, 20), min(args.warmup, 3)       # 3.4 ms steps; the default K = 200 is sized for acq
+        if args.workload == "all" and wl == "receivers":
+            a.steps, a.warmup = min(args.steps, 40), min(args.warmup, 4)
+        fn = {"acq": lambda: run_acq(a, dist), "acq10ms": lambda: run_acq(a, dist, ten_ms=True),
+              "acq59": lambda: run_acq(a, dist, all_svs=True), "wf14": lambda: run_wf14(a, dist),
+              "ddc14": lambda: run_ddc14(a, dist), "cfg2_chain": lambda: run_cfg2_chain(a, dist),
+              "receivers": lambda: run_receivers(a, dist)}[wl]
         r = fn()
-        line = dict(r, **common)
-        line["steps"] = r.get("steps", args.steps)
+        if dist.dev is not None:
+            import torch
+            torch.cuda.synchronize(dist.dev)
+            torch.cuda.empty_cache()
+        if not args.pmc_child:
+            r.setdefault("steps", a.steps)
+            r.setdefault("warmup", a.warmup)
+        return r
+
+    if args.workload == "stub":
+        line = dict(common, **run_stub(args, dist))
+    elif args.workload == "all":
+        rs = {wl: run(wl) for wl in ALL_WORKLOADS}
+        if args.pmc_child:
+            line = {"pmc_child": list(rs)}
+        else:
+            a = rs["acq"]
+            line = dict(a, **common)
+            line["metric"] = "IQ Msamples/s ingested (waterfall + GPS acq); value = GPS acq, BASELINE configs[1]"
+            line["workloads"] = dict({"acq": {k: a[k] for k in a if k not in ("metric", "config")}},
+                                     **{wl: rs[wl] for wl in ALL_WORKLOADS[1:]})
+            line["config"]["also_in_this_line"] = ("workloads.wf14 / ddc14 / cfg2_chain: BASELINE configs[2] (frames, DDC, end to "
+                                                   "end); workloads.receivers: configs[3] per-GPU share; workloads.acq10ms: configs[4]")
     else:
-        import torch
-        a = run_acq(args, dist)
-        torch.cuda.empty_cache()
-        w = run_wf14(args, dist)
-        torch.cuda.empty_cache()
-        d = run_ddc14(args, dist)
-        line = dict(a, **common)
-        line["metric"] = "IQ Msamples/s ingested (waterfall + GPS acq); value = GPS acq, BASELINE configs[1]"
-        line["workloads"] = {"acq": {k: a[k] for k in a if k not in ("metric", "config")},
-                             "wf14": w, "ddc14": d}
-        line["config"]["also_in_this_line"] = "workloads.wf14 and workloads.ddc14: BASELINE configs[2]"
+        r = run(args.workload)
+        line = dict(common, **r)
     if dist.rank == 0:
         print(json.dumps(line), flush=True)
     dist.close()

@@ -61,6 +61,7 @@ SYMBOLS = {
     "kg_dev_mem_info": (_i, [_vp, _vp, _vp]),
     "kg_timer_start": (_i, [_vp]),
     "kg_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
+    "kg_ctx_mark": (_i, [_vp, _i]),
     "kg_acq_create": (_i, [_vp, _i, _i, _i, _i, C.POINTER(_vp)]),
     "kg_acq_create_shape": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
     "kg_acq_nsamples": (_i, [_vp]),
@@ -88,6 +89,7 @@ SYMBOLS = {
     "kg_wf_set_tables": (_i, [_vp, _vp, _vp]),
     "kg_wf_set_channel": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "kg_wf_frames_dev": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "kg_wf_frames_at_dev": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "kg_wf_frames": (_i, [_vp, _i, _vp, _vp, _vp]),
     "kg_wf_debug_frame": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "kg_ddc_create": (_i, [_vp, _i, _sz, C.POINTER(_vp)]),
@@ -161,7 +163,12 @@ def _share_hip_runtime_with_torch():
         return
     import importlib.util
     if importlib.util.find_spec("torch") is not None:
-        import torch  # noqa: F401
+        try:
+            import torch  # noqa: F401
+        except Exception as e:      # noqa: BLE001 -- a broken torch install must not take the C-ABI users down
+            import warnings
+            warnings.warn("kiwigpu: torch is installed but failed to import (%s: %s); libkiwigpu.so will use "
+                          "the system HIP runtime" % (type(e).__name__, e))
 
 
 def load_library():
@@ -273,6 +280,10 @@ class Context:
         f, t = C.c_size_t(), C.c_size_t()
         check(self.lib.kg_dev_mem_info(self.h, C.byref(f), C.byref(t)), "kg_dev_mem_info")
         return f.value, t.value
+
+    def mark(self, tag):
+        """profiling aid: an empty kernel of `tag` workgroups on the stream (kg_ctx_mark)"""
+        check(self.lib.kg_ctx_mark(self.h, int(tag)), "kg_ctx_mark")
 
     def timer_start(self):
         check(self.lib.kg_timer_start(self.h), "kg_timer_start")

@@ -294,7 +294,11 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
     // group and that spectrum stays in one L2.  Speed only, never correctness.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
     const int gpairs = (walk.npairs - xcd + 7) >> 3;           // pairs xcd, xcd + 8, ...
-    const int ndop = walk.ndop, ncell = gpairs * ndop;
+    // Fewer pairs than groups -- the reference's own calling pattern, one SV per Correlate() call -- would
+    // leave 8 - npairs XCDs idle: the CELLS are then dealt round-robin instead (cell c of the launch, pair-major,
+    // belongs to group c & 7); the code spectrum lands in several L2s, which one or a few pairs can afford.
+    const bool spread = walk.npairs < 8;
+    const int ndop = walk.ndop, ncell = spread ? (walk.npairs * ndop - xcd + 7) >> 3 : gpairs * ndop;
 
     // Operand fetch: eight 16-byte buffer loads per spectrum.  The descriptor
     // (SGPRs) carries the plane base, soffset the row, voffset the lane column:
@@ -342,8 +346,9 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
     };
     // cell index -> descriptor: one (uniform) division, one s_load_dwordx4
     auto describe = [&](int idx) {
-        const int pg = idx / ndop, di = idx - pg * ndop;
-        const acq_pair_desc pd = pairs[(pg << 3) + xcd];
+        const int cell = spread ? (idx << 3) + xcd : idx;
+        const int pg = cell / ndop, di = cell - pg * ndop;
+        const acq_pair_desc pd = pairs[spread ? pg : (pg << 3) + xcd];
         return acq_cell_desc{pd.data_off, pd.code_off, walk.dop_lo + di, pd.limit, pd.out + di};
     };
 

@@ -88,7 +88,19 @@ void kg_stage_cache_free(kg_stage_cache *sc)
     sc->dev = nullptr; sc->host = nullptr; sc->cap = sc->bytes = 0;
 }
 
+__global__ void kg_mark_kernel() {}
+
 extern "C" {
+
+int kg_ctx_mark(kg_ctx *c, int tag)
+{
+    int rc = kg_ctx_use(c);
+    if (rc) return rc;
+    KG_REQUIRE(tag >= 1 && tag <= 65535, KG_ERR_INVALID, "kg_ctx_mark: tag %d (1..65535)", tag);
+    hipLaunchKernelGGL(kg_mark_kernel, dim3(tag), dim3(64), 0, c->stream);
+    KG_HIP(hipGetLastError());
+    return KG_OK;
+}
 
 const char *kg_last_error(void) { return g_err; }
 

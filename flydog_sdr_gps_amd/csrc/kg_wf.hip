@@ -52,8 +52,8 @@ struct wf_chan_dev {
 
 template <bool TAPS>
 __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
-    const short2 *__restrict__ iq,            // [nframes][8192] iq_t {i, q}
-    const int *__restrict__ chan_of,          // [nframes]
+    const short2 *__restrict__ iq,            // iq_t {i, q}: frame f = 8192 of them from iq + 2 * frames[f].y
+    const int2 *__restrict__ frames,          // [nframes] {channel, offset of the frame's first sample in units of two iq_t}
     const wf_chan_dev *__restrict__ chans,
     const float *__restrict__ windows,        // [4][8192]
     const float *__restrict__ cic_comp,       // [8192], kg_wf_set_tables' order: pairs of bins, then 4096 x 1.0f
@@ -85,8 +85,8 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
     // the next frame's even samples land there while the rest of this frame is computed.  The frame
     // fetch is the kernel's one HBM access: at the top of the loop its whole latency was exposed.
     int2 raw[16];
-    auto fetch = [&](int f) {
-        const int2 *src = (const int2 *) (iq + (size_t) f * WF_NFFT);
+    auto fetch = [&](int off2) {
+        const int2 *src = (const int2 *) iq + (size_t) (unsigned) off2;
 #pragma unroll
         for (int j = 0; j < 16; j++) raw[j] = src[t + 256 * j];         // samples 2 n1 (even) and 2 n1 + 1 (odd), n1 = t + 256 j
     };
@@ -116,14 +116,15 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
     // claimed at the top of a frame and crosses the workgroup through LDS at the power-stage barrier.
     // The last workgroup to leave resets the two counters for the next launch.
     int f = blockIdx.x, fn = blockIdx.x + gridDim.x;
-    int cid = chan_of[f];                     // grid <= nframes: every workgroup has a first frame
-    fetch(f);
+    int cid;                                  // grid <= nframes: every workgroup has a first frame
+    { const int2 fr = frames[f]; cid = fr.x; fetch(fr.y); }
     fetch_window(windows + (size_t) chans[cid].window_func * WF_NFFT);
     for (;;) {
         const wf_chan_dev *ch = chans + cid;
         const int interp = ch->interp, dc = ch->dc, comp_on = ch->comp_on;
         const bool more = fn < nframes;
-        const int cid_next = chan_of[more ? fn : f];
+        const int2 fr_next = frames[more ? fn : f];
+        const int cid_next = fr_next.x;
         const int wfn_next = chans[cid_next].window_func;
         int claimed = 0;
         if (t == 0) claimed = 2 * gridDim.x + __hip_atomic_fetch_add(&claim[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
         windowed(x, 0);
         kg_subfft4096_l<-1>(x, y0, tileA, tileB, tw1, p2, t);
         windowed(x, 1);
-        if (more) fetch(fn);                  // the next frame, both parities, into the registers just consumed
+        if (more) fetch(fr_next.y);           // the next frame, both parities, into the registers just consumed
         // CIC compensation factors of this thread's sixteen bins, fetched here in one batch and used
         // after the transform (one load + wait per bin inside the power loop cost sixteen exposed L2
         // round trips per frame)
@@ -270,7 +271,8 @@ struct kg_wf {
     wf_chan_dev *d_chans;
     float *d_windows, *d_cic;
     short2 *d_iq;    unsigned char *d_out;  int stage_cap;      // staging for host-buffer calls
-    kg_stage_cache chan_of_cache;          // the frame -> channel map of the last batch (usually unchanged)
+    kg_stage_cache chan_of_cache;          // the {channel, offset} records of the last batch (usually unchanged)
+    std::vector<int2> frame_tab;
     float *d_tap_pwr, *d_tap_pwr_out, *d_tap_db;
     int *d_claim;                             // wf_frame_kernel's two counters, zero between launches
     std::vector<char> chan_set;
@@ -340,9 +342,11 @@ int kg_wf_set_tables(kg_wf *w, const float *windows, const float *cic_comp)
         std::vector<float> tr(WF_NFFT, 1.0f);
         for (int t = 0; t < 256; t++)
             for (int m = 0; m < 16; m++) tr[(m >> 1) * 512 + 2 * t + (m & 1)] = cic_comp[t + 256 * m];
-        KG_HIP(hipMemcpy(w->d_cic, tr.data(), sizeof(float) * WF_NFFT, hipMemcpyHostToDevice));
+        // in stream order like the window copy (frames still queued read the old table); the synchronise
+        // below keeps `tr` alive until the transfer has run
+        KG_HIP(hipMemcpyAsync(w->d_cic, tr.data(), sizeof(float) * WF_NFFT, hipMemcpyHostToDevice, st));
+        KG_HIP(hipStreamSynchronize(st));
     }
-    KG_HIP(hipStreamSynchronize(st));
     w->tables_set = true;
     return KG_OK;
 }
@@ -403,7 +407,8 @@ int kg_wf_set_channel(kg_wf *w, int ch, const kg_wf_chan_cfg *cfg, const uint16_
     return KG_OK;
 }
 
-static int wf_launch(kg_wf *w, int nframes, const int32_t *chan_of, const void *d_iq, void *d_out, bool taps)
+static int wf_launch(kg_wf *w, int nframes, const int32_t *chan_of, const uint64_t *frame_off, const void *d_iq,
+                     void *d_out, bool taps)
 {
     KG_REQUIRE(w->tables_set, KG_ERR_STATE, "kg_wf_frames: kg_wf_set_tables was not called");
     KG_REQUIRE(nframes >= 1, KG_ERR_INVALID, "kg_wf_frames: nframes %d", nframes);
@@ -413,21 +418,29 @@ static int wf_launch(kg_wf *w, int nframes, const int32_t *chan_of, const void *
         KG_REQUIRE(w->chan_set[chan_of[f]], KG_ERR_STATE, "kg_wf_frames: channel %d is not configured", chan_of[f]);
     }
     hipStream_t st = w->ctx->stream;
-    void *d_chan_of = nullptr;                 // chan_of is the caller's: staged copy, no stream synchronisation
+    // per-frame records {channel, offset / 2}: frames back to back unless the caller says where each one starts
+    w->frame_tab.resize(nframes);
+    for (int f = 0; f < nframes; f++) {
+        const uint64_t off = frame_off ? frame_off[f] : (uint64_t) f * WF_NFFT;
+        KG_REQUIRE((off & 1) == 0 && off < ((uint64_t) 1 << 32), KG_ERR_INVALID,
+                   "kg_wf_frames: frame_off[%d] = %llu (even, below 2^32 samples)", f, (unsigned long long) off);
+        w->frame_tab[f] = make_int2(chan_of[f], (int) (unsigned) (off >> 1));
+    }
+    void *d_chan_of = nullptr;                 // the arrays are the caller's: staged copy, no stream synchronisation
     {
-        int rc = kg_ctx_stage_cached(w->ctx, &w->chan_of_cache, chan_of, sizeof(int) * nframes, &d_chan_of);
+        int rc = kg_ctx_stage_cached(w->ctx, &w->chan_of_cache, w->frame_tab.data(), sizeof(int2) * nframes, &d_chan_of);
         if (rc) return rc;
     }
     const int grid = nframes < w->grid ? nframes : w->grid;
     if (!taps) {
         hipLaunchKernelGGL(wf_frame_kernel<false>, dim3(grid), dim3(256), WF_LDS_BYTES, st,
-                           (const short2 *) d_iq, (const int *) d_chan_of, (const wf_chan_dev *) w->d_chans,
+                           (const short2 *) d_iq, (const int2 *) d_chan_of, (const wf_chan_dev *) w->d_chans,
                            (const float *) w->d_windows, (const float *) w->d_cic,
                            (const float2 *) w->ctx->d_tab4096, (const float2 *) w->ctx->d_tab8192, nframes,
                            (unsigned char *) d_out, w->d_claim, (float *) nullptr, (float *) nullptr, (float *) nullptr);
     } else {
         hipLaunchKernelGGL(wf_frame_kernel<true>, dim3(grid), dim3(256), WF_LDS_BYTES, st,
-                           (const short2 *) d_iq, (const int *) d_chan_of, (const wf_chan_dev *) w->d_chans,
+                           (const short2 *) d_iq, (const int2 *) d_chan_of, (const wf_chan_dev *) w->d_chans,
                            (const float *) w->d_windows, (const float *) w->d_cic,
                            (const float2 *) w->ctx->d_tab4096, (const float2 *) w->ctx->d_tab8192, nframes,
                            (unsigned char *) d_out, w->d_claim, w->d_tap_pwr, w->d_tap_pwr_out, w->d_tap_db);
@@ -443,7 +456,18 @@ int kg_wf_frames_dev(kg_wf *w, int nframes, const int32_t *chan_of, const void *
     if (rc) return rc;
     KG_REQUIRE(((uintptr_t) d_iq & 7) == 0 && ((uintptr_t) d_out & 3) == 0, KG_ERR_INVALID,
                "kg_wf_frames_dev: d_iq must be 8-byte and d_out 4-byte aligned");
-    return wf_launch(w, nframes, chan_of, d_iq, d_out, false);
+    return wf_launch(w, nframes, chan_of, nullptr, d_iq, d_out, false);
+}
+
+int kg_wf_frames_at_dev(kg_wf *w, int nframes, const int32_t *chan_of, const uint64_t *frame_off, const void *d_iq,
+                        void *d_out)
+{
+    KG_REQUIRE(w && chan_of && frame_off && d_iq && d_out, KG_ERR_INVALID, "kg_wf_frames_at_dev: null argument");
+    int rc = kg_ctx_use(w->ctx);
+    if (rc) return rc;
+    KG_REQUIRE(((uintptr_t) d_iq & 7) == 0 && ((uintptr_t) d_out & 3) == 0, KG_ERR_INVALID,
+               "kg_wf_frames_at_dev: d_iq must be 8-byte and d_out 4-byte aligned");
+    return wf_launch(w, nframes, chan_of, frame_off, d_iq, d_out, false);
 }
 
 static int wf_stage(kg_wf *w, int nframes)
@@ -469,7 +493,7 @@ int kg_wf_frames(kg_wf *w, int nframes, const int32_t *chan_of, const int16_t *i
     if ((rc = wf_stage(w, nframes)) != KG_OK) return rc;
     hipStream_t st = w->ctx->stream;
     KG_HIP(hipMemcpyAsync(w->d_iq, iq, sizeof(short2) * WF_NFFT * (size_t) nframes, hipMemcpyHostToDevice, st));
-    if ((rc = wf_launch(w, nframes, chan_of, w->d_iq, w->d_out, false)) != KG_OK) return rc;
+    if ((rc = wf_launch(w, nframes, chan_of, nullptr, w->d_iq, w->d_out, false)) != KG_OK) return rc;
     KG_HIP(hipMemcpyAsync(out, w->d_out, (size_t) WF_WIDTH * nframes, hipMemcpyDeviceToHost, st));
     KG_HIP(hipStreamSynchronize(st));
     return KG_OK;
@@ -490,7 +514,7 @@ int kg_wf_debug_frame(kg_wf *w, int ch, const int16_t *iq, uint8_t *out, float *
     KG_HIP(hipMemsetAsync(w->d_tap_pwr, 0, sizeof(float) * SUB, st));
     KG_HIP(hipMemcpyAsync(w->d_iq, iq, sizeof(short2) * WF_NFFT, hipMemcpyHostToDevice, st));
     const int32_t c = ch;
-    if ((rc = wf_launch(w, 1, &c, w->d_iq, w->d_out, true)) != KG_OK) return rc;
+    if ((rc = wf_launch(w, 1, &c, nullptr, w->d_iq, w->d_out, true)) != KG_OK) return rc;
     KG_HIP(hipMemcpyAsync(out, w->d_out, WF_WIDTH, hipMemcpyDeviceToHost, st));
     KG_HIP(hipMemcpyAsync(pwr, w->d_tap_pwr, sizeof(float) * SUB, hipMemcpyDeviceToHost, st));
     KG_HIP(hipMemcpyAsync(pwr_out, w->d_tap_pwr_out, sizeof(float) * WF_WIDTH, hipMemcpyDeviceToHost, st));

@@ -47,6 +47,18 @@ def gather_results(local, device=None):
     return np.concatenate(parts, axis=0)
 
 
+def merge_sv_shards(parts, nblocks, ranges):
+    """Strong-scaling acquisition (first bullet): rank r searched the SVs ranges[r] = (lo, hi) of the
+    SAME nblocks sample blocks and holds results [nblocks][hi - lo] (block-major, the layout of kg_acq_fetch) at the
+    start of its gathered row parts[r] (rows are padded to the largest share).  -> [nblocks][total SVs]."""
+    total = ranges[-1][1]
+    out = np.zeros((nblocks, total), parts.dtype)
+    for r, (lo, hi) in enumerate(ranges):
+        if hi > lo:
+            out[:, lo:hi] = np.asarray(parts[r])[:nblocks * (hi - lo)].reshape(nblocks, hi - lo)
+    return out
+
+
 def best_of(results):
     """Merge per-rank kg_acq_result rows for the SAME (block, SV) searched over
     disjoint Doppler ranges: keep the higher snr, ties to the lower Doppler bin,

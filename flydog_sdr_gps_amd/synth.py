@@ -100,31 +100,19 @@ CONFIG4_PRESENT = [(0, 300.5, 1500.0, 0.7, 41.0), (6, 911.0, 7300.0, 0.1, 40.0),
                    (58, 12.0, 60.0, 0.3, 42.0)]                        # E1B E36
 
 
-def e1b_chips_fixture(path=None):
-    """{prn: chips uint8[4092]} from tests/golden/e1b_ref.npz: the 50 Galileo E1-B memory codes as the
-    reference's own gps/e1bcode.h produced them (tools/make_ref_golden.py).  Input data for tests
-    and bench.py; in a deployment the caller hands over its own table."""
-    import os
-    if path is None:
-        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
-                            "e1b_ref.npz")
-    g = np.load(path)
-    chips = np.unpackbits(g["chips_packed"], axis=1)[:, :4092]
-    return {i + 1: chips[i].copy() for i in range(chips.shape[0])}
-
-
-def all_sv_codes(e1b=None):
-    """[(chips, boc)] for every row of sats.SATS (36 C/A + QZSS rows, 23 E1B rows)."""
-    e1b = e1b if e1b is not None else e1b_chips_fixture()
+def all_sv_codes(e1b):
+    """[(chips, boc)] for every row of sats.SATS (36 C/A + QZSS rows, 23 E1B rows).
+    e1b: {prn: chips uint8[4092]} -- the Galileo E1-B memory codes are ICD data the CALLER hands over
+    (tests and bench.py take them from tests/fixtures.py)."""
     out = []
     for prn, t1, t2, kind in _sats.SATS:
         out.append((e1b[prn], True) if kind == _sats.E1B else (_prn.cacode(t1, t2), False))
     return out
 
 
-def config4_iq16(seed=0x5EED0005, codes=None, present=CONFIG4_PRESENT):
-    """One 10 ms block of complex int16 IF samples holding the SVs of CONFIG4_PRESENT."""
-    codes = codes if codes is not None else all_sv_codes()
+def config4_iq16(codes, seed=0x5EED0005, present=CONFIG4_PRESENT):
+    """One 10 ms block of complex int16 IF samples holding the SVs of CONFIG4_PRESENT
+    (codes = all_sv_codes(e1b))."""
     svs = [(codes[sat][0], tau, fd, th, cn0, codes[sat][1]) for sat, tau, fd, th, cn0 in present]
     return gps_scene_iq16(svs, seed, n=NSAMPLES_10MS)
 

@@ -158,11 +158,19 @@ class Waterfall:
               "kg_wf_frames")
         return out
 
-    def frames_dev(self, chan_of, d_iq, d_out):
-        """Device pointers (ints); enqueue only."""
+    def frames_dev(self, chan_of, d_iq, d_out, frame_off=None):
+        """Device pointers (ints); enqueue only.  frame_off: where each frame starts, in iq_t pairs
+        after d_iq (default: frames back to back)."""
         chan_of = np.ascontiguousarray(chan_of, np.int32)
-        check(self.lib.kg_wf_frames_dev(self.h, chan_of.size, ptr(chan_of), ptr(int(d_iq)),
-                                        ptr(int(d_out))), "kg_wf_frames_dev")
+        if frame_off is None:
+            check(self.lib.kg_wf_frames_dev(self.h, chan_of.size, ptr(chan_of), ptr(int(d_iq)),
+                                            ptr(int(d_out))), "kg_wf_frames_dev")
+            return
+        frame_off = np.ascontiguousarray(frame_off, np.uint64)
+        if frame_off.size != chan_of.size:
+            raise ValueError("frame_off and chan_of differ in length")
+        check(self.lib.kg_wf_frames_at_dev(self.h, chan_of.size, ptr(chan_of), ptr(frame_off), ptr(int(d_iq)),
+                                           ptr(int(d_out))), "kg_wf_frames_at_dev")
 
     def debug_frame(self, ch, iq):
         iq = np.ascontiguousarray(iq, np.int16).reshape(WF_NFFT, 2)

@@ -81,6 +81,11 @@ int kg_dev_mem_info(kg_ctx *ctx, size_t *free_bytes, size_t *total_bytes);
 /* HIP-event stopwatch on the context's stream (bench.py and C++ callers). */
 int kg_timer_start(kg_ctx *ctx);
 int kg_timer_stop(kg_ctx *ctx, float *elapsed_ms);    /* synchronises on the stop event */
+/* Profiling aid: enqueues an empty kernel (`kg_mark_kernel`) of `tag` workgroups of 64 threads on the
+ * context's stream (1 <= tag <= 65535).  Counter rows of `rocprofv3 --pmc`, which carry no timestamps
+ * or user markers, can then be attributed to the phase between two tags by dispatch order
+ * (bench.py's live HBM-traffic passes). */
+int kg_ctx_mark(kg_ctx *ctx, int tag);
 
 /* ------------------------------------------------------------------------ */
 /* GPS C/A + E1B parallel-code-phase acquisition.                            */
@@ -167,9 +172,12 @@ int kg_acq_get_data_fft(kg_acq *acq, int block, float *data_fft);
 int kg_acq_get_data_td(kg_acq *acq, int block, float *td);
 
 /* Correlate() for nsats SVs x (dop_hi-dop_lo+1) bins x nblocks blocks
- * (blocks 0..nblocks-1), one launch.  Enqueue only: the call never waits for the
- * stream, also when the SV list differs from the previous call's (the reference's
- * SearchTask loop asks for one SV at a time).
+ * (blocks 0..nblocks-1), one launch.  Enqueue only: no stream synchronisation in steady
+ * state, also when the SV list differs from the previous call's (the reference's
+ * SearchTask loop asks for one SV at a time); the pair table goes through the context's
+ * staging ring, whose slot reuse can wait on an event once 32 uploads are outstanding.
+ * With fewer than 8 (block, SV) pairs in a launch -- that calling pattern -- the cells,
+ * not the pairs, are dealt over the 8 XCDs, so one SV's bins use the whole GPU.
  * Stream model: Sample() and Correlate() run in order on the context's stream
  * (a second stream for Sample() is an opt-in experiment). */
 int kg_acq_correlate_async(kg_acq *acq, int nblocks, const int *sats, int nsats);
@@ -225,6 +233,11 @@ int kg_wf_set_channel(kg_wf *wf, int ch, const kg_wf_chan_cfg *cfg, const uint16
  * bytes (wf_pkt_t.un.buf).  _dev: device pointers, enqueue only. */
 int kg_wf_frames_dev(kg_wf *wf, int nframes, const int32_t *chan_of, const void *d_iq, void *d_out);
 int kg_wf_frames(kg_wf *wf, int nframes, const int32_t *chan_of, const int16_t *iq, uint8_t *out);
+/* The same for frames that are NOT back to back: frame f starts frame_off[f] samples (iq_t pairs; even,
+ * below 2^32) after d_iq -- frames taken where the DDC left them (kg_ddc_wf_push_dev's per-channel rows),
+ * the way sample_wf() reads the FPGA's sample ring in place (rx/rx_waterfall.cpp:1036-1066). */
+int kg_wf_frames_at_dev(kg_wf *wf, int nframes, const int32_t *chan_of, const uint64_t *frame_off,
+                        const void *d_iq, void *d_out);
 /* One frame with the intermediate arrays of compute_frame(): pwr[4096] (entries
  * below fft_used are written), pwr_out[1024], dB[1024] (before the clamp). */
 int kg_wf_debug_frame(kg_wf *wf, int ch, const int16_t *iq, uint8_t *out, float *pwr,

@@ -54,7 +54,9 @@ def lib():
     global _lib
     if _lib is None:
         build()
-        L = C.CDLL(_LIB_PATH)
+        # KIWI_ORACLE_LIBRARY: another build of the same sources (the sanitizer build, oracle/Makefile `asan`;
+        # bench.py's -march=native build for the cpu_baseline leg)
+        L = C.CDLL(os.environ.get("KIWI_ORACLE_LIBRARY") or _LIB_PATH)
         vp = C.c_void_p
         L.ko_cacode.argtypes = [C.c_int, C.c_int, vp]
         L.ko_e1b_from_hex.argtypes = [C.c_char_p, vp]

@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 from flydog_sdr_gps_amd import Searcher, acq, sats, synth
+from tests.fixtures import e1b_chips
 
 pytestmark = pytest.mark.gpu
 
@@ -26,7 +27,7 @@ def relmax(a, b):
 
 @pytest.fixture(scope="module")
 def codes():
-    return synth.all_sv_codes()
+    return synth.all_sv_codes(e1b_chips())
 
 
 @pytest.fixture(scope="module")
@@ -61,7 +62,7 @@ def test_code_tables_65536(searcher10, oracle_codes):
 
 
 def test_sample_10ms_iq16_and_bits(searcher10, oracle, codes):
-    iq = synth.config4_iq16(codes=codes)
+    iq = synth.config4_iq16(codes)
     searcher10.sample_iq16(iq)
     want, td = oracle.sample_iq16(iq, want_td=True, nsamples=N10, fft_len=FFT10)
     got_td = searcher10.get_data_td()
@@ -82,7 +83,7 @@ def test_sample_10ms_iq16_and_bits(searcher10, oracle, codes):
 
 def test_config4_all_59_svs_256_bins(searcher10, oracle, codes, oracle_codes):
     """Every one of the 59 x 256 = 15104 cells against the oracle chain run from the samples."""
-    iq = synth.config4_iq16(codes=codes)
+    iq = synth.config4_iq16(codes)
     searcher10.sample_iq16(iq)
     svs = list(range(len(codes)))
     res, cells = searcher10.correlate_many(svs)
@@ -132,7 +133,7 @@ def test_injected_spectrum_and_shift_edges_65536(searcher10, oracle_codes, oracl
 def test_two_blocks_per_sv_calls_and_zero_input(searcher10, oracle, codes, oracle_codes):
     """Two resident 10 ms blocks in one launch; then the reference's calling pattern -- one SV per
     Correlate() call, the list changing every time (no call may disturb another's tables)."""
-    iqs = [synth.config4_iq16(seed=900 + b, codes=codes) for b in range(2)]
+    iqs = [synth.config4_iq16(codes, seed=900 + b) for b in range(2)]
     for b in range(2):
         searcher10.sample_iq16(iqs[b], block=b)
     svs = [0, 36, 21, 45, 5]

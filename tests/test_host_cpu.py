@@ -251,6 +251,84 @@ def test_bench_gpus_flag_launches_ranks():
         assert out.returncode != 0 and "needs GPU" in out.stderr
 
 
+def test_bench_shard_sv_world2_on_the_stub():
+    """`bench.py --workload acq10ms --shard sv` splits the 59 SVs of ONE block over the ranks, all-gathers the
+    winners and merges them (shard.split_units / merge_sv_shards).  The exchange runs here at world 2 over gloo
+    on the GPU-free stub: the merged table must equal the unsharded one (asserted inside, reported in the line)."""
+    import json
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, bench, "--gpus", "2", "--workload", "stub", "--shard", "sv"], env=env,
+                         capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert line["scaling"] == "strong" and line["shard_sv"] == {"world": 2, "ranges": [[0, 30], [30, 59]],
+                                                                  "merged_equals_unsharded": True}
+
+
+def test_merge_sv_shards_layout():
+    from flydog_sdr_gps_amd import shard
+    from flydog_sdr_gps_amd._lib import result_dtype
+    B, ranges = 3, shard.split_units(7, 3)                    # shares of 3, 2, 2 SVs
+    full = np.zeros((B, 7), result_dtype)
+    full["snr"] = np.arange(21).reshape(B, 7)
+    full["dop"] = full["snr"].astype(int) - 5
+    parts = np.zeros((3, B * 3), result_dtype)               # rows padded to the largest share
+    for r, (lo, hi) in enumerate(ranges):
+        parts[r, :B * (hi - lo)] = full[:, lo:hi].reshape(-1)
+        parts[r, B * (hi - lo):]["snr"] = -1                  # slack must not leak
+    assert np.array_equal(shard.merge_sv_shards(parts, B, ranges), full)
+
+
+def test_bench_attributes_counter_rows_to_marked_windows(tmp_path):
+    """bench.py's live HBM-traffic passes: `rocprofv3 --pmc` rows carry no timestamps, so a workload's rows are the
+    ones dispatched between its two kg_ctx_mark kernels (grid size = tag).  Parser and attribution on a made-up CSV."""
+    import bench
+    t_acq, t_ddc = bench.pmc_tag("acq"), bench.pmc_tag("ddc14")
+    rows = [("setup_kernel", 10, 5.0), ("kg_mark_kernel()", t_acq, 0.0)]
+    for _ in range(bench.PMC_STEPS):
+        rows += [("acq_frontend_kernel<1>", 64, 7.0), ("void acq_correlate_kernel<4, 1, true, false>(...)", 512, 100.0)]
+    rows += [("kg_mark_kernel()", t_acq + 1, 0.0), ("noise", 3, 1e6), ("kg_mark_kernel()", t_ddc, 0.0)]
+    for _ in range(bench.PMC_STEPS):
+        rows += [("ddc_pass_a", 100, 10.0), ("ddc_pass_b", 100, 30.0)]
+    rows += [("kg_mark_kernel()", t_ddc + 1, 0.0)]
+    f = tmp_path / "x_counter_collection.csv"
+    with open(f, "w") as fh:
+        fh.write("Dispatch_Id,Kernel_Name,Grid_Size,Workgroup_Size,Counter_Name,Counter_Value\n")
+        for i, (name, groups, val) in enumerate(rows):
+            fh.write('%d,"%s",%d,64,FETCH_SIZE,%f\n' % (i + 1, name, groups * 64, val))
+            fh.write('%d,"%s",%d,64,OTHER,%f\n' % (i + 1, name, groups * 64, 999.0))
+    parsed = bench.parse_counter_rows([str(f)], "FETCH_SIZE")
+    assert len(parsed) == len(rows)
+    kb, top = bench.window_traffic(parsed, "acq")            # the dominant kernel, per launch
+    assert kb == 100.0 and max(top, key=top.get).startswith("void acq_correlate")
+    kb, top = bench.window_traffic(parsed, "ddc14")          # every kernel of the step, per step
+    assert kb == 40.0 and top == {"ddc_pass_b": 30.0, "ddc_pass_a": 10.0}
+    with pytest.raises(RuntimeError):
+        bench.window_traffic(parsed, "wf14")                 # no such window in this pass
+
+
+def test_bench_numpy_waterfall_rows_equal_the_oracle(oracle):
+    """bench.py's cpu_baseline_pocketfft leg for the waterfall (scipy.fft + numpy) must be the same computation as the
+    oracle's compute_frame (WF_CMA), or its timing would be of something else: rows identical on two zooms."""
+    import bench
+    from flydog_sdr_gps_amd import WfParams, synth, wf
+    tables = (wf.window_functions(), wf.cic_comp_table())
+    base = np.stack([synth.wf_iq_frame(seed=i) for i in range(2)])
+    for z in (0, 5):
+        p = WfParams.for_zoom(z, 1.0e6)
+        fmap, drop = wf.build_maps(p.fft_used, p.plot_width, p.plot_width_clamped, False)
+        rows = bench.wf_rows_numpy(base, p, tables[0][wf.WINF_HANNING], tables[1], fmap, p.zoom > 1)
+        sc = np.full(1024, p.fft_scale, np.float32)
+        for f in range(2):
+            samps = oracle.wf_window_iq(base[f], tables[0][wf.WINF_HANNING])
+            want = oracle.wf_compute_frame(samps, p.zoom, wf.WINF_HANNING, wf.WF_CMA, True, False, p.fft_used, p.plot_width,
+                                           p.plot_width_clamped, fmap, drop, sc, (sc / np.float32(2)).astype(np.float32),
+                                           p.fft_offset, tables[1], prec=0)[0]
+            d = np.abs(rows[f].astype(int) - want.astype(int))
+            assert d.max() <= 1 and (d == 0).mean() > 0.99
+
+
 def _have_gpu_count(n):
     try:
         import torch

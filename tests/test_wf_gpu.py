@@ -202,6 +202,45 @@ def test_channel_map_changing_between_calls(engine, oracle, tables):
             check_row(out[k], w_out, w_dB, db_bound(w_po))
 
 
+def test_frames_read_in_place_at_offsets(engine, gpu_ctx, oracle, tables):
+    """kg_wf_frames_at_dev: frames that are not back to back (taken where the DDC left them: per-channel rows, a
+    frame starting anywhere on an even sample).  Five frames scattered over a buffer in a shuffled order, offsets
+    changing between two calls of the same length -- every row against the oracle on the samples at ITS offset;
+    an odd offset is refused."""
+    from flydog_sdr_gps_amd import KiwiGpuError
+    zooms = [0, 4, 9]
+    ps = []
+    for ch, z in enumerate(zooms):
+        p = WfParams.for_zoom(z, 1.0e6 * ch)
+        ps.append(p)
+        engine.set_channel(ch, p, interp=wf.WF_CMA, window_func=wf.WINF_HANNING, cic_comp=True)
+    nbuf = 6 * 8192 + 4096
+    rng = np.random.default_rng(11)
+    buf = np.zeros((nbuf, 2), np.int16)
+    frames = [synth.wf_iq_frame(seed=900 + i) for i in range(5)]
+    d_iq = gpu_ctx.alloc(buf.nbytes)
+    d_out = gpu_ctx.alloc(5 * 1024)
+    try:
+        for offs in ([2 * 8192 + 2, 0, 5 * 8192 + 4096, 8192 + 2048, 4 * 8192 - 6], [2, 8192 + 4, 2 * 8192 + 6, 3 * 8192 + 8, 5 * 8192]):
+            buf[:] = rng.integers(-100, 100, buf.shape)
+            for fr, off in zip(frames, offs):
+                buf[off:off + 8192] = fr
+            chan_of = [1, 0, 2, 1, 0]
+            gpu_ctx.upload(d_iq, buf)
+            engine.frames_dev(chan_of, d_iq, d_out, frame_off=offs)
+            out = np.zeros((5, 1024), np.uint8)
+            gpu_ctx.download(d_out, out)
+            for k, ch in enumerate(chan_of):
+                w_out, _, w_po, w_dB = oracle_frame(oracle, tables, buf[offs[k]:offs[k] + 8192], ps[ch], wf.WF_CMA,
+                                                    wf.WINF_HANNING, True, False, False)
+                check_row(out[k], w_out, w_dB, db_bound(w_po))
+        with pytest.raises(KiwiGpuError):
+            engine.frames_dev([0], d_iq, d_out, frame_off=[3])
+    finally:
+        gpu_ctx.free(d_iq)
+        gpu_ctx.free(d_out)
+
+
 def test_wf_error_paths(gpu_ctx, tables):
     from flydog_sdr_gps_amd import KiwiGpuError
     w = Waterfall(gpu_ctx, nchan=2)

@@ -5,14 +5,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from flydog_sdr_gps_amd import Context, Searcher, acq, sats, synth
 from oracle import kiwi_oracle as ko
+from tests.fixtures import e1b_chips
 
 N10, FFT10 = acq.NSAMPLES_10MS, acq.FFT_LEN_10MS
-codes = synth.all_sv_codes()
+codes = synth.all_sv_codes(e1b_chips())
 ctx = Context(0)
 s = Searcher(ctx, dop_lo=-128, dop_hi=127, max_blocks=1, nsamples=N10, fft_len=FFT10)
 for sat, (chips, boc) in enumerate(codes):
     s.set_code(sat, chips, boc=boc)
-iq = synth.config4_iq16(codes=codes)
+iq = synth.config4_iq16(codes)
 s.sample_iq16(iq)
 data = ko.sample_iq16(iq, nsamples=N10, fft_len=FFT10)
 for svs in ([0], [8], [0, 8], [36], [37, 38], list(range(16)), list(range(59))):
