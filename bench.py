@@ -150,6 +150,16 @@ class Dist:
             dist.destroy_process_group()
 
 
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    """progress on stderr (stdout carries the ONE JSON line)"""
+    if os.environ.get("RANK", "0") == "0":
+        sys.stderr.write("bench.py [%6.1f s] %s\n" % (time.perf_counter() - _T0, msg))
+        sys.stderr.flush()
+
+
 def usable_cores():
     """Host threads this process can really run at once: the affinity mask, capped by the
     cgroup CPU quota (os.cpu_count() reports the machine, not the container)."""
@@ -328,6 +338,7 @@ def live_traffic_passes(args):
             if rc != 0:
                 raise RuntimeError("pass failed, status %d" % rc)
             rows = parse_counter_rows(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), counter)
+            log("counter pass %s: %d rows" % (counter, len(rows)))
             for wl in wls:
                 try:
                     kb.setdefault(wl, {})[counter] = window_traffic(rows, wl)
@@ -1152,7 +1163,6 @@ def run_cfg2_chain(args, dist):
     steps = max(2 * cyc, (args.steps + cyc - 1) // cyc * cyc)          # whole cycles
     elapsed, t_enq, spread = timed_steps(dist, step, steps, max(cyc, args.warmup // cyc * cyc))
     torch.cuda.synchronize(dev)
-    assert kstep[0] % cyc == 0
     ctx.timer_start()
     for _ in range(steps):
         step()
@@ -1561,6 +1571,7 @@ def main():
     if not args.no_cpu and not args.pmc_child and args.workload != "stub" and (world_env is None or int(world_env) == 1):
         native_oracle()                                      # before anything loads the oracle
         pocketfft_legs(args)                                 # forked workers: before this process touches the GPU
+        log("pocketfft legs done: %s" % {k: v.get("value") for k, v in POCKETFFT.items()})
     dist = Dist("gloo" if args.workload == "stub" else "nccl")
     common = {"n_gpus": dist.world, "steps": args.steps, "warmup": args.warmup, "preroll_s": PREROLL_S, "higher_is_better": True,
               "scaling": "weak", "vs_baseline": None, "data": "synthetic"}
@@ -1580,6 +1591,7 @@ def main():
               "acq59": lambda: run_acq(a, dist, all_svs=True), "wf14": lambda: run_wf14(a, dist),
               "ddc14": lambda: run_ddc14(a, dist), "cfg2_chain": lambda: run_cfg2_chain(a, dist),
               "receivers": lambda: run_receivers(a, dist)}[wl]
+        log("workload %s ..." % wl)
         r = fn()
         if dist.dev is not None:
             import torch
