@@ -27,7 +27,14 @@
 // the reference materialises (rev_buf, :58) never exists.  The Doppler shift
 // code[(k - dop) mod N] (:471) is, in this layout, a contiguous rotated read
 // of plane (k2 - dop) & 3.  E1B (16368 outputs) keeps four accumulators per
-// point, one per output quarter.
+// point, one per output quarter, in a 512-thread kernel at 8 points per thread
+// (acq_correlate8_kernel).  Its operands use a second arrangement of the same
+// planes, "layout B": element k1 = i + 512 j (the value thread i of 512 feeds
+// into leg j of its first radix-8) at row j>>1 (of 4), column 2*(i + H) + (j&1),
+// so that a thread fetches its 8 inputs with four 16-byte loads, contiguous
+// across the wave.  Every data spectrum is written in both arrangements by the
+// forward transform; a code spectrum in the one its kernel reads (B when the
+// SV's window is longer than 4096 lags).
 #include "kg_common.h"
 #include "kg_fft.h"
 
@@ -166,7 +173,8 @@ __global__ __launch_bounds__(256) void acq_fft_sub_kernel(const float2 *__restri
 
 template <int P>
 __global__ __launch_bounds__(256) void acq_fft_combine_kernel(const float2 *__restrict__ scratch,
-                                                             float2 *__restrict__ planes,
+                                                             float2 *__restrict__ planes,     // layout A, or null
+                                                             float2 *__restrict__ planes_b,   // layout B, or null
                                                              size_t planes_stride,   // in float2
                                                              const float2 *__restrict__ tabN,
                                                              int halo)               // H: 0 data, >0 code
@@ -174,7 +182,6 @@ __global__ __launch_bounds__(256) void acq_fft_combine_kernel(const float2 *__re
     static_assert(P == 4 || P == 16, "N = 16384 or 65536");
     const int k = blockIdx.x * 256 + threadIdx.x;      // k' < 4096
     const float2 *f = scratch + (size_t) blockIdx.y * (P * SUB);
-    float2 *out = planes + (size_t) blockIdx.y * planes_stride;
     cf v[P];
     v[0] = kg_ld(&f[k]);
 #pragma unroll
@@ -188,21 +195,41 @@ __global__ __launch_bounds__(256) void acq_fft_combine_kernel(const float2 *__re
     } else {
         kg_radix16<-1>(v, fq);
     }
-    // bin k + 4096 q -> plane k & (P-1), element k1 = k / P + (4096 / P) q = tt + 256 j
-    const int row = 2 * (256 + 2 * halo), plane = 8 * row;
-    float2 *o = out + (size_t) (k & (P - 1)) * plane;
+    // bin k + 4096 q -> plane k & (P-1), element k1 = k / P + (4096 / P) q
+    if (planes) {                                      // layout A: k1 = tt + 256 j -> row j>>1, column 2 (tt + H) + (j&1)
+        const int row = 2 * (256 + 2 * halo), plane = 8 * row;
+        float2 *o = planes + (size_t) blockIdx.y * planes_stride + (size_t) (k & (P - 1)) * plane;
 #pragma unroll
-    for (int q = 0; q < P; q++) {
-        const int k1 = k / P + (SUB / P) * q;
-        const int tt = k1 & 255, j = k1 >> 8;
-        kg_st(&o[(j >> 1) * row + 2 * (tt + halo) + (j & 1)], fq[q]);
-        if (tt < halo) {                               // also the right halo of leg j-1
-            const int jj = (j - 1) & 15;
-            kg_st(&o[(jj >> 1) * row + 2 * (tt + 256 + halo) + (jj & 1)], fq[q]);
+        for (int q = 0; q < P; q++) {
+            const int k1 = k / P + (SUB / P) * q;
+            const int tt = k1 & 255, j = k1 >> 8;
+            kg_st(&o[(j >> 1) * row + 2 * (tt + halo) + (j & 1)], fq[q]);
+            if (tt < halo) {                               // also the right halo of leg j-1
+                const int jj = (j - 1) & 15;
+                kg_st(&o[(jj >> 1) * row + 2 * (tt + 256 + halo) + (jj & 1)], fq[q]);
+            }
+            if (tt >= 256 - halo) {                        // and the left halo of leg j+1
+                const int jj = (j + 1) & 15;
+                kg_st(&o[(jj >> 1) * row + 2 * (tt - 256 + halo) + (jj & 1)], fq[q]);
+            }
         }
-        if (tt >= 256 - halo) {                        // and the left halo of leg j+1
-            const int jj = (j + 1) & 15;
-            kg_st(&o[(jj >> 1) * row + 2 * (tt - 256 + halo) + (jj & 1)], fq[q]);
+    }
+    if (planes_b) {                                    // layout B: k1 = ii + 512 j -> row j>>1, column 2 (ii + H) + (j&1)
+        const int row = 2 * (512 + 2 * halo), plane = 4 * row;
+        float2 *o = planes_b + (size_t) blockIdx.y * planes_stride + (size_t) (k & (P - 1)) * plane;
+#pragma unroll
+        for (int q = 0; q < P; q++) {
+            const int k1 = k / P + (SUB / P) * q;
+            const int ii = k1 & 511, j = k1 >> 9;
+            kg_st(&o[(j >> 1) * row + 2 * (ii + halo) + (j & 1)], fq[q]);
+            if (ii < halo) {
+                const int jj = (j - 1) & 7;
+                kg_st(&o[(jj >> 1) * row + 2 * (ii + 512 + halo) + (jj & 1)], fq[q]);
+            }
+            if (ii >= 512 - halo) {
+                const int jj = (j + 1) & 7;
+                kg_st(&o[(jj >> 1) * row + 2 * (ii - 512 + halo) + (jj & 1)], fq[q]);
+            }
         }
     }
 }
@@ -648,6 +675,370 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
     if (STAMPS && wgt) { wgt[1] = __builtin_amdgcn_s_memrealtime(); wgt[3] = (unsigned long long) wg_cells; }
 }
 
+// ---------------------------------------------------------------------------
+// Correlate() for the 16368-lag window (E1B): the same cell walk with FOUR output quarters per point, by a
+// 512-thread workgroup at 8 points per thread (kg_subfft4096_r8, kg_fft.h).  The 256 x 16 form above needs
+// acc[4][16] = 128 registers of accumulators per thread on top of its transform: 438-453 registers, one wave per
+// SIMD, nothing to issue while that wave waits (7 500 cycles per 4096-point item against 3 050 for the C/A
+// kernel's pair of workgroups).  Here a thread owns outputs n = i + 512 m (m < 8) of each quarter: 64 registers of
+// accumulators, two waves on every SIMD.  Thread i reads elements k1 = i + 512 j of a plane in layout B (head of
+// this file): four 16-byte buffer loads per spectrum.
+// Combine twiddle W_N^{n k2} = W_N^{i k2} (registers) x W_{N/512}^{m k2}, m = 4a + b: comb8[k2] = { W^{k2},
+// W^{2 k2}, W^{3 k2}, W^{4 k2} } with W = W_{N/512}.
+// ---------------------------------------------------------------------------
+#define ACQ8_LDS_BYTES (3 * SUB * sizeof(float2) + 8 * sizeof(acq_red) + 16 + 16 * 8 * sizeof(float2))   // + the per-k2 constants
+
+template <int P, bool STAMPS = false>        // STAMPS: diagnostic instantiation only (kg_acq_debug_corr_stamps)
+__global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
+    const float2 *__restrict__ data, const float2 *__restrict__ code,
+    const float2 *__restrict__ tab4096, const float2 *__restrict__ tabN,
+    const float2 *__restrict__ comb8,          // [P][4]
+    const float2 *__restrict__ quart,          // [P][4]
+    const acq_pair_desc *__restrict__ pairs, int *__restrict__ claim, acq_walk walk, int halo,
+    kg_acq_cell *__restrict__ cells, unsigned long long *__restrict__ stamps = nullptr)
+{
+    static_assert(P == 4 || P == 16, "N = 16384 or 65536");
+    constexpr int LOGP = P == 4 ? 2 : 4;
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    float2 *tile0 = smem, *tile1 = smem + SUB, *tile2 = smem + 2 * SUB;
+    acq_red *red = (acq_red *) (smem + 3 * SUB);
+    volatile int *red_claim = (volatile int *) (red + 8);
+    // per-item constants { W^{k2}, W^{2 k2}, W^{3 k2}, W^{4 k2}, W_P^{k2}, W_P^{2 k2}, W_P^{3 k2}, - } (W = W_{N/512}) in LDS,
+    // read by broadcast ds_reads: as scalar loads they shared the lgkmcnt counter with the tile reads, which then
+    // waited for a scalar-cache round trip in every item
+    float2 *cst = (float2 *) ((char *) (red + 8) + 16);
+    const int i = threadIdx.x;
+    if (i < 8 * P) {
+        const int k2 = i >> 3, k = i & 7;
+        kg_st(&cst[i], k < 4 ? kg_ld(&comb8[4 * k2 + k]) : (k < 7 ? kg_ld(&quart[4 * k2 + (k - 3)]) : cf{0.f, 0.f}));
+    }
+    // diagnostics: workgroup 8, lane 0 of waves 0 and 4 (which share a SIMD), 16 stamps per item from slot 16 / 1040
+    unsigned long long *st = (STAMPS && (i & 255) == 0 && blockIdx.x == 8) ? stamps + (i ? 1024 : 0) : nullptr;
+    int st_item = 0;
+
+    kg_tw4096_r8 tw;
+    kg_tw4096_r8_load(tw, tab4096, i);
+    cf wb[3], wa[3];                            // W_N^{i b}, W_N^{4 i a}: the lane half of the combine twiddle
+#pragma unroll
+    for (int k = 1; k < 4; k++) { wb[k - 1] = kg_ld(&tabN[i * k]); wa[k - 1] = kg_ld(&tabN[(4 * i * k) & (P * SUB - 1)]); }
+    (void) wa;
+    auto sel3 = [](const cf (&w)[3], int k) { return k == 1 ? w[0] : (k == 2 ? w[1] : w[2]); };
+
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+    const int gpairs = (walk.npairs - xcd + 7) >> 3;
+    const bool spread = walk.npairs < 8;       // as in acq_correlate_kernel
+    const int ndop = walk.ndop, ncell = spread ? (walk.npairs * ndop - xcd + 7) >> 3 : gpairs * ndop;
+
+    // Operand fetch (layout B, head of this file): four 16-byte buffer loads per spectrum -- legs 2p and 2p + 1 of
+    // thread i sit side by side in row p, the wave's 64 lanes cover a contiguous KiB.  (First version: the 256-thread
+    // layout read with eight 8-byte loads per spectrum at a 16-byte lane stride -- 128 load instructions per item and
+    // CU at ~20 cycles of the one texture addresser each were 2 600 of an item's 4 300 cycles.)
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const int rowb_c = 2 * (512 + 2 * halo) * (int) sizeof(float2);   // code row, bytes
+    const int plane_c = 4 * 2 * (512 + 2 * halo);                     // code plane, float2
+    cf d[8], c[8];
+    struct acq_rsrc { __amdgpu_buffer_rsrc_t drs, crs; int dvo, cvo; };
+    auto fetch_prepare = [&](int data_off, int code_off, int dop, int k2) {
+        const int s = k2 - dop;
+        const int q0 = s >> LOGP;
+        acq_rsrc r;
+        r.drs = __builtin_amdgcn_make_buffer_rsrc(
+            (void *) (data + data_off + k2 * SUB), 0, SUB * (int) sizeof(float2), 0x00020000);
+        r.crs = __builtin_amdgcn_make_buffer_rsrc(
+            (void *) (code + code_off + (s & (P - 1)) * plane_c), 0, plane_c * (int) sizeof(float2), 0x00020000);
+        r.dvo = i * 16; r.cvo = (i + q0 + halo) * 16;
+        return r;
+    };
+    auto fetch_row = [&](const acq_rsrc &r, int p) {       // row p: legs 2p, 2p + 1 of both spectra
+        const u4 dv = __builtin_amdgcn_raw_buffer_load_b128(r.drs, r.dvo, p * 8192, 0);
+        const u4 cv = __builtin_amdgcn_raw_buffer_load_b128(r.crs, r.cvo, p * rowb_c, 0);
+        d[2 * p] = cf{__uint_as_float(dv[0]), __uint_as_float(dv[1])};
+        d[2 * p + 1] = cf{__uint_as_float(dv[2]), __uint_as_float(dv[3])};
+        c[2 * p] = cf{__uint_as_float(cv[0]), __uint_as_float(cv[1])};
+        c[2 * p + 1] = cf{__uint_as_float(cv[2]), __uint_as_float(cv[3])};
+    };
+    // cell index -> descriptor.  The 16-byte pair record comes through the VECTOR memory path (every lane loads the same
+    // address, readfirstlane makes it scalar again): as an s_load it shared lgkmcnt with the tile reads of the cell's
+    // first item, which waited ~1 000 cycles for it (in-kernel stamps); a vector load is waited for where it is used.
+    int vzero = 0;
+    asm volatile("" : "+v"(vzero));                // opaque: keeps the compiler from scalarising the load below
+    auto describe = [&](int idx) {
+        const int cell = spread ? (idx << 3) + xcd : idx;
+        const int pg = cell / ndop, di = cell - pg * ndop;
+        const int4 pv = *(const int4 *) (pairs + (spread ? pg : (pg << 3) + xcd) + vzero);
+        const int data_off = __builtin_amdgcn_readfirstlane(pv.x), code_off = __builtin_amdgcn_readfirstlane(pv.y);
+        const int lim = __builtin_amdgcn_readfirstlane(pv.z), out = __builtin_amdgcn_readfirstlane(pv.w);
+        return acq_cell_desc{data_off, code_off, walk.dop_lo + di, lim, out + di};
+    };
+
+    // The four passes of an item are software-pipelined over two items so that an item costs TWO workgroup
+    // barriers, not three, and every interval between barriers holds two independent chains:
+    //   phase A:  pass 2 of item n (tile 1 -> tile 2)   |  conj-multiply + pass 0 of item n+1 (-> tile 0)     barrier
+    //   phase B:  pass 3 of item n (tile 2 -> registers, accumulate)  |  pass 1 of item n+1 (tile 0 -> tile 1)  barrier
+    // (tile k is rewritten one barrier after its last read was consumed).  Items run on across cells: item n+1 of a
+    // cell's last item is item 0 of the next cell, so there is no drain at a cell boundary and the barrier of the
+    // cell-end reduction is the one that closes the last phase B.  d, c hold the operands of item n+1 at the top of
+    // item n; the loads of item n+2 are issued as soon as the conjugate product has consumed them.
+    const int c0 = (i >> 1) & 7, b1 = (i >> 3) & 1;
+    const int r0 = i ^ ((i >> 4) & 7), r1 = i ^ (((i >> 6) & 1) << 3);
+    const int w1 = (i >> 3) * 64 + (i & 7), w2 = (i >> 6) * 512 + (i & 63);
+    auto fetch_item = [&](const acq_cell_desc &cd, int k2) {
+        const acq_rsrc r = fetch_prepare(cd.data_off, cd.code_off, cd.dop, k2);
+#pragma unroll
+        for (int p = 0; p < 4; p++) fetch_row(r, p);
+    };
+    int cur_idx = slot, nxt_idx = slot + nslots;
+    if (cur_idx >= ncell) return;
+    acq_cell_desc cur = describe(cur_idx);
+    fetch_item(cur, 0);
+    {   // prologue: item 0 of the workgroup's first cell up to tile 1 (passes 0 and 1), operands of item 1 requested
+        cf x[8], y[8];
+#pragma unroll
+        for (int j = 0; j < 8; j += 4) {
+            x[j] = c[j]; x[j + 1] = c[j + 1]; x[j + 2] = c[j + 2]; x[j + 3] = c[j + 3];
+            kg_cmul4v<true>(x[j], x[j + 1], x[j + 2], x[j + 3], d[j], d[j + 1], d[j + 2], d[j + 3]);
+        }
+        kg_pin();
+        fetch_item(cur, 1);
+        kg_pin();
+        kg_radix8<+1>(x, y);
+#pragma unroll
+        for (int m = 0; m < 8; m++) kg_st(&tile0[8 * i + (m ^ c0)], y[m]);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = kg_ld_tile(&tile0[r0 + 512 * j]);
+        kg_twiddle8<+1>(x, tw.p1);
+        kg_radix8<+1>(x, y);
+#pragma unroll
+        for (int m = 0; m < 8; m++) kg_st(&tile1[w1 + 8 * (m ^ b1)], y[m]);
+        __syncthreads();
+    }
+    int prev_out = -1, prev_limit = 1;
+    auto merge_store = [&](int out, int limit) {
+        if (i < 64) {                                  // lanes 0..7 of wave 0 merge the eight waves
+            const acq_red r = red[i & 7];
+            float bp = r.p, sum = r.s;
+            int mi = r.i;
+#define ACQ_RED_STEP(L)                                                               \
+            {                                                                            \
+                const float op = kg_xchg<L>(bp), os = kg_xchg<L>(sum);                   \
+                const int oi = kg_xchg<L>(mi);                                           \
+                const bool take = (op > bp) | ((op == bp) & (oi < mi));                  \
+                bp = take ? op : bp; mi = take ? oi : mi;                                \
+                sum += os;                                                               \
+            }
+            ACQ_RED_STEP(0) ACQ_RED_STEP(1) ACQ_RED_STEP(2)
+#undef ACQ_RED_STEP
+            if (i == 0) {
+                const float ave = sum / (float) limit;     // :493
+                kg_acq_cell cc;
+                cc.snr = bp / ave;                         // :494
+                cc.max_pwr = bp; cc.tot_pwr = sum; cc.idx = mi;
+                cells[out] = cc;
+            }
+        }
+    };
+    for (;;) {
+        const bool more = nxt_idx < ncell;
+        const acq_cell_desc nxt = describe(more ? nxt_idx : cur_idx);
+        int claimed = 0;
+        // (lane 0 of wave 7 claims: wave 0 already carries the result merge and store of every cell)
+        if (i == 448) claimed = 2 * nslots + __hip_atomic_fetch_add(&claim[xcd], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cf acc[4][8];
+#pragma unroll 1
+        for (int k2 = 0; k2 < P; k2++) {
+            cf base;                                           // W_N^{i k2}
+            if constexpr (P == 4) base = sel3(wb, k2);
+            else {
+                const int ka = k2 >> 2, kb = k2 & 3;
+                const cf A = sel3(wa, ka), Bv = sel3(wb, kb);
+                base = ka == 0 ? Bv : (kb == 0 ? A : kg_cmul(A, Bv));
+            }
+            // (the workgroup's very last item has no item n+1: its phases still run pass 0 / pass 1 on re-read operands,
+            // once per launch, because a conditional load site would make the compiler drain vmcnt at the join -- the
+            // prefetch of every item would be waited for on the spot)
+            unsigned long long *sti = (STAMPS && st && st_item < 60) ? st + 16 + 16 * st_item : nullptr;
+            KG_STAMP(STAMPS, sti, 0);
+            // The operands of item n+2 -- (cur, k2 + 2) or (nxt, k2 + 2 - P); ONE set of load sites, never skipped --
+            // are requested one row (a data and a code load, two legs each) at a time BETWEEN the arithmetic blocks of both phases:
+            // a buffer load costs the CU's one texture addresser about twenty cycles, all eight waves reach the same
+            // point of an item together, and sixteen loads issued back to back held every wave in the issue queue for
+            // 1 600 cycles of a 5 700-cycle item (in-kernel stamps, profiles/r03_e1b8_stamps_burst.txt).
+            const acq_rsrc nr = fetch_prepare(k2 + 2 < P ? cur.data_off : nxt.data_off, k2 + 2 < P ? cur.code_off : nxt.code_off,
+                                              k2 + 2 < P ? cur.dop : nxt.dop, (k2 + 2) & (P - 1));
+            auto ld = [&](int j) { kg_pin(); fetch_row(nr, j); kg_pin(); };
+            // ---- phase A: pass 2 of this item | conj-multiply + pass 0 of the next
+            {
+                cf xa[8], ya[8], xb[8], yb[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) xa[j] = kg_ld_tile(&tile1[r1 + 512 * j]);
+                // conj(data) * code, simd_multiply_conjugate_ccc (support/simd.cpp:39-67)
+#pragma unroll
+                for (int j = 0; j < 8; j += 4)
+                    kg_cmulc4_o(xb[j], xb[j + 1], xb[j + 2], xb[j + 3], c[j], c[j + 1], c[j + 2], c[j + 3],
+                                d[j], d[j + 1], d[j + 2], d[j + 3]);
+                KG_STAMP(STAMPS, sti, 1);
+                ld(0);
+                kg_radix8<+1>(xb, yb);
+#pragma unroll
+                for (int m = 0; m < 8; m++) kg_st(&tile0[8 * i + (m ^ c0)], yb[m]);
+                KG_STAMP(STAMPS, sti, 2);
+                kg_twiddle8<+1>(xa, tw.p2);
+                ld(1);
+                kg_radix8<+1>(xa, ya);
+                KG_STAMP(STAMPS, sti, 3);
+#pragma unroll
+                for (int m = 0; m < 8; m++) kg_st(&tile2[w2 + 64 * m], ya[m]);
+                KG_STAMP(STAMPS, sti, 4);
+                if (STAMPS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                KG_STAMP(STAMPS, sti, 5);
+            }
+            __syncthreads();
+            KG_STAMP(STAMPS, sti, 6);
+            // ---- phase B: pass 3 of this item + accumulate | pass 1 of the next
+            cf x[8], y[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) x[j] = kg_ld_tile(&tile2[i + 512 * j]);
+            {
+                cf xb[8], yb[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) xb[j] = kg_ld_tile(&tile0[r0 + 512 * j]);
+                kg_twiddle8<+1>(xb, tw.p1);
+                ld(2);
+                kg_radix8<+1>(xb, yb);
+#pragma unroll
+                for (int m = 0; m < 8; m++) kg_st(&tile1[w1 + 8 * (m ^ b1)], yb[m]);
+            }
+            KG_STAMP(STAMPS, sti, 7);
+            // this item's constants (broadcast LDS reads, in order with the tile reads)
+            cf g[3], G, Q[3];
+            (void) Q;
+#pragma unroll
+            for (int k = 0; k < 3; k++) g[k] = kg_ld_tile(&cst[8 * k2 + k]);
+            G = kg_ld_tile(&cst[8 * k2 + 3]);
+            if constexpr (P != 4) {
+#pragma unroll
+                for (int q = 1; q < 4; q++) Q[q - 1] = kg_ld_tile(&cst[8 * k2 + 3 + q]);
+            }
+            kg_twiddle8<+1>(x, tw.p3);
+            ld(3);
+            kg_radix8<+1>(x, y);                               // y[m]: the sub-transform at n = i + 512 m
+            if (k2 == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int m = 0; m < 8; m++) acc[q][m] = y[m];
+                if (prev_out >= 0) merge_store(prev_out, prev_limit);      // the cell before (wave 0; see the cell end)
+            } else {
+                // z[m] = y[m] * base * W^{4a k2} * W^{b k2}, m = 4a + b; then acc_q[m] += z[m] * W_P^{q k2}
+                const cf B1 = kg_cmul(base, G);
+                cf C1, C2, C3, C5, C6, C7;
+                kg_cmul1x3v(C1, C2, C3, base, g[0], g[1], g[2]);
+                kg_cmul1x3v(C5, C6, C7, B1, g[0], g[1], g[2]);
+                kg_cmul4v<false>(y[0], y[1], y[2], y[3], base, C1, C2, C3);
+                kg_cmul4v<false>(y[4], y[5], y[6], y[7], B1, C5, C6, C7);
+#pragma unroll
+                for (int m = 0; m < 8; m++) acc[0][m] = acc[0][m] + y[m];
+                if constexpr (P == 4) {                        // quarters 1..3: times j^(q k2), wave-uniform
+                    if (k2 == 1) {
+#pragma unroll
+                        for (int m = 0; m < 8; m++) {
+                            acc[1][m] = kg_addj(acc[1][m], y[m]); acc[2][m] = acc[2][m] - y[m]; acc[3][m] = kg_subj(acc[3][m], y[m]);
+                        }
+                    } else if (k2 == 2) {
+#pragma unroll
+                        for (int m = 0; m < 8; m++) {
+                            acc[1][m] = acc[1][m] - y[m]; acc[2][m] = acc[2][m] + y[m]; acc[3][m] = acc[3][m] - y[m];
+                        }
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < 8; m++) {
+                            acc[1][m] = kg_subj(acc[1][m], y[m]); acc[2][m] = acc[2][m] - y[m]; acc[3][m] = kg_addj(acc[3][m], y[m]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 1; q < 4; q++) {
+                        kg_cmac4v1(acc[q][0], acc[q][1], acc[q][2], acc[q][3], y[0], y[1], y[2], y[3], Q[q - 1]);
+                        kg_cmac4v1(acc[q][4], acc[q][5], acc[q][6], acc[q][7], y[4], y[5], y[6], y[7], Q[q - 1]);
+                    }
+                }
+            }
+            KG_STAMP(STAMPS, sti, 8);
+            if (STAMPS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            KG_STAMP(STAMPS, sti, 9);
+            if (k2 < P - 1) __syncthreads();                   // (the last item's phase B is closed by the cell-end barrier)
+            KG_STAMP(STAMPS, sti, 10);
+            if (STAMPS) st_item++;
+        }
+        // search.cpp:486-490: power, first maximum (strict >) over ascending n, running total; n = i + 512 m + 4096 q
+        // Row r = m + 8 q holds n = i + 512 r.  `limit` is wave-uniform: a row lies wholly inside the window
+        // (512 (r + 1) <= limit: a scalar test; all but the last row for 16368) or needs the per-lane test; the row
+        // number, not n, is tracked as the position of the maximum.
+        unsigned long long *stc = (STAMPS && st && st_item <= 60) ? st + 16 * st_item + 11 : nullptr;   // slots 11..15 of the cell's last item
+        KG_STAMP(STAMPS, stc, 0);
+        // Row r = m + 8 q holds n = i + 512 r; `limit` is wave-uniform, so only the rows from limit >> 9 on need the
+        // per-lane window test.  The scan costs every lane 32 points and both waves of a SIMD run it together, so it is
+        // written for instruction count, not as the serial loop (8.4 instructions per point as compare + two selects +
+        // add): the powers (kept: 32 registers), their total in packed pairs, their maximum by v_max3; then the lane's
+        // FIRST row holding that maximum -- what the strict-> scan of search.cpp:486-490 ends with -- from a 32-bit
+        // row mask built with one compare and one add-with-carry per row (mask = 2 mask + (pw[r] == max), r
+        // descending) and a find-first-bit.  All powers zero: row 0, as bi = 0 there.
+        const int limit = cur.limit, full_rows = limit >> 9;
+        float pw[32];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const int r = m + 8 * q;
+                const cf sq = acc[q][m] * acc[q][m];
+                pw[r] = sq.x + sq.y;
+                // (limit > 4096 in this kernel: rows 0..7 are always whole; for the others a REAL scalar branch per row --
+                // the empty asm keeps the compiler from turning 24 wave-uniform tests into per-lane compares and selects)
+                if (r >= 8 && r >= full_rows) {
+                    asm volatile("");
+                    pw[r] = (i + 512 * r < limit) ? pw[r] : 0.f;
+                }
+            }
+        }
+        cf s2 = cf{0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 32; r += 2) s2 = s2 + cf{pw[r], pw[r + 1]};
+        float sum = s2.x + s2.y, bp = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; r += 2) bp = __builtin_fmaxf(bp, __builtin_fmaxf(pw[r], pw[r + 1]));
+        unsigned qm[4] = {0, 0, 0, 0};                             // one 8-bit mask per quarter: four independent chains
+#pragma unroll
+        for (int m = 7; m >= 0; m--)
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                asm("v_cmp_eq_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(qm[q]) : "v"(pw[m + 8 * q]), "v"(bp) : "vcc");
+        const unsigned rowmask = (qm[0] | (qm[1] << 8)) | ((qm[2] << 16) | (qm[3] << 24));
+        int bi = i + 512 * (int) __builtin_ctz(rowmask | 0x80000000u);
+        KG_STAMP(STAMPS, stc, 1);
+        {
+            float wmax = bp, wsum = sum;
+            kg_wave_max_sum(wmax, wsum);
+            const int wn = kg_wave_min(bp == wmax ? bi : 0x7fffffff);
+            if ((i & 63) == 0) { red[i >> 6].p = wmax; red[i >> 6].i = wn; red[i >> 6].s = wsum; }
+        }
+        KG_STAMP(STAMPS, stc, 2);
+        if (i == 448) *red_claim = claimed;
+        __syncthreads();
+        KG_STAMP(STAMPS, stc, 3);
+        const int nn_idx = __builtin_amdgcn_readfirstlane(*red_claim);
+        // The merge of the eight wave results and the store of the cell are DEFERRED: wave 0 does them in phase B of the
+        // next cell's first item, where it otherwise waits at the barrier for hundreds of cycles (as the first thing after
+        // this barrier they made wave 0 800 cycles late for the whole workgroup's next barrier).  red[] is rewritten at
+        // the next cell end only.
+        prev_out = cur.out; prev_limit = limit;
+        if (!more) merge_store(prev_out, prev_limit);
+        KG_STAMP(STAMPS, stc, 4);
+        if (!more) break;
+        cur = nxt; cur_idx = nxt_idx; nxt_idx = nn_idx;
+    }
+}
+
 // search.cpp:455,495: best Doppler bin per (block, SV): the serial scan keeps the
 // first bin (ascending dop) holding the maximum snr, and only if it is > 0.
 // One wave per pair; lane l scans bins l, l+64, ...
@@ -697,8 +1088,12 @@ struct kg_acq {
     bool own_tabN;
     float2 *d_comb;        // [P][8]  combine constants (acq_correlate_kernel)
     float2 *d_quart;       // [P][4]
+    float2 *d_comb8;       // [P][4]  combine constants of the 512-thread four-quarter kernel
+    int grid8;             // its persistent grid; 0: use acq_correlate_kernel<P, 4> (KIWIGPU_ACQ_E1B8=0)
     float2 *d_code;        // [max_sats][P planes with halo]
-    float2 *d_data;        // [max_blocks][P][4096]
+    float2 *d_data;        // [max_blocks][P][4096]  layout A
+    float2 *d_data_b;      // [max_blocks][P][4096]  layout B (the 512-thread kernel's); null when that kernel is off
+    std::vector<char> code_layout;   // per SV: 0 = A, 1 = B
     float2 *d_td;          // [max_blocks][N]  decimated time-domain samples per block
     float2 *d_td_code;     // [N]              same, for the code-table build
     float2 *d_fsub;        // [max_blocks][P][4096] sub-transforms awaiting the radix-P combine
@@ -739,32 +1134,39 @@ struct kg_acq {
     int grid1, grid4;
 };
 
-// Host mirror of the plane layout (see the head of this file).
-static inline size_t plane_pos(int k1, int halo_col, int H)
+// Host mirror of the plane layouts (see the head of this file): A = 256 threads x 16 legs, B = 512 x 8.
+static inline size_t plane_pos(int k1, int halo_col, int H, int layout)
 {
-    const int t = k1 & 255, j = k1 >> 8, row = 2 * (256 + 2 * H);
+    if (layout == 0) {
+        const int t = k1 & 255, j = k1 >> 8, row = 2 * (256 + 2 * H);
+        return (size_t) (j >> 1) * row + 2 * (t + halo_col + H) + (j & 1);
+    }
+    const int t = k1 & 511, j = k1 >> 9, row = 2 * (512 + 2 * H);
     return (size_t) (j >> 1) * row + 2 * (t + halo_col + H) + (j & 1);
 }
+// float2 per spectrum: layout A's size (the larger: 32 H against 16 H halo elements per plane) is the stride of both
 static inline size_t spec_len(int P, int H) { return (size_t) P * 8 * 2 * (256 + 2 * H); }
+static inline size_t plane_len(int H, int layout) { return layout == 0 ? (size_t) 8 * 2 * (256 + 2 * H) : (size_t) 4 * 2 * (512 + 2 * H); }
 
-static void to_planes(const float *nat, std::vector<float2> &pl, int P, int H)
+static void to_planes(const float *nat, std::vector<float2> &pl, int P, int H, int layout)
 {
-    const size_t plane = spec_len(P, H) / P;
+    const size_t plane = plane_len(H, layout);
+    const int T = layout == 0 ? 256 : 512, J = SUB / T;
     pl.assign(spec_len(P, H), make_float2(0.f, 0.f));
     for (int k = 0; k < P * SUB; k++) {
         const float2 v = make_float2(nat[2 * k], nat[2 * k + 1]);
-        const int k1 = k / P, t = k1 & 255, j = k1 >> 8;
+        const int k1 = k / P, t = k1 & (T - 1), j = k1 / T;
         float2 *p = pl.data() + (size_t) (k % P) * plane;
-        p[plane_pos(k1, 0, H)] = v;
-        if (t < H) p[plane_pos(t + 256 * ((j - 1) & 15), 256, H)] = v;
-        if (t >= 256 - H) p[plane_pos(t + 256 * ((j + 1) & 15), -256, H)] = v;
+        p[plane_pos(k1, 0, H, layout)] = v;
+        if (t < H) p[plane_pos(t + T * ((j - 1) & (J - 1)), T, H, layout)] = v;
+        if (t >= T - H) p[plane_pos(t + T * ((j + 1) & (J - 1)), -T, H, layout)] = v;
     }
 }
-static void from_planes(const std::vector<float2> &pl, float *nat, int P, int H)
+static void from_planes(const std::vector<float2> &pl, float *nat, int P, int H, int layout)
 {
-    const size_t plane = spec_len(P, H) / P;
+    const size_t plane = plane_len(H, layout);
     for (int k = 0; k < P * SUB; k++) {
-        const float2 v = pl[(size_t) (k % P) * plane + plane_pos(k / P, 0, H)];
+        const float2 v = pl[(size_t) (k % P) * plane + plane_pos(k / P, 0, H, layout)];
         nat[2 * k] = v.x; nat[2 * k + 1] = v.y;
     }
 }
@@ -785,7 +1187,7 @@ static float2 unit_root(long k, long n)
 template <int SRC>
 static int launch_frontend(kg_acq *a, hipStream_t st, const uint8_t *d_src, size_t stride, int nbatch,
                            int nvalid, int nchips, int boc, float2 *d_td, float2 *d_scratch,
-                           float2 *d_planes, size_t planes_stride, int halo)
+                           float2 *d_planes, float2 *d_planes_b, size_t planes_stride, int halo)
 {
     kg_ctx *c = a->ctx;
     hipLaunchKernelGGL(acq_frontend_kernel<SRC>, dim3(a->fft_len / FE_TILE, nbatch), dim3(256), 0,
@@ -797,11 +1199,11 @@ static int launch_frontend(kg_acq *a, hipStream_t st, const uint8_t *d_src, size
     KG_HIP(hipGetLastError());
     if (a->P == 4)
         hipLaunchKernelGGL(acq_fft_combine_kernel<4>, dim3(SUB / 256, nbatch), dim3(256), 0, st,
-                           (const float2 *) d_scratch, d_planes, planes_stride,
+                           (const float2 *) d_scratch, d_planes, d_planes_b, planes_stride,
                            (const float2 *) a->d_tabN, halo);
     else
         hipLaunchKernelGGL(acq_fft_combine_kernel<16>, dim3(SUB / 256, nbatch), dim3(256), 0, st,
-                           (const float2 *) d_scratch, d_planes, planes_stride,
+                           (const float2 *) d_scratch, d_planes, d_planes_b, planes_stride,
                            (const float2 *) a->d_tabN, halo);
     KG_HIP(hipGetLastError());
     return KG_OK;
@@ -816,7 +1218,7 @@ static int acq_init(kg_acq *a)
         a->halo = (m + P - 1) / P + 2;
         a->code_len = spec_len(P, a->halo);
     }
-    a->limits.assign(max_sats, 0); a->code_set.assign(max_sats, 0);
+    a->limits.assign(max_sats, 0); a->code_set.assign(max_sats, 0); a->code_layout.assign(max_sats, 0);
     a->last_first = a->last_nblocks = a->last_nsats = a->np1 = a->np4 = a->table_nblocks = 0;
     a->d_pairs1 = a->d_pairs4 = nullptr; a->pairs_seq = 0;
     a->in_stride = (size_t) a->nsamples * 4;
@@ -841,6 +1243,11 @@ static int acq_init(kg_acq *a)
         KG_HIP(hipMalloc((void **) &a->d_quart, sizeof(float2) * quart.size()));
         KG_HIP(hipMemcpy(a->d_comb, comb.data(), sizeof(float2) * comb.size(), hipMemcpyHostToDevice));
         KG_HIP(hipMemcpy(a->d_quart, quart.data(), sizeof(float2) * quart.size(), hipMemcpyHostToDevice));
+        std::vector<float2> comb8(P * 4);
+        for (int k2 = 0; k2 < P; k2++)
+            for (int k = 0; k < 4; k++) comb8[4 * k2 + k] = unit_root((long) (k + 1) * k2, N / 512);
+        KG_HIP(hipMalloc((void **) &a->d_comb8, sizeof(float2) * comb8.size()));
+        KG_HIP(hipMemcpy(a->d_comb8, comb8.data(), sizeof(float2) * comb8.size(), hipMemcpyHostToDevice));
     }
     KG_HIP(hipMalloc((void **) &a->d_code, sizeof(float2) * a->code_len * max_sats));
     KG_HIP(hipMalloc((void **) &a->d_data, spec * max_blocks));
@@ -884,6 +1291,8 @@ static int acq_init(kg_acq *a)
         a->ev_done.push_back(e2);
     }
     KG_HIP(hipMemset(a->d_data, 0, spec * max_blocks));
+    KG_HIP(hipMalloc((void **) &a->d_data_b, spec * max_blocks));      // (freed again below if the 512-thread kernel is off)
+    KG_HIP(hipMemset(a->d_data_b, 0, spec * max_blocks));
     KG_HIP(hipFuncSetAttribute((const void *) acq_fft_sub_kernel<false>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SUB * sizeof(float2)));
     KG_HIP(hipFuncSetAttribute((const void *) acq_fft_sub_kernel<true>,
@@ -909,6 +1318,23 @@ static int acq_init(kg_acq *a)
     }
     a->grid1 = (ctx->num_cus * occ1) & ~7;
     a->grid4 = (ctx->num_cus * occ4) & ~7;
+    {
+        // the 16368-lag window runs on the 512-thread form (one workgroup = eight waves per CU, two per SIMD);
+        // KIWIGPU_ACQ_E1B8=0 keeps the 256-thread four-accumulator kernel (A/B measurements)
+        const char *e = getenv("KIWIGPU_ACQ_E1B8");
+        a->grid8 = 0;
+        if (!(e && e[0] == '0')) {
+            if (P == 4)
+                KG_HIP(hipFuncSetAttribute((const void *) acq_correlate8_kernel<4>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, ACQ8_LDS_BYTES));
+            else
+                KG_HIP(hipFuncSetAttribute((const void *) acq_correlate8_kernel<16>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, ACQ8_LDS_BYTES));
+            a->grid8 = ctx->num_cus & ~7;
+            if (a->grid8 < 8) a->grid8 = 8;
+        }
+        if (a->grid8 == 0) { (void) hipFree(a->d_data_b); a->d_data_b = nullptr; }
+    }
     if (a->grid1 < 8) a->grid1 = 8;
     if (a->grid4 < 8) a->grid4 = 8;
     return KG_OK;
@@ -964,8 +1390,8 @@ void kg_acq_destroy(kg_acq *a)
     for (size_t b = 0; b < a->ev_done.size(); b++) (void) hipEventDestroy(a->ev_done[b]);
     if (a->own_fstream) (void) hipStreamDestroy(a->fstream);
     if (a->own_tabN) (void) hipFree(a->d_tabN);
-    (void) hipFree(a->d_comb); (void) hipFree(a->d_quart);          // hipFree(nullptr) is a no-op
-    (void) hipFree(a->d_code); (void) hipFree(a->d_data); (void) hipFree(a->d_td);
+    (void) hipFree(a->d_comb); (void) hipFree(a->d_quart); (void) hipFree(a->d_comb8);   // hipFree(nullptr) is a no-op
+    (void) hipFree(a->d_code); (void) hipFree(a->d_data); (void) hipFree(a->d_data_b); (void) hipFree(a->d_td);
     (void) hipFree(a->d_td_code);
     (void) hipFree(a->d_fsub); (void) hipFree(a->d_fsub_code);
     (void) hipFree(a->d_in); (void) hipFree(a->d_chips);
@@ -988,6 +1414,7 @@ static int set_limit(kg_acq *a, int sat, int limit)
     KG_REQUIRE(limit >= 1 && limit <= 4 * SUB, KG_ERR_INVALID, "limit %d out of range (1..%d)", limit,
                4 * SUB);
     a->limits[sat] = limit;
+    a->code_layout[sat] = (limit > SUB && a->grid8 > 0) ? 1 : 0;     // which kernel will read this SV's code spectrum
     a->code_set[sat] = 1;
     a->last_sats.clear();        // force the pair tables to be rebuilt
     return KG_OK;
@@ -1004,9 +1431,10 @@ int kg_acq_set_code(kg_acq *a, int sat, const uint8_t *chips, int nchips, int bo
     if ((rc = set_limit(a, sat, limit)) != KG_OK) return rc;
     KG_HIP(hipMemcpyAsync(a->d_chips, chips, nchips, hipMemcpyHostToDevice, a->ctx->stream));
     // the replica covers all DECIM * N samples, as the reference's covers NSAMPLES (:250)
+    float2 *d_sv = a->d_code + (size_t) sat * a->code_len;
     rc = launch_frontend<SRC_CHIPS>(a, a->ctx->stream, a->d_chips, 0, 1, DECIM * a->fft_len, nchips, boc ? 1 : 0,
-                                    a->d_td_code, a->d_fsub_code, a->d_code + (size_t) sat * a->code_len,
-                                    a->code_len, a->halo);
+                                    a->d_td_code, a->d_fsub_code, a->code_layout[sat] ? nullptr : d_sv,
+                                    a->code_layout[sat] ? d_sv : nullptr, a->code_len, a->halo);
     if (rc) return rc;
     KG_HIP(hipStreamSynchronize(a->ctx->stream));       // chips buffer is reused per call
     return KG_OK;
@@ -1019,20 +1447,20 @@ int kg_acq_set_code_fft(kg_acq *a, int sat, const float *code_fft, int limit)
     if (rc) return rc;
     if ((rc = set_limit(a, sat, limit)) != KG_OK) return rc;
     std::vector<float2> pl;
-    to_planes(code_fft, pl, a->P, a->halo);
+    to_planes(code_fft, pl, a->P, a->halo, a->code_layout[sat]);
     KG_HIP(hipMemcpyAsync(a->d_code + (size_t) sat * a->code_len, pl.data(), sizeof(float2) * a->code_len,
                           hipMemcpyHostToDevice, a->ctx->stream));
     KG_HIP(hipStreamSynchronize(a->ctx->stream));
     return KG_OK;
 }
 
-static int get_planes(kg_acq *a, const float2 *d, float *nat, int H)
+static int get_planes(kg_acq *a, const float2 *d, float *nat, int H, int layout)
 {
     std::vector<float2> pl(spec_len(a->P, H));
     KG_HIP(hipStreamSynchronize(a->fstream));
     KG_HIP(hipMemcpyAsync(pl.data(), d, sizeof(float2) * pl.size(), hipMemcpyDeviceToHost, a->ctx->stream));
     KG_HIP(hipStreamSynchronize(a->ctx->stream));
-    from_planes(pl, nat, a->P, H);
+    from_planes(pl, nat, a->P, H, layout);
     return KG_OK;
 }
 
@@ -1043,7 +1471,7 @@ int kg_acq_get_code_fft(kg_acq *a, int sat, float *code_fft)
     if (rc) return rc;
     KG_REQUIRE(sat >= 0 && sat < a->max_sats, KG_ERR_INVALID, "kg_acq_get_code_fft: sat %d", sat);
     KG_REQUIRE(a->code_set[sat], KG_ERR_STATE, "kg_acq_get_code_fft: no code set for sat %d", sat);
-    return get_planes(a, a->d_code + (size_t) sat * a->code_len, code_fft, a->halo);
+    return get_planes(a, a->d_code + (size_t) sat * a->code_len, code_fft, a->halo, a->code_layout[sat]);
 }
 
 static int check_block(kg_acq *a, int block, const void *p, const char *who)
@@ -1127,7 +1555,8 @@ static int sample_dev(kg_acq *a, int first, int nblocks, const void *d_src, size
     if ((rc = front_begin(a, first, nblocks)) != KG_OK) return rc;
     const size_t off = (size_t) first * a->fft_len;
     rc = launch_frontend<SRC>(a, a->fstream, (const uint8_t *) d_src, stride, nblocks, a->nsamples, 0, 0,
-                              a->d_td + off, a->d_fsub + off, a->d_data + off, a->fft_len, 0);
+                              a->d_td + off, a->d_fsub + off, a->d_data + off, a->d_data_b ? a->d_data_b + off : nullptr,
+                              a->fft_len, 0);
     if (rc) return rc;
     return front_end(a, first, nblocks);
 }
@@ -1213,11 +1642,16 @@ int kg_acq_set_data_fft(kg_acq *a, int block, const float *data_fft)
 {
     int rc = check_block(a, block, data_fft, "kg_acq_set_data_fft");
     if (rc) return rc;
-    std::vector<float2> pl;
-    to_planes(data_fft, pl, a->P, 0);
+    std::vector<float2> pl, plb;
+    to_planes(data_fft, pl, a->P, 0, 0);
     if ((rc = front_begin(a, block)) != KG_OK) return rc;
     KG_HIP(hipMemcpyAsync(a->d_data + (size_t) block * a->fft_len, pl.data(), sizeof(float2) * a->fft_len,
                           hipMemcpyHostToDevice, a->fstream));
+    if (a->d_data_b) {
+        to_planes(data_fft, plb, a->P, 0, 1);
+        KG_HIP(hipMemcpyAsync(a->d_data_b + (size_t) block * a->fft_len, plb.data(), sizeof(float2) * a->fft_len,
+                              hipMemcpyHostToDevice, a->fstream));
+    }
     if ((rc = front_end(a, block)) != KG_OK) return rc;
     KG_HIP(hipStreamSynchronize(a->fstream));
     return KG_OK;
@@ -1227,7 +1661,7 @@ int kg_acq_get_data_fft(kg_acq *a, int block, float *data_fft)
 {
     int rc = check_block(a, block, data_fft, "kg_acq_get_data_fft");
     if (rc) return rc;
-    return get_planes(a, a->d_data + (size_t) block * a->fft_len, data_fft, 0);
+    return get_planes(a, a->d_data + (size_t) block * a->fft_len, data_fft, 0, 0);
 }
 
 int kg_acq_get_data_td(kg_acq *a, int block, float *td)
@@ -1317,7 +1751,19 @@ int kg_acq_correlate_blocks_async(kg_acq *a, int first, int nblocks, const int *
         KG_HIP(hipGetLastError());
     }
     if (a->np4 > 0) {
-        if (a->P == 4) launch_correlate<4, 4, false>(a, st, first, a->d_pairs4, a->np4, nullptr);
+        if (a->grid8 > 0) {
+            const acq_walk w = {a->np4, a->ndop, a->dop_lo};
+            if (a->P == 4)
+                hipLaunchKernelGGL(acq_correlate8_kernel<4>, dim3(a->grid8), dim3(512), ACQ8_LDS_BYTES, st,
+                                   (const float2 *) (a->d_data_b + (size_t) first * a->fft_len), (const float2 *) a->d_code,
+                                   (const float2 *) a->ctx->d_tab4096, (const float2 *) a->d_tabN, (const float2 *) a->d_comb8,
+                                   (const float2 *) a->d_quart, a->d_pairs4, a->d_claim + 8, w, a->halo, a->d_cells);
+            else
+                hipLaunchKernelGGL(acq_correlate8_kernel<16>, dim3(a->grid8), dim3(512), ACQ8_LDS_BYTES, st,
+                                   (const float2 *) (a->d_data_b + (size_t) first * a->fft_len), (const float2 *) a->d_code,
+                                   (const float2 *) a->ctx->d_tab4096, (const float2 *) a->d_tabN, (const float2 *) a->d_comb8,
+                                   (const float2 *) a->d_quart, a->d_pairs4, a->d_claim + 8, w, a->halo, a->d_cells);
+        } else if (a->P == 4) launch_correlate<4, 4, false>(a, st, first, a->d_pairs4, a->np4, nullptr);
         else launch_correlate<16, 4, false>(a, st, first, a->d_pairs4, a->np4, nullptr);
         KG_HIP(hipGetLastError());
     }
@@ -1369,8 +1815,37 @@ int kg_acq_debug_corr_stamps(kg_acq *a, int nblocks, const int *sats, int nsats,
     KG_REQUIRE(a && stamps && n >= 512 + 4 * 1024, KG_ERR_INVALID, "kg_acq_debug_corr_stamps: need 4608 slots");
     int rc = kg_acq_correlate_async(a, nblocks, sats, nsats);      // builds the lists, warms up
     if (rc) return rc;
-    KG_REQUIRE(a->np1 > 0, KG_ERR_STATE, "kg_acq_debug_corr_stamps: no C/A SV in the list");
     hipStream_t st = a->ctx->stream;
+    if (a->np1 == 0 && a->np4 > 0 && a->grid8 > 0) {           // an all-E1B list: the 512-thread kernel's stamps
+        unsigned long long *d = nullptr;
+        const size_t bytes = sizeof(unsigned long long) * (512 + 4 * 1024);
+        KG_HIP(hipMalloc((void **) &d, bytes));
+        KG_HIP(hipMemset(d, 0, bytes));
+        KG_HIP(hipMemsetAsync(a->d_claim, 0, sizeof(int) * 16, st));
+        const acq_walk w = {a->np4, a->ndop, a->dop_lo};
+        if (a->P == 4) {
+            KG_HIP(hipFuncSetAttribute((const void *) acq_correlate8_kernel<4, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, ACQ8_LDS_BYTES));
+            hipLaunchKernelGGL((acq_correlate8_kernel<4, true>), dim3(a->grid8), dim3(512), ACQ8_LDS_BYTES, st,
+                               (const float2 *) a->d_data_b, (const float2 *) a->d_code, (const float2 *) a->ctx->d_tab4096,
+                               (const float2 *) a->d_tabN, (const float2 *) a->d_comb8, (const float2 *) a->d_quart,
+                               a->d_pairs4, a->d_claim + 8, w, a->halo, a->d_cells, d);
+        } else {
+            KG_HIP(hipFuncSetAttribute((const void *) acq_correlate8_kernel<16, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, ACQ8_LDS_BYTES));
+            hipLaunchKernelGGL((acq_correlate8_kernel<16, true>), dim3(a->grid8), dim3(512), ACQ8_LDS_BYTES, st,
+                               (const float2 *) a->d_data_b, (const float2 *) a->d_code, (const float2 *) a->ctx->d_tab4096,
+                               (const float2 *) a->d_tabN, (const float2 *) a->d_comb8, (const float2 *) a->d_quart,
+                               a->d_pairs4, a->d_claim + 8, w, a->halo, a->d_cells, d);
+        }
+        KG_HIP(hipGetLastError());
+        KG_HIP(hipMemsetAsync(a->d_claim, 0, sizeof(int) * 16, st));
+        KG_HIP(hipStreamSynchronize(st));
+        KG_HIP(hipMemcpy(stamps, d, bytes, hipMemcpyDeviceToHost));
+        KG_HIP(hipFree(d));
+        return KG_OK;
+    }
+    KG_REQUIRE(a->np1 > 0, KG_ERR_STATE, "kg_acq_debug_corr_stamps: no C/A SV in the list");
     unsigned long long *d = nullptr;
     const size_t bytes = sizeof(unsigned long long) * (512 + 4 * 1024);
     KG_REQUIRE(a->grid1 <= 1024, KG_ERR_STATE, "kg_acq_debug_corr_stamps: grid %d", a->grid1);

@@ -124,6 +124,15 @@ KG_DEV void kg_cmul1x3s(cf &o0, cf &o1, cf &o2, cf a, cf w0, cf w1, cf w2)
         : "=&v"(o0), "=&v"(o1), "=&v"(o2) : "v"(a), "s"(w0), "s"(w1), "s"(w2));
 }
 
+// the same with the w_i in vector registers
+KG_DEV void kg_cmul1x3v(cf &o0, cf &o1, cf &o2, cf a, cf w0, cf w1, cf w2)
+{
+    asm(KG_MUL_("%0", "%3", "%4") KG_MUL_("%1", "%3", "%5") KG_MUL_("%2", "%3", "%6")
+        KG_FMA3_("%0", "%3", "%4", "neg_lo:[0,1,0]") KG_FMA3_("%1", "%3", "%5", "neg_lo:[0,1,0]")
+        KG_FMA3_("%2", "%3", "%6", "neg_lo:[0,1,0]")
+        : "=&v"(o0), "=&v"(o1), "=&v"(o2) : "v"(a), "v"(w0), "v"(w1), "v"(w2));
+}
+
 template <bool CONJ> KG_DEV void kg_cmul4v(cf &a0, cf &a1, cf &a2, cf &a3, cf w0, cf w1, cf w2, cf w3)
 {
     cf r0, r1, r2, r3;
@@ -139,6 +148,16 @@ template <bool CONJ> KG_DEV void kg_cmul4v(cf &a0, cf &a1, cf &a2, cf &a3, cf w0
             KG_FMA_("%2", "%10", "%6", "neg_hi:[0,1,0]") KG_FMA_("%3", "%11", "%7", "neg_hi:[0,1,0]")
             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
             : "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+}
+// o_i = a_i * conj(w_i), NOT in place (a_i and w_i stay live: no copy of an operand that is overwritten later anyway)
+KG_DEV void kg_cmulc4_o(cf &o0, cf &o1, cf &o2, cf &o3, cf a0, cf a1, cf a2, cf a3, cf w0, cf w1, cf w2, cf w3)
+{
+#define KG_FMAO_(o, a, w) "v_pk_fma_f32 " o ", " a ", " w ", " o " op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
+    asm(KG_MUL_("%0", "%4", "%8") KG_MUL_("%1", "%5", "%9") KG_MUL_("%2", "%6", "%10") KG_MUL_("%3", "%7", "%11")
+        KG_FMAO_("%0", "%4", "%8") KG_FMAO_("%1", "%5", "%9") KG_FMAO_("%2", "%6", "%10") KG_FMAO_("%3", "%7", "%11")
+        : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+#undef KG_FMAO_
 }
 // the same with wave-uniform w_i (SGPR pairs)
 template <bool CONJ> KG_DEV void kg_cmul4s(cf &a0, cf &a1, cf &a2, cf &a3, cf w0, cf w1, cf w2, cf w3)
@@ -182,6 +201,14 @@ KG_DEV void kg_cmac4v(cf &c0, cf &c1, cf &c2, cf &c3, cf y0, cf y1, cf y2, cf y3
         KG_MAC2_("%0", "%4", "%8") KG_MAC2_("%1", "%5", "%9") KG_MAC2_("%2", "%6", "%10") KG_MAC2_("%3", "%7", "%11")
         : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
         : "v"(y0), "v"(y1), "v"(y2), "v"(y3), "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+}
+// the same with one factor w (a VGPR pair) for all four points
+KG_DEV void kg_cmac4v1(cf &c0, cf &c1, cf &c2, cf &c3, cf y0, cf y1, cf y2, cf y3, cf w)
+{
+    asm(KG_MAC1_("%0", "%4", "%8") KG_MAC1_("%1", "%5", "%8") KG_MAC1_("%2", "%6", "%8") KG_MAC1_("%3", "%7", "%8")
+        KG_MAC2_("%0", "%4", "%8") KG_MAC2_("%1", "%5", "%8") KG_MAC2_("%2", "%6", "%8") KG_MAC2_("%3", "%7", "%8")
+        : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+        : "v"(y0), "v"(y1), "v"(y2), "v"(y3), "v"(w));
 }
 // the same with one wave-uniform factor w (an SGPR pair) for all four points
 KG_DEV void kg_cmac4s(cf &c0, cf &c1, cf &c2, cf &c3, cf y0, cf y1, cf y2, cf y3, cf w)
@@ -467,6 +494,99 @@ KG_DEV void kg_subfft4096_once(cf (&x)[16], cf (&y)[16], float2 *tile,
             __syncthreads();
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// The same 4096-point transform by a 512-thread group: 8 points per thread, four radix-8 passes (Stockham
+// autosort), three exchanges.  Half the registers per thread of the 256 x 16 form -- for the kernel that must keep
+// four accumulators per output point (the 16368-lag window of E1B, kg_acq.hip) -- at the price of a third
+// exchange.  Pass p (Ns = 8^p): thread i reads in[i + 512 j], multiplies by W_{8 Ns}^{j (i mod Ns)}, and writes
+// out[(i div Ns) 8 Ns + (i mod Ns) + m Ns].  Each exchange has its own tile and its own swizzle, chosen so that every
+// ds_write_b64 (16-lane groups, element index mod 16 distinct) and ds_read_b64 (32-lane groups, mod 32) is
+// conflict-free and every read is base + immediate offset (tools/proto_fft8.py checks both exhaustively):
+//   exchange 0: P(e) = e ^ ((e >> 4) & 7)      written at 8 i + (m ^ ((i >> 1) & 7)),  read at 512 j + (i ^ ((i >> 4) & 7))
+//   exchange 1: P(e) = e ^ (((e >> 6) & 1) << 3)  written at (i >> 3) 64 + (i & 7) + 8 (m ^ ((i >> 3) & 1)),  read at 512 j + (i ^ (((i >> 6) & 1) << 3))
+//   exchange 2: identity                        written at (i >> 6) 512 + (i & 63) + 64 m,  read at 512 j + i
+// Three tiles (96 KiB): exchange k always uses tile k, rewritten two barriers after its last read.
+// ---------------------------------------------------------------------------
+template <bool CONJ> KG_DEV void kg_cmul2s(cf &a0, cf &a1, cf w0, cf w1)
+{
+    cf r0, r1;
+    if constexpr (!CONJ)
+        asm(KG_MUL_("%2", "%0", "%4") KG_MUL_("%3", "%1", "%5")
+            KG_FMA_("%0", "%4", "%2", "neg_lo:[0,1,0]") KG_FMA_("%1", "%5", "%3", "neg_lo:[0,1,0]")
+            : "+v"(a0), "+v"(a1), "=&v"(r0), "=&v"(r1) : "s"(w0), "s"(w1));
+    else
+        asm(KG_MUL_("%2", "%0", "%4") KG_MUL_("%3", "%1", "%5")
+            KG_FMA_("%0", "%4", "%2", "neg_hi:[0,1,0]") KG_FMA_("%1", "%5", "%3", "neg_hi:[0,1,0]")
+            : "+v"(a0), "+v"(a1), "=&v"(r0), "=&v"(r1) : "s"(w0), "s"(w1));
+}
+
+// In: x[j].  Out: y[m] = sum_j x[j] exp(SIGN*2*pi*i*j*m/8).  28 packed instructions.
+// j = 2a + b: a radix-4 over a for b = 0, 1 (u_b[c] lands in x[2c + b]), u_1[c] *= W8^c (c = 2: SIGN*j, folded into
+// the last adds), then y[c] = u_0[c] + u_1[c], y[c + 4] = u_0[c] - u_1[c].
+template <int SIGN> KG_DEV void kg_radix8(cf (&x)[8], cf (&y)[8])
+{
+    kg_radix4<SIGN>(x[0], x[2], x[4], x[6]);
+    kg_radix4<SIGN>(x[1], x[3], x[5], x[7]);
+    kg_cmul2s<(SIGN < 0)>(x[3], x[7], cf{KG_W16[2][0], KG_W16[2][1]}, cf{KG_W16[6][0], KG_W16[6][1]});
+    y[0] = x[0] + x[1]; y[4] = x[0] - x[1];
+    y[1] = x[2] + x[3]; y[5] = x[2] - x[3];
+    kg_addsub_sj<SIGN>(y[2], y[6], x[4], x[5]);
+    y[3] = x[6] + x[7]; y[7] = x[6] - x[7];
+}
+
+struct kg_tw7 { cf w[7]; };
+struct kg_tw4096_r8 { kg_tw7 p1, p2, p3; };     // W_64^(j (i & 7)), W_512^(j (i & 63)), W_4096^(j i), j = 1..7
+
+KG_DEV void kg_tw4096_r8_load(kg_tw4096_r8 &tw, const float2 *__restrict__ tab4096, int i)
+{
+#pragma unroll
+    for (int j = 1; j < 8; j++) {
+        tw.p1.w[j - 1] = kg_ld(&tab4096[(j * (i & 7)) << 6]);
+        tw.p2.w[j - 1] = kg_ld(&tab4096[(j * (i & 63)) << 3]);
+        tw.p3.w[j - 1] = kg_ld(&tab4096[j * i]);
+    }
+}
+
+template <int SIGN> KG_DEV void kg_twiddle8(cf (&x)[8], const kg_tw7 &w)
+{
+    kg_cmul4v<(SIGN < 0)>(x[1], x[2], x[3], x[4], w.w[0], w.w[1], w.w[2], w.w[3]);
+    kg_cmul3v<(SIGN < 0)>(x[5], x[6], x[7], w.w[4], w.w[5], w.w[6]);
+}
+
+// Passes 0..2 with their exchanges: in x (thread i holds X[i + 512 j]); on return x holds the inputs of pass 3
+// (tile 2 read back).  Three __syncthreads().  The caller finishes with kg_twiddle8(x, tw.p3); kg_radix8(x, y):
+// y[m] is the output at n = i + 512 m.
+template <int SIGN>
+KG_DEV void kg_subfft4096_r8_a(cf (&x)[8], cf (&y)[8], float2 *tile0, float2 *tile1, float2 *tile2,
+                               const kg_tw4096_r8 &tw, int i)
+{
+    const int c0 = (i >> 1) & 7, b1 = (i >> 3) & 1;
+    kg_radix8<SIGN>(x, y);
+#pragma unroll
+    for (int m = 0; m < 8; m++) kg_st(&tile0[8 * i + (m ^ c0)], y[m]);
+    __syncthreads();
+    const int r0 = i ^ ((i >> 4) & 7);
+#pragma unroll
+    for (int j = 0; j < 8; j++) x[j] = kg_ld_tile(&tile0[r0 + 512 * j]);
+    kg_twiddle8<SIGN>(x, tw.p1);
+    kg_radix8<SIGN>(x, y);
+    const int w1 = (i >> 3) * 64 + (i & 7);
+#pragma unroll
+    for (int m = 0; m < 8; m++) kg_st(&tile1[w1 + 8 * (m ^ b1)], y[m]);
+    __syncthreads();
+    const int r1 = i ^ (((i >> 6) & 1) << 3);
+#pragma unroll
+    for (int j = 0; j < 8; j++) x[j] = kg_ld_tile(&tile1[r1 + 512 * j]);
+    kg_twiddle8<SIGN>(x, tw.p2);
+    kg_radix8<SIGN>(x, y);
+    const int w2 = (i >> 6) * 512 + (i & 63);
+#pragma unroll
+    for (int m = 0; m < 8; m++) kg_st(&tile2[w2 + 64 * m], y[m]);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; j++) x[j] = kg_ld_tile(&tile2[i + 512 * j]);
 }
 
 // ---------------------------------------------------------------------------

@@ -45,7 +45,7 @@ struct wf_chan_dev {
     int pad[3];
     unsigned short first[WF_WIDTH];     // run of bins of each pixel (DROP: the sampled bin)
     unsigned short count[WF_WIDTH];
-    float scale[WF_WIDTH], scale_div2[WF_WIDTH];
+    float scale[WF_WIDTH];              // what the dB stage multiplies by (WF_CMA: already divided by the run length)
 };
 
 #define WF_LDS_BYTES (2 * SUB * sizeof(float2) + 240 * sizeof(float2) + 16)       // + pass-1 twiddles + the claimed frame index
@@ -102,7 +102,8 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
         for (int j = 0; j < 16; j++) {
             const int r = g ? raw[j].y : raw[j].x;
             const float w = g ? wv[j].y : wv[j].x;
-            x[j] = cf{(float) (short) (r & 0xffff) * w, (float) (short) (r >> 16) * w};
+            // two SDWA conversions (sign-extended halves), ONE packed multiply with the window value broadcast
+            x[j] = cf{(float) (short) (r & 0xffff), (float) (short) (r >> 16)} * cf{w, w};
         }
     };
 
@@ -154,9 +155,8 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
         const ushort4 pf = ((const ushort4 *) ch->first)[t];
         const ushort4 pc = ((const ushort4 *) ch->count)[t];
         const float4 ps = ((const float4 *) ch->scale)[t];
-        const float4 ps2 = ((const float4 *) ch->scale_div2)[t];
         const int pfirst[4] = {pf.x, pf.y, pf.z, pf.w}, pcount[4] = {pc.x, pc.y, pc.z, pc.w};
-        const float pscale[4] = {ps.x, ps.y, ps.z, ps.w}, pscale2[4] = {ps2.x, ps2.y, ps2.z, ps2.w};
+        const float pscale[4] = {ps.x, ps.y, ps.z, ps.w};
         const int pwc = ch->pwc;
         const float fft_offset = ch->fft_offset;
         // X[k] = F0[k] + F1[k] * conj(W_8192^t) * conj(W_32^m), k = t + 256 m: the two factors applied to
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
             X = X * cf{cicv[m], cicv[m]};     // re *= CIC_comp[k], im *= CIC_comp[k] (:1342); 1.0f when off: exact
             const cf sq = X * X;
             float p = sq.x + sq.y;                                                      // re*re + im*im, :1345
-            if (k < dc) p = 0.f;                                                        // :1304
+            if (m == 0 && k < dc) p = 0.f;                                              // :1304 (dc <= 4: row 0 only)
             pwr[k] = p;
             if (TAPS && k < ch->fft_used) tap_pwr[(size_t) f * SUB + k] = p;
         }
@@ -192,7 +192,6 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
         // predicated: no divergent loops, the four pixels of a thread advance together, and every
         // pixel still sees its bins in ascending order (same result as the serial :1458-1478 loop).
         float pp[4] = {0.f, 0.f, 0.f, 0.f};   // memset(pwr_out, 0), :1385
-        int avgs[4] = {0, 0, 0, 0};
         if (interp == WF_DROP) {
 #pragma unroll
             for (int u = 0; u < 4; u++)
@@ -202,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
             const int cmax = kg_wave_max(max(max(pcount[0], pcount[1]), max(pcount[2], pcount[3])));
 #pragma unroll
             for (int u = 0; u < 4; u++)
-                if (pcount[u] > 0) { pp[u] = pwr[pfirst[u]]; avgs[u] = 1; }            // :1468-1475
+                if (pcount[u] > 0) pp[u] = pwr[pfirst[u]];                             // :1468-1475
             int plast[4];                     // last bin of each run (the run's first bin when it is empty)
 #pragma unroll
             for (int u = 0; u < 4; u++) plast[u] = pfirst[u] + max(pcount[u] - 1, 0);
@@ -216,10 +215,7 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
                 }
             };
             switch (interp) {                                                           // :1461-1466
-            case WF_CMA:  walk([](float p, float q) { return p + q; });
-#pragma unroll
-                          for (int u = 0; u < 4; u++) avgs[u] = pcount[u];
-                          break;
+            case WF_CMA:  walk([](float p, float q) { return p + q; }); break;
             case WF_MAX:  walk([](float p, float q) { return q > p ? q : p; }); break;
             case WF_MIN:  walk([](float p, float q) { return q < p ? q : p; }); break;
             default:      walk([](float, float q) { return q; }); break;               // WF_LAST
@@ -230,13 +226,16 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
         for (int u = 0; u < 4; u++) {
             const int px = 4 * t + u;
             const float p = pp[u];
-            float scale = pscale[u];
-            if (interp == WF_CMA)                                                        // :1499-1500
-                scale = (avgs[u] == 1) ? scale : ((avgs[u] == 2) ? pscale2[u] : scale / (float) avgs[u]);
+            // (WF_CMA: the divisor of :1499-1500 -- the pixel's run length, fixed per channel -- is already in
+            // the scale the host stored: fft_scale, fft_scale_div2 or fft_scale / avgs, kg_wf_set_channel)
+            const float scale = pscale[u];
             // dB = 10.0 * log10f(p*scale + 1e-30F) + fft_offset: the product and sum in
-            // float, the 10.0* and + in double, one rounding to float (:1507)
+            // float, the 10.0* and + in double, one rounding to float (:1507).  log10f as v_log_f32 (log2, 1 ulp)
+            // times log10(2): one instruction and a multiply instead of the library's twenty-odd; the argument
+            // is never below 1e-30 (no denormal path), NaN stays NaN; the difference from log10f is a few 1e-6
+            // in l, i.e. some 1e-5 dB, inside the bound the parity tests allow for the last ulp of log10f
             const float arg = p * scale + 1e-30f;
-            const float l = log10f(arg);
+            const float l = __builtin_amdgcn_logf(arg) * 0.30102999566398120f;
             float dB = (float) (10.0 * (double) l + (double) fft_offset);
             if (TAPS) { tap_pwr_out[(size_t) f * WF_WIDTH + px] = p; tap_db[(size_t) f * WF_WIDTH + px] = dB; }
             unsigned b;
@@ -398,8 +397,18 @@ int kg_wf_set_channel(kg_wf *w, int ch, const kg_wf_chan_cfg *cfg, const uint16_
             i = j;
         }
     }
-    memcpy(h.scale, fft_scale, sizeof h.scale);
-    memcpy(h.scale_div2, fft_scale_div2, sizeof h.scale_div2);
+    // The scale the dB stage multiplies by: for WF_CMA the reference picks fft_scale, fft_scale_div2 or
+    // fft_scale / avgs by the pixel's bin count (:1499-1500), a property of the map, so it is resolved here
+    // (the same float division); a CMA pixel no bin maps to keeps avgs = 0: scale / 0 = inf, 0 * inf = NaN,
+    // (u1_t)(int)NaN = byte 0, as in the reference.
+    for (int i = 0; i < WF_WIDTH; i++) {
+        float sc = fft_scale[i];
+        if (cfg->interp == WF_CMA) {
+            const int avgs = h.count[i];
+            sc = (avgs == 1) ? fft_scale[i] : ((avgs == 2) ? fft_scale_div2[i] : fft_scale[i] / (float) avgs);
+        }
+        h.scale[i] = sc;
+    }
     hipStream_t st = w->ctx->stream;
     KG_HIP(hipStreamSynchronize(st));         // frames in flight may read the old record
     KG_HIP(hipMemcpy(w->d_chans + ch, &h, sizeof h, hipMemcpyHostToDevice));
