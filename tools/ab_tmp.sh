@@ -1,26 +1,12 @@
 export TMPDIR=/tmp
-for v in base r02 base r02; do
- if [ $v = base ]; then lib=""; else lib=$PWD/flydog_sdr_gps_amd/libkiwigpu_$v.so; fi
- KIWIGPU_LIBRARY=$lib python3 - <<PY
-import sys, time, os
-sys.path.insert(0, os.getcwd())
-import numpy as np, torch
-from flydog_sdr_gps_amd import Context, Searcher, prn, sats, synth
-import flydog_sdr_gps_amd._lib as L
-dev = torch.device("cuda", 0)
-ctx = Context(0, torch.cuda.current_stream(dev).cuda_stream)
-B = 32
-s = Searcher(ctx, max_blocks=2 * B)
-for sat in range(32): s.set_code(sat, prn.cacode(sats.SATS[sat][1], sats.SATS[sat][2]))
-iq = torch.from_numpy(np.stack([synth.config1_iq16(seed=b) for b in range(B)])).to(dev)
-svs = list(range(32))
-def step(first):
-    s.sample_iq16_batch(int(iq.data_ptr()), B, first_block=first); s.correlate_async(svs, nblocks=B, first_block=first)
-for i in range(300): step((i & 1) * B)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for i in range(200): step((i & 1) * B)
-t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
-print("$v enqueue %.4f ms/step, total %.4f ms/step" % ((t1 - t0) / 200 * 1e3, (t2 - t0) / 200 * 1e3))
-PY
+KIWIGPU_ACQ_CA8=1 python3 -m pytest tests/test_acq_gpu.py tests/test_acq10_gpu.py tests/test_golden_gpu.py tests/test_example_gpu.py -q -x -p no:cacheprovider 2>&1 | tail -3
+for v in 1 0 1 0; do
+  KIWIGPU_ACQ_CA8=$v python3 bench.py --workload acq --no-cpu --no-live-traffic --steps 100 2>/dev/null | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('CA8=$v acq kernel_ms %.4f min %.4f frac %.4f' % (r['kernel_ms'], r['kernel_ms_min'], r['frac']))"
 done
+for v in 1 0; do
+  KIWIGPU_ACQ_CA8=$v python3 bench.py --workload acq10ms --no-cpu --no-live-traffic --steps 10 --warmup 2 2>/dev/null | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('CA8=$v acq10ms kernel_ms %.4f frac %.4f' % (r['kernel_ms'], r['frac']))"
+done
+KIWIGPU_ACQ_CA8=1 KIWIGPU_ACQ_CA8_WGS=1 python3 bench.py --workload acq --no-cpu --no-live-traffic --steps 100 2>/dev/null | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('CA8=1 one WG per CU: kernel_ms %.4f' % (r['kernel_ms']))"
