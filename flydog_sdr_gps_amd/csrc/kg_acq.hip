@@ -1039,228 +1039,6 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
     }
 }
 
-// ---------------------------------------------------------------------------
-// Correlate() for the 4092-lag window (C/A, QZSS) in the same 512-thread, 8-points-per-thread form, built to
-// 128 registers: TWO workgroups = sixteen waves per CU, four per SIMD, two independent barrier domains.  One
-// accumulator set (16 registers), pass-1 and pass-2 twiddles in LDS tables (56 + 448 entries), pass-3 twiddles in
-// registers, two tiles used alternately by the three exchanges of an item (a, b, a | b, a, b | ...: a tile is
-// rewritten one barrier after its last read), operands of the next item in layout B fetched a row at a time
-// between the passes.
-// ---------------------------------------------------------------------------
-#define ACQ8Q1_LDS_BYTES (2 * SUB * sizeof(float2) + (56 + 448) * sizeof(float2) + 8 * sizeof(acq_red) + 16 + 16 * 4 * sizeof(float2))
-
-template <int P>
-__global__ __launch_bounds__(512, 4) void acq_correlate8q1_kernel(   // 4 waves per SIMD: 128 registers
-    const float2 *__restrict__ data, const float2 *__restrict__ code,
-    const float2 *__restrict__ tab4096, const float2 *__restrict__ tabN,
-    const float2 *__restrict__ comb8,          // [P][4]
-    const acq_pair_desc *__restrict__ pairs, int *__restrict__ claim, acq_walk walk, int halo,
-    kg_acq_cell *__restrict__ cells)
-{
-    static_assert(P == 4 || P == 16, "N = 16384 or 65536");
-    constexpr int LOGP = P == 4 ? 2 : 4;
-    extern __shared__ __attribute__((aligned(16))) float2 smem[];
-    float2 *tw1 = smem + 2 * SUB, *tw2 = tw1 + 56;
-    acq_red *red = (acq_red *) (tw2 + 448);
-    volatile int *red_claim = (volatile int *) (red + 8);
-    float2 *cst = (float2 *) ((char *) (red + 8) + 16);       // [P][4]: W^{k2}, W^{2 k2}, W^{3 k2}, W^{4 k2}, W = W_{N/512}
-    const int i = threadIdx.x;
-    if (i < 56) kg_st(&tw1[i], kg_ld(&tab4096[(((i >> 3) + 1) * (i & 7)) << 6]));
-    if (i < 448) kg_st(&tw2[i], kg_ld(&tab4096[(((i >> 6) + 1) * (i & 63)) << 3]));
-    if (i < 4 * P) kg_st(&cst[i], kg_ld(&comb8[i]));
-    kg_tw7 p3;
-#pragma unroll
-    for (int j = 1; j < 8; j++) p3.w[j - 1] = kg_ld(&tab4096[j * i]);
-    cf wb[3], wa[3];
-#pragma unroll
-    for (int k = 1; k < 4; k++) { wb[k - 1] = kg_ld(&tabN[i * k]); wa[k - 1] = kg_ld(&tabN[(4 * i * k) & (P * SUB - 1)]); }
-    (void) wa;
-    auto sel3 = [](const cf (&w)[3], int k) { return k == 1 ? w[0] : (k == 2 ? w[1] : w[2]); };
-    __syncthreads();                                   // the LDS tables are filled
-
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
-    const int gpairs = (walk.npairs - xcd + 7) >> 3;
-    const bool spread = walk.npairs < 8;
-    const int ndop = walk.ndop, ncell = spread ? (walk.npairs * ndop - xcd + 7) >> 3 : gpairs * ndop;
-
-    typedef unsigned u4 __attribute__((ext_vector_type(4)));
-    const int rowb_c = 2 * (512 + 2 * halo) * (int) sizeof(float2);
-    const int plane_c = 4 * 2 * (512 + 2 * halo);
-    cf d[8], c[8];
-    struct acq_rsrc { __amdgpu_buffer_rsrc_t drs, crs; int dvo, cvo; };
-    auto fetch_prepare = [&](int data_off, int code_off, int dop, int k2) {
-        const int s = k2 - dop;
-        const int q0 = s >> LOGP;
-        acq_rsrc r;
-        r.drs = __builtin_amdgcn_make_buffer_rsrc(
-            (void *) (data + data_off + k2 * SUB), 0, SUB * (int) sizeof(float2), 0x00020000);
-        r.crs = __builtin_amdgcn_make_buffer_rsrc(
-            (void *) (code + code_off + (s & (P - 1)) * plane_c), 0, plane_c * (int) sizeof(float2), 0x00020000);
-        r.dvo = i * 16; r.cvo = (i + q0 + halo) * 16;
-        return r;
-    };
-    auto fetch_row = [&](const acq_rsrc &r, int p) {
-        const u4 dv = __builtin_amdgcn_raw_buffer_load_b128(r.drs, r.dvo, p * 8192, 0);
-        const u4 cv = __builtin_amdgcn_raw_buffer_load_b128(r.crs, r.cvo, p * rowb_c, 0);
-        d[2 * p] = cf{__uint_as_float(dv[0]), __uint_as_float(dv[1])};
-        d[2 * p + 1] = cf{__uint_as_float(dv[2]), __uint_as_float(dv[3])};
-        c[2 * p] = cf{__uint_as_float(cv[0]), __uint_as_float(cv[1])};
-        c[2 * p + 1] = cf{__uint_as_float(cv[2]), __uint_as_float(cv[3])};
-    };
-    int vzero = 0;
-    asm volatile("" : "+v"(vzero));
-    auto describe = [&](int idx) {                     // (the pair record through the vector path: see acq_correlate8_kernel)
-        const int cell = spread ? (idx << 3) + xcd : idx;
-        const int pg = cell / ndop, di = cell - pg * ndop;
-        const int4 pv = *(const int4 *) (pairs + (spread ? pg : (pg << 3) + xcd) + vzero);
-        return acq_cell_desc{__builtin_amdgcn_readfirstlane(pv.x), __builtin_amdgcn_readfirstlane(pv.y), walk.dop_lo + di,
-                             __builtin_amdgcn_readfirstlane(pv.z), __builtin_amdgcn_readfirstlane(pv.w) + di};
-    };
-    const int c0 = (i >> 1) & 7, b1 = (i >> 3) & 1;
-    const int r0 = i ^ ((i >> 4) & 7), r1 = i ^ (((i >> 6) & 1) << 3);
-    const int w1 = (i >> 3) * 64 + (i & 7), w2 = (i >> 6) * 512 + (i & 63);
-    const int t1 = i & 7, t2 = i & 63;
-
-    int cur_idx = slot, nxt_idx = slot + nslots;
-    if (cur_idx >= ncell) return;
-    acq_cell_desc cur = describe(cur_idx);
-    {
-        const acq_rsrc r = fetch_prepare(cur.data_off, cur.code_off, cur.dop, 0);
-#pragma unroll
-        for (int p = 0; p < 4; p++) fetch_row(r, p);
-    }
-    int par = 0;                                        // which tile takes this item's first exchange
-    for (;;) {
-        const bool more = nxt_idx < ncell;
-        const acq_cell_desc nxt = describe(more ? nxt_idx : cur_idx);
-        int claimed = 0;
-        if (i == 448) claimed = 2 * nslots + __hip_atomic_fetch_add(&claim[xcd], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        cf acc[8];
-#pragma unroll 1
-        for (int k2 = 0; k2 < P; k2++) {
-            cf base;                                           // W_N^{i k2}
-            if constexpr (P == 4) base = sel3(wb, k2);
-            else {
-                const int ka = k2 >> 2, kb = k2 & 3;
-                const cf A = sel3(wa, ka), Bv = sel3(wb, kb);
-                base = ka == 0 ? Bv : (kb == 0 ? A : kg_cmul(A, Bv));
-            }
-            float2 *ta = smem + par * SUB, *tb = smem + (par ^ 1) * SUB;
-            par ^= 1;
-            // the next item's operands: (cur, k2 + 1) or (nxt, 0); ONE set of load sites, never skipped
-            const bool same = k2 < P - 1;
-            const acq_rsrc nr = fetch_prepare(same ? cur.data_off : nxt.data_off, same ? cur.code_off : nxt.code_off,
-                                              same ? cur.dop : nxt.dop, (k2 + 1) & (P - 1));
-            auto ld = [&](int p) { kg_pin(); fetch_row(nr, p); kg_pin(); };
-            cf x[8], y[8];
-            // conj(data) * code, simd_multiply_conjugate_ccc (support/simd.cpp:39-67)
-#pragma unroll
-            for (int j = 0; j < 8; j += 4)
-                kg_cmulc4_o(x[j], x[j + 1], x[j + 2], x[j + 3], c[j], c[j + 1], c[j + 2], c[j + 3], d[j], d[j + 1], d[j + 2], d[j + 3]);
-            ld(0);
-            kg_radix8<+1>(x, y);
-#pragma unroll
-            for (int m = 0; m < 8; m++) kg_st(&ta[8 * i + (m ^ c0)], y[m]);
-            __syncthreads();
-            {
-                kg_tw7 w;
-#pragma unroll
-                for (int j = 1; j < 8; j++) w.w[j - 1] = kg_ld_tile(&tw1[(j - 1) * 8 + t1]);
-#pragma unroll
-                for (int j = 0; j < 8; j++) x[j] = kg_ld_tile(&ta[r0 + 512 * j]);
-                ld(1);
-                kg_twiddle8<+1>(x, w);
-            }
-            kg_radix8<+1>(x, y);
-#pragma unroll
-            for (int m = 0; m < 8; m++) kg_st(&tb[w1 + 8 * (m ^ b1)], y[m]);
-            __syncthreads();
-            {
-                kg_tw7 w;
-#pragma unroll
-                for (int j = 1; j < 8; j++) w.w[j - 1] = kg_ld_tile(&tw2[(j - 1) * 64 + t2]);
-#pragma unroll
-                for (int j = 0; j < 8; j++) x[j] = kg_ld_tile(&tb[r1 + 512 * j]);
-                ld(2);
-                kg_twiddle8<+1>(x, w);
-            }
-            kg_radix8<+1>(x, y);
-#pragma unroll
-            for (int m = 0; m < 8; m++) kg_st(&ta[w2 + 64 * m], y[m]);
-            __syncthreads();
-            cf g[3], G;
-#pragma unroll
-            for (int k = 0; k < 3; k++) g[k] = kg_ld_tile(&cst[4 * k2 + k]);
-            G = kg_ld_tile(&cst[4 * k2 + 3]);
-#pragma unroll
-            for (int j = 0; j < 8; j++) x[j] = kg_ld_tile(&ta[i + 512 * j]);
-            ld(3);
-            kg_twiddle8<+1>(x, p3);
-            kg_radix8<+1>(x, y);                               // y[m]: the sub-transform at n = i + 512 m
-            if (k2 == 0) {
-#pragma unroll
-                for (int m = 0; m < 8; m++) acc[m] = y[m];
-            } else {
-                // acc[m] += y[m] * base * W^{4a k2} * W^{b k2}, m = 4a + b
-                const cf B1 = kg_cmul(base, G);
-                cf C1, C2, C3, C5, C6, C7;
-                kg_cmul1x3v(C1, C2, C3, base, g[0], g[1], g[2]);
-                kg_cmul1x3v(C5, C6, C7, B1, g[0], g[1], g[2]);
-                kg_cmac4v(acc[0], acc[1], acc[2], acc[3], y[0], y[1], y[2], y[3], base, C1, C2, C3);
-                kg_cmac4v(acc[4], acc[5], acc[6], acc[7], y[4], y[5], y[6], y[7], B1, C5, C6, C7);
-            }
-        }
-        // search.cpp:486-490: power, first maximum (strict >), running total.  Row m holds n = i + 512 m; `limit` is
-        // wave-uniform: only the rows from limit >> 9 on need the per-lane window test (a real scalar branch per row).
-        const int limit = cur.limit, full_rows = limit >> 9;
-        float bp = 0.f, sum = 0.f;
-        int br = 0;
-#pragma unroll
-        for (int m = 0; m < 8; m++) {
-            const cf sq = acc[m] * acc[m];
-            float pw = sq.x + sq.y;
-            if (m >= full_rows) { asm volatile(""); pw = (i + 512 * m < limit) ? pw : 0.f; }
-            const bool take = pw > bp;
-            bp = take ? pw : bp; br = take ? m : br;
-            sum += pw;
-        }
-        const int bi = i + 512 * br;
-        {
-            float wmax = bp, wsum = sum;
-            kg_wave_max_sum(wmax, wsum);
-            const int wn = kg_wave_min(bp == wmax ? bi : 0x7fffffff);
-            if ((i & 63) == 0) { red[i >> 6].p = wmax; red[i >> 6].i = wn; red[i >> 6].s = wsum; }
-        }
-        if (i == 448) *red_claim = claimed;
-        __syncthreads();
-        const int nn_idx = __builtin_amdgcn_readfirstlane(*red_claim);
-        if (i < 64) {                                  // lanes 0..7 of wave 0 merge the eight waves
-            const acq_red r = red[i & 7];
-            float mp = r.p, ms = r.s;
-            int mi = r.i;
-#define ACQ_RED_STEP(L)                                                               \
-            {                                                                            \
-                const float op = kg_xchg<L>(mp), os = kg_xchg<L>(ms);                    \
-                const int oi = kg_xchg<L>(mi);                                           \
-                const bool take = (op > mp) | ((op == mp) & (oi < mi));                  \
-                mp = take ? op : mp; mi = take ? oi : mi;                                \
-                ms += os;                                                                \
-            }
-            ACQ_RED_STEP(0) ACQ_RED_STEP(1) ACQ_RED_STEP(2)
-#undef ACQ_RED_STEP
-            if (i == 0) {
-                const float ave = ms / (float) limit;      // :493
-                kg_acq_cell cc;
-                cc.snr = mp / ave;                         // :494
-                cc.max_pwr = mp; cc.tot_pwr = ms; cc.idx = mi;
-                cells[cur.out] = cc;
-            }
-        }
-        if (!more) break;
-        cur = nxt; cur_idx = nxt_idx; nxt_idx = nn_idx;
-    }
-}
-
 // search.cpp:455,495: best Doppler bin per (block, SV): the serial scan keeps the
 // first bin (ascending dop) holding the maximum snr, and only if it is > 0.
 // One wave per pair; lane l scans bins l, l+64, ...
@@ -1312,7 +1090,6 @@ struct kg_acq {
     float2 *d_quart;       // [P][4]
     float2 *d_comb8;       // [P][4]  combine constants of the 512-thread four-quarter kernel
     int grid8;             // its persistent grid; 0: use acq_correlate_kernel<P, 4> (KIWIGPU_ACQ_E1B8=0)
-    int grid8q1;           // persistent grid of the 512-thread C/A kernel; 0: acq_correlate_kernel<P, 1>
     float2 *d_code;        // [max_sats][P planes with halo]
     float2 *d_data;        // [max_blocks][P][4096]  layout A
     float2 *d_data_b;      // [max_blocks][P][4096]  layout B (the 512-thread kernel's); null when that kernel is off
@@ -1556,23 +1333,6 @@ static int acq_init(kg_acq *a)
             a->grid8 = ctx->num_cus & ~7;
             if (a->grid8 < 8) a->grid8 = 8;
         }
-        a->grid8q1 = 0;
-        const char *e1 = getenv("KIWIGPU_ACQ_CA8");
-        if (a->grid8 > 0 && e1 && e1[0] == '1') {
-            int occ = 0;
-            if (P == 4) {
-                KG_HIP(hipFuncSetAttribute((const void *) acq_correlate8q1_kernel<4>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, ACQ8Q1_LDS_BYTES));
-                KG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, acq_correlate8q1_kernel<4>, 512, ACQ8Q1_LDS_BYTES));
-            } else {
-                KG_HIP(hipFuncSetAttribute((const void *) acq_correlate8q1_kernel<16>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, ACQ8Q1_LDS_BYTES));
-                KG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, acq_correlate8q1_kernel<16>, 512, ACQ8Q1_LDS_BYTES));
-            }
-            if (occ < 1) occ = 1;
-            if (const char *e2 = getenv("KIWIGPU_ACQ_CA8_WGS")) { const int v = atoi(e2); if (v >= 1 && v < occ) occ = v; }
-            a->grid8q1 = (ctx->num_cus * occ) & ~7;
-        }
         if (a->grid8 == 0) { (void) hipFree(a->d_data_b); a->d_data_b = nullptr; }
     }
     if (a->grid1 < 8) a->grid1 = 8;
@@ -1654,7 +1414,7 @@ static int set_limit(kg_acq *a, int sat, int limit)
     KG_REQUIRE(limit >= 1 && limit <= 4 * SUB, KG_ERR_INVALID, "limit %d out of range (1..%d)", limit,
                4 * SUB);
     a->limits[sat] = limit;
-    a->code_layout[sat] = ((limit > SUB && a->grid8 > 0) || a->grid8q1 > 0) ? 1 : 0;     // which kernel will read this SV's code spectrum
+    a->code_layout[sat] = (limit > SUB && a->grid8 > 0) ? 1 : 0;     // which kernel will read this SV's code spectrum
     a->code_set[sat] = 1;
     a->last_sats.clear();        // force the pair tables to be rebuilt
     return KG_OK;
@@ -1986,19 +1746,7 @@ int kg_acq_correlate_blocks_async(kg_acq *a, int first, int nblocks, const int *
     }
     if (a->own_fstream && (rc = wait_once(st, a->ev_ready, a->ready_of, first, nblocks)) != KG_OK) return rc;   // RAW
     if (a->np1 > 0) {
-        if (a->grid8q1 > 0) {
-            const acq_walk w = {a->np1, a->ndop, a->dop_lo};
-            if (a->P == 4)
-                hipLaunchKernelGGL(acq_correlate8q1_kernel<4>, dim3(a->grid8q1), dim3(512), ACQ8Q1_LDS_BYTES, st,
-                                   (const float2 *) (a->d_data_b + (size_t) first * a->fft_len), (const float2 *) a->d_code,
-                                   (const float2 *) a->ctx->d_tab4096, (const float2 *) a->d_tabN, (const float2 *) a->d_comb8,
-                                   a->d_pairs1, a->d_claim, w, a->halo, a->d_cells);
-            else
-                hipLaunchKernelGGL(acq_correlate8q1_kernel<16>, dim3(a->grid8q1), dim3(512), ACQ8Q1_LDS_BYTES, st,
-                                   (const float2 *) (a->d_data_b + (size_t) first * a->fft_len), (const float2 *) a->d_code,
-                                   (const float2 *) a->ctx->d_tab4096, (const float2 *) a->d_tabN, (const float2 *) a->d_comb8,
-                                   a->d_pairs1, a->d_claim, w, a->halo, a->d_cells);
-        } else if (a->P == 4) launch_correlate<4, 1, false>(a, st, first, a->d_pairs1, a->np1, nullptr);
+        if (a->P == 4) launch_correlate<4, 1, false>(a, st, first, a->d_pairs1, a->np1, nullptr);
         else launch_correlate<16, 1, false>(a, st, first, a->d_pairs1, a->np1, nullptr);
         KG_HIP(hipGetLastError());
     }
