@@ -182,30 +182,42 @@ def usable_cores():
     return max(1, n)
 
 
+_CPU_UNIT = {}               # what the forked workers of a CPU leg run (inherited through fork, never pickled)
+
+
+def _cpu_worker(budget):
+    fn = _CPU_UNIT["unit"]
+    fn()                                              # warm-up in this process (page faults, lazy imports)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        fn()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget:
+            return n, el
+
+
 def cpu_threads(one_unit, budget_s):
-    """Every usable host thread runs whole single-threaded units back to back for about budget_s
-    seconds (independent units, like the GPU's batch; ctypes drops the GIL inside the oracle).
-    -> (units done, seconds, cores, seconds of one unit on one thread)"""
-    import threading
+    """Every usable host core runs whole single-threaded units back to back for about budget_s seconds
+    (independent units, like the GPU's batch), one forked worker PROCESS per core: threads of one interpreter
+    serialise on its lock wherever a unit is many short calls (round 2's thread version gave the 14-channel
+    frame leg 1.5x on 16 threads).  Forks: so this is only ever called BEFORE the process initialises the GPU
+    (cpu_legs).  -> (units done, seconds, cores, seconds of one unit on one core)"""
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
     cores = usable_cores()
+    one_unit()                                                    # warm-up, then the single-core figure
     t0 = time.perf_counter()
-    one_unit()                                                    # warm-up + single-thread figure
+    one_unit()
     t1 = time.perf_counter() - t0
-    done = [0] * cores
-    deadline = time.perf_counter() + budget_s
+    _CPU_UNIT["unit"] = one_unit
+    with ProcessPoolExecutor(cores, mp_context=mp.get_context("fork")) as pool:
+        got = list(pool.map(_cpu_worker, [budget_s] * cores))
+    el = max(e for _, e in got)
+    return sum(n for n, _ in got), el, cores, t1
 
-    def worker(k):
-        while time.perf_counter() < deadline:
-            one_unit()
-            done[k] += 1
 
-    t0 = time.perf_counter()
-    threads = [threading.Thread(target=worker, args=(k,)) for k in range(cores)]
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join()
-    return sum(done), time.perf_counter() - t0, cores, t1
+CPU_LEGS = {}                # workload -> cpu_baseline object, filled by cpu_legs() BEFORE the GPU is touched
 
 
 # ------------------------------------------------------------------------------------------------
@@ -218,8 +230,8 @@ LIVE_TRAFFIC = {}            # workload -> (bytes, source), filled by live_traff
 # What `traffic` is per workload: the named (dominant) kernels per launch -- the same unit as roofline.achieved --
 # or, for the workloads whose roofline is the whole step, every kernel dispatched in a step.
 TRAFFIC_KERNELS = {"acq": ("acq_correlate_kernel<4, 1,",),
-                   "acq59": ("acq_correlate_kernel<4, 1,", "acq_correlate_kernel<4, 4,"),
-                   "acq10ms": ("acq_correlate_kernel<16, 1,", "acq_correlate_kernel<16, 4,"),
+                   "acq59": ("acq_correlate_kernel<4, 1,", "acq_correlate8_kernel<4"),
+                   "acq10ms": ("acq_correlate_kernel<16, 1,", "acq_correlate8_kernel<16"),
                    "wf14": ("wf_frame_kernel",),
                    "ddc14": None, "cfg2_chain": None, "receivers": None}
 
@@ -588,7 +600,7 @@ def run_acq(args, dist, ten_ms=False, all_svs=False):
         # What bounds the correlator: fp32 vector arithmetic -- every operand is
         # served from L2, the kernel cannot be HBM-bound.  achieved = nominal FFT flops / HIP-event time.
         "roofline": {
-            "bound": "valu", "kernel": "acq_correlate_kernel<%d,1>%s" % (P, " + <%d,4>" % P if n4 else ""),
+            "bound": "valu", "kernel": "acq_correlate_kernel<%d,1>%s" % (P, " + acq_correlate8_kernel<%d>" % P if n4 else ""),
             "achieved": round(tfl, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tfl / VALU_PEAK_TFLOPS, 4),
             "traffic": traffic, "traffic_source": source,
@@ -628,8 +640,8 @@ def run_acq(args, dist, ten_ms=False, all_svs=False):
         out["ingest_pcie_Msps"] = round(B * nsamples / t_host / 1e6, 1)
         out["ingest_pcie_note"] = ("host int16 IQ in (%d blocks per pinned batch transfer, two batches in flight), winners "
                                    "fetched to the host: %.1f us per block" % (B, t_host / B * 1e6))
-    if not args.no_cpu and dist.world == 1 and dist.rank == 0:
-        out["cpu_baseline"] = cpu_acq(iq_host[0], codes, nsamples, fft_len, dop_lo, dop_hi, args.cpu_seconds)
+    if wl in CPU_LEGS:
+        out["cpu_baseline"] = CPU_LEGS[wl]
         out["speedup_vs_cpu_all_cores"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         if wl in POCKETFFT:
             out["cpu_baseline_pocketfft"] = POCKETFFT[wl]
@@ -687,7 +699,7 @@ def cpu_acq(iq, codes, nsamples, fft_len, dop_lo, dop_hi, budget_s):
     return {
         "value": round(value, 5), "unit": "Msamples/s", "cores": cores,
         "machine_cpus": os.cpu_count(), "kind": "port",
-        "sample": "%s, oracle fp32 FFT (%s), %d threads each running whole units, ~%.0f s" % (what, native_oracle_note(), cores, el),
+        "sample": "%s, oracle fp32 FFT (%s), %d worker processes each running whole units, ~%.0f s" % (what, native_oracle_note(), cores, el),
         "single_thread_value": round(single, 5),
         "port_vs_reference": "FFTW3f is unavailable here; cpu_baseline_pocketfft times the same work with the tuned FFT "
                              "that IS in the image (scipy.fft / pocketfft)",
@@ -907,27 +919,8 @@ def run_wf14(args, dist):
                  "achieved_TFLOPs": round(nfr * 5 * 8192 * 13 / (kernel_ms * 1e-3) / 1e12, 2), "peak": VALU_PEAK_TFLOPS,
                  "frac": round(nfr * 5 * 8192 * 13 / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)},
     }
-    if not args.no_cpu and dist.world == 1 and dist.rank == 0:
-        from oracle import kiwi_oracle as ko
-        ko.lib()
-        maps = [wf.build_maps(p.fft_used, p.plot_width, p.plot_width_clamped, False) for p in params]
-        scales = [np.full(1024, p.fft_scale, np.float32) for p in params]
-        k = [0]
-
-        def unit():                                   # one frame of each of the 14 channels
-            for ch, p in enumerate(params):
-                f = base[(k[0] + ch) % 32]
-                samps = ko.wf_window_iq(f, tables[0][wf.WINF_HANNING])
-                ko.wf_compute_frame(samps, p.zoom, wf.WINF_HANNING, wf.WF_CMA, True, False, p.fft_used,
-                                    p.plot_width, p.plot_width_clamped, maps[ch][0], maps[ch][1], scales[ch],
-                                    (scales[ch] / np.float32(2)).astype(np.float32), p.fft_offset, tables[1], prec=0)
-            k[0] += 1
-        reps_done, el, cores, t1 = cpu_threads(unit, args.cpu_seconds)
-        res["cpu_baseline"] = {
-            "value": round(reps_done * 14 * 8192 / el / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": "%d x (one frame of each of the 14 channels: sample_wf window + compute_frame), oracle fp32 "
-                      "FFT, %d threads, %.1f s" % (reps_done, cores, el),
-            "single_thread_value": round(14 * 8192 / t1 / 1e6, 4)}
+    if "wf14" in CPU_LEGS:
+        res["cpu_baseline"] = CPU_LEGS["wf14"]
         res["speedup_vs_cpu_all_cores"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
         if "wf14" in POCKETFFT:
             res["cpu_baseline_pocketfft"] = POCKETFFT["wf14"]
@@ -1069,22 +1062,8 @@ def run_ddc14(args, dist):
                 "measured_GBps": None if traffic is None else round(traffic / (gpu_ms * 1e-3) / 1e9, 1),
                 "peak": HBM_PEAK_GBS},
     }
-    if not args.no_cpu and dist.world == 1 and dist.rank == 0:
-        from oracle import kiwi_oracle as ko
-        ko.lib()
-        m = 1 << 18                                      # a bounded piece of the same stream
-        piece = adc_host[:m]
-        log2r = [int(np.log2(p.decim)) for p in prm]
-
-        def unit():                                      # all 14 channels over the piece
-            for ch, p in enumerate(prm):
-                ko.ddc_wf(piece, p.i_offset, log2r[ch])
-        reps_done, el, cores, t1 = cpu_threads(unit, args.cpu_seconds)
-        res["cpu_baseline"] = {
-            "value": round(reps_done * m / el / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": "%d x (2^18 ADC samples through the 14 channels), the oracle's sequential Verilog-structured "
-                      "model (the reference has no CPU DDC: it is FPGA fabric), %d threads, %.1f s" % (reps_done, cores, el),
-            "single_thread_value": round(m / t1 / 1e6, 4)}
+    if "ddc14" in CPU_LEGS:
+        res["cpu_baseline"] = CPU_LEGS["ddc14"]
         res["speedup_vs_cpu_all_cores"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
     d.close()
     ctx.close()
@@ -1208,34 +1187,8 @@ def run_cfg2_chain(args, dist):
                 "measured_GBps": None if traffic is None else round(traffic / (gpu_ms * 1e-3) / 1e9, 1),
                 "peak": HBM_PEAK_GBS},
     }
-    if not args.no_cpu and dist.world == 1 and dist.rank == 0:
-        from oracle import kiwi_oracle as ko
-        ko.lib()
-        m = 1 << 20                                      # a bounded piece of the same stream
-        piece = adc_host[:m]
-        log2r = [int(np.log2(p.decim)) for p in prm]
-        maps = [wf.build_maps(p.fft_used, p.plot_width, p.plot_width_clamped, False) for p in prm]
-        scales = [np.full(1024, p.fft_scale, np.float32) for p in prm]
-        done_frames = [0]
-
-        def unit():                                      # 2^20 ADC samples: 14 DDC channels, then every complete frame
-            nf = 0
-            for ch, p in enumerate(prm):
-                iq, _ = ko.ddc_wf(piece, p.i_offset, log2r[ch])
-                for f in range(iq.shape[0] // 8192):
-                    samps = ko.wf_window_iq(iq[8192 * f:8192 * (f + 1)], tables[0][wf.WINF_HANNING])
-                    ko.wf_compute_frame(samps, p.zoom, wf.WINF_HANNING, wf.WF_CMA, True, False, p.fft_used,
-                                        p.plot_width, p.plot_width_clamped, maps[ch][0], maps[ch][1], scales[ch],
-                                        (scales[ch] / np.float32(2)).astype(np.float32), p.fft_offset, tables[1], prec=0)
-                    nf += 1
-            done_frames[0] = nf
-        reps_done, el, cores, t1 = cpu_threads(unit, args.cpu_seconds)
-        res["cpu_baseline"] = {
-            "value": round(max(reps_done, 1) * m / el / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": "%d x (2^20 ADC samples through the oracle's 14 DDC channels, then sample_wf window + compute_frame of the "
-                      "%d complete frames they hold; the whole step holds %.1f per 2^20), %d threads, %.1f s"
-                      % (reps_done, done_frames[0], frames_per_step * m / n, cores, el),
-            "single_thread_value": round(m / t1 / 1e6, 4)}
+    if "cfg2_chain" in CPU_LEGS:
+        res["cpu_baseline"] = CPU_LEGS["cfg2_chain"]
         res["speedup_vs_cpu_all_cores"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
     d.close()
     w.close()
@@ -1285,13 +1238,8 @@ class ReceiverBank:
         self.d = d = Ddc(ctx, nchan=NR, max_samples=n)
         self.W = W = Waterfall(ctx, nchan=NR)
         W.set_tables()
-        hz_per_start = self.UI_SRATE / (1024 << 14)
-        self.params = []
-        for ch in range(NR):
-            k = first_rx + ch
-            z = 1 + k % 10
-            p = WfParams.for_zoom(z, (1.0e6 + 0.2e6 * (k % 97)) / hz_per_start, adc_clock=self.ADC_CLOCK, ui_srate=self.UI_SRATE)
-            self.params.append(p)
+        self.params, self.rx_inc = self.receiver_params(NR, first_rx)
+        for ch, p in enumerate(self.params):
             d.set_wf(ch, p.i_offset, p.decim)
             W.set_channel(ch, p, interp=wf.WF_MAX, window_func=wf.WINF_HANNING, cic_comp=True)
         self.rx = RxDdc(ctx_au, nchan=NR, max_samples=n)
@@ -1300,9 +1248,7 @@ class ReceiverBank:
         self.P = Post(self.ctx_tail, nchan=NR)
         self.A = Adpcm(self.ctx_tail, nchan=NR)
         self.fs = fs = self.ADC_CLOCK / RX_DECIM
-        self.rx_inc = []
         for ch in range(NR):
-            self.rx_inc.append(rx_phase_inc(0.0123 * self.ADC_CLOCK - 1000.0 - 10.0 * (first_rx + ch), self.ADC_CLOCK))
             self.rx.set_freq(ch, self.rx_inc[ch])
             self.fir.setup(ch, 300.0, 2700.0, 0.0, fs)
             self.P.set_agc(ch, True, False, -100, 50, 6, 1000, fs)
@@ -1322,6 +1268,20 @@ class ReceiverBank:
         self.counts = {"frames": 0, "audio_blocks": 0}
         self.last = {}                                                # what the last step produced (counts per stage)
         torch.cuda.synchronize(dev)                                   # buffers exist before the side stream touches them
+
+    @classmethod
+    def receiver_params(cls, NR, first_rx):
+        """Waterfall parameters and audio NCO words of receivers first_rx .. first_rx + NR - 1 of the 1024 (no GPU needed)."""
+        from flydog_sdr_gps_amd import WfParams
+        from flydog_sdr_gps_amd.ddc import rx_phase_inc
+        hz_per_start = cls.UI_SRATE / (1024 << 14)
+        params, rx_inc = [], []
+        for ch in range(NR):
+            k = first_rx + ch
+            params.append(WfParams.for_zoom(1 + k % 10, (1.0e6 + 0.2e6 * (k % 97)) / hz_per_start, adc_clock=cls.ADC_CLOCK,
+                                            ui_srate=cls.UI_SRATE))
+            rx_inc.append(rx_phase_inc(0.0123 * cls.ADC_CLOCK - 1000.0 - 10.0 * k, cls.ADC_CLOCK))
+        return params, rx_inc
 
     def audio(self):
         from flydog_sdr_gps_amd import snd
@@ -1441,32 +1401,32 @@ def run_receivers(args, dist):
                      "kernel_ms_median": round(dts[len(dts) // 2], 5), "int_ops_per_sample_per_receiver": ops},
         "hbm": {"measured_GBps": None if traffic is None else round(traffic / step_s / 1e9, 1), "peak": HBM_PEAK_GBS},
     }
-    if not args.no_cpu and dist.world == 1 and dist.rank == 0:
-        res["cpu_baseline"] = cpu_receivers(bank, args.cpu_seconds)
+    if "receivers" in CPU_LEGS:
+        res["cpu_baseline"] = CPU_LEGS["receivers"]
         res["speedup_vs_cpu_all_cores"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
     bank.close()
     return res
 
 
-def cpu_receivers(bank, budget_s):
-    """The oracle on whole receivers of the same bank: one unit = one receiver's complete step (waterfall DDC -> frame ->
+def cpu_receivers(NR, n, budget_s):
+    """The oracle on whole receivers of the bench's bank: one unit = one receiver's complete step (waterfall DDC -> frame ->
     row -> wf_pkt_t; audio DDC -> rx_iq_t -> unpack -> CFastFIR -> CAgc mono16 -> ADPCM) on the bank's ADC block."""
     import numpy as np
     from flydog_sdr_gps_amd import wf
+    from flydog_sdr_gps_amd.ddc import RX_DECIM
     from oracle import kiwi_oracle as ko
     ko.lib()
-    adc, n = bank.adc_host, bank.n
+    adc = adc_block(n, 0x5EED0004)
+    params, rx_inc = ReceiverBank.receiver_params(NR, 0)
+    fs = ReceiverBank.ADC_CLOCK / RX_DECIM
     tables = (wf.window_functions(), wf.cic_comp_table())
-    coef = ko.fir_design(300.0, 2700.0, 0.0, bank.fs, prec=0)[1]
-    k = [0]
-    import threading
-    lock = threading.Lock()
+    coef = ko.fir_design(300.0, 2700.0, 0.0, fs, prec=0)[1]
+    k = [os.getpid() % NR]                            # (workers are forked: each walks the receivers from its own start)
 
     def unit():
-        with lock:
-            ch = k[0] % bank.NR
-            k[0] += 1
-        p = bank.params[ch]
+        ch = k[0] % NR
+        k[0] += 1
+        p = params[ch]
         iq, _ = ko.ddc_wf(adc, p.i_offset, int(np.log2(p.decim)))
         fmap, drop = wf.build_maps(p.fft_used, p.plot_width, p.plot_width_clamped, False)
         scale = np.full(1024, p.fft_scale, np.float32)
@@ -1475,20 +1435,133 @@ def cpu_receivers(bank, budget_s):
                                   p.plot_width_clamped, fmap, drop, scale, (scale / np.float32(2)).astype(np.float32),
                                   p.fft_offset, tables[1], prec=0)[0]
         ko.wf_packet(row, int(p.start), p.zoom, 0, True)
-        raw, _ = ko.ddc_rx(adc, bank.rx_inc[ch])
+        raw, _ = ko.ddc_rx(adc, rx_inc[ch])
         nrec = raw.size // 6
         x = ko.dpump_unpack(raw, nrec, 1)[0]
         y, _ = ko.fir_process(ko.fir_new_state(), coef, x, prec=0)
         if y.size:
             agc = ko.Agc()
-            agc.set_parameters(True, False, -100, 50, 6, 1000, bank.fs)
+            agc.set_parameters(True, False, -100, 50, 6, 1000, fs)
             ko.adpcm_encode_i16(agc.process_s16(y[:512]))
     reps, el, cores, t1 = cpu_threads(unit, budget_s)
     return {"value": round(reps * n / el / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
             "sample": "%d x (one virtual receiver over the step's %d ADC samples: both chains, every stage; the DDCs are the "
-                      "oracle's sequential Verilog-structured models -- in the reference they are FPGA fabric), %d threads, %.1f s"
+                      "oracle's sequential Verilog-structured models -- in the reference they are FPGA fabric), %d worker processes, %.1f s"
                       % (reps, n, cores, el),
             "single_thread_value": round(n / t1 / 1e6, 4)}
+
+
+def cpu_wf14(budget_s):
+    import numpy as np
+    from flydog_sdr_gps_amd import WfParams, synth, wf
+    from oracle import kiwi_oracle as ko
+    ko.lib()
+    params = [WfParams.for_zoom(z, 1.0e6 * ch) for ch, z in enumerate(ZOOMS14)]
+    tables = (wf.window_functions(), wf.cic_comp_table())
+    base = np.stack([synth.wf_iq_frame(seed=i) for i in range(32)])
+    maps = [wf.build_maps(p.fft_used, p.plot_width, p.plot_width_clamped, False) for p in params]
+    scales = [np.full(1024, p.fft_scale, np.float32) for p in params]
+    k = [0]
+
+    def unit():                                   # one frame of each of the 14 channels
+        for ch, p in enumerate(params):
+            f = base[(k[0] + ch) % 32]
+            samps = ko.wf_window_iq(f, tables[0][wf.WINF_HANNING])
+            ko.wf_compute_frame(samps, p.zoom, wf.WINF_HANNING, wf.WF_CMA, True, False, p.fft_used,
+                                p.plot_width, p.plot_width_clamped, maps[ch][0], maps[ch][1], scales[ch],
+                                (scales[ch] / np.float32(2)).astype(np.float32), p.fft_offset, tables[1], prec=0)
+        k[0] += 1
+    reps_done, el, cores, t1 = cpu_threads(unit, budget_s)
+    return {"value": round(reps_done * 14 * 8192 / el / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "%d x (one frame of each of the 14 channels: sample_wf window + compute_frame), oracle fp32 "
+                      "FFT, %d worker processes, %.1f s" % (reps_done, cores, el),
+            "single_thread_value": round(14 * 8192 / t1 / 1e6, 4)}
+
+
+def ddc14_params(adc_clock=66.6666e6, ui_srate=30.0e6):
+    from flydog_sdr_gps_amd import WfParams
+    return [WfParams.for_zoom(z, 1.0e6 * ch, adc_clock=adc_clock, ui_srate=ui_srate) for ch, z in enumerate(ZOOMS14)]
+
+
+def cpu_ddc14(n, budget_s):
+    import numpy as np
+    from oracle import kiwi_oracle as ko
+    ko.lib()
+    prm = ddc14_params()
+    m = 1 << 18                                      # a bounded piece of the same stream
+    piece = adc_block(n, 0x5EED0003)[:m]
+    log2r = [int(np.log2(p.decim)) for p in prm]
+
+    def unit():                                      # all 14 channels over the piece
+        for ch, p in enumerate(prm):
+            ko.ddc_wf(piece, p.i_offset, log2r[ch])
+    reps_done, el, cores, t1 = cpu_threads(unit, budget_s)
+    return {"value": round(reps_done * m / el / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "%d x (2^18 ADC samples through the 14 channels), the oracle's sequential Verilog-structured "
+                      "model (the reference has no CPU DDC: it is FPGA fabric), %d worker processes, %.1f s" % (reps_done, cores, el),
+            "single_thread_value": round(m / t1 / 1e6, 4)}
+
+
+def cpu_cfg2_chain(n, budget_s):
+    import numpy as np
+    from flydog_sdr_gps_amd import wf
+    from oracle import kiwi_oracle as ko
+    ko.lib()
+    prm = ddc14_params()
+    tables = (wf.window_functions(), wf.cic_comp_table())
+    m = 1 << 20                                      # a bounded piece of the same stream
+    piece = adc_block(n, 0x5EED0003)[:m]
+    log2r = [int(np.log2(p.decim)) for p in prm]
+    maps = [wf.build_maps(p.fft_used, p.plot_width, p.plot_width_clamped, False) for p in prm]
+    scales = [np.full(1024, p.fft_scale, np.float32) for p in prm]
+    done_frames = [0]
+
+    def unit():                                      # 2^20 ADC samples: 14 DDC channels, then every complete frame
+        nf = 0
+        for ch, p in enumerate(prm):
+            iq, _ = ko.ddc_wf(piece, p.i_offset, log2r[ch])
+            for f in range(iq.shape[0] // 8192):
+                samps = ko.wf_window_iq(iq[8192 * f:8192 * (f + 1)], tables[0][wf.WINF_HANNING])
+                ko.wf_compute_frame(samps, p.zoom, wf.WINF_HANNING, wf.WF_CMA, True, False, p.fft_used,
+                                    p.plot_width, p.plot_width_clamped, maps[ch][0], maps[ch][1], scales[ch],
+                                    (scales[ch] / np.float32(2)).astype(np.float32), p.fft_offset, tables[1], prec=0)
+                nf += 1
+        done_frames[0] = nf
+    reps_done, el, cores, t1 = cpu_threads(unit, budget_s)
+    return {"value": round(reps_done * m / el / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "%d x (2^20 ADC samples through the oracle's 14 DDC channels, then sample_wf window + compute_frame of the "
+                      "%d complete frames they hold), %d worker processes, %.1f s" % (reps_done, done_frames[0], cores, el),
+            "single_thread_value": round(m / t1 / 1e6, 4)}
+
+
+def cpu_legs(args):
+    """cpu_baseline of every workload of this run: the oracle ("port") on the box's usable cores, one forked worker process
+    per core -- hence BEFORE this process initialises the GPU.  Inputs are the workloads' own (same seeds)."""
+    from flydog_sdr_gps_amd import acq, prn, sats, synth
+    from tests.fixtures import e1b_chips
+    wls = ALL_WORKLOADS if args.workload == "all" else [args.workload]
+    T = args.cpu_seconds
+
+    def log2n_for(wl):
+        return args.log2n if args.log2n_given else (22 if wl == "receivers" else 24)
+    for wl in wls:
+        if wl == "acq":
+            codes = [(prn.cacode(sats.SATS[s][1], sats.SATS[s][2]), False) for s in range(NSV)]
+            CPU_LEGS[wl] = cpu_acq(synth.config1_iq16(seed=0x5EED0002), codes, NSAMPLES, FFT_LEN, -20, 20, T)
+        elif wl == "acq59":
+            CPU_LEGS[wl] = cpu_acq(synth.config1_iq16(seed=0x5EED0002), synth.all_sv_codes(e1b_chips()), NSAMPLES, FFT_LEN, -20, 20, T)
+        elif wl == "acq10ms":
+            codes = synth.all_sv_codes(e1b_chips())
+            CPU_LEGS[wl] = cpu_acq(synth.config4_iq16(codes, seed=0x5EED0005), codes, acq.NSAMPLES_10MS, acq.FFT_LEN_10MS, -128, 127, T)
+        elif wl == "wf14":
+            CPU_LEGS[wl] = cpu_wf14(T)
+        elif wl == "ddc14":
+            CPU_LEGS[wl] = cpu_ddc14(1 << log2n_for(wl), T)
+        elif wl == "cfg2_chain":
+            CPU_LEGS[wl] = cpu_cfg2_chain(1 << log2n_for(wl), T)
+        elif wl == "receivers":
+            CPU_LEGS[wl] = cpu_receivers(args.receivers, 1 << log2n_for(wl), T)
+        log("cpu_baseline %s: %s %s on %d cores" % (wl, CPU_LEGS[wl]["value"], CPU_LEGS[wl]["unit"], CPU_LEGS[wl]["cores"]))
 
 
 def run_stub(args, dist):
@@ -1570,7 +1643,8 @@ def main():
         live_traffic_passes(args)                            # children; this process has not touched the GPU yet
     if not args.no_cpu and not args.pmc_child and args.workload != "stub" and (world_env is None or int(world_env) == 1):
         native_oracle()                                      # before anything loads the oracle
-        pocketfft_legs(args)                                 # forked workers: before this process touches the GPU
+        cpu_legs(args)                                       # forked workers: before this process touches the GPU
+        pocketfft_legs(args)
         log("pocketfft legs done: %s" % {k: v.get("value") for k, v in POCKETFFT.items()})
     dist = Dist("gloo" if args.workload == "stub" else "nccl")
     common = {"n_gpus": dist.world, "steps": args.steps, "warmup": args.warmup, "preroll_s": PREROLL_S, "higher_is_better": True,
