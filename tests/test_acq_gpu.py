@@ -209,7 +209,8 @@ def test_custom_limit_and_narrow_doppler(gpu_ctx, oracle):
     s.close()
 
 
-@pytest.mark.parametrize("limit", [1, 255, 256, 257, 3839, 3840, 3841, 4095, 4096, 4097, 8191, 12288, 16367, 16384])
+@pytest.mark.parametrize("limit", [1, 255, 256, 257, 3839, 3840, 3841, 4095, 4096, 4097, 4607, 4608, 4609, 8191, 8192, 12288,
+                                   15871, 15872, 15873, 16367, 16384])   # (> 4096: the 512-thread kernel, rows of 512 lags)
 def test_search_window_boundaries(gpu_ctx, oracle, limit):
     """The peak-search window (search.cpp:486 `limit`) on and around the 256-lag rows of the cell-end scan
     (rows wholly inside the window skip the per-lane test) and around 4096, where the four-accumulator

@@ -1,6 +1,6 @@
-"""Copies the judged summaries of a tools/prof_round.sh run from gpurun_out/<tag>_* into profiles/r02_*
+"""Copies the judged summaries of a tools/prof_round.sh run from gpurun_out/<tag>_* into profiles/<round>_*
 and rewrites profiles/hbm_traffic.json from their PMC passes (2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes).
-usage: python tools/collect_profiles.py <tag> [round-prefix, default r02]"""
+usage: python tools/collect_profiles.py <tag> [round-prefix, default r03]"""
 import glob
 import json
 import os
@@ -9,7 +9,7 @@ import shutil
 import sys
 
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 go, pr = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 
@@ -19,7 +19,7 @@ def first(pat):
     return f[0] if f else None
 
 
-for wl in ("acq", "acq59", "acq10ms", "wf14", "ddc14", "receivers"):
+for wl in ("acq", "acq59", "acq10ms", "wf14", "ddc14", "cfg2_chain", "receivers"):
     ks = first(os.path.join(go, "%s_%s" % (tag, wl), "trace", "**", "*kernel_stats.csv"))
     if ks:
         shutil.copy(ks, os.path.join(pr, "%s_%s_kernel_stats.csv" % (rnd, wl)))
@@ -56,12 +56,12 @@ tab = {"_how": "tools/prof_round.sh on MI355X: separate rocprofv3 --pmc passes o
 tab["acq"] = {"32": entry("acq", "acq_correlate_kernel<4, 1,", "acq_correlate_kernel<4, 1, true, false>")}
 tab["wf14"] = {"28672": entry("wf14", "wf_frame_kernel", "wf_frame_kernel<false>")}
 p1 = entry("acq10ms", "acq_correlate_kernel<16, 1,", "acq_correlate_kernel<16, 1, true, false>")
-p4 = entry("acq10ms", "acq_correlate_kernel<16, 4,", "acq_correlate_kernel<16, 4, true, false>")
-tab["acq10ms"] = {"2": {"kernel": "acq_correlate_kernel<16,1> + <16,4>",
+p4 = entry("acq10ms", "acq_correlate8_kernel<16", "acq_correlate8_kernel<16, false>")
+tab["acq10ms"] = {"2": {"kernel": "acq_correlate_kernel<16,1> + acq_correlate8_kernel<16>",
                         "bytes_per_launch": p1["bytes_per_launch"] + p4["bytes_per_launch"], "parts": [p1, p4]}}
 q1 = entry("acq59", "acq_correlate_kernel<4, 1,", "acq_correlate_kernel<4, 1, true, false>")
-q4 = entry("acq59", "acq_correlate_kernel<4, 4,", "acq_correlate_kernel<4, 4, true, false>")
-tab["acq59"] = {"32": {"kernel": "acq_correlate_kernel<4,1> + <4,4>",
+q4 = entry("acq59", "acq_correlate8_kernel<4", "acq_correlate8_kernel<4, false>")
+tab["acq59"] = {"32": {"kernel": "acq_correlate_kernel<4,1> + acq_correlate8_kernel<4>",
                        "bytes_per_launch": q1["bytes_per_launch"] + q4["bytes_per_launch"], "parts": [q1, q4]}}
 json.dump(tab, open(os.path.join(pr, "hbm_traffic.json"), "w"), indent=1)
 print(json.dumps({k: (v if k.startswith("_") else {kk: vv.get("bytes_per_launch") for kk, vv in v.items()}) for k, v in tab.items()}, indent=1))

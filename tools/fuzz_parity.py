@@ -166,32 +166,51 @@ _acq = {}
 
 
 def trial_acq():
-    """One SV on one block of 1-bit IF: a PRN injected at a random code phase / Doppler / C/N0 (or
-    absent); the GPU's (valid, Doppler bin, index) must be the oracle's, snr within 2e-5."""
+    """A block of 1-bit IF holding one SV -- C/A or Galileo E1B (BOC(1,1), all 16368 lags or a random window longer
+    than 4096: the 512-thread correlator) -- at a random code phase / Doppler / C/N0, or absent; a random list of 1 .. 12 SVs
+    of both kinds is searched (fewer than 8 pairs: cells dealt over the XCDs; more: pairs).  For the SV that is there the GPU's
+    (valid, Doppler bin, index) must be the oracle's and snr within 2e-5; for the others the level must agree."""
+    from tests.fixtures import e1b_chips
     if not _acq:
         _acq["s"] = Searcher(ctx, max_blocks=1)
-        _acq["chips"] = {}
+        _acq["codes"] = {}
+        _acq["e1b"] = e1b_chips()
     s = _acq["s"]
-    sat = int(rng.integers(0, 36))
-    if sat not in _acq["chips"]:
-        _, t1, t2, _ = sats.SATS[sat]
-        _acq["chips"][sat] = prn.cacode(t1, t2)
-        s.set_code(sat, _acq["chips"][sat])
-    chips = _acq["chips"][sat]
+
+    def code_of(sat, limit=None):
+        prn_no, t1, t2, kind = sats.SATS[sat]
+        boc = kind == sats.E1B
+        chips = _acq["e1b"][prn_no] if boc else prn.cacode(t1, t2)
+        lim = limit if limit is not None else (sats.E1B_LIMIT if boc else sats.L1_LIMIT)
+        if _acq["codes"].get(sat, (None, None))[1] != lim:
+            s.set_code(sat, chips, boc=boc, limit=lim)
+            _acq["codes"][sat] = (chips, lim)
+        return chips, boc, lim
+    nsv = int(rng.integers(1, 13))
+    svs = [int(x) for x in rng.choice(len(sats.SATS), nsv, replace=False)]
+    target = svs[int(rng.integers(0, nsv))]
+    tkind = sats.SATS[target][3] == sats.E1B
+    tlimit = int(rng.integers(4097, 16385)) if tkind and rng.random() < 0.5 else None
+    info = {sat: code_of(sat, tlimit if sat == target else None) for sat in svs}
+    chips, boc, _ = info[target]
     present = rng.random() < 0.85
-    other = prn.cacode(*sats.SATS[(sat + 7) % 32][1:3])
-    scene = [(chips if present else other, float(rng.uniform(0, 1023)), float(rng.uniform(-5000, 5000)), float(rng.uniform(0, 6.28)))]
-    bits = synth.gps_scene_bits(scene, int(rng.integers(0, 1 << 31)), float(rng.uniform(38, 50)))
+    other = prn.cacode(*sats.SATS[(target + 7) % 32][1:3])
+    scene = [(chips if present else other, float(rng.uniform(0, chips.size)), float(rng.uniform(-5000, 5000)),
+              float(rng.uniform(0, 6.28)), float(rng.uniform(40, 50)), bool(boc and present))]
+    bits = synth.gps_scene_bits(scene, int(rng.integers(0, 1 << 31)))
     s.sample(bits, block=0)
-    got, _ = s.correlate_many([sat], nblocks=1, want_cells=False)
-    g = got[0, 0]
-    res = ko.correlate(ko.code_fft(chips, prec=1), ko.sample_bits(bits, prec=1))
-    w_snr, w_dop, w_idx, w_valid = (res[0][k] for k in ("snr", "dop", "idx", "valid"))
-    if w_snr >= 20:                                     # a detection: everything must agree
-        assert (int(g["valid"]), int(g["dop"]), int(g["idx"])) == (int(w_valid), int(w_dop), int(w_idx)), ("acq", g, res[0])
-        assert abs(float(g["snr"]) - w_snr) <= 2e-5 * w_snr, ("acq snr", g["snr"], w_snr)
-    else:                                               # noise: the maximum may sit on a near-tie; the level must agree
-        assert abs(float(g["snr"]) - w_snr) <= 1e-3 * max(w_snr, 1.0), ("acq noise snr", g["snr"], w_snr)
+    got, _ = s.correlate_many(svs, nblocks=1, want_cells=False)
+    data = ko.sample_bits(bits, prec=1)
+    for k, sat in enumerate(svs):
+        c, b, lim = info[sat]
+        g = got[0, k]
+        res = ko.correlate(ko.code_fft(c, boc=b, prec=1), data, limit=lim)
+        w_snr, w_dop, w_idx, w_valid = (res[0][x] for x in ("snr", "dop", "idx", "valid"))
+        if w_snr >= 24:                                 # a detection: everything must agree
+            assert (int(g["valid"]), int(g["dop"]), int(g["idx"])) == (int(w_valid), int(w_dop), int(w_idx)), ("acq", sat, lim, g, res[0])
+            assert abs(float(g["snr"]) - w_snr) <= 2e-5 * w_snr, ("acq snr", sat, g["snr"], w_snr)
+        else:                                           # noise: the maximum may sit on a near-tie; the level must agree
+            assert abs(float(g["snr"]) - w_snr) <= 1e-3 * max(w_snr, 1.0), ("acq noise snr", sat, g["snr"], w_snr)
 
 
 _wf = {}

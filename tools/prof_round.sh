@@ -8,9 +8,10 @@ for wl in acq acq59 acq10ms wf14; do
   tools/prof.sh ${tag}_$wl --workload $wl $extra > gpurun_out/${tag}_$wl.summary.txt 2>&1
   echo "== $wl"; grep -E "calls" gpurun_out/${tag}_$wl.summary.txt | head -6
 done
-for wl in ddc14 receivers; do
+for wl in ddc14 cfg2_chain receivers; do
   out=gpurun_out/${tag}_$wl; mkdir -p $out
   extra="--steps 40"; [ $wl = receivers ] && extra="--steps 20 --warmup 3"
+  [ $wl = ddc14 ] && { tools/prof.sh ${tag}_$wl --workload $wl $extra > gpurun_out/${tag}_$wl.summary.txt 2>&1; echo "== $wl"; grep -E "calls" gpurun_out/${tag}_$wl.summary.txt | head -7; continue; }
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --no-cpu --no-live-traffic --workload $wl $extra > $out/trace.log 2>&1
   echo "== $wl"; f=$(find $out/trace -name "*kernel_stats.csv" | head -1); head -8 $f | cut -d, -f1-5 | cut -c1-140
 done
