@@ -583,30 +583,62 @@ __global__ __launch_bounds__(64 * DDC_SCAN_WAVES) void ddc_wf_scan_states_kernel
 }
 
 // Prefix sum of the runs' integrator-5 totals: one workgroup of eight waves per (channel, I/Q).
+// Run r = k * 512 + thread: every load and store of a tile of 512 runs is contiguous across the workgroup
+// (round 2 gave each thread 32 consecutive runs: every access its own line, 28 us for a 16 384-entry prefix).
+// Per tile a wave scan (tile values stay in registers), the (tile, wave) totals -- at most 32 x 8 -- through LDS
+// and one more scan by the first four waves, then the offsets are applied.
+#define DDC_TAU_TILES 32                      // max_runs = 16384 = 32 tiles of 512
 __global__ __launch_bounds__(64 * DDC_SCAN_WAVES) void ddc_wf_scan_tau_kernel(
     u32 *__restrict__ tau, int nruns, ddc_chan *__restrict__ chans, const int *__restrict__ chan_list)
 {
-    __shared__ u32 w_tot[DDC_SCAN_WAVES];
+    __shared__ u32 s_tot[DDC_TAU_TILES * DDC_SCAN_WAVES];       // totals, then exclusive offsets
+    __shared__ u32 s_w4[4];
     const int li = blockIdx.x >> 1, comp = blockIdx.x & 1, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = threadIdx.x;
     ddc_chan *ch = chans + chan_list[li];
     if (ch->log2r == 0) return;
     u32 *tv = tau + ((long) li * 2 + comp) * nruns;
-    const int per = (nruns + 64 * DDC_SCAN_WAVES - 1) / (64 * DDC_SCAN_WAVES);
-    const int r0 = gl * per < nruns ? gl * per : nruns, r1 = (r0 + per < nruns) ? r0 + per : nruns;
-    u32 acc = 0;
-    for (int r = r0; r < r1; r++) acc += tv[r];
-    u32 inc = acc;
-    for (int d = 1; d < 64; d <<= 1) { const u32 a = __shfl_up(inc, d); if (lane >= d) inc += a; }
-    if (lane == 63) w_tot[wave] = inc;
-    u32 c = __shfl_up(inc, 1);
-    if (lane == 0) c = 0;
+    const int ntile = (nruns + 511) >> 9;         // <= DDC_TAU_TILES (kg_ddc_create caps max_runs at 16384)
+    u32 inc[DDC_TAU_TILES], own[DDC_TAU_TILES];
+#pragma unroll
+    for (int k = 0; k < DDC_TAU_TILES; k++) {
+        const int r = (k << 9) + gl;
+        own[k] = (k < ntile && r < nruns) ? tv[r] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < DDC_TAU_TILES; k++) {
+        u32 v = own[k];
+        for (int d = 1; d < 64; d <<= 1) { const u32 a = __shfl_up(v, d); if (lane >= d) v += a; }
+        inc[k] = v;
+        if (lane == 63) s_tot[k * DDC_SCAN_WAVES + wave] = v;
+    }
     __syncthreads();
+    // exclusive prefix over the 256 (tile, wave) totals, in time order: waves 0..3, one total per lane
+    u32 t = 0, tinc = 0;
+    if (gl < 256) {
+        t = s_tot[gl];
+        tinc = t;
+        for (int d = 1; d < 64; d <<= 1) { const u32 a = __shfl_up(tinc, d); if (lane >= d) tinc += a; }
+        if (lane == 63) s_w4[wave] = tinc;
+    }
+    __syncthreads();
+    if (gl < 256) {
+        u32 base = 0;
+        for (int w = 0; w < wave; w++) base += s_w4[w];
+        s_tot[gl] = base + tinc - t;              // exclusive
+    }
     const u32 i5 = ch->integ5[comp];
-    __syncthreads();                              // every wave has read the saved value
-    for (int w = 0; w < wave; w++) c += w_tot[w];
-    c = (c + i5) & 0x0FFFFFFFu;
-    for (int r = r0; r < r1; r++) { const u32 e = tv[r]; tv[r] = c; c = (c + e) & 0x0FFFFFFFu; }   // tv[r] = I5 at run start
-    if (r1 == nruns && r0 < nruns) ch->integ5[comp] = c;
+    __syncthreads();                              // offsets written; every wave has read the saved value
+#pragma unroll
+    for (int k = 0; k < DDC_TAU_TILES; k++) {
+        const int r = (k << 9) + gl;
+        if (k < ntile && r < nruns)
+            tv[r] = (i5 + s_tot[k * DDC_SCAN_WAVES + wave] + inc[k] - own[k]) & 0x0FFFFFFFu;     // I5 at the run's start
+    }
+    if (gl == 0) {                                // the sum of every run = state after the call
+        u32 total = i5;
+        for (int w = 0; w < 4; w++) total += s_w4[w];
+        ch->integ5[comp] = total & 0x0FFFFFFFu;
+    }
 }
 
 // sign-extend the low `bits` bits

@@ -201,29 +201,57 @@ __global__ __launch_bounds__(64 * RX_SCAN_WAVES) void rx1_scan_kernel(u64 *__res
     if (r1 == nruns && r0 < nruns) { ch->i1[comp] = c1; ch->i2[comp] = c2; }
 }
 
+// Prefix sum of the runs' integrator-3 totals (mod 2^26): one workgroup per (channel, I/Q), run r = k * 512 + thread
+// so that every tile of 512 runs is loaded and stored contiguously (as ddc_wf_scan_tau_kernel, kg_ddc.hip).
+#define RX_TAU_TILES 32                       // max_runs = 16384 = 32 tiles of 512
 __global__ __launch_bounds__(64 * RX_SCAN_WAVES) void rx1_scan_tau_kernel(u32 *__restrict__ tau, int nruns, rx_chan *__restrict__ chans,
                                                                          const int *__restrict__ chan_list)
 {
-    __shared__ u32 w_tot[RX_SCAN_WAVES];
+    __shared__ u32 s_tot[RX_TAU_TILES * RX_SCAN_WAVES];
+    __shared__ u32 s_w4[4];
     const int li = blockIdx.x >> 1, comp = blockIdx.x & 1, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = threadIdx.x;
     rx_chan *ch = chans + chan_list[li];
     u32 *tv = tau + ((long) li * 2 + comp) * nruns;
-    const int per = (nruns + 64 * RX_SCAN_WAVES - 1) / (64 * RX_SCAN_WAVES);
-    const int r0 = gl * per < nruns ? gl * per : nruns, r1 = (r0 + per < nruns) ? r0 + per : nruns;
-    u32 acc = 0;
-    for (int r = r0; r < r1; r++) acc += tv[r];
-    u32 inc = acc;
-    for (int d = 1; d < 64; d <<= 1) { const u32 a = __shfl_up(inc, d); if (lane >= d) inc += a; }
-    if (lane == 63) w_tot[wave] = inc;
-    u32 c = __shfl_up(inc, 1);
-    if (lane == 0) c = 0;
+    const int ntile = (nruns + 511) >> 9;
+    u32 inc[RX_TAU_TILES], own[RX_TAU_TILES];
+#pragma unroll
+    for (int k = 0; k < RX_TAU_TILES; k++) {
+        const int r = (k << 9) + gl;
+        own[k] = (k < ntile && r < nruns) ? tv[r] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < RX_TAU_TILES; k++) {
+        u32 v = own[k];
+        for (int d = 1; d < 64; d <<= 1) { const u32 a = __shfl_up(v, d); if (lane >= d) v += a; }
+        inc[k] = v;
+        if (lane == 63) s_tot[k * RX_SCAN_WAVES + wave] = v;
+    }
     __syncthreads();
+    u32 t = 0, tinc = 0;
+    if (gl < 256) {
+        t = s_tot[gl];
+        tinc = t;
+        for (int d = 1; d < 64; d <<= 1) { const u32 a = __shfl_up(tinc, d); if (lane >= d) tinc += a; }
+        if (lane == 63) s_w4[wave] = tinc;
+    }
+    __syncthreads();
+    if (gl < 256) {
+        u32 base = 0;
+        for (int w = 0; w < wave; w++) base += s_w4[w];
+        s_tot[gl] = base + tinc - t;
+    }
     const u32 i3 = ch->i3[comp];
-    __syncthreads();                              // every wave has read the saved value
-    for (int w = 0; w < wave; w++) c += w_tot[w];
-    c = (c + i3) & 0x03FFFFFFu;
-    for (int r = r0; r < r1; r++) { const u32 e = tv[r]; tv[r] = c; c = (c + e) & 0x03FFFFFFu; }
-    if (r1 == nruns && r0 < nruns) ch->i3[comp] = c;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RX_TAU_TILES; k++) {
+        const int r = (k << 9) + gl;
+        if (k < ntile && r < nruns) tv[r] = (i3 + s_tot[k * RX_SCAN_WAVES + wave] + inc[k] - own[k]) & 0x03FFFFFFu;
+    }
+    if (gl == 0) {
+        u32 total = i3;
+        for (int w = 0; w < 4; w++) total += s_w4[w];
+        ch->i3[comp] = total & 0x03FFFFFFu;
+    }
 }
 
 // rx1 combs + rounding -> 18-bit samples appended behind the channel's history.
