@@ -460,6 +460,45 @@ KG_DEV void kg_subfft4096_l(cf (&x)[16], cf (&y)[16], float2 *tileA, float2 *til
     kg_radix16<SIGN>(x, y);
 }
 
+// kg_subfft4096_l with a caller hook h(k), k = 0..7, at eight points spread over the transform (after the pass-0
+// butterfly, after its stores, behind the issued tile reads of each exchange, after each twiddle block, after the
+// pass-1 butterfly and its stores): callers issue a few global loads at each (fenced with kg_pin()), so that the
+// loads of a frame do not reach the texture addresser as one burst from four waves at once.
+template <int SIGN, class H>
+KG_DEV void kg_subfft4096_l_h(cf (&x)[16], cf (&y)[16], float2 *tileA, float2 *tileB, const float2 *tw1,
+                              const kg_tw15 &p2, int t, H h)
+{
+    // (spreading the LDS stores of passes 0 and 1 through the butterflies as well, kg_radix16_h, measured the same)
+    const int tl = t & 15, th = t >> 4;
+    const int rd = t ^ (th & 15);
+    kg_radix16<SIGN>(x, y);
+    h(0);
+#pragma unroll
+    for (int m = 0; m < 16; m++) kg_st(&tileA[16 * t + (m ^ tl)], y[m]);
+    h(1);
+    __syncthreads();
+    kg_tw15 w1;
+#pragma unroll
+    for (int j = 1; j < 16; j++) w1.w[j - 1] = kg_ld_tile(&tw1[(j - 1) * 16 + tl]);
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = kg_ld_tile(&tileA[rd + 256 * j]);
+    h(2);
+    kg_twiddle16<SIGN>(x, w1);
+    h(3);
+    kg_radix16<SIGN>(x, y);
+    h(4);
+#pragma unroll
+    for (int m = 0; m < 16; m++) kg_st(&tileB[th * 256 + 16 * m + (tl ^ m)], y[m]);
+    h(5);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = kg_ld_tile(&tileB[rd + 256 * j]);
+    h(6);
+    kg_twiddle16<SIGN>(x, p2);
+    h(7);
+    kg_radix16<SIGN>(x, y);
+}
+
 // The same transform for kernels that run it once per workgroup (forward FFT of
 // a sample block, code-table build): one tile, one rolled radix-16 body, the
 // twiddles fetched per pass instead of being held (half the registers).

@@ -134,20 +134,28 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
         windowed(x, 0);
         kg_subfft4096_l<-1>(x, y0, tileA, tileB, tw1, p2, t);
         windowed(x, 1);
-        if (more) fetch(fr_next.y);           // the next frame, both parities, into the registers just consumed
-        // CIC compensation factors of this thread's sixteen bins, fetched here in one batch and used
-        // after the transform (one load + wait per bin inside the power loop cost sixteen exposed L2
-        // round trips per frame)
-        // (a per-thread-contiguous copy of the table, four 16-byte loads, measured slower: 0.434 against 0.427 ms)
-        // (1.0f = CIC_comp[0] where the frame is not compensated: x * 1.0f is exact; a branch that skips
-        // those loads measured 20 % SLOWER -- it splits the block the scheduler interleaves)
+        // Everything the second transform's duration can hide is requested DURING it, five loads at each of eight
+        // points (kg_subfft4096_l_h): the next frame (both parities, into the registers just consumed; the last frame
+        // of a workgroup re-reads its own: one load site, never skipped -- a conditional one makes the compiler
+        // drain vmcnt at the join), this frame's CIC compensation factors (1.0f = the table's second half where the
+        // frame is not compensated: x * 1.0f is exact) and the next frame's window values.  As three bursts of 16,
+        // 8 and 16 loads from four waves at once they queued behind each other in the CU's one texture addresser
+        // (a load costs it about twenty cycles; the same finding as in acq_correlate8_kernel).
         float cicv[16];
         {
+            const int2 *nsrc = (const int2 *) iq + (size_t) (unsigned) fr_next.y;
             const float2 *cp = (const float2 *) cic_comp + (comp_on ? 0 : 2048) + t;
-#pragma unroll
-            for (int i = 0; i < 8; i++) { const float2 v = cp[256 * i]; cicv[2 * i] = v.x; cicv[2 * i + 1] = v.y; }
+            const float2 *nwin = (const float2 *) (windows + (size_t) wfn_next * WF_NFFT);
+            kg_subfft4096_l_h<-1>(x, y1, tileA, tileB, tw1, p2, t, [&](int k) {
+                kg_pin();
+                raw[2 * k] = nsrc[t + 256 * (2 * k)];
+                raw[2 * k + 1] = nsrc[t + 256 * (2 * k + 1)];
+                { const float2 v = cp[256 * k]; cicv[2 * k] = v.x; cicv[2 * k + 1] = v.y; }
+                wv[2 * k] = nwin[t + 256 * (2 * k)];
+                wv[2 * k + 1] = nwin[t + 256 * (2 * k + 1)];
+                kg_pin();
+            });
         }
-        kg_subfft4096_l<-1>(x, y1, tileA, tileB, tw1, p2, t);
         // (tile A, about to become pwr[], was last read before the second transform's
         // second barrier)
         // this thread's four pixels: run starts, run lengths, scales -- four vector loads
@@ -183,8 +191,6 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
         if (t == 0) *lds_claim = claimed;
         __syncthreads();
         const int fnn = __builtin_amdgcn_readfirstlane(*lds_claim);    // wave-uniform; rewritten after >= 6 barriers
-        // the next frame's first window values arrive during the pixel stage
-        fetch_window(windows + (size_t) wfn_next * WF_NFFT);
         cid = cid_next;
 
         // pixels 4t .. 4t+3.  The interpolation mode is the frame's (wave-uniform); the run lengths
