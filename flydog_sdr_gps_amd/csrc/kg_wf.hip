@@ -119,12 +119,14 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
     int f = blockIdx.x, fn = blockIdx.x + gridDim.x;
     int cid;                                  // grid <= nframes: every workgroup has a first frame
     { const int2 fr = frames[f]; cid = fr.x; fetch(fr.y); }
+    // the record of the frame after this one is fetched a frame ahead (at the bottom of the loop, as soon as its
+    // index is known): at the top of a frame it would be a scalar-cache round trip with nothing to hide behind
+    int2 fr_next = frames[fn < nframes ? fn : f];
     fetch_window(windows + (size_t) chans[cid].window_func * WF_NFFT);
     for (;;) {
         const wf_chan_dev *ch = chans + cid;
         const int interp = ch->interp, dc = ch->dc, comp_on = ch->comp_on;
         const bool more = fn < nframes;
-        const int2 fr_next = frames[more ? fn : f];
         const int cid_next = fr_next.x;
         const int wfn_next = chans[cid_next].window_func;
         int claimed = 0;
@@ -258,6 +260,7 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
         ((unsigned *) (out + (size_t) f * WF_WIDTH))[t] = bytes;
         __syncthreads();                      // pwr[] (tile A) is rewritten by the next frame
         if (!more) break;
+        fr_next = frames[fnn < nframes ? fnn : fn];
         f = fn; fn = fnn;
     }
     if (t == 0) {
