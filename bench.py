@@ -121,6 +121,8 @@ class Dist:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")                   # (KIWIGPU_BENCH_FORCE_DIST=1 without a launcher)
+            os.environ.setdefault("WORLD_SIZE", "1")
             if backend == "nccl":
                 dist.init_process_group("nccl", device_id=self.dev)
             else:
@@ -338,7 +340,10 @@ def live_traffic_passes(args):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
             cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child
-            env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+            # (a child of a rank started by torch.distributed.run must not think it is one)
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                                     "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+            env["TMPDIR"] = os.environ.get("TMPDIR", "/tmp")
             p = subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                                  start_new_session=True)     # its own process group: a stuck pass is ended whole
             try:
@@ -1639,7 +1644,8 @@ def main():
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%s\n" % (args.gpus, world_env))
         sys.exit(2)
 
-    if world_env is None and args.gpus == 1 and not args.no_live_traffic and not args.pmc_child and args.workload != "stub":
+    single = args.gpus == 1 and (world_env is None or int(world_env) == 1)
+    if single and not args.no_live_traffic and not args.pmc_child and args.workload != "stub":
         live_traffic_passes(args)                            # children; this process has not touched the GPU yet
     if not args.no_cpu and not args.pmc_child and args.workload != "stub" and (world_env is None or int(world_env) == 1):
         native_oracle()                                      # before anything loads the oracle
