@@ -12,10 +12,13 @@ pytestmark = pytest.mark.gpu
 def use_everything(ctx):
     s = Searcher(ctx, max_blocks=2)
     s.set_code(0, prn.cacode(*sats.SATS[0][1:3]))
+    s.set_code(1, np.arange(4092, dtype=np.uint8) & 1, boc=True)      # a 16368-lag SV: the 512-thread correlator and its layout
     s.sample_iq16(synth.config1_iq16(seed=1), block=0)
-    s.correlate_async([0], nblocks=1)
+    s.correlate_async([0, 1], nblocks=1)
     s.fetch()
     s.close()
+    ctx.mark(7)                                                        # the profiling marker kernel
+    ctx.sync()
     w = Waterfall(ctx, nchan=2)
     w.set_tables()
     p = WfParams.for_zoom(3, 1000.0)
@@ -73,3 +76,14 @@ def test_contexts_come_and_go():
         free.append(c.mem_info()[0])
         c.close()
     assert max(free) - min(free[1:]) < 64 * 2 ** 20
+
+
+
+def test_mark_rejects_tags_out_of_range(gpu_ctx):
+    from flydog_sdr_gps_amd import KiwiGpuError
+    gpu_ctx.mark(1)
+    gpu_ctx.mark(65535)
+    gpu_ctx.sync()
+    for bad in (0, -3, 65536):
+        with pytest.raises(KiwiGpuError):
+            gpu_ctx.mark(bad)
