@@ -329,6 +329,27 @@ def test_bench_numpy_waterfall_rows_equal_the_oracle(oracle):
             assert d.max() <= 1 and (d == 0).mean() > 0.99
 
 
+def test_radix8_form_index_math_and_swizzles():
+    """tools/proto_fft8.py is the numpy model of kg_subfft4096_r8 (the 512-thread, 8-points-per-thread transform of the
+    16368-lag correlator): the four Stockham passes must be the 4096-point transform, the three exchange swizzles
+    bijections that leave every ds_write_b64 / ds_read_b64 of the kernel conflict-free under the gfx950 banking rules,
+    and the device code's address forms (base + XOR of a per-thread constant) the same positions."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import proto_fft8 as pf
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(4096) + 1j * rng.standard_normal(4096)
+    for sign, ref in ((+1, np.fft.ifft(x) * 4096), (-1, np.fft.fft(x))):
+        assert np.abs(pf.subfft4096_r8(x, sign) - ref).max() <= 1e-12 * np.abs(ref).max()
+    assert pf.conflicts() == 0
+    i = np.arange(512)
+    for m in range(8):
+        assert np.array_equal(pf.P0(pf.write_idx(0, i, m)), 8 * i + (m ^ ((i >> 1) & 7)))
+        assert np.array_equal(pf.P1(pf.write_idx(1, i, m)), (i >> 3) * 64 + (i & 7) + 8 * (m ^ ((i >> 3) & 1)))
+    for j in range(8):
+        assert np.array_equal(pf.P0(i + 512 * j), 512 * j + (i ^ ((i >> 4) & 7)))
+        assert np.array_equal(pf.P1(i + 512 * j), 512 * j + (i ^ (((i >> 6) & 1) << 3)))
+
+
 def _have_gpu_count(n):
     try:
         import torch
