@@ -1,6 +1,6 @@
 """A short run of the randomised differential soak (tools/fuzz_parity.py: random configurations of
 the DDCs, CFastFIR, the S-meter/AGC/detector block and the wire formats against the oracle).
-The full soak (25 s per module: 124k trials, 0 failures on MI355X) is run by hand."""
+The full soak (25 s per module: 134k trials, 0 failures on MI355X, profiles/r03_fuzz_soak.txt) is run by hand."""
 import os
 import subprocess
 import sys
