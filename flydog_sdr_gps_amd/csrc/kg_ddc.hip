@@ -171,15 +171,21 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
     long o = (long) (cnt0 >> log2r);                      // index of the next strobe's output
     u32 *c0i = c0rel + c0off[li], *c0q = c0i + ((nouts[li] + 3) & ~3l);      // planes start 16-byte aligned
     // eight samples per round from one 16-byte load (runs start 128-byte aligned relative to
-    // the block; an unaligned block or the ragged end of the last run go sample by sample)
-    auto samples8 = [&](long t, short (&buf)[8]) {
-        if ((((uintptr_t) (adc + t)) & 15) == 0 && t + 8 <= s1) {
-            const int4 v = *(const int4 *) (adc + t);
-            buf[0] = (short) v.x; buf[1] = (short) (v.x >> 16); buf[2] = (short) v.y; buf[3] = (short) (v.y >> 16);
-            buf[4] = (short) v.z; buf[5] = (short) (v.z >> 16); buf[6] = (short) v.w; buf[7] = (short) (v.w >> 16);
-        } else {
-            for (int q = 0; q < 8; q++) buf[q] = (t + q < s1) ? adc[t + q] : (short) 0;
-        }
+    // the block; an unaligned block or the ragged end of the last run go sample by sample).
+    // The load runs ONE GROUP AHEAD of the arithmetic: issued at the top of a group and consumed at the
+    // top of the next, its L2 latency hides behind the ~170 instructions of the group in between (a
+    // load consumed where it is issued stalled every group of every lane for the whole round trip).
+    // The last whole group of a run re-reads itself: one load site, never skipped.
+    const bool al = (((uintptr_t) (adc + s0)) & 15) == 0;          // L is a multiple of 8: every group of the run is aligned alike
+    const long g1 = al ? s1 : s0;                                  // the group loops run to g1: a misaligned block goes sample by sample
+    int4 ahead = make_int4(0, 0, 0, 0);
+    if (s0 + 8 <= g1) ahead = *(const int4 *) (adc + s0);
+    auto samples8 = [&](long t, short (&buf)[8]) {                 // callers guarantee t + 8 <= g1 and walk t in steps of 8 from s0
+        const int4 v = ahead;
+        const long tn = (t + 16 <= g1) ? t + 8 : t;
+        ahead = *(const int4 *) (adc + tn);
+        buf[0] = (short) v.x; buf[1] = (short) (v.x >> 16); buf[2] = (short) v.y; buf[3] = (short) (v.y >> 16);
+        buf[4] = (short) v.z; buf[5] = (short) (v.z >> 16); buf[6] = (short) v.w; buf[7] = (short) (v.w >> 16);
     };
 
     // Pass A always starts from zero: over a run of at most 1024 samples the integrators hold plain
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
         // aligned staging rows; anything else takes the paths below.
         if (PASS_B && stage_bytes && log2r <= 3) {
             const int lane = threadIdx.x & 63, K = L >> log2r;
-            const bool ok = c == 0 && (s1 - s0) == L && (K & 15) == 0 && (o & 3) == 0 &&
+            const bool ok = al && c == 0 && (s1 - s0) == L && (K & 15) == 0 && (o & 3) == 0 &&
                             ((uintptr_t) c0i & 15) == 0 && ((uintptr_t) c0q & 15) == 0;
             if (__popcll(__ballot(ok)) == 64) {
                 u32 *tI = stage_lds + (threadIdx.x >> 6) * (2 * 64 * DDC_STAGE_ROW), *tQ = tI + 64 * DDC_STAGE_ROW;
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
                 const long o_wave = ((long) __shfl((int) (o >> 32), 0) << 32) | (unsigned) __shfl((int) o, 0);
                 int kcol = 0;
                 long kdone = 0;                                           // strobes of this run already flushed
-                for (; t + 8 <= s1; t += 8) {
+                for (; t + 8 <= g1; t += 8) {
                     short buf[8];
                     samples8(t, buf);
 #pragma unroll
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
                 i5q = (i5q + (u32) (Q[3] >> sh5)) & 0x0FFFFFFFu;
             };
             if (log2r == 1) {
-                for (; t + 8 <= s1; t += 8) {
+                for (; t + 8 <= g1; t += 8) {
                     short buf[8];
                     samples8(t, buf);
                     uint4 vi, vq;
@@ -299,7 +305,7 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
                     o += 4;
                 }
             } else {
-                for (; t + 8 <= s1; t += 8) {
+                for (; t + 8 <= g1; t += 8) {
                     short buf[8];
                     samples8(t, buf);
                     uint2 vi, vq;
@@ -311,7 +317,7 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
             }
             // c is 0 again: eight is a multiple of R
         }
-        for (; t + 8 <= s1; t += 8) {                     // whole groups, no per-sample masking
+        for (; t + 8 <= g1; t += 8) {                     // whole groups, no per-sample masking
             short buf[8];
             samples8(t, buf);
 #pragma unroll
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
         }
     };
     long t = s0;
-    for (; t + 8 <= s1; t += 8) {
+    for (; t + 8 <= g1; t += 8) {
         short buf[8];
         samples8(t, buf);
 #pragma unroll
