@@ -32,6 +32,7 @@
 //   C  per output: absolute I5, the five pruned combs (a 6-tap dependency on
 //      earlier outputs only, so fully parallel), rounding, int16 store.
 // All arithmetic is modulo 2^128, which keeps the low 89 bits exact.
+#include <type_traits>
 #include "kg_common.h"
 
 #include <math.h>
@@ -242,43 +243,58 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
                 const long o_wave = ((long) __shfl((int) (o >> 32), 0) << 32) | (unsigned) __shfl((int) o, 0);
                 int kcol = 0;
                 long kdone = 0;                                           // strobes of this run already flushed
-                for (; t + 8 <= g1; t += 8) {
-                    short buf[8];
-                    samples8(t, buf);
+                auto flush = [&]() {                                      // 16 strobes of 64 runs -> 2 x 4 stores of whole lines
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int w = 0; w < 8; w++) {
-                        const u32 e = tab[ph >> 51];
-                        const long long mi = mix24(buf[w], (short) (e & 0xffff)), mq = mix24(buf[w], (short) (e >> 16));
-                        ph += inc16;
-                        I[0] += (u64) mi; I[1] += I[0]; I[2] += I[1]; I[3] += I[2];
-                        Q[0] += (u64) mq; Q[1] += Q[0]; Q[2] += Q[1]; Q[3] += Q[2];
-                        i5i = (i5i + (u32) (I[3] >> sh5)) & 0x0FFFFFFFu;
-                        i5q = (i5q + (u32) (Q[3] >> sh5)) & 0x0FFFFFFFu;
-                        if (((w + 1) & (int) Rm1) == 0) {                 // strobe (the group starts aligned)
-                            tI[lane * DDC_STAGE_ROW + kcol] = i5i;
-                            tQ[lane * DDC_STAGE_ROW + kcol] = i5q;
-                            kcol++;
-                        }
+                    for (int q = 0; q < 4; q++) {
+                        const int rl = q * 16 + (lane >> 2), col = (lane & 3) * 4;
+                        const u32 *ri = tI + rl * DDC_STAGE_ROW + col, *rq = tQ + rl * DDC_STAGE_ROW + col;
+                        const uint4 vi = make_uint4(ri[0], ri[1], ri[2], ri[3]);
+                        const uint4 vq = make_uint4(rq[0], rq[1], rq[2], rq[3]);
+                        const long dst = o_wave + (long) rl * K + kdone + col;
+                        *(uint4 *) (c0i + dst) = vi;
+                        *(uint4 *) (c0q + dst) = vq;
                     }
-                    if (kcol == 16) {                                      // wave-uniform
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    kdone += 16;
+                    kcol = 0;
+                };
+                // One copy of the loop per decimation: the strobe positions of a group are compile-time, so the group
+                // is straight-line code -- the eight table reads go out together at its top (with a branch per sample
+                // each read was waited for where it was issued: a lone wave per SIMD has nothing to hide that behind).
+                // A full tile is flushed at the TOP of the next group, before that group's sample load is issued: the
+                // load is then always the youngest vector-memory operation, and waiting for it does not wait for stores
+                // issued a moment ago.
+                auto staged_loop = [&](auto lr_tag) {
+                    constexpr int LR = decltype(lr_tag)::value;
+                    for (; t + 8 <= g1; t += 8) {
+                        if (kcol == 16) flush();                          // wave-uniform
+                        short buf[8];
+                        samples8(t, buf);
+                        u32 e[8];
 #pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const int rl = q * 16 + (lane >> 2), col = (lane & 3) * 4;
-                            const u32 *ri = tI + rl * DDC_STAGE_ROW + col, *rq = tQ + rl * DDC_STAGE_ROW + col;
-                            const uint4 vi = make_uint4(ri[0], ri[1], ri[2], ri[3]);
-                            const uint4 vq = make_uint4(rq[0], rq[1], rq[2], rq[3]);
-                            const long dst = o_wave + (long) rl * K + kdone + col;
-                            *(uint4 *) (c0i + dst) = vi;
-                            *(uint4 *) (c0q + dst) = vq;
+                        for (int w = 0; w < 8; w++) { e[w] = tab[ph >> 51]; ph += inc16; }
+#pragma unroll
+                        for (int w = 0; w < 8; w++) {
+                            const long long mi = mix24(buf[w], (short) (e[w] & 0xffff)), mq = mix24(buf[w], (short) (e[w] >> 16));
+                            I[0] += (u64) mi; I[1] += I[0]; I[2] += I[1]; I[3] += I[2];
+                            Q[0] += (u64) mq; Q[1] += Q[0]; Q[2] += Q[1]; Q[3] += Q[2];
+                            i5i = (i5i + (u32) (I[3] >> sh5)) & 0x0FFFFFFFu;
+                            i5q = (i5q + (u32) (Q[3] >> sh5)) & 0x0FFFFFFFu;
+                            if (((w + 1) & ((1 << LR) - 1)) == 0) {       // strobe (the group starts aligned)
+                                tI[lane * DDC_STAGE_ROW + kcol + ((w + 1) >> LR) - 1] = i5i;
+                                tQ[lane * DDC_STAGE_ROW + kcol + ((w + 1) >> LR) - 1] = i5q;
+                            }
                         }
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        kdone += 16;
-                        kcol = 0;
+                        kcol += 8 >> LR;
                     }
-                }
+                    if (kcol == 16) flush();
+                };
+                if (log2r == 1) staged_loop(std::integral_constant<int, 1>());
+                else if (log2r == 2) staged_loop(std::integral_constant<int, 2>());
+                else staged_loop(std::integral_constant<int, 3>());
                 o += K;                                                    // all K strobes of the run are out
             }
         }
@@ -320,6 +336,23 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
         for (; t + 8 <= g1; t += 8) {                     // whole groups, no per-sample masking
             short buf[8];
             samples8(t, buf);
+            if (PASS_B && c + 8 <= (u32) Rm1) {
+                // no strobe inside this group (most groups once R >= 16): straight-line code, the eight table
+                // reads go out together (with the strobe test between them each was waited for where it was issued)
+                u32 e[8];
+#pragma unroll
+                for (int w = 0; w < 8; w++) { e[w] = tab[ph >> 51]; ph += inc16; }
+#pragma unroll
+                for (int w = 0; w < 8; w++) {
+                    const long long mi = mix24(buf[w], (short) (e[w] & 0xffff)), mq = mix24(buf[w], (short) (e[w] >> 16));
+                    I[0] += (u64) mi; I[1] += I[0]; I[2] += I[1]; I[3] += I[2];
+                    Q[0] += (u64) mq; Q[1] += Q[0]; Q[2] += Q[1]; Q[3] += Q[2];
+                    i5i = (i5i + (u32) (I[3] >> sh5)) & 0x0FFFFFFFu;
+                    i5q = (i5q + (u32) (Q[3] >> sh5)) & 0x0FFFFFFFu;
+                }
+                c += 8;
+                continue;
+            }
 #pragma unroll
             for (int w = 0; w < 8; w++) step(buf[w]);
         }
@@ -343,6 +376,76 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
         return;
     }
 
+    if (PASS_B) {
+        // Pass B, R >= 512.  Nothing above bit 88 of an integrator is ever read (integrator 5 takes [88 -: 28]), so
+        // the states are kept mod 2^96 as three 32-bit limbs: an integrator step is one three-instruction carry
+        // chain (v_add_co / v_addc_co / v_addc_co) where the 128-bit form took an add, a compare for the carry and
+        // a second add with carry-in per half -- 89 -> 57 instructions per sample and channel, and these five of
+        // the fourteen BASELINE channels were two thirds of pass B's work.
+        struct u96 { u32 w[3]; };
+        auto add96 = [](u96 &a, const u96 &b) {
+            unsigned c0, c1;
+            a.w[0] = __builtin_addc(a.w[0], b.w[0], 0u, &c0);
+            a.w[1] = __builtin_addc(a.w[1], b.w[1], c0, &c1);
+            a.w[2] = a.w[2] + b.w[2] + c1;
+        };
+        u96 I[4], Q[4];
+        {
+            const ddc_state4 a = local[lI], b = local[lQ];
+            for (int k = 0; k < 4; k++) {
+                I[k].w[0] = (u32) a.i[k].lo; I[k].w[1] = (u32) (a.i[k].lo >> 32); I[k].w[2] = (u32) a.i[k].hi;
+                Q[k].w[0] = (u32) b.i[k].lo; Q[k].w[1] = (u32) (b.i[k].lo >> 32); Q[k].w[2] = (u32) b.i[k].hi;
+            }
+        }
+        auto step = [&](int a) {
+            const u32 e = tab[ph >> 51];
+            const long long mi = mix24(a, (short) (e & 0xffff)), mq = mix24(a, (short) (e >> 16));
+            ph += inc16;
+            // in = sign-extended m << shift (shift = 65 - 5 log2 R is 0 .. 20 here), 96 bits
+            const u64 li = (u64) mi << shift, lq = (u64) mq << shift;
+            u96 xi, xq;
+            xi.w[0] = (u32) li; xi.w[1] = (u32) (li >> 32); xi.w[2] = (u32) (shift ? mi >> (64 - shift) : mi >> 63);
+            xq.w[0] = (u32) lq; xq.w[1] = (u32) (lq >> 32); xq.w[2] = (u32) (shift ? mq >> (64 - shift) : mq >> 63);
+            add96(I[0], xi); add96(I[1], I[0]); add96(I[2], I[1]); add96(I[3], I[2]);
+            add96(Q[0], xq); add96(Q[1], Q[0]); add96(Q[2], Q[1]); add96(Q[3], Q[2]);
+            // integrator 5 accumulates integrator4[88 -: 28] (cic_wf1.vh)
+            i5i = (i5i + ((I[3].w[2] << 3) | (I[3].w[1] >> 29))) & 0x0FFFFFFFu;
+            i5q = (i5q + ((Q[3].w[2] << 3) | (Q[3].w[1] >> 29))) & 0x0FFFFFFFu;
+            c = (c + 1) & (u32) Rm1;
+            if (c == 0) { c0i[o] = i5i; c0q[o] = i5q; o++; }              // strobe: sample_no was R - 1
+        };
+        long t = s0;
+        for (; t + 8 <= g1; t += 8) {
+            short buf[8];
+            samples8(t, buf);
+            if (c + 8 <= (u32) Rm1) {                         // no strobe inside this group: see the narrow path
+                u32 e[8];
+#pragma unroll
+                for (int w = 0; w < 8; w++) { e[w] = tab[ph >> 51]; ph += inc16; }
+#pragma unroll
+                for (int w = 0; w < 8; w++) {
+                    const long long mi = mix24(buf[w], (short) (e[w] & 0xffff)), mq = mix24(buf[w], (short) (e[w] >> 16));
+                    const u64 li = (u64) mi << shift, lq = (u64) mq << shift;
+                    u96 xi, xq;
+                    xi.w[0] = (u32) li; xi.w[1] = (u32) (li >> 32); xi.w[2] = (u32) (shift ? mi >> (64 - shift) : mi >> 63);
+                    xq.w[0] = (u32) lq; xq.w[1] = (u32) (lq >> 32); xq.w[2] = (u32) (shift ? mq >> (64 - shift) : mq >> 63);
+                    add96(I[0], xi); add96(I[1], I[0]); add96(I[2], I[1]); add96(I[3], I[2]);
+                    add96(Q[0], xq); add96(Q[1], Q[0]); add96(Q[2], Q[1]); add96(Q[3], Q[2]);
+                    i5i = (i5i + ((I[3].w[2] << 3) | (I[3].w[1] >> 29))) & 0x0FFFFFFFu;
+                    i5q = (i5q + ((Q[3].w[2] << 3) | (Q[3].w[1] >> 29))) & 0x0FFFFFFFu;
+                }
+                c += 8;
+                continue;
+            }
+#pragma unroll
+            for (int w = 0; w < 8; w++) step(buf[w]);
+        }
+        for (; t < s1; t++) step(adc[t]);
+        tau[lI] = i5i;
+        tau[lQ] = i5q;
+        return;
+    }
+    // pass A of runs longer than 1024 samples at R >= 512: the zero-state sums need the full width
     ddc_state4 SI, SQ;
     if (PASS_B) {
         SI = local[lI];
