@@ -131,7 +131,11 @@ DDC_DEV int mix24(int adc, int dds)
 }
 
 #define DDC_THREADS 256
-#define DDC_STAGE_ROW 17          // words per lane row of a staging tile: 16 strobes + 1 (odd stride: conflict-free)
+#define DDC_TAB 10240             // NCO table entries: sin(a) = T[a], cos(a) = T[a + 2048], a < 8192
+#ifndef DDC_STAGE_STROBES
+#define DDC_STAGE_STROBES 16      // strobes per run collected before a flush: 64 bytes per run and store (8 = half lines: ddc14 +6 %)
+#endif
+#define DDC_STAGE_ROW (DDC_STAGE_STROBES + 1)    // words per lane row of a staging tile (odd stride: conflict-free)
 #define DDC_STAGE_BYTES ((DDC_THREADS / 64) * 2 * 64 * DDC_STAGE_ROW * 4)
 
 // Passes A and B.  grid = (ceil(nruns / 256), nchan).
@@ -139,7 +143,7 @@ template <bool PASS_B>
 __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
     const short *__restrict__ adc, long n, int L, int nruns,
     const ddc_chan *__restrict__ chans, const int *__restrict__ chan_list,
-    const u32 *__restrict__ nco,              // [8192] {cos | sin << 16}
+    const u32 *__restrict__ nco,              // the 16-bit table T[DDC_TAB] (kg_ddc_create), two entries per word
     ddc_state4 *__restrict__ local,           // A: out [nlist][2][nruns];  B: in = carried states
     u32 *__restrict__ c0rel,                  // B: relative I5 at strobes; entry li: I at c0off[li], Q right after
     u32 *__restrict__ tau,                    // B: [nlist][2][nruns]
@@ -147,9 +151,9 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
     const int *__restrict__ sel,              // list entries this launch covers (null: all, in order)
     int stage_bytes)                          // pass B, R <= 8: dynamic LDS for the strobe staging tiles, else 0
 {
-    __shared__ u32 tab[8192];
+    __shared__ short tab[DDC_TAB];
     extern __shared__ u32 stage_lds[];        // [waves][2][64][DDC_STAGE_ROW] when stage_bytes != 0
-    for (int i = threadIdx.x; i < 8192; i += DDC_THREADS) tab[i] = nco[i];
+    for (int i = threadIdx.x; i < DDC_TAB / 2; i += DDC_THREADS) ((u32 *) tab)[i] = nco[i];
     __syncthreads();
     const int li = sel ? sel[blockIdx.y] : (int) blockIdx.y;
     const ddc_chan ch = chans[chan_list[li]];
@@ -209,8 +213,8 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
             for (int k = 0; k < 4; k++) I[k] = Q[k] = 0;
         }
         auto step = [&](int a) {
-            const u32 e = tab[ph >> 51];
-            const long long mi = mix24(a, (short) (e & 0xffff)), mq = mix24(a, (short) (e >> 16));
+            const int ec = tab[(ph >> 51) + 2048], es = tab[ph >> 51];
+            const long long mi = mix24(a, ec), mq = mix24(a, es);
             ph += inc16;
             I[0] += (u64) mi; I[1] += I[0]; I[2] += I[1]; I[3] += I[2];
             Q[0] += (u64) mq; Q[1] += Q[0]; Q[2] += Q[1]; Q[3] += Q[2];
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
         // aligned staging rows; anything else takes the paths below.
         if (PASS_B && stage_bytes && log2r <= 3) {
             const int lane = threadIdx.x & 63, K = L >> log2r;
-            const bool ok = al && c == 0 && (s1 - s0) == L && (K & 15) == 0 && (o & 3) == 0 &&
+            const bool ok = al && c == 0 && (s1 - s0) == L && (K & (DDC_STAGE_STROBES - 1)) == 0 && (o & 3) == 0 &&
                             ((uintptr_t) c0i & 15) == 0 && ((uintptr_t) c0q & 15) == 0;
             if (__popcll(__ballot(ok)) == 64) {
                 u32 *tI = stage_lds + (threadIdx.x >> 6) * (2 * 64 * DDC_STAGE_ROW), *tQ = tI + 64 * DDC_STAGE_ROW;
@@ -246,9 +250,10 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
                 auto flush = [&]() {                                      // 16 strobes of 64 runs -> 2 x 4 stores of whole lines
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
+                    constexpr int LPR = DDC_STAGE_STROBES / 4, RPS = 64 / LPR;   // lanes per run, runs per store instruction
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const int rl = q * 16 + (lane >> 2), col = (lane & 3) * 4;
+                    for (int q = 0; q < 64 / RPS; q++) {
+                        const int rl = q * RPS + lane / LPR, col = (lane % LPR) * 4;
                         const u32 *ri = tI + rl * DDC_STAGE_ROW + col, *rq = tQ + rl * DDC_STAGE_ROW + col;
                         const uint4 vi = make_uint4(ri[0], ri[1], ri[2], ri[3]);
                         const uint4 vq = make_uint4(rq[0], rq[1], rq[2], rq[3]);
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
-                    kdone += 16;
+                    kdone += DDC_STAGE_STROBES;
                     kcol = 0;
                 };
                 // One copy of the loop per decimation: the strobe positions of a group are compile-time, so the group
@@ -270,15 +275,15 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
                 auto staged_loop = [&](auto lr_tag) {
                     constexpr int LR = decltype(lr_tag)::value;
                     for (; t + 8 <= g1; t += 8) {
-                        if (kcol == 16) flush();                          // wave-uniform
+                        if (kcol == DDC_STAGE_STROBES) flush();           // wave-uniform
                         short buf[8];
                         samples8(t, buf);
-                        u32 e[8];
+                        int ec[8], es[8];
 #pragma unroll
-                        for (int w = 0; w < 8; w++) { e[w] = tab[ph >> 51]; ph += inc16; }
+                        for (int w = 0; w < 8; w++) { ec[w] = tab[(ph >> 51) + 2048]; es[w] = tab[ph >> 51]; ph += inc16; }
 #pragma unroll
                         for (int w = 0; w < 8; w++) {
-                            const long long mi = mix24(buf[w], (short) (e[w] & 0xffff)), mq = mix24(buf[w], (short) (e[w] >> 16));
+                            const long long mi = mix24(buf[w], ec[w]), mq = mix24(buf[w], es[w]);
                             I[0] += (u64) mi; I[1] += I[0]; I[2] += I[1]; I[3] += I[2];
                             Q[0] += (u64) mq; Q[1] += Q[0]; Q[2] += Q[1]; Q[3] += Q[2];
                             i5i = (i5i + (u32) (I[3] >> sh5)) & 0x0FFFFFFFu;
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
                         }
                         kcol += 8 >> LR;
                     }
-                    if (kcol == 16) flush();
+                    if (kcol == DDC_STAGE_STROBES) flush();
                 };
                 if (log2r == 1) staged_loop(std::integral_constant<int, 1>());
                 else if (log2r == 2) staged_loop(std::integral_constant<int, 2>());
@@ -300,8 +305,8 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
         }
         if (PASS_B && log2r <= 2 && c == 0 && (o & 3) == 0 && ((uintptr_t) c0i & 15) == 0 && ((uintptr_t) c0q & 15) == 0) {
             auto quiet = [&](int a) {                     // step() without the strobe store
-                const u32 e = tab[ph >> 51];
-                const long long mi = mix24(a, (short) (e & 0xffff)), mq = mix24(a, (short) (e >> 16));
+                const int ec = tab[(ph >> 51) + 2048], es = tab[ph >> 51];
+                const long long mi = mix24(a, ec), mq = mix24(a, es);
                 ph += inc16;
                 I[0] += (u64) mi; I[1] += I[0]; I[2] += I[1]; I[3] += I[2];
                 Q[0] += (u64) mq; Q[1] += Q[0]; Q[2] += Q[1]; Q[3] += Q[2];
@@ -339,12 +344,12 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
             if (PASS_B && c + 8 <= (u32) Rm1) {
                 // no strobe inside this group (most groups once R >= 16): straight-line code, the eight table
                 // reads go out together (with the strobe test between them each was waited for where it was issued)
-                u32 e[8];
+                int ec[8], es[8];
 #pragma unroll
-                for (int w = 0; w < 8; w++) { e[w] = tab[ph >> 51]; ph += inc16; }
+                for (int w = 0; w < 8; w++) { ec[w] = tab[(ph >> 51) + 2048]; es[w] = tab[ph >> 51]; ph += inc16; }
 #pragma unroll
                 for (int w = 0; w < 8; w++) {
-                    const long long mi = mix24(buf[w], (short) (e[w] & 0xffff)), mq = mix24(buf[w], (short) (e[w] >> 16));
+                    const long long mi = mix24(buf[w], ec[w]), mq = mix24(buf[w], es[w]);
                     I[0] += (u64) mi; I[1] += I[0]; I[2] += I[1]; I[3] += I[2];
                     Q[0] += (u64) mq; Q[1] += Q[0]; Q[2] += Q[1]; Q[3] += Q[2];
                     i5i = (i5i + (u32) (I[3] >> sh5)) & 0x0FFFFFFFu;
@@ -398,8 +403,8 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
             }
         }
         auto step = [&](int a) {
-            const u32 e = tab[ph >> 51];
-            const long long mi = mix24(a, (short) (e & 0xffff)), mq = mix24(a, (short) (e >> 16));
+            const int ec = tab[(ph >> 51) + 2048], es = tab[ph >> 51];
+            const long long mi = mix24(a, ec), mq = mix24(a, es);
             ph += inc16;
             // in = sign-extended m << shift (shift = 65 - 5 log2 R is 0 .. 20 here), 96 bits
             const u64 li = (u64) mi << shift, lq = (u64) mq << shift;
@@ -419,12 +424,12 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
             short buf[8];
             samples8(t, buf);
             if (c + 8 <= (u32) Rm1) {                         // no strobe inside this group: see the narrow path
-                u32 e[8];
+                int ec[8], es[8];
 #pragma unroll
-                for (int w = 0; w < 8; w++) { e[w] = tab[ph >> 51]; ph += inc16; }
+                for (int w = 0; w < 8; w++) { ec[w] = tab[(ph >> 51) + 2048]; es[w] = tab[ph >> 51]; ph += inc16; }
 #pragma unroll
                 for (int w = 0; w < 8; w++) {
-                    const long long mi = mix24(buf[w], (short) (e[w] & 0xffff)), mq = mix24(buf[w], (short) (e[w] >> 16));
+                    const long long mi = mix24(buf[w], ec[w]), mq = mix24(buf[w], es[w]);
                     const u64 li = (u64) mi << shift, lq = (u64) mq << shift;
                     u96 xi, xq;
                     xi.w[0] = (u32) li; xi.w[1] = (u32) (li >> 32); xi.w[2] = (u32) (shift ? mi >> (64 - shift) : mi >> 63);
@@ -454,8 +459,8 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
         for (int k = 0; k < 4; k++) { SI.i[k] = mk128(0, 0); SQ.i[k] = mk128(0, 0); }
     }
     auto step = [&](int a) {
-        const u32 e = tab[ph >> 51];
-        const long long mi = mix24(a, (short) (e & 0xffff)), mq = mix24(a, (short) (e >> 16));
+        const int ec = tab[(ph >> 51) + 2048], es = tab[ph >> 51];
+        const long long mi = mix24(a, ec), mq = mix24(a, es);
         ph += inc16;
         // in = sign-extended m << shift, 128 bits
         const u128 xi = mk128((u64) mi << shift, (u64) (shift ? mi >> (64 - shift) : mi >> 63));
@@ -496,8 +501,8 @@ __global__ __launch_bounds__(256) void ddc_wf_bypass_kernel(
     const int *__restrict__ bypass_list,      // list entries with R == 1
     const u32 *__restrict__ nco, short2 *__restrict__ out, long out_stride)
 {
-    __shared__ u32 tab[8192];
-    for (int i = threadIdx.x; i < 8192; i += 256) tab[i] = nco[i];
+    __shared__ short tab[DDC_TAB];
+    for (int i = threadIdx.x; i < DDC_TAB / 2; i += 256) ((u32 *) tab)[i] = nco[i];
     __syncthreads();
     const int li = bypass_list[blockIdx.y];
     const ddc_chan ch = chans[chan_list[li]];
@@ -526,8 +531,8 @@ __global__ __launch_bounds__(256) void ddc_wf_bypass_kernel(
             short2 r[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const u32 e = tab[ph >> 51];
-                const int mi = mix24(a[q], (short) (e & 0xffff)), mq = mix24(a[q], (short) (e >> 16));
+                const int ec = tab[(ph >> 51) + 2048], es = tab[ph >> 51];
+                const int mi = mix24(a[q], ec), mq = mix24(a[q], es);
                 r[q] = make_short2((short) (mi >> 8), (short) (mq >> 8));
                 ph += inc16;
             }
@@ -903,7 +908,7 @@ int kg_ddc_create(kg_ctx *ctx, int nchan, size_t max_samples, kg_ddc **out)
     d->c0_cap = 0; d->d_c0rel = nullptr;
     KG_HIP(hipMalloc((void **) &d->d_chans, sizeof(ddc_chan) * nchan));
     KG_HIP(hipMemset(d->d_chans, 0, sizeof(ddc_chan) * nchan));
-    KG_HIP(hipMalloc((void **) &d->d_nco, sizeof(u32) * 8192));
+    KG_HIP(hipMalloc((void **) &d->d_nco, sizeof(short) * DDC_TAB));
     KG_HIP(hipFuncSetAttribute((const void *) ddc_wf_run_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                DDC_STAGE_BYTES));
     KG_HIP(hipMalloc((void **) &d->d_local, sizeof(ddc_state4) * 2 * (size_t) nchan * d->max_runs));
@@ -914,14 +919,18 @@ int kg_ddc_create(kg_ctx *ctx, int nchan, size_t max_samples, kg_ddc **out)
     KG_HIP(hipMalloc((void **) &d->d_ticket, sizeof(u32)));
     KG_HIP(hipMemset(d->d_ticket, 0, sizeof(u32)));
     d->ticket_base = 0; d->epoch = 0;
-    // NCO table (frozen by us; the Xilinx DDS IP is closed): round(16383 * cos/sin(2 pi a / 8192))
-    std::vector<u32> tab(8192);
-    for (int a = 0; a < 8192; a++) {
-        const double ph = 2.0 * M_PI * a / 8192.0;
-        const short c = (short) lrint(16383.0 * cos(ph)), s = (short) lrint(16383.0 * sin(ph));
-        tab[a] = (u32) (unsigned short) c | ((u32) (unsigned short) s << 16);
+    // NCO table (frozen by us; the Xilinx DDS IP is closed): round(16383 * cos/sin(2 pi a / 8192)), kept as ONE
+    // 16-bit table of 10240 entries T[j] = sin(2 pi j / 8192): sin(a) = T[a], cos(a) = T[a + 2048] -- two
+    // sign-extending 16-bit LDS reads from one address (no unpacking), 20 KiB per workgroup instead of 32.
+    // The entries past 8191 are the cosine's; where both definitions apply they must agree value for value.
+    std::vector<short> tab(DDC_TAB);
+    for (int j = 0; j < DDC_TAB; j++) {
+        const double ps = 2.0 * M_PI * j / 8192.0, pc = 2.0 * M_PI * (j - 2048) / 8192.0;
+        const short s = (short) lrint(16383.0 * sin(ps)), c = (short) lrint(16383.0 * cos(pc));
+        KG_REQUIRE(j < 2048 || j >= 8192 || s == c, KG_ERR_STATE, "kg_ddc_create: NCO table: sin(%d) != cos(%d)", j, j - 2048);
+        tab[j] = j < 8192 ? s : c;
     }
-    KG_HIP(hipMemcpy(d->d_nco, tab.data(), sizeof(u32) * 8192, hipMemcpyHostToDevice));
+    KG_HIP(hipMemcpy(d->d_nco, tab.data(), sizeof(short) * DDC_TAB, hipMemcpyHostToDevice));
     *out = d;
     return KG_OK;
 }
