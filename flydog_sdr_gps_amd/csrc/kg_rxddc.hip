@@ -37,6 +37,7 @@ typedef unsigned int u32;
 
 #define RX_HIST 256          // rx1 outputs kept from earlier calls (a final output spans 203 of them)
 #define RX_THREADS 256
+#define RX_TAB 10240
 
 // The three RX instances the reference builds (kiwi.config:101-105, fir_iq.sv:39-123); the widths
 // are what verilog/rx/cic_gen.c emits for those decimations (tests/golden/cic_ref.json):
@@ -103,8 +104,8 @@ __global__ __launch_bounds__(RX_THREADS) void rx1_run_kernel(
 {
     const u32 RX_R1 = (u32) md.r1;
     const int SH3 = md.sh3;
-    __shared__ u32 tab[8192];
-    for (int i = threadIdx.x; i < 8192; i += RX_THREADS) tab[i] = nco[i];
+    __shared__ short tab[RX_TAB];             // sin(a) = tab[a], cos(a) = tab[a + 2048] (kg_rxddc_create; kg_ddc.hip)
+    for (int i = threadIdx.x; i < RX_TAB / 2; i += RX_THREADS) ((u32 *) tab)[i] = nco[i];
     __syncthreads();
     const int li = blockIdx.y;
     const rx_chan ch = chans[chan_list[li]];
@@ -123,8 +124,8 @@ __global__ __launch_bounds__(RX_THREADS) void rx1_run_kernel(
     long o = (long) (c0 / RX_R1);             // strobes of this call before the run
     u32 *c0i = c0rel + ((long) li * 2 + 0) * max_out, *c0q = c0rel + ((long) li * 2 + 1) * max_out;
     auto step = [&](int a) {
-        const u32 e = tab[ph >> 51];
-        const long long mi = mix22(a, (short) (e & 0xffff)), mq = mix22(a, (short) (e >> 16));
+        const int ec = tab[(ph >> 51) + 2048], es = tab[ph >> 51];
+        const long long mi = mix22(a, ec), mq = mix22(a, es);
         ph += inc16;
         a1i += (u64) mi; a2i += a1i;
         a1q += (u64) mq; a2q += a1q;
@@ -423,20 +424,22 @@ int kg_rxddc_create_mode(kg_ctx *ctx, int nchan, size_t max_samples, int mode, k
     d->c1_stride = RX_HIST + d->max_out + RX_HIST;
     KG_HIP(hipMalloc((void **) &d->d_chans, sizeof(rx_chan) * nchan));
     KG_HIP(hipMemset(d->d_chans, 0, sizeof(rx_chan) * nchan));
-    KG_HIP(hipMalloc((void **) &d->d_nco, sizeof(u32) * 8192));
+    KG_HIP(hipMalloc((void **) &d->d_nco, sizeof(short) * RX_TAB));
     KG_HIP(hipMalloc((void **) &d->d_st, sizeof(u64) * 4 * (size_t) nchan * d->max_runs));
     KG_HIP(hipMalloc((void **) &d->d_tau, sizeof(u32) * 2 * (size_t) nchan * d->max_runs));
     KG_HIP(hipMalloc((void **) &d->d_c0rel, sizeof(u32) * 2 * (size_t) nchan * d->max_out));
     KG_HIP(hipMalloc((void **) &d->d_hist, sizeof(u32) * 6 * (size_t) nchan));
     KG_HIP(hipMalloc((void **) &d->d_c1buf, sizeof(int) * 2 * (size_t) nchan * d->c1_stride));
     KG_HIP(hipMemset(d->d_c1buf, 0, sizeof(int) * 2 * (size_t) nchan * d->c1_stride));
-    std::vector<u32> tab(8192);
-    for (int a = 0; a < 8192; a++) {
-        const double ph = 2.0 * M_PI * a / 8192.0;
-        const short c = (short) lrint(16383.0 * cos(ph)), s = (short) lrint(16383.0 * sin(ph));
-        tab[a] = (u32) (unsigned short) c | ((u32) (unsigned short) s << 16);
+    // the NCO table as one 16-bit sine table of 10240 entries (kg_ddc.hip, kg_ddc_create): cos(a) = T[a + 2048]
+    std::vector<short> tab(RX_TAB);
+    for (int j = 0; j < RX_TAB; j++) {
+        const double ps = 2.0 * M_PI * j / 8192.0, pc = 2.0 * M_PI * (j - 2048) / 8192.0;
+        const short s = (short) lrint(16383.0 * sin(ps)), c = (short) lrint(16383.0 * cos(pc));
+        KG_REQUIRE(j < 2048 || j >= 8192 || s == c, KG_ERR_STATE, "kg_rxddc_create: NCO table: sin(%d) != cos(%d)", j, j - 2048);
+        tab[j] = j < 8192 ? s : c;
     }
-    KG_HIP(hipMemcpy(d->d_nco, tab.data(), sizeof(u32) * 8192, hipMemcpyHostToDevice));
+    KG_HIP(hipMemcpy(d->d_nco, tab.data(), sizeof(short) * RX_TAB, hipMemcpyHostToDevice));
     *out = d;
     return KG_OK;
 }
