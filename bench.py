@@ -1146,6 +1146,7 @@ def run_cfg2_chain(args, dist):
         return res
     steps = max(2 * cyc, (args.steps + cyc - 1) // cyc * cyc)          # whole cycles
     elapsed, t_enq, spread = timed_steps(dist, step, steps, max(cyc, args.warmup // cyc * cyc))
+    log("cfg2_chain: host enqueue %.4f ms per step, wall %.4f ms per step" % (t_enq / steps * 1e3, elapsed / steps * 1e3))
     torch.cuda.synchronize(dev)
     ctx.timer_start()
     for _ in range(steps):

@@ -883,6 +883,7 @@ struct kg_ddc {
     int max_runs; long c0_cap;
     ddc_chunk_agg *d_aggs; u32 *d_ticket; u32 ticket_base, epoch;     // chunked state scan
     hipStream_t side; hipEvent_t ev_fork, ev_join;                   // pass B of the small decimations beside the rest
+    kg_stage_cache pack_cache;                 // the per-call tables of the last push (a steady stream repeats them: no upload)
 };
 
 static const int DDC_RUN_MIN = 64, DDC_RUN_MAX = 8192, DDC_TARGET_RUNS = 8192;
@@ -944,6 +945,7 @@ void kg_ddc_destroy(kg_ddc *d)
     (void) hipFree(d->d_local);
     (void) hipFree(d->d_tau); (void) hipFree(d->d_c0rel); (void) hipFree(d->d_hist);
     (void) hipFree(d->d_aggs); (void) hipFree(d->d_ticket);
+    kg_stage_cache_free(&d->pack_cache);
     if (d->side) { (void) hipStreamSynchronize(d->side); (void) hipEventDestroy(d->ev_fork); (void) hipEventDestroy(d->ev_join); (void) hipStreamDestroy(d->side); }
     
     delete d;
@@ -1095,7 +1097,7 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
         const size_t o_small = put(h_small.data(), sizeof(int) * h_small.size());
         const size_t o_rest = put(h_rest.data(), sizeof(int) * h_rest.size());
         void *base = nullptr;
-        if ((rc = kg_ctx_stage(d->ctx, pack.data(), pack.size(), &base))) return rc;
+        if ((rc = kg_ctx_stage_cached(d->ctx, &d->pack_cache, pack.data(), pack.size(), &base))) return rc;
         const unsigned char *b = (const unsigned char *) base;
         s_c0off = (const long *) (b + o_off); s_nouts = (const long *) (b + o_nouts);
         s_list = (const int *) (b + o_list); s_cnt = (const u32 *) (b + o_cnt); s_wgoff = (const int *) (b + o_wg);

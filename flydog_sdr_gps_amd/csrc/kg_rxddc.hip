@@ -390,6 +390,7 @@ struct kg_rxddc {
     u64 *d_st; u32 *d_c0rel, *d_tau, *d_hist;
     int *d_c1buf; long c1_stride;
     int max_runs; long max_out;
+    kg_stage_cache pack_cache;                 // the per-call tables of the last push (a steady stream repeats them: no upload)
 };
 
 extern "C" {
@@ -453,6 +454,7 @@ void kg_rxddc_destroy(kg_rxddc *d)
     
     (void) hipFree(d->d_st); (void) hipFree(d->d_tau); (void) hipFree(d->d_c0rel); (void) hipFree(d->d_hist);
     (void) hipFree(d->d_c1buf);
+    kg_stage_cache_free(&d->pack_cache);
     delete d;
 }
 
@@ -552,7 +554,7 @@ int kg_rxddc_push_dev(kg_rxddc *d, const void *d_adc, size_t n, const int32_t *c
         const size_t o_n1b = put(h_n1b.data(), sizeof(long) * nlist), o_qf = put(h_qfirst.data(), sizeof(long) * nlist);
         const size_t o_nf = put(h_nfinal.data(), sizeof(int) * nlist), o_cnt = put(h_cnt.data(), sizeof(u32) * nlist);
         void *base = nullptr;
-        if ((rc = kg_ctx_stage(d->ctx, pack.data(), pack.size(), &base))) return rc;
+        if ((rc = kg_ctx_stage_cached(d->ctx, &d->pack_cache, pack.data(), pack.size(), &base))) return rc;
         const unsigned char *b = (const unsigned char *) base;
         s_list = (const int *) (b + o_list); s_nouts = (const long *) (b + o_nouts); s_n1b = (const long *) (b + o_n1b);
         s_qfirst = (const long *) (b + o_qf); s_nfinal = (const int *) (b + o_nf); s_cnt = (const u32 *) (b + o_cnt);
