@@ -559,16 +559,73 @@ DDC_DEV u64 shfl64(u64 v, int src)
     const u32 lo = __shfl((u32) v, src), hi = __shfl((u32) (v >> 32), src);
     return ((u64) hi << 32) | lo;
 }
-DDC_DEV ddc_state4 shfl_state(const ddc_state4 &s, int src)
+// The scan's arithmetic.  Nothing above bit 88 of an integrator is ever read, so the scan keeps a state as 4 x 96
+// bits in 32-bit limbs (the stored form stays 128 bits wide, upper limb zero): a product with a coefficient is
+// 3 / 5 / 6 multiply-adds of 32 x 32 -> 64 bits (the run length and its binomials have 1-2 / 2 / 3 limbs) where
+// the 128 x 128-bit product took some forty-five instructions, and a state crosses lanes in 12 shuffles, not 32.
+struct u96 { u32 w[3]; };
+struct sc4 { u96 i[4]; };                     // integrators 1..4, mod 2^96
+struct sc_coef { u64 L, c2; u96 c3; };        // len, len (len+1) / 2, len (len+1) (len+2) / 6 mod 2^96 (len <= 2^32)
+DDC_DEV u96 u96_zero() { u96 r; r.w[0] = r.w[1] = r.w[2] = 0; return r; }
+DDC_DEV u96 u96_of(const u128 &v) { u96 r; r.w[0] = (u32) v.lo; r.w[1] = (u32) (v.lo >> 32); r.w[2] = (u32) v.hi; return r; }
+DDC_DEV u128 u128_of(const u96 &v) { return mk128((u64) v.w[0] | ((u64) v.w[1] << 32), (u64) v.w[2]); }
+DDC_DEV u96 add96(const u96 &a, const u96 &b)
 {
-    ddc_state4 r;
-    for (int k = 0; k < 4; k++) { r.i[k].lo = shfl64(s.i[k].lo, src); r.i[k].hi = shfl64(s.i[k].hi, src); }
+    u96 r; unsigned c0, c1;
+    r.w[0] = __builtin_addc(a.w[0], b.w[0], 0u, &c0);
+    r.w[1] = __builtin_addc(a.w[1], b.w[1], c0, &c1);
+    r.w[2] = a.w[2] + b.w[2] + c1;
     return r;
 }
-DDC_DEV ddc_state4 shfl_up_state(const ddc_state4 &s, int d)
+DDC_DEV u96 mul96_64(const u96 &a, u64 b)      // a * b mod 2^96
 {
-    ddc_state4 r;
-    for (int k = 0; k < 4; k++) { r.i[k].lo = shfl_up64(s.i[k].lo, d); r.i[k].hi = shfl_up64(s.i[k].hi, d); }
+    const u32 b0 = (u32) b, b1 = (u32) (b >> 32);
+    const u64 p0 = (u64) a.w[0] * b0;
+    const u64 p1 = (u64) a.w[1] * b0 + (p0 >> 32);
+    const u64 q0 = (u64) a.w[0] * b1 + (u32) p1;
+    u96 r;
+    r.w[0] = (u32) p0;
+    r.w[1] = (u32) q0;
+    r.w[2] = a.w[2] * b0 + a.w[1] * b1 + (u32) (p1 >> 32) + (u32) (q0 >> 32);
+    return r;
+}
+DDC_DEV u96 mul96_96(const u96 &a, const u96 &b)
+{
+    u96 r = mul96_64(a, (u64) b.w[0] | ((u64) b.w[1] << 32));
+    r.w[2] += a.w[0] * b.w[2];
+    return r;
+}
+DDC_DEV sc_coef sc_coef_for(u64 len)
+{
+    sc_coef c;
+    c.L = len; c.c2 = binom2(len).lo; c.c3 = u96_of(binom3(len));
+    return c;
+}
+DDC_DEV sc4 sc_zero() { sc4 r; for (int k = 0; k < 4; k++) r.i[k] = u96_zero(); return r; }
+DDC_DEV sc4 sc_of(const ddc_state4 &s) { sc4 r; for (int k = 0; k < 4; k++) r.i[k] = u96_of(s.i[k]); return r; }
+DDC_DEV ddc_state4 state_of(const sc4 &s) { ddc_state4 r; for (int k = 0; k < 4; k++) r.i[k] = u128_of(s.i[k]); return r; }
+// advance a state over len zero-input samples: the binomial matrix of the four cascaded integrators
+DDC_DEV sc4 sc_Tc(const sc_coef &k, const sc4 &s)
+{
+    sc4 r;
+    r.i[0] = s.i[0];
+    r.i[1] = add96(s.i[1], mul96_64(s.i[0], k.L));
+    r.i[2] = add96(add96(s.i[2], mul96_64(s.i[1], k.L)), mul96_64(s.i[0], k.c2));
+    r.i[3] = add96(add96(add96(s.i[3], mul96_64(s.i[2], k.L)), mul96_64(s.i[1], k.c2)), mul96_96(s.i[0], k.c3));
+    return r;
+}
+DDC_DEV sc4 sc_T(u64 len, const sc4 &s) { return sc_Tc(sc_coef_for(len), s); }
+DDC_DEV sc4 sc_add(const sc4 &a, const sc4 &b) { sc4 r; for (int k = 0; k < 4; k++) r.i[k] = add96(a.i[k], b.i[k]); return r; }
+DDC_DEV sc4 sc_shfl(const sc4 &s, int src)
+{
+    sc4 r;
+    for (int k = 0; k < 4; k++) for (int w = 0; w < 3; w++) r.i[k].w[w] = __shfl(s.i[k].w[w], src);
+    return r;
+}
+DDC_DEV sc4 sc_shfl_up(const sc4 &s, int d)
+{
+    sc4 r;
+    for (int k = 0; k < 4; k++) for (int w = 0; w < 3; w++) r.i[k].w[w] = __shfl_up(s.i[k].w[w], d);
     return r;
 }
 
@@ -576,14 +633,14 @@ DDC_DEV ddc_state4 shfl_up_state(const ddc_state4 &s, int d)
 #define DDC_SCAN_MAX_CHUNKS 16
 // Ordered fold of the affine maps held by lanes 0 .. 2^LOG - 1 (lane order = time order; a lane with
 // len = 0 and e = 0 is the identity): log steps of the inclusive scan instead of a serial chain of
-// 128-bit multiply-adds.  -> the fold of lanes 0 .. lane (every lane of the group must call it)
-template <int LOG> DDC_DEV void ddc_fold_lanes(ddc_state4 &e, u64 &len, int lane)
+// wide multiply-adds.  -> the fold of lanes 0 .. lane (every lane of the group must call it)
+template <int LOG> DDC_DEV void ddc_fold_lanes(sc4 &e, u64 &len, int lane)
 {
 #pragma unroll
     for (int d = 1; d < (1 << LOG); d <<= 1) {
-        const ddc_state4 a = shfl_up_state(e, d);
+        const sc4 a = sc_shfl_up(e, d);
         const u64 alen = shfl_up64(len, d);
-        if (lane >= d) { e = ddc_add(ddc_T(len, a), e); len += alen; }
+        if (lane >= d) { e = sc_add(sc_T(len, a), e); len += alen; }
     }
 }
 // What a chunk of runs does to the integrator state: state_out = T(len) state_in + e.  Published by the
@@ -603,9 +660,9 @@ __global__ __launch_bounds__(64 * DDC_SCAN_WAVES) void ddc_wf_scan_states_kernel
     const int *__restrict__ chan_list, int npairs, int nchunk, ddc_chunk_agg *__restrict__ aggs,
     u32 *__restrict__ ticket, u32 ticket_base, u32 epoch)
 {
-    __shared__ ddc_state4 w_state[DDC_SCAN_WAVES];
+    __shared__ sc4 w_state[DDC_SCAN_WAVES];
     __shared__ u64 w_len[DDC_SCAN_WAVES];
-    __shared__ ddc_state4 s_start;
+    __shared__ sc4 s_start;
     __shared__ u32 s_id;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = threadIdx.x;
     if (gl == 0) s_id = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ticket_base;
@@ -623,77 +680,75 @@ __global__ __launch_bounds__(64 * DDC_SCAN_WAVES) void ddc_wf_scan_states_kernel
     auto run_len = [&](int r) -> u64 { const long s0 = (long) r * L; return (u64) ((s0 + L < n ? s0 + L : n) - s0); };
     // the saved state is read before anything is published: the last chunk rewrites it at the end, after
     // it has seen every other chunk's aggregate
-    ddc_state4 saved;
-    for (int k = 0; k < 4; k++) saved.i[k] = mk128(0, 0);
-    if (gl == 0) saved = ch->integ[comp];
+    sc4 saved = sc_zero();
+    if (gl == 0) saved = sc_of(ch->integ[comp]);
     // 1. lane-local composition
-    ddc_state4 acc; u64 len = 0;
-    for (int k = 0; k < 4; k++) acc.i[k] = mk128(0, 0);
-    const ddc_coef kL = ddc_coef_for((u64) L);    // every run but possibly the last has length L
+    sc4 acc = sc_zero(); u64 len = 0;
+    const sc_coef kL = sc_coef_for((u64) L);      // every run but possibly the last has length L
     for (int r = r0; r < r1; r++) {
         const u64 l = run_len(r);
-        acc = ddc_add(l == (u64) L ? ddc_Tc(kL, acc) : ddc_T(l, acc), st[r]);
+        acc = sc_add(l == (u64) L ? sc_Tc(kL, acc) : sc_T(l, acc), sc_of(st[r]));
         len += l;
     }
     // 2. inclusive wave scan: earlier lanes first
-    ddc_state4 inc = acc; u64 ilen = len;
+    sc4 inc = acc; u64 ilen = len;
     for (int d = 1; d < 64; d <<= 1) {
-        const ddc_state4 a = shfl_up_state(inc, d);
+        const sc4 a = sc_shfl_up(inc, d);
         const u64 alen = shfl_up64(ilen, d);
-        if (lane >= d) { inc = ddc_add(ddc_T(ilen, a), inc); ilen += alen; }
+        if (lane >= d) { inc = sc_add(sc_T(ilen, a), inc); ilen += alen; }
     }
     if (lane == 63) { w_state[wave] = inc; w_len[wave] = ilen; }
     __syncthreads();
     // 3. the chunk's aggregate out, the aggregates of the earlier chunks in: wave 0, one lane per wave
     // total / per earlier chunk, folded in log steps
     if (wave == 0) {
-        ddc_state4 e; u64 l = 0;
-        for (int k = 0; k < 4; k++) e.i[k] = mk128(0, 0);
+        sc4 e = sc_zero(); u64 l = 0;
         if (lane < DDC_SCAN_WAVES) { e = w_state[lane]; l = w_len[lane]; }
         ddc_fold_lanes<3>(e, l, lane);
         if (lane == DDC_SCAN_WAVES - 1 && g + 1 < nchunk) {
-            agg[g].e = e; agg[g].len = l;
+            agg[g].e = state_of(e); agg[g].len = l;
             __hip_atomic_store(&agg[g].epoch, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
-        for (int k = 0; k < 4; k++) e.i[k] = mk128(0, 0);
+        e = sc_zero();
         l = 0;
         if (lane < g) {
             while (__hip_atomic_load(&agg[lane].epoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch)
                 __builtin_amdgcn_s_sleep(2);
+            ddc_state4 ge;
             for (int k = 0; k < 4; k++) {          // past the acquire: loads that do not come from a stale line
-                e.i[k].lo = __hip_atomic_load(&agg[lane].e.i[k].lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                e.i[k].hi = __hip_atomic_load(&agg[lane].e.i[k].hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ge.i[k].lo = __hip_atomic_load(&agg[lane].e.i[k].lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ge.i[k].hi = __hip_atomic_load(&agg[lane].e.i[k].hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            e = sc_of(ge);
             l = __hip_atomic_load(&agg[lane].len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         ddc_fold_lanes<4>(e, l, lane);             // DDC_SCAN_MAX_CHUNKS = 16 lanes
-        const ddc_state4 sv = shfl_state(saved, 0);
-        if (lane == DDC_SCAN_MAX_CHUNKS - 1) s_start = ddc_add(ddc_T(l, sv), e);
+        const sc4 sv = sc_shfl(saved, 0);
+        if (lane == DDC_SCAN_MAX_CHUNKS - 1) s_start = sc_add(sc_T(l, sv), e);
     }
     __syncthreads();
     // state at the start of this wave's first run: the chunk's start advanced through the earlier waves
-    ddc_state4 ws;
+    sc4 ws;
     {
-        ddc_state4 e; u64 l = 0;
-        for (int k = 0; k < 4; k++) e.i[k] = mk128(0, 0);
+        sc4 e = sc_zero(); u64 l = 0;
         if (lane < wave) { e = w_state[lane]; l = w_len[lane]; }
         ddc_fold_lanes<3>(e, l, lane);
-        e = shfl_state(e, DDC_SCAN_WAVES - 1); l = shfl64(l, DDC_SCAN_WAVES - 1);
-        ws = ddc_add(ddc_T(l, s_start), e);
+        e = sc_shfl(e, DDC_SCAN_WAVES - 1); l = shfl64(l, DDC_SCAN_WAVES - 1);
+        ws = sc_add(sc_T(l, s_start), e);
     }
     // exclusive prefix of this lane inside its wave = inclusive of lane - 1
-    ddc_state4 exc = shfl_up_state(inc, 1); u64 elen = shfl_up64(ilen, 1);
-    if (lane == 0) { for (int k = 0; k < 4; k++) exc.i[k] = mk128(0, 0); elen = 0; }
-    ddc_state4 c = ddc_add(ddc_T(elen, ws), exc);
+    sc4 exc = sc_shfl_up(inc, 1); u64 elen = shfl_up64(ilen, 1);
+    if (lane == 0) { exc = sc_zero(); elen = 0; }
+    sc4 c = sc_add(sc_T(elen, ws), exc);
     // 4. per-run carried states
     for (int r = r0; r < r1; r++) {
-        const ddc_state4 e = st[r];
-        st[r] = c;
+        const sc4 e = sc_of(st[r]);
+        st[r] = state_of(c);
         const u64 l = run_len(r);
-        c = ddc_add(l == (u64) L ? ddc_Tc(kL, c) : ddc_T(l, c), e);
+        c = sc_add(l == (u64) L ? sc_Tc(kL, c) : sc_T(l, c), e);
     }
     // the lane that owns the last run holds the end state
-    if (r1 == nruns && r0 < nruns) ch->integ[comp] = c;
+    if (r1 == nruns && r0 < nruns) ch->integ[comp] = state_of(c);
 }
 
 // Prefix sum of the runs' integrator-5 totals: one workgroup of eight waves per (channel, I/Q).
