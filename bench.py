@@ -409,7 +409,7 @@ def event_spread(launch, reps):
     return round(dts[0], 5), round(dts[len(dts) // 2], 5)
 
 
-PREROLL_S = 0.12
+PREROLL_S = float(os.environ.get("KIWIGPU_BENCH_PREROLL_S", "0.5"))    # 0.12 s left the first timed region of a workload 5-30 % slow on some boxes
 
 
 def preroll(step, warmup):
@@ -1147,6 +1147,27 @@ def run_cfg2_chain(args, dist):
     steps = max(2 * cyc, (args.steps + cyc - 1) // cyc * cyc)          # whole cycles
     elapsed, t_enq, spread = timed_steps(dist, step, steps, max(cyc, args.warmup // cyc * cyc))
     log("cfg2_chain: host enqueue %.4f ms per step, wall %.4f ms per step" % (t_enq / steps * 1e3, elapsed / steps * 1e3))
+    if os.environ.get("KIWIGPU_BENCH_HOST_SPLIT") == "1":           # where the host spends a step (a diagnostic, not in the line)
+        for rep in range(3):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            t1 = time.perf_counter()
+            torch.cuda.synchronize(dev)
+            t2 = time.perf_counter()
+            log("cfg2_chain repeat %d: host loop %.1f us, wall %.1f us per step" % (rep, (t1 - t0) / steps * 1e6, (t2 - t0) / steps * 1e6))
+        torch.cuda.synchronize(dev)
+        ta = tb = 0.0
+        t0 = time.perf_counter()
+        for i in range(steps):
+            a = time.perf_counter(); ddc_part(i % cyc); b = time.perf_counter(); frames_part(i % cyc); c = time.perf_counter()
+            ta += b - a; tb += c - b
+        t1 = time.perf_counter()
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        log("cfg2_chain host split: push_dev %.1f us, frames_dev %.1f us per step; loop %.1f us, with the drain %.1f us per step"
+            % (ta / steps * 1e6, tb / steps * 1e6, (t1 - t0) / steps * 1e6, (t2 - t0) / steps * 1e6))
     torch.cuda.synchronize(dev)
     ctx.timer_start()
     for _ in range(steps):
