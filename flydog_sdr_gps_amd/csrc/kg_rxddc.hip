@@ -166,6 +166,7 @@ RX_DEV u64 rx_shfl_up64(u64 v, int d)
 
 // carry scan of (i1, i2) per (channel, comp): one wave each
 #define RX_SCAN_WAVES 8
+#define RX_SCAN_PER 16                        // runs per lane held in registers (8192 runs per channel)
 // Carry scan of the two exact integrators over the runs: one workgroup of eight waves per (channel, I/Q)
 // (one wave took 171 us for 128 receivers x 16 384 runs: 256 sequential, uncoalesced steps per lane, twice).
 __global__ __launch_bounds__(64 * RX_SCAN_WAVES) void rx1_scan_kernel(u64 *__restrict__ st, long n, int L, int nruns,
@@ -178,8 +179,29 @@ __global__ __launch_bounds__(64 * RX_SCAN_WAVES) void rx1_scan_kernel(u64 *__res
     const int per = (nruns + 64 * RX_SCAN_WAVES - 1) / (64 * RX_SCAN_WAVES);
     const int r0 = gl * per < nruns ? gl * per : nruns, r1 = (r0 + per < nruns) ? r0 + per : nruns;
     auto run_len = [&](int r) -> u64 { const long s0 = (long) r * L; return (u64) ((s0 + L < n ? s0 + L : n) - s0); };
+    // A lane's runs are consecutive (their order is the composition's), so its loads are its own lines: with up to
+    // RX_SCAN_PER runs per lane they all go out at once into registers and both walks read those (the loop that
+    // loaded a run, waited, composed, and loaded the same runs again for the second walk took 168 us of 16 + 16
+    // dependent round trips for 128 receivers beside the waterfall's pass A).
+    const bool regs = per <= RX_SCAN_PER;
+    u64 f1[RX_SCAN_PER], f2[RX_SCAN_PER];
+    if (regs) {
+#pragma unroll
+        for (int k = 0; k < RX_SCAN_PER; k++) {
+            const int r = r0 + k;
+            f1[k] = r < r1 ? e1[r] : 0ull;
+            f2[k] = r < r1 ? e2[r] : 0ull;
+        }
+    }
     u64 a1 = 0, a2 = 0, len = 0;
-    for (int r = r0; r < r1; r++) { const u64 l = run_len(r); a2 = a2 + l * a1 + e2[r]; a1 = a1 + e1[r]; len += l; }
+    if (regs) {
+#pragma unroll
+        for (int k = 0; k < RX_SCAN_PER; k++) {
+            if (r0 + k < r1) { const u64 l = run_len(r0 + k); a2 = a2 + l * a1 + f2[k]; a1 = a1 + f1[k]; len += l; }
+        }
+    } else {
+        for (int r = r0; r < r1; r++) { const u64 l = run_len(r); a2 = a2 + l * a1 + e2[r]; a1 = a1 + e1[r]; len += l; }
+    }
     u64 i1 = a1, i2 = a2, ilen = len;
     for (int d = 1; d < 64; d <<= 1) {
         const u64 p1 = rx_shfl_up64(i1, d), p2 = rx_shfl_up64(i2, d), pl = rx_shfl_up64(ilen, d);
@@ -194,10 +216,22 @@ __global__ __launch_bounds__(64 * RX_SCAN_WAVES) void rx1_scan_kernel(u64 *__res
     __syncthreads();                              // every wave has read the saved state
     for (int w = 0; w < wave; w++) { s2 = s2 + wl[w] * s1 + w2[w]; s1 = s1 + w1[w]; }
     u64 c1 = s1 + x1, c2 = s2 + xl * s1 + x2;
-    for (int r = r0; r < r1; r++) {
-        const u64 l = run_len(r), f1 = e1[r], f2 = e2[r];
-        e1[r] = c1; e2[r] = c2;
-        c2 = c2 + l * c1 + f2; c1 = c1 + f1;
+    if (regs) {
+#pragma unroll
+        for (int k = 0; k < RX_SCAN_PER; k++) {
+            const int r = r0 + k;
+            if (r < r1) {
+                const u64 l = run_len(r);
+                e1[r] = c1; e2[r] = c2;
+                c2 = c2 + l * c1 + f2[k]; c1 = c1 + f1[k];
+            }
+        }
+    } else {
+        for (int r = r0; r < r1; r++) {
+            const u64 l = run_len(r), g1 = e1[r], g2 = e2[r];
+            e1[r] = c1; e2[r] = c2;
+            c2 = c2 + l * c1 + g2; c1 = c1 + g1;
+        }
     }
     if (r1 == nruns && r0 < nruns) { ch->i1[comp] = c1; ch->i2[comp] = c2; }
 }
