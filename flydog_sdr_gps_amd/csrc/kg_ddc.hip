@@ -615,6 +615,17 @@ DDC_DEV sc4 sc_Tc(const sc_coef &k, const sc4 &s)
     return r;
 }
 DDC_DEV sc4 sc_T(u64 len, const sc4 &s) { return sc_Tc(sc_coef_for(len), s); }
+// The lengths the scan's log steps advance a state by are the same in every lane but a few: u << k (u = the samples
+// of a full lane's runs: steps of the wave scan, then of the fold over the wave totals) and v << m (v = a full
+// chunk).  Their coefficients come from the host in the kernel arguments (scalar registers); a lane whose length
+// is another one (the ragged end of the last chunk) computes its own -- the binomials are 40 % of an advance.
+#define DDC_SCAN_TAB 13
+struct sc_tab { u64 len[DDC_SCAN_TAB]; sc_coef c[DDC_SCAN_TAB]; };
+DDC_DEV sc4 sc_T_tab(const sc_tab &t, int j, u64 len, const sc4 &s)
+{
+    if (len == t.len[j]) return sc_Tc(t.c[j], s);
+    return sc_T(len, s);
+}
 DDC_DEV sc4 sc_add(const sc4 &a, const sc4 &b) { sc4 r; for (int k = 0; k < 4; k++) r.i[k] = add96(a.i[k], b.i[k]); return r; }
 DDC_DEV sc4 sc_shfl(const sc4 &s, int src)
 {
@@ -634,13 +645,13 @@ DDC_DEV sc4 sc_shfl_up(const sc4 &s, int d)
 // Ordered fold of the affine maps held by lanes 0 .. 2^LOG - 1 (lane order = time order; a lane with
 // len = 0 and e = 0 is the identity): log steps of the inclusive scan instead of a serial chain of
 // wide multiply-adds.  -> the fold of lanes 0 .. lane (every lane of the group must call it)
-template <int LOG> DDC_DEV void ddc_fold_lanes(sc4 &e, u64 &len, int lane)
+template <int LOG> DDC_DEV void ddc_fold_lanes(sc4 &e, u64 &len, int lane, const sc_tab &t, int j0)
 {
 #pragma unroll
-    for (int d = 1; d < (1 << LOG); d <<= 1) {
+    for (int d = 1, j = j0; d < (1 << LOG); d <<= 1, j++) {
         const sc4 a = sc_shfl_up(e, d);
         const u64 alen = shfl_up64(len, d);
-        if (lane >= d) { e = sc_add(sc_T(len, a), e); len += alen; }
+        if (lane >= d) { e = sc_add(sc_T_tab(t, j, len, a), e); len += alen; }
     }
 }
 // What a chunk of runs does to the integrator state: state_out = T(len) state_in + e.  Published by the
@@ -658,7 +669,7 @@ struct ddc_chunk_agg { ddc_state4 e; u64 len; u32 epoch; u32 pad; };
 __global__ __launch_bounds__(64 * DDC_SCAN_WAVES) void ddc_wf_scan_states_kernel(
     ddc_state4 *__restrict__ local, long n, int L, int nruns, ddc_chan *__restrict__ chans,
     const int *__restrict__ chan_list, int npairs, int nchunk, ddc_chunk_agg *__restrict__ aggs,
-    u32 *__restrict__ ticket, u32 ticket_base, u32 epoch)
+    u32 *__restrict__ ticket, u32 ticket_base, u32 epoch, const sc_tab tab)
 {
     __shared__ sc4 w_state[DDC_SCAN_WAVES];
     __shared__ u64 w_len[DDC_SCAN_WAVES];
@@ -692,25 +703,29 @@ __global__ __launch_bounds__(64 * DDC_SCAN_WAVES) void ddc_wf_scan_states_kernel
     }
     // 2. inclusive wave scan: earlier lanes first
     sc4 inc = acc; u64 ilen = len;
-    for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+    for (int d = 1, j = 0; d < 64; d <<= 1, j++) {
         const sc4 a = sc_shfl_up(inc, d);
         const u64 alen = shfl_up64(ilen, d);
-        if (lane >= d) { inc = sc_add(sc_T(ilen, a), inc); ilen += alen; }
+        if (lane >= d) { inc = sc_add(sc_T_tab(tab, j, ilen, a), inc); ilen += alen; }
     }
     if (lane == 63) { w_state[wave] = inc; w_len[wave] = ilen; }
     __syncthreads();
-    // 3. the chunk's aggregate out, the aggregates of the earlier chunks in: wave 0, one lane per wave
-    // total / per earlier chunk, folded in log steps
+    // 3. wave 0: the inclusive prefixes of the eight wave totals (back into w_state / w_len: wave w starts behind
+    // prefix w - 1), the chunk's aggregate out, the aggregates of the earlier chunks in, folded in log steps
     if (wave == 0) {
         sc4 e = sc_zero(); u64 l = 0;
         if (lane < DDC_SCAN_WAVES) { e = w_state[lane]; l = w_len[lane]; }
-        ddc_fold_lanes<3>(e, l, lane);
+        ddc_fold_lanes<3>(e, l, lane, tab, 6);
+        if (lane < DDC_SCAN_WAVES) { w_state[lane] = e; w_len[lane] = l; }
         if (lane == DDC_SCAN_WAVES - 1 && g + 1 < nchunk) {
             agg[g].e = state_of(e); agg[g].len = l;
             __hip_atomic_store(&agg[g].epoch, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
+        // lanes past the earlier chunks carry a zero aggregate of a full chunk's length: nobody reads their fold, and
+        // with it every lane advances by the table's lengths
         e = sc_zero();
-        l = 0;
+        l = tab.len[9];
         if (lane < g) {
             while (__hip_atomic_load(&agg[lane].epoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch)
                 __builtin_amdgcn_s_sleep(2);
@@ -722,18 +737,19 @@ __global__ __launch_bounds__(64 * DDC_SCAN_WAVES) void ddc_wf_scan_states_kernel
             e = sc_of(ge);
             l = __hip_atomic_load(&agg[lane].len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        ddc_fold_lanes<4>(e, l, lane);             // DDC_SCAN_MAX_CHUNKS = 16 lanes
+        ddc_fold_lanes<4>(e, l, lane, tab, 9);     // DDC_SCAN_MAX_CHUNKS = 16 lanes; lane g - 1: chunks 0 .. g - 1
+        const int src = g > 0 ? g - 1 : 0;
+        e = sc_shfl(e, src); l = shfl64(l, src);
+        if (g == 0) { e = sc_zero(); l = 0; }
         const sc4 sv = sc_shfl(saved, 0);
-        if (lane == DDC_SCAN_MAX_CHUNKS - 1) s_start = sc_add(sc_T(l, sv), e);
+        if (lane == 0) s_start = sc_add(sc_T(l, sv), e);
     }
     __syncthreads();
     // state at the start of this wave's first run: the chunk's start advanced through the earlier waves
     sc4 ws;
     {
         sc4 e = sc_zero(); u64 l = 0;
-        if (lane < wave) { e = w_state[lane]; l = w_len[lane]; }
-        ddc_fold_lanes<3>(e, l, lane);
-        e = sc_shfl(e, DDC_SCAN_WAVES - 1); l = shfl64(l, DDC_SCAN_WAVES - 1);
+        if (wave > 0) { e = w_state[wave - 1]; l = w_len[wave - 1]; }
         ws = sc_add(sc_T(l, s_start), e);
     }
     // exclusive prefix of this lane inside its wave = inclusive of lane - 1
@@ -1202,9 +1218,27 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
         if (nchunk > DDC_SCAN_MAX_CHUNKS) nchunk = DDC_SCAN_MAX_CHUNKS;
         while (nchunk > 1 && nruns / nchunk < 64 * DDC_SCAN_WAVES) nchunk--;
         if (nchunk < 1) nchunk = 1;
+        // the advance coefficients of the scan's regular steps (sc_tab): a full lane's samples u << 0 .. 8, a full
+        // chunk's v << 0 .. 3
+        sc_tab tab;
+        {
+            const long cper = (nruns + nchunk - 1) / nchunk, per = (cper + 64 * DDC_SCAN_WAVES - 1) / (64 * DDC_SCAN_WAVES);
+            const u64 u = (u64) per * (u64) L, v = (u64) cper * (u64) L;
+            for (int j = 0; j < DDC_SCAN_TAB; j++) {
+                const u64 len = j < 9 ? u << j : v << (j - 9);
+                const unsigned __int128 l = len;
+                const unsigned __int128 c2 = l * (l + 1) / 2;                     // len <= 2^36: below 2^73
+                // len (len + 1) (len + 2) / 6 mod 2^96: c2 (len + 2) is 3 x the binomial; divide the exact product
+                // (below 2^111) by 3
+                const unsigned __int128 c3 = c2 * (l + 2) / 3;
+                tab.len[j] = len;
+                tab.c[j].L = len; tab.c[j].c2 = (u64) c2;
+                tab.c[j].c3.w[0] = (u32) c3; tab.c[j].c3.w[1] = (u32) (c3 >> 32); tab.c[j].c3.w[2] = (u32) (c3 >> 64);
+            }
+        }
         hipLaunchKernelGGL(ddc_wf_scan_states_kernel, dim3((unsigned) (npairs * nchunk)), dim3(64 * DDC_SCAN_WAVES), 0, st,
                            d->d_local, (long) n, L, nruns, d->d_chans, s_list, npairs, nchunk, d->d_aggs, d->d_ticket,
-                           d->ticket_base, d->epoch + 1);
+                           d->ticket_base, d->epoch + 1, tab);
         KG_HIP(hipGetLastError());
         // only a launch that was accepted advances the ticket counter and publishes under the new epoch
         d->epoch++;
