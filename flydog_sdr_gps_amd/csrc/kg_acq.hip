@@ -391,7 +391,8 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
         const bool more = nxt_idx < ncell;
         const acq_cell_desc nxt = describe(more ? nxt_idx : cur_idx);
         int claimed = 0;
-        if (t == 0) claimed = 2 * nslots + __hip_atomic_fetch_add(&claim[xcd], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (the counter's value only, and the atomic optimizer off: see wf_frame_kernel -- otherwise wave 0 waits for it here)
+        if (t == 0) claimed = __hip_atomic_fetch_add(&claim[xcd], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         cf acc[NQ][16];
         // The twiddle-accumulate of item k2 is DEFERRED into item k2+1's exchanges, where a wave otherwise
         // only waits (slots: behind the stores before a barrier, or after it while the tile reads are in
@@ -649,7 +650,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
             // red[] was last read before this cell's barriers
             if ((t & 63) == 0) { red[t >> 6].p = wmax; red[t >> 6].i = wn; red[t >> 6].s = wsum; }
         }
-        if (t == 0) *red_claim = claimed;
+        if (t == 0) *red_claim = 2 * nslots + claimed;
         __syncthreads();
         // (rewritten only after eight more barriers; readfirstlane: the index must stay wave-uniform, or
         // every buffer load below turns into a waterfall loop over its descriptor)
@@ -843,7 +844,7 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
         const acq_cell_desc nxt = describe(more ? nxt_idx : cur_idx);
         int claimed = 0;
         // (lane 0 of wave 7 claims: wave 0 already carries the result merge and store of every cell)
-        if (i == 448) claimed = 2 * nslots + __hip_atomic_fetch_add(&claim[xcd], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (i == 448) claimed = __hip_atomic_fetch_add(&claim[xcd], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         cf acc[4][8];
 #pragma unroll 1
         for (int k2 = 0; k2 < P; k2++) {
@@ -1023,7 +1024,7 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
             if ((i & 63) == 0) { red[i >> 6].p = wmax; red[i >> 6].i = wn; red[i >> 6].s = wsum; }
         }
         KG_STAMP(STAMPS, stc, 2);
-        if (i == 448) *red_claim = claimed;
+        if (i == 448) *red_claim = 2 * nslots + claimed;
         __syncthreads();
         KG_STAMP(STAMPS, stc, 3);
         const int nn_idx = __builtin_amdgcn_readfirstlane(*red_claim);

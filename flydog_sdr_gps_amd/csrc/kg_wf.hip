@@ -129,8 +129,12 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
         const bool more = fn < nframes;
         const int cid_next = fr_next.x;
         const int wfn_next = chans[cid_next].window_func;
+        // (the counter's value only: anything computed from it here would be waited for here.  Built with the
+        // atomic optimizer off -- Makefile: its wave-aggregated form reads the result back with v_readfirstlane
+        // right behind the atomic, an s_waitcnt vmcnt(0) at the top of the frame that made wave 0 reach the first
+        // exchange barrier a memory round trip late, with the other three waiting there.)
         int claimed = 0;
-        if (t == 0) claimed = 2 * gridDim.x + __hip_atomic_fetch_add(&claim[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == 0) claimed = __hip_atomic_fetch_add(&claim[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
         cf x[16], y0[16], y1[16];
         windowed(x, 0);
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
             pwr[k] = p;
             if (TAPS && k < ch->fft_used) tap_pwr[(size_t) f * SUB + k] = p;
         }
-        if (t == 0) *lds_claim = claimed;
+        if (t == 0) *lds_claim = 2 * gridDim.x + claimed;
         __syncthreads();
         const int fnn = __builtin_amdgcn_readfirstlane(*lds_claim);    // wave-uniform; rewritten after >= 6 barriers
         cid = cid_next;
