@@ -845,7 +845,7 @@ __global__ __launch_bounds__(256) void ddc_wf_comb_kernel(
     const int *__restrict__ wg_start, int nlist,
     short2 *__restrict__ out, long out_stride, u32 *__restrict__ hist_out)   // [nlist][2][5]
 {
-    __shared__ int s_c0[2][DDC_COMB_TILE + 8];       // [d]: output o0 - 8 + d (three unused slots keep 16-byte rows)
+    __shared__ __attribute__((aligned(16))) int s_c0[2][DDC_COMB_TILE + 8];       // [d]: output o0 - 8 + d (three unused slots keep 16-byte rows)
     int lo = 0, hi = nlist;                   // wg_start[lo] <= blockIdx.x < wg_start[hi]
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int) blockIdx.x >= wg_start[mid]) lo = mid; else hi = mid; }
     const int li = lo, t = threadIdx.x;
@@ -871,14 +871,17 @@ __global__ __launch_bounds__(256) void ddc_wf_comb_kernel(
         } else {
             for (int k = 0; k < 4; k++) if (oo + k < nout) v[k] = src[oo + k];
         }
+        int4 w4;                              // one 16-byte LDS store per thread (four 4-byte ones: stride-4 words, 4-way conflicts)
+        int *w4p = (int *) &w4;
         for (int k = 0; k < 4; k++) {
             u32 a = 0;
             if (oo + k < nout) {
                 a = absolute(comp, oo + k, v[k]);
                 if (oo + k >= nout - 5) hist_out[((long) li * 2 + comp) * 5 + (int) (oo + k - (nout - 5))] = a;
             }
-            s_c0[comp][8 + 4 * t + k] = sext32((int) a, 28);
+            w4p[k] = sext32((int) a, 28);
         }
+        *(int4 *) &s_c0[comp][8 + 4 * t] = w4;
         // the five outputs before the tile: strobes of earlier calls (zero after a reset) or earlier tiles
         if (t < 5) {
             const long pb = o0 - 5 + t;
@@ -894,7 +897,11 @@ __global__ __launch_bounds__(256) void ddc_wf_comb_kernel(
             // comb k output at position d needs its input at d and d-1
             const int W[5] = {23, 22, 21, 20, 20}, D[5] = {5, 1, 1, 1, 0};
             int v[9];
-            for (int d = 0; d < 9; d++) v[d] = s_c0[comp][3 + 4 * t + d];
+            {                                 // the nine-value window [3 + 4t, 12 + 4t) from three 16-byte reads of [4t, 4t + 12)
+                const int4 q0 = *(const int4 *) &s_c0[comp][4 * t], q1 = *(const int4 *) &s_c0[comp][4 * t + 4],
+                           q2 = *(const int4 *) &s_c0[comp][4 * t + 8];
+                v[0] = q0.w; v[1] = q1.x; v[2] = q1.y; v[3] = q1.z; v[4] = q1.w; v[5] = q2.x; v[6] = q2.y; v[7] = q2.z; v[8] = q2.w;
+            }
             int cnt = 9;
             for (int k = 0; k < 5; k++) {
                 int x[9];
@@ -908,7 +915,12 @@ __global__ __launch_bounds__(256) void ddc_wf_comb_kernel(
     // out through LDS, so that the stores are lane-contiguous whatever the alignment of the caller's rows
     __syncthreads();                          // every thread has read its window
     int *s_out = &s_c0[0][0];
-    for (int k = 0; k < 4; k++) s_out[4 * t + k] = (int) ((unsigned short) res[0][k] | ((unsigned) (unsigned short) res[1][k] << 16));
+    {
+        int4 o4;
+        int *o4p = (int *) &o4;
+        for (int k = 0; k < 4; k++) o4p[k] = (int) ((unsigned short) res[0][k] | ((unsigned) (unsigned short) res[1][k] << 16));
+        *(int4 *) &s_out[4 * t] = o4;
+    }
     __syncthreads();
     short2 *dst = out + (long) li * out_stride + o0;
     for (int k = 0; k < 4; k++) {
