@@ -4,6 +4,7 @@
 set -u
 tag=$1; shift
 export TMPDIR=/tmp
+export KIWIGPU_BENCH_PREROLL_S=${KIWIGPU_BENCH_PREROLL_S:-0.12}     # fewer traced launches
 out=$PWD/gpurun_out/$tag
 mkdir -p $out
 args="$@"
@@ -13,4 +14,6 @@ timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS 
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc3 -- python3 bench.py --no-cpu --no-live-traffic $args > $out/pmc3.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/pmc4 -- python3 bench.py --no-cpu --no-live-traffic $args > $out/pmc4.log 2>&1
 python3 tools/prof_summary.py $out > $out/summary.txt 2>&1
+# the raw per-dispatch files are tens of MB per pass (gpurun brings back 64 MiB at most): the summary and the stats stay
+find $out -name "*kernel_trace.csv" -delete; find $out -name "*counter_collection.csv" -delete; find $out -name "*agent_info.csv" -delete
 cat $out/summary.txt
