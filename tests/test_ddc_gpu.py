@@ -113,6 +113,44 @@ def test_fourteen_channels_baseline_zoom_set(gpu_ctx, oracle):
     d.close()
 
 
+def test_adc_block_at_any_alignment(gpu_ctx, oracle):
+    """The ADC block's device address need not be 16-byte aligned (the run passes then walk it sample by sample
+    instead of in 16-byte groups loaded one group ahead; the bypass kernel takes its scalar loads): a block that starts
+    1, 3 and 4 samples into an allocation, every kind of channel (bypass, staged R <= 8, 64-bit and 96-bit pass B),
+    state carried from push to push."""
+    log2rs = [0, 1, 3, 6, 10, 13]
+    n = 3 * 40_000
+    adc = adc_stream(n, seed=21, tones=((0.0123, 9000.0), (0.25, 1200.0)))
+    incs = [inc_for(0.011 + 0.013 * k) for k in range(len(log2rs))]
+    d = Ddc(gpu_ctx, nchan=len(log2rs), max_samples=n)
+    d_adc = gpu_ctx.alloc(2 * (n + 16))
+    chans = list(range(len(log2rs)))
+    try:
+        for ch, lr in enumerate(log2rs):
+            d.set_wf(ch, incs[ch], 1 << lr)
+        stride = n + 2
+        d_out = gpu_ctx.alloc(len(chans) * stride * 4)
+        parts = [[] for _ in chans]
+        for piece, shift in enumerate((1, 3, 4)):
+            blk = np.ascontiguousarray(adc[piece * 40_000:(piece + 1) * 40_000])
+            pad = np.zeros(blk.size + 16, np.int16)
+            pad[shift:shift + blk.size] = blk
+            gpu_ctx.upload(d_adc, pad)
+            nouts = d.push_dev(d_adc + 2 * shift, blk.size, chans, d_out, stride)
+            host = np.zeros((len(chans), stride, 2), np.int16)
+            gpu_ctx.download(d_out, host)
+            for ch in chans:
+                parts[ch].append(host[ch, :int(nouts[ch])].copy())
+        gpu_ctx.free(d_out)
+        for ch, lr in enumerate(log2rs):
+            want, _ = oracle.ddc_wf(adc, incs[ch], lr)
+            got = np.concatenate(parts[ch])
+            assert got.shape == want.shape and np.array_equal(got, want), (ch, lr)
+    finally:
+        gpu_ctx.free(d_adc)
+        d.close()
+
+
 def test_extreme_inputs_wrap_like_the_registers(gpu_ctx, oracle):
     """Full-scale square wave at DC offset: the integrators wrap many times."""
     n = 1 << 17
