@@ -127,8 +127,6 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
         const wf_chan_dev *ch = chans + cid;
         const int interp = ch->interp, dc = ch->dc, comp_on = ch->comp_on;
         const bool more = fn < nframes;
-        const int cid_next = fr_next.x;
-        const int wfn_next = chans[cid_next].window_func;
         // (the counter's value only: anything computed from it here would be waited for here.  Built with the
         // atomic optimizer off -- Makefile: its wave-aggregated form reads the result back with v_readfirstlane
         // right behind the atomic, an s_waitcnt vmcnt(0) at the top of the frame that made wave 0 reach the first
@@ -139,6 +137,13 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
         cf x[16], y0[16], y1[16];
         windowed(x, 0);
         kg_subfft4096_l<-1>(x, y0, tileA, tileB, tw1, p2, t);
+        // (the next frame's record was requested at the bottom of the previous frame; read here, not at the top of the
+        // frame, where the dependent load of its channel's window number made every wave wait for it before its first
+        // instruction of arithmetic)
+        kg_pin();
+        const int cid_next = fr_next.x;
+        const int wfn_next = chans[cid_next].window_func;
+        kg_pin();
         windowed(x, 1);
         // Everything the second transform's duration can hide is requested DURING it, five loads at each of eight
         // points (kg_subfft4096_l_h): the next frame (both parities, into the registers just consumed; the last frame
