@@ -1665,6 +1665,11 @@ def main():
     if world_env is not None and int(world_env) != args.gpus:
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%s\n" % (args.gpus, world_env))
         sys.exit(2)
+    # stdout carries exactly ONE line, the JSON: whatever a native library writes to file descriptor 1 (RCCL prints its
+    # version banner there when a process group comes up) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     single = args.gpus == 1 and (world_env is None or int(world_env) == 1)
     if single and not args.no_live_traffic and not args.pmc_child and args.workload != "stub":
@@ -1722,7 +1727,7 @@ def main():
         r = run(args.workload)
         line = dict(common, **r)
     if dist.rank == 0:
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     dist.close()
 
 
