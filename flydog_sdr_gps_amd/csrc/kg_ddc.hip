@@ -20,18 +20,22 @@
 // pruning (the 5th integrator accumulates floor(I4 / 2^61)) makes the output depend
 // on the exact wrapped value of I4 at every ADC sample, so time cannot simply be
 // cut into independent pieces.  The stream is cut into runs of L samples:
-//   A  every run integrates from a zero state  -> local end state e_r (4 x 128 bit)
+//   A  every run integrates from a zero state  -> local end state e_r (stored 4 x 128 bit)
 //   S  carry scan: c_{r+1} = T(L) c_r + e_r, where T(L) advances a state over L
 //      zero-input samples (binomial coefficients; validated in tools/ and the
-//      tests).  One wave per (channel, I/Q): lane-local sequential compose, a
-//      6-step wave scan with the affine combine, lane-local re-expansion.
+//      tests).  Chunks of runs per (channel, I/Q), one workgroup each: lane-local
+//      sequential compose, a 6-step wave scan with the affine combine, the wave and
+//      chunk totals folded in log steps, lane-local re-expansion.
 //   B  every run integrates again from its exact carried state, feeds the pruned
 //      5th integrator and records its value at every decimation strobe (relative
 //      to the run start) plus the run total
 //   S2 prefix sum of the run totals (mod 2^28)
 //   C  per output: absolute I5, the five pruned combs (a 6-tap dependency on
 //      earlier outputs only, so fully parallel), rounding, int16 store.
-// All arithmetic is modulo 2^128, which keeps the low 89 bits exact.
+// Nothing above bit 88 of an integrator is ever read, so any modulus 2^k with k >= 89 keeps
+// the result exact: the run passes work modulo 2^64 on (state >> shift) where 24 + 5 log2 R
+// <= 64, modulo 2^96 (three 32-bit limbs) above that, and the scan modulo 2^96 throughout;
+// states are stored 128 bits wide (upper limb zero).
 #include <type_traits>
 #include "kg_common.h"
 
