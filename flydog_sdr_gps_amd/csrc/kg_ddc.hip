@@ -84,36 +84,6 @@ DDC_DEV u128 binom3(u64 j)
 
 struct ddc_state4 { u128 i[4]; };            // integrators 1..4
 
-struct ddc_coef { u128 L, c2, c3; };
-DDC_DEV ddc_coef ddc_coef_for(u64 len) { ddc_coef c; c.L = mk128(len, 0); c.c2 = binom2(len); c.c3 = binom3(len); return c; }
-DDC_DEV ddc_state4 ddc_Tc(const ddc_coef &k, const ddc_state4 &s)
-{
-    ddc_state4 r;
-    r.i[0] = s.i[0];
-    r.i[1] = add128(s.i[1], mul128(k.L, s.i[0]));
-    r.i[2] = add128(add128(s.i[2], mul128(k.L, s.i[1])), mul128(k.c2, s.i[0]));
-    r.i[3] = add128(add128(add128(s.i[3], mul128(k.L, s.i[2])), mul128(k.c2, s.i[1])), mul128(k.c3, s.i[0]));
-    return r;
-}
-
-// advance a state over len zero-input samples
-DDC_DEV ddc_state4 ddc_T(u64 len, const ddc_state4 &s)
-{
-    const u128 L = mk128(len, 0), c2 = binom2(len), c3 = binom3(len);
-    ddc_state4 r;
-    r.i[0] = s.i[0];
-    r.i[1] = add128(s.i[1], mul128(L, s.i[0]));
-    r.i[2] = add128(add128(s.i[2], mul128(L, s.i[1])), mul128(c2, s.i[0]));
-    r.i[3] = add128(add128(add128(s.i[3], mul128(L, s.i[2])), mul128(c2, s.i[1])), mul128(c3, s.i[0]));
-    return r;
-}
-DDC_DEV ddc_state4 ddc_add(const ddc_state4 &a, const ddc_state4 &b)
-{
-    ddc_state4 r;
-    for (int k = 0; k < 4; k++) r.i[k] = add128(a.i[k], b.i[k]);
-    return r;
-}
-
 // Per-channel persistent state (HBM).
 struct ddc_chan {
     u64 phase;            // 48-bit NCO accumulator: phase of the next sample
