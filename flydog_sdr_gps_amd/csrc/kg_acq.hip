@@ -600,7 +600,36 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
         const int limit = cur.limit, full_rows = limit >> 8;
         float bp = 0.f, sum = 0.f;
         int bi = 0;
-        if constexpr (NQ == 1) {
+        if constexpr (NQ == 1 && P == 4) {
+            // the 16368-lag kernel's form of the scan (acq_correlate8_kernel): powers kept, total in packed pairs, maximum
+            // by fmax, the lane's FIRST row holding it from a row mask built with a compare and an add-with-carry per row
+            // (acq 0.796 -> 0.789 ms; P = 16 keeps the serial form below: its sixteen more registers of powers spill there,
+            // configs[4] 2.72 -> 2.76 ms)
+            float pw[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) {
+                const cf sq = acc[0][m] * acc[0][m];
+                pw[m] = sq.x + sq.y;
+                if (m >= full_rows) {
+                    asm volatile("");
+                    pw[m] = (t + 256 * m < limit) ? pw[m] : 0.f;
+                }
+            }
+            cf s2 = cf{0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 16; m += 2) s2 = s2 + cf{pw[m], pw[m + 1]};
+            sum = s2.x + s2.y;
+#pragma unroll
+            for (int m = 0; m < 16; m += 2) bp = __builtin_fmaxf(bp, __builtin_fmaxf(pw[m], pw[m + 1]));
+            unsigned qm[2] = {0, 0};                               // two independent chains of eight rows
+#pragma unroll
+            for (int m = 7; m >= 0; m--)
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+                    asm("v_cmp_eq_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(qm[h]) : "v"(pw[m + 8 * h]), "v"(bp) : "vcc");
+            const unsigned rowmask = qm[0] | (qm[1] << 8);
+            bi = t + 256 * (int) __builtin_ctz(rowmask | 0x80000000u);
+        } else if constexpr (NQ == 1) {
             int br = 0;
 #pragma unroll
             for (int m = 0; m < 16; m++) {
