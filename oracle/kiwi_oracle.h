@@ -65,6 +65,10 @@ int ko_e1b_from_hex(const char *hex, uint8_t *chips);
  * Replaces fftwf_execute at gps/search.cpp:280,342,447,481,
  * rx/rx_waterfall.cpp:1291, rx/CuteSDR/fastfir.cpp:274,304. */
 void ko_fft(int n, int sign, const ko_cpx *in, ko_cpx *out, int prec);
+/* prec: 1 = double radix-2 rounded to fp32 on store, 0 = fp32 radix-4 Stockham, 2 = the registered hook (an
+ * independent FFT supplied by the test: unnormalised, sign -1 forward / +1 backward, in may equal out) */
+typedef void (*ko_fft_hook)(int n, int sign, const ko_cpx *in, ko_cpx *out);
+void ko_set_fft_hook(ko_fft_hook fn);
 
 /* ---- GPS acquisition ------------------------------------------------------ */
 /* gps/search.cpp:140-166 DecimateBy2float, in place.  buf must have room for

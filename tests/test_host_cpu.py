@@ -53,13 +53,16 @@ def test_gold_code_correlation_property(oracle):
 
 
 def test_e1b_known_answers(oracle):
-    """gps/search.cpp:295,302: first 20 chips of E01 = 0xf5d71, E02 = 0x96b85."""
+    """gps/search.cpp:295,302: first 20 chips of E01 = 0xf5d71, E02 = 0x96b85 (chips: the reference's E1BCODE outputs,
+    tests/golden/e1b_ref.npz; the hex digits are re-derived from them, no reference text is kept here)."""
     from flydog_sdr_gps_amd import prn
-    g = np.load(os.path.join(ROOT, "tests", "golden", "e1b_codes.npz"))
-    for name, first in (("E01", 0xF5D71), ("E02", 0x96B85)):
-        hexstr = str(g[name + "_hex"])
+    from tests.fixtures import e1b_chips
+    from tests.test_ref_pins_cpu import chips_to_hex
+    table = e1b_chips()
+    for p, first in ((1, 0xF5D71), (2, 0x96B85)):
+        hexstr = chips_to_hex(table[p])
         chips = oracle.e1b_from_hex(hexstr)
-        assert np.array_equal(chips, prn.e1b_from_hex(hexstr))
+        assert np.array_equal(chips, prn.e1b_from_hex(hexstr)) and np.array_equal(chips, table[p])
         assert int("".join(map(str, chips[:20])), 2) == first
         assert chips.size == 4092
     with pytest.raises(ValueError):

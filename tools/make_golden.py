@@ -1,9 +1,5 @@
 """Generates the committed fixtures under tests/golden/ (run in the build container).
 
-  e1b_codes.npz   Galileo E1-B memory codes (hex, straight from the SIS ICD table the
-                  reference carries in gps/e1bcode.h) for the PRNs the tests use:
-                  E01/E02 (the reference's known answers, gps/search.cpp:295,302)
-                  and E11 (an acquisition case).  Data only.
   acq_golden.npz  acquisition cases: packed 1-bit IF input + the CPU oracle's
                   (snr, dop, idx, valid) and per-Doppler peak indices.
 
@@ -13,7 +9,6 @@ unbuildable here, so the expected values come from the oracle
 travel to the GPU box; they are not reference outputs.
 """
 import os
-import re
 import sys
 
 import numpy as np
@@ -26,11 +21,7 @@ from oracle import kiwi_oracle as ko                  # noqa: E402
 GOLD = os.path.join(ROOT, "tests", "golden")
 os.makedirs(GOLD, exist_ok=True)
 
-ref = "/root/reference/gps/e1bcode.h"
-strings = re.findall(r'"([0-9A-F]{1023})"', open(ref).read())
-assert len(strings) == 50
-e1b = {"E01_hex": strings[0], "E02_hex": strings[1], "E11_hex": strings[10]}
-np.savez_compressed(os.path.join(GOLD, "e1b_codes.npz"), **e1b)
+from tests.fixtures import e1b_chips                   # noqa: E402  (the reference's own E1BCODE outputs, e1b_ref.npz)
 
 cases = []
 
@@ -56,7 +47,7 @@ add(16, synth.gps_scene_bits([(ca(16), 17.75, -4100.0, 2.0)], seed=11, cn0_dbhz=
 add(32, synth.gps_scene_bits([(ca(32), 800.5, 2600.0, 1.0)], seed=12, cn0_dbhz=47.0))   # QZSS 194
 add(4, synth.gps_scene_bits([(ca(0), 300.5, 1500.0, 0.7)], seed=13))           # PRN5 absent
 add(8, synth.gps_scene_bits([(ca(8), 1022.9, 5000.0, 0.0)], seed=14, cn0_dbhz=41.0))    # edge Doppler, weak
-e11 = prn.e1b_from_hex(e1b["E11_hex"])
+e11 = e1b_chips()[11]
 sat_e11 = [i for i, s in enumerate(sats.SATS) if s[3] == sats.E1B and s[0] == 11][0]
 add(sat_e11, synth.gps_scene_bits([(e11, 2000.25, -1250.0, 0.5, 48.0, True)], seed=15), e11)
 

@@ -3,8 +3,8 @@
 sources, see oracle/build_ref.sh).  What is committed is data: inputs made here from fixed seeds and
 the outputs the reference's code produced for them.
 
-  e1b_ref.npz     the 50 Galileo E1-B memory codes: the ICD hex strings (data table of
-                  gps/e1bcode.h) and the chips E1BCODE(prn) of that header produces
+  e1b_ref.npz     the 50 Galileo E1-B memory codes: the chips E1BCODE(prn) of gps/e1bcode.h produces
+                  (outputs only; the header's hex table is read from $REFERENCE at test time)
   consts_ref.json the constants of gps/gps.h, kiwi.h and the generated kiwi.gen.h
   cic_ref.json    register widths / truncations / output slices verilog/rx/cic_gen.c emits for every
                   CIC instance of kiwi.config (rx1 std + wide, rx2 std + wide, wf1)
@@ -37,10 +37,9 @@ chips = np.zeros((50, 4092), np.uint8)
 for line in out.decode().splitlines():
     prn, bits = line.split()
     chips[int(prn) - 1] = np.frombuffer(bits.encode(), np.uint8) - ord("0")
-hexes = re.findall(r'"([0-9A-F]{1023})"', open(os.path.join(REFERENCE, "gps", "e1bcode.h")).read())
-assert len(hexes) == 50
-np.savez_compressed(os.path.join(GOLD, "e1b_ref.npz"), chips_packed=np.packbits(chips, axis=1),
-                    hex=np.array(hexes))
+# outputs only: the ICD hex table itself (text of gps/e1bcode.h) is NOT kept under tests/ -- the tests read it
+# from $REFERENCE at run time where the reference is present (tests/test_ref_pins_cpu.py)
+np.savez_compressed(os.path.join(GOLD, "e1b_ref.npz"), chips_packed=np.packbits(chips, axis=1))
 print("e1b_ref.npz: 50 codes, E01 first 20 chips 0x%x" % int("".join(map(str, chips[0, :20])), 2))
 
 # ---- constants ----------------------------------------------------------------------------
