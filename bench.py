@@ -155,6 +155,44 @@ class Dist:
 _T0 = time.perf_counter()
 
 
+def sha16(path):
+    import hashlib
+    try:
+        with open(path, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def box_identity(local_rank=0):
+    """Which machine, which GPU, which build produced this line (the profiles/ files of the same gpurun lease carry the
+    same record, tools/prof.sh): boxes differ by +-4 %, so a trace and a bench line are comparable only when these agree.
+    Never initialises the GPU in this process (rocminfo / rocm-smi run as children)."""
+    import re
+    import shutil
+    import socket
+    box = {"host": socket.gethostname(), "lib_sha16": sha16(os.path.join(ROOT, "flydog_sdr_gps_amd", "libkiwigpu.so")),
+           "bench_sha16": sha16(os.path.abspath(__file__)), "gpu_uuid": None, "gpu_name": None}
+    try:
+        if shutil.which("rocminfo"):
+            txt = subprocess.run(["rocminfo"], capture_output=True, text=True, timeout=60).stdout
+            gpus = re.findall(r"Uuid:\s+(GPU-\S+)", txt)
+            names = re.findall(r"Marketing Name:\s+(.*\S)", txt)
+            if gpus:
+                box["gpu_uuid"] = gpus[min(local_rank, len(gpus) - 1)]
+            gnames = [n for n in names if "Instinct" in n or "MI3" in n]
+            if gnames:
+                box["gpu_name"] = gnames[0]
+    except (OSError, subprocess.SubprocessError):
+        pass
+    try:
+        with open("/etc/machine-id") as f:
+            box["machine_id8"] = f.read().strip()[:8]
+    except OSError:
+        pass
+    return box
+
+
 def log(msg):
     """progress on stderr (stdout carries the ONE JSON line)"""
     if os.environ.get("RANK", "0") == "0":
@@ -502,9 +540,12 @@ def run_acq(args, dist, ten_ms=False, all_svs=False):
         make_block = lambda b: synth.config1_iq16(seed=0x5EED0002 + b)                  # noqa: E731
     nsv_all = len(codes)
     # --shard sv (first bullet; gps/search.cpp:512-604 is the loop being partitioned): every rank
-    # holds the SAME block(s) and searches its contiguous share of the SV list
-    sv_lo, sv_hi = shard.split_units(nsv_all, dist.world)[dist.rank] if shard_sv else (0, nsv_all)
-    svs = list(range(sv_lo, sv_hi))
+    # holds the SAME block(s) and searches its share of the SV list -- cost-balanced (shard.split_units_weighted: an
+    # E1B SV costs 1.6 C/A ones and gps/sats.cpp:25-142 puts the 23 E1B rows last; a contiguous split gives one rank of
+    # eight 124 % of the mean)
+    sv_weights = shard.sv_weights([b for _, b in codes])
+    sv_shares = shard.split_units_weighted(sv_weights, dist.world) if shard_sv else [list(range(nsv_all))]
+    svs = sv_shares[dist.rank] if shard_sv else list(range(nsv_all))
     ndop, P = dop_hi - dop_lo + 1, fft_len // 4096
     s = Searcher(ctx, dop_lo=dop_lo, dop_hi=dop_hi, max_blocks=2 * B, nsamples=nsamples, fft_len=fft_len)
     for sat in svs:
@@ -515,7 +556,7 @@ def run_acq(args, dist, ten_ms=False, all_svs=False):
     iq_dev = torch.from_numpy(np.stack(iq_host)).to(dev)          # [B][2*nsamples] int16, resident
     iq_ptr = int(iq_dev.data_ptr())
     parity = [0]
-    nsv_max = max(hi - lo for lo, hi in shard.split_units(nsv_all, dist.world)) if shard_sv else len(svs)
+    nsv_max = max(len(sh) for sh in sv_shares) if shard_sv else len(svs)
     rbytes = B * nsv_max * result_dtype.itemsize
     if shard_sv and dist.on and dist.backend == "nccl":
         res_dev = torch.as_tensor(DevBytes(s.results_dev(), rbytes), device=dev)     # the library's result array, zero copy
@@ -557,7 +598,7 @@ def run_acq(args, dist, ten_ms=False, all_svs=False):
             parts = gathered_dev.cpu().numpy().view(result_dtype).reshape(dist.world, -1)
         else:
             parts = res.reshape(1, -1)
-        res = shard.merge_sv_shards(parts, B, shard.split_units(nsv_all, dist.world))       # [B][59]
+        res = shard.merge_sv_shards(parts, B, sv_shares)                                    # [B][59]
         assert res.shape == (B, nsv_all)
     # (E1B rows: 41 x 16368 trials per SV put the noise maximum close to the reference's MIN_SIG = 16)
     min_sig = synth.MIN_SIG_10MS if ten_ms else (24.0 if all_svs else acq.MIN_SIG)
@@ -598,8 +639,10 @@ def run_acq(args, dist, ten_ms=False, all_svs=False):
                          ("BASELINE configs[1]: 32 GPS L1 C/A SVs x 41 Doppler bins, 4 ms coherent FFT correlate, "
                           "synthetic int16 IQ @16.368 MS/s resident in HBM")),
             "blocks_per_step_per_gpu": B, "samples_per_block": nsamples, "cells_per_step_per_gpu": cells,
-            "parallelism": ("--shard sv: the same %d block(s) on every GPU, the %d SVs split over %d GPU(s) (this rank: %d..%d), "
-                            "winners all-gathered over RCCL every step" % (B, nsv_all, dist.world, sv_lo, sv_hi - 1)) if shard_sv else
+            "parallelism": ("--shard sv: the same %d block(s) on every GPU, the %d SVs split over %d GPU(s) by cost (E1B = %.1f C/A; "
+                            "rank loads %s of mean %.2f), winners all-gathered over RCCL every step"
+                            % (B, nsv_all, dist.world, shard.SV_WEIGHT_E1B, [round(sum(sv_weights[i] for i in sh), 1) for sh in sv_shares],
+                               sum(sv_weights) / dist.world)) if shard_sv else
                            "replicated codes, sample blocks sharded over %d GPU(s), no data-path collective" % dist.world,
         },
         # What bounds the correlator: fp32 vector arithmetic -- every operand is
@@ -858,6 +901,37 @@ def native_oracle_note():
 
 
 # ------------------------------------------------------------------------------------------------
+# Result checks of the timed workloads: the same objects, right after their timed region, against the oracle
+# ------------------------------------------------------------------------------------------------
+def check_wf_rows(cases, interp, window_func=None):
+    """cases: [(WfParams, int16 frame [8192][2], the GPU's u8 row)] -> rows checked.  The oracle's sample_wf window +
+    compute_frame (rx/rx_waterfall.cpp:1049-1066, 1275-1575) on the same frame; bytes must agree under the rule of
+    tests/test_wf_gpu.py (identical but for one-LSB flips where the oracle's dB lies within the 1e-5 power bound of an
+    (int) edge).  Raises AssertionError on a mismatch: the bench fails."""
+    from flydog_sdr_gps_amd import wf
+    from oracle import kiwi_oracle as ko
+    from tests.test_wf_gpu import check_row, db_bound, oracle_frame
+    ko.lib()
+    tables = (wf.window_functions(), wf.cic_comp_table())
+    wfun = wf.WINF_HANNING if window_func is None else window_func
+    for p, iq, got in cases:
+        w_out, _, w_pwr_out, w_dB = oracle_frame(ko, tables, iq, p, interp, wfun, True, False, False)
+        check_row(got, w_out, w_dB, db_bound(w_pwr_out))
+    return len(cases)
+
+
+def adc_rotation(adc_host, dev, nblk, world_rank=0):
+    """nblk distinct copies of the ADC block in HBM (block r = the base rotated by 4099 r samples; block 0 = the base):
+    the steps walk them in turn so that consecutive pushes never read the same lines -- 9 x 32 MiB is past the
+    256 MiB Infinity Cache, as wf14's input is.  -> (list of tensors, host function giving block r)"""
+    import numpy as np
+    import torch
+    base = torch.from_numpy(adc_host).to(dev)
+    blocks = [base] + [torch.roll(base, 4099 * r) for r in range(1, nblk)]
+    return blocks, (lambda r: adc_host if r == 0 else np.roll(adc_host, 4099 * r))
+
+
+# ------------------------------------------------------------------------------------------------
 # Waterfall frames (configs[2], frame half)
 # ------------------------------------------------------------------------------------------------
 def run_wf14(args, dist):
@@ -902,6 +976,15 @@ def run_wf14(args, dist):
     kernel_ms = ctx.timer_stop() / steps
     k_min, k_med = event_spread(step, steps)
     assert int(out.max()) > 100
+    # result check at the bench's own shape: 42 frames spread over the launch (every channel three times, the first and
+    # the last frame among them), rows as the timed steps left them, against the oracle on the same frames
+    picks = sorted(set([0, nfr - 1] + [int(x) for x in np.linspace(0, nfr - 1, 3 * len(zooms)).round()]))
+    picks = sorted(set(picks + [f + c for f in (0, nfr // 2 // len(zooms) * len(zooms)) for c in range(len(zooms)) if f + c < nfr]))
+    t_chk = time.perf_counter()
+    sel = torch.as_tensor(picks, device=dev)
+    iq_sel, out_sel = iq[sel].cpu().numpy(), out[sel].cpu().numpy()
+    checked = check_wf_rows([(params[f % len(zooms)], iq_sel[i], out_sel[i]) for i, f in enumerate(picks)], wf.WF_CMA)
+    log("wf14: %d rows of the timed launch checked against the oracle in %.2f s" % (checked, time.perf_counter() - t_chk))
     bytes_frame = 8192 * 4 + 1024          # int16 IQ in + u8 row out; window/maps are L2-resident
     achieved = nfr * bytes_frame / (kernel_ms * 1e-3) / 1e9
     traffic, source, _ = measured_traffic("wf14", nfr)
@@ -917,6 +1000,8 @@ def run_wf14(args, dist):
                      "traffic": traffic, "traffic_source": source, "kernel_ms": round(kernel_ms, 5),
                      "kernel_ms_min": k_min, "kernel_ms_median": k_med,
                      "algorithmic_bytes_per_launch": nfr * bytes_frame},
+        "checked": {"rows_vs_oracle": checked, "channels": len(zooms),
+                    "rule": "u8 rows of the timed launch; identical but for <= 1 LSB at (int) edges inside the 1e-5 power bound (tests/test_wf_gpu.py)"},
         # the other roof, for scale: nominal flops of the 8192-point transform (5 N log2 N) per frame against
         # the fp32 vector peak; the kernel issues 1239 vector instructions per wave and frame, 600 of them
         # the two 4096-point transforms, so its vector floor (0.25 ms) is above its HBM floor
@@ -1003,6 +1088,35 @@ def _adc_block(n, seed):
     return np.clip(np.rint(x), -32768, 32767).astype(np.int16)
 
 
+ADC_BLOCKS = int(os.environ.get("KIWIGPU_BENCH_ADC_BLOCKS", "9"))     # x 32 MiB at the default 2^24 samples: past the 256 MiB Infinity Cache
+CHECK_SAMPLES = 1 << 20                                             # ADC samples of a step the oracle re-computes after the timed region
+
+
+def check_ddc_prefix(d, prm, push_block0, out, adc_host, n):
+    """After the timed region: every channel re-armed (CmdSetWFFreq / CmdSetWFDecim: phase 0, CIC registers and
+    decimation counter cleared), ONE more push of block 0 through the same object and buffers, and the first
+    CHECK_SAMPLES / R output pairs of every channel compared BIT FOR BIT with the oracle's sequential Verilog-structured
+    model of verilog/rx/waterfall_1cic.v on the same samples (an output depends only on the samples before it).
+    -> output pairs checked"""
+    import numpy as np
+    import torch
+    from oracle import kiwi_oracle as ko
+    ko.lib()
+    for ch, p in enumerate(prm):
+        d.set_wf(ch, p.i_offset, p.decim)
+    push_block0()
+    torch.cuda.synchronize()
+    m = min(CHECK_SAMPLES, n)
+    total = 0
+    for ch, p in enumerate(prm):
+        want, _ = ko.ddc_wf(adc_host[:m], p.i_offset, int(np.log2(p.decim)))
+        got = out[ch, :want.shape[0]].cpu().numpy()
+        assert want.shape[0] == m // p.decim and np.array_equal(got, want), \
+            "waterfall DDC channel %d (R = %d) differs from the oracle in the bench's own run" % (ch, p.decim)
+        total += want.shape[0]
+    return total
+
+
 def run_ddc14(args, dist):
     import numpy as np
     import torch
@@ -1012,7 +1126,7 @@ def run_ddc14(args, dist):
     zooms = ZOOMS14
     n = 1 << args.log2n
     adc_host = adc_block(n, 0x5EED0003)               # the same stream on every rank (configs[2]/[3])
-    adc = torch.from_numpy(adc_host).to(dev)
+    adc_blocks, _ = adc_rotation(adc_host, dev, ADC_BLOCKS)
     d = Ddc(ctx, nchan=len(zooms), max_samples=n)
     chans = list(range(len(zooms)))
     prm = []
@@ -1022,9 +1136,12 @@ def run_ddc14(args, dist):
         d.set_wf(ch, p.i_offset, p.decim)
     stride = n + 1
     out = torch.zeros((len(zooms), stride, 2), dtype=torch.int16, device=dev)
+    kstep = [0]
 
     def step():
-        d.push_dev(adc.data_ptr(), n, chans, out.data_ptr(), stride)
+        a = adc_blocks[kstep[0] % ADC_BLOCKS]          # a different 32 MiB of ADC samples every step
+        kstep[0] += 1
+        d.push_dev(a.data_ptr(), n, chans, out.data_ptr(), stride)
 
     if args.pmc_child:
         res = pmc_window(ctx, "ddc14", step, lambda: torch.cuda.synchronize(dev))
@@ -1038,6 +1155,9 @@ def run_ddc14(args, dist):
         step()
     gpu_ms = ctx.timer_stop() / steps
     k_min, k_med = event_spread(step, steps)
+    t_chk = time.perf_counter()
+    checked = check_ddc_prefix(d, prm, lambda: d.push_dev(adc_blocks[0].data_ptr(), n, chans, out.data_ptr(), stride), out, adc_host, n)
+    log("ddc14: %d output pairs of 14 channels bit-exact against the oracle in %.2f s" % (checked, time.perf_counter() - t_chk))
     traffic, source, top = measured_traffic("ddc14", n)
     # Integer work per ADC sample and channel, counted in 32-bit operations on the algorithm (not on
     # the kernels): NCO phase add (48 bit: 2) + 2 table reads + 2 multiplies + 2 roundings (4) = 10;
@@ -1051,8 +1171,11 @@ def run_ddc14(args, dist):
         "value": round(float(n) * steps * dist.world / elapsed / 1e6, 1), "unit": "Msamples/s",
         "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 5), "step_ms_spread": spread,
         "dtype": "int128/int64/int32",
-        "config": {"workload": "BASELINE configs[2] DDC: %d ADC samples per step, 14 channels, zooms %s" % (n, zooms),
-                   "adc_samples_per_step": n},
+        "config": {"workload": "BASELINE configs[2] DDC: %d ADC samples per step, 14 channels, zooms %s; the steps walk %d distinct "
+                               "ADC blocks (%.0f MiB, past the 256 MiB Infinity Cache)" % (n, zooms, ADC_BLOCKS, ADC_BLOCKS * n * 2 / 2 ** 20),
+                   "adc_samples_per_step": n, "adc_blocks": ADC_BLOCKS},
+        "checked": {"ddc_pairs_bit_exact_vs_oracle": checked,
+                    "rule": "channels re-armed after the timed region, one push of block 0, first 2^20 / R pairs of all 14 channels bit for bit"},
         "x_realtime_at_66.6MSps": round(n / (gpu_ms * 1e-3) / 66.6666e6, 1),
         # integer-VALU bound by arithmetic intensity (SURVEY 8d's caveat): 2 bytes in per ADC sample for
         # 14 x 36 integer operations
@@ -1092,7 +1215,7 @@ def run_cfg2_chain(args, dist):
     zooms = ZOOMS14
     n = 1 << args.log2n
     adc_host = adc_block(n, 0x5EED0003)
-    adc = torch.from_numpy(adc_host).to(dev)
+    adc_blocks, adc_host_of = adc_rotation(adc_host, dev, ADC_BLOCKS)
     C14 = len(zooms)
     d = Ddc(ctx, nchan=C14, max_samples=n)
     w = Waterfall(ctx, nchan=C14)
@@ -1128,16 +1251,17 @@ def run_cfg2_chain(args, dist):
     kstep = [0]
     base_ptr = wf_iq.data_ptr()
 
-    def ddc_part(k):
-        d.push_dev(adc.data_ptr(), n, chans, base_ptr + 4 * q * k, stride)
+    def ddc_part(k, blk=0):
+        d.push_dev(adc_blocks[blk].data_ptr(), n, chans, base_ptr + 4 * q * k, stride)
 
     def frames_part(k):
-        w.frames_dev(tabs[k][0], base_ptr, rows.data_ptr(), frame_off=tabs[k][1])
+        w.frames_dev(tabs[k][0], base_ptr, rows.data_ptr(), frame_off=tabs[k][1], iq_len=C14 * stride)
 
     def step():
         k = kstep[0] % cyc
+        blk = kstep[0] % ADC_BLOCKS                        # a different 32 MiB of ADC samples every step
         kstep[0] += 1
-        ddc_part(k)
+        ddc_part(k, blk)
         frames_part(k)
 
     if args.pmc_child:
@@ -1176,13 +1300,48 @@ def run_cfg2_chain(args, dist):
     k_min, k_med = event_spread(step, steps)
     ctx.timer_start()
     for i in range(steps):
-        ddc_part(i % cyc)
+        ddc_part(i % cyc, i % ADC_BLOCKS)
     ddc_ms = ctx.timer_stop() / steps
     ctx.timer_start()
     for i in range(steps):
         frames_part(i % cyc)
     frames_ms = ctx.timer_stop() / steps
     assert int(rows.max()) > 100
+    # ---- result check at the bench's own shape (after the timed region, the same objects and buffers): channels
+    # re-armed, one cycle of steps over ADC blocks 0 .. cyc-1; per channel the DDC output that holds its first frames
+    # bit for bit against the oracle, and the u8 rows of up to six of those frames under the tests' rule
+    from oracle import kiwi_oracle as ko
+    ko.lib()
+    t_chk = time.perf_counter()
+    for ch, p in enumerate(prm):
+        d.set_wf(ch, p.i_offset, p.decim)
+    kstep[0] = 0
+    snap = {}
+    for k in range(cyc):
+        step()
+        torch.cuda.synchronize(dev)
+        if k in (0, cyc - 1):
+            snap[k] = (wf_iq.cpu().numpy(), rows.cpu().numpy().copy())
+    adc_cat = np.concatenate([adc_host_of(k % ADC_BLOCKS) for k in range(cyc)]) if cyc > 1 else adc_host
+    pairs_checked, row_cases = 0, []
+    for ch, p in enumerate(prm):
+        R = p.decim
+        slow = nout[ch] < 8192                                    # its frame is taken on the last step of the cycle
+        need = min(max(CHECK_SAMPLES, 8192 * R), adc_cat.size if slow else n)
+        want, _ = ko.ddc_wf(adc_cat[:need], p.i_offset, int(np.log2(R)))
+        g_iq, g_rows = snap[cyc - 1 if slow else 0]
+        got = g_iq[ch, :want.shape[0]]
+        assert want.shape[0] == need // R and np.array_equal(got, want), "chain: DDC channel %d (R = %d) differs from the oracle" % (ch, R)
+        pairs_checked += want.shape[0]
+        k_tab = cyc - 1 if slow else 0
+        mine = [i for i, c in enumerate(tabs[k_tab][0]) if c == ch]       # this channel's frames in that step's table, in order
+        nfull = want.shape[0] // 8192
+        for f in sorted(set(list(range(min(3, nfull))) + list(range(max(0, nfull - 3), nfull)))):
+            row_cases.append((p, want[8192 * f:8192 * (f + 1)], g_rows[mine[f]]))
+    rows_checked = check_wf_rows(row_cases, wf.WF_CMA)
+    assert len(set(id(c[0]) for c in row_cases)) == C14, "every channel's rows must be among the checked ones"
+    log("cfg2_chain: %d DDC pairs bit-exact and %d rows of all 14 channels checked against the oracle in %.2f s"
+        % (pairs_checked, rows_checked, time.perf_counter() - t_chk))
     frames_per_step = sum(len(t[0]) for t in tabs) / cyc
     ops_sample_chan = 36                                   # run_ddc14's count: NCO + mixer + five integrators per sample and channel
     tops = n * C14 * ops_sample_chan / (gpu_ms * 1e-3) / 1e12
@@ -1197,7 +1356,9 @@ def run_cfg2_chain(args, dist):
         "config": {"workload": "BASELINE configs[2] end to end: %d ADC samples per step -> 14 DDC channels (zooms %s) -> "
                                "the %.2f frames per step those complete -> window + 8192-pt FFT + power + pixels + dB + u8 rows"
                                % (n, zooms, frames_per_step),
-                   "adc_samples_per_step": n, "frames_per_step": frames_per_step},
+                   "adc_samples_per_step": n, "frames_per_step": frames_per_step, "adc_blocks": ADC_BLOCKS},
+        "checked": {"ddc_pairs_bit_exact_vs_oracle": pairs_checked, "rows_vs_oracle": rows_checked, "channels": C14,
+                    "rule": "after the timed region: channels re-armed, one cycle of steps; DDC prefix bit for bit, u8 rows under tests/test_wf_gpu.py's rule"},
         "x_realtime_at_66.6MSps": round(n / (gpu_ms * 1e-3) / 66.6666e6, 1),
         "frames_per_s": round(frames_per_step * steps * dist.world / elapsed, 1),
         # the step is the DDC's integer work (ddc14's roof) plus a quarter as much frame time; the numerator counts the
@@ -1359,6 +1520,82 @@ class ReceiverBank:
             o.close()
 
 
+def check_receiver_bank(bank, chs, steps=3):
+    """Steps a FRESH ReceiverBank `steps` times over its ADC block and checks EVERY stage of the receivers `chs` against the
+    oracle fed the same stream with its state carried from step to step: both DDCs bit-exact on all their output, the frame
+    the waterfall took, the u8 row (tests/test_wf_gpu.py's rule), the wf_pkt_t, the unpacked audio samples bit for bit,
+    CFastFIR (1e-5 of max), CAgc mono16 (<= 1 LSB, >= 99 % identical) and the ADPCM payload.  Called by bench.py after the
+    timed region of `receivers` (a sample of the receivers) and by tests/test_receivers_gpu.py (all of them).
+    -> {"receivers": n, "steps": steps, "audio_blocks": n}"""
+    import numpy as np
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from flydog_sdr_gps_amd import wf
+    from oracle import kiwi_oracle as ko
+    from tests.test_wf_gpu import check_row, db_bound, oracle_frame
+    ko.lib()
+    chs = list(chs)
+    adc = bank.adc_host
+    tables = (wf.window_functions(), wf.cic_comp_table())
+    wf_st, rx_st = {ch: None for ch in chs}, {ch: None for ch in chs}
+    fir_st = {ch: ko.fir_new_state() for ch in chs}
+    agcs = {ch: ko.Agc() for ch in chs}
+    for a in agcs.values():
+        a.set_parameters(True, False, -100, 50, 6, 1000, bank.fs)
+    ad_st = {ch: None for ch in chs}
+    audio_blocks = 0
+    with ThreadPoolExecutor(8) as pool:                          # the oracle's C calls release the GIL
+        for step in range(steps):
+            bank.step()
+            torch.cuda.synchronize(bank.dev)
+            nrec, nout, nw = bank.last["nrec"], bank.last["nout"], bank.last["nw"]
+            sel = torch.as_tensor(chs, device=bank.dev)
+            g = {k: getattr(bank, k)[sel].cpu().numpy() for k in ("wf_iq", "frames", "rows", "pkts", "raw", "xin", "firo", "s16", "pay")}
+
+            def wf_ref(ch):
+                p = bank.params[ch]
+                return ko.ddc_wf(adc, p.i_offset, int(np.log2(p.decim)), wf_st[ch])
+
+            def rx_ref(ch):
+                return ko.ddc_rx(adc, bank.rx_inc[ch], rx_st[ch])
+
+            wf_out = list(pool.map(wf_ref, chs))
+            rx_out = list(pool.map(rx_ref, chs))
+            for i, ch in enumerate(chs):
+                p = bank.params[ch]
+                # waterfall DDC: all of this step's output, then the frame the waterfall took
+                iq, wf_st[ch] = wf_out[i]
+                assert iq.shape[0] == int(nw[ch]), (step, ch)
+                assert np.array_equal(g["wf_iq"][i, :iq.shape[0]], iq), (step, ch)
+                assert np.array_equal(g["frames"][i], iq[:8192])
+                w_out, _, w_pwr_out, w_dB = oracle_frame(ko, tables, iq[:8192], p, wf.WF_MAX, wf.WINF_HANNING, True, False, False)
+                check_row(g["rows"][i], w_out, w_dB, db_bound(w_pwr_out))
+                want_pkt = ko.wf_packet(g["rows"][i], int(p.start), p.zoom, 0, True)
+                assert np.array_equal(g["pkts"][i, :want_pkt.size], want_pkt), (step, ch)
+
+                # audio DDC -> rx_iq_t records -> unpack
+                raw, rx_st[ch] = rx_out[i]
+                assert raw.size == 6 * nrec, (step, ch, raw.size, nrec)
+                assert np.array_equal(g["raw"][i, :raw.size], raw), (step, ch)
+                x = ko.dpump_unpack(raw, nrec, 1)[0]
+                got_x = np.ascontiguousarray(g["xin"][i, :nrec]).view(np.complex64).ravel()
+                assert np.array_equal(got_x.view(np.uint32), x.view(np.uint32)), (step, ch)
+
+                # CFastFIR on the GPU's own input, then CAgc and ADPCM on the GPU's own upstream output
+                want_y, _ = ko.fir_process(fir_st[ch], bank.fir.get_coef(ch), got_x, prec=0)
+                assert want_y.size == nout, (step, ch, want_y.size, nout)
+                if nout:
+                    got_y = np.ascontiguousarray(g["firo"][i, :nout]).view(np.complex64).ravel()
+                    assert np.abs(got_y - want_y).max() <= 1e-5 * np.abs(want_y).max(), (step, ch)
+                    want_s = agcs[ch].process_s16(got_y)
+                    dlt = np.abs(g["s16"][i].astype(int) - want_s.astype(int))
+                    assert dlt.max() <= 1 and (dlt == 0).mean() > 0.99, (step, ch, dlt.max())
+                    want_enc, ad_st[ch] = ko.adpcm_encode_i16(g["s16"][i], ad_st[ch])
+                    assert np.array_equal(g["pay"][i], want_enc), (step, ch)
+                    audio_blocks += 1
+    return {"receivers": len(chs), "steps": steps, "audio_blocks": audio_blocks}
+
+
 def run_receivers(args, dist):
     """BASELINE configs[3]: a ReceiverBank per GPU (weak scaling over ranks)."""
     import numpy as np
@@ -1404,6 +1641,24 @@ def run_receivers(args, dist):
     ops = 36 + 20
     tops = n * NR * ops / step_s / 1e12
     traffic, source, top = measured_traffic("receivers", NR)
+    # result check at the bench's own shape: a fresh bank of the same receivers (the timed one's state is 100s of steps old),
+    # three steps, every stage of a sample of the receivers (every zoom at least once) against the oracle
+    params = bank.params
+    bank.close()
+    t_chk = time.perf_counter()
+    pick = sorted(set([0, NR - 1] + [int(x) for x in np.linspace(0, NR - 1, min(NR, 12)).round()]))
+    bank2 = ReceiverBank(dist.local_rank, dev, NR, n, dist.rank * NR, two)
+    try:
+        checked = check_receiver_bank(bank2, pick)
+    finally:
+        bank2.close()
+    checked["rule"] = "fresh bank, 3 steps, every stage of %d of the %d receivers vs the oracle (tests/test_receivers_gpu.py checks all)" % (len(pick), NR)
+    log("receivers: %s in %.2f s" % (checked, time.perf_counter() - t_chk))
+    # SURVEY 8(d) bytes of a step: the ADC block once, every waterfall channel's DDC row out, its frame back in and its u8
+    # row out (33 792 B), the audio chain's rx_iq_t records out and in + unpacked samples (6 + 6 + 8 B), a CFastFIR block
+    # (16 384 B) every 512 records
+    nrec_step = n / 10416.0
+    alg_bytes = 2 * n + sum(4 * (n // p.decim) for p in params) + NR * (8192 * 4 + 1024) + NR * nrec_step * (20 + 16384 / 512.0)
     res = {
         "metric": "receiver x ADC Msamples/s ingested (waterfall + audio chain per virtual receiver)",
         "value": round(n * NR * world / step_s / 1e6, 1), "unit": "Msamples/s", "n_gpus": world,
@@ -1426,12 +1681,14 @@ def run_receivers(args, dist):
                      "traffic": traffic, "traffic_source": source, "traffic_top_kernels": top,
                      "kernel_ms": round(step_s * 1e3, 5), "kernel_ms_min": round(dts[0], 5),
                      "kernel_ms_median": round(dts[len(dts) // 2], 5), "int_ops_per_sample_per_receiver": ops},
-        "hbm": {"measured_GBps": None if traffic is None else round(traffic / step_s / 1e9, 1), "peak": HBM_PEAK_GBS},
+        "hbm": {"algorithmic_bytes_per_step": int(alg_bytes),
+                "algorithmic_GBps": round(alg_bytes / step_s / 1e9, 1),
+                "measured_GBps": None if traffic is None else round(traffic / step_s / 1e9, 1), "peak": HBM_PEAK_GBS},
+        "checked": checked,
     }
     if "receivers" in CPU_LEGS:
         res["cpu_baseline"] = CPU_LEGS["receivers"]
         res["speedup_vs_cpu_all_cores"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
-    bank.close()
     return res
 
 
@@ -1610,15 +1867,16 @@ def run_stub(args, dist):
         from flydog_sdr_gps_amd import shard
         from flydog_sdr_gps_amd._lib import result_dtype
         B, nsv = 2, 59
-        ranges = shard.split_units(nsv, dist.world)
+        weights = shard.sv_weights([sv >= 36 for sv in range(nsv)])     # gps/sats.cpp:25-142: the 23 E1B rows come last
+        shares = shard.split_units_weighted(weights, dist.world)
 
         def fake(b, sv):
             return (16.0 + sv + 0.25 * b, sv - 30, (97 * sv + b) % 4092, 1)
         full = np.array([[fake(b, sv) for sv in range(nsv)] for b in range(B)], result_dtype)
-        lo, hi = ranges[dist.rank]
-        nmax = max(h - l for l, h in ranges)
+        my = shares[dist.rank]
+        nmax = max(len(sh) for sh in shares)
         mine = np.zeros(B * nmax, result_dtype)                 # the library's result array: [B][this rank's SVs], then slack
-        mine[:B * (hi - lo)] = full[:, lo:hi].reshape(-1)
+        mine[:B * len(my)] = full[:, my].reshape(-1)
         raw = torch.from_numpy(mine.view(np.uint8).copy())
         if dist.on:
             outs = [torch.empty_like(raw) for _ in range(dist.world)]
@@ -1626,11 +1884,25 @@ def run_stub(args, dist):
             parts = np.stack([o.numpy().view(result_dtype) for o in outs])
         else:
             parts = mine.reshape(1, -1)
-        merged = shard.merge_sv_shards(parts, B, ranges)
+        merged = shard.merge_sv_shards(parts, B, shares)
         assert merged.shape == (B, nsv) and np.array_equal(merged, full), "sv-sharded merge differs from the unsharded table"
-        out["shard_sv"] = {"world": dist.world, "ranges": ranges, "merged_equals_unsharded": True}
+        out["shard_sv"] = {"world": dist.world, "shares": shares, "load": [round(sum(weights[i] for i in sh), 3) for sh in shares],
+                           "merged_equals_unsharded": True}
         out["scaling"] = "strong"
     return out
+
+
+def by_workload_table(rs):
+    tab = {"_cols": ["ms_per_step", "frac", "bound", "hbm_frac_algorithmic", "traffic_over_algorithmic"]}
+    for wl, r in rs.items():
+        rf, hb = r.get("roofline", {}), r.get("hbm", {})
+        alg = hb.get("algorithmic_bytes_per_launch") or hb.get("algorithmic_bytes_per_step") or rf.get("algorithmic_bytes_per_launch")
+        ms = rf.get("kernel_ms") or r.get("ms_per_step")
+        tr = rf.get("traffic")
+        tab[wl] = [r.get("ms_per_step"), rf.get("frac"), rf.get("bound"),
+                   None if not (alg and ms) else round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                   None if not (alg and tr) else round(tr / alg, 3)]
+    return tab
 
 
 def main():
@@ -1709,10 +1981,26 @@ def main():
             r.setdefault("warmup", a.warmup)
         return r
 
+    multi_note = {"value": None, "note": "measured on rank 0 at N = 1 only (the bench contract): see the --gpus 1 line of the same build"}
+
+    def same_fields(r):
+        """An N > 1 line carries the same fields as the N = 1 line: roofline.traffic falls back to the committed counter
+        passes (measured_traffic says so), cpu_baseline is a note."""
+        if isinstance(r, dict) and "roofline" in r:
+            r.setdefault("cpu_baseline", dict(multi_note))
+        return r
+
     if args.workload == "stub":
         line = dict(common, **run_stub(args, dist))
     elif args.workload == "all":
         rs = {wl: run(wl) for wl in ALL_WORKLOADS}
+        if dist.world > 1 and not args.pmc_child:
+            # strong scaling of ONE configs[4] acquisition (SURVEY.md 8e, first bullet): the same block on every GPU, the 59
+            # SVs dealt over the ranks by cost, winners all-gathered over RCCL every step -- so that a driver SCALE run
+            # (N = 1, 2, 4, 8 of this command) records it beside the weak-scaling workloads
+            args.shard = "sv"
+            rs["acq10ms_sv"] = run("acq10ms")
+            args.shard = "blocks"
         if args.pmc_child:
             line = {"pmc_child": list(rs)}
         else:
@@ -1720,12 +2008,27 @@ def main():
             line = dict(a, **common)
             line["metric"] = "IQ Msamples/s ingested (waterfall + GPS acq); value = GPS acq, BASELINE configs[1]"
             line["workloads"] = dict({"acq": {k: a[k] for k in a if k not in ("metric", "config")}},
-                                     **{wl: rs[wl] for wl in ALL_WORKLOADS[1:]})
+                                     **{wl: rs[wl] for wl in rs if wl != "acq"})
             line["config"]["also_in_this_line"] = ("workloads.wf14 / ddc14 / cfg2_chain: BASELINE configs[2] (frames, DDC, end to "
-                                                   "end); workloads.receivers: configs[3] per-GPU share; workloads.acq10ms: configs[4]")
+                                                   "end); workloads.receivers: configs[3] per-GPU share; workloads.acq10ms: configs[4]"
+                                                   + ("; workloads.acq10ms_sv: configs[4] with the SVs split over the GPUs (strong)"
+                                                      if "acq10ms_sv" in rs else ""))
+            if dist.world > 1:
+                same_fields(line)
+                for r in line["workloads"].values():
+                    same_fields(r)
+            # every workload's step time, roofline fraction and traffic ratio in ONE compact object inside `roofline`, so that
+            # a record that keeps only the top-level keys still holds all of them: [ms_per_step, frac of the roof that
+            # binds it (roofline.bound of the workload), algorithmic HBM bytes / time as a fraction of 8 TB/s, counter
+            # traffic / algorithmic bytes]
+            line["roofline"] = dict(line["roofline"], by_workload=by_workload_table(rs))
     else:
         r = run(args.workload)
         line = dict(common, **r)
+        if dist.world > 1:
+            same_fields(line)
+    if args.workload != "stub" and not args.pmc_child:
+        line["box"] = box_identity(dist.local_rank)
     if dist.rank == 0:
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     dist.close()

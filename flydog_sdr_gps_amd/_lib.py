@@ -7,7 +7,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class KiwiGpuError(RuntimeError):
@@ -89,7 +89,7 @@ SYMBOLS = {
     "kg_wf_set_tables": (_i, [_vp, _vp, _vp]),
     "kg_wf_set_channel": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "kg_wf_frames_dev": (_i, [_vp, _i, _vp, _vp, _vp]),
-    "kg_wf_frames_at_dev": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "kg_wf_frames_at_dev": (_i, [_vp, _i, _vp, _vp, C.c_uint64, _vp, _vp]),
     "kg_wf_frames": (_i, [_vp, _i, _vp, _vp, _vp]),
     "kg_wf_debug_frame": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "kg_ddc_create": (_i, [_vp, _i, _sz, C.POINTER(_vp)]),
@@ -97,6 +97,7 @@ SYMBOLS = {
     "kg_ddc_set_wf": (_i, [_vp, _i, C.c_uint64, _i]),
     "kg_ddc_reset_wf": (_i, [_vp, _i]),
     "kg_ddc_set_phase": (_i, [_vp, _i, C.c_uint64]),
+    "kg_ddc_nco_table": (_i, [_vp, _vp]),
     "kg_ddc_wf_outputs": (C.c_long, [_vp, _i, _sz]),
     "kg_ddc_wf_push_dev": (_i, [_vp, _vp, _sz, _vp, _i, _vp, _sz, _vp]),
     "kg_rxddc_create": (_i, [_vp, _i, _sz, C.POINTER(_vp)]),

@@ -1321,8 +1321,8 @@ static int acq_init(kg_acq *a)
         a->ev_done.push_back(e2);
     }
     KG_HIP(hipMemset(a->d_data, 0, spec * max_blocks));
-    KG_HIP(hipMalloc((void **) &a->d_data_b, spec * max_blocks));      // (freed again below if the 512-thread kernel is off)
-    KG_HIP(hipMemset(a->d_data_b, 0, spec * max_blocks));
+    a->d_data_b = nullptr;      // layout B: allocated (and from then on written by every Sample()) when the first code with a
+                                // window longer than 4096 lags is set (ensure_data_b) -- a C/A-only searcher never pays for it
     KG_HIP(hipFuncSetAttribute((const void *) acq_fft_sub_kernel<false>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SUB * sizeof(float2)));
     KG_HIP(hipFuncSetAttribute((const void *) acq_fft_sub_kernel<true>,
@@ -1363,7 +1363,6 @@ static int acq_init(kg_acq *a)
             a->grid8 = ctx->num_cus & ~7;
             if (a->grid8 < 8) a->grid8 = 8;
         }
-        if (a->grid8 == 0) { (void) hipFree(a->d_data_b); a->d_data_b = nullptr; }
     }
     if (a->grid1 < 8) a->grid1 = 8;
     if (a->grid4 < 8) a->grid4 = 8;
@@ -1437,6 +1436,37 @@ void kg_acq_destroy(kg_acq *a)
     delete a;
 }
 
+// The 512-thread correlator reads the data spectra in layout B.  The second copy exists only once an SV needs it: the
+// blocks sampled before that moment (none in the reference's order, SearchInit before Sample) are converted through the
+// host, once; afterwards every Sample() writes both layouts in its combine kernel.
+static int ensure_data_b(kg_acq *a)
+{
+    if (a->d_data_b || a->grid8 == 0) return KG_OK;
+    const size_t n = (size_t) a->fft_len * a->max_blocks;
+    KG_HIP(hipStreamSynchronize(a->fstream));
+    KG_HIP(hipStreamSynchronize(a->ctx->stream));
+    float2 *d = nullptr;
+    KG_HIP(hipMalloc((void **) &d, sizeof(float2) * n));
+    std::vector<float2> pl(a->fft_len), plb, all(n);
+    std::vector<float> nat(2 * (size_t) a->fft_len);
+    if (hipMemcpy(all.data(), a->d_data, sizeof(float2) * n, hipMemcpyDeviceToHost) != hipSuccess) {
+        (void) hipFree(d);
+        KG_REQUIRE(false, KG_ERR_HIP, "ensure_data_b: download of the data spectra failed");
+    }
+    for (int b = 0; b < a->max_blocks; b++) {
+        pl.assign(all.begin() + (size_t) b * a->fft_len, all.begin() + (size_t) (b + 1) * a->fft_len);
+        from_planes(pl, nat.data(), a->P, 0, 0);
+        to_planes(nat.data(), plb, a->P, 0, 1);
+        memcpy(all.data() + (size_t) b * a->fft_len, plb.data(), sizeof(float2) * a->fft_len);
+    }
+    if (hipMemcpy(d, all.data(), sizeof(float2) * n, hipMemcpyHostToDevice) != hipSuccess) {
+        (void) hipFree(d);
+        KG_REQUIRE(false, KG_ERR_HIP, "ensure_data_b: upload of layout B failed");
+    }
+    a->d_data_b = d;
+    return KG_OK;
+}
+
 static int set_limit(kg_acq *a, int sat, int limit)
 {
     KG_REQUIRE(sat >= 0 && sat < a->max_sats, KG_ERR_INVALID, "sat %d out of range (0..%d)", sat,
@@ -1445,6 +1475,10 @@ static int set_limit(kg_acq *a, int sat, int limit)
                4 * SUB);
     a->limits[sat] = limit;
     a->code_layout[sat] = (limit > SUB && a->grid8 > 0) ? 1 : 0;     // which kernel will read this SV's code spectrum
+    if (a->code_layout[sat]) {
+        int rc = ensure_data_b(a);
+        if (rc) return rc;
+    }
     a->code_set[sat] = 1;
     a->last_sats.clear();        // force the pair tables to be rebuilt
     return KG_OK;

@@ -79,3 +79,11 @@ static inline int kg_ctx_use(kg_ctx *ctx)
     KG_HIP(hipSetDevice(ctx->device));
     return KG_OK;
 }
+
+// The DDCs' NCO table (frozen by us: the Xilinx DDS core of verilog/rx/iq_mixer.v is closed IP), as ONE 16-bit sine
+// table of KG_NCO_TAB = 10240 entries: T[j] = round(16383 sin(2 pi j / 8192)) for j < 8192 and, BY CONSTRUCTION,
+// T[j] = T[j - 8192] beyond.  sin(a) = T[a], cos(a) = T[a + 2048] for a < 8192: two sign-extending 16-bit LDS reads
+// from one address.  That this equals round(16383 cos(2 pi a / 8192)) -- the oracle's definition -- is checked once in
+// the CPU suite through kg_ddc_nco_table (tests/test_host_cpu.py), not at run time.
+#define KG_NCO_TAB 10240
+extern "C" __attribute__((visibility("hidden"))) void kg_nco_table_build(short *tab);        // kg_ctx.hip (not part of the ABI: kg_ddc_nco_table is)

@@ -106,6 +106,21 @@ const char *kg_last_error(void) { return g_err; }
 
 int kg_abi_version(void) { return KG_ABI_VERSION; }
 
+void kg_nco_table_build(short *tab)
+{
+    for (int j = 0; j < 8192; j++) tab[j] = (short) lrint(16383.0 * sin(2.0 * M_PI * j / 8192.0));
+    for (int j = 8192; j < KG_NCO_TAB; j++) tab[j] = tab[j - 8192];
+}
+
+int kg_ddc_nco_table(int16_t *cos_tab, int16_t *sin_tab)
+{
+    KG_REQUIRE(cos_tab && sin_tab, KG_ERR_INVALID, "kg_ddc_nco_table: null argument");
+    short tab[KG_NCO_TAB];
+    kg_nco_table_build(tab);
+    for (int a = 0; a < 8192; a++) { sin_tab[a] = tab[a]; cos_tab[a] = tab[a + 2048]; }
+    return KG_OK;
+}
+
 const char *kg_strerror(int s)
 {
     switch (s) {

@@ -105,7 +105,7 @@ DDC_DEV int mix24(int adc, int dds)
 }
 
 #define DDC_THREADS 256
-#define DDC_TAB 10240             // NCO table entries: sin(a) = T[a], cos(a) = T[a + 2048], a < 8192
+#define DDC_TAB KG_NCO_TAB            // NCO table entries: sin(a) = T[a], cos(a) = T[a + 2048], a < 8192
 #ifndef DDC_STAGE_STROBES
 #define DDC_STAGE_STROBES 16      // strobes per run collected before a flush: 64 bytes per run and store (8 = half lines: ddc14 +6 %)
 #endif
@@ -539,7 +539,7 @@ DDC_DEV u64 shfl64(u64 v, int src)
 // the 128 x 128-bit product took some forty-five instructions, and a state crosses lanes in 12 shuffles, not 32.
 struct u96 { u32 w[3]; };
 struct sc4 { u96 i[4]; };                     // integrators 1..4, mod 2^96
-struct sc_coef { u64 L, c2; u96 c3; };        // len, len (len+1) / 2, len (len+1) (len+2) / 6 mod 2^96 (len <= 2^32)
+struct sc_coef { u64 L, c2; u96 c3; };        // len, len (len+1) / 2 (exact: len < 2^32, asserted where the table is built), len (len+1) (len+2) / 6 mod 2^96
 DDC_DEV u96 u96_zero() { u96 r; r.w[0] = r.w[1] = r.w[2] = 0; return r; }
 DDC_DEV u96 u96_of(const u128 &v) { u96 r; r.w[0] = (u32) v.lo; r.w[1] = (u32) (v.lo >> 32); r.w[2] = (u32) v.hi; return r; }
 DDC_DEV u128 u128_of(const u96 &v) { return mk128((u64) v.w[0] | ((u64) v.w[1] << 32), (u64) v.w[2]); }
@@ -977,17 +977,9 @@ int kg_ddc_create(kg_ctx *ctx, int nchan, size_t max_samples, kg_ddc **out)
     KG_HIP(hipMalloc((void **) &d->d_ticket, sizeof(u32)));
     KG_HIP(hipMemset(d->d_ticket, 0, sizeof(u32)));
     d->ticket_base = 0; d->epoch = 0;
-    // NCO table (frozen by us; the Xilinx DDS IP is closed): round(16383 * cos/sin(2 pi a / 8192)), kept as ONE
-    // 16-bit table of 10240 entries T[j] = sin(2 pi j / 8192): sin(a) = T[a], cos(a) = T[a + 2048] -- two
-    // sign-extending 16-bit LDS reads from one address (no unpacking), 20 KiB per workgroup instead of 32.
-    // The entries past 8191 are the cosine's; where both definitions apply they must agree value for value.
+    // NCO table: ONE 16-bit sine table, sin(a) = T[a], cos(a) = T[a + 2048] (kg_common.h, kg_nco_table_build)
     std::vector<short> tab(DDC_TAB);
-    for (int j = 0; j < DDC_TAB; j++) {
-        const double ps = 2.0 * M_PI * j / 8192.0, pc = 2.0 * M_PI * (j - 2048) / 8192.0;
-        const short s = (short) lrint(16383.0 * sin(ps)), c = (short) lrint(16383.0 * cos(pc));
-        KG_REQUIRE(j < 2048 || j >= 8192 || s == c, KG_ERR_STATE, "kg_ddc_create: NCO table: sin(%d) != cos(%d)", j, j - 2048);
-        tab[j] = j < 8192 ? s : c;
-    }
+    kg_nco_table_build(tab.data());
     KG_HIP(hipMemcpy(d->d_nco, tab.data(), sizeof(short) * DDC_TAB, hipMemcpyHostToDevice));
     *out = d;
     return KG_OK;
@@ -1213,7 +1205,13 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
             for (int j = 0; j < DDC_SCAN_TAB; j++) {
                 const u64 len = j < 9 ? u << j : v << (j - 9);
                 const unsigned __int128 l = len;
-                const unsigned __int128 c2 = l * (l + 1) / 2;                     // len <= 2^36: below 2^73
+                // sc_coef keeps c2 = len (len + 1) / 2 in 64 bits (host table and sc_coef_for alike): exact while len < 2^32.
+                // The longest advance is v << 3 <= 8 (n + nchunk L) with n <= max_runs x DDC_RUN_MAX = 2^27 samples per push.
+                static_assert((unsigned long long) DDC_TARGET_RUNS * 2 * DDC_RUN_MAX * 16 <= (1ull << 32),
+                              "sc_coef.c2 is 64 bits wide: an advance of 2^32 samples or more needs a u96 there");
+                KG_REQUIRE(len < (1ull << 32), KG_ERR_INVALID, "kg_ddc_wf_push_dev: scan advance %llu too long for the 64-bit c2",
+                           (unsigned long long) len);
+                const unsigned __int128 c2 = l * (l + 1) / 2;                     // len < 2^32: below 2^63
                 // len (len + 1) (len + 2) / 6 mod 2^96: c2 (len + 2) is 3 x the binomial; divide the exact product
                 // (below 2^111) by 3
                 const unsigned __int128 c3 = c2 * (l + 2) / 3;

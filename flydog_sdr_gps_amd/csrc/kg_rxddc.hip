@@ -37,7 +37,7 @@ typedef unsigned int u32;
 
 #define RX_HIST 256          // rx1 outputs kept from earlier calls (a final output spans 203 of them)
 #define RX_THREADS 256
-#define RX_TAB 10240
+#define RX_TAB KG_NCO_TAB
 
 // The three RX instances the reference builds (kiwi.config:101-105, fir_iq.sv:39-123); the widths
 // are what verilog/rx/cic_gen.c emits for those decimations (tests/golden/cic_ref.json):
@@ -466,14 +466,9 @@ int kg_rxddc_create_mode(kg_ctx *ctx, int nchan, size_t max_samples, int mode, k
     KG_HIP(hipMalloc((void **) &d->d_hist, sizeof(u32) * 6 * (size_t) nchan));
     KG_HIP(hipMalloc((void **) &d->d_c1buf, sizeof(int) * 2 * (size_t) nchan * d->c1_stride));
     KG_HIP(hipMemset(d->d_c1buf, 0, sizeof(int) * 2 * (size_t) nchan * d->c1_stride));
-    // the NCO table as one 16-bit sine table of 10240 entries (kg_ddc.hip, kg_ddc_create): cos(a) = T[a + 2048]
+    // the NCO table as one 16-bit sine table of 10240 entries: cos(a) = T[a + 2048] (kg_common.h, kg_nco_table_build)
     std::vector<short> tab(RX_TAB);
-    for (int j = 0; j < RX_TAB; j++) {
-        const double ps = 2.0 * M_PI * j / 8192.0, pc = 2.0 * M_PI * (j - 2048) / 8192.0;
-        const short s = (short) lrint(16383.0 * sin(ps)), c = (short) lrint(16383.0 * cos(pc));
-        KG_REQUIRE(j < 2048 || j >= 8192 || s == c, KG_ERR_STATE, "kg_rxddc_create: NCO table: sin(%d) != cos(%d)", j, j - 2048);
-        tab[j] = j < 8192 ? s : c;
-    }
+    kg_nco_table_build(tab.data());
     KG_HIP(hipMemcpy(d->d_nco, tab.data(), sizeof(short) * RX_TAB, hipMemcpyHostToDevice));
     *out = d;
     return KG_OK;

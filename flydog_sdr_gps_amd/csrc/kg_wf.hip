@@ -434,8 +434,8 @@ int kg_wf_set_channel(kg_wf *w, int ch, const kg_wf_chan_cfg *cfg, const uint16_
     return KG_OK;
 }
 
-static int wf_launch(kg_wf *w, int nframes, const int32_t *chan_of, const uint64_t *frame_off, const void *d_iq,
-                     void *d_out, bool taps)
+static int wf_launch(kg_wf *w, int nframes, const int32_t *chan_of, const uint64_t *frame_off, uint64_t iq_len,
+                     const void *d_iq, void *d_out, bool taps)
 {
     KG_REQUIRE(w->tables_set, KG_ERR_STATE, "kg_wf_frames: kg_wf_set_tables was not called");
     KG_REQUIRE(nframes >= 1, KG_ERR_INVALID, "kg_wf_frames: nframes %d", nframes);
@@ -450,7 +450,12 @@ static int wf_launch(kg_wf *w, int nframes, const int32_t *chan_of, const uint64
     for (int f = 0; f < nframes; f++) {
         const uint64_t off = frame_off ? frame_off[f] : (uint64_t) f * WF_NFFT;
         KG_REQUIRE((off & 1) == 0 && off < ((uint64_t) 1 << 32), KG_ERR_INVALID,
-                   "kg_wf_frames: frame_off[%d] = %llu (even, below 2^32 samples)", f, (unsigned long long) off);
+                   "kg_wf_frames: frame_off[%d] = %llu (even, below 2^32 samples; back-to-back frames: nframes <= 524288)",
+                   f, (unsigned long long) off);
+        // the caller states the extent of what d_iq points at: a stale offset must not become an out-of-bounds read
+        KG_REQUIRE(!frame_off || off + WF_NFFT <= iq_len, KG_ERR_INVALID,
+                   "kg_wf_frames_at_dev: frame %d at %llu + 8192 runs past iq_len %llu", f, (unsigned long long) off,
+                   (unsigned long long) iq_len);
         w->frame_tab[f] = make_int2(chan_of[f], (int) (unsigned) (off >> 1));
     }
     void *d_chan_of = nullptr;                 // the arrays are the caller's: staged copy, no stream synchronisation
@@ -483,18 +488,18 @@ int kg_wf_frames_dev(kg_wf *w, int nframes, const int32_t *chan_of, const void *
     if (rc) return rc;
     KG_REQUIRE(((uintptr_t) d_iq & 7) == 0 && ((uintptr_t) d_out & 3) == 0, KG_ERR_INVALID,
                "kg_wf_frames_dev: d_iq must be 8-byte and d_out 4-byte aligned");
-    return wf_launch(w, nframes, chan_of, nullptr, d_iq, d_out, false);
+    return wf_launch(w, nframes, chan_of, nullptr, 0, d_iq, d_out, false);
 }
 
-int kg_wf_frames_at_dev(kg_wf *w, int nframes, const int32_t *chan_of, const uint64_t *frame_off, const void *d_iq,
-                        void *d_out)
+int kg_wf_frames_at_dev(kg_wf *w, int nframes, const int32_t *chan_of, const uint64_t *frame_off, uint64_t iq_len,
+                        const void *d_iq, void *d_out)
 {
     KG_REQUIRE(w && chan_of && frame_off && d_iq && d_out, KG_ERR_INVALID, "kg_wf_frames_at_dev: null argument");
     int rc = kg_ctx_use(w->ctx);
     if (rc) return rc;
     KG_REQUIRE(((uintptr_t) d_iq & 7) == 0 && ((uintptr_t) d_out & 3) == 0, KG_ERR_INVALID,
                "kg_wf_frames_at_dev: d_iq must be 8-byte and d_out 4-byte aligned");
-    return wf_launch(w, nframes, chan_of, frame_off, d_iq, d_out, false);
+    return wf_launch(w, nframes, chan_of, frame_off, iq_len, d_iq, d_out, false);
 }
 
 static int wf_stage(kg_wf *w, int nframes)
@@ -520,7 +525,7 @@ int kg_wf_frames(kg_wf *w, int nframes, const int32_t *chan_of, const int16_t *i
     if ((rc = wf_stage(w, nframes)) != KG_OK) return rc;
     hipStream_t st = w->ctx->stream;
     KG_HIP(hipMemcpyAsync(w->d_iq, iq, sizeof(short2) * WF_NFFT * (size_t) nframes, hipMemcpyHostToDevice, st));
-    if ((rc = wf_launch(w, nframes, chan_of, nullptr, w->d_iq, w->d_out, false)) != KG_OK) return rc;
+    if ((rc = wf_launch(w, nframes, chan_of, nullptr, 0, w->d_iq, w->d_out, false)) != KG_OK) return rc;
     KG_HIP(hipMemcpyAsync(out, w->d_out, (size_t) WF_WIDTH * nframes, hipMemcpyDeviceToHost, st));
     KG_HIP(hipStreamSynchronize(st));
     return KG_OK;
@@ -541,7 +546,7 @@ int kg_wf_debug_frame(kg_wf *w, int ch, const int16_t *iq, uint8_t *out, float *
     KG_HIP(hipMemsetAsync(w->d_tap_pwr, 0, sizeof(float) * SUB, st));
     KG_HIP(hipMemcpyAsync(w->d_iq, iq, sizeof(short2) * WF_NFFT, hipMemcpyHostToDevice, st));
     const int32_t c = ch;
-    if ((rc = wf_launch(w, 1, &c, nullptr, w->d_iq, w->d_out, true)) != KG_OK) return rc;
+    if ((rc = wf_launch(w, 1, &c, nullptr, 0, w->d_iq, w->d_out, true)) != KG_OK) return rc;
     KG_HIP(hipMemcpyAsync(out, w->d_out, WF_WIDTH, hipMemcpyDeviceToHost, st));
     KG_HIP(hipMemcpyAsync(pwr, w->d_tap_pwr, sizeof(float) * SUB, hipMemcpyDeviceToHost, st));
     KG_HIP(hipMemcpyAsync(pwr_out, w->d_tap_pwr_out, sizeof(float) * WF_WIDTH, hipMemcpyDeviceToHost, st));

@@ -158,9 +158,10 @@ class Waterfall:
               "kg_wf_frames")
         return out
 
-    def frames_dev(self, chan_of, d_iq, d_out, frame_off=None):
+    def frames_dev(self, chan_of, d_iq, d_out, frame_off=None, iq_len=None):
         """Device pointers (ints); enqueue only.  frame_off: where each frame starts, in iq_t pairs
-        after d_iq (default: frames back to back)."""
+        after d_iq (default: frames back to back); iq_len: how many pairs d_iq points at (required
+        with frame_off: a frame that would run past it is rejected, never read)."""
         chan_of = np.ascontiguousarray(chan_of, np.int32)
         if frame_off is None:
             check(self.lib.kg_wf_frames_dev(self.h, chan_of.size, ptr(chan_of), ptr(int(d_iq)),
@@ -169,8 +170,10 @@ class Waterfall:
         frame_off = np.ascontiguousarray(frame_off, np.uint64)
         if frame_off.size != chan_of.size:
             raise ValueError("frame_off and chan_of differ in length")
-        check(self.lib.kg_wf_frames_at_dev(self.h, chan_of.size, ptr(chan_of), ptr(frame_off), ptr(int(d_iq)),
-                                           ptr(int(d_out))), "kg_wf_frames_at_dev")
+        if iq_len is None:
+            raise ValueError("frames_dev(frame_off=...) needs iq_len, the extent of d_iq in iq_t pairs")
+        check(self.lib.kg_wf_frames_at_dev(self.h, chan_of.size, ptr(chan_of), ptr(frame_off), int(iq_len),
+                                           ptr(int(d_iq)), ptr(int(d_out))), "kg_wf_frames_at_dev")
 
     def debug_frame(self, ch, iq):
         iq = np.ascontiguousarray(iq, np.int16).reshape(WF_NFFT, 2)

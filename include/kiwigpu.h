@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define KG_ABI_VERSION 1
+#define KG_ABI_VERSION 2     /* 2 (round 4): kg_wf_frames_at_dev takes the extent of d_iq; kg_ctx_mark; code spectra in layout B */
 
 typedef enum {
     KG_OK = 0,
@@ -230,14 +230,17 @@ int kg_wf_set_channel(kg_wf *wf, int ch, const kg_wf_chan_cfg *cfg, const uint16
                       const float *fft_scale_div2);
 /* nframes frames; frame f belongs to channel chan_of[f] (host array), its input is
  * iq[f][8192] {int16 i, int16 q} (struct iq_t, :95-97) and its output out[f][1024]
- * bytes (wf_pkt_t.un.buf).  _dev: device pointers, enqueue only. */
+ * bytes (wf_pkt_t.un.buf).  _dev: device pointers, enqueue only.  A frame's start is
+ * kept as a 32-bit sample offset: nframes <= 524288 (2^32 / 8192) per call. */
 int kg_wf_frames_dev(kg_wf *wf, int nframes, const int32_t *chan_of, const void *d_iq, void *d_out);
 int kg_wf_frames(kg_wf *wf, int nframes, const int32_t *chan_of, const int16_t *iq, uint8_t *out);
 /* The same for frames that are NOT back to back: frame f starts frame_off[f] samples (iq_t pairs; even,
  * below 2^32) after d_iq -- frames taken where the DDC left them (kg_ddc_wf_push_dev's per-channel rows),
- * the way sample_wf() reads the FPGA's sample ring in place (rx/rx_waterfall.cpp:1036-1066). */
+ * the way sample_wf() reads the FPGA's sample ring in place (rx/rx_waterfall.cpp:1036-1066).  iq_len = how
+ * many iq_t pairs d_iq points at: every frame must satisfy frame_off[f] + 8192 <= iq_len (KG_ERR_INVALID
+ * otherwise -- an offset is never turned into a device read outside the caller's buffer). */
 int kg_wf_frames_at_dev(kg_wf *wf, int nframes, const int32_t *chan_of, const uint64_t *frame_off,
-                        const void *d_iq, void *d_out);
+                        uint64_t iq_len, const void *d_iq, void *d_out);
 /* One frame with the intermediate arrays of compute_frame(): pwr[4096] (entries
  * below fft_used are written), pwr_out[1024], dB[1024] (before the clamp). */
 int kg_wf_debug_frame(kg_wf *wf, int ch, const int16_t *iq, uint8_t *out, float *pwr,
@@ -262,6 +265,11 @@ int kg_ddc_set_wf(kg_ddc *ddc, int ch, uint64_t phase_inc, int decim);
  * counter; the NCO phase keeps running. */
 int kg_ddc_reset_wf(kg_ddc *ddc, int ch);
 int kg_ddc_set_phase(kg_ddc *ddc, int ch, uint64_t phase);
+/* The NCO sine / cosine tables both DDCs use (8192 int16 entries each, addressed by phase bits 47:35):
+ * round(16383 cos / sin(2 pi a / 8192)) -- the frozen stand-in for the closed Xilinx DDS core of
+ * verilog/rx/iq_mixer.v:60-65 (no dither).  Host function, needs no GPU; the device keeps the two as one
+ * 10240-entry sine table (cos a = T[a + 2048]). */
+int kg_ddc_nco_table(int16_t *cos_tab, int16_t *sin_tab);
 /* IQ pairs channel ch will produce for the next n ADC samples. */
 long kg_ddc_wf_outputs(kg_ddc *ddc, int ch, size_t n);
 /* Run n ADC samples (device int16 array) through the listed channels.  Channel

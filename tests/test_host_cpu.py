@@ -147,7 +147,7 @@ def test_library_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(kg_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     lib = _lib.load_library()                      # raises if the .so is missing a symbol
-    assert lib.kg_abi_version() == 1
+    assert lib.kg_abi_version() == _lib.ABI_VERSION == 2          # bumped with every change of an existing signature or layout
     assert lib.kg_strerror(-1).decode().startswith("no usable")
 
 
@@ -177,6 +177,65 @@ def test_shard_helpers():
                                         (45, 52), (52, 59)]
     with pytest.raises(ValueError):
         shard.block_ids(4, 4, 1)
+
+
+def test_weighted_sv_split_is_balanced_and_a_partition():
+    """shard.split_units_weighted on the reference's own SV order (gps/sats.cpp:25-142: 36 C/A + QZSS rows, then the 23
+    E1B rows, an E1B SV costing 1.6 C/A ones): the worst rank within 105 % of the mean at world 2, 4, 8 (the
+    contiguous split: 124 % at world 8); every SV in exactly one share; shares ascending; deterministic."""
+    from flydog_sdr_gps_amd import sats, shard
+    is_e1b = [row[3] == sats.E1B for row in sats.SATS]
+    assert (len(is_e1b), sum(is_e1b)) == (59, 23) and not any(is_e1b[:36])
+    w = shard.sv_weights(is_e1b)
+    mean_of = lambda world: sum(w) / world                                  # noqa: E731
+    for world in (1, 2, 3, 4, 5, 6, 7, 8):
+        shares = shard.split_units_weighted(w, world)
+        assert len(shares) == world and sorted(i for sh in shares for i in sh) == list(range(59))
+        assert all(sh == sorted(sh) for sh in shares)
+        worst = max(sum(w[i] for i in sh) for sh in shares)
+        assert worst <= 1.05 * mean_of(world), (world, worst / mean_of(world))
+        assert shares == shard.split_units_weighted(w, world)
+    contiguous = max(sum(w[i] for i in range(lo, hi)) for lo, hi in shard.split_units(59, 8))
+    assert contiguous > 1.2 * mean_of(8)                                    # what the weighted split replaces
+    # degenerate shapes: more ranks than units, one unit, equal weights
+    assert sorted(map(tuple, shard.split_units_weighted([1.0, 1.0], 4))) == [(), (), (0,), (1,)]
+    assert shard.split_units_weighted([2.5], 1) == [[0]]
+    eq = shard.split_units_weighted([1.0] * 32, 8)
+    assert sorted(len(sh) for sh in eq) == [4] * 8
+    with pytest.raises(ValueError):
+        shard.split_units_weighted([1.0, 0.0], 2)
+
+
+def test_merge_sv_shards_takes_index_lists():
+    from flydog_sdr_gps_amd import shard
+    from flydog_sdr_gps_amd._lib import result_dtype
+    B, shares = 2, [[0, 3, 4], [1, 5], [2, 6]]
+    full = np.zeros((B, 7), result_dtype)
+    full["snr"] = np.arange(14).reshape(B, 7)
+    full["idx"] = 100 + full["snr"].astype(int)
+    parts = np.zeros((3, B * 3), result_dtype)
+    for r, sh in enumerate(shares):
+        parts[r, :B * len(sh)] = full[:, sh].reshape(-1)
+        parts[r, B * len(sh):]["snr"] = -1
+    assert np.array_equal(shard.merge_sv_shards(parts, B, shares), full)
+    with pytest.raises(AssertionError):
+        shard.merge_sv_shards(parts, B, [[0, 1], [1, 2], [3]])              # not a partition
+
+
+def test_nco_table_by_construction_equals_the_oracle_definition(oracle):
+    """kg_ddc_nco_table (host function of libkiwigpu, no GPU): the device's ONE sine table with cos(a) = T[a + 2048]
+    against the oracle's two separately rounded tables round(16383 cos / sin(2 pi a / 8192)) -- checked here once
+    instead of inside kg_ddc_create / kg_rxddc_create (a libm that rounds a half-way point differently
+    must fail a test, not a create call)."""
+    import ctypes as C
+    from flydog_sdr_gps_amd import load_library
+    lib = load_library()
+    c = np.empty(8192, np.int16)
+    s = np.empty(8192, np.int16)
+    assert lib.kg_ddc_nco_table(c.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p)) == 0
+    want_c, want_s = oracle.ddc_nco_table()
+    assert np.array_equal(s, want_s) and np.array_equal(c, want_c)
+    assert (int(c[0]), int(s[2048]), int(c[4096]), int(s[6144])) == (16383, 16383, -16383, -16383)
 
 
 def test_best_of_merges_like_serial_scan():
@@ -256,7 +315,7 @@ def test_bench_gpus_flag_launches_ranks():
 
 def test_bench_shard_sv_world2_on_the_stub():
     """`bench.py --workload acq10ms --shard sv` splits the 59 SVs of ONE block over the ranks, all-gathers the
-    winners and merges them (shard.split_units / merge_sv_shards).  The exchange runs here at world 2 over gloo
+    winners and merges them (shard.split_units_weighted / merge_sv_shards).  The exchange runs here at world 2 over gloo
     on the GPU-free stub: the merged table must equal the unsharded one (asserted inside, reported in the line)."""
     import json
     bench = os.path.join(ROOT, "bench.py")
@@ -265,8 +324,12 @@ def test_bench_shard_sv_world2_on_the_stub():
                          capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout + out.stderr
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
-    assert line["scaling"] == "strong" and line["shard_sv"] == {"world": 2, "ranges": [[0, 30], [30, 59]],
-                                                                  "merged_equals_unsharded": True}
+    sv = line["shard_sv"]
+    assert line["scaling"] == "strong" and sv["world"] == 2 and sv["merged_equals_unsharded"] is True
+    # the cost-balanced split (shard.split_units_weighted): both kinds of SV on both ranks, a partition of the 59
+    assert sorted(sv["shares"][0] + sv["shares"][1]) == list(range(59))
+    assert all(any(i < 36 for i in sh) and any(i >= 36 for i in sh) for sh in sv["shares"])
+    assert max(sv["load"]) <= 1.05 * sum(sv["load"]) / 2
 
 
 def test_merge_sv_shards_layout():

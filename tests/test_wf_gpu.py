@@ -206,7 +206,7 @@ def test_frames_read_in_place_at_offsets(engine, gpu_ctx, oracle, tables):
     """kg_wf_frames_at_dev: frames that are not back to back (taken where the DDC left them: per-channel rows, a
     frame starting anywhere on an even sample).  Five frames scattered over a buffer in a shuffled order, offsets
     changing between two calls of the same length -- every row against the oracle on the samples at ITS offset;
-    an odd offset is refused."""
+    an odd offset, or a frame that would run past the stated extent of the buffer, is refused."""
     from flydog_sdr_gps_amd import KiwiGpuError
     zooms = [0, 4, 9]
     ps = []
@@ -227,7 +227,7 @@ def test_frames_read_in_place_at_offsets(engine, gpu_ctx, oracle, tables):
                 buf[off:off + 8192] = fr
             chan_of = [1, 0, 2, 1, 0]
             gpu_ctx.upload(d_iq, buf)
-            engine.frames_dev(chan_of, d_iq, d_out, frame_off=offs)
+            engine.frames_dev(chan_of, d_iq, d_out, frame_off=offs, iq_len=nbuf)
             out = np.zeros((5, 1024), np.uint8)
             gpu_ctx.download(d_out, out)
             for k, ch in enumerate(chan_of):
@@ -235,7 +235,13 @@ def test_frames_read_in_place_at_offsets(engine, gpu_ctx, oracle, tables):
                                                     wf.WINF_HANNING, True, False, False)
                 check_row(out[k], w_out, w_dB, db_bound(w_po))
         with pytest.raises(KiwiGpuError):
-            engine.frames_dev([0], d_iq, d_out, frame_off=[3])
+            engine.frames_dev([0], d_iq, d_out, frame_off=[3], iq_len=nbuf)
+        # a frame must end inside the extent the caller states: the last admissible start, then one pair past it
+        engine.frames_dev([0], d_iq, d_out, frame_off=[nbuf - 8192], iq_len=nbuf)
+        with pytest.raises(KiwiGpuError):
+            engine.frames_dev([0], d_iq, d_out, frame_off=[nbuf - 8190], iq_len=nbuf)
+        with pytest.raises(KiwiGpuError):
+            engine.frames_dev([0, 1], d_iq, d_out, frame_off=[0, 8192], iq_len=8192 + 8190)
     finally:
         gpu_ctx.free(d_iq)
         gpu_ctx.free(d_out)

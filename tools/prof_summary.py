@@ -12,6 +12,22 @@ def find(sub, pat):
     return sorted(glob.glob(os.path.join(out, sub, "**", pat), recursive=True))
 
 
+box = os.path.join(out, "box.json")
+if os.path.isfile(box):
+    print("== box " + open(box).read().strip())
+tl = os.path.join(out, "trace.log")
+if os.path.isfile(tl):                              # the bench line the traced run itself printed (its step time, same box)
+    for line in open(tl):
+        if line.startswith("{"):
+            import json
+            try:
+                d = json.loads(line)
+                rf = d.get("roofline", {})
+                print("== traced run's own line: ms_per_step %s kernel_ms %s frac %s value %s %s" % (
+                    d.get("ms_per_step"), rf.get("kernel_ms"), rf.get("frac"), d.get("value"), d.get("unit")))
+            except ValueError:
+                pass
+
 for f in find("trace", "*kernel_stats.csv"):
     print("== kernel stats (%s)" % os.path.relpath(f, out))
     rows = list(csv.DictReader(open(f)))
