@@ -98,6 +98,9 @@ SYMBOLS = {
     "kg_ddc_reset_wf": (_i, [_vp, _i]),
     "kg_ddc_set_phase": (_i, [_vp, _i, C.c_uint64]),
     "kg_ddc_nco_table": (_i, [_vp, _vp]),
+    "kg_ddc_wf_set_deferred": (_i, [_vp, _i]),
+    "kg_ddc_wf_join": (_i, [_vp, _vp]),
+    "kg_ddc_wf_tail_after": (_i, [_vp, _vp]),
     "kg_ddc_wf_outputs": (C.c_long, [_vp, _i, _sz]),
     "kg_ddc_wf_push_dev": (_i, [_vp, _vp, _sz, _vp, _i, _vp, _sz, _vp]),
     "kg_rxddc_create": (_i, [_vp, _i, _sz, C.POINTER(_vp)]),

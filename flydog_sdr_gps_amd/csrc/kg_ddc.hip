@@ -86,10 +86,15 @@ struct ddc_state4 { u128 i[4]; };            // integrators 1..4
 
 // Per-channel persistent state (HBM).
 struct ddc_chan {
-    u64 phase;            // 48-bit NCO accumulator: phase of the next sample
+    // phase and sample_no are REFERENCE values: the NCO accumulator and the decimation counter as they stood when the host
+    // last set them (set_wf / set_phase / reset).  A push passes the number of samples pushed since then (`pushed`, the
+    // same for every channel of the call) and every kernel derives its own start values from it: no kernel writes these
+    // two fields, so kernels of consecutive pushes on different streams (round 4: the deferred output stage) all read
+    // consistent values.
+    u64 phase;            // 48-bit NCO accumulator at the reference point
     u64 phase_inc;        // CmdSetWFFreq (rx_waterfall.cpp:507)
     int log2r;            // CmdSetWFDecim: R = 1 << log2r
-    u32 sample_no;        // decimation counter (cic_prune_var.v:65-80)
+    u32 sample_no;        // decimation counter (cic_prune_var.v:65-80) at the reference point
     ddc_state4 integ[2];  // I, Q integrators 1..4
     u32 integ5[2];        // 28-bit integrator 5
     u32 hist[2][5];       // integrator-5 value at the last five strobes (what the comb registers hold)
@@ -123,7 +128,8 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
     u32 *__restrict__ tau,                    // B: [nlist][2][nruns]
     const long *__restrict__ c0off, const long *__restrict__ nouts,
     const int *__restrict__ sel,              // list entries this launch covers (null: all, in order)
-    int stage_bytes)                          // pass B, R <= 8: dynamic LDS for the strobe staging tiles, else 0
+    int stage_bytes,                          // pass B, R <= 8: dynamic LDS for the strobe staging tiles, else 0
+    u64 pushed)                               // samples pushed since the channels' reference point (ddc_chan)
 {
     __shared__ short tab[DDC_TAB];
     extern __shared__ u32 stage_lds[];        // [waves][2][64][DDC_STAGE_ROW] when stage_bytes != 0
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
     if (r >= nruns) return;
     const long s0 = (long) r * L, s1 = (s0 + L < n) ? s0 + L : n;
     // the 48-bit accumulator sits in the TOP bits of a 64-bit register: it wraps by itself (no mask per sample)
-    u64 ph = (ch.phase + (u64) s0 * ch.phase_inc) << 16;
+    u64 ph = (ch.phase + (pushed + (u64) s0) * ch.phase_inc) << 16;
     const u64 inc16 = ch.phase_inc << 16;
     const int log2r = ch.log2r;
     const u64 Rm1 = (1ull << log2r) - 1;
@@ -143,7 +149,8 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
 
     if (log2r == 0) return;                   // R == 1 bypass: ddc_wf_bypass_kernel
 
-    const u64 cnt0 = (u64) ch.sample_no + (u64) s0;      // samples since the counter was last zero
+    const u64 cnt_call = ((u64) ch.sample_no + pushed) & Rm1;      // the decimation counter at the start of this call
+    const u64 cnt0 = cnt_call + (u64) s0;                // samples since the counter was last zero
     const long lI = ((long) li * 2 + 0) * nruns + r, lQ = ((long) li * 2 + 1) * nruns + r;
     u32 i5i = 0, i5q = 0;
     u32 c = (u32) (cnt0 & Rm1);                           // decimation counter, sample_no
@@ -472,16 +479,15 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
 // so it is sample-parallel: two lane-contiguous groups of four samples per thread.
 __global__ __launch_bounds__(256) void ddc_wf_bypass_kernel(
     const short *__restrict__ adc, long n, const ddc_chan *__restrict__ chans, const int *__restrict__ chan_list,
-    const int *__restrict__ bypass_list,      // list entries with R == 1
-    const u32 *__restrict__ nco, short2 *__restrict__ out, long out_stride)
+    const int *__restrict__ bypass_list, int nbypass,     // list entries with R == 1
+    const u32 *__restrict__ nco, short2 *__restrict__ out, long out_stride, u64 pushed)
 {
     __shared__ short tab[DDC_TAB];
     for (int i = threadIdx.x; i < DDC_TAB / 2; i += 256) ((u32 *) tab)[i] = nco[i];
     __syncthreads();
-    const int li = bypass_list[blockIdx.y];
-    const ddc_chan ch = chans[chan_list[li]];
-    // persistent over the 2048-sample blocks of the channel: the 32 KiB table is staged once per
-    // workgroup, not once per 8 KiB of output
+    // persistent over the 2048-sample blocks of the stream: the 20 KiB table is staged once per
+    // workgroup, not once per 8 KiB of output.  Round 4: ONE pass over the ADC samples for ALL bypass channels
+    // (the three R = 1 channels of BASELINE configs[2] each re-read the 32 MiB block: a third of this kernel's reads)
     const long nblk = (n + 2047) / 2048;
     for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         // two groups of four samples per thread, lane-contiguous: a wave's 8-byte loads cover 512
@@ -491,9 +497,6 @@ __global__ __launch_bounds__(256) void ddc_wf_bypass_kernel(
         for (int g = 0; g < 2; g++) {
             const long t0 = blk * 2048 + g * 1024 + 4 * (long) threadIdx.x;
             if (t0 >= n) continue;
-            u64 ph = (ch.phase + (u64) t0 * ch.phase_inc) << 16;    // top-aligned: wraps by itself
-            const u64 inc16 = ch.phase_inc << 16;
-            short2 *o = out + (long) li * out_stride + t0;
             short a[4];
             const bool full = t0 + 4 <= n;
             if (full && (((uintptr_t) (adc + t0)) & 7) == 0) {
@@ -502,20 +505,27 @@ __global__ __launch_bounds__(256) void ddc_wf_bypass_kernel(
             } else {
                 for (int q = 0; q < 4; q++) a[q] = (t0 + q < n) ? adc[t0 + q] : (short) 0;
             }
-            short2 r[4];
+            for (int b = 0; b < nbypass; b++) {
+                const int li = bypass_list[b];
+                const ddc_chan *ch = chans + chan_list[li];
+                const u64 inc16 = ch->phase_inc << 16;
+                u64 ph = (ch->phase + (pushed + (u64) t0) * ch->phase_inc) << 16;    // top-aligned: wraps by itself
+                short2 *o = out + (long) li * out_stride + t0;
+                short2 r[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int ec = tab[(ph >> 51) + 2048], es = tab[ph >> 51];
-                const int mi = mix24(a[q], ec), mq = mix24(a[q], es);
-                r[q] = make_short2((short) (mi >> 8), (short) (mq >> 8));
-                ph += inc16;
-            }
-            if (full && (((uintptr_t) o) & 15) == 0) {
-                int4 w0;
-                w0.x = *(int *) &r[0]; w0.y = *(int *) &r[1]; w0.z = *(int *) &r[2]; w0.w = *(int *) &r[3];
-                *(int4 *) o = w0;
-            } else {
-                for (int q = 0; q < 4; q++) if (t0 + q < n) o[q] = r[q];
+                for (int q = 0; q < 4; q++) {
+                    const int ec = tab[(ph >> 51) + 2048], es = tab[ph >> 51];
+                    const int mi = mix24(a[q], ec), mq = mix24(a[q], es);
+                    r[q] = make_short2((short) (mi >> 8), (short) (mq >> 8));
+                    ph += inc16;
+                }
+                if (full && (((uintptr_t) o) & 15) == 0) {
+                    int4 w0;
+                    w0.x = *(int *) &r[0]; w0.y = *(int *) &r[1]; w0.z = *(int *) &r[2]; w0.w = *(int *) &r[3];
+                    *(int4 *) o = w0;
+                } else {
+                    for (int q = 0; q < 4; q++) if (t0 + q < n) o[q] = r[q];
+                }
             }
         }
     }
@@ -815,7 +825,7 @@ DDC_DEV int sext32(int v, int bits) { return (v << (32 - bits)) >> (32 - bits); 
 __global__ __launch_bounds__(256) void ddc_wf_comb_kernel(
     const u32 *__restrict__ c0rel, const u32 *__restrict__ i5start, int log2L, int nruns,
     const long *__restrict__ c0off, const ddc_chan *__restrict__ chans, const int *__restrict__ chan_list, const long *__restrict__ nouts,
-    const u32 *__restrict__ cnt_before,       // [nlist] sample_no before this call
+    u64 pushed,                               // samples pushed since the channels' reference point
     const int *__restrict__ wg_start, int nlist,
     short2 *__restrict__ out, long out_stride, u32 *__restrict__ hist_out)   // [nlist][2][5]
 {
@@ -827,7 +837,7 @@ __global__ __launch_bounds__(256) void ddc_wf_comb_kernel(
     const int log2r = ch->log2r;
     const long nout = nouts[li], plane = (nout + 3) & ~3l;
     const long o0 = (long) (blockIdx.x - wg_start[li]) * DDC_COMB_TILE;
-    const u32 base = cnt_before[li];
+    const u32 base = (u32) (((u64) ch->sample_no + pushed) & ((1ull << log2r) - 1));     // sample_no before this call
     auto absolute = [&](int comp, long oo, u32 rel) -> u32 {
         const long g = ((oo + 1) << log2r) - 1 - (long) base;    // sample index of the strobe
         const int run = (int) (g >> log2L);
@@ -903,17 +913,14 @@ __global__ __launch_bounds__(256) void ddc_wf_comb_kernel(
     }
 }
 
-// after a call: phase, counter, comb history
+// after a call: the comb history (phase and counter are reference values + the host's `pushed`, see ddc_chan)
 __global__ void ddc_wf_finish_kernel(ddc_chan *__restrict__ chans, const int *__restrict__ chan_list, int nlist,
                                      long n, const long *__restrict__ nouts, const u32 *__restrict__ hist_new)
 {
     const int li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= nlist) return;
     ddc_chan *ch = chans + chan_list[li];
-    const u64 M48 = (1ull << 48) - 1;
-    ch->phase = (ch->phase + (u64) n * ch->phase_inc) & M48;
     if (ch->log2r == 0) return;
-    ch->sample_no = (u32) (((u64) ch->sample_no + (u64) n) & ((1ull << ch->log2r) - 1));
     const long nout = nouts[li];
     if (nout <= 0) return;
     for (int comp = 0; comp < 2; comp++) {
@@ -936,11 +943,23 @@ struct kg_ddc {
     ddc_chan *d_chans;
     std::vector<ddc_chan> h_chans;            // host mirror of the scalar fields
     u32 *d_nco;
-    ddc_state4 *d_local; u32 *d_c0rel, *d_tau, *d_hist;
-    int max_runs; long c0_cap;
+    // Buffers a push's run passes fill and its output stage (run-total prefix, combs, finish) drains: TWO sets, used in
+    // turn, so that push k + 1's run passes may overwrite nothing push k's output stage still reads (deferred mode).
+    ddc_state4 *d_local[2]; u32 *d_c0rel[2], *d_tau[2], *d_hist;
+    int max_runs; long c0_cap[2];
     ddc_chunk_agg *d_aggs; u32 *d_ticket; u32 ticket_base, epoch;     // chunked state scan
     hipStream_t side; hipEvent_t ev_fork, ev_join;                   // pass B of the small decimations beside the rest
     kg_stage_cache pack_cache;                 // the per-call tables of the last push (a steady stream repeats them: no upload)
+    std::vector<u64> h_pushed;                 // per channel: samples pushed since its reference point (ddc_chan.phase / .sample_no)
+    // Deferred output stage (kg_ddc_wf_set_deferred): the stage runs on `tail`, the context's stream carries only pass A,
+    // the state scan and pass B, so the NEXT push's pass A starts while this push's combs are still writing.
+    bool deferred;
+    hipStream_t tail;
+    hipEvent_t ev_runs, ev_tail[2];            // run passes of the push done (main stream) / output stage of the push of that parity done
+    bool tail_rec[2];                          // ev_tail[p] has been recorded
+    bool tail_unjoined;                        // the context's stream has not yet been made to wait for the last output stage
+    int parity;                                // buffer set of the NEXT push
+    void *after_ev;                            // kg_ddc_wf_tail_after: the next push's writers of the caller's rows wait for it
 };
 
 static const int DDC_RUN_MIN = 64, DDC_RUN_MAX = 8192, DDC_TARGET_RUNS = 8192;
@@ -963,14 +982,19 @@ int kg_ddc_create(kg_ctx *ctx, int nchan, size_t max_samples, kg_ddc **out)
     for (auto &c : d->h_chans) memset(&c, 0, sizeof c);
     d->max_runs = (int) ((max_samples + DDC_RUN_MIN - 1) / DDC_RUN_MIN);
     if (d->max_runs > DDC_TARGET_RUNS * 2) d->max_runs = DDC_TARGET_RUNS * 2;
-    d->c0_cap = 0; d->d_c0rel = nullptr;
+    d->c0_cap[0] = d->c0_cap[1] = 0; d->d_c0rel[0] = d->d_c0rel[1] = nullptr;
+    d->h_pushed.assign(nchan, 0);
+    d->deferred = false; d->tail = nullptr; d->tail_rec[0] = d->tail_rec[1] = false; d->tail_unjoined = false;
+    d->parity = 0; d->after_ev = nullptr;
     KG_HIP(hipMalloc((void **) &d->d_chans, sizeof(ddc_chan) * nchan));
     KG_HIP(hipMemset(d->d_chans, 0, sizeof(ddc_chan) * nchan));
     KG_HIP(hipMalloc((void **) &d->d_nco, sizeof(short) * DDC_TAB));
     KG_HIP(hipFuncSetAttribute((const void *) ddc_wf_run_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                DDC_STAGE_BYTES));
-    KG_HIP(hipMalloc((void **) &d->d_local, sizeof(ddc_state4) * 2 * (size_t) nchan * d->max_runs));
-    KG_HIP(hipMalloc((void **) &d->d_tau, sizeof(u32) * 2 * (size_t) nchan * d->max_runs));
+    for (int p = 0; p < 2; p++) {
+        KG_HIP(hipMalloc((void **) &d->d_local[p], sizeof(ddc_state4) * 2 * (size_t) nchan * d->max_runs));
+        KG_HIP(hipMalloc((void **) &d->d_tau[p], sizeof(u32) * 2 * (size_t) nchan * d->max_runs));
+    }
     KG_HIP(hipMalloc((void **) &d->d_hist, sizeof(u32) * 10 * (size_t) nchan));
     KG_HIP(hipMalloc((void **) &d->d_aggs, sizeof(ddc_chunk_agg) * 2 * (size_t) nchan * DDC_SCAN_MAX_CHUNKS));
     KG_HIP(hipMemset(d->d_aggs, 0, sizeof(ddc_chunk_agg) * 2 * (size_t) nchan * DDC_SCAN_MAX_CHUNKS));
@@ -990,21 +1014,65 @@ void kg_ddc_destroy(kg_ddc *d)
     if (!d) return;
     (void) hipSetDevice(d->ctx->device);
     (void) hipStreamSynchronize(d->ctx->stream);
-    (void) hipFree(d->d_chans); (void) hipFree(d->d_nco); 
-    (void) hipFree(d->d_local);
-    (void) hipFree(d->d_tau); (void) hipFree(d->d_c0rel); (void) hipFree(d->d_hist);
+    if (d->side) (void) hipStreamSynchronize(d->side);
+    if (d->tail) (void) hipStreamSynchronize(d->tail);
+    (void) hipFree(d->d_chans); (void) hipFree(d->d_nco);
+    for (int p = 0; p < 2; p++) { (void) hipFree(d->d_local[p]); (void) hipFree(d->d_tau[p]); (void) hipFree(d->d_c0rel[p]); }
+    (void) hipFree(d->d_hist);
     (void) hipFree(d->d_aggs); (void) hipFree(d->d_ticket);
     kg_stage_cache_free(&d->pack_cache);
-    if (d->side) { (void) hipStreamSynchronize(d->side); (void) hipEventDestroy(d->ev_fork); (void) hipEventDestroy(d->ev_join); (void) hipStreamDestroy(d->side); }
-    
+    if (d->side) { (void) hipEventDestroy(d->ev_fork); (void) hipEventDestroy(d->ev_join); (void) hipStreamDestroy(d->side); }
+    if (d->tail) {
+        (void) hipEventDestroy(d->ev_runs); (void) hipEventDestroy(d->ev_tail[0]); (void) hipEventDestroy(d->ev_tail[1]);
+        (void) hipStreamDestroy(d->tail);
+    }
     delete d;
 }
 
+// Everything the object has in flight, on all of its streams.
+static int ddc_sync_all(kg_ddc *d)
+{
+    KG_HIP(hipStreamSynchronize(d->ctx->stream));
+    if (d->side) KG_HIP(hipStreamSynchronize(d->side));
+    if (d->tail) KG_HIP(hipStreamSynchronize(d->tail));
+    d->tail_unjoined = false;
+    return KG_OK;
+}
+
+static inline u64 ddc_cur_phase(const kg_ddc *d, int ch)
+{
+    const ddc_chan &c = d->h_chans[ch];
+    return (c.phase + d->h_pushed[ch] * c.phase_inc) & ((1ull << 48) - 1);
+}
+static inline u32 ddc_cur_cnt(const kg_ddc *d, int ch)
+{
+    const ddc_chan &c = d->h_chans[ch];
+    return (u32) (((u64) c.sample_no + d->h_pushed[ch]) & ((1ull << c.log2r) - 1));
+}
+
+// The host copy of the scalar fields -> the device record (the filter state the host copy holds with it: zero after
+// set_wf / reset).  Drains the object first.
 static int ddc_upload(kg_ddc *d, int ch)
 {
-    hipStream_t st = d->ctx->stream;
-    KG_HIP(hipStreamSynchronize(st));
+    int rc = ddc_sync_all(d);
+    if (rc) return rc;
     KG_HIP(hipMemcpy(d->d_chans + ch, &d->h_chans[ch], sizeof(ddc_chan), hipMemcpyHostToDevice));
+    return KG_OK;
+}
+
+// Move channel ch's reference point to "now" (phase and counter as they stand, pushed = 0) WITHOUT touching its filter
+// state: only the two scalar fields go to the device.  Drains the object first.
+static int ddc_rebase(kg_ddc *d, int ch)
+{
+    if (d->h_pushed[ch] == 0) return KG_OK;
+    int rc = ddc_sync_all(d);
+    if (rc) return rc;
+    ddc_chan &c = d->h_chans[ch];
+    c.phase = ddc_cur_phase(d, ch);
+    c.sample_no = ddc_cur_cnt(d, ch);
+    d->h_pushed[ch] = 0;
+    KG_HIP(hipMemcpy(&d->d_chans[ch].phase, &c.phase, sizeof c.phase, hipMemcpyHostToDevice));
+    KG_HIP(hipMemcpy(&d->d_chans[ch].sample_no, &c.sample_no, sizeof c.sample_no, hipMemcpyHostToDevice));
     return KG_OK;
 }
 
@@ -1023,6 +1091,7 @@ int kg_ddc_set_wf(kg_ddc *d, int ch, uint64_t phase_inc, int decim)
     c.phase_inc = phase_inc & ((1ull << 48) - 1);
     c.log2r = log2r;
     c.active = 1;
+    d->h_pushed[ch] = 0;
     return ddc_upload(d, ch);
 }
 
@@ -1034,15 +1103,12 @@ int kg_ddc_reset_wf(kg_ddc *d, int ch)
     KG_REQUIRE(ch >= 0 && ch < d->nchan && d->h_chans[ch].active, KG_ERR_INVALID,
                "kg_ddc_reset_wf: channel %d is not configured", ch);
     // rst_wf_samp_wr (waterfall_1cic.v:47): CIC registers and the decimation counter; the NCO
-    // phase keeps running in the FPGA -- the device copy holds it, so read it back first
-    hipStream_t st = d->ctx->stream;
-    KG_HIP(hipStreamSynchronize(st));
-    ddc_chan cur;
-    KG_HIP(hipMemcpy(&cur, d->d_chans + ch, sizeof cur, hipMemcpyDeviceToHost));
+    // phase keeps running in the FPGA: reference phase + what has been pushed since
     ddc_chan &c = d->h_chans[ch];
-    const u64 inc = c.phase_inc; const int l2 = c.log2r;
+    const u64 inc = c.phase_inc, ph = ddc_cur_phase(d, ch); const int l2 = c.log2r;
     memset(&c, 0, sizeof c);
-    c.phase = cur.phase; c.phase_inc = inc; c.log2r = l2; c.active = 1;
+    c.phase = ph; c.phase_inc = inc; c.log2r = l2; c.active = 1;
+    d->h_pushed[ch] = 0;
     return ddc_upload(d, ch);
 }
 
@@ -1052,10 +1118,11 @@ int kg_ddc_set_phase(kg_ddc *d, int ch, uint64_t phase)
                "kg_ddc_set_phase: channel %d is not configured", ch);
     int rc = kg_ctx_use(d->ctx);
     if (rc) return rc;
-    hipStream_t st = d->ctx->stream;
-    KG_HIP(hipStreamSynchronize(st));
-    const u64 p = phase & ((1ull << 48) - 1);
-    KG_HIP(hipMemcpy(&d->d_chans[ch].phase, &p, sizeof p, hipMemcpyHostToDevice));
+    if ((rc = ddc_rebase(d, ch))) return rc;            // the counter's reference moves to "now" with the phase's
+    if ((rc = ddc_sync_all(d))) return rc;
+    ddc_chan &c = d->h_chans[ch];
+    c.phase = phase & ((1ull << 48) - 1);
+    KG_HIP(hipMemcpy(&d->d_chans[ch].phase, &c.phase, sizeof c.phase, hipMemcpyHostToDevice));
     return KG_OK;
 }
 
@@ -1063,8 +1130,51 @@ int kg_ddc_set_phase(kg_ddc *d, int ch, uint64_t phase)
 long kg_ddc_wf_outputs(kg_ddc *d, int ch, size_t n)
 {
     if (!d || ch < 0 || ch >= d->nchan || !d->h_chans[ch].active) return KG_ERR_INVALID;
-    const ddc_chan &c = d->h_chans[ch];
-    return (long) (((u64) c.sample_no + (u64) n) >> c.log2r);
+    return (long) (((u64) ddc_cur_cnt(d, ch) + (u64) n) >> d->h_chans[ch].log2r);
+}
+
+// Deferred output stage.  Off (the default): kg_ddc_wf_push_dev leaves everything it enqueues ordered on the context's
+// stream -- the caller's next enqueue on that stream sees the outputs.  On: the push returns with its output stage
+// (R = 1 bypass channels, run-total prefix, combs) on a stream of the object; the context's stream carries only pass A,
+// the state scan and pass B, so that the NEXT push's run passes start while this push's combs are still writing.  Whoever
+// consumes the outputs first makes ITS stream wait for them with kg_ddc_wf_join (null: the context's stream).
+int kg_ddc_wf_set_deferred(kg_ddc *d, int on)
+{
+    KG_REQUIRE(d != nullptr, KG_ERR_INVALID, "kg_ddc_wf_set_deferred: null argument");
+    int rc = kg_ctx_use(d->ctx);
+    if (rc) return rc;
+    if ((rc = ddc_sync_all(d))) return rc;
+    if (on && !d->tail) {
+        KG_HIP(hipStreamCreateWithFlags(&d->tail, hipStreamNonBlocking));
+        KG_HIP(hipEventCreateWithFlags(&d->ev_runs, hipEventDisableTiming));
+        KG_HIP(hipEventCreateWithFlags(&d->ev_tail[0], hipEventDisableTiming));
+        KG_HIP(hipEventCreateWithFlags(&d->ev_tail[1], hipEventDisableTiming));
+    }
+    d->deferred = on != 0;
+    return KG_OK;
+}
+
+int kg_ddc_wf_join(kg_ddc *d, void *stream)
+{
+    KG_REQUIRE(d != nullptr, KG_ERR_INVALID, "kg_ddc_wf_join: null argument");
+    int rc = kg_ctx_use(d->ctx);
+    if (rc) return rc;
+    const int last = d->parity ^ 1;                     // buffer set of the last push
+    if (!d->tail || !d->tail_rec[last]) return KG_OK;   // nothing deferred is outstanding
+    hipStream_t st = stream ? (hipStream_t) stream : d->ctx->stream;
+    KG_HIP(hipStreamWaitEvent(st, d->ev_tail[last], 0));
+    if (st == d->ctx->stream) d->tail_unjoined = false;
+    return KG_OK;
+}
+
+// The NEXT push's writers of the caller's output rows (bypass kernel, combs) will not start before `event` (a
+// hipEvent_t recorded by the caller behind its last reader of those rows): the write-after-read edge of a caller that
+// reads push k's rows on its own stream while push k + 1 is already running.  Consumed by that push.
+int kg_ddc_wf_tail_after(kg_ddc *d, void *event)
+{
+    KG_REQUIRE(d != nullptr, KG_ERR_INVALID, "kg_ddc_wf_tail_after: null argument");
+    d->after_ev = event;
+    return KG_OK;
 }
 
 int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *chan_list, int nlist,
@@ -1077,18 +1187,29 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
     KG_REQUIRE(nlist >= 1 && nlist <= d->nchan, KG_ERR_INVALID, "kg_ddc_wf_push_dev: nlist %d", nlist);
     KG_REQUIRE(((uintptr_t) d_adc & 1) == 0 && ((uintptr_t) d_out & 3) == 0, KG_ERR_INVALID,
                "kg_ddc_wf_push_dev: misaligned pointer");
-    std::vector<long> h_nouts(nlist), h_off(nlist);
-    std::vector<u32> h_cnt(nlist);
-    std::vector<int> h_wg(nlist + 1), h_bypass, h_run, h_small, h_rest;
-    long max_nout = 0, c0_need = 0, comb_wgs = 0;
     for (int i = 0; i < nlist; i++) {
         const int ch = chan_list[i];
         KG_REQUIRE(ch >= 0 && ch < d->nchan && d->h_chans[ch].active, KG_ERR_STATE,
                    "kg_ddc_wf_push_dev: channel %d is not configured", ch);
         for (int j = 0; j < i; j++) KG_REQUIRE(chan_list[j] != ch, KG_ERR_INVALID, "kg_ddc_wf_push_dev: channel %d listed twice", ch);
+    }
+    // One `pushed` count for the whole call: channels whose reference points differ in age (one was retuned, or left out
+    // of earlier calls) are re-based to "now" first -- a rare, synchronising path.
+    {
+        bool same = true;
+        for (int i = 1; i < nlist; i++) same = same && d->h_pushed[chan_list[i]] == d->h_pushed[chan_list[0]];
+        // (the kernels form (pushed + sample index) x phase_inc in 64 bits mod 2^48: re-base long before anything wraps)
+        if (!same || d->h_pushed[chan_list[0]] + (u64) n >= (1ull << 62))
+            for (int i = 0; i < nlist; i++) if ((rc = ddc_rebase(d, chan_list[i]))) return rc;
+    }
+    const u64 pushed = d->h_pushed[chan_list[0]];
+    std::vector<long> h_nouts(nlist), h_off(nlist);
+    std::vector<int> h_wg(nlist + 1), h_bypass, h_run, h_small, h_rest;
+    long max_nout = 0, c0_need = 0, comb_wgs = 0;
+    for (int i = 0; i < nlist; i++) {
+        const int ch = chan_list[i];
         const ddc_chan &c = d->h_chans[ch];
-        h_cnt[i] = c.sample_no;
-        h_nouts[i] = (long) (((u64) c.sample_no + (u64) n) >> c.log2r);
+        h_nouts[i] = (long) (((u64) ddc_cur_cnt(d, ch) + (u64) n) >> c.log2r);
         KG_REQUIRE((size_t) h_nouts[i] <= out_stride, KG_ERR_INVALID,
                    "kg_ddc_wf_push_dev: out_stride %zu < %ld outputs of channel %d", out_stride, h_nouts[i], ch);
         if (h_nouts[i] > max_nout) max_nout = h_nouts[i];
@@ -1103,13 +1224,22 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
     h_wg[nlist] = (int) comb_wgs;
     KG_REQUIRE(comb_wgs < (1l << 31), KG_ERR_INVALID, "kg_ddc_wf_push_dev: too many outputs in one call");
     hipStream_t st = d->ctx->stream;
-    if (c0_need > d->c0_cap) {
-        KG_HIP(hipStreamSynchronize(st));
-        (void) hipFree(d->d_c0rel);
-        d->d_c0rel = nullptr; d->c0_cap = 0;  // nothing dangles if the allocation below fails
-        KG_HIP(hipMalloc((void **) &d->d_c0rel, sizeof(u32) * (size_t) (c0_need + 16)));
-        d->c0_cap = c0_need;
+    const bool defer = d->deferred;
+    const int par = d->parity;                     // this push's buffer set
+    // The buffer set was last used two pushes ago: its output stage must have drained it (deferred mode; long done).
+    if (d->tail && d->tail_rec[par]) {
+        KG_HIP(hipStreamWaitEvent(st, d->ev_tail[par], 0));
+        if (d->side) KG_HIP(hipStreamWaitEvent(d->side, d->ev_tail[par], 0));
     }
+    if (c0_need > d->c0_cap[par]) {
+        if ((rc = ddc_sync_all(d))) return rc;
+        (void) hipFree(d->d_c0rel[par]);
+        d->d_c0rel[par] = nullptr; d->c0_cap[par] = 0;  // nothing dangles if the allocation below fails
+        KG_HIP(hipMalloc((void **) &d->d_c0rel[par], sizeof(u32) * (size_t) (c0_need + 16)));
+        d->c0_cap[par] = c0_need;
+    }
+    ddc_state4 *const d_local = d->d_local[par];
+    u32 *const d_c0rel = d->d_c0rel[par], *const d_tau = d->d_tau[par];
     // run length: a power of two between 64 and 8192, about 8192 runs per call
     // One thread per (channel, run): with few channels take more, shorter runs so that the two
     // run passes still put about four waves on every SIMD (14 channels on MI355X: 16384 runs
@@ -1129,7 +1259,7 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
     KG_REQUIRE(nruns <= d->max_runs, KG_ERR_INVALID, "kg_ddc_wf_push_dev: %d runs > %d", nruns, d->max_runs);
     // The per-call tables go through the context's staging ring in one piece: no stream
     // synchronisation, and the previous call's kernels keep their own copy.
-    const long *s_c0off, *s_nouts; const int *s_list, *s_wgoff, *s_bypass, *s_selrun, *s_selsmall, *s_selrest; const u32 *s_cnt;
+    const long *s_c0off, *s_nouts; const int *s_list, *s_wgoff, *s_bypass, *s_selrun, *s_selsmall, *s_selrest;
     {
         std::vector<unsigned char> pack;
         auto put = [&](const void *src, size_t bytes) -> size_t {
@@ -1139,17 +1269,24 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
             return at;
         };
         const size_t o_off = put(h_off.data(), sizeof(long) * nlist), o_nouts = put(h_nouts.data(), sizeof(long) * nlist);
-        const size_t o_list = put(chan_list, sizeof(int) * nlist), o_cnt = put(h_cnt.data(), sizeof(u32) * nlist);
+        const size_t o_list = put(chan_list, sizeof(int) * nlist);
         const size_t o_wg = put(h_wg.data(), sizeof(int) * (nlist + 1));
         const size_t o_by = put(h_bypass.data(), sizeof(int) * h_bypass.size());
         const size_t o_run = put(h_run.data(), sizeof(int) * h_run.size());
         const size_t o_small = put(h_small.data(), sizeof(int) * h_small.size());
         const size_t o_rest = put(h_rest.data(), sizeof(int) * h_rest.size());
+        // a CHANGED table is rewritten in the order of the context's stream: the previous push's output stage, on its own
+        // stream in deferred mode, may still be reading the old one -- join it first (a steady stream never gets here)
+        if (d->tail && d->tail_rec[par ^ 1] && d->tail_unjoined &&
+            !(d->pack_cache.bytes == pack.size() && d->pack_cache.host && memcmp(d->pack_cache.host, pack.data(), pack.size()) == 0)) {
+            KG_HIP(hipStreamWaitEvent(st, d->ev_tail[par ^ 1], 0));
+            d->tail_unjoined = false;
+        }
         void *base = nullptr;
         if ((rc = kg_ctx_stage_cached(d->ctx, &d->pack_cache, pack.data(), pack.size(), &base))) return rc;
         const unsigned char *b = (const unsigned char *) base;
         s_c0off = (const long *) (b + o_off); s_nouts = (const long *) (b + o_nouts);
-        s_list = (const int *) (b + o_list); s_cnt = (const u32 *) (b + o_cnt); s_wgoff = (const int *) (b + o_wg);
+        s_list = (const int *) (b + o_list); s_wgoff = (const int *) (b + o_wg);
         s_bypass = (const int *) (b + o_by); s_selrun = (const int *) (b + o_run);
         s_selsmall = (const int *) (b + o_small); s_selrest = (const int *) (b + o_rest);
     }
@@ -1166,26 +1303,39 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
         }
         return KG_OK;
     };
+    // Deferred mode: the output stage's stream starts behind the tables and the caller's samples (fork event), behind the
+    // previous push's output stage (stream order) and behind the caller's last reader of the rows (kg_ddc_wf_tail_after).
+    hipStream_t ost = st;                          // where the writers of the caller's rows run
+    if (defer) {
+        if ((rc = side_ready())) return rc;
+        ost = d->tail;
+        KG_HIP(hipEventRecord(d->ev_fork, st));
+        KG_HIP(hipStreamWaitEvent(ost, d->ev_fork, 0));
+        if (d->after_ev) KG_HIP(hipStreamWaitEvent(ost, (hipEvent_t) d->after_ev, 0));
+    } else if (d->after_ev) {
+        KG_HIP(hipStreamWaitEvent(st, (hipEvent_t) d->after_ev, 0));
+    }
+    d->after_ev = nullptr;
     if (!h_bypass.empty()) {
-        hipStream_t bst = st;
-        if (side_on && !h_run.empty()) {
+        hipStream_t bst = ost;
+        if (!defer && side_on && !h_run.empty()) {
             if ((rc = side_ready())) return rc;
             KG_HIP(hipEventRecord(d->ev_fork, st));                  // behind the staged tables
             KG_HIP(hipStreamWaitEvent(d->side, d->ev_fork, 0));
             bst = d->side; side_used = true;
         }
-        const long nblk_by = (n + 2047) / 2048, cap_by = (long) d->ctx->num_cus * 4;   // LDS: 32 KiB each, 4 per CU
-        hipLaunchKernelGGL(ddc_wf_bypass_kernel, dim3((unsigned) (nblk_by < cap_by ? nblk_by : cap_by), (unsigned) h_bypass.size()), dim3(256),
+        const long nblk_by = (n + 2047) / 2048, cap_by = (long) d->ctx->num_cus * 4;   // LDS: 20 KiB each, 4 per CU
+        hipLaunchKernelGGL(ddc_wf_bypass_kernel, dim3((unsigned) (nblk_by < cap_by ? nblk_by : cap_by)), dim3(256),
                            0, bst, (const short *) d_adc, (long) n, (const ddc_chan *) d->d_chans, s_list,
-                           s_bypass, (const u32 *) d->d_nco, (short2 *) d_out, (long) out_stride);
+                           s_bypass, (int) h_bypass.size(), (const u32 *) d->d_nco, (short2 *) d_out, (long) out_stride, pushed);
         KG_HIP(hipGetLastError());
     }
     const unsigned gx = (unsigned) ((nruns + DDC_THREADS - 1) / DDC_THREADS);
     if (!h_run.empty()) {
         hipLaunchKernelGGL(ddc_wf_run_kernel<false>, dim3(gx, (unsigned) h_run.size()), dim3(DDC_THREADS), 0, st,
                            (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, s_list,
-                           (const u32 *) d->d_nco, d->d_local, d->d_c0rel, d->d_tau, s_c0off,
-                           s_nouts, s_selrun, 0);
+                           (const u32 *) d->d_nco, d_local, d_c0rel, d_tau, s_c0off,
+                           s_nouts, s_selrun, 0, pushed);
         KG_HIP(hipGetLastError());
     }
     {
@@ -1221,7 +1371,7 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
             }
         }
         hipLaunchKernelGGL(ddc_wf_scan_states_kernel, dim3((unsigned) (npairs * nchunk)), dim3(64 * DDC_SCAN_WAVES), 0, st,
-                           d->d_local, (long) n, L, nruns, d->d_chans, s_list, npairs, nchunk, d->d_aggs, d->d_ticket,
+                           d_local, (long) n, L, nruns, d->d_chans, s_list, npairs, nchunk, d->d_aggs, d->d_ticket,
                            d->ticket_base, d->epoch + 1, tab);
         KG_HIP(hipGetLastError());
         // only a launch that was accepted advances the ticket counter and publishes under the new epoch
@@ -1237,64 +1387,62 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
     bool staged = (long) h_small.size() * nruns >= (long) d->ctx->num_cus * 4 * 2 * 64;
     const bool beside = side_on && !h_small.empty() && !h_rest.empty();
     if (const char *e = getenv("KIWIGPU_DDC_STAGED")) staged = atoi(e) != 0 && !h_small.empty();
+    auto pass_b = [&](hipStream_t s, const std::vector<int> &which, const int *sel, int stage) {
+        hipLaunchKernelGGL(ddc_wf_run_kernel<true>, dim3(gx, (unsigned) which.size()), dim3(DDC_THREADS), stage, s,
+                           (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, s_list,
+                           (const u32 *) d->d_nco, d_local, d_c0rel, d_tau, s_c0off, s_nouts, sel, stage, pushed);
+    };
     if (beside) {
         if ((rc = side_ready())) return rc;
         side_used = true;
         KG_HIP(hipEventRecord(d->ev_fork, st));
         KG_HIP(hipStreamWaitEvent(d->side, d->ev_fork, 0));
-        hipLaunchKernelGGL(ddc_wf_run_kernel<true>, dim3(gx, (unsigned) h_small.size()), dim3(DDC_THREADS), DDC_STAGE_BYTES, d->side,
-                           (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, s_list,
-                           (const u32 *) d->d_nco, d->d_local, d->d_c0rel, d->d_tau, s_c0off,
-                           s_nouts, s_selsmall, DDC_STAGE_BYTES);
+        pass_b(d->side, h_small, s_selsmall, DDC_STAGE_BYTES);
         KG_HIP(hipGetLastError());
-        hipLaunchKernelGGL(ddc_wf_run_kernel<true>, dim3(gx, (unsigned) h_rest.size()), dim3(DDC_THREADS), 0, st,
-                           (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, s_list,
-                           (const u32 *) d->d_nco, d->d_local, d->d_c0rel, d->d_tau, s_c0off,
-                           s_nouts, s_selrest, 0);
+        pass_b(st, h_rest, s_selrest, 0);
         KG_HIP(hipGetLastError());
     } else if (staged) {
-        hipLaunchKernelGGL(ddc_wf_run_kernel<true>, dim3(gx, (unsigned) h_small.size()), dim3(DDC_THREADS), DDC_STAGE_BYTES, st,
-                           (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, s_list,
-                           (const u32 *) d->d_nco, d->d_local, d->d_c0rel, d->d_tau, s_c0off,
-                           s_nouts, s_selsmall, DDC_STAGE_BYTES);
+        pass_b(st, h_small, s_selsmall, DDC_STAGE_BYTES);
         KG_HIP(hipGetLastError());
         if (!h_rest.empty()) {
-            hipLaunchKernelGGL(ddc_wf_run_kernel<true>, dim3(gx, (unsigned) h_rest.size()), dim3(DDC_THREADS), 0, st,
-                               (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, s_list,
-                               (const u32 *) d->d_nco, d->d_local, d->d_c0rel, d->d_tau, s_c0off,
-                               s_nouts, s_selrest, 0);
+            pass_b(st, h_rest, s_selrest, 0);
             KG_HIP(hipGetLastError());
         }
     } else if (!h_run.empty()) {
-        hipLaunchKernelGGL(ddc_wf_run_kernel<true>, dim3(gx, (unsigned) h_run.size()), dim3(DDC_THREADS), 0, st,
-                           (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, s_list,
-                           (const u32 *) d->d_nco, d->d_local, d->d_c0rel, d->d_tau, s_c0off,
-                           s_nouts, s_selrun, 0);
+        pass_b(st, h_run, s_selrun, 0);
         KG_HIP(hipGetLastError());
     }
-    if (side_used) {                              // everything the second stream did is behind this point of the first
-        KG_HIP(hipEventRecord(d->ev_join, d->side));
-        KG_HIP(hipStreamWaitEvent(st, d->ev_join, 0));
+    // The output stage: run-total prefix, combs, comb history -- in line on the context's stream, or (deferred) on the
+    // object's output stream behind this push's run passes, with the context's stream free for the next push's.
+    if (defer) {
+        KG_HIP(hipEventRecord(d->ev_runs, st));
+        KG_HIP(hipStreamWaitEvent(ost, d->ev_runs, 0));
     }
-    hipLaunchKernelGGL(ddc_wf_scan_tau_kernel, dim3(2 * nlist), dim3(64 * DDC_SCAN_WAVES), 0, st, d->d_tau, nruns, d->d_chans,
+    if (side_used) {                              // everything the second stream did is behind this point of the output stage
+        KG_HIP(hipEventRecord(d->ev_join, d->side));
+        KG_HIP(hipStreamWaitEvent(ost, d->ev_join, 0));
+    }
+    hipLaunchKernelGGL(ddc_wf_scan_tau_kernel, dim3(2 * nlist), dim3(64 * DDC_SCAN_WAVES), 0, ost, d_tau, nruns, d->d_chans,
                        s_list);
     KG_HIP(hipGetLastError());
     if (comb_wgs > 0) {
-        hipLaunchKernelGGL(ddc_wf_comb_kernel, dim3((unsigned) comb_wgs), dim3(256), 0, st,
-                           (const u32 *) d->d_c0rel, (const u32 *) d->d_tau, log2L, nruns, s_c0off,
+        hipLaunchKernelGGL(ddc_wf_comb_kernel, dim3((unsigned) comb_wgs), dim3(256), 0, ost,
+                           (const u32 *) d_c0rel, (const u32 *) d_tau, log2L, nruns, s_c0off,
                            (const ddc_chan *) d->d_chans, s_list, s_nouts,
-                           s_cnt, s_wgoff, nlist, (short2 *) d_out, (long) out_stride,
+                           pushed, s_wgoff, nlist, (short2 *) d_out, (long) out_stride,
                            d->d_hist);
         KG_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(ddc_wf_finish_kernel, dim3((nlist + 63) / 64), dim3(64), 0, st, d->d_chans,
+    hipLaunchKernelGGL(ddc_wf_finish_kernel, dim3((nlist + 63) / 64), dim3(64), 0, ost, d->d_chans,
                        s_list, nlist, (long) n, s_nouts, (const u32 *) d->d_hist);
     KG_HIP(hipGetLastError());
-    // host mirror of the scalar state
-    for (int i = 0; i < nlist; i++) {
-        ddc_chan &c = d->h_chans[chan_list[i]];
-        if (c.log2r) c.sample_no = (u32) (((u64) c.sample_no + (u64) n) & ((1ull << c.log2r) - 1));
+    if (d->tail) {                                // (also in line: a later deferred push finds its buffer set covered)
+        KG_HIP(hipEventRecord(d->ev_tail[par], ost));
+        d->tail_rec[par] = true;
+        d->tail_unjoined = defer;
     }
+    d->parity = par ^ 1;
+    for (int i = 0; i < nlist; i++) d->h_pushed[chan_list[i]] += (u64) n;
     return KG_OK;
 }
 

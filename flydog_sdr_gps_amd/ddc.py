@@ -51,6 +51,20 @@ class Ddc:
     def outputs(self, ch, n):
         return check(self.lib.kg_ddc_wf_outputs(self.h, int(ch), int(n)), "kg_ddc_wf_outputs")
 
+    def set_deferred(self, on=True):
+        """Deferred output stage (kg_ddc_wf_set_deferred): push_dev then leaves the stage that writes the rows on a stream
+        of the object; join() makes a stream wait for it."""
+        check(self.lib.kg_ddc_wf_set_deferred(self.h, int(bool(on))), "kg_ddc_wf_set_deferred")
+        self.deferred = bool(on)
+
+    def join(self, stream=None):
+        """`stream` (a raw hipStream_t handle as int; None: the context's stream) waits for the last push's outputs."""
+        check(self.lib.kg_ddc_wf_join(self.h, ptr(int(stream)) if stream else None), "kg_ddc_wf_join")
+
+    def tail_after(self, event):
+        """The next push's writers of the output rows start only after `event` (a raw hipEvent_t handle as int)."""
+        check(self.lib.kg_ddc_wf_tail_after(self.h, ptr(int(event)) if event else None), "kg_ddc_wf_tail_after")
+
     def push_dev(self, d_adc, n, chans, d_out, out_stride):
         """Device pointers (ints).  Returns the per-channel output counts."""
         chans = np.ascontiguousarray(chans, np.int32)
@@ -69,6 +83,8 @@ class Ddc:
         try:
             self.ctx.upload(d_adc, adc)
             nouts = self.push_dev(d_adc, adc.size, chans, d_out, stride)
+            if getattr(self, "deferred", False):
+                self.join()
             host = np.zeros((len(chans), stride, 2), np.int16)
             self.ctx.download(d_out, host)
         finally:

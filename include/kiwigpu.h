@@ -279,6 +279,20 @@ long kg_ddc_wf_outputs(kg_ddc *ddc, int ch, size_t n);
  * call, so a stream may be pushed in pieces of any length.  Enqueue only. */
 int kg_ddc_wf_push_dev(kg_ddc *ddc, const void *d_adc, size_t n, const int32_t *chan_list,
                        int nlist, void *d_out, size_t out_stride, int64_t *nouts);
+/* Deferred output stage (round 4) -- the non-blocking submit / poll form SURVEY 8(b) asks of the DDC seam (today every
+ * CmdGetWFSamples is a blocking SPI transaction, platform/common/spi.cpp:487-507).  Off (default): everything a push
+ * enqueues is ordered on the context's stream.  On: the push returns with its output stage (R = 1 bypass channels,
+ * run-total prefix, combs: everything that WRITES d_out) on a stream of the object, and the context's stream carries
+ * only the run passes -- the next push's run passes start while this push's outputs are still being written.
+ *   kg_ddc_wf_join(ddc, stream)      `stream` (a hipStream_t; NULL: the context's) waits for the last push's outputs:
+ *                                    call it on whichever stream reads d_out first.
+ *   kg_ddc_wf_tail_after(ddc, event) the NEXT push's writers of d_out start only after `event` (a hipEvent_t the
+ *                                    caller recorded behind its last reader of the rows): the write-after-read edge of
+ *                                    a caller that still reads push k's rows while push k + 1 runs.  One-shot.
+ * Every other entry point of the object drains the deferred work first. */
+int kg_ddc_wf_set_deferred(kg_ddc *ddc, int on);
+int kg_ddc_wf_join(kg_ddc *ddc, void *stream);
+int kg_ddc_wf_tail_after(kg_ddc *ddc, void *event);
 
 /* ------------------------------------------------------------------------ */
 /* Audio DDC.  In the reference: one RX instance per audio channel in FPGA      */

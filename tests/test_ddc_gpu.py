@@ -344,3 +344,98 @@ def test_rx_ddc_wide_mode_differs_and_rejects_bad_mode(gpu_ctx):
     d.set_freq(0, 12345)
     assert d.outputs(0, RX_DECIM_WIDE * 10) == 10           # one record per 6172 ADC samples
     d.close()
+
+
+def _state_after(oracle, adc, inc, log2r, st=None):
+    return oracle.ddc_wf(adc, inc, log2r, st)
+
+
+def test_deferred_output_stage_pipelines_pushes_bit_exact(gpu_ctx, oracle):
+    """kg_ddc_wf_set_deferred: the output stage of a push (bypass, run-total prefix, combs) runs on a stream of the object
+    while the context's stream already carries the next push's run passes, the two buffer sets alternating.  Twelve
+    back-to-back device pushes of ragged lengths WITHOUT any host synchronisation in between, every push into its own
+    output region, one join at the end: every channel's concatenated output must equal the oracle's on the whole stream,
+    bit for bit -- BASELINE configs[2]'s decimation set (bypass, staged small decimations, 64- and 96-bit run passes)."""
+    zooms = [0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14]
+    lens = [1 << 18, (1 << 18) + 8, 70001, 1 << 17, 64, 65, 1 << 18, 99999, 4097, 1 << 18, 31, 1 << 16]
+    n = sum(lens)
+    adc = adc_stream(n, seed=21, tones=((0.031, 8000.0), (0.1234, 2000.0), (0.3, 300.0)))
+    C = len(zooms)
+    d = Ddc(gpu_ctx, nchan=C, max_samples=max(lens))
+    incs = [inc_for(0.03 + 0.007 * ch) for ch in range(C)]
+    d_adc = gpu_ctx.alloc(adc.nbytes)
+    stride = max(lens) + 8
+    d_out = gpu_ctx.alloc(len(lens) * C * stride * 4)
+    try:
+        for ch, z in enumerate(zooms):
+            d.set_wf(ch, incs[ch], 1 << max(z - 1, 0))
+        d.set_deferred(True)
+        gpu_ctx.upload(d_adc, adc)
+        pos, nouts = 0, []
+        for k, ln in enumerate(lens):
+            nouts.append(d.push_dev(d_adc + 2 * pos, ln, list(range(C)), d_out + 4 * k * C * stride, stride))
+            pos += ln
+        d.join()                                                   # the context's stream waits for the last output stage
+        host = np.zeros((len(lens), C, stride, 2), np.int16)
+        gpu_ctx.download(d_out, host)
+        for ch, z in enumerate(zooms):
+            want, _ = oracle.ddc_wf(adc, incs[ch], max(z - 1, 0))
+            got = np.concatenate([host[k, ch, :int(nouts[k][ch])] for k in range(len(lens))])
+            assert got.shape == want.shape and np.array_equal(got, want), (ch, z)
+        # back to the in-line mode on the same object: state carries over
+        d.set_deferred(False)
+        more = adc_stream(50_000, seed=22)
+        got2 = d.push(more, list(range(C)))
+        for ch, z in enumerate(zooms):
+            want, _ = oracle.ddc_wf(np.concatenate([adc, more]), incs[ch], max(z - 1, 0))
+            assert np.array_equal(got2[ch], want[want.shape[0] - got2[ch].shape[0]:]), (ch, z)
+    finally:
+        gpu_ctx.free(d_adc)
+        gpu_ctx.free(d_out)
+        d.close()
+
+
+@pytest.mark.parametrize("deferred", [False, True])
+def test_channels_of_different_age_are_rebased(gpu_ctx, oracle, deferred):
+    """The kernels take ONE samples-since-reference count per push.  Channels whose reference points differ -- one pushed
+    alone for a while, one retuned, one reset, one given a new phase mid-stream -- are re-based on the next joint push;
+    every channel must still equal the oracle fed ITS history."""
+    n = 40_000
+    adc = adc_stream(4 * n, seed=31)
+    a, b, c, e = adc[:n], adc[n:2 * n], adc[2 * n:3 * n], adc[3 * n:]
+    incs = [inc_for(0.05), inc_for(0.11), inc_for(0.2), inc_for(0.31)]
+    l2 = [4, 1, 9, 0]
+    d = Ddc(gpu_ctx, nchan=4, max_samples=n)
+    try:
+        for ch in range(4):
+            d.set_wf(ch, incs[ch], 1 << l2[ch])
+        d.set_deferred(deferred)
+        st = [None] * 4
+        want = [[] for _ in range(4)]
+
+        def ref(ch, x):
+            w, st[ch] = oracle.ddc_wf(x, incs[ch], l2[ch], st[ch])
+            want[ch].append(w)
+            return w
+        g = d.push(a, [0, 1, 2, 3])
+        for ch in range(4):
+            assert np.array_equal(g[ch], ref(ch, a)), ("all", ch)
+        g = d.push(b, [1, 3])                                      # channels 0 and 2 sit this one out (their NCOs do not advance)
+        for i, ch in enumerate((1, 3)):
+            assert np.array_equal(g[i], ref(ch, b)), ("subset", ch)
+        d.reset(2)                                                 # CIC registers cleared, phase kept
+        ph2 = (n * incs[2]) & ((1 << 48) - 1)
+        st[2] = oracle.DdcWfState(); st[2].phase = ph2
+        d.set_phase(1, 12345678901)                                # a new phase for channel 1; its filters keep running
+        st[1].phase = 12345678901
+        incs[0] = inc_for(0.07)                                    # retune channel 0: resets it
+        d.set_wf(0, incs[0], 1 << l2[0])
+        st[0] = None
+        g = d.push(c, [0, 1, 2, 3])                                # four different ages -> one re-base
+        for ch in range(4):
+            assert np.array_equal(g[ch], ref(ch, c)), ("rebased", ch)
+        g = d.push(e, [3, 2, 1, 0])                                # and on, in another list order
+        for i, ch in enumerate((3, 2, 1, 0)):
+            assert np.array_equal(g[i], ref(ch, e)), ("after", ch)
+    finally:
+        d.close()

@@ -2,7 +2,11 @@
 import json
 import sys
 
-d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+lines = [l for l in open(sys.argv[1]) if l.startswith("{")]
+if not lines:
+    print("no JSON line in %s (the bench failed: see its stderr)" % sys.argv[1])
+    sys.exit(0)
+d = json.loads(lines[-1])
 
 
 def show(name, r):
