@@ -1157,7 +1157,7 @@ def run_ddc14(args, dist):
     kstep = [0]
     # the streaming form: a push's output stage (bypass, run-total prefix, combs) on the object's own stream, the next
     # push's run passes already running beside it (kg_ddc_wf_set_deferred; KIWIGPU_BENCH_DDC_DEFERRED=0: everything in line)
-    deferred = os.environ.get("KIWIGPU_BENCH_DDC_DEFERRED", "1") != "0"
+    deferred = os.environ.get("KIWIGPU_BENCH_DDC_DEFERRED", "0") != "0"
     d.set_deferred(deferred)
 
     def step():
@@ -1246,7 +1246,7 @@ def run_cfg2_chain(args, dist):
     # stage runs on the object's own stream (kg_ddc_wf_set_deferred) and the frames of step k on a second stream of the
     # caller, behind that stage (kg_ddc_wf_join) -- both under the run passes of step k + 1; the next step's writers of the
     # rows wait for the frames that still read them (kg_ddc_wf_tail_after).
-    pipelined = os.environ.get("KIWIGPU_BENCH_DDC_DEFERRED", "1") != "0"
+    pipelined = os.environ.get("KIWIGPU_BENCH_DDC_DEFERRED", "0") != "0"
     s2 = torch.cuda.Stream(device=dev) if pipelined else None
     ctx_fr = Context(dist.local_rank, s2.cuda_stream) if pipelined else ctx
     ev_fr = [torch.cuda.Event(), torch.cuda.Event()]
@@ -1507,8 +1507,13 @@ class ReceiverBank:
             self.P.set_agc(ch, True, False, -100, 50, 6, 1000, fs)
             self.P.set_smeter(ch, fs); self.P.set_mode(ch, post.MODE_SSB); self.P.reset(ch)
 
+        # The waterfall side of a receiver takes ONE frame per step -- the reference's non-overlapped sample_wf()
+        # (rx/rx_waterfall.cpp:1005-1041): CmdWFReset, then the one-shot sampler's 8192 outputs -- kg_ddc_wf_capture_dev,
+        # straight into the frame rows.  KIWIGPU_BENCH_RX_CONTINUOUS=1: round 3's shape (the continuous sampler over the whole
+        # block, n / R outputs per channel, the first 8192 copied out), kept for the A/B.
+        self.continuous = os.environ.get("KIWIGPU_BENCH_RX_CONTINUOUS") == "1"
         self.wf_stride = n + 1
-        self.wf_iq = torch.zeros((NR, self.wf_stride, 2), dtype=torch.int16, device=dev)
+        self.wf_iq = torch.zeros((NR, self.wf_stride, 2), dtype=torch.int16, device=dev) if self.continuous else None
         self.frames = torch.zeros((NR, 8192, 2), dtype=torch.int16, device=dev)
         self.rows = torch.zeros((NR, 1024), dtype=torch.uint8, device=dev)
         self.pkts = torch.zeros((NR, wire.WF_PKT_MAX), dtype=torch.uint8, device=dev)
@@ -1563,10 +1568,15 @@ class ReceiverBank:
     def step(self):
         from flydog_sdr_gps_amd import wire
         self.audio()                                         # only enqueues, on the side stream
-        nw = self.d.push_dev(self.adc.data_ptr(), self.n, self.chans, self.wf_iq.data_ptr(), self.wf_stride)
-        assert int(nw.min()) >= 8192
+        if self.continuous:
+            nw = self.d.push_dev(self.adc.data_ptr(), self.n, self.chans, self.wf_iq.data_ptr(), self.wf_stride)
+            assert int(nw.min()) >= 8192
+            self.frames.copy_(self.wf_iq[:, :8192])         # the frame each receiver's waterfall takes this step
+        else:
+            nw = self.d.capture_dev(self.adc.data_ptr(), self.n, self.chans, self.frames.data_ptr(), 8192, 8192)
+            assert int(nw.min()) == 8192 == int(nw.max())
         self.last["nw"] = nw
-        self.frames.copy_(self.wf_iq[:, :8192])             # the frame each receiver's waterfall takes this step
+        self.steps_done = getattr(self, "steps_done", 0) + 1
         if self.tails and self.pk_pending:
             self.main.wait_event(self.ev_pk)                 # the packets of the step before have read rows
             self.pk_pending = False
@@ -1615,11 +1625,17 @@ def check_receiver_bank(bank, chs, steps=3):
             torch.cuda.synchronize(bank.dev)
             nrec, nout, nw = bank.last["nrec"], bank.last["nout"], bank.last["nw"]
             sel = torch.as_tensor(chs, device=bank.dev)
-            g = {k: getattr(bank, k)[sel].cpu().numpy() for k in ("wf_iq", "frames", "rows", "pkts", "raw", "xin", "firo", "s16", "pay")}
+            g = {k: getattr(bank, k)[sel].cpu().numpy() for k in (("wf_iq",) if bank.continuous else ()) +
+                 ("frames", "rows", "pkts", "raw", "xin", "firo", "s16", "pay")}
 
             def wf_ref(ch):
                 p = bank.params[ch]
-                return ko.ddc_wf(adc, p.i_offset, int(np.log2(p.decim)), wf_st[ch])
+                if bank.continuous:
+                    return ko.ddc_wf(adc, p.i_offset, int(np.log2(p.decim)), wf_st[ch])
+                # the non-overlapped frame: CICs reset at the block's first sample, the NCO running on from the steps before
+                st = ko.DdcWfState()
+                st.phase = (step * bank.n * p.i_offset) & ((1 << 48) - 1)
+                return ko.ddc_wf(adc[:8192 * p.decim], p.i_offset, int(np.log2(p.decim)), st)
 
             def rx_ref(ch):
                 return ko.ddc_rx(adc, bank.rx_inc[ch], rx_st[ch])
@@ -1631,8 +1647,9 @@ def check_receiver_bank(bank, chs, steps=3):
                 # waterfall DDC: all of this step's output, then the frame the waterfall took
                 iq, wf_st[ch] = wf_out[i]
                 assert iq.shape[0] == int(nw[ch]), (step, ch)
-                assert np.array_equal(g["wf_iq"][i, :iq.shape[0]], iq), (step, ch)
-                assert np.array_equal(g["frames"][i], iq[:8192])
+                if bank.continuous:
+                    assert np.array_equal(g["wf_iq"][i, :iq.shape[0]], iq), (step, ch)
+                assert np.array_equal(g["frames"][i], iq[:8192]), (step, ch)
                 w_out, _, w_pwr_out, w_dB = oracle_frame(ko, tables, iq[:8192], p, wf.WF_MAX, wf.WINF_HANNING, True, False, False)
                 check_row(g["rows"][i], w_out, w_dB, db_bound(w_pwr_out))
                 want_pkt = ko.wf_packet(g["rows"][i], int(p.start), p.zoom, 0, True)
@@ -1703,8 +1720,11 @@ def run_receivers(args, dist):
     # Integer work per ADC sample and receiver, counted on the algorithm: the waterfall DDC's 36 (run_ddc14) + the audio
     # DDC's NCO / mixer (10) and rx1's three integrators on I and Q (55, 55 and 26 bits: 2 + 2 + 1 words, x 2 = 10);
     # everything behind the first decimation (rx2, CICF, CFastFIR, CAgc, frames, coders) runs at <= 1 / 1543 of the rate.
-    ops = 36 + 20
-    tops = n * NR * ops / step_s / 1e12
+    # The waterfall DDC of the non-overlapped frame consumes 8192 R samples per receiver and step, not the whole block.
+    continuous = os.environ.get("KIWIGPU_BENCH_RX_CONTINUOUS") == "1"
+    wf_samples = sum(n if continuous else min(n, 8192 * p.decim) for p in bank.params)
+    ops = round((36.0 * wf_samples + 20.0 * n * NR) / (n * NR), 2)       # per receiver and ADC sample of the block
+    tops = (36.0 * wf_samples + 20.0 * n * NR) / step_s / 1e12
     traffic, source, top = measured_traffic("receivers", NR)
     # result check at the bench's own shape: a fresh bank of the same receivers (the timed one's state is 100s of steps old),
     # three steps, every stage of a sample of the receivers (every zoom at least once) against the oracle
@@ -1723,7 +1743,7 @@ def run_receivers(args, dist):
     # row out (33 792 B), the audio chain's rx_iq_t records out and in + unpacked samples (6 + 6 + 8 B), a CFastFIR block
     # (16 384 B) every 512 records
     nrec_step = n / 10416.0
-    alg_bytes = 2 * n + sum(4 * (n // p.decim) for p in params) + NR * (8192 * 4 + 1024) + NR * nrec_step * (20 + 16384 / 512.0)
+    alg_bytes = 2 * n + sum(4 * ((n // p.decim) if continuous else 8192) for p in params) + NR * (8192 * 4 + 1024) + NR * nrec_step * (20 + 16384 / 512.0)
     res = {
         "metric": "receiver x ADC Msamples/s ingested (waterfall + audio chain per virtual receiver)",
         "value": round(n * NR * world / step_s / 1e6, 1), "unit": "Msamples/s", "n_gpus": world,
@@ -1734,7 +1754,9 @@ def run_receivers(args, dist):
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[3]: %d virtual receivers per GPU x %d GPU(s), one %d-sample 16-bit ADC "
                                "block @66.67 MS/s (the same stream on every GPU) resident in HBM per step; per receiver a "
-                               "waterfall channel (zooms 1..10) and an SSB audio channel" % (NR, world, n),
+                               "waterfall channel (zooms 1..10; one frame per step, %s) and an SSB audio channel (continuous)"
+                               % (NR, world, n, "continuous sampler over the whole block (round 3's shape)" if continuous else
+                                  "the reference's non-overlapped frame: CmdWFReset + one-shot sampler, rx/rx_waterfall.cpp:1005-1041"),
                    "receivers_per_gpu": NR, "adc_samples_per_step": n,
                    "parallelism": "receivers sharded over ranks, no data-path collective"},
         "adc_ms_per_step": round(n / adc_clock * 1e3, 3),
@@ -1745,7 +1767,8 @@ def run_receivers(args, dist):
                      "achieved": round(tops, 3), "peak": INT_PEAK_TOPS, "unit": "Tiop/s", "frac": round(tops / INT_PEAK_TOPS, 4),
                      "traffic": traffic, "traffic_source": source, "traffic_top_kernels": top,
                      "kernel_ms": round(step_s * 1e3, 5), "kernel_ms_min": round(dts[0], 5),
-                     "kernel_ms_median": round(dts[len(dts) // 2], 5), "int_ops_per_sample_per_receiver": ops},
+                     "kernel_ms_median": round(dts[len(dts) // 2], 5), "int_ops_per_sample_per_receiver": ops,
+                     "waterfall_ddc_samples_per_step": wf_samples, "audio_ddc_samples_per_step": n * NR},
         "hbm": {"algorithmic_bytes_per_step": int(alg_bytes),
                 "algorithmic_GBps": round(alg_bytes / step_s / 1e9, 1),
                 "measured_GBps": None if traffic is None else round(traffic / step_s / 1e9, 1), "peak": HBM_PEAK_GBS},
@@ -1770,13 +1793,15 @@ def cpu_receivers(NR, n, budget_s):
     fs = ReceiverBank.ADC_CLOCK / RX_DECIM
     tables = (wf.window_functions(), wf.cic_comp_table())
     coef = ko.fir_design(300.0, 2700.0, 0.0, fs, prec=0)[1]
+    continuous = os.environ.get("KIWIGPU_BENCH_RX_CONTINUOUS") == "1"
     k = [os.getpid() % NR]                            # (workers are forked: each walks the receivers from its own start)
 
     def unit():
         ch = k[0] % NR
         k[0] += 1
         p = params[ch]
-        iq, _ = ko.ddc_wf(adc, p.i_offset, int(np.log2(p.decim)))
+        # the non-overlapped frame (CmdWFReset + one-shot sampler): the 8192 R samples that fill the sampler, as the GPU path
+        iq, _ = ko.ddc_wf(adc[:8192 * p.decim] if not continuous else adc, p.i_offset, int(np.log2(p.decim)))
         fmap, drop = wf.build_maps(p.fft_used, p.plot_width, p.plot_width_clamped, False)
         scale = np.full(1024, p.fft_scale, np.float32)
         samps = ko.wf_window_iq(iq[:8192], tables[0][wf.WINF_HANNING])

@@ -98,6 +98,7 @@ SYMBOLS = {
     "kg_ddc_reset_wf": (_i, [_vp, _i]),
     "kg_ddc_set_phase": (_i, [_vp, _i, C.c_uint64]),
     "kg_ddc_nco_table": (_i, [_vp, _vp]),
+    "kg_ddc_wf_capture_dev": (_i, [_vp, _vp, _sz, _vp, _i, _vp, _sz, _sz, _vp]),
     "kg_ddc_wf_set_deferred": (_i, [_vp, _i]),
     "kg_ddc_wf_join": (_i, [_vp, _vp]),
     "kg_ddc_wf_tail_after": (_i, [_vp, _vp]),

@@ -129,7 +129,9 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
     const long *__restrict__ c0off, const long *__restrict__ nouts,
     const int *__restrict__ sel,              // list entries this launch covers (null: all, in order)
     int stage_bytes,                          // pass B, R <= 8: dynamic LDS for the strobe staging tiles, else 0
-    u64 pushed)                               // samples pushed since the channels' reference point (ddc_chan)
+    u64 pushed,                               // samples pushed since the channels' reference point (ddc_chan)
+    const long *__restrict__ nlim,            // [nlist] samples of the block this entry consumes (capture: 8192 R; else n)
+    int reset_first)                          // capture: the decimation counter starts the block at zero (rst_wf_samp_wr)
 {
     __shared__ short tab[DDC_TAB];
     extern __shared__ u32 stage_lds[];        // [waves][2][64][DDC_STAGE_ROW] when stage_bytes != 0
@@ -138,7 +140,8 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
     const int li = sel ? sel[blockIdx.y] : (int) blockIdx.y;
     const ddc_chan ch = chans[chan_list[li]];
     const int r = blockIdx.x * DDC_THREADS + threadIdx.x;
-    if (r >= nruns) return;
+    n = nlim[li];                             // this entry's share of the block (wave-uniform)
+    if (r >= nruns || (long) r * L >= n) return;
     const long s0 = (long) r * L, s1 = (s0 + L < n) ? s0 + L : n;
     // the 48-bit accumulator sits in the TOP bits of a 64-bit register: it wraps by itself (no mask per sample)
     u64 ph = (ch.phase + (pushed + (u64) s0) * ch.phase_inc) << 16;
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
 
     if (log2r == 0) return;                   // R == 1 bypass: ddc_wf_bypass_kernel
 
-    const u64 cnt_call = ((u64) ch.sample_no + pushed) & Rm1;      // the decimation counter at the start of this call
+    const u64 cnt_call = reset_first ? 0ull : (((u64) ch.sample_no + pushed) & Rm1);   // the decimation counter at the start of this call
     const u64 cnt0 = cnt_call + (u64) s0;                // samples since the counter was last zero
     const long lI = ((long) li * 2 + 0) * nruns + r, lQ = ((long) li * 2 + 1) * nruns + r;
     u32 i5i = 0, i5q = 0;
@@ -480,7 +483,8 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
 __global__ __launch_bounds__(256) void ddc_wf_bypass_kernel(
     const short *__restrict__ adc, long n, const ddc_chan *__restrict__ chans, const int *__restrict__ chan_list,
     const int *__restrict__ bypass_list, int nbypass,     // list entries with R == 1
-    const u32 *__restrict__ nco, short2 *__restrict__ out, long out_stride, u64 pushed)
+    const u32 *__restrict__ nco, short2 *__restrict__ out, long out_stride, u64 pushed,
+    const long *__restrict__ nlim)            // [nlist] samples this entry takes (capture: max_out; else n)
 {
     __shared__ short tab[DDC_TAB];
     for (int i = threadIdx.x; i < DDC_TAB / 2; i += 256) ((u32 *) tab)[i] = nco[i];
@@ -507,6 +511,9 @@ __global__ __launch_bounds__(256) void ddc_wf_bypass_kernel(
             }
             for (int b = 0; b < nbypass; b++) {
                 const int li = bypass_list[b];
+                const long nb = nlim[li];
+                if (t0 >= nb) continue;
+                const bool fullb = t0 + 4 <= nb;
                 const ddc_chan *ch = chans + chan_list[li];
                 const u64 inc16 = ch->phase_inc << 16;
                 u64 ph = (ch->phase + (pushed + (u64) t0) * ch->phase_inc) << 16;    // top-aligned: wraps by itself
@@ -519,12 +526,12 @@ __global__ __launch_bounds__(256) void ddc_wf_bypass_kernel(
                     r[q] = make_short2((short) (mi >> 8), (short) (mq >> 8));
                     ph += inc16;
                 }
-                if (full && (((uintptr_t) o) & 15) == 0) {
+                if (fullb && (((uintptr_t) o) & 15) == 0) {
                     int4 w0;
                     w0.x = *(int *) &r[0]; w0.y = *(int *) &r[1]; w0.z = *(int *) &r[2]; w0.w = *(int *) &r[3];
                     *(int4 *) o = w0;
                 } else {
-                    for (int q = 0; q < 4; q++) if (t0 + q < n) o[q] = r[q];
+                    for (int q = 0; q < 4; q++) if (t0 + q < nb) o[q] = r[q];
                 }
             }
         }
@@ -653,7 +660,8 @@ struct ddc_chunk_agg { ddc_state4 e; u64 len; u32 epoch; u32 pad; };
 __global__ __launch_bounds__(64 * DDC_SCAN_WAVES) void ddc_wf_scan_states_kernel(
     ddc_state4 *__restrict__ local, long n, int L, int nruns, ddc_chan *__restrict__ chans,
     const int *__restrict__ chan_list, int npairs, int nchunk, ddc_chunk_agg *__restrict__ aggs,
-    u32 *__restrict__ ticket, u32 ticket_base, u32 epoch, const sc_tab tab)
+    u32 *__restrict__ ticket, u32 ticket_base, u32 epoch, const sc_tab tab,
+    const long *__restrict__ nlim, int reset_first)      // per entry: samples consumed; capture: the carried-in state is zero
 {
     __shared__ sc4 w_state[DDC_SCAN_WAVES];
     __shared__ u64 w_len[DDC_SCAN_WAVES];
@@ -666,7 +674,9 @@ __global__ __launch_bounds__(64 * DDC_SCAN_WAVES) void ddc_wf_scan_states_kernel
     const int li = pair >> 1, comp = pair & 1;
     ddc_chan *ch = chans + chan_list[li];
     if (ch->log2r == 0) return;                   // (the whole pair: nobody waits for a bypass channel)
-    ddc_state4 *st = local + ((long) li * 2 + comp) * nruns;
+    ddc_state4 *st = local + ((long) li * 2 + comp) * nruns;        // (rows of the whole launch's run count apart)
+    n = nlim[li];                                 // this entry's share of the block and the runs that hold it
+    { const int nr = (int) ((n + L - 1) / L); nruns = nr < nruns ? nr : nruns; }
     ddc_chunk_agg *agg = aggs + (long) pair * DDC_SCAN_MAX_CHUNKS;
     const int cper = (nruns + nchunk - 1) / nchunk;
     const int c0 = g * cper < nruns ? g * cper : nruns, c1 = c0 + cper < nruns ? c0 + cper : nruns;
@@ -676,7 +686,7 @@ __global__ __launch_bounds__(64 * DDC_SCAN_WAVES) void ddc_wf_scan_states_kernel
     // the saved state is read before anything is published: the last chunk rewrites it at the end, after
     // it has seen every other chunk's aggregate
     sc4 saved = sc_zero();
-    if (gl == 0) saved = sc_of(ch->integ[comp]);
+    if (gl == 0 && !reset_first) saved = sc_of(ch->integ[comp]);
     // 1. lane-local composition
     sc4 acc = sc_zero(); u64 len = 0;
     const sc_coef kL = sc_coef_for((u64) L);      // every run but possibly the last has length L
@@ -758,7 +768,8 @@ __global__ __launch_bounds__(64 * DDC_SCAN_WAVES) void ddc_wf_scan_states_kernel
 // and one more scan by the first four waves, then the offsets are applied.
 #define DDC_TAU_TILES 32                      // max_runs = 16384 = 32 tiles of 512
 __global__ __launch_bounds__(64 * DDC_SCAN_WAVES) void ddc_wf_scan_tau_kernel(
-    u32 *__restrict__ tau, int nruns, ddc_chan *__restrict__ chans, const int *__restrict__ chan_list)
+    u32 *__restrict__ tau, int nruns, ddc_chan *__restrict__ chans, const int *__restrict__ chan_list,
+    const long *__restrict__ nlim, int L, int reset_first)
 {
     __shared__ u32 s_tot[DDC_TAU_TILES * DDC_SCAN_WAVES];       // totals, then exclusive offsets
     __shared__ u32 s_w4[4];
@@ -766,6 +777,7 @@ __global__ __launch_bounds__(64 * DDC_SCAN_WAVES) void ddc_wf_scan_tau_kernel(
     ddc_chan *ch = chans + chan_list[li];
     if (ch->log2r == 0) return;
     u32 *tv = tau + ((long) li * 2 + comp) * nruns;
+    { const int nr = (int) ((nlim[li] + L - 1) / L); nruns = nr < nruns ? nr : nruns; }      // the runs this entry walked
     const int ntile = (nruns + 511) >> 9;         // <= DDC_TAU_TILES (kg_ddc_create caps max_runs at 16384)
     u32 inc[DDC_TAU_TILES], own[DDC_TAU_TILES];
 #pragma unroll
@@ -795,7 +807,7 @@ __global__ __launch_bounds__(64 * DDC_SCAN_WAVES) void ddc_wf_scan_tau_kernel(
         for (int w = 0; w < wave; w++) base += s_w4[w];
         s_tot[gl] = base + tinc - t;              // exclusive
     }
-    const u32 i5 = ch->integ5[comp];
+    const u32 i5 = reset_first ? 0u : ch->integ5[comp];
     __syncthreads();                              // offsets written; every wave has read the saved value
 #pragma unroll
     for (int k = 0; k < DDC_TAU_TILES; k++) {
@@ -826,6 +838,7 @@ __global__ __launch_bounds__(256) void ddc_wf_comb_kernel(
     const u32 *__restrict__ c0rel, const u32 *__restrict__ i5start, int log2L, int nruns,
     const long *__restrict__ c0off, const ddc_chan *__restrict__ chans, const int *__restrict__ chan_list, const long *__restrict__ nouts,
     u64 pushed,                               // samples pushed since the channels' reference point
+    int reset_first,                          // capture: counter and comb registers start the block at zero
     const int *__restrict__ wg_start, int nlist,
     short2 *__restrict__ out, long out_stride, u32 *__restrict__ hist_out)   // [nlist][2][5]
 {
@@ -837,7 +850,7 @@ __global__ __launch_bounds__(256) void ddc_wf_comb_kernel(
     const int log2r = ch->log2r;
     const long nout = nouts[li], plane = (nout + 3) & ~3l;
     const long o0 = (long) (blockIdx.x - wg_start[li]) * DDC_COMB_TILE;
-    const u32 base = (u32) (((u64) ch->sample_no + pushed) & ((1ull << log2r) - 1));     // sample_no before this call
+    const u32 base = reset_first ? 0u : (u32) (((u64) ch->sample_no + pushed) & ((1ull << log2r) - 1));     // sample_no before this call
     auto absolute = [&](int comp, long oo, u32 rel) -> u32 {
         const long g = ((oo + 1) << log2r) - 1 - (long) base;    // sample index of the strobe
         const int run = (int) (g >> log2L);
@@ -869,7 +882,7 @@ __global__ __launch_bounds__(256) void ddc_wf_comb_kernel(
         // the five outputs before the tile: strobes of earlier calls (zero after a reset) or earlier tiles
         if (t < 5) {
             const long pb = o0 - 5 + t;
-            const u32 a = pb < 0 ? ch->hist[comp][5 + pb] : absolute(comp, pb, src[pb]);
+            const u32 a = pb < 0 ? (reset_first ? 0u : ch->hist[comp][5 + pb]) : absolute(comp, pb, src[pb]);
             s_c0[comp][3 + t] = sext32((int) a, 28);
         }
     }
@@ -915,7 +928,7 @@ __global__ __launch_bounds__(256) void ddc_wf_comb_kernel(
 
 // after a call: the comb history (phase and counter are reference values + the host's `pushed`, see ddc_chan)
 __global__ void ddc_wf_finish_kernel(ddc_chan *__restrict__ chans, const int *__restrict__ chan_list, int nlist,
-                                     long n, const long *__restrict__ nouts, const u32 *__restrict__ hist_new)
+                                     long n, const long *__restrict__ nouts, const u32 *__restrict__ hist_new, int reset_first)
 {
     const int li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= nlist) return;
@@ -929,7 +942,7 @@ __global__ void ddc_wf_finish_kernel(ddc_chan *__restrict__ chans, const int *__
             // the last five strobes: fewer than five new ones keep part of the old history
             const long back = 4 - d;             // 0 = most recent
             if (back < nout) h[d] = hist_new[((long) li * 2 + comp) * 5 + d];
-            else h[d] = ch->hist[comp][d + nout];
+            else h[d] = reset_first ? 0u : ch->hist[comp][d + nout];
         }
         for (int d = 0; d < 5; d++) ch->hist[comp][d] = h[d];
     }
@@ -951,6 +964,7 @@ struct kg_ddc {
     hipStream_t side; hipEvent_t ev_fork, ev_join;                   // pass B of the small decimations beside the rest
     kg_stage_cache pack_cache;                 // the per-call tables of the last push (a steady stream repeats them: no upload)
     std::vector<u64> h_pushed;                 // per channel: samples pushed since its reference point (ddc_chan.phase / .sample_no)
+    std::vector<char> h_stale;                 // per channel: a capture cut its filters short; the next continuous push resets it
     // Deferred output stage (kg_ddc_wf_set_deferred): the stage runs on `tail`, the context's stream carries only pass A,
     // the state scan and pass B, so the NEXT push's pass A starts while this push's combs are still writing.
     bool deferred;
@@ -984,6 +998,7 @@ int kg_ddc_create(kg_ctx *ctx, int nchan, size_t max_samples, kg_ddc **out)
     if (d->max_runs > DDC_TARGET_RUNS * 2) d->max_runs = DDC_TARGET_RUNS * 2;
     d->c0_cap[0] = d->c0_cap[1] = 0; d->d_c0rel[0] = d->d_c0rel[1] = nullptr;
     d->h_pushed.assign(nchan, 0);
+    d->h_stale.assign(nchan, 0);
     d->deferred = false; d->tail = nullptr; d->tail_rec[0] = d->tail_rec[1] = false; d->tail_unjoined = false;
     d->parity = 0; d->after_ev = nullptr;
     KG_HIP(hipMalloc((void **) &d->d_chans, sizeof(ddc_chan) * nchan));
@@ -1092,6 +1107,7 @@ int kg_ddc_set_wf(kg_ddc *d, int ch, uint64_t phase_inc, int decim)
     c.log2r = log2r;
     c.active = 1;
     d->h_pushed[ch] = 0;
+    d->h_stale[ch] = 0;
     return ddc_upload(d, ch);
 }
 
@@ -1109,6 +1125,7 @@ int kg_ddc_reset_wf(kg_ddc *d, int ch)
     memset(&c, 0, sizeof c);
     c.phase = ph; c.phase_inc = inc; c.log2r = l2; c.active = 1;
     d->h_pushed[ch] = 0;
+    d->h_stale[ch] = 0;
     return ddc_upload(d, ch);
 }
 
@@ -1177,9 +1194,13 @@ int kg_ddc_wf_tail_after(kg_ddc *d, void *event)
     return KG_OK;
 }
 
-int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *chan_list, int nlist,
-                       void *d_out, size_t out_stride, int64_t *nouts)
+// kg_ddc_wf_push_dev (max_out = 0: the continuous sampler) and kg_ddc_wf_capture_dev (max_out >= 1: CmdWFReset with
+// WF_SAMP_WR_RST at the block's first sample, then the one-shot sampler of verilog/rx/iq_sampler_8k_32b.v, which stops
+// when it holds max_out pairs: only the first max_out << log2r samples of the block reach a channel's filters).
+static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *chan_list, int nlist,
+                         void *d_out, size_t out_stride, size_t max_out, int64_t *nouts)
 {
+    const bool capture = max_out != 0;
     KG_REQUIRE(d && d_adc && chan_list && d_out, KG_ERR_INVALID, "kg_ddc_wf_push_dev: null argument");
     int rc = kg_ctx_use(d->ctx);
     if (rc) return rc;
@@ -1203,13 +1224,27 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
             for (int i = 0; i < nlist; i++) if ((rc = ddc_rebase(d, chan_list[i]))) return rc;
     }
     const u64 pushed = d->h_pushed[chan_list[0]];
-    std::vector<long> h_nouts(nlist), h_off(nlist);
+    // A channel a capture left behind holds the filter state of a block cut short: the next CONTINUOUS push starts it
+    // from the reset state, as the reference does when it changes sampler mode (CmdWFReset with WF_SAMP_CONTIN,
+    // rx/rx_waterfall.cpp:971-978).  Synchronising, rare.
+    if (!capture)
+        for (int i = 0; i < nlist; i++)
+            if (d->h_stale[chan_list[i]]) {
+                if ((rc = kg_ddc_reset_wf(d, chan_list[i]))) return rc;
+                d->h_stale[chan_list[i]] = 0;
+            }
+    std::vector<long> h_nouts(nlist), h_off(nlist), h_nlim(nlist);
     std::vector<int> h_wg(nlist + 1), h_bypass, h_run, h_small, h_rest;
-    long max_nout = 0, c0_need = 0, comb_wgs = 0;
+    long max_nout = 0, c0_need = 0, comb_wgs = 0, n_run_max = 0, n_by_max = 0, n_run_sum = 0;
     for (int i = 0; i < nlist; i++) {
         const int ch = chan_list[i];
         const ddc_chan &c = d->h_chans[ch];
-        h_nouts[i] = (long) (((u64) ddc_cur_cnt(d, ch) + (u64) n) >> c.log2r);
+        // samples of the block this channel's filters see: all of them, or (capture) what fills the one-shot sampler
+        const u64 want = capture ? (u64) max_out << c.log2r : (u64) n;
+        h_nlim[i] = (long) (want < (u64) n ? want : (u64) n);
+        h_nouts[i] = (long) (((capture ? 0ull : (u64) ddc_cur_cnt(d, ch)) + (u64) h_nlim[i]) >> c.log2r);
+        if (c.log2r) { if (h_nlim[i] > n_run_max) n_run_max = h_nlim[i]; n_run_sum += h_nlim[i]; }
+        else if (h_nlim[i] > n_by_max) n_by_max = h_nlim[i];
         KG_REQUIRE((size_t) h_nouts[i] <= out_stride, KG_ERR_INVALID,
                    "kg_ddc_wf_push_dev: out_stride %zu < %ld outputs of channel %d", out_stride, h_nouts[i], ch);
         if (h_nouts[i] > max_nout) max_nout = h_nouts[i];
@@ -1251,15 +1286,27 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
         if (per_chan > target) target = per_chan < d->max_runs ? (int) per_chan : d->max_runs;
     }
     if (const char *e = getenv("KIWIGPU_DDC_RUNS")) { const int v = atoi(e); if (v >= 64 && v <= d->max_runs) target = v; }
+    // the runs cover the longest share of the block any filtered channel takes (the whole block unless capturing)
+    const long n_cover = n_run_max > 0 ? n_run_max : 1;
     int L = DDC_RUN_MIN;
-    while (L < DDC_RUN_MAX && (long) ((n + L - 1) / L) > target) L <<= 1;
-    const int nruns = (int) ((n + L - 1) / L);
+    while (L < DDC_RUN_MAX && (long) ((n_cover + L - 1) / L) > target) L <<= 1;
+    if (capture) {
+        // a capture's channels take very different shares (8192 R samples each): size the runs by the TOTAL work, about
+        // four waves per SIMD over all of them, inside what the longest share allows
+        const long want_threads = (long) d->ctx->num_cus * 4 * 4 * 64;
+        int Lw = DDC_RUN_MIN;
+        while (Lw < DDC_RUN_MAX && n_run_sum / Lw > want_threads) Lw <<= 1;
+        if (Lw > L) L = Lw;
+        while (L < DDC_RUN_MAX && (n_cover + L - 1) / L > d->max_runs) L <<= 1;
+    }
+    const int nruns = (int) ((n_cover + L - 1) / L);
     int log2L = 0;
     while ((1 << log2L) < L) log2L++;
     KG_REQUIRE(nruns <= d->max_runs, KG_ERR_INVALID, "kg_ddc_wf_push_dev: %d runs > %d", nruns, d->max_runs);
     // The per-call tables go through the context's staging ring in one piece: no stream
     // synchronisation, and the previous call's kernels keep their own copy.
-    const long *s_c0off, *s_nouts; const int *s_list, *s_wgoff, *s_bypass, *s_selrun, *s_selsmall, *s_selrest;
+    const long *s_c0off, *s_nouts, *s_nlim; const int *s_list, *s_wgoff, *s_bypass, *s_selrun, *s_selsmall, *s_selrest;
+    const int reset_first = capture ? 1 : 0;
     {
         std::vector<unsigned char> pack;
         auto put = [&](const void *src, size_t bytes) -> size_t {
@@ -1269,6 +1316,7 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
             return at;
         };
         const size_t o_off = put(h_off.data(), sizeof(long) * nlist), o_nouts = put(h_nouts.data(), sizeof(long) * nlist);
+        const size_t o_nlim = put(h_nlim.data(), sizeof(long) * nlist);
         const size_t o_list = put(chan_list, sizeof(int) * nlist);
         const size_t o_wg = put(h_wg.data(), sizeof(int) * (nlist + 1));
         const size_t o_by = put(h_bypass.data(), sizeof(int) * h_bypass.size());
@@ -1285,7 +1333,7 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
         void *base = nullptr;
         if ((rc = kg_ctx_stage_cached(d->ctx, &d->pack_cache, pack.data(), pack.size(), &base))) return rc;
         const unsigned char *b = (const unsigned char *) base;
-        s_c0off = (const long *) (b + o_off); s_nouts = (const long *) (b + o_nouts);
+        s_c0off = (const long *) (b + o_off); s_nouts = (const long *) (b + o_nouts); s_nlim = (const long *) (b + o_nlim);
         s_list = (const int *) (b + o_list); s_wgoff = (const int *) (b + o_wg);
         s_bypass = (const int *) (b + o_by); s_selrun = (const int *) (b + o_run);
         s_selsmall = (const int *) (b + o_small); s_selrest = (const int *) (b + o_rest);
@@ -1324,10 +1372,10 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
             KG_HIP(hipStreamWaitEvent(d->side, d->ev_fork, 0));
             bst = d->side; side_used = true;
         }
-        const long nblk_by = (n + 2047) / 2048, cap_by = (long) d->ctx->num_cus * 4;   // LDS: 20 KiB each, 4 per CU
+        const long nblk_by = (n_by_max + 2047) / 2048, cap_by = (long) d->ctx->num_cus * 4;   // LDS: 20 KiB each, 4 per CU
         hipLaunchKernelGGL(ddc_wf_bypass_kernel, dim3((unsigned) (nblk_by < cap_by ? nblk_by : cap_by)), dim3(256),
-                           0, bst, (const short *) d_adc, (long) n, (const ddc_chan *) d->d_chans, s_list,
-                           s_bypass, (int) h_bypass.size(), (const u32 *) d->d_nco, (short2 *) d_out, (long) out_stride, pushed);
+                           0, bst, (const short *) d_adc, (long) n_by_max, (const ddc_chan *) d->d_chans, s_list,
+                           s_bypass, (int) h_bypass.size(), (const u32 *) d->d_nco, (short2 *) d_out, (long) out_stride, pushed, s_nlim);
         KG_HIP(hipGetLastError());
     }
     const unsigned gx = (unsigned) ((nruns + DDC_THREADS - 1) / DDC_THREADS);
@@ -1335,7 +1383,7 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
         hipLaunchKernelGGL(ddc_wf_run_kernel<false>, dim3(gx, (unsigned) h_run.size()), dim3(DDC_THREADS), 0, st,
                            (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, s_list,
                            (const u32 *) d->d_nco, d_local, d_c0rel, d_tau, s_c0off,
-                           s_nouts, s_selrun, 0, pushed);
+                           s_nouts, s_selrun, 0, pushed, s_nlim, reset_first);
         KG_HIP(hipGetLastError());
     }
     {
@@ -1372,7 +1420,7 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
         }
         hipLaunchKernelGGL(ddc_wf_scan_states_kernel, dim3((unsigned) (npairs * nchunk)), dim3(64 * DDC_SCAN_WAVES), 0, st,
                            d_local, (long) n, L, nruns, d->d_chans, s_list, npairs, nchunk, d->d_aggs, d->d_ticket,
-                           d->ticket_base, d->epoch + 1, tab);
+                           d->ticket_base, d->epoch + 1, tab, s_nlim, reset_first);
         KG_HIP(hipGetLastError());
         // only a launch that was accepted advances the ticket counter and publishes under the new epoch
         d->epoch++;
@@ -1390,7 +1438,7 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
     auto pass_b = [&](hipStream_t s, const std::vector<int> &which, const int *sel, int stage) {
         hipLaunchKernelGGL(ddc_wf_run_kernel<true>, dim3(gx, (unsigned) which.size()), dim3(DDC_THREADS), stage, s,
                            (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, s_list,
-                           (const u32 *) d->d_nco, d_local, d_c0rel, d_tau, s_c0off, s_nouts, sel, stage, pushed);
+                           (const u32 *) d->d_nco, d_local, d_c0rel, d_tau, s_c0off, s_nouts, sel, stage, pushed, s_nlim, reset_first);
     };
     if (beside) {
         if ((rc = side_ready())) return rc;
@@ -1423,18 +1471,18 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
         KG_HIP(hipStreamWaitEvent(ost, d->ev_join, 0));
     }
     hipLaunchKernelGGL(ddc_wf_scan_tau_kernel, dim3(2 * nlist), dim3(64 * DDC_SCAN_WAVES), 0, ost, d_tau, nruns, d->d_chans,
-                       s_list);
+                       s_list, s_nlim, L, reset_first);
     KG_HIP(hipGetLastError());
     if (comb_wgs > 0) {
         hipLaunchKernelGGL(ddc_wf_comb_kernel, dim3((unsigned) comb_wgs), dim3(256), 0, ost,
                            (const u32 *) d_c0rel, (const u32 *) d_tau, log2L, nruns, s_c0off,
                            (const ddc_chan *) d->d_chans, s_list, s_nouts,
-                           pushed, s_wgoff, nlist, (short2 *) d_out, (long) out_stride,
+                           pushed, reset_first, s_wgoff, nlist, (short2 *) d_out, (long) out_stride,
                            d->d_hist);
         KG_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(ddc_wf_finish_kernel, dim3((nlist + 63) / 64), dim3(64), 0, ost, d->d_chans,
-                       s_list, nlist, (long) n, s_nouts, (const u32 *) d->d_hist);
+                       s_list, nlist, (long) n, s_nouts, (const u32 *) d->d_hist, reset_first);
     KG_HIP(hipGetLastError());
     if (d->tail) {                                // (also in line: a later deferred push finds its buffer set covered)
         KG_HIP(hipEventRecord(d->ev_tail[par], ost));
@@ -1442,8 +1490,24 @@ int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *ch
         d->tail_unjoined = defer;
     }
     d->parity = par ^ 1;
-    for (int i = 0; i < nlist; i++) d->h_pushed[chan_list[i]] += (u64) n;
+    for (int i = 0; i < nlist; i++) {
+        d->h_pushed[chan_list[i]] += (u64) n;                      // the NCO runs through the whole block either way
+        if (capture) d->h_stale[chan_list[i]] = 1;                // filters stopped short of the block's end
+    }
     return KG_OK;
+}
+
+int kg_ddc_wf_push_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *chan_list, int nlist,
+                       void *d_out, size_t out_stride, int64_t *nouts)
+{
+    return ddc_push_impl(d, d_adc, n, chan_list, nlist, d_out, out_stride, 0, nouts);
+}
+
+int kg_ddc_wf_capture_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *chan_list, int nlist,
+                          void *d_out, size_t out_stride, size_t max_out, int64_t *nouts)
+{
+    KG_REQUIRE(max_out >= 1 && max_out <= ((size_t) 1 << 31), KG_ERR_INVALID, "kg_ddc_wf_capture_dev: max_out %zu", max_out);
+    return ddc_push_impl(d, d_adc, n, chan_list, nlist, d_out, out_stride, max_out, nouts);
 }
 
 }  // extern "C"

@@ -74,6 +74,33 @@ class Ddc:
               "kg_ddc_wf_push_dev")
         return nouts
 
+    def capture_dev(self, d_adc, n, chans, d_out, out_stride, max_out=8192):
+        """The reference's non-overlapped frame (CmdWFReset + one-shot sampler, kg_ddc_wf_capture_dev): CICs reset at the
+        block's first sample, each channel's first max_out outputs written, NCOs advanced by the whole block."""
+        chans = np.ascontiguousarray(chans, np.int32)
+        nouts = np.zeros(chans.size, np.int64)
+        check(self.lib.kg_ddc_wf_capture_dev(self.h, ptr(int(d_adc)), int(n), ptr(chans), chans.size,
+                                             ptr(int(d_out)), int(out_stride), int(max_out), ptr(nouts)),
+              "kg_ddc_wf_capture_dev")
+        return nouts
+
+    def capture(self, adc, chans, max_out=8192):
+        """Convenience for tests: host int16 array in, list of [<= max_out, 2] int16 arrays out."""
+        adc = np.ascontiguousarray(adc, np.int16)
+        d_adc = self.ctx.alloc(adc.nbytes)
+        d_out = self.ctx.alloc(len(chans) * max_out * 4)
+        try:
+            self.ctx.upload(d_adc, adc)
+            nouts = self.capture_dev(d_adc, adc.size, chans, d_out, max_out, max_out)
+            if getattr(self, "deferred", False):
+                self.join()
+            host = np.zeros((len(chans), max_out, 2), np.int16)
+            self.ctx.download(d_out, host)
+        finally:
+            self.ctx.free(d_adc)
+            self.ctx.free(d_out)
+        return [host[i, :int(nouts[i])].copy() for i in range(len(chans))]
+
     def push(self, adc, chans):
         """Convenience for tests: host int16 array in, list of [nout, 2] int16 arrays out."""
         adc = np.ascontiguousarray(adc, np.int16)

@@ -279,6 +279,17 @@ long kg_ddc_wf_outputs(kg_ddc *ddc, int ch, size_t n);
  * call, so a stream may be pushed in pieces of any length.  Enqueue only. */
 int kg_ddc_wf_push_dev(kg_ddc *ddc, const void *d_adc, size_t n, const int32_t *chan_list,
                        int nlist, void *d_out, size_t out_stride, int64_t *nouts);
+/* The reference's NON-OVERLAPPED waterfall frame (sample_wf(), rx/rx_waterfall.cpp:1005-1041): CmdWFReset with
+ * WF_SAMP_RD_RST | WF_SAMP_WR_RST -- verilog/rx/waterfall_1cic.v:45-47,106-128: both CICs (registers, decimation
+ * counter) and the sampler's write pointer are cleared, the NCO keeps running -- then the ONE-SHOT sampler
+ * (IQ_SAMPLER_8K_32B, wr_continuous = 0) fills with the next 8192 outputs and stops.  Here: the reset falls on the
+ * block's first sample; channel chan_list[i] writes its first min(max_out, n >> log2 R) pairs to d_out + i*out_stride
+ * and only the max_out * R samples that produce them reach its filters (a zoom-1 channel reads 8192 samples of a
+ * 4 Mi-sample block, not all of it); every NCO advances by the whole block.  A channel captured from is left with its
+ * filters stopped short: the next kg_ddc_wf_push_dev on it starts from the reset state, as the reference does when it
+ * switches the sampler to continuous mode (CmdWFReset with WF_SAMP_CONTIN, :971-978).  Enqueue only. */
+int kg_ddc_wf_capture_dev(kg_ddc *ddc, const void *d_adc, size_t n, const int32_t *chan_list,
+                          int nlist, void *d_out, size_t out_stride, size_t max_out, int64_t *nouts);
 /* Deferred output stage (round 4) -- the non-blocking submit / poll form SURVEY 8(b) asks of the DDC seam (today every
  * CmdGetWFSamples is a blocking SPI transaction, platform/common/spi.cpp:487-507).  Off (default): everything a push
  * enqueues is ordered on the context's stream.  On: the push returns with its output stage (R = 1 bypass channels,

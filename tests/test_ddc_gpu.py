@@ -439,3 +439,79 @@ def test_channels_of_different_age_are_rebased(gpu_ctx, oracle, deferred):
             assert np.array_equal(g[i], ref(ch, e)), ("after", ch)
     finally:
         d.close()
+
+
+def _capture_ref(oracle, adc, inc, log2r, phase0, max_out):
+    """CmdWFReset (CIC registers and decimation counter cleared, NCO running on at phase0) + one-shot sampler."""
+    st = oracle.DdcWfState()
+    st.phase = phase0 & ((1 << 48) - 1)
+    need = min(adc.size, max_out << log2r)
+    w, _ = oracle.ddc_wf(adc[:need], inc, log2r, st)
+    return w[:max_out]
+
+
+@pytest.mark.parametrize("deferred", [False, True])
+def test_capture_is_reset_plus_one_shot_sampler(gpu_ctx, oracle, deferred):
+    """kg_ddc_wf_capture_dev = the reference's non-overlapped frame (rx/rx_waterfall.cpp:1005-1041,
+    verilog/rx/waterfall_1cic.v:45-47): per block every channel's CICs restart, the NCO runs on, the first 8192 outputs are
+    kept.  Three consecutive blocks of 2^21 samples, decimations 1 .. 512 (zooms 1 .. 10, the receivers' set) plus one too
+    slow to fill the sampler (R = 2048: 1024 outputs per block): every block's capture against the oracle started from
+    a cleared filter at that block's NCO phase -- bit for bit.  Then a continuous push on the same channels: it starts
+    from the reset state (the reference resets when it changes sampler mode), NCO still running."""
+    n = 1 << 21
+    log2rs = [0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11]
+    C = len(log2rs)
+    adc = adc_stream(4 * n, seed=41, tones=((0.031, 8000.0), (0.1234, 2000.0), (0.3, 300.0)))
+    incs = [inc_for(0.03 + 0.011 * ch) for ch in range(C)]
+    d = Ddc(gpu_ctx, nchan=C, max_samples=n)
+    try:
+        for ch in range(C):
+            d.set_wf(ch, incs[ch], 1 << log2rs[ch])
+        d.set_deferred(deferred)
+        for k in range(3):
+            blk = adc[k * n:(k + 1) * n]
+            got = d.capture(blk, list(range(C)), 8192)
+            for ch in range(C):
+                want = _capture_ref(oracle, blk, incs[ch], log2rs[ch], k * n * incs[ch], 8192)
+                assert got[ch].shape[0] == min(8192, n >> log2rs[ch]) == want.shape[0], (k, ch)
+                assert np.array_equal(got[ch], want), (k, ch, log2rs[ch])
+        # a smaller sampler and a subset of the channels in another order
+        blk = adc[3 * n:3 * n + 300_000]
+        sub = [7, 2, 0, 11]
+        got = d.capture(blk, sub, 1000)
+        for i, ch in enumerate(sub):
+            want = _capture_ref(oracle, blk, incs[ch], log2rs[ch], 3 * n * incs[ch], 1000)
+            assert np.array_equal(got[i], want), ("subset", ch)
+        # continuous push after captures: reset filters, phase = everything pushed so far (the subset's channels are
+        # 300 000 samples further on than the others: one re-base)
+        tail = adc[3 * n + 300_000:3 * n + 400_000]
+        got = d.push(tail, list(range(C)))
+        for ch in range(C):
+            st = oracle.DdcWfState()
+            st.phase = ((3 * n + (300_000 if ch in sub else 0)) * incs[ch]) & ((1 << 48) - 1)
+            want, _ = oracle.ddc_wf(tail, incs[ch], log2rs[ch], st)
+            assert np.array_equal(got[ch], want), ("push after capture", ch)
+    finally:
+        d.close()
+
+
+def test_capture_of_a_short_block_and_odd_sizes(gpu_ctx, oracle):
+    """Blocks shorter than the sampler needs (fewer than max_out outputs come back), sizes that are no multiple of a run,
+    max_out = 1."""
+    d = Ddc(gpu_ctx, nchan=3, max_samples=1 << 18)
+    try:
+        incs = [inc_for(0.07), inc_for(0.2), inc_for(0.013)]
+        l2 = [3, 6, 0]
+        for ch in range(3):
+            d.set_wf(ch, incs[ch], 1 << l2[ch])
+        pos = 0
+        adc = adc_stream(400_000, seed=43)
+        for ln, mo in ((70_001, 8192), (64, 8192), (131_072, 1), (99_999, 300), (12_345, 8192)):
+            blk = adc[pos:pos + ln]
+            got = d.capture(blk, [0, 1, 2], mo)
+            for ch in range(3):
+                want = _capture_ref(oracle, blk, incs[ch], l2[ch], pos * incs[ch], mo)
+                assert got[ch].shape == want.shape and np.array_equal(got[ch], want), (ln, mo, ch)
+            pos += ln
+    finally:
+        d.close()
