@@ -716,7 +716,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
 // Combine twiddle W_N^{n k2} = W_N^{i k2} (registers) x W_{N/512}^{m k2}, m = 4a + b: comb8[k2] = { W^{k2},
 // W^{2 k2}, W^{3 k2}, W^{4 k2} } with W = W_{N/512}.
 // ---------------------------------------------------------------------------
-#define ACQ8_LDS_BYTES (3 * SUB * sizeof(float2) + 8 * sizeof(acq_red) + 16 + 16 * 8 * sizeof(float2))   // + the per-k2 constants
+#define ACQ8_LDS_BYTES (3 * SUB * sizeof(float2) + 8 * sizeof(acq_red) + 16 + 16 * 8 * sizeof(float2) + 3 * 512 * 4)   // + the per-k2 constants + the cell-end hand-over
 
 template <int P, bool STAMPS = false>        // STAMPS: diagnostic instantiation only (kg_acq_debug_corr_stamps)
 __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
@@ -737,6 +737,11 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
     // read by broadcast ds_reads: as scalar loads they shared the lgkmcnt counter with the tile reads, which then
     // waited for a scalar-cache round trip in every item
     float2 *cst = (float2 *) ((char *) (red + 8) + 16);
+    // cell-end hand-over (round 4): every lane's (maximum, its n, total) of the cell that just ended; waves 0..3 reduce
+    // them -- their own and their SIMD partner's (lane i + 256) -- one item later, in barrier slack
+    float *xch_p = (float *) (cst + 16 * 8);
+    int *xch_i = (int *) (xch_p + 512);
+    float *xch_s = (float *) (xch_i + 512);
     const int i = threadIdx.x;
     if (i < 8 * P) {
         const int k2 = i >> 3, k = i & 7;
@@ -792,14 +797,21 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
     // first item, which waited ~1 000 cycles for it (in-kernel stamps); a vector load is waited for where it is used.
     int vzero = 0;
     asm volatile("" : "+v"(vzero));                // opaque: keeps the compiler from scalarising the load below
-    auto describe = [&](int idx) {
+    // Round 4: the record is REQUESTED at the top of a cell and turned into scalars only where the next cell's first
+    // operands are addressed (item P - 2): resolved on the spot, every cell began with an exposed L2 round trip -- ~1 000
+    // cycles of the ~4 800 between a cell's last item and the next cell's first (profiles/r03_e1b8_stamps_final.txt).
+    struct acq_pend { int4 pv; int di; };
+    auto describe_issue = [&](int idx) {
         const int cell = spread ? (idx << 3) + xcd : idx;
         const int pg = cell / ndop, di = cell - pg * ndop;
-        const int4 pv = *(const int4 *) (pairs + (spread ? pg : (pg << 3) + xcd) + vzero);
-        const int data_off = __builtin_amdgcn_readfirstlane(pv.x), code_off = __builtin_amdgcn_readfirstlane(pv.y);
-        const int lim = __builtin_amdgcn_readfirstlane(pv.z), out = __builtin_amdgcn_readfirstlane(pv.w);
-        return acq_cell_desc{data_off, code_off, walk.dop_lo + di, lim, out + di};
+        return acq_pend{*(const int4 *) (pairs + (spread ? pg : (pg << 3) + xcd) + vzero), di};
     };
+    auto describe_resolve = [&](const acq_pend &pd) {
+        const int data_off = __builtin_amdgcn_readfirstlane(pd.pv.x), code_off = __builtin_amdgcn_readfirstlane(pd.pv.y);
+        const int lim = __builtin_amdgcn_readfirstlane(pd.pv.z), out = __builtin_amdgcn_readfirstlane(pd.pv.w);
+        return acq_cell_desc{data_off, code_off, walk.dop_lo + pd.di, lim, out + pd.di};
+    };
+    auto describe = [&](int idx) { return describe_resolve(describe_issue(idx)); };
 
     // The four passes of an item are software-pipelined over two items so that an item costs TWO workgroup
     // barriers, not three, and every interval between barriers holds two independent chains:
@@ -843,10 +855,30 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
         for (int m = 0; m < 8; m++) kg_st(&tile1[w1 + 8 * (m ^ b1)], y[m]);
         __syncthreads();
     }
+#ifndef KG_E1B_HANDOVER
+#define KG_E1B_HANDOVER(P) true
+#endif
+    constexpr bool HANDOVER = KG_E1B_HANDOVER(P);
     int prev_out = -1, prev_limit = 1;
+    // waves 0..3: lane i reduces its own and lane i + 256's hand-over values, then the wave; red[wave] out
+    auto reduce_pairs = [&]() {
+        if (i < 256) {
+            float bp = xch_p[i], sum = xch_s[i];
+            int bi = xch_i[i];
+            const float op = xch_p[i + 256], os = xch_s[i + 256];
+            const int oi = xch_i[i + 256];
+            const bool take = (op > bp) | ((op == bp) & (oi < bi));        // first maximum in ascending n
+            bp = take ? op : bp; bi = take ? oi : bi;
+            sum += os;
+            float wmax = bp, wsum = sum;
+            kg_wave_max_sum(wmax, wsum);
+            const int wn = kg_wave_min(bp == wmax ? bi : 0x7fffffff);
+            if ((i & 63) == 0) { red[i >> 6].p = wmax; red[i >> 6].i = wn; red[i >> 6].s = wsum; }
+        }
+    };
     auto merge_store = [&](int out, int limit) {
-        if (i < 64) {                                  // lanes 0..7 of wave 0 merge the eight waves
-            const acq_red r = red[i & 7];
+        if (i < 64) {                                  // lanes 0..3 (0..7 without the hand-over) of wave 0 merge the wave results
+            const acq_red r = red[HANDOVER ? (i & 3) : (i & 7)];
             float bp = r.p, sum = r.s;
             int mi = r.i;
 #define ACQ_RED_STEP(L)                                                               \
@@ -857,7 +889,8 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
                 bp = take ? op : bp; mi = take ? oi : mi;                                \
                 sum += os;                                                               \
             }
-            ACQ_RED_STEP(0) ACQ_RED_STEP(1) ACQ_RED_STEP(2)
+            ACQ_RED_STEP(0) ACQ_RED_STEP(1)
+            if (!HANDOVER) ACQ_RED_STEP(2)
 #undef ACQ_RED_STEP
             if (i == 0) {
                 const float ave = sum / (float) limit;     // :493
@@ -870,7 +903,12 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
     };
     for (;;) {
         const bool more = nxt_idx < ncell;
+#ifndef KG_E1B_EAGER_DESCRIBE
+        const acq_pend pend = describe_issue(more ? nxt_idx : cur_idx);
+        acq_cell_desc nxt = cur;                       // (resolved at item P - 2, the first one that addresses the next cell)
+#else
         const acq_cell_desc nxt = describe(more ? nxt_idx : cur_idx);
+#endif
         int claimed = 0;
         // (lane 0 of wave 7 claims: wave 0 already carries the result merge and store of every cell)
         if (i == 448) claimed = __hip_atomic_fetch_add(&claim[xcd], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -889,6 +927,9 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
             // prefetch of every item would be waited for on the spot)
             unsigned long long *sti = (STAMPS && st && st_item < 60) ? st + 16 + 16 * st_item : nullptr;
             KG_STAMP(STAMPS, sti, 0);
+#ifndef KG_E1B_EAGER_DESCRIBE
+            if (k2 == P - 2) nxt = describe_resolve(pend);
+#endif
             // The operands of item n+2 -- (cur, k2 + 2) or (nxt, k2 + 2 - P); ONE set of load sites, never skipped --
             // are requested one row (a data and a code load, two legs each) at a time BETWEEN the arithmetic blocks of both phases:
             // a buffer load costs the CU's one texture addresser about twenty cycles, all eight waves reach the same
@@ -958,7 +999,7 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
                 for (int q = 0; q < 4; q++)
 #pragma unroll
                     for (int m = 0; m < 8; m++) acc[q][m] = y[m];
-                if (prev_out >= 0) merge_store(prev_out, prev_limit);      // the cell before (wave 0; see the cell end)
+                if (!HANDOVER && prev_out >= 0) merge_store(prev_out, prev_limit);      // the cell before (wave 0; see the cell end)
             } else {
                 // z[m] = y[m] * base * W^{4a k2} * W^{b k2}, m = 4a + b; then acc_q[m] += z[m] * W_P^{q k2}
                 const cf B1 = kg_cmul(base, G);
@@ -994,6 +1035,10 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
                     }
                 }
             }
+            // The cell before: its wave reductions in item 1 (waves 0..3, which wait ~700 cycles at this barrier otherwise),
+            // its merge and store in item 2 (wave 0) -- see the cell end.
+            if (HANDOVER && k2 == 1 && prev_out >= 0) reduce_pairs();
+            if (HANDOVER && k2 == 2 && prev_out >= 0) merge_store(prev_out, prev_limit);
             KG_STAMP(STAMPS, sti, 8);
             if (STAMPS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             KG_STAMP(STAMPS, sti, 9);
@@ -1046,7 +1091,14 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
         const unsigned rowmask = (qm[0] | (qm[1] << 8)) | ((qm[2] << 16) | (qm[3] << 24));
         int bi = i + 512 * (int) __builtin_ctz(rowmask | 0x80000000u);
         KG_STAMP(STAMPS, stc, 1);
-        {
+        // Round 4: NO wave reduction here.  The three dependent DPP chains (maximum, lowest n among its holders, total) took
+        // ~680 cycles in every wave, and at a cell end the waves that lose the issue arbitration (4..7) are the ones the
+        // barrier waits for.  Every lane hands its three values over through LDS (three stores) instead; waves 0..3 reduce
+        // their own and their partner's in item 1 of the next cell and wave 0 merges and stores in item 2, both inside the
+        // ~700 cycles those waves wait at the phase-B barrier anyway (profiles/r03_e1b8_stamps_final.txt).
+        if (HANDOVER) {
+            xch_p[i] = bp; xch_i[i] = bi; xch_s[i] = sum;
+        } else {                                       // in place: every wave reduces its own lanes here
             float wmax = bp, wsum = sum;
             kg_wave_max_sum(wmax, wsum);
             const int wn = kg_wave_min(bp == wmax ? bi : 0x7fffffff);
@@ -1057,12 +1109,14 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
         __syncthreads();
         KG_STAMP(STAMPS, stc, 3);
         const int nn_idx = __builtin_amdgcn_readfirstlane(*red_claim);
-        // The merge of the eight wave results and the store of the cell are DEFERRED: wave 0 does them in phase B of the
-        // next cell's first item, where it otherwise waits at the barrier for hundreds of cycles (as the first thing after
-        // this barrier they made wave 0 800 cycles late for the whole workgroup's next barrier).  red[] is rewritten at
-        // the next cell end only.
         prev_out = cur.out; prev_limit = limit;
-        if (!more) merge_store(prev_out, prev_limit);
+        if (!more) {                                   // the workgroup's last cell: nothing to hide behind
+            if (HANDOVER) {
+                reduce_pairs();
+                __syncthreads();
+            }
+            merge_store(prev_out, prev_limit);
+        }
         KG_STAMP(STAMPS, stc, 4);
         if (!more) break;
         cur = nxt; cur_idx = nxt_idx; nxt_idx = nn_idx;

@@ -167,12 +167,29 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
     // The last whole group of a run re-reads itself: one load site, never skipped.
     const bool al = (((uintptr_t) (adc + s0)) & 15) == 0;          // L is a multiple of 8: every group of the run is aligned alike
     const long g1 = al ? s1 : s0;                                  // the group loops run to g1: a misaligned block goes sample by sample
-    int4 ahead = make_int4(0, 0, 0, 0);
-    if (s0 + 8 <= g1) ahead = *(const int4 *) (adc + s0);
+    // Round 4: TWO groups ahead.  With the ADC stream coming from HBM (a block larger than the Infinity Cache, or one the
+    // DMA engine has just written) the first touch of a 128-byte line -- one in eight of a lane's loads -- takes longer than
+    // the one group of arithmetic the load used to run ahead of: the bench's rotation of nine 32 MiB blocks cost ddc14
+    // 0.44 -> 0.47 ms.  KG_DDC_AHEAD=1 restores the single look-ahead.
+#ifndef KG_DDC_AHEAD
+#define KG_DDC_AHEAD 2
+#endif
+    const long last_grp = g1 - 8;                                  // start of the run's last whole group (callers check s0 + 8 <= g1)
+    int4 ahead = make_int4(0, 0, 0, 0), ahead2 = make_int4(0, 0, 0, 0);
+    if (s0 + 8 <= g1) {
+        ahead = *(const int4 *) (adc + s0);
+        if (KG_DDC_AHEAD == 2) ahead2 = *(const int4 *) (adc + (s0 + 8 <= last_grp ? s0 + 8 : last_grp));
+    }
     auto samples8 = [&](long t, short (&buf)[8]) {                 // callers guarantee t + 8 <= g1 and walk t in steps of 8 from s0
         const int4 v = ahead;
-        const long tn = (t + 16 <= g1) ? t + 8 : t;
-        ahead = *(const int4 *) (adc + tn);
+        if (KG_DDC_AHEAD == 2) {
+            ahead = ahead2;
+            const long tn = t + 16 <= last_grp ? t + 16 : last_grp;     // (the last groups re-read the run's last one: one load site, never skipped)
+            ahead2 = *(const int4 *) (adc + tn);
+        } else {
+            const long tn = (t + 16 <= g1) ? t + 8 : t;
+            ahead = *(const int4 *) (adc + tn);
+        }
         buf[0] = (short) v.x; buf[1] = (short) (v.x >> 16); buf[2] = (short) v.y; buf[3] = (short) (v.y >> 16);
         buf[4] = (short) v.z; buf[5] = (short) (v.z >> 16); buf[6] = (short) v.w; buf[7] = (short) (v.w >> 16);
     };
@@ -670,13 +687,15 @@ __global__ __launch_bounds__(64 * DDC_SCAN_WAVES) void ddc_wf_scan_states_kernel
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = threadIdx.x;
     if (gl == 0) s_id = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ticket_base;
     __syncthreads();
-    const int id = (int) s_id, g = id / npairs, pair = id - g * npairs;     // chunk-major: chunk 0 of every pair first
+    // (through readfirstlane: the ticket is the same in every lane, and with it everything derived from the entry -- its
+    // share of the block, its run count, the chunk bounds -- stays in scalar registers)
+    const int id = __builtin_amdgcn_readfirstlane((int) s_id), g = id / npairs, pair = id - g * npairs;     // chunk-major: chunk 0 of every pair first
     const int li = pair >> 1, comp = pair & 1;
     ddc_chan *ch = chans + chan_list[li];
     if (ch->log2r == 0) return;                   // (the whole pair: nobody waits for a bypass channel)
     ddc_state4 *st = local + ((long) li * 2 + comp) * nruns;        // (rows of the whole launch's run count apart)
     n = nlim[li];                                 // this entry's share of the block and the runs that hold it
-    { const int nr = (int) ((n + L - 1) / L); nruns = nr < nruns ? nr : nruns; }
+    { const int nr = (int) ((n + L - 1) >> (31 - __builtin_clz(L))); nruns = nr < nruns ? nr : nruns; }    // L is a power of two
     ddc_chunk_agg *agg = aggs + (long) pair * DDC_SCAN_MAX_CHUNKS;
     const int cper = (nruns + nchunk - 1) / nchunk;
     const int c0 = g * cper < nruns ? g * cper : nruns, c1 = c0 + cper < nruns ? c0 + cper : nruns;
@@ -777,7 +796,10 @@ __global__ __launch_bounds__(64 * DDC_SCAN_WAVES) void ddc_wf_scan_tau_kernel(
     ddc_chan *ch = chans + chan_list[li];
     if (ch->log2r == 0) return;
     u32 *tv = tau + ((long) li * 2 + comp) * nruns;
-    { const int nr = (int) ((nlim[li] + L - 1) / L); nruns = nr < nruns ? nr : nruns; }      // the runs this entry walked
+    {   // the runs this entry walked (li comes from blockIdx: a scalar load, a scalar ntile)
+        const int nr = (int) ((nlim[li] + L - 1) >> (31 - __builtin_clz(L)));       // L is a power of two
+        nruns = nr < nruns ? nr : nruns;
+    }
     const int ntile = (nruns + 511) >> 9;         // <= DDC_TAU_TILES (kg_ddc_create caps max_runs at 16384)
     u32 inc[DDC_TAU_TILES], own[DDC_TAU_TILES];
 #pragma unroll
@@ -787,8 +809,11 @@ __global__ __launch_bounds__(64 * DDC_SCAN_WAVES) void ddc_wf_scan_tau_kernel(
     }
 #pragma unroll
     for (int k = 0; k < DDC_TAU_TILES; k++) {
-        u32 v = own[k];
-        for (int d = 1; d < 64; d <<= 1) { const u32 a = __shfl_up(v, d); if (lane >= d) v += a; }
+        u32 v = 0;
+        if (k < ntile) {                              // scalar branch (ntile is wave-uniform): a capture's short entries skip the tiles they lack
+            v = own[k];
+            for (int d = 1; d < 64; d <<= 1) { const u32 a = __shfl_up(v, d); if (lane >= d) v += a; }
+        }
         inc[k] = v;
         if (lane == 63) s_tot[k * DDC_SCAN_WAVES + wave] = v;
     }
