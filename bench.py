@@ -1719,15 +1719,26 @@ def run_receivers(args, dist):
     ev0.record(bank.main)
     for s_ in streams[1:]:
         s_.wait_event(ev0)                           # one time origin for all four
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in streams] for _ in range(args.steps)]
-    for i in range(args.steps):
+    # (the pass starts from an idle GPU and ends by draining four streams: the first FILL and the last DRAIN intervals are
+    # the pipeline filling and emptying -- 2.0 ... 1.4 ms and 0.6 ... 0.5 ms in a trace of 24 steps -- not the cadence)
+    FILL, DRAIN = 6, 3
+    nst = args.steps + FILL + DRAIN
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in streams] for _ in range(nst)]
+    for i in range(nst):
         step()
         for e, s_ in zip(evs[i], streams):
             e.record(s_)
     torch.cuda.synchronize(dev)
-    done = [max(ev0.elapsed_time(e) for e in evs[i]) for i in range(args.steps)]
-    dts = sorted([done[0]] + [done[i + 1] - done[i] for i in range(args.steps - 1)])[:]
-    dts_main = sorted(evs[i][0].elapsed_time(evs[i + 1][0]) for i in range(args.steps - 1))
+    done = [max(ev0.elapsed_time(e) for e in evs[i]) for i in range(nst)]
+    iv = [done[i + 1] - done[i] for i in range(FILL - 1, nst - DRAIN - 1)]            # args.steps steady-state intervals
+    dts = sorted(iv)
+    # the audio chain emits a 512-sample block on two steps of three (402 rx_iq_t records a step): a period-3 pattern in
+    # the work of a step; over whole audio cycles the cadence is the figure to watch
+    cyc3 = sorted(sum(iv[i:i + 3]) / 3.0 for i in range(0, len(iv) - 2, 3))
+    dts_main = sorted(evs[i][0].elapsed_time(evs[i + 1][0]) for i in range(FILL - 1, nst - DRAIN - 1))
+    if os.environ.get("KIWIGPU_BENCH_RX_TRACE") == "1":              # a diagnostic: when each stream finished each step (ms from the origin)
+        for i in range(nst):
+            log("step %2d done %8.3f  per stream %s" % (i, done[i], " ".join("%8.3f" % ev0.elapsed_time(e) for e in evs[i])))
     # Integer work per ADC sample and receiver, counted on the algorithm: the waterfall DDC's 36 (run_ddc14) + the audio
     # DDC's NCO / mixer (10) and rx1's three integrators on I and Q (55, 55 and 26 bits: 2 + 2 + 1 words, x 2 = 10);
     # everything behind the first decimation (rx2, CICF, CFastFIR, CAgc, frames, coders) runs at <= 1 / 1543 of the rate.
@@ -1760,8 +1771,11 @@ def run_receivers(args, dist):
         "value": round(n * NR * world / step_s / 1e6, 1), "unit": "Msamples/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 4),
         "step_ms_spread": {"min": round(dts[0], 5), "median": round(dts[len(dts) // 2], 5), "max": round(dts[-1], 5),
-                           "how": "a second, untimed pass; an event on each of the step's four streams behind every step, a step's "
-                                  "completion = the latest of its four, spread over the differences between consecutive completions",
+                           "how": "a second, untimed pass of K + 9 steps; an event on each of the step's four streams behind every step, a "
+                                  "step's completion = the latest of its four; spread over the K steady-state differences between "
+                                  "consecutive completions (the first 6 and last 3, pipeline fill and drain, left out)",
+                           "per_audio_cycle_of_3_steps": {"min": round(cyc3[0], 5), "median": round(cyc3[len(cyc3) // 2], 5),
+                                                          "max": round(cyc3[-1], 5)},
                            "main_stream_only": {"min": round(dts_main[0], 5), "median": round(dts_main[len(dts_main) // 2], 5),
                                                 "max": round(dts_main[-1], 5)}},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int128/int64/f32",
