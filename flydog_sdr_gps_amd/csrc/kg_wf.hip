@@ -29,6 +29,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include <vector>
 
 #define WF_NFFT  8192        // rx/rx_waterfall.h:61-62
@@ -126,6 +127,11 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
     for (;;) {
         const wf_chan_dev *ch = chans + cid;
         const int interp = ch->interp, dc = ch->dc, comp_on = ch->comp_on;
+        // Round 4: a zoomed channel displays bins below fft_used = 2048 of the 8192 (rx/rx_waterfall.cpp:756-763; zoom 0:
+        // 4096) -- 13 of BASELINE configs[2]'s 14 channels.  For those frames the upper half of the radix-2 combine, of the
+        // CIC factors and of the power stage (k = t + 256 m, m >= 8) is never read: skipped behind ONE wave-uniform branch
+        // (two copies of the frame body, with the last butterflies pruned as well, spilled 79 registers).
+        const bool half = ch->fft_used <= 2048;
         const bool more = fn < nframes;
         // (the counter's value only: anything computed from it here would be waited for here.  Built with the
         // atomic optimizer off -- Makefile: its wave-aggregated form reads the result back with v_readfirstlane
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
                 kg_pin();
                 raw[2 * k] = nsrc[t + 256 * (2 * k)];
                 raw[2 * k + 1] = nsrc[t + 256 * (2 * k + 1)];
-                { const float2 v = cp[256 * k]; cicv[2 * k] = v.x; cicv[2 * k + 1] = v.y; }
+                if (k < 4 || !half) { const float2 v = cp[256 * k]; cicv[2 * k] = v.x; cicv[2 * k + 1] = v.y; }
                 wv[2 * k] = nwin[t + 256 * (2 * k)];
                 wv[2 * k + 1] = nwin[t + 256 * (2 * k + 1)];
                 kg_pin();
@@ -180,25 +186,28 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
         const float fft_offset = ch->fft_offset;
         // X[k] = F0[k] + F1[k] * conj(W_8192^t) * conj(W_32^m), k = t + 256 m: the two factors applied to
         // all sixteen bins in blocks of four products (kg_fft.h), then the sum
-#pragma unroll
-        for (int m = 0; m < 16; m += 4) kg_cmul4v<true>(y1[m], y1[m + 1], y1[m + 2], y1[m + 3], wbase, wbase, wbase, wbase);
 #define WF_W32(m) cf{KG_W64[2 * (m)][0], KG_W64[2 * (m)][1]}
-        kg_cmul4s<true>(y1[0], y1[1], y1[2], y1[3], WF_W32(0), WF_W32(1), WF_W32(2), WF_W32(3));
-        kg_cmul4s<true>(y1[4], y1[5], y1[6], y1[7], WF_W32(4), WF_W32(5), WF_W32(6), WF_W32(7));
-        kg_cmul4s<true>(y1[8], y1[9], y1[10], y1[11], WF_W32(8), WF_W32(9), WF_W32(10), WF_W32(11));
-        kg_cmul4s<true>(y1[12], y1[13], y1[14], y1[15], WF_W32(12), WF_W32(13), WF_W32(14), WF_W32(15));
-#undef WF_W32
+        auto combine_power = [&](auto m0_tag) {           // bins k = t + 256 m, m = m0 .. m0 + 7
+            constexpr int m0 = decltype(m0_tag)::value;
+            kg_cmul4v<true>(y1[m0], y1[m0 + 1], y1[m0 + 2], y1[m0 + 3], wbase, wbase, wbase, wbase);
+            kg_cmul4v<true>(y1[m0 + 4], y1[m0 + 5], y1[m0 + 6], y1[m0 + 7], wbase, wbase, wbase, wbase);
+            kg_cmul4s<true>(y1[m0], y1[m0 + 1], y1[m0 + 2], y1[m0 + 3], WF_W32(m0), WF_W32(m0 + 1), WF_W32(m0 + 2), WF_W32(m0 + 3));
+            kg_cmul4s<true>(y1[m0 + 4], y1[m0 + 5], y1[m0 + 6], y1[m0 + 7], WF_W32(m0 + 4), WF_W32(m0 + 5), WF_W32(m0 + 6), WF_W32(m0 + 7));
 #pragma unroll
-        for (int m = 0; m < 16; m++) {
-            const int k = t + 256 * m;
-            cf X = y0[m] + y1[m];
-            X = X * cf{cicv[m], cicv[m]};     // re *= CIC_comp[k], im *= CIC_comp[k] (:1342); 1.0f when off: exact
-            const cf sq = X * X;
-            float p = sq.x + sq.y;                                                      // re*re + im*im, :1345
-            if (m == 0 && k < dc) p = 0.f;                                              // :1304 (dc <= 4: row 0 only)
-            pwr[k] = p;
-            if (TAPS && k < ch->fft_used) tap_pwr[(size_t) f * SUB + k] = p;
-        }
+            for (int m = m0; m < m0 + 8; m++) {
+                const int k = t + 256 * m;
+                cf X = y0[m] + y1[m];
+                X = X * cf{cicv[m], cicv[m]};     // re *= CIC_comp[k], im *= CIC_comp[k] (:1342); 1.0f when off: exact
+                const cf sq = X * X;
+                float p = sq.x + sq.y;                                                      // re*re + im*im, :1345
+                if (m == 0 && k < dc) p = 0.f;                                              // :1304 (dc <= 4: row 0 only)
+                pwr[k] = p;
+                if (TAPS && k < ch->fft_used) tap_pwr[(size_t) f * SUB + k] = p;
+            }
+        };
+        combine_power(std::integral_constant<int, 0>());
+        if (!half) combine_power(std::integral_constant<int, 8>());
+#undef WF_W32
         if (t == 0) *lds_claim = 2 * gridDim.x + claimed;
         __syncthreads();
         const int fnn = __builtin_amdgcn_readfirstlane(*lds_claim);    // wave-uniform; rewritten after >= 6 barriers
