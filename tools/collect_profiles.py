@@ -9,7 +9,7 @@ import shutil
 import sys
 
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 go, pr = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 
@@ -19,10 +19,37 @@ def first(pat):
     return f[0] if f else None
 
 
+def box_of(wl):
+    """The lease's identity record (tools/prof.sh writes it beside every trace): host, GPU uuid, library and bench hashes."""
+    f = os.path.join(go, "%s_%s" % (tag, wl), "box.json")
+    return open(f).read().strip() if os.path.isfile(f) else "{}"
+
+
+def own_line(wl):
+    """ms_per_step / kernel_ms / frac of the line the TRACED run itself printed (same box, same library, under the tracer)."""
+    f = os.path.join(go, "%s_%s" % (tag, wl), "trace.log")
+    if not os.path.isfile(f):
+        return ""
+    for line in open(f):
+        if line.startswith("{"):
+            try:
+                d = json.loads(line)
+                rf = d.get("roofline", {})
+                return "ms_per_step=%s kernel_ms=%s frac=%s value=%s" % (d.get("ms_per_step"), rf.get("kernel_ms"), rf.get("frac"), d.get("value"))
+            except ValueError:
+                pass
+    return ""
+
+
 for wl in ("acq", "acq59", "acq10ms", "wf14", "ddc14", "cfg2_chain", "receivers"):
     ks = first(os.path.join(go, "%s_%s" % (tag, wl), "trace", "**", "*kernel_stats.csv"))
     if ks:
-        shutil.copy(ks, os.path.join(pr, "%s_%s_kernel_stats.csv" % (rnd, wl)))
+        dst = os.path.join(pr, "%s_%s_kernel_stats.csv" % (rnd, wl))
+        shutil.copy(ks, dst)
+        # the identity of the lease as a last row (name column; numeric columns zero so that CSV readers keep working)
+        ncol = len(open(dst).readline().split(",")) - 1
+        with open(dst, "a") as fh:
+            fh.write('"# box %s | traced run: %s"%s\n' % (box_of(wl).replace('"', "'"), own_line(wl), ",0" * ncol))
     sm = os.path.join(go, "%s_%s.summary.txt" % (tag, wl))
     if os.path.isfile(sm):
         shutil.copy(sm, os.path.join(pr, "%s_%s_summary.txt" % (rnd, wl)))
@@ -42,6 +69,8 @@ def counters(wl, kernel_sub):
 
 def entry(wl, sub, label):
     c = counters(wl, sub)
+    if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+        raise SystemExit("no FETCH_SIZE / WRITE_SIZE for %s in %s" % (sub, wl))
     return {"kernel": label, "fetch_size_kb": c["FETCH_SIZE"], "write_size_kb": c["WRITE_SIZE"],
             "bytes_per_launch": int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024),
             "tcc_hit": c.get("TCC_HIT_sum"), "tcc_miss": c.get("TCC_MISS_sum"),
