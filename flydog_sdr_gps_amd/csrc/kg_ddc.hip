@@ -1239,6 +1239,16 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
                    "kg_ddc_wf_push_dev: channel %d is not configured", ch);
         for (int j = 0; j < i; j++) KG_REQUIRE(chan_list[j] != ch, KG_ERR_INVALID, "kg_ddc_wf_push_dev: channel %d listed twice", ch);
     }
+    // A channel a capture left behind holds the filter state of a block cut short: the next CONTINUOUS push starts it
+    // from the reset state, as the reference does when it changes sampler mode (CmdWFReset with WF_SAMP_CONTIN,
+    // rx/rx_waterfall.cpp:971-978).  Synchronising, rare.  (Before the ages are compared: a reset moves the channel's
+    // reference point.)
+    if (!capture)
+        for (int i = 0; i < nlist; i++)
+            if (d->h_stale[chan_list[i]]) {
+                if ((rc = kg_ddc_reset_wf(d, chan_list[i]))) return rc;
+                d->h_stale[chan_list[i]] = 0;
+            }
     // One `pushed` count for the whole call: channels whose reference points differ in age (one was retuned, or left out
     // of earlier calls) are re-based to "now" first -- a rare, synchronising path.
     {
@@ -1249,15 +1259,6 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
             for (int i = 0; i < nlist; i++) if ((rc = ddc_rebase(d, chan_list[i]))) return rc;
     }
     const u64 pushed = d->h_pushed[chan_list[0]];
-    // A channel a capture left behind holds the filter state of a block cut short: the next CONTINUOUS push starts it
-    // from the reset state, as the reference does when it changes sampler mode (CmdWFReset with WF_SAMP_CONTIN,
-    // rx/rx_waterfall.cpp:971-978).  Synchronising, rare.
-    if (!capture)
-        for (int i = 0; i < nlist; i++)
-            if (d->h_stale[chan_list[i]]) {
-                if ((rc = kg_ddc_reset_wf(d, chan_list[i]))) return rc;
-                d->h_stale[chan_list[i]] = 0;
-            }
     std::vector<long> h_nouts(nlist), h_off(nlist), h_nlim(nlist);
     std::vector<int> h_wg(nlist + 1), h_bypass, h_run, h_small, h_rest;
     long max_nout = 0, c0_need = 0, comb_wgs = 0, n_run_max = 0, n_by_max = 0, n_run_sum = 0;

@@ -495,6 +495,37 @@ def test_capture_is_reset_plus_one_shot_sampler(gpu_ctx, oracle, deferred):
         d.close()
 
 
+def test_push_after_a_capture_of_some_channels(gpu_ctx, oracle):
+    """A capture of a SUBSET leaves those channels stale (reset on their next continuous push) and every channel of the
+    object at a different distance from its reference point than before: the joint push that follows must reset the stale
+    ones first and only then compare ages (found by tools/fuzz_parity.py: the reset used to come after)."""
+    n = 30_000
+    adc = adc_stream(3 * n, seed=51)
+    incs = [inc_for(0.04), inc_for(0.17), inc_for(0.29)]
+    l2 = [5, 0, 2]
+    M48 = (1 << 48) - 1
+    d = Ddc(gpu_ctx, nchan=3, max_samples=n)
+    try:
+        for ch in range(3):
+            d.set_wf(ch, incs[ch], 1 << l2[ch])
+        st = [None] * 3
+        g = d.push(adc[:n], [0, 1, 2])
+        for ch in range(3):
+            w, st[ch] = oracle.ddc_wf(adc[:n], incs[ch], l2[ch], st[ch])
+            assert np.array_equal(g[ch], w)
+        g = d.capture(adc[n:2 * n], [2, 0], 200)                  # channel 1 sits out: its NCO does not advance
+        for i, ch in enumerate((2, 0)):
+            assert np.array_equal(g[i], _capture_ref(oracle, adc[n:2 * n], incs[ch], l2[ch], n * incs[ch], 200)), ch
+        g = d.push(adc[2 * n:], [0, 1, 2])                        # 0 and 2: from reset at phase 2 n inc; 1: carries on from n
+        for ch in range(3):
+            if ch != 1:
+                st[ch] = oracle.DdcWfState(); st[ch].phase = (2 * n * incs[ch]) & M48
+            w, st[ch] = oracle.ddc_wf(adc[2 * n:], incs[ch], l2[ch], st[ch])
+            assert np.array_equal(g[ch], w), ch
+    finally:
+        d.close()
+
+
 def test_capture_of_a_short_block_and_odd_sizes(gpu_ctx, oracle):
     """Blocks shorter than the sampler needs (fewer than max_out outputs come back), sizes that are no multiple of a run,
     max_out = 1."""

@@ -45,21 +45,63 @@ def soak(name, trial):
 
 
 def trial_wfddc():
+    """Random sequences of everything the waterfall DDC's object does between two samples: continuous pushes (all channels or a
+    subset), one-shot captures (CmdWFReset + sampler, random sampler size), CIC resets, retunes, new phases -- in line or
+    with the deferred output stage -- against an oracle channel model that is told the same story."""
     nch = int(rng.integers(1, 5))
     big = rng.random() < 0.15                        # long blocks: the carry scan cut into chunks across workgroups
     d = Ddc(ctx, nchan=nch, max_samples=1 << (20 if big else 17))
     incs = [int(rng.integers(0, 1 << 48)) for _ in range(nch)]
     l2 = [int(rng.integers(0, 14)) for _ in range(nch)]
-    states = [None] * nch
+    M48 = (1 << 48) - 1
+    states = [None] * nch                            # oracle filter state (None: reset)
+    phase = [0] * nch                                # NCO phase of each channel's next sample
+    stale = [False] * nch                            # a capture cut the filters short: the next continuous push starts from reset
     for ch in range(nch):
         d.set_wf(ch, incs[ch], 1 << l2[ch])
-    for _ in range(int(rng.integers(1, 4))):
+    d.set_deferred(bool(rng.random() < 0.4))
+
+    def fresh(ch):
+        st = ko.DdcWfState()
+        st.phase = phase[ch] & M48
+        return st
+    for _ in range(int(rng.integers(1, 6))):
         n = int(rng.integers(1 << 17, 1 << 20)) if big else int(rng.integers(1, 1 << 16))
         adc = adc_block(n)
-        got = d.push(adc, list(range(nch)))
-        for ch in range(nch):
-            want, states[ch] = ko.ddc_wf(adc, incs[ch], l2[ch], states[ch])
-            assert np.array_equal(got[ch], want), ("wf ddc", l2[ch], n)
+        chans = list(range(nch))
+        if nch > 1 and rng.random() < 0.3:
+            chans = sorted(rng.choice(nch, int(rng.integers(1, nch + 1)), replace=False).tolist(), key=lambda _: rng.random())
+        what = rng.random()
+        if what < 0.35:                              # capture
+            mo = int(rng.choice([1, 7, 300, 8192]))
+            got = d.capture(adc, chans, mo)
+            for i, ch in enumerate(chans):
+                need = min(n, mo << l2[ch])
+                want, _ = ko.ddc_wf(adc[:need], incs[ch], l2[ch], fresh(ch))
+                assert np.array_equal(got[i], want[:mo]), ("wf capture", l2[ch], n, mo)
+                phase[ch] = (phase[ch] + n * incs[ch]) & M48
+                stale[ch], states[ch] = True, None
+        else:
+            got = d.push(adc, chans)
+            for i, ch in enumerate(chans):
+                if stale[ch] or states[ch] is None:
+                    states[ch] = fresh(ch)
+                    stale[ch] = False
+                want, states[ch] = ko.ddc_wf(adc, incs[ch], l2[ch], states[ch])
+                assert np.array_equal(got[i], want), ("wf ddc", l2[ch], n)
+                phase[ch] = (phase[ch] + n * incs[ch]) & M48
+        ev = rng.random()                            # something the host does between blocks
+        ch = int(rng.integers(0, nch))
+        if ev < 0.15:
+            d.reset(ch); states[ch], stale[ch] = None, False
+        elif ev < 0.25:
+            incs[ch] = int(rng.integers(0, 1 << 48)); l2[ch] = int(rng.integers(0, 14))
+            d.set_wf(ch, incs[ch], 1 << l2[ch]); states[ch], stale[ch], phase[ch] = None, False, 0
+        elif ev < 0.32:
+            phase[ch] = int(rng.integers(0, 1 << 48))
+            d.set_phase(ch, phase[ch])
+            if states[ch] is not None:
+                states[ch].phase = phase[ch]
     d.close()
 
 
