@@ -46,6 +46,13 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order; streams
+# beyond that SHARE a queue and run in order with whoever they share it with.  The workloads here use up to six streams
+# (the library's side streams included) and RCCL brings its own: with four queues, which streams serialise depended on
+# what else had created a stream first -- `receivers` ran 1.12 ms per step alone and 1.40 ms with a process group up,
+# `ddc14` 0.48 and 0.58.  Eight queues make the stream topology the one the code states (measured: tools/ab_rxenv.sh).
+# Read by the runtime when it initialises, i.e. it must be set before anything touches the GPU.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 NSAMPLES = 65536
 FFT_LEN = 16384
@@ -1476,9 +1483,12 @@ class ReceiverBank:
         # the tails of both chains are sequential per-channel recurrences (ADPCM of the waterfall row; CAgc and
         # ADPCM of the audio block: one lane per channel, 100-140 us each whatever the load): on streams of
         # their own they no longer stand between a chain's DDC of this step and of the next one
-        self.tails = two_streams and os.environ.get("KIWIGPU_BENCH_TAIL_STREAMS") != "0"
+        # ONE stream for both tails (measured, eight hardware queues: a stream per tail 1.42 ms per step -- the two
+        # latency-bound tails running side by side with both chains; one shared tail stream 1.10 ms; tails in line 1.15 ms)
+        tails_mode = os.environ.get("KIWIGPU_BENCH_TAIL_STREAMS", "1")     # 2: a stream per tail; 1: ONE stream for both tails; 0: in line
+        self.tails = two_streams and tails_mode != "0"
         self.s_pk = torch.cuda.Stream(device=dev) if self.tails else None
-        self.s_tail = torch.cuda.Stream(device=dev) if self.tails else None
+        self.s_tail = (self.s_pk if tails_mode == "1" else torch.cuda.Stream(device=dev)) if self.tails else None
         self.ctx_pk = Context(local_rank, self.s_pk.cuda_stream) if self.tails else ctx
         self.ctx_tail = Context(local_rank, self.s_tail.cuda_stream) if self.tails else ctx_au
         self.main = torch.cuda.current_stream(dev)
@@ -1708,12 +1718,15 @@ def run_receivers(args, dist):
     frames_total, audio_total = counts["frames"], counts["audio_blocks"]
     step_s = elapsed / args.steps
     world = dist.world
-    # Per-step cadence: a step's work runs on FOUR streams (the two chains and their tails) and a step is complete when the
+    # Per-step cadence: a step's work runs on several streams (the two chains and their tails) and a step is complete when the
     # last of them has finished it, so every stream gets an event behind each step and step i's completion time is the
     # latest of its four; the spread is over the differences between consecutive completions.  (Round 3 took events on
     # the main stream alone: that measures how the waterfall chain's share of a step interleaves with the other three
     # streams -- 1.2 ... 2.8 ms on a 1.74 ms mean -- not how regularly steps complete.)
-    streams = [s for s in (bank.main, bank.side, bank.s_pk, bank.s_tail) if s is not None]
+    streams = []
+    for s_ in (bank.main, bank.side, bank.s_pk, bank.s_tail):
+        if s_ is not None and all(s_ is not x for x in streams):
+            streams.append(s_)
     torch.cuda.synchronize(dev)
     ev0 = torch.cuda.Event(enable_timing=True)
     ev0.record(bank.main)
@@ -1771,7 +1784,7 @@ def run_receivers(args, dist):
         "value": round(n * NR * world / step_s / 1e6, 1), "unit": "Msamples/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 4),
         "step_ms_spread": {"min": round(dts[0], 5), "median": round(dts[len(dts) // 2], 5), "max": round(dts[-1], 5),
-                           "how": "a second, untimed pass of K + 9 steps; an event on each of the step's four streams behind every step, a "
+                           "how": "a second, untimed pass of K + 9 steps; an event on each of the step's streams behind every step, a "
                                   "step's completion = the latest of its four; spread over the K steady-state differences between "
                                   "consecutive completions (the first 6 and last 3, pipeline fill and drain, left out)",
                            "per_audio_cycle_of_3_steps": {"min": round(cyc3[0], 5), "median": round(cyc3[len(cyc3) // 2], 5),
@@ -1791,7 +1804,7 @@ def run_receivers(args, dist):
         "x_realtime_all_receivers": round(n / adc_clock / step_s, 2),
         "waterfall_frames_per_s": round(frames_total * world / elapsed, 1),
         "audio_blocks_per_s": round(audio_total * world / elapsed, 1),
-        "roofline": {"bound": "valu", "kernel": "whole step (both DDCs' run passes dominate; four streams)",
+        "roofline": {"bound": "valu", "kernel": "whole step (both DDCs' run passes dominate; three streams: the two chains and one for both tails)",
                      "achieved": round(tops, 3), "peak": INT_PEAK_TOPS, "unit": "Tiop/s", "frac": round(tops / INT_PEAK_TOPS, 4),
                      "traffic": traffic, "traffic_source": source, "traffic_top_kernels": top,
                      "kernel_ms": round(step_s * 1e3, 5), "kernel_ms_min": round(dts[0], 5),
@@ -2112,7 +2125,7 @@ def main():
         line = dict(common, **run_stub(args, dist))
     elif args.workload == "all":
         rs = {wl: run(wl) for wl in ALL_WORKLOADS}
-        if dist.world > 1 and not args.pmc_child:
+        if (dist.world > 1 or os.environ.get("KIWIGPU_BENCH_FORCE_SV") == "1") and not args.pmc_child:     # (FORCE_SV: the N > 1 shape of the line on one GPU, for testing)
             # strong scaling of ONE configs[4] acquisition (first bullet): the same block on every GPU, the 59
             # SVs dealt over the ranks by cost, winners all-gathered over RCCL every step -- so that a driver SCALE run
             # (N = 1, 2, 4, 8 of this command) records it beside the weak-scaling workloads
@@ -2131,7 +2144,7 @@ def main():
                                                    "end); workloads.receivers: configs[3] per-GPU share; workloads.acq10ms: configs[4]"
                                                    + ("; workloads.acq10ms_sv: configs[4] with the SVs split over the GPUs (strong)"
                                                       if "acq10ms_sv" in rs else ""))
-            if dist.world > 1:
+            if dist.world > 1 or os.environ.get("KIWIGPU_BENCH_FORCE_SV") == "1":
                 same_fields(line)
                 for r in line["workloads"].values():
                     same_fields(r)

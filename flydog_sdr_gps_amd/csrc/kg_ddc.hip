@@ -807,15 +807,26 @@ __global__ __launch_bounds__(64 * DDC_SCAN_WAVES) void ddc_wf_scan_tau_kernel(
         const int r = (k << 9) + gl;
         own[k] = (k < ntile && r < nruns) ? tv[r] : 0u;
     }
+    // eight tiles at a time behind ONE scalar branch (ntile is wave-uniform): a capture's short entries skip the groups of
+    // tiles they lack, and inside a group the eight scans stay independent straight-line chains (a branch per tile made
+    // the continuous case -- all 32 tiles -- 13 -> 20 us: the chains then ran one after the other)
 #pragma unroll
-    for (int k = 0; k < DDC_TAU_TILES; k++) {
-        u32 v = 0;
-        if (k < ntile) {                              // scalar branch (ntile is wave-uniform): a capture's short entries skip the tiles they lack
-            v = own[k];
-            for (int d = 1; d < 64; d <<= 1) { const u32 a = __shfl_up(v, d); if (lane >= d) v += a; }
+    for (int g8 = 0; g8 < DDC_TAU_TILES; g8 += 8) {
+        if (g8 < ntile) {
+#pragma unroll
+            for (int k = g8; k < g8 + 8; k++) {
+                u32 v = own[k];                       // (zero past ntile: loaded so above)
+                for (int d = 1; d < 64; d <<= 1) { const u32 a = __shfl_up(v, d); if (lane >= d) v += a; }
+                inc[k] = v;
+                if (lane == 63) s_tot[k * DDC_SCAN_WAVES + wave] = v;
+            }
+        } else {
+#pragma unroll
+            for (int k = g8; k < g8 + 8; k++) {
+                inc[k] = 0;
+                if (lane == 63) s_tot[k * DDC_SCAN_WAVES + wave] = 0;
+            }
         }
-        inc[k] = v;
-        if (lane == 63) s_tot[k * DDC_SCAN_WAVES + wave] = v;
     }
     __syncthreads();
     // exclusive prefix over the 256 (tile, wave) totals, in time order: waves 0..3, one total per lane
