@@ -1,13 +1,11 @@
 #!/bin/bash
-# A/B of environment switches on the GPU box: tools/ab_env.sh "<bench args>" "VAR=val [VAR=val]" ...   ("-" = none)
+# GPU box: A/B of environment switches on one workload, twice each.  usage: tools/ab_env.sh "<bench args>" "VAR=1 VAR2=x" "-" ...   ("-" = no extra variables)
+export TMPDIR=/tmp
 args=$1; shift
 for rep in 1 2; do
-  for v in "$@"; do
-    if [ "$v" = "-" ]; then e=""; else e="$v"; fi
-    env $e timeout 300 python3 bench.py --no-cpu --no-live-traffic $args 2>/dev/null | python3 -c "
-import json,sys
-d=json.loads(sys.stdin.read())
-r=d['roofline']
-print('%-60s kernel %.5f ms  step %.5f ms' % ('$v', r['kernel_ms'], d['ms_per_step']))"
+  for cfg in "$@"; do
+    vars=$cfg; [ "$cfg" = "-" ] && vars="KIWIGPU_NOP=1"
+    env $vars timeout 300 python3 bench.py --no-cpu --no-live-traffic $args 2>/dev/null | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; s=d['step_ms_spread']; print('%-44s ms/step %.4f (min %.4f med %.4f) kernel_ms %.4f value %.1f' % ('$cfg', d['ms_per_step'], s['min'], s['median'], r['kernel_ms'], d['value']))"
   done
 done
