@@ -67,6 +67,11 @@ int kg_ctx_stage(kg_ctx *ctx, const void *src, size_t bytes, void **d_out);
 struct kg_stage_cache { unsigned char *host; void *dev; size_t cap, bytes; };
 int kg_ctx_stage_cached(kg_ctx *ctx, kg_stage_cache *sc, const void *src, size_t bytes, void **d_out);
 void kg_stage_cache_free(kg_stage_cache *sc);       // the caller has drained the stream
+// The same with `ways` caches looked up in turn and replaced round robin: a caller whose table cycles through a few
+// variants (the frame tables of a streaming waterfall: the slow channel's frame completes every fourth push, so four
+// tables alternate) uploads each of them once.  With one way every push of bench.py's cfg2_chain re-uploaded 64 KiB:
+// a pinned-ring copy + two enqueued transfers, ~34 us of copy engines in line with the kernels of a 0.58 ms step.
+int kg_ctx_stage_cached_ways(kg_ctx *ctx, kg_stage_cache *sc, int ways, int *victim, const void *src, size_t bytes, void **d_out);
 
 // Device scratch of at least `bytes`, filled from `src` before returning (synchronous: the
 // previous user of the scratch is drained first).  Valid until the next call on this context.

@@ -80,6 +80,16 @@ int kg_ctx_stage_cached(kg_ctx *c, kg_stage_cache *sc, const void *src, size_t b
     return KG_OK;
 }
 
+int kg_ctx_stage_cached_ways(kg_ctx *c, kg_stage_cache *sc, int ways, int *victim, const void *src, size_t bytes, void **d_out)
+{
+    KG_REQUIRE(c && sc && victim && src && d_out && bytes > 0 && ways >= 1, KG_ERR_INVALID, "kg_ctx_stage_cached_ways: bad argument");
+    for (int w = 0; w < ways; w++)
+        if (sc[w].dev && sc[w].bytes == bytes && memcmp(sc[w].host, src, bytes) == 0) { *d_out = sc[w].dev; return KG_OK; }
+    const int v = *victim % ways;
+    *victim = (v + 1) % ways;
+    return kg_ctx_stage_cached(c, &sc[v], src, bytes, d_out);
+}
+
 void kg_stage_cache_free(kg_stage_cache *sc)
 {
     if (!sc) return;

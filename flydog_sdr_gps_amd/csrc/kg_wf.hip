@@ -49,6 +49,7 @@ struct wf_chan_dev {
     float scale[WF_WIDTH];              // what the dB stage multiplies by (WF_CMA: already divided by the run length)
 };
 
+#define WF_TABLE_WAYS 8
 #define WF_LDS_BYTES (2 * SUB * sizeof(float2) + 240 * sizeof(float2) + 16)       // + pass-1 twiddles + the claimed frame index
 
 template <bool TAPS>
@@ -297,7 +298,8 @@ struct kg_wf {
     wf_chan_dev *d_chans;
     float *d_windows, *d_cic;
     short2 *d_iq;    unsigned char *d_out;  int stage_cap;      // staging for host-buffer calls
-    kg_stage_cache chan_of_cache;          // the {channel, offset} records of the last batch (usually unchanged)
+    kg_stage_cache chan_of_cache[WF_TABLE_WAYS];   // the {channel, offset} records of the last few distinct batches (a stream cycles through a few)
+    int chan_of_victim;
     std::vector<int2> frame_tab;
     float *d_tap_pwr, *d_tap_pwr_out, *d_tap_db;
     int *d_claim;                             // wf_frame_kernel's two counters, zero between launches
@@ -350,7 +352,7 @@ void kg_wf_destroy(kg_wf *w)
     (void) hipFree(w->d_chans); (void) hipFree(w->d_windows); (void) hipFree(w->d_cic); (void) hipFree(w->d_claim);
     (void) hipFree(w->d_iq); (void) hipFree(w->d_out);
     (void) hipFree(w->d_tap_pwr); (void) hipFree(w->d_tap_pwr_out); (void) hipFree(w->d_tap_db);
-    kg_stage_cache_free(&w->chan_of_cache);
+    for (int k = 0; k < WF_TABLE_WAYS; k++) kg_stage_cache_free(&w->chan_of_cache[k]);
     delete w;
 }
 
@@ -469,7 +471,8 @@ static int wf_launch(kg_wf *w, int nframes, const int32_t *chan_of, const uint64
     }
     void *d_chan_of = nullptr;                 // the arrays are the caller's: staged copy, no stream synchronisation
     {
-        int rc = kg_ctx_stage_cached(w->ctx, &w->chan_of_cache, w->frame_tab.data(), sizeof(int2) * nframes, &d_chan_of);
+        int rc = kg_ctx_stage_cached_ways(w->ctx, w->chan_of_cache, WF_TABLE_WAYS, &w->chan_of_victim, w->frame_tab.data(),
+                                          sizeof(int2) * nframes, &d_chan_of);
         if (rc) return rc;
     }
     const int grid = nframes < w->grid ? nframes : w->grid;
