@@ -213,17 +213,26 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
         } else {
             for (int k = 0; k < 4; k++) I[k] = Q[k] = 0;
         }
+        // Round 4, two instructions per sample and channel off each pass:
+        //  pass A integrates BIASED mixer outputs, u = mix24 + 2^24 = (m + 32 + 2^30) >> 6 as an unsigned value (|m| < 2^30):
+        //  no sign extension into the 64-bit adds; what a constant 2^24 leaves in the four integrators after len samples
+        //  -- 2^24 x C(len + k - 1, k) -- is taken off once per run (everything is modulo 2^64 either way);
+        //  pass B lets integrator 5 run on in 32 bits and masks it to 28 where it is stored (2^28 divides 2^32).
         auto step = [&](int a) {
             const int ec = tab[(ph >> 51) + 2048], es = tab[ph >> 51];
-            const long long mi = mix24(a, ec), mq = mix24(a, es);
             ph += inc16;
-            I[0] += (u64) mi; I[1] += I[0]; I[2] += I[1]; I[3] += I[2];
-            Q[0] += (u64) mq; Q[1] += Q[0]; Q[2] += Q[1]; Q[3] += Q[2];
-            if (PASS_B) {
-                i5i = (i5i + (u32) (I[3] >> sh5)) & 0x0FFFFFFFu;      // integrator4[88 -: 28] (cic_wf1.vh)
-                i5q = (i5q + (u32) (Q[3] >> sh5)) & 0x0FFFFFFFu;
+            if (!PASS_B) {
+                const u32 ui = ((u32) (a * ec) + 0x40000020u) >> 6, uq = ((u32) (a * es) + 0x40000020u) >> 6;
+                I[0] += (u64) ui; I[1] += I[0]; I[2] += I[1]; I[3] += I[2];
+                Q[0] += (u64) uq; Q[1] += Q[0]; Q[2] += Q[1]; Q[3] += Q[2];
+            } else {
+                const long long mi = mix24(a, ec), mq = mix24(a, es);
+                I[0] += (u64) mi; I[1] += I[0]; I[2] += I[1]; I[3] += I[2];
+                Q[0] += (u64) mq; Q[1] += Q[0]; Q[2] += Q[1]; Q[3] += Q[2];
+                i5i += (u32) (I[3] >> sh5);                           // integrator4[88 -: 28] (cic_wf1.vh), masked where stored
+                i5q += (u32) (Q[3] >> sh5);
                 c = (c + 1) & (u32) Rm1;
-                if (c == 0) { c0i[o] = i5i; c0q[o] = i5q; o++; }      // strobe: sample_no was R - 1
+                if (c == 0) { c0i[o] = i5i & 0x0FFFFFFFu; c0q[o] = i5q & 0x0FFFFFFFu; o++; }      // strobe: sample_no was R - 1
             }
         };
         long t = s0;
@@ -287,11 +296,11 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
                             const long long mi = mix24(buf[w], ec[w]), mq = mix24(buf[w], es[w]);
                             I[0] += (u64) mi; I[1] += I[0]; I[2] += I[1]; I[3] += I[2];
                             Q[0] += (u64) mq; Q[1] += Q[0]; Q[2] += Q[1]; Q[3] += Q[2];
-                            i5i = (i5i + (u32) (I[3] >> sh5)) & 0x0FFFFFFFu;
-                            i5q = (i5q + (u32) (Q[3] >> sh5)) & 0x0FFFFFFFu;
+                            i5i += (u32) (I[3] >> sh5);
+                            i5q += (u32) (Q[3] >> sh5);
                             if (((w + 1) & ((1 << LR) - 1)) == 0) {       // strobe (the group starts aligned)
-                                tI[lane * DDC_STAGE_ROW + kcol + ((w + 1) >> LR) - 1] = i5i;
-                                tQ[lane * DDC_STAGE_ROW + kcol + ((w + 1) >> LR) - 1] = i5q;
+                                tI[lane * DDC_STAGE_ROW + kcol + ((w + 1) >> LR) - 1] = i5i & 0x0FFFFFFFu;
+                                tQ[lane * DDC_STAGE_ROW + kcol + ((w + 1) >> LR) - 1] = i5q & 0x0FFFFFFFu;
                             }
                         }
                         kcol += 8 >> LR;
@@ -311,18 +320,19 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
                 ph += inc16;
                 I[0] += (u64) mi; I[1] += I[0]; I[2] += I[1]; I[3] += I[2];
                 Q[0] += (u64) mq; Q[1] += Q[0]; Q[2] += Q[1]; Q[3] += Q[2];
-                i5i = (i5i + (u32) (I[3] >> sh5)) & 0x0FFFFFFFu;
-                i5q = (i5q + (u32) (Q[3] >> sh5)) & 0x0FFFFFFFu;
+                i5i += (u32) (I[3] >> sh5);
+                i5q += (u32) (Q[3] >> sh5);
             };
+            const u32 M28 = 0x0FFFFFFFu;
             if (log2r == 1) {
                 for (; t + 8 <= g1; t += 8) {
                     short buf[8];
                     samples8(t, buf);
                     uint4 vi, vq;
-                    quiet(buf[0]); quiet(buf[1]); vi.x = i5i; vq.x = i5q;
-                    quiet(buf[2]); quiet(buf[3]); vi.y = i5i; vq.y = i5q;
-                    quiet(buf[4]); quiet(buf[5]); vi.z = i5i; vq.z = i5q;
-                    quiet(buf[6]); quiet(buf[7]); vi.w = i5i; vq.w = i5q;
+                    quiet(buf[0]); quiet(buf[1]); vi.x = i5i & M28; vq.x = i5q & M28;
+                    quiet(buf[2]); quiet(buf[3]); vi.y = i5i & M28; vq.y = i5q & M28;
+                    quiet(buf[4]); quiet(buf[5]); vi.z = i5i & M28; vq.z = i5q & M28;
+                    quiet(buf[6]); quiet(buf[7]); vi.w = i5i & M28; vq.w = i5q & M28;
                     *(uint4 *) (c0i + o) = vi; *(uint4 *) (c0q + o) = vq;
                     o += 4;
                 }
@@ -331,8 +341,8 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
                     short buf[8];
                     samples8(t, buf);
                     uint2 vi, vq;
-                    quiet(buf[0]); quiet(buf[1]); quiet(buf[2]); quiet(buf[3]); vi.x = i5i; vq.x = i5q;
-                    quiet(buf[4]); quiet(buf[5]); quiet(buf[6]); quiet(buf[7]); vi.y = i5i; vq.y = i5q;
+                    quiet(buf[0]); quiet(buf[1]); quiet(buf[2]); quiet(buf[3]); vi.x = i5i & M28; vq.x = i5q & M28;
+                    quiet(buf[4]); quiet(buf[5]); quiet(buf[6]); quiet(buf[7]); vi.y = i5i & M28; vq.y = i5q & M28;
                     *(uint2 *) (c0i + o) = vi; *(uint2 *) (c0q + o) = vq;
                     o += 2;
                 }
@@ -353,8 +363,8 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
                     const long long mi = mix24(buf[w], ec[w]), mq = mix24(buf[w], es[w]);
                     I[0] += (u64) mi; I[1] += I[0]; I[2] += I[1]; I[3] += I[2];
                     Q[0] += (u64) mq; Q[1] += Q[0]; Q[2] += Q[1]; Q[3] += Q[2];
-                    i5i = (i5i + (u32) (I[3] >> sh5)) & 0x0FFFFFFFu;
-                    i5q = (i5q + (u32) (Q[3] >> sh5)) & 0x0FFFFFFFu;
+                    i5i += (u32) (I[3] >> sh5);
+                    i5q += (u32) (Q[3] >> sh5);
                 }
                 c += 8;
                 continue;
@@ -364,9 +374,16 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
         }
         for (; t < s1; t++) step(adc[t]);                 // ragged end of the block's last run
         if (PASS_B) {
-            tau[lI] = i5i;
-            tau[lQ] = i5q;
+            tau[lI] = i5i & 0x0FFFFFFFu;
+            tau[lQ] = i5q & 0x0FFFFFFFu;
         } else {
+            {   // the bias of pass A's inputs, out of the four integrators: 2^24 x C(len + k - 1, k), k = 1 .. 4, modulo 2^64
+                const u64 len = (u64) (s1 - s0);          // <= 8192: len (len+1) (len+2) (len+3) < 2^53
+                const u64 b1 = len, b2 = len * (len + 1) / 2, b3 = len * (len + 1) * (len + 2) / 6,
+                          b4 = len * (len + 1) * (len + 2) * (len + 3) / 24;
+                I[0] -= b1 << 24; I[1] -= b2 << 24; I[2] -= b3 << 24; I[3] -= b4 << 24;
+                Q[0] -= b1 << 24; Q[1] -= b2 << 24; Q[2] -= b3 << 24; Q[3] -= b4 << 24;
+            }
             ddc_state4 a, b;
             for (int k = 0; k < 4; k++) {
                 // R <= 256: bits above 88 are never read, a logical shift will do; wider R (zero-state
@@ -415,10 +432,10 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
             add96(I[0], xi); add96(I[1], I[0]); add96(I[2], I[1]); add96(I[3], I[2]);
             add96(Q[0], xq); add96(Q[1], Q[0]); add96(Q[2], Q[1]); add96(Q[3], Q[2]);
             // integrator 5 accumulates integrator4[88 -: 28] (cic_wf1.vh)
-            i5i = (i5i + ((I[3].w[2] << 3) | (I[3].w[1] >> 29))) & 0x0FFFFFFFu;
-            i5q = (i5q + ((Q[3].w[2] << 3) | (Q[3].w[1] >> 29))) & 0x0FFFFFFFu;
+            i5i += (I[3].w[2] << 3) | (I[3].w[1] >> 29);             // (masked to 28 bits where it is stored)
+            i5q += (Q[3].w[2] << 3) | (Q[3].w[1] >> 29);
             c = (c + 1) & (u32) Rm1;
-            if (c == 0) { c0i[o] = i5i; c0q[o] = i5q; o++; }              // strobe: sample_no was R - 1
+            if (c == 0) { c0i[o] = i5i & 0x0FFFFFFFu; c0q[o] = i5q & 0x0FFFFFFFu; o++; }              // strobe: sample_no was R - 1
         };
         long t = s0;
         for (; t + 8 <= g1; t += 8) {
@@ -437,8 +454,8 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
                     xq.w[0] = (u32) lq; xq.w[1] = (u32) (lq >> 32); xq.w[2] = (u32) (shift ? mq >> (64 - shift) : mq >> 63);
                     add96(I[0], xi); add96(I[1], I[0]); add96(I[2], I[1]); add96(I[3], I[2]);
                     add96(Q[0], xq); add96(Q[1], Q[0]); add96(Q[2], Q[1]); add96(Q[3], Q[2]);
-                    i5i = (i5i + ((I[3].w[2] << 3) | (I[3].w[1] >> 29))) & 0x0FFFFFFFu;
-                    i5q = (i5q + ((Q[3].w[2] << 3) | (Q[3].w[1] >> 29))) & 0x0FFFFFFFu;
+                    i5i += (I[3].w[2] << 3) | (I[3].w[1] >> 29);
+                    i5q += (Q[3].w[2] << 3) | (Q[3].w[1] >> 29);
                 }
                 c += 8;
                 continue;
@@ -447,8 +464,8 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
             for (int w = 0; w < 8; w++) step(buf[w]);
         }
         for (; t < s1; t++) step(adc[t]);
-        tau[lI] = i5i;
-        tau[lQ] = i5q;
+        tau[lI] = i5i & 0x0FFFFFFFu;
+        tau[lQ] = i5q & 0x0FFFFFFFu;
         return;
     }
     // pass A of runs longer than 1024 samples at R >= 512: the zero-state sums need the full width

@@ -123,19 +123,27 @@ __global__ __launch_bounds__(RX_THREADS) void rx1_run_kernel(
     u32 k = (u32) (c0 % RX_R1);               // decimation counter at the run start
     long o = (long) (c0 / RX_R1);             // strobes of this call before the run
     u32 *c0i = c0rel + ((long) li * 2 + 0) * max_out, *c0q = c0rel + ((long) li * 2 + 1) * max_out;
+    // Round 4 (as in kg_ddc.hip): pass A integrates BIASED mixer outputs, u = mix22 + 2^22 = (m + 128 + 2^30) >> 8 as an
+    // unsigned value -- no sign extension into the 64-bit adds; a constant 2^22 leaves 2^22 len and 2^22 len (len + 1) / 2 in
+    // the two integrators, taken off once per run (modulo 2^64).  Pass B lets integrator 3 run on in 32 bits and masks it to
+    // 26 where it is stored (2^26 divides 2^32).
     auto step = [&](int a) {
         const int ec = tab[(ph >> 51) + 2048], es = tab[ph >> 51];
-        const long long mi = mix22(a, ec), mq = mix22(a, es);
         ph += inc16;
-        a1i += (u64) mi; a2i += a1i;
-        a1q += (u64) mq; a2q += a1q;
-        if (PASS_B) {
-            i3i = (i3i + (u32) (a2i >> SH3)) & 0x03FFFFFFu;     // integrator2[acc-1 -: 26]
-            i3q = (i3q + (u32) (a2q >> SH3)) & 0x03FFFFFFu;
+        if (!PASS_B) {
+            const u32 ui = ((u32) (a * ec) + 0x40000080u) >> 8, uq = ((u32) (a * es) + 0x40000080u) >> 8;
+            a1i += (u64) ui; a2i += a1i;
+            a1q += (u64) uq; a2q += a1q;
+        } else {
+            const long long mi = mix22(a, ec), mq = mix22(a, es);
+            a1i += (u64) mi; a2i += a1i;
+            a1q += (u64) mq; a2q += a1q;
+            i3i += (u32) (a2i >> SH3);                          // integrator2[acc-1 -: 26], masked where stored
+            i3q += (u32) (a2q >> SH3);
             if (++k == RX_R1) {
                 k = 0;
-                c0i[o] = i3i;
-                c0q[o] = i3q;
+                c0i[o] = i3i & 0x03FFFFFFu;
+                c0q[o] = i3q & 0x03FFFFFFu;
                 o++;
             }
         }
@@ -151,9 +159,13 @@ __global__ __launch_bounds__(RX_THREADS) void rx1_run_kernel(
     }
     for (; t < s1; t++) step(adc[t]);
     if (PASS_B) {
-        tau[((long) li * 2 + 0) * nruns + r] = i3i;
-        tau[((long) li * 2 + 1) * nruns + r] = i3q;
+        tau[((long) li * 2 + 0) * nruns + r] = i3i & 0x03FFFFFFu;
+        tau[((long) li * 2 + 1) * nruns + r] = i3q & 0x03FFFFFFu;
     } else {
+        {   // the bias of pass A's inputs, out of the two integrators
+            const u64 len = (u64) (s1 - s0), b1 = len << 22, b2 = (len * (len + 1) / 2) << 22;
+            a1i -= b1; a2i -= b2; a1q -= b1; a2q -= b2;
+        }
         base[0 * nruns + r] = a1i; base[1 * nruns + r] = a2i; base[2 * nruns + r] = a1q; base[3 * nruns + r] = a2q;
     }
 }
