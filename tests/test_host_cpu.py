@@ -1,6 +1,7 @@
 """CPU-side tests: oracle vs known answers / reference build, host logic, C-ABI
 surface, and the N>1 sharding path on gloo (world_size 2)."""
 import ctypes
+import json
 import os
 import re
 import subprocess
@@ -849,3 +850,26 @@ def test_oracle_is_clean_under_asan_and_ubsan():
                          timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "asan driver ok" in out.stdout and "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr
+
+
+def test_bench_line_helpers_without_a_gpu():
+    """bench.py's round-4 line furniture: the box / build identity record (no GPU: the GPU fields stay None, the hashes are
+    those of the files in the tree) and the compact per-workload table kept inside `roofline`."""
+    import hashlib
+    import bench
+    box = bench.box_identity()
+    assert set(box) >= {"host", "lib_sha16", "bench_sha16", "gpu_uuid", "gpu_name"}
+    assert box["bench_sha16"] == hashlib.sha256(open(os.path.join(ROOT, "bench.py"), "rb").read()).hexdigest()[:16]
+    assert box["lib_sha16"] == hashlib.sha256(open(os.path.join(ROOT, "flydog_sdr_gps_amd", "libkiwigpu.so"), "rb").read()).hexdigest()[:16]
+    rs = {"acq": {"ms_per_step": 0.8, "roofline": {"frac": 0.4, "bound": "valu", "traffic": 4.0e7, "kernel_ms": 0.78},
+                  "hbm": {"algorithmic_bytes_per_launch": 1.1e10}},
+          "ddc14": {"ms_per_step": 0.47, "roofline": {"frac": 0.22, "bound": "valu", "traffic": 1.05e9, "kernel_ms": 0.47},
+                    "hbm": {"algorithmic_bytes_per_step": 3.0e8}},
+          "stub": {"ms_per_step": 1.0}}
+    tab = bench.by_workload_table(rs)
+    assert tab["_cols"] == ["ms_per_step", "frac", "bound", "hbm_frac_algorithmic", "traffic_over_algorithmic"]
+    assert tab["acq"][:3] == [0.8, 0.4, "valu"] and abs(tab["acq"][3] - 1.1e10 / 0.78e-3 / 1e9 / 8000.0) < 1e-3
+    assert abs(tab["ddc14"][4] - 3.5) < 1e-9 and tab["stub"] == [1.0, None, None, None, None]
+    assert len(json.dumps(bench.by_workload_table({k: rs["acq"] for k in bench.ALL_WORKLOADS}))) < 500
+    # the environment bench.py fixes before anything touches the GPU (DESIGN.md section 4, hardware queues)
+    assert os.environ.get("GPU_MAX_HW_QUEUES") is not None

@@ -40,7 +40,7 @@ table = ("| Config | CPU T₁ (Msamples/s) | CPU T_all (Msamples/s) | 1 GPU | 2 
          "|---|---|---|---|---|---|---|---|---|---|\n" + "\n".join(rows))
 src = open("BASELINE.md").read()
 start = src.index("Results table")
-out = src[:start] + ("Results table, filled from the default `python bench.py` line of round 3 (`%s`; one MI355X; CPU legs: the oracle port\n"
+out = src[:start] + ("Results table, filled from the default `python bench.py` line of round 4 (`%s`; one MI355X; CPU legs: the oracle port\n"
                      "and, where the work goes through an FFT, scipy.fft / pocketfft, on the GPU box's host cores in the same run):\n\n" % sys.argv[1]
                      ) + table + "\n" + NOTES if (NOTES := """
 Notes recorded beside the configs:
@@ -50,7 +50,11 @@ Notes recorded beside the configs:
   `MIN_SIG` = 16 (`gps/gps.h:60`), which is sized for 41 × 4092 trials per SV: 256 × 4092 (E1B: 16368) lags are 1.0 M
   (4.2 M) trials whose noise maximum alone reaches 14 … 19.
 * configs[3]'s line is ONE GPU's share (128 of the 1024 receivers, `--receivers 128`); `bench.py --gpus 8 --workload
-  receivers` runs the eight shares, one rank per GPU, no data-path collective.
+  receivers` runs the eight shares, one rank per GPU, no data-path collective.  Since round 4 the waterfall side of a
+  receiver takes its frame the way the reference's non-overlapped `sample_wf()` does -- `CmdWFReset` + the one-shot sampler,
+  `kg_ddc_wf_capture_dev` -- and so does the CPU baseline (1.75 ms per step and 1 584 Msamples/s on all cores in round 3,
+  with the continuous sampler over the whole block on both sides).
+* configs[2] DDC / end to end: since round 4 the steps walk nine distinct 32 MiB ADC blocks (past the Infinity Cache).
 * `value` is the HBM-resident rate; the PCIe-inclusive rate of configs[1] is `ingest_pcie_Msps` in the same line.
 """) else ""
 open("BASELINE.md", "w").write(out)
