@@ -1486,9 +1486,19 @@ class ReceiverBank:
         # ONE stream for both tails (measured, eight hardware queues: a stream per tail 1.42 ms per step -- the two
         # latency-bound tails running side by side with both chains; one shared tail stream 1.10 ms; tails in line 1.15 ms)
         tails_mode = os.environ.get("KIWIGPU_BENCH_TAIL_STREAMS", "1")     # 2: a stream per tail; 1: ONE stream for both tails; 0: in line
+        # (experiments: "pk" = only the packet coder on a stream of its own, CAgc + ADPCM in line with the audio chain;
+        #  "au" = the other way round)
         self.tails = two_streams and tails_mode != "0"
-        self.s_pk = torch.cuda.Stream(device=dev) if self.tails else None
-        self.s_tail = (self.s_pk if tails_mode == "1" else torch.cuda.Stream(device=dev)) if self.tails else None
+        self.main = torch.cuda.current_stream(dev)
+        if not self.tails:
+            self.s_pk = self.s_tail = None
+        elif tails_mode == "pk":
+            self.s_pk, self.s_tail = torch.cuda.Stream(device=dev), self.side
+        elif tails_mode == "au":
+            self.s_pk, self.s_tail = self.main, torch.cuda.Stream(device=dev)
+        else:
+            self.s_pk = torch.cuda.Stream(device=dev)
+            self.s_tail = self.s_pk if tails_mode == "1" else torch.cuda.Stream(device=dev)
         self.ctx_pk = Context(local_rank, self.s_pk.cuda_stream) if self.tails else ctx
         self.ctx_tail = Context(local_rank, self.s_tail.cuda_stream) if self.tails else ctx_au
         self.main = torch.cuda.current_stream(dev)

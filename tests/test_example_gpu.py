@@ -64,3 +64,65 @@ def test_cpp_caller_per_sv_latency_32_svs(gpu_ctx, tmp_path):
     assert len(rows) == 32 and rows[0][1:3] == (6, 4808)
     print(text.splitlines()[-1])
     assert lat[0] < 500.0, text
+
+
+# ---- the waterfall seam from C++ ---------------------------------------------------------------------------------
+WF_EXE = os.path.join(ROOT, "examples", "waterfall_dropin")
+
+
+def write_wf_tables(path, params, interp, window_func):
+    """tables.bin of examples/waterfall_dropin.cpp: the arrays a reference build would hand over (WF_SHMEM->window_function,
+    ->CIC_comp, each wf_inst_t's fft2wf_map / drop_sample / fft_scale / fft_scale_div2), here from the host mirror wf.py."""
+    import struct
+    from flydog_sdr_gps_amd import wf
+    with open(path, "wb") as f:
+        f.write(struct.pack("<i", len(params)))
+        f.write(np.ascontiguousarray(wf.window_functions(), np.float32).tobytes())
+        f.write(np.ascontiguousarray(wf.cic_comp_table(), np.float32).tobytes())
+        for p in params:
+            m, d = wf.build_maps(p.fft_used, p.plot_width, p.plot_width_clamped, False)
+            m4096 = np.zeros(4096, np.uint16)
+            m4096[:len(m)] = m
+            scale = np.full(1024, p.fft_scale, np.float32)
+            f.write(struct.pack("<8if", p.zoom, window_func, interp, 1, 0, p.fft_used, p.plot_width, p.plot_width_clamped,
+                                float(p.fft_offset)))
+            f.write(struct.pack("<QiI", p.i_offset & ((1 << 48) - 1), p.decim, int(p.start) & 0xFFFFFFFF))
+            f.write(m4096.tobytes())
+            f.write(np.ascontiguousarray(d, np.uint16).tobytes())
+            f.write(scale.tobytes())
+            f.write((scale / np.float32(2)).astype(np.float32).tobytes())
+
+
+def test_cpp_waterfall_caller_against_the_oracle(gpu_ctx, oracle, tmp_path):
+    """examples/waterfall_dropin.cpp -- c2s_waterfall_init / CmdSetWFFreq + CmdSetWFDecim / sample_wf (CmdWFReset + one-shot
+    sampler) / compute_frame / the W/F packet, through include/kiwigpu.h from plain C++ -- on two consecutive ADC blocks and
+    six channels (zooms 0 .. 9): every row and every packet against the ORACLE's chain on the same samples (the DDC model
+    started from a cleared filter at each block's NCO phase, sample_wf window + compute_frame, wf_pkt_t with ADPCM)."""
+    from flydog_sdr_gps_amd import WfParams, wf
+    from tests.test_ddc_gpu import adc_stream
+    from tests.test_wf_gpu import check_row, db_bound, oracle_frame
+    assert os.path.exists(WF_EXE), "examples/waterfall_dropin is not built (run __graft_entry__.build())"
+    zooms = [0, 1, 3, 5, 7, 9]
+    params = [WfParams.for_zoom(z, 2.0e6 + 0.7e6 * k, adc_clock=66.6666e6, ui_srate=30.0e6) for k, z in enumerate(zooms)]
+    n, steps = 8192 * 256, 2                                  # zoom 9 (R = 256) just fills the sampler
+    adc = adc_stream(n * steps, seed=61, tones=((0.031, 8000.0), (0.1234, 2000.0), (0.3, 300.0)))
+    tb, ab, ob = tmp_path / "tables.bin", tmp_path / "adc.bin", tmp_path / "out.bin"
+    write_wf_tables(tb, params, wf.WF_MAX, wf.WINF_HANNING)
+    ab.write_bytes(adc.tobytes())
+    r = subprocess.run([WF_EXE, str(tb), str(ab), str(ob), str(steps)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rec = np.dtype([("row", np.uint8, 1024), ("nb", "<i4"), ("pkt", np.uint8, 16 + 10 + 1024)])
+    out = np.frombuffer(ob.read_bytes(), rec).reshape(steps, len(zooms))
+    tables = (wf.window_functions(), wf.cic_comp_table())
+    for s in range(steps):
+        blk = adc[s * n:(s + 1) * n]
+        for c, p in enumerate(params):
+            st = oracle.DdcWfState()
+            st.phase = (s * n * p.i_offset) & ((1 << 48) - 1)
+            iq, _ = oracle.ddc_wf(blk[:8192 * p.decim], p.i_offset, int(np.log2(p.decim)), st)
+            assert iq.shape[0] == 8192
+            w_out, _, w_po, w_dB = oracle_frame(oracle, tables, iq, p, wf.WF_MAX, wf.WINF_HANNING, True, False, False)
+            check_row(out[s, c]["row"], w_out, w_dB, db_bound(w_po))
+            want_pkt = oracle.wf_packet(out[s, c]["row"], int(p.start), p.zoom, s, True)
+            assert int(out[s, c]["nb"]) == want_pkt.size
+            assert np.array_equal(out[s, c]["pkt"][:want_pkt.size], want_pkt), (s, c)

@@ -873,3 +873,22 @@ def test_bench_line_helpers_without_a_gpu():
     assert len(json.dumps(bench.by_workload_table({k: rs["acq"] for k in bench.ALL_WORKLOADS}))) < 500
     # the environment bench.py fixes before anything touches the GPU (hardware queues)
     assert os.environ.get("GPU_MAX_HW_QUEUES") is not None
+
+
+def test_cpp_waterfall_example_builds_and_refuses_without_a_gpu(tmp_path):
+    """examples/waterfall_dropin (compiled against include/kiwigpu.h only) parses its inputs and, on a box without a gfx950
+    device, stops at kg_ctx_create with the library's no-device error: there is no CPU path behind the C ABI."""
+    import struct
+    import torch
+    exe = os.path.join(ROOT, "examples", "waterfall_dropin")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    tb, ab = tmp_path / "t.bin", tmp_path / "a.bin"
+    tb.write_bytes(struct.pack("<i", 0) + bytes(4 * 4 * 8192 + 4 * 8192))
+    ab.write_bytes(bytes(2 * 8192))
+    r = subprocess.run([exe, str(tb), str(ab), str(tmp_path / "o.bin")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3 and "kg_ctx_create" in r.stderr, r.stdout + r.stderr
+    r = subprocess.run([exe, str(tb), str(tmp_path / "missing"), str(tmp_path / "o.bin")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2
