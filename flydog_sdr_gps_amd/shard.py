@@ -97,7 +97,8 @@ def shares_of(ranges):
 def gather_results(local, device=None):
     """all_gather a structured numpy array of per-unit results (equal shape on every
     rank) along axis 0.  Works on any initialised process group: nccl (= RCCL)
-    with device given, gloo with device None."""
+    with device given -- ONE all_gather_into_tensor on the device, one copy back --
+    gloo with device None."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size()
@@ -105,10 +106,14 @@ def gather_results(local, device=None):
     raw = torch.from_numpy(local.view(np.uint8).reshape(-1).copy())
     if device is not None:
         raw = raw.to(device)
-    outs = [torch.empty_like(raw) for _ in range(world)]
-    dist.all_gather(outs, raw)
-    parts = [o.cpu().numpy().view(local.dtype).reshape(local.shape) for o in outs]
-    return np.concatenate(parts, axis=0)
+        out = torch.empty(world * raw.numel(), dtype=torch.uint8, device=device)
+        dist.all_gather_into_tensor(out, raw)
+        flat = out.cpu().numpy()
+    else:
+        outs = [torch.empty_like(raw) for _ in range(world)]
+        dist.all_gather(outs, raw)
+        flat = np.concatenate([o.numpy() for o in outs])
+    return flat.view(local.dtype).reshape((world * local.shape[0],) + local.shape[1:])
 
 
 def merge_sv_shards(parts, nblocks, shares):
