@@ -507,6 +507,28 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
             const bool same = k2 < P - 1;
             const acq_rsrc nr = fetch_prepare(same ? cur.data_off : nxt.data_off, same ? cur.code_off : nxt.code_off,
                                               same ? cur.dop : nxt.dop, (k2 + 1) & (P - 1));
+#ifndef KG_FUSED_TW
+#define KG_FUSED_TW 1
+#endif
+#if KG_FUSED_TW
+            // Round 4: conj(data) * code (simd_multiply_conjugate_ccc, support/simd.cpp:39-67) FUSED into the first stage of
+            // pass 0 (kg_cc_radix16_h, kg_fft.h): 99 packed instructions where products + butterfly took 112, and no copies
+            // of the code operands (the in-place products needed sixteen).  The next item's data rows are requested two at
+            // a time as the operands they overwrite are consumed; the LDS stores group by group as before.
+            KG_STAMP(STAMPS, sti, 9);
+            KG_STAMP(STAMPS, sti, 10);
+            kg_cc_radix16_h<+1>(c, d, y, [&](int s) {
+                kg_pin();
+                if (s < 4) {
+                    if constexpr (NQ == 1) { fetch_drow(nr, 2 * s); fetch_drow(nr, 2 * s + 1); }
+                    else { fetch_row(nr, 2 * s); fetch_row(nr, 2 * s + 1); }
+                } else {
+#pragma unroll
+                    for (int m = s - 4; m < 16; m += 4) kg_st(&tileA[16 * t + (m ^ tl)], y[m]);
+                }
+                kg_pin();
+            });
+#else
             // conj(data) * code, simd_multiply_conjugate_ccc (support/simd.cpp:39-67)
 #pragma unroll
             for (int j = 0; j < 16; j += 4) {
@@ -533,6 +555,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
                 }
                 kg_pin();
             });
+#endif
             KG_STAMP(STAMPS, sti, 0);
             deferred(0, k2);
             KG_STAMP(STAMPS, sti, 1);
@@ -544,8 +567,12 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
             if (STAMPS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             KG_STAMP(STAMPS, sti, 3);
             // pass 1: twiddle W256^(j*(t&15)), out index (t>>4)*256 + (t&15) + 16 m
+#if KG_FUSED_TW
+            kg_tw_radix16_h<+1>(x, y, tw.p1, [&](int s) {
+#else
             kg_twiddle16<+1>(x, tw.p1);
             kg_radix16_h<+1>(x, y, [&](int s) {
+#endif
                 if (s >= 4) {
                     kg_pin();
 #pragma unroll
@@ -572,14 +599,18 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
             if (STAMPS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             KG_STAMP(STAMPS, sti, 6);
             // pass 2: twiddle W4096^(j*t), out index t + 256 m (kept in registers)
-            kg_twiddle16<+1>(x, tw.p2);
             // (NQ == 1: the next item's code rows, two per first-stage group)
             auto crows = [&](int s) {
                 if constexpr (NQ == 1) {
                     if (s < 4) { kg_pin(); fetch_crow(nr, 2 * s); fetch_crow(nr, 2 * s + 1); kg_pin(); }
                 }
             };
+#if KG_FUSED_TW
+            kg_tw_radix16_h<+1>(x, yprev, tw.p2, crows);
+#else
+            kg_twiddle16<+1>(x, tw.p2);
             kg_radix16_h<+1>(x, yprev, crows);
+#endif
             pbase = base;
 #pragma unroll
             for (int i = 0; i < 3; i++) { pg[i] = g[i]; pG[i] = G[i]; }

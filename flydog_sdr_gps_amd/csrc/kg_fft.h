@@ -273,6 +273,189 @@ template <int SIGN> KG_DEV void kg_radix16(cf (&x)[16], cf (&y)[16])
     for (int m = 0; m < 16; m++) y[m] = x[4 * (m & 3) + (m >> 2)];
 }
 
+struct kg_tw15 { cf w[15]; };     // the fifteen inter-pass twiddles of one pass (w[j - 1] for input j)
+
+// ---------------------------------------------------------------------------
+// Round 4: twiddles FUSED into the butterflies.  A radix-2 step on a twiddled operand, (u + w z, u - w z), is written
+//     s = u + w z     two fused multiply-adds (the product is never formed on its own)
+//     d = 2 u - s     one
+// -- three packed instructions where product, sum and difference took four.  Every pair of a radix-4 with a twiddled
+// member saves one: 8 in a first stage behind inter-pass twiddles (or behind the conjugate products of pass 0), 5 in a
+// second stage (the internal W16 constants): 13 of the 110 packed instructions of twiddle16 + radix16.  d carries the
+// rounding of s instead of the product's own -- the same size of error, a different value: results move in the last
+// bits (the parity bars are 1e-5 of the spectrum's maximum; peak indices stay exact).
+// Blocks of up to four independent operations per asm statement, as above (no wait state per product).
+// ---------------------------------------------------------------------------
+#define KG_CFMA1_(t, a, w, c) "v_pk_fma_f32 " t ", " a ", " w ", " c " op_sel_hi:[1,0,1]\n\t"
+#define KG_CFMA2P_(t, a, w) "v_pk_fma_f32 " t ", " a ", " w ", " t " op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]\n\t"
+#define KG_CFMA2C_(t, a, w) "v_pk_fma_f32 " t ", " a ", " w ", " t " op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
+#define KG_2CMT_(d, c, two, t) "v_pk_fma_f32 " d ", " c ", " two ", " t " neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
+// t_i = c_i + a_i w_i (CONJ: a_i conj(w_i)), four at a time, w_i in vector registers
+template <bool CONJ> KG_DEV void kg_cfma4v(cf &t0, cf &t1, cf &t2, cf &t3, cf c0, cf c1, cf c2, cf c3,
+                                           cf a0, cf a1, cf a2, cf a3, cf w0, cf w1, cf w2, cf w3)
+{
+    if constexpr (!CONJ)
+        asm(KG_CFMA1_("%0", "%8", "%12", "%4") KG_CFMA1_("%1", "%9", "%13", "%5") KG_CFMA1_("%2", "%10", "%14", "%6") KG_CFMA1_("%3", "%11", "%15", "%7")
+            KG_CFMA2P_("%0", "%8", "%12") KG_CFMA2P_("%1", "%9", "%13") KG_CFMA2P_("%2", "%10", "%14") KG_CFMA2P_("%3", "%11", "%15")
+            : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+            : "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+    else
+        asm(KG_CFMA1_("%0", "%8", "%12", "%4") KG_CFMA1_("%1", "%9", "%13", "%5") KG_CFMA1_("%2", "%10", "%14", "%6") KG_CFMA1_("%3", "%11", "%15", "%7")
+            KG_CFMA2C_("%0", "%8", "%12") KG_CFMA2C_("%1", "%9", "%13") KG_CFMA2C_("%2", "%10", "%14") KG_CFMA2C_("%3", "%11", "%15")
+            : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+            : "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+}
+// o_i = a_i w_i (CONJ: a_i conj(w_i)), NOT in place, four at a time
+template <bool CONJ> KG_DEV void kg_cmul4v_o(cf &o0, cf &o1, cf &o2, cf &o3, cf a0, cf a1, cf a2, cf a3, cf w0, cf w1, cf w2, cf w3)
+{
+    if constexpr (!CONJ)
+        asm(KG_MUL_("%0", "%4", "%8") KG_MUL_("%1", "%5", "%9") KG_MUL_("%2", "%6", "%10") KG_MUL_("%3", "%7", "%11")
+            KG_CFMA2P_("%0", "%4", "%8") KG_CFMA2P_("%1", "%5", "%9") KG_CFMA2P_("%2", "%6", "%10") KG_CFMA2P_("%3", "%7", "%11")
+            : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)
+            : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+    else
+        asm(KG_MUL_("%0", "%4", "%8") KG_MUL_("%1", "%5", "%9") KG_MUL_("%2", "%6", "%10") KG_MUL_("%3", "%7", "%11")
+            KG_CFMA2C_("%0", "%4", "%8") KG_CFMA2C_("%1", "%5", "%9") KG_CFMA2C_("%2", "%6", "%10") KG_CFMA2C_("%3", "%7", "%11")
+            : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)
+            : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+}
+// d_i = 2 c_i - t_i, four at a time (d_i may be c_i)
+KG_DEV void kg_2cmt4(cf &d0, cf &d1, cf &d2, cf &d3, cf c0, cf c1, cf c2, cf c3, cf t0, cf t1, cf t2, cf t3)
+{
+    const cf two = cf{2.0f, 2.0f};
+    asm(KG_2CMT_("%0", "%4", "%12", "%8") KG_2CMT_("%1", "%5", "%12", "%9") KG_2CMT_("%2", "%6", "%12", "%10") KG_2CMT_("%3", "%7", "%12", "%11")
+        : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
+        : "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "s"(two));
+}
+
+// Second stage of the radix-16 with its internal twiddles fused.  In: x[4c + d] = the first stage's u_d[c] (NOT yet multiplied
+// by W16^(c d)); out: y[c + 4 d]; hook(4 + c) when row c is final.  43 packed instructions (16 + 32 as products + radix-4s).
+template <int SIGN, class H> KG_DEV void kg_radix16_stage2f(cf (&x)[16], cf (&y)[16], H hook)
+{
+#define KG_W16C(K) cf{KG_W16[K][0], KG_W16[K][1]}
+    const cf two = cf{2.0f, 2.0f};
+    kg_radix4<SIGN>(x[0], x[1], x[2], x[3]);                        // row 0: no twiddles
+    y[0] = x[0]; y[4] = x[1]; y[8] = x[2]; y[12] = x[3];
+    hook(4);
+    // rows c = 1, 2, 3 (z_d = x[4c + d]):  u1 = W^c z1,  s13 = u1 + W^(3c) z3,  d13 = 2 u1 - s13,
+    //                                      s02 = z0 + W^(2c) z2,  d02 = 2 z0 - s02   (c = 2: W^4 = SIGN j: an add and a subtract)
+    cf u1[3], s13[3], d13[3], s02a, s02b, d02a, d02b;
+    if constexpr (SIGN > 0) {
+        asm(KG_MUL_("%0", "%3", "%6") KG_MUL_("%1", "%4", "%7") KG_MUL_("%2", "%5", "%8")
+            KG_CFMA2P_("%0", "%3", "%6") KG_CFMA2P_("%1", "%4", "%7") KG_CFMA2P_("%2", "%5", "%8")
+            : "=&v"(u1[0]), "=&v"(u1[1]), "=&v"(u1[2]) : "v"(x[5]), "v"(x[9]), "v"(x[13]), "s"(KG_W16C(1)), "s"(KG_W16C(2)), "s"(KG_W16C(3)));
+        asm(KG_CFMA1_("%0", "%6", "%9", "%3") KG_CFMA1_("%1", "%7", "%10", "%4") KG_CFMA1_("%2", "%8", "%11", "%5")
+            KG_CFMA2P_("%0", "%6", "%9") KG_CFMA2P_("%1", "%7", "%10") KG_CFMA2P_("%2", "%8", "%11")
+            : "=&v"(s13[0]), "=&v"(s13[1]), "=&v"(s13[2])
+            : "v"(u1[0]), "v"(u1[1]), "v"(u1[2]), "v"(x[7]), "v"(x[11]), "v"(x[15]), "s"(KG_W16C(3)), "s"(KG_W16C(6)), "s"(KG_W16C(9)));
+        asm(KG_CFMA1_("%0", "%4", "%6", "%2") KG_CFMA1_("%1", "%5", "%7", "%3")
+            KG_CFMA2P_("%0", "%4", "%6") KG_CFMA2P_("%1", "%5", "%7")
+            : "=&v"(s02a), "=&v"(s02b) : "v"(x[4]), "v"(x[12]), "v"(x[6]), "v"(x[14]), "s"(KG_W16C(2)), "s"(KG_W16C(6)));
+    } else {
+        asm(KG_MUL_("%0", "%3", "%6") KG_MUL_("%1", "%4", "%7") KG_MUL_("%2", "%5", "%8")
+            KG_CFMA2C_("%0", "%3", "%6") KG_CFMA2C_("%1", "%4", "%7") KG_CFMA2C_("%2", "%5", "%8")
+            : "=&v"(u1[0]), "=&v"(u1[1]), "=&v"(u1[2]) : "v"(x[5]), "v"(x[9]), "v"(x[13]), "s"(KG_W16C(1)), "s"(KG_W16C(2)), "s"(KG_W16C(3)));
+        asm(KG_CFMA1_("%0", "%6", "%9", "%3") KG_CFMA1_("%1", "%7", "%10", "%4") KG_CFMA1_("%2", "%8", "%11", "%5")
+            KG_CFMA2C_("%0", "%6", "%9") KG_CFMA2C_("%1", "%7", "%10") KG_CFMA2C_("%2", "%8", "%11")
+            : "=&v"(s13[0]), "=&v"(s13[1]), "=&v"(s13[2])
+            : "v"(u1[0]), "v"(u1[1]), "v"(u1[2]), "v"(x[7]), "v"(x[11]), "v"(x[15]), "s"(KG_W16C(3)), "s"(KG_W16C(6)), "s"(KG_W16C(9)));
+        asm(KG_CFMA1_("%0", "%4", "%6", "%2") KG_CFMA1_("%1", "%5", "%7", "%3")
+            KG_CFMA2C_("%0", "%4", "%6") KG_CFMA2C_("%1", "%5", "%7")
+            : "=&v"(s02a), "=&v"(s02b) : "v"(x[4]), "v"(x[12]), "v"(x[6]), "v"(x[14]), "s"(KG_W16C(2)), "s"(KG_W16C(6)));
+    }
+    // the five differences d = 2 u - s
+    asm(KG_2CMT_("%0", "%5", "%15", "%10") KG_2CMT_("%1", "%6", "%15", "%11") KG_2CMT_("%2", "%7", "%15", "%12")
+        KG_2CMT_("%3", "%8", "%15", "%13") KG_2CMT_("%4", "%9", "%15", "%14")
+        : "=&v"(d13[0]), "=&v"(d13[1]), "=&v"(d13[2]), "=&v"(d02a), "=&v"(d02b)
+        : "v"(u1[0]), "v"(u1[1]), "v"(u1[2]), "v"(x[4]), "v"(x[12]),
+          "v"(s13[0]), "v"(s13[1]), "v"(s13[2]), "v"(s02a), "v"(s02b), "s"(two));
+    // row 1
+    y[1] = s02a + s13[0]; y[9] = s02a - s13[0];
+    kg_addsub_sj<SIGN>(y[5], y[13], d02a, d13[0]);
+    hook(5);
+    // row 2: s02, d02 = z0 +- (SIGN j) z2
+    {
+        cf s02, d02;
+        kg_addsub_sj<SIGN>(s02, d02, x[8], x[10]);
+        y[2] = s02 + s13[1]; y[10] = s02 - s13[1];
+        kg_addsub_sj<SIGN>(y[6], y[14], d02, d13[1]);
+    }
+    hook(6);
+    // row 3
+    y[3] = s02b + s13[2]; y[11] = s02b - s13[2];
+    kg_addsub_sj<SIGN>(y[7], y[15], d02b, d13[2]);
+    hook(7);
+#undef KG_W16C
+}
+
+// First stage behind inter-pass twiddles, fused:  in X[j] (j = 4a + b) and the fifteen twiddles w (w.w[j - 1] for X[j]);
+// out x[4c + b] = u_b[c] = sum_a (w X)[4a + b] (SIGN j)^(a c), the input of kg_radix16_stage2f.  hook(0..3) between its blocks.
+// 54 packed instructions (30 + 32 as products + radix-4s).
+template <int SIGN, class H> KG_DEV void kg_radix16_stage1_tw(cf (&x)[16], const kg_tw15 &w, H hook)
+{
+    constexpr bool CJ = SIGN < 0;
+    // u0_b = w_b X_b (b = 1..3; X_0 has no twiddle), u1_b = w_(4+b) X_(4+b)
+    kg_cmul3v<CJ>(x[1], x[2], x[3], w.w[0], w.w[1], w.w[2]);
+    hook(0);
+    kg_cmul4v<CJ>(x[4], x[5], x[6], x[7], w.w[3], w.w[4], w.w[5], w.w[6]);
+    hook(1);
+    cf s02[4], s13[4];
+    kg_cfma4v<CJ>(s02[0], s02[1], s02[2], s02[3], x[0], x[1], x[2], x[3], x[8], x[9], x[10], x[11], w.w[7], w.w[8], w.w[9], w.w[10]);
+    hook(2);
+    kg_cfma4v<CJ>(s13[0], s13[1], s13[2], s13[3], x[4], x[5], x[6], x[7], x[12], x[13], x[14], x[15], w.w[11], w.w[12], w.w[13], w.w[14]);
+    hook(3);
+    cf d02[4], d13[4];
+    kg_2cmt4(d02[0], d02[1], d02[2], d02[3], x[0], x[1], x[2], x[3], s02[0], s02[1], s02[2], s02[3]);
+    kg_2cmt4(d13[0], d13[1], d13[2], d13[3], x[4], x[5], x[6], x[7], s13[0], s13[1], s13[2], s13[3]);
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        x[b] = s02[b] + s13[b];
+        x[8 + b] = s02[b] - s13[b];
+        kg_addsub_sj<SIGN>(x[4 + b], x[12 + b], d02[b], d13[b]);
+    }
+}
+
+// First stage of pass 0 of a correlator item, the conjugate products fused in:  p_j = c_j conj(d_j) (simd_multiply_conjugate_ccc,
+// support/simd.cpp:39-67) never formed on their own for j >= 8; c and d are left intact.  hook(s), s = 0..3, is called when
+// operands 4 s .. 4 s + 3 (rows 2 s, 2 s + 1 of the fetch) have been consumed.  56 packed instructions (32 + 32).
+template <int SIGN, class H> KG_DEV void kg_radix16_stage1_cc(const cf (&c)[16], const cf (&d)[16], cf (&x)[16], H hook)
+{
+    cf u0[4], u1[4];
+    kg_cmul4v_o<true>(u0[0], u0[1], u0[2], u0[3], c[0], c[1], c[2], c[3], d[0], d[1], d[2], d[3]);
+    hook(0);
+    kg_cmul4v_o<true>(u1[0], u1[1], u1[2], u1[3], c[4], c[5], c[6], c[7], d[4], d[5], d[6], d[7]);
+    hook(1);
+    cf s02[4], s13[4];
+    kg_cfma4v<true>(s02[0], s02[1], s02[2], s02[3], u0[0], u0[1], u0[2], u0[3], c[8], c[9], c[10], c[11], d[8], d[9], d[10], d[11]);
+    hook(2);
+    kg_cfma4v<true>(s13[0], s13[1], s13[2], s13[3], u1[0], u1[1], u1[2], u1[3], c[12], c[13], c[14], c[15], d[12], d[13], d[14], d[15]);
+    hook(3);
+    cf d02[4], d13[4];
+    kg_2cmt4(d02[0], d02[1], d02[2], d02[3], u0[0], u0[1], u0[2], u0[3], s02[0], s02[1], s02[2], s02[3]);
+    kg_2cmt4(d13[0], d13[1], d13[2], d13[3], u1[0], u1[1], u1[2], u1[3], s13[0], s13[1], s13[2], s13[3]);
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        x[b] = s02[b] + s13[b];
+        x[8 + b] = s02[b] - s13[b];
+        kg_addsub_sj<SIGN>(x[4 + b], x[12 + b], d02[b], d13[b]);
+    }
+}
+
+// twiddle16 + radix16 fused (97 packed instructions instead of 110), hooks as kg_radix16_h: s = 0..3 inside the first stage,
+// s = 4..7 when row s - 4 of the outputs (y[s-4], y[s], y[s+4], y[s+8]) is final
+template <int SIGN, class H> KG_DEV void kg_tw_radix16_h(cf (&x)[16], cf (&y)[16], const kg_tw15 &w, H hook)
+{
+    kg_radix16_stage1_tw<SIGN>(x, w, hook);
+    kg_radix16_stage2f<SIGN>(x, y, hook);
+}
+// conj-products + radix16 fused (99 instead of 112; no copies of the operands)
+template <int SIGN, class H> KG_DEV void kg_cc_radix16_h(const cf (&c)[16], const cf (&d)[16], cf (&y)[16], H hook)
+{
+    cf x[16];
+    kg_radix16_stage1_cc<SIGN>(c, d, x, hook);
+    kg_radix16_stage2f<SIGN>(x, y, hook);
+}
+
 // The same butterfly with a hook after each of its eight radix-4 groups (s = 0..3: the first stage,
 // s = 4..7: the second, after which y[s-4], y[s], y[s+4], y[s+8] are final).  Callers use the hooks
 // to issue memory instructions between the groups (operand loads of the next item, the LDS stores of
@@ -306,7 +489,6 @@ template <int SIGN, class H> KG_DEV void kg_radix16_h(cf (&x)[16], cf (&y)[16], 
 // (60 VGPRs) for the life of the kernel.  Values come from
 // tab4096[k] = exp(+2*pi*i*k/4096) (fp32 roundings of double-precision values,
 // host-built, L2 resident).
-struct kg_tw15 { cf w[15]; };
 struct kg_tw4096 { kg_tw15 p1, p2; };
 
 KG_DEV void kg_tw4096_load(kg_tw4096 &tw, const float2 *__restrict__ tab4096, int t)
