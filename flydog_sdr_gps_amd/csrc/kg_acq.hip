@@ -866,22 +866,14 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
     fetch_item(cur, 0);
     {   // prologue: item 0 of the workgroup's first cell up to tile 1 (passes 0 and 1), operands of item 1 requested
         cf x[8], y[8];
-#pragma unroll
-        for (int j = 0; j < 8; j += 4) {
-            x[j] = c[j]; x[j + 1] = c[j + 1]; x[j + 2] = c[j + 2]; x[j + 3] = c[j + 3];
-            kg_cmul4v<true>(x[j], x[j + 1], x[j + 2], x[j + 3], d[j], d[j + 1], d[j + 2], d[j + 3]);
-        }
-        kg_pin();
-        fetch_item(cur, 1);
-        kg_pin();
-        kg_radix8<+1>(x, y);
+        // (round 4: products and twiddles fused into the butterflies, kg_fft.h)
+        kg_cc_radix8_h<+1>(c, d, y, [&]() { kg_pin(); fetch_item(cur, 1); kg_pin(); });
 #pragma unroll
         for (int m = 0; m < 8; m++) kg_st(&tile0[8 * i + (m ^ c0)], y[m]);
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 8; j++) x[j] = kg_ld_tile(&tile0[r0 + 512 * j]);
-        kg_twiddle8<+1>(x, tw.p1);
-        kg_radix8<+1>(x, y);
+        kg_tw_radix8<+1>(x, y, tw.p1);
 #pragma unroll
         for (int m = 0; m < 8; m++) kg_st(&tile1[w1 + 8 * (m ^ b1)], y[m]);
         __syncthreads();
@@ -974,20 +966,15 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
                 cf xa[8], ya[8], xb[8], yb[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++) xa[j] = kg_ld_tile(&tile1[r1 + 512 * j]);
-                // conj(data) * code, simd_multiply_conjugate_ccc (support/simd.cpp:39-67)
-#pragma unroll
-                for (int j = 0; j < 8; j += 4)
-                    kg_cmulc4_o(xb[j], xb[j + 1], xb[j + 2], xb[j + 3], c[j], c[j + 1], c[j + 2], c[j + 3],
-                                d[j], d[j + 1], d[j + 2], d[j + 3]);
+                // conj(data) * code, simd_multiply_conjugate_ccc (support/simd.cpp:39-67) -- round 4: fused into pass 0's first
+                // stage, as the inter-pass twiddles are into theirs (kg_fft.h: 6 of 42 / 44 packed instructions per pass)
+                (void) xb;
                 KG_STAMP(STAMPS, sti, 1);
-                ld(0);
-                kg_radix8<+1>(xb, yb);
+                kg_cc_radix8_h<+1>(c, d, yb, [&]() { ld(0); });
 #pragma unroll
                 for (int m = 0; m < 8; m++) kg_st(&tile0[8 * i + (m ^ c0)], yb[m]);
                 KG_STAMP(STAMPS, sti, 2);
-                kg_twiddle8<+1>(xa, tw.p2);
-                ld(1);
-                kg_radix8<+1>(xa, ya);
+                kg_tw_radix8_h<+1>(xa, ya, tw.p2, [&]() { ld(1); });
                 KG_STAMP(STAMPS, sti, 3);
 #pragma unroll
                 for (int m = 0; m < 8; m++) kg_st(&tile2[w2 + 64 * m], ya[m]);
@@ -1005,9 +992,7 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
                 cf xb[8], yb[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++) xb[j] = kg_ld_tile(&tile0[r0 + 512 * j]);
-                kg_twiddle8<+1>(xb, tw.p1);
-                ld(2);
-                kg_radix8<+1>(xb, yb);
+                kg_tw_radix8_h<+1>(xb, yb, tw.p1, [&]() { ld(2); });
 #pragma unroll
                 for (int m = 0; m < 8; m++) kg_st(&tile1[w1 + 8 * (m ^ b1)], yb[m]);
             }
@@ -1022,9 +1007,7 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
 #pragma unroll
                 for (int q = 1; q < 4; q++) Q[q - 1] = kg_ld_tile(&cst[8 * k2 + 3 + q]);
             }
-            kg_twiddle8<+1>(x, tw.p3);
-            ld(3);
-            kg_radix8<+1>(x, y);                               // y[m]: the sub-transform at n = i + 512 m
+            kg_tw_radix8_h<+1>(x, y, tw.p3, [&]() { ld(3); });       // y[m]: the sub-transform at n = i + 512 m
             if (k2 == 0) {
 #pragma unroll
                 for (int q = 0; q < 4; q++)
