@@ -631,15 +631,23 @@ KG_DEV void kg_subfft4096_l(cf (&x)[16], cf (&y)[16], float2 *tileA, float2 *til
     for (int j = 1; j < 16; j++) w1.w[j - 1] = kg_ld_tile(&tw1[(j - 1) * 16 + tl]);
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = kg_ld_tile(&tileA[rd + 256 * j]);
+#ifdef KG_WF_FUSED_TW
+    kg_tw_radix16_h<SIGN>(x, y, w1, [](int) {});
+#else
     kg_twiddle16<SIGN>(x, w1);
     kg_radix16<SIGN>(x, y);
+#endif
 #pragma unroll
     for (int m = 0; m < 16; m++) kg_st(&tileB[th * 256 + 16 * m + (tl ^ m)], y[m]);
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = kg_ld_tile(&tileB[rd + 256 * j]);
+#ifdef KG_WF_FUSED_TW
+    kg_tw_radix16_h<SIGN>(x, y, p2, [](int) {});
+#else
     kg_twiddle16<SIGN>(x, p2);
     kg_radix16<SIGN>(x, y);
+#endif
 }
 
 // kg_subfft4096_l with a caller hook h(k), k = 0..7, at eight points spread over the transform (after the pass-0
@@ -665,9 +673,13 @@ KG_DEV void kg_subfft4096_l_h(cf (&x)[16], cf (&y)[16], float2 *tileA, float2 *t
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = kg_ld_tile(&tileA[rd + 256 * j]);
     h(2);
+#ifdef KG_WF_FUSED_TW
+    kg_tw_radix16_h<SIGN>(x, y, w1, [&](int s) { if (s == 1) h(3); });
+#else
     kg_twiddle16<SIGN>(x, w1);
     h(3);
     kg_radix16<SIGN>(x, y);
+#endif
     h(4);
 #pragma unroll
     for (int m = 0; m < 16; m++) kg_st(&tileB[th * 256 + 16 * m + (tl ^ m)], y[m]);
@@ -676,9 +688,13 @@ KG_DEV void kg_subfft4096_l_h(cf (&x)[16], cf (&y)[16], float2 *tileA, float2 *t
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = kg_ld_tile(&tileB[rd + 256 * j]);
     h(6);
+#ifdef KG_WF_FUSED_TW
+    kg_tw_radix16_h<SIGN>(x, y, p2, [&](int s) { if (s == 1) h(7); });
+#else
     kg_twiddle16<SIGN>(x, p2);
     h(7);
     kg_radix16<SIGN>(x, y);
+#endif
 }
 
 // The same transform for kernels that run it once per workgroup (forward FFT of
