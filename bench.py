@@ -910,6 +910,11 @@ def native_oracle_note():
 # ------------------------------------------------------------------------------------------------
 # Result checks of the timed workloads: the same objects, right after their timed region, against the oracle
 # ------------------------------------------------------------------------------------------------
+# knock-out builds of a kernel (tools/, DESIGN 6.1: "what is the time sensitive to") produce wrong rows by construction: the
+# row checks are skipped and the line says so
+TIMING_EXPERIMENT = os.environ.get("KIWIGPU_BENCH_TIMING_EXPERIMENT", "0") == "1"
+
+
 def check_wf_rows(cases, interp, window_func=None):
     """cases: [(WfParams, int16 frame [8192][2], the GPU's u8 row)] -> rows checked.  The oracle's sample_wf window +
     compute_frame (rx/rx_waterfall.cpp:1049-1066, 1275-1575) on the same frame; bytes must agree under the rule of
@@ -920,6 +925,8 @@ def check_wf_rows(cases, interp, window_func=None):
     transform does.  (The tests' synthetic frames have their maximum inside the plot, where both bounds coincide.)
     Raises AssertionError on a mismatch: the bench fails."""
     import numpy as np
+    if TIMING_EXPERIMENT:
+        return 0, 0
     from flydog_sdr_gps_amd import wf
     from oracle import kiwi_oracle as ko
     from tests.test_wf_gpu import DB_EDGE, RTOL, oracle_frame
@@ -1000,7 +1007,7 @@ def run_wf14(args, dist):
         step()
     kernel_ms = ctx.timer_stop() / steps
     k_min, k_med = event_spread(step, steps)
-    assert int(out.max()) > 100
+    assert TIMING_EXPERIMENT or int(out.max()) > 100
     # result check at the bench's own shape: 42 frames spread over the launch (every channel three times, the first and
     # the last frame among them), rows as the timed steps left them, against the oracle on the same frames
     picks = sorted(set([0, nfr - 1] + [int(x) for x in np.linspace(0, nfr - 1, 3 * len(zooms)).round()]))
@@ -2170,6 +2177,8 @@ def main():
             same_fields(line)
     if args.workload != "stub" and not args.pmc_child:
         line["box"] = box_identity(dist.local_rank)
+        if TIMING_EXPERIMENT:
+            line["invalid"] = "KIWIGPU_BENCH_TIMING_EXPERIMENT: a knock-out build whose rows are wrong by construction; not a measurement of the path"
     if dist.rank == 0:
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     dist.close()

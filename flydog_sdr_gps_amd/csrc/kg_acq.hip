@@ -240,6 +240,9 @@ __global__ __launch_bounds__(256) void acq_fft_combine_kernel(const float2 *__re
 // ---------------------------------------------------------------------------
 struct acq_red { float p; int i; float s; int pad; };
 
+// Round 4: each claim counter on its own 128-byte line.  Agent-scope atomics on ONE line are served one at a time, some 12.7 ns
+// each chip-wide (the waterfall kernel's single counter was its floor, kg_wf.hip); the eight group counters sat in one line.
+#define ACQ_CLAIM_STRIDE 32
 #define ACQ_LDS_BYTES (2 * SUB * sizeof(float2) + 4 * sizeof(acq_red) + 16)     // + the claimed cell index
 
 // One (block, SV) pair, prepared by the host: 16 bytes = one s_load_dwordx4.  The
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
     const float2 *__restrict__ comb,           // [P][8]
     const float2 *__restrict__ quart,          // [P][4]
     const acq_pair_desc *__restrict__ pairs,   // pair p belongs to XCD group p & 7
-    int *__restrict__ claim,                   // [8] per-group cell counters, zero at launch
+    int *__restrict__ claim,                   // [8][ACQ_CLAIM_STRIDE] per-group cell counters, zero at launch
     acq_walk walk,
     int halo,                                  // H of the code planes
     kg_acq_cell *__restrict__ cells,           // [nblocks][nsats][ndop]
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
         const acq_cell_desc nxt = describe(more ? nxt_idx : cur_idx);
         int claimed = 0;
         // (the counter's value only, and the atomic optimizer off: see wf_frame_kernel -- otherwise wave 0 waits for it here)
-        if (t == 0) claimed = __hip_atomic_fetch_add(&claim[xcd], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == 0) claimed = __hip_atomic_fetch_add(&claim[xcd * ACQ_CLAIM_STRIDE], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         cf acc[NQ][16];
         // The twiddle-accumulate of item k2 is DEFERRED into item k2+1's exchanges, where a wave otherwise
         // only waits (slots: behind the stores before a barrier, or after it while the tile reads are in
@@ -934,7 +937,7 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
 #endif
         int claimed = 0;
         // (lane 0 of wave 7 claims: wave 0 already carries the result merge and store of every cell)
-        if (i == 448) claimed = __hip_atomic_fetch_add(&claim[xcd], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (i == 448) claimed = __hip_atomic_fetch_add(&claim[xcd * ACQ_CLAIM_STRIDE], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         cf acc[4][8];
 #pragma unroll 1
         for (int k2 = 0; k2 < P; k2++) {
@@ -1145,7 +1148,7 @@ __global__ __launch_bounds__(64) void acq_select_kernel(const kg_acq_cell *__res
                                                        kg_acq_result *__restrict__ out, int *__restrict__ claim)
 {
     const int p = blockIdx.x, lane = threadIdx.x;
-    if (p == 0 && lane < 16) claim[lane] = 0;          // the correlators' cell counters, for the next launch
+    if (p == 0 && lane < 16) claim[lane * ACQ_CLAIM_STRIDE] = 0;          // the correlators' cell counters, for the next launch
     if (p >= npairs) return;
     float bs = 0.f;
     int bd = 0x7fffffff, bidx = 0;
@@ -1211,7 +1214,7 @@ struct kg_acq {
     uint8_t *d_chips;  // [E1B_CODELEN max]
     kg_acq_cell *d_cells;
     kg_acq_result *d_results;
-    int *d_claim;      // [16] cell counters of the C/A ([0..8)) and E1B ([8..16)) launches; zero between launches
+    int *d_claim;      // [16][ACQ_CLAIM_STRIDE] cell counters of the C/A ([0..8)) and E1B ([8..16)) launches; zero between launches
     std::vector<int> limits, code_set;
     // The (block, SV) pair tables of the last launch live in a slot of the context's staging
     // ring; they are reused while the SV list is unchanged and the slot has not come round.
@@ -1364,8 +1367,8 @@ static int acq_init(kg_acq *a)
     KG_HIP(hipMalloc((void **) &a->d_chips, 8192));
     KG_HIP(hipMalloc((void **) &a->d_cells, sizeof(kg_acq_cell) * (size_t) max_blocks * max_sats * a->ndop));
     KG_HIP(hipMalloc((void **) &a->d_results, sizeof(kg_acq_result) * (size_t) max_blocks * max_sats));
-    KG_HIP(hipMalloc((void **) &a->d_claim, sizeof(int) * 16));
-    KG_HIP(hipMemset(a->d_claim, 0, sizeof(int) * 16));
+    KG_HIP(hipMalloc((void **) &a->d_claim, sizeof(int) * 16 * ACQ_CLAIM_STRIDE));
+    KG_HIP(hipMemset(a->d_claim, 0, sizeof(int) * 16 * ACQ_CLAIM_STRIDE));
     {
         // Sample() and Correlate() run in order on the context's stream.  A second stream
         // (KIWIGPU_ACQ_FRONT_STREAM=1) lets block b+1's front end overlap block b's
@@ -1819,7 +1822,7 @@ static void launch_correlate(kg_acq *a, hipStream_t st, int first, const acq_pai
                        (const float2 *) (a->d_data + (size_t) first * a->fft_len), (const float2 *) a->d_code,
                        (const float2 *) a->ctx->d_tab4096, (const float2 *) a->d_tabN,
                        (const float2 *) a->d_comb, (const float2 *) a->d_quart, d_pairs,
-                       a->d_claim + (NQ == 1 ? 0 : 8), w, a->halo, a->d_cells, d_stamps);
+                       a->d_claim + (NQ == 1 ? 0 : 8 * ACQ_CLAIM_STRIDE), w, a->halo, a->d_cells, d_stamps);
 }
 
 extern "C" {
@@ -1889,12 +1892,12 @@ int kg_acq_correlate_blocks_async(kg_acq *a, int first, int nblocks, const int *
                 hipLaunchKernelGGL(acq_correlate8_kernel<4>, dim3(a->grid8), dim3(512), ACQ8_LDS_BYTES, st,
                                    (const float2 *) (a->d_data_b + (size_t) first * a->fft_len), (const float2 *) a->d_code,
                                    (const float2 *) a->ctx->d_tab4096, (const float2 *) a->d_tabN, (const float2 *) a->d_comb8,
-                                   (const float2 *) a->d_quart, a->d_pairs4, a->d_claim + 8, w, a->halo, a->d_cells);
+                                   (const float2 *) a->d_quart, a->d_pairs4, a->d_claim + 8 * ACQ_CLAIM_STRIDE, w, a->halo, a->d_cells);
             else
                 hipLaunchKernelGGL(acq_correlate8_kernel<16>, dim3(a->grid8), dim3(512), ACQ8_LDS_BYTES, st,
                                    (const float2 *) (a->d_data_b + (size_t) first * a->fft_len), (const float2 *) a->d_code,
                                    (const float2 *) a->ctx->d_tab4096, (const float2 *) a->d_tabN, (const float2 *) a->d_comb8,
-                                   (const float2 *) a->d_quart, a->d_pairs4, a->d_claim + 8, w, a->halo, a->d_cells);
+                                   (const float2 *) a->d_quart, a->d_pairs4, a->d_claim + 8 * ACQ_CLAIM_STRIDE, w, a->halo, a->d_cells);
         } else if (a->P == 4) launch_correlate<4, 4, false>(a, st, first, a->d_pairs4, a->np4, nullptr);
         else launch_correlate<16, 4, false>(a, st, first, a->d_pairs4, a->np4, nullptr);
         KG_HIP(hipGetLastError());
@@ -1953,7 +1956,7 @@ int kg_acq_debug_corr_stamps(kg_acq *a, int nblocks, const int *sats, int nsats,
         const size_t bytes = sizeof(unsigned long long) * (512 + 4 * 1024);
         KG_HIP(hipMalloc((void **) &d, bytes));
         KG_HIP(hipMemset(d, 0, bytes));
-        KG_HIP(hipMemsetAsync(a->d_claim, 0, sizeof(int) * 16, st));
+        KG_HIP(hipMemsetAsync(a->d_claim, 0, sizeof(int) * 16 * ACQ_CLAIM_STRIDE, st));
         const acq_walk w = {a->np4, a->ndop, a->dop_lo};
         if (a->P == 4) {
             KG_HIP(hipFuncSetAttribute((const void *) acq_correlate8_kernel<4, true>,
@@ -1961,17 +1964,17 @@ int kg_acq_debug_corr_stamps(kg_acq *a, int nblocks, const int *sats, int nsats,
             hipLaunchKernelGGL((acq_correlate8_kernel<4, true>), dim3(a->grid8), dim3(512), ACQ8_LDS_BYTES, st,
                                (const float2 *) a->d_data_b, (const float2 *) a->d_code, (const float2 *) a->ctx->d_tab4096,
                                (const float2 *) a->d_tabN, (const float2 *) a->d_comb8, (const float2 *) a->d_quart,
-                               a->d_pairs4, a->d_claim + 8, w, a->halo, a->d_cells, d);
+                               a->d_pairs4, a->d_claim + 8 * ACQ_CLAIM_STRIDE, w, a->halo, a->d_cells, d);
         } else {
             KG_HIP(hipFuncSetAttribute((const void *) acq_correlate8_kernel<16, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, ACQ8_LDS_BYTES));
             hipLaunchKernelGGL((acq_correlate8_kernel<16, true>), dim3(a->grid8), dim3(512), ACQ8_LDS_BYTES, st,
                                (const float2 *) a->d_data_b, (const float2 *) a->d_code, (const float2 *) a->ctx->d_tab4096,
                                (const float2 *) a->d_tabN, (const float2 *) a->d_comb8, (const float2 *) a->d_quart,
-                               a->d_pairs4, a->d_claim + 8, w, a->halo, a->d_cells, d);
+                               a->d_pairs4, a->d_claim + 8 * ACQ_CLAIM_STRIDE, w, a->halo, a->d_cells, d);
         }
         KG_HIP(hipGetLastError());
-        KG_HIP(hipMemsetAsync(a->d_claim, 0, sizeof(int) * 16, st));
+        KG_HIP(hipMemsetAsync(a->d_claim, 0, sizeof(int) * 16 * ACQ_CLAIM_STRIDE, st));
         KG_HIP(hipStreamSynchronize(st));
         KG_HIP(hipMemcpy(stamps, d, bytes, hipMemcpyDeviceToHost));
         KG_HIP(hipFree(d));
@@ -1983,7 +1986,7 @@ int kg_acq_debug_corr_stamps(kg_acq *a, int nblocks, const int *sats, int nsats,
     KG_REQUIRE(a->grid1 <= 1024, KG_ERR_STATE, "kg_acq_debug_corr_stamps: grid %d", a->grid1);
     KG_HIP(hipMalloc((void **) &d, bytes));
     KG_HIP(hipMemset(d, 0, bytes));
-    KG_HIP(hipMemsetAsync(a->d_claim, 0, sizeof(int) * 16, st));
+    KG_HIP(hipMemsetAsync(a->d_claim, 0, sizeof(int) * 16 * ACQ_CLAIM_STRIDE, st));
     if (a->P == 4) {
         KG_HIP(hipFuncSetAttribute((const void *) acq_correlate_kernel<4, 1, true, true>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, ACQ_LDS_BYTES));
@@ -1994,7 +1997,7 @@ int kg_acq_debug_corr_stamps(kg_acq *a, int nblocks, const int *sats, int nsats,
         launch_correlate<16, 1, true>(a, st, 0, a->d_pairs1, a->np1, d);
     }
     KG_HIP(hipGetLastError());
-    KG_HIP(hipMemsetAsync(a->d_claim, 0, sizeof(int) * 16, st));
+    KG_HIP(hipMemsetAsync(a->d_claim, 0, sizeof(int) * 16 * ACQ_CLAIM_STRIDE, st));
     KG_HIP(hipStreamSynchronize(st));
     KG_HIP(hipMemcpy(stamps, d, bytes, hipMemcpyDeviceToHost));
     KG_HIP(hipFree(d));

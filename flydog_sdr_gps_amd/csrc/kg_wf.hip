@@ -49,7 +49,11 @@ struct wf_chan_dev {
     float scale[WF_WIDTH];              // what the dB stage multiplies by (WF_CMA: already divided by the run length)
 };
 
+#ifndef WF_PERSIST
+#define WF_PERSIST 16     // window rows (of 16) a thread keeps from frame to frame
+#endif
 #define WF_TABLE_WAYS 8
+#define WF_CLAIM_STRIDE 32      // ints between the frame-claim counters (a 128-byte line each): eight groups + the exit count
 #define WF_LDS_BYTES (2 * SUB * sizeof(float2) + 240 * sizeof(float2) + 16)       // + pass-1 twiddles + the claimed frame index
 
 template <bool TAPS>
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
     const float2 *__restrict__ tab4096, const float2 *__restrict__ tab8192,
     int nframes,
     unsigned char *__restrict__ out,          // [nframes][1024]
-    int *__restrict__ claim,                  // [2]: frames handed out beyond the first two per workgroup; workgroups done
+    int *__restrict__ claim,                  // [9][WF_CLAIM_STRIDE]: per group, frames handed out beyond the first two per workgroup; [8]: workgroups done
     float *__restrict__ tap_pwr, float *__restrict__ tap_pwr_out, float *__restrict__ tap_db)
 {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
@@ -81,22 +85,35 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
     // combine twiddle W_8192^{k}, k = t + 256 m: W_8192^{t} (per thread) * W_32^{m} (immediate)
     const cf wbase = kg_ld(&tab8192[t]);
 
-    // A frame is read in two passes of sixteen 4-byte loads per thread: the even samples (n = 2*n1) for
-    // the first 4096-point transform, then the odd ones -- the same 128-byte lines, by then in L2 -- for
-    // the second, into the same sixteen registers; and once the second transform's inputs are formed
-    // the next frame's even samples land there while the rest of this frame is computed.  The frame
-    // fetch is the kernel's one HBM access: at the top of the loop its whole latency was exposed.
+    // A frame is read as sixteen 8-byte loads per thread (samples 2 n1 and 2 n1 + 1, n1 = t + 256 j: the even ones feed the
+    // first 4096-point transform, the odd ones the second) into registers the previous frame has just consumed, a frame
+    // ahead: the frame fetch is the kernel's one HBM access, and at the top of the loop its whole latency was exposed.
+    // All three streams -- frame, window, CIC factors -- are buffer loads: a scalar descriptor per stream, one lane offset
+    // (8 t), the row as an immediate / scalar offset.
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
     int2 raw[16];
+    const int vo8 = t * 8;
+    auto ld8 = [&](__amdgpu_buffer_rsrc_t rs, int row) {
+        const u2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, vo8, row * 2048, 0);
+        return v;
+    };
+    auto frame_rsrc = [&](int off2) {
+        return __builtin_amdgcn_make_buffer_rsrc((void *) ((const int2 *) iq + (size_t) (unsigned) off2), 0, WF_NFFT * 4, 0x00020000);
+    };
+    auto window_rsrc = [&](int wfn) {
+        return __builtin_amdgcn_make_buffer_rsrc((void *) (windows + (size_t) wfn * WF_NFFT), 0, WF_NFFT * 4, 0x00020000);
+    };
     auto fetch = [&](int off2) {
-        const int2 *src = (const int2 *) iq + (size_t) (unsigned) off2;
+        const __amdgpu_buffer_rsrc_t rs = frame_rsrc(off2);
 #pragma unroll
-        for (int j = 0; j < 16; j++) raw[j] = src[t + 256 * j];         // samples 2 n1 (even) and 2 n1 + 1 (odd), n1 = t + 256 j
+        for (int j = 0; j < 16; j++) { const u2 v = ld8(rs, j); raw[j] = int2{(int) v[0], (int) v[1]}; }   // samples 2 n1 (even), 2 n1 + 1 (odd), n1 = t + 256 j
     };
     // window values of this thread's thirty-two samples (8-byte loads, L1 / L2 hits)
     float2 wv[16];
-    auto fetch_window = [&](const float *win) {
+    auto fetch_window = [&](int wfn) {
+        const __amdgpu_buffer_rsrc_t rs = window_rsrc(wfn);
 #pragma unroll
-        for (int j = 0; j < 16; j++) wv[j] = ((const float2 *) win)[t + 256 * j];
+        for (int j = 0; j < 16; j++) { const u2 v = ld8(rs, j); wv[j] = float2{__uint_as_float(v[0]), __uint_as_float(v[1])}; }
     };
     auto windowed = [&](cf (&x)[16], int g) {
         // sample_wf(): fi = (float)(s2_t)i * window[sn]  (:1054-1061)
@@ -118,13 +135,28 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
     // arbitration), so equal static shares leave CUs half empty at the end.  The frame after next is
     // claimed at the top of a frame and crosses the workgroup through LDS at the power-stage barrier.
     // The last workgroup to leave resets the two counters for the next launch.
+    // Round 4: EIGHT claim counters, one per group of workgroups (blockIdx % 8: the workgroups of one XCD), each handing out the
+    // frames f = 8 k + g of its group.  One counter for the whole chip was the kernel's floor: 28 672 agent-scope atomics on
+    // one address take 0.36 ms whatever the frames cost (knock-out builds without butterflies, without tile traffic, without
+    // the frame fetch all ran 0.363 ms; tools/ko_wf.sh).  A grid that is not a multiple of eight (a short list)
+    // keeps one group.
+    const int cng = (gridDim.x & 7) == 0 ? 8 : 1, cg = blockIdx.x & (cng - 1);
     int f = blockIdx.x, fn = blockIdx.x + gridDim.x;
     int cid;                                  // grid <= nframes: every workgroup has a first frame
     { const int2 fr = frames[f]; cid = fr.x; fetch(fr.y); }
     // the record of the frame after this one is fetched a frame ahead (at the bottom of the loop, as soon as its
     // index is known): at the top of a frame it would be a scalar-cache round trip with nothing to hide behind
     int2 fr_next = frames[fn < nframes ? fn : f];
-    fetch_window(windows + (size_t) chans[cid].window_func * WF_NFFT);
+    // Round 4: a thread's thirty-two window values are the same for every frame of a window function, and the channels of a
+    // receiver nearly always share one (the client's default): they stay in their registers from frame to frame and are
+    // re-read only when the next frame's channel uses another window (a wave-uniform branch around the loads; the
+    // conservative wait counts the compiler merges at its join only cost the frames that do reload).
+    int wfn_cur = chans[cid].window_func;
+    fetch_window(wfn_cur);
+    // ... and so are the sixteen CIC compensation factors of its bins (one table, applied or not per channel; a zoomed channel
+    // reads the lower eight only): kept while the next frame wants the same ones
+    float cicv[16];
+    int cic_have = -1;                        // -1 nothing, else comp_on * 2 + (all sixteen loaded)
     for (;;) {
         const wf_chan_dev *ch = chans + cid;
         const int interp = ch->interp, dc = ch->dc, comp_on = ch->comp_on;
@@ -139,7 +171,9 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
         // right behind the atomic, an s_waitcnt vmcnt(0) at the top of the frame that made wave 0 reach the first
         // exchange barrier a memory round trip late, with the other three waiting there.)
         int claimed = 0;
-        if (t == 0) claimed = __hip_atomic_fetch_add(&claim[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if KG_WF_KO != 7
+        if (t == 0) claimed = __hip_atomic_fetch_add(&claim[cg * WF_CLAIM_STRIDE], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 
         cf x[16], y0[16], y1[16];
         windowed(x, 0);
@@ -147,30 +181,55 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
         // (the next frame's record was requested at the bottom of the previous frame; read here, not at the top of the
         // frame, where the dependent load of its channel's window number made every wave wait for it before its first
         // instruction of arithmetic)
+        // (the compiler otherwise sinks half of the last butterflies of y0 to their use in the combine stage and keeps their
+        // inputs AND the other half alive through the whole second transform: 46 registers instead of 32)
+#pragma unroll
+        for (int m = 0; m < 16; m++) asm volatile("" : "+v"(y0[m]));
         kg_pin();
         const int cid_next = fr_next.x;
         const int wfn_next = chans[cid_next].window_func;
+        const bool rewin = wfn_next != wfn_cur;
+        wfn_cur = wfn_next;
         kg_pin();
         windowed(x, 1);
-        // Everything the second transform's duration can hide is requested DURING it, five loads at each of eight
-        // points (kg_subfft4096_l_h): the next frame (both parities, into the registers just consumed; the last frame
-        // of a workgroup re-reads its own: one load site, never skipped -- a conditional one makes the compiler
-        // drain vmcnt at the join), this frame's CIC compensation factors (1.0f = the table's second half where the
-        // frame is not compensated: x * 1.0f is exact) and the next frame's window values.  As three bursts of 16,
-        // 8 and 16 loads from four waves at once they queued behind each other in the CU's one texture addresser
-        // (a load costs it about twenty cycles; the same finding as in acq_correlate8_kernel).
-        float cicv[16];
+        // Everything the second transform's duration can hide is requested DURING it, at eight points (kg_subfft4096_l_h):
+        // in its first half the next frame's window values IF they are not the ones held, in its second half -- where the
+        // pass-1 twiddles' registers are free -- the next frame (both parities, into the registers just consumed; the last
+        // frame of a workgroup re-reads its own: one load site, never skipped -- a conditional one makes the compiler drain
+        // vmcnt at the join) and this frame's CIC compensation factors (1.0f = the table's second half where the frame is not
+        // compensated: x * 1.0f is exact) IF they are not the ones held.  As bursts from four waves at once the loads
+        // queued behind each other in the CU's one texture addresser (the same finding as in acq_correlate8_kernel,
+        // DESIGN.md 2.6).
+        const int con = comp_on ? 1 : 0, cic_want = con * 2 + (half ? 0 : 1);
+        const bool recic = (cic_have >> 1) != con || (!half && !(cic_have & 1));
+        if (recic) cic_have = cic_want;
         {
-            const int2 *nsrc = (const int2 *) iq + (size_t) (unsigned) fr_next.y;
-            const float2 *cp = (const float2 *) cic_comp + (comp_on ? 0 : 2048) + t;
-            const float2 *nwin = (const float2 *) (windows + (size_t) wfn_next * WF_NFFT);
+            const __amdgpu_buffer_rsrc_t nsrc = frame_rsrc(fr_next.y);
+            const __amdgpu_buffer_rsrc_t nwin = window_rsrc(wfn_next);
+            const __amdgpu_buffer_rsrc_t cp = __builtin_amdgcn_make_buffer_rsrc(
+                (void *) ((const float2 *) cic_comp + (comp_on ? 0 : 2048)), 0, 2048 * 8, 0x00020000);
             kg_subfft4096_l_h<-1>(x, y1, tileA, tileB, tw1, p2, t, [&](int k) {
                 kg_pin();
-                raw[2 * k] = nsrc[t + 256 * (2 * k)];
-                raw[2 * k + 1] = nsrc[t + 256 * (2 * k + 1)];
-                if (k < 4 || !half) { const float2 v = cp[256 * k]; cicv[2 * k] = v.x; cicv[2 * k + 1] = v.y; }
-                wv[2 * k] = nwin[t + 256 * (2 * k)];
-                wv[2 * k + 1] = nwin[t + 256 * (2 * k + 1)];
+                if (k < 4) {
+                    if (k < WF_PERSIST / 4) {
+                        if (rewin) {
+#pragma unroll
+                            for (int j = 4 * k; j < 4 * k + 4; j++) { const u2 v = ld8(nwin, j); wv[j] = float2{__uint_as_float(v[0]), __uint_as_float(v[1])}; }
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 4 * k; j < 4 * k + 4; j++) { const u2 v = ld8(nwin, j); wv[j] = float2{__uint_as_float(v[0]), __uint_as_float(v[1])}; }
+                    }
+                } else {
+                    const int q = k - 4;
+#if KG_WF_KO != 4
+#pragma unroll
+                    for (int j = 4 * q; j < 4 * q + 4; j++) { const u2 v = ld8(nsrc, j); raw[j] = int2{(int) v[0], (int) v[1]}; }
+#endif
+#pragma unroll
+                    for (int j = 2 * q; j < 2 * q + 2; j++)
+                        if (recic && (j < 4 || !half)) { const u2 v = ld8(cp, j); cicv[2 * j] = __uint_as_float(v[0]); cicv[2 * j + 1] = __uint_as_float(v[1]); }
+                }
                 kg_pin();
             });
         }
@@ -206,10 +265,19 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
                 if (TAPS && k < ch->fft_used) tap_pwr[(size_t) f * SUB + k] = p;
             }
         };
+#if KG_WF_KO != 6
         combine_power(std::integral_constant<int, 0>());
         if (!half) combine_power(std::integral_constant<int, 8>());
+#else
+#pragma unroll
+        for (int m = 0; m < 16; m++) asm volatile("" :: "v"(y0[m]), "v"(y1[m]), "v"(cicv[m]));
+#endif
 #undef WF_W32
-        if (t == 0) *lds_claim = 2 * gridDim.x + claimed;
+#if KG_WF_KO != 7
+        if (t == 0) *lds_claim = 2 * gridDim.x + cng * claimed + cg;
+#else
+        if (t == 0) *lds_claim = fn + gridDim.x + claimed;
+#endif
         __syncthreads();
         const int fnn = __builtin_amdgcn_readfirstlane(*lds_claim);    // wave-uniform; rewritten after >= 6 barriers
         cid = cid_next;
@@ -219,11 +287,19 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
         // predicated: no divergent loops, the four pixels of a thread advance together, and every
         // pixel still sees its bins in ascending order (same result as the serial :1458-1478 loop).
         float pp[4] = {0.f, 0.f, 0.f, 0.f};   // memset(pwr_out, 0), :1385
+#if KG_WF_KO == 5
+        if (interp == 77) {
+#else
         if (interp == WF_DROP) {
+#endif
 #pragma unroll
             for (int u = 0; u < 4; u++)
                 if (4 * t + u < pwc) pp[u] = pwr[pfirst[u]];                            // :1418
+#if KG_WF_KO == 5
+        } else if (interp == 78) {
+#else
         } else {
+#endif
             // (DPP reduce: six dependent ds_bpermute round trips per frame otherwise)
             const int cmax = kg_wave_max(max(max(pcount[0], pcount[1]), max(pcount[2], pcount[3])));
 #pragma unroll
@@ -283,10 +359,9 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
         f = fn; fn = fnn;
     }
     if (t == 0) {
-        const int done = __hip_atomic_fetch_add(&claim[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int done = __hip_atomic_fetch_add(&claim[8 * WF_CLAIM_STRIDE], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (done == (int) gridDim.x - 1) {    // every other workgroup has made its last claim
-            __hip_atomic_store(&claim[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&claim[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int g = 0; g <= 8; g++) __hip_atomic_store(&claim[g * WF_CLAIM_STRIDE], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -302,7 +377,7 @@ struct kg_wf {
     int chan_of_victim;
     std::vector<int2> frame_tab;
     float *d_tap_pwr, *d_tap_pwr_out, *d_tap_db;
-    int *d_claim;                             // wf_frame_kernel's two counters, zero between launches
+    int *d_claim;                             // the frame kernels' claim counters, zero between launches
     std::vector<char> chan_set;
     bool tables_set;
     int grid;
@@ -326,8 +401,8 @@ int kg_wf_create(kg_ctx *ctx, int nchan, kg_wf **out)
     KG_HIP(hipMalloc((void **) &w->d_chans, sizeof(wf_chan_dev) * nchan));
     KG_HIP(hipMalloc((void **) &w->d_windows, sizeof(float) * 4 * WF_NFFT));
     KG_HIP(hipMalloc((void **) &w->d_cic, sizeof(float) * WF_NFFT));
-    KG_HIP(hipMalloc((void **) &w->d_claim, sizeof(int) * 2));
-    KG_HIP(hipMemset(w->d_claim, 0, sizeof(int) * 2));
+    KG_HIP(hipMalloc((void **) &w->d_claim, sizeof(int) * 9 * WF_CLAIM_STRIDE));
+    KG_HIP(hipMemset(w->d_claim, 0, sizeof(int) * 9 * WF_CLAIM_STRIDE));
     KG_HIP(hipFuncSetAttribute((const void *) wf_frame_kernel<false>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS_BYTES));
     KG_HIP(hipFuncSetAttribute((const void *) wf_frame_kernel<true>,

@@ -176,6 +176,37 @@ def test_batch_of_frames_over_mixed_channels(engine, oracle, tables):
         check_row(out[k], w_out, w_dB, db_bound(w_po))
 
 
+def test_long_list_with_windows_and_compensation_changing(engine, oracle, tables):
+    """A workgroup keeps its window values and CIC factors in registers from frame to frame and re-reads them only when the
+    next frame's channel wants others (round 4).  1 600 frames -- three and more per workgroup -- over six channels that
+    differ in window function, in compensation on / off and in zoom 0 (all sixteen factor rows) against zoomed (eight), in a
+    random order: every row against the oracle for ITS channel."""
+    cfgs = [(0, wf.WINF_HANNING, True), (5, wf.WINF_HAMMING, True), (3, wf.WINF_HANNING, False),
+            (0, wf.WINF_BLACKMAN_HARRIS, False), (9, wf.WINF_NONE, True), (1, wf.WINF_HANNING, True)]
+    ps = []
+    for ch, (z, wfn, comp) in enumerate(cfgs):
+        p = WfParams.for_zoom(z, 1.5e6 * ch)
+        ps.append(p)
+        engine.set_channel(ch, p, interp=wf.WF_MAX, window_func=wfn, cic_comp=comp)
+    niq = 12
+    iqs = [synth.wf_iq_frame(seed=4100 + i) for i in range(niq)]
+    rng = np.random.default_rng(2024)
+    n = 1600
+    chan_of = rng.integers(0, len(cfgs), n)
+    chan_of[:40] = 0                         # a run without any change, then changes of every kind
+    chan_of[40:80] = np.tile([0, 5], 20)     # same window, same compensation, 16 rows <-> 8 rows... both zoom 0 / 1
+    which = rng.integers(0, niq, n)
+    out = engine.frames([int(c) for c in chan_of], np.stack([iqs[i] for i in which]))
+    want = {}
+    for k in range(n):
+        key = (int(chan_of[k]), int(which[k]))
+        if key not in want:
+            z, wfn, comp = cfgs[key[0]]
+            want[key] = oracle_frame(oracle, tables, iqs[key[1]], ps[key[0]], wf.WF_MAX, wfn, comp, False, False)
+        w_out, _, w_po, w_dB = want[key]
+        check_row(out[k], w_out, w_dB, db_bound(w_po))
+
+
 def test_channel_map_changing_between_calls(engine, oracle, tables):
     """The frame -> channel map of a batch is kept on the device while it does not change
     (kg_stage_cache): same map again, a permuted one of the same length, a longer one, the first one
