@@ -53,6 +53,9 @@ sys.path.insert(0, ROOT)
 # `ddc14` 0.48 and 0.58.  Eight queues make the stream topology the one the code states (measured: tools/ab_rxenv.sh).
 # Read by the runtime when it initialises, i.e. it must be set before anything touches the GPU.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# knock-out builds of a kernel (tools/ko_*.sh: "what is the time sensitive to") produce wrong results by construction: the
+# result checks are skipped and the line says so
+TIMING_EXPERIMENT = os.environ.get("KIWIGPU_BENCH_TIMING_EXPERIMENT", "0") == "1"
 
 NSAMPLES = 65536
 FFT_LEN = 16384
@@ -618,9 +621,9 @@ def run_acq(args, dist, ten_ms=False, all_svs=False):
         sorted(p - 1 for p, *_ in synth.CONFIG1_PRESENT)
     # every injected SV must be found on every rank; an absent SV above the threshold is a noise
     # false alarm of that rank's own seeded block (41 x 4092 trials at MIN_SIG = 16: about 2 % per SV)
-    assert set(expect) <= set(found), "acquisition result wrong: %s lacks %s" % (found, sorted(set(expect) - set(found)))
+    assert TIMING_EXPERIMENT or set(expect) <= set(found), "acquisition result wrong: %s lacks %s" % (found, sorted(set(expect) - set(found)))
     if dist.rank == 0 and not all_svs:
-        assert found == expect, "acquisition result wrong: %s != %s" % (found, expect)
+        assert TIMING_EXPERIMENT or found == expect, "acquisition result wrong: %s != %s" % (found, expect)
 
     n1 = sum(1 for sat in svs if not codes[sat][1])
     n4 = len(svs) - n1
@@ -910,11 +913,6 @@ def native_oracle_note():
 # ------------------------------------------------------------------------------------------------
 # Result checks of the timed workloads: the same objects, right after their timed region, against the oracle
 # ------------------------------------------------------------------------------------------------
-# knock-out builds of a kernel (tools/, DESIGN 6.1: "what is the time sensitive to") produce wrong rows by construction: the
-# row checks are skipped and the line says so
-TIMING_EXPERIMENT = os.environ.get("KIWIGPU_BENCH_TIMING_EXPERIMENT", "0") == "1"
-
-
 def check_wf_rows(cases, interp, window_func=None):
     """cases: [(WfParams, int16 frame [8192][2], the GPU's u8 row)] -> rows checked.  The oracle's sample_wf window +
     compute_frame (rx/rx_waterfall.cpp:1049-1066, 1275-1575) on the same frame; bytes must agree under the rule of

@@ -276,6 +276,72 @@ struct acq_walk {
 // = W_R^{4a k2} * W_R^{b k2}.  comb[k2] = { W_R^{k2}, W_R^{2 k2}, W_R^{3 k2},
 // W_R^{4 k2}, W_R^{8 k2}, W_R^{12 k2}, -, - } (host-built, fp32 roundings of double
 // values); quart[k2][q] = W_P^{q k2}: the factor of output quarter q (NQ = 4).
+// Knock-out builds of the C/A correlator (timing experiments, wrong results by construction: tools/ko_acq.sh):
+// -DACQ_KO=1 no barriers inside the item, 3 no butterflies / products / twiddles, 4 no operand rows of the next item, 8 no
+// tile stores, 9 no tile loads, 10 no twiddle-accumulate, 11 no power / maximum scan.
+#ifndef ACQ_KO
+#define ACQ_KO 0
+#endif
+#if ACQ_KO == 1
+#define ACQ_KO_SYNC() do {} while (0)
+#else
+#define ACQ_KO_SYNC() __syncthreads()
+#endif
+template <class H> KG_DEV void acq_ko_pass16(const cf (&x)[16], cf (&y)[16], H hook)
+{
+#pragma unroll
+    for (int m = 0; m < 16; m++) { y[m] = x[m]; asm volatile("" : "+v"(y[m])); }
+#pragma unroll
+    for (int sgrp = 0; sgrp < 8; sgrp++) hook(sgrp);
+}
+template <class H> KG_DEV void ACQ_KO_CC(const cf (&c)[16], const cf (&d)[16], cf (&y)[16], H hook)
+{
+#if ACQ_KO == 3
+#pragma unroll
+    for (int q = 0; q < 16; q++) asm volatile("" :: "v"(d[q]));
+    acq_ko_pass16(c, y, hook);
+#else
+    kg_cc_radix16_h<+1>(c, d, y, hook);
+#endif
+}
+template <class H> KG_DEV void ACQ_KO_TW(cf (&x)[16], cf (&y)[16], const kg_tw15 &w, H hook)
+{
+#if ACQ_KO == 3
+#pragma unroll
+    for (int q = 0; q < 15; q++) asm volatile("" :: "v"(w.w[q]));
+    acq_ko_pass16(x, y, hook);
+#else
+    kg_tw_radix16_h<+1>(x, y, w, hook);
+#endif
+}
+#if ACQ_KO == 8
+KG_DEV void ACQ_KO_ST(float2 *, cf v) { asm volatile("" :: "v"(v)); }
+#else
+#define ACQ_KO_ST kg_st
+#endif
+#if ACQ_KO == 9
+KG_DEV cf ACQ_KO_LD(const float2 *) { cf v = cf{1.f, 2.f}; asm volatile("" : "+v"(v)); return v; }
+#else
+#define ACQ_KO_LD kg_ld_tile
+#endif
+#if ACQ_KO == 10
+#define ACQ_KO_DEFERRED(slot, k2) do {} while (0)
+#else
+#define ACQ_KO_DEFERRED(slot, k2) deferred(slot, k2)
+#endif
+
+// Round 4: the second exchange without the swizzle (kg_fft.h, kg_subfft4096_l: its writer has the slot column in the lane, its
+// stores and loads are conflict-free as they stand): one address register instead of sixteen.  -DACQ_X2_SWIZZLE=1: as before.
+#ifndef ACQ_X2_SWIZZLE
+#define ACQ_X2_SWIZZLE 0
+#endif
+#if ACQ_X2_SWIZZLE
+#define ACQ_X2_WR(t, th, tl, m) ((th) * 256 + 16 * (m) + ((tl) ^ (m)))
+#define ACQ_X2_RD(t, rd) (rd)
+#else
+#define ACQ_X2_WR(t, th, tl, m) ((t) + 16 * (15 * (th) + (m)))
+#define ACQ_X2_RD(t, rd) (t)
+#endif
 template <int P, int NQ, bool PREFETCH, bool STAMPS = false>   // PREFETCH: always true (kept in the names)
 __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
     const float2 *__restrict__ data,  // [nblocks][P][4096]
@@ -360,11 +426,13 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
         c[2 * i + 1] = cf{__uint_as_float(cv[2]), __uint_as_float(cv[3])};
     };
     auto fetch_drow = [&](const acq_rsrc &r, int i) {
+        if (ACQ_KO == 4) return;
         const u4 dv = __builtin_amdgcn_raw_buffer_load_b128(r.drs, r.dvo, i * 4096, 0);
         d[2 * i] = cf{__uint_as_float(dv[0]), __uint_as_float(dv[1])};
         d[2 * i + 1] = cf{__uint_as_float(dv[2]), __uint_as_float(dv[3])};
     };
     auto fetch_crow = [&](const acq_rsrc &r, int i) {
+        if (ACQ_KO == 4) return;
         const u4 cv = __builtin_amdgcn_raw_buffer_load_b128(r.crs, r.cvo, i * rowb_c, 0);
         c[2 * i] = cf{__uint_as_float(cv[0]), __uint_as_float(cv[1])};
         c[2 * i + 1] = cf{__uint_as_float(cv[2]), __uint_as_float(cv[3])};
@@ -520,14 +588,14 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
             // a time as the operands they overwrite are consumed; the LDS stores group by group as before.
             KG_STAMP(STAMPS, sti, 9);
             KG_STAMP(STAMPS, sti, 10);
-            kg_cc_radix16_h<+1>(c, d, y, [&](int s) {
+            ACQ_KO_CC(c, d, y, [&](int s) {
                 kg_pin();
                 if (s < 4) {
                     if constexpr (NQ == 1) { fetch_drow(nr, 2 * s); fetch_drow(nr, 2 * s + 1); }
                     else { fetch_row(nr, 2 * s); fetch_row(nr, 2 * s + 1); }
                 } else {
 #pragma unroll
-                    for (int m = s - 4; m < 16; m += 4) kg_st(&tileA[16 * t + (m ^ tl)], y[m]);
+                    for (int m = s - 4; m < 16; m += 4) ACQ_KO_ST(&tileA[16 * t + (m ^ tl)], y[m]);
                 }
                 kg_pin();
             });
@@ -554,24 +622,24 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
                     else { fetch_row(nr, 3 + s); if (s == 3) fetch_row(nr, 7); }
                 } else {
 #pragma unroll
-                    for (int m = s - 4; m < 16; m += 4) kg_st(&tileA[16 * t + (m ^ tl)], y[m]);
+                    for (int m = s - 4; m < 16; m += 4) ACQ_KO_ST(&tileA[16 * t + (m ^ tl)], y[m]);
                 }
                 kg_pin();
             });
 #endif
             KG_STAMP(STAMPS, sti, 0);
-            deferred(0, k2);
+            ACQ_KO_DEFERRED(0, k2);
             KG_STAMP(STAMPS, sti, 1);
-            __syncthreads();
+            ACQ_KO_SYNC();
             KG_STAMP(STAMPS, sti, 2);
 #pragma unroll
-            for (int j = 0; j < 16; j++) x[j] = kg_ld_tile(&tileA[rd + 256 * j]);
-            deferred(1, k2);
+            for (int j = 0; j < 16; j++) x[j] = ACQ_KO_LD(&tileA[rd + 256 * j]);
+            ACQ_KO_DEFERRED(1, k2);
             if (STAMPS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             KG_STAMP(STAMPS, sti, 3);
             // pass 1: twiddle W256^(j*(t&15)), out index (t>>4)*256 + (t&15) + 16 m
 #if KG_FUSED_TW
-            kg_tw_radix16_h<+1>(x, y, tw.p1, [&](int s) {
+            ACQ_KO_TW(x, y, tw.p1, [&](int s) {
 #else
             kg_twiddle16<+1>(x, tw.p1);
             kg_radix16_h<+1>(x, y, [&](int s) {
@@ -579,13 +647,13 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
                 if (s >= 4) {
                     kg_pin();
 #pragma unroll
-                    for (int m = s - 4; m < 16; m += 4) kg_st(&tileB[th * 256 + 16 * m + (tl ^ m)], y[m]);
+                    for (int m = s - 4; m < 16; m += 4) ACQ_KO_ST(&tileB[ACQ_X2_WR(t, th, tl, m)], y[m]);
                     kg_pin();
                 }
             });
             KG_STAMP(STAMPS, sti, 4);
-            deferred(2, k2);
-            __syncthreads();
+            ACQ_KO_DEFERRED(2, k2);
+            ACQ_KO_SYNC();
             KG_STAMP(STAMPS, sti, 5);
             // wave-uniform constants (s_load), hidden behind pass 2
             cf g[3], G[3], Q[3];
@@ -597,8 +665,8 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
                 for (int q = 1; q < 4; q++) Q[q - 1] = kg_ld(&quart[4 * k2 + q]);
             }
 #pragma unroll
-            for (int j = 0; j < 16; j++) x[j] = kg_ld_tile(&tileB[rd + 256 * j]);
-            deferred(3, k2);
+            for (int j = 0; j < 16; j++) x[j] = ACQ_KO_LD(&tileB[ACQ_X2_RD(t, rd) + 256 * j]);
+            ACQ_KO_DEFERRED(3, k2);
             if (STAMPS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             KG_STAMP(STAMPS, sti, 6);
             // pass 2: twiddle W4096^(j*t), out index t + 256 m (kept in registers)
@@ -609,7 +677,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
                 }
             };
 #if KG_FUSED_TW
-            kg_tw_radix16_h<+1>(x, yprev, tw.p2, crows);
+            ACQ_KO_TW(x, yprev, tw.p2, crows);
 #else
             kg_twiddle16<+1>(x, tw.p2);
             kg_radix16_h<+1>(x, yprev, crows);
@@ -634,11 +702,16 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
         const int limit = cur.limit, full_rows = limit >> 8;
         float bp = 0.f, sum = 0.f;
         int bi = 0;
-        if constexpr (NQ == 1 && P == 4) {
+        if constexpr (ACQ_KO == 11) {
+#pragma unroll
+            for (int m = 0; m < 16; m++) asm volatile("" :: "v"(acc[0][m]));
+            bp = (float) t; sum = 1.f; bi = t;
+        } else if constexpr (NQ == 1 && P == 4) {
             // the 16368-lag kernel's form of the scan (acq_correlate8_kernel): powers kept, total in packed pairs, maximum
             // by fmax, the lane's FIRST row holding it from a row mask built with a compare and an add-with-carry per row
-            // (acq 0.796 -> 0.789 ms; P = 16 keeps the serial form below: its sixteen more registers of powers spill there,
-            // configs[4] 2.72 -> 2.76 ms)
+            // (acq 0.796 -> 0.789 ms; P = 16 keeps the serial form below: its sixteen more registers of powers spilled there,
+            // configs[4] 2.72 -> 2.76 ms; re-measured in round 4 with the sixteen registers the unswizzled exchange freed: no
+            // spills, 2.66 -> 2.70 .. 2.73 ms)
             float pw[16];
 #pragma unroll
             for (int m = 0; m < 16; m++) {
