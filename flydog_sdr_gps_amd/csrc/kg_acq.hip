@@ -825,6 +825,50 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
 // ---------------------------------------------------------------------------
 #define ACQ8_LDS_BYTES (3 * SUB * sizeof(float2) + 8 * sizeof(acq_red) + 16 + 16 * 8 * sizeof(float2) + 3 * 512 * 4)   // + the per-k2 constants + the cell-end hand-over
 
+// Knock-out builds of the 16368-lag correlator (timing experiments, wrong results by construction: tools/ko_acq.sh acq59 ...):
+// -DE1B_KO=1 no barriers inside the item, 3 no butterflies / products / twiddles, 4 no operand rows of the next item, 8 no tile
+// stores, 9 no tile loads, 10 no twiddle-accumulate.
+#ifndef E1B_KO
+#define E1B_KO 0
+#endif
+#if E1B_KO == 1
+#define E1B_KO_SYNC() do {} while (0)
+#else
+#define E1B_KO_SYNC() __syncthreads()
+#endif
+template <class H> KG_DEV void E1B_KO_CC(const cf (&c)[8], const cf (&d)[8], cf (&y)[8], H hook)
+{
+#if E1B_KO == 3
+#pragma unroll
+    for (int q = 0; q < 8; q++) { asm volatile("" :: "v"(d[q])); y[q] = c[q]; asm volatile("" : "+v"(y[q])); }
+    hook();
+#else
+    kg_cc_radix8_h<+1>(c, d, y, hook);
+#endif
+}
+template <class H> KG_DEV void E1B_KO_TW(cf (&x)[8], cf (&y)[8], const kg_tw7 &w, H hook)
+{
+#if E1B_KO == 3
+#pragma unroll
+    for (int q = 0; q < 7; q++) asm volatile("" :: "v"(w.w[q]));
+#pragma unroll
+    for (int q = 0; q < 8; q++) { y[q] = x[q]; asm volatile("" : "+v"(y[q])); }
+    hook();
+#else
+    kg_tw_radix8_h<+1>(x, y, w, hook);
+#endif
+}
+#if E1B_KO == 8
+KG_DEV void E1B_KO_ST(float2 *, cf v) { asm volatile("" :: "v"(v)); }
+#else
+#define E1B_KO_ST kg_st
+#endif
+#if E1B_KO == 9
+KG_DEV cf E1B_KO_LD(const float2 *) { cf v = cf{1.f, 2.f}; asm volatile("" : "+v"(v)); return v; }
+#else
+#define E1B_KO_LD kg_ld_tile
+#endif
+
 template <int P, bool STAMPS = false>        // STAMPS: diagnostic instantiation only (kg_acq_debug_corr_stamps)
 __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
     const float2 *__restrict__ data, const float2 *__restrict__ code,
@@ -943,15 +987,15 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
     {   // prologue: item 0 of the workgroup's first cell up to tile 1 (passes 0 and 1), operands of item 1 requested
         cf x[8], y[8];
         // (round 4: products and twiddles fused into the butterflies, kg_fft.h)
-        kg_cc_radix8_h<+1>(c, d, y, [&]() { kg_pin(); fetch_item(cur, 1); kg_pin(); });
+        E1B_KO_CC(c, d, y, [&]() { kg_pin(); fetch_item(cur, 1); kg_pin(); });
 #pragma unroll
-        for (int m = 0; m < 8; m++) kg_st(&tile0[8 * i + (m ^ c0)], y[m]);
+        for (int m = 0; m < 8; m++) E1B_KO_ST(&tile0[8 * i + (m ^ c0)], y[m]);
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 8; j++) x[j] = kg_ld_tile(&tile0[r0 + 512 * j]);
+        for (int j = 0; j < 8; j++) x[j] = E1B_KO_LD(&tile0[r0 + 512 * j]);
         kg_tw_radix8<+1>(x, y, tw.p1);
 #pragma unroll
-        for (int m = 0; m < 8; m++) kg_st(&tile1[w1 + 8 * (m ^ b1)], y[m]);
+        for (int m = 0; m < 8; m++) E1B_KO_ST(&tile1[w1 + 8 * (m ^ b1)], y[m]);
         __syncthreads();
     }
 #ifndef KG_E1B_HANDOVER
@@ -1036,41 +1080,41 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
             // 1 600 cycles of a 5 700-cycle item (in-kernel stamps, profiles/r03_e1b8_stamps_burst.txt).
             const acq_rsrc nr = fetch_prepare(k2 + 2 < P ? cur.data_off : nxt.data_off, k2 + 2 < P ? cur.code_off : nxt.code_off,
                                               k2 + 2 < P ? cur.dop : nxt.dop, (k2 + 2) & (P - 1));
-            auto ld = [&](int j) { kg_pin(); fetch_row(nr, j); kg_pin(); };
+            auto ld = [&](int j) { if (E1B_KO == 4) return; kg_pin(); fetch_row(nr, j); kg_pin(); };
             // ---- phase A: pass 2 of this item | conj-multiply + pass 0 of the next
             {
                 cf xa[8], ya[8], xb[8], yb[8];
 #pragma unroll
-                for (int j = 0; j < 8; j++) xa[j] = kg_ld_tile(&tile1[r1 + 512 * j]);
+                for (int j = 0; j < 8; j++) xa[j] = E1B_KO_LD(&tile1[r1 + 512 * j]);
                 // conj(data) * code, simd_multiply_conjugate_ccc (support/simd.cpp:39-67) -- round 4: fused into pass 0's first
                 // stage, as the inter-pass twiddles are into theirs (kg_fft.h: 6 of 42 / 44 packed instructions per pass)
                 (void) xb;
                 KG_STAMP(STAMPS, sti, 1);
-                kg_cc_radix8_h<+1>(c, d, yb, [&]() { ld(0); });
+                E1B_KO_CC(c, d, yb, [&]() { ld(0); });
 #pragma unroll
-                for (int m = 0; m < 8; m++) kg_st(&tile0[8 * i + (m ^ c0)], yb[m]);
+                for (int m = 0; m < 8; m++) E1B_KO_ST(&tile0[8 * i + (m ^ c0)], yb[m]);
                 KG_STAMP(STAMPS, sti, 2);
-                kg_tw_radix8_h<+1>(xa, ya, tw.p2, [&]() { ld(1); });
+                E1B_KO_TW(xa, ya, tw.p2, [&]() { ld(1); });
                 KG_STAMP(STAMPS, sti, 3);
 #pragma unroll
-                for (int m = 0; m < 8; m++) kg_st(&tile2[w2 + 64 * m], ya[m]);
+                for (int m = 0; m < 8; m++) E1B_KO_ST(&tile2[w2 + 64 * m], ya[m]);
                 KG_STAMP(STAMPS, sti, 4);
                 if (STAMPS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 KG_STAMP(STAMPS, sti, 5);
             }
-            __syncthreads();
+            E1B_KO_SYNC();
             KG_STAMP(STAMPS, sti, 6);
             // ---- phase B: pass 3 of this item + accumulate | pass 1 of the next
             cf x[8], y[8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) x[j] = kg_ld_tile(&tile2[i + 512 * j]);
+            for (int j = 0; j < 8; j++) x[j] = E1B_KO_LD(&tile2[i + 512 * j]);
             {
                 cf xb[8], yb[8];
 #pragma unroll
-                for (int j = 0; j < 8; j++) xb[j] = kg_ld_tile(&tile0[r0 + 512 * j]);
-                kg_tw_radix8_h<+1>(xb, yb, tw.p1, [&]() { ld(2); });
+                for (int j = 0; j < 8; j++) xb[j] = E1B_KO_LD(&tile0[r0 + 512 * j]);
+                E1B_KO_TW(xb, yb, tw.p1, [&]() { ld(2); });
 #pragma unroll
-                for (int m = 0; m < 8; m++) kg_st(&tile1[w1 + 8 * (m ^ b1)], yb[m]);
+                for (int m = 0; m < 8; m++) E1B_KO_ST(&tile1[w1 + 8 * (m ^ b1)], yb[m]);
             }
             KG_STAMP(STAMPS, sti, 7);
             // this item's constants (broadcast LDS reads, in order with the tile reads)
@@ -1083,8 +1127,11 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
 #pragma unroll
                 for (int q = 1; q < 4; q++) Q[q - 1] = kg_ld_tile(&cst[8 * k2 + 3 + q]);
             }
-            kg_tw_radix8_h<+1>(x, y, tw.p3, [&]() { ld(3); });       // y[m]: the sub-transform at n = i + 512 m
-            if (k2 == 0) {
+            E1B_KO_TW(x, y, tw.p3, [&]() { ld(3); });       // y[m]: the sub-transform at n = i + 512 m
+            if (E1B_KO == 10 && k2 != 0) {
+#pragma unroll
+                for (int m = 0; m < 8; m++) asm volatile("" :: "v"(y[m]));
+            } else if (k2 == 0) {
 #pragma unroll
                 for (int q = 0; q < 4; q++)
 #pragma unroll
@@ -1132,7 +1179,7 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
             KG_STAMP(STAMPS, sti, 8);
             if (STAMPS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             KG_STAMP(STAMPS, sti, 9);
-            if (k2 < P - 1) __syncthreads();                   // (the last item's phase B is closed by the cell-end barrier)
+            if (k2 < P - 1) E1B_KO_SYNC();                   // (the last item's phase B is closed by the cell-end barrier)
             KG_STAMP(STAMPS, sti, 10);
             if (STAMPS) st_item++;
         }

@@ -117,9 +117,173 @@ DDC_DEV int mix24(int adc, int dds)
 #define DDC_STAGE_ROW (DDC_STAGE_STROBES + 1)    // words per lane row of a staging tile (odd stride: conflict-free)
 #define DDC_STAGE_BYTES ((DDC_THREADS / 64) * 2 * 64 * DDC_STAGE_ROW * 4)
 
-// Passes A and B.  grid = (ceil(nruns / 256), nchan).
+// The scan's arithmetic.  Nothing above bit 88 of an integrator is ever read, so the scan keeps a state as 4 x 96
+// bits in 32-bit limbs (the stored form stays 128 bits wide, upper limb zero): a product with a coefficient is
+// 3 / 5 / 6 multiply-adds of 32 x 32 -> 64 bits (the run length and its binomials have 1-2 / 2 / 3 limbs) where
+// the 128 x 128-bit product took some forty-five instructions, and a state crosses lanes in 12 shuffles, not 32.
+struct u96 { u32 w[3]; };
+struct sc4 { u96 i[4]; };                     // integrators 1..4, mod 2^96
+struct sc_coef { u64 L, c2; u96 c3; };        // len, len (len+1) / 2 (exact: len < 2^32, asserted where the table is built), len (len+1) (len+2) / 6 mod 2^96
+DDC_DEV u96 u96_zero() { u96 r; r.w[0] = r.w[1] = r.w[2] = 0; return r; }
+DDC_DEV u96 u96_of(const u128 &v) { u96 r; r.w[0] = (u32) v.lo; r.w[1] = (u32) (v.lo >> 32); r.w[2] = (u32) v.hi; return r; }
+DDC_DEV u128 u128_of(const u96 &v) { return mk128((u64) v.w[0] | ((u64) v.w[1] << 32), (u64) v.w[2]); }
+DDC_DEV u96 add96(const u96 &a, const u96 &b)
+{
+    u96 r; unsigned c0, c1;
+    r.w[0] = __builtin_addc(a.w[0], b.w[0], 0u, &c0);
+    r.w[1] = __builtin_addc(a.w[1], b.w[1], c0, &c1);
+    r.w[2] = a.w[2] + b.w[2] + c1;
+    return r;
+}
+DDC_DEV u96 mul96_64(const u96 &a, u64 b)      // a * b mod 2^96
+{
+    const u32 b0 = (u32) b, b1 = (u32) (b >> 32);
+    const u64 p0 = (u64) a.w[0] * b0;
+    const u64 p1 = (u64) a.w[1] * b0 + (p0 >> 32);
+    const u64 q0 = (u64) a.w[0] * b1 + (u32) p1;
+    u96 r;
+    r.w[0] = (u32) p0;
+    r.w[1] = (u32) q0;
+    r.w[2] = a.w[2] * b0 + a.w[1] * b1 + (u32) (p1 >> 32) + (u32) (q0 >> 32);
+    return r;
+}
+DDC_DEV u96 mul96_96(const u96 &a, const u96 &b)
+{
+    u96 r = mul96_64(a, (u64) b.w[0] | ((u64) b.w[1] << 32));
+    r.w[2] += a.w[0] * b.w[2];
+    return r;
+}
+DDC_DEV sc_coef sc_coef_for(u64 len)
+{
+    sc_coef c;
+    c.L = len; c.c2 = binom2(len).lo; c.c3 = u96_of(binom3(len));
+    return c;
+}
+DDC_DEV sc4 sc_zero() { sc4 r; for (int k = 0; k < 4; k++) r.i[k] = u96_zero(); return r; }
+DDC_DEV sc4 sc_of(const ddc_state4 &s) { sc4 r; for (int k = 0; k < 4; k++) r.i[k] = u96_of(s.i[k]); return r; }
+DDC_DEV ddc_state4 state_of(const sc4 &s) { ddc_state4 r; for (int k = 0; k < 4; k++) r.i[k] = u128_of(s.i[k]); return r; }
+// advance a state over len zero-input samples: the binomial matrix of the four cascaded integrators
+DDC_DEV sc4 sc_Tc(const sc_coef &k, const sc4 &s)
+{
+    sc4 r;
+    r.i[0] = s.i[0];
+    r.i[1] = add96(s.i[1], mul96_64(s.i[0], k.L));
+    r.i[2] = add96(add96(s.i[2], mul96_64(s.i[1], k.L)), mul96_64(s.i[0], k.c2));
+    r.i[3] = add96(add96(add96(s.i[3], mul96_64(s.i[2], k.L)), mul96_64(s.i[1], k.c2)), mul96_96(s.i[0], k.c3));
+    return r;
+}
+DDC_DEV sc4 sc_T(u64 len, const sc4 &s) { return sc_Tc(sc_coef_for(len), s); }
+// The lengths the scan's log steps advance a state by are the same in every lane but a few: u << k (u = the samples
+// of a full lane's runs: steps of the wave scan, then of the fold over the wave totals) and v << m (v = a full
+// chunk).  Their coefficients come from the host in the kernel arguments (scalar registers); a lane whose length
+// is another one (the ragged end of the last chunk) computes its own -- the binomials are 40 % of an advance.
+#define DDC_SCAN_TAB 13
+struct sc_tab { u64 len[DDC_SCAN_TAB]; sc_coef c[DDC_SCAN_TAB]; };
+DDC_DEV sc4 sc_T_tab(const sc_tab &t, int j, u64 len, const sc4 &s)
+{
+    if (len == t.len[j]) return sc_Tc(t.c[j], s);
+    return sc_T(len, s);
+}
+DDC_DEV sc4 sc_add(const sc4 &a, const sc4 &b) { sc4 r; for (int k = 0; k < 4; k++) r.i[k] = add96(a.i[k], b.i[k]); return r; }
+DDC_DEV sc4 sc_shfl(const sc4 &s, int src)
+{
+    sc4 r;
+    for (int k = 0; k < 4; k++) for (int w = 0; w < 3; w++) r.i[k].w[w] = __shfl(s.i[k].w[w], src);
+    return r;
+}
+DDC_DEV sc4 sc_shfl_up(const sc4 &s, int d)
+{
+    sc4 r;
+    for (int k = 0; k < 4; k++) for (int w = 0; w < 3; w++) r.i[k].w[w] = __shfl_up(s.i[k].w[w], d);
+    return r;
+}
+
+// Round 4: END-REFERRED states.  T(a) T(b) = T(a + b) for every integer a, b (the binomial matrix of the cascaded
+// integrators), so the state a run starts from, sum over the earlier runs j of T(s0 - s1_j) e_j + T(s0) S_0, is
+// T(-(n - s0)) [ sum_j T(n - s1_j) e_j + T(n) S_0 ]: pass A advances its zero-state result to the END of the entry's share
+// of the block (one advance per run, in the pass that has 17 instructions per sample to hide it in), the carry scan is a
+// plain prefix SUM of 96-bit words -- no multiplications, no lengths -- and pass B takes its start state back from the end
+// (one inverse advance per run); the state after the block is the sum itself.  A sum can be taken in levels wherever the
+// values happen to be: inside pass A's workgroups, then over the workgroup totals (ddc_wf_run_kernel, ddc_wf_scan_wg_kernel)
+// -- where the affine scan was a kernel of its own between the passes, 36 us alone and 57 us beside the bypass kernel (a
+// chunked prefix-sum kernel in its place measured the same 36: waiting on other workgroups, not the multiplications, was
+// its cost).
+DDC_DEV u96 sub96(const u96 &a, const u96 &b)
+{
+    u96 r; unsigned c0, c1;
+    r.w[0] = __builtin_subc(a.w[0], b.w[0], 0u, &c0);
+    r.w[1] = __builtin_subc(a.w[1], b.w[1], c0, &c1);
+    r.w[2] = a.w[2] - b.w[2] - c1;
+    return r;
+}
+// T(-m): the coefficients of T(len) at len = -m are -m, m (m - 1) / 2, -m (m - 1) (m - 2) / 6  (m < 2^32)
+DDC_DEV sc4 sc_Tinv(u64 m, const sc4 &s)
+{
+    if (m == 0) return s;
+    const u64 c2 = binom2(m - 1).lo;
+    const u96 c3 = m >= 2 ? u96_of(binom3(m - 2)) : u96_zero();
+    sc4 r;
+    r.i[0] = s.i[0];
+    r.i[1] = sub96(s.i[1], mul96_64(s.i[0], m));
+    r.i[2] = add96(sub96(s.i[2], mul96_64(s.i[1], m)), mul96_64(s.i[0], c2));
+    r.i[3] = sub96(add96(sub96(s.i[3], mul96_64(s.i[2], m)), mul96_64(s.i[1], c2)), mul96_96(s.i[0], c3));
+    return r;
+}
+DDC_DEV sc4 sc_Tinv_c(u64 m, u64 c2, const u96 &c3, const sc4 &s)
+{
+    sc4 r;
+    r.i[0] = s.i[0];
+    r.i[1] = sub96(s.i[1], mul96_64(s.i[0], m));
+    r.i[2] = add96(sub96(s.i[2], mul96_64(s.i[1], m)), mul96_64(s.i[0], c2));
+    r.i[3] = sub96(add96(sub96(s.i[3], mul96_64(s.i[2], m)), mul96_64(s.i[1], c2)), mul96_96(s.i[0], c3));
+    return r;
+}
+// The distances to the end are the same for every channel that takes the whole block: n - k L, k = 0 .. nruns (run r ends
+// at k = r + 1, starts at k = r).  Their coefficients -- 40 % of an advance, 128-bit products -- come from a table built
+// once per (n, L) (ddc_endco_kernel; a steady stream of equal blocks builds it once); an entry with another share of the
+// block (a capture) computes its own.
+struct ddc_endco { u64 m, c2, c2i; u96 c3, c3i; u32 pad[2]; };        // T(m): m, c2, c3;  T(-m): -m, c2i, -c3i
+DDC_DEV ddc_state4 ddc_to_end(const ddc_state4 &e, u64 len, const ddc_endco *__restrict__ co)
+{
+    if (co) {
+        sc_coef k; k.L = co->m; k.c2 = co->c2; k.c3 = co->c3;
+        return state_of(sc_Tc(k, sc_of(e)));
+    }
+    return state_of(sc_T(len, sc_of(e)));
+}
+DDC_DEV ddc_state4 ddc_from_end(const ddc_state4 &e, u64 len, const ddc_endco *__restrict__ co)
+{
+    if (co) return state_of(sc_Tinv_c(co->m, co->c2i, co->c3i, sc_of(e)));
+    return state_of(sc_Tinv(len, sc_of(e)));
+}
+__global__ void ddc_endco_kernel(ddc_endco *__restrict__ tab, long n, int L, int nruns)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > nruns) return;
+    const long at = (long) k * L;
+    const u64 m = at < n ? (u64) (n - at) : 0ull;
+    ddc_endco c;
+    c.m = m; c.c2 = binom2(m).lo; c.c3 = u96_of(binom3(m));
+    c.c2i = m >= 1 ? binom2(m - 1).lo : 0ull;
+    c.c3i = m >= 2 ? u96_of(binom3(m - 2)) : u96_zero();
+    c.pad[0] = c.pad[1] = 0;
+    tab[k] = c;
+}
+// inclusive prefix sum over lanes 0 .. 2^LOG - 1 (every lane of the group calls it)
+template <int LOG> DDC_DEV void sc_scan_add(sc4 &e, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < (1 << LOG); d <<= 1) {
+        const sc4 a = sc_shfl_up(e, d);
+        if (lane >= d) e = sc_add(a, e);
+    }
+}
+
+DDC_DEV ddc_state4 ddc_add_state(const ddc_state4 &a, const ddc_state4 &b) { return state_of(sc_add(sc_of(a), sc_of(b))); }
+// Passes A and B.  grid = (ceil(nruns / 256), nchan).  The body of a thread's run; the kernel below adds pass A's
+// workgroup-level prefix sum of the end-referred results (endref == 2).
 template <bool PASS_B>
-__global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
+DDC_DEV void ddc_wf_run_body(
     const short *__restrict__ adc, long n, int L, int nruns,
     const ddc_chan *__restrict__ chans, const int *__restrict__ chan_list,
     const u32 *__restrict__ nco,              // the 16-bit table T[DDC_TAB] (kg_ddc_create), two entries per word
@@ -131,7 +295,11 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
     int stage_bytes,                          // pass B, R <= 8: dynamic LDS for the strobe staging tiles, else 0
     u64 pushed,                               // samples pushed since the channels' reference point (ddc_chan)
     const long *__restrict__ nlim,            // [nlist] samples of the block this entry consumes (capture: 8192 R; else n)
-    int reset_first)                          // capture: the decimation counter starts the block at zero (rst_wf_samp_wr)
+    int reset_first,                          // capture: the decimation counter starts the block at zero (rst_wf_samp_wr)
+    int endref,                               // states in `local` are referred to the END of the entry's share (sc_Tinv above)
+    const ddc_endco *__restrict__ endco, long endco_n,    // [nruns + 1] coefficients of the distances n - k L for a share of endco_n samples
+    const ddc_state4 *__restrict__ wgbase,    // endref == 2, pass B: [nlist][2][gridDim.x] what the workgroup's first run adds to local[]
+    ddc_state4 &outI, ddc_state4 &outQ, bool &have)       // endref == 2, pass A: the run's end-referred result goes to the caller instead of local[]
 {
     __shared__ short tab[DDC_TAB];
     extern __shared__ u32 stage_lds[];        // [waves][2][64][DDC_STAGE_ROW] when stage_bytes != 0
@@ -143,6 +311,9 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
     n = nlim[li];                             // this entry's share of the block (wave-uniform)
     if (r >= nruns || (long) r * L >= n) return;
     const long s0 = (long) r * L, s1 = (s0 + L < n) ? s0 + L : n;
+    const ddc_endco *co = (endref && n == endco_n) ? endco + (PASS_B ? r : r + 1) : nullptr;
+    const long wbI = ((long) li * 2 + 0) * gridDim.x + blockIdx.x, wbQ = ((long) li * 2 + 1) * gridDim.x + blockIdx.x;
+    (void) wbI; (void) wbQ;
     // the 48-bit accumulator sits in the TOP bits of a 64-bit register: it wraps by itself (no mask per sample)
     u64 ph = (ch.phase + (pushed + (u64) s0) * ch.phase_inc) << 16;
     const u64 inc16 = ch.phase_inc << 16;
@@ -205,7 +376,9 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
         const int sh5 = 5 * log2r - 4;                    // 61 - shift
         u64 I[4], Q[4];
         if (PASS_B) {
-            const ddc_state4 a = local[lI], b = local[lQ];
+            ddc_state4 a = local[lI], b = local[lQ];
+            if (endref == 2) { a = ddc_add_state(a, wgbase[wbI]); b = ddc_add_state(b, wgbase[wbQ]); }
+            if (endref) { a = ddc_from_end(a, (u64) (n - s0), co); b = ddc_from_end(b, (u64) (n - s0), co); }
             for (int k = 0; k < 4; k++) {
                 I[k] = (a.i[k].lo >> shift) | (a.i[k].hi << (64 - shift));
                 Q[k] = (b.i[k].lo >> shift) | (b.i[k].hi << (64 - shift));
@@ -393,8 +566,9 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
                 a.i[k] = mk128(I[k] << shift, hi_i);
                 b.i[k] = mk128(Q[k] << shift, hi_q);
             }
-            local[lI] = a;
-            local[lQ] = b;
+            if (endref) { a = ddc_to_end(a, (u64) (n - s1), co); b = ddc_to_end(b, (u64) (n - s1), co); }
+            if (endref == 2) { outI = a; outQ = b; have = true; }
+            else { local[lI] = a; local[lQ] = b; }
         }
         return;
     }
@@ -414,7 +588,9 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
         };
         u96 I[4], Q[4];
         {
-            const ddc_state4 a = local[lI], b = local[lQ];
+            ddc_state4 a = local[lI], b = local[lQ];
+            if (endref == 2) { a = ddc_add_state(a, wgbase[wbI]); b = ddc_add_state(b, wgbase[wbQ]); }
+            if (endref) { a = ddc_from_end(a, (u64) (n - s0), co); b = ddc_from_end(b, (u64) (n - s0), co); }
             for (int k = 0; k < 4; k++) {
                 I[k].w[0] = (u32) a.i[k].lo; I[k].w[1] = (u32) (a.i[k].lo >> 32); I[k].w[2] = (u32) a.i[k].hi;
                 Q[k].w[0] = (u32) b.i[k].lo; Q[k].w[1] = (u32) (b.i[k].lo >> 32); Q[k].w[2] = (u32) b.i[k].hi;
@@ -473,6 +649,8 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
     if (PASS_B) {
         SI = local[lI];
         SQ = local[lQ];
+        if (endref == 2) { SI = ddc_add_state(SI, wgbase[wbI]); SQ = ddc_add_state(SQ, wgbase[wbQ]); }
+        if (endref) { SI = ddc_from_end(SI, (u64) (n - s0), co); SQ = ddc_from_end(SQ, (u64) (n - s0), co); }
     } else {
         for (int k = 0; k < 4; k++) { SI.i[k] = mk128(0, 0); SQ.i[k] = mk128(0, 0); }
     }
@@ -507,9 +685,75 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
         tau[lI] = i5i;
         tau[lQ] = i5q;
     } else {
-        local[lI] = SI;
-        local[lQ] = SQ;
+        if (endref) { SI = ddc_to_end(SI, (u64) (n - s1), co); SQ = ddc_to_end(SQ, (u64) (n - s1), co); }
+        if (endref == 2) { outI = SI; outQ = SQ; have = true; }
+        else { local[lI] = SI; local[lQ] = SQ; }
     }
+}
+
+// endref == 2 (round 4): the carry scan's first two levels ride on pass A.  A workgroup's 256 threads hold 256 consecutive runs of
+// one channel: their end-referred results are prefix-summed right here (additions of 4 x 96 bits: a wave scan, the four wave
+// totals through LDS) -- local[r] = the sum of the workgroup's runs before r, wgtot = the workgroup's total -- and what is
+// left for a kernel of its own is the prefix over at most 64 workgroup totals per (channel, I/Q) (ddc_wf_scan_wg_kernel:
+// one wave each, a few microseconds where the chunked scan took 36 alone and 57 .. 85 beside the bypass kernel).
+template <bool PASS_B>
+__global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
+    const short *__restrict__ adc, long n, int L, int nruns,
+    const ddc_chan *__restrict__ chans, const int *__restrict__ chan_list, const u32 *__restrict__ nco,
+    ddc_state4 *__restrict__ local, u32 *__restrict__ c0rel, u32 *__restrict__ tau,
+    const long *__restrict__ c0off, const long *__restrict__ nouts, const int *__restrict__ sel, int stage_bytes,
+    u64 pushed, const long *__restrict__ nlim, int reset_first, int endref,
+    const ddc_endco *__restrict__ endco, long endco_n,
+    ddc_state4 *__restrict__ wgtot,           // pass A, endref == 2: [nlist][2][gridDim.x] out
+    const ddc_state4 *__restrict__ wgbase)    // pass B, endref == 2: [nlist][2][gridDim.x] in
+{
+    ddc_state4 oI, oQ;
+    bool have = false;
+    ddc_wf_run_body<PASS_B>(adc, n, L, nruns, chans, chan_list, nco, local, c0rel, tau, c0off, nouts, sel, stage_bytes, pushed,
+                            nlim, reset_first, endref, endco, endco_n, wgbase, oI, oQ, have);
+    if (!PASS_B && endref == 2) {
+        __shared__ sc4 s_w[2][DDC_THREADS / 64];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int li = sel ? sel[blockIdx.y] : (int) blockIdx.y;
+        const long r = (long) blockIdx.x * DDC_THREADS + threadIdx.x;
+        sc4 iI = have ? sc_of(oI) : sc_zero(), iQ = have ? sc_of(oQ) : sc_zero();
+        sc_scan_add<6>(iI, lane);
+        sc_scan_add<6>(iQ, lane);
+        if (lane == 63) { s_w[0][wave] = iI; s_w[1][wave] = iQ; }
+        __syncthreads();
+        sc4 pI = sc_zero(), pQ = sc_zero();
+        for (int w = 0; w < wave; w++) { pI = sc_add(pI, s_w[0][w]); pQ = sc_add(pQ, s_w[1][w]); }
+        if (threadIdx.x == DDC_THREADS - 1) {                      // inclusive of the last thread: the workgroup's total
+            wgtot[((long) li * 2 + 0) * gridDim.x + blockIdx.x] = state_of(sc_add(pI, iI));
+            wgtot[((long) li * 2 + 1) * gridDim.x + blockIdx.x] = state_of(sc_add(pQ, iQ));
+        }
+        sc4 xI = sc_shfl_up(iI, 1), xQ = sc_shfl_up(iQ, 1);        // exclusive inside the wave
+        if (lane == 0) { xI = sc_zero(); xQ = sc_zero(); }
+        if (have) {
+            local[((long) li * 2 + 0) * nruns + r] = state_of(sc_add(pI, xI));
+            local[((long) li * 2 + 1) * nruns + r] = state_of(sc_add(pQ, xQ));
+        }
+    }
+}
+
+// The third level: one wave per (channel, I/Q) over its workgroup totals (at most 64: max_runs / 256).
+__global__ __launch_bounds__(64) void ddc_wf_scan_wg_kernel(
+    const ddc_state4 *__restrict__ wgtot, ddc_state4 *__restrict__ wgbase, int gx, ddc_chan *__restrict__ chans,
+    const int *__restrict__ chan_list, const long *__restrict__ nlim, int reset_first)
+{
+    const int pair = blockIdx.x, li = pair >> 1, comp = pair & 1, lane = threadIdx.x;
+    ddc_chan *ch = chans + chan_list[li];
+    if (ch->log2r == 0) return;
+    sc4 inc = lane < gx ? sc_of(wgtot[(long) pair * gx + lane]) : sc_zero();
+    // the carried-in state, advanced to the end of the entry's share (lane 0; the loads above are in flight meanwhile)
+    sc4 base = sc_zero();
+    if (lane == 0 && !reset_first) base = sc_T((u64) nlim[li], sc_of(ch->integ[comp]));
+    sc_scan_add<6>(inc, lane);
+    base = sc_shfl(base, 0);
+    sc4 exc = sc_shfl_up(inc, 1);
+    if (lane == 0) exc = sc_zero();
+    if (lane < gx) wgbase[(long) pair * gx + lane] = state_of(sc_add(base, exc));
+    if (lane == 63) ch->integ[comp] = state_of(sc_add(base, inc));     // the state after the block
 }
 
 // R == 1 bypass (cic_prune_var.v:289-297): out = mixer output [23 -: 16], no filter state at all,
@@ -584,87 +828,6 @@ DDC_DEV u64 shfl64(u64 v, int src)
     const u32 lo = __shfl((u32) v, src), hi = __shfl((u32) (v >> 32), src);
     return ((u64) hi << 32) | lo;
 }
-// The scan's arithmetic.  Nothing above bit 88 of an integrator is ever read, so the scan keeps a state as 4 x 96
-// bits in 32-bit limbs (the stored form stays 128 bits wide, upper limb zero): a product with a coefficient is
-// 3 / 5 / 6 multiply-adds of 32 x 32 -> 64 bits (the run length and its binomials have 1-2 / 2 / 3 limbs) where
-// the 128 x 128-bit product took some forty-five instructions, and a state crosses lanes in 12 shuffles, not 32.
-struct u96 { u32 w[3]; };
-struct sc4 { u96 i[4]; };                     // integrators 1..4, mod 2^96
-struct sc_coef { u64 L, c2; u96 c3; };        // len, len (len+1) / 2 (exact: len < 2^32, asserted where the table is built), len (len+1) (len+2) / 6 mod 2^96
-DDC_DEV u96 u96_zero() { u96 r; r.w[0] = r.w[1] = r.w[2] = 0; return r; }
-DDC_DEV u96 u96_of(const u128 &v) { u96 r; r.w[0] = (u32) v.lo; r.w[1] = (u32) (v.lo >> 32); r.w[2] = (u32) v.hi; return r; }
-DDC_DEV u128 u128_of(const u96 &v) { return mk128((u64) v.w[0] | ((u64) v.w[1] << 32), (u64) v.w[2]); }
-DDC_DEV u96 add96(const u96 &a, const u96 &b)
-{
-    u96 r; unsigned c0, c1;
-    r.w[0] = __builtin_addc(a.w[0], b.w[0], 0u, &c0);
-    r.w[1] = __builtin_addc(a.w[1], b.w[1], c0, &c1);
-    r.w[2] = a.w[2] + b.w[2] + c1;
-    return r;
-}
-DDC_DEV u96 mul96_64(const u96 &a, u64 b)      // a * b mod 2^96
-{
-    const u32 b0 = (u32) b, b1 = (u32) (b >> 32);
-    const u64 p0 = (u64) a.w[0] * b0;
-    const u64 p1 = (u64) a.w[1] * b0 + (p0 >> 32);
-    const u64 q0 = (u64) a.w[0] * b1 + (u32) p1;
-    u96 r;
-    r.w[0] = (u32) p0;
-    r.w[1] = (u32) q0;
-    r.w[2] = a.w[2] * b0 + a.w[1] * b1 + (u32) (p1 >> 32) + (u32) (q0 >> 32);
-    return r;
-}
-DDC_DEV u96 mul96_96(const u96 &a, const u96 &b)
-{
-    u96 r = mul96_64(a, (u64) b.w[0] | ((u64) b.w[1] << 32));
-    r.w[2] += a.w[0] * b.w[2];
-    return r;
-}
-DDC_DEV sc_coef sc_coef_for(u64 len)
-{
-    sc_coef c;
-    c.L = len; c.c2 = binom2(len).lo; c.c3 = u96_of(binom3(len));
-    return c;
-}
-DDC_DEV sc4 sc_zero() { sc4 r; for (int k = 0; k < 4; k++) r.i[k] = u96_zero(); return r; }
-DDC_DEV sc4 sc_of(const ddc_state4 &s) { sc4 r; for (int k = 0; k < 4; k++) r.i[k] = u96_of(s.i[k]); return r; }
-DDC_DEV ddc_state4 state_of(const sc4 &s) { ddc_state4 r; for (int k = 0; k < 4; k++) r.i[k] = u128_of(s.i[k]); return r; }
-// advance a state over len zero-input samples: the binomial matrix of the four cascaded integrators
-DDC_DEV sc4 sc_Tc(const sc_coef &k, const sc4 &s)
-{
-    sc4 r;
-    r.i[0] = s.i[0];
-    r.i[1] = add96(s.i[1], mul96_64(s.i[0], k.L));
-    r.i[2] = add96(add96(s.i[2], mul96_64(s.i[1], k.L)), mul96_64(s.i[0], k.c2));
-    r.i[3] = add96(add96(add96(s.i[3], mul96_64(s.i[2], k.L)), mul96_64(s.i[1], k.c2)), mul96_96(s.i[0], k.c3));
-    return r;
-}
-DDC_DEV sc4 sc_T(u64 len, const sc4 &s) { return sc_Tc(sc_coef_for(len), s); }
-// The lengths the scan's log steps advance a state by are the same in every lane but a few: u << k (u = the samples
-// of a full lane's runs: steps of the wave scan, then of the fold over the wave totals) and v << m (v = a full
-// chunk).  Their coefficients come from the host in the kernel arguments (scalar registers); a lane whose length
-// is another one (the ragged end of the last chunk) computes its own -- the binomials are 40 % of an advance.
-#define DDC_SCAN_TAB 13
-struct sc_tab { u64 len[DDC_SCAN_TAB]; sc_coef c[DDC_SCAN_TAB]; };
-DDC_DEV sc4 sc_T_tab(const sc_tab &t, int j, u64 len, const sc4 &s)
-{
-    if (len == t.len[j]) return sc_Tc(t.c[j], s);
-    return sc_T(len, s);
-}
-DDC_DEV sc4 sc_add(const sc4 &a, const sc4 &b) { sc4 r; for (int k = 0; k < 4; k++) r.i[k] = add96(a.i[k], b.i[k]); return r; }
-DDC_DEV sc4 sc_shfl(const sc4 &s, int src)
-{
-    sc4 r;
-    for (int k = 0; k < 4; k++) for (int w = 0; w < 3; w++) r.i[k].w[w] = __shfl(s.i[k].w[w], src);
-    return r;
-}
-DDC_DEV sc4 sc_shfl_up(const sc4 &s, int d)
-{
-    sc4 r;
-    for (int k = 0; k < 4; k++) for (int w = 0; w < 3; w++) r.i[k].w[w] = __shfl_up(s.i[k].w[w], d);
-    return r;
-}
-
 #define DDC_SCAN_WAVES 8
 #define DDC_SCAN_MAX_CHUNKS 16
 // Ordered fold of the affine maps held by lanes 0 .. 2^LOG - 1 (lane order = time order; a lane with
@@ -1027,9 +1190,13 @@ struct kg_ddc {
     bool tail_unjoined;                        // the context's stream has not yet been made to wait for the last output stage
     int parity;                                // buffer set of the NEXT push
     void *after_ev;                            // kg_ddc_wf_tail_after: the next push's writers of the caller's rows wait for it
+    ddc_endco *d_endco; long endco_n; int endco_L, endco_runs;      // end-distance coefficients of the last (n, L, nruns)
+    ddc_state4 *d_wgtot[2], *d_wgbase[2];     // [nchan][2][DDC_MAX_GX] per buffer set: pass A's workgroup totals, pass B's workgroup bases
 };
 
 static const int DDC_RUN_MIN = 64, DDC_RUN_MAX = 8192, DDC_TARGET_RUNS = 8192;
+static const int DDC_MAX_GX = DDC_TARGET_RUNS * 2 / DDC_THREADS;      // workgroups of a run pass per channel: one lane each in ddc_wf_scan_wg_kernel
+static_assert(DDC_MAX_GX <= 64, "ddc_wf_scan_wg_kernel scans one workgroup total per lane");
 
 extern "C" {
 
@@ -1064,6 +1231,12 @@ int kg_ddc_create(kg_ctx *ctx, int nchan, size_t max_samples, kg_ddc **out)
         KG_HIP(hipMalloc((void **) &d->d_tau[p], sizeof(u32) * 2 * (size_t) nchan * d->max_runs));
     }
     KG_HIP(hipMalloc((void **) &d->d_hist, sizeof(u32) * 10 * (size_t) nchan));
+    KG_HIP(hipMalloc((void **) &d->d_endco, sizeof(ddc_endco) * ((size_t) d->max_runs + 1)));
+    for (int p = 0; p < 2; p++) {
+        KG_HIP(hipMalloc((void **) &d->d_wgtot[p], sizeof(ddc_state4) * 2 * (size_t) nchan * DDC_MAX_GX));
+        KG_HIP(hipMalloc((void **) &d->d_wgbase[p], sizeof(ddc_state4) * 2 * (size_t) nchan * DDC_MAX_GX));
+    }
+    d->endco_n = -1; d->endco_L = 0; d->endco_runs = 0;
     KG_HIP(hipMalloc((void **) &d->d_aggs, sizeof(ddc_chunk_agg) * 2 * (size_t) nchan * DDC_SCAN_MAX_CHUNKS));
     KG_HIP(hipMemset(d->d_aggs, 0, sizeof(ddc_chunk_agg) * 2 * (size_t) nchan * DDC_SCAN_MAX_CHUNKS));
     KG_HIP(hipMalloc((void **) &d->d_ticket, sizeof(u32)));
@@ -1087,7 +1260,8 @@ void kg_ddc_destroy(kg_ddc *d)
     (void) hipFree(d->d_chans); (void) hipFree(d->d_nco);
     for (int p = 0; p < 2; p++) { (void) hipFree(d->d_local[p]); (void) hipFree(d->d_tau[p]); (void) hipFree(d->d_c0rel[p]); }
     (void) hipFree(d->d_hist);
-    (void) hipFree(d->d_aggs); (void) hipFree(d->d_ticket);
+    (void) hipFree(d->d_aggs); (void) hipFree(d->d_ticket); (void) hipFree(d->d_endco);
+    for (int p = 0; p < 2; p++) { (void) hipFree(d->d_wgtot[p]); (void) hipFree(d->d_wgbase[p]); }
     kg_stage_cache_free(&d->pack_cache);
     if (d->side) { (void) hipEventDestroy(d->ev_fork); (void) hipEventDestroy(d->ev_join); (void) hipStreamDestroy(d->side); }
     if (d->tail) {
@@ -1432,12 +1606,25 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
                            s_bypass, (int) h_bypass.size(), (const u32 *) d->d_nco, (short2 *) d_out, (long) out_stride, pushed, s_nlim);
         KG_HIP(hipGetLastError());
     }
+    // end-referred carry states (round 4): prefix sums inside pass A's workgroups + one wave per (channel, I/Q) over the
+    // workgroup totals; KIWIGPU_DDC_ENDREF=0: run-start states and the chunked affine scan -- the A/B reference
+    int endref = 2;
+    if (const char *e = getenv("KIWIGPU_DDC_ENDREF")) endref = atoi(e) != 0 ? 2 : 0;
+    if (endref && !h_run.empty() && (d->endco_n != n_cover || d->endco_L != L || d->endco_runs != nruns)) {
+        // (a changed block length: rare.  The previous push's pass B may still be reading the old table on the object's
+        // second stream)
+        if ((rc = ddc_sync_all(d))) return rc;
+        hipLaunchKernelGGL(ddc_endco_kernel, dim3((unsigned) ((nruns + 1 + 255) / 256)), dim3(256), 0, st, d->d_endco, n_cover, L, nruns);
+        KG_HIP(hipGetLastError());
+        d->endco_n = n_cover; d->endco_L = L; d->endco_runs = nruns;
+    }
     const unsigned gx = (unsigned) ((nruns + DDC_THREADS - 1) / DDC_THREADS);
     if (!h_run.empty()) {
         hipLaunchKernelGGL(ddc_wf_run_kernel<false>, dim3(gx, (unsigned) h_run.size()), dim3(DDC_THREADS), 0, st,
                            (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, s_list,
                            (const u32 *) d->d_nco, d_local, d_c0rel, d_tau, s_c0off,
-                           s_nouts, s_selrun, 0, pushed, s_nlim, reset_first);
+                           s_nouts, s_selrun, 0, pushed, s_nlim, reset_first, endref, (const ddc_endco *) d->d_endco, d->endco_n,
+                           d->d_wgtot[par], (const ddc_state4 *) nullptr);
         KG_HIP(hipGetLastError());
     }
     {
@@ -1472,13 +1659,19 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
                 tab.c[j].c3.w[0] = (u32) c3; tab.c[j].c3.w[1] = (u32) (c3 >> 32); tab.c[j].c3.w[2] = (u32) (c3 >> 64);
             }
         }
-        hipLaunchKernelGGL(ddc_wf_scan_states_kernel, dim3((unsigned) (npairs * nchunk)), dim3(64 * DDC_SCAN_WAVES), 0, st,
-                           d_local, (long) n, L, nruns, d->d_chans, s_list, npairs, nchunk, d->d_aggs, d->d_ticket,
-                           d->ticket_base, d->epoch + 1, tab, s_nlim, reset_first);
+        if (endref == 2)
+            hipLaunchKernelGGL(ddc_wf_scan_wg_kernel, dim3((unsigned) npairs), dim3(64), 0, st, (const ddc_state4 *) d->d_wgtot[par],
+                               d->d_wgbase[par], (int) gx, d->d_chans, s_list, s_nlim, reset_first);
+        else
+            hipLaunchKernelGGL(ddc_wf_scan_states_kernel, dim3((unsigned) (npairs * nchunk)), dim3(64 * DDC_SCAN_WAVES), 0, st,
+                               d_local, (long) n, L, nruns, d->d_chans, s_list, npairs, nchunk, d->d_aggs, d->d_ticket,
+                               d->ticket_base, d->epoch + 1, tab, s_nlim, reset_first);
         KG_HIP(hipGetLastError());
         // only a launch that was accepted advances the ticket counter and publishes under the new epoch
-        d->epoch++;
-        d->ticket_base += (u32) (npairs * nchunk);
+        if (endref != 2) {
+            d->epoch++;
+            d->ticket_base += (u32) (npairs * nchunk);
+        }
     }
     // Pass B.  The staged strobe flush (R <= 8) needs 34 KiB more LDS, hence its own launch.  Neither
     // launch fills the GPU by itself (a lane walks a whole run: 64 workgroups per channel), so when both
@@ -1492,7 +1685,8 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
     auto pass_b = [&](hipStream_t s, const std::vector<int> &which, const int *sel, int stage) {
         hipLaunchKernelGGL(ddc_wf_run_kernel<true>, dim3(gx, (unsigned) which.size()), dim3(DDC_THREADS), stage, s,
                            (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, s_list,
-                           (const u32 *) d->d_nco, d_local, d_c0rel, d_tau, s_c0off, s_nouts, sel, stage, pushed, s_nlim, reset_first);
+                           (const u32 *) d->d_nco, d_local, d_c0rel, d_tau, s_c0off, s_nouts, sel, stage, pushed, s_nlim, reset_first, endref, (const ddc_endco *) d->d_endco, d->endco_n,
+                           (ddc_state4 *) nullptr, (const ddc_state4 *) d->d_wgbase[par]);
     };
     if (beside) {
         if ((rc = side_ready())) return rc;

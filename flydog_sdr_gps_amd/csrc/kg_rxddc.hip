@@ -94,13 +94,21 @@ RX_DEV int mix22(int adc, int dds)            // iq_mixer.v:43-51 with OUT_WIDTH
 RX_DEV int sx(int v, int bits) { return (v << (32 - bits)) >> (32 - bits); }
 RX_DEV long long sx64(long long v, int bits) { return (v << (64 - bits)) >> (64 - bits); }
 
+RX_DEV u64 rx_shfl_up64(u64 v, int d)
+{
+    const u32 lo = __shfl_up((u32) v, d), hi = __shfl_up((u32) (v >> 32), d);
+    return ((u64) hi << 32) | lo;
+}
+
 // passes A and B of rx1.  grid = (ceil(nruns / 256), nlist)
 template <bool PASS_B>
 __global__ __launch_bounds__(RX_THREADS) void rx1_run_kernel(
     const short *__restrict__ adc, long n, int L, int nruns, const rx_chan *__restrict__ chans,
     const int *__restrict__ chan_list, const u32 *__restrict__ nco,
     u64 *__restrict__ st,                     // [nlist][2 comp][2 integ][nruns]: A out, B in (carried)
-    u32 *__restrict__ c0rel, u32 *__restrict__ tau, long max_out, rx_mode md)
+    u32 *__restrict__ c0rel, u32 *__restrict__ tau, long max_out, rx_mode md,
+    int endref,                               // round 4: states referred to the END of the block, summed in levels (below)
+    u64 *__restrict__ wg)                     // endref: [nlist][4][gridDim.x]: A out = the workgroup's totals, B in = what its first run adds
 {
     const u32 RX_R1 = (u32) md.r1;
     const int SH3 = md.sh3;
@@ -110,14 +118,26 @@ __global__ __launch_bounds__(RX_THREADS) void rx1_run_kernel(
     const int li = blockIdx.y;
     const rx_chan ch = chans[chan_list[li]];
     const int r = blockIdx.x * RX_THREADS + threadIdx.x;
-    if (r >= nruns) return;
-    const long s0 = (long) r * L, s1 = (s0 + L < n) ? s0 + L : n;
+    const bool active = r < nruns;
+    if (!active && (PASS_B || !endref)) return;   // (pass A's workgroup-level sums need every thread at their barrier)
+    const long s0 = active ? (long) r * L : n, s1 = (s0 + L < n) ? s0 + L : n;
     // the 48-bit accumulator sits in the TOP bits of a 64-bit register: it wraps by itself (no mask per sample)
     u64 ph = (ch.phase + (u64) s0 * ch.phase_inc) << 16;
     const u64 inc16 = ch.phase_inc << 16;
     u64 a1i = 0, a2i = 0, a1q = 0, a2q = 0;
     u64 *base = st + (long) li * 4 * nruns;
-    if (PASS_B) { a1i = base[0 * nruns + r]; a2i = base[1 * nruns + r]; a1q = base[2 * nruns + r]; a2q = base[3 * nruns + r]; }
+    if (PASS_B) {
+        a1i = base[0 * nruns + r]; a2i = base[1 * nruns + r]; a1q = base[2 * nruns + r]; a2q = base[3 * nruns + r];
+        if (endref) {
+            // End-referred (kg_ddc.hip, sc_Tinv): what is stored is the sum over the earlier runs of their results advanced
+            // to the block's end -- T(len): c1, c2 + len c1 -- plus the carried-in state advanced likewise; the state this run
+            // starts from is that sum taken back by its distance to the end.
+            const u64 *wb = wg + (long) li * 4 * gridDim.x + blockIdx.x;
+            a1i += wb[0 * gridDim.x]; a2i += wb[1 * gridDim.x]; a1q += wb[2 * gridDim.x]; a2q += wb[3 * gridDim.x];
+            const u64 back = (u64) (n - s0);
+            a2i -= back * a1i; a2q -= back * a1q;
+        }
+    }
     u32 i3i = 0, i3q = 0;
     const u64 c0 = (u64) ch.cnt1 + (u64) s0;
     u32 k = (u32) (c0 % RX_R1);               // decimation counter at the run start
@@ -166,14 +186,38 @@ __global__ __launch_bounds__(RX_THREADS) void rx1_run_kernel(
             const u64 len = (u64) (s1 - s0), b1 = len << 22, b2 = (len * (len + 1) / 2) << 22;
             a1i -= b1; a2i -= b2; a1q -= b1; a2q -= b2;
         }
-        base[0 * nruns + r] = a1i; base[1 * nruns + r] = a2i; base[2 * nruns + r] = a1q; base[3 * nruns + r] = a2q;
+        if (!endref) {
+            base[0 * nruns + r] = a1i; base[1 * nruns + r] = a2i; base[2 * nruns + r] = a1q; base[3 * nruns + r] = a2q;
+            return;
+        }
+        // Round 4: the carry scan's first two levels ride on pass A (as in kg_ddc.hip).  The run's result advanced to the end of
+        // the block, then prefix sums -- plain additions modulo 2^64 -- over the workgroup's 256 consecutive runs: st[r] = the
+        // sum of the workgroup's runs before r, wg = the workgroup's total; rx1_scan_wg_kernel does the third level (one
+        // wave per (channel, I/Q) over at most 64 totals) where rx1_scan_kernel was 52 us between the passes.
+        {
+            const u64 fwd = (u64) (n - s1);
+            a2i += fwd * a1i; a2q += fwd * a1q;
+        }
+        if (!active) { a1i = a2i = a1q = a2q = 0; }
+        __shared__ u64 s_w[4][RX_THREADS / 64];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        u64 v[4] = {a1i, a2i, a1q, a2q}, x[4];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const u64 p = rx_shfl_up64(v[k], d); if (lane >= d) v[k] += p; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { x[k] = rx_shfl_up64(v[k], 1); if (lane == 0) x[k] = 0; if (lane == 63) s_w[k][wave] = v[k]; }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            u64 p = 0;
+            for (int w = 0; w < wave; w++) p += s_w[k][w];
+            if (active) base[(long) k * nruns + r] = p + x[k];
+            if (threadIdx.x == RX_THREADS - 1) wg[((long) li * 4 + k) * gridDim.x + blockIdx.x] = p + v[k];
+        }
     }
-}
-
-RX_DEV u64 rx_shfl_up64(u64 v, int d)
-{
-    const u32 lo = __shfl_up((u32) v, d), hi = __shfl_up((u32) (v >> 32), d);
-    return ((u64) hi << 32) | lo;
 }
 
 // carry scan of (i1, i2) per (channel, comp): one wave each
@@ -246,6 +290,27 @@ __global__ __launch_bounds__(64 * RX_SCAN_WAVES) void rx1_scan_kernel(u64 *__res
         }
     }
     if (r1 == nruns && r0 < nruns) { ch->i1[comp] = c1; ch->i2[comp] = c2; }
+}
+
+// The third level of the end-referred scan: one wave per (channel, I/Q) over its workgroup totals (at most 64: max_runs / 256).
+// In: wg[li][2 comp + {0, 1}][w] = totals of workgroup w; out: the same slots = the carried-in state advanced to the end of the
+// block + the totals of the workgroups before w; the pair's grand total is the state after the block.
+__global__ __launch_bounds__(64) void rx1_scan_wg_kernel(u64 *__restrict__ wg, int gx, long n, rx_chan *__restrict__ chans,
+                                                        const int *__restrict__ chan_list)
+{
+    const int li = blockIdx.x >> 1, comp = blockIdx.x & 1, lane = threadIdx.x;
+    rx_chan *ch = chans + chan_list[li];
+    u64 *t1 = wg + ((long) li * 4 + 2 * comp) * gx, *t2 = t1 + gx;
+    u64 v1 = lane < gx ? t1[lane] : 0ull, v2 = lane < gx ? t2[lane] : 0ull;
+    const u64 b1 = ch->i1[comp], b2 = ch->i2[comp] + (u64) n * b1;
+    for (int d = 1; d < 64; d <<= 1) {
+        const u64 p1 = rx_shfl_up64(v1, d), p2 = rx_shfl_up64(v2, d);
+        if (lane >= d) { v1 += p1; v2 += p2; }
+    }
+    u64 x1 = rx_shfl_up64(v1, 1), x2 = rx_shfl_up64(v2, 1);
+    if (lane == 0) { x1 = 0; x2 = 0; }
+    if (lane < gx) { t1[lane] = b1 + x1; t2[lane] = b2 + x2; }
+    if (lane == 63) { ch->i1[comp] = b1 + v1; ch->i2[comp] = b2 + v2; }
 }
 
 // Prefix sum of the runs' integrator-3 totals (mod 2^26): one workgroup per (channel, I/Q), run r = k * 512 + thread
@@ -434,6 +499,7 @@ struct kg_rxddc {
     rx_chan *d_chans; std::vector<rx_chan> h;
     u32 *d_nco;
     u64 *d_st; u32 *d_c0rel, *d_tau, *d_hist;
+    u64 *d_wg;                                 // [nchan][4][64]: workgroup totals / bases of the end-referred carry scan
     int *d_c1buf; long c1_stride;
     int max_runs; long max_out;
     kg_stage_cache pack_cache;                 // the per-call tables of the last push (a steady stream repeats them: no upload)
@@ -473,6 +539,7 @@ int kg_rxddc_create_mode(kg_ctx *ctx, int nchan, size_t max_samples, int mode, k
     KG_HIP(hipMemset(d->d_chans, 0, sizeof(rx_chan) * nchan));
     KG_HIP(hipMalloc((void **) &d->d_nco, sizeof(short) * RX_TAB));
     KG_HIP(hipMalloc((void **) &d->d_st, sizeof(u64) * 4 * (size_t) nchan * d->max_runs));
+    KG_HIP(hipMalloc((void **) &d->d_wg, sizeof(u64) * 4 * (size_t) nchan * 64));
     KG_HIP(hipMalloc((void **) &d->d_tau, sizeof(u32) * 2 * (size_t) nchan * d->max_runs));
     KG_HIP(hipMalloc((void **) &d->d_c0rel, sizeof(u32) * 2 * (size_t) nchan * d->max_out));
     KG_HIP(hipMalloc((void **) &d->d_hist, sizeof(u32) * 6 * (size_t) nchan));
@@ -493,7 +560,7 @@ void kg_rxddc_destroy(kg_rxddc *d)
     (void) hipStreamSynchronize(d->ctx->stream);
     (void) hipFree(d->d_chans); (void) hipFree(d->d_nco); 
     
-    (void) hipFree(d->d_st); (void) hipFree(d->d_tau); (void) hipFree(d->d_c0rel); (void) hipFree(d->d_hist);
+    (void) hipFree(d->d_st); (void) hipFree(d->d_wg); (void) hipFree(d->d_tau); (void) hipFree(d->d_c0rel); (void) hipFree(d->d_hist);
     (void) hipFree(d->d_c1buf);
     kg_stage_cache_free(&d->pack_cache);
     delete d;
@@ -601,16 +668,24 @@ int kg_rxddc_push_dev(kg_rxddc *d, const void *d_adc, size_t n, const int32_t *c
         s_qfirst = (const long *) (b + o_qf); s_nfinal = (const int *) (b + o_nf); s_cnt = (const u32 *) (b + o_cnt);
     }
     const dim3 grid((nruns + RX_THREADS - 1) / RX_THREADS, nlist);
+    // end-referred carry states, summed inside pass A's workgroups and by one wave per (channel, I/Q) over the workgroup
+    // totals (round 4); KIWIGPU_RXDDC_ENDREF=0: run-start states and rx1_scan_kernel, the A/B reference
+    int endref = 1;
+    if (const char *e = getenv("KIWIGPU_RXDDC_ENDREF")) endref = atoi(e) != 0;
+    static_assert(16384 / RX_THREADS <= 64, "rx1_scan_wg_kernel scans one workgroup total per lane");
     hipLaunchKernelGGL(rx1_run_kernel<false>, grid, dim3(RX_THREADS), 0, st, (const short *) d_adc, (long) n, L, nruns,
                        (const rx_chan *) d->d_chans, s_list, (const u32 *) d->d_nco, d->d_st,
-                       d->d_c0rel, d->d_tau, d->max_out, d->md);
+                       d->d_c0rel, d->d_tau, d->max_out, d->md, endref, d->d_wg);
     KG_HIP(hipGetLastError());
-    hipLaunchKernelGGL(rx1_scan_kernel, dim3(2 * nlist), dim3(64 * RX_SCAN_WAVES), 0, st, d->d_st, (long) n, L, nruns, d->d_chans,
-                       s_list);
+    if (endref)
+        hipLaunchKernelGGL(rx1_scan_wg_kernel, dim3(2 * nlist), dim3(64), 0, st, d->d_wg, (int) grid.x, (long) n, d->d_chans, s_list);
+    else
+        hipLaunchKernelGGL(rx1_scan_kernel, dim3(2 * nlist), dim3(64 * RX_SCAN_WAVES), 0, st, d->d_st, (long) n, L, nruns, d->d_chans,
+                           s_list);
     KG_HIP(hipGetLastError());
     hipLaunchKernelGGL(rx1_run_kernel<true>, grid, dim3(RX_THREADS), 0, st, (const short *) d_adc, (long) n, L, nruns,
                        (const rx_chan *) d->d_chans, s_list, (const u32 *) d->d_nco, d->d_st,
-                       d->d_c0rel, d->d_tau, d->max_out, d->md);
+                       d->d_c0rel, d->d_tau, d->max_out, d->md, endref, d->d_wg);
     KG_HIP(hipGetLastError());
     hipLaunchKernelGGL(rx1_scan_tau_kernel, dim3(2 * nlist), dim3(64 * RX_SCAN_WAVES), 0, st, d->d_tau, nruns, d->d_chans,
                        s_list);
