@@ -299,7 +299,8 @@ DDC_DEV void ddc_wf_run_body(
     int endref,                               // states in `local` are referred to the END of the entry's share (sc_Tinv above)
     const ddc_endco *__restrict__ endco, long endco_n,    // [nruns + 1] coefficients of the distances n - k L for a share of endco_n samples
     const ddc_state4 *__restrict__ wgbase,    // endref == 2, pass B: [nlist][2][gridDim.x] what the workgroup's first run adds to local[]
-    ddc_state4 &outI, ddc_state4 &outQ, bool &have)       // endref == 2, pass A: the run's end-referred result goes to the caller instead of local[]
+    ddc_state4 &outI, ddc_state4 &outQ, bool &have,       // endref == 2, pass A: the run's end-referred result goes to the caller instead of local[]
+    u32 &outTi, u32 &outTq)                                // endref == 2, pass B: the run's integrator-5 totals likewise (instead of tau[])
 {
     __shared__ short tab[DDC_TAB];
     extern __shared__ u32 stage_lds[];        // [waves][2][64][DDC_STAGE_ROW] when stage_bytes != 0
@@ -547,8 +548,8 @@ DDC_DEV void ddc_wf_run_body(
         }
         for (; t < s1; t++) step(adc[t]);                 // ragged end of the block's last run
         if (PASS_B) {
-            tau[lI] = i5i & 0x0FFFFFFFu;
-            tau[lQ] = i5q & 0x0FFFFFFFu;
+            if (endref == 2) { outTi = i5i & 0x0FFFFFFFu; outTq = i5q & 0x0FFFFFFFu; have = true; }
+            else { tau[lI] = i5i & 0x0FFFFFFFu; tau[lQ] = i5q & 0x0FFFFFFFu; }
         } else {
             {   // the bias of pass A's inputs, out of the four integrators: 2^24 x C(len + k - 1, k), k = 1 .. 4, modulo 2^64
                 const u64 len = (u64) (s1 - s0);          // <= 8192: len (len+1) (len+2) (len+3) < 2^53
@@ -640,8 +641,8 @@ DDC_DEV void ddc_wf_run_body(
             for (int w = 0; w < 8; w++) step(buf[w]);
         }
         for (; t < s1; t++) step(adc[t]);
-        tau[lI] = i5i & 0x0FFFFFFFu;
-        tau[lQ] = i5q & 0x0FFFFFFFu;
+        if (endref == 2) { outTi = i5i & 0x0FFFFFFFu; outTq = i5q & 0x0FFFFFFFu; have = true; }
+        else { tau[lI] = i5i & 0x0FFFFFFFu; tau[lQ] = i5q & 0x0FFFFFFFu; }
         return;
     }
     // pass A of runs longer than 1024 samples at R >= 512: the zero-state sums need the full width
@@ -682,8 +683,8 @@ DDC_DEV void ddc_wf_run_body(
     }
     for (; t < s1; t++) step(adc[t]);
     if (PASS_B) {
-        tau[lI] = i5i;
-        tau[lQ] = i5q;
+        if (endref == 2) { outTi = i5i; outTq = i5q; have = true; }
+        else { tau[lI] = i5i; tau[lQ] = i5q; }
     } else {
         if (endref) { SI = ddc_to_end(SI, (u64) (n - s1), co); SQ = ddc_to_end(SQ, (u64) (n - s1), co); }
         if (endref == 2) { outI = SI; outQ = SQ; have = true; }
@@ -705,12 +706,42 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
     u64 pushed, const long *__restrict__ nlim, int reset_first, int endref,
     const ddc_endco *__restrict__ endco, long endco_n,
     ddc_state4 *__restrict__ wgtot,           // pass A, endref == 2: [nlist][2][gridDim.x] out
-    const ddc_state4 *__restrict__ wgbase)    // pass B, endref == 2: [nlist][2][gridDim.x] in
+    const ddc_state4 *__restrict__ wgbase,    // pass B, endref == 2: [nlist][2][gridDim.x] in
+    u32 *__restrict__ wgtau)                  // pass B, endref == 2: [nlist][2][gridDim.x] out: the workgroup's integrator-5 total
 {
     ddc_state4 oI, oQ;
     bool have = false;
+    u32 oTi = 0, oTq = 0;
     ddc_wf_run_body<PASS_B>(adc, n, L, nruns, chans, chan_list, nco, local, c0rel, tau, c0off, nouts, sel, stage_bytes, pushed,
-                            nlim, reset_first, endref, endco, endco_n, wgbase, oI, oQ, have);
+                            nlim, reset_first, endref, endco, endco_n, wgbase, oI, oQ, have, oTi, oTq);
+    if (PASS_B && endref == 2) {
+        // The prefix of the runs' integrator-5 totals in the same levels: tau[r] = the sum of the workgroup's runs before r,
+        // wgtau = the workgroup's total; ddc_wf_tau_wg_kernel turns the totals into each workgroup's absolute start value and
+        // the combs add the two (ddc_wf_scan_tau_kernel was 16 us on the step's critical path, 100 in a busy GPU).
+        __shared__ u32 s_t[2][DDC_THREADS / 64];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int li = sel ? sel[blockIdx.y] : (int) blockIdx.y;
+        const long r = (long) blockIdx.x * DDC_THREADS + threadIdx.x;
+        u32 vi = have ? oTi : 0u, vq = have ? oTq : 0u;
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 ai = __shfl_up(vi, d), aq = __shfl_up(vq, d);
+            if (lane >= d) { vi += ai; vq += aq; }
+        }
+        if (lane == 63) { s_t[0][wave] = vi; s_t[1][wave] = vq; }
+        u32 xi = __shfl_up(vi, 1), xq = __shfl_up(vq, 1);
+        if (lane == 0) { xi = 0; xq = 0; }
+        __syncthreads();
+        u32 pi = 0, pq = 0;
+        for (int w = 0; w < wave; w++) { pi += s_t[0][w]; pq += s_t[1][w]; }
+        if (have) {
+            tau[((long) li * 2 + 0) * nruns + r] = (pi + xi) & 0x0FFFFFFFu;
+            tau[((long) li * 2 + 1) * nruns + r] = (pq + xq) & 0x0FFFFFFFu;
+        }
+        if (threadIdx.x == DDC_THREADS - 1) {
+            wgtau[((long) li * 2 + 0) * gridDim.x + blockIdx.x] = (pi + vi) & 0x0FFFFFFFu;
+            wgtau[((long) li * 2 + 1) * gridDim.x + blockIdx.x] = (pq + vq) & 0x0FFFFFFFu;
+        }
+    }
     if (!PASS_B && endref == 2) {
         __shared__ sc4 s_w[2][DDC_THREADS / 64];
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -960,6 +991,22 @@ __global__ __launch_bounds__(64 * DDC_SCAN_WAVES) void ddc_wf_scan_states_kernel
     if (r1 == nruns && r0 < nruns) ch->integ[comp] = state_of(c);
 }
 
+// ... and of the integrator-5 totals: in = the workgroups' totals, out = integrator 5 at each workgroup's first run.
+__global__ __launch_bounds__(64) void ddc_wf_tau_wg_kernel(u32 *__restrict__ wgtau, int gx, ddc_chan *__restrict__ chans,
+                                                          const int *__restrict__ chan_list, int reset_first)
+{
+    const int pair = blockIdx.x, li = pair >> 1, comp = pair & 1, lane = threadIdx.x;
+    ddc_chan *ch = chans + chan_list[li];
+    if (ch->log2r == 0) return;
+    u32 v = lane < gx ? wgtau[(long) pair * gx + lane] : 0u;
+    const u32 i5 = reset_first ? 0u : ch->integ5[comp];
+    for (int d = 1; d < 64; d <<= 1) { const u32 a = __shfl_up(v, d); if (lane >= d) v += a; }
+    u32 x = __shfl_up(v, 1);
+    if (lane == 0) x = 0;
+    if (lane < gx) wgtau[(long) pair * gx + lane] = (i5 + x) & 0x0FFFFFFFu;
+    if (lane == 63) ch->integ5[comp] = (i5 + v) & 0x0FFFFFFFu;       // the state after the call
+}
+
 // Prefix sum of the runs' integrator-5 totals: one workgroup of eight waves per (channel, I/Q).
 // Run r = k * 512 + thread: every load and store of a tile of 512 runs is contiguous across the workgroup
 // (round 2 gave each thread 32 consecutive runs: every access its own line, 28 us for a 16 384-entry prefix).
@@ -1056,7 +1103,8 @@ __global__ __launch_bounds__(256) void ddc_wf_comb_kernel(
     u64 pushed,                               // samples pushed since the channels' reference point
     int reset_first,                          // capture: counter and comb registers start the block at zero
     const int *__restrict__ wg_start, int nlist,
-    short2 *__restrict__ out, long out_stride, u32 *__restrict__ hist_out)   // [nlist][2][5]
+    short2 *__restrict__ out, long out_stride, u32 *__restrict__ hist_out,   // [nlist][2][5]
+    const u32 *__restrict__ wgtau, int gx)    // end-referred levels: i5start[] is relative to its run pass workgroup's start value wgtau[li][comp][run / 256]; or null
 {
     __shared__ __attribute__((aligned(16))) int s_c0[2][DDC_COMB_TILE + 8];       // [d]: output o0 - 8 + d (three unused slots keep 16-byte rows)
     int lo = 0, hi = nlist;                   // wg_start[lo] <= blockIdx.x < wg_start[hi]
@@ -1070,7 +1118,8 @@ __global__ __launch_bounds__(256) void ddc_wf_comb_kernel(
     auto absolute = [&](int comp, long oo, u32 rel) -> u32 {
         const long g = ((oo + 1) << log2r) - 1 - (long) base;    // sample index of the strobe
         const int run = (int) (g >> log2L);
-        return (rel + i5start[((long) li * 2 + comp) * nruns + run]) & 0x0FFFFFFFu;
+        const u32 wb = wgtau ? wgtau[((long) li * 2 + comp) * gx + (run >> 8)] : 0u;
+        return (rel + i5start[((long) li * 2 + comp) * nruns + run] + wb) & 0x0FFFFFFFu;
     };
 #pragma unroll
     for (int comp = 0; comp < 2; comp++) {
@@ -1192,11 +1241,13 @@ struct kg_ddc {
     void *after_ev;                            // kg_ddc_wf_tail_after: the next push's writers of the caller's rows wait for it
     ddc_endco *d_endco; long endco_n; int endco_L, endco_runs;      // end-distance coefficients of the last (n, L, nruns)
     ddc_state4 *d_wgtot[2], *d_wgbase[2];     // [nchan][2][DDC_MAX_GX] per buffer set: pass A's workgroup totals, pass B's workgroup bases
+    u32 *d_wgtau[2];                           // likewise: the integrator-5 totals of pass B's workgroups, then their start values
 };
 
 static const int DDC_RUN_MIN = 64, DDC_RUN_MAX = 8192, DDC_TARGET_RUNS = 8192;
 static const int DDC_MAX_GX = DDC_TARGET_RUNS * 2 / DDC_THREADS;      // workgroups of a run pass per channel: one lane each in ddc_wf_scan_wg_kernel
 static_assert(DDC_MAX_GX <= 64, "ddc_wf_scan_wg_kernel scans one workgroup total per lane");
+static_assert(DDC_THREADS == 256, "ddc_wf_comb_kernel finds a run's pass-B workgroup as run >> 8");
 
 extern "C" {
 
@@ -1235,6 +1286,7 @@ int kg_ddc_create(kg_ctx *ctx, int nchan, size_t max_samples, kg_ddc **out)
     for (int p = 0; p < 2; p++) {
         KG_HIP(hipMalloc((void **) &d->d_wgtot[p], sizeof(ddc_state4) * 2 * (size_t) nchan * DDC_MAX_GX));
         KG_HIP(hipMalloc((void **) &d->d_wgbase[p], sizeof(ddc_state4) * 2 * (size_t) nchan * DDC_MAX_GX));
+        KG_HIP(hipMalloc((void **) &d->d_wgtau[p], sizeof(u32) * 2 * (size_t) nchan * DDC_MAX_GX));
     }
     d->endco_n = -1; d->endco_L = 0; d->endco_runs = 0;
     KG_HIP(hipMalloc((void **) &d->d_aggs, sizeof(ddc_chunk_agg) * 2 * (size_t) nchan * DDC_SCAN_MAX_CHUNKS));
@@ -1261,7 +1313,7 @@ void kg_ddc_destroy(kg_ddc *d)
     for (int p = 0; p < 2; p++) { (void) hipFree(d->d_local[p]); (void) hipFree(d->d_tau[p]); (void) hipFree(d->d_c0rel[p]); }
     (void) hipFree(d->d_hist);
     (void) hipFree(d->d_aggs); (void) hipFree(d->d_ticket); (void) hipFree(d->d_endco);
-    for (int p = 0; p < 2; p++) { (void) hipFree(d->d_wgtot[p]); (void) hipFree(d->d_wgbase[p]); }
+    for (int p = 0; p < 2; p++) { (void) hipFree(d->d_wgtot[p]); (void) hipFree(d->d_wgbase[p]); (void) hipFree(d->d_wgtau[p]); }
     kg_stage_cache_free(&d->pack_cache);
     if (d->side) { (void) hipEventDestroy(d->ev_fork); (void) hipEventDestroy(d->ev_join); (void) hipStreamDestroy(d->side); }
     if (d->tail) {
@@ -1624,7 +1676,7 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
                            (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, s_list,
                            (const u32 *) d->d_nco, d_local, d_c0rel, d_tau, s_c0off,
                            s_nouts, s_selrun, 0, pushed, s_nlim, reset_first, endref, (const ddc_endco *) d->d_endco, d->endco_n,
-                           d->d_wgtot[par], (const ddc_state4 *) nullptr);
+                           d->d_wgtot[par], (const ddc_state4 *) nullptr, (u32 *) nullptr);
         KG_HIP(hipGetLastError());
     }
     {
@@ -1686,7 +1738,7 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
         hipLaunchKernelGGL(ddc_wf_run_kernel<true>, dim3(gx, (unsigned) which.size()), dim3(DDC_THREADS), stage, s,
                            (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, s_list,
                            (const u32 *) d->d_nco, d_local, d_c0rel, d_tau, s_c0off, s_nouts, sel, stage, pushed, s_nlim, reset_first, endref, (const ddc_endco *) d->d_endco, d->endco_n,
-                           (ddc_state4 *) nullptr, (const ddc_state4 *) d->d_wgbase[par]);
+                           (ddc_state4 *) nullptr, (const ddc_state4 *) d->d_wgbase[par], d->d_wgtau[par]);
     };
     if (beside) {
         if ((rc = side_ready())) return rc;
@@ -1718,15 +1770,19 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
         KG_HIP(hipEventRecord(d->ev_join, d->side));
         KG_HIP(hipStreamWaitEvent(ost, d->ev_join, 0));
     }
-    hipLaunchKernelGGL(ddc_wf_scan_tau_kernel, dim3(2 * nlist), dim3(64 * DDC_SCAN_WAVES), 0, ost, d_tau, nruns, d->d_chans,
-                       s_list, s_nlim, L, reset_first);
+    if (endref == 2)
+        hipLaunchKernelGGL(ddc_wf_tau_wg_kernel, dim3(2 * nlist), dim3(64), 0, ost, d->d_wgtau[par], (int) gx, d->d_chans, s_list,
+                           reset_first);
+    else
+        hipLaunchKernelGGL(ddc_wf_scan_tau_kernel, dim3(2 * nlist), dim3(64 * DDC_SCAN_WAVES), 0, ost, d_tau, nruns, d->d_chans,
+                           s_list, s_nlim, L, reset_first);
     KG_HIP(hipGetLastError());
     if (comb_wgs > 0) {
         hipLaunchKernelGGL(ddc_wf_comb_kernel, dim3((unsigned) comb_wgs), dim3(256), 0, ost,
                            (const u32 *) d_c0rel, (const u32 *) d_tau, log2L, nruns, s_c0off,
                            (const ddc_chan *) d->d_chans, s_list, s_nouts,
                            pushed, reset_first, s_wgoff, nlist, (short2 *) d_out, (long) out_stride,
-                           d->d_hist);
+                           d->d_hist, endref == 2 ? (const u32 *) d->d_wgtau[par] : (const u32 *) nullptr, (int) gx);
         KG_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(ddc_wf_finish_kernel, dim3((nlist + 63) / 64), dim3(64), 0, ost, d->d_chans,

@@ -108,7 +108,8 @@ __global__ __launch_bounds__(RX_THREADS) void rx1_run_kernel(
     u64 *__restrict__ st,                     // [nlist][2 comp][2 integ][nruns]: A out, B in (carried)
     u32 *__restrict__ c0rel, u32 *__restrict__ tau, long max_out, rx_mode md,
     int endref,                               // round 4: states referred to the END of the block, summed in levels (below)
-    u64 *__restrict__ wg)                     // endref: [nlist][4][gridDim.x]: A out = the workgroup's totals, B in = what its first run adds
+    u64 *__restrict__ wg,                     // endref: [nlist][4][gridDim.x]: A out = the workgroup's totals, B in = what its first run adds
+    u32 *__restrict__ wgt)                    // endref, pass B: [nlist][2][gridDim.x] out: the workgroup's integrator-3 total
 {
     const u32 RX_R1 = (u32) md.r1;
     const int SH3 = md.sh3;
@@ -119,14 +120,14 @@ __global__ __launch_bounds__(RX_THREADS) void rx1_run_kernel(
     const rx_chan ch = chans[chan_list[li]];
     const int r = blockIdx.x * RX_THREADS + threadIdx.x;
     const bool active = r < nruns;
-    if (!active && (PASS_B || !endref)) return;   // (pass A's workgroup-level sums need every thread at their barrier)
+    if (!active && !endref) return;               // (the workgroup-level sums of both passes need every thread at their barrier)
     const long s0 = active ? (long) r * L : n, s1 = (s0 + L < n) ? s0 + L : n;
     // the 48-bit accumulator sits in the TOP bits of a 64-bit register: it wraps by itself (no mask per sample)
     u64 ph = (ch.phase + (u64) s0 * ch.phase_inc) << 16;
     const u64 inc16 = ch.phase_inc << 16;
     u64 a1i = 0, a2i = 0, a1q = 0, a2q = 0;
     u64 *base = st + (long) li * 4 * nruns;
-    if (PASS_B) {
+    if (PASS_B && active) {
         a1i = base[0 * nruns + r]; a2i = base[1 * nruns + r]; a1q = base[2 * nruns + r]; a2q = base[3 * nruns + r];
         if (endref) {
             // End-referred (kg_ddc.hip, sc_Tinv): what is stored is the sum over the earlier runs of their results advanced
@@ -179,8 +180,34 @@ __global__ __launch_bounds__(RX_THREADS) void rx1_run_kernel(
     }
     for (; t < s1; t++) step(adc[t]);
     if (PASS_B) {
-        tau[((long) li * 2 + 0) * nruns + r] = i3i & 0x03FFFFFFu;
-        tau[((long) li * 2 + 1) * nruns + r] = i3q & 0x03FFFFFFu;
+        if (!endref) {
+            tau[((long) li * 2 + 0) * nruns + r] = i3i & 0x03FFFFFFu;
+            tau[((long) li * 2 + 1) * nruns + r] = i3q & 0x03FFFFFFu;
+            return;
+        }
+        // the prefix of the runs' integrator-3 totals in the same levels as the carry states: tau[r] = the sum of the
+        // workgroup's runs before r, wgt = the workgroup's total (rx1_tau_wg_kernel: its start value; rx1_comb_kernel adds both)
+        __shared__ u32 s_t[2][RX_THREADS / 64];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        u32 vi = active ? i3i : 0u, vq = active ? i3q : 0u;
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 ai = __shfl_up(vi, d), aq = __shfl_up(vq, d);
+            if (lane >= d) { vi += ai; vq += aq; }
+        }
+        if (lane == 63) { s_t[0][wave] = vi; s_t[1][wave] = vq; }
+        u32 xi = __shfl_up(vi, 1), xq = __shfl_up(vq, 1);
+        if (lane == 0) { xi = 0; xq = 0; }
+        __syncthreads();
+        u32 pi = 0, pq = 0;
+        for (int w = 0; w < wave; w++) { pi += s_t[0][w]; pq += s_t[1][w]; }
+        if (active) {
+            tau[((long) li * 2 + 0) * nruns + r] = (pi + xi) & 0x03FFFFFFu;
+            tau[((long) li * 2 + 1) * nruns + r] = (pq + xq) & 0x03FFFFFFu;
+        }
+        if (threadIdx.x == RX_THREADS - 1) {
+            wgt[((long) li * 2 + 0) * gridDim.x + blockIdx.x] = (pi + vi) & 0x03FFFFFFu;
+            wgt[((long) li * 2 + 1) * gridDim.x + blockIdx.x] = (pq + vq) & 0x03FFFFFFu;
+        }
     } else {
         {   // the bias of pass A's inputs, out of the two integrators
             const u64 len = (u64) (s1 - s0), b1 = len << 22, b2 = (len * (len + 1) / 2) << 22;
@@ -366,13 +393,28 @@ __global__ __launch_bounds__(64 * RX_SCAN_WAVES) void rx1_scan_tau_kernel(u32 *_
     }
 }
 
+// ... and of the integrator-3 totals: in = the workgroups' totals, out = integrator 3 at each workgroup's first run.
+__global__ __launch_bounds__(64) void rx1_tau_wg_kernel(u32 *__restrict__ wgt, int gx, rx_chan *__restrict__ chans, const int *__restrict__ chan_list)
+{
+    const int li = blockIdx.x >> 1, comp = blockIdx.x & 1, lane = threadIdx.x;
+    rx_chan *ch = chans + chan_list[li];
+    u32 v = lane < gx ? wgt[(long) blockIdx.x * gx + lane] : 0u;
+    const u32 i3 = ch->i3[comp];
+    for (int d = 1; d < 64; d <<= 1) { const u32 a = __shfl_up(v, d); if (lane >= d) v += a; }
+    u32 x = __shfl_up(v, 1);
+    if (lane == 0) x = 0;
+    if (lane < gx) wgt[(long) blockIdx.x * gx + lane] = (i3 + x) & 0x03FFFFFFu;
+    if (lane == 63) ch->i3[comp] = (i3 + v) & 0x03FFFFFFu;
+}
+
 // rx1 combs + rounding -> 18-bit samples appended behind the channel's history.
 // one thread per (list entry, output)
 __global__ __launch_bounds__(256) void rx1_comb_kernel(
     const u32 *__restrict__ c0rel, const u32 *__restrict__ i3start, int L, int nruns, long max_out,
     const rx_chan *__restrict__ chans, const int *__restrict__ chan_list, const long *__restrict__ nouts,
     const u32 *__restrict__ cnt_before, int *__restrict__ c1buf, long c1_stride, u32 *__restrict__ hist_out,
-    int RX_R1)
+    int RX_R1,
+    const u32 *__restrict__ wgt, int gx)      // end-referred levels: i3start[] is relative to wgt[li][comp][run / 256]; or null
 {
     const int li = blockIdx.y;
     const rx_chan *ch = chans + chan_list[li];
@@ -388,7 +430,9 @@ __global__ __launch_bounds__(256) void rx1_comb_kernel(
             if (oo < 0) v = ch->hist3[comp][3 + oo];
             else {
                 const long g = (oo + 1) * RX_R1 - 1 - (long) base;      // sample index of the strobe
-                v = (c0rel[((long) li * 2 + comp) * max_out + oo] + i3start[((long) li * 2 + comp) * nruns + (int) (g / L)]) & 0x03FFFFFFu;
+                const int run = (int) (g / L);
+                const u32 wb = wgt ? wgt[((long) li * 2 + comp) * gx + (run >> 8)] : 0u;
+                v = (c0rel[((long) li * 2 + comp) * max_out + oo] + i3start[((long) li * 2 + comp) * nruns + run] + wb) & 0x03FFFFFFu;
             }
             c0[d] = sx((int) v, 26);
             if (o == nout - 1 && d >= 1) hist_out[((long) li * 2 + comp) * 3 + (d - 1)] = v;
@@ -500,6 +544,7 @@ struct kg_rxddc {
     u32 *d_nco;
     u64 *d_st; u32 *d_c0rel, *d_tau, *d_hist;
     u64 *d_wg;                                 // [nchan][4][64]: workgroup totals / bases of the end-referred carry scan
+    u32 *d_wgt;                                // [nchan][2][64]: likewise for the integrator-3 totals
     int *d_c1buf; long c1_stride;
     int max_runs; long max_out;
     kg_stage_cache pack_cache;                 // the per-call tables of the last push (a steady stream repeats them: no upload)
@@ -540,6 +585,7 @@ int kg_rxddc_create_mode(kg_ctx *ctx, int nchan, size_t max_samples, int mode, k
     KG_HIP(hipMalloc((void **) &d->d_nco, sizeof(short) * RX_TAB));
     KG_HIP(hipMalloc((void **) &d->d_st, sizeof(u64) * 4 * (size_t) nchan * d->max_runs));
     KG_HIP(hipMalloc((void **) &d->d_wg, sizeof(u64) * 4 * (size_t) nchan * 64));
+    KG_HIP(hipMalloc((void **) &d->d_wgt, sizeof(u32) * 2 * (size_t) nchan * 64));
     KG_HIP(hipMalloc((void **) &d->d_tau, sizeof(u32) * 2 * (size_t) nchan * d->max_runs));
     KG_HIP(hipMalloc((void **) &d->d_c0rel, sizeof(u32) * 2 * (size_t) nchan * d->max_out));
     KG_HIP(hipMalloc((void **) &d->d_hist, sizeof(u32) * 6 * (size_t) nchan));
@@ -560,7 +606,7 @@ void kg_rxddc_destroy(kg_rxddc *d)
     (void) hipStreamSynchronize(d->ctx->stream);
     (void) hipFree(d->d_chans); (void) hipFree(d->d_nco); 
     
-    (void) hipFree(d->d_st); (void) hipFree(d->d_wg); (void) hipFree(d->d_tau); (void) hipFree(d->d_c0rel); (void) hipFree(d->d_hist);
+    (void) hipFree(d->d_st); (void) hipFree(d->d_wg); (void) hipFree(d->d_wgt); (void) hipFree(d->d_tau); (void) hipFree(d->d_c0rel); (void) hipFree(d->d_hist);
     (void) hipFree(d->d_c1buf);
     kg_stage_cache_free(&d->pack_cache);
     delete d;
@@ -675,7 +721,7 @@ int kg_rxddc_push_dev(kg_rxddc *d, const void *d_adc, size_t n, const int32_t *c
     static_assert(16384 / RX_THREADS <= 64, "rx1_scan_wg_kernel scans one workgroup total per lane");
     hipLaunchKernelGGL(rx1_run_kernel<false>, grid, dim3(RX_THREADS), 0, st, (const short *) d_adc, (long) n, L, nruns,
                        (const rx_chan *) d->d_chans, s_list, (const u32 *) d->d_nco, d->d_st,
-                       d->d_c0rel, d->d_tau, d->max_out, d->md, endref, d->d_wg);
+                       d->d_c0rel, d->d_tau, d->max_out, d->md, endref, d->d_wg, d->d_wgt);
     KG_HIP(hipGetLastError());
     if (endref)
         hipLaunchKernelGGL(rx1_scan_wg_kernel, dim3(2 * nlist), dim3(64), 0, st, d->d_wg, (int) grid.x, (long) n, d->d_chans, s_list);
@@ -685,16 +731,20 @@ int kg_rxddc_push_dev(kg_rxddc *d, const void *d_adc, size_t n, const int32_t *c
     KG_HIP(hipGetLastError());
     hipLaunchKernelGGL(rx1_run_kernel<true>, grid, dim3(RX_THREADS), 0, st, (const short *) d_adc, (long) n, L, nruns,
                        (const rx_chan *) d->d_chans, s_list, (const u32 *) d->d_nco, d->d_st,
-                       d->d_c0rel, d->d_tau, d->max_out, d->md, endref, d->d_wg);
+                       d->d_c0rel, d->d_tau, d->max_out, d->md, endref, d->d_wg, d->d_wgt);
     KG_HIP(hipGetLastError());
-    hipLaunchKernelGGL(rx1_scan_tau_kernel, dim3(2 * nlist), dim3(64 * RX_SCAN_WAVES), 0, st, d->d_tau, nruns, d->d_chans,
-                       s_list);
+    if (endref)
+        hipLaunchKernelGGL(rx1_tau_wg_kernel, dim3(2 * nlist), dim3(64), 0, st, d->d_wgt, (int) grid.x, d->d_chans, s_list);
+    else
+        hipLaunchKernelGGL(rx1_scan_tau_kernel, dim3(2 * nlist), dim3(64 * RX_SCAN_WAVES), 0, st, d->d_tau, nruns, d->d_chans,
+                           s_list);
     KG_HIP(hipGetLastError());
     if (max_n1 > 0) {
         hipLaunchKernelGGL(rx1_comb_kernel, dim3((unsigned) ((max_n1 + 255) / 256), nlist), dim3(256), 0, st,
                            (const u32 *) d->d_c0rel, (const u32 *) d->d_tau, L, nruns, d->max_out,
                            (const rx_chan *) d->d_chans, s_list, s_nouts,
-                           s_cnt, d->d_c1buf, d->c1_stride, d->d_hist, d->md.r1);
+                           s_cnt, d->d_c1buf, d->c1_stride, d->d_hist, d->md.r1,
+                           endref ? (const u32 *) d->d_wgt : (const u32 *) nullptr, (int) grid.x);
         KG_HIP(hipGetLastError());
     }
     if (max_final > 0) {
