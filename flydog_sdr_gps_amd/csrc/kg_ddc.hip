@@ -787,9 +787,63 @@ __global__ __launch_bounds__(64) void ddc_wf_scan_wg_kernel(
     if (lane == 63) ch->integ[comp] = state_of(sc_add(base, inc));     // the state after the block
 }
 
+#define BYP_G 4                                // groups of four samples per thread and block: a block is BYP_G x 1024 samples
+// A whole, aligned block of NB bypass channels, straight-line (the general form in the kernel spends most of its instructions
+// on the ragged cases: a branch and an exec mask per group, channel and store).
+template <int NB>
+DDC_DEV void ddc_bypass_block(const int2 (&cur)[BYP_G], long blk, const short *tab, const u64 (&inc16)[4], const u64 (&ph0)[4],
+                              short2 *const (&orow)[4])
+{
+#pragma unroll
+    for (int g = 0; g < BYP_G; g++) {
+        const long t0 = blk * (BYP_G * 1024) + g * 1024 + 4 * (long) threadIdx.x;
+        const int2 v = cur[g];
+        const short a[4] = {(short) v.x, (short) (v.x >> 16), (short) v.y, (short) (v.y >> 16)};
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            u64 ph = (ph0[b] + (u64) t0 * (inc16[b] >> 16)) << 16;    // top-aligned: wraps by itself
+            int4 w0;
+            int *w = (int *) &w0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int ec = tab[(ph >> 51) + 2048], es = tab[ph >> 51];
+                const int mi = mix24(a[q], ec), mq = mix24(a[q], es);
+                w[q] = (int) (((u32) (mi >> 8) & 0xffffu) | ((u32) (mq >> 8) << 16));      // short2 {i, q}
+                ph += inc16[b];
+            }
+            *(int4 *) (orow[b] + t0) = w0;
+        }
+    }
+}
+// The whole blocks of a pass, in a loop of their own: the next block's loads, this block's arithmetic, its stores -- nothing
+// conditional, so the wait in front of the arithmetic counts exactly the operations issued since this block's loads.
+template <int NB>
+DDC_DEV long ddc_bypass_whole(const short *__restrict__ adc, long blk, long nfb, const short *tab, const u64 (&inc16)[4],
+                              const u64 (&ph0)[4], short2 *const (&orow)[4])
+{
+    auto fetch = [&](long bk, int2 (&v)[BYP_G]) {
+#pragma unroll
+        for (int g = 0; g < BYP_G; g++) v[g] = *(const int2 *) (adc + bk * (BYP_G * 1024) + g * 1024 + 4 * (long) threadIdx.x);
+    };
+    if (blk >= nfb) return blk;
+    int2 cur[BYP_G], nxt[BYP_G];
+    fetch(blk, cur);
+    for (; blk < nfb; blk += gridDim.x) {
+        fetch(blk + gridDim.x < nfb ? blk + gridDim.x : blk, nxt);
+        // (opaque: a phase accumulator and a row address per group and channel, carried from block to block by the
+        // compiler's strength reduction, were 216 registers and two waves per SIMD)
+        long bo = blk;
+        asm volatile("" : "+s"(bo));
+        ddc_bypass_block<NB>(cur, bo, tab, inc16, ph0, orow);
+#pragma unroll
+        for (int g = 0; g < BYP_G; g++) cur[g] = nxt[g];
+    }
+    return blk;
+}
+
 // R == 1 bypass (cic_prune_var.v:289-297): out = mixer output [23 -: 16], no filter state at all,
-// so it is sample-parallel: two lane-contiguous groups of four samples per thread.
-__global__ __launch_bounds__(256) void ddc_wf_bypass_kernel(
+// so it is sample-parallel: lane-contiguous groups of four samples per thread.
+__global__ __launch_bounds__(256, 4) void ddc_wf_bypass_kernel(
     const short *__restrict__ adc, long n, const ddc_chan *__restrict__ chans, const int *__restrict__ chan_list,
     const int *__restrict__ bypass_list, int nbypass,     // list entries with R == 1
     const u32 *__restrict__ nco, short2 *__restrict__ out, long out_stride, u64 pushed,
@@ -798,49 +852,75 @@ __global__ __launch_bounds__(256) void ddc_wf_bypass_kernel(
     __shared__ short tab[DDC_TAB];
     for (int i = threadIdx.x; i < DDC_TAB / 2; i += 256) ((u32 *) tab)[i] = nco[i];
     __syncthreads();
-    // persistent over the 2048-sample blocks of the stream: the 20 KiB table is staged once per
-    // workgroup, not once per 8 KiB of output.  Round 4: ONE pass over the ADC samples for ALL bypass channels
-    // (the three R = 1 channels of BASELINE configs[2] each re-read the 32 MiB block: a third of this kernel's reads)
-    const long nblk = (n + 2047) / 2048;
-    for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        // two groups of four samples per thread, lane-contiguous: a wave's 8-byte loads cover 512
-        // contiguous bytes and its 16-byte stores 1 KiB of whole lines (eight consecutive samples per
-        // thread made every store instruction touch sixteen half-written lines)
+    // Persistent over the blocks of the stream: the 20 KiB table is staged once per workgroup.  Round 4: ONE pass over the ADC
+    // samples for ALL bypass channels (up to four at a time; the channels' parameters are read once, into scalar registers),
+    // and the kernel was LATENCY-bound on its own reads: one 8-byte load per lane, waited for where it was issued, 8 KiB in
+    // flight per CU -- 33 MB took 48 us of the kernel's 86 (knock-out builds: no stores 69 us, no table reads 83, loads alone
+    // 8.6).  Now a thread has eight loads in flight (this block's four groups and the next block's) and the whole blocks
+    // run in a straight-line loop (ddc_bypass_whole).
+    const long bs = BYP_G * 1024;
+    const long nblk = (n + bs - 1) / bs;
+    const bool al8 = (((uintptr_t) adc) & 7) == 0;
+    for (int b0 = 0; b0 < nbypass; b0 += 4) {
+        const int nb4 = nbypass - b0 < 4 ? nbypass - b0 : 4;
+        u64 inc16[4], ph0[4]; long nbs[4]; short2 *orow[4];
 #pragma unroll
-        for (int g = 0; g < 2; g++) {
-            const long t0 = blk * 2048 + g * 1024 + 4 * (long) threadIdx.x;
-            if (t0 >= n) continue;
-            short a[4];
-            const bool full = t0 + 4 <= n;
-            if (full && (((uintptr_t) (adc + t0)) & 7) == 0) {
-                const int2 v = *(const int2 *) (adc + t0);
-                a[0] = (short) v.x; a[1] = (short) (v.x >> 16); a[2] = (short) v.y; a[3] = (short) (v.y >> 16);
-            } else {
-                for (int q = 0; q < 4; q++) a[q] = (t0 + q < n) ? adc[t0 + q] : (short) 0;
-            }
-            for (int b = 0; b < nbypass; b++) {
-                const int li = bypass_list[b];
-                const long nb = nlim[li];
-                if (t0 >= nb) continue;
-                const bool fullb = t0 + 4 <= nb;
-                const ddc_chan *ch = chans + chan_list[li];
-                const u64 inc16 = ch->phase_inc << 16;
-                u64 ph = (ch->phase + (pushed + (u64) t0) * ch->phase_inc) << 16;    // top-aligned: wraps by itself
-                short2 *o = out + (long) li * out_stride + t0;
-                short2 r[4];
+        for (int b = 0; b < 4; b++) {
+            const int li = bypass_list[b0 + (b < nb4 ? b : 0)];
+            const ddc_chan *ch = chans + chan_list[li];
+            inc16[b] = ch->phase_inc << 16;
+            ph0[b] = ch->phase + pushed * ch->phase_inc;
+            nbs[b] = b < nb4 ? nlim[li] : 0;
+            orow[b] = out + (long) li * out_stride;
+        }
+        // samples up to which every channel of the four takes whole aligned blocks, rows that take 16-byte stores
+        long nfull = al8 ? n : 0;
+        bool rows16 = true;
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int ec = tab[(ph >> 51) + 2048], es = tab[ph >> 51];
-                    const int mi = mix24(a[q], ec), mq = mix24(a[q], es);
-                    r[q] = make_short2((short) (mi >> 8), (short) (mq >> 8));
-                    ph += inc16;
-                }
-                if (fullb && (((uintptr_t) o) & 15) == 0) {
-                    int4 w0;
-                    w0.x = *(int *) &r[0]; w0.y = *(int *) &r[1]; w0.z = *(int *) &r[2]; w0.w = *(int *) &r[3];
-                    *(int4 *) o = w0;
+        for (int b = 0; b < 4; b++)
+            if (b < nb4) { nfull = nbs[b] < nfull ? nbs[b] : nfull; rows16 = rows16 && (((uintptr_t) orow[b]) & 15) == 0; }
+        const long nfb = rows16 ? nfull / bs : 0;
+        long blk = blockIdx.x;
+        switch (nb4) {
+        case 1: blk = ddc_bypass_whole<1>(adc, blk, nfb, tab, inc16, ph0, orow); break;
+        case 2: blk = ddc_bypass_whole<2>(adc, blk, nfb, tab, inc16, ph0, orow); break;
+        case 3: blk = ddc_bypass_whole<3>(adc, blk, nfb, tab, inc16, ph0, orow); break;
+        default: blk = ddc_bypass_whole<4>(adc, blk, nfb, tab, inc16, ph0, orow); break;
+        }
+        // what is left: the ragged end of the stream, entries that take less than the block (a capture), unaligned rows
+        for (; blk < nblk; blk += gridDim.x) {
+            for (int g = 0; g < BYP_G; g++) {
+                const long t0 = blk * bs + g * 1024 + 4 * (long) threadIdx.x;
+                if (t0 >= n) continue;
+                short a[4];
+                const bool full = t0 + 4 <= n;
+                if (full && al8) {
+                    const int2 v = *(const int2 *) (adc + t0);
+                    a[0] = (short) v.x; a[1] = (short) (v.x >> 16); a[2] = (short) v.y; a[3] = (short) (v.y >> 16);
                 } else {
-                    for (int q = 0; q < 4; q++) if (t0 + q < nb) o[q] = r[q];
+                    for (int q = 0; q < 4; q++) a[q] = (t0 + q < n) ? adc[t0 + q] : (short) 0;
+                }
+                for (int b = 0; b < nb4; b++) {
+                    const long nb = nbs[b];
+                    if (t0 >= nb) continue;
+                    const bool fullb = t0 + 4 <= nb;
+                    u64 ph = (ph0[b] + (u64) t0 * (inc16[b] >> 16)) << 16;    // top-aligned: wraps by itself
+                    short2 *o = orow[b] + t0;
+                    short2 r[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int ec = tab[(ph >> 51) + 2048], es = tab[ph >> 51];
+                        const int mi = mix24(a[q], ec), mq = mix24(a[q], es);
+                        r[q] = make_short2((short) (mi >> 8), (short) (mq >> 8));
+                        ph += inc16[b];
+                    }
+                    if (fullb && (((uintptr_t) o) & 15) == 0) {
+                        int4 w0;
+                        w0.x = *(int *) &r[0]; w0.y = *(int *) &r[1]; w0.z = *(int *) &r[2]; w0.w = *(int *) &r[3];
+                        *(int4 *) o = w0;
+                    } else {
+                        for (int q = 0; q < 4; q++) if (t0 + q < nb) o[q] = r[q];
+                    }
                 }
             }
         }
@@ -1652,7 +1732,7 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
             KG_HIP(hipStreamWaitEvent(d->side, d->ev_fork, 0));
             bst = d->side; side_used = true;
         }
-        const long nblk_by = (n_by_max + 2047) / 2048, cap_by = (long) d->ctx->num_cus * 4;   // LDS: 20 KiB each, 4 per CU
+        const long nblk_by = (n_by_max + BYP_G * 1024 - 1) / (BYP_G * 1024), cap_by = (long) d->ctx->num_cus * 4;   // LDS: 20 KiB each, 4 per CU
         hipLaunchKernelGGL(ddc_wf_bypass_kernel, dim3((unsigned) (nblk_by < cap_by ? nblk_by : cap_by)), dim3(256),
                            0, bst, (const short *) d_adc, (long) n_by_max, (const ddc_chan *) d->d_chans, s_list,
                            s_bypass, (int) h_bypass.size(), (const u32 *) d->d_nco, (short2 *) d_out, (long) out_stride, pushed, s_nlim);
