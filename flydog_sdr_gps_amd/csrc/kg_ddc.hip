@@ -841,6 +841,54 @@ DDC_DEV long ddc_bypass_whole(const short *__restrict__ adc, long blk, long nfb,
     return blk;
 }
 
+// The same whole blocks when the caller's rows (or the sample stream) are NOT 16-byte (8-byte) aligned -- `out_stride = n + 1`
+// is enough: four single-dword stores per lane and channel at a 16-byte pitch then took the place of one 16-byte store
+// (86 us instead of 36 for 2^24 samples x 2 channels; tools/micro/bypass_rate.hip).  Transposed lane mapping instead: lane l of
+// wave w takes samples 256 w + 64 q + l (q = 0 .. 3) of a 1024-sample group, so every load instruction reads 128 contiguous
+// bytes and every store instruction writes 256, whatever the alignment.
+template <int NB>
+DDC_DEV long ddc_bypass_whole_t(const short *__restrict__ adc, long blk, long nfb, const short *tab, const u64 (&inc16)[4],
+                                const u64 (&ph0)[4], short2 *const (&orow)[4])
+{
+    const long lo = 256 * (long) (threadIdx.x >> 6) + (threadIdx.x & 63);       // this lane's first sample inside a group
+    auto fetch = [&](long bk, short (&v)[BYP_G][4]) {
+#pragma unroll
+        for (int g = 0; g < BYP_G; g++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) v[g][q] = adc[bk * (BYP_G * 1024) + g * 1024 + lo + 64 * q];
+    };
+    if (blk >= nfb) return blk;
+    short cur[BYP_G][4], nxt[BYP_G][4];
+    fetch(blk, cur);
+    for (; blk < nfb; blk += gridDim.x) {
+        fetch(blk + gridDim.x < nfb ? blk + gridDim.x : blk, nxt);
+        long bo = blk;
+        asm volatile("" : "+s"(bo));
+#pragma unroll
+        for (int g = 0; g < BYP_G; g++) {
+            const long t0 = bo * (BYP_G * 1024) + g * 1024 + lo;
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                u64 ph = (ph0[b] + (u64) t0 * (inc16[b] >> 16)) << 16;    // top-aligned: wraps by itself
+                const u64 step = inc16[b] << 6;                           // 64 samples on
+                int *o = (int *) (orow[b] + t0);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int ec = tab[(ph >> 51) + 2048], es = tab[ph >> 51];
+                    const int mi = mix24(cur[g][q], ec), mq = mix24(cur[g][q], es);
+                    o[64 * q] = (int) (((u32) (mi >> 8) & 0xffffu) | ((u32) (mq >> 8) << 16));      // short2 {i, q}
+                    ph += step;
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < BYP_G; g++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) cur[g][q] = nxt[g][q];
+    }
+    return blk;
+}
+
 // R == 1 bypass (cic_prune_var.v:289-297): out = mixer output [23 -: 16], no filter state at all,
 // so it is sample-parallel: lane-contiguous groups of four samples per thread.
 __global__ __launch_bounds__(256, 4) void ddc_wf_bypass_kernel(
@@ -874,18 +922,29 @@ __global__ __launch_bounds__(256, 4) void ddc_wf_bypass_kernel(
             orow[b] = out + (long) li * out_stride;
         }
         // samples up to which every channel of the four takes whole aligned blocks, rows that take 16-byte stores
-        long nfull = al8 ? n : 0;
+        long nfull = n;
         bool rows16 = true;
 #pragma unroll
         for (int b = 0; b < 4; b++)
             if (b < nb4) { nfull = nbs[b] < nfull ? nbs[b] : nfull; rows16 = rows16 && (((uintptr_t) orow[b]) & 15) == 0; }
-        const long nfb = rows16 ? nfull / bs : 0;
+        const long nany = nfull;                   // samples up to which every channel of the four takes whole blocks
         long blk = blockIdx.x;
-        switch (nb4) {
-        case 1: blk = ddc_bypass_whole<1>(adc, blk, nfb, tab, inc16, ph0, orow); break;
-        case 2: blk = ddc_bypass_whole<2>(adc, blk, nfb, tab, inc16, ph0, orow); break;
-        case 3: blk = ddc_bypass_whole<3>(adc, blk, nfb, tab, inc16, ph0, orow); break;
-        default: blk = ddc_bypass_whole<4>(adc, blk, nfb, tab, inc16, ph0, orow); break;
+        if (rows16 && al8) {
+            const long nfb = nfull / bs;
+            switch (nb4) {
+            case 1: blk = ddc_bypass_whole<1>(adc, blk, nfb, tab, inc16, ph0, orow); break;
+            case 2: blk = ddc_bypass_whole<2>(adc, blk, nfb, tab, inc16, ph0, orow); break;
+            case 3: blk = ddc_bypass_whole<3>(adc, blk, nfb, tab, inc16, ph0, orow); break;
+            default: blk = ddc_bypass_whole<4>(adc, blk, nfb, tab, inc16, ph0, orow); break;
+            }
+        } else {
+            const long nfb = nany / bs;
+            switch (nb4) {
+            case 1: blk = ddc_bypass_whole_t<1>(adc, blk, nfb, tab, inc16, ph0, orow); break;
+            case 2: blk = ddc_bypass_whole_t<2>(adc, blk, nfb, tab, inc16, ph0, orow); break;
+            case 3: blk = ddc_bypass_whole_t<3>(adc, blk, nfb, tab, inc16, ph0, orow); break;
+            default: blk = ddc_bypass_whole_t<4>(adc, blk, nfb, tab, inc16, ph0, orow); break;
+            }
         }
         // what is left: the ragged end of the stream, entries that take less than the block (a capture), unaligned rows
         for (; blk < nblk; blk += gridDim.x) {

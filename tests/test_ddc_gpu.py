@@ -151,6 +151,45 @@ def test_adc_block_at_any_alignment(gpu_ctx, oracle):
         d.close()
 
 
+@pytest.mark.parametrize("nby,stride_pad,shift", [(1, 4, 0), (2, 1, 0), (3, 8, 0), (5, 4, 0), (2, 4, 1), (4, 3, 2), (2, 0, 4)])
+def test_bypass_channels_rows_and_samples_at_any_alignment(gpu_ctx, oracle, nby, stride_pad, shift):
+    """R = 1 channels (ddc_wf_bypass_kernel): whole 4096-sample blocks go through a straight-line loop -- 16-byte stores when the
+    caller's rows and the sample stream are aligned, a transposed lane mapping with coalesced 4-byte stores when they are not
+    (out_stride = n + 1 is enough) -- the ragged end through the general form; one to five bypass channels (four per pass over
+    the samples) beside a filtered one, two pushes so that the phase carries."""
+    n = 5 * 4096 + 1234
+    log2rs = [0] * nby + [4]
+    adc = adc_stream(2 * n, seed=77, tones=((0.031, 7000.0), (0.2, 900.0)))
+    incs = [inc_for(0.017 + 0.019 * k) for k in range(len(log2rs))]
+    d = Ddc(gpu_ctx, nchan=len(log2rs), max_samples=n)
+    d_adc = gpu_ctx.alloc(2 * (n + 16))
+    chans = list(range(len(log2rs)))
+    stride = n + stride_pad
+    d_out = gpu_ctx.alloc(len(chans) * stride * 4)
+    try:
+        for ch, lr in enumerate(log2rs):
+            d.set_wf(ch, incs[ch], 1 << lr)
+        parts = [[] for _ in chans]
+        for piece in range(2):
+            blk = np.ascontiguousarray(adc[piece * n:(piece + 1) * n])
+            pad = np.zeros(n + 16, np.int16)
+            pad[shift:shift + n] = blk
+            gpu_ctx.upload(d_adc, pad)
+            nouts = d.push_dev(d_adc + 2 * shift, n, chans, d_out, stride)
+            host = np.zeros((len(chans), stride, 2), np.int16)
+            gpu_ctx.download(d_out, host)
+            for ch in chans:
+                parts[ch].append(host[ch, :int(nouts[ch])].copy())
+        for ch, lr in enumerate(log2rs):
+            want, _ = oracle.ddc_wf(adc, incs[ch], lr)
+            got = np.concatenate(parts[ch])
+            assert got.shape == want.shape and np.array_equal(got, want), (ch, lr)
+    finally:
+        gpu_ctx.free(d_out)
+        gpu_ctx.free(d_adc)
+        d.close()
+
+
 def test_extreme_inputs_wrap_like_the_registers(gpu_ctx, oracle):
     """Full-scale square wave at DC offset: the integrators wrap many times."""
     n = 1 << 17
