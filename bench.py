@@ -1475,6 +1475,8 @@ class ReceiverBank:
     ADC_CLOCK, UI_SRATE = 66.6666e6, 30.0e6
 
     def __init__(self, local_rank, dev, NR, n, first_rx, two_streams=True):
+        if os.environ.get("KIWIGPU_BENCH_RX_SERIAL") == "1":          # a diagnostic: every kernel of a step in ONE stream -> their times alone
+            two_streams = False
         import torch
         from flydog_sdr_gps_amd import Adpcm, Context, Ddc, FastFir, Post, RxDdc, Waterfall, WfParams, post, wf, wire
         from flydog_sdr_gps_amd.ddc import RX_DECIM, rx_phase_inc
