@@ -276,7 +276,9 @@ long kg_ddc_wf_outputs(kg_ddc *ddc, int ch, size_t n);
  * chan_list[i] writes its IQ pairs {int16 i, int16 q} (struct iq_t) to
  * d_out + i*out_stride (in pairs); nouts[i] (may be NULL) receives the count.
  * State (NCO phase, CIC registers, decimation phase) carries over to the next
- * call, so a stream may be pushed in pieces of any length.  Enqueue only. */
+ * call, so a stream may be pushed in pieces of any length.  Enqueue only.
+ * d_adc and the rows may sit at any 2- / 4-byte alignment; R = 1 channels are fastest (16-byte stores) when d_adc is
+ * 8-byte aligned and every row 16-byte aligned, i.e. d_out 16-byte aligned and out_stride a multiple of 4. */
 int kg_ddc_wf_push_dev(kg_ddc *ddc, const void *d_adc, size_t n, const int32_t *chan_list,
                        int nlist, void *d_out, size_t out_stride, int64_t *nouts);
 /* The reference's NON-OVERLAPPED waterfall frame (sample_wf(), rx/rx_waterfall.cpp:1005-1041): CmdWFReset with
