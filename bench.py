@@ -1726,10 +1726,12 @@ def run_receivers(args, dist):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_enq = time.perf_counter() - t0                 # the host's share: some thirty C-ABI calls and stream / event operations per step
     torch.cuda.synchronize(dev)                      # every stream of this rank
     local = time.perf_counter() - t0
     dist.barrier()
     elapsed = dist.max_over_ranks(local)
+    log("receivers: host enqueue %.4f ms per step, wall %.4f ms per step" % (t_enq / args.steps * 1e3, local / args.steps * 1e3))
     # sanity: the strongest carrier is in the band of every waterfall row and audio came out
     assert int(rows.max()) > 100 and counts["audio_blocks"] > 0 and int(pay.to(torch.int32).abs().sum()) > 0
     frames_total, audio_total = counts["frames"], counts["audio_blocks"]
