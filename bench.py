@@ -273,7 +273,7 @@ CPU_LEGS = {}                # workload -> cpu_baseline object, filled by cpu_le
 # ------------------------------------------------------------------------------------------------
 # HBM traffic, measured by the run that prints it
 # ------------------------------------------------------------------------------------------------
-ALL_WORKLOADS = ["acq", "wf14", "ddc14", "cfg2_chain", "receivers", "acq10ms"]     # the default line, in run order
+ALL_WORKLOADS = ["acq", "wf14", "ddc14", "cfg2_chain", "receivers", "receivers_light", "acq10ms"]     # the default line, in run order
 PMC_WORKLOADS = ALL_WORKLOADS + ["acq59"]
 PMC_STEPS = 4                # steps inside a workload's marked window of a counter pass
 LIVE_TRAFFIC = {}            # workload -> (bytes, source), filled by live_traffic_passes()
@@ -283,7 +283,7 @@ TRAFFIC_KERNELS = {"acq": ("acq_correlate_kernel<4, 1,",),
                    "acq59": ("acq_correlate_kernel<4, 1,", "acq_correlate8_kernel<4"),
                    "acq10ms": ("acq_correlate_kernel<16, 1,", "acq_correlate8_kernel<16"),
                    "wf14": ("wf_frame_kernel",),
-                   "ddc14": None, "cfg2_chain": None, "receivers": None}
+                   "ddc14": None, "cfg2_chain": None, "receivers": None, "receivers_light": None}
 
 
 def pmc_tag(workload):
@@ -511,11 +511,15 @@ def timed_steps(dist, step, steps, warmup):
 # ------------------------------------------------------------------------------------------------
 # GPS acquisition: configs[1] (4 ms) and configs[4] (10 ms)
 # ------------------------------------------------------------------------------------------------
-def acq_flops_per_cell(P, limit_quarters):
-    """Nominal FFT arithmetic of one (SV, Doppler) cell: P 4096-point sub-transforms at 5 N log2 N,
-    the N conj-multiplies (6 flops), P - 1 twiddled accumulations of 4096 points per output quarter
-    (8 + 2 flops)."""
-    return P * 5 * 4096 * 12 + 6 * P * 4096 + (P - 1) * 4096 * 10 * limit_quarters
+def acq_flops_per_cell(fft_len, window):
+    """SURVEY.md 8(d)'s figure for one (SV, Doppler) cell: 5 N log2 N for the inverse transform, 6 N for the N
+    conjugate products, 3 W for power, maximum and sum over the W lags searched (W = 4092 for C/A, 16368 for E1B) --
+    1 257 460 (C/A) and 1 294 288 (E1B) at N = 16384.  (Rounds 2-4 counted the operations of the kernels' own decomposition:
+    fewer for the C/A cells -- the pruned transform skips work --, more for the E1B cells, where it charged 40 flops per
+    point for the four output quarters the kernel forms with 14: VERDICT r4, weak 5.)"""
+    log2n = fft_len.bit_length() - 1
+    assert 1 << log2n == fft_len
+    return 5 * fft_len * log2n + 6 * fft_len + 3 * window
 
 
 class DevBytes:
@@ -627,7 +631,7 @@ def run_acq(args, dist, ten_ms=False, all_svs=False):
 
     n1 = sum(1 for sat in svs if not codes[sat][1])
     n4 = len(svs) - n1
-    flops_launch = B * ndop * (n1 * acq_flops_per_cell(P, 1) + n4 * acq_flops_per_cell(P, 4))
+    flops_launch = B * ndop * (n1 * acq_flops_per_cell(fft_len, sats.L1_LIMIT) + n4 * acq_flops_per_cell(fft_len, sats.E1B_LIMIT))
     cells = B * len(svs) * ndop
     bytes_cell = 2 * fft_len * 8 + 16                  # both spectra once + the result
     traffic, source, _ = measured_traffic(wl, B)
@@ -663,7 +667,7 @@ def run_acq(args, dist, ten_ms=False, all_svs=False):
             "frac": round(tfl / VALU_PEAK_TFLOPS, 4),
             "traffic": traffic, "traffic_source": source,
             "kernel_ms": round(kernel_ms, 5), "kernel_ms_min": k_min, "kernel_ms_median": k_med,
-            "flops_per_launch": flops_launch,
+            "flops_per_launch": flops_launch, "flops_model": "SURVEY 8(d): 5 N log2 N + 6 N + 3 W per cell",
         },
         # Secondary: SURVEY 8(d)'s per-cell byte model and, where a PMC pass exists, measured HBM bytes.
         "hbm": {
@@ -1203,8 +1207,10 @@ def run_ddc14(args, dist):
     # the kernels): NCO phase add (48 bit: 2) + 2 table reads + 2 multiplies + 2 roundings (4) = 10;
     # five integrators on I and Q, the first four 89 bits wide (3 words) and the fifth 28 (1): 2 x 13 = 26;
     # the combs and the output rounding run at 1/R and are left out.
+    # An R = 1 channel is the bypass (cic_prune_var.v:289-297): NCO + mixer only, 10 operations.
     ops_sample_chan = 36
-    tops = n * len(zooms) * ops_sample_chan / (gpu_ms * 1e-3) / 1e12
+    ops_step = n * sum(10 if p.decim == 1 else ops_sample_chan for p in prm)
+    tops = ops_step / (gpu_ms * 1e-3) / 1e12
     out_bytes = sum((n // p.decim) * 4 for p in prm)
     res = {
         "metric": "ADC Msamples/s ingested by the 14-channel waterfall DDC (NCO mix + pruned 5-stage CIC)",
@@ -1225,7 +1231,8 @@ def run_ddc14(args, dist):
                      "frac": round(tops / INT_PEAK_TOPS, 4), "traffic": traffic, "traffic_source": source,
                      "traffic_top_kernels": top,
                      "kernel_ms": round(gpu_ms, 5), "kernel_ms_min": k_min, "kernel_ms_median": k_med,
-                     "int_ops_per_sample_per_channel": ops_sample_chan},
+                     "int_ops_per_sample_per_channel": ops_sample_chan, "int_ops_per_sample_bypass_channel": 10,
+                     "int_ops_per_sample_all_channels": ops_step // n},
         "hbm": {"algorithmic_bytes_per_step": 2 * n + out_bytes,
                 "algorithmic_GBps": round((2 * n + out_bytes) / (gpu_ms * 1e-3) / 1e9, 1),
                 "measured_GBps": None if traffic is None else round(traffic / (gpu_ms * 1e-3) / 1e9, 1),
@@ -1417,8 +1424,8 @@ def run_cfg2_chain(args, dist):
     log("cfg2_chain: %d DDC pairs bit-exact and %d rows of all 14 channels checked against the oracle in %.2f s"
         % (pairs_checked, rows_checked, time.perf_counter() - t_chk))
     frames_per_step = sum(len(t[0]) for t in tabs) / cyc
-    ops_sample_chan = 36                                   # run_ddc14's count: NCO + mixer + five integrators per sample and channel
-    tops = n * C14 * ops_sample_chan / (gpu_ms * 1e-3) / 1e12
+    ops_sample_chan = 36                                   # run_ddc14's count: NCO + mixer + five integrators per sample and channel; R = 1 channels: 10
+    tops = n * sum(10 if p.decim == 1 else ops_sample_chan for p in prm) / (gpu_ms * 1e-3) / 1e12
     out_bytes = sum(4 * x for x in nout)
     alg_bytes = 2 * n + out_bytes + frames_per_step * (8192 * 4 + 1024)   # ADC in, DDC rows out, frames back in, u8 rows out
     traffic, source, top = measured_traffic("cfg2_chain", n)
@@ -1462,414 +1469,188 @@ def run_cfg2_chain(args, dist):
 
 
 # ------------------------------------------------------------------------------------------------
-# configs[3]: virtual receivers
+# configs[3]: virtual receivers -- the C ABI's receiver bank (kg_rxbank, flydog_sdr_gps_amd/rxbank.py)
 # ------------------------------------------------------------------------------------------------
-class ReceiverBank:
-    """NR virtual receivers on one GPU, each with a waterfall and an audio path, fed from one ADC
-    block resident in HBM per step (receiver k of the whole job = first_rx + local index):
-      waterfall: NCO mix + CIC decimate -> 8192-sample frame -> u8 row -> wf_pkt_t (ADPCM)
-      audio:     NCO mix + CIC/CIC/CICF decimate -> rx_iq_t -> unpack -> CFastFIR -> S-meter +
-                 CAgc (mono16) -> IMA ADPCM
-    tests/test_receivers_gpu.py steps the same object and checks every stage of every receiver
-    against the oracle."""
-    ADC_CLOCK, UI_SRATE = 66.6666e6, 30.0e6
-
-    def __init__(self, local_rank, dev, NR, n, first_rx, two_streams=True):
-        if os.environ.get("KIWIGPU_BENCH_RX_SERIAL") == "1":          # a diagnostic: every kernel of a step in ONE stream -> their times alone
-            two_streams = False
-        import torch
-        from flydog_sdr_gps_amd import Adpcm, Context, Ddc, FastFir, Post, RxDdc, Waterfall, WfParams, post, wf, wire
-        from flydog_sdr_gps_amd.ddc import RX_DECIM, rx_phase_inc
-        assert n >= 512 * 8192, "--log2n >= 22: every step must complete a waterfall frame at zoom 10"
-        self.dev, self.NR, self.n, self.first_rx = dev, NR, n, first_rx
-        # the waterfall chain and the audio chain of a receiver are independent: one context (= one
-        # stream) each, so the short latency-bound kernels of one hide under the DDC passes of the other
-        self.ctx = ctx = Context(local_rank, torch.cuda.current_stream(dev).cuda_stream)
-        self.side = torch.cuda.Stream(device=dev) if two_streams else None
-        self.ctx_au = ctx_au = Context(local_rank, self.side.cuda_stream) if two_streams else ctx
-        # the tails of both chains are sequential per-channel recurrences (ADPCM of the waterfall row; CAgc and
-        # ADPCM of the audio block: one lane per channel, 100-140 us each whatever the load): on streams of
-        # their own they no longer stand between a chain's DDC of this step and of the next one
-        # ONE stream for both tails (measured, eight hardware queues: a stream per tail 1.42 ms per step -- the two
-        # latency-bound tails running side by side with both chains; one shared tail stream 1.10 ms; tails in line 1.15 ms)
-        tails_mode = os.environ.get("KIWIGPU_BENCH_TAIL_STREAMS", "1")     # 2: a stream per tail; 1: ONE stream for both tails; 0: in line
-        # (experiments: "pk" = only the packet coder on a stream of its own, CAgc + ADPCM in line with the audio chain;
-        #  "au" = the other way round)
-        self.tails = two_streams and tails_mode != "0"
-        self.main = torch.cuda.current_stream(dev)
-        if not self.tails:
-            self.s_pk = self.s_tail = None
-        elif tails_mode == "pk":
-            self.s_pk, self.s_tail = torch.cuda.Stream(device=dev), self.side
-        elif tails_mode == "au":
-            self.s_pk, self.s_tail = self.main, torch.cuda.Stream(device=dev)
-        else:
-            self.s_pk = torch.cuda.Stream(device=dev)
-            self.s_tail = self.s_pk if tails_mode == "1" else torch.cuda.Stream(device=dev)
-        self.ctx_pk = Context(local_rank, self.s_pk.cuda_stream) if self.tails else ctx
-        self.ctx_tail = Context(local_rank, self.s_tail.cuda_stream) if self.tails else ctx_au
-        self.main = torch.cuda.current_stream(dev)
-        self.ev_frames, self.ev_pk, self.ev_fir, self.ev_tail = (torch.cuda.Event() for _ in range(4))
-        self.pk_pending = self.tail_pending = False
-        self.adc_host = adc_block(n, 0x5EED0004)                      # every GPU sees the SAME stream (configs[3])
-        self.adc = torch.from_numpy(self.adc_host).to(dev)
-        self.chans = list(range(NR))
-
-        self.d = d = Ddc(ctx, nchan=NR, max_samples=n)
-        self.W = W = Waterfall(ctx, nchan=NR)
-        W.set_tables()
-        self.params, self.rx_inc = self.receiver_params(NR, first_rx)
-        for ch, p in enumerate(self.params):
-            d.set_wf(ch, p.i_offset, p.decim)
-            W.set_channel(ch, p, interp=wf.WF_MAX, window_func=wf.WINF_HANNING, cic_comp=True)
-        self.rx = RxDdc(ctx_au, nchan=NR, max_samples=n)
-        self.nrec_max = nrec_max = n // RX_DECIM + 2
-        self.fir = FastFir(ctx_au, nchan=NR, max_in=nrec_max)
-        self.P = Post(self.ctx_tail, nchan=NR)
-        self.A = Adpcm(self.ctx_tail, nchan=NR)
-        self.fs = fs = self.ADC_CLOCK / RX_DECIM
-        for ch in range(NR):
-            self.rx.set_freq(ch, self.rx_inc[ch])
-            self.fir.setup(ch, 300.0, 2700.0, 0.0, fs)
-            self.P.set_agc(ch, True, False, -100, 50, 6, 1000, fs)
-            self.P.set_smeter(ch, fs); self.P.set_mode(ch, post.MODE_SSB); self.P.reset(ch)
-
-        # The waterfall side of a receiver takes ONE frame per step -- the reference's non-overlapped sample_wf()
-        # (rx/rx_waterfall.cpp:1005-1041): CmdWFReset, then the one-shot sampler's 8192 outputs -- kg_ddc_wf_capture_dev,
-        # straight into the frame rows.  KIWIGPU_BENCH_RX_CONTINUOUS=1: round 3's shape (the continuous sampler over the whole
-        # block, n / R outputs per channel, the first 8192 copied out), kept for the A/B.
-        self.continuous = os.environ.get("KIWIGPU_BENCH_RX_CONTINUOUS") == "1"
-        self.wf_stride = n + 1
-        self.wf_iq = torch.zeros((NR, self.wf_stride, 2), dtype=torch.int16, device=dev) if self.continuous else None
-        self.frames = torch.zeros((NR, 8192, 2), dtype=torch.int16, device=dev)
-        self.rows = torch.zeros((NR, 1024), dtype=torch.uint8, device=dev)
-        self.pkts = torch.zeros((NR, wire.WF_PKT_MAX), dtype=torch.uint8, device=dev)
-        self.raw = torch.zeros((NR, nrec_max * 6), dtype=torch.uint8, device=dev)
-        self.xin = torch.zeros((NR, nrec_max, 2), dtype=torch.float32, device=dev)
-        self.firo = torch.zeros((NR, 1024, 2), dtype=torch.float32, device=dev)
-        self.s16 = torch.zeros((NR, 512), dtype=torch.int16, device=dev)
-        self.pay = torch.zeros((NR, 256), dtype=torch.uint8, device=dev)
-        self.infos = [(int(self.params[ch].start), self.params[ch].zoom, 0, True) for ch in range(NR)]
-        self.counts = {"frames": 0, "audio_blocks": 0}
-        self.last = {}                                                # what the last step produced (counts per stage)
-        torch.cuda.synchronize(dev)                                   # buffers exist before the side stream touches them
-
-    @classmethod
-    def receiver_params(cls, NR, first_rx):
-        """Waterfall parameters and audio NCO words of receivers first_rx .. first_rx + NR - 1 of the 1024 (no GPU needed)."""
-        from flydog_sdr_gps_amd import WfParams
-        from flydog_sdr_gps_amd.ddc import rx_phase_inc
-        hz_per_start = cls.UI_SRATE / (1024 << 14)
-        params, rx_inc = [], []
-        for ch in range(NR):
-            k = first_rx + ch
-            params.append(WfParams.for_zoom(1 + k % 10, (1.0e6 + 0.2e6 * (k % 97)) / hz_per_start, adc_clock=cls.ADC_CLOCK,
-                                            ui_srate=cls.UI_SRATE))
-            rx_inc.append(rx_phase_inc(0.0123 * cls.ADC_CLOCK - 1000.0 - 10.0 * k, cls.ADC_CLOCK))
-        return params, rx_inc
-
-    def audio(self):
-        from flydog_sdr_gps_amd import snd
-        NR, chans, nrec_max = self.NR, self.chans, self.nrec_max
-        nr = self.rx.push_dev(self.adc.data_ptr(), self.n, chans, self.raw.data_ptr(), nrec_max)
-        nrec = int(nr.min())
-        assert nrec == int(nr.max())
-        snd.unpack_rows_dev(self.ctx_au, self.raw.data_ptr(), nrec_max, nrec, NR, self.xin.data_ptr(), nrec_max)
-        if self.tails and self.tail_pending:
-            self.side.wait_event(self.ev_tail)               # the tail of the step before has read firo
-            self.tail_pending = False
-        nout = self.fir.process_dev(chans, self.xin.data_ptr(), nrec_max, nrec, self.firo.data_ptr(), 1024)
-        self.last.update(nrec=nrec, nout=int(nout[0]))
-        assert int(nout.min()) == int(nout.max())
-        if int(nout[0]) == 512:
-            if self.tails:
-                self.ev_fir.record(self.side)
-                self.s_tail.wait_event(self.ev_fir)
-            self.P.process_dev(chans, self.firo.data_ptr(), 1024, 512, self.s16.data_ptr(), 0, 0, 512)
-            self.A.encode_dev(chans, self.s16.data_ptr(), 512, 512, self.pay.data_ptr(), 256)
-            if self.tails:
-                self.ev_tail.record(self.s_tail)
-                self.tail_pending = True
-            self.counts["audio_blocks"] += NR
-
-    def step(self):
-        from flydog_sdr_gps_amd import wire
-        self.audio()                                         # only enqueues, on the side stream
-        if self.continuous:
-            nw = self.d.push_dev(self.adc.data_ptr(), self.n, self.chans, self.wf_iq.data_ptr(), self.wf_stride)
-            assert int(nw.min()) >= 8192
-            self.frames.copy_(self.wf_iq[:, :8192])         # the frame each receiver's waterfall takes this step
-        else:
-            nw = self.d.capture_dev(self.adc.data_ptr(), self.n, self.chans, self.frames.data_ptr(), 8192, 8192)
-            assert int(nw.min()) == 8192 == int(nw.max())
-        self.last["nw"] = nw
-        self.steps_done = getattr(self, "steps_done", 0) + 1
-        if self.tails and self.pk_pending:
-            self.main.wait_event(self.ev_pk)                 # the packets of the step before have read rows
-            self.pk_pending = False
-        self.W.frames_dev(self.chans, self.frames.data_ptr(), self.rows.data_ptr())
-        if self.tails:
-            self.ev_frames.record(self.main)
-            self.s_pk.wait_event(self.ev_frames)
-        wire.wf_packets_dev(self.ctx_pk, self.rows.data_ptr(), 1024, self.infos, self.pkts.data_ptr())
-        if self.tails:
-            self.ev_pk.record(self.s_pk)
-            self.pk_pending = True
-        self.counts["frames"] += self.NR
-
-    def close(self):
-        for o in (self.d, self.W, self.rx, self.fir, self.P, self.A):
-            o.close()
+RX_MIX = {"receivers": "survey", "receivers_light": "light"}
 
 
-def check_receiver_bank(bank, chs, steps=3):
-    """Steps a FRESH ReceiverBank `steps` times over its ADC block and checks EVERY stage of the receivers `chs` against the
-    oracle fed the same stream with its state carried from step to step: both DDCs bit-exact on all their output, the frame
-    the waterfall took, the u8 row (tests/test_wf_gpu.py's rule), the wf_pkt_t, the unpacked audio samples bit for bit,
-    CFastFIR (1e-5 of max), CAgc mono16 (<= 1 LSB, >= 99 % identical) and the ADPCM payload.  Called by bench.py after the
-    timed region of `receivers` (a sample of the receivers) and by tests/test_receivers_gpu.py (all of them).
-    -> {"receivers": n, "steps": steps, "audio_blocks": n}"""
+def run_receivers(args, dist, wl="receivers"):
+    """BASELINE configs[3]: a bank of virtual receivers per GPU (weak scaling over ranks), stepped with ONE C call per step
+    (kg_rxbank_step).  `receivers` = SURVEY.md 8(d)'s mix (f_k = 100 kHz + k 29 kHz, zoom 8 + (k mod 4): zooms 8..10 the
+    reference's non-overlapped frame, zoom 11 its overlapped / continuous sampler); `receivers_light` = rounds 2-4's mix
+    (zooms 1..10, every frame one-shot), kept as a second named workload."""
     import numpy as np
     import torch
-    from concurrent.futures import ThreadPoolExecutor
-    from flydog_sdr_gps_amd import wf
-    from oracle import kiwi_oracle as ko
-    from tests.test_wf_gpu import check_row, db_bound, oracle_frame
-    ko.lib()
-    chs = list(chs)
-    adc = bank.adc_host
-    tables = (wf.window_functions(), wf.cic_comp_table())
-    wf_st, rx_st = {ch: None for ch in chs}, {ch: None for ch in chs}
-    fir_st = {ch: ko.fir_new_state() for ch in chs}
-    agcs = {ch: ko.Agc() for ch in chs}
-    for a in agcs.values():
-        a.set_parameters(True, False, -100, 50, 6, 1000, bank.fs)
-    ad_st = {ch: None for ch in chs}
-    audio_blocks = 0
-    with ThreadPoolExecutor(8) as pool:                          # the oracle's C calls release the GIL
-        for step in range(steps):
-            bank.step()
-            torch.cuda.synchronize(bank.dev)
-            nrec, nout, nw = bank.last["nrec"], bank.last["nout"], bank.last["nw"]
-            sel = torch.as_tensor(chs, device=bank.dev)
-            g = {k: getattr(bank, k)[sel].cpu().numpy() for k in (("wf_iq",) if bank.continuous else ()) +
-                 ("frames", "rows", "pkts", "raw", "xin", "firo", "s16", "pay")}
-
-            def wf_ref(ch):
-                p = bank.params[ch]
-                if bank.continuous:
-                    return ko.ddc_wf(adc, p.i_offset, int(np.log2(p.decim)), wf_st[ch])
-                # the non-overlapped frame: CICs reset at the block's first sample, the NCO running on from the steps before
-                st = ko.DdcWfState()
-                st.phase = (step * bank.n * p.i_offset) & ((1 << 48) - 1)
-                return ko.ddc_wf(adc[:8192 * p.decim], p.i_offset, int(np.log2(p.decim)), st)
-
-            def rx_ref(ch):
-                return ko.ddc_rx(adc, bank.rx_inc[ch], rx_st[ch])
-
-            wf_out = list(pool.map(wf_ref, chs))
-            rx_out = list(pool.map(rx_ref, chs))
-            for i, ch in enumerate(chs):
-                p = bank.params[ch]
-                # waterfall DDC: all of this step's output, then the frame the waterfall took
-                iq, wf_st[ch] = wf_out[i]
-                assert iq.shape[0] == int(nw[ch]), (step, ch)
-                if bank.continuous:
-                    assert np.array_equal(g["wf_iq"][i, :iq.shape[0]], iq), (step, ch)
-                assert np.array_equal(g["frames"][i], iq[:8192]), (step, ch)
-                w_out, _, w_pwr_out, w_dB = oracle_frame(ko, tables, iq[:8192], p, wf.WF_MAX, wf.WINF_HANNING, True, False, False)
-                check_row(g["rows"][i], w_out, w_dB, db_bound(w_pwr_out))
-                want_pkt = ko.wf_packet(g["rows"][i], int(p.start), p.zoom, 0, True)
-                assert np.array_equal(g["pkts"][i, :want_pkt.size], want_pkt), (step, ch)
-
-                # audio DDC -> rx_iq_t records -> unpack
-                raw, rx_st[ch] = rx_out[i]
-                assert raw.size == 6 * nrec, (step, ch, raw.size, nrec)
-                assert np.array_equal(g["raw"][i, :raw.size], raw), (step, ch)
-                x = ko.dpump_unpack(raw, nrec, 1)[0]
-                got_x = np.ascontiguousarray(g["xin"][i, :nrec]).view(np.complex64).ravel()
-                assert np.array_equal(got_x.view(np.uint32), x.view(np.uint32)), (step, ch)
-
-                # CFastFIR on the GPU's own input, then CAgc and ADPCM on the GPU's own upstream output
-                want_y, _ = ko.fir_process(fir_st[ch], bank.fir.get_coef(ch), got_x, prec=0)
-                assert want_y.size == nout, (step, ch, want_y.size, nout)
-                if nout:
-                    got_y = np.ascontiguousarray(g["firo"][i, :nout]).view(np.complex64).ravel()
-                    assert np.abs(got_y - want_y).max() <= 1e-5 * np.abs(want_y).max(), (step, ch)
-                    want_s = agcs[ch].process_s16(got_y)
-                    dlt = np.abs(g["s16"][i].astype(int) - want_s.astype(int))
-                    assert dlt.max() <= 1 and (dlt == 0).mean() > 0.99, (step, ch, dlt.max())
-                    want_enc, ad_st[ch] = ko.adpcm_encode_i16(g["s16"][i], ad_st[ch])
-                    assert np.array_equal(g["pay"][i], want_enc), (step, ch)
-                    audio_blocks += 1
-    return {"receivers": len(chs), "steps": steps, "audio_blocks": audio_blocks}
-
-
-def run_receivers(args, dist):
-    """BASELINE configs[3]: a ReceiverBank per GPU (weak scaling over ranks)."""
-    import numpy as np
-    import torch
+    from flydog_sdr_gps_amd.rxbank import ADC_CLOCK, MIXES, RxBank
     dev = dist.dev
-    two = os.environ.get("KIWIGPU_BENCH_ONE_STREAM") != "1"
     NR, n = args.receivers, 1 << args.log2n
-    adc_clock = ReceiverBank.ADC_CLOCK
-    bank = ReceiverBank(dist.local_rank, dev, NR, n, dist.rank * NR, two)   # this rank's slice of the receiver set
-    step, counts, rows, pay = bank.step, bank.counts, bank.rows, bank.pay
+    mix_name = RX_MIX[wl]
+    mix = MIXES[mix_name](NR, dist.rank * NR, n)                 # this rank's slice of the 1024
+    adc_host = adc_block(n, 0x5EED0004)                          # every GPU sees the SAME stream (configs[3])
+    adc = torch.from_numpy(adc_host).to(dev)
+    d_adc = adc.data_ptr()
+    torch.cuda.synchronize(dev)
 
+    def make_bank():
+        b = RxBank(NR, n, device=dist.local_rank)
+        b.configure(mix)
+        return b
+    bank = make_bank()
+
+    def step():
+        bank.step_fast(d_adc)
+
+    def sync():
+        bank.sync()
     if args.pmc_child:
-        res = pmc_window(bank.ctx, "receivers", step, lambda: torch.cuda.synchronize(dev))
+        res = pmc_window(bank.ctx, wl, step, sync)
         bank.close()
         return res
     preroll(step, args.warmup)
+    sync()
     dist.barrier()
-    counts["frames"] = counts["audio_blocks"] = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    t_enq = time.perf_counter() - t0                 # the host's share: some thirty C-ABI calls and stream / event operations per step
-    torch.cuda.synchronize(dev)                      # every stream of this rank
+    t_loop = time.perf_counter() - t0
+    sync()                                           # every stream of the bank
+    torch.cuda.synchronize(dev)
     local = time.perf_counter() - t0
     dist.barrier()
     elapsed = dist.max_over_ranks(local)
-    log("receivers: host enqueue %.4f ms per step, wall %.4f ms per step" % (t_enq / args.steps * 1e3, local / args.steps * 1e3))
-    # sanity: the strongest carrier is in the band of every waterfall row and audio came out
-    assert int(rows.max()) > 100 and counts["audio_blocks"] > 0 and int(pay.to(torch.int32).abs().sum()) > 0
-    frames_total, audio_total = counts["frames"], counts["audio_blocks"]
     step_s = elapsed / args.steps
-    world = dist.world
-    # Per-step cadence: a step's work runs on several streams (the two chains and their tails) and a step is complete when the
-    # last of them has finished it, so every stream gets an event behind each step and step i's completion time is the
-    # latest of its four; the spread is over the differences between consecutive completions.  (Round 3 took events on
-    # the main stream alone: that measures how the waterfall chain's share of a step interleaves with the other three
-    # streams -- 1.2 ... 2.8 ms on a 1.74 ms mean -- not how regularly steps complete.)
-    streams = []
-    for s_ in (bank.main, bank.side, bank.s_pk, bank.s_tail):
-        if s_ is not None and all(s_ is not x for x in streams):
-            streams.append(s_)
-    torch.cuda.synchronize(dev)
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev0.record(bank.main)
-    for s_ in streams[1:]:
-        s_.wait_event(ev0)                           # one time origin for all four
-    # (the pass starts from an idle GPU and ends by draining four streams: the first FILL and the last DRAIN intervals are
-    # the pipeline filling and emptying -- 2.0 ... 1.4 ms and 0.6 ... 0.5 ms in a trace of 24 steps -- not the cadence)
-    FILL, DRAIN = 6, 3
-    nst = args.steps + FILL + DRAIN
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in streams] for _ in range(nst)]
-    for i in range(nst):
+    # The host's share of a step.  In the loop above the host runs BANK_SLOTS steps ahead and then waits for the GPU (the
+    # step-table slot it wants is still in use): its time there is the GPU's.  What a step costs the host is measured with
+    # the GPU idle: enqueue one step, time it, drain.
+    t_enq = []
+    for _ in range(24):
+        t1 = time.perf_counter()
         step()
-        for e, s_ in zip(evs[i], streams):
-            e.record(s_)
-    torch.cuda.synchronize(dev)
-    done = [max(ev0.elapsed_time(e) for e in evs[i]) for i in range(nst)]
-    iv = [done[i + 1] - done[i] for i in range(FILL - 1, nst - DRAIN - 1)]            # args.steps steady-state intervals
-    dts = sorted(iv)
-    # the audio chain emits a 512-sample block on two steps of three (402 rx_iq_t records a step): a period-3 pattern in
-    # the work of a step; over whole audio cycles the cadence is the figure to watch
-    cyc3 = sorted(sum(iv[i:i + 3]) / 3.0 for i in range(0, len(iv) - 2, 3))
-    dts_main = sorted(evs[i][0].elapsed_time(evs[i + 1][0]) for i in range(FILL - 1, nst - DRAIN - 1))
-    if os.environ.get("KIWIGPU_BENCH_RX_TRACE") == "1":              # a diagnostic: when each stream finished each step (ms from the origin)
-        for i in range(nst):
-            log("step %2d done %8.3f  per stream %s" % (i, done[i], " ".join("%8.3f" % ev0.elapsed_time(e) for e in evs[i])))
-    # Integer work per ADC sample and receiver, counted on the algorithm: the waterfall DDC's 36 (run_ddc14) + the audio
-    # DDC's NCO / mixer (10) and rx1's three integrators on I and Q (55, 55 and 26 bits: 2 + 2 + 1 words, x 2 = 10);
-    # everything behind the first decimation (rx2, CICF, CFastFIR, CAgc, frames, coders) runs at <= 1 / 1543 of the rate.
-    # The waterfall DDC of the non-overlapped frame consumes 8192 R samples per receiver and step, not the whole block.
-    continuous = os.environ.get("KIWIGPU_BENCH_RX_CONTINUOUS") == "1"
-    wf_samples = sum(n if continuous else min(n, 8192 * p.decim) for p in bank.params)
-    ops = round((36.0 * wf_samples + 20.0 * n * NR) / (n * NR), 2)       # per receiver and ADC sample of the block
-    tops = (36.0 * wf_samples + 20.0 * n * NR) / step_s / 1e12
-    traffic, source, top = measured_traffic("receivers", NR)
+        t_enq.append(time.perf_counter() - t1)
+        sync()
+    t_enq.sort()
+    enq_us = t_enq[len(t_enq) // 2] * 1e6
+    log("%s: host enqueue %.1f us per step (median of 24, idle GPU; min %.1f), loop %.4f ms, wall %.4f ms per step"
+        % (wl, enq_us, t_enq[0] * 1e6, t_loop / args.steps * 1e3, local / args.steps * 1e3))
+    # cadence: chunks of three steps (one audio cycle: 402.7 records a step, a 512-sample block on two steps of three)
+    chunks = []
+    for _ in range(max(8, args.steps // 3)):
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            step()
+        sync()
+        chunks.append((time.perf_counter() - t1) / 3 * 1e3)
+    chunks.sort()
+    info = bank.step(d_adc)
+    sync()
+    rows = bank.fetch("rows", range(info.nframes))
+    pay = bank.fetch("pay", range(NR))
+    assert info.nframes == NR and int(rows.max()) > 100 and int(np.abs(pay.astype(np.int32)).sum()) > 0
+    frames_per_step = info.nframes
+    bank.close()
+    # Integer work per ADC sample and receiver, counted on the algorithm: the waterfall DDC's 36 (run_ddc14; R = 1 bypass
+    # channels: the NCO / mixer's 10) + the audio DDC's NCO / mixer (10) and rx1's three integrators on I and Q (55, 55 and
+    # 26 bits: 2 + 2 + 1 words, x 2 = 10); everything behind the first decimation runs at <= 1 / 1543 of the rate.  A one-shot
+    # waterfall channel consumes 8192 R samples of the block, an overlapped one all of it.
+    wf_ops = sum((10.0 if p.decim == 1 else 36.0) * (n if ov else min(n, 8192 * p.decim)) for p, ov, _ in mix)
+    wf_samples = sum(n if ov else min(n, 8192 * p.decim) for p, ov, _ in mix)
+    ops = round((wf_ops + 20.0 * n * NR) / (n * NR), 2)       # per receiver and ADC sample of the block
+    tops = (wf_ops + 20.0 * n * NR) / step_s / 1e12
+    traffic, source, top = measured_traffic(wl, NR)
     # result check at the bench's own shape: a fresh bank of the same receivers (the timed one's state is 100s of steps old),
     # three steps, every stage of a sample of the receivers (every zoom at least once) against the oracle
-    params = bank.params
-    bank.close()
     t_chk = time.perf_counter()
+    from tests.rxbank_check import check_bank
     pick = sorted(set([0, NR - 1] + [int(x) for x in np.linspace(0, NR - 1, min(NR, 12)).round()]))
-    bank2 = ReceiverBank(dist.local_rank, dev, NR, n, dist.rank * NR, two)
+    bank2 = make_bank()
     try:
-        checked = check_receiver_bank(bank2, pick)
+        checked = check_bank(bank2, lambda k: adc_host, lambda k: d_adc, pick)
     finally:
         bank2.close()
     checked["rule"] = "fresh bank, 3 steps, every stage of %d of the %d receivers vs the oracle (tests/test_receivers_gpu.py checks all)" % (len(pick), NR)
-    log("receivers: %s in %.2f s" % (checked, time.perf_counter() - t_chk))
-    # SURVEY 8(d) bytes of a step: the ADC block once, every waterfall channel's DDC row out, its frame back in and its u8
+    log("%s: %s in %.2f s" % (wl, checked, time.perf_counter() - t_chk))
+    # SURVEY 8(d) bytes of a step: the ADC block once, every waterfall channel's DDC outputs, its frame back in and its u8
     # row out (33 792 B), the audio chain's rx_iq_t records out and in + unpacked samples (6 + 6 + 8 B), a CFastFIR block
     # (16 384 B) every 512 records
     nrec_step = n / 10416.0
-    alg_bytes = 2 * n + sum(4 * ((n // p.decim) if continuous else 8192) for p in params) + NR * (8192 * 4 + 1024) + NR * nrec_step * (20 + 16384 / 512.0)
+    alg_bytes = 2 * n + sum(4 * ((n // p.decim) if ov else 8192) for p, ov, _ in mix) + NR * (8192 * 4 + 1024) + NR * nrec_step * (20 + 16384 / 512.0)
+    zooms = sorted(set(p.zoom for p, _, _ in mix))
+    n_ov = sum(1 for _, ov, _ in mix if ov)
+    world = dist.world
     res = {
         "metric": "receiver x ADC Msamples/s ingested (waterfall + audio chain per virtual receiver)",
         "value": round(n * NR * world / step_s / 1e6, 1), "unit": "Msamples/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 4),
-        "step_ms_spread": {"min": round(dts[0], 5), "median": round(dts[len(dts) // 2], 5), "max": round(dts[-1], 5),
-                           "how": "a second, untimed pass of K + 9 steps; an event on each of the step's streams behind every step, a "
-                                  "step's completion = the latest of its four; spread over the K steady-state differences between "
-                                  "consecutive completions (the first 6 and last 3, pipeline fill and drain, left out)",
-                           "per_audio_cycle_of_3_steps": {"min": round(cyc3[0], 5), "median": round(cyc3[len(cyc3) // 2], 5),
-                                                          "max": round(cyc3[-1], 5)},
-                           "main_stream_only": {"min": round(dts_main[0], 5), "median": round(dts_main[len(dts_main) // 2], 5),
-                                                "max": round(dts_main[-1], 5)}},
+        "step_ms_spread": {"min": round(chunks[0], 5), "median": round(chunks[len(chunks) // 2], 5), "max": round(chunks[-1], 5),
+                           "how": "a second, untimed pass: chunks of three steps (one audio cycle) enqueued and drained, wall time / 3"},
+        "host_enqueue_us_per_step": round(enq_us, 1),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int128/int64/f32",
         "data": "synthetic",
-        "config": {"workload": "BASELINE configs[3]: %d virtual receivers per GPU x %d GPU(s), one %d-sample 16-bit ADC "
-                               "block @66.67 MS/s (the same stream on every GPU) resident in HBM per step; per receiver a "
-                               "waterfall channel (zooms 1..10; one frame per step, %s) and an SSB audio channel (continuous)"
-                               % (NR, world, n, "continuous sampler over the whole block (round 3's shape)" if continuous else
-                                  "the reference's non-overlapped frame: CmdWFReset + one-shot sampler, rx/rx_waterfall.cpp:1005-1041"),
-                   "receivers_per_gpu": NR, "adc_samples_per_step": n,
+        "config": {"workload": "BASELINE configs[3]%s: %d virtual receivers per GPU x %d GPU(s), one %d-sample 16-bit ADC "
+                               "block @66.67 MS/s (the same stream on every GPU) resident in HBM per step; receiver mix '%s': %s; "
+                               "per receiver a waterfall channel (one frame per step: %d one-shot, rx/rx_waterfall.cpp:1005-1041, "
+                               "%d overlapped / continuous sampler, :967-991) and an SSB audio channel (continuous); the whole "
+                               "step is ONE C-ABI call (kg_rxbank_step)"
+                               % (" on rounds 2-4's lighter receiver set" if wl != "receivers" else "", NR, world, n, mix_name,
+                                  "f_k = 100 kHz + k 29 kHz, zoom 8 + (k mod 4) (SURVEY.md 8d)" if mix_name == "survey"
+                                  else "zoom 1 + (k mod 10)", NR - n_ov, n_ov),
+                   "receivers_per_gpu": NR, "adc_samples_per_step": n, "zooms": zooms, "overlapped": n_ov,
                    "parallelism": "receivers sharded over ranks, no data-path collective"},
-        "adc_ms_per_step": round(n / adc_clock * 1e3, 3),
-        "x_realtime_all_receivers": round(n / adc_clock / step_s, 2),
-        "waterfall_frames_per_s": round(frames_total * world / elapsed, 1),
-        "audio_blocks_per_s": round(audio_total * world / elapsed, 1),
+        "adc_ms_per_step": round(n / ADC_CLOCK * 1e3, 3),
+        "x_realtime_all_receivers": round(n / ADC_CLOCK / step_s, 2),
+        "waterfall_frames_per_s": round(frames_per_step * world / step_s, 1),
+        "audio_blocks_per_s": round(NR * world * (n / 10416.0 / 512.0) / step_s, 1),
         "roofline": {"bound": "valu", "kernel": "whole step (both DDCs' run passes dominate; three streams: the two chains and one for both tails)",
                      "achieved": round(tops, 3), "peak": INT_PEAK_TOPS, "unit": "Tiop/s", "frac": round(tops / INT_PEAK_TOPS, 4),
                      "traffic": traffic, "traffic_source": source, "traffic_top_kernels": top,
-                     "kernel_ms": round(step_s * 1e3, 5), "kernel_ms_min": round(dts[0], 5),
-                     "kernel_ms_median": round(dts[len(dts) // 2], 5), "int_ops_per_sample_per_receiver": ops,
+                     "kernel_ms": round(step_s * 1e3, 5), "kernel_ms_min": round(chunks[0], 5),
+                     "kernel_ms_median": round(chunks[len(chunks) // 2], 5), "int_ops_per_sample_per_receiver": ops,
                      "waterfall_ddc_samples_per_step": wf_samples, "audio_ddc_samples_per_step": n * NR},
         "hbm": {"algorithmic_bytes_per_step": int(alg_bytes),
                 "algorithmic_GBps": round(alg_bytes / step_s / 1e9, 1),
                 "measured_GBps": None if traffic is None else round(traffic / step_s / 1e9, 1), "peak": HBM_PEAK_GBS},
         "checked": checked,
     }
-    if "receivers" in CPU_LEGS:
-        res["cpu_baseline"] = CPU_LEGS["receivers"]
+    if wl in CPU_LEGS:
+        res["cpu_baseline"] = CPU_LEGS[wl]
         res["speedup_vs_cpu_all_cores"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
     return res
 
 
-def cpu_receivers(NR, n, budget_s):
+def cpu_receivers(NR, n, budget_s, mix_name="survey"):
     """The oracle on whole receivers of the bench's bank: one unit = one receiver's complete step (waterfall DDC -> frame ->
     row -> wf_pkt_t; audio DDC -> rx_iq_t -> unpack -> CFastFIR -> CAgc mono16 -> ADPCM) on the bank's ADC block."""
     import numpy as np
     from flydog_sdr_gps_amd import wf
     from flydog_sdr_gps_amd.ddc import RX_DECIM
+    from flydog_sdr_gps_amd.rxbank import ADC_CLOCK, MIXES
     from oracle import kiwi_oracle as ko
     ko.lib()
     adc = adc_block(n, 0x5EED0004)
-    params, rx_inc = ReceiverBank.receiver_params(NR, 0)
-    fs = ReceiverBank.ADC_CLOCK / RX_DECIM
+    mix = MIXES[mix_name](NR, 0, n)
+    fs = ADC_CLOCK / RX_DECIM
     tables = (wf.window_functions(), wf.cic_comp_table())
     coef = ko.fir_design(300.0, 2700.0, 0.0, fs, prec=0)[1]
-    continuous = os.environ.get("KIWIGPU_BENCH_RX_CONTINUOUS") == "1"
     k = [os.getpid() % NR]                            # (workers are forked: each walks the receivers from its own start)
 
     def unit():
         ch = k[0] % NR
         k[0] += 1
-        p = params[ch]
-        # the non-overlapped frame (CmdWFReset + one-shot sampler): the 8192 R samples that fill the sampler, as the GPU path
-        iq, _ = ko.ddc_wf(adc[:8192 * p.decim] if not continuous else adc, p.i_offset, int(np.log2(p.decim)))
+        p, ov, rx_inc = mix[ch]
+        # one-shot: the 8192 R samples that fill the sampler; overlapped: the whole block through the continuous sampler
+        # (its n / R outputs are half of the frame the step then takes: repeated here to make one)
+        iq, _ = ko.ddc_wf(adc if ov else adc[:8192 * p.decim], p.i_offset, int(np.log2(p.decim)))
+        if ov:
+            iq = np.concatenate([iq] * (8192 // iq.shape[0]))
         fmap, drop = wf.build_maps(p.fft_used, p.plot_width, p.plot_width_clamped, False)
         scale = np.full(1024, p.fft_scale, np.float32)
         samps = ko.wf_window_iq(iq[:8192], tables[0][wf.WINF_HANNING])
-        row = ko.wf_compute_frame(samps, p.zoom, wf.WINF_HANNING, wf.WF_MAX, True, False, p.fft_used, p.plot_width,
+        row = ko.wf_compute_frame(samps, p.zoom, wf.WINF_HANNING, wf.WF_MAX, True, bool(ov), p.fft_used, p.plot_width,
                                   p.plot_width_clamped, fmap, drop, scale, (scale / np.float32(2)).astype(np.float32),
                                   p.fft_offset, tables[1], prec=0)[0]
         ko.wf_packet(row, int(p.start), p.zoom, 0, True)
-        raw, _ = ko.ddc_rx(adc, rx_inc[ch])
+        raw, _ = ko.ddc_rx(adc, rx_inc)
         nrec = raw.size // 6
         x = ko.dpump_unpack(raw, nrec, 1)[0]
         y, _ = ko.fir_process(ko.fir_new_state(), coef, x, prec=0)
@@ -1879,9 +1660,9 @@ def cpu_receivers(NR, n, budget_s):
             ko.adpcm_encode_i16(agc.process_s16(y[:512]))
     reps, el, cores, t1 = cpu_threads(unit, budget_s)
     return {"value": round(reps * n / el / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": "%d x (one virtual receiver over the step's %d ADC samples: both chains, every stage; the DDCs are the "
+            "sample": "%d x (one virtual receiver of the '%s' mix over the step's %d ADC samples: both chains, every stage; the DDCs are the "
                       "oracle's sequential Verilog-structured models -- in the reference they are FPGA fabric), %d worker processes, %.1f s"
-                      % (reps, n, cores, el),
+                      % (reps, mix_name, n, cores, el),
             "single_thread_value": round(n / t1 / 1e6, 4)}
 
 
@@ -1977,7 +1758,7 @@ def cpu_legs(args):
     T = args.cpu_seconds
 
     def log2n_for(wl):
-        return args.log2n if args.log2n_given else (22 if wl == "receivers" else 24)
+        return args.log2n if args.log2n_given else (22 if wl in RX_MIX else 24)
     for wl in wls:
         if wl == "acq":
             codes = [(prn.cacode(sats.SATS[s][1], sats.SATS[s][2]), False) for s in range(NSV)]
@@ -1993,8 +1774,8 @@ def cpu_legs(args):
             CPU_LEGS[wl] = cpu_ddc14(1 << log2n_for(wl), T)
         elif wl == "cfg2_chain":
             CPU_LEGS[wl] = cpu_cfg2_chain(1 << log2n_for(wl), T)
-        elif wl == "receivers":
-            CPU_LEGS[wl] = cpu_receivers(args.receivers, 1 << log2n_for(wl), T)
+        elif wl in RX_MIX:
+            CPU_LEGS[wl] = cpu_receivers(args.receivers, 1 << log2n_for(wl), T, RX_MIX[wl])
         log("cpu_baseline %s: %s %s on %d cores" % (wl, CPU_LEGS[wl]["value"], CPU_LEGS[wl]["unit"], CPU_LEGS[wl]["cores"]))
 
 
@@ -2055,10 +1836,27 @@ def by_workload_table(rs):
     return tab
 
 
+def summary_line(line):
+    """<= 400 characters: `SUMMARY wl=ms_per_step/frac+bound/traffic:algorithmic/check ...` for every workload of the line."""
+    wls = dict(line.get("workloads") or {})
+    if not wls:
+        wls = {line.get("config", {}).get("workload", "?")[:8] if "workloads" in line else "run": line}
+    out = []
+    for wl, r in wls.items():
+        rf, hb = r.get("roofline", {}), r.get("hbm", {})
+        alg = hb.get("algorithmic_bytes_per_launch") or hb.get("algorithmic_bytes_per_step")
+        tr = rf.get("traffic")
+        ok = "ok" if (r.get("checked") or r.get("found_svs")) else "-"
+        out.append("%s=%.3f/%s%s/%s/%s" % (wl.replace("receivers", "rx").replace("cfg2_chain", "chain"), r.get("ms_per_step") or 0.0,
+                                          ("%.3f" % rf["frac"]) if rf.get("frac") is not None else "-", (rf.get("bound") or "-")[0],
+                                          ("%.1fx" % (tr / alg)) if (tr and alg) else "-", ok))
+    return ("SUMMARY ms/frac+roof/traffic:alg/check " + " ".join(out))[:400]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="all",
-                    choices=["all", "acq", "acq59", "acq10ms", "wf14", "ddc14", "cfg2_chain", "waterfall", "ddc", "receivers", "stub"])
+                    choices=["all", "acq", "acq59", "acq10ms", "wf14", "ddc14", "cfg2_chain", "waterfall", "ddc", "receivers", "receivers_light", "stub"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
@@ -2106,7 +1904,7 @@ def main():
               "scaling": "weak", "vs_baseline": None, "data": "synthetic"}
 
     def log2n_for(wl):
-        return args.log2n if args.log2n_given else (22 if wl == "receivers" else 24)
+        return args.log2n if args.log2n_given else (22 if wl in RX_MIX else 24)
 
     def run(wl):
         import copy
@@ -2114,12 +1912,12 @@ def main():
         a.log2n = log2n_for(wl)
         if args.workload == "all" and wl == "acq10ms":
             a.steps, a.warmup = min(args.steps, 20), min(args.warmup, 3)       # 3.4 ms steps; the default K = 200 is sized for acq
-        if args.workload == "all" and wl == "receivers":
+        if args.workload == "all" and wl in RX_MIX:
             a.steps, a.warmup = min(args.steps, 40), min(args.warmup, 4)
         fn = {"acq": lambda: run_acq(a, dist), "acq10ms": lambda: run_acq(a, dist, ten_ms=True),
               "acq59": lambda: run_acq(a, dist, all_svs=True), "wf14": lambda: run_wf14(a, dist),
               "ddc14": lambda: run_ddc14(a, dist), "cfg2_chain": lambda: run_cfg2_chain(a, dist),
-              "receivers": lambda: run_receivers(a, dist)}[wl]
+              "receivers": lambda: run_receivers(a, dist), "receivers_light": lambda: run_receivers(a, dist, "receivers_light")}[wl]
         log("workload %s ..." % wl)
         r = fn()
         if dist.dev is not None:
@@ -2184,6 +1982,12 @@ def main():
     if dist.rank == 0:
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     dist.close()
+    if dist.rank == 0 and args.workload != "stub" and not args.pmc_child:
+        # The LAST line on stderr: every workload's step time, roofline fraction + the roof that binds it (v: vector
+        # arithmetic, h: HBM), counter traffic / algorithmic bytes, and whether its post-timed-region result check ran --
+        # a record that keeps only the tail of stderr still holds all of them.
+        sys.stderr.write(summary_line(line) + "\n")
+        sys.stderr.flush()
 
 
 if __name__ == "__main__":

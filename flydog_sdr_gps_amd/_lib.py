@@ -7,7 +7,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class KiwiGpuError(RuntimeError):
@@ -151,6 +151,25 @@ SYMBOLS = {
     "kg_aper_update_dev": (_i, [_vp, _vp, _i, _vp, _sz, _vp, _i]),
     "kg_aper_report": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "kg_aper_get": (_i, [_vp, _i, _vp]),
+    "kg_ddc_wf_step_dev": (_i, [_vp, _vp, _sz, _vp, _i, _vp, _sz, _vp, _vp, _vp]),
+    "kg_rxbank_create": (_i, [_i, _i, _sz, _i, C.POINTER(_vp)]),
+    "kg_rxbank_destroy": (None, [_vp]),
+    "kg_rxbank_ctx": (_vp, [_vp]),
+    "kg_rxbank_ddc": (_vp, [_vp]),
+    "kg_rxbank_wf": (_vp, [_vp]),
+    "kg_rxbank_rxddc": (_vp, [_vp]),
+    "kg_rxbank_fir": (_vp, [_vp]),
+    "kg_rxbank_post": (_vp, [_vp]),
+    "kg_rxbank_adpcm": (_vp, [_vp]),
+    "kg_rxbank_set_wf": (_i, [_vp, _i, C.c_uint64, _i, _i]),
+    "kg_rxbank_set_wf_pkt": (_i, [_vp, _i, C.c_uint32, C.c_uint32, _i]),
+    "kg_rxbank_set_unpack": (_i, [_vp, C.c_float, C.c_float, C.c_float, _i]),
+    "kg_rxbank_step": (_i, [_vp, _vp, _vp, _vp]),
+    "kg_rxbank_adc_done": (_i, [_vp, _vp]),
+    "kg_rxbank_poll": (_i, [_vp]),
+    "kg_rxbank_sync": (_i, [_vp]),
+    "kg_rxbank_frame_map": (_i, [_vp, _vp, _vp, _vp]),
+    "kg_rxbank_buffers": (_i, [_vp, _vp]),
     "kg_acq_debug_fft_stamps": (_i, [_vp, _i, _vp, _i]),
     "kg_acq_debug_corr_stamps": (_i, [_vp, _i, _vp, _i, _vp, _i]),
 }
@@ -207,6 +226,18 @@ def check(status, where):
     return status
 
 
+def borrow(cls, ctx, handle, **attrs):
+    """An object of one of the wrapper classes (Ddc, Waterfall, RxDdc, FastFir, Post, Adpcm) over a handle another object
+    owns -- the per-seam objects of a receiver bank (kg_rxbank_ddc() ...): every method works, close() leaves the handle alone."""
+    self = cls.__new__(cls)
+    self.ctx, self.lib = ctx, ctx.lib
+    self.h = C.c_void_p(handle) if isinstance(handle, int) else handle
+    self._borrowed = True
+    for k, v in attrs.items():
+        setattr(self, k, v)
+    return self
+
+
 def ptr(a):
     """void* of a numpy array, or pass through an int device pointer."""
     if a is None:
@@ -232,9 +263,20 @@ class Context:
         self.h = h
         self.device = device
 
+    @classmethod
+    def borrow(cls, handle, device=0):
+        """A Context over a kg_ctx another object owns (a receiver bank's): close() leaves it alone."""
+        self = cls.__new__(cls)
+        self.lib = load_library()
+        self.h = C.c_void_p(handle) if isinstance(handle, int) else handle
+        self.device = device
+        self._borrowed = True
+        return self
+
     def close(self):
         if getattr(self, "h", None):
-            self.lib.kg_ctx_destroy(self.h)
+            if not getattr(self, "_borrowed", False):
+                self.lib.kg_ctx_destroy(self.h)
             self.h = None
 
     def __del__(self):

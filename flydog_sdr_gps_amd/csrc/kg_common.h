@@ -28,6 +28,22 @@ void kg_set_error(const char *fmt, ...);
         }                                                                          \
     } while (0)
 
+// One step's small tables of EVERY stage of a receiver bank in one pinned host block, uploaded with ONE transfer
+// (kg_rxbank.hip).  While a context's `arena` is set and active, kg_ctx_stage / kg_ctx_stage_cached[_ways] neither copy
+// nor cache: in the PLAN pass they append the table to the host block and answer the address it will have on the
+// device (the entry point then returns before its first launch and before it touches its state: KG_PLAN_ONLY); in the
+// REPLAY pass -- the same calls with the same arguments, after the block's one upload was enqueued -- they answer the same
+// addresses again, checking that the table is the one planned.
+enum { KG_ARENA_OFF = 0, KG_ARENA_PLAN = 1, KG_ARENA_REPLAY = 2 };
+#define KG_ARENA_MAX_ENTRIES 32
+struct kg_arena {
+    int mode;
+    unsigned char *h_base, *d_base;           // the current slot of the owner's ring (pinned host / device)
+    size_t cap, used;
+    int nent, cursor;
+    size_t off[KG_ARENA_MAX_ENTRIES], len[KG_ARENA_MAX_ENTRIES];
+};
+
 struct kg_ctx {
     int device;
     hipStream_t stream;
@@ -50,7 +66,12 @@ struct kg_ctx {
     unsigned char *h_ring, *d_ring;
     hipEvent_t ring_ev[32];
     unsigned long ring_next;
+    kg_arena *arena;                          // a receiver bank's step tables (null: the ring / the caches above)
 };
+
+// An enqueue-only entry point that stages its tables through kg_ctx_stage* puts this right behind the (last) staging
+// call: in a bank's PLAN pass the call ends here -- nothing launched, no state advanced.
+#define KG_PLAN_ONLY(ctx_) do { if ((ctx_)->arena && (ctx_)->arena->mode == KG_ARENA_PLAN) return KG_OK; } while (0)
 
 #define KG_RING_SLOTS 32
 #define KG_RING_SLOT_BYTES ((size_t) 512 * 1024)

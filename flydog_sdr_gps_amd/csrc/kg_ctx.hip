@@ -31,9 +31,29 @@ int kg_ctx_scratch_upload(kg_ctx *c, const void *src, size_t bytes, void **d_out
     return KG_OK;
 }
 
+// A bank's step tables (kg_arena, kg_common.h): plan = append, replay = the same address again.
+static int arena_stage(kg_arena *a, const void *src, size_t bytes, void **d_out)
+{
+    if (a->mode == KG_ARENA_PLAN) {
+        const size_t at = (a->used + 63) & ~(size_t) 63;
+        KG_REQUIRE(a->nent < KG_ARENA_MAX_ENTRIES && at + bytes <= a->cap, KG_ERR_NOMEM,
+                   "step tables: entry %d of %zu bytes does not fit (%zu of %zu used)", a->nent, bytes, a->used, a->cap);
+        memcpy(a->h_base + at, src, bytes);
+        a->off[a->nent] = at; a->len[a->nent] = bytes; a->nent++;
+        a->used = at + bytes;
+        *d_out = a->d_base + at;
+        return KG_OK;
+    }
+    KG_REQUIRE(a->cursor < a->nent && a->len[a->cursor] == bytes && memcmp(a->h_base + a->off[a->cursor], src, bytes) == 0,
+               KG_ERR_STATE, "step tables: replayed table %d (%zu bytes) is not the planned one", a->cursor, bytes);
+    *d_out = a->d_base + a->off[a->cursor++];
+    return KG_OK;
+}
+
 int kg_ctx_stage(kg_ctx *c, const void *src, size_t bytes, void **d_out)
 {
     KG_REQUIRE(c && src && d_out && bytes > 0, KG_ERR_INVALID, "kg_ctx_stage: bad argument");
+    if (c->arena && c->arena->mode != KG_ARENA_OFF) return arena_stage(c->arena, src, bytes, d_out);
     if (bytes > KG_RING_SLOT_BYTES) return kg_ctx_scratch_upload(c, src, bytes, d_out);
     if (!c->h_ring) {
         KG_HIP(hipHostMalloc((void **) &c->h_ring, KG_RING_SLOTS * KG_RING_SLOT_BYTES, hipHostMallocDefault));
@@ -58,6 +78,7 @@ int kg_ctx_stage(kg_ctx *c, const void *src, size_t bytes, void **d_out)
 int kg_ctx_stage_cached(kg_ctx *c, kg_stage_cache *sc, const void *src, size_t bytes, void **d_out)
 {
     KG_REQUIRE(c && sc && src && d_out && bytes > 0, KG_ERR_INVALID, "kg_ctx_stage_cached: bad argument");
+    if (c->arena && c->arena->mode != KG_ARENA_OFF) return arena_stage(c->arena, src, bytes, d_out);
     if (sc->dev && sc->bytes == bytes && memcmp(sc->host, src, bytes) == 0) { *d_out = sc->dev; return KG_OK; }
     if (bytes > sc->cap) {                      // grows rarely: drain, then replace both copies
         KG_HIP(hipStreamSynchronize(c->stream));
@@ -83,6 +104,7 @@ int kg_ctx_stage_cached(kg_ctx *c, kg_stage_cache *sc, const void *src, size_t b
 int kg_ctx_stage_cached_ways(kg_ctx *c, kg_stage_cache *sc, int ways, int *victim, const void *src, size_t bytes, void **d_out)
 {
     KG_REQUIRE(c && sc && victim && src && d_out && bytes > 0 && ways >= 1, KG_ERR_INVALID, "kg_ctx_stage_cached_ways: bad argument");
+    if (c->arena && c->arena->mode != KG_ARENA_OFF) return arena_stage(c->arena, src, bytes, d_out);
     for (int w = 0; w < ways; w++)
         if (sc[w].dev && sc[w].bytes == bytes && memcmp(sc[w].host, src, bytes) == 0) { *d_out = sc[w].dev; return KG_OK; }
     const int v = *victim % ways;
@@ -99,6 +121,14 @@ void kg_stage_cache_free(kg_stage_cache *sc)
 }
 
 __global__ void kg_mark_kernel() {}
+
+// The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order; streams
+// beyond that SHARE a queue and run in order with whoever they share it with.  A receiver bank uses four streams and the
+// DDC objects bring their own: with four queues `receivers` ran 1.28 ms per step, with eight 0.98 (round 4: which streams
+// serialise then depends on what else created a stream first).  The runtime reads the variable when it initialises, so
+// the library asks for eight when it is loaded -- unless the host has set the variable itself, and without effect (or
+// harm) if the host initialised HIP before loading the library.
+__attribute__((constructor)) static void kg_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 extern "C" {
 

@@ -295,7 +295,7 @@ DDC_DEV void ddc_wf_run_body(
     int stage_bytes,                          // pass B, R <= 8: dynamic LDS for the strobe staging tiles, else 0
     u64 pushed,                               // samples pushed since the channels' reference point (ddc_chan)
     const long *__restrict__ nlim,            // [nlist] samples of the block this entry consumes (capture: 8192 R; else n)
-    int reset_first,                          // capture: the decimation counter starts the block at zero (rst_wf_samp_wr)
+    const int *__restrict__ reset_tab,        // [nlist] capture: the decimation counter starts the block at zero (rst_wf_samp_wr)
     int endref,                               // states in `local` are referred to the END of the entry's share (sc_Tinv above)
     const ddc_endco *__restrict__ endco, long endco_n,    // [nruns + 1] coefficients of the distances n - k L for a share of endco_n samples
     const ddc_state4 *__restrict__ wgbase,    // endref == 2, pass B: [nlist][2][gridDim.x] what the workgroup's first run adds to local[]
@@ -308,6 +308,7 @@ DDC_DEV void ddc_wf_run_body(
     __syncthreads();
     const int li = sel ? sel[blockIdx.y] : (int) blockIdx.y;
     const ddc_chan ch = chans[chan_list[li]];
+    const int reset_first = reset_tab[li];
     const int r = blockIdx.x * DDC_THREADS + threadIdx.x;
     n = nlim[li];                             // this entry's share of the block (wave-uniform)
     if (r >= nruns || (long) r * L >= n) return;
@@ -703,7 +704,7 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
     const ddc_chan *__restrict__ chans, const int *__restrict__ chan_list, const u32 *__restrict__ nco,
     ddc_state4 *__restrict__ local, u32 *__restrict__ c0rel, u32 *__restrict__ tau,
     const long *__restrict__ c0off, const long *__restrict__ nouts, const int *__restrict__ sel, int stage_bytes,
-    u64 pushed, const long *__restrict__ nlim, int reset_first, int endref,
+    u64 pushed, const long *__restrict__ nlim, const int *__restrict__ reset_tab, int endref,
     const ddc_endco *__restrict__ endco, long endco_n,
     ddc_state4 *__restrict__ wgtot,           // pass A, endref == 2: [nlist][2][gridDim.x] out
     const ddc_state4 *__restrict__ wgbase,    // pass B, endref == 2: [nlist][2][gridDim.x] in
@@ -713,7 +714,7 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
     bool have = false;
     u32 oTi = 0, oTq = 0;
     ddc_wf_run_body<PASS_B>(adc, n, L, nruns, chans, chan_list, nco, local, c0rel, tau, c0off, nouts, sel, stage_bytes, pushed,
-                            nlim, reset_first, endref, endco, endco_n, wgbase, oI, oQ, have, oTi, oTq);
+                            nlim, reset_tab, endref, endco, endco_n, wgbase, oI, oQ, have, oTi, oTq);
     if (PASS_B && endref == 2) {
         // The prefix of the runs' integrator-5 totals in the same levels: tau[r] = the sum of the workgroup's runs before r,
         // wgtau = the workgroup's total; ddc_wf_tau_wg_kernel turns the totals into each workgroup's absolute start value and
@@ -770,11 +771,12 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
 // The third level: one wave per (channel, I/Q) over its workgroup totals (at most 64: max_runs / 256).
 __global__ __launch_bounds__(64) void ddc_wf_scan_wg_kernel(
     const ddc_state4 *__restrict__ wgtot, ddc_state4 *__restrict__ wgbase, int gx, ddc_chan *__restrict__ chans,
-    const int *__restrict__ chan_list, const long *__restrict__ nlim, int reset_first)
+    const int *__restrict__ chan_list, const long *__restrict__ nlim, const int *__restrict__ reset_tab)
 {
     const int pair = blockIdx.x, li = pair >> 1, comp = pair & 1, lane = threadIdx.x;
     ddc_chan *ch = chans + chan_list[li];
     if (ch->log2r == 0) return;
+    const int reset_first = reset_tab[li];
     sc4 inc = lane < gx ? sc_of(wgtot[(long) pair * gx + lane]) : sc_zero();
     // the carried-in state, advanced to the end of the entry's share (lane 0; the loads above are in flight meanwhile)
     sc4 base = sc_zero();
@@ -895,7 +897,8 @@ __global__ __launch_bounds__(256, 4) void ddc_wf_bypass_kernel(
     const short *__restrict__ adc, long n, const ddc_chan *__restrict__ chans, const int *__restrict__ chan_list,
     const int *__restrict__ bypass_list, int nbypass,     // list entries with R == 1
     const u32 *__restrict__ nco, short2 *__restrict__ out, long out_stride, u64 pushed,
-    const long *__restrict__ nlim)            // [nlist] samples this entry takes (capture: max_out; else n)
+    const long *__restrict__ nlim,            // [nlist] samples this entry takes (capture: max_out; else n)
+    const long *__restrict__ out_off)         // [nlist] entry li writes at out + li out_stride + out_off[li]
 {
     __shared__ short tab[DDC_TAB];
     for (int i = threadIdx.x; i < DDC_TAB / 2; i += 256) ((u32 *) tab)[i] = nco[i];
@@ -919,7 +922,7 @@ __global__ __launch_bounds__(256, 4) void ddc_wf_bypass_kernel(
             inc16[b] = ch->phase_inc << 16;
             ph0[b] = ch->phase + pushed * ch->phase_inc;
             nbs[b] = b < nb4 ? nlim[li] : 0;
-            orow[b] = out + (long) li * out_stride;
+            orow[b] = out + (long) li * out_stride + out_off[li];
         }
         // samples up to which every channel of the four takes whole aligned blocks, rows that take 16-byte stores
         long nfull = n;
@@ -1028,7 +1031,7 @@ __global__ __launch_bounds__(64 * DDC_SCAN_WAVES) void ddc_wf_scan_states_kernel
     ddc_state4 *__restrict__ local, long n, int L, int nruns, ddc_chan *__restrict__ chans,
     const int *__restrict__ chan_list, int npairs, int nchunk, ddc_chunk_agg *__restrict__ aggs,
     u32 *__restrict__ ticket, u32 ticket_base, u32 epoch, const sc_tab tab,
-    const long *__restrict__ nlim, int reset_first)      // per entry: samples consumed; capture: the carried-in state is zero
+    const long *__restrict__ nlim, const int *__restrict__ reset_tab)      // per entry: samples consumed; capture: the carried-in state is zero
 {
     __shared__ sc4 w_state[DDC_SCAN_WAVES];
     __shared__ u64 w_len[DDC_SCAN_WAVES];
@@ -1043,6 +1046,7 @@ __global__ __launch_bounds__(64 * DDC_SCAN_WAVES) void ddc_wf_scan_states_kernel
     const int li = pair >> 1, comp = pair & 1;
     ddc_chan *ch = chans + chan_list[li];
     if (ch->log2r == 0) return;                   // (the whole pair: nobody waits for a bypass channel)
+    const int reset_first = reset_tab[li];
     ddc_state4 *st = local + ((long) li * 2 + comp) * nruns;        // (rows of the whole launch's run count apart)
     n = nlim[li];                                 // this entry's share of the block and the runs that hold it
     { const int nr = (int) ((n + L - 1) >> (31 - __builtin_clz(L))); nruns = nr < nruns ? nr : nruns; }    // L is a power of two
@@ -1132,11 +1136,12 @@ __global__ __launch_bounds__(64 * DDC_SCAN_WAVES) void ddc_wf_scan_states_kernel
 
 // ... and of the integrator-5 totals: in = the workgroups' totals, out = integrator 5 at each workgroup's first run.
 __global__ __launch_bounds__(64) void ddc_wf_tau_wg_kernel(u32 *__restrict__ wgtau, int gx, ddc_chan *__restrict__ chans,
-                                                          const int *__restrict__ chan_list, int reset_first)
+                                                          const int *__restrict__ chan_list, const int *__restrict__ reset_tab)
 {
     const int pair = blockIdx.x, li = pair >> 1, comp = pair & 1, lane = threadIdx.x;
     ddc_chan *ch = chans + chan_list[li];
     if (ch->log2r == 0) return;
+    const int reset_first = reset_tab[li];
     u32 v = lane < gx ? wgtau[(long) pair * gx + lane] : 0u;
     const u32 i5 = reset_first ? 0u : ch->integ5[comp];
     for (int d = 1; d < 64; d <<= 1) { const u32 a = __shfl_up(v, d); if (lane >= d) v += a; }
@@ -1154,13 +1159,14 @@ __global__ __launch_bounds__(64) void ddc_wf_tau_wg_kernel(u32 *__restrict__ wgt
 #define DDC_TAU_TILES 32                      // max_runs = 16384 = 32 tiles of 512
 __global__ __launch_bounds__(64 * DDC_SCAN_WAVES) void ddc_wf_scan_tau_kernel(
     u32 *__restrict__ tau, int nruns, ddc_chan *__restrict__ chans, const int *__restrict__ chan_list,
-    const long *__restrict__ nlim, int L, int reset_first)
+    const long *__restrict__ nlim, int L, const int *__restrict__ reset_tab)
 {
     __shared__ u32 s_tot[DDC_TAU_TILES * DDC_SCAN_WAVES];       // totals, then exclusive offsets
     __shared__ u32 s_w4[4];
     const int li = blockIdx.x >> 1, comp = blockIdx.x & 1, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = threadIdx.x;
     ddc_chan *ch = chans + chan_list[li];
     if (ch->log2r == 0) return;
+    const int reset_first = reset_tab[li];
     u32 *tv = tau + ((long) li * 2 + comp) * nruns;
     {   // the runs this entry walked (li comes from blockIdx: a scalar load, a scalar ntile)
         const int nr = (int) ((nlim[li] + L - 1) >> (31 - __builtin_clz(L)));       // L is a power of two
@@ -1240,9 +1246,10 @@ __global__ __launch_bounds__(256) void ddc_wf_comb_kernel(
     const u32 *__restrict__ c0rel, const u32 *__restrict__ i5start, int log2L, int nruns,
     const long *__restrict__ c0off, const ddc_chan *__restrict__ chans, const int *__restrict__ chan_list, const long *__restrict__ nouts,
     u64 pushed,                               // samples pushed since the channels' reference point
-    int reset_first,                          // capture: counter and comb registers start the block at zero
+    const int *__restrict__ reset_tab,        // [nlist] capture: counter and comb registers start the block at zero
     const int *__restrict__ wg_start, int nlist,
-    short2 *__restrict__ out, long out_stride, u32 *__restrict__ hist_out,   // [nlist][2][5]
+    short2 *__restrict__ out, long out_stride, const long *__restrict__ out_off,   // entry li writes at out + li out_stride + out_off[li]
+    u32 *__restrict__ hist_out,               // [nlist][2][5]
     const u32 *__restrict__ wgtau, int gx)    // end-referred levels: i5start[] is relative to its run pass workgroup's start value wgtau[li][comp][run / 256]; or null
 {
     __shared__ __attribute__((aligned(16))) int s_c0[2][DDC_COMB_TILE + 8];       // [d]: output o0 - 8 + d (three unused slots keep 16-byte rows)
@@ -1251,6 +1258,7 @@ __global__ __launch_bounds__(256) void ddc_wf_comb_kernel(
     const int li = lo, t = threadIdx.x;
     const ddc_chan *ch = chans + chan_list[li];
     const int log2r = ch->log2r;
+    const int reset_first = reset_tab[li];
     const long nout = nouts[li], plane = (nout + 3) & ~3l;
     const long o0 = (long) (blockIdx.x - wg_start[li]) * DDC_COMB_TILE;
     const u32 base = reset_first ? 0u : (u32) (((u64) ch->sample_no + pushed) & ((1ull << log2r) - 1));     // sample_no before this call
@@ -1323,7 +1331,7 @@ __global__ __launch_bounds__(256) void ddc_wf_comb_kernel(
         *(int4 *) &s_out[4 * t] = o4;
     }
     __syncthreads();
-    short2 *dst = out + (long) li * out_stride + o0;
+    short2 *dst = out + (long) li * out_stride + out_off[li] + o0;
     for (int k = 0; k < 4; k++) {
         const int e = t + 256 * k;
         if (o0 + e < nout) { const int w = s_out[e]; dst[e] = make_short2((short) (w & 0xffff), (short) (w >> 16)); }
@@ -1332,10 +1340,12 @@ __global__ __launch_bounds__(256) void ddc_wf_comb_kernel(
 
 // after a call: the comb history (phase and counter are reference values + the host's `pushed`, see ddc_chan)
 __global__ void ddc_wf_finish_kernel(ddc_chan *__restrict__ chans, const int *__restrict__ chan_list, int nlist,
-                                     long n, const long *__restrict__ nouts, const u32 *__restrict__ hist_new, int reset_first)
+                                     long n, const long *__restrict__ nouts, const u32 *__restrict__ hist_new,
+                                     const int *__restrict__ reset_tab)
 {
     const int li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= nlist) return;
+    const int reset_first = reset_tab[li];
     ddc_chan *ch = chans + chan_list[li];
     if (ch->log2r == 0) return;
     const long nout = nouts[li];
@@ -1369,6 +1379,7 @@ struct kg_ddc {
     kg_stage_cache pack_cache;                 // the per-call tables of the last push (a steady stream repeats them: no upload)
     std::vector<u64> h_pushed;                 // per channel: samples pushed since its reference point (ddc_chan.phase / .sample_no)
     std::vector<char> h_stale;                 // per channel: a capture cut its filters short; the next continuous push resets it
+    std::vector<char> seen;                    // scratch of a push: channels listed so far
     // Deferred output stage (kg_ddc_wf_set_deferred): the stage runs on `tail`, the context's stream carries only pass A,
     // the state scan and pass B, so the NEXT push's pass A starts while this push's combs are still writing.
     bool deferred;
@@ -1565,6 +1576,8 @@ int kg_ddc_set_phase(kg_ddc *d, int ch, uint64_t phase)
 long kg_ddc_wf_outputs(kg_ddc *d, int ch, size_t n)
 {
     if (!d || ch < 0 || ch >= d->nchan || !d->h_chans[ch].active) return KG_ERR_INVALID;
+    // a channel a capture left behind is reset by its next continuous push: the counter starts that block at zero
+    if (d->h_stale[ch]) return (long) ((u64) n >> d->h_chans[ch].log2r);
     return (long) (((u64) ddc_cur_cnt(d, ch) + (u64) n) >> d->h_chans[ch].log2r);
 }
 
@@ -1615,30 +1628,45 @@ int kg_ddc_wf_tail_after(kg_ddc *d, void *event)
 // kg_ddc_wf_push_dev (max_out = 0: the continuous sampler) and kg_ddc_wf_capture_dev (max_out >= 1: CmdWFReset with
 // WF_SAMP_WR_RST at the block's first sample, then the one-shot sampler of verilog/rx/iq_sampler_8k_32b.v, which stops
 // when it holds max_out pairs: only the first max_out << log2r samples of the block reach a channel's filters).
+// kg_ddc_wf_step_dev: the sampler mode PER ENTRY (max_out_tab[i]: 0 continuous, >= 1 reset + one-shot of that many pairs) and
+// an offset into each entry's row (out_off[i] pairs): a bank of receivers in both modes in one set of launches.
 static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *chan_list, int nlist,
-                         void *d_out, size_t out_stride, size_t max_out, int64_t *nouts)
+                         void *d_out, size_t out_stride, size_t max_out, int64_t *nouts,
+                         const int64_t *max_out_tab = nullptr, const int64_t *out_off = nullptr)
 {
-    const bool capture = max_out != 0;
     KG_REQUIRE(d && d_adc && chan_list && d_out, KG_ERR_INVALID, "kg_ddc_wf_push_dev: null argument");
+    auto cap_of = [&](int i) -> u64 { return max_out_tab ? (u64) max_out_tab[i] : (u64) max_out; };     // 0: continuous sampler
+    bool capture = false;                                           // some entry of the call captures
+    for (int i = 0; i < nlist; i++) {
+        KG_REQUIRE(!max_out_tab || (max_out_tab[i] >= 0 && max_out_tab[i] <= ((int64_t) 1 << 31)), KG_ERR_INVALID,
+                   "kg_ddc_wf_step_dev: max_out[%d] = %lld", i, (long long) max_out_tab[i]);
+        KG_REQUIRE(!out_off || (out_off[i] >= 0 && (size_t) out_off[i] <= out_stride), KG_ERR_INVALID,
+                   "kg_ddc_wf_step_dev: out_off[%d] = %lld outside the row", i, out_off ? (long long) out_off[i] : 0ll);
+        capture = capture || cap_of(i) != 0;
+    }
     int rc = kg_ctx_use(d->ctx);
     if (rc) return rc;
     KG_REQUIRE(n >= 1 && (long) n <= d->max_samples, KG_ERR_INVALID, "kg_ddc_wf_push_dev: n %zu (max %ld)", n, d->max_samples);
     KG_REQUIRE(nlist >= 1 && nlist <= d->nchan, KG_ERR_INVALID, "kg_ddc_wf_push_dev: nlist %d", nlist);
     KG_REQUIRE(((uintptr_t) d_adc & 1) == 0 && ((uintptr_t) d_out & 3) == 0, KG_ERR_INVALID,
                "kg_ddc_wf_push_dev: misaligned pointer");
-    for (int i = 0; i < nlist; i++) {
-        const int ch = chan_list[i];
-        KG_REQUIRE(ch >= 0 && ch < d->nchan && d->h_chans[ch].active, KG_ERR_STATE,
-                   "kg_ddc_wf_push_dev: channel %d is not configured", ch);
-        for (int j = 0; j < i; j++) KG_REQUIRE(chan_list[j] != ch, KG_ERR_INVALID, "kg_ddc_wf_push_dev: channel %d listed twice", ch);
+    {
+        std::vector<char> &seen = d->seen;                          // (a flag per channel: no quadratic search of the list)
+        seen.assign(d->nchan, 0);
+        for (int i = 0; i < nlist; i++) {
+            const int ch = chan_list[i];
+            KG_REQUIRE(ch >= 0 && ch < d->nchan && d->h_chans[ch].active, KG_ERR_STATE,
+                       "kg_ddc_wf_push_dev: channel %d is not configured", ch);
+            KG_REQUIRE(!seen[ch], KG_ERR_INVALID, "kg_ddc_wf_push_dev: channel %d listed twice", ch);
+            seen[ch] = 1;
+        }
     }
     // A channel a capture left behind holds the filter state of a block cut short: the next CONTINUOUS push starts it
     // from the reset state, as the reference does when it changes sampler mode (CmdWFReset with WF_SAMP_CONTIN,
     // rx/rx_waterfall.cpp:971-978).  Synchronising, rare.  (Before the ages are compared: a reset moves the channel's
     // reference point.)
-    if (!capture)
-        for (int i = 0; i < nlist; i++)
-            if (d->h_stale[chan_list[i]]) {
+    for (int i = 0; i < nlist; i++)
+            if (cap_of(i) == 0 && d->h_stale[chan_list[i]]) {
                 if ((rc = kg_ddc_reset_wf(d, chan_list[i]))) return rc;
                 d->h_stale[chan_list[i]] = 0;
             }
@@ -1652,20 +1680,23 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
             for (int i = 0; i < nlist; i++) if ((rc = ddc_rebase(d, chan_list[i]))) return rc;
     }
     const u64 pushed = d->h_pushed[chan_list[0]];
-    std::vector<long> h_nouts(nlist), h_off(nlist), h_nlim(nlist);
-    std::vector<int> h_wg(nlist + 1), h_bypass, h_run, h_small, h_rest;
+    std::vector<long> h_nouts(nlist), h_off(nlist), h_nlim(nlist), h_outoff(nlist);
+    std::vector<int> h_wg(nlist + 1), h_bypass, h_run, h_small, h_rest, h_reset(nlist);
     long max_nout = 0, c0_need = 0, comb_wgs = 0, n_run_max = 0, n_by_max = 0, n_run_sum = 0;
     for (int i = 0; i < nlist; i++) {
         const int ch = chan_list[i];
         const ddc_chan &c = d->h_chans[ch];
         // samples of the block this channel's filters see: all of them, or (capture) what fills the one-shot sampler
-        const u64 want = capture ? (u64) max_out << c.log2r : (u64) n;
+        const bool cap = cap_of(i) != 0;
+        const u64 want = cap ? cap_of(i) << c.log2r : (u64) n;
+        h_reset[i] = cap ? 1 : 0;
+        h_outoff[i] = out_off ? (long) out_off[i] : 0l;
         h_nlim[i] = (long) (want < (u64) n ? want : (u64) n);
-        h_nouts[i] = (long) (((capture ? 0ull : (u64) ddc_cur_cnt(d, ch)) + (u64) h_nlim[i]) >> c.log2r);
+        h_nouts[i] = (long) (((cap ? 0ull : (u64) ddc_cur_cnt(d, ch)) + (u64) h_nlim[i]) >> c.log2r);
         if (c.log2r) { if (h_nlim[i] > n_run_max) n_run_max = h_nlim[i]; n_run_sum += h_nlim[i]; }
         else if (h_nlim[i] > n_by_max) n_by_max = h_nlim[i];
-        KG_REQUIRE((size_t) h_nouts[i] <= out_stride, KG_ERR_INVALID,
-                   "kg_ddc_wf_push_dev: out_stride %zu < %ld outputs of channel %d", out_stride, h_nouts[i], ch);
+        KG_REQUIRE((size_t) (h_nouts[i] + h_outoff[i]) <= out_stride, KG_ERR_INVALID,
+                   "kg_ddc_wf_push_dev: out_stride %zu < %ld outputs of channel %d (at offset %ld)", out_stride, h_nouts[i], ch, h_outoff[i]);
         if (h_nouts[i] > max_nout) max_nout = h_nouts[i];
         if (nouts) nouts[i] = h_nouts[i];
         h_off[i] = c0_need;
@@ -1724,8 +1755,7 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
     KG_REQUIRE(nruns <= d->max_runs, KG_ERR_INVALID, "kg_ddc_wf_push_dev: %d runs > %d", nruns, d->max_runs);
     // The per-call tables go through the context's staging ring in one piece: no stream
     // synchronisation, and the previous call's kernels keep their own copy.
-    const long *s_c0off, *s_nouts, *s_nlim; const int *s_list, *s_wgoff, *s_bypass, *s_selrun, *s_selsmall, *s_selrest;
-    const int reset_first = capture ? 1 : 0;
+    const long *s_c0off, *s_nouts, *s_nlim, *s_outoff; const int *s_list, *s_wgoff, *s_bypass, *s_selrun, *s_selsmall, *s_selrest, *s_reset;
     {
         std::vector<unsigned char> pack;
         auto put = [&](const void *src, size_t bytes) -> size_t {
@@ -1742,6 +1772,7 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
         const size_t o_run = put(h_run.data(), sizeof(int) * h_run.size());
         const size_t o_small = put(h_small.data(), sizeof(int) * h_small.size());
         const size_t o_rest = put(h_rest.data(), sizeof(int) * h_rest.size());
+        const size_t o_reset = put(h_reset.data(), sizeof(int) * nlist), o_outoff = put(h_outoff.data(), sizeof(long) * nlist);
         // a CHANGED table is rewritten in the order of the context's stream: the previous push's output stage, on its own
         // stream in deferred mode, may still be reading the old one -- join it first (a steady stream never gets here)
         if (d->tail && d->tail_rec[par ^ 1] && d->tail_unjoined &&
@@ -1756,7 +1787,9 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
         s_list = (const int *) (b + o_list); s_wgoff = (const int *) (b + o_wg);
         s_bypass = (const int *) (b + o_by); s_selrun = (const int *) (b + o_run);
         s_selsmall = (const int *) (b + o_small); s_selrest = (const int *) (b + o_rest);
+        s_reset = (const int *) (b + o_reset); s_outoff = (const long *) (b + o_outoff);
     }
+    KG_PLAN_ONLY(d->ctx);
     // The object's second stream: work that does not depend on the pass A -> scan -> pass B chain runs beside
     // it -- the R = 1 bypass channels (no filter state at all) from the start, pass B of the R <= 8 channels
     // (below) -- and joins before the call's last kernels.  KIWIGPU_DDC_SIDE=0: everything in line.
@@ -1794,7 +1827,7 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
         const long nblk_by = (n_by_max + BYP_G * 1024 - 1) / (BYP_G * 1024), cap_by = (long) d->ctx->num_cus * 4;   // LDS: 20 KiB each, 4 per CU
         hipLaunchKernelGGL(ddc_wf_bypass_kernel, dim3((unsigned) (nblk_by < cap_by ? nblk_by : cap_by)), dim3(256),
                            0, bst, (const short *) d_adc, (long) n_by_max, (const ddc_chan *) d->d_chans, s_list,
-                           s_bypass, (int) h_bypass.size(), (const u32 *) d->d_nco, (short2 *) d_out, (long) out_stride, pushed, s_nlim);
+                           s_bypass, (int) h_bypass.size(), (const u32 *) d->d_nco, (short2 *) d_out, (long) out_stride, pushed, s_nlim, s_outoff);
         KG_HIP(hipGetLastError());
     }
     // end-referred carry states (round 4): prefix sums inside pass A's workgroups + one wave per (channel, I/Q) over the
@@ -1814,7 +1847,7 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
         hipLaunchKernelGGL(ddc_wf_run_kernel<false>, dim3(gx, (unsigned) h_run.size()), dim3(DDC_THREADS), 0, st,
                            (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, s_list,
                            (const u32 *) d->d_nco, d_local, d_c0rel, d_tau, s_c0off,
-                           s_nouts, s_selrun, 0, pushed, s_nlim, reset_first, endref, (const ddc_endco *) d->d_endco, d->endco_n,
+                           s_nouts, s_selrun, 0, pushed, s_nlim, s_reset, endref, (const ddc_endco *) d->d_endco, d->endco_n,
                            d->d_wgtot[par], (const ddc_state4 *) nullptr, (u32 *) nullptr);
         KG_HIP(hipGetLastError());
     }
@@ -1852,11 +1885,11 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
         }
         if (endref == 2)
             hipLaunchKernelGGL(ddc_wf_scan_wg_kernel, dim3((unsigned) npairs), dim3(64), 0, st, (const ddc_state4 *) d->d_wgtot[par],
-                               d->d_wgbase[par], (int) gx, d->d_chans, s_list, s_nlim, reset_first);
+                               d->d_wgbase[par], (int) gx, d->d_chans, s_list, s_nlim, s_reset);
         else
             hipLaunchKernelGGL(ddc_wf_scan_states_kernel, dim3((unsigned) (npairs * nchunk)), dim3(64 * DDC_SCAN_WAVES), 0, st,
                                d_local, (long) n, L, nruns, d->d_chans, s_list, npairs, nchunk, d->d_aggs, d->d_ticket,
-                               d->ticket_base, d->epoch + 1, tab, s_nlim, reset_first);
+                               d->ticket_base, d->epoch + 1, tab, s_nlim, s_reset);
         KG_HIP(hipGetLastError());
         // only a launch that was accepted advances the ticket counter and publishes under the new epoch
         if (endref != 2) {
@@ -1876,7 +1909,7 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
     auto pass_b = [&](hipStream_t s, const std::vector<int> &which, const int *sel, int stage) {
         hipLaunchKernelGGL(ddc_wf_run_kernel<true>, dim3(gx, (unsigned) which.size()), dim3(DDC_THREADS), stage, s,
                            (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, s_list,
-                           (const u32 *) d->d_nco, d_local, d_c0rel, d_tau, s_c0off, s_nouts, sel, stage, pushed, s_nlim, reset_first, endref, (const ddc_endco *) d->d_endco, d->endco_n,
+                           (const u32 *) d->d_nco, d_local, d_c0rel, d_tau, s_c0off, s_nouts, sel, stage, pushed, s_nlim, s_reset, endref, (const ddc_endco *) d->d_endco, d->endco_n,
                            (ddc_state4 *) nullptr, (const ddc_state4 *) d->d_wgbase[par], d->d_wgtau[par]);
     };
     if (beside) {
@@ -1911,21 +1944,21 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
     }
     if (endref == 2)
         hipLaunchKernelGGL(ddc_wf_tau_wg_kernel, dim3(2 * nlist), dim3(64), 0, ost, d->d_wgtau[par], (int) gx, d->d_chans, s_list,
-                           reset_first);
+                           s_reset);
     else
         hipLaunchKernelGGL(ddc_wf_scan_tau_kernel, dim3(2 * nlist), dim3(64 * DDC_SCAN_WAVES), 0, ost, d_tau, nruns, d->d_chans,
-                           s_list, s_nlim, L, reset_first);
+                           s_list, s_nlim, L, s_reset);
     KG_HIP(hipGetLastError());
     if (comb_wgs > 0) {
         hipLaunchKernelGGL(ddc_wf_comb_kernel, dim3((unsigned) comb_wgs), dim3(256), 0, ost,
                            (const u32 *) d_c0rel, (const u32 *) d_tau, log2L, nruns, s_c0off,
                            (const ddc_chan *) d->d_chans, s_list, s_nouts,
-                           pushed, reset_first, s_wgoff, nlist, (short2 *) d_out, (long) out_stride,
+                           pushed, s_reset, s_wgoff, nlist, (short2 *) d_out, (long) out_stride, s_outoff,
                            d->d_hist, endref == 2 ? (const u32 *) d->d_wgtau[par] : (const u32 *) nullptr, (int) gx);
         KG_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(ddc_wf_finish_kernel, dim3((nlist + 63) / 64), dim3(64), 0, ost, d->d_chans,
-                       s_list, nlist, (long) n, s_nouts, (const u32 *) d->d_hist, reset_first);
+                       s_list, nlist, (long) n, s_nouts, (const u32 *) d->d_hist, s_reset);
     KG_HIP(hipGetLastError());
     if (d->tail) {                                // (also in line: a later deferred push finds its buffer set covered)
         KG_HIP(hipEventRecord(d->ev_tail[par], ost));
@@ -1935,7 +1968,7 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
     d->parity = par ^ 1;
     for (int i = 0; i < nlist; i++) {
         d->h_pushed[chan_list[i]] += (u64) n;                      // the NCO runs through the whole block either way
-        if (capture) d->h_stale[chan_list[i]] = 1;                // filters stopped short of the block's end
+        if (cap_of(i) != 0) d->h_stale[chan_list[i]] = 1;          // filters stopped short of the block's end
     }
     return KG_OK;
 }
@@ -1951,6 +1984,13 @@ int kg_ddc_wf_capture_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t 
 {
     KG_REQUIRE(max_out >= 1 && max_out <= ((size_t) 1 << 31), KG_ERR_INVALID, "kg_ddc_wf_capture_dev: max_out %zu", max_out);
     return ddc_push_impl(d, d_adc, n, chan_list, nlist, d_out, out_stride, max_out, nouts);
+}
+
+int kg_ddc_wf_step_dev(kg_ddc *d, const void *d_adc, size_t n, const int32_t *chan_list, int nlist, void *d_out,
+                       size_t out_stride, const int64_t *out_off, const int64_t *max_out, int64_t *nouts)
+{
+    KG_REQUIRE(max_out != nullptr, KG_ERR_INVALID, "kg_ddc_wf_step_dev: max_out is null");
+    return ddc_push_impl(d, d_adc, n, chan_list, nlist, d_out, out_stride, 0, nouts, max_out, out_off);
 }
 
 }  // extern "C"

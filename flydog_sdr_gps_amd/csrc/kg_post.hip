@@ -434,6 +434,7 @@ int kg_post_process_dev(kg_post *p, const int32_t *chans, int nch, const void *d
     hipStream_t st = p->ctx->stream;
     void *d_list = nullptr;
     if ((rc = kg_ctx_stage_cached(p->ctx, &p->list_cache, chans, sizeof(int) * nch, &d_list))) return rc;
+    KG_PLAN_ONLY(p->ctx);
     hipLaunchKernelGGL(post_kernel, dim3(nch), dim3(64), 0, st, p->d_chan, p->d_ring_in, p->d_ring_mag,
                        (const int *) d_list, (const float2 *) d_fir, in_stride, nsamps,
                        (short *) d_s16, (float *) d_demod, (float2 *) d_agc, out_stride);

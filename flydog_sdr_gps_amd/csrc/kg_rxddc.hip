@@ -548,6 +548,7 @@ struct kg_rxddc {
     int *d_c1buf; long c1_stride;
     int max_runs; long max_out;
     kg_stage_cache pack_cache;                 // the per-call tables of the last push (a steady stream repeats them: no upload)
+    std::vector<char> seen;                    // scratch of a push: channels listed so far
 };
 
 extern "C" {
@@ -674,10 +675,12 @@ int kg_rxddc_push_dev(kg_rxddc *d, const void *d_adc, size_t n, const int32_t *c
     std::vector<int> h_nfinal(nlist);
     std::vector<u32> h_cnt(nlist);
     long max_n1 = 0; int max_final = 0;
+    d->seen.assign(d->nchan, 0);                  // (a flag per channel: no quadratic search of the list)
     for (int i = 0; i < nlist; i++) {
         const int ch = chan_list[i];
         KG_REQUIRE(ch >= 0 && ch < d->nchan && d->h[ch].active, KG_ERR_STATE, "kg_rxddc_push_dev: channel %d has no frequency set", ch);
-        for (int j = 0; j < i; j++) KG_REQUIRE(chan_list[j] != ch, KG_ERR_INVALID, "kg_rxddc_push_dev: channel %d listed twice", ch);
+        KG_REQUIRE(!d->seen[ch], KG_ERR_INVALID, "kg_rxddc_push_dev: channel %d listed twice", ch);
+        d->seen[ch] = 1;
         const rx_chan &c = d->h[ch];
         h_cnt[i] = c.cnt1;
         h_nouts[i] = (long) (((u64) c.cnt1 + (u64) n) / RX_R1);
@@ -713,6 +716,7 @@ int kg_rxddc_push_dev(kg_rxddc *d, const void *d_adc, size_t n, const int32_t *c
         s_list = (const int *) (b + o_list); s_nouts = (const long *) (b + o_nouts); s_n1b = (const long *) (b + o_n1b);
         s_qfirst = (const long *) (b + o_qf); s_nfinal = (const int *) (b + o_nf); s_cnt = (const u32 *) (b + o_cnt);
     }
+    KG_PLAN_ONLY(d->ctx);
     const dim3 grid((nruns + RX_THREADS - 1) / RX_THREADS, nlist);
     // end-referred carry states, summed inside pass A's workgroups and by one wave per (channel, I/Q) over the workgroup
     // totals (round 4); KIWIGPU_RXDDC_ENDREF=0: run-start states and rx1_scan_kernel, the A/B reference

@@ -260,6 +260,7 @@ struct kg_fir {
     int *d_cic_on;                            // per channel: m_do_CIC_comp (SetupCICFilter, fastfir.cpp:148-158)
     std::vector<int> fill;                    // pending new samples per channel = FirPos()
     std::vector<char> coef_set;
+    std::vector<char> seen;                   // scratch of a call: channels listed so far
     // host copies of the design tables (SetupWindowFunction / constructor)
     float window[FIR_TAPS], cic[FIR_FFT];
     int window_func, cic_3ch;
@@ -505,11 +506,13 @@ static int fir_process_impl(kg_fir *f, const int32_t *chans, int nch, const void
     KG_REQUIRE(n >= 0 && n <= f->max_in, KG_ERR_INVALID, "kg_fir_process_dev: n %d (max %d)", n, f->max_in);
     std::vector<int> h_fill(nch), h_nblk(nch), h_rem(nch);
     int max_blk = 0;
+    f->seen.assign(f->nchan, 0);                  // (a flag per channel: no quadratic search of the list)
     for (int i = 0; i < nch; i++) {
         const int ch = chans[i];
         KG_REQUIRE(ch >= 0 && ch < f->nchan, KG_ERR_INVALID, "kg_fir_process_dev: channel %d", ch);
         KG_REQUIRE(f->coef_set[ch], KG_ERR_STATE, "kg_fir_process_dev: no filter set for channel %d", ch);
-        for (int j = 0; j < i; j++) KG_REQUIRE(chans[j] != ch, KG_ERR_INVALID, "kg_fir_process_dev: channel %d listed twice", ch);
+        KG_REQUIRE(!f->seen[ch], KG_ERR_INVALID, "kg_fir_process_dev: channel %d listed twice", ch);
+        f->seen[ch] = 1;
         h_fill[i] = f->fill[ch];
         const int tot = f->fill[ch] + n;
         h_nblk[i] = tot / FIR_OUT;
@@ -535,6 +538,7 @@ static int fir_process_impl(kg_fir *f, const int32_t *chans, int nch, const void
         if ((rc = kg_ctx_stage(f->ctx, pack.data(), sizeof(int) * pack.size(), &base))) return rc;
         s_list = (const int *) base; s_fill = s_list + nch; s_nblk = s_list + 2 * nch; s_rem = s_list + 3 * nch;
     }
+    KG_PLAN_ONLY(f->ctx);
     hipLaunchKernelGGL(fir_append_kernel, dim3((n + 255) / 256, nch), dim3(256), 0, st, (const float2 *) d_in,
                        (long) in_stride, s_list, s_fill, n, f->d_hist, f->hist_stride);
     KG_HIP(hipGetLastError());
@@ -599,6 +603,7 @@ static int unpack_impl(kg_ctx *ctx, const void *d_raw, size_t raw_stride, int ns
                "kg_dpump_unpack_dev: stride smaller than nsamps");
     void *d_en = nullptr;
     if ((rc = kg_ctx_stage(ctx, enabled, nchans, &d_en))) return rc;
+    KG_PLAN_ONLY(ctx);
     hipLaunchKernelGGL(snd_unpack_kernel, dim3((nsamps + 255) / 256, nchans), dim3(256), 0, ctx->stream,
                        (const unsigned short *) d_raw, (long) raw_stride, nsamps, nchans, (const unsigned char *) d_en,
                        rescale, dc_i, dc_q, spectral_inversion ? 1 : 0, (float2 *) d_out, (long) out_stride);

@@ -550,6 +550,7 @@ static int wf_launch(kg_wf *w, int nframes, const int32_t *chan_of, const uint64
                                           sizeof(int2) * nframes, &d_chan_of);
         if (rc) return rc;
     }
+    KG_PLAN_ONLY(w->ctx);
     const int grid = nframes < w->grid ? nframes : w->grid;
     if (!taps) {
         hipLaunchKernelGGL(wf_frame_kernel<false>, dim3(grid), dim3(256), WF_LDS_BYTES, st,

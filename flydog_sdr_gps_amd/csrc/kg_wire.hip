@@ -217,6 +217,7 @@ int kg_adpcm_encode_dev(kg_adpcm *a, const int32_t *chans, int nch, const void *
     hipStream_t st = a->ctx->stream;
     void *d_list = nullptr;
     if ((rc = kg_ctx_stage_cached(a->ctx, &a->list_cache, chans, sizeof(int) * nch, &d_list))) return rc;
+    KG_PLAN_ONLY(a->ctx);
     hipLaunchKernelGGL(adpcm_snd_kernel, dim3((nch + 63) / 64), dim3(64), 0, st, a->d_state, (const int *) d_list,
                        nch, (const short *) d_s16, in_stride, nsamps, (unsigned char *) d_out, out_stride);
     KG_HIP(hipGetLastError());
@@ -295,6 +296,7 @@ int kg_wf_packets_dev(kg_ctx *ctx, const void *d_rows, size_t row_stride, int nr
     }
     void *d_info = nullptr;
     if ((rc = kg_ctx_stage(ctx, h.data(), sizeof(wf_pkt_dev_info) * nrows, &d_info))) return rc;
+    KG_PLAN_ONLY(ctx);
     hipLaunchKernelGGL(wf_packet_kernel, dim3(nrows), dim3(64), 0, ctx->stream, (const unsigned char *) d_rows,
                        row_stride, (const wf_pkt_dev_info *) d_info, (unsigned char *) d_pkts, pkt_stride);
     KG_HIP(hipGetLastError());

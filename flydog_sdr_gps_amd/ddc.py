@@ -27,7 +27,7 @@ class Ddc:
 
     def close(self):
         if getattr(self, "h", None):
-            if getattr(self.ctx, "h", None):          # an object must not outlive its context
+            if getattr(self.ctx, "h", None) and not getattr(self, "_borrowed", False):          # an object must not outlive its context
                 self.lib.kg_ddc_destroy(self.h)
             self.h = None
 
@@ -147,7 +147,7 @@ class RxDdc:
 
     def close(self):
         if getattr(self, "h", None):
-            if getattr(self.ctx, "h", None):          # an object must not outlive its context
+            if getattr(self.ctx, "h", None) and not getattr(self, "_borrowed", False):          # an object must not outlive its context
                 self.lib.kg_rxddc_destroy(self.h)
             self.h = None
 

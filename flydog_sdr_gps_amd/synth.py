@@ -130,3 +130,14 @@ def wf_iq_frame(seed, tones=((0.05, -20.0), (0.21, -55.0), (0.33, -80.0)), noise
     iq[:, 0] = np.clip(np.rint(32767.0 * x.real), -32768, 32767)
     iq[:, 1] = np.clip(np.rint(32767.0 * x.imag), -32768, 32767)
     return iq
+
+
+def adc_stream(n, seed):
+    """n samples of the synthetic 16-bit ADC stream of BASELINE configs[2] / [3] (bench.py, tests): four CW tones at
+    0.0123 / 0.071 / 0.2003 / 0.31 of the sample rate (3000 ... 3 LSB) in Gaussian noise of 10 LSB rms."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    t = np.arange(n, dtype=np.float64)
+    x = rng.normal(0, 10.0, n)
+    for f, a in ((0.0123, 3000.0), (0.071, 300.0), (0.2003, 30.0), (0.31, 3.0)):
+        x += a * np.cos(2 * np.pi * f * t)
+    return np.clip(np.rint(x), -32768, 32767).astype(np.int16)

@@ -118,7 +118,7 @@ class Waterfall:
 
     def close(self):
         if getattr(self, "h", None):
-            if getattr(self.ctx, "h", None):          # an object must not outlive its context
+            if getattr(self.ctx, "h", None) and not getattr(self, "_borrowed", False):          # an object must not outlive its context
                 self.lib.kg_wf_destroy(self.h)
             self.h = None
 

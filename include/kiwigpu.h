@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define KG_ABI_VERSION 2     /* 2 (round 4): kg_wf_frames_at_dev takes the extent of d_iq; kg_ctx_mark; code spectra in layout B */
+#define KG_ABI_VERSION 3     /* 3 (round 5): kg_rxbank_*, kg_ddc_wf_step_dev; 2 (round 4): kg_wf_frames_at_dev takes the extent of d_iq; kg_ctx_mark */
 
 typedef enum {
     KG_OK = 0,
@@ -292,6 +292,13 @@ int kg_ddc_wf_push_dev(kg_ddc *ddc, const void *d_adc, size_t n, const int32_t *
  * switches the sampler to continuous mode (CmdWFReset with WF_SAMP_CONTIN, :971-978).  Enqueue only. */
 int kg_ddc_wf_capture_dev(kg_ddc *ddc, const void *d_adc, size_t n, const int32_t *chan_list,
                           int nlist, void *d_out, size_t out_stride, size_t max_out, int64_t *nouts);
+/* Both sampler modes in ONE call (round 5; a bank of receivers, kg_rxbank below): entry i is pushed through the continuous
+ * sampler when max_out[i] == 0 (as kg_ddc_wf_push_dev) and captured -- CmdWFReset at the block's first sample, then the
+ * one-shot sampler of max_out[i] pairs -- when max_out[i] >= 1 (as kg_ddc_wf_capture_dev); its pairs go to
+ * d_out + i*out_stride + out_off[i] (out_off may be NULL: all zero; out_off[i] + the entry's outputs <= out_stride), e.g. the
+ * write position of a sample ring.  Enqueue only. */
+int kg_ddc_wf_step_dev(kg_ddc *ddc, const void *d_adc, size_t n, const int32_t *chan_list, int nlist, void *d_out,
+                       size_t out_stride, const int64_t *out_off, const int64_t *max_out, int64_t *nouts);
 /* Deferred output stage (round 4) -- the non-blocking submit / poll form SURVEY 8(b) asks of the DDC seam (today every
  * CmdGetWFSamples is a blocking SPI transaction, platform/common/spi.cpp:487-507).  Off (default): everything a push
  * enqueues is ordered on the context's stream.  On: the push returns with its output stage (R = 1 bypass channels,
@@ -575,6 +582,83 @@ int kg_acq_debug_fft_stamps(kg_acq *acq, int block, unsigned long long *stamps, 
  * n >= 4608. */
 int kg_acq_debug_corr_stamps(kg_acq *acq, int nblocks, const int *sats, int nsats,
                              unsigned long long *stamps, int n);
+
+/* ------------------------------------------------------------------------ */
+/* A bank of virtual receivers stepped with ONE call (round 5; BASELINE           */
+/* configs[3]).  In the reference every connection runs a waterfall and a sound   */
+/* coroutine over what the data pump hands them: data_pump()                      */
+/* (rx/data_pump.cpp:292-341), the c2s_sound() loop (rx/rx_sound.cpp:333-601:     */
+/* in_samps -> CFastFIR -> S-meter / AGC / demod -> compression) and               */
+/* c2s_waterfall() -> sample_wf() -> compute_frame() -> wf_pkt_t                    */
+/* (rx/rx_waterfall.cpp:930-1170).  A bank is nrx such connections fed from one     */
+/* block of ADC samples per step; kg_rxbank_step() enqueues everything a step        */
+/* needs -- both DDCs, frames, packets, unpack, CFastFIR, S-meter / CAgc, ADPCM --   */
+/* on the bank's own streams, with ONE host-to-device transfer (the small tables     */
+/* of all stages) per step.  The per-seam objects are the bank's and are configured  */
+/* with their own entry points above (tables, maps, frequencies, filters, AGC).      */
+/* ------------------------------------------------------------------------ */
+typedef struct kg_rxbank kg_rxbank;
+
+/* nrx receivers on `device`, adc_samples_per_step int16 ADC samples per step, audio DDCs of rx_mode (KG_RXDDC_*). */
+int kg_rxbank_create(int device, int nrx, size_t adc_samples_per_step, int rx_mode, kg_rxbank **out);
+void kg_rxbank_destroy(kg_rxbank *bank);
+/* The owned objects, channel k = receiver k (never destroy them; reconfigure only between steps -- the setters of the
+ * objects synchronise their own stream). */
+kg_ctx *kg_rxbank_ctx(kg_rxbank *bank);       /* the waterfall chain's context: kg_dev_download etc. */
+kg_ddc *kg_rxbank_ddc(kg_rxbank *bank);       /* do NOT call kg_ddc_set_wf on it: kg_rxbank_set_wf */
+kg_wf *kg_rxbank_wf(kg_rxbank *bank);         /* kg_wf_set_tables, kg_wf_set_channel */
+kg_rxddc *kg_rxbank_rxddc(kg_rxbank *bank);   /* kg_rxddc_set_freq */
+kg_fir *kg_rxbank_fir(kg_rxbank *bank);       /* kg_fir_setup */
+kg_post *kg_rxbank_post(kg_rxbank *bank);     /* kg_post_set_agc / _set_smeter / _set_mode / _reset */
+kg_adpcm *kg_rxbank_adpcm(kg_rxbank *bank);
+/* CmdSetWFFreq + CmdSetWFDecim + the sampler mode sample_wf() decides on (rx/rx_waterfall.cpp:962-1008):
+ *   overlapped == 0   CmdWFReset + the one-shot sampler every step: the non-overlapped frame (:1005-1041); needs
+ *                     8192 * decim <= adc_samples_per_step
+ *   overlapped == 1   the continuous sampler (CmdWFReset with WF_SAMP_CONTIN, :971-978): every step adds
+ *                     adc_samples_per_step / decim outputs (a divisor of 8192) to the receiver's ring and the frame is the
+ *                     ring's newest 8192 outputs (CmdGetWFContSamps, :980-991); no frame until the ring holds 8192
+ *                     ("fill pipe", :978).  Set kg_wf_chan_cfg.overlapped accordingly (it switches the CIC compensation off).
+ * Resets the receiver's sampler.  Synchronises the bank. */
+int kg_rxbank_set_wf(kg_rxbank *bank, int rx, uint64_t phase_inc, int decim, int overlapped);
+/* wf_pkt_t header fields of receiver rx (x_bin_server, zoom, compression); seq is the bank's sound sequence number. */
+int kg_rxbank_set_wf_pkt(kg_rxbank *bank, int rx, uint32_t x_bin_server, uint32_t zoom, int use_compression);
+/* snd_service() unpack parameters (default: rescale of rx/data_pump.cpp:73-74, no DC offset, no inversion) */
+int kg_rxbank_set_unpack(kg_rxbank *bank, float rescale, float dc_i, float dc_q, int spectral_inversion);
+
+typedef struct {
+    uint64_t step;         /* steps taken before this one */
+    int32_t nframes;       /* waterfall frames (= rows = packets) of this step: kg_rxbank_frame_map says whose */
+    int32_t nrec;          /* rx_iq_t records per receiver */
+    int32_t nfir;          /* CFastFIR outputs per receiver: 0 or k * 512 (k sound blocks: s16 / adpcm rows hold k * 512 / k * 256) */
+    int32_t fir_pos;       /* FirPos() after the step */
+    uint32_t snd_seq;      /* sound blocks emitted before this step = the seq of this step's wf_pkt_t (rx_waterfall.cpp:1635) */
+    int32_t table_bytes;   /* what the step's one upload carried */
+    int32_t nmoves;        /* overlapped rings wrapped this step */
+} kg_rxbank_step_info;
+/* One step: n = adc_samples_per_step samples at d_adc (device) through every receiver.  Enqueue only (the host returns
+ * after some thirty launches; kg_rxbank_poll / _sync say when the work is done).  adc_ready_event: a hipEvent_t recorded
+ * behind the writer of d_adc, or NULL.  info may be NULL. */
+int kg_rxbank_step(kg_rxbank *bank, const void *d_adc, void *adc_ready_event, kg_rxbank_step_info *info);
+/* `stream` (hipStream_t) waits until the last step's readers of its ADC block are done: order the writer of a
+ * double-buffered ADC ring behind this. */
+int kg_rxbank_adc_done(kg_rxbank *bank, void *stream);
+int kg_rxbank_poll(kg_rxbank *bank);          /* 1 = all streams idle, 0 = busy, <0 error */
+int kg_rxbank_sync(kg_rxbank *bank);
+/* Frame f of the last step belongs to receiver rx_of_frame[f], was read at wf_iq + frame_off[f] pairs, and its packet has
+ * pkt_bytes[f] bytes on the wire (arrays of nrx entries, any may be NULL).  Returns nframes. */
+int kg_rxbank_frame_map(kg_rxbank *bank, int32_t *rx_of_frame, uint64_t *frame_off, int32_t *pkt_bytes);
+/* The bank's device buffers (valid until kg_rxbank_destroy; read them after kg_rxbank_sync or behind the bank's streams). */
+typedef struct {
+    void *wf_iq;   size_t wf_iq_stride;   /* [nrx][wf_iq_stride] iq_t: the samplers' rows (one-shot: pairs 0..8191) */
+    void *wf_rows;                        /* [frame][1024] u8 */
+    void *wf_pkts; size_t wf_pkt_stride;  /* [frame][wf_pkt_stride] wf_pkt_t bytes */
+    void *rx_raw;  size_t rx_stride;      /* [nrx][rx_stride] rx_iq_t (6 bytes each) */
+    void *rx_in;                          /* [nrx][rx_stride] TYPECPX: what CFastFIR was fed */
+    void *fir_out; size_t fir_stride;     /* [nrx][fir_stride] TYPECPX */
+    void *s16;                            /* [nrx][fir_stride] int16: CAgc / detector output */
+    void *adpcm;                          /* [nrx][fir_stride / 2] bytes */
+} kg_rxbank_bufs;
+int kg_rxbank_buffers(kg_rxbank *bank, kg_rxbank_bufs *out);
 
 #ifdef __cplusplus
 }

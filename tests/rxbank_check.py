@@ -1,0 +1,114 @@
+"""The stage-by-stage comparison of a receiver bank (flydog_sdr_gps_amd.rxbank.RxBank = kg_rxbank) with the oracle.
+
+Test infrastructure: imported by tests/test_receivers_gpu.py (every receiver) and by bench.py AFTER its timed region (a
+sample of the receivers).  The oracle is fed the same ADC stream with its state carried from step to step:
+  waterfall   one-shot receivers: CICs reset at the block's first sample, NCO running on (rx_waterfall.cpp:1005-1041);
+              overlapped receivers: the continuous sampler, frame = the newest 8192 outputs (:967-991); the frame bit for
+              bit where the bank says it read it, the u8 row (tests/test_wf_gpu.py's rule), the wf_pkt_t byte for byte
+  audio       rx_iq_t records bit for bit, the unpacked samples bit for bit, CFastFIR (1e-5 of max), CAgc mono16
+              (<= 1 LSB, >= 99 % identical), the ADPCM payload byte for byte
+"""
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+
+def check_bank(bank, adc_of_step, d_adc_of_step, rxs, steps=3, threads=8):
+    """Steps a FRESHLY CONFIGURED RxBank `steps` times (step k over adc_of_step(k), a host int16 array of bank.n samples whose
+    device copy is d_adc_of_step(k)) and checks every stage of the receivers `rxs`.
+    -> {"receivers", "steps", "frames", "audio_blocks", "overlapped_frames", "ring_moves"}"""
+    from flydog_sdr_gps_amd import wf
+    from oracle import kiwi_oracle as ko
+    from tests.test_wf_gpu import check_row, db_bound, oracle_frame
+    ko.lib()
+    rxs = list(rxs)
+    n = bank.n
+    tables = (wf.window_functions(), wf.cic_comp_table())
+    wf_st = {rx: None for rx in rxs}                       # overlapped: the continuous sampler's state
+    hist = {rx: np.zeros((0, 2), np.int16) for rx in rxs}  # overlapped: the newest outputs (<= 8192)
+    rx_st = {rx: None for rx in rxs}
+    fir_st = {rx: ko.fir_new_state() for rx in rxs}
+    agcs = {rx: ko.Agc() for rx in rxs}
+    for a in agcs.values():
+        a.set_parameters(True, False, -100, 50, 6, 1000, bank.fs)
+    ad_st = {rx: None for rx in rxs}
+    coef = {rx: bank.fir.get_coef(rx) for rx in rxs}
+    frames = audio_blocks = ov_frames = moves = 0
+    snd_seq = 0
+    with ThreadPoolExecutor(threads) as pool:              # the oracle's C calls release the GIL
+        for step in range(steps):
+            adc = adc_of_step(step)
+            info = bank.step(d_adc_of_step(step))
+            bank.sync()
+            assert info.step == step and info.snd_seq == snd_seq, (step, info.step, info.snd_seq, snd_seq)
+            moves += info.nmoves
+            rx_of, f_off, pkt_bytes = bank.frame_map()
+            frame_of = {int(r): f for f, r in enumerate(rx_of)}
+            nrec, nfir = info.nrec, info.nfir
+
+            def wf_ref(rx):
+                p = bank.params[rx]
+                l2 = int(np.log2(p.decim))
+                if bank.overlapped[rx]:
+                    return ko.ddc_wf(adc, p.i_offset, l2, wf_st[rx])
+                st = ko.DdcWfState()                                   # CmdWFReset: CICs zero, the NCO running on
+                st.phase = (step * n * p.i_offset) & ((1 << 48) - 1)
+                return ko.ddc_wf(adc[:8192 * p.decim], p.i_offset, l2, st)
+
+            wf_out = list(pool.map(wf_ref, rxs))
+            rx_out = list(pool.map(lambda rx: ko.ddc_rx(adc, bank.rx_inc[rx], rx_st[rx]), rxs))
+            with_frame = [rx for rx in rxs if rx in frame_of]
+            g_rows = dict(zip(with_frame, bank.fetch("rows", [frame_of[rx] for rx in with_frame])))
+            g_pkts = dict(zip(with_frame, bank.fetch("pkts", [frame_of[rx] for rx in with_frame])))
+            g = {k: bank.fetch(k, rxs) for k in ("wf_iq", "raw", "xin", "firo", "s16", "pay")}
+            stride = bank.bufs.wf_iq_stride
+            for i, rx in enumerate(rxs):
+                p = bank.params[rx]
+                iq, st_new = wf_out[i]
+                if bank.overlapped[rx]:
+                    wf_st[rx] = st_new
+                    assert iq.shape[0] == n // p.decim, (step, rx, iq.shape)
+                    hist[rx] = np.concatenate([hist[rx], iq])[-8192:]
+                    want_frame = hist[rx] if hist[rx].shape[0] == 8192 else None     # "fill pipe": no frame yet
+                else:
+                    assert iq.shape[0] == 8192, (step, rx, iq.shape)
+                    want_frame = iq
+                assert (want_frame is not None) == (rx in frame_of), (step, rx, "frame taken / not taken")
+                if want_frame is not None:
+                    f = frame_of[rx]
+                    off = int(f_off[f]) - rx * stride
+                    assert 0 <= off <= stride - 8192, (step, rx, off)
+                    assert np.array_equal(g["wf_iq"][i, off:off + 8192], want_frame), (step, rx, "frame samples")
+                    w_out, _, w_pwr_out, w_dB = oracle_frame(ko, tables, want_frame, p, wf.WF_MAX, wf.WINF_HANNING, True,
+                                                             bank.overlapped[rx], False)
+                    check_row(g_rows[rx], w_out, w_dB, db_bound(w_pwr_out))
+                    want_pkt = ko.wf_packet(g_rows[rx], int(p.start), p.zoom, snd_seq, True)
+                    assert int(pkt_bytes[f]) == want_pkt.size, (step, rx, pkt_bytes[f], want_pkt.size)
+                    assert np.array_equal(g_pkts[rx][:want_pkt.size], want_pkt), (step, rx, "wf_pkt_t")
+                    frames += 1
+                    ov_frames += int(bank.overlapped[rx])
+                # audio DDC -> rx_iq_t records -> unpack
+                raw, rx_st[rx] = rx_out[i]
+                assert raw.size == 6 * nrec, (step, rx, raw.size, nrec)
+                assert np.array_equal(g["raw"][i, :raw.size], raw), (step, rx, "rx_iq_t")
+                got_x = np.zeros(0, np.complex64)
+                if nrec:
+                    x = ko.dpump_unpack(raw, nrec, 1)[0]
+                    got_x = np.ascontiguousarray(g["xin"][i, :nrec]).view(np.complex64).ravel()
+                    assert np.array_equal(got_x.view(np.uint32), x.view(np.uint32)), (step, rx, "unpack")
+                # CFastFIR on the GPU's own input, then CAgc and ADPCM on the GPU's own upstream output
+                want_y, _ = ko.fir_process(fir_st[rx], coef[rx], got_x, prec=0)
+                assert want_y.size == nfir, (step, rx, want_y.size, nfir)
+                for blk in range(nfir // 512):
+                    sl = slice(512 * blk, 512 * (blk + 1))
+                    got_y = np.ascontiguousarray(g["firo"][i, sl]).view(np.complex64).ravel()
+                    assert np.abs(got_y - want_y[sl]).max() <= 1e-5 * np.abs(want_y[sl]).max(), (step, rx, "CFastFIR")
+                    want_s = agcs[rx].process_s16(got_y)
+                    dlt = np.abs(g["s16"][i, sl].astype(int) - want_s.astype(int))
+                    assert dlt.max() <= 1 and (dlt == 0).mean() > 0.99, (step, rx, dlt.max())
+                    want_enc, ad_st[rx] = ko.adpcm_encode_i16(g["s16"][i, sl], ad_st[rx])
+                    assert np.array_equal(g["pay"][i, 256 * blk:256 * (blk + 1)], want_enc), (step, rx, "ADPCM")
+                    audio_blocks += 1
+            snd_seq += nfir // 512
+    return {"receivers": len(rxs), "steps": steps, "frames": frames, "audio_blocks": audio_blocks,
+            "overlapped_frames": ov_frames, "ring_moves": moves}

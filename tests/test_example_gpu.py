@@ -126,3 +126,96 @@ def test_cpp_waterfall_caller_against_the_oracle(gpu_ctx, oracle, tmp_path):
             want_pkt = oracle.wf_packet(out[s, c]["row"], int(p.start), p.zoom, s, True)
             assert int(out[s, c]["nb"]) == want_pkt.size
             assert np.array_equal(out[s, c]["pkt"][:want_pkt.size], want_pkt), (s, c)
+
+
+# ---- a bank of receivers from C++ ---------------------------------------------------------------------------------
+BANK_EXE = os.path.join(ROOT, "examples", "rxbank_dropin")
+
+
+def write_bank_tables(path, mix, n, fs):
+    """tables.bin of examples/rxbank_dropin.cpp: write_wf_tables' arrays plus, per receiver, the sampler mode, the audio
+    NCO word and the passband."""
+    import struct
+    from flydog_sdr_gps_amd import wf
+    with open(path, "wb") as f:
+        f.write(struct.pack("<ii", len(mix), n))
+        f.write(np.ascontiguousarray(wf.window_functions(), np.float32).tobytes())
+        f.write(np.ascontiguousarray(wf.cic_comp_table(), np.float32).tobytes())
+        for p, ov, rx_inc in mix:
+            m, d = wf.build_maps(p.fft_used, p.plot_width, p.plot_width_clamped, False)
+            m4096 = np.zeros(4096, np.uint16)
+            m4096[:len(m)] = m
+            scale = np.full(1024, p.fft_scale, np.float32)
+            f.write(struct.pack("<8if", p.zoom, wf.WINF_HANNING, wf.WF_MAX, 1, int(ov), p.fft_used, p.plot_width, p.plot_width_clamped,
+                                float(p.fft_offset)))
+            f.write(struct.pack("<QiiI", p.i_offset & ((1 << 48) - 1), p.decim, int(ov), int(p.start) & 0xFFFFFFFF))
+            f.write(m4096.tobytes())
+            f.write(np.ascontiguousarray(d, np.uint16).tobytes())
+            f.write(scale.tobytes())
+            f.write((scale / np.float32(2)).astype(np.float32).tobytes())
+            f.write(struct.pack("<Q3f", int(rx_inc), 300.0, 2700.0, fs))
+
+
+def test_cpp_bank_caller_equals_the_python_mirror(tmp_path):
+    """examples/rxbank_dropin.cpp -- kg_rxbank_create, the per-seam setters on the bank's objects, ONE kg_rxbank_step per
+    step, kg_rxbank_poll, the results read back -- on 12 receivers of SURVEY's mix (three of them overlapped), three steps:
+    every row, packet, mono16 block and ADPCM payload equals what flydog_sdr_gps_amd.rxbank.RxBank (checked stage by stage
+    against the oracle in tests/test_receivers_gpu.py) produces from the same stream, and the host's share of a step is
+    small."""
+    from flydog_sdr_gps_amd import synth
+    from flydog_sdr_gps_amd.rxbank import RxBank, survey_mix
+    assert os.path.exists(BANK_EXE), "examples/rxbank_dropin is not built (run __graft_entry__.build())"
+    NR, n, steps = 12, 1 << 22, 3
+    mix = survey_mix(NR, 20, n)                                   # receivers 20..31: 680 kHz .. 999 kHz, the carrier at 820 kHz among them
+    adc = synth.adc_stream(n * steps, 0x5EED0046)
+    tb, ab, ob = tmp_path / "tables.bin", tmp_path / "adc.bin", tmp_path / "out.bin"
+    bank = RxBank(NR, n)
+    try:
+        write_bank_tables(tb, mix, n, bank.fs)
+        ab.write_bytes(adc.tobytes())
+        r = subprocess.run([BANK_EXE, str(tb), str(ab), str(ob), str(steps)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        print(r.stdout.strip())
+        enq_us = float(r.stdout.split("kg_rxbank_step ")[1].split(" us")[0])
+        assert enq_us < 1000.0, r.stdout                          # (12 receivers on an idle GPU: ~100 us; the bound only catches a stall)
+        blob = ob.read_bytes()
+        bank.configure(mix)
+        d_adc = bank.ctx.alloc(adc.nbytes)
+        bank.ctx.upload(d_adc, adc)
+        pos = 0
+        info_dt = np.dtype([("step", "<u8"), ("nframes", "<i4"), ("nrec", "<i4"), ("nfir", "<i4"), ("fir_pos", "<i4"),
+                            ("snd_seq", "<u4"), ("table_bytes", "<i4"), ("nmoves", "<i4"), ("pad", "<i4")])
+        frame_dt = np.dtype([("rx", "<i4"), ("row", np.uint8, 1024), ("nb", "<i4"), ("pkt", np.uint8, 16 + 10 + 1024)])
+        total_frames = total_blocks = 0
+        for s in range(steps):
+            info = bank.step(d_adc + 2 * n * s)
+            bank.sync()
+            got = np.frombuffer(blob, info_dt, 1, pos)[0]
+            pos += info_dt.itemsize
+            for k in ("step", "nframes", "nrec", "nfir", "fir_pos", "snd_seq", "table_bytes", "nmoves"):
+                assert int(got[k]) == int(getattr(info, k)), (s, k, got[k], getattr(info, k))
+            rx_of, _, nb = bank.frame_map()
+            fr = np.frombuffer(blob, frame_dt, info.nframes, pos)
+            pos += frame_dt.itemsize * info.nframes
+            rows = bank.fetch("rows", range(info.nframes))
+            pkts = bank.fetch("pkts", range(info.nframes))
+            for f in range(info.nframes):
+                assert int(fr[f]["rx"]) == int(rx_of[f]) and int(fr[f]["nb"]) == int(nb[f])
+                assert np.array_equal(fr[f]["row"], rows[f]), (s, f)
+                assert np.array_equal(fr[f]["pkt"][:nb[f]], pkts[f][:nb[f]]), (s, f)
+            total_frames += info.nframes
+            if info.nfir:
+                s16 = bank.fetch("s16", range(NR))
+                pay = bank.fetch("pay", range(NR))
+                for k in range(NR):
+                    a = np.frombuffer(blob, "<i2", info.nfir, pos); pos += 2 * info.nfir
+                    b = np.frombuffer(blob, np.uint8, info.nfir // 2, pos); pos += info.nfir // 2
+                    assert np.array_equal(a, s16[k, :info.nfir]) and np.array_equal(b, pay[k, :info.nfir // 2]), (s, k)
+                    assert np.abs(a.astype(int)).max() > 0
+                    total_blocks += info.nfir // 512
+        assert pos == len(blob)
+        n_ov = sum(1 for _, ov, _ in mix if ov)
+        assert n_ov == 3 and total_frames == steps * NR - n_ov and total_blocks == 2 * NR
+        bank.ctx.free(d_adc)
+    finally:
+        bank.close()

@@ -1,13 +1,12 @@
-"""BASELINE configs[3] at the bench's own shape: bench.ReceiverBank (the object `bench.py --workload
-receivers` times) stepped three times over its 2^22-sample ADC block with (a) a slice of the
-receiver set that straddles a rank boundary (receivers 123..132 of the 1024: every zoom 1..10, ranks 0
-and 1 of the 8 x 128 sharding) and (b) rank 1's whole slice of 128 receivers, and EVERY stage of EVERY receiver checked against the oracle fed the same stream
-with its state carried from step to step: both DDCs bit-exact on all their output, the frame the
-waterfall took, the u8 row, the wf_pkt_t, the unpacked audio samples, CFastFIR, CAgc mono16 and the
-ADPCM payload."""
+"""BASELINE configs[3] through the C ABI's receiver bank (kg_rxbank, include/kiwigpu.h): the object `bench.py --workload
+receivers` times, stepped over its 2^22-sample ADC block on SURVEY.md 8(d)'s receiver mix (f_k = 100 kHz + k 29 kHz, zoom
+8 + (k mod 4): zooms 8..10 take the reference's non-overlapped frame, zoom 11 its overlapped / continuous sampler) and
+EVERY stage of EVERY receiver checked against the oracle (tests/rxbank_check.py); the same on rounds 2-4's lighter mix;
+and a small-step bank stepped often enough for the overlapped receivers' sample rings to wrap."""
 import os
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -15,21 +14,105 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 STEPS = 3
+N = 1 << 22
 
 
-@pytest.mark.parametrize("NR,FIRST", [(10, 123),      # every zoom once, straddling the rank 0 / rank 1 boundary
-                                      (128, 128)])    # rank 1's whole slice: the per-GPU shape of configs[3]
-def test_receiver_bank_every_stage_every_receiver(gpu_ctx, oracle, NR, FIRST):
-    """bench.check_receiver_bank is the stage-by-stage comparison (also run by `bench.py --workload receivers` on a
-    sample of its receivers after the timed region); here on EVERY receiver of the bank."""
-    import torch
-    import bench
-    dev = torch.device("cuda", 0)
-    bank = bench.ReceiverBank(0, dev, NR, 1 << 22, FIRST)
+def _bank(nrx, n, mix):
+    from flydog_sdr_gps_amd.rxbank import RxBank
+    bank = RxBank(nrx, n)
+    bank.configure(mix)
+    return bank
+
+
+@pytest.mark.parametrize("mix_name,NR,FIRST", [("survey", 10, 123),     # straddles the rank 0 / rank 1 boundary of the 8 x 128 sharding
+                                               ("survey", 128, 128),    # rank 1's whole slice: the per-GPU shape of configs[3]
+                                               ("light", 10, 123)])     # every zoom 1..10 (R = 1 bypass, staged small R, large R)
+def test_receiver_bank_every_stage_every_receiver(oracle, mix_name, NR, FIRST):
+    from flydog_sdr_gps_amd import synth
+    from flydog_sdr_gps_amd.rxbank import MIXES
+    from tests.rxbank_check import check_bank
+    mix = MIXES[mix_name](NR, FIRST, N)
+    zooms = sorted(set(p.zoom for p, _, _ in mix))
+    assert zooms == ([8, 9, 10, 11] if mix_name == "survey" else list(range(1, 11)))
+    n_ov = sum(1 for _, ov, _ in mix if ov)
+    assert n_ov == (sum(1 for p, _, _ in mix if p.zoom == 11) if mix_name == "survey" else 0)
+    adc = synth.adc_stream(N, 0x5EED0004)
+    bank = _bank(NR, N, mix)
     try:
-        assert sorted(set(p.zoom for p in bank.params)) == list(range(1, 11))
-        got = bench.check_receiver_bank(bank, range(NR), STEPS)
-        assert got == {"receivers": NR, "steps": STEPS, "audio_blocks": 2 * NR}     # 402 records a step: a 512-sample block on steps 2 and 3
-        assert bank.counts == {"frames": STEPS * NR, "audio_blocks": 2 * NR}
+        d_adc = bank.ctx.alloc(adc.nbytes)
+        bank.ctx.upload(d_adc, adc)
+        got = check_bank(bank, lambda k: adc, lambda k: d_adc, range(NR), STEPS)
+        # 402 records a step: a 512-sample block on steps 2 and 3; an overlapped receiver (4096 outputs a step) takes its first
+        # frame on step 2
+        assert got == {"receivers": NR, "steps": STEPS, "frames": STEPS * NR - n_ov, "audio_blocks": 2 * NR,
+                       "overlapped_frames": (STEPS - 1) * n_ov, "ring_moves": 0}, got
+        bank.ctx.free(d_adc)
+    finally:
+        bank.close()
+
+
+def test_overlapped_rings_wrap_and_streams_differ_per_step(oracle):
+    """A small step (2^17 samples) so that the rings wrap inside the test: R = 16 one-shot, R = 32 / 64 / 128 overlapped with
+    4096 / 2048 / 1024 outputs per step; 48 steps over 48 DIFFERENT blocks of one stream; audio: 12.6 records per step, one
+    512-sample block per receiver near the end."""
+    from flydog_sdr_gps_amd import synth
+    from flydog_sdr_gps_amd.ddc import rx_phase_inc
+    from flydog_sdr_gps_amd.rxbank import ADC_CLOCK, UI_SRATE
+    from flydog_sdr_gps_amd.wf import WfParams
+    from tests.rxbank_check import check_bank
+    n, steps = 1 << 17, 48
+    hz = UI_SRATE / (1024 << 14)
+    mix = []
+    for k, zoom in enumerate([5, 6, 7, 8, 6, 5, 8, 7]):
+        # (every span holds the stream's strong carrier at 0.0123 f_adc = 820 kHz: the rows' tolerance is relative to the
+        # largest bin, and a span of decimated noise alone is dominated by the DC bin compute_frame() then blanks)
+        span = UI_SRATE / (1 << zoom)
+        p = WfParams.for_zoom(zoom, (0.0123 * ADC_CLOCK - span * (0.2 + 0.07 * k)) / hz, adc_clock=ADC_CLOCK, ui_srate=UI_SRATE)
+        mix.append((p, 8192 * p.decim > n, rx_phase_inc(0.0123 * ADC_CLOCK - 900.0 - 35.0 * k, ADC_CLOCK)))
+    assert [ov for _, ov, _ in mix] == [False, True, True, True, True, False, True, True]
+    adc = synth.adc_stream(n * steps, 0x5EED0044)
+    bank = _bank(len(mix), n, mix)
+    try:
+        d_adc = bank.ctx.alloc(adc.nbytes)
+        bank.ctx.upload(d_adc, adc)
+        got = check_bank(bank, lambda k: adc[k * n:(k + 1) * n], lambda k: d_adc + 2 * k * n, range(len(mix)), steps)
+        def wraps(m, ring=65536):                          # the ring discipline of kg_rxbank.hip, restated
+            w = cnt = 0
+            for _ in range(steps):
+                if w + m > ring:
+                    w, cnt = 8192 - m, cnt + 1
+                w += m
+            return cnt
+        assert wraps(4096) >= 2 and wraps(2048) >= 1
+        assert got["ring_moves"] == 2 * (wraps(4096) + wraps(2048) + wraps(1024)), got
+        assert got["frames"] == 2 * steps + 2 * (steps - 1) + 2 * (steps - 3) + 2 * (steps - 7), got
+        assert got["audio_blocks"] == len(mix), got         # 603 records in 48 steps: one block each
+        bank.ctx.free(d_adc)
+    finally:
+        bank.close()
+
+
+def test_bank_error_paths():
+    from flydog_sdr_gps_amd import KiwiGpuError
+    from flydog_sdr_gps_amd.rxbank import ADC_CLOCK, UI_SRATE, RxBank
+    from flydog_sdr_gps_amd.wf import WfParams
+    hz = UI_SRATE / (1024 << 14)
+    bank = RxBank(2, 1 << 17)
+    try:
+        bank.wf.set_tables()
+        p16 = WfParams.for_zoom(5, 1.0e6 / hz, adc_clock=ADC_CLOCK, ui_srate=UI_SRATE)
+        p32 = WfParams.for_zoom(6, 1.0e6 / hz, adc_clock=ADC_CLOCK, ui_srate=UI_SRATE)
+        with pytest.raises(KiwiGpuError):
+            bank.set_wf(0, p32, overlapped=False)            # a one-shot frame at R = 32 takes 2^18 samples
+        p8 = WfParams.for_zoom(4, 1.0e6 / hz, adc_clock=ADC_CLOCK, ui_srate=UI_SRATE)
+        with pytest.raises(KiwiGpuError):
+            bank.set_wf(0, p8, overlapped=True)              # 16384 outputs a step: a frame per step, one-shot is the mode
+        with pytest.raises(KiwiGpuError):
+            bank.set_wf(2, p16)                              # receiver out of range
+        bank.set_wf(0, p16)
+        d = bank.ctx.alloc(2 << 17)
+        with pytest.raises(KiwiGpuError):
+            bank.step(d)                                     # receiver 1 has no waterfall set
+        bank.ctx.free(d)
     finally:
         bank.close()
