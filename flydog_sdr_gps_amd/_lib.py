@@ -170,6 +170,7 @@ SYMBOLS = {
     "kg_rxbank_sync": (_i, [_vp]),
     "kg_rxbank_frame_map": (_i, [_vp, _vp, _vp, _vp]),
     "kg_rxbank_buffers": (_i, [_vp, _vp]),
+    "kg_rxbank_host_profile": (_i, [_vp, C.c_char_p, _sz]),
     "kg_acq_debug_fft_stamps": (_i, [_vp, _i, _vp, _i]),
     "kg_acq_debug_corr_stamps": (_i, [_vp, _i, _vp, _i, _vp, _i]),
 }

@@ -113,3 +113,7 @@ static inline int kg_ctx_use(kg_ctx *ctx)
 // the CPU suite through kg_ddc_nco_table (tests/test_host_cpu.py), not at run time.
 #define KG_NCO_TAB 10240
 extern "C" __attribute__((visibility("hidden"))) void kg_nco_table_build(short *tab);        // kg_ctx.hip (not part of the ABI: kg_ddc_nco_table is)
+
+// kg_ddc.hip, for kg_rxbank.hip (not part of the ABI): the DDC's second stream supplied by the owner.
+struct kg_ddc;
+__attribute__((visibility("hidden"))) int kg_ddc_use_side_stream(kg_ddc *ddc, hipStream_t stream);

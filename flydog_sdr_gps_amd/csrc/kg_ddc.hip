@@ -1376,6 +1376,7 @@ struct kg_ddc {
     int max_runs; long c0_cap[2];
     ddc_chunk_agg *d_aggs; u32 *d_ticket; u32 ticket_base, epoch;     // chunked state scan
     hipStream_t side; hipEvent_t ev_fork, ev_join;                   // pass B of the small decimations beside the rest
+    bool side_borrowed;                                              // `side` is the owner's (a receiver bank's): not destroyed here
     kg_stage_cache pack_cache;                 // the per-call tables of the last push (a steady stream repeats them: no upload)
     std::vector<u64> h_pushed;                 // per channel: samples pushed since its reference point (ddc_chan.phase / .sample_no)
     std::vector<char> h_stale;                 // per channel: a capture cut its filters short; the next continuous push resets it
@@ -1398,6 +1399,17 @@ static const int DDC_RUN_MIN = 64, DDC_RUN_MAX = 8192, DDC_TARGET_RUNS = 8192;
 static const int DDC_MAX_GX = DDC_TARGET_RUNS * 2 / DDC_THREADS;      // workgroups of a run pass per channel: one lane each in ddc_wf_scan_wg_kernel
 static_assert(DDC_MAX_GX <= 64, "ddc_wf_scan_wg_kernel scans one workgroup total per lane");
 static_assert(DDC_THREADS == 256, "ddc_wf_comb_kernel finds a run's pass-B workgroup as run >> 8");
+
+// The object's second stream, handed over by an owner that lays out its streams itself (kg_rxbank.hip: which hardware queue
+// a stream lands on follows from the order streams are created in).  Before the first push.  Not part of the ABI.
+int kg_ddc_use_side_stream(kg_ddc *d, hipStream_t s)
+{
+    KG_REQUIRE(d && s && !d->side, KG_ERR_STATE, "kg_ddc_use_side_stream: the object already has a second stream");
+    KG_HIP(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
+    KG_HIP(hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming));
+    d->side = s; d->side_borrowed = true;
+    return KG_OK;
+}
 
 extern "C" {
 
@@ -1465,7 +1477,7 @@ void kg_ddc_destroy(kg_ddc *d)
     (void) hipFree(d->d_aggs); (void) hipFree(d->d_ticket); (void) hipFree(d->d_endco);
     for (int p = 0; p < 2; p++) { (void) hipFree(d->d_wgtot[p]); (void) hipFree(d->d_wgbase[p]); (void) hipFree(d->d_wgtau[p]); }
     kg_stage_cache_free(&d->pack_cache);
-    if (d->side) { (void) hipEventDestroy(d->ev_fork); (void) hipEventDestroy(d->ev_join); (void) hipStreamDestroy(d->side); }
+    if (d->side) { (void) hipEventDestroy(d->ev_fork); (void) hipEventDestroy(d->ev_join); if (!d->side_borrowed) (void) hipStreamDestroy(d->side); }
     if (d->tail) {
         (void) hipEventDestroy(d->ev_runs); (void) hipEventDestroy(d->ev_tail[0]); (void) hipEventDestroy(d->ev_tail[1]);
         (void) hipStreamDestroy(d->tail);

@@ -21,6 +21,7 @@
 // launched, no state advanced), then -- behind the one transfer -- for real.
 #include "kg_common.h"
 
+#include <chrono>
 #include <math.h>
 #include <stdlib.h>
 #include <vector>
@@ -45,6 +46,7 @@ struct kg_rxbank {
     int device, nrx, mode, decim_rx;
     size_t n;                                   // ADC samples per step
     hipStream_t s_main, s_side, s_tail, s_up;   // waterfall chain / audio chain / both sequential coders / the table upload
+    hipStream_t s_ddc2;                         // the waterfall DDC's second stream (R = 1 bypass, pass B of R <= 8 beside the rest)
     kg_ctx *c_main, *c_side, *c_tail;
     kg_ddc *ddc; kg_wf *wf; kg_rxddc *rx; kg_fir *fir; kg_post *post; kg_adpcm *adpcm;
     // device buffers
@@ -71,6 +73,21 @@ struct kg_rxbank {
     std::vector<uint8_t> enabled; std::vector<bank_move> moves; std::vector<kg_wf_pkt_info> pkt_step;
     std::vector<long> ring_w2, ring_total2;
     kg_rxbank_step_info last;
+    // where the host's share of a step goes (kg_rxbank_host_profile): seconds per phase, summed over `prof_steps` steps
+    double prof[16]; uint64_t prof_steps;
+};
+
+enum { PF_PLAN = 0, PF_UPLOAD, PF_RXDDC, PF_UNPACK, PF_FIR, PF_POST, PF_ADPCM, PF_DDC, PF_FRAMES, PF_PKT, PF_EVENTS, PF_END, PF_N };
+static const char *const PF_NAME[PF_N] = {"plan pass", "slot wait + upload", "rxddc", "unpack", "fir", "post", "adpcm", "wf ddc", "frames", "packets",
+                                          "events between the chains", "end-of-step events"};
+struct bank_tick {
+    std::chrono::steady_clock::time_point t;
+    bank_tick() : t(std::chrono::steady_clock::now()) {}
+    void lap(kg_rxbank *b, int k, bool on) {
+        const auto n = std::chrono::steady_clock::now();
+        if (on) b->prof[k] += std::chrono::duration<double>(n - t).count();
+        t = n;
+    }
 };
 
 static void bank_set_arena(kg_rxbank *b, int mode)
@@ -86,8 +103,11 @@ static int bank_pass(kg_rxbank *b, const void *d_adc, bool plan)
     const int NR = b->nrx;
     const int32_t *all = b->all.data();
     int rc;
+    bank_tick tk;
+    const bool pf = !plan;
     // ---- audio chain (side stream): rx.v -> rx_iq_t -> snd_service() unpack -> CFastFIR; the tail: S-meter, CAgc, ADPCM
     if ((rc = kg_rxddc_push_dev(b->rx, d_adc, b->n, all, NR, b->d_raw, b->nrec_max, b->h_nrec.data()))) return rc;
+    tk.lap(b, PF_RXDDC, pf);
     const int nrec = b->h_nrec[0];
     for (int i = 1; i < NR; i++)
         KG_REQUIRE(b->h_nrec[i] == nrec, KG_ERR_STATE, "kg_rxbank_step: receiver %d yields %d records, receiver 0 %d "
@@ -96,11 +116,14 @@ static int bank_pass(kg_rxbank *b, const void *d_adc, bool plan)
         (rc = kg_dpump_unpack_rows_dev(b->c_side, b->d_raw, b->nrec_max, nrec, NR, b->enabled.data(), b->rescale, b->dc_i, b->dc_q, b->spectral_inversion,
                                        b->d_xin, b->nrec_max)))
         return rc;
+    tk.lap(b, PF_UNPACK, pf);
     if (!plan && b->tail_pending) {                       // the coders of the step before have read fir_out
         KG_HIP(hipStreamWaitEvent(b->s_side, b->ev_tail, 0));
         b->tail_pending = false;
     }
+    tk.lap(b, PF_EVENTS, pf);
     if ((rc = kg_fir_process_dev(b->fir, all, NR, b->d_xin, b->nrec_max, nrec, b->d_firo, b->firo_stride, b->h_nfir.data()))) return rc;
+    tk.lap(b, PF_FIR, pf);
     const int nfir = b->h_nfir[0];
     for (int i = 1; i < NR; i++)
         KG_REQUIRE(b->h_nfir[i] == nfir, KG_ERR_STATE, "kg_rxbank_step: CFastFIR of receiver %d is at another position than receiver 0's", i);
@@ -109,18 +132,22 @@ static int bank_pass(kg_rxbank *b, const void *d_adc, bool plan)
             KG_HIP(hipEventRecord(b->ev_fir, b->s_side));
             KG_HIP(hipStreamWaitEvent(b->s_tail, b->ev_fir, 0));
         }
+        tk.lap(b, PF_EVENTS, pf);
         for (int blk = 0; blk < nfir / KG_FIR_OUT; blk++) {             // one sound packet per 512 samples (rx_sound.cpp:601-1170)
             const size_t o = (size_t) blk * KG_FIR_OUT;
             if ((rc = kg_post_process_dev(b->post, all, NR, b->d_firo + o, b->firo_stride, KG_FIR_OUT, b->d_s16 + o, nullptr, nullptr,
                                           b->firo_stride)))
                 return rc;
+            tk.lap(b, PF_POST, pf);
             if ((rc = kg_adpcm_encode_dev(b->adpcm, all, NR, b->d_s16 + o, b->firo_stride, KG_FIR_OUT, b->d_pay + o / 2, b->firo_stride / 2)))
                 return rc;
+            tk.lap(b, PF_ADPCM, pf);
         }
         if (!plan) {
             KG_HIP(hipEventRecord(b->ev_tail, b->s_tail));
             b->tail_pending = true;
         }
+        tk.lap(b, PF_EVENTS, pf);
     }
     // ---- waterfall chain (main stream)
     int nframes = 0;
@@ -161,18 +188,22 @@ static int bank_pass(kg_rxbank *b, const void *d_adc, bool plan)
     if ((rc = kg_ddc_wf_step_dev(b->ddc, d_adc, b->n, all, NR, b->d_wfiq, b->wf_stride, b->out_off.data(), b->max_out.data(),
                                  b->h_nw.data())))
         return rc;
+    tk.lap(b, PF_DDC, pf);
     if (!plan && b->pk_pending) {                         // the packets of the step before have read the rows
         KG_HIP(hipStreamWaitEvent(b->s_main, b->ev_pk, 0));
         b->pk_pending = false;
     }
+    tk.lap(b, PF_EVENTS, pf);
     if (nframes > 0) {
         if ((rc = kg_wf_frames_at_dev(b->wf, nframes, b->chan_of.data(), b->frame_off.data(), (uint64_t) NR * b->wf_stride, b->d_wfiq,
                                       b->d_rows)))
             return rc;
+        tk.lap(b, PF_FRAMES, pf);
         if (!plan) {
             KG_HIP(hipEventRecord(b->ev_frames, b->s_main));
             KG_HIP(hipStreamWaitEvent(b->s_tail, b->ev_frames, 0));
         }
+        tk.lap(b, PF_EVENTS, pf);
         for (int f = 0; f < nframes; f++) {
             b->pkt_step[f] = b->pkt[b->chan_of[f]];
             b->pkt_step[f].seq = b->snd_seq;                              // out->seq = wf->snd_seq, rx_waterfall.cpp:1635
@@ -180,10 +211,12 @@ static int bank_pass(kg_rxbank *b, const void *d_adc, bool plan)
         if ((rc = kg_wf_packets_dev(b->c_tail, b->d_rows, KG_WF_WIDTH, nframes, b->pkt_step.data(), b->d_pkts, BANK_PKT_STRIDE,
                                     b->pkt_bytes.data())))
             return rc;
+        tk.lap(b, PF_PKT, pf);
         if (!plan) {
             KG_HIP(hipEventRecord(b->ev_pk, b->s_tail));
             b->pk_pending = true;
         }
+        tk.lap(b, PF_EVENTS, pf);
     }
     if (!plan) {
         for (int k = 0; k < NR; k++)
@@ -203,8 +236,8 @@ void kg_rxbank_destroy(kg_rxbank *b)
 {
     if (!b) return;
     (void) hipSetDevice(b->device);
-    for (hipStream_t s : {b->s_main, b->s_side, b->s_tail, b->s_up}) if (s) (void) hipStreamSynchronize(s);
-    if (b->c_main) bank_set_arena(b, KG_ARENA_OFF);
+    for (hipStream_t s : {b->s_main, b->s_side, b->s_tail, b->s_ddc2, b->s_up}) if (s) (void) hipStreamSynchronize(s);
+    if (b->c_main && b->c_side && b->c_tail) bank_set_arena(b, KG_ARENA_OFF);
     kg_adpcm_destroy(b->adpcm); kg_post_destroy(b->post); kg_fir_destroy(b->fir); kg_rxddc_destroy(b->rx);
     kg_wf_destroy(b->wf); kg_ddc_destroy(b->ddc);
     kg_ctx_destroy(b->c_tail); kg_ctx_destroy(b->c_side); kg_ctx_destroy(b->c_main);
@@ -214,7 +247,7 @@ void kg_rxbank_destroy(kg_rxbank *b)
     (void) hipFree(b->d_slots);
     for (int i = 0; i < BANK_SLOTS; i++) for (int j = 0; j < 3; j++) if (b->ev_end[i][j]) (void) hipEventDestroy(b->ev_end[i][j]);
     for (hipEvent_t e : {b->ev_tab, b->ev_fir, b->ev_tail, b->ev_frames, b->ev_pk}) if (e) (void) hipEventDestroy(e);
-    if (b->s_up) (void) hipStreamDestroy(b->s_up);         // (the other three are the contexts' own)
+    for (hipStream_t s : {b->s_main, b->s_side, b->s_tail, b->s_ddc2, b->s_up}) if (s) (void) hipStreamDestroy(s);
     delete b;
 }
 
@@ -229,19 +262,36 @@ int kg_rxbank_create(int device, int nrx, size_t adc_samples_per_step, int rx_mo
     KG_REQUIRE(b != nullptr, KG_ERR_NOMEM, "kg_rxbank_create: alloc");
     b->device = device; b->nrx = nrx; b->mode = rx_mode; b->n = adc_samples_per_step;
     int rc = KG_OK;
-    // the contexts first: kg_ctx_create is what says "no gfx950 device" (there is no CPU fallback)
-    kg_ctx *probe = nullptr;
-    if ((rc = kg_ctx_create(device, nullptr, &probe))) { delete b; return rc; }
-    b->c_main = probe; b->s_main = probe->stream;     // (the contexts own the streams)
+    {   // (what says "no gfx950 device": there is no CPU fallback)
+        int ndev = 0;
+        const hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev <= 0) {
+            kg_set_error("kg_rxbank_create: no HIP device (%s); libkiwigpu has no CPU fallback", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+            delete b;
+            return KG_ERR_NO_DEVICE;
+        }
+        if (device < 0 || device >= ndev) { kg_set_error("kg_rxbank_create: device %d out of range (0..%d)", device, ndev - 1); delete b; return KG_ERR_INVALID; }
+    }
 #define BANK_TRY(call) do { if ((rc = (call)) != KG_OK) { kg_rxbank_destroy(b); return rc; } } while (0)
 #define BANK_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { kg_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, \
                             hipGetErrorString(e_)); kg_rxbank_destroy(b); return KG_ERR_HIP; } } while (0)
-    BANK_TRY(kg_ctx_create(device, nullptr, &b->c_side));
-    b->s_side = b->c_side->stream;
-    BANK_TRY(kg_ctx_create(device, nullptr, &b->c_tail));
-    b->s_tail = b->c_tail->stream;
+    // The four streams that carry kernels are created FIRST and back to back: the HIP runtime deals hardware queues to
+    // streams in creation order, and queues whose numbers are equal modulo four took turns instead of running side by side
+    // (measured, rocprofv3 queue ids: with torch's null stream created first the waterfall chain landed on queue 2 and the
+    // DDC's own second stream, created lazily as the sixth, on queue 6 -- 1.31 ms per step against 1.02 with queues 1 and 6).
+    // Four consecutive queues are distinct modulo four whatever was created before them; the upload stream (a DMA
+    // transfer, no kernels) comes fifth.
+    BANK_HIP(hipSetDevice(device));
+    BANK_HIP(hipStreamCreateWithFlags(&b->s_main, hipStreamNonBlocking));
+    BANK_HIP(hipStreamCreateWithFlags(&b->s_side, hipStreamNonBlocking));
+    BANK_HIP(hipStreamCreateWithFlags(&b->s_tail, hipStreamNonBlocking));
+    BANK_HIP(hipStreamCreateWithFlags(&b->s_ddc2, hipStreamNonBlocking));
     BANK_HIP(hipStreamCreateWithFlags(&b->s_up, hipStreamNonBlocking));
+    BANK_TRY(kg_ctx_create_on_stream(device, b->s_main, &b->c_main));
+    BANK_TRY(kg_ctx_create_on_stream(device, b->s_side, &b->c_side));
+    BANK_TRY(kg_ctx_create_on_stream(device, b->s_tail, &b->c_tail));
     BANK_TRY(kg_ddc_create(b->c_main, nrx, b->n, &b->ddc));
+    BANK_TRY(kg_ddc_use_side_stream(b->ddc, b->s_ddc2));
     BANK_TRY(kg_wf_create(b->c_main, nrx, &b->wf));
     BANK_TRY(kg_rxddc_create_mode(b->c_side, nrx, b->n, rx_mode, &b->rx));
     b->decim_rx = kg_rxddc_decim(b->rx);
@@ -341,14 +391,17 @@ int kg_rxbank_step(kg_rxbank *b, const void *d_adc, void *adc_ready_event, kg_rx
 {
     KG_REQUIRE(b && d_adc, KG_ERR_INVALID, "kg_rxbank_step: null argument");
     KG_HIP(hipSetDevice(b->device));
+    bank_tick tk;
     const int slot = (int) (b->step % BANK_SLOTS);
     if (b->ev_end_rec[slot])                               // the step that last used this slot (BANK_SLOTS steps ago) has run
         for (int j = 0; j < 3; j++) KG_HIP(hipEventSynchronize(b->ev_end[slot][j]));
     kg_arena &a = b->arena;
     a.h_base = b->h_slots + (size_t) slot * b->slot_bytes; a.d_base = b->d_slots + (size_t) slot * b->slot_bytes;
     a.cap = b->slot_bytes; a.used = 0; a.nent = 0; a.cursor = 0;
+    tk.lap(b, PF_UPLOAD, true);
     bank_set_arena(b, KG_ARENA_PLAN);
     int rc = bank_pass(b, d_adc, true);
+    tk.lap(b, PF_PLAN, true);
     if (rc == KG_OK) {
         // the ONE transfer of the step, on a stream of its own (ordered behind nothing but earlier uploads: the slot is free)
         hipError_t e = hipMemcpyAsync(a.d_base, a.h_base, a.used, hipMemcpyHostToDevice, b->s_up);
@@ -361,6 +414,7 @@ int kg_rxbank_step(kg_rxbank *b, const void *d_adc, void *adc_ready_event, kg_rx
         }
         if (e != hipSuccess) { kg_set_error("kg_rxbank_step: %s", hipGetErrorString(e)); rc = KG_ERR_HIP; }
     }
+    tk.lap(b, PF_UPLOAD, true);
     if (rc == KG_OK) {
         a.mode = KG_ARENA_REPLAY;
         rc = bank_pass(b, d_adc, false);
@@ -368,10 +422,13 @@ int kg_rxbank_step(kg_rxbank *b, const void *d_adc, void *adc_ready_event, kg_rx
     }
     bank_set_arena(b, KG_ARENA_OFF);
     if (rc) return rc;
+    tk = bank_tick();
     KG_HIP(hipEventRecord(b->ev_end[slot][0], b->s_main));
     KG_HIP(hipEventRecord(b->ev_end[slot][1], b->s_side));
     KG_HIP(hipEventRecord(b->ev_end[slot][2], b->s_tail));
     b->ev_end_rec[slot] = true;
+    tk.lap(b, PF_END, true);
+    b->prof_steps++;
     b->step++;
     if (info) *info = b->last;
     return KG_OK;
@@ -406,6 +463,22 @@ int kg_rxbank_sync(kg_rxbank *b)
     KG_REQUIRE(b != nullptr, KG_ERR_INVALID, "kg_rxbank_sync: null argument");
     KG_HIP(hipSetDevice(b->device));
     for (hipStream_t s : {b->s_up, b->s_main, b->s_side, b->s_tail}) KG_HIP(hipStreamSynchronize(s));
+    return KG_OK;
+}
+
+// The host's share of the steps since the last call (or since create), by phase: text into buf.  The slot wait is where a
+// host that runs ahead of the GPU blocks (BANK_SLOTS steps deep), so measure with the bank drained between steps.
+int kg_rxbank_host_profile(kg_rxbank *b, char *buf, size_t len)
+{
+    KG_REQUIRE(b && buf && len > 0, KG_ERR_INVALID, "kg_rxbank_host_profile: null argument");
+    size_t at = 0;
+    double tot = 0;
+    const double n = b->prof_steps ? (double) b->prof_steps : 1.0;
+    for (int k = 0; k < PF_N; k++) tot += b->prof[k];
+    at += (size_t) snprintf(buf + at, len - at, "%llu steps, %.1f us of host time per step:", (unsigned long long) b->prof_steps, tot / n * 1e6);
+    for (int k = 0; k < PF_N && at < len; k++) at += (size_t) snprintf(buf + at, len - at, " %s %.1f;", PF_NAME[k], b->prof[k] / n * 1e6);
+    for (int k = 0; k < PF_N; k++) b->prof[k] = 0;
+    b->prof_steps = 0;
     return KG_OK;
 }
 

@@ -159,6 +159,12 @@ class RxBank:
     def adc_done(self, stream):
         check(self.lib.kg_rxbank_adc_done(self.h, C.c_void_p(int(stream))), "kg_rxbank_adc_done")
 
+    def host_profile(self):
+        """Where the host's share of the steps since the last call went (text; kg_rxbank_host_profile)."""
+        buf = C.create_string_buffer(1024)
+        check(self.lib.kg_rxbank_host_profile(self.h, buf, 1024), "kg_rxbank_host_profile")
+        return buf.value.decode()
+
     def frame_map(self):
         """-> (rx_of_frame, frame_off, pkt_bytes) of the last step"""
         rx_of = np.zeros(self.nrx, np.int32)

@@ -659,6 +659,8 @@ typedef struct {
     void *adpcm;                          /* [nrx][fir_stride / 2] bytes */
 } kg_rxbank_bufs;
 int kg_rxbank_buffers(kg_rxbank *bank, kg_rxbank_bufs *out);
+/* Where the host's share of the steps since the last call went, by phase (microseconds per step, text). */
+int kg_rxbank_host_profile(kg_rxbank *bank, char *buf, size_t len);
 
 #ifdef __cplusplus
 }
