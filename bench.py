@@ -181,8 +181,12 @@ def box_identity(local_rank=0):
     import re
     import shutil
     import socket
-    box = {"host": socket.gethostname(), "lib_sha16": sha16(os.path.join(ROOT, "flydog_sdr_gps_amd", "libkiwigpu.so")),
-           "bench_sha16": sha16(os.path.abspath(__file__)), "gpu_uuid": None, "gpu_name": None}
+    # the library that is MEASURED: KIWIGPU_LIBRARY names another build for A/B runs (flydog_sdr_gps_amd/_lib.py, library_path)
+    lib_path = os.environ.get("KIWIGPU_LIBRARY") or os.path.join(ROOT, "flydog_sdr_gps_amd", "libkiwigpu.so")
+    box = {"host": socket.gethostname(), "lib_sha16": sha16(lib_path), "bench_sha16": sha16(os.path.abspath(__file__)),
+           "gpu_uuid": None, "gpu_name": None}
+    if os.environ.get("KIWIGPU_LIBRARY"):
+        box["lib_path"] = lib_path
     try:
         if shutil.which("rocminfo"):
             txt = subprocess.run(["rocminfo"], capture_output=True, text=True, timeout=60).stdout

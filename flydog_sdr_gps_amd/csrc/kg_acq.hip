@@ -276,59 +276,6 @@ struct acq_walk {
 // = W_R^{4a k2} * W_R^{b k2}.  comb[k2] = { W_R^{k2}, W_R^{2 k2}, W_R^{3 k2},
 // W_R^{4 k2}, W_R^{8 k2}, W_R^{12 k2}, -, - } (host-built, fp32 roundings of double
 // values); quart[k2][q] = W_P^{q k2}: the factor of output quarter q (NQ = 4).
-// Knock-out builds of the C/A correlator (timing experiments, wrong results by construction: tools/ko_acq.sh):
-// -DACQ_KO=1 no barriers inside the item, 3 no butterflies / products / twiddles, 4 no operand rows of the next item, 8 no
-// tile stores, 9 no tile loads, 10 no twiddle-accumulate, 11 no power / maximum scan.
-#ifndef ACQ_KO
-#define ACQ_KO 0
-#endif
-#if ACQ_KO == 1
-#define ACQ_KO_SYNC() do {} while (0)
-#else
-#define ACQ_KO_SYNC() __syncthreads()
-#endif
-template <class H> KG_DEV void acq_ko_pass16(const cf (&x)[16], cf (&y)[16], H hook)
-{
-#pragma unroll
-    for (int m = 0; m < 16; m++) { y[m] = x[m]; asm volatile("" : "+v"(y[m])); }
-#pragma unroll
-    for (int sgrp = 0; sgrp < 8; sgrp++) hook(sgrp);
-}
-template <class H> KG_DEV void ACQ_KO_CC(const cf (&c)[16], const cf (&d)[16], cf (&y)[16], H hook)
-{
-#if ACQ_KO == 3
-#pragma unroll
-    for (int q = 0; q < 16; q++) asm volatile("" :: "v"(d[q]));
-    acq_ko_pass16(c, y, hook);
-#else
-    kg_cc_radix16_h<+1>(c, d, y, hook);
-#endif
-}
-template <class H> KG_DEV void ACQ_KO_TW(cf (&x)[16], cf (&y)[16], const kg_tw15 &w, H hook)
-{
-#if ACQ_KO == 3
-#pragma unroll
-    for (int q = 0; q < 15; q++) asm volatile("" :: "v"(w.w[q]));
-    acq_ko_pass16(x, y, hook);
-#else
-    kg_tw_radix16_h<+1>(x, y, w, hook);
-#endif
-}
-#if ACQ_KO == 8
-KG_DEV void ACQ_KO_ST(float2 *, cf v) { asm volatile("" :: "v"(v)); }
-#else
-#define ACQ_KO_ST kg_st
-#endif
-#if ACQ_KO == 9
-KG_DEV cf ACQ_KO_LD(const float2 *) { cf v = cf{1.f, 2.f}; asm volatile("" : "+v"(v)); return v; }
-#else
-#define ACQ_KO_LD kg_ld_tile
-#endif
-#if ACQ_KO == 10
-#define ACQ_KO_DEFERRED(slot, k2) do {} while (0)
-#else
-#define ACQ_KO_DEFERRED(slot, k2) deferred(slot, k2)
-#endif
 
 // Round 4: the second exchange without the swizzle (kg_fft.h, kg_subfft4096_l: its writer has the slot column in the lane, its
 // stores and loads are conflict-free as they stand): one address register instead of sixteen.  -DACQ_X2_SWIZZLE=1: as before.
@@ -426,13 +373,11 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
         c[2 * i + 1] = cf{__uint_as_float(cv[2]), __uint_as_float(cv[3])};
     };
     auto fetch_drow = [&](const acq_rsrc &r, int i) {
-        if (ACQ_KO == 4) return;
         const u4 dv = __builtin_amdgcn_raw_buffer_load_b128(r.drs, r.dvo, i * 4096, 0);
         d[2 * i] = cf{__uint_as_float(dv[0]), __uint_as_float(dv[1])};
         d[2 * i + 1] = cf{__uint_as_float(dv[2]), __uint_as_float(dv[3])};
     };
     auto fetch_crow = [&](const acq_rsrc &r, int i) {
-        if (ACQ_KO == 4) return;
         const u4 cv = __builtin_amdgcn_raw_buffer_load_b128(r.crs, r.cvo, i * rowb_c, 0);
         c[2 * i] = cf{__uint_as_float(cv[0]), __uint_as_float(cv[1])};
         c[2 * i + 1] = cf{__uint_as_float(cv[2]), __uint_as_float(cv[3])};
@@ -588,14 +533,14 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
             // a time as the operands they overwrite are consumed; the LDS stores group by group as before.
             KG_STAMP(STAMPS, sti, 9);
             KG_STAMP(STAMPS, sti, 10);
-            ACQ_KO_CC(c, d, y, [&](int s) {
+            kg_cc_radix16_h<+1>(c, d, y, [&](int s) {
                 kg_pin();
                 if (s < 4) {
                     if constexpr (NQ == 1) { fetch_drow(nr, 2 * s); fetch_drow(nr, 2 * s + 1); }
                     else { fetch_row(nr, 2 * s); fetch_row(nr, 2 * s + 1); }
                 } else {
 #pragma unroll
-                    for (int m = s - 4; m < 16; m += 4) ACQ_KO_ST(&tileA[16 * t + (m ^ tl)], y[m]);
+                    for (int m = s - 4; m < 16; m += 4) kg_st(&tileA[16 * t + (m ^ tl)], y[m]);
                 }
                 kg_pin();
             });
@@ -622,24 +567,24 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
                     else { fetch_row(nr, 3 + s); if (s == 3) fetch_row(nr, 7); }
                 } else {
 #pragma unroll
-                    for (int m = s - 4; m < 16; m += 4) ACQ_KO_ST(&tileA[16 * t + (m ^ tl)], y[m]);
+                    for (int m = s - 4; m < 16; m += 4) kg_st(&tileA[16 * t + (m ^ tl)], y[m]);
                 }
                 kg_pin();
             });
 #endif
             KG_STAMP(STAMPS, sti, 0);
-            ACQ_KO_DEFERRED(0, k2);
+            deferred(0, k2);
             KG_STAMP(STAMPS, sti, 1);
-            ACQ_KO_SYNC();
+            __syncthreads();
             KG_STAMP(STAMPS, sti, 2);
 #pragma unroll
-            for (int j = 0; j < 16; j++) x[j] = ACQ_KO_LD(&tileA[rd + 256 * j]);
-            ACQ_KO_DEFERRED(1, k2);
+            for (int j = 0; j < 16; j++) x[j] = kg_ld_tile(&tileA[rd + 256 * j]);
+            deferred(1, k2);
             if (STAMPS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             KG_STAMP(STAMPS, sti, 3);
             // pass 1: twiddle W256^(j*(t&15)), out index (t>>4)*256 + (t&15) + 16 m
 #if KG_FUSED_TW
-            ACQ_KO_TW(x, y, tw.p1, [&](int s) {
+            kg_tw_radix16_h<+1>(x, y, tw.p1, [&](int s) {
 #else
             kg_twiddle16<+1>(x, tw.p1);
             kg_radix16_h<+1>(x, y, [&](int s) {
@@ -647,13 +592,13 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
                 if (s >= 4) {
                     kg_pin();
 #pragma unroll
-                    for (int m = s - 4; m < 16; m += 4) ACQ_KO_ST(&tileB[ACQ_X2_WR(t, th, tl, m)], y[m]);
+                    for (int m = s - 4; m < 16; m += 4) kg_st(&tileB[ACQ_X2_WR(t, th, tl, m)], y[m]);
                     kg_pin();
                 }
             });
             KG_STAMP(STAMPS, sti, 4);
-            ACQ_KO_DEFERRED(2, k2);
-            ACQ_KO_SYNC();
+            deferred(2, k2);
+            __syncthreads();
             KG_STAMP(STAMPS, sti, 5);
             // wave-uniform constants (s_load), hidden behind pass 2
             cf g[3], G[3], Q[3];
@@ -665,8 +610,8 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
                 for (int q = 1; q < 4; q++) Q[q - 1] = kg_ld(&quart[4 * k2 + q]);
             }
 #pragma unroll
-            for (int j = 0; j < 16; j++) x[j] = ACQ_KO_LD(&tileB[ACQ_X2_RD(t, rd) + 256 * j]);
-            ACQ_KO_DEFERRED(3, k2);
+            for (int j = 0; j < 16; j++) x[j] = kg_ld_tile(&tileB[ACQ_X2_RD(t, rd) + 256 * j]);
+            deferred(3, k2);
             if (STAMPS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             KG_STAMP(STAMPS, sti, 6);
             // pass 2: twiddle W4096^(j*t), out index t + 256 m (kept in registers)
@@ -677,7 +622,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
                 }
             };
 #if KG_FUSED_TW
-            ACQ_KO_TW(x, yprev, tw.p2, crows);
+            kg_tw_radix16_h<+1>(x, yprev, tw.p2, crows);
 #else
             kg_twiddle16<+1>(x, tw.p2);
             kg_radix16_h<+1>(x, yprev, crows);
@@ -702,11 +647,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
         const int limit = cur.limit, full_rows = limit >> 8;
         float bp = 0.f, sum = 0.f;
         int bi = 0;
-        if constexpr (ACQ_KO == 11) {
-#pragma unroll
-            for (int m = 0; m < 16; m++) asm volatile("" :: "v"(acc[0][m]));
-            bp = (float) t; sum = 1.f; bi = t;
-        } else if constexpr (NQ == 1 && P == 4) {
+        if constexpr (NQ == 1 && P == 4) {
             // the 16368-lag kernel's form of the scan (acq_correlate8_kernel): powers kept, total in packed pairs, maximum
             // by fmax, the lane's FIRST row holding it from a row mask built with a compare and an add-with-carry per row
             // (acq 0.796 -> 0.789 ms; P = 16 keeps the serial form below: its sixteen more registers of powers spilled there,
@@ -825,49 +766,6 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
 // ---------------------------------------------------------------------------
 #define ACQ8_LDS_BYTES (3 * SUB * sizeof(float2) + 8 * sizeof(acq_red) + 16 + 16 * 8 * sizeof(float2) + 3 * 512 * 4)   // + the per-k2 constants + the cell-end hand-over
 
-// Knock-out builds of the 16368-lag correlator (timing experiments, wrong results by construction: tools/ko_acq.sh acq59 ...):
-// -DE1B_KO=1 no barriers inside the item, 3 no butterflies / products / twiddles, 4 no operand rows of the next item, 8 no tile
-// stores, 9 no tile loads, 10 no twiddle-accumulate.
-#ifndef E1B_KO
-#define E1B_KO 0
-#endif
-#if E1B_KO == 1
-#define E1B_KO_SYNC() do {} while (0)
-#else
-#define E1B_KO_SYNC() __syncthreads()
-#endif
-template <class H> KG_DEV void E1B_KO_CC(const cf (&c)[8], const cf (&d)[8], cf (&y)[8], H hook)
-{
-#if E1B_KO == 3
-#pragma unroll
-    for (int q = 0; q < 8; q++) { asm volatile("" :: "v"(d[q])); y[q] = c[q]; asm volatile("" : "+v"(y[q])); }
-    hook();
-#else
-    kg_cc_radix8_h<+1>(c, d, y, hook);
-#endif
-}
-template <class H> KG_DEV void E1B_KO_TW(cf (&x)[8], cf (&y)[8], const kg_tw7 &w, H hook)
-{
-#if E1B_KO == 3
-#pragma unroll
-    for (int q = 0; q < 7; q++) asm volatile("" :: "v"(w.w[q]));
-#pragma unroll
-    for (int q = 0; q < 8; q++) { y[q] = x[q]; asm volatile("" : "+v"(y[q])); }
-    hook();
-#else
-    kg_tw_radix8_h<+1>(x, y, w, hook);
-#endif
-}
-#if E1B_KO == 8
-KG_DEV void E1B_KO_ST(float2 *, cf v) { asm volatile("" :: "v"(v)); }
-#else
-#define E1B_KO_ST kg_st
-#endif
-#if E1B_KO == 9
-KG_DEV cf E1B_KO_LD(const float2 *) { cf v = cf{1.f, 2.f}; asm volatile("" : "+v"(v)); return v; }
-#else
-#define E1B_KO_LD kg_ld_tile
-#endif
 
 template <int P, bool STAMPS = false>        // STAMPS: diagnostic instantiation only (kg_acq_debug_corr_stamps)
 __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
@@ -987,15 +885,15 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
     {   // prologue: item 0 of the workgroup's first cell up to tile 1 (passes 0 and 1), operands of item 1 requested
         cf x[8], y[8];
         // (round 4: products and twiddles fused into the butterflies, kg_fft.h)
-        E1B_KO_CC(c, d, y, [&]() { kg_pin(); fetch_item(cur, 1); kg_pin(); });
+        kg_cc_radix8_h<+1>(c, d, y, [&]() { kg_pin(); fetch_item(cur, 1); kg_pin(); });
 #pragma unroll
-        for (int m = 0; m < 8; m++) E1B_KO_ST(&tile0[8 * i + (m ^ c0)], y[m]);
+        for (int m = 0; m < 8; m++) kg_st(&tile0[8 * i + (m ^ c0)], y[m]);
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 8; j++) x[j] = E1B_KO_LD(&tile0[r0 + 512 * j]);
+        for (int j = 0; j < 8; j++) x[j] = kg_ld_tile(&tile0[r0 + 512 * j]);
         kg_tw_radix8<+1>(x, y, tw.p1);
 #pragma unroll
-        for (int m = 0; m < 8; m++) E1B_KO_ST(&tile1[w1 + 8 * (m ^ b1)], y[m]);
+        for (int m = 0; m < 8; m++) kg_st(&tile1[w1 + 8 * (m ^ b1)], y[m]);
         __syncthreads();
     }
 #ifndef KG_E1B_HANDOVER
@@ -1080,41 +978,41 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
             // 1 600 cycles of a 5 700-cycle item (in-kernel stamps, profiles/r03_e1b8_stamps_burst.txt).
             const acq_rsrc nr = fetch_prepare(k2 + 2 < P ? cur.data_off : nxt.data_off, k2 + 2 < P ? cur.code_off : nxt.code_off,
                                               k2 + 2 < P ? cur.dop : nxt.dop, (k2 + 2) & (P - 1));
-            auto ld = [&](int j) { if (E1B_KO == 4) return; kg_pin(); fetch_row(nr, j); kg_pin(); };
+            auto ld = [&](int j) { kg_pin(); fetch_row(nr, j); kg_pin(); };
             // ---- phase A: pass 2 of this item | conj-multiply + pass 0 of the next
             {
                 cf xa[8], ya[8], xb[8], yb[8];
 #pragma unroll
-                for (int j = 0; j < 8; j++) xa[j] = E1B_KO_LD(&tile1[r1 + 512 * j]);
+                for (int j = 0; j < 8; j++) xa[j] = kg_ld_tile(&tile1[r1 + 512 * j]);
                 // conj(data) * code, simd_multiply_conjugate_ccc (support/simd.cpp:39-67) -- round 4: fused into pass 0's first
                 // stage, as the inter-pass twiddles are into theirs (kg_fft.h: 6 of 42 / 44 packed instructions per pass)
                 (void) xb;
                 KG_STAMP(STAMPS, sti, 1);
-                E1B_KO_CC(c, d, yb, [&]() { ld(0); });
+                kg_cc_radix8_h<+1>(c, d, yb, [&]() { ld(0); });
 #pragma unroll
-                for (int m = 0; m < 8; m++) E1B_KO_ST(&tile0[8 * i + (m ^ c0)], yb[m]);
+                for (int m = 0; m < 8; m++) kg_st(&tile0[8 * i + (m ^ c0)], yb[m]);
                 KG_STAMP(STAMPS, sti, 2);
-                E1B_KO_TW(xa, ya, tw.p2, [&]() { ld(1); });
+                kg_tw_radix8_h<+1>(xa, ya, tw.p2, [&]() { ld(1); });
                 KG_STAMP(STAMPS, sti, 3);
 #pragma unroll
-                for (int m = 0; m < 8; m++) E1B_KO_ST(&tile2[w2 + 64 * m], ya[m]);
+                for (int m = 0; m < 8; m++) kg_st(&tile2[w2 + 64 * m], ya[m]);
                 KG_STAMP(STAMPS, sti, 4);
                 if (STAMPS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 KG_STAMP(STAMPS, sti, 5);
             }
-            E1B_KO_SYNC();
+            __syncthreads();
             KG_STAMP(STAMPS, sti, 6);
             // ---- phase B: pass 3 of this item + accumulate | pass 1 of the next
             cf x[8], y[8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) x[j] = E1B_KO_LD(&tile2[i + 512 * j]);
+            for (int j = 0; j < 8; j++) x[j] = kg_ld_tile(&tile2[i + 512 * j]);
             {
                 cf xb[8], yb[8];
 #pragma unroll
-                for (int j = 0; j < 8; j++) xb[j] = E1B_KO_LD(&tile0[r0 + 512 * j]);
-                E1B_KO_TW(xb, yb, tw.p1, [&]() { ld(2); });
+                for (int j = 0; j < 8; j++) xb[j] = kg_ld_tile(&tile0[r0 + 512 * j]);
+                kg_tw_radix8_h<+1>(xb, yb, tw.p1, [&]() { ld(2); });
 #pragma unroll
-                for (int m = 0; m < 8; m++) E1B_KO_ST(&tile1[w1 + 8 * (m ^ b1)], yb[m]);
+                for (int m = 0; m < 8; m++) kg_st(&tile1[w1 + 8 * (m ^ b1)], yb[m]);
             }
             KG_STAMP(STAMPS, sti, 7);
             // this item's constants (broadcast LDS reads, in order with the tile reads)
@@ -1127,11 +1025,8 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
 #pragma unroll
                 for (int q = 1; q < 4; q++) Q[q - 1] = kg_ld_tile(&cst[8 * k2 + 3 + q]);
             }
-            E1B_KO_TW(x, y, tw.p3, [&]() { ld(3); });       // y[m]: the sub-transform at n = i + 512 m
-            if (E1B_KO == 10 && k2 != 0) {
-#pragma unroll
-                for (int m = 0; m < 8; m++) asm volatile("" :: "v"(y[m]));
-            } else if (k2 == 0) {
+            kg_tw_radix8_h<+1>(x, y, tw.p3, [&]() { ld(3); });       // y[m]: the sub-transform at n = i + 512 m
+            if (k2 == 0) {
 #pragma unroll
                 for (int q = 0; q < 4; q++)
 #pragma unroll
@@ -1179,7 +1074,7 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
             KG_STAMP(STAMPS, sti, 8);
             if (STAMPS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             KG_STAMP(STAMPS, sti, 9);
-            if (k2 < P - 1) E1B_KO_SYNC();                   // (the last item's phase B is closed by the cell-end barrier)
+            if (k2 < P - 1) __syncthreads();                   // (the last item's phase B is closed by the cell-end barrier)
             KG_STAMP(STAMPS, sti, 10);
             if (STAMPS) st_item++;
         }
@@ -1352,7 +1247,7 @@ struct kg_acq {
     // wait is a packet the command processor handles between two kernels (8 blocks per
     // call: 358 -> 288 us per step when the per-block events went away).
     std::vector<int> ready_of, done_of;
-    int grid1, grid4;
+    int grid1;
 };
 
 // Host mirror of the plane layouts (see the head of this file): A = 256 threads x 16 legs, B = 512 x 8.
@@ -1496,7 +1391,7 @@ static int acq_init(kg_acq *a)
         // kernels are dispatched together with the persistent correlator the latter can
         // spend its first pass at one workgroup per CU (16 blocks per step: 887 us against
         // 528 us in order; profiles/r01_streams.txt), so the overlap is opt-in.
-        const char *e = getenv("KIWIGPU_ACQ_FRONT_STREAM");
+        const char *e = kg_tuning_env("KIWIGPU_ACQ_FRONT_STREAM");
         if (e && e[0] == '1') {
             KG_HIP(hipStreamCreateWithFlags(&a->fstream, hipStreamNonBlocking));
             a->own_fstream = true;
@@ -1519,44 +1414,31 @@ static int acq_init(kg_acq *a)
     KG_HIP(hipFuncSetAttribute((const void *) acq_fft_sub_kernel<true>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SUB * sizeof(float2)));
     // persistent grid: resident workgroups per CU x CUs, rounded to a multiple of 8 (XCDs)
-    int occ1 = 0, occ4 = 0;
+    int occ1 = 0;
 #define ACQ_SETUP(PP)                                                                                          \
     KG_HIP(hipFuncSetAttribute((const void *) acq_correlate_kernel<PP, 1, true>,                              \
                                hipFuncAttributeMaxDynamicSharedMemorySize, ACQ_LDS_BYTES));                   \
-    KG_HIP(hipFuncSetAttribute((const void *) acq_correlate_kernel<PP, 4, true>,                              \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, ACQ_LDS_BYTES));                   \
     KG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ1, acq_correlate_kernel<PP, 1, true>, 256,        \
-                                                        ACQ_LDS_BYTES));                                      \
-    KG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ4, acq_correlate_kernel<PP, 4, true>, 256,        \
                                                         ACQ_LDS_BYTES));
     if (P == 4) { ACQ_SETUP(4) } else { ACQ_SETUP(16) }
 #undef ACQ_SETUP
     if (occ1 < 1) occ1 = 1;
-    if (occ4 < 1) occ4 = 1;
-    if (const char *e = getenv("KIWIGPU_ACQ_WGS_PER_CU")) {      // experiments: fewer resident workgroups per CU
+    if (const char *e = kg_tuning_env("KIWIGPU_ACQ_WGS_PER_CU")) {      // experiments: fewer resident workgroups per CU
         const int v = atoi(e);
         if (v >= 1 && v < occ1) occ1 = v;
     }
     a->grid1 = (ctx->num_cus * occ1) & ~7;
-    a->grid4 = (ctx->num_cus * occ4) & ~7;
-    {
-        // the 16368-lag window runs on the 512-thread form (one workgroup = eight waves per CU, two per SIMD);
-        // KIWIGPU_ACQ_E1B8=0 keeps the 256-thread four-accumulator kernel (A/B measurements)
-        const char *e = getenv("KIWIGPU_ACQ_E1B8");
-        a->grid8 = 0;
-        if (!(e && e[0] == '0')) {
-            if (P == 4)
-                KG_HIP(hipFuncSetAttribute((const void *) acq_correlate8_kernel<4>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, ACQ8_LDS_BYTES));
-            else
-                KG_HIP(hipFuncSetAttribute((const void *) acq_correlate8_kernel<16>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, ACQ8_LDS_BYTES));
-            a->grid8 = ctx->num_cus & ~7;
-            if (a->grid8 < 8) a->grid8 = 8;
-        }
-    }
+    // the 16368-lag window runs on the 512-thread form (one workgroup = eight waves per CU, two per SIMD); round 3's
+    // 256-thread four-accumulator form (acq_correlate_kernel<P, 4>) is no longer instantiated
+    if (P == 4)
+        KG_HIP(hipFuncSetAttribute((const void *) acq_correlate8_kernel<4>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, ACQ8_LDS_BYTES));
+    else
+        KG_HIP(hipFuncSetAttribute((const void *) acq_correlate8_kernel<16>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, ACQ8_LDS_BYTES));
+    a->grid8 = ctx->num_cus & ~7;
+    if (a->grid8 < 8) a->grid8 = 8;
     if (a->grid1 < 8) a->grid1 = 8;
-    if (a->grid4 < 8) a->grid4 = 8;
     return KG_OK;
 }
 
@@ -1664,12 +1546,15 @@ static int set_limit(kg_acq *a, int sat, int limit)
                a->max_sats - 1);
     KG_REQUIRE(limit >= 1 && limit <= 4 * SUB, KG_ERR_INVALID, "limit %d out of range (1..%d)", limit,
                4 * SUB);
-    a->limits[sat] = limit;
-    a->code_layout[sat] = (limit > SUB && a->grid8 > 0) ? 1 : 0;     // which kernel will read this SV's code spectrum
-    if (a->code_layout[sat]) {
+    const int layout = (limit > SUB && a->grid8 > 0) ? 1 : 0;        // which kernel will read this SV's code spectrum
+    if (layout) {
+        // layout B of the data spectra first: if it cannot be had the SV keeps what it had (an earlier code with its own
+        // limit and layout stays searchable; nothing points the 512-thread kernel at a buffer that does not exist)
         int rc = ensure_data_b(a);
         if (rc) return rc;
     }
+    a->limits[sat] = limit;
+    a->code_layout[sat] = layout;
     a->code_set[sat] = 1;
     a->last_sats.clear();        // force the pair tables to be rebuilt
     return KG_OK;
@@ -1936,7 +1821,8 @@ template <int P, int NQ, bool STAMPS>
 static void launch_correlate(kg_acq *a, hipStream_t st, int first, const acq_pair_desc *d_pairs, int npairs,
                              unsigned long long *d_stamps)
 {
-    const int grid = NQ == 1 ? a->grid1 : a->grid4;
+    static_assert(NQ == 1, "the four-accumulator form is not built any more (acq_correlate8_kernel took its place)");
+    const int grid = a->grid1;
     const acq_walk w = {npairs, a->ndop, a->dop_lo};
     hipLaunchKernelGGL((acq_correlate_kernel<P, NQ, true, STAMPS>), dim3(grid), dim3(256), ACQ_LDS_BYTES, st,
                        (const float2 *) (a->d_data + (size_t) first * a->fft_len), (const float2 *) a->d_code,
@@ -2006,7 +1892,8 @@ int kg_acq_correlate_blocks_async(kg_acq *a, int first, int nblocks, const int *
         KG_HIP(hipGetLastError());
     }
     if (a->np4 > 0) {
-        if (a->grid8 > 0) {
+        {
+            KG_REQUIRE(a->d_data_b != nullptr, KG_ERR_STATE, "kg_acq_correlate_async: a long-window code without its layout of the data spectra");
             const acq_walk w = {a->np4, a->ndop, a->dop_lo};
             if (a->P == 4)
                 hipLaunchKernelGGL(acq_correlate8_kernel<4>, dim3(a->grid8), dim3(512), ACQ8_LDS_BYTES, st,
@@ -2018,8 +1905,7 @@ int kg_acq_correlate_blocks_async(kg_acq *a, int first, int nblocks, const int *
                                    (const float2 *) (a->d_data_b + (size_t) first * a->fft_len), (const float2 *) a->d_code,
                                    (const float2 *) a->ctx->d_tab4096, (const float2 *) a->d_tabN, (const float2 *) a->d_comb8,
                                    (const float2 *) a->d_quart, a->d_pairs4, a->d_claim + 8 * ACQ_CLAIM_STRIDE, w, a->halo, a->d_cells);
-        } else if (a->P == 4) launch_correlate<4, 4, false>(a, st, first, a->d_pairs4, a->np4, nullptr);
-        else launch_correlate<16, 4, false>(a, st, first, a->d_pairs4, a->np4, nullptr);
+        }
         KG_HIP(hipGetLastError());
     }
     const int npairs = nblocks * nsats;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/kiwigpu.h"
@@ -97,6 +98,15 @@ int kg_ctx_stage_cached_ways(kg_ctx *ctx, kg_stage_cache *sc, int ways, int *vic
 // Device scratch of at least `bytes`, filled from `src` before returning (synchronous: the
 // previous user of the scratch is drained first).  Valid until the next call on this context.
 int kg_ctx_scratch_upload(kg_ctx *ctx, const void *src, size_t bytes, void **d_out);
+
+// The library's tuning switches (KIWIGPU_DDC_RUNS, KIWIGPU_DDC_SIDE, KIWIGPU_DDC_ENDREF, KIWIGPU_DDC_STAGED,
+// KIWIGPU_RXDDC_ENDREF, KIWIGPU_WF_WGS_PER_CU, KIWIGPU_ACQ_WGS_PER_CU, KIWIGPU_ACQ_FRONT_STREAM) are A/B aids: they are read
+// ONLY when KIWIGPU_TUNING=1 is set too -- a stray variable in a host's environment does not change what the library does.
+static inline const char *kg_tuning_env(const char *name)
+{
+    const char *on = getenv("KIWIGPU_TUNING");
+    return (on && on[0] == '1' && on[1] == 0) ? getenv(name) : nullptr;
+}
 
 // Make ctx's device current on the calling thread.
 static inline int kg_ctx_use(kg_ctx *ctx)

@@ -1386,6 +1386,7 @@ struct kg_ddc {
     bool deferred;
     hipStream_t tail;
     hipEvent_t ev_runs, ev_tail[2];            // run passes of the push done (main stream) / output stage of the push of that parity done
+    hipEvent_t ev_adc;                         // deferred mode: behind the output stream's last reader of the caller's samples (the bypass kernel)
     bool tail_rec[2];                          // ev_tail[p] has been recorded
     bool tail_unjoined;                        // the context's stream has not yet been made to wait for the last output stage
     int parity;                                // buffer set of the NEXT push
@@ -1480,6 +1481,7 @@ void kg_ddc_destroy(kg_ddc *d)
     if (d->side) { (void) hipEventDestroy(d->ev_fork); (void) hipEventDestroy(d->ev_join); if (!d->side_borrowed) (void) hipStreamDestroy(d->side); }
     if (d->tail) {
         (void) hipEventDestroy(d->ev_runs); (void) hipEventDestroy(d->ev_tail[0]); (void) hipEventDestroy(d->ev_tail[1]);
+        (void) hipEventDestroy(d->ev_adc);
         (void) hipStreamDestroy(d->tail);
     }
     delete d;
@@ -1609,6 +1611,7 @@ int kg_ddc_wf_set_deferred(kg_ddc *d, int on)
         KG_HIP(hipEventCreateWithFlags(&d->ev_runs, hipEventDisableTiming));
         KG_HIP(hipEventCreateWithFlags(&d->ev_tail[0], hipEventDisableTiming));
         KG_HIP(hipEventCreateWithFlags(&d->ev_tail[1], hipEventDisableTiming));
+        KG_HIP(hipEventCreateWithFlags(&d->ev_adc, hipEventDisableTiming));
     }
     d->deferred = on != 0;
     return KG_OK;
@@ -1747,7 +1750,7 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
         const long per_chan = (want_threads + nlist - 1) / nlist;
         if (per_chan > target) target = per_chan < d->max_runs ? (int) per_chan : d->max_runs;
     }
-    if (const char *e = getenv("KIWIGPU_DDC_RUNS")) { const int v = atoi(e); if (v >= 64 && v <= d->max_runs) target = v; }
+    if (const char *e = kg_tuning_env("KIWIGPU_DDC_RUNS")) { const int v = atoi(e); if (v >= 64 && v <= d->max_runs) target = v; }
     // the runs cover the longest share of the block any filtered channel takes (the whole block unless capturing)
     const long n_cover = n_run_max > 0 ? n_run_max : 1;
     int L = DDC_RUN_MIN;
@@ -1806,7 +1809,7 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
     // it -- the R = 1 bypass channels (no filter state at all) from the start, pass B of the R <= 8 channels
     // (below) -- and joins before the call's last kernels.  KIWIGPU_DDC_SIDE=0: everything in line.
     bool side_on = true, side_used = false;
-    if (const char *e = getenv("KIWIGPU_DDC_SIDE")) side_on = atoi(e) != 0;
+    if (const char *e = kg_tuning_env("KIWIGPU_DDC_SIDE")) side_on = atoi(e) != 0;
     auto side_ready = [&]() -> int {
         if (!d->side) {
             KG_HIP(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
@@ -1841,11 +1844,12 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
                            0, bst, (const short *) d_adc, (long) n_by_max, (const ddc_chan *) d->d_chans, s_list,
                            s_bypass, (int) h_bypass.size(), (const u32 *) d->d_nco, (short2 *) d_out, (long) out_stride, pushed, s_nlim, s_outoff);
         KG_HIP(hipGetLastError());
+        if (defer) KG_HIP(hipEventRecord(d->ev_adc, bst));           // the output stream's only reader of d_adc
     }
     // end-referred carry states (round 4): prefix sums inside pass A's workgroups + one wave per (channel, I/Q) over the
     // workgroup totals; KIWIGPU_DDC_ENDREF=0: run-start states and the chunked affine scan -- the A/B reference
     int endref = 2;
-    if (const char *e = getenv("KIWIGPU_DDC_ENDREF")) endref = atoi(e) != 0 ? 2 : 0;
+    if (const char *e = kg_tuning_env("KIWIGPU_DDC_ENDREF")) endref = atoi(e) != 0 ? 2 : 0;
     if (endref && !h_run.empty() && (d->endco_n != n_cover || d->endco_L != L || d->endco_runs != nruns)) {
         // (a changed block length: rare.  The previous push's pass B may still be reading the old table on the object's
         // second stream)
@@ -1917,7 +1921,7 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
     // than the smaller grid.
     bool staged = (long) h_small.size() * nruns >= (long) d->ctx->num_cus * 4 * 2 * 64;
     const bool beside = side_on && !h_small.empty() && !h_rest.empty();
-    if (const char *e = getenv("KIWIGPU_DDC_STAGED")) staged = atoi(e) != 0 && !h_small.empty();
+    if (const char *e = kg_tuning_env("KIWIGPU_DDC_STAGED")) staged = atoi(e) != 0 && !h_small.empty();
     auto pass_b = [&](hipStream_t s, const std::vector<int> &which, const int *sel, int stage) {
         hipLaunchKernelGGL(ddc_wf_run_kernel<true>, dim3(gx, (unsigned) which.size()), dim3(DDC_THREADS), stage, s,
                            (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, s_list,
@@ -1976,6 +1980,14 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
         KG_HIP(hipEventRecord(d->ev_tail[par], ost));
         d->tail_rec[par] = true;
         d->tail_unjoined = defer;
+    }
+    if (defer) {
+        // Everything that READS the caller's samples is ordered in front of whatever the caller enqueues next on the
+        // context's stream (a streaming caller refills or recycles d_adc there): the run passes are on that stream already;
+        // the bypass kernel (output stream) and pass B of the small decimations (second stream) are joined here.  Only the
+        // readers: the output stage proper (run-total prefix, combs) stays free to run beside the next push.
+        if (!h_bypass.empty()) KG_HIP(hipStreamWaitEvent(st, d->ev_adc, 0));
+        if (side_used) KG_HIP(hipStreamWaitEvent(st, d->ev_join, 0));
     }
     d->parity = par ^ 1;
     for (int i = 0; i < nlist; i++) {

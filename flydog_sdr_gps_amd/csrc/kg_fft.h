@@ -625,65 +625,37 @@ KG_DEV void kg_tw1_fill(float2 *tw1, const float2 *__restrict__ tab4096, int t)
 #ifndef KG_WF_FUSED_TW
 #define KG_WF_FUSED_TW 1     // twiddles fused into the first butterflies (kg_tw_radix16_h), as in the correlators; 0: the A/B reference
 #endif
-#ifndef KG_WF_KO
-#define KG_WF_KO 0
-#endif
-#if KG_WF_KO == 1
-#define KO_SYNC() do {} while (0)
-#else
-#define KO_SYNC() __syncthreads()
-#endif
-#if KG_WF_KO == 2
-KG_DEV void KO_ST(float2 *p, cf v) { asm volatile("" :: "v"(v), "v"(p)); }
-KG_DEV cf KO_LD(const float2 *p) { cf v = cf{1.f, 2.f}; asm volatile("" : "+v"(v) : "v"(p)); return v; }
-#elif KG_WF_KO == 8
-KG_DEV void KO_ST(float2 *p, cf v) { asm volatile("" :: "v"(v)); }
-#define KO_LD kg_ld_tile
-#elif KG_WF_KO == 9
-#define KO_ST kg_st
-KG_DEV cf KO_LD(const float2 *p) { cf v = cf{1.f, 2.f}; asm volatile("" : "+v"(v)); return v; }
-#else
-#define KO_ST kg_st
-#define KO_LD kg_ld_tile
-#endif
-#if KG_WF_KO == 3
-#define KO_RADIX(x, y) do { _Pragma("unroll") for (int q_ = 0; q_ < 16; q_++) { y[q_] = x[q_]; asm volatile("" : "+v"(y[q_])); } } while (0)
-#define KO_TW(x, tw_) do { _Pragma("unroll") for (int q_ = 0; q_ < 15; q_++) asm volatile("" :: "v"((tw_).w[q_])); } while (0)
-#else
-#define KO_RADIX(x, y) kg_radix16<SIGN>(x, y)
-#define KO_TW(x, w) kg_twiddle16<SIGN>(x, w)
-#endif
 template <int SIGN>
 KG_DEV void kg_subfft4096_l(cf (&x)[16], cf (&y)[16], float2 *tileA, float2 *tileB, const float2 *tw1,
                             const kg_tw15 &p2, int t)
 {
     const int tl = t & 15, th = t >> 4;
     const int rd = t ^ (th & 15);
-    KO_RADIX(x, y);
+    kg_radix16<SIGN>(x, y);
 #pragma unroll
-    for (int m = 0; m < 16; m++) KO_ST(&tileA[16 * t + (m ^ tl)], y[m]);
-    KO_SYNC();
+    for (int m = 0; m < 16; m++) kg_st(&tileA[16 * t + (m ^ tl)], y[m]);
+    __syncthreads();
     kg_tw15 w1;
 #pragma unroll
     for (int j = 1; j < 16; j++) w1.w[j - 1] = kg_ld_tile(&tw1[(j - 1) * 16 + tl]);
 #pragma unroll
-    for (int j = 0; j < 16; j++) x[j] = KO_LD(&tileA[rd + 256 * j]);
+    for (int j = 0; j < 16; j++) x[j] = kg_ld_tile(&tileA[rd + 256 * j]);
 #if KG_WF_FUSED_TW
     kg_tw_radix16_h<SIGN>(x, y, w1, [](int) {});
 #else
-    KO_TW(x, w1);
-    KO_RADIX(x, y);
+    kg_twiddle16<SIGN>(x, w1);
+    kg_radix16<SIGN>(x, y);
 #endif
 #pragma unroll
-    for (int m = 0; m < 16; m++) KO_ST(&tileB[t + 16 * (15 * th + m)], y[m]);    // 256 th + 16 m + tl: no swizzle needed (see above)
-    KO_SYNC();
+    for (int m = 0; m < 16; m++) kg_st(&tileB[t + 16 * (15 * th + m)], y[m]);    // 256 th + 16 m + tl: no swizzle needed (see above)
+    __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 16; j++) x[j] = KO_LD(&tileB[t + 256 * j]);
+    for (int j = 0; j < 16; j++) x[j] = kg_ld_tile(&tileB[t + 256 * j]);
 #if KG_WF_FUSED_TW
     kg_tw_radix16_h<SIGN>(x, y, p2, [](int) {});
 #else
-    KO_TW(x, p2);
-    KO_RADIX(x, y);
+    kg_twiddle16<SIGN>(x, p2);
+    kg_radix16<SIGN>(x, y);
 #endif
 }
 
@@ -698,39 +670,39 @@ KG_DEV void kg_subfft4096_l_h(cf (&x)[16], cf (&y)[16], float2 *tileA, float2 *t
     // (spreading the LDS stores of passes 0 and 1 through the butterflies as well, kg_radix16_h, measured the same)
     const int tl = t & 15, th = t >> 4;
     const int rd = t ^ (th & 15);
-    KO_RADIX(x, y);
+    kg_radix16<SIGN>(x, y);
     h(0);
 #pragma unroll
-    for (int m = 0; m < 16; m++) KO_ST(&tileA[16 * t + (m ^ tl)], y[m]);
+    for (int m = 0; m < 16; m++) kg_st(&tileA[16 * t + (m ^ tl)], y[m]);
     h(1);
-    KO_SYNC();
+    __syncthreads();
     kg_tw15 w1;
 #pragma unroll
     for (int j = 1; j < 16; j++) w1.w[j - 1] = kg_ld_tile(&tw1[(j - 1) * 16 + tl]);
 #pragma unroll
-    for (int j = 0; j < 16; j++) x[j] = KO_LD(&tileA[rd + 256 * j]);
+    for (int j = 0; j < 16; j++) x[j] = kg_ld_tile(&tileA[rd + 256 * j]);
     h(2);
 #if KG_WF_FUSED_TW
     kg_tw_radix16_h<SIGN>(x, y, w1, [&](int s) { if (s == 1) h(3); });
 #else
-    KO_TW(x, w1);
+    kg_twiddle16<SIGN>(x, w1);
     h(3);
-    KO_RADIX(x, y);
+    kg_radix16<SIGN>(x, y);
 #endif
     h(4);
 #pragma unroll
-    for (int m = 0; m < 16; m++) KO_ST(&tileB[t + 16 * (15 * th + m)], y[m]);    // 256 th + 16 m + tl: no swizzle needed (see above)
+    for (int m = 0; m < 16; m++) kg_st(&tileB[t + 16 * (15 * th + m)], y[m]);    // 256 th + 16 m + tl: no swizzle needed (see above)
     h(5);
-    KO_SYNC();
+    __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 16; j++) x[j] = KO_LD(&tileB[t + 256 * j]);
+    for (int j = 0; j < 16; j++) x[j] = kg_ld_tile(&tileB[t + 256 * j]);
     h(6);
 #if KG_WF_FUSED_TW
     kg_tw_radix16_h<SIGN>(x, y, p2, [&](int s) { if (s == 1) h(7); });
 #else
-    KO_TW(x, p2);
+    kg_twiddle16<SIGN>(x, p2);
     h(7);
-    KO_RADIX(x, y);
+    kg_radix16<SIGN>(x, y);
 #endif
 }
 

@@ -721,7 +721,7 @@ int kg_rxddc_push_dev(kg_rxddc *d, const void *d_adc, size_t n, const int32_t *c
     // end-referred carry states, summed inside pass A's workgroups and by one wave per (channel, I/Q) over the workgroup
     // totals (round 4); KIWIGPU_RXDDC_ENDREF=0: run-start states and rx1_scan_kernel, the A/B reference
     int endref = 1;
-    if (const char *e = getenv("KIWIGPU_RXDDC_ENDREF")) endref = atoi(e) != 0;
+    if (const char *e = kg_tuning_env("KIWIGPU_RXDDC_ENDREF")) endref = atoi(e) != 0;
     static_assert(16384 / RX_THREADS <= 64, "rx1_scan_wg_kernel scans one workgroup total per lane");
     hipLaunchKernelGGL(rx1_run_kernel<false>, grid, dim3(RX_THREADS), 0, st, (const short *) d_adc, (long) n, L, nruns,
                        (const rx_chan *) d->d_chans, s_list, (const u32 *) d->d_nco, d->d_st,

@@ -171,9 +171,7 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
         // right behind the atomic, an s_waitcnt vmcnt(0) at the top of the frame that made wave 0 reach the first
         // exchange barrier a memory round trip late, with the other three waiting there.)
         int claimed = 0;
-#if KG_WF_KO != 7
         if (t == 0) claimed = __hip_atomic_fetch_add(&claim[cg * WF_CLAIM_STRIDE], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
 
         cf x[16], y0[16], y1[16];
         windowed(x, 0);
@@ -222,10 +220,8 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
                     }
                 } else {
                     const int q = k - 4;
-#if KG_WF_KO != 4
 #pragma unroll
                     for (int j = 4 * q; j < 4 * q + 4; j++) { const u2 v = ld8(nsrc, j); raw[j] = int2{(int) v[0], (int) v[1]}; }
-#endif
 #pragma unroll
                     for (int j = 2 * q; j < 2 * q + 2; j++)
                         if (recic && (j < 4 || !half)) { const u2 v = ld8(cp, j); cicv[2 * j] = __uint_as_float(v[0]); cicv[2 * j + 1] = __uint_as_float(v[1]); }
@@ -265,19 +261,10 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
                 if (TAPS && k < ch->fft_used) tap_pwr[(size_t) f * SUB + k] = p;
             }
         };
-#if KG_WF_KO != 6
         combine_power(std::integral_constant<int, 0>());
         if (!half) combine_power(std::integral_constant<int, 8>());
-#else
-#pragma unroll
-        for (int m = 0; m < 16; m++) asm volatile("" :: "v"(y0[m]), "v"(y1[m]), "v"(cicv[m]));
-#endif
 #undef WF_W32
-#if KG_WF_KO != 7
         if (t == 0) *lds_claim = 2 * gridDim.x + cng * claimed + cg;
-#else
-        if (t == 0) *lds_claim = fn + gridDim.x + claimed;
-#endif
         __syncthreads();
         const int fnn = __builtin_amdgcn_readfirstlane(*lds_claim);    // wave-uniform; rewritten after >= 6 barriers
         cid = cid_next;
@@ -287,19 +274,11 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
         // predicated: no divergent loops, the four pixels of a thread advance together, and every
         // pixel still sees its bins in ascending order (same result as the serial :1458-1478 loop).
         float pp[4] = {0.f, 0.f, 0.f, 0.f};   // memset(pwr_out, 0), :1385
-#if KG_WF_KO == 5
-        if (interp == 77) {
-#else
         if (interp == WF_DROP) {
-#endif
 #pragma unroll
             for (int u = 0; u < 4; u++)
                 if (4 * t + u < pwc) pp[u] = pwr[pfirst[u]];                            // :1418
-#if KG_WF_KO == 5
-        } else if (interp == 78) {
-#else
         } else {
-#endif
             // (DPP reduce: six dependent ds_bpermute round trips per frame otherwise)
             const int cmax = kg_wave_max(max(max(pcount[0], pcount[1]), max(pcount[2], pcount[3])));
 #pragma unroll
@@ -410,7 +389,7 @@ int kg_wf_create(kg_ctx *ctx, int nchan, kg_wf **out)
     int occ = 0;
     KG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, wf_frame_kernel<false>, 256, WF_LDS_BYTES));
     if (occ < 1) occ = 1;
-    if (const char *e = getenv("KIWIGPU_WF_WGS_PER_CU")) {      // experiment: fewer workgroups per CU
+    if (const char *e = kg_tuning_env("KIWIGPU_WF_WGS_PER_CU")) {      // experiment: fewer workgroups per CU
         const int v = atoi(e);
         if (v >= 1 && v < occ) occ = v;
     }
@@ -487,7 +466,10 @@ int kg_wf_set_channel(kg_wf *w, int ch, const kg_wf_chan_cfg *cfg, const uint16_
     h.limit = limit;
     if (cfg->interp == WF_DROP) {
         for (int i = 0; i < cfg->plot_width_clamped; i++) {
-            KG_REQUIRE(drop_sample[i] < SUB, KG_ERR_INVALID, "kg_wf_set_channel: drop_sample[%d] = %d", i, drop_sample[i]);
+            // (bins at and above fft_used are never displayed -- rx_waterfall.cpp:756-763 -- and, for fft_used <= 2048, no longer
+            // computed: an entry up there would read what an earlier frame left in the tile)
+            KG_REQUIRE(drop_sample[i] < cfg->fft_used, KG_ERR_INVALID, "kg_wf_set_channel: drop_sample[%d] = %d is not below fft_used %d", i,
+                       drop_sample[i], cfg->fft_used);
             h.first[i] = drop_sample[i]; h.count[i] = 1;
         }
     } else {

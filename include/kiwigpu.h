@@ -309,6 +309,8 @@ int kg_ddc_wf_step_dev(kg_ddc *ddc, const void *d_adc, size_t n, const int32_t *
  *   kg_ddc_wf_tail_after(ddc, event) the NEXT push's writers of d_out start only after `event` (a hipEvent_t the
  *                                    caller recorded behind its last reader of the rows): the write-after-read edge of
  *                                    a caller that still reads push k's rows while push k + 1 runs.  One-shot.
+ * d_adc: whatever reads the caller's samples is ordered on the context's stream before the push returns (in both modes), so
+ * the caller may refill or recycle d_adc on that stream right behind the push; only the rows need kg_ddc_wf_join.
  * Every other entry point of the object drains the deferred work first. */
 int kg_ddc_wf_set_deferred(kg_ddc *ddc, int on);
 int kg_ddc_wf_join(kg_ddc *ddc, void *stream);

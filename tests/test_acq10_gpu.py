@@ -5,7 +5,7 @@ shape: 4 ms / 16384 points / 41 bins): the checker is the oracle's `_n` restatem
 loops at the larger shape, end to end from the int16 samples (never the GPU's own spectra).
 
 Bars: decimated samples bit-exact; spectra <= 1e-5 of the spectrum's max; every (SV, bin) cell's
-peak index identical, max/total power <= 1e-5, snr <= 2e-5; winners identical."""
+peak index identical, max / total power and snr <= 1e-5; winners identical."""
 import os
 
 import numpy as np
@@ -17,6 +17,7 @@ from tests.fixtures import e1b_chips
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-5
+SNR_RTOL = RTOL           # north_star's 1e-5 on snr too: the achieved maxima are 3.1e-6 (configs[1]) and 7.3e-6 (configs[4]), profiles/r05_float_errors.txt
 N10, FFT10 = acq.NSAMPLES_10MS, acq.FFT_LEN_10MS
 DOP_LO, DOP_HI = -128, 127
 
@@ -91,14 +92,17 @@ def test_config4_all_59_svs_256_bins(searcher10, oracle, codes, oracle_codes):
     limits = [sats.E1B_LIMIT if boc else sats.L1_LIMIT for _, boc in codes]
     want, wcells = oracle.correlate_many(oracle_codes, data, limits, dop_lo=DOP_LO, dop_hi=DOP_HI,
                                          nthreads=max(1, len(os.sched_getaffinity(0))))
+    from tests.errlog import record
+    for k, tol in (("max_pwr", RTOL), ("tot_pwr", RTOL), ("snr", SNR_RTOL)):
+        record("configs[4] 15104 cells.%s" % k, cells[0][k], wcells[k], tol)
     np.testing.assert_allclose(cells[0]["max_pwr"], wcells["max_pwr"], rtol=RTOL)
     np.testing.assert_allclose(cells[0]["tot_pwr"], wcells["tot_pwr"], rtol=RTOL)
-    np.testing.assert_allclose(cells[0]["snr"], wcells["snr"], rtol=2 * RTOL)
+    np.testing.assert_allclose(cells[0]["snr"], wcells["snr"], rtol=SNR_RTOL)
     assert np.array_equal(cells[0]["idx"], wcells["idx"])            # bit-exact peak index, all cells
     assert np.array_equal(res[0]["dop"], want["dop"])
     assert np.array_equal(res[0]["idx"], want["idx"])
     assert np.array_equal(res[0]["valid"], want["valid"])
-    np.testing.assert_allclose(res[0]["snr"], want["snr"], rtol=2 * RTOL)
+    np.testing.assert_allclose(res[0]["snr"], want["snr"], rtol=SNR_RTOL)
     # MIN_SIG = 16 is the reference's threshold for 41 x 4092 trials per SV; with 256 x 4092
     # (16368 for E1B) trials the noise maximum alone reaches 14..19, so this shape needs its own
     found = {s for s in svs if res[0, s]["snr"] >= synth.MIN_SIG_10MS}
@@ -144,7 +148,7 @@ def test_two_blocks_per_sv_calls_and_zero_input(searcher10, oracle, codes, oracl
         want, _ = oracle.correlate_many(oracle_codes[svs], data, limits, dop_lo=DOP_LO, dop_hi=DOP_HI,
                                         nthreads=max(1, len(os.sched_getaffinity(0))), want_cells=False)
         assert np.array_equal(res[b]["dop"], want["dop"]) and np.array_equal(res[b]["idx"], want["idx"])
-        np.testing.assert_allclose(res[b]["snr"], want["snr"], rtol=2 * RTOL)
+        np.testing.assert_allclose(res[b]["snr"], want["snr"], rtol=SNR_RTOL)
         if b == 0:
             for k, sv in enumerate(svs):                       # per-SV calls, block 0
                 one, _ = searcher10.correlate_many([sv], want_cells=False)

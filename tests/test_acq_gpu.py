@@ -79,11 +79,17 @@ def test_sample_iq16(searcher, oracle):
     assert relmax(searcher.get_data_fft(), want) < RTOL
 
 
-def check_cells(got_cells, want_cells):
+SNR_RTOL = RTOL           # north_star's 1e-5 on snr too: the achieved maxima are 3.1e-6 (configs[1]) and 7.3e-6 (configs[4]), profiles/r05_float_errors.txt
+
+
+def check_cells(got_cells, want_cells, tag="cells"):
+    from tests.errlog import record
     assert np.array_equal(got_cells["idx"], want_cells["idx"])          # bit-exact peak index
+    for k, tol in (("max_pwr", RTOL), ("tot_pwr", RTOL), ("snr", SNR_RTOL)):
+        record("%s.%s" % (tag, k), got_cells[k], want_cells[k], tol)
     np.testing.assert_allclose(got_cells["max_pwr"], want_cells["max_pwr"], rtol=RTOL)
     np.testing.assert_allclose(got_cells["tot_pwr"], want_cells["tot_pwr"], rtol=RTOL)
-    np.testing.assert_allclose(got_cells["snr"], want_cells["snr"], rtol=2 * RTOL)
+    np.testing.assert_allclose(got_cells["snr"], want_cells["snr"], rtol=SNR_RTOL)
 
 
 def test_config0_prn1(searcher, navstar_codes, oracle):
@@ -95,9 +101,9 @@ def test_config0_prn1(searcher, navstar_codes, oracle):
     want, wcells = oracle.correlate(navstar_codes[0], data)
     r = res[0, 0]
     assert (int(r["dop"]), int(r["idx"]), int(r["valid"])) == (want["dop"], want["idx"], 1)
-    assert abs(r["snr"] - want["snr"]) <= 2 * RTOL * want["snr"]
+    assert abs(r["snr"] - want["snr"]) <= SNR_RTOL * want["snr"]
     assert int(r["dop"]) == 6 and int(r["idx"]) == 1202           # injected +1500 Hz, 300.5 chips
-    check_cells(cells[0, 0], wcells)
+    check_cells(cells[0, 0], wcells, "configs[0] 41 cells")
     # the SearchTask view: ca_shift *= DECIM
     out = searcher.search([0], packed=bits)
     assert out[0].lo_shift == 6 and out[0].ca_shift == 4808 and out[0].snr >= 16
@@ -115,8 +121,8 @@ def test_config1_32sv_41bins(searcher, navstar_codes, oracle):
     assert np.array_equal(res[0]["dop"], want["dop"])
     assert np.array_equal(res[0]["idx"], want["idx"])
     assert np.array_equal(res[0]["valid"], want["valid"])
-    np.testing.assert_allclose(res[0]["snr"], want["snr"], rtol=2 * RTOL)
-    check_cells(cells[0], wcells)
+    np.testing.assert_allclose(res[0]["snr"], want["snr"], rtol=SNR_RTOL)
+    check_cells(cells[0], wcells, "configs[1] 1312 cells")
     found = {s + 1 for s in svs if res[0, s]["snr"] >= 16}
     assert found == {p for p, *_ in synth.CONFIG1_PRESENT}
     for p, tau, fd, _ in synth.CONFIG1_PRESENT:

@@ -585,3 +585,107 @@ def test_capture_of_a_short_block_and_odd_sizes(gpu_ctx, oracle):
             pos += ln
     finally:
         d.close()
+
+
+def test_deferred_push_then_the_sample_buffer_is_recycled_at_once(gpu_ctx, oracle):
+    """in deferred mode the R = 1 bypass kernel (output stream) and pass B of the small decimations (second
+    stream) read the caller's samples off the context's stream.  A streaming caller refills ONE sample buffer on the
+    context's stream right behind each push (kg_dev_upload is ordered there): every push must still have seen its own
+    block -- ten blocks through one buffer, no host synchronisation except the upload's own, bypass + small + large
+    decimations, every channel's whole output bit for bit against the oracle."""
+    l2 = [0, 0, 1, 2, 3, 5, 8]
+    C, n, blocks = len(l2), 1 << 18, 10
+    adc = adc_stream(n * blocks, seed=77, tones=((0.031, 8000.0), (0.21, 900.0)))
+    incs = [inc_for(0.02 + 0.011 * ch) for ch in range(C)]
+    d = Ddc(gpu_ctx, nchan=C, max_samples=n)
+    d_adc = gpu_ctx.alloc(2 * n)
+    stride = n + 8
+    d_out = gpu_ctx.alloc(blocks * C * stride * 4)
+    try:
+        for ch in range(C):
+            d.set_wf(ch, incs[ch], 1 << l2[ch])
+        d.set_deferred(True)
+        nouts = []
+        for k in range(blocks):
+            gpu_ctx.upload(d_adc, adc[k * n:(k + 1) * n])           # on the context's stream, behind the push before
+            nouts.append(d.push_dev(d_adc, n, list(range(C)), d_out + 4 * k * C * stride, stride))
+        gpu_ctx.upload(d_adc, np.zeros(n, np.int16))                # ... and once more behind the last push
+        d.join()
+        host = np.zeros((blocks, C, stride, 2), np.int16)
+        gpu_ctx.download(d_out, host)
+        for ch in range(C):
+            want, _ = oracle.ddc_wf(adc, incs[ch], l2[ch])
+            got = np.concatenate([host[k, ch, :int(nouts[k][ch])] for k in range(blocks)])
+            assert got.shape == want.shape and np.array_equal(got, want), ch
+    finally:
+        gpu_ctx.free(d_adc)
+        gpu_ctx.free(d_out)
+        d.close()
+
+
+def test_step_call_mixes_sampler_modes_and_row_offsets(gpu_ctx, oracle):
+    """kg_ddc_wf_step_dev (round 5): ONE call in which some entries run the continuous sampler (max_out 0) and the others
+    are captured (CmdWFReset + one-shot of max_out pairs), each writing at its own offset into its row.  Three blocks; the
+    continuous entries' outputs concatenate to the oracle's on the whole stream, a captured entry's equal a fresh filter's
+    at the block's NCO phase."""
+    import ctypes as C
+    from flydog_sdr_gps_amd._lib import check, ptr
+    l2 = [0, 2, 5, 7, 9, 3, 0, 6]
+    mo = [0, 0, 0, 0, 300, 8192, 1000, 0]                           # 0: continuous
+    nch, n, blocks = len(l2), 1 << 19, 3
+    adc = adc_stream(n * blocks, seed=91, tones=((0.05, 7000.0), (0.33, 500.0)))
+    incs = [inc_for(0.013 + 0.017 * ch) for ch in range(nch)]
+    d = Ddc(gpu_ctx, nchan=nch, max_samples=n)
+    stride = n + 64
+    d_adc = gpu_ctx.alloc(adc.nbytes)
+    d_out = gpu_ctx.alloc(nch * stride * 4)
+    chans = np.arange(nch, dtype=np.int32)
+    try:
+        for ch in range(nch):
+            d.set_wf(ch, incs[ch], 1 << l2[ch])
+        gpu_ctx.upload(d_adc, adc)
+        cont = {ch: [] for ch in range(nch) if mo[ch] == 0}
+        for k in range(blocks):
+            off = np.array([(7 * ch + 16 * k) & ~1 for ch in range(nch)], np.int64)        # any (even) offset inside the row
+            nouts = np.zeros(nch, np.int64)
+            check(d.lib.kg_ddc_wf_step_dev(d.h, ptr(int(d_adc + 2 * k * n)), n, ptr(chans), nch, ptr(int(d_out)), stride, ptr(off),
+                                           ptr(np.array(mo, np.int64)), ptr(nouts)), "kg_ddc_wf_step_dev")
+            gpu_ctx.sync()
+            host = np.zeros((nch, stride, 2), np.int16)
+            gpu_ctx.download(d_out, host)
+            blk = adc[k * n:(k + 1) * n]
+            for ch in range(nch):
+                got = host[ch, int(off[ch]):int(off[ch]) + int(nouts[ch])]
+                if mo[ch] == 0:
+                    cont[ch].append(got.copy())
+                else:
+                    want = _capture_ref(oracle, blk, incs[ch], l2[ch], k * n * incs[ch], mo[ch])
+                    assert got.shape == want.shape and np.array_equal(got, want), (k, ch)
+        for ch, parts in cont.items():
+            want, _ = oracle.ddc_wf(adc, incs[ch], l2[ch])
+            got = np.concatenate(parts)
+            assert got.shape == want.shape and np.array_equal(got, want), ch
+        # an offset that leaves no room for the entry's outputs is refused, nothing enqueued
+        bad = np.full(nch, stride - 8, np.int64)
+        rc = d.lib.kg_ddc_wf_step_dev(d.h, ptr(int(d_adc)), n, ptr(chans), nch, ptr(int(d_out)), stride, ptr(bad),
+                                      ptr(np.array(mo, np.int64)), None)
+        assert rc < 0
+    finally:
+        gpu_ctx.free(d_adc)
+        gpu_ctx.free(d_out)
+        d.close()
+
+
+def test_outputs_predictor_after_a_capture(gpu_ctx):
+    """after a capture the next continuous push resets the channel, so kg_ddc_wf_outputs must answer n >> log2 R
+    (not what the un-reset counter would give)."""
+    d = Ddc(gpu_ctx, nchan=1, max_samples=1 << 16)
+    try:
+        d.set_wf(0, inc_for(0.1), 64)
+        adc = adc_stream(1000, seed=5)
+        d.capture(adc, [0], 8192)                                   # 1000 samples at R = 64: the counter would stand at 40
+        assert d.outputs(0, 100) == 1
+        got = d.push(adc_stream(100, seed=6), [0])
+        assert got[0].shape[0] == 1
+    finally:
+        d.close()

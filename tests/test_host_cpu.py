@@ -892,3 +892,79 @@ def test_cpp_waterfall_example_builds_and_refuses_without_a_gpu(tmp_path):
     assert r.returncode == 3 and "kg_ctx_create" in r.stderr, r.stdout + r.stderr
     r = subprocess.run([exe, str(tb), str(tmp_path / "missing"), str(tmp_path / "o.bin")], capture_output=True, text=True, timeout=60)
     assert r.returncode == 2
+
+
+# ---- round 5: no experiment code in the product, tuning switches gated, the receiver bank's surface -------------------
+def test_no_knock_out_code_and_no_four_accumulator_kernel_in_the_product():
+    """the knock-out builds (ACQ_KO / E1B_KO / KG_WF_KO: results wrong by construction) are gone from the
+    sources, and the superseded four-accumulator correlator acq_correlate_kernel<P, 4, ...> is not in the shipped library."""
+    import glob
+    import subprocess
+    for f in glob.glob(os.path.join(ROOT, "flydog_sdr_gps_amd", "csrc", "*.h*")):
+        text = open(f).read()
+        assert "_KO" not in text and "KO_" not in text, f
+    lib = os.path.join(ROOT, "flydog_sdr_gps_amd", "libkiwigpu.so")
+    syms = subprocess.run(["nm", "-C", lib], capture_output=True, text=True, check=True).stdout
+    kernels = [ln for ln in syms.splitlines() if "acq_correlate_kernel<" in ln]
+    assert kernels and all(re.search(r"acq_correlate_kernel<(4|16), 1, true", ln) for ln in kernels), kernels[:3]
+
+
+def test_tuning_variables_are_read_only_behind_kiwigpu_tuning():
+    """The library's A/B switches (KIWIGPU_DDC_RUNS ...) are read through kg_tuning_env(), which answers only when
+    KIWIGPU_TUNING=1: no other getenv of a KIWIGPU_ variable in the library's sources."""
+    import glob
+    names = set()
+    for f in glob.glob(os.path.join(ROOT, "flydog_sdr_gps_amd", "csrc", "*.h*")):
+        text = open(f).read()
+        for m in re.finditer(r'(\w+)\("(KIWIGPU_[A-Z0-9_]+)"\)', text):
+            fn, var = m.group(1), m.group(2)
+            names.add(var)
+            assert (fn == "getenv" and var == "KIWIGPU_TUNING") or fn == "kg_tuning_env", (f, fn, var)
+    assert "KIWIGPU_TUNING" in names and len(names) >= 5
+    common = open(os.path.join(ROOT, "flydog_sdr_gps_amd", "csrc", "kg_common.h")).read()
+    assert 'on[0] == \'1\'' in common and "kg_tuning_env" in common
+
+
+def test_receiver_bank_needs_a_gpu_and_checks_its_arguments():
+    import ctypes as C
+    import torch
+    from flydog_sdr_gps_amd import _lib
+    lib = _lib.load_library()
+    h = C.c_void_p()
+    assert lib.kg_rxbank_create(0, 0, 1 << 22, 0, C.byref(h)) == -2          # nrx out of range: KG_ERR_INVALID, before any device call
+    assert lib.kg_rxbank_create(0, 4, 100, 0, C.byref(h)) == -2              # a step shorter than a frame
+    if not torch.cuda.is_available():
+        assert lib.kg_rxbank_create(0, 4, 1 << 22, 0, C.byref(h)) == -1      # KG_ERR_NO_DEVICE: no CPU fallback
+        assert b"no CPU fallback" in lib.kg_last_error()
+    assert not h.value
+
+
+def test_receiver_mixes_are_the_surveys():
+    """flydog_sdr_gps_amd.rxbank.survey_mix = SURVEY.md 8(d) configs[3]: f_k = 100 kHz + k 29 kHz, zoom 8 + (k mod 4); with a
+    2^22-sample step zoom 11 (R = 1024) is the overlapped sampler, zooms 8..10 the one-shot."""
+    from flydog_sdr_gps_amd.ddc import rx_phase_inc
+    from flydog_sdr_gps_amd.rxbank import ADC_CLOCK, UI_SRATE, light_mix, survey_mix
+    mix = survey_mix(1024, 0, 1 << 22)
+    hz = UI_SRATE / (1024 << 14)
+    for k in (0, 1, 2, 3, 127, 128, 1023):
+        p, ov, inc = mix[k]
+        f = 100.0e3 + 29.0e3 * k
+        assert p.zoom == 8 + k % 4 and p.decim == 1 << (p.zoom - 1) and ov == (p.zoom == 11)
+        assert inc == rx_phase_inc(f, ADC_CLOCK)
+        span = UI_SRATE / (1 << p.zoom)
+        assert abs(p.start * hz + span / 2 - f) < 2 * hz or p.start == 0.0       # the waterfall is centred on f_k
+    assert survey_mix(128, 128, 1 << 22)[0][0].i_offset == mix[128][0].i_offset  # a rank's slice is a slice of the 1024
+    assert sorted(set(p.zoom for p, _, _ in light_mix(128, 0))) == list(range(1, 11))
+    assert not any(ov for _, ov, _ in light_mix(128, 0))
+
+
+def test_bench_summary_line_fits_and_names_every_workload():
+    import bench
+    r = {"ms_per_step": 1.2345, "roofline": {"frac": 0.4321, "bound": "valu", "traffic": 3.0e8}, "hbm": {"algorithmic_bytes_per_step": 1.0e8},
+         "checked": {"x": 1}}
+    line = {"workloads": {wl: r for wl in bench.ALL_WORKLOADS}}
+    s = bench.summary_line(line)
+    assert s.startswith("SUMMARY") and len(s) <= 400
+    for wl in bench.ALL_WORKLOADS:
+        assert wl.replace("receivers", "rx").replace("cfg2_chain", "chain") + "=1.234/0.432v/3.0x/ok" in s, (wl, s)
+    assert bench.acq_flops_per_cell(16384, 4092) == 1257460 and bench.acq_flops_per_cell(16384, 16368) == 1294288   # SURVEY 8(d)
