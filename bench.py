@@ -118,6 +118,12 @@ class Dist:
         self.on = self.world > 1 or os.environ.get("KIWIGPU_BENCH_FORCE_DIST") == "1"
         self.backend = backend
         self.dev = None
+        # KIWIGPU_BENCH_SHARE_GPU=1: a REHEARSAL of the N > 1 code path on a box with one GPU -- every rank on device 0, the
+        # process group over gloo (RCCL refuses two ranks on one device); the line is tagged invalid_for_scaling
+        self.share_gpu = backend == "nccl" and self.world > 1 and os.environ.get("KIWIGPU_BENCH_SHARE_GPU") == "1"
+        if self.share_gpu:
+            self.local_rank = 0
+            self.backend = "gloo"
         if backend == "nccl":
             import torch
             ndev = torch.cuda.device_count()       # does not initialise the GPU
@@ -133,7 +139,7 @@ class Dist:
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")                   # (KIWIGPU_BENCH_FORCE_DIST=1 without a launcher)
             os.environ.setdefault("WORLD_SIZE", "1")
-            if backend == "nccl":
+            if self.backend == "nccl":
                 dist.init_process_group("nccl", device_id=self.dev)
             else:
                 dist.init_process_group("gloo")
@@ -151,9 +157,22 @@ class Dist:
             return seconds
         import torch
         import torch.distributed as dist
-        t = torch.tensor([seconds], dtype=torch.float64, device=self.dev if self.dev is not None else "cpu")
+        t = torch.tensor([seconds], dtype=torch.float64, device=self.dev if (self.dev is not None and self.backend == "nccl") else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
+
+    def all_gather_bytes(self, out_dev, mine_dev):
+        """every rank's `mine_dev` (a uint8 device tensor) into out_dev, rank-major: one RCCL all-gather on the device; in the
+        one-GPU rehearsal (gloo) through the host"""
+        import torch
+        import torch.distributed as dist
+        if self.backend == "nccl":
+            dist.all_gather_into_tensor(out_dev, mine_dev)
+            return
+        raw = mine_dev.cpu()
+        outs = [torch.empty_like(raw) for _ in range(self.world)]
+        dist.all_gather(outs, raw)
+        out_dev.copy_(torch.cat(outs))
 
     def close(self):
         if self.on:
@@ -576,7 +595,7 @@ def run_acq(args, dist, ten_ms=False, all_svs=False):
     parity = [0]
     nsv_max = max(len(sh) for sh in sv_shares) if shard_sv else len(svs)
     rbytes = B * nsv_max * result_dtype.itemsize
-    if shard_sv and dist.on and dist.backend == "nccl":
+    if shard_sv and dist.on and dist.dev is not None:
         res_dev = torch.as_tensor(DevBytes(s.results_dev(), rbytes), device=dev)     # the library's result array, zero copy
         gathered_dev = torch.empty(dist.world * rbytes, dtype=torch.uint8, device=dev)
 
@@ -587,11 +606,10 @@ def run_acq(args, dist, ten_ms=False, all_svs=False):
         parity[0] ^= 1
         s.sample_iq16_batch(iq_ptr, B, first_block=first)
         s.correlate_async(svs, nblocks=B, first_block=first)
-        if shard_sv and dist.on and dist.backend == "nccl":
+        if shard_sv and dist.on and dist.dev is not None:
             # the exchange step of the SV-sharded search: every rank's winners to every rank (RCCL, 16 B per
             # (block, SV)); the merge is shard.merge_sv_shards on the host after the timed region
-            import torch.distributed as tdist
-            tdist.all_gather_into_tensor(gathered_dev, res_dev)
+            dist.all_gather_bytes(gathered_dev, res_dev)
 
     if args.pmc_child:
         out = pmc_window(ctx, wl, step, lambda: torch.cuda.synchronize(dev))
@@ -612,7 +630,7 @@ def run_acq(args, dist, ten_ms=False, all_svs=False):
 
     res, _ = s.fetch(want_cells=False)
     if shard_sv:
-        if dist.on and dist.backend == "nccl":
+        if dist.on and dist.dev is not None:
             parts = gathered_dev.cpu().numpy().view(result_dtype).reshape(dist.world, -1)
         else:
             parts = res.reshape(1, -1)
@@ -622,8 +640,8 @@ def run_acq(args, dist, ten_ms=False, all_svs=False):
     min_sig = synth.MIN_SIG_10MS if ten_ms else (24.0 if all_svs else acq.MIN_SIG)
     res_svs = list(range(nsv_all)) if shard_sv else svs
     found = sorted(int(sv) for i, sv in enumerate(res_svs) if res[0, i]["snr"] >= min_sig)
-    if dist.on and dist.backend == "nccl" and not shard_sv:
-        gathered = shard.gather_results(res, dev)       # RCCL all_gather of the tiny result arrays
+    if dist.on and dist.dev is not None and not shard_sv:
+        gathered = shard.gather_results(res, dev if dist.backend == "nccl" else None)       # RCCL all_gather of the tiny result arrays
         assert gathered.shape[0] == dist.world * B
     expect = sorted(p[0] for p in synth.CONFIG4_PRESENT) if ten_ms else \
         sorted(p - 1 for p, *_ in synth.CONFIG1_PRESENT)
@@ -1981,6 +1999,9 @@ def main():
             same_fields(line)
     if args.workload != "stub" and not args.pmc_child:
         line["box"] = box_identity(dist.local_rank)
+        if dist.share_gpu:
+            line["invalid_for_scaling"] = ("KIWIGPU_BENCH_SHARE_GPU=1: %d ranks on ONE GPU, process group over gloo -- a rehearsal of the "
+                                           "N > 1 code path (sharding, gathers, merge, line fields), not a scaling measurement" % dist.world)
         if TIMING_EXPERIMENT:
             line["invalid"] = "KIWIGPU_BENCH_TIMING_EXPERIMENT: a knock-out build whose rows are wrong by construction; not a measurement of the path"
     if dist.rank == 0:

@@ -1759,8 +1759,11 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
         // a capture's channels take very different shares (8192 R samples each): size the runs by the TOTAL work, about
         // four waves per SIMD over all of them, inside what the longest share allows
         const long want_threads = (long) d->ctx->num_cus * 4 * 4 * 64;
+        // (runs of at most 1024 samples: pass A then integrates every decimation in 64 bits -- short_zero_run in
+        // ddc_wf_run_body; with SURVEY's receiver mix, 352 M sample-channels per step, the total-work rule alone chose 2048 and
+        // pass A of the R >= 512 channels ran its 128-bit form: 1.13 ms per step against pass B's 0.71)
         int Lw = DDC_RUN_MIN;
-        while (Lw < DDC_RUN_MAX && n_run_sum / Lw > want_threads) Lw <<= 1;
+        while (Lw < 1024 && n_run_sum / Lw > want_threads) Lw <<= 1;
         if (Lw > L) L = Lw;
         while (L < DDC_RUN_MAX && (n_cover + L - 1) / L > d->max_runs) L <<= 1;
     }

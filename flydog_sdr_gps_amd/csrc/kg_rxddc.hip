@@ -692,8 +692,9 @@ int kg_rxddc_push_dev(kg_rxddc *d, const void *d_adc, size_t n, const int32_t *c
         if (h_nfinal[i] > max_final) max_final = h_nfinal[i];
         if (nouts) nouts[i] = h_nfinal[i];
     }
-    int L = 64;
-    while (L < 8192 && (long) ((n + L - 1) / L) > 8192) L <<= 1;
+    int L = 64, target_runs = 8192;
+    if (const char *e = kg_tuning_env("KIWIGPU_RXDDC_RUNS")) { const int v = atoi(e); if (v >= 256 && v <= d->max_runs) target_runs = v; }
+    while (L < 8192 && (long) ((n + L - 1) / L) > target_runs) L <<= 1;
     const int nruns = (int) ((n + L - 1) / L);
     KG_REQUIRE(nruns <= d->max_runs, KG_ERR_INVALID, "kg_rxddc_push_dev: %d runs > %d", nruns, d->max_runs);
     hipStream_t st = d->ctx->stream;
