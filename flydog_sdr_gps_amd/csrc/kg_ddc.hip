@@ -282,7 +282,19 @@ template <int LOG> DDC_DEV void sc_scan_add(sc4 &e, int lane)
 DDC_DEV ddc_state4 ddc_add_state(const ddc_state4 &a, const ddc_state4 &b) { return state_of(sc_add(sc_of(a), sc_of(b))); }
 // Passes A and B.  grid = (ceil(nruns / 256), nchan).  The body of a thread's run; the kernel below adds pass A's
 // workgroup-level prefix sum of the end-referred results (endref == 2).
-template <bool PASS_B>
+// MODE (round 5): which of the body's forms an instantiation carries.  The register budget of a kernel is that of its
+// widest form -- with everything in one function 119 / 124 registers, four waves per SIMD, for passes that stall on
+// table reads and dependent adds and gain from every further wave -- so the launches are split by what their entries need:
+//   DDC_ALL     every form (the staged and vector-store forms of R <= 8, the 128-bit pass A of runs longer than 1024)
+//   DDC_NARROW  the 64-bit form alone: pass A of any decimation in runs of at most 1024 samples, pass B of 16 <= R <= 256
+//   DDC_WIDE    pass B of R >= 512 alone (96-bit integrators)
+enum { DDC_ALL = 0, DDC_NARROW = 1, DDC_WIDE = 2 };
+#ifdef KG_DDC_ONE_FORM           // A/B build: every launch carries every form (round 4's shape)
+static const bool DDC_ONE_FORM = true;
+#else
+static const bool DDC_ONE_FORM = false;
+#endif
+template <bool PASS_B, int MODE>
 DDC_DEV void ddc_wf_run_body(
     const short *__restrict__ adc, long n, int L, int nruns,
     const ddc_chan *__restrict__ chans, const int *__restrict__ chan_list,
@@ -370,7 +382,7 @@ DDC_DEV void ddc_wf_run_body(
     // Pass A always starts from zero: over a run of at most 1024 samples the integrators hold plain
     // sums below 2^23 * 1024^4 / 24 < 2^59, so 64 bits are exact for every R (stored sign-extended).
     const bool short_zero_run = !PASS_B && L <= 1024;
-    if (log2r <= 8 || short_zero_run) {
+    if (MODE == DDC_NARROW || (MODE == DDC_ALL && (log2r <= 8 || short_zero_run))) {
         // Narrow path.  The integrator inputs are m << shift, so bits [shift-1:0] of every
         // integrator stay zero, and nothing above bit 88 is ever read (integrator 5 takes
         // [88 -: 28]): for R <= 256 the live bits [88:shift] are 24 + 5 log2 R <= 64 bits, kept
@@ -422,7 +434,7 @@ DDC_DEV void ddc_wf_run_body(
         // one run's 64 bytes, a store instruction writes 16 whole lines.  Needs the regular case:
         // a full wave of full runs aligned to the decimation, 16 | strobes per run, 16-byte
         // aligned staging rows; anything else takes the paths below.
-        if (PASS_B && stage_bytes && log2r <= 3) {
+        if (MODE == DDC_ALL && PASS_B && stage_bytes && log2r <= 3) {
             const int lane = threadIdx.x & 63, K = L >> log2r;
             const bool ok = al && c == 0 && (s1 - s0) == L && (K & (DDC_STAGE_STROBES - 1)) == 0 && (o & 3) == 0 &&
                             ((uintptr_t) c0i & 15) == 0 && ((uintptr_t) c0q & 15) == 0;
@@ -488,7 +500,7 @@ DDC_DEV void ddc_wf_run_body(
                 o += K;                                                    // all K strobes of the run are out
             }
         }
-        if (PASS_B && log2r <= 2 && c == 0 && (o & 3) == 0 && ((uintptr_t) c0i & 15) == 0 && ((uintptr_t) c0q & 15) == 0) {
+        if (MODE == DDC_ALL && PASS_B && log2r <= 2 && c == 0 && (o & 3) == 0 && ((uintptr_t) c0i & 15) == 0 && ((uintptr_t) c0q & 15) == 0) {
             auto quiet = [&](int a) {                     // step() without the strobe store
                 const int ec = tab[(ph >> 51) + 2048], es = tab[ph >> 51];
                 const long long mi = mix24(a, ec), mq = mix24(a, es);
@@ -575,6 +587,7 @@ DDC_DEV void ddc_wf_run_body(
         return;
     }
 
+    if (MODE == DDC_NARROW) return;               // (not reached: the narrow form returned above)
     if (PASS_B) {
         // Pass B, R >= 512.  Nothing above bit 88 of an integrator is ever read (integrator 5 takes [88 -: 28]), so
         // the states are kept mod 2^96 as three 32-bit limbs: an integrator step is one three-instruction carry
@@ -646,6 +659,7 @@ DDC_DEV void ddc_wf_run_body(
         else { tau[lI] = i5i & 0x0FFFFFFFu; tau[lQ] = i5q & 0x0FFFFFFFu; }
         return;
     }
+    if (MODE != DDC_ALL) return;
     // pass A of runs longer than 1024 samples at R >= 512: the zero-state sums need the full width
     ddc_state4 SI, SQ;
     if (PASS_B) {
@@ -698,7 +712,7 @@ DDC_DEV void ddc_wf_run_body(
 // totals through LDS) -- local[r] = the sum of the workgroup's runs before r, wgtot = the workgroup's total -- and what is
 // left for a kernel of its own is the prefix over at most 64 workgroup totals per (channel, I/Q) (ddc_wf_scan_wg_kernel:
 // one wave each, a few microseconds where the chunked scan took 36 alone and 57 .. 85 beside the bypass kernel).
-template <bool PASS_B>
+template <bool PASS_B, int MODE>
 __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
     const short *__restrict__ adc, long n, int L, int nruns,
     const ddc_chan *__restrict__ chans, const int *__restrict__ chan_list, const u32 *__restrict__ nco,
@@ -713,7 +727,7 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
     ddc_state4 oI, oQ;
     bool have = false;
     u32 oTi = 0, oTq = 0;
-    ddc_wf_run_body<PASS_B>(adc, n, L, nruns, chans, chan_list, nco, local, c0rel, tau, c0off, nouts, sel, stage_bytes, pushed,
+    ddc_wf_run_body<PASS_B, MODE>(adc, n, L, nruns, chans, chan_list, nco, local, c0rel, tau, c0off, nouts, sel, stage_bytes, pushed,
                             nlim, reset_tab, endref, endco, endco_n, wgbase, oI, oQ, have, oTi, oTq);
     if (PASS_B && endref == 2) {
         // The prefix of the runs' integrator-5 totals in the same levels: tau[r] = the sum of the workgroup's runs before r,
@@ -1438,7 +1452,7 @@ int kg_ddc_create(kg_ctx *ctx, int nchan, size_t max_samples, kg_ddc **out)
     KG_HIP(hipMalloc((void **) &d->d_chans, sizeof(ddc_chan) * nchan));
     KG_HIP(hipMemset(d->d_chans, 0, sizeof(ddc_chan) * nchan));
     KG_HIP(hipMalloc((void **) &d->d_nco, sizeof(short) * DDC_TAB));
-    KG_HIP(hipFuncSetAttribute((const void *) ddc_wf_run_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    KG_HIP(hipFuncSetAttribute((const void *) ddc_wf_run_kernel<true, DDC_ALL>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                DDC_STAGE_BYTES));
     for (int p = 0; p < 2; p++) {
         KG_HIP(hipMalloc((void **) &d->d_local[p], sizeof(ddc_state4) * 2 * (size_t) nchan * d->max_runs));
@@ -1696,7 +1710,7 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
     }
     const u64 pushed = d->h_pushed[chan_list[0]];
     std::vector<long> h_nouts(nlist), h_off(nlist), h_nlim(nlist), h_outoff(nlist);
-    std::vector<int> h_wg(nlist + 1), h_bypass, h_run, h_small, h_rest, h_reset(nlist);
+    std::vector<int> h_wg(nlist + 1), h_bypass, h_run, h_small, h_rest, h_big, h_reset(nlist);
     long max_nout = 0, c0_need = 0, comb_wgs = 0, n_run_max = 0, n_by_max = 0, n_run_sum = 0;
     for (int i = 0; i < nlist; i++) {
         const int ch = chan_list[i];
@@ -1719,8 +1733,10 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
         h_wg[i] = (int) comb_wgs;
         if (c.log2r) comb_wgs += (h_nouts[i] + DDC_COMB_TILE - 1) / DDC_COMB_TILE;
         else h_bypass.push_back(i);
-        if (c.log2r) { h_run.push_back(i); (c.log2r <= 3 ? h_small : h_rest).push_back(i); }
+        if (c.log2r) { h_run.push_back(i); (c.log2r <= 3 ? h_small : (c.log2r <= 8 ? h_rest : h_big)).push_back(i); }
     }
+    const size_t nmid = h_rest.size();            // h_rest = the 16 <= R <= 256 entries, then the R >= 512 ones
+    h_rest.insert(h_rest.end(), h_big.begin(), h_big.end());
     h_wg[nlist] = (int) comb_wgs;
     KG_REQUIRE(comb_wgs < (1l << 31), KG_ERR_INVALID, "kg_ddc_wf_push_dev: too many outputs in one call");
     hipStream_t st = d->ctx->stream;
@@ -1863,7 +1879,9 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
     }
     const unsigned gx = (unsigned) ((nruns + DDC_THREADS - 1) / DDC_THREADS);
     if (!h_run.empty()) {
-        hipLaunchKernelGGL(ddc_wf_run_kernel<false>, dim3(gx, (unsigned) h_run.size()), dim3(DDC_THREADS), 0, st,
+        // (runs of at most 1024 samples: every decimation integrates from zero in 64 bits -- the narrow form alone)
+        auto pass_a = (L <= 1024 && !DDC_ONE_FORM) ? ddc_wf_run_kernel<false, DDC_NARROW> : ddc_wf_run_kernel<false, DDC_ALL>;
+        hipLaunchKernelGGL(pass_a, dim3(gx, (unsigned) h_run.size()), dim3(DDC_THREADS), 0, st,
                            (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, s_list,
                            (const u32 *) d->d_nco, d_local, d_c0rel, d_tau, s_c0off,
                            s_nouts, s_selrun, 0, pushed, s_nlim, s_reset, endref, (const ddc_endco *) d->d_endco, d->endco_n,
@@ -1925,30 +1943,45 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
     bool staged = (long) h_small.size() * nruns >= (long) d->ctx->num_cus * 4 * 2 * 64;
     const bool beside = side_on && !h_small.empty() && !h_rest.empty();
     if (const char *e = kg_tuning_env("KIWIGPU_DDC_STAGED")) staged = atoi(e) != 0 && !h_small.empty();
-    auto pass_b = [&](hipStream_t s, const std::vector<int> &which, const int *sel, int stage) {
-        hipLaunchKernelGGL(ddc_wf_run_kernel<true>, dim3(gx, (unsigned) which.size()), dim3(DDC_THREADS), stage, s,
+    auto pass_b = [&](hipStream_t s, size_t nwhich, const int *sel, int stage, int mode) {
+        auto k = mode == DDC_NARROW ? ddc_wf_run_kernel<true, DDC_NARROW> : (mode == DDC_WIDE ? ddc_wf_run_kernel<true, DDC_WIDE> : ddc_wf_run_kernel<true, DDC_ALL>);
+        hipLaunchKernelGGL(k, dim3(gx, (unsigned) nwhich), dim3(DDC_THREADS), stage, s,
                            (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, s_list,
                            (const u32 *) d->d_nco, d_local, d_c0rel, d_tau, s_c0off, s_nouts, sel, stage, pushed, s_nlim, s_reset, endref, (const ddc_endco *) d->d_endco, d->endco_n,
                            (ddc_state4 *) nullptr, (const ddc_state4 *) d->d_wgbase[par], d->d_wgtau[par]);
+    };
+    // The entries above R = 8 by the form they need (DDC_NARROW / DDC_WIDE: fewer registers, more waves per SIMD) -- as two
+    // launches when each of them fills the GPU by itself (a bank of receivers), as one launch of the general form otherwise
+    // (configs[2]'s five and three such channels: two half-empty launches one after the other would lose more than the
+    // waves gain).
+    const long fill = (long) d->ctx->num_cus * 4 * 2 * 64;
+    const size_t nbig = h_rest.size() - nmid;
+    const bool split = !DDC_ONE_FORM && (nmid == 0 || (long) nmid * nruns >= fill) && (nbig == 0 || (long) nbig * nruns >= fill);
+    auto pass_b_rest = [&](hipStream_t s) {
+        if (h_rest.empty()) return;
+        if (!split) { pass_b(s, h_rest.size(), s_selrest, 0, DDC_ALL); return; }
+        if (nmid) pass_b(s, nmid, s_selrest, 0, DDC_NARROW);
+        if (nbig) pass_b(s, nbig, s_selrest + nmid, 0, DDC_WIDE);
     };
     if (beside) {
         if ((rc = side_ready())) return rc;
         side_used = true;
         KG_HIP(hipEventRecord(d->ev_fork, st));
         KG_HIP(hipStreamWaitEvent(d->side, d->ev_fork, 0));
-        pass_b(d->side, h_small, s_selsmall, DDC_STAGE_BYTES);
+        pass_b(d->side, h_small.size(), s_selsmall, DDC_STAGE_BYTES, DDC_ALL);
         KG_HIP(hipGetLastError());
-        pass_b(st, h_rest, s_selrest, 0);
+        pass_b_rest(st);
         KG_HIP(hipGetLastError());
     } else if (staged) {
-        pass_b(st, h_small, s_selsmall, DDC_STAGE_BYTES);
+        pass_b(st, h_small.size(), s_selsmall, DDC_STAGE_BYTES, DDC_ALL);
         KG_HIP(hipGetLastError());
-        if (!h_rest.empty()) {
-            pass_b(st, h_rest, s_selrest, 0);
-            KG_HIP(hipGetLastError());
-        }
+        pass_b_rest(st);
+        KG_HIP(hipGetLastError());
+    } else if (!h_small.empty()) {
+        pass_b(st, h_run.size(), s_selrun, 0, DDC_ALL);           // a few R <= 8 entries, not staged: everything in one launch
+        KG_HIP(hipGetLastError());
     } else if (!h_run.empty()) {
-        pass_b(st, h_run, s_selrun, 0);
+        pass_b_rest(st);
         KG_HIP(hipGetLastError());
     }
     // The output stage: run-total prefix, combs, comb history -- in line on the context's stream, or (deferred) on the

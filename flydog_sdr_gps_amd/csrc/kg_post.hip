@@ -63,6 +63,9 @@ __global__ __launch_bounds__(64) void post_kernel(
     __shared__ float bufB[POST_MAXW + KG_POST_MAX_SAMPLES];
     __shared__ float s_db[KG_POST_MAX_SAMPLES];
     __shared__ float2 s_agc[KG_POST_MAX_SAMPLES];
+    // one wave per channel walking sequential recursions (S-meter, CAgc): latency, among workgroups that fill the vector
+    // units -- it takes the issue priority (beside the DDCs' run passes the kernel stretched from 77 to 450 .. 980 us)
+    __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x, row = blockIdx.x, ch = chans[row];
     post_chan *pc = &chan_tab[ch];
     const post_chan c = *pc;

@@ -36,7 +36,10 @@ typedef unsigned long long u64;
 typedef unsigned int u32;
 
 #define RX_HIST 256          // rx1 outputs kept from earlier calls (a final output spans 203 of them)
-#define RX_THREADS 256
+#ifndef RX_LOG_THREADS
+#define RX_LOG_THREADS 8     // threads (= runs) per workgroup of a run pass, log2
+#endif
+#define RX_THREADS (1 << RX_LOG_THREADS)
 #define RX_TAB KG_NCO_TAB
 
 // The three RX instances the reference builds (kiwi.config:101-105, fir_iq.sv:39-123); the widths
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(256) void rx1_comb_kernel(
             else {
                 const long g = (oo + 1) * RX_R1 - 1 - (long) base;      // sample index of the strobe
                 const int run = (int) (g / L);
-                const u32 wb = wgt ? wgt[((long) li * 2 + comp) * gx + (run >> 8)] : 0u;
+                const u32 wb = wgt ? wgt[((long) li * 2 + comp) * gx + (run >> RX_LOG_THREADS)] : 0u;
                 v = (c0rel[((long) li * 2 + comp) * max_out + oo] + i3start[((long) li * 2 + comp) * nruns + run] + wb) & 0x03FFFFFFu;
             }
             c0[d] = sx((int) v, 26);

@@ -24,18 +24,11 @@ __constant__ int c_step_size[89] = {
 struct adpcm_state { int index, previous; };
 
 // One sample: ImaAdpcmEncode + the ImaAdpcmDecode it ends with (ima_adpcm.cpp:161-181, 110-135).
-// The coder is a recurrence over (index, previousValue) and the step-size lookup tab[index] sat on its critical path: an LDS
-// round trip per sample in a wave that has nothing else to issue (round 4: 207 ns per sample in wf_packet_kernel).  The next
-// sample can only meet one of FIVE step sizes -- indexAdjustTable moves the index by -1, +2, +4, +6 or +8 (:89-94) -- so
-// all five are requested at the top of a sample, before its code is known, and the one the code selects is a register
-// select: the lookup's latency runs beside the sample's own arithmetic.  `tab` holds the 89 step sizes and eight more copies
-// of the last one (an index clamps at 88).  `step` = tab[index] on entry and on exit.
-#define ADPCM_TAB 97
+// `tab` is the step table in LDS (a lane-indexed lookup on the recurrence's critical path).
 template <int POS, int NEG>
-__device__ __forceinline__ unsigned adpcm_step(int sample, int &index, int &previous, int &step, const int *tab)
+__device__ __forceinline__ unsigned adpcm_step(int sample, int &index, int &previous, const int *tab)
 {
-    const int im1 = index > 0 ? index - 1 : 0;
-    const int n0 = tab[im1], n1 = tab[index + 2], n2 = tab[index + 4], n3 = tab[index + 6], n4 = tab[index + 8];
+    const int step = tab[index];
     int diff = sample - previous;
     unsigned code = 0;
     if (diff < 0) { code = 8; diff = -diff; }
@@ -49,87 +42,49 @@ __device__ __forceinline__ unsigned adpcm_step(int sample, int &index, int &prev
     previous += difference;
     previous = previous > POS ? POS : (previous < NEG ? NEG : previous);
     // indexAdjustTable (:89-94): -1 for magnitudes 0..3, 2/4/6/8 for 4..7
-    if (code & 4) {
-        const int m = (int) (code & 3);
-        index = index + 2 * (m + 1);
-        index = index > 88 ? 88 : index;
-        step = m == 0 ? n1 : (m == 1 ? n2 : (m == 2 ? n3 : n4));
-    } else {
-        index = im1;
-        step = n0;
-    }
+    index += (code & 4) ? 2 * ((int) (code & 3) + 1) : -1;
+    index = index < 0 ? 0 : (index > 88 ? 88 : index);
     return code;
 }
-__device__ __forceinline__ void adpcm_tab_load(int *tab, int t, int nthreads)
-{
-    for (int i = t; i < ADPCM_TAB; i += nthreads) tab[i] = c_step_size[i < 89 ? i : 88];
-}
 
-// encode_ima_adpcm_i16_e8 for many channels: lane = channel, 64 channels per workgroup.  Round 5: the samples of a chunk
-// come into LDS with lane-contiguous loads (a lane reading its own row sample by sample is 64 lines per load instruction
-// and a global round trip per four samples: 108 ... 143 us per 512-sample block) and the code bytes leave the same way.
-#define ADPCM_CHUNK 512                     // samples per row staged at a time
-#define ADPCM_IN_PITCH (ADPCM_CHUNK / 2 + 1)    // dwords per staged input row: odd, so the lanes' rows fall in different banks
-#define ADPCM_OUT_PITCH (ADPCM_CHUNK / 8 + 1)   // dwords per staged output row (one code byte per two samples)
+// encode_ima_adpcm_i16_e8 for many channels: lane = channel.
 __global__ __launch_bounds__(64) void adpcm_snd_kernel(adpcm_state *__restrict__ states, const int *__restrict__ chans,
                                                        int nch, const short *__restrict__ in, size_t in_stride,
                                                        int nsamps, unsigned char *__restrict__ out, size_t out_stride)
 {
-    __shared__ int tab[ADPCM_TAB];
-    __shared__ unsigned s_in[64 * ADPCM_IN_PITCH];
-    __shared__ unsigned s_out[64 * ADPCM_OUT_PITCH];
-    const int lane = threadIdx.x, row0 = blockIdx.x * 64;
-    const int nrows = nch - row0 < 64 ? nch - row0 : 64;
-    adpcm_tab_load(tab, lane, 64);
-    const int row = row0 + lane;
-    int index = 0, previous = 0, ch = 0;
-    if (lane < nrows) { ch = chans[row]; index = states[ch].index; previous = states[ch].previous; }
+    __shared__ int tab[89];
+    // a single wave's recurrence among workgroups that fill the vector units: it takes the issue priority (the coder is
+    // latency, the others are throughput).  Round 5 measured two rewrites of this recurrence and kept neither: the five
+    // step sizes the next sample can meet requested ahead of the code (the table read off the critical path) and the rows
+    // staged through LDS with lane-contiguous loads -- 86 us alone against this form's 66: the chain of dependent compares
+    // and selects, not the memory, is what a sample costs (130 ns in wf_packet_kernel either way).
+    __builtin_amdgcn_s_setprio(3);
+    for (int i = threadIdx.x; i < 89; i += 64) tab[i] = c_step_size[i];
     __syncthreads();
-    int step = tab[index];
-    for (int c0 = 0; c0 < nsamps; c0 += ADPCM_CHUNK) {
-        const int cn = nsamps - c0 < ADPCM_CHUNK ? nsamps - c0 : ADPCM_CHUNK;        // even (the host checks nsamps)
-        // stage: row r, samples lane, lane + 64, ... (rows are only guaranteed 2-byte aligned)
-        for (int r = 0; r < nrows; r++) {
-            const short *p = in + (size_t) (row0 + r) * in_stride + c0;
-            unsigned short *d = (unsigned short *) (s_in + r * ADPCM_IN_PITCH);
-            for (int i = lane; i < cn; i += 64) d[i] = (unsigned short) p[i];
-        }
-        __syncthreads();
-        if (lane < nrows) {
-            const unsigned *src = s_in + lane * ADPCM_IN_PITCH;
-            unsigned *dst = s_out + lane * ADPCM_OUT_PITCH;
-            int i = 0;
-            for (; i + 8 <= cn; i += 8) {                              // eight samples -> one dword of codes
-                unsigned w = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const unsigned v = src[i / 2 + k];
-                    const unsigned b0 = adpcm_step<32767, -32768>((int) (short) (v & 0xffff), index, previous, step, tab);
-                    const unsigned b1 = adpcm_step<32767, -32768>((int) (short) (v >> 16), index, previous, step, tab);
-                    w |= (b0 | (b1 << 4)) << (8 * k);
-                }
-                dst[i / 8] = w;
-            }
-            if (i < cn) {                                              // a ragged end: 2, 4 or 6 samples
-                unsigned w = 0;
-                for (int k = 0; i + 2 * k < cn; k++) {
-                    const unsigned v = src[i / 2 + k];
-                    const unsigned b0 = adpcm_step<32767, -32768>((int) (short) (v & 0xffff), index, previous, step, tab);
-                    const unsigned b1 = adpcm_step<32767, -32768>((int) (short) (v >> 16), index, previous, step, tab);
-                    w |= (b0 | (b1 << 4)) << (8 * k);
-                }
-                dst[i / 8] = w;
-            }
-        }
-        __syncthreads();
-        for (int r = 0; r < nrows; r++) {
-            unsigned char *q = out + (size_t) (row0 + r) * out_stride + c0 / 2;
-            const unsigned char *sb = (const unsigned char *) (s_out + r * ADPCM_OUT_PITCH);
-            for (int i = lane; i < cn / 2; i += 64) q[i] = sb[i];
-        }
-        __syncthreads();
+    const int row = blockIdx.x * 64 + threadIdx.x;
+    if (row >= nch) return;
+    const int ch = chans[row];
+    int index = states[ch].index, previous = states[ch].previous;
+    const short *p = in + (size_t) row * in_stride;
+    unsigned char *q = out + (size_t) row * out_stride;
+    int i = 0;
+    // four samples -> two bytes per round; rows are only guaranteed 2-byte aligned
+    for (; i + 4 <= nsamps; i += 4) {
+        const int s0 = p[i], s1 = p[i + 1], s2 = p[i + 2], s3 = p[i + 3];
+        unsigned b0 = adpcm_step<32767, -32768>(s0, index, previous, tab);
+        b0 |= adpcm_step<32767, -32768>(s1, index, previous, tab) << 4;
+        unsigned b1 = adpcm_step<32767, -32768>(s2, index, previous, tab);
+        b1 |= adpcm_step<32767, -32768>(s3, index, previous, tab) << 4;
+        q[i / 2] = (unsigned char) b0;
+        q[i / 2 + 1] = (unsigned char) b1;
     }
-    if (lane < nrows) { states[ch].index = index; states[ch].previous = previous; }
+    for (; i + 2 <= nsamps; i += 2) {
+        unsigned b = adpcm_step<32767, -32768>(p[i], index, previous, tab);
+        b |= adpcm_step<32767, -32768>(p[i + 1], index, previous, tab) << 4;
+        q[i / 2] = (unsigned char) b;
+    }
+    states[ch].index = index;
+    states[ch].previous = previous;
 }
 
 __global__ void snd_payload_kernel(const unsigned short *__restrict__ in, size_t in_stride, int nch, int nsamps,
@@ -144,19 +99,20 @@ __global__ void snd_payload_kernel(const unsigned short *__restrict__ in, size_t
 
 struct wf_pkt_dev_info { unsigned x_bin_server, flags_x_zoom_server, seq; int use_compression; };
 
-// One workgroup (one wave) per row: the row is staged in LDS, lane 0 runs the coder (with the step sizes of the next sample
-// requested ahead: adpcm_step), the packet bytes are stored by all lanes.
+// One workgroup (one wave) per row: the row is staged in LDS, lane 0 runs the coder, the
+// packet bytes are stored by all lanes.
 __global__ __launch_bounds__(64) void wf_packet_kernel(const unsigned char *__restrict__ rows, size_t row_stride,
                                                        const wf_pkt_dev_info *__restrict__ info,
                                                        unsigned char *__restrict__ pkts, size_t pkt_stride)
 {
-    __shared__ int tab[ADPCM_TAB];
-    __shared__ __attribute__((aligned(4))) unsigned char s_in[KG_WF_ADPCM_PAD + 1024 + 2];
-    __shared__ __attribute__((aligned(4))) unsigned char s_out[KG_WF_PKT_MAX + 2];
+    __shared__ int tab[89];
+    __shared__ unsigned char s_in[KG_WF_ADPCM_PAD + 1024 + 2];
+    __shared__ unsigned char s_out[KG_WF_PKT_MAX];
+    __builtin_amdgcn_s_setprio(3);                 // one lane's recurrence: latency, not throughput (see adpcm_snd_kernel)
     const int lane = threadIdx.x, r = blockIdx.x;
     const wf_pkt_dev_info f = info[r];
     const unsigned char *row = rows + (size_t) r * row_stride;
-    adpcm_tab_load(tab, lane, 64);
+    for (int i = lane; i < 89; i += 64) tab[i] = c_step_size[i];
     for (int i = lane; i < 1024; i += 64) s_in[KG_WF_ADPCM_PAD + i] = row[i];
     __syncthreads();
     if (lane < KG_WF_ADPCM_PAD) s_in[lane] = s_in[KG_WF_ADPCM_PAD];      // adpcm_pad <- buf2[0], rx_waterfall.cpp:1625
@@ -170,23 +126,11 @@ __global__ __launch_bounds__(64) void wf_packet_kernel(const unsigned char *__re
     if (f.use_compression) {
         nbytes = (KG_WF_ADPCM_PAD + 1024) / 2;
         if (lane == 0) {
-            int index = 0, previous = 0, step = tab[0];                  // memset(&adpcm_wf, 0, ...) :1626
-            static_assert((KG_WF_ADPCM_PAD + 1024) % 2 == 0 && KG_WF_PKT_HDR % 2 == 0, "two samples -> one code byte, two bytes per store");
-            const unsigned short *src = (const unsigned short *) s_in;
-            unsigned short *dst = (unsigned short *) (s_out + KG_WF_PKT_HDR);
-            for (int i = 0; i < (KG_WF_ADPCM_PAD + 1024) / 4; i++) {      // four samples -> two code bytes (258 rounds; 1034 = 4 x 258 + 2)
-                const unsigned a = src[2 * i], c = src[2 * i + 1];
-                unsigned b0 = adpcm_step<255, 0>((int) (a & 0xff), index, previous, step, tab);
-                b0 |= adpcm_step<255, 0>((int) (a >> 8), index, previous, step, tab) << 4;
-                unsigned b1 = adpcm_step<255, 0>((int) (c & 0xff), index, previous, step, tab);
-                b1 |= adpcm_step<255, 0>((int) (c >> 8), index, previous, step, tab) << 4;
-                dst[i] = (unsigned short) (b0 | (b1 << 8));
-            }
-            {
-                const unsigned a = src[(KG_WF_ADPCM_PAD + 1024) / 2 - 1];                // the last two samples
-                unsigned b0 = adpcm_step<255, 0>((int) (a & 0xff), index, previous, step, tab);
-                b0 |= adpcm_step<255, 0>((int) (a >> 8), index, previous, step, tab) << 4;
-                s_out[KG_WF_PKT_HDR + (KG_WF_ADPCM_PAD + 1024) / 2 - 1] = (unsigned char) b0;
+            int index = 0, previous = 0;                                 // memset(&adpcm_wf, 0, ...) :1626
+            for (int i = 0; i < KG_WF_ADPCM_PAD + 1024; i += 2) {
+                unsigned b = adpcm_step<255, 0>(s_in[i], index, previous, tab);
+                b |= adpcm_step<255, 0>(s_in[i + 1], index, previous, tab) << 4;
+                s_out[KG_WF_PKT_HDR + i / 2] = (unsigned char) b;
             }
         }
     } else {

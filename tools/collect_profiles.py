@@ -9,7 +9,7 @@ import shutil
 import sys
 
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r05"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 go, pr = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 
@@ -41,7 +41,7 @@ def own_line(wl):
     return ""
 
 
-for wl in ("acq", "acq59", "acq10ms", "wf14", "ddc14", "cfg2_chain", "receivers"):
+for wl in ("acq", "acq59", "acq10ms", "wf14", "ddc14", "cfg2_chain", "receivers", "receivers_light"):
     ks = first(os.path.join(go, "%s_%s" % (tag, wl), "trace", "**", "*kernel_stats.csv"))
     if ks:
         dst = os.path.join(pr, "%s_%s_kernel_stats.csv" % (rnd, wl))

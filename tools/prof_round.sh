@@ -8,8 +8,8 @@ for wl in acq acq59 acq10ms wf14 ddc14; do
   tools/prof.sh ${tag}_$wl --workload $wl $extra > gpurun_out/${tag}_$wl.summary.txt 2>&1
   echo "== $wl"; grep -E "calls|traced run" gpurun_out/${tag}_$wl.summary.txt | head -8
 done
-for wl in cfg2_chain receivers; do
-  extra="--steps 200"; [ $wl = receivers ] && extra="--steps 40 --warmup 4"
+for wl in cfg2_chain receivers receivers_light; do
+  extra="--steps 200"; case $wl in receivers*) extra="--steps 60 --warmup 4";; esac
   PROF_PMC=0 tools/prof.sh ${tag}_$wl --workload $wl $extra > gpurun_out/${tag}_$wl.summary.txt 2>&1
   echo "== $wl"; grep -E "calls|traced run" gpurun_out/${tag}_$wl.summary.txt | head -10
 done
