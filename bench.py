@@ -1531,11 +1531,13 @@ def run_receivers(args, dist, wl="receivers"):
     preroll(step, args.warmup)
     sync()
     dist.barrier()
+    bank.host_profile()                              # (reset: the next call reports the timed loop alone)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     t_loop = time.perf_counter() - t0
     sync()                                           # every stream of the bank
+    log("%s: host phases of the timed loop: %s" % (wl, bank.host_profile()))
     torch.cuda.synchronize(dev)
     local = time.perf_counter() - t0
     dist.barrier()

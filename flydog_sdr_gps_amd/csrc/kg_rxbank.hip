@@ -44,6 +44,7 @@ __global__ __launch_bounds__(256) void rxbank_move_kernel(short2 *__restrict__ i
 
 struct kg_rxbank {
     int device, nrx, mode, decim_rx;
+
     size_t n;                                   // ADC samples per step
     hipStream_t s_main, s_side, s_tail, s_up;   // waterfall chain / audio chain / both sequential coders / the table upload
     hipStream_t s_ddc2;                         // the waterfall DDC's second stream (R = 1 bypass, pass B of R <= 8 beside the rest)
@@ -275,13 +276,22 @@ int kg_rxbank_create(int device, int nrx, size_t adc_samples_per_step, int rx_mo
 #define BANK_TRY(call) do { if ((rc = (call)) != KG_OK) { kg_rxbank_destroy(b); return rc; } } while (0)
 #define BANK_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { kg_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, \
                             hipGetErrorString(e_)); kg_rxbank_destroy(b); return KG_ERR_HIP; } } while (0)
-    // The four streams that carry kernels are created FIRST and back to back: the HIP runtime deals hardware queues to
-    // streams in creation order, and queues whose numbers are equal modulo four took turns instead of running side by side
-    // (measured, rocprofv3 queue ids: with torch's null stream created first the waterfall chain landed on queue 2 and the
-    // DDC's own second stream, created lazily as the sixth, on queue 6 -- 1.31 ms per step against 1.02 with queues 1 and 6).
-    // Four consecutive queues are distinct modulo four whatever was created before them; the upload stream (a DMA
-    // transfer, no kernels) comes fifth.
+    // The four streams that carry kernels are created back to back, the upload's fifth.  Which hardware queue (and, behind
+    // it, which of the four dispatch pipes) a stream lands on is the HIP runtime's choice -- the least-shared queue of its pool
+    // at that moment -- and depends on every stream the process created before: measured on one bank, 0.98 ms per step or
+    // 1.25 ... 1.38 by what had run earlier in the process (tools/micro/stream_pairs.hip measures which pairs of
+    // streams run side by side).  Creating them together at least keeps them off one another's queues while the pool has
+    // free ones.
     BANK_HIP(hipSetDevice(device));
+    {
+        hipDeviceProp_t prop;
+        BANK_HIP(hipGetDeviceProperties(&prop, device));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            kg_set_error("kg_rxbank_create: device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+            delete b;
+            return KG_ERR_NO_DEVICE;
+        }
+    }
     BANK_HIP(hipStreamCreateWithFlags(&b->s_main, hipStreamNonBlocking));
     BANK_HIP(hipStreamCreateWithFlags(&b->s_side, hipStreamNonBlocking));
     BANK_HIP(hipStreamCreateWithFlags(&b->s_tail, hipStreamNonBlocking));
@@ -404,10 +414,12 @@ int kg_rxbank_step(kg_rxbank *b, const void *d_adc, void *adc_ready_event, kg_rx
     tk.lap(b, PF_PLAN, true);
     if (rc == KG_OK) {
         // the ONE transfer of the step, on a stream of its own (ordered behind nothing but earlier uploads: the slot is free)
-        hipError_t e = hipMemcpyAsync(a.d_base, a.h_base, a.used, hipMemcpyHostToDevice, b->s_up);
-        if (e == hipSuccess) e = hipEventRecord(b->ev_tab, b->s_up);
-        if (e == hipSuccess) e = hipStreamWaitEvent(b->s_main, b->ev_tab, 0);
-        if (e == hipSuccess) e = hipStreamWaitEvent(b->s_side, b->ev_tab, 0);
+        hipStream_t us = b->s_up;
+        if (const char *ev = kg_tuning_env("KIWIGPU_BANK_UPLOAD")) us = ev[0] == 'm' ? b->s_main : (ev[0] == 's' ? b->s_side : b->s_up);
+        hipError_t e = hipMemcpyAsync(a.d_base, a.h_base, a.used, hipMemcpyHostToDevice, us);
+        if (e == hipSuccess) e = hipEventRecord(b->ev_tab, us);
+        if (e == hipSuccess && us != b->s_main) e = hipStreamWaitEvent(b->s_main, b->ev_tab, 0);
+        if (e == hipSuccess && us != b->s_side) e = hipStreamWaitEvent(b->s_side, b->ev_tab, 0);
         if (e == hipSuccess && adc_ready_event) {
             e = hipStreamWaitEvent(b->s_main, (hipEvent_t) adc_ready_event, 0);
             if (e == hipSuccess) e = hipStreamWaitEvent(b->s_side, (hipEvent_t) adc_ready_event, 0);

@@ -83,6 +83,8 @@ class RxBank:
         self.ddc = borrow(Ddc, self.ctx, self.lib.kg_rxbank_ddc(h), nchan=nrx, max_samples=n)
         self.wf = borrow(Waterfall, self.ctx, self.lib.kg_rxbank_wf(h), nchan=nrx)
         self.rxddc = borrow(RxDdc, self.ctx, self.lib.kg_rxbank_rxddc(h), nchan=nrx, max_samples=n, mode=rx_mode)
+        self.rxddc.decim = check(self.lib.kg_rxddc_decim(self.rxddc.h), "kg_rxddc_decim")
+        self.rx_mode = int(rx_mode)
         self.fir = borrow(FastFir, self.ctx, self.lib.kg_rxbank_fir(h), nchan=nrx)
         self.post = borrow(Post, self.ctx, self.lib.kg_rxbank_post(h), nchan=nrx)
         self.adpcm = borrow(Adpcm, self.ctx, self.lib.kg_rxbank_adpcm(h), nchan=nrx)
@@ -93,7 +95,7 @@ class RxBank:
         self.params = [None] * nrx
         self.overlapped = [False] * nrx
         self.rx_inc = [0] * nrx
-        self.fs = ADC_CLOCK / RX_DECIM
+        self.fs = ADC_CLOCK / self.rxddc.decim          # RX_DECIM (rx4 / rx8, rx14) or RX_DECIM_WIDE (rx3)
 
     def close(self):
         if getattr(self, "h", None):

@@ -13,9 +13,12 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 
-def check_bank(bank, adc_of_step, d_adc_of_step, rxs, steps=3, threads=8):
+def check_bank(bank, adc_of_step, d_adc_of_step, rxs, steps=3, threads=8, events=None):
     """Steps a FRESHLY CONFIGURED RxBank `steps` times (step k over adc_of_step(k), a host int16 array of bank.n samples whose
     device copy is d_adc_of_step(k)) and checks every stage of the receivers `rxs`.
+    events: {step: [("wf", rx, WfParams, overlapped) | ("freq", rx, phase_inc)]} -- the connection's `SET zoom= start=` /
+    `SET freq=` commands, applied to the bank and to the oracle's state before that step: a new waterfall setting resets
+    the receiver's sampler (CmdWFReset, fill pipe), a new audio frequency leaves the filters running (rx_sound_cmd.cpp:41-51).
     -> {"receivers", "steps", "frames", "audio_blocks", "overlapped_frames", "ring_moves"}"""
     from flydog_sdr_gps_amd import wf
     from oracle import kiwi_oracle as ko
@@ -35,8 +38,20 @@ def check_bank(bank, adc_of_step, d_adc_of_step, rxs, steps=3, threads=8):
     coef = {rx: bank.fir.get_coef(rx) for rx in rxs}
     frames = audio_blocks = ov_frames = moves = 0
     snd_seq = 0
+    nco0 = {rx: 0 for rx in rxs}                           # one-shot receivers: ADC samples since the waterfall NCO was last set
+    total_n = 0
     with ThreadPoolExecutor(threads) as pool:              # the oracle's C calls release the GIL
         for step in range(steps):
+            for ev in (events or {}).get(step, ()):
+                if ev[0] == "wf":
+                    _, rx, p, ov = ev
+                    bank.set_wf(rx, p, ov)                 # kg_rxbank_set_wf: phase = 0, sampler reset
+                    if rx in wf_st:
+                        wf_st[rx], hist[rx], nco0[rx] = None, np.zeros((0, 2), np.int16), total_n
+                elif ev[0] == "freq":
+                    _, rx, inc = ev
+                    bank.rxddc.set_freq(rx, inc)
+                    bank.rx_inc[rx] = int(inc)
             adc = adc_of_step(step)
             info = bank.step(d_adc_of_step(step))
             bank.sync()
@@ -52,11 +67,11 @@ def check_bank(bank, adc_of_step, d_adc_of_step, rxs, steps=3, threads=8):
                 if bank.overlapped[rx]:
                     return ko.ddc_wf(adc, p.i_offset, l2, wf_st[rx])
                 st = ko.DdcWfState()                                   # CmdWFReset: CICs zero, the NCO running on
-                st.phase = (step * n * p.i_offset) & ((1 << 48) - 1)
+                st.phase = ((total_n - nco0[rx]) * p.i_offset) & ((1 << 48) - 1)
                 return ko.ddc_wf(adc[:8192 * p.decim], p.i_offset, l2, st)
 
             wf_out = list(pool.map(wf_ref, rxs))
-            rx_out = list(pool.map(lambda rx: ko.ddc_rx(adc, bank.rx_inc[rx], rx_st[rx]), rxs))
+            rx_out = list(pool.map(lambda rx: ko.ddc_rx(adc, bank.rx_inc[rx], rx_st[rx], bank.rx_mode), rxs))
             with_frame = [rx for rx in rxs if rx in frame_of]
             g_rows = dict(zip(with_frame, bank.fetch("rows", [frame_of[rx] for rx in with_frame])))
             g_pkts = dict(zip(with_frame, bank.fetch("pkts", [frame_of[rx] for rx in with_frame])))
@@ -110,5 +125,6 @@ def check_bank(bank, adc_of_step, d_adc_of_step, rxs, steps=3, threads=8):
                     assert np.array_equal(g["pay"][i, 256 * blk:256 * (blk + 1)], want_enc), (step, rx, "ADPCM")
                     audio_blocks += 1
             snd_seq += nfir // 512
+            total_n += n
     return {"receivers": len(rxs), "steps": steps, "frames": frames, "audio_blocks": audio_blocks,
             "overlapped_frames": ov_frames, "ring_moves": moves}

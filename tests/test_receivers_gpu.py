@@ -116,3 +116,69 @@ def test_bank_error_paths():
         bank.ctx.free(d)
     finally:
         bank.close()
+
+
+def _small_mix(zooms, n):
+    from flydog_sdr_gps_amd.ddc import rx_phase_inc
+    from flydog_sdr_gps_amd.rxbank import ADC_CLOCK, UI_SRATE
+    from flydog_sdr_gps_amd.wf import WfParams
+    hz = UI_SRATE / (1024 << 14)
+    mix = []
+    for k, zoom in enumerate(zooms):
+        span = UI_SRATE / (1 << zoom)
+        p = WfParams.for_zoom(zoom, (0.0123 * ADC_CLOCK - span * (0.2 + 0.05 * (k % 9))) / hz, adc_clock=ADC_CLOCK, ui_srate=UI_SRATE)
+        mix.append((p, 8192 * p.decim > n, rx_phase_inc(0.0123 * ADC_CLOCK - 900.0 - 35.0 * k, ADC_CLOCK)))
+    return mix
+
+
+def test_connections_retune_between_steps(oracle):
+    """`SET zoom= start=` and `SET freq=` while the bank runs (rx_waterfall.cpp:410-515, rx_sound_cmd.cpp:41-51): a receiver
+    goes from the one-shot sampler to the overlapped one and back, another changes its span inside the overlapped mode
+    (its ring starts empty again: "fill pipe"), a third moves its audio NCO (filters keep running).  12 steps of 2^17
+    samples over one stream, every stage of every receiver against the oracle with the same events applied."""
+    from flydog_sdr_gps_amd import synth
+    from flydog_sdr_gps_amd.ddc import rx_phase_inc
+    from flydog_sdr_gps_amd.rxbank import ADC_CLOCK
+    from tests.rxbank_check import check_bank
+    n, steps = 1 << 17, 12
+    mix = _small_mix([5, 6, 7, 5, 8], n)
+    alt = _small_mix([6, 5, 8, 4, 7], n)                     # what the receivers are retuned to
+    adc = synth.adc_stream(n * steps, 0x5EED0047)
+    bank = _bank(len(mix), n, mix)
+    try:
+        d_adc = bank.ctx.alloc(adc.nbytes)
+        bank.ctx.upload(d_adc, adc)
+        events = {3: [("wf", 0, alt[0][0], alt[0][1])],                                   # one-shot -> overlapped
+                  5: [("wf", 2, alt[2][0], alt[2][1]), ("freq", 4, rx_phase_inc(0.0123 * ADC_CLOCK - 1500.0, ADC_CLOCK))],
+                  8: [("wf", 0, mix[0][0], mix[0][1]), ("wf", 3, alt[3][0], alt[3][1])]}  # back to one-shot; another one-shot zoom
+        assert alt[0][1] and not mix[0][1] and alt[2][1] and mix[2][1]
+        got = check_bank(bank, lambda k: adc[k * n:(k + 1) * n], lambda k: d_adc + 2 * k * n, range(len(mix)), steps, events=events)
+        assert got["frames"] > 0 and got["overlapped_frames"] > 0, got
+        bank.ctx.free(d_adc)
+    finally:
+        bank.close()
+
+
+@pytest.mark.parametrize("mode_name", ["wide", "rx14"])
+def test_bank_of_the_other_rx_instances(oracle, mode_name):
+    """The rx3 (20.25 kHz, ADC / 6172) and rx14 (17-tap CICF) audio DDCs under the bank (KG_RXDDC_WIDE / KG_RXDDC_RX14), 70
+    receivers -- not a multiple of a wave -- over 44 steps of 2^17 samples (one or two sound blocks each); a sample of the
+    receivers against the oracle."""
+    from flydog_sdr_gps_amd import synth
+    from flydog_sdr_gps_amd.ddc import RX_14, RX_WIDE
+    from flydog_sdr_gps_amd.rxbank import RxBank
+    from tests.rxbank_check import check_bank
+    n, steps, nrx = 1 << 17, 44, 70
+    mode = RX_WIDE if mode_name == "wide" else RX_14
+    mix = _small_mix([5 + k % 4 for k in range(nrx)], n)
+    adc = synth.adc_stream(n * steps, 0x5EED0048)
+    bank = RxBank(nrx, n, rx_mode=mode)
+    try:
+        bank.configure(mix)
+        d_adc = bank.ctx.alloc(adc.nbytes)
+        bank.ctx.upload(d_adc, adc)
+        got = check_bank(bank, lambda k: adc[k * n:(k + 1) * n], lambda k: d_adc + 2 * k * n, [0, 1, 2, 3, 33, 63, 64, 69], steps)
+        assert got["frames"] > 0 and got["audio_blocks"] >= 8, got
+        bank.ctx.free(d_adc)
+    finally:
+        bank.close()
