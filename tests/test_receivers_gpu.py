@@ -182,3 +182,32 @@ def test_bank_of_the_other_rx_instances(oracle, mode_name):
         bank.ctx.free(d_adc)
     finally:
         bank.close()
+
+
+def test_overlapped_mode_at_its_edges(oracle):
+    """The overlapped sampler at the ends of what kg_rxbank_set_wf accepts: a receiver whose step yields exactly one frame
+    (R = 16 with 2^17 samples: 8192 outputs a step -- the ring wraps without anything to keep) and two that fill their pipes
+    slowly (R = 2048 / 4096: 64 / 32 outputs a step, no frame inside the test), beside a one-shot receiver.  12 steps."""
+    from flydog_sdr_gps_amd import synth
+    from flydog_sdr_gps_amd.ddc import rx_phase_inc
+    from flydog_sdr_gps_amd.rxbank import ADC_CLOCK, UI_SRATE
+    from flydog_sdr_gps_amd.wf import WfParams
+    from tests.rxbank_check import check_bank
+    n, steps = 1 << 17, 12
+    hz = UI_SRATE / (1024 << 14)
+    mix = []
+    for k, (zoom, ov) in enumerate([(5, True), (5, False), (12, True), (13, True)]):
+        span = UI_SRATE / (1 << zoom)
+        p = WfParams.for_zoom(zoom, (0.0123 * ADC_CLOCK - span * 0.3) / hz, adc_clock=ADC_CLOCK, ui_srate=UI_SRATE)
+        mix.append((p, ov, rx_phase_inc(0.0123 * ADC_CLOCK - 800.0 - 50.0 * k, ADC_CLOCK)))
+    assert [p.decim for p, _, _ in mix] == [16, 16, 2048, 4096]
+    adc = synth.adc_stream(n * steps, 0x5EED0049)
+    bank = _bank(len(mix), n, mix)
+    try:
+        d_adc = bank.ctx.alloc(adc.nbytes)
+        bank.ctx.upload(d_adc, adc)
+        got = check_bank(bank, lambda k: adc[k * n:(k + 1) * n], lambda k: d_adc + 2 * k * n, range(len(mix)), steps)
+        assert got["frames"] == 2 * steps and got["overlapped_frames"] == steps and got["ring_moves"] == 0, got
+        bank.ctx.free(d_adc)
+    finally:
+        bank.close()
