@@ -297,6 +297,10 @@ CPU_LEGS = {}                # workload -> cpu_baseline object, filled by cpu_le
 # HBM traffic, measured by the run that prints it
 # ------------------------------------------------------------------------------------------------
 ALL_WORKLOADS = ["acq", "wf14", "ddc14", "cfg2_chain", "receivers", "receivers_light", "acq10ms"]     # the default line, in run order
+if os.environ.get("KIWIGPU_BENCH_ORDER"):            # a diagnostic: another run order / a subset (the line then lacks workloads)
+    ALL_WORKLOADS = [w for w in os.environ["KIWIGPU_BENCH_ORDER"].split(",") if w in ALL_WORKLOADS]
+    if "acq" not in ALL_WORKLOADS:
+        ALL_WORKLOADS.insert(0, "acq")
 PMC_WORKLOADS = ALL_WORKLOADS + ["acq59"]
 PMC_STEPS = 4                # steps inside a workload's marked window of a counter pass
 LIVE_TRAFFIC = {}            # workload -> (bytes, source), filled by live_traffic_passes()

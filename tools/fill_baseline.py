@@ -33,14 +33,15 @@ rows = [
     row("2 frames", "wf14", "IQ Msamples/s of DDC output"),
     row("2 DDC", "ddc14", "ADC Msamples/s"),
     row("2 end to end", "cfg2_chain", "ADC Msamples/s"),
-    row("3 (128 receivers = one GPU's share)", "receivers", "receiver x ADC Msamples/s"),
+    row("3 (128 receivers = one GPU's share; SURVEY's mix)", "receivers", "receiver x ADC Msamples/s"),
+    row("3 (the same on rounds 2-4's lighter receiver set)", "receivers_light", "receiver x ADC Msamples/s"),
     row("4 (2 blocks per step)", "acq10ms", "IQ Msamples/s"),
 ]
 table = ("| Config | CPU T₁ (Msamples/s) | CPU T_all (Msamples/s) | 1 GPU | 2 GPU | 4 GPU | 8 GPU | value (unit) | HBM GB/s (rocprof) | % of 8 TB/s |\n"
          "|---|---|---|---|---|---|---|---|---|---|\n" + "\n".join(rows))
 src = open("BASELINE.md").read()
 start = src.index("Results table")
-out = src[:start] + ("Results table, filled from the default `python bench.py` line of round 4 (`%s`; one MI355X; CPU legs: the oracle port\n"
+out = src[:start] + ("Results table, filled from the default `python bench.py` line of round 5 (`%s`; one MI355X; CPU legs: the oracle port\n"
                      "and, where the work goes through an FFT, scipy.fft / pocketfft, on the GPU box's host cores in the same run):\n\n" % sys.argv[1]
                      ) + table + "\n" + NOTES if (NOTES := """
 Notes recorded beside the configs:
@@ -50,10 +51,12 @@ Notes recorded beside the configs:
   `MIN_SIG` = 16 (`gps/gps.h:60`), which is sized for 41 × 4092 trials per SV: 256 × 4092 (E1B: 16368) lags are 1.0 M
   (4.2 M) trials whose noise maximum alone reaches 14 … 19.
 * configs[3]'s line is ONE GPU's share (128 of the 1024 receivers, `--receivers 128`); `bench.py --gpus 8 --workload
-  receivers` runs the eight shares, one rank per GPU, no data-path collective.  Since round 4 the waterfall side of a
-  receiver takes its frame the way the reference's non-overlapped `sample_wf()` does -- `CmdWFReset` + the one-shot sampler,
-  `kg_ddc_wf_capture_dev` -- and so does the CPU baseline (1.75 ms per step and 1 584 Msamples/s on all cores in round 3,
-  with the continuous sampler over the whole block on both sides).
+  receivers` runs the eight shares, one rank per GPU, no data-path collective.  Since round 5 the receivers are SURVEY.md
+  8(d)'s -- receiver k at 100 kHz + k 29 kHz, zoom 8 + (k mod 4) -- stepped by ONE C-ABI call (`kg_rxbank_step`): zooms
+  8..10 take the reference's non-overlapped frame (`CmdWFReset` + one-shot sampler), zoom 11 its overlapped / continuous
+  sampler (`rx/rx_waterfall.cpp:962-1041`), and so does the CPU baseline.  Rounds 2-4 ran a lighter set (zoom 1 + k mod 10,
+  a quarter of the waterfall DDC work): kept as `receivers_light`; neither is comparable with round 3's figure (continuous
+  sampler over the whole block for every receiver).
 * configs[2] DDC / end to end: since round 4 the steps walk nine distinct 32 MiB ADC blocks (past the Infinity Cache).
 * `value` is the HBM-resident rate; the PCIe-inclusive rate of configs[1] is `ingest_pcie_Msps` in the same line.
 """) else ""
