@@ -1577,6 +1577,18 @@ def run_receivers(args, dist, wl="receivers"):
     assert info.nframes == NR and int(rows.max()) > 100 and int(np.abs(pay.astype(np.int32)).sum()) > 0
     frames_per_step = info.nframes
     bank.close()
+    if os.environ.get("KIWIGPU_BENCH_RX_REPEAT"):    # a diagnostic: is the step time a property of the bank INSTANCE (its streams)?
+        for rep in range(int(os.environ["KIWIGPU_BENCH_RX_REPEAT"])):
+            bk = make_bank()
+            for _ in range(12):
+                bk.step_fast(d_adc)
+            bk.sync()
+            t1 = time.perf_counter()
+            for _ in range(30):
+                bk.step_fast(d_adc)
+            bk.sync()
+            log("%s: bank instance %d: %.4f ms per step" % (wl, rep, (time.perf_counter() - t1) / 30 * 1e3))
+            bk.close()
     # Integer work per ADC sample and receiver, counted on the algorithm: the waterfall DDC's 36 (run_ddc14; R = 1 bypass
     # channels: the NCO / mixer's 10) + the audio DDC's NCO / mixer (10) and rx1's three integrators on I and Q (55, 55 and
     # 26 bits: 2 + 2 + 1 words, x 2 = 10); everything behind the first decimation runs at <= 1 / 1543 of the rate.  A one-shot
@@ -1787,7 +1799,10 @@ def cpu_legs(args):
 
     def log2n_for(wl):
         return args.log2n if args.log2n_given else (22 if wl in RX_MIX else 24)
+    skip_legs = os.environ.get("KIWIGPU_BENCH_SKIP_LEGS", "").split(",")       # a diagnostic
     for wl in wls:
+        if wl in skip_legs:
+            continue
         if wl == "acq":
             codes = [(prn.cacode(sats.SATS[s][1], sats.SATS[s][2]), False) for s in range(NSV)]
             CPU_LEGS[wl] = cpu_acq(synth.config1_iq16(seed=0x5EED0002), codes, NSAMPLES, FFT_LEN, -20, 20, T)
@@ -1923,9 +1938,13 @@ def main():
     if single and not args.no_live_traffic and not args.pmc_child and args.workload != "stub":
         live_traffic_passes(args)                            # children; this process has not touched the GPU yet
     if not args.no_cpu and not args.pmc_child and args.workload != "stub" and (world_env is None or int(world_env) == 1):
-        native_oracle()                                      # before anything loads the oracle
-        cpu_legs(args)                                       # forked workers: before this process touches the GPU
-        pocketfft_legs(args)
+        skip = os.environ.get("KIWIGPU_BENCH_SKIP", "").split(",")          # a diagnostic: leave parts of the CPU side out
+        if "native" not in skip:
+            native_oracle()                                  # before anything loads the oracle
+        if "cpu" not in skip:
+            cpu_legs(args)                                   # forked workers: before this process touches the GPU
+        if "pocketfft" not in skip:
+            pocketfft_legs(args)
         log("pocketfft legs done: %s" % {k: v.get("value") for k, v in POCKETFFT.items()})
     dist = Dist("gloo" if args.workload == "stub" else "nccl")
     common = {"n_gpus": dist.world, "steps": args.steps, "warmup": args.warmup, "preroll_s": PREROLL_S, "higher_is_better": True,

@@ -24,6 +24,7 @@
 #include <chrono>
 #include <math.h>
 #include <stdlib.h>
+#include <mutex>
 #include <vector>
 
 #define BANK_SLOTS 8                       // step-table slots in flight (a slot is reused BANK_SLOTS steps later)
@@ -90,6 +91,15 @@ struct bank_tick {
         t = n;
     }
 };
+
+// The streams of closed banks are kept for the next one (per device, never destroyed).  Which hardware queue a NEW stream lands
+// on is the HIP runtime's choice at that moment, and a process that had created and destroyed a few banks got streams whose
+// kernels took turns instead of running side by side: every later bank of the default bench run stepped in 1.37 ... 1.50 ms
+// where the first one took 1.24 (and the same bank 0.98 alone).  A bank that inherits the streams of the first keeps its
+// placement.
+struct bank_stream_set { int device; hipStream_t s[5]; };
+static std::vector<bank_stream_set> g_free_sets;
+static std::mutex g_free_mutex;
 
 static void bank_set_arena(kg_rxbank *b, int mode)
 {
@@ -248,7 +258,12 @@ void kg_rxbank_destroy(kg_rxbank *b)
     (void) hipFree(b->d_slots);
     for (int i = 0; i < BANK_SLOTS; i++) for (int j = 0; j < 3; j++) if (b->ev_end[i][j]) (void) hipEventDestroy(b->ev_end[i][j]);
     for (hipEvent_t e : {b->ev_tab, b->ev_fir, b->ev_tail, b->ev_frames, b->ev_pk}) if (e) (void) hipEventDestroy(e);
-    for (hipStream_t s : {b->s_main, b->s_side, b->s_tail, b->s_ddc2, b->s_up}) if (s) (void) hipStreamDestroy(s);
+    if (b->s_main && b->s_side && b->s_tail && b->s_ddc2 && b->s_up) {          // a complete set: kept for the next bank
+        std::lock_guard<std::mutex> lk(g_free_mutex);
+        g_free_sets.push_back(bank_stream_set{b->device, {b->s_main, b->s_side, b->s_tail, b->s_ddc2, b->s_up}});
+    } else {
+        for (hipStream_t s : {b->s_main, b->s_side, b->s_tail, b->s_ddc2, b->s_up}) if (s) (void) hipStreamDestroy(s);
+    }
     delete b;
 }
 
@@ -292,11 +307,25 @@ int kg_rxbank_create(int device, int nrx, size_t adc_samples_per_step, int rx_mo
             return KG_ERR_NO_DEVICE;
         }
     }
+    bool reused = false;
+    {
+        std::lock_guard<std::mutex> lk(g_free_mutex);
+        for (size_t i = 0; i < g_free_sets.size(); i++)
+            if (g_free_sets[i].device == device) {
+                const bank_stream_set st = g_free_sets[i];
+                g_free_sets.erase(g_free_sets.begin() + (long) i);
+                b->s_main = st.s[0]; b->s_side = st.s[1]; b->s_tail = st.s[2]; b->s_ddc2 = st.s[3]; b->s_up = st.s[4];
+                reused = true;
+                break;
+            }
+    }
+    if (!reused) {
     BANK_HIP(hipStreamCreateWithFlags(&b->s_main, hipStreamNonBlocking));
     BANK_HIP(hipStreamCreateWithFlags(&b->s_side, hipStreamNonBlocking));
     BANK_HIP(hipStreamCreateWithFlags(&b->s_tail, hipStreamNonBlocking));
     BANK_HIP(hipStreamCreateWithFlags(&b->s_ddc2, hipStreamNonBlocking));
     BANK_HIP(hipStreamCreateWithFlags(&b->s_up, hipStreamNonBlocking));
+    }
     BANK_TRY(kg_ctx_create_on_stream(device, b->s_main, &b->c_main));
     BANK_TRY(kg_ctx_create_on_stream(device, b->s_side, &b->c_side));
     BANK_TRY(kg_ctx_create_on_stream(device, b->s_tail, &b->c_tail));
