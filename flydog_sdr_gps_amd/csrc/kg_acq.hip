@@ -1378,7 +1378,7 @@ static int acq_init(kg_acq *a)
     }
     KG_HIP(hipEventCreateWithFlags(&a->ev_batch, hipEventDisableTiming));
     KG_HIP(hipEventCreateWithFlags(&a->ev_in_free, hipEventDisableTiming));
-    KG_HIP(hipStreamCreateWithFlags(&a->cstream, hipStreamNonBlocking));
+    { const int rc_ = kg_stream_get(ctx->device, &a->cstream); if (rc_) return rc_; }
     KG_HIP(hipMalloc((void **) &a->d_chips, 8192));
     KG_HIP(hipMalloc((void **) &a->d_cells, sizeof(kg_acq_cell) * (size_t) max_blocks * max_sats * a->ndop));
     KG_HIP(hipMalloc((void **) &a->d_results, sizeof(kg_acq_result) * (size_t) max_blocks * max_sats));
@@ -1393,7 +1393,7 @@ static int acq_init(kg_acq *a)
         // 528 us in order; profiles/r01_streams.txt), so the overlap is opt-in.
         const char *e = kg_tuning_env("KIWIGPU_ACQ_FRONT_STREAM");
         if (e && e[0] == '1') {
-            KG_HIP(hipStreamCreateWithFlags(&a->fstream, hipStreamNonBlocking));
+            { const int rc_ = kg_stream_get(ctx->device, &a->fstream); if (rc_) return rc_; }
             a->own_fstream = true;
         }
     }
@@ -1490,7 +1490,7 @@ void kg_acq_destroy(kg_acq *a)
     (void) hipStreamSynchronize(a->ctx->stream);
     for (size_t b = 0; b < a->ev_ready.size(); b++) (void) hipEventDestroy(a->ev_ready[b]);
     for (size_t b = 0; b < a->ev_done.size(); b++) (void) hipEventDestroy(a->ev_done[b]);
-    if (a->own_fstream) (void) hipStreamDestroy(a->fstream);
+    if (a->own_fstream) kg_stream_put(a->ctx->device, a->fstream);
     if (a->own_tabN) (void) hipFree(a->d_tabN);
     (void) hipFree(a->d_comb); (void) hipFree(a->d_quart); (void) hipFree(a->d_comb8);   // hipFree(nullptr) is a no-op
     (void) hipFree(a->d_code); (void) hipFree(a->d_data); (void) hipFree(a->d_data_b); (void) hipFree(a->d_td);
@@ -1504,7 +1504,7 @@ void kg_acq_destroy(kg_acq *a)
     if (a->h_batch) (void) hipHostFree(a->h_batch);
     if (a->ev_batch) (void) hipEventDestroy(a->ev_batch);
     if (a->ev_in_free) (void) hipEventDestroy(a->ev_in_free);
-    if (a->cstream) { (void) hipStreamSynchronize(a->cstream); (void) hipStreamDestroy(a->cstream); }
+    if (a->cstream) { (void) hipStreamSynchronize(a->cstream); kg_stream_put(a->ctx->device, a->cstream); }
     (void) hipFree(a->d_cells); (void) hipFree(a->d_results); (void) hipFree(a->d_claim);
     delete a;
 }

@@ -36,7 +36,7 @@ void kg_set_error(const char *fmt, ...);
 // REPLAY pass -- the same calls with the same arguments, after the block's one upload was enqueued -- they answer the same
 // addresses again, checking that the table is the one planned.
 enum { KG_ARENA_OFF = 0, KG_ARENA_PLAN = 1, KG_ARENA_REPLAY = 2 };
-#define KG_ARENA_MAX_ENTRIES 32
+#define KG_ARENA_MAX_ENTRIES 96      /* 9 tables per step + 2 per sound block of the step */
 struct kg_arena {
     int mode;
     unsigned char *h_base, *d_base;           // the current slot of the owner's ring (pinned host / device)
@@ -127,3 +127,10 @@ extern "C" __attribute__((visibility("hidden"))) void kg_nco_table_build(short *
 // kg_ddc.hip, for kg_rxbank.hip (not part of the ABI): the DDC's second stream supplied by the owner.
 struct kg_ddc;
 __attribute__((visibility("hidden"))) int kg_ddc_use_side_stream(kg_ddc *ddc, hipStream_t stream);
+
+// The library's own streams come from a per-device pool and go back to it; they are never destroyed.  Which hardware queue a
+// NEW stream lands on is the runtime's choice at that moment, and streams created after others had been destroyed were seen
+// to get queues on which kernels take turns with other streams' instead of running beside them: an object
+// that inherits a stream inherits its placement.  Synchronise a stream before giving it back.
+int kg_stream_get(int device, hipStream_t *out);          // the device is current (kg_ctx_use) when this is called
+void kg_stream_put(int device, hipStream_t s);

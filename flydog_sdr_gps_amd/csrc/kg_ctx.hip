@@ -120,6 +120,32 @@ void kg_stage_cache_free(kg_stage_cache *sc)
     sc->dev = nullptr; sc->host = nullptr; sc->cap = sc->bytes = 0;
 }
 
+#include <mutex>
+static std::mutex g_stream_mutex;
+static std::vector<std::pair<int, hipStream_t>> g_stream_pool;
+
+int kg_stream_get(int device, hipStream_t *out)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_stream_mutex);
+        for (size_t i = 0; i < g_stream_pool.size(); i++)
+            if (g_stream_pool[i].first == device) {
+                *out = g_stream_pool[i].second;
+                g_stream_pool.erase(g_stream_pool.begin() + (long) i);
+                return KG_OK;
+            }
+    }
+    KG_HIP(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    return KG_OK;
+}
+
+void kg_stream_put(int device, hipStream_t s)
+{
+    if (!s) return;
+    std::lock_guard<std::mutex> lk(g_stream_mutex);
+    g_stream_pool.push_back(std::make_pair(device, s));
+}
+
 __global__ void kg_mark_kernel() {}
 
 // The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order; streams
@@ -222,7 +248,7 @@ static int ctx_create(int device, void *stream, bool use_given, kg_ctx **out)
         c->stream = (hipStream_t) stream;
         c->own_stream = false;
     } else {
-        KG_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        { const int rc_ = kg_stream_get(device, &c->stream); if (rc_) { free(c); return rc_; } }
         c->own_stream = true;
     }
     KG_HIP(hipEventCreate(&c->ev_start));
@@ -260,7 +286,7 @@ void kg_ctx_destroy(kg_ctx *c)
     }
     (void) hipEventDestroy(c->ev_start);
     (void) hipEventDestroy(c->ev_stop);
-    if (c->own_stream) (void) hipStreamDestroy(c->stream);
+    if (c->own_stream) kg_stream_put(c->device, c->stream);
     free(c);
 }
 

@@ -1492,11 +1492,11 @@ void kg_ddc_destroy(kg_ddc *d)
     (void) hipFree(d->d_aggs); (void) hipFree(d->d_ticket); (void) hipFree(d->d_endco);
     for (int p = 0; p < 2; p++) { (void) hipFree(d->d_wgtot[p]); (void) hipFree(d->d_wgbase[p]); (void) hipFree(d->d_wgtau[p]); }
     kg_stage_cache_free(&d->pack_cache);
-    if (d->side) { (void) hipEventDestroy(d->ev_fork); (void) hipEventDestroy(d->ev_join); if (!d->side_borrowed) (void) hipStreamDestroy(d->side); }
+    if (d->side) { (void) hipEventDestroy(d->ev_fork); (void) hipEventDestroy(d->ev_join); if (!d->side_borrowed) kg_stream_put(d->ctx->device, d->side); }
     if (d->tail) {
         (void) hipEventDestroy(d->ev_runs); (void) hipEventDestroy(d->ev_tail[0]); (void) hipEventDestroy(d->ev_tail[1]);
         (void) hipEventDestroy(d->ev_adc);
-        (void) hipStreamDestroy(d->tail);
+        kg_stream_put(d->ctx->device, d->tail);
     }
     delete d;
 }
@@ -1621,7 +1621,7 @@ int kg_ddc_wf_set_deferred(kg_ddc *d, int on)
     if (rc) return rc;
     if ((rc = ddc_sync_all(d))) return rc;
     if (on && !d->tail) {
-        KG_HIP(hipStreamCreateWithFlags(&d->tail, hipStreamNonBlocking));
+        if ((rc = kg_stream_get(d->ctx->device, &d->tail))) return rc;
         KG_HIP(hipEventCreateWithFlags(&d->ev_runs, hipEventDisableTiming));
         KG_HIP(hipEventCreateWithFlags(&d->ev_tail[0], hipEventDisableTiming));
         KG_HIP(hipEventCreateWithFlags(&d->ev_tail[1], hipEventDisableTiming));
@@ -1831,7 +1831,7 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
     if (const char *e = kg_tuning_env("KIWIGPU_DDC_SIDE")) side_on = atoi(e) != 0;
     auto side_ready = [&]() -> int {
         if (!d->side) {
-            KG_HIP(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
+            { const int rc_ = kg_stream_get(d->ctx->device, &d->side); if (rc_) return rc_; }
             KG_HIP(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
             KG_HIP(hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming));
         }
