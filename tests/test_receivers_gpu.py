@@ -211,3 +211,24 @@ def test_overlapped_mode_at_its_edges(oracle):
         bank.ctx.free(d_adc)
     finally:
         bank.close()
+
+
+def test_long_steps_carry_several_sound_blocks(oracle):
+    """A step of 2^24 ADC samples is 1610 rx_iq_t records per receiver: three (then four) 512-sample CFastFIR blocks -- and as
+    many S-meter / CAgc / ADPCM calls -- inside ONE kg_rxbank_step; R = 4096 is the overlapped sampler there (4096 outputs a
+    step), R = 256 ... 2048 one-shot.  Two steps over two different blocks."""
+    from flydog_sdr_gps_amd import synth
+    from tests.rxbank_check import check_bank
+    n, steps = 1 << 24, 2
+    mix = _small_mix([9, 11, 12, 13], n)
+    assert [ov for _, ov, _ in mix] == [False, False, False, True]
+    adc = synth.adc_stream(n * steps, 0x5EED004A)
+    bank = _bank(len(mix), n, mix)
+    try:
+        d_adc = bank.ctx.alloc(adc.nbytes)
+        bank.ctx.upload(d_adc, adc)
+        got = check_bank(bank, lambda k: adc[k * n:(k + 1) * n], lambda k: d_adc + 2 * k * n, range(len(mix)), steps)
+        assert got["audio_blocks"] == len(mix) * (2 * n // 10416 // 512) and got["frames"] == 3 * steps + 1, got
+        bank.ctx.free(d_adc)
+    finally:
+        bank.close()

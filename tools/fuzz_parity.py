@@ -289,7 +289,56 @@ def trial_wf():
         check_row(out[k], w_out, w_dB, db_bound(w_po))
 
 
-for name, fn in (("acq", trial_acq), ("wf ddc", trial_wfddc), ("rx ddc", trial_rxddc), ("fastfir", trial_fir), ("post", trial_post), ("wire", trial_wire), ("wf frames", trial_wf)):
+def trial_rxbank():
+    """A receiver bank (kg_rxbank): random receiver count, step length, zooms, sampler modes (wherever both are allowed a coin
+    decides), audio NCOs, a handful of steps over a random stream with retunes in between; every stage of every receiver
+    against the oracle (tests/rxbank_check.py)."""
+    from flydog_sdr_gps_amd.ddc import rx_phase_inc
+    from flydog_sdr_gps_amd.rxbank import ADC_CLOCK, UI_SRATE, RxBank
+    from flydog_sdr_gps_amd.wf import WfParams
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tests.rxbank_check import check_bank
+    log2n = int(rng.integers(15, 19))
+    n = 1 << log2n
+    nrx = int(rng.integers(1, 9))
+    steps = int(rng.integers(2, 12))
+    hz = UI_SRATE / (1024 << 14)
+
+    def receiver():
+        zoom = int(rng.integers(1, 15))
+        decim = 1 << max(zoom - 1, 0)
+        span = UI_SRATE / (1 << zoom)
+        # (a span that holds the stream's strong carrier: the rows' tolerance is relative to the largest bin)
+        p = WfParams.for_zoom(zoom, max(0.0123 * ADC_CLOCK - span * rng.uniform(0.1, 0.6), 0.0) / hz, adc_clock=ADC_CLOCK, ui_srate=UI_SRATE)
+        can_shot, can_ov = 8192 * decim <= n, n // decim <= 8192 and n // decim >= 1
+        ov = bool(rng.integers(0, 2)) if (can_shot and can_ov) else can_ov
+        return p, ov, rx_phase_inc(0.0123 * ADC_CLOCK - rng.uniform(400.0, 2500.0), ADC_CLOCK)
+    mix = [receiver() for _ in range(nrx)]
+    events = {}
+    for st in range(1, steps):
+        if rng.random() < 0.3:
+            rx = int(rng.integers(0, nrx))
+            p, ov, inc = receiver()
+            events[st] = [("wf", rx, p, ov)] if rng.random() < 0.6 else [("freq", rx, inc)]
+    t = np.arange(n * steps)
+    x = rng.normal(0, 10.0, n * steps) + 3000.0 * np.cos(2 * np.pi * 0.0123 * t) + rng.uniform(0, 2000) * np.cos(2 * np.pi * rng.uniform(0, 0.5) * t)
+    adc = np.clip(np.rint(x), -32768, 32767).astype(np.int16)
+    bank = RxBank(nrx, n)
+    try:
+        bank.configure(mix)
+        d_adc = bank.ctx.alloc(adc.nbytes)
+        bank.ctx.upload(d_adc, adc)
+        try:
+            check_bank(bank, lambda k: adc[k * n:(k + 1) * n], lambda k: d_adc + 2 * k * n, range(nrx), steps, threads=4, events=events)
+        except AssertionError as e:
+            raise AssertionError("n 2^%d, %d receivers %s, %d steps, events %s: %s" % (
+                log2n, nrx, [(p.zoom, ov) for p, ov, _ in mix], steps, {k: [(e_[0], e_[1]) for e_ in v] for k, v in events.items()}, e))
+        bank.ctx.free(d_adc)
+    finally:
+        bank.close()
+
+
+for name, fn in (("rxbank", trial_rxbank), ("acq", trial_acq), ("wf ddc", trial_wfddc), ("rx ddc", trial_rxddc), ("fastfir", trial_fir), ("post", trial_post), ("wire", trial_wire), ("wf frames", trial_wf)):
     soak(name, fn)
 print("failures:", fails)
 if _acq:
