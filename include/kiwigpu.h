@@ -639,7 +639,9 @@ typedef struct {
 } kg_rxbank_step_info;
 /* One step: n = adc_samples_per_step samples at d_adc (device) through every receiver.  Enqueue only (the host returns
  * after some thirty launches; kg_rxbank_poll / _sync say when the work is done).  adc_ready_event: a hipEvent_t recorded
- * behind the writer of d_adc, or NULL.  info may be NULL. */
+ * behind the writer of d_adc, or NULL.  info may be NULL.  A negative return from the PLAN half of the call (bad state, a
+ * receiver without a waterfall setting) leaves the bank as it was; an error of the HIP runtime while the step is being
+ * enqueued leaves it half-advanced: destroy the bank.  One host thread per bank. */
 int kg_rxbank_step(kg_rxbank *bank, const void *d_adc, void *adc_ready_event, kg_rxbank_step_info *info);
 /* `stream` (hipStream_t) waits until the last step's readers of its ADC block are done: order the writer of a
  * double-buffered ADC ring behind this. */
