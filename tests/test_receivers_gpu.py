@@ -232,3 +232,61 @@ def test_long_steps_carry_several_sound_blocks(oracle):
         bank.ctx.free(d_adc)
     finally:
         bank.close()
+
+
+def test_double_buffered_adc_ring_without_host_synchronisation(oracle):
+    """The streaming shape INTEGRATION.md 5a describes: TWO device buffers refilled in turn on the caller's own stream, no
+    host synchronisation between steps -- `adc_ready_event` orders a step behind the writer of its block, kg_rxbank_adc_done
+    orders the writer of a buffer behind the step that last read it.  Ten steps enqueued back to back; a missing edge in
+    either direction would let block k + 2 overwrite block k while step k is still running: 64 receivers and 2^22 samples make
+    a step 0.7 ms of GPU work against 0.1 ms of host time, so the host IS steps ahead (with kg_rxbank_adc_done made a no-op
+    the comparison below fails).  The audio DDC's records of the LAST step (state carried through all six blocks) and the
+    last step's frames of four of the receivers must equal the oracle's over the same stream."""
+    import torch
+    from flydog_sdr_gps_amd import synth
+    n, steps = 1 << 22, 6
+    mix = _small_mix([8 + k % 4 for k in range(64)], n)       # zooms 8 .. 10: one-shot; zoom 11: overlapped (4096 a step)
+    check = [0, 1, 2, 3]
+    adc = synth.adc_stream(n * steps, 0x5EED004B)
+    host = torch.from_numpy(adc).pin_memory()
+    dev = torch.device("cuda", 0)
+    bank = _bank(len(mix), n, mix)
+    try:
+        bufs = [torch.zeros(n, dtype=torch.int16, device=dev) for _ in range(2)]
+        up = torch.cuda.Stream(device=dev)
+        evs = [torch.cuda.Event() for _ in range(steps)]
+        torch.cuda.synchronize(dev)
+        infos = []
+        for k in range(steps):
+            with torch.cuda.stream(up):
+                bank.adc_done(up.cuda_stream)                # the step that read bufs[k % 2] two steps ago is behind us
+                bufs[k % 2].copy_(host[k * n:(k + 1) * n], non_blocking=True)
+                evs[k].record(up)
+            infos.append(bank.step(bufs[k % 2].data_ptr(), adc_ready_event=evs[k].cuda_event))
+        bank.sync()
+        torch.cuda.synchronize(dev)
+        # the oracle over the whole stream
+        nrec_last = infos[-1].nrec
+        raw = bank.fetch("raw", check)
+        rx_of, f_off, _ = bank.frame_map()
+        wf_iq = bank.fetch("wf_iq", check)
+        stride = bank.bufs.wf_iq_stride
+        for rx in check:
+            p, ov, inc = mix[rx]
+            st = None
+            for k in range(steps):
+                rec, st = oracle.ddc_rx(adc[k * n:(k + 1) * n], inc, st)
+            assert rec.size == 6 * nrec_last and np.array_equal(raw[rx, :rec.size], rec), ("audio records of the last step", rx)
+            l2 = int(np.log2(p.decim))
+            if ov:
+                iq, _ = oracle.ddc_wf(adc, p.i_offset, l2)
+                want = iq[-8192:]
+            else:
+                s0 = oracle.DdcWfState()
+                s0.phase = ((steps - 1) * n * p.i_offset) & ((1 << 48) - 1)
+                want, _ = oracle.ddc_wf(adc[(steps - 1) * n:(steps - 1) * n + 8192 * p.decim], p.i_offset, l2, s0)
+            f = list(rx_of).index(rx)
+            off = int(f_off[f]) - rx * stride
+            assert np.array_equal(wf_iq[rx, off:off + 8192], want), ("frame of the last step", rx)
+    finally:
+        bank.close()
