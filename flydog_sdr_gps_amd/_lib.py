@@ -165,7 +165,7 @@ SYMBOLS = {
     "kg_rxbank_set_wf_pkt": (_i, [_vp, _i, C.c_uint32, C.c_uint32, _i]),
     "kg_rxbank_set_unpack": (_i, [_vp, C.c_float, C.c_float, C.c_float, _i]),
     "kg_rxbank_step": (_i, [_vp, _vp, _vp, _vp]),
-    "kg_rxbank_adc_done": (_i, [_vp, _vp]),
+    "kg_rxbank_adc_done": (_i, [_vp, _vp, _i]),
     "kg_rxbank_poll": (_i, [_vp]),
     "kg_rxbank_sync": (_i, [_vp]),
     "kg_rxbank_frame_map": (_i, [_vp, _vp, _vp, _vp]),

@@ -27,7 +27,7 @@
 #include <mutex>
 #include <vector>
 
-#define BANK_SLOTS 8                       // step-table slots in flight (a slot is reused BANK_SLOTS steps later)
+#define BANK_SLOTS KG_RXBANK_SLOTS         // step-table slots in flight (a slot is reused BANK_SLOTS steps later)
 #define BANK_RING_PAIRS (8 * KG_WF_NFFT)   // an overlapped receiver's sample ring (iq_t pairs); >= 2 frames
 #define BANK_PKT_STRIDE 1056               // >= KG_WF_PKT_MAX, a multiple of 16
 
@@ -475,13 +475,15 @@ int kg_rxbank_step(kg_rxbank *b, const void *d_adc, void *adc_ready_event, kg_rx
     return KG_OK;
 }
 
-// `stream` waits until the last step's readers of its ADC block are done (both DDCs): the caller's writer of a
-// double-buffered ADC ring goes behind this.
-int kg_rxbank_adc_done(kg_rxbank *b, void *stream)
+// `stream` waits until the readers (both DDCs) of the ADC block of the step `steps_back` steps ago are done -- 1: the last
+// step, 2: the one before it (the buffer a double-buffered ADC ring is about to refill), ... up to BANK_SLOTS.  The caller's
+// writer of that buffer goes behind this.
+int kg_rxbank_adc_done(kg_rxbank *b, void *stream, int steps_back)
 {
     KG_REQUIRE(b && stream, KG_ERR_INVALID, "kg_rxbank_adc_done: null argument");
-    if (b->step == 0) return KG_OK;
-    const int slot = (int) ((b->step - 1) % BANK_SLOTS);
+    KG_REQUIRE(steps_back >= 1 && steps_back <= BANK_SLOTS, KG_ERR_INVALID, "kg_rxbank_adc_done: steps_back %d (1..%d)", steps_back, BANK_SLOTS);
+    if (b->step < (uint64_t) steps_back) return KG_OK;      // no such step yet: nothing has read the buffer
+    const int slot = (int) ((b->step - (uint64_t) steps_back) % BANK_SLOTS);
     KG_HIP(hipStreamWaitEvent((hipStream_t) stream, b->ev_end[slot][0], 0));
     KG_HIP(hipStreamWaitEvent((hipStream_t) stream, b->ev_end[slot][1], 0));
     return KG_OK;

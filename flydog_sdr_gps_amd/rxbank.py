@@ -158,8 +158,10 @@ class RxBank:
     def poll(self):
         return check(self.lib.kg_rxbank_poll(self.h), "kg_rxbank_poll") == 1
 
-    def adc_done(self, stream):
-        check(self.lib.kg_rxbank_adc_done(self.h, C.c_void_p(int(stream))), "kg_rxbank_adc_done")
+    def adc_done(self, stream, steps_back=1):
+        """`stream` waits for the readers of the ADC block of the step `steps_back` steps ago (2: the buffer a double-buffered
+        ring refills next)."""
+        check(self.lib.kg_rxbank_adc_done(self.h, C.c_void_p(int(stream)), int(steps_back)), "kg_rxbank_adc_done")
 
     def host_profile(self):
         """Where the host's share of the steps since the last call went (text; kg_rxbank_host_profile)."""

@@ -643,9 +643,16 @@ typedef struct {
  * receiver without a waterfall setting) leaves the bank as it was; an error of the HIP runtime while the step is being
  * enqueued leaves it half-advanced: destroy the bank.  One host thread per bank. */
 int kg_rxbank_step(kg_rxbank *bank, const void *d_adc, void *adc_ready_event, kg_rxbank_step_info *info);
-/* `stream` (hipStream_t) waits until the last step's readers of its ADC block are done: order the writer of a
- * double-buffered ADC ring behind this. */
-int kg_rxbank_adc_done(kg_rxbank *bank, void *stream);
+/* The host runs at most KG_RXBANK_SLOTS steps ahead of the GPU: kg_rxbank_step(k) returns only when step k - 8 has
+ * completed on the device.  An ADC ring of KG_RXBANK_SLOTS + 1 buffers therefore needs NO device-side ordering of its writer:
+ * when step k has been enqueued, the buffer step k + 1 will use was last read by step k - 8, which is done (measured: the
+ * resident step time with every block copied from pinned host memory, 1.25 ms).  A shorter ring orders its writer with
+ * kg_rxbank_adc_done: `stream` (hipStream_t) waits until the readers of the ADC block of the step `steps_back` steps ago are
+ * done (1: the last step; 2: the one before it = the buffer a double-buffered ring refills next; at most 8) -- correct, but a
+ * wait enqueued on a stream that shares a hardware queue with one of the bank's holds that queue until the old step has
+ * completed (measured with two buffers: 1.47 ms per step instead of 1.25). */
+#define KG_RXBANK_SLOTS 8
+int kg_rxbank_adc_done(kg_rxbank *bank, void *stream, int steps_back);
 int kg_rxbank_poll(kg_rxbank *bank);          /* 1 = all streams idle, 0 = busy, <0 error */
 int kg_rxbank_sync(kg_rxbank *bank);
 /* Frame f of the last step belongs to receiver rx_of_frame[f], was read at wf_iq + frame_off[f] pairs, and its packet has

@@ -234,17 +234,19 @@ def test_long_steps_carry_several_sound_blocks(oracle):
         bank.close()
 
 
-def test_double_buffered_adc_ring_without_host_synchronisation(oracle):
-    """The streaming shape INTEGRATION.md 5a describes: TWO device buffers refilled in turn on the caller's own stream, no
-    host synchronisation between steps -- `adc_ready_event` orders a step behind the writer of its block, kg_rxbank_adc_done
-    orders the writer of a buffer behind the step that last read it.  Ten steps enqueued back to back; a missing edge in
+@pytest.mark.parametrize("depth", [2, 9])
+def test_adc_ring_refilled_without_host_synchronisation(oracle, depth):
+    """The streaming shape INTEGRATION.md 5a describes: a ring of device buffers refilled in turn on the caller's own stream,
+    no host synchronisation between steps -- `adc_ready_event` orders a step behind the writer of its block; with TWO buffers
+    kg_rxbank_adc_done orders the writer of a buffer behind the step that last read it, with NINE (KG_RXBANK_SLOTS + 1) the
+    writer needs no ordering at all, because kg_rxbank_step returns only when the step eight before it has completed.  Ten steps enqueued back to back; a missing edge in
     either direction would let block k + 2 overwrite block k while step k is still running: 64 receivers and 2^22 samples make
     a step 0.7 ms of GPU work against 0.1 ms of host time, so the host IS steps ahead (with kg_rxbank_adc_done made a no-op
     the comparison below fails).  The audio DDC's records of the LAST step (state carried through all six blocks) and the
     last step's frames of four of the receivers must equal the oracle's over the same stream."""
     import torch
     from flydog_sdr_gps_amd import synth
-    n, steps = 1 << 22, 6
+    n, steps = 1 << 22, 6 if depth == 2 else 20
     mix = _small_mix([8 + k % 4 for k in range(64)], n)       # zooms 8 .. 10: one-shot; zoom 11: overlapped (4096 a step)
     check = [0, 1, 2, 3]
     adc = synth.adc_stream(n * steps, 0x5EED004B)
@@ -252,17 +254,18 @@ def test_double_buffered_adc_ring_without_host_synchronisation(oracle):
     dev = torch.device("cuda", 0)
     bank = _bank(len(mix), n, mix)
     try:
-        bufs = [torch.zeros(n, dtype=torch.int16, device=dev) for _ in range(2)]
+        bufs = [torch.zeros(n, dtype=torch.int16, device=dev) for _ in range(depth)]
         up = torch.cuda.Stream(device=dev)
         evs = [torch.cuda.Event() for _ in range(steps)]
         torch.cuda.synchronize(dev)
         infos = []
         for k in range(steps):
             with torch.cuda.stream(up):
-                bank.adc_done(up.cuda_stream)                # the step that read bufs[k % 2] two steps ago is behind us
-                bufs[k % 2].copy_(host[k * n:(k + 1) * n], non_blocking=True)
+                if depth == 2:
+                    bank.adc_done(up.cuda_stream, 2)         # the step that read bufs[k % 2], two steps ago, is behind us
+                bufs[k % depth].copy_(host[k * n:(k + 1) * n], non_blocking=True)
                 evs[k].record(up)
-            infos.append(bank.step(bufs[k % 2].data_ptr(), adc_ready_event=evs[k].cuda_event))
+            infos.append(bank.step(bufs[k % depth].data_ptr(), adc_ready_event=evs[k].cuda_event))
         bank.sync()
         torch.cuda.synchronize(dev)
         # the oracle over the whole stream
