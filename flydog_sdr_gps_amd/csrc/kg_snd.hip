@@ -85,7 +85,7 @@ KG_DEV void fir_fft1024(cf (&x)[16], float2 *tile, const fir_tw &tw, int t)
     cf y[16];
     kg_radix16<SIGN>(x, y);                                            // pass 0: out 16 t + m
 #pragma unroll
-    for (int m = 0; m < 16; m++) kg_st(&tile[16 * t + (m ^ tl)], y[m]);
+    for (int m = 0; m < 16; m++) kg_st_tile(&tile[16 * t + (m ^ tl)], y[m]);
     wave_lds_fence();
 #pragma unroll
     for (int j = 0; j < 16; j++) {                                     // pass 1 in: t + 64 j
@@ -97,7 +97,7 @@ KG_DEV void fir_fft1024(cf (&x)[16], float2 *tile, const fir_tw &tw, int t)
     for (int j = 1; j < 16; j++) x[j] = kg_twmul<SIGN>(x[j], tw.p1[j - 1]);
     kg_radix16<SIGN>(x, y);                                            // out (t>>4)*256 + (t&15) + 16 m
 #pragma unroll
-    for (int m = 0; m < 16; m++) kg_st(&tile[th * 256 + 16 * m + (tl ^ m)], y[m]);
+    for (int m = 0; m < 16; m++) kg_st_tile(&tile[th * 256 + 16 * m + (tl ^ m)], y[m]);
     wave_lds_fence();
 #pragma unroll
     for (int u = 0; u < 4; u++) {                                      // pass 2: radix 4, b = t + 64 u
