@@ -764,25 +764,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
 // Combine twiddle W_N^{n k2} = W_N^{i k2} (registers) x W_{N/512}^{m k2}, m = 4a + b: comb8[k2] = { W^{k2},
 // W^{2 k2}, W^{3 k2}, W^{4 k2} } with W = W_{N/512}.
 // ---------------------------------------------------------------------------
-#ifndef KG_E1B_WAVELOCAL
-#define KG_E1B_WAVELOCAL 1
-#endif
-#ifndef KG_E1B_WL_ORDER
-#define KG_E1B_WL_ORDER 3
-#endif
-#ifdef KG_E1B_NOPIN
-#define KG_WLPIN() do {} while (0)
-#else
-#define KG_WLPIN() kg_pin()
-#endif
-#define ACQ8_S1 72       // row strides (float2) of the wave-private tiles of exchanges 1 and 2: every ds_write_b64 / ds_read_b64
-#define ACQ8_S2 65       // conflict-free with base + immediate addressing (tools/proto_fft8w.py)
-#if KG_E1B_WAVELOCAL
-#define ACQ8_TILE_ELEMS (2 * SUB + 64 * ACQ8_S1 + 64 * ACQ8_S2)
-#else
-#define ACQ8_TILE_ELEMS (3 * SUB)
-#endif
-#define ACQ8_LDS_BYTES (ACQ8_TILE_ELEMS * sizeof(float2) + 8 * sizeof(acq_red) + 16 + 16 * 8 * sizeof(float2) + 3 * 512 * 4)   // + the per-k2 constants + the cell-end hand-over
+#define ACQ8_LDS_BYTES (3 * SUB * sizeof(float2) + 8 * sizeof(acq_red) + 16 + 16 * 8 * sizeof(float2) + 3 * 512 * 4)   // + the per-k2 constants + the cell-end hand-over
 
 
 template <int P, bool STAMPS = false>        // STAMPS: diagnostic instantiation only (kg_acq_debug_corr_stamps)
@@ -798,8 +780,7 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
     constexpr int LOGP = P == 4 ? 2 : 4;
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     float2 *tile0 = smem, *tile1 = smem + SUB, *tile2 = smem + 2 * SUB;
-    (void) tile1; (void) tile2;
-    acq_red *red = (acq_red *) (smem + ACQ8_TILE_ELEMS);
+    acq_red *red = (acq_red *) (smem + 3 * SUB);
     volatile int *red_claim = (volatile int *) (red + 8);
     // per-item constants { W^{k2}, W^{2 k2}, W^{3 k2}, W^{4 k2}, W_P^{k2}, W_P^{2 k2}, W_P^{3 k2}, - } (W = W_{N/512}) in LDS,
     // read by broadcast ds_reads: as scalar loads they shared the lgkmcnt counter with the tile reads, which then
@@ -811,13 +792,6 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
     int *xch_i = (int *) (xch_p + 512);
     float *xch_s = (float *) (xch_i + 512);
     const int i = threadIdx.x;
-#if KG_E1B_WAVELOCAL
-    // thread i = 64 T2 + 8 T1 + T0 (T2: the wave).  Its place in the INPUT: elements pi + 512 j; in the OUTPUT: register m holds
-    // the transform at n = ri + 512 m (see the item loop)
-    const int pi = 64 * ((i >> 3) & 7) + 8 * (i >> 6) + (i & 7), ri = ((i >> 3) & 7) + 8 * (i >> 6) + 64 * (i & 7);
-#else
-    const int pi = i, ri = i;
-#endif
     if (i < 8 * P) {
         const int k2 = i >> 3, k = i & 7;
         kg_st(&cst[i], k < 4 ? kg_ld(&comb8[4 * k2 + k]) : (k < 7 ? kg_ld(&quart[4 * k2 + (k - 3)]) : cf{0.f, 0.f}));
@@ -827,10 +801,10 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
     int st_item = 0;
 
     kg_tw4096_r8 tw;
-    kg_tw4096_r8_load(tw, tab4096, ri);
-    cf wb[3], wa[3];                            // W_N^{ri b}, W_N^{4 ri a}: the lane half of the combine twiddle
+    kg_tw4096_r8_load(tw, tab4096, i);
+    cf wb[3], wa[3];                            // W_N^{i b}, W_N^{4 i a}: the lane half of the combine twiddle
 #pragma unroll
-    for (int k = 1; k < 4; k++) { wb[k - 1] = kg_ld(&tabN[ri * k]); wa[k - 1] = kg_ld(&tabN[(4 * ri * k) & (P * SUB - 1)]); }
+    for (int k = 1; k < 4; k++) { wb[k - 1] = kg_ld(&tabN[i * k]); wa[k - 1] = kg_ld(&tabN[(4 * i * k) & (P * SUB - 1)]); }
     (void) wa;
     auto sel3 = [](const cf (&w)[3], int k) { return k == 1 ? w[0] : (k == 2 ? w[1] : w[2]); };
 
@@ -856,7 +830,7 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
             (void *) (data + data_off + k2 * SUB), 0, SUB * (int) sizeof(float2), 0x00020000);
         r.crs = __builtin_amdgcn_make_buffer_rsrc(
             (void *) (code + code_off + (s & (P - 1)) * plane_c), 0, plane_c * (int) sizeof(float2), 0x00020000);
-        r.dvo = pi * 16; r.cvo = (pi + q0 + halo) * 16;
+        r.dvo = i * 16; r.cvo = (i + q0 + halo) * 16;
         return r;
     };
     auto fetch_row = [&](const acq_rsrc &r, int p) {       // row p: legs 2p, 2p + 1 of both spectra
@@ -899,7 +873,6 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
     const int c0 = (i >> 1) & 7, b1 = (i >> 3) & 1;
     const int r0 = i ^ ((i >> 4) & 7), r1 = i ^ (((i >> 6) & 1) << 3);
     const int w1 = (i >> 3) * 64 + (i & 7), w2 = (i >> 6) * 512 + (i & 63);
-    (void) c0; (void) b1; (void) r0; (void) r1; (void) w1; (void) w2;
     auto fetch_item = [&](const acq_cell_desc &cd, int k2) {
         const acq_rsrc r = fetch_prepare(cd.data_off, cd.code_off, cd.dop, k2);
 #pragma unroll
@@ -909,35 +882,6 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
     if (cur_idx >= ncell) return;
     acq_cell_desc cur = describe(cur_idx);
     fetch_item(cur, 0);
-#if KG_E1B_WAVELOCAL
-    // Round 5: the exchanges by DIGIT.  Thread i = 64 T2 + 8 T1 + T0 (T2: the wave) holds the input elements pi + 512 j,
-    // pi = 64 T1 + 8 T2 + T0 (n2 = T1, n1 = T2, n0 = T0: the operand loads of a wave are eight 128-byte pieces per row), and every
-    // exchange swaps the register digit with ONE digit of the thread index: exchange 0 with T1 and exchange 2 with T0 -- inside the
-    // wave: wave-private tiles, LDS in program order, no barrier -- exchange 1 with T2, the only one that crosses waves: the
-    // double-buffered cross tile, ONE workgroup barrier per item (the Stockham form moved every element across waves three times:
-    // two barriers per item even software-pipelined).  Same butterflies and twiddles with ri = T1 + 8 T2 + 64 T0 in i's seat: the
-    // outputs of thread i are n = ri + 512 m (tools/proto_fft8w.py: transform, combine, conflict-freedom of every LDS access).
-    //   interval of item n:  cross[n & 1] -> pass 2 -> tile 2w -> pass 3 -> accumulate
-    //                        | conj-multiply + pass 0 of item n + 1 -> tile 1w -> pass 1 -> cross[(n + 1) & 1]          barrier
-    // two chains of two passes each; a chain's wave-private store -> load round trip stands in the shadow of the other chain.
-    // (the cross tile's halves are addressed as tile0 + an integer: through an array of two pointers the stores lost their
-    // address space and became flat_store)
-    float2 *t1w = smem + 2 * SUB + (i >> 6) * 8 * ACQ8_S1, *t2w = smem + 2 * SUB + 64 * ACQ8_S1 + (i >> 6) * 8 * ACQ8_S2;
-    const int rcw = (i >> 6) * 512 + (i & 63);
-    const int r1w = ((i >> 3) & 7) * ACQ8_S1 + (i & 7), r2w = (i & 7) * ACQ8_S2 + ((i >> 3) & 7) * 8;
-    {   // prologue: passes 0 and 1 of item 0 of the workgroup's first cell, operands of item 1 requested
-        cf x[8], y[8];
-        kg_cc_radix8_h<+1>(c, d, y, [&]() { kg_pin(); fetch_item(cur, 1); kg_pin(); });
-#pragma unroll
-        for (int m = 0; m < 8; m++) kg_st_tile(&t1w[(i & 63) + ACQ8_S1 * m], y[m]);
-#pragma unroll
-        for (int j = 0; j < 8; j++) x[j] = kg_ld_tile(&t1w[r1w + 8 * j]);
-        kg_tw_radix8<+1>(x, y, tw.p1);
-#pragma unroll
-        for (int m = 0; m < 8; m++) kg_st_tile(&tile0[512 * m + i], y[m]);
-        __syncthreads();
-    }
-#else
     {   // prologue: item 0 of the workgroup's first cell up to tile 1 (passes 0 and 1), operands of item 1 requested
         cf x[8], y[8];
         // (round 4: products and twiddles fused into the butterflies, kg_fft.h)
@@ -952,7 +896,6 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
         for (int m = 0; m < 8; m++) kg_st_tile(&tile1[w1 + 8 * (m ^ b1)], y[m]);
         __syncthreads();
     }
-#endif
 #ifndef KG_E1B_HANDOVER
 #define KG_E1B_HANDOVER(P) true
 #endif
@@ -1036,88 +979,6 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
             const acq_rsrc nr = fetch_prepare(k2 + 2 < P ? cur.data_off : nxt.data_off, k2 + 2 < P ? cur.code_off : nxt.code_off,
                                               k2 + 2 < P ? cur.dop : nxt.dop, (k2 + 2) & (P - 1));
             auto ld = [&](int j) { kg_pin(); fetch_row(nr, j); kg_pin(); };
-#if KG_E1B_WAVELOCAL
-            cf x[8], y[8], xb[8], yb[8];
-            {
-                const float2 *tin = tile0 + (k2 & 1) * SUB;
-#pragma unroll
-                for (int j = 0; j < 8; j++) x[j] = kg_ld_tile(&tin[rcw + 64 * j]);
-                KG_STAMP(STAMPS, sti, 1);
-#if KG_E1B_WL_ORDER == 4
-                // order 3 with every pass's eight tile stores handed over one by one from inside its last butterfly stage
-                kg_cc_radix8_he<+1>(c, d, yb, [&]() { ld(0); }, [&](int m) { kg_st_tile(&t1w[(i & 63) + ACQ8_S1 * m], yb[m]); });
-                KG_WLPIN();
-#pragma unroll
-                for (int j = 0; j < 8; j++) xb[j] = kg_ld_tile(&t1w[r1w + 8 * j]);
-                KG_WLPIN();
-                KG_STAMP(STAMPS, sti, 2);
-                kg_tw_radix8_he<+1>(x, y, tw.p2, [&]() { ld(1); }, [&](int m) { kg_st_tile(&t2w[(i & 63) + ACQ8_S2 * m], y[m]); });
-                KG_WLPIN();
-                KG_STAMP(STAMPS, sti, 3);
-#pragma unroll
-                for (int j = 0; j < 8; j++) x[j] = kg_ld_tile(&t2w[r2w + j]);
-                KG_WLPIN();
-                KG_STAMP(STAMPS, sti, 4);
-                {
-                    float2 *tout = tile0 + ((k2 + 1) & 1) * SUB;
-                    kg_tw_radix8_he<+1>(xb, yb, tw.p1, [&]() { ld(2); }, [&](int m) { kg_st_tile(&tout[512 * m + i], yb[m]); });
-                }
-                KG_WLPIN();
-                KG_STAMP(STAMPS, sti, 5);
-#elif KG_E1B_WL_ORDER == 3
-                // every LDS round trip in the shadow of a whole pass of the other chain:
-                //   cross reads | products + pass 0 (n+1) -> t1w | pass 2 -> t2w | pass 1 (n+1) -> cross | pass 3, accumulate
-                kg_cc_radix8_h<+1>(c, d, yb, [&]() { ld(0); });
-                KG_WLPIN();
-#pragma unroll
-                for (int m = 0; m < 8; m++) kg_st_tile(&t1w[(i & 63) + ACQ8_S1 * m], yb[m]);
-#pragma unroll
-                for (int j = 0; j < 8; j++) xb[j] = kg_ld_tile(&t1w[r1w + 8 * j]);
-                KG_WLPIN();
-                KG_STAMP(STAMPS, sti, 2);
-                kg_tw_radix8_h<+1>(x, y, tw.p2, [&]() { ld(1); });
-                KG_WLPIN();
-                KG_STAMP(STAMPS, sti, 3);
-#pragma unroll
-                for (int m = 0; m < 8; m++) kg_st_tile(&t2w[(i & 63) + ACQ8_S2 * m], y[m]);
-#pragma unroll
-                for (int j = 0; j < 8; j++) x[j] = kg_ld_tile(&t2w[r2w + j]);
-                KG_WLPIN();
-                KG_STAMP(STAMPS, sti, 4);
-                {
-                    float2 *tout = tile0 + ((k2 + 1) & 1) * SUB;
-                    kg_tw_radix8_h<+1>(xb, yb, tw.p1, [&]() { ld(2); });
-#pragma unroll
-                    for (int m = 0; m < 8; m++) kg_st_tile(&tout[512 * m + i], yb[m]);
-                }
-                KG_WLPIN();
-                KG_STAMP(STAMPS, sti, 5);
-#else
-                // conj(data) * code (simd_multiply_conjugate_ccc, support/simd.cpp:39-67) fused into pass 0 of the NEXT item; this
-                // item's pass 2 between its products and its butterflies
-                kg_cc_radix8_h<+1>(c, d, yb, [&]() {
-                    KG_STAMP(STAMPS, sti, 2);
-                    ld(0);
-                    kg_tw_radix8_h<+1>(x, y, tw.p2, [&]() { ld(1); });
-                    kg_pin();
-                    KG_STAMP(STAMPS, sti, 3);
-#pragma unroll
-                    for (int m = 0; m < 8; m++) kg_st_tile(&t2w[(i & 63) + ACQ8_S2 * m], y[m]);
-#pragma unroll
-                    for (int j = 0; j < 8; j++) x[j] = kg_ld_tile(&t2w[r2w + j]);
-                    kg_pin();
-                    KG_STAMP(STAMPS, sti, 4);
-                });
-                kg_pin();
-#pragma unroll
-                for (int m = 0; m < 8; m++) kg_st_tile(&t1w[(i & 63) + ACQ8_S1 * m], yb[m]);
-#pragma unroll
-                for (int j = 0; j < 8; j++) xb[j] = kg_ld_tile(&t1w[r1w + 8 * j]);
-                kg_pin();
-                KG_STAMP(STAMPS, sti, 5);
-#endif
-            }
-#else
             // ---- phase A: pass 2 of this item | conj-multiply + pass 0 of the next
             {
                 cf xa[8], ya[8], xb[8], yb[8];
@@ -1154,7 +1015,6 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
                 for (int m = 0; m < 8; m++) kg_st_tile(&tile1[w1 + 8 * (m ^ b1)], yb[m]);
             }
             KG_STAMP(STAMPS, sti, 7);
-#endif
             // this item's constants (broadcast LDS reads, in order with the tile reads)
             cf g[3], G, Q[3];
             (void) Q;
@@ -1165,25 +1025,7 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
 #pragma unroll
                 for (int q = 1; q < 4; q++) Q[q - 1] = kg_ld_tile(&cst[8 * k2 + 3 + q]);
             }
-#if KG_E1B_WAVELOCAL && KG_E1B_WL_ORDER >= 3
-            kg_tw_radix8_h<+1>(x, y, tw.p3, [&]() { ld(3); });       // y[m]: the sub-transform at n = ri + 512 m
-            KG_STAMP(STAMPS, sti, 6);
-            KG_STAMP(STAMPS, sti, 7);
-#elif KG_E1B_WAVELOCAL
-            kg_tw_radix8_h<+1>(x, y, tw.p3, [&]() { ld(2); });       // y[m]: the sub-transform at n = ri + 512 m
-            kg_pin();
-            KG_STAMP(STAMPS, sti, 6);
-            {
-                float2 *tout = tile0 + ((k2 + 1) & 1) * SUB;
-                kg_tw_radix8_h<+1>(xb, yb, tw.p1, [&]() { ld(3); });
-#pragma unroll
-                for (int m = 0; m < 8; m++) kg_st_tile(&tout[512 * m + i], yb[m]);
-            }
-            kg_pin();
-            KG_STAMP(STAMPS, sti, 7);
-#else
             kg_tw_radix8_h<+1>(x, y, tw.p3, [&]() { ld(3); });       // y[m]: the sub-transform at n = i + 512 m
-#endif
             if (k2 == 0) {
 #pragma unroll
                 for (int q = 0; q < 4; q++)
@@ -1262,7 +1104,7 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
                 // the empty asm keeps the compiler from turning 24 wave-uniform tests into per-lane compares and selects)
                 if (r >= 8 && r >= full_rows) {
                     asm volatile("");
-                    pw[r] = (ri + 512 * r < limit) ? pw[r] : 0.f;
+                    pw[r] = (i + 512 * r < limit) ? pw[r] : 0.f;
                 }
             }
         }
@@ -1279,7 +1121,7 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
             for (int q = 0; q < 4; q++)
                 asm("v_cmp_eq_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(qm[q]) : "v"(pw[m + 8 * q]), "v"(bp) : "vcc");
         const unsigned rowmask = (qm[0] | (qm[1] << 8)) | ((qm[2] << 16) | (qm[3] << 24));
-        int bi = ri + 512 * (int) __builtin_ctz(rowmask | 0x80000000u);
+        int bi = i + 512 * (int) __builtin_ctz(rowmask | 0x80000000u);
         KG_STAMP(STAMPS, stc, 1);
         // Round 4: NO wave reduction here.  The three dependent DPP chains (maximum, lowest n among its holders, total) took
         // ~680 cycles in every wave, and at a cell end the waves that lose the issue arbitration (4..7) are the ones the

@@ -838,30 +838,6 @@ template <int SIGN> KG_DEV void kg_radix8_stage2f(cf (&x)[8], cf (&y)[8])
     kg_addsub_sj<SIGN>(y[2], y[6], x[4], x[5]);
     y[3] = s3; y[7] = d3;
 }
-// the same, handing every output over as soon as it exists (emit(m): the caller stores y[m]): the eight LDS stores of a pass
-// leave between the butterfly's last instructions instead of in one burst behind them
-template <int SIGN, class E> KG_DEV void kg_radix8_stage2f_e(cf (&x)[8], cf (&y)[8], E emit)
-{
-    const cf two = cf{2.0f, 2.0f};
-    const cf w1 = cf{KG_W16[2][0], KG_W16[2][1]}, w3 = cf{KG_W16[6][0], KG_W16[6][1]};
-    cf s1, s3, d1, d3;
-    if constexpr (SIGN > 0)
-        asm(KG_CFMA1_("%0", "%6", "%8", "%4") KG_CFMA1_("%1", "%7", "%9", "%5")
-            KG_CFMA2P_("%0", "%6", "%8") KG_CFMA2P_("%1", "%7", "%9")
-            KG_2CMT_("%2", "%4", "%10", "%0") KG_2CMT_("%3", "%5", "%10", "%1")
-            : "=&v"(s1), "=&v"(s3), "=&v"(d1), "=&v"(d3) : "v"(x[2]), "v"(x[6]), "v"(x[3]), "v"(x[7]), "s"(w1), "s"(w3), "s"(two));
-    else
-        asm(KG_CFMA1_("%0", "%6", "%8", "%4") KG_CFMA1_("%1", "%7", "%9", "%5")
-            KG_CFMA2C_("%0", "%6", "%8") KG_CFMA2C_("%1", "%7", "%9")
-            KG_2CMT_("%2", "%4", "%10", "%0") KG_2CMT_("%3", "%5", "%10", "%1")
-            : "=&v"(s1), "=&v"(s3), "=&v"(d1), "=&v"(d3) : "v"(x[2]), "v"(x[6]), "v"(x[3]), "v"(x[7]), "s"(w1), "s"(w3), "s"(two));
-    y[1] = s1; y[5] = d1; y[3] = s3; y[7] = d3;
-    __builtin_amdgcn_sched_barrier(0); emit(1); emit(5); __builtin_amdgcn_sched_barrier(0);
-    y[0] = x[0] + x[1]; y[4] = x[0] - x[1];
-    __builtin_amdgcn_sched_barrier(0); emit(3); emit(7); __builtin_amdgcn_sched_barrier(0);
-    kg_addsub_sj<SIGN>(y[2], y[6], x[4], x[5]);
-    __builtin_amdgcn_sched_barrier(0); emit(0); emit(4); emit(2); emit(6); __builtin_amdgcn_sched_barrier(0);
-}
 // the finals of the two first-stage radix-4s (b = 0, 1): u_b[c] lands in x[2c + b]
 template <int SIGN> KG_DEV void kg_radix8_stage1_finals(cf (&x)[8], const cf (&s)[4], const cf (&dd)[4])
 {
@@ -886,17 +862,6 @@ template <int SIGN, class H> KG_DEV void kg_tw_radix8_h(cf (&x)[8], cf (&y)[8], 
     kg_radix8_stage2f<SIGN>(x, y);
 }
 template <int SIGN> KG_DEV void kg_tw_radix8(cf (&x)[8], cf (&y)[8], const kg_tw7 &w) { kg_tw_radix8_h<SIGN>(x, y, w, []() {}); }
-template <int SIGN, class H, class E> KG_DEV void kg_tw_radix8_he(cf (&x)[8], cf (&y)[8], const kg_tw7 &w, H hook, E emit)
-{
-    constexpr bool CJ = SIGN < 0;
-    kg_cmul3v<CJ>(x[1], x[2], x[3], w.w[0], w.w[1], w.w[2]);
-    cf s[4], dd[4];
-    kg_cfma4v<CJ>(s[0], s[1], s[2], s[3], x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], w.w[3], w.w[4], w.w[5], w.w[6]);
-    kg_2cmt4(dd[0], dd[1], dd[2], dd[3], x[0], x[1], x[2], x[3], s[0], s[1], s[2], s[3]);
-    kg_radix8_stage1_finals<SIGN>(x, s, dd);
-    hook();
-    kg_radix8_stage2f_e<SIGN>(x, y, emit);
-}
 // the eight conjugate products c_j conj(d_j) + radix8 fused (c, d intact); hook() when every operand has been consumed
 template <int SIGN, class H> KG_DEV void kg_cc_radix8_h(const cf (&c)[8], const cf (&d)[8], cf (&y)[8], H hook)
 {
@@ -907,16 +872,6 @@ template <int SIGN, class H> KG_DEV void kg_cc_radix8_h(const cf (&c)[8], const 
     kg_2cmt4(dd[0], dd[1], dd[2], dd[3], u[0], u[1], u[2], u[3], s[0], s[1], s[2], s[3]);
     kg_radix8_stage1_finals<SIGN>(x, s, dd);
     kg_radix8_stage2f<SIGN>(x, y);
-}
-template <int SIGN, class H, class E> KG_DEV void kg_cc_radix8_he(const cf (&c)[8], const cf (&d)[8], cf (&y)[8], H hook, E emit)
-{
-    cf u[4], s[4], dd[4], x[8];
-    kg_cmul4v_o<true>(u[0], u[1], u[2], u[3], c[0], c[1], c[2], c[3], d[0], d[1], d[2], d[3]);
-    kg_cfma4v<true>(s[0], s[1], s[2], s[3], u[0], u[1], u[2], u[3], c[4], c[5], c[6], c[7], d[4], d[5], d[6], d[7]);
-    hook();
-    kg_2cmt4(dd[0], dd[1], dd[2], dd[3], u[0], u[1], u[2], u[3], s[0], s[1], s[2], s[3]);
-    kg_radix8_stage1_finals<SIGN>(x, s, dd);
-    kg_radix8_stage2f_e<SIGN>(x, y, emit);
 }
 
 // Passes 0..2 with their exchanges: in x (thread i holds X[i + 512 j]); on return x holds the inputs of pass 3

@@ -18,11 +18,6 @@ s.sample_iq16_host_batch(iq, 0)
 svs = np.arange(23, dtype=np.int32)
 cs = np.zeros(512 + 4 * 1024, np.uint64)
 check(s.lib.kg_acq_debug_corr_stamps(s.h, B, ptr(svs), 23, ptr(cs), cs.size), "corr stamps")
-if os.environ.get("E1B_WAVELOCAL", "1") == "1":
-    labels_wl = ["cross reads issued", "operands + products (n+1)", "pass 2", "t2w stores, reads issued", "pass 0 rest (n+1), t1w stores, reads issued",
-                 "constants + pass 3", "pass 1 (n+1) + cross stores", "accumulate", "stores land", "barrier"]
-else:
-    labels_wl = None
 labels = ["A: wait operands + conj-mul", "A: pass0 + T0 stores (2 rows)", "A: pass2 (2 rows)", "A: T2 stores", "A: stores land",
           "A: barrier", "B: T2/T0 reads + pass1 + T1 stores (2 rows)", "B: pass3 + accumulate (2 rows)", "B: stores land", "B: barrier"]
 for wave, base in ((0, 0), (4, 1024)):
@@ -37,6 +32,6 @@ for wave, base in ((0, 0), (4, 1024)):
         prev = v[10]
         if v[11]:
             print("     cell end after item %d: scan %d, wave reductions + red %d, barrier %d, merge + store %d" % ((it,) + tuple(np.diff(v[11:16]))))
-        print("  item %2d: %5d cyc (+%4d between items) | " % (it, v[10] - v[0], gap) + ", ".join("%s %d" % (l if labels_wl else l.split(":")[0] + ":" + l.split(":")[1][:18], x) for l, x in zip(labels_wl or labels, d)))
+        print("  item %2d: %5d cyc (+%4d between items) | " % (it, v[10] - v[0], gap) + ", ".join("%s %d" % (l.split(":")[0] + ":" + l.split(":")[1][:18], x) for l, x in zip(labels, d)))
 tot = cs[16 + 16 * 59 + 10] - cs[16 + 0] if cs[16 + 16 * 59] else 0
 print("60 items: %d cycles = %.0f per item" % (tot, tot / 60.0))
