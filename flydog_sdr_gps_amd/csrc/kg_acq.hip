@@ -670,11 +670,19 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void acq_correlate_kernel(
 #pragma unroll
             for (int m = 0; m < 16; m += 2) bp = __builtin_fmaxf(bp, __builtin_fmaxf(pw[m], pw[m + 1]));
             unsigned qm[2] = {0, 0};                               // two independent chains of eight rows
+            // (gfx950 wants two wait states between a VALU that writes a carry / mask register and the VALU that reads it -- the
+            // compiler pads its own pairs with s_nop 1, inside an asm block nobody does: two rows' compares first, into two
+            // register pairs, then the four add-with-carry, every consumer three instructions behind its producer)
 #pragma unroll
-            for (int m = 7; m >= 0; m--)
-#pragma unroll
-                for (int h = 0; h < 2; h++)
-                    asm("v_cmp_eq_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(qm[h]) : "v"(pw[m + 8 * h]), "v"(bp) : "vcc");
+            for (int m = 7; m >= 0; m -= 2) {
+                unsigned long long k0, k1, k2, k3;
+                asm("v_cmp_eq_f32_e64 %2, %6, %10\n\tv_cmp_eq_f32_e64 %3, %7, %10\n\t"
+                    "v_cmp_eq_f32_e64 %4, %8, %10\n\tv_cmp_eq_f32_e64 %5, %9, %10\n\t"
+                    "v_addc_co_u32_e64 %0, %2, %0, %0, %2\n\tv_addc_co_u32_e64 %1, %3, %1, %1, %3\n\t"
+                    "v_addc_co_u32_e64 %0, %4, %0, %0, %4\n\tv_addc_co_u32_e64 %1, %5, %1, %1, %5"
+                    : "+v"(qm[0]), "+v"(qm[1]), "=&s"(k0), "=&s"(k1), "=&s"(k2), "=&s"(k3)
+                    : "v"(pw[m]), "v"(pw[m + 8]), "v"(pw[m - 1]), "v"(pw[m + 7]), "v"(bp));
+            }
             const unsigned rowmask = qm[0] | (qm[1] << 8);
             bi = t + 256 * (int) __builtin_ctz(rowmask | 0x80000000u);
         } else if constexpr (NQ == 1) {
@@ -1115,11 +1123,18 @@ __global__ __launch_bounds__(512, 1) void acq_correlate8_kernel(
 #pragma unroll
         for (int r = 0; r < 32; r += 2) bp = __builtin_fmaxf(bp, __builtin_fmaxf(pw[r], pw[r + 1]));
         unsigned qm[4] = {0, 0, 0, 0};                             // one 8-bit mask per quarter: four independent chains
+        // (two wait states between the compare that writes a mask register and the add that takes it as carry: the four quarters'
+        // compares first, into four register pairs, then the four adds -- see the scan of acq_correlate_kernel)
 #pragma unroll
-        for (int m = 7; m >= 0; m--)
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                asm("v_cmp_eq_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(qm[q]) : "v"(pw[m + 8 * q]), "v"(bp) : "vcc");
+        for (int m = 7; m >= 0; m--) {
+            unsigned long long k0, k1, k2, k3;
+            asm("v_cmp_eq_f32_e64 %4, %8, %12\n\tv_cmp_eq_f32_e64 %5, %9, %12\n\t"
+                "v_cmp_eq_f32_e64 %6, %10, %12\n\tv_cmp_eq_f32_e64 %7, %11, %12\n\t"
+                "v_addc_co_u32_e64 %0, %4, %0, %0, %4\n\tv_addc_co_u32_e64 %1, %5, %1, %1, %5\n\t"
+                "v_addc_co_u32_e64 %2, %6, %2, %2, %6\n\tv_addc_co_u32_e64 %3, %7, %3, %3, %7"
+                : "+v"(qm[0]), "+v"(qm[1]), "+v"(qm[2]), "+v"(qm[3]), "=&s"(k0), "=&s"(k1), "=&s"(k2), "=&s"(k3)
+                : "v"(pw[m]), "v"(pw[m + 8]), "v"(pw[m + 16]), "v"(pw[m + 24]), "v"(bp));
+        }
         const unsigned rowmask = (qm[0] | (qm[1] << 8)) | ((qm[2] << 16) | (qm[3] << 24));
         int bi = i + 512 * (int) __builtin_ctz(rowmask | 0x80000000u);
         KG_STAMP(STAMPS, stc, 1);
