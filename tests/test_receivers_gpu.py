@@ -293,3 +293,78 @@ def test_adc_ring_refilled_without_host_synchronisation(oracle, depth):
             assert np.array_equal(wf_iq[rx, off:off + 8192], want), ("frame of the last step", rx)
     finally:
         bank.close()
+
+
+def test_two_banks_stepped_from_two_threads_equal_their_solo_runs():
+    """Two connections' worth of banks on ONE device, each stepped by its own host thread at the same time (the C calls release
+    the interpreter lock): every output buffer of every step equals, byte for byte, what the same bank produces alone.  Holds
+    the process-wide pieces -- the stream pools, the library's tables, the contexts' staging -- to 'no shared mutable state'."""
+    import threading
+    from flydog_sdr_gps_amd import synth
+    n, steps = 1 << 20, 7
+    mixes = [_small_mix([6, 7, 8, 5, 7, 6], n), _small_mix([4, 5, 6, 7, 8, 3, 2, 1, 6, 7], n)]
+    adcs = [synth.adc_stream(n * steps, 0x5EED0070 + b) for b in range(2)]
+    keys = ("rows", "pkts", "raw", "xin", "firo", "s16", "pay")
+
+    def run(b, out, barrier=None):
+        bank = _bank(len(mixes[b]), n, mixes[b])
+        try:
+            d_adc = bank.ctx.alloc(adcs[b].nbytes)
+            bank.ctx.upload(d_adc, adcs[b])
+            if barrier is not None:
+                barrier.wait()
+            for k in range(steps):
+                info = bank.step(d_adc + 2 * k * n)
+                bank.sync()
+                rec = {"info": (info.nframes, info.nrec, info.nfir, info.snd_seq, info.nmoves)}
+                nrx = len(mixes[b])
+                rx_of, f_off, pkt_bytes = bank.frame_map()
+                rec["map"] = (rx_of.tolist(), f_off.tolist(), pkt_bytes.tolist())
+                # what a step DEFINES of each buffer (the rest of a row is whatever the allocation held)
+                valid = {"rows": 1024, "pkts": None, "raw": 6 * info.nrec, "xin": info.nrec, "firo": info.nfir, "s16": info.nfir,
+                         "pay": info.nfir // 2}
+                for key in keys:
+                    rows = range(info.nframes) if key in ("rows", "pkts") else range(nrx)
+                    got = bank.fetch(key, rows)
+                    if key == "pkts":
+                        rec[key] = [got[f, :int(pkt_bytes[f])].copy() for f in range(info.nframes)]
+                    else:
+                        rec[key] = got[:, :valid[key]].copy()
+                out.append(rec)
+            bank.ctx.free(d_adc)
+        finally:
+            bank.close()
+
+    solo = [[], []]
+    for b in range(2):
+        run(b, solo[b])
+    both = [[], []]
+    errs = []
+    barrier = threading.Barrier(2)
+
+    def guarded(b):
+        try:
+            run(b, both[b], barrier)
+        except BaseException as e:        # noqa: BLE001 -- re-raised below, in the test's thread
+            errs.append(e)
+            barrier.abort()
+    threads = [threading.Thread(target=guarded, args=(b,)) for b in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errs:
+        raise errs[0]
+    frames = 0
+    for b in range(2):
+        assert len(both[b]) == steps
+        for k in range(steps):
+            assert both[b][k]["info"] == solo[b][k]["info"], (b, k)
+            frames += both[b][k]["info"][0]
+            assert both[b][k]["map"] == solo[b][k]["map"], (b, k)
+            for key in keys:
+                if key == "pkts":
+                    assert all(np.array_equal(x, y) for x, y in zip(both[b][k][key], solo[b][k][key])), (b, k, key)
+                else:
+                    assert np.array_equal(both[b][k][key], solo[b][k][key]), (b, k, key)
+    assert frames > 0 and any(r["info"][2] for r in both[0]) and any(r["info"][2] for r in both[1])
