@@ -487,24 +487,36 @@ def event_spread(launch, reps):
 PREROLL_S = float(os.environ.get("KIWIGPU_BENCH_PREROLL_S", "0.5"))    # 0.12 s left the first timed region of a workload 5-30 % slow on some boxes
 
 
-def preroll(step, warmup):
+def dev_sync():
+    """torch.cuda.synchronize() where there is a device (the launcher self-test runs timed_steps without one)"""
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+def preroll(step, warmup, dist=None):
     """The W untimed warm-up steps, then more untimed ones until about PREROLL_S seconds of work have run
     (at least 64 steps): an MI355X that has been idle reaches its steady clock only after tens of
     milliseconds of load (measured on the correlator: 0.96 ms per launch at the start, 0.84 after 20
     launches, 0.80 after 60), and the first time two streams of a process depend on each other (the DDC's
     side stream) the HIP runtime stalls the GPU side for 30-50 ms, once per process, some thirty calls
-    in.  A short timed region would otherwise hold both.  Never part of the timed region."""
-    import torch
+    in.  A short timed region would otherwise hold both.  Never part of the timed region.
+    The NUMBER of pre-roll steps is agreed between the ranks (the largest estimate counts): a step may hold a collective --
+    `--shard sv` gathers the winners every step -- and ranks that each sized their pre-roll from their own clock ran different
+    numbers of steps: the ranks with more of them waited for ever (found by the one-GPU rehearsal of the N > 1 line, round 5)."""
     for _ in range(max(1, warmup)):
         step()
-    torch.cuda.synchronize()                         # one-time costs (code load, lazy allocations) are behind us
+    dev_sync()                                       # one-time costs (code load, lazy allocations) are behind us
     probe = max(4, min(warmup, 16))
     t0 = time.perf_counter()
     for _ in range(probe):
         step()
-    torch.cuda.synchronize()
+    dev_sync()
     est = max((time.perf_counter() - t0) / probe, 1e-5)
-    for _ in range(min(4000, max(64, int(PREROLL_S / est)))):
+    count = min(4000, max(64, int(PREROLL_S / est)))
+    if dist is not None and dist.on:
+        count = int(dist.max_over_ranks(float(count)))
+    for _ in range(count):
         step()
 
 
@@ -513,16 +525,24 @@ def timed_steps(dist, step, steps, warmup):
     over ranks; then the same K steps once more with a device event between steps for the spread
     (not part of the headline time).  -> (seconds, host enqueue seconds, spread dict)"""
     import torch
-    preroll(step, warmup)
+    preroll(step, warmup, dist)
     dist.barrier()                                   # barrier, then synchronize
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     t_enq = time.perf_counter() - t0
-    torch.cuda.synchronize()                         # this rank's K steps are done ...
+    dev_sync()                                       # this rank's K steps are done ...
     local = time.perf_counter() - t0
     dist.barrier()                                   # ... every rank's are: the slowest rank's time counts
     elapsed = dist.max_over_ranks(local)
+    if not torch.cuda.is_available():                # (the launcher self-test: the same K steps once more, host clock)
+        dts = []
+        for i in range(steps):
+            t1 = time.perf_counter()
+            step()
+            dts.append((time.perf_counter() - t1) * 1e3)
+        dts.sort()
+        return elapsed, t_enq, {"min": round(dts[0], 5), "median": round(dts[len(dts) // 2], 5), "max": round(dts[-1], 5), "how": "host clock (no device)"}
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     ev[0].record()
     for i in range(steps):
@@ -1532,7 +1552,7 @@ def run_receivers(args, dist, wl="receivers"):
         res = pmc_window(bank.ctx, wl, step, sync)
         bank.close()
         return res
-    preroll(step, args.warmup)
+    preroll(step, args.warmup, dist)
     sync()
     dist.barrier()
     bank.host_profile()                              # (reset: the next call reports the timed loop alone)
@@ -1893,6 +1913,24 @@ def run_stub(args, dist):
             parts = mine.reshape(1, -1)
         merged = shard.merge_sv_shards(parts, B, shares)
         assert merged.shape == (B, nsv) and np.array_equal(merged, full), "sv-sharded merge differs from the unsharded table"
+        # the timed loop of run_acq's --shard sv leg, shape for shape: a collective inside every step, and ranks whose steps take
+        # DIFFERENT times (so that their own pre-roll estimates differ: the ranks must still run the same number of steps)
+        ncalls = [0]
+
+        def step():
+            time.sleep(0.0002 * (1 + 3 * dist.rank))
+            if dist.on:
+                tdist.all_gather([torch.empty_like(raw) for _ in range(dist.world)], raw)
+            ncalls[0] += 1
+        el_s, _, spread = timed_steps(dist, step, 6, 2)
+        counts = [ncalls[0]]
+        if dist.on:
+            t = torch.tensor([ncalls[0]], dtype=torch.int64)
+            got = [torch.empty_like(t) for _ in range(dist.world)]
+            tdist.all_gather(got, t)
+            counts = [int(g.item()) for g in got]
+        assert len(set(counts)) == 1, "the ranks ran different numbers of steps: %s" % counts
+        out["shard_sv_timed_steps"] = {"steps_per_rank": counts, "seconds": round(el_s, 4)}
         out["shard_sv"] = {"world": dist.world, "shares": shares, "load": [round(sum(weights[i] for i in sh), 3) for sh in shares],
                            "merged_equals_unsharded": True}
         out["scaling"] = "strong"
@@ -1956,6 +1994,9 @@ def main():
     args.workload = {"waterfall": "wf14", "ddc": "ddc14"}.get(args.workload, args.workload)
 
     world_env = os.environ.get("WORLD_SIZE")
+    if os.environ.get("KIWIGPU_BENCH_WATCHDOG_S") and not (world_env is None and args.gpus > 1):
+        import faulthandler                                   # a diagnostic: a RANK that hangs says where (every thread's stack) and exits
+        faulthandler.dump_traceback_later(float(os.environ["KIWIGPU_BENCH_WATCHDOG_S"]), exit=True)
     if world_env is None and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))      # the parent never touches the GPU
     if world_env is not None and int(world_env) != args.gpus:

@@ -321,10 +321,17 @@ def test_bench_shard_sv_world2_on_the_stub():
     import json
     bench = os.path.join(ROOT, "bench.py")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["KIWIGPU_BENCH_PREROLL_S"] = "0.2"
+    env["KIWIGPU_BENCH_WATCHDOG_S"] = "200"           # a hung rank says where and exits
     out = subprocess.run([sys.executable, bench, "--gpus", "2", "--workload", "stub", "--shard", "sv"], env=env,
                          capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout + out.stderr
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    # the timed loop with a collective inside every step (timed_steps, as the --shard sv leg runs it): the two ranks' steps
+    # take 0.2 and 0.8 ms, their own pre-roll estimates differ fourfold -- they must still have run the same number of steps
+    # (round 5: they did not, and the N > 1 line hung in its strong-scaling leg)
+    ts = line["shard_sv_timed_steps"]["steps_per_rank"]
+    assert len(ts) == 2 and ts[0] == ts[1] and ts[0] >= 64 + 12, ts
     sv = line["shard_sv"]
     assert line["scaling"] == "strong" and sv["world"] == 2 and sv["merged_equals_unsharded"] is True
     # the cost-balanced split (shard.split_units_weighted): both kinds of SV on both ranks, a partition of the 59
