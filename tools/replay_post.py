@@ -29,7 +29,6 @@ while "x%d" % seg in d.files:
     if bad.size:
         i0 = max(0, bad[0] - 3)
         for i in range(i0, min(x.size, i0 + 10)):
-            g = np.abs(agc[0][i]) / max(np.abs(x[max(0, i - int(a_delay)) if False else i]), 1e-30) if False else 0
             print("   i %4d  |x| %10.3f  got %s  want %s  rel %.2e" % (i, np.abs(x[i]), agc[0][i], want[i], err[i] / scale))
         # gain ratio got / want along the segment: a step in it = a branch taken differently
         with np.errstate(divide="ignore", invalid="ignore"):
