@@ -735,10 +735,13 @@ def run_acq(args, dist, ten_ms=False, all_svs=False):
         # stream) and the winners end there; two batches in flight.  Never `value`.
         host = np.ascontiguousarray(np.stack(iq_host))
         reps = max(6, min(40, args.steps))
-        for _ in range(2):
-            s.sample_iq16_host_batch(host, 0); s.correlate_async(svs, nblocks=B); s.fetch(want_cells=False)
-        t0 = time.perf_counter()
         par = 0
+        t0 = time.perf_counter()                             # untimed, 0.3 s: a process's first host-to-device copies are slow (the link /
+        while time.perf_counter() - t0 < 0.3:                # DMA engine leaving its idle state: see run_receivers)
+            for _ in range(4):
+                s.sample_iq16_host_batch(host, par * B); s.correlate_async(svs, nblocks=B, first_block=par * B); par ^= 1
+            s.fetch(want_cells=False)
+        t0 = time.perf_counter()
         for _ in range(reps):
             s.sample_iq16_host_batch(host, par * B)
             s.correlate_async(svs, nblocks=B, first_block=par * B)
