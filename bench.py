@@ -1886,8 +1886,17 @@ def run_stub(args, dist):
     time.sleep(0.01 * (dist.rank + 1))
     dist.barrier()
     el = dist.max_over_ranks(time.perf_counter() - t0)
-    out = {"metric": "launcher self-test", "value": round(dist.world / el, 3), "unit": "ranks/s",
-           "config": {"workload": "stub (no GPU)"}, "dtype": "none"}
+    out = {"metric": "launcher self-test", "value": round(dist.world / el, 3), "unit": "ranks/s", "ms_per_step": round(el * 1e3, 3),
+           "config": {"workload": "stub (no GPU)"}, "dtype": "none",
+           # the SHAPE of a real line, so that the CPU suite holds the stdout line's size and top-level fields (compact_line):
+           # placeholders, not measurements
+           "roofline": {"bound": "none", "kernel": "stub", "achieved": 0.0, "peak": 1.0, "unit": "GB/s", "frac": 0.0, "traffic": None,
+                        "traffic_source": "x" * 300, "by_workload": {"pad": ["y" * 200] * 8}},
+           "cpu_baseline": {"value": 0.0, "unit": "ranks/s", "cores": 1, "kind": "port", "sample": "none (stub) " + "z" * 400},
+           "workloads": {"w%d" % i: {"ms_per_step": 1.0, "value": 2.0, "unit": "u", "roofline": {"bound": "hbm", "frac": 0.5, "kernel_ms": 0.9,
+                                                                                                   "traffic": 10, "algorithmic_bytes_per_launch": 5},
+                                     "cpu_baseline": {"value": 3.0, "kind": "port"}, "checked": {"n": 1}, "notes": "n" * 3000}
+                         for i in range(8)}}
     if args.shard == "sv":
         # the --shard sv exchange of run_acq without a GPU: every rank fabricates the winners of ITS share of the 59 SVs
         # (a pure function of block and SV), all ranks gather (gloo), the merge must give the unsharded table
@@ -1953,6 +1962,75 @@ def by_workload_table(rs):
     return tab
 
 
+COMPACT_MAX = 6000                     # bytes of the ONE stdout line (the driver's record keeps the last 8 000 characters)
+_KEEP_TOP = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+             "dtype", "data", "invalid", "invalid_for_scaling")
+_KEEP_ROOF = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "flops_per_launch",
+              "algorithmic_bytes_per_launch", "int_ops_per_launch")
+_KEEP_CPU = ("value", "unit", "cores", "kind", "sample", "note")
+
+
+def _short(v, n):
+    return v if not isinstance(v, str) or len(v) <= n else v[:n - 1] + "~"
+
+
+def compact_line(line):
+    """The ONE stdout line: the headline's contract fields, its `roofline` and `cpu_baseline` at top level, and one row per
+    other workload -- [ms_per_step, value, unit, bound, frac, kernel_ms, traffic / algorithmic bytes, cpu value, cpu kind,
+    result check ran].  Everything else (full workload objects, host phases, notes) goes to stderr and to
+    gpurun_out/bench_full.json (publish_full_line).  Kept well under COMPACT_MAX bytes; tests/test_host_cpu.py holds it there."""
+    out = {k: line[k] for k in _KEEP_TOP if k in line}
+    cfg = dict(line.get("config") or {})
+    cfg.pop("also_in_this_line", None)
+    out["config"] = {k: _short(v, 160) for k, v in cfg.items()}
+    if "roofline" in line:
+        out["roofline"] = {k: line["roofline"][k] for k in _KEEP_ROOF if k in line["roofline"]}
+    if "cpu_baseline" in line:
+        out["cpu_baseline"] = {k: _short(line["cpu_baseline"][k], 200) for k in _KEEP_CPU if k in line["cpu_baseline"]}
+    pf = line.get("cpu_baseline_pocketfft")
+    if pf:
+        out["cpu_baseline_tuned_fft"] = {"value": pf.get("value"), "unit": pf.get("unit"), "cores": pf.get("cores"), "kind": "scipy.fft (pocketfft)"}
+    if line.get("found_svs") is not None:
+        out["checked"] = {"found_svs": line["found_svs"]}
+    elif line.get("checked") is not None:
+        out["checked"] = True
+    wls = line.get("workloads")
+    if wls:
+        tab = {"_cols": ["ms_per_step", "value", "unit", "bound", "frac", "kernel_ms", "traffic_over_algorithmic", "cpu_value", "cpu_kind", "checked"]}
+        for wl, r in wls.items():
+            rf, hb, cb = r.get("roofline", {}), r.get("hbm", {}), r.get("cpu_baseline", {})
+            alg = hb.get("algorithmic_bytes_per_launch") or hb.get("algorithmic_bytes_per_step") or rf.get("algorithmic_bytes_per_launch")
+            tr = rf.get("traffic")
+            tab[wl] = [r.get("ms_per_step"), r.get("value"), r.get("unit"), rf.get("bound"), rf.get("frac"), rf.get("kernel_ms"),
+                       None if not (alg and tr) else round(tr / alg, 3), cb.get("value"), cb.get("kind"),
+                       bool(r.get("checked") or r.get("found_svs"))]
+        out["workloads"] = tab
+    if "box" in line:
+        out["box"] = {k: line["box"].get(k) for k in ("lib_sha16", "bench_sha16", "gpu_uuid")}
+    out["full_line"] = "stderr `FULL {...}` and gpurun_out/bench_full.json"
+    n = len(json.dumps(out, separators=(",", ":")))
+    if n > COMPACT_MAX:                                    # never near the record's limit: drop the optional parts, largest first
+        for k in ("workloads", "cpu_baseline_tuned_fft", "box", "checked"):
+            out.pop(k, None)
+            if len(json.dumps(out, separators=(",", ":"))) <= COMPACT_MAX:
+                break
+    return out
+
+
+def publish_full_line(line):
+    """The whole object: one `FULL {...}` line on stderr and, when the directory can be written, gpurun_out/bench_full.json."""
+    txt = json.dumps(line)
+    sys.stderr.write("FULL " + txt + "\n")
+    sys.stderr.flush()
+    try:
+        d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "bench_full.json"), "w") as f:
+            f.write(txt + "\n")
+    except OSError as e:
+        log("bench_full.json not written: %s" % e)
+
+
 def summary_line(line):
     """<= 400 characters: `SUMMARY wl=ms_per_step/frac+bound/traffic:algorithmic/check ...` for every workload of the line."""
     wls = dict(line.get("workloads") or {})
@@ -1988,6 +2066,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="skip the rocprofv3 --pmc child passes; roofline.traffic then comes from profiles/hbm_traffic.json")
+    ap.add_argument("--full-line", action="store_true",
+                    help="print the whole object on stdout instead of the compact line (tools/*.sh; the default stdout line stays "
+                         "under COMPACT_MAX bytes, the whole object goes to stderr as `FULL {...}` and to gpurun_out/bench_full.json)")
     ap.add_argument("--pmc-child", action="store_true",
                     help="(internal) counter-pass mode: a few steps of every workload between marker kernels, no timing")
     args = ap.parse_args()
@@ -2107,7 +2188,14 @@ def main():
         if TIMING_EXPERIMENT:
             line["invalid"] = "KIWIGPU_BENCH_TIMING_EXPERIMENT: a knock-out build whose rows are wrong by construction; not a measurement of the path"
     if dist.rank == 0:
-        os.write(json_fd, (json.dumps(line) + "\n").encode())
+        if args.pmc_child or args.full_line:
+            out = line
+        elif args.workload == "stub":
+            out = compact_line(line)
+        else:
+            publish_full_line(line)
+            out = compact_line(line)
+        os.write(json_fd, (json.dumps(out, separators=(",", ":")) + "\n").encode())
     dist.close()
     if dist.rank == 0 and args.workload != "stub" and not args.pmc_child:
         # The LAST line on stderr: every workload's step time, roofline fraction + the roof that binds it (v: vector

@@ -19,7 +19,7 @@ def test_process_group_path_over_rccl_with_one_rank():
     env.update(KIWIGPU_BENCH_FORCE_DIST="1", KIWIGPU_BENCH_FORCE_SV="1", KIWIGPU_BENCH_PREROLL_S="0.05", KIWIGPU_BENCH_WATCHDOG_S="240",
                MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "acq10ms", "--shard", "sv", "--steps", "6", "--warmup", "2",
-                          "--no-cpu", "--no-live-traffic"], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+                          "--no-cpu", "--no-live-traffic", "--full-line"], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["scaling"] == "strong" and line["steps"] == 6

@@ -303,6 +303,14 @@ def test_bench_gpus_flag_launches_ranks():
     assert len(lines) == 1                                   # ONE line, from rank 0
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["higher_is_better"] is True
+    # the stdout line is the LAST stdout line, small and flat (the driver's record keeps 8 000 characters of it: round 5's
+    # 24 KB line was lost whole), with the headline's roofline and cpu_baseline at top level; the stub carries > 24 KB of
+    # workload objects, which must have gone to stderr instead
+    assert out.stdout.rstrip().splitlines()[-1] == lines[0] and len(lines[0]) <= 8192 // 2
+    assert line["roofline"]["frac"] is not None and line["cpu_baseline"]["value"] is not None
+    assert set(line["workloads"]) == {"_cols"} | {"w%d" % i for i in range(8)} and line["workloads"]["w3"][4] == 0.5
+    full = [l for l in out.stderr.splitlines() if l.startswith("FULL {")]
+    assert not full                                          # the stub publishes nothing; a real workload writes `FULL {...}` to stderr
     # a rank started by torchrun with another world size than --gpus refuses to run
     out = subprocess.run([sys.executable, bench, "--gpus", "2", "--workload", "stub"],
                          env=dict(env, WORLD_SIZE="3", RANK="0"), capture_output=True, text=True, timeout=60)
@@ -314,6 +322,34 @@ def test_bench_gpus_flag_launches_ranks():
         assert out.returncode != 0 and "needs GPU" in out.stderr
 
 
+def test_bench_compact_line_of_a_recorded_full_line():
+    """bench.compact_line on round 5's recorded 24 KB default line (profiles/r05_bench_default_final.json): parses, <= 4 KB,
+    every contract field and the headline's roofline / cpu_baseline at top level, one row per workload."""
+    import json
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_default_final.json")))
+    assert len(json.dumps(full)) > 20000
+    txt = json.dumps(bench.compact_line(full), separators=(",", ":"))
+    assert len(txt) <= 4096, len(txt)
+    line = json.loads(txt)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"]
+    assert line["roofline"]["frac"] == full["roofline"]["frac"] and line["roofline"]["traffic"] == full["roofline"]["traffic"]
+    assert line["cpu_baseline"]["value"] == full["cpu_baseline"]["value"] and line["cpu_baseline"]["kind"] == "port"
+    assert "workload" in line["config"] and "model" not in line["config"]
+    cols = line["workloads"]["_cols"]
+    for wl, r in full["workloads"].items():
+        row = dict(zip(cols, line["workloads"][wl]))
+        assert row["ms_per_step"] == r["ms_per_step"] and row["frac"] == r["roofline"]["frac"]
+        assert row["cpu_value"] == r["cpu_baseline"]["value"]
+    # a pathologically large input still yields a line under the cap (optional parts are dropped, the contract fields stay)
+    huge = dict(full, workloads={("w%04d" % i): full["workloads"]["wf14"] for i in range(400)})
+    txt = json.dumps(bench.compact_line(huge), separators=(",", ":"))
+    assert len(txt) <= bench.COMPACT_MAX and "roofline" in json.loads(txt)
+
+
 def test_bench_shard_sv_world2_on_the_stub():
     """`bench.py --workload acq10ms --shard sv` splits the 59 SVs of ONE block over the ranks, all-gathers the
     winners and merges them (shard.split_units_weighted / merge_sv_shards).  The exchange runs here at world 2 over gloo
@@ -323,7 +359,7 @@ def test_bench_shard_sv_world2_on_the_stub():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env["KIWIGPU_BENCH_PREROLL_S"] = "0.2"
     env["KIWIGPU_BENCH_WATCHDOG_S"] = "200"           # a hung rank says where and exits
-    out = subprocess.run([sys.executable, bench, "--gpus", "2", "--workload", "stub", "--shard", "sv"], env=env,
+    out = subprocess.run([sys.executable, bench, "--gpus", "2", "--workload", "stub", "--shard", "sv", "--full-line"], env=env,
                          capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout + out.stderr
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])

@@ -5,7 +5,7 @@ args=$1; shift
 for rep in 1 2; do
   for v in "$@"; do
     if [ "$v" = base ]; then lib=""; else lib=$PWD/flydog_sdr_gps_amd/libkiwigpu_$v.so; fi
-    KIWIGPU_LIBRARY=$lib timeout 300 python3 bench.py --no-cpu --no-live-traffic $args 2>/dev/null | python3 -c "
+    KIWIGPU_LIBRARY=$lib timeout 300 python3 bench.py --full-line --no-cpu --no-live-traffic $args 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 r=d['roofline']

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 for v in "$@"; do
   if [ "$v" = base ]; then lib=""; else lib=$PWD/flydog_sdr_gps_amd/libkiwigpu_$v.so; fi
   out=/tmp/abk_$v; rm -rf $out
-  KIWIGPU_LIBRARY=$lib timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --no-cpu --no-live-traffic $args > /dev/null 2>&1
+  KIWIGPU_LIBRARY=$lib timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --full-line --no-cpu --no-live-traffic $args > /dev/null 2>&1
   f=$(find $out -name "*kernel_stats.csv" | head -1)
   echo "== $v"
   python3 - "$f" <<'PY'

@@ -4,7 +4,7 @@ cd $R
 for cond in cpu nocpu; do
   if [ $cond = cpu ]; then extra=""; else extra="--no-cpu"; fi
   rm -rf $R/gpurun_out/rxq_$cond
-  timeout 900 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/rxq_$cond -- python3 bench.py --no-live-traffic $extra --steps 40 --warmup 4 > $R/gpurun_out/rxq_$cond.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/rxq_$cond -- python3 bench.py --full-line --no-live-traffic $extra --steps 40 --warmup 4 > $R/gpurun_out/rxq_$cond.log 2>&1
   echo "== $cond"; grep SUMMARY $R/gpurun_out/rxq_$cond.log | cut -c1-300
   python3 - $cond <<'PY'
 import csv,glob,collections,sys

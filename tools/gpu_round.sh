@@ -11,6 +11,9 @@ timeout 1800 python3 -m pytest tests -m gpu -q --maxfail=10 -x -p no:cacheprovid
 tail -15 $out/pytest.log
 fi
 start=$(date +%s)
-timeout 900 python3 bench.py > $out/bench_all.json 2> $out/bench_all.err; echo "bench rc=$? in $(( $(date +%s) - start )) s"
-python3 tools/show_line.py $out/bench_all.json; tail -12 $out/bench_all.err
+# the driver's own command: the compact line on stdout (<= 8 KB), the whole object in gpurun_out/bench_full.json
+timeout 900 python3 bench.py > $out/bench_line.json 2> $out/bench_all.err; echo "bench rc=$? in $(( $(date +%s) - start )) s"
+echo "stdout line: $(wc -c < $out/bench_line.json) bytes"; cat $out/bench_line.json
+cp gpurun_out/bench_full.json $out/bench_all.json
+python3 tools/show_line.py $out/bench_all.json; grep -v "^FULL " $out/bench_all.err | tail -12
 if [ "${PROF:-0}" = 1 ]; then tools/prof_round.sh ${tag}p; fi

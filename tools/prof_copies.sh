@@ -4,7 +4,7 @@
 export TMPDIR=/tmp
 out=gpurun_out/prof_copies; mkdir -p $out
 for st in 40 240; do
-  KIWIGPU_BENCH_PREROLL_S=0.12 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/t$st -- python3 bench.py --no-cpu --no-live-traffic --workload receivers --steps $st --warmup 4 > $out/t$st.log 2>&1
+  KIWIGPU_BENCH_PREROLL_S=0.12 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/t$st -- python3 bench.py --full-line --no-cpu --no-live-traffic --workload receivers --steps $st --warmup 4 > $out/t$st.log 2>&1
 done
 python3 - <<'PY'
 import csv,glob

@@ -16,7 +16,7 @@ for set in "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" \
            "TCC_REQ_sum TCC_BUSY_sum" \
            "GRBM_GUI_ACTIVE TD_TD_BUSY_sum"; do
   i=$((i+1))
-  timeout 120 rocprofv3 --pmc $set --output-format csv -d $out/p$i -- python3 bench.py --no-cpu --no-live-traffic --workload acq --steps 30 --warmup 5 "$@" > $out/p$i.log 2>&1
+  timeout 120 rocprofv3 --pmc $set --output-format csv -d $out/p$i -- python3 bench.py --full-line --no-cpu --no-live-traffic --workload acq --steps 30 --warmup 5 "$@" > $out/p$i.log 2>&1
   echo "pass $i ($set): rc $?"
 done
 python3 - $out <<'PY'

@@ -12,7 +12,7 @@ for set in "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" \
            "TCC_REQ_sum TCC_BUSY_sum" \
            "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
   i=$((i+1))
-  timeout 120 rocprofv3 --pmc $set --output-format csv -d $out/p$i -- python3 bench.py --no-cpu --no-live-traffic --workload ddc14 --steps 10 --warmup 3 "$@" > $out/p$i.log 2>&1
+  timeout 120 rocprofv3 --pmc $set --output-format csv -d $out/p$i -- python3 bench.py --full-line --no-cpu --no-live-traffic --workload ddc14 --steps 10 --warmup 3 "$@" > $out/p$i.log 2>&1
   echo "pass $i ($set): rc $?"
 done
 python3 - $out <<'PY'

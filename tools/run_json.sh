@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/run_json.sh <bench args...>: run bench.py and print the interesting numbers of its line
-python3 bench.py "$@" 2>/dev/null | python3 -c "
+python3 bench.py --full-line "$@" 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 def show(name, r):
