@@ -13,6 +13,8 @@
 #        gpsconst_ref  gps/gps.h, kiwi.h, kiwi.gen.h     (the constants the oracle hard-pins)
 #        agc_ref       rx/CuteSDR/agc.cpp                (CAgc)
 #        adpcm_ref     rx/csdr/ima_adpcm.cpp             (IMA ADPCM coder/decoder)
+#        fir_ref       rx/CuteSDR/fir.cpp                (CFir: m_AM_FIR, the de-emphasis filters)
+#        squelch_ref   rx/CuteSDR/squelch.cpp + fir.cpp  (CSquelch: the NBFM noise squelch)
 #        cic_gen_ref   verilog/rx/cic_gen.c              (Hogenauer pruning generator; its .vh
 #                                                         output for every CIC instance -> _ref/cic/)
 #
@@ -63,6 +65,14 @@ $CXX $OPT $DEF $INC -o "$OUT/e1b_ref" "$HERE/ref/ref_e1b_main.cpp"
 $CXX $OPT $DEF $INC -o "$OUT/gpsconst_ref" "$HERE/ref/ref_gpsconst_main.cpp"
 $CXX $OPT $DEF $INC -o "$OUT/agc_ref" "$HERE/ref/ref_agc_main.cpp" "$R/rx/CuteSDR/agc.cpp" -lm
 $CXX $OPT $DEF $INC -o "$OUT/adpcm_ref" "$HERE/ref/ref_adpcm_main.cpp" "$R/rx/csdr/ima_adpcm.cpp"
+# fir.cpp's InitLPFilter(..., dump = false) references the server's debug printer real_printf
+# (support/printf.cpp, which does not link without the web-server runtime) inside `if (dump)`.  No
+# stand-in is written for it: the symbol is left unresolved at link time (it resolves to address 0);
+# the drivers never pass dump = true, so it is never called.
+UNRES="-Wl,--unresolved-symbols=ignore-all"
+$CXX $OPT $DEF $INC -o "$OUT/fir_ref" "$HERE/ref/ref_fir_main.cpp" "$R/rx/CuteSDR/fir.cpp" -lm $UNRES
+$CXX $OPT $DEF $INC -o "$OUT/squelch_ref" "$HERE/ref/ref_squelch_main.cpp" "$R/rx/CuteSDR/squelch.cpp" \
+    "$R/rx/CuteSDR/fir.cpp" -lm $UNRES
 $CC -O1 -w -DKIWISDR -I"$OUT/gen" "$R/verilog/rx/cic_gen.c" -lm -o "$OUT/cic_gen_ref"
 (cd "$OUT/cic" && "$OUT/cic_gen_ref" > cic_gen.log 2>&1)
-echo "built oracle/_ref: cacode_ref e1b_ref gpsconst_ref agc_ref adpcm_ref cic_gen_ref (+ gen/kiwi.gen.h, cic/*.vh) from $REFERENCE"
+echo "built oracle/_ref: cacode_ref e1b_ref gpsconst_ref agc_ref adpcm_ref fir_ref squelch_ref cic_gen_ref (+ gen/kiwi.gen.h, cic/*.vh) from $REFERENCE"

@@ -258,6 +258,40 @@ float ko_smeter_process(float avg_dB, float alpha, int n, const ko_cpx *in, floa
 void ko_am_detect(double *z1, int n, const ko_cpx *agc, float *demod);
 void ko_nbfm_detect(ko_cpx *last, int n, const ko_cpx *agc, float *demod);
 
+/* ---- part 6b: CFir (m_AM_FIR, the de-emphasis filters) and CSquelch (kiwi_oracle_cfir.c) ---- */
+#define KO_CFIR_MAX_NUMCOEF 97           /* fir.h:20 */
+#define KO_SQ_MAX_SQBUF_SIZE 1024        /* squelch.h:14 */
+typedef struct {                          /* fir.h:24-52, the real-valued members */
+    int num_taps, state;
+    float sample_rate;
+    float coef[KO_CFIR_MAX_NUMCOEF * 2];
+    float zbuf[KO_CFIR_MAX_NUMCOEF];
+} ko_cfir_state;
+size_t ko_cfir_state_size(void);
+void ko_cfir_init(ko_cfir_state *f);
+int ko_cfir_num_taps(const ko_cfir_state *f);
+void ko_cfir_get_taps(const ko_cfir_state *f, float *taps);
+void ko_cfir_init_const(ko_cfir_state *f, int num_taps, const float *coef, float fs);
+int ko_cfir_init_lp(ko_cfir_state *f, int NumTaps, float Scale, float Astop, float Fpass, float Fstop, float Fsamprate);
+int ko_cfir_init_hp(ko_cfir_state *f, int NumTaps, float Scale, float Astop, float Fpass, float Fstop, float Fsamprate);
+void ko_cfir_process_rr(ko_cfir_state *f, int n, const float *in, float *out);
+void ko_cfir_process_rm(ko_cfir_state *f, int n, const float *in, int16_t *out);
+void ko_cfir_process_mm(ko_cfir_state *f, int n, const int16_t *in, int16_t *out);
+typedef struct {                          /* squelch.h:30-56, what PerformFMSquelch uses */
+    int squelch_state, set_squelch;
+    float sample_rate, squelch_hp_freq;
+    float squelch_value, squelch_threshold, squelch_ave, squelch_alpha;
+    ko_cfir_state hp;
+} ko_squelch_state;
+size_t ko_squelch_state_size(void);
+void ko_squelch_init(ko_squelch_state *s);
+void ko_squelch_reset(ko_squelch_state *s);
+void ko_squelch_setup(ko_squelch_state *s, float samplerate);
+void ko_squelch_set(ko_squelch_state *s, int Value, int SquelchMax);
+int ko_squelch_is_squelched(const ko_squelch_state *s);
+float ko_squelch_ave(const ko_squelch_state *s);
+int ko_squelch_perform_fm(ko_squelch_state *s, int n, const float *in, int16_t *out);
+
 /* ---- part 7: wire formats (kiwi_oracle_wire.c) ---- */
 #define KO_WF_WIDTH 1024                 /* rx_waterfall.h:64 */
 #define KO_WF_ADPCM_PAD 10               /* rx_waterfall.h:83 */

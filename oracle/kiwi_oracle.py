@@ -436,6 +436,97 @@ def nbfm_detect(last, agc):
     return out, (float(l[0].real), float(l[0].imag))
 
 
+# ---- CFir, CSquelch (kiwi_oracle_cfir.c) ---------------------------------------------
+class CFir:
+    """One CFir instance (rx/CuteSDR/fir.cpp), real-valued paths."""
+
+    def __init__(self):
+        L = lib()
+        L.ko_cfir_state_size.restype = C.c_size_t
+        self._buf = C.create_string_buffer(L.ko_cfir_state_size())
+        L.ko_cfir_init(self._buf)
+
+    def init_const(self, coef, fs=12000.0):
+        coef = np.ascontiguousarray(coef, np.float32)
+        L = lib()
+        L.ko_cfir_init_const.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_float]
+        L.ko_cfir_init_const(self._buf, coef.size, _p(coef), float(fs))
+
+    def _design(self, fn, numtaps, scale, astop, fpass, fstop, fs):
+        fn.argtypes = [C.c_void_p, C.c_int] + [C.c_float] * 5
+        fn.restype = C.c_int
+        return int(fn(self._buf, int(numtaps), float(scale), float(astop), float(fpass), float(fstop), float(fs)))
+
+    def init_lp(self, numtaps, scale, astop, fpass, fstop, fs):
+        return self._design(lib().ko_cfir_init_lp, numtaps, scale, astop, fpass, fstop, fs)
+
+    def init_hp(self, numtaps, scale, astop, fpass, fstop, fs):
+        return self._design(lib().ko_cfir_init_hp, numtaps, scale, astop, fpass, fstop, fs)
+
+    def taps(self):
+        L = lib()
+        n = int(L.ko_cfir_num_taps(self._buf))
+        t = np.empty(n, np.float32)
+        L.ko_cfir_get_taps(self._buf, _p(t))
+        return t
+
+    def process_rr(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.empty(x.size, np.float32)
+        lib().ko_cfir_process_rr(self._buf, C.c_int(x.size), _p(x), _p(out))
+        return out
+
+    def process_rm(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.empty(x.size, np.int16)
+        lib().ko_cfir_process_rm(self._buf, C.c_int(x.size), _p(x), _p(out))
+        return out
+
+    def process_mm(self, x):
+        x = np.ascontiguousarray(x, np.int16)
+        out = np.empty(x.size, np.int16)
+        lib().ko_cfir_process_mm(self._buf, C.c_int(x.size), _p(x), _p(out))
+        return out
+
+
+class Squelch:
+    """One CSquelch instance (rx/CuteSDR/squelch.cpp), the NBFM noise squelch."""
+
+    def __init__(self):
+        L = lib()
+        L.ko_squelch_state_size.restype = C.c_size_t
+        self._buf = C.create_string_buffer(L.ko_squelch_state_size())
+        L.ko_squelch_init(self._buf)
+
+    def setup(self, rate):
+        L = lib()
+        L.ko_squelch_setup.argtypes = [C.c_void_p, C.c_float]
+        L.ko_squelch_setup(self._buf, float(rate))
+
+    def set_squelch(self, value, squelch_max):
+        lib().ko_squelch_set(self._buf, C.c_int(int(value)), C.c_int(int(squelch_max)))
+
+    def reset(self):
+        lib().ko_squelch_reset(self._buf)
+
+    def squelched(self):
+        return bool(lib().ko_squelch_is_squelched(self._buf))
+
+    def ave(self):
+        L = lib()
+        L.ko_squelch_ave.restype = C.c_float
+        return float(L.ko_squelch_ave(self._buf))
+
+    def perform_fm(self, x):
+        """-> (mono16 out, nsq_nc_sq)"""
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.zeros(x.size, np.int16)
+        L = lib()
+        L.ko_squelch_perform_fm.restype = C.c_int
+        rc = L.ko_squelch_perform_fm(self._buf, C.c_int(x.size), _p(x), _p(out))
+        return out, int(rc)
+
+
 # ---- wire formats (kiwi_oracle_wire.c) ----------------------------------------------
 class AdpcmState(C.Structure):
     _fields_ = [("index", C.c_int), ("previous", C.c_int)]

@@ -13,3 +13,53 @@ def e1b_chips(path=None):
     g = np.load(path or os.path.join(GOLDEN, "e1b_ref.npz"))
     chips = np.unpackbits(g["chips_packed"], axis=1)[:, :4092]
     return {i + 1: chips[i].copy() for i in range(chips.shape[0])}
+
+
+def run_fir_script(fir, script, x):
+    """The script language of oracle/ref/ref_fir_main.cpp on an object with init_lp / init_hp / init_const /
+    process_rr / process_rm / process_mm.  Returns the floats the reference driver would have written."""
+    import numpy as np
+    out, pos = [], 0
+    for line in script:
+        f = str(line).split()
+        if f[0] in "LH":
+            fn = fir.init_lp if f[0] == "L" else fir.init_hp
+            out.append(np.array([fn(int(f[1]), *[float(v) for v in f[2:7]])], np.float32))
+        elif f[0] == "K":
+            n = int(f[1])
+            fir.init_const(x[pos:pos + n], float(f[2]))
+            pos += n
+        else:
+            n = int(f[1])
+            blk = x[pos:pos + n]
+            pos += n
+            if f[0] == "R":
+                out.append(np.asarray(fir.process_rr(blk), np.float32))
+            elif f[0] == "M":
+                out.append(np.asarray(fir.process_rm(blk)).astype(np.float32))
+            else:
+                out.append(np.asarray(fir.process_mm(blk.astype(np.int16))).astype(np.float32))
+    assert pos == x.size
+    return np.concatenate(out)
+
+
+def run_squelch_script(sq, script, x):
+    """The script language of oracle/ref/ref_squelch_main.cpp on an object with setup / set_squelch / reset /
+    perform_fm (-> mono16 out, nsq_nc_sq)."""
+    import numpy as np
+    out, pos = [], 0
+    for line in script:
+        f = str(line).split()
+        if f[0] == "P":
+            sq.setup(float(f[1]))
+        elif f[0] == "Q":
+            sq.set_squelch(int(f[1]), int(f[2]))
+        elif f[0] == "Z":
+            sq.reset()
+        else:
+            n = int(f[1])
+            y, rc = sq.perform_fm(x[pos:pos + n])
+            pos += n
+            out.append(np.concatenate([np.asarray(y).astype(np.float32), np.array([rc], np.float32)]))
+    assert pos == x.size
+    return np.concatenate(out)

@@ -200,3 +200,66 @@ def test_all_three_cicf_tap_sets_match_fir_iq_sv(oracle):
                           ("ko_cicf_taps65", 33, sets[2])):
         got = list((C.c_int32 * n).in_dll(L, name))
         assert got == want[:n] and len(want) >= n, name
+
+
+def test_cfir_oracle_matches_reference_fir_cpp(oracle):
+    """rx/CuteSDR/fir.cpp built from its own source (oracle/_ref/fir_ref): Kaiser low-pass / high-pass designs (taps read
+    back through an impulse, tap counts), InitConstFir with the de-emphasis tables, and the real -> real, real -> mono16 and
+    mono16 -> mono16 ProcessFilter paths with their rotating accumulation order: bit-identical."""
+    from tests.fixtures import run_fir_script
+    g = np.load(os.path.join(GOLD, "fir_ref.npz"))
+    assert len(g["names"]) == 15
+    for name in g["names"]:
+        name = str(name)
+        got = run_fir_script(oracle.CFir(), g[name + "_script"], g[name + "_in"])
+        want = g[name + "_out"]
+        assert got.shape == want.shape, name
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "%s: max |diff| %g" % (name, np.abs(got - want).max())
+    # what the vectors say about the designs rx_sound_cmd.cpp:270-282 / squelch.cpp:137 ask for
+    assert g["am_fir_am_12k_out"][0] == 32 and g["am_fir_amn_12k_out"][0] == 18 and g["am_fir_am_20k_out"][0] == 15
+    assert g["hp_squelch_12k_out"][0] == 79 and g["hp_squelch_20k_out"][0] == 97      # 96 | 1: fills MAX_NUMCOEF
+    assert g["am_fir_full_band_out"][0] == 9          # Fstop == Fpass: (int) of +inf, as x86 converts it
+
+
+def test_squelch_oracle_matches_reference_squelch_cpp(oracle):
+    """rx/CuteSDR/squelch.cpp (+ fir.cpp for its m_HpFir) built from its own sources (oracle/_ref/squelch_ref): outputs and
+    the nsq_nc_sq return value of every PerformFMSquelch call, bit-identical; the vectors open and close the squelch."""
+    from tests.fixtures import run_squelch_script
+    g = np.load(os.path.join(GOLD, "squelch_ref.npz"))
+    seen = set()
+    for name in g["names"]:
+        name = str(name)
+        got = run_squelch_script(oracle.Squelch(), g[name + "_script"], g[name + "_in"])
+        want = g[name + "_out"]
+        assert got.shape == want.shape, name
+        assert np.array_equal(got, want), "%s: %d differ" % (name, np.count_nonzero(got != want))
+        pos = 0
+        for line in g[name + "_script"]:
+            f = str(line).split()
+            if f[0] == "F":
+                pos += int(f[1]) + 1
+                seen.add(int(want[pos - 1]))
+    assert seen == {-1, 0, 1}
+    w = g["threshold_80_out"].reshape(12, 513)
+    closed = [bool(np.all(r[:512] == 1)) for r in w]
+    assert closed[2] and not closed[7] and closed[11], closed          # noise closes it, a quiet carrier opens it, noise again
+
+
+@pytest.mark.skipif(not os.path.isfile("/root/reference/rx/rx_filter.h"), reason="reference tree not present")
+def test_deemphasis_tables_match_rx_filter_h():
+    """rx/rx_filter.h:29-73: the four [2][79] de-emphasis tables the host mirror carries (flydog_sdr_gps_amd/deemp.py) are the
+    reference's numbers, and the reference's CFir, handed them, answers an impulse with exactly them (fir_ref.npz)."""
+    import re
+    from flydog_sdr_gps_amd import deemp
+    text = open("/root/reference/rx/rx_filter.h").read()
+    g = np.load(os.path.join(GOLD, "fir_ref.npz"))
+    for name in ("nfm_deemp_12000", "nfm_deemp_20250", "am_ssb_deemp_12000", "am_ssb_deemp_20250"):
+        body = re.search(r"const float %s\[N_NFM_DEEMP\]\[N_DEEMP_TAPS\] = \{(.*?)\n\};" % name, text, re.S).group(1)
+        rows = re.findall(r"\{([^{}]*)\}", body)
+        tab = np.array([[float(v) for v in re.sub(r"//[^\n]*", "", r).replace("\n", " ").split(",") if v.strip()] for r in rows],
+                       np.float32)
+        assert tab.shape == (2, deemp.N_DEEMP_TAPS)
+        assert np.array_equal(getattr(deemp, name.upper()), tab), name
+        for k in range(2):
+            assert np.array_equal(g["%s_%d_out" % (name, k)][:79], tab[k])
+    assert int(re.search(r"#define N_DEEMP_TAPS (\d+)", text).group(1)) == deemp.N_DEEMP_TAPS

@@ -10,6 +10,9 @@ the outputs the reference's code produced for them.
                   CIC instance of kiwi.config (rx1 std + wide, rx2 std + wide, wf1)
   agc_ref.npz     CAgc (rx/CuteSDR/agc.cpp): SetParameters / ProcessData scripts, inputs, outputs
   adpcm_ref.npz   rx/csdr/ima_adpcm.cpp: i16 and u8 coder + decoder, inputs, outputs, end states
+  fir_ref.npz     CFir (rx/CuteSDR/fir.cpp): InitLPFilter / InitHPFilter / InitConstFir + the three real-valued
+                  ProcessFilter paths -- the designed taps (read back through an impulse), inputs, outputs
+  squelch_ref.npz CSquelch (rx/CuteSDR/squelch.cpp): SetupParameters / SetSquelch / Reset / PerformFMSquelch scripts
 """
 import json
 import os
@@ -158,3 +161,120 @@ ad["u8_enc"] = np.stack(u8enc)
 ad["u8_dec"] = np.stack(u8dec)
 np.savez_compressed(os.path.join(GOLD, "adpcm_ref.npz"), **ad)
 print("adpcm_ref.npz: %d int16 samples, %d rows; end state %s" % (sig.size, rows.shape[0], ad["i16_enc_state"]))
+
+# ---- CFir -----------------------------------------------------------------------------------
+rng = np.random.Generator(np.random.PCG64(0x5EED00F1))
+# the de-emphasis tables (rx/rx_filter.h:29-73): read as numbers, handed to the reference's InitConstFir
+text = open(os.path.join(REFERENCE, "rx", "rx_filter.h")).read()
+deemp = {}
+for name in ("nfm_deemp_12000", "nfm_deemp_20250", "am_ssb_deemp_12000", "am_ssb_deemp_20250"):
+    body = re.search(r"const float %s\[N_NFM_DEEMP\]\[N_DEEMP_TAPS\] = \{(.*?)\n\};" % name, text, re.S).group(1)
+    rows = re.findall(r"\{([^{}]*)\}", body)
+    tab = np.array([[float(v) for v in re.sub(r"//[^\n]*", "", r).replace("\n", " ").split(",") if v.strip()] for r in rows], np.float32)
+    assert tab.shape == (2, 79), (name, tab.shape)
+    deemp[name] = tab
+
+
+def audio(kind, n):
+    t = np.arange(n)
+    if kind == "am":                      # what the AM detector hands over: envelope minus DC, a few thousand counts
+        return (6000.0 * np.sin(2 * np.pi * 0.031 * t) * (1 + 0.3 * np.sin(2 * np.pi * 0.0007 * t)) + 400.0 * rng.standard_normal(n)).astype(np.float32)
+    if kind == "loud":                    # past the int16 range: the (TYPEMONO16) cast of an out-of-range float
+        return (60000.0 * np.sin(2 * np.pi * 0.011 * t) + 100.0 * rng.standard_normal(n)).astype(np.float32)
+    if kind == "s16":                     # mono16 audio (SSB / detector outputs)
+        return np.round(9000.0 * np.sin(2 * np.pi * 0.05 * t) + 3000.0 * rng.standard_normal(n)).clip(-32768, 32767).astype(np.float32)
+    if kind == "fm":                      # the NBFM detector's output: clipped at +-8192 (rx_sound.cpp:860)
+        return np.clip(5000.0 * rng.standard_normal(n), -8192, 8192).astype(np.float32)
+    raise ValueError(kind)
+
+
+def impulse(n):
+    x = np.zeros(n, np.float32)
+    x[0] = 1.0
+    return x
+
+
+# (name, [(script line, input floats or None)]): `R` after a design line with an impulse reads the taps back
+fir_scen = [
+    # m_AM_FIR as rx_sound_cmd.cpp:270-282 designs it: AM 9.8 kHz (hbw 4900, stop min(8820, 6000)), AMN 5 kHz, 12 kHz rate
+    ("am_fir_am_12k", [("L 0 1.0 50.0 4900 6000 12000", None), ("R 100", impulse(100)),
+                       ("L 0 1.0 50.0 4900 6000 12000", None)] + [("M 512", audio("am", 512)) for _ in range(4)]),
+    ("am_fir_amn_12k", [("L 0 1.0 50.0 2500 4500 12000", None), ("R 100", impulse(100)),
+                        ("L 0 1.0 50.0 2500 4500 12000", None), ("M 512", audio("am", 512)), ("M 300", audio("am", 300)),
+                        ("M 212", audio("am", 212)), ("M 1", audio("am", 1)), ("M 511", audio("loud", 511))]),
+    ("am_fir_am_20k", [("L 0 1.0 50.0 6000 10125 20250", None), ("R 100", impulse(100)),
+                       ("L 0 1.0 50.0 6000 10125 20250", None)] + [("M 512", audio("am", 512)) for _ in range(2)]),
+    # hbw == frate / 2: Fstop == Fpass, an infinite tap estimate whose (int) is undefined; this build (x86-64) gives 9 taps
+    ("am_fir_full_band", [("L 0 1.0 50.0 6000 6000 12000", None), ("R 20", impulse(20)), ("M 256", audio("am", 256))]),
+    ("lp_forced_taps_weak_stop", [("L 33 0.5 35.0 1000 3000 12000", None), ("R 40", impulse(40)), ("R 300", audio("am", 300)),
+                                  ("L 0 1.0 15.0 1000 1200 12000", None), ("R 100", impulse(100))]),
+    # CSquelch::InitNoiseSquelch (squelch.cpp:137) at both sound rates
+    ("hp_squelch_12k", [("H 0 1.0 50.0 2400 1950 12000", None), ("R 100", impulse(100)),
+                        ("H 0 1.0 50.0 2400 1950 12000", None), ("R 512", audio("fm", 512)), ("R 170", audio("fm", 170)),
+                        ("R 512", audio("fm", 512))]),
+    ("hp_squelch_20k", [("H 0 1.0 50.0 2400 1950 20250", None), ("R 100", impulse(100)), ("R 512", audio("fm", 512))]),
+]
+for tname, tab in deemp.items():
+    fs = 12000 if tname.endswith("12000") else 20250
+    for k in range(2):
+        fir_scen.append(("%s_%d" % (tname, k), [("K 79 %d" % fs, tab[k]), ("R 80", impulse(80)), ("K 79 %d" % fs, tab[k]),
+                                                ("S 512", audio("s16", 512)), ("S 340", audio("s16", 340)),
+                                                ("S 172", audio("s16", 172)), ("S 512", audio("s16", 512))]))
+fir = {}
+with tempfile.TemporaryDirectory() as tmp:
+    for name, steps in fir_scen:
+        script = [s for s, _ in steps]
+        x = np.concatenate([np.asarray(v, np.float32) for _, v in steps if v is not None])
+        open(os.path.join(tmp, "s.txt"), "w").write("\n".join(script) + "\n")
+        x.tofile(os.path.join(tmp, "in.bin"))
+        run([os.path.join(REF, "fir_ref"), os.path.join(tmp, "s.txt"), os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")])
+        y = np.fromfile(os.path.join(tmp, "out.bin"), np.float32)
+        fir[name + "_script"] = np.array(script)
+        fir[name + "_in"] = x
+        fir[name + "_out"] = y
+        print("fir_ref.npz: %-24s %5d floats in, %5d floats out" % (name, x.size, y.size))
+fir["names"] = np.array([s[0] for s in fir_scen])
+np.savez_compressed(os.path.join(GOLD, "fir_ref.npz"), **fir)
+
+# ---- CSquelch -------------------------------------------------------------------------------
+rng = np.random.Generator(np.random.PCG64(0x5EED0059))
+
+
+def fm_noise(n, level=5000.0):
+    return np.clip(level * rng.standard_normal(n), -8192, 8192).astype(np.float32)
+
+
+def fm_voice(n, f=0.07):
+    return (4000.0 * np.sin(2 * np.pi * f * np.arange(n)) + 30.0 * rng.standard_normal(n)).astype(np.float32)
+
+
+sq_scen = [
+    # rx_sound.cpp:261-262: SetupParameters, SetSquelch(0, 0) -- always open
+    ("open_default", ["P 12000", "Q 0 0"] + ["F 512"] * 3, [fm_noise(512), fm_voice(512), fm_noise(512)]),
+    # mid threshold: noise closes it, a quiet carrier opens it, noise closes it again (hysteresis both ways)
+    ("threshold_80", ["P 12000", "Q 80 0"] + ["F 512"] * 12,
+     [fm_noise(512)] * 0 + [fm_noise(512) for _ in range(3)] + [fm_voice(512) for _ in range(5)] + [fm_noise(512) for _ in range(4)]),
+    ("threshold_99_forced", ["P 12000", "Q 0 0", "F 512", "Q 99 0", "F 512", "F 512", "Q 0 0", "F 512"],
+     [fm_voice(512) for _ in range(4)]),
+    ("explicit_max_and_reset", ["P 12000", "Q 30 3000", "F 512", "F 512", "F 512", "Z", "F 512", "Q 60 3000", "F 170", "F 342", "F 512"],
+     [fm_voice(512), fm_noise(512, 1500.0), fm_noise(512, 6000.0), fm_voice(512), fm_noise(170), fm_voice(342), fm_voice(512)]),
+    ("wide_rate_20250", ["P 20250", "Q 75 0"] + ["F 512"] * 6,
+     [fm_noise(512) for _ in range(2)] + [fm_voice(512, 0.03) for _ in range(3)] + [fm_noise(512)]),
+    ("near_threshold_levels", ["P 12000", "Q 85 0"] + ["F 512"] * 16,
+     [fm_noise(512, 1200.0 + 250.0 * k) for k in range(10)] + [fm_noise(512, 3450.0 - 450.0 * k) for k in range(6)]),
+]
+sq = {}
+with tempfile.TemporaryDirectory() as tmp:
+    for name, script, blocks in sq_scen:
+        x = np.concatenate(blocks)
+        assert x.size == sum(int(l.split()[1]) for l in script if l[0] == "F"), name
+        open(os.path.join(tmp, "s.txt"), "w").write("\n".join(script) + "\n")
+        x.tofile(os.path.join(tmp, "in.bin"))
+        run([os.path.join(REF, "squelch_ref"), os.path.join(tmp, "s.txt"), os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")])
+        y = np.fromfile(os.path.join(tmp, "out.bin"), np.float32)
+        sq[name + "_script"] = np.array(script)
+        sq[name + "_in"] = x
+        sq[name + "_out"] = y
+        print("squelch_ref.npz: %-24s %5d floats in, %5d floats out" % (name, x.size, y.size))
+sq["names"] = np.array([s[0] for s in sq_scen])
+np.savez_compressed(os.path.join(GOLD, "squelch_ref.npz"), **sq)
