@@ -132,6 +132,17 @@ SYMBOLS = {
     "kg_post_reset": (_i, [_vp, _i]),
     "kg_post_process_dev": (_i, [_vp, _vp, _i, _vp, _sz, _i, _vp, _vp, _vp, _sz]),
     "kg_post_smeter": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "kg_post_cfir_init_lp": (_i, [_vp, _i, _i, _i, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "kg_post_cfir_init_const": (_i, [_vp, _i, _i, _i, _vp, C.c_float]),
+    "kg_post_cfir_get_taps": (_i, [_vp, _i, _i, _vp]),
+    "kg_post_cfir_process_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _sz, _i, _vp, _sz]),
+    "kg_post_squelch_perform_dev": (_i, [_vp, _vp, _i, _vp, _sz, _i, _vp, _sz]),
+    "kg_post_set_am_passband": (_i, [_vp, _i, C.c_double, C.c_double, C.c_double]),
+    "kg_post_set_deemp": (_i, [_vp, _i, _i, _i]),
+    "kg_post_squelch_setup": (_i, [_vp, _i, C.c_float]),
+    "kg_post_squelch_set": (_i, [_vp, _i, _i, _i]),
+    "kg_post_squelch_reset": (_i, [_vp, _i]),
+    "kg_post_squelch_state": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "kg_adpcm_create": (_i, [_vp, _i, C.POINTER(_vp)]),
     "kg_adpcm_destroy": (None, [_vp]),
     "kg_adpcm_set_state": (_i, [_vp, _i, _i, _i]),

@@ -1,7 +1,9 @@
-// kg_post.hip -- S-meter, CAgc and the AM / NBFM detectors for many receiver channels.
+// kg_post.hip -- S-meter, CAgc, the AM / NBFM detectors and what follows them up to out_samps_s2 (m_AM_FIR, the NBFM noise
+// squelch, the de-emphasis filters) for many receiver channels.
 //
 // Reference: rx/rx_sound.cpp:676-696 (S-meter), rx/CuteSDR/agc.cpp (CAgc),
-// rx/rx_sound.cpp:766-783 (AM), :845-881 (NBFM).  TYPEREAL is float there and the
+// rx/rx_sound.cpp:766-787 (AM + m_AM_FIR), :845-877 (NBFM + m_Squelch), :898-907 (de-emphasis); rx/CuteSDR/fir.cpp (CFir),
+// rx/CuteSDR/squelch.cpp (CSquelch).  TYPEREAL is float there and the
 // literals are double, so the expressions below keep the reference's operand types
 // (the library is built with -ffp-contract=off): the only operations that can differ
 // from the CPU path are log10f and powf (device libm vs the host's).
@@ -15,7 +17,12 @@
 //     the rescan; the window maximum is computed by log2(W) doubling passes in LDS;
 //   * the two averagers with their data-dependent branches, the hang timer, the S-meter
 //     recurrence and the AM DC-removal IIR are sequential: lane 0 walks the samples;
-//   * gain (powf), scaling, the mono16 cast and the NBFM detector are parallel again.
+//   * gain (powf), scaling, the mono16 cast and the NBFM detector are parallel again;
+//   * CFir::ProcessFilter keeps its samples in a circular buffer and sums coefficient x sample over the BUFFER positions 0 ..
+//     N-1 (fir.cpp:79-91), so the order of the float additions rotates with the write position: sample number g (since the
+//     filter was initialised) starts its sum at the tap of age g mod N, runs up to age N-1 and wraps to age 0.  Restated per
+//     output sample, that is a sum every lane can do for its own sample -- in that order, over a linear history in LDS;
+//   * the squelch's noise average is one more sequential recursion (lane 0); its verdict applies to the whole block.
 #include "kg_common.h"
 
 #include <math.h>
@@ -43,6 +50,21 @@ struct post_chan {
     double z1;                    // rx_sound.cpp:244
     float last_re, last_im;       // conn->last_sample
     int mode;
+    // CSquelch (squelch.cpp:106-107, 122-129) and its state (:67-77)
+    float sq_alpha, sq_value, sq_threshold, sq_ave;
+    int sq_state, sq_set;         // m_SquelchState, m_SetSquelch
+    int sq_rc, squelched;         // the last nsq_nc_sq; s->squelched (rx_sound.cpp:877)
+    int deemp, deemp_nfm;         // s->deemp, s->deemp_nfm (rx_sound_cmd.cpp:554)
+};
+
+#define POST_MAXTAPS 97           // MAX_NUMCOEF, fir.h:20
+#define POST_HIST (POST_MAXTAPS - 1)
+enum { POST_FIR_AM = 0, POST_FIR_SQ_HP = 1, POST_FIR_DEEMP_NFM = 2, POST_FIR_DEEMP_AM_SSB = 3, POST_NFIR = 4 };
+
+struct post_cfir {                // one CFir, real-valued (fir.h:24-52)
+    int ntaps, pos;               // m_NumTaps; samples since the filter was initialised, mod ntaps (m_State = (ntaps - pos) % ntaps)
+    float taps[POST_MAXTAPS];
+    float hist[POST_HIST];        // the last 96 inputs, newest last (m_rZBuf unrolled)
 };
 
 // (TYPEMONO16) v
@@ -54,8 +76,109 @@ __device__ __forceinline__ short post_mono16(float v)
     return (short) (unsigned short) (unsigned) w;
 }
 
+// CFir::ProcessFilter for the n samples at src (fir.cpp:74-92 real -> real; :176-194 / :199-217 -> mono16 when `mono`).
+// X: LDS, POST_HIST + n floats; T: LDS, POST_MAXTAPS floats; src, dst: LDS, dst may be src, neither may overlap X or T.
+__device__ __forceinline__ void post_cfir_block(post_cfir *__restrict__ f, float *X, float *T, const float *src, float *dst, int n,
+                                                int lane, bool mono)
+{
+    const int N = f->ntaps, pos = f->pos;
+    for (int k = lane; k < POST_HIST; k += 64) X[k] = f->hist[k];
+    for (int k = lane; k < N; k += 64) T[k] = f->taps[k];
+    for (int j = lane; j < n; j += 64) X[POST_HIST + j] = src[j];
+    __syncthreads();
+    for (int j = lane; j < n; j += 64) {
+        const float *x = X + POST_HIST + j;
+        int a = (pos + j) % N;                                  // the age at buffer position 0
+        float acc = T[a] * x[-a];                               // "do the 1st MAC"
+        for (int t = 1; t < N; t++) {
+            a = a + 1 == N ? 0 : a + 1;
+            acc += T[a] * x[-a];
+        }
+        dst[j] = mono ? (float) post_mono16(acc) : acc;
+    }
+    __syncthreads();
+    for (int k = lane; k < POST_HIST; k += 64) f->hist[k] = X[n + k];
+    if (lane == 0) f->pos = (pos + n) % N;
+    __syncthreads();
+}
+
+// CSquelch::PerformFMSquelch (squelch.cpp:151-231) for the n detector samples at demod (LDS; demod + KG_POST_MAX_SAMPLES .. + n is
+// scratch): the mono16 output as floats at out (LDS), state and return value into *pc.  X, T as post_cfir_block.
+__device__ __forceinline__ void post_squelch_block(post_chan *__restrict__ pc, const post_chan &c, post_cfir *__restrict__ hp, float *X,
+                                                   float *T, float *demod, float *out, int n, int lane, int *s_sq)
+{
+    float *sqbuf = demod + KG_POST_MAX_SAMPLES;
+    post_cfir_block(hp, X, T, demod, sqbuf, n, lane, false);                                     // :161
+    if (lane == 0) {
+        float ave = c.sq_ave;
+        const double om = 1.0 - c.sq_alpha;
+        for (int i = 0; i < n; i++) {
+            const float mag = fabsf(sqbuf[i]);
+            ave = om * ave + c.sq_alpha * mag;                                                   // :166
+        }
+        int state = c.sq_state, rc = 0;
+        if (c.sq_value == 0) {                                                                   // :176-179
+            if (state) rc = -1;
+            state = 0;
+        } else if (c.sq_threshold == 0) {                                                        // :182-185
+            if (!state) rc = 1;
+            state = 1;
+        } else if (state) {                                                                      // :188-193
+            if (ave < (c.sq_threshold - 50.0)) { rc = -1; state = 0; }
+        } else {                                                                                 // :195-200
+            if (ave >= (c.sq_threshold + 50.0)) { rc = 1; state = 1; }
+        }
+        if (c.sq_set) rc = state ? 1 : -1;                                                       // :218-221
+        pc->sq_ave = ave; pc->sq_state = state; pc->sq_set = 0; pc->sq_rc = rc;
+        if (rc != 0) pc->squelched = rc == 1;                                                    // rx_sound.cpp:877
+        *s_sq = state;
+    }
+    __syncthreads();
+    const int squelched = *s_sq;
+    for (int j = lane; j < n; j += 64) out[j] = squelched ? 1.0f : (float) post_mono16(demod[j]);   // :205-207, :214-215
+    __syncthreads();
+}
+
+// The two seams called on their own: m_*_FIR[ch].ProcessFilter(n, in, out) (kind 0: real -> real, 1: real -> mono16, 2: mono16 ->
+// mono16) and m_Squelch[ch].PerformFMSquelch(n, in, out) -- the same device functions as the fused pass below.
+__global__ __launch_bounds__(64) void post_cfir_kernel(post_cfir *__restrict__ cfir_tab, const int *__restrict__ chans, int slot, int kind,
+                                                       const void *__restrict__ in, size_t in_stride, int n, void *__restrict__ out,
+                                                       size_t out_stride)
+{
+    __shared__ float X[POST_HIST + KG_POST_MAX_SAMPLES];
+    __shared__ float buf[KG_POST_MAX_SAMPLES];
+    __shared__ float T[POST_MAXTAPS];
+    const int lane = threadIdx.x, row = blockIdx.x, ch = chans[row];
+    for (int j = lane; j < n; j += 64)
+        buf[j] = kind == 2 ? (float) ((const short *) in)[(size_t) row * in_stride + j] : ((const float *) in)[(size_t) row * in_stride + j];
+    __syncthreads();
+    post_cfir_block(cfir_tab + (size_t) ch * POST_NFIR + slot, X, T, buf, buf, n, lane, kind != 0);
+    for (int j = lane; j < n; j += 64) {
+        if (kind == 0) ((float *) out)[(size_t) row * out_stride + j] = buf[j];
+        else ((short *) out)[(size_t) row * out_stride + j] = (short) buf[j];
+    }
+}
+
+__global__ __launch_bounds__(64) void post_squelch_kernel(post_chan *__restrict__ chan_tab, post_cfir *__restrict__ cfir_tab,
+                                                          const int *__restrict__ chans, const float *__restrict__ in, size_t in_stride, int n,
+                                                          short *__restrict__ out, size_t out_stride)
+{
+    __shared__ float X[POST_HIST + KG_POST_MAX_SAMPLES];
+    __shared__ float demod[2 * KG_POST_MAX_SAMPLES];
+    __shared__ float res[KG_POST_MAX_SAMPLES];
+    __shared__ float T[POST_MAXTAPS];
+    __shared__ int s_sq;
+    const int lane = threadIdx.x, row = blockIdx.x, ch = chans[row];
+    post_chan *pc = &chan_tab[ch];
+    const post_chan c = *pc;
+    for (int j = lane; j < n; j += 64) demod[j] = in[(size_t) row * in_stride + j];
+    __syncthreads();
+    post_squelch_block(pc, c, cfir_tab + (size_t) ch * POST_NFIR + POST_FIR_SQ_HP, X, T, demod, res, n, lane, &s_sq);
+    for (int j = lane; j < n; j += 64) out[(size_t) row * out_stride + j] = (short) res[j];
+}
+
 __global__ __launch_bounds__(64) void post_kernel(
-    post_chan *__restrict__ chan_tab, float2 *__restrict__ ring_in, float *__restrict__ ring_mag,
+    post_chan *__restrict__ chan_tab, post_cfir *__restrict__ cfir_tab, float2 *__restrict__ ring_in, float *__restrict__ ring_mag,
     const int *__restrict__ chans, const float2 *__restrict__ fir, size_t in_stride, int n,
     short *__restrict__ o_s16, float *__restrict__ o_demod, float2 *__restrict__ o_agc, size_t out_stride)
 {
@@ -63,6 +186,8 @@ __global__ __launch_bounds__(64) void post_kernel(
     __shared__ float bufB[POST_MAXW + KG_POST_MAX_SAMPLES];
     __shared__ float s_db[KG_POST_MAX_SAMPLES];
     __shared__ float2 s_agc[KG_POST_MAX_SAMPLES];
+    __shared__ float s_taps[POST_MAXTAPS];
+    __shared__ int s_sq;
     // one wave per channel walking sequential recursions (S-meter, CAgc): latency, among workgroups that fill the vector
     // units -- it takes the issue priority (beside the DDCs' run passes the kernel stretched from 77 to 450 .. 980 us)
     __builtin_amdgcn_s_setprio(3);
@@ -183,10 +308,14 @@ __global__ __launch_bounds__(64) void post_kernel(
             const float pwr = y.x * y.x + y.y * y.y;
             s_db[j] = sqrtf(pwr);
         }
-        if (c.mode == KG_POST_SSB && ps16) ps16[j] = post_mono16(mono);
+        if (c.mode == KG_POST_SSB) {                    // rx_sound.cpp:893
+            if (c.deemp) s_db[j] = (float) post_mono16(mono);
+            else if (ps16) ps16[j] = post_mono16(mono);
+        }
         if (pagc && c.mode != KG_POST_SSB) pagc[j] = y;
     }
     __syncthreads();
+    post_cfir *fir4 = cfir_tab + (size_t) ch * POST_NFIR;
 
     if (c.mode == KG_POST_AM) {
         // rx_sound.cpp:773-779: the DC-removal IIR is a recurrence -> lane 0; the envelope
@@ -204,6 +333,8 @@ __global__ __launch_bounds__(64) void post_kernel(
         __syncthreads();
         if (pdem)
             for (int j = lane; j < n; j += 64) pdem[j] = s_dm[j];
+        // rx_sound.cpp:787: m_AM_FIR.ProcessFilter(ns_out, demod_samps_r, out_samps_s2)
+        post_cfir_block(fir4 + POST_FIR_AM, bufB, s_taps, s_dm, s_db, n, lane, true);
     } else if (c.mode == KG_POST_NBFM) {
         // rx_sound.cpp:845-881
         const float max_val = 32767, clipper_val = 8192;
@@ -216,9 +347,22 @@ __global__ __launch_bounds__(64) void post_kernel(
                                (i * (q - qL) - q * (i - iL)) / pwr) : 0;
             out = out < -clipper_val ? -clipper_val : (out > clipper_val ? clipper_val : out);
             if (pdem) pdem[j] = out;
+            bufA[j] = out;
         }
         if (lane == 0 && n > 0) { pc->last_re = s_agc[n - 1].x; pc->last_im = s_agc[n - 1].y; }
+        __syncthreads();
+        // rx_sound.cpp:876: m_Squelch.PerformFMSquelch(ns_out, demod_samps_r, out_samps_s2)
+        post_squelch_block(pc, c, fir4 + POST_FIR_SQ_HP, bufB, s_taps, bufA, s_db, n, lane, &s_sq);
     }
+    if (c.mode == KG_POST_IQ) return;
+    // rx_sound.cpp:898-907: de-emphasis, out_samps_s2 in place
+    const bool nbfm = c.mode == KG_POST_NBFM;
+    const bool de_emp = nbfm ? c.deemp_nfm != 0 : c.deemp != 0;
+    if (c.mode == KG_POST_SSB && !de_emp) return;               // written by the gain loop
+    if (de_emp)
+        post_cfir_block(fir4 + (nbfm ? POST_FIR_DEEMP_NFM : POST_FIR_DEEMP_AM_SSB), bufB, s_taps, s_db, s_db, n, lane, true);
+    if (ps16)
+        for (int j = lane; j < n; j += 64) ps16[j] = (short) s_db[j];
 }
 
 __global__ void post_reset_rings_kernel(float2 *ring_in, float *ring_mag, int ch0)
@@ -244,8 +388,12 @@ struct kg_post {
     post_chan *d_chan;
     float2 *d_ring_in;
     float *d_ring_mag;
+    post_cfir *d_cfir;                   // [nchan][POST_NFIR]
     std::vector<post_chan> h_chan;       // parameters only; the state lives on the device
     std::vector<post_host> h_args;
+    std::vector<post_cfir> h_cfir;       // taps as designed / handed over; pos and hist are the device's
+    std::vector<char> h_fir_ready;       // [nchan][POST_NFIR]: initialised since create
+    std::vector<char> h_sq_ready;        // kg_post_squelch_setup AND kg_post_squelch_set were called
     kg_stage_cache list_cache = {};      // the channel list of the last process call
 };
 
@@ -265,6 +413,118 @@ template <typename T> static int post_put(kg_post *p, int ch, T post_chan::*fiel
     KG_HIP(hipMemcpyAsync((char *) (p->d_chan + ch) + off, &(p->h_chan[ch].*field), sizeof(T),
                           hipMemcpyHostToDevice, p->ctx->stream));
     return KG_OK;
+}
+
+// ---- CFir designs (fir.cpp:282-384 InitLPFilter, :403-486 InitHPFilter, :538-555 Izero): host arithmetic, operand types as there
+namespace cfir_design {
+static const double K_2PI = 2.0 * 3.14159265358979323846, K_PI = 3.14159265358979323846;      // datatypes.h:103-104
+
+static float izero(float x)
+{
+    const float x2 = x / 2.0;
+    float sum = 1.0, ds = 1.0, di = 1.0, tmp;
+    const float errorlimit = 1e-9;
+    do {
+        tmp = x2 / di;
+        tmp *= tmp;
+        ds *= tmp;
+        sum += ds;
+        di += 1.0;
+    } while (ds >= errorlimit * sum);
+    return sum;
+}
+
+static float beta_of(float Astop)                             // :294-301 = :415-422
+{
+    if (Astop < 20.96) return 0;
+    if (Astop >= 50.0) return .1102 * (Astop - 8.71);
+    return .5842 * powf((Astop - 20.96), 0.4) + .07886 * (Astop - 20.96);
+}
+
+// (int) of the tap estimate; Fstop == Fpass makes it infinite, whose conversion C leaves undefined: as x86 converts it
+static int to_int(double v) { return (v > -2147483649.0 && v < 2147483648.0) ? (int) v : (int) 0x80000000u; }
+
+static float kaiser(int n, int ntaps, float Beta, float izb, float Scale, float c)             // :327-328 = :451-452
+{
+    const float x = ((float) n - ((float) ntaps - 1.0) / 2.0) / (((float) ntaps - 1.0) / 2.0);
+    return Scale * c * izero(Beta * sqrtf(1 - (x * x))) / izb;
+}
+
+static int lowpass(int NumTaps, float Scale, float Astop, float Fpass, float Fstop, float Fsamprate, float *coef)
+{
+    const float normFpass = Fpass / Fsamprate, normFstop = Fstop / Fsamprate;
+    const float normFcut = (normFstop + normFpass) / 2.0;
+    const float Beta = beta_of(Astop);
+    int ntaps = to_int((Astop - 8.0) / (2.285 * K_2PI * (normFstop - normFpass)) + 1);          // :304
+    if (ntaps > POST_MAXTAPS) ntaps = POST_MAXTAPS;
+    if (ntaps < 9) ntaps = 9;
+    if (NumTaps) ntaps = NumTaps;
+    const float fCenter = .5 * (float) (ntaps - 1);
+    const float izb = izero(Beta);
+    for (int n = 0; n < ntaps; n++) {
+        const float x = (float) n - fCenter;
+        float c;
+        if ((float) n == fCenter) c = 2.0 * normFcut;                                           // :322-323
+        else c = (float) sinf(K_2PI * x * normFcut) / (K_PI * x);                               // :325
+        coef[n] = kaiser(n, ntaps, Beta, izb, Scale, c);
+    }
+    return ntaps;
+}
+
+static int highpass(int NumTaps, float Scale, float Astop, float Fpass, float Fstop, float Fsamprate, float *coef)
+{
+    const float normFpass = Fpass / Fsamprate, normFstop = Fstop / Fsamprate;
+    const float normFcut = (normFstop + normFpass) / 2.0;
+    const float Beta = beta_of(Astop);
+    int ntaps = to_int((Astop - 8.0) / (2.285 * K_2PI * (normFpass - normFstop)) + 1);          // :425
+    if (ntaps > (POST_MAXTAPS - 1)) ntaps = POST_MAXTAPS - 1;
+    if (ntaps < 3) ntaps = 3;
+    ntaps |= 1;                                                                                 // :433
+    if (NumTaps) ntaps = NumTaps;
+    const float izb = izero(Beta);
+    const float fCenter = .5 * (float) (ntaps - 1);
+    for (int n = 0; n < ntaps; n++) {
+        const float x = (float) n - (float) (ntaps - 1) / 2.0;                                  // :442
+        float c;
+        if ((float) n == fCenter) c = 1.0 - 2.0 * normFcut;                                     // :446
+        else c = (float) (sinf(K_PI * x) / (K_PI * x) - sinf(K_2PI * x * normFcut) / (K_PI * x));   // :448
+        coef[n] = kaiser(n, ntaps, Beta, izb, Scale, c);
+    }
+    return ntaps;
+}
+}  // namespace cfir_design
+
+// A freshly initialised CFir on the device: the taps of h_cfir, zeroed buffer, m_State = 0 (fir.cpp:230-236, :344-350)
+static int post_cfir_upload(kg_post *p, int ch, int which)
+{
+    post_cfir &f = p->h_cfir[(size_t) ch * POST_NFIR + which];
+    f.pos = 0;
+    memset(f.hist, 0, sizeof f.hist);
+    KG_HIP(hipMemcpyAsync(p->d_cfir + (size_t) ch * POST_NFIR + which, &f, sizeof f, hipMemcpyHostToDevice, p->ctx->stream));
+    KG_HIP(hipStreamSynchronize(p->ctx->stream));
+    p->h_fir_ready[(size_t) ch * POST_NFIR + which] = 1;
+    return KG_OK;
+}
+
+static int post_which(int which, bool init, const char *who)
+{
+    KG_REQUIRE(which == KG_CFIR_AM || which == KG_CFIR_DEEMP_NFM || which == KG_CFIR_DEEMP_AM_SSB || (!init && which == KG_CFIR_SQUELCH_HP),
+               KG_ERR_INVALID, "%s: filter %d (KG_CFIR_AM, KG_CFIR_DEEMP_NFM, KG_CFIR_DEEMP_AM_SSB%s)", who, which,
+               init ? "; the squelch's high-pass is designed by kg_post_squelch_setup" : ", KG_CFIR_SQUELCH_HP");
+    return KG_OK;
+}
+static const int POST_WHICH_SLOT[4] = {POST_FIR_AM, POST_FIR_DEEMP_NFM, POST_FIR_DEEMP_AM_SSB, POST_FIR_SQ_HP};
+
+static int post_list(kg_post *p, const int32_t *chans, int nch, const char *who, void **d_list)
+{
+    KG_REQUIRE(nch >= 1 && nch <= p->nchan, KG_ERR_INVALID, "%s: nch %d", who, nch);
+    std::vector<char> seen(p->nchan, 0);
+    for (int i = 0; i < nch; i++) {
+        KG_REQUIRE(chans[i] >= 0 && chans[i] < p->nchan && !seen[chans[i]], KG_ERR_INVALID,
+                   "%s: chans[%d] = %d out of range or listed twice", who, i, chans[i]);
+        seen[chans[i]] = 1;
+    }
+    return kg_ctx_stage_cached(p->ctx, &p->list_cache, chans, sizeof(int) * nch, d_list);
 }
 
 static int post_reset_agc_state(kg_post *p, int ch)         // agc.cpp:117-131
@@ -295,12 +555,21 @@ int kg_post_create(kg_ctx *ctx, int nchan, kg_post **out)
     KG_HIP(hipMalloc((void **) &p->d_chan, sizeof(post_chan) * nchan));
     KG_HIP(hipMalloc((void **) &p->d_ring_in, sizeof(float2) * POST_CIRC * (size_t) nchan));
     KG_HIP(hipMalloc((void **) &p->d_ring_mag, sizeof(float) * POST_CIRC * (size_t) nchan));
+    KG_HIP(hipMalloc((void **) &p->d_cfir, sizeof(post_cfir) * POST_NFIR * (size_t) nchan));
+    post_cfir f0;
+    memset(&f0, 0, sizeof f0);
+    f0.ntaps = 1;                                   // CFir::CFir(), fir.cpp:60-64 (its coefficient is indeterminate there: 0 here;
+    p->h_cfir.assign((size_t) nchan * POST_NFIR, f0);      // a mode that needs an uninitialised filter is refused, kg_post_process_dev)
+    p->h_fir_ready.assign((size_t) nchan * POST_NFIR, 0);
+    p->h_sq_ready.assign(nchan, 0);
+    KG_HIP(hipMemcpyAsync(p->d_cfir, p->h_cfir.data(), sizeof(post_cfir) * p->h_cfir.size(), hipMemcpyHostToDevice, ctx->stream));
     post_chan z;
     memset(&z, 0, sizeof z);
     z.agc_on = 1;                                   // CAgc::CAgc(), agc.cpp:77-86
     z.delay_samples = 1; z.window_samples = 1;      // (int)(100.0 * .015), (int)(100.0 * .018)
     z.decay_ave = -5.0f; z.attack_ave = -5.0f;
     z.mode = KG_POST_SSB;
+    z.sq_state = 1;                                 // CSquelch::Reset(), squelch.cpp:67-77
     p->h_chan.assign(nchan, z);
     post_host a = {1, 0, 0, 0, 0, 0.f, 100.0f};
     p->h_args.assign(nchan, a);
@@ -318,7 +587,7 @@ void kg_post_destroy(kg_post *p)
     if (!p) return;
     (void) hipSetDevice(p->ctx->device);
     (void) hipStreamSynchronize(p->ctx->stream);
-    (void) hipFree(p->d_chan); (void) hipFree(p->d_ring_in); (void) hipFree(p->d_ring_mag);
+    (void) hipFree(p->d_chan); (void) hipFree(p->d_ring_in); (void) hipFree(p->d_ring_mag); (void) hipFree(p->d_cfir);
     kg_stage_cache_free(&p->list_cache);
     delete p;
 }
@@ -433,15 +702,179 @@ int kg_post_process_dev(kg_post *p, const int32_t *chans, int nch, const void *d
         KG_REQUIRE(chans[i] >= 0 && chans[i] < p->nchan && !seen[chans[i]], KG_ERR_INVALID,
                    "kg_post_process_dev: chans[%d] = %d out of range or listed twice", i, chans[i]);
         seen[chans[i]] = 1;
+        const int ch = chans[i], mode = p->h_chan[ch].mode;
+        const char *fr = &p->h_fir_ready[(size_t) ch * POST_NFIR];
+        KG_REQUIRE(mode != KG_POST_AM || fr[POST_FIR_AM], KG_ERR_STATE,
+                   "kg_post_process_dev: channel %d is in AM mode and its m_AM_FIR was never designed (kg_post_set_am_passband)", ch);
+        KG_REQUIRE(mode != KG_POST_NBFM || p->h_sq_ready[ch], KG_ERR_STATE,
+                   "kg_post_process_dev: channel %d is in NBFM mode without kg_post_squelch_setup + kg_post_squelch_set (rx_sound.cpp:261-262)", ch);
+        KG_REQUIRE(!(mode == KG_POST_NBFM && p->h_chan[ch].deemp_nfm) || fr[POST_FIR_DEEMP_NFM], KG_ERR_STATE,
+                   "kg_post_process_dev: channel %d has NBFM de-emphasis on and no m_nfm_deemp_FIR coefficients", ch);
+        KG_REQUIRE(!((mode == KG_POST_AM || mode == KG_POST_SSB) && p->h_chan[ch].deemp) || fr[POST_FIR_DEEMP_AM_SSB], KG_ERR_STATE,
+                   "kg_post_process_dev: channel %d has AM/SSB de-emphasis on and no m_am_ssb_deemp_FIR coefficients", ch);
     }
     hipStream_t st = p->ctx->stream;
     void *d_list = nullptr;
     if ((rc = kg_ctx_stage_cached(p->ctx, &p->list_cache, chans, sizeof(int) * nch, &d_list))) return rc;
     KG_PLAN_ONLY(p->ctx);
-    hipLaunchKernelGGL(post_kernel, dim3(nch), dim3(64), 0, st, p->d_chan, p->d_ring_in, p->d_ring_mag,
+    hipLaunchKernelGGL(post_kernel, dim3(nch), dim3(64), 0, st, p->d_chan, p->d_cfir, p->d_ring_in, p->d_ring_mag,
                        (const int *) d_list, (const float2 *) d_fir, in_stride, nsamps,
                        (short *) d_s16, (float *) d_demod, (float2 *) d_agc, out_stride);
     KG_HIP(hipGetLastError());
+    return KG_OK;
+}
+
+int kg_post_cfir_init_lp(kg_post *p, int ch, int which, int NumTaps, float Scale, float Astop, float Fpass, float Fstop, float Fsamprate)
+{
+    int rc = post_check(p, ch, "kg_post_cfir_init_lp");
+    if (rc || (rc = post_which(which, true, "kg_post_cfir_init_lp"))) return rc;
+    KG_REQUIRE(NumTaps >= 0 && NumTaps <= POST_MAXTAPS && Fsamprate > 0.f, KG_ERR_INVALID,
+               "kg_post_cfir_init_lp: NumTaps %d (0..%d), sample rate %g", NumTaps, POST_MAXTAPS, (double) Fsamprate);
+    post_cfir &f = p->h_cfir[(size_t) ch * POST_NFIR + POST_WHICH_SLOT[which]];
+    f.ntaps = cfir_design::lowpass(NumTaps, Scale, Astop, Fpass, Fstop, Fsamprate, f.taps);
+    if ((rc = post_cfir_upload(p, ch, POST_WHICH_SLOT[which]))) return rc;
+    return f.ntaps;
+}
+
+int kg_post_cfir_init_const(kg_post *p, int ch, int which, int NumTaps, const float *coef, float Fsamprate)
+{
+    int rc = post_check(p, ch, "kg_post_cfir_init_const");
+    if (rc || (rc = post_which(which, true, "kg_post_cfir_init_const"))) return rc;
+    KG_REQUIRE(coef != nullptr && NumTaps >= 1, KG_ERR_INVALID, "kg_post_cfir_init_const: %d coefficients at %p", NumTaps, (const void *) coef);
+    (void) Fsamprate;                                           // m_SampleRate is only used by GenerateHBFilter
+    post_cfir &f = p->h_cfir[(size_t) ch * POST_NFIR + POST_WHICH_SLOT[which]];
+    f.ntaps = NumTaps > POST_MAXTAPS ? POST_MAXTAPS : NumTaps;  // fir.cpp:223-226
+    memcpy(f.taps, coef, sizeof(float) * (size_t) f.ntaps);
+    if ((rc = post_cfir_upload(p, ch, POST_WHICH_SLOT[which]))) return rc;
+    return f.ntaps;
+}
+
+int kg_post_cfir_get_taps(kg_post *p, int ch, int which, float *taps)
+{
+    int rc = post_check(p, ch, "kg_post_cfir_get_taps");
+    if (rc || (rc = post_which(which, false, "kg_post_cfir_get_taps"))) return rc;
+    const post_cfir &f = p->h_cfir[(size_t) ch * POST_NFIR + POST_WHICH_SLOT[which]];
+    if (taps) memcpy(taps, f.taps, sizeof(float) * (size_t) f.ntaps);
+    return f.ntaps;
+}
+
+int kg_post_cfir_process_dev(kg_post *p, const int32_t *chans, int nch, int which, int kind, const void *d_in, size_t in_stride, int nsamps,
+                             void *d_out, size_t out_stride)
+{
+    KG_REQUIRE(p && chans && d_in && d_out, KG_ERR_INVALID, "kg_post_cfir_process_dev: null argument");
+    int rc = kg_ctx_use(p->ctx);
+    if (rc || (rc = post_which(which, false, "kg_post_cfir_process_dev"))) return rc;
+    KG_REQUIRE(kind >= KG_CFIR_REAL_REAL && kind <= KG_CFIR_MONO16_MONO16, KG_ERR_INVALID, "kg_post_cfir_process_dev: kind %d", kind);
+    KG_REQUIRE(nsamps >= 1 && nsamps <= KG_POST_MAX_SAMPLES && in_stride >= (size_t) nsamps && out_stride >= (size_t) nsamps, KG_ERR_INVALID,
+               "kg_post_cfir_process_dev: nsamps %d (1..%d), strides %zu / %zu", nsamps, KG_POST_MAX_SAMPLES, in_stride, out_stride);
+    void *d_list = nullptr;
+    if ((rc = post_list(p, chans, nch, "kg_post_cfir_process_dev", &d_list))) return rc;
+    for (int i = 0; i < nch; i++)
+        KG_REQUIRE(p->h_fir_ready[(size_t) chans[i] * POST_NFIR + POST_WHICH_SLOT[which]], KG_ERR_STATE,
+                   "kg_post_cfir_process_dev: filter %d of channel %d was never initialised", which, chans[i]);
+    KG_PLAN_ONLY(p->ctx);
+    hipLaunchKernelGGL(post_cfir_kernel, dim3(nch), dim3(64), 0, p->ctx->stream, p->d_cfir, (const int *) d_list, POST_WHICH_SLOT[which], kind,
+                       d_in, in_stride, nsamps, d_out, out_stride);
+    KG_HIP(hipGetLastError());
+    return KG_OK;
+}
+
+int kg_post_squelch_perform_dev(kg_post *p, const int32_t *chans, int nch, const void *d_in, size_t in_stride, int nsamps, void *d_out,
+                                size_t out_stride)
+{
+    KG_REQUIRE(p && chans && d_in && d_out, KG_ERR_INVALID, "kg_post_squelch_perform_dev: null argument");
+    int rc = kg_ctx_use(p->ctx);
+    if (rc) return rc;
+    KG_REQUIRE(nsamps >= 1 && nsamps <= KG_POST_MAX_SAMPLES && in_stride >= (size_t) nsamps && out_stride >= (size_t) nsamps, KG_ERR_INVALID,
+               "kg_post_squelch_perform_dev: nsamps %d (1..%d; squelch.cpp:155 returns at once past 1024), strides %zu / %zu", nsamps,
+               KG_POST_MAX_SAMPLES, in_stride, out_stride);
+    void *d_list = nullptr;
+    if ((rc = post_list(p, chans, nch, "kg_post_squelch_perform_dev", &d_list))) return rc;
+    for (int i = 0; i < nch; i++)
+        KG_REQUIRE(p->h_sq_ready[chans[i]], KG_ERR_STATE, "kg_post_squelch_perform_dev: channel %d: kg_post_squelch_setup + kg_post_squelch_set first",
+                   chans[i]);
+    KG_PLAN_ONLY(p->ctx);
+    hipLaunchKernelGGL(post_squelch_kernel, dim3(nch), dim3(64), 0, p->ctx->stream, p->d_chan, p->d_cfir, (const int *) d_list,
+                       (const float *) d_in, in_stride, nsamps, (short *) d_out, out_stride);
+    KG_HIP(hipGetLastError());
+    return KG_OK;
+}
+
+int kg_post_set_am_passband(kg_post *p, int ch, double locut, double hicut, double frate)
+{
+    // rx_sound_cmd.cpp:268-282: "hbw for post AM det is max of hi/lo filter cuts"
+    float hbw = fmaxf(fabs(hicut), fabs(locut));
+    if (hbw > frate / 2) hbw = frate / 2;
+    float stop = hbw * 1.8;
+    if (stop > frate / 2) stop = frate / 2;
+    return kg_post_cfir_init_lp(p, ch, KG_CFIR_AM, 0, 1.0, 50.0, hbw, stop, frate);
+}
+
+int kg_post_set_deemp(kg_post *p, int ch, int nfm, int de_emp)
+{
+    int rc = post_check(p, ch, "kg_post_set_deemp");
+    if (rc) return rc;
+    if ((rc = post_put(p, ch, nfm ? &post_chan::deemp_nfm : &post_chan::deemp, de_emp))) return rc;     // rx_sound_cmd.cpp:554
+    KG_HIP(hipStreamSynchronize(p->ctx->stream));
+    return KG_OK;
+}
+
+int kg_post_squelch_setup(kg_post *p, int ch, float samplerate)
+{
+    int rc = post_check(p, ch, "kg_post_squelch_setup");
+    if (rc) return rc;
+    KG_REQUIRE(samplerate > 0.f, KG_ERR_INVALID, "kg_post_squelch_setup: sample rate %g", (double) samplerate);
+    // squelch.cpp:84-116: the noise average's time constant, the high-pass above the voice band (:135-139), Reset()
+    const float squelch_hp_freq = 3000.0;                                                       // VOICE_BANDWIDTH, :46, :106
+    const float alpha = (1.0 - expf(-1.0 / (samplerate * .02)));                                // :107
+    post_cfir &f = p->h_cfir[(size_t) ch * POST_NFIR + POST_FIR_SQ_HP];
+    f.ntaps = cfir_design::highpass(0, 1.0, 50.0, squelch_hp_freq * .8, squelch_hp_freq * .65, samplerate, f.taps);
+    if ((rc = post_cfir_upload(p, ch, POST_FIR_SQ_HP))) return rc;
+    if ((rc = post_put(p, ch, &post_chan::sq_alpha, alpha))) return rc;
+    return kg_post_squelch_reset(p, ch);
+}
+
+int kg_post_squelch_reset(kg_post *p, int ch)                   // squelch.cpp:67-77
+{
+    int rc = post_check(p, ch, "kg_post_squelch_reset");
+    if (rc) return rc;
+    if ((rc = post_put(p, ch, &post_chan::sq_ave, 0.f))) return rc;
+    if ((rc = post_put(p, ch, &post_chan::sq_state, 1))) return rc;
+    if ((rc = post_put(p, ch, &post_chan::sq_set, 0))) return rc;
+    KG_HIP(hipStreamSynchronize(p->ctx->stream));
+    return KG_OK;
+}
+
+int kg_post_squelch_set(kg_post *p, int ch, int Value, int SquelchMax)
+{
+    int rc = post_check(p, ch, "kg_post_squelch_set");
+    if (rc) return rc;
+    KG_REQUIRE(p->h_fir_ready[(size_t) ch * POST_NFIR + POST_FIR_SQ_HP], KG_ERR_STATE,
+               "kg_post_squelch_set: kg_post_squelch_setup first (rx_sound.cpp:261-262)");
+    if (SquelchMax == 0) SquelchMax = 8192;                                                     // SQUELCH_MAX = CLIPPER_NBFM_VAL, squelch.cpp:57
+    const float threshold = (float) (SquelchMax - ((SquelchMax * Value) / 99));                 // :126
+    if ((rc = post_put(p, ch, &post_chan::sq_value, (float) Value))) return rc;
+    if ((rc = post_put(p, ch, &post_chan::sq_threshold, threshold))) return rc;
+    if ((rc = post_put(p, ch, &post_chan::sq_set, 1))) return rc;
+    KG_HIP(hipStreamSynchronize(p->ctx->stream));
+    p->h_sq_ready[ch] = 1;
+    return KG_OK;
+}
+
+int kg_post_squelch_state(kg_post *p, const int32_t *chans, int nch, int32_t *nsq_nc_sq, int32_t *squelched, float *ave)
+{
+    KG_REQUIRE(p && chans, KG_ERR_INVALID, "kg_post_squelch_state: null argument");
+    int rc = kg_ctx_use(p->ctx);
+    if (rc) return rc;
+    std::vector<post_chan> h(p->nchan);
+    KG_HIP(hipMemcpyAsync(h.data(), p->d_chan, sizeof(post_chan) * p->nchan, hipMemcpyDeviceToHost, p->ctx->stream));
+    KG_HIP(hipStreamSynchronize(p->ctx->stream));
+    for (int i = 0; i < nch; i++) {
+        KG_REQUIRE(chans[i] >= 0 && chans[i] < p->nchan, KG_ERR_INVALID, "kg_post_squelch_state: chans[%d] = %d", i, chans[i]);
+        if (nsq_nc_sq) nsq_nc_sq[i] = h[chans[i]].sq_rc;
+        if (squelched) squelched[i] = h[chans[i]].squelched;
+        if (ave) ave[i] = h[chans[i]].sq_ave;
+    }
     return KG_OK;
 }
 

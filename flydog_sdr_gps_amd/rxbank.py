@@ -95,6 +95,7 @@ class RxBank:
         self.params = [None] * nrx
         self.overlapped = [False] * nrx
         self.rx_inc = [0] * nrx
+        self.audio = [None] * nrx                       # (mode, lo, hi, fs, de_emp, squelch) as set_audio configured it
         self.fs = ADC_CLOCK / self.rxddc.decim          # RX_DECIM (rx4 / rx8, rx14) or RX_DECIM_WIDE (rx3)
 
     def close(self):
@@ -122,16 +123,29 @@ class RxBank:
               "kg_rxbank_set_wf_pkt")
         self.params[rx], self.overlapped[rx] = params, bool(overlapped)
 
-    def set_audio(self, rx, phase_inc, lo=300.0, hi=2700.0, fs=None, mode=post_mod.MODE_SSB):
-        """`SET mod= low_cut= high_cut= freq=` of receiver rx: NCO, passband filter, AGC / S-meter / detector."""
+    def set_audio(self, rx, phase_inc, lo=300.0, hi=2700.0, fs=None, mode=post_mod.MODE_SSB, de_emp=0, squelch=0):
+        """A connection's `SET mod= low_cut= high_cut= freq=`, `SET de_emp=`, `SET squelch=` for receiver rx: NCO, passband
+        filter and the post-AM-detector filter designed with it (rx/rx_sound_cmd.cpp:268-282), AGC / S-meter / detector, the
+        squelch of a new connection (rx/rx_sound.cpp:261-262) then the command's value, the mode's de-emphasis filter."""
         fs = self.fs if fs is None else fs
         self.rxddc.set_freq(rx, phase_inc)
         self.fir.setup(rx, lo, hi, 0.0, fs)
+        self.post.set_am_passband(rx, lo, hi, fs)
         self.post.set_agc(rx, True, False, -100, 50, 6, 1000, fs)
         self.post.set_smeter(rx, fs)
         self.post.set_mode(rx, mode)
         self.post.reset(rx)
+        self.post.squelch_setup(rx, fs)
+        self.post.squelch_set(rx, 0, 0)
+        if squelch:
+            self.post.squelch_set(rx, squelch, 0)
+        nfm = mode == post_mod.MODE_NBFM
+        self.post.set_deemp(rx, True, 0)
+        self.post.set_deemp(rx, False, 0)
+        if de_emp:
+            self.post.set_de_emp(rx, de_emp, nfm, snd_rate_12k=abs(fs - 12000.0) < abs(fs - 20250.0), frate=fs)
         self.rx_inc[rx] = int(phase_inc)
+        self.audio[rx] = (int(mode), float(lo), float(hi), float(fs), int(de_emp), int(squelch))
 
     def configure(self, mix):
         """mix: [(WfParams, overlapped, audio phase increment)] per receiver (survey_mix / light_mix)."""

@@ -410,11 +410,12 @@ int kg_fir_process_dev(kg_fir *fir, const int32_t *chans, int nch, const void *d
 typedef struct kg_post kg_post;
 
 enum {                      /* what follows the S-meter for a channel (the `switch (s->mode)` of :763-900) */
-    KG_POST_IQ   = 0,       /* MODE_IQ/DRM: CAgc complex -> complex (rx_sound.cpp:1096-1100)       -> d_agc   */
-    KG_POST_SSB  = 1,       /* MODE_USB/USN/LSB/LSN/CW/CWN: CAgc complex -> mono16 (:893)          -> d_s16   */
-    KG_POST_AM   = 2,       /* MODE_AM/AMN: CAgc, envelope, DC-removal IIR (:766-783)              -> d_demod */
-    KG_POST_NBFM = 3        /* MODE_NBFM/NNFM: CAgc, fmdemod_quadri + clipper (:845-881)           -> d_demod */
-};
+    KG_POST_IQ   = 0,       /* MODE_IQ/DRM: CAgc complex -> complex (rx_sound.cpp:1096-1100)                      -> d_agc */
+    KG_POST_SSB  = 1,       /* MODE_USB/USN/LSB/LSN/CW/CWN: CAgc complex -> mono16 (:893)                         -> d_s16 */
+    KG_POST_AM   = 2,       /* MODE_AM/AMN: CAgc, envelope, DC-removal IIR (:766-783) -> d_demod; m_AM_FIR (:787) -> d_s16 */
+    KG_POST_NBFM = 3        /* MODE_NBFM/NNFM: CAgc, fmdemod_quadri + clipper (:845-875) -> d_demod;
+                             * m_Squelch.PerformFMSquelch (:876, rx/CuteSDR/squelch.cpp:151-231)                  -> d_s16 */
+};                          /* SSB, AM, NBFM: then the de-emphasis filter over d_s16 in place when it is on (:898-907)   */
 
 #define KG_POST_MAX_SAMPLES 1024  /* per call and channel; c2s_sound() hands over ns_out = 512 */
 
@@ -435,12 +436,56 @@ int kg_post_set_mode(kg_post *post, int chan, int mode);
  * conn->last_sample = 0.  The AGC object persists across connections, as m_Agc[] does. */
 int kg_post_reset(kg_post *post, int chan);
 /* One pass over nsamps FIR output samples of each listed channel (d_fir + i*in_stride,
- * complex float).  Outputs (any may be NULL) at row i*out_stride of d_s16 (int16),
- * d_demod (float), d_agc (complex float), by the channel's mode.  Float -> mono16 is
+ * complex float).  Outputs (any may be NULL) at row i*out_stride of d_s16 (int16: out_samps_s2, every
+ * mode but IQ), d_demod (float: the detector's output, AM / NBFM), d_agc (complex float: the AGC's output,
+ * every mode but SSB).  Float -> mono16 is
  * the reference's (TYPEMONO16) cast: truncation; outside the int16 range (undefined in
  * C) the low 16 bits of the int32 conversion, as x86 does.  Enqueue only. */
 int kg_post_process_dev(kg_post *post, const int32_t *chans, int nch, const void *d_fir, size_t in_stride,
                         int nsamps, void *d_s16, void *d_demod, void *d_agc, size_t out_stride);
+/* The CFir objects of a channel (rx/rx_sound.cpp:153-156; rx/CuteSDR/fir.cpp): the filter behind the AM detector and the
+ * two de-emphasis filters.  (CSquelch owns a fourth, its noise high-pass: kg_post_squelch_setup.) */
+enum { KG_CFIR_AM = 0, KG_CFIR_DEEMP_NFM = 1, KG_CFIR_DEEMP_AM_SSB = 2,
+       KG_CFIR_SQUELCH_HP = 3 };     /* CSquelch::m_HpFir: readable and runnable, designed only by kg_post_squelch_setup */
+enum { KG_CFIR_REAL_REAL = 0, KG_CFIR_REAL_MONO16 = 1, KG_CFIR_MONO16_MONO16 = 2 };   /* the ProcessFilter overloads, fir.cpp:74, :176, :199 */
+/* CFir::InitLPFilter(NumTaps, Scale, Astop, Fpass, Fstop, Fsamprate) (fir.cpp:282-384): Kaiser-windowed sinc designed on the
+ * host in the reference's float arithmetic; clears the filter's sample buffer.  Returns the tap count (9..97), or < 0. */
+int kg_post_cfir_init_lp(kg_post *post, int chan, int which, int NumTaps, float Scale, float Astop, float Fpass,
+                         float Fstop, float Fsamprate);
+/* CFir::InitConstFir(NumTaps, pCoef, Fsamprate) (fir.cpp:220-240): the caller's coefficients (the reference hands over a row
+ * of rx/rx_filter.h's de-emphasis tables, rx/rx_sound_cmd.cpp:556-585); more than 97 are cut to 97.  Returns the tap count. */
+int kg_post_cfir_init_const(kg_post *post, int chan, int which, int NumTaps, const float *coef, float Fsamprate);
+int kg_post_cfir_get_taps(kg_post *post, int chan, int which, float *taps);    /* -> tap count; taps may be NULL */
+/* m_*_FIR[chan].ProcessFilter(nsamps, in, out) on its own, for a list of channels (rows in_stride / out_stride elements apart;
+ * float or int16 by `kind`; in == out allowed): the same device code as inside kg_post_process_dev.  The sums run in the
+ * reference's order (fir.cpp:79-91: over the circular buffer's positions, so the first tap of the sum rotates with the
+ * write position): bit-exact.  Enqueue only. */
+int kg_post_cfir_process_dev(kg_post *post, const int32_t *chans, int nch, int which, int kind, const void *d_in, size_t in_stride,
+                             int nsamps, void *d_out, size_t out_stride);
+/* m_Squelch[chan].PerformFMSquelch(nsamps, in, out) on its own (squelch.cpp:151-231): float detector samples -> mono16 (1 when
+ * squelched); the return values through kg_post_squelch_state.  Enqueue only. */
+int kg_post_squelch_perform_dev(kg_post *post, const int32_t *chans, int nch, const void *d_in, size_t in_stride, int nsamps,
+                                void *d_out, size_t out_stride);
+/* The post-AM-detector filter as a passband change designs it (rx/rx_sound_cmd.cpp:268-282): hbw = max(|hicut|, |locut|)
+ * capped at frate / 2, stop = 1.8 hbw capped at frate / 2, m_AM_FIR.InitLPFilter(0, 1.0, 50.0, hbw, stop, frate).  Returns the
+ * tap count.  A channel in KG_POST_AM mode without it is refused (the reference's undesigned CFir holds garbage). */
+int kg_post_set_am_passband(kg_post *post, int chan, double locut, double hicut, double frate);
+/* "SET de_emp=%d nfm=%d" (rx/rx_sound_cmd.cpp:543-554): s->deemp_nfm (nfm != 0) or s->deemp = de_emp; non-zero turns the
+ * corresponding filter on for the channel's NBFM resp. AM / SSB modes (do_de_emp, rx/rx_sound.cpp:482).  The coefficients
+ * come through kg_post_cfir_init_const. */
+int kg_post_set_deemp(kg_post *post, int chan, int nfm, int de_emp);
+/* CSquelch (rx/CuteSDR/squelch.cpp) of a channel: SetupParameters(rx_chan, samplerate) (:84-116; designs the noise high-pass,
+ * InitHPFilter(0, 1.0, 50.0, 2400, 1950, samplerate), and resets), SetSquelch(Value, SquelchMax) (:122-129; SquelchMax 0 =
+ * 8192), Reset() (:67-77).  rx/rx_sound.cpp:261-262 calls the first two for every new connection; a channel in KG_POST_NBFM
+ * mode without them is refused.  (The reference clears conn->last_sample with Reset(), rx/rx_sound_cmd.cpp:238-239: that
+ * is kg_post_reset's.) */
+int kg_post_squelch_setup(kg_post *post, int chan, float samplerate);
+int kg_post_squelch_set(kg_post *post, int chan, int Value, int SquelchMax);
+int kg_post_squelch_reset(kg_post *post, int chan);
+/* After the last pass: nsq_nc_sq[i] = what PerformFMSquelch returned for channel chans[i] (-1 opened, 0 no change, +1 closed),
+ * squelched[i] = s->squelched as rx/rx_sound.cpp:877 keeps it (SND_FLAG_SQUELCH_UI, :1232), ave[i] = m_SquelchAve.  Any
+ * output may be NULL.  Synchronises the stream. */
+int kg_post_squelch_state(kg_post *post, const int32_t *chans, int nch, int32_t *nsq_nc_sq, int32_t *squelched, float *ave);
 /* S-meter state after the last pass: avg_dB[i] = sMeterAvg_dB, and (taps != NULL)
  * taps[2i], taps[2i+1] = the values receive_S_meter() is handed at j == 0 and j == ns_out/2
  * (rx_sound.cpp:693), all before S_meter_cal is added.  Synchronises the stream. */

@@ -63,3 +63,11 @@ def run_squelch_script(sq, script, x):
             out.append(np.concatenate([np.asarray(y).astype(np.float32), np.array([rc], np.float32)]))
     assert pos == x.size
     return np.concatenate(out)
+
+
+def arm_audio_tail(P, ch, rate=12000.0, hbw=4900.0, squelch=0):
+    """What the reference has always done before a channel can demodulate AM / NBFM: the post-detector filter of the passband
+    command (rx/rx_sound_cmd.cpp:268-282) and the squelch of a new connection (rx/rx_sound.cpp:261-262)."""
+    P.set_am_passband(ch, -hbw, hbw, rate)
+    P.squelch_setup(ch, rate)
+    P.squelch_set(ch, squelch, 0)

@@ -60,6 +60,7 @@ def test_post_golden(gpu_ctx):
     """S-meter / CAgc / detectors against the committed oracle outputs (tests/golden/post_golden.npz);
     bars as in tests/test_post_gpu.py."""
     from flydog_sdr_gps_amd import Post, post
+    from tests.fixtures import arm_audio_tail
     g = np.load(os.path.join(GOLD, "post_golden.npz"))
     x, n = g["x"], g["x"].size
     P = Post(gpu_ctx, nchan=9)
@@ -69,6 +70,7 @@ def test_post_golden(gpu_ctx):
                 ch = 3 * k + m
                 P.set_agc(ch, *[int(v) for v in args], float(g["rate"]))
                 P.set_smeter(ch, float(g["rate"])); P.set_mode(ch, mode); P.reset(ch)
+                arm_audio_tail(P, ch, float(g["rate"]))
         outs = [P.process(np.arange(9), np.tile(x[i:i + 512], (9, 1))) for i in range(0, n, 512)]
         s16 = np.concatenate([o[0] for o in outs], axis=1)
         dem = np.concatenate([o[1] for o in outs], axis=1)

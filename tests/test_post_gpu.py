@@ -15,6 +15,7 @@ import numpy as np
 import pytest
 
 from flydog_sdr_gps_amd import Post, post
+from tests.fixtures import arm_audio_tail
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-5
@@ -105,6 +106,7 @@ def test_batch_of_channels_matches_oracle(gpu_ctx, oracle, mode):
             P.set_agc(ch, *PARAMS[p])
             P.set_smeter(ch, PARAMS[p][6])
             P.set_mode(ch, mode)
+            arm_audio_tail(P, ch, PARAMS[p][6])
             P.reset(ch)
         chans = np.arange(len(combos), dtype=np.int32)
         got = []
@@ -224,6 +226,7 @@ def test_known_answers(gpu_ctx):
             P.set_smeter(ch, 12000.0); P.set_mode(ch, post.MODE_IQ); P.reset(ch)
         P.set_agc(2, False, False, -100, 80, 6, 1000, 12000.0); P.set_mode(2, post.MODE_NBFM); P.reset(2)
         P.set_agc(3, False, False, -100, 100, 6, 1000, 12000.0); P.set_mode(3, post.MODE_AM); P.reset(3)
+        arm_audio_tail(P, 2); arm_audio_tail(P, 3)
         x = np.stack([300.0 * np.exp(2j * np.pi * 0.05 * t), 20000.0 * np.exp(2j * np.pi * 0.05 * t),
                       1000.0 * np.exp(2j * np.pi * 0.01 * t), 0.25 * np.exp(2j * np.pi * 0.02 * t)]).astype(np.complex64)
         for b in range(nblk):
@@ -274,7 +277,7 @@ def test_a_branch_taken_differently_is_a_gain_step_and_nothing_else(gpu_ctx, ora
     d = np.load(os.path.join(os.path.dirname(__file__), "golden", "post_branch_case.npz"))
     P = Post(gpu_ctx, nchan=1)
     a = oracle.Agc()
-    P.set_mode(0, int(d["mode"])); P.set_smeter(0, 12000.0); P.reset(0)
+    P.set_mode(0, int(d["mode"])); P.set_smeter(0, 12000.0); P.reset(0); arm_audio_tail(P, 0)
     steps = []
     for seg in range(4):
         prm = d["prm%d" % seg]
@@ -294,3 +297,155 @@ def test_a_branch_taken_differently_is_a_gain_step_and_nothing_else(gpu_ctx, ora
         steps.append((seg, first))
     P.close()
     assert steps in ([], [(3, 652)]), steps         # (a libm that rounds the other way at that sample has no step at all)
+
+
+# ---- the chains up to out_samps_s2 (rx/rx_sound.cpp:762-907) -----------------------------------------------------------------
+def oracle_chain(oracle, prm, mode, blocks, rate, hbw, squelch, de_emp, nfm_flag):
+    """One channel of c2s_sound() from the CFastFIR output to out_samps_s2, oracle side.  -> (s16 per block, nsq_nc_sq per block)"""
+    from flydog_sdr_gps_amd import deemp
+    a = oracle.Agc()
+    a.set_parameters(*prm)
+    z1, last = 0.0, (0.0, 0.0)
+    am = oracle.CFir()
+    hb = np.float32(min(float(np.float32(hbw)), rate / 2))                         # rx_sound_cmd.cpp:268-281: float hbw, double frate
+    stop = np.float32(float(hb) * 1.8)
+    stop = np.float32(min(float(stop), rate / 2))
+    am.init_lp(0, 1.0, 50.0, hb, stop, rate)
+    sq = oracle.Squelch()
+    sq.setup(rate)
+    sq.set_squelch(squelch, 0)
+    de = oracle.CFir()
+    nbfm = mode == post.MODE_NBFM
+    on = de_emp and (nfm_flag == nbfm)
+    if de_emp:
+        de.init_const(deemp.table(nfm_flag, rate == 12000.0)[de_emp - 1], rate)
+    outs, rcs = [], []
+    for x in blocks:
+        rc = 0
+        if mode == post.MODE_SSB:
+            s = a.process_s16(x)
+        else:
+            y = a.process_cpx(x)
+            if mode == post.MODE_AM:
+                d, z1 = oracle.am_detect(z1, y)
+                s = am.process_rm(d)
+            else:
+                d, last = oracle.nbfm_detect(last, y)
+                s, rc = sq.perform_fm(d)
+        if on:
+            s = de.process_mm(s)
+        outs.append(s)
+        rcs.append(rc)
+    return outs, rcs
+
+
+CHAINS = [   # mode, agc parameters, rate, AM half bandwidth, squelch value, de_emp (0 off, 1, 2), the de_emp command's nfm flag
+    (post.MODE_AM, PARAMS[0], 12000.0, 4900.0, 0, 0, 0),
+    (post.MODE_AM, PARAMS[1], 12000.0, 2500.0, 0, 1, 0),
+    (post.MODE_AM, PARAMS[2], 20250.0, 6000.0, 0, 2, 0),
+    (post.MODE_AM, PARAMS[0], 12000.0, 4900.0, 0, 1, 1),          # the NBFM filter is on: AM is not touched by it
+    (post.MODE_NBFM, PARAMS[0], 12000.0, 4900.0, 0, 0, 1),        # squelch open (the new-connection default)
+    (post.MODE_NBFM, PARAMS[3], 12000.0, 4900.0, 80, 1, 1),       # manual gain, a threshold the noise blocks cross
+    (post.MODE_NBFM, PARAMS[2], 20250.0, 4900.0, 75, 2, 1),
+    (post.MODE_NBFM, PARAMS[0], 12000.0, 4900.0, 99, 0, 1),       # threshold 0: forced shut
+    (post.MODE_SSB, PARAMS[0], 12000.0, 4900.0, 0, 1, 0),
+    (post.MODE_SSB, PARAMS[4], 12000.0, 4900.0, 0, 2, 0),
+    (post.MODE_SSB, PARAMS[1], 12000.0, 4900.0, 0, 0, 0),
+]
+
+
+def chain_signal(mode, nblk, n, rng):
+    t = np.arange(nblk * n)
+    if mode == post.MODE_NBFM:
+        # blocks of a clean FM carrier (quiet above the voice band), then noise (the squelch's high-pass sees it), then carrier again
+        ph = 2 * np.pi * np.cumsum(0.02 * np.sin(2 * np.pi * t / 40.0))
+        x = 5000.0 * np.exp(1j * ph)
+        noise = rng.normal(0, 3000, t.size) + 1j * rng.normal(0, 3000, t.size)
+        quiet = ((t // n) % 6) < 3
+        return np.where(quiet, x + 0.002 * noise, noise).astype(np.complex64)
+    am = 4000.0 * (1 + 0.6 * np.sin(2 * np.pi * t / 37.0) + 0.2 * np.sin(2 * np.pi * t / 11.0))
+    return (am * np.exp(2j * np.pi * 0.07 * t) + rng.normal(0, 20, t.size) + 1j * rng.normal(0, 20, t.size)).astype(np.complex64)
+
+
+def test_am_nbfm_ssb_chains_reach_out_samps_s2(gpu_ctx, oracle):
+    """Every mode's chain from the CFastFIR output to the mono16 block the sound packet carries: AGC -> detector -> m_AM_FIR resp.
+    the noise squelch -> de-emphasis (rx/rx_sound.cpp:762-907), all channels in one launch per block, ragged block lengths.
+    The filter and squelch stages are bit-exact on equal inputs (tests/test_ref_pins_gpu.py); what they are fed differs from the
+    host's by the AGC's log10f / powf ulps, so the bars are those of the stage in front: SSB / NBFM within 1 LSB before
+    de-emphasis and 2 after it; AM within the detector's own resolution (the float step of its IIR state) through the filters;
+    squelch verdicts (nsq_nc_sq, s->squelched) identical."""
+    rng = np.random.default_rng(77)
+    lens = [512, 512, 300, 212, 512, 512, 512, 170, 342, 512, 512, 512]
+    nblk = len(lens)
+    P = Post(gpu_ctx, nchan=len(CHAINS))
+    try:
+        sigs = []
+        for ch, (mode, prm, rate, hbw, sqv, de, nfm) in enumerate(CHAINS):
+            P.set_agc(ch, *prm[:6], rate)
+            P.set_smeter(ch, rate); P.set_mode(ch, mode); P.reset(ch)
+            P.set_am_passband(ch, -hbw, hbw * 0.5, rate)
+            P.squelch_setup(ch, rate); P.squelch_set(ch, sqv, 0)
+            P.set_de_emp(ch, de, nfm, snd_rate_12k=(rate == 12000.0))
+            sigs.append(chain_signal(mode, nblk, 512, rng))
+        chans = np.arange(len(CHAINS), dtype=np.int32)
+        got, got_rc, got_sq, pos = [], [], [], 0
+        for n in lens:
+            x = np.stack([s[pos:pos + n] for s in sigs])
+            pos += n
+            got.append(P.process(chans, x)[0])
+            rc, sq, _ = P.squelch_state(chans)
+            got_rc.append(rc); got_sq.append(sq)
+        for ch, (mode, prm, rate, hbw, sqv, de, nfm) in enumerate(CHAINS):
+            blocks, pos = [], 0
+            for n in lens:
+                blocks.append(sigs[ch][pos:pos + n]); pos += n
+            want, rcs = oracle_chain(oracle, (*prm[:6], rate), mode, blocks, rate, hbw, sqv, de, bool(nfm))
+            squelched = False
+            for b in range(nblk):
+                d = np.abs(got[b][ch].astype(np.int32) - want[b].astype(np.int32))
+                if mode == post.MODE_AM:
+                    bar = 2 + int(4 * 100.0 * 23000.0 * 2 ** -23)        # the IIR state z ~ 100 x the envelope: its float step, x 4
+                else:
+                    bar = 2 if de and (bool(nfm) == (mode == post.MODE_NBFM)) else 1
+                assert d.max() <= bar, (ch, b, int(d.max()), bar)
+                assert (d <= 1).mean() >= 0.9, (ch, b, float((d <= 1).mean()))
+                if mode == post.MODE_NBFM:
+                    assert int(got_rc[b][ch]) == rcs[b], (ch, b, int(got_rc[b][ch]), rcs[b])
+                    if rcs[b] != 0:
+                        squelched = rcs[b] == 1
+                    assert bool(got_sq[b][ch]) == squelched
+        # the scenario did what it says: the threshold-80 channel shut on noise and opened on the carrier
+        rc5 = [int(r[5]) for r in got_rc]
+        assert 1 in rc5 and -1 in rc5, rc5
+        assert all(np.all(got[b][7] == 1) for b in range(1, nblk))        # threshold 0: silence marker 1 (squelch.cpp:205-207)
+    finally:
+        P.close()
+
+
+def test_am_and_nbfm_refuse_to_run_unprepared(gpu_ctx):
+    """The reference's CFir() holds garbage until InitLPFilter and its CSquelch an unset threshold until SetSquelch: a channel
+    switched to AM / NBFM before the host has done what rx_sound_cmd.cpp / rx_sound.cpp always do first is refused, loudly."""
+    from flydog_sdr_gps_amd._lib import KiwiGpuError
+    P = Post(gpu_ctx, nchan=2)
+    try:
+        x = np.ones((1, 64), np.complex64)
+        P.set_mode(0, post.MODE_AM)
+        with pytest.raises(KiwiGpuError, match="m_AM_FIR"):
+            P.process([0], x)
+        P.set_am_passband(0, -4900, 4900, 12000.0)
+        P.process([0], x)
+        P.set_mode(1, post.MODE_NBFM)
+        with pytest.raises(KiwiGpuError, match="squelch"):
+            P.process([1], x)
+        P.squelch_setup(1, 12000.0)
+        with pytest.raises(KiwiGpuError, match="squelch"):
+            P.process([1], x)
+        P.squelch_set(1, 0, 0)
+        P.process([1], x)
+        P.set_deemp(1, True, 1)
+        with pytest.raises(KiwiGpuError, match="de-emphasis"):
+            P.process([1], x)
+        P.set_de_emp(1, 1, True)
+        P.process([1], x)
+    finally:
+        P.close()

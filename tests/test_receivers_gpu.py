@@ -368,3 +368,42 @@ def test_two_banks_stepped_from_two_threads_equal_their_solo_runs():
                 else:
                     assert np.array_equal(both[b][k][key], solo[b][k][key]), (b, k, key)
     assert frames > 0 and any(r["info"][2] for r in both[0]) and any(r["info"][2] for r in both[1])
+
+
+def test_bank_of_mixed_demodulators_reaches_the_sound_payload(oracle):
+    """One bank whose receivers listen in different modes -- SSB, AM (wide and narrow), NBFM (squelch open, a threshold the
+    channel's noise crosses, forced shut), with and without de-emphasis -- stepped six times: every receiver's out_samps_s2
+    (rx/rx_sound.cpp:762-907: AGC -> detector -> m_AM_FIR resp. m_Squelch -> de-emphasis) against the oracle's chain on the
+    GPU's own CFastFIR output, and its ADPCM sound payload byte for byte on the GPU's own mono16 block."""
+    from flydog_sdr_gps_amd import post, synth
+    from flydog_sdr_gps_amd.rxbank import MIXES
+    from tests.rxbank_check import check_bank
+    modes = [   # mode, low_cut, high_cut, de_emp, squelch
+        (post.MODE_SSB, 300.0, 2700.0, 0, 0),
+        (post.MODE_AM, -2500.0, 2500.0, 0, 0),
+        (post.MODE_NBFM, -3000.0, 3000.0, 0, 0),
+        (post.MODE_AM, -2500.0, 2500.0, 1, 0),
+        (post.MODE_NBFM, -3000.0, 3000.0, 2, 80),
+        (post.MODE_SSB, -2700.0, -300.0, 2, 0),
+        (post.MODE_AM, -1200.0, 1250.0, 2, 0),
+        (post.MODE_NBFM, -3000.0, 3000.0, 1, 99),
+        (post.MODE_SSB, 300.0, 2700.0, 0, 0),
+    ]
+    NR, steps = len(modes), 6
+    mix = MIXES["survey"](NR, 123, N)
+    adc = synth.adc_stream(N, 0x5EED0004)
+    bank = _bank(NR, N, mix)
+    try:
+        for rx, (mode, lo, hi, de, sq) in enumerate(modes):
+            bank.set_audio(rx, mix[rx][2], lo, hi, mode=mode, de_emp=de, squelch=sq)
+        d_adc = bank.ctx.alloc(adc.nbytes)
+        bank.ctx.upload(d_adc, adc)
+        got = check_bank(bank, lambda k: adc, lambda k: d_adc, range(NR), steps)
+        assert got["audio_blocks"] == 4 * NR, got              # 402 records a step: blocks on steps 2, 3, 4 and 6
+        rc, sq, ave = bank.post.squelch_state(list(range(NR)))
+        assert not sq[2] and sq[7], (sq, ave)                   # value 0: always open; value 99 (threshold 0): forced shut
+        s16 = bank.fetch("s16", [7])[0]
+        assert np.all(s16[:512] == 1)                           # squelch.cpp:205-207: the squelched block is all ones
+        bank.ctx.free(d_adc)
+    finally:
+        bank.close()

@@ -84,3 +84,87 @@ def test_e1b_code_tables_from_reference_chips(gpu_ctx, oracle):
         got = s.get_code_fft(sat)
         assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
     s.close()
+
+
+class GpuCFir:
+    """One CFir of a kg_post channel behind the script interface of tests/fixtures.run_fir_script."""
+
+    def __init__(self, P, ch):
+        self.P, self.ch, self.which = P, ch, post.CFIR_AM
+
+    def init_lp(self, numtaps, scale, astop, fpass, fstop, fs):
+        self.which = post.CFIR_AM
+        return self.P.cfir_init_lp(self.ch, self.which, numtaps, scale, astop, fpass, fstop, fs)
+
+    def init_hp(self, numtaps, scale, astop, fpass, fstop, fs):
+        # the one high-pass the path designs: CSquelch::InitNoiseSquelch (squelch.cpp:137), through kg_post_squelch_setup
+        assert (numtaps, scale, astop, fpass, fstop) == (0, 1.0, 50.0, 2400.0, 1950.0)
+        self.which = post.CFIR_SQUELCH_HP
+        self.P.squelch_setup(self.ch, fs)
+        return self.P.cfir_taps(self.ch, self.which).size
+
+    def init_const(self, coef, fs):
+        self.which = post.CFIR_DEEMP_NFM
+        self.P.cfir_init_const(self.ch, self.which, coef, fs)
+
+    def process_rr(self, x):
+        return self.P.cfir_process([self.ch], self.which, post.CFIR_REAL_REAL, x[None, :])[0]
+
+    def process_rm(self, x):
+        return self.P.cfir_process([self.ch], self.which, post.CFIR_REAL_MONO16, x[None, :])[0]
+
+    def process_mm(self, x):
+        return self.P.cfir_process([self.ch], self.which, post.CFIR_MONO16_MONO16, x[None, :])[0]
+
+
+def test_cfir_on_the_gpu_matches_reference_fir_cpp(gpu_ctx):
+    """m_AM_FIR / the de-emphasis filters / the squelch's high-pass against rx/CuteSDR/fir.cpp itself (fir_ref.npz): the designs
+    (host arithmetic, taps read back through an impulse on the reference side, through the GPU here) and the three real-valued
+    ProcessFilter paths, whose float sums the kernel forms in the reference's rotating order: BIT-EXACT."""
+    from tests.fixtures import run_fir_script
+    g = np.load(os.path.join(GOLD, "fir_ref.npz"))
+    names = [str(n) for n in g["names"]]
+    P = Post(gpu_ctx, nchan=len(names))
+    try:
+        for ch, name in enumerate(names):
+            got = run_fir_script(GpuCFir(P, ch), g[name + "_script"], g[name + "_in"])
+            want = g[name + "_out"]
+            assert got.shape == want.shape, name
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), \
+                "%s: %d of %d differ, max |diff| %g" % (name, np.count_nonzero(got != want), got.size, np.abs(got - want).max())
+    finally:
+        P.close()
+
+
+class GpuSquelch:
+    def __init__(self, P, ch):
+        self.P, self.ch = P, ch
+
+    def setup(self, rate):
+        self.P.squelch_setup(self.ch, rate)
+
+    def set_squelch(self, value, squelch_max):
+        self.P.squelch_set(self.ch, value, squelch_max)
+
+    def reset(self):
+        self.P.squelch_reset(self.ch)
+
+    def perform_fm(self, x):
+        out, rc = self.P.squelch_perform([self.ch], x[None, :])
+        return out[0], int(rc[0])
+
+
+def test_squelch_on_the_gpu_matches_reference_squelch_cpp(gpu_ctx):
+    """m_Squelch[ch].SetupParameters / SetSquelch / Reset / PerformFMSquelch sequences against rx/CuteSDR/squelch.cpp itself
+    (squelch_ref.npz): outputs and return values BIT-EXACT (the noise average is a float/double recursion with no libm call)."""
+    from tests.fixtures import run_squelch_script
+    g = np.load(os.path.join(GOLD, "squelch_ref.npz"))
+    names = [str(n) for n in g["names"]]
+    P = Post(gpu_ctx, nchan=len(names))
+    try:
+        for ch, name in enumerate(names):
+            got = run_squelch_script(GpuSquelch(P, ch), g[name + "_script"], g[name + "_in"])
+            want = g[name + "_out"]
+            assert got.shape == want.shape and np.array_equal(got, want), "%s: %d differ" % (name, np.count_nonzero(got != want))
+    finally:
+        P.close()

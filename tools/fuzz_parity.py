@@ -13,6 +13,7 @@ from flydog_sdr_gps_amd import (Adpcm, Context, Ddc, FastFir, Post, RxDdc, Searc
                                 wire)
 from flydog_sdr_gps_amd.ddc import RX_DECIM   # noqa: E402
 from oracle import kiwi_oracle as ko          # noqa: E402
+from tests.fixtures import arm_audio_tail    # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
 only = sys.argv[3] if len(sys.argv) > 3 else None
@@ -163,6 +164,7 @@ def trial_post():
     a = ko.Agc()
     mode = int(rng.integers(0, 4))
     P.set_mode(0, mode)
+    arm_audio_tail(P, 0)
     P.set_smeter(0, 12000.0)
     P.reset(0)
     avg, alpha, z1, last = 0.0, ko.smeter_alpha(12000.0), 0.0, (0.0, 0.0)

@@ -13,6 +13,7 @@ ctx = Context(0)
 P = Post(ctx, nchan=1)
 a = ko.Agc()
 P.set_mode(0, mode); P.set_smeter(0, 12000.0); P.reset(0)
+P.set_am_passband(0, -4900, 4900, 12000.0); P.squelch_setup(0, 12000.0); P.squelch_set(0, 0, 0)
 seg = 0
 while "x%d" % seg in d.files:
     prm = d["prm%d" % seg]

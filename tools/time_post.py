@@ -21,6 +21,7 @@ for nchan in [int(a) for a in sys.argv[1:]] or [14, 128, 1024, 8192]:
             P.set_agc(ch, True, ch & 1, -100, 50, 6, 1000, 12000.0)
             P.set_smeter(ch, 12000.0)
             P.set_mode(ch, mode)
+            P.set_am_passband(ch, -4900, 4900, 12000.0); P.squelch_setup(ch, 12000.0); P.squelch_set(ch, 0, 0)
         chans = np.arange(nchan, dtype=np.int32)
         d_x = ctx.alloc(x.nbytes); ctx.upload(d_x, x)
         d_s = ctx.alloc(nchan * n * 2); d_d = ctx.alloc(nchan * n * 4); d_a = ctx.alloc(nchan * n * 8)
