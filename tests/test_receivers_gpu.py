@@ -388,6 +388,7 @@ def test_bank_of_mixed_demodulators_reaches_the_sound_payload(oracle):
         (post.MODE_AM, -1200.0, 1250.0, 2, 0),
         (post.MODE_NBFM, -3000.0, 3000.0, 1, 99),
         (post.MODE_SSB, 300.0, 2700.0, 0, 0),
+        (post.MODE_NBFM, -3000.0, 3000.0, 0, 99),
     ]
     NR, steps = len(modes), 6
     mix = MIXES["survey"](NR, 123, N)
@@ -401,9 +402,10 @@ def test_bank_of_mixed_demodulators_reaches_the_sound_payload(oracle):
         got = check_bank(bank, lambda k: adc, lambda k: d_adc, range(NR), steps)
         assert got["audio_blocks"] == 4 * NR, got              # 402 records a step: blocks on steps 2, 3, 4 and 6
         rc, sq, ave = bank.post.squelch_state(list(range(NR)))
-        assert not sq[2] and sq[7], (sq, ave)                   # value 0: always open; value 99 (threshold 0): forced shut
-        s16 = bank.fetch("s16", [7])[0]
-        assert np.all(s16[:512] == 1)                           # squelch.cpp:205-207: the squelched block is all ones
+        assert not sq[2] and sq[7] and sq[9], (sq, ave)         # value 0: always open; value 99 (threshold 0): forced shut
+        s16 = bank.fetch("s16", [7, 9])
+        assert np.all(s16[1][:512] == 1)                        # squelch.cpp:205-207: the squelched block is all ones ...
+        assert not np.all(s16[0][:512] == 1)                    # ... which receiver 7's de-emphasis filter then filters (rx_sound.cpp:898-900)
         bank.ctx.free(d_adc)
     finally:
         bank.close()
