@@ -178,6 +178,12 @@ SYMBOLS = {
     "kg_rxbank_step": (_i, [_vp, _vp, _vp, _vp]),
     "kg_rxbank_adc_done": (_i, [_vp, _vp, _i]),
     "kg_rxbank_poll": (_i, [_vp]),
+    "kg_rxbank_ready": (_i, [_vp]),
+    "kg_rxbank_join": (_i, [_vp, _i]),
+    "kg_rxbank_leave": (_i, [_vp, _i]),
+    "kg_rxbank_is_active": (_i, [_vp, _i]),
+    "kg_rxbank_audio_map": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "kg_fir_process_each_dev": (_i, [_vp, _vp, _i, _vp, _sz, _vp, _vp, _sz, _vp]),
     "kg_rxbank_sync": (_i, [_vp]),
     "kg_rxbank_frame_map": (_i, [_vp, _vp, _vp, _vp]),
     "kg_rxbank_buffers": (_i, [_vp, _vp]),
@@ -240,7 +246,9 @@ def check(status, where):
 
 def borrow(cls, ctx, handle, **attrs):
     """An object of one of the wrapper classes (Ddc, Waterfall, RxDdc, FastFir, Post, Adpcm) over a handle another object
-    owns -- the per-seam objects of a receiver bank (kg_rxbank_ddc() ...): every method works, close() leaves the handle alone."""
+    owns -- the per-seam objects of a receiver bank (kg_rxbank_ddc() ...): the configuration methods work, close() leaves the handle
+    alone.  The host-buffer conveniences (push / process / encode ...) refuse: a bank's objects address the rows of every
+    caller-visible buffer by RECEIVER number (its buffers hold one row per receiver), not by position in the call's list."""
     self = cls.__new__(cls)
     self.ctx, self.lib = ctx, ctx.lib
     self.h = C.c_void_p(handle) if isinstance(handle, int) else handle
@@ -248,6 +256,13 @@ def borrow(cls, ctx, handle, **attrs):
     for k, v in attrs.items():
         setattr(self, k, v)
     return self
+
+
+def own_rows(obj, what):
+    """Guard of the host-buffer conveniences: see borrow()."""
+    if getattr(obj, "_borrowed", False):
+        raise KiwiGpuError("%s on an object a receiver bank owns: its rows are addressed by receiver number -- step the bank and read "
+                           "its buffers (RxBank.fetch)" % what)
 
 
 def ptr(a):

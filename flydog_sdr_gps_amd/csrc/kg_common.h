@@ -68,6 +68,10 @@ struct kg_ctx {
     hipEvent_t ring_ev[32];
     unsigned long ring_next;
     kg_arena *arena;                          // a receiver bank's step tables (null: the ring / the caches above)
+    // A receiver bank's buffers hold one row per RECEIVER while its calls list only the receivers that are active (or, for
+    // the coders, that completed a sound block this step): on the bank's contexts the row of list entry li, in every
+    // caller-visible buffer of the enqueue-only entry points, is chans[li] instead of li.
+    int rows_by_chan;
 };
 
 // An enqueue-only entry point that stages its tables through kg_ctx_stage* puts this right behind the (last) staging

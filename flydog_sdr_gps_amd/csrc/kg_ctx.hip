@@ -149,12 +149,10 @@ void kg_stream_put(int device, hipStream_t s)
 __global__ void kg_mark_kernel() {}
 
 // The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order; streams
-// beyond that SHARE a queue and run in order with whoever they share it with.  A receiver bank uses four streams and the
-// DDC objects bring their own: with four queues `receivers` ran 1.28 ms per step, with eight 0.98 (round 4: which streams
-// serialise then depends on what else created a stream first).  The runtime reads the variable when it initialises, so
-// the library asks for eight when it is loaded -- unless the host has set the variable itself, and without effect (or
-// harm) if the host initialised HIP before loading the library.
-__attribute__((constructor)) static void kg_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// beyond that SHARE a queue and run in order with whoever they share it with.  A receiver bank uses five streams: a HOST that
+// runs banks should export GPU_MAX_HW_QUEUES=8 before it initialises HIP (bench.py does).  The library
+// does not touch the process environment (rounds 4-5 set the variable from a constructor: a side effect on every other HIP
+// user of the process, and a race with getenv in a threaded host).
 
 extern "C" {
 

@@ -305,7 +305,8 @@ DDC_DEV void ddc_wf_run_body(
     const long *__restrict__ c0off, const long *__restrict__ nouts,
     const int *__restrict__ sel,              // list entries this launch covers (null: all, in order)
     int stage_bytes,                          // pass B, R <= 8: dynamic LDS for the strobe staging tiles, else 0
-    u64 pushed,                               // samples pushed since the channels' reference point (ddc_chan)
+    u64 pushed,                               // samples pushed since the call's reference point: the entry's own count is
+    const u64 *__restrict__ pdelta,           //   pushed + pdelta[li] (channels retuned or joined at different times differ in age)
     const long *__restrict__ nlim,            // [nlist] samples of the block this entry consumes (capture: 8192 R; else n)
     const int *__restrict__ reset_tab,        // [nlist] capture: the decimation counter starts the block at zero (rst_wf_samp_wr)
     int endref,                               // states in `local` are referred to the END of the entry's share (sc_Tinv above)
@@ -321,6 +322,7 @@ DDC_DEV void ddc_wf_run_body(
     const int li = sel ? sel[blockIdx.y] : (int) blockIdx.y;
     const ddc_chan ch = chans[chan_list[li]];
     const int reset_first = reset_tab[li];
+    pushed += pdelta[li];
     const int r = blockIdx.x * DDC_THREADS + threadIdx.x;
     n = nlim[li];                             // this entry's share of the block (wave-uniform)
     if (r >= nruns || (long) r * L >= n) return;
@@ -718,7 +720,7 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
     const ddc_chan *__restrict__ chans, const int *__restrict__ chan_list, const u32 *__restrict__ nco,
     ddc_state4 *__restrict__ local, u32 *__restrict__ c0rel, u32 *__restrict__ tau,
     const long *__restrict__ c0off, const long *__restrict__ nouts, const int *__restrict__ sel, int stage_bytes,
-    u64 pushed, const long *__restrict__ nlim, const int *__restrict__ reset_tab, int endref,
+    u64 pushed, const u64 *__restrict__ pdelta, const long *__restrict__ nlim, const int *__restrict__ reset_tab, int endref,
     const ddc_endco *__restrict__ endco, long endco_n,
     ddc_state4 *__restrict__ wgtot,           // pass A, endref == 2: [nlist][2][gridDim.x] out
     const ddc_state4 *__restrict__ wgbase,    // pass B, endref == 2: [nlist][2][gridDim.x] in
@@ -728,7 +730,7 @@ __global__ __launch_bounds__(DDC_THREADS) void ddc_wf_run_kernel(
     bool have = false;
     u32 oTi = 0, oTq = 0;
     ddc_wf_run_body<PASS_B, MODE>(adc, n, L, nruns, chans, chan_list, nco, local, c0rel, tau, c0off, nouts, sel, stage_bytes, pushed,
-                            nlim, reset_tab, endref, endco, endco_n, wgbase, oI, oQ, have, oTi, oTq);
+                            pdelta, nlim, reset_tab, endref, endco, endco_n, wgbase, oI, oQ, have, oTi, oTq);
     if (PASS_B && endref == 2) {
         // The prefix of the runs' integrator-5 totals in the same levels: tau[r] = the sum of the workgroup's runs before r,
         // wgtau = the workgroup's total; ddc_wf_tau_wg_kernel turns the totals into each workgroup's absolute start value and
@@ -910,9 +912,10 @@ DDC_DEV long ddc_bypass_whole_t(const short *__restrict__ adc, long blk, long nf
 __global__ __launch_bounds__(256, 4) void ddc_wf_bypass_kernel(
     const short *__restrict__ adc, long n, const ddc_chan *__restrict__ chans, const int *__restrict__ chan_list,
     const int *__restrict__ bypass_list, int nbypass,     // list entries with R == 1
-    const u32 *__restrict__ nco, short2 *__restrict__ out, long out_stride, u64 pushed,
+    const u32 *__restrict__ nco, short2 *__restrict__ out, long out_stride, u64 pushed, const u64 *__restrict__ pdelta,
     const long *__restrict__ nlim,            // [nlist] samples this entry takes (capture: max_out; else n)
-    const long *__restrict__ out_off)         // [nlist] entry li writes at out + li out_stride + out_off[li]
+    const long *__restrict__ out_off,         // [nlist] entry li writes at out + li out_stride + out_off[li]
+    int by_chan)                              // ... or at row chan_list[li] (kg_ctx::rows_by_chan)
 {
     __shared__ short tab[DDC_TAB];
     for (int i = threadIdx.x; i < DDC_TAB / 2; i += 256) ((u32 *) tab)[i] = nco[i];
@@ -934,9 +937,9 @@ __global__ __launch_bounds__(256, 4) void ddc_wf_bypass_kernel(
             const int li = bypass_list[b0 + (b < nb4 ? b : 0)];
             const ddc_chan *ch = chans + chan_list[li];
             inc16[b] = ch->phase_inc << 16;
-            ph0[b] = ch->phase + pushed * ch->phase_inc;
+            ph0[b] = ch->phase + (pushed + pdelta[li]) * ch->phase_inc;
             nbs[b] = b < nb4 ? nlim[li] : 0;
-            orow[b] = out + (long) li * out_stride + out_off[li];
+            orow[b] = out + (long) (by_chan ? chan_list[li] : li) * out_stride + out_off[li];
         }
         // samples up to which every channel of the four takes whole aligned blocks, rows that take 16-byte stores
         long nfull = n;
@@ -1259,12 +1262,13 @@ DDC_DEV int sext32(int v, int bits) { return (v << (32 - bits)) >> (32 - bits); 
 __global__ __launch_bounds__(256) void ddc_wf_comb_kernel(
     const u32 *__restrict__ c0rel, const u32 *__restrict__ i5start, int log2L, int nruns,
     const long *__restrict__ c0off, const ddc_chan *__restrict__ chans, const int *__restrict__ chan_list, const long *__restrict__ nouts,
-    u64 pushed,                               // samples pushed since the channels' reference point
+    u64 pushed, const u64 *__restrict__ pdelta,   // samples pushed since the entry's reference point: pushed + pdelta[li]
     const int *__restrict__ reset_tab,        // [nlist] capture: counter and comb registers start the block at zero
     const int *__restrict__ wg_start, int nlist,
     short2 *__restrict__ out, long out_stride, const long *__restrict__ out_off,   // entry li writes at out + li out_stride + out_off[li]
     u32 *__restrict__ hist_out,               // [nlist][2][5]
-    const u32 *__restrict__ wgtau, int gx)    // end-referred levels: i5start[] is relative to its run pass workgroup's start value wgtau[li][comp][run / 256]; or null
+    const u32 *__restrict__ wgtau, int gx,    // end-referred levels: i5start[] is relative to its run pass workgroup's start value wgtau[li][comp][run / 256]; or null
+    int by_chan)                              // rows of `out` by channel number (kg_ctx::rows_by_chan)
 {
     __shared__ __attribute__((aligned(16))) int s_c0[2][DDC_COMB_TILE + 8];       // [d]: output o0 - 8 + d (three unused slots keep 16-byte rows)
     int lo = 0, hi = nlist;                   // wg_start[lo] <= blockIdx.x < wg_start[hi]
@@ -1275,7 +1279,7 @@ __global__ __launch_bounds__(256) void ddc_wf_comb_kernel(
     const int reset_first = reset_tab[li];
     const long nout = nouts[li], plane = (nout + 3) & ~3l;
     const long o0 = (long) (blockIdx.x - wg_start[li]) * DDC_COMB_TILE;
-    const u32 base = reset_first ? 0u : (u32) (((u64) ch->sample_no + pushed) & ((1ull << log2r) - 1));     // sample_no before this call
+    const u32 base = reset_first ? 0u : (u32) (((u64) ch->sample_no + pushed + pdelta[li]) & ((1ull << log2r) - 1));     // sample_no before this call
     auto absolute = [&](int comp, long oo, u32 rel) -> u32 {
         const long g = ((oo + 1) << log2r) - 1 - (long) base;    // sample index of the strobe
         const int run = (int) (g >> log2L);
@@ -1345,7 +1349,7 @@ __global__ __launch_bounds__(256) void ddc_wf_comb_kernel(
         *(int4 *) &s_out[4 * t] = o4;
     }
     __syncthreads();
-    short2 *dst = out + (long) li * out_stride + out_off[li] + o0;
+    short2 *dst = out + (long) (by_chan ? chan_list[li] : li) * out_stride + out_off[li] + o0;
     for (int k = 0; k < 4; k++) {
         const int e = t + 256 * k;
         if (o0 + e < nout) { const int w = s_out[e]; dst[e] = make_short2((short) (w & 0xffff), (short) (w >> 16)); }
@@ -1694,21 +1698,35 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
     // from the reset state, as the reference does when it changes sampler mode (CmdWFReset with WF_SAMP_CONTIN,
     // rx/rx_waterfall.cpp:971-978).  Synchronising, rare.  (Before the ages are compared: a reset moves the channel's
     // reference point.)
+    // (A bank's PLAN pass changes nothing: it computes with the counts the reset WILL leave and the replay pass resets.)
+    const bool plan_pass = d->ctx->arena && d->ctx->arena->mode == KG_ARENA_PLAN;
+    std::vector<char> will_reset(nlist, 0);
     for (int i = 0; i < nlist; i++)
             if (cap_of(i) == 0 && d->h_stale[chan_list[i]]) {
+                if (plan_pass) { will_reset[i] = 1; continue; }
                 if ((rc = kg_ddc_reset_wf(d, chan_list[i]))) return rc;
                 d->h_stale[chan_list[i]] = 0;
             }
-    // One `pushed` count for the whole call: channels whose reference points differ in age (one was retuned, or left out
-    // of earlier calls) are re-based to "now" first -- a rare, synchronising path.
-    {
-        bool same = true;
-        for (int i = 1; i < nlist; i++) same = same && d->h_pushed[chan_list[i]] == d->h_pushed[chan_list[0]];
-        // (the kernels form (pushed + sample index) x phase_inc in 64 bits mod 2^48: re-base long before anything wraps)
-        if (!same || d->h_pushed[chan_list[0]] + (u64) n >= (1ull << 62))
-            for (int i = 0; i < nlist; i++) if ((rc = ddc_rebase(d, chan_list[i]))) return rc;
+    // Channels whose reference points differ in age (one was retuned -- the most common command of a connection -- or joined
+    // later, or was left out of earlier calls): the call passes the YOUNGEST age as `pushed` and a table of what each entry has
+    // on top of it.  The table is the same from push to push while no channel is touched (every age grows by n), so it rides in
+    // the content-cached per-call tables; rounds 4-5 re-based every other channel of the call instead: two blocking copies per
+    // channel, ~2000 for a bank of 1024 receivers after ONE `SET zoom=`.
+    auto age_of = [&](int i) -> u64 { return will_reset[i] ? 0ull : d->h_pushed[chan_list[i]]; };
+    u64 pushed = age_of(0), oldest = pushed;
+    for (int i = 1; i < nlist; i++) {
+        const u64 a = age_of(i);
+        if (a < pushed) pushed = a;
+        if (a > oldest) oldest = a;
     }
-    const u64 pushed = d->h_pushed[chan_list[0]];
+    // (the kernels form (age + sample index) x phase_inc in 64 bits mod 2^48: re-base long before anything wraps -- 2^62 samples)
+    KG_REQUIRE(!(plan_pass && oldest + (u64) n >= (1ull << 62)), KG_ERR_STATE, "kg_ddc_wf_push_dev: 2^62 samples since a channel was last set");
+    if (oldest + (u64) n >= (1ull << 62)) {
+        for (int i = 0; i < nlist; i++) if ((rc = ddc_rebase(d, chan_list[i]))) return rc;
+        pushed = 0;
+    }
+    std::vector<u64> h_pdelta(nlist);
+    for (int i = 0; i < nlist; i++) h_pdelta[i] = age_of(i) - pushed;
     std::vector<long> h_nouts(nlist), h_off(nlist), h_nlim(nlist), h_outoff(nlist);
     std::vector<int> h_wg(nlist + 1), h_bypass, h_run, h_small, h_rest, h_big, h_reset(nlist);
     long max_nout = 0, c0_need = 0, comb_wgs = 0, n_run_max = 0, n_by_max = 0, n_run_sum = 0;
@@ -1721,7 +1739,7 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
         h_reset[i] = cap ? 1 : 0;
         h_outoff[i] = out_off ? (long) out_off[i] : 0l;
         h_nlim[i] = (long) (want < (u64) n ? want : (u64) n);
-        h_nouts[i] = (long) (((cap ? 0ull : (u64) ddc_cur_cnt(d, ch)) + (u64) h_nlim[i]) >> c.log2r);
+        h_nouts[i] = (long) (((cap || will_reset[i] ? 0ull : (u64) ddc_cur_cnt(d, ch)) + (u64) h_nlim[i]) >> c.log2r);
         if (c.log2r) { if (h_nlim[i] > n_run_max) n_run_max = h_nlim[i]; n_run_sum += h_nlim[i]; }
         else if (h_nlim[i] > n_by_max) n_by_max = h_nlim[i];
         KG_REQUIRE((size_t) (h_nouts[i] + h_outoff[i]) <= out_stride, KG_ERR_INVALID,
@@ -1789,7 +1807,7 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
     KG_REQUIRE(nruns <= d->max_runs, KG_ERR_INVALID, "kg_ddc_wf_push_dev: %d runs > %d", nruns, d->max_runs);
     // The per-call tables go through the context's staging ring in one piece: no stream
     // synchronisation, and the previous call's kernels keep their own copy.
-    const long *s_c0off, *s_nouts, *s_nlim, *s_outoff; const int *s_list, *s_wgoff, *s_bypass, *s_selrun, *s_selsmall, *s_selrest, *s_reset;
+    const long *s_c0off, *s_nouts, *s_nlim, *s_outoff; const u64 *s_pdelta; const int *s_list, *s_wgoff, *s_bypass, *s_selrun, *s_selsmall, *s_selrest, *s_reset;
     {
         std::vector<unsigned char> pack;
         auto put = [&](const void *src, size_t bytes) -> size_t {
@@ -1799,7 +1817,7 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
             return at;
         };
         const size_t o_off = put(h_off.data(), sizeof(long) * nlist), o_nouts = put(h_nouts.data(), sizeof(long) * nlist);
-        const size_t o_nlim = put(h_nlim.data(), sizeof(long) * nlist);
+        const size_t o_nlim = put(h_nlim.data(), sizeof(long) * nlist), o_pdelta = put(h_pdelta.data(), sizeof(u64) * nlist);
         const size_t o_list = put(chan_list, sizeof(int) * nlist);
         const size_t o_wg = put(h_wg.data(), sizeof(int) * (nlist + 1));
         const size_t o_by = put(h_bypass.data(), sizeof(int) * h_bypass.size());
@@ -1821,7 +1839,7 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
         s_list = (const int *) (b + o_list); s_wgoff = (const int *) (b + o_wg);
         s_bypass = (const int *) (b + o_by); s_selrun = (const int *) (b + o_run);
         s_selsmall = (const int *) (b + o_small); s_selrest = (const int *) (b + o_rest);
-        s_reset = (const int *) (b + o_reset); s_outoff = (const long *) (b + o_outoff);
+        s_reset = (const int *) (b + o_reset); s_outoff = (const long *) (b + o_outoff); s_pdelta = (const u64 *) (b + o_pdelta);
     }
     KG_PLAN_ONLY(d->ctx);
     // The object's second stream: work that does not depend on the pass A -> scan -> pass B chain runs beside
@@ -1861,7 +1879,7 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
         const long nblk_by = (n_by_max + BYP_G * 1024 - 1) / (BYP_G * 1024), cap_by = (long) d->ctx->num_cus * 4;   // LDS: 20 KiB each, 4 per CU
         hipLaunchKernelGGL(ddc_wf_bypass_kernel, dim3((unsigned) (nblk_by < cap_by ? nblk_by : cap_by)), dim3(256),
                            0, bst, (const short *) d_adc, (long) n_by_max, (const ddc_chan *) d->d_chans, s_list,
-                           s_bypass, (int) h_bypass.size(), (const u32 *) d->d_nco, (short2 *) d_out, (long) out_stride, pushed, s_nlim, s_outoff);
+                           s_bypass, (int) h_bypass.size(), (const u32 *) d->d_nco, (short2 *) d_out, (long) out_stride, pushed, s_pdelta, s_nlim, s_outoff, d->ctx->rows_by_chan);
         KG_HIP(hipGetLastError());
         if (defer) KG_HIP(hipEventRecord(d->ev_adc, bst));           // the output stream's only reader of d_adc
     }
@@ -1884,7 +1902,7 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
         hipLaunchKernelGGL(pass_a, dim3(gx, (unsigned) h_run.size()), dim3(DDC_THREADS), 0, st,
                            (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, s_list,
                            (const u32 *) d->d_nco, d_local, d_c0rel, d_tau, s_c0off,
-                           s_nouts, s_selrun, 0, pushed, s_nlim, s_reset, endref, (const ddc_endco *) d->d_endco, d->endco_n,
+                           s_nouts, s_selrun, 0, pushed, s_pdelta, s_nlim, s_reset, endref, (const ddc_endco *) d->d_endco, d->endco_n,
                            d->d_wgtot[par], (const ddc_state4 *) nullptr, (u32 *) nullptr);
         KG_HIP(hipGetLastError());
     }
@@ -1947,7 +1965,7 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
         auto k = mode == DDC_NARROW ? ddc_wf_run_kernel<true, DDC_NARROW> : (mode == DDC_WIDE ? ddc_wf_run_kernel<true, DDC_WIDE> : ddc_wf_run_kernel<true, DDC_ALL>);
         hipLaunchKernelGGL(k, dim3(gx, (unsigned) nwhich), dim3(DDC_THREADS), stage, s,
                            (const short *) d_adc, (long) n, L, nruns, (const ddc_chan *) d->d_chans, s_list,
-                           (const u32 *) d->d_nco, d_local, d_c0rel, d_tau, s_c0off, s_nouts, sel, stage, pushed, s_nlim, s_reset, endref, (const ddc_endco *) d->d_endco, d->endco_n,
+                           (const u32 *) d->d_nco, d_local, d_c0rel, d_tau, s_c0off, s_nouts, sel, stage, pushed, s_pdelta, s_nlim, s_reset, endref, (const ddc_endco *) d->d_endco, d->endco_n,
                            (ddc_state4 *) nullptr, (const ddc_state4 *) d->d_wgbase[par], d->d_wgtau[par]);
     };
     // The entries above R = 8 by the form they need (DDC_NARROW / DDC_WIDE: fewer registers, more waves per SIMD) -- as two
@@ -2005,8 +2023,8 @@ static int ddc_push_impl(kg_ddc *d, const void *d_adc, size_t n, const int32_t *
         hipLaunchKernelGGL(ddc_wf_comb_kernel, dim3((unsigned) comb_wgs), dim3(256), 0, ost,
                            (const u32 *) d_c0rel, (const u32 *) d_tau, log2L, nruns, s_c0off,
                            (const ddc_chan *) d->d_chans, s_list, s_nouts,
-                           pushed, s_reset, s_wgoff, nlist, (short2 *) d_out, (long) out_stride, s_outoff,
-                           d->d_hist, endref == 2 ? (const u32 *) d->d_wgtau[par] : (const u32 *) nullptr, (int) gx);
+                           pushed, s_pdelta, s_reset, s_wgoff, nlist, (short2 *) d_out, (long) out_stride, s_outoff,
+                           d->d_hist, endref == 2 ? (const u32 *) d->d_wgtau[par] : (const u32 *) nullptr, (int) gx, d->ctx->rows_by_chan);
         KG_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(ddc_wf_finish_kernel, dim3((nlist + 63) / 64), dim3(64), 0, ost, d->d_chans,

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64) void post_squelch_kernel(post_chan *__restrict_
 __global__ __launch_bounds__(64) void post_kernel(
     post_chan *__restrict__ chan_tab, post_cfir *__restrict__ cfir_tab, float2 *__restrict__ ring_in, float *__restrict__ ring_mag,
     const int *__restrict__ chans, const float2 *__restrict__ fir, size_t in_stride, int n,
-    short *__restrict__ o_s16, float *__restrict__ o_demod, float2 *__restrict__ o_agc, size_t out_stride)
+    short *__restrict__ o_s16, float *__restrict__ o_demod, float2 *__restrict__ o_agc, size_t out_stride, int by_chan)
 {
     __shared__ float bufA[POST_MAXW + KG_POST_MAX_SAMPLES];
     __shared__ float bufB[POST_MAXW + KG_POST_MAX_SAMPLES];
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(64) void post_kernel(
     // one wave per channel walking sequential recursions (S-meter, CAgc): latency, among workgroups that fill the vector
     // units -- it takes the issue priority (beside the DDCs' run passes the kernel stretched from 77 to 450 .. 980 us)
     __builtin_amdgcn_s_setprio(3);
-    const int lane = threadIdx.x, row = blockIdx.x, ch = chans[row];
+    const int lane = threadIdx.x, ch = chans[blockIdx.x], row = by_chan ? ch : (int) blockIdx.x;      // kg_ctx::rows_by_chan
     post_chan *pc = &chan_tab[ch];
     const post_chan c = *pc;
     const float2 *in = fir + (size_t) row * in_stride;
@@ -719,7 +719,7 @@ int kg_post_process_dev(kg_post *p, const int32_t *chans, int nch, const void *d
     KG_PLAN_ONLY(p->ctx);
     hipLaunchKernelGGL(post_kernel, dim3(nch), dim3(64), 0, st, p->d_chan, p->d_cfir, p->d_ring_in, p->d_ring_mag,
                        (const int *) d_list, (const float2 *) d_fir, in_stride, nsamps,
-                       (short *) d_s16, (float *) d_demod, (float2 *) d_agc, out_stride);
+                       (short *) d_s16, (float *) d_demod, (float2 *) d_agc, out_stride, p->ctx->rows_by_chan);
     KG_HIP(hipGetLastError());
     return KG_OK;
 }

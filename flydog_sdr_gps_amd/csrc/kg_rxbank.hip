@@ -63,10 +63,17 @@ struct kg_rxbank {
     bool ev_end_rec[BANK_SLOTS];
     hipEvent_t ev_tab, ev_fir, ev_tail, ev_frames, ev_pk;
     bool tail_pending, pk_pending;
-    uint64_t step; uint32_t snd_seq;
+    uint64_t step;
     float rescale, dc_i, dc_q; int spectral_inversion;      // snd_service() unpack, rx/data_pump.cpp:73-74,145-208
     // per receiver
     std::vector<int> decim; std::vector<char> wf_set, overlapped;
+    // Connections come and go one at a time (rx/rx_sound.cpp:264-269: every c2s_sound() has its own CFastFIR position, sequence
+    // number and loop): a receiver is stepped while `active`; its audio DDC / CFastFIR were reset when IT joined, so what a step
+    // yields -- records, sound blocks -- is per receiver.
+    std::vector<char> active;
+    std::vector<uint32_t> snd_seq;              // per receiver: sound blocks emitted since it joined (the seq of its packets)
+    std::vector<int32_t> last_nrec, last_nfir;  // per receiver: the last step's counts (kg_rxbank_audio_map)
+    std::vector<int32_t> act, blk_list, nfir_act;   // scratch: this step's active receivers; one sound block's receivers
     std::vector<long> ring_w, ring_total;       // overlapped: next write position, outputs written since the sampler was set
     std::vector<kg_wf_pkt_info> pkt;
     // scratch of a step
@@ -112,45 +119,56 @@ static void bank_set_arena(kg_rxbank *b, int mode)
 static int bank_pass(kg_rxbank *b, const void *d_adc, bool plan)
 {
     const int NR = b->nrx;
-    const int32_t *all = b->all.data();
     int rc;
     bank_tick tk;
     const bool pf = !plan;
-    // ---- audio chain (side stream): rx.v -> rx_iq_t -> snd_service() unpack -> CFastFIR; the tail: S-meter, CAgc, ADPCM
-    if ((rc = kg_rxddc_push_dev(b->rx, d_adc, b->n, all, NR, b->d_raw, b->nrec_max, b->h_nrec.data()))) return rc;
-    tk.lap(b, PF_RXDDC, pf);
-    const int nrec = b->h_nrec[0];
-    for (int i = 1; i < NR; i++)
-        KG_REQUIRE(b->h_nrec[i] == nrec, KG_ERR_STATE, "kg_rxbank_step: receiver %d yields %d records, receiver 0 %d "
-                   "(the audio DDCs of a bank run in step: kg_rxddc_reset one of them = reset all)", i, b->h_nrec[i], nrec);
-    if (nrec > 0 &&
-        (rc = kg_dpump_unpack_rows_dev(b->c_side, b->d_raw, b->nrec_max, nrec, NR, b->enabled.data(), b->rescale, b->dc_i, b->dc_q, b->spectral_inversion,
-                                       b->d_xin, b->nrec_max)))
-        return rc;
-    tk.lap(b, PF_UNPACK, pf);
-    if (!plan && b->tail_pending) {                       // the coders of the step before have read fir_out
-        KG_HIP(hipStreamWaitEvent(b->s_side, b->ev_tail, 0));
-        b->tail_pending = false;
+    b->act.clear();
+    for (int k = 0; k < NR; k++) {
+        b->enabled[k] = b->active[k] ? 1 : 0;
+        if (b->active[k]) b->act.push_back(k);
     }
-    tk.lap(b, PF_EVENTS, pf);
-    if ((rc = kg_fir_process_dev(b->fir, all, NR, b->d_xin, b->nrec_max, nrec, b->d_firo, b->firo_stride, b->h_nfir.data()))) return rc;
-    tk.lap(b, PF_FIR, pf);
-    const int nfir = b->h_nfir[0];
-    for (int i = 1; i < NR; i++)
-        KG_REQUIRE(b->h_nfir[i] == nfir, KG_ERR_STATE, "kg_rxbank_step: CFastFIR of receiver %d is at another position than receiver 0's", i);
-    if (nfir > 0) {
+    const int NA = (int) b->act.size();
+    const int32_t *act = b->act.data();
+    int nrec_max = 0, nfir_max = 0;
+    if (!plan) for (int k = 0; k < NR; k++) { b->last_nrec[k] = 0; b->last_nfir[k] = 0; }
+    // ---- audio chain (side stream): rx.v -> rx_iq_t -> snd_service() unpack -> CFastFIR; the tail: S-meter, CAgc, detector, ADPCM
+    if (NA > 0) {
+        if ((rc = kg_rxddc_push_dev(b->rx, d_adc, b->n, act, NA, b->d_raw, b->nrec_max, b->h_nrec.data()))) return rc;
+        tk.lap(b, PF_RXDDC, pf);
+        for (int i = 0; i < NA; i++) if (b->h_nrec[i] > nrec_max) nrec_max = b->h_nrec[i];
+        // (rows are unpacked up to the largest count of the step; a receiver's CFastFIR takes its own count of them)
+        if (nrec_max > 0 &&
+            (rc = kg_dpump_unpack_rows_dev(b->c_side, b->d_raw, b->nrec_max, nrec_max, NR, b->enabled.data(), b->rescale, b->dc_i, b->dc_q,
+                                           b->spectral_inversion, b->d_xin, b->nrec_max)))
+            return rc;
+        tk.lap(b, PF_UNPACK, pf);
+        if (!plan && b->tail_pending) {                       // the coders of the step before have read fir_out
+            KG_HIP(hipStreamWaitEvent(b->s_side, b->ev_tail, 0));
+            b->tail_pending = false;
+        }
+        tk.lap(b, PF_EVENTS, pf);
+        if ((rc = kg_fir_process_each_dev(b->fir, act, NA, b->d_xin, b->nrec_max, b->h_nrec.data(), b->d_firo, b->firo_stride, b->h_nfir.data())))
+            return rc;
+        tk.lap(b, PF_FIR, pf);
+        for (int i = 0; i < NA; i++) if (b->h_nfir[i] > nfir_max) nfir_max = b->h_nfir[i];
+    }
+    if (nfir_max > 0) {
         if (!plan) {
             KG_HIP(hipEventRecord(b->ev_fir, b->s_side));
             KG_HIP(hipStreamWaitEvent(b->s_tail, b->ev_fir, 0));
         }
         tk.lap(b, PF_EVENTS, pf);
-        for (int blk = 0; blk < nfir / KG_FIR_OUT; blk++) {             // one sound packet per 512 samples (rx_sound.cpp:601-1170)
+        for (int blk = 0; blk < nfir_max / KG_FIR_OUT; blk++) {         // one sound packet per 512 samples (rx_sound.cpp:601-1170)
             const size_t o = (size_t) blk * KG_FIR_OUT;
-            if ((rc = kg_post_process_dev(b->post, all, NR, b->d_firo + o, b->firo_stride, KG_FIR_OUT, b->d_s16 + o, nullptr, nullptr,
-                                          b->firo_stride)))
+            b->blk_list.clear();                                          // the receivers that completed this block in this step
+            for (int i = 0; i < NA; i++) if (b->h_nfir[i] >= (int) (o + KG_FIR_OUT)) b->blk_list.push_back(act[i]);
+            const int NB = (int) b->blk_list.size();
+            if ((rc = kg_post_process_dev(b->post, b->blk_list.data(), NB, b->d_firo + o, b->firo_stride, KG_FIR_OUT, b->d_s16 + o, nullptr,
+                                          nullptr, b->firo_stride)))
                 return rc;
             tk.lap(b, PF_POST, pf);
-            if ((rc = kg_adpcm_encode_dev(b->adpcm, all, NR, b->d_s16 + o, b->firo_stride, KG_FIR_OUT, b->d_pay + o / 2, b->firo_stride / 2)))
+            if ((rc = kg_adpcm_encode_dev(b->adpcm, b->blk_list.data(), NB, b->d_s16 + o, b->firo_stride, KG_FIR_OUT, b->d_pay + o / 2,
+                                          b->firo_stride / 2)))
                 return rc;
             tk.lap(b, PF_ADPCM, pf);
         }
@@ -163,8 +181,9 @@ static int bank_pass(kg_rxbank *b, const void *d_adc, bool plan)
     // ---- waterfall chain (main stream)
     int nframes = 0;
     b->moves.clear();
-    for (int k = 0; k < NR; k++) {
-        KG_REQUIRE(b->wf_set[k], KG_ERR_STATE, "kg_rxbank_step: kg_rxbank_set_wf was not called for receiver %d", k);
+    for (int i = 0; i < NA; i++) {
+        const int k = act[i];
+        KG_REQUIRE(b->wf_set[k], KG_ERR_STATE, "kg_rxbank_step: kg_rxbank_set_wf was not called for receiver %d (since it joined)", k);
         if (b->overlapped[k]) {
             const long m = (long) (b->n / (size_t) b->decim[k]);
             long w = b->ring_w[k];
@@ -173,7 +192,7 @@ static int bank_pass(kg_rxbank *b, const void *d_adc, bool plan)
                 if (keep > 0) b->moves.push_back(bank_move{k, (int) (w - keep), 0, (int) keep});
                 w = keep;
             }
-            b->out_off[k] = w; b->max_out[k] = 0;
+            b->out_off[i] = w; b->max_out[i] = 0;
             b->ring_w2[k] = w + m; b->ring_total2[k] = b->ring_total[k] + m;
             if (b->ring_total2[k] >= KG_WF_NFFT) {                       // (before that: the reference sleeps, "fill pipe", :978)
                 b->chan_of[nframes] = k;
@@ -181,7 +200,7 @@ static int bank_pass(kg_rxbank *b, const void *d_adc, bool plan)
                 nframes++;
             }
         } else {
-            b->out_off[k] = 0; b->max_out[k] = KG_WF_NFFT;
+            b->out_off[i] = 0; b->max_out[i] = KG_WF_NFFT;
             b->chan_of[nframes] = k;
             b->frame_off[nframes] = (uint64_t) k * b->wf_stride;
             nframes++;
@@ -196,7 +215,8 @@ static int bank_pass(kg_rxbank *b, const void *d_adc, bool plan)
             KG_HIP(hipGetLastError());
         }
     }
-    if ((rc = kg_ddc_wf_step_dev(b->ddc, d_adc, b->n, all, NR, b->d_wfiq, b->wf_stride, b->out_off.data(), b->max_out.data(),
+    if (NA > 0 &&
+        (rc = kg_ddc_wf_step_dev(b->ddc, d_adc, b->n, act, NA, b->d_wfiq, b->wf_stride, b->out_off.data(), b->max_out.data(),
                                  b->h_nw.data())))
         return rc;
     tk.lap(b, PF_DDC, pf);
@@ -217,7 +237,7 @@ static int bank_pass(kg_rxbank *b, const void *d_adc, bool plan)
         tk.lap(b, PF_EVENTS, pf);
         for (int f = 0; f < nframes; f++) {
             b->pkt_step[f] = b->pkt[b->chan_of[f]];
-            b->pkt_step[f].seq = b->snd_seq;                              // out->seq = wf->snd_seq, rx_waterfall.cpp:1635
+            b->pkt_step[f].seq = b->snd_seq[b->chan_of[f]];              // out->seq = wf->snd_seq, rx_waterfall.cpp:1635
         }
         if ((rc = kg_wf_packets_dev(b->c_tail, b->d_rows, KG_WF_WIDTH, nframes, b->pkt_step.data(), b->d_pkts, BANK_PKT_STRIDE,
                                     b->pkt_bytes.data())))
@@ -230,13 +250,20 @@ static int bank_pass(kg_rxbank *b, const void *d_adc, bool plan)
         tk.lap(b, PF_EVENTS, pf);
     }
     if (!plan) {
-        for (int k = 0; k < NR; k++)
+        for (int i = 0; i < NA; i++) {
+            const int k = act[i];
             if (b->overlapped[k]) { b->ring_w[k] = b->ring_w2[k]; b->ring_total[k] = b->ring_total2[k]; }
+        }
         for (int f = 0; f < nframes; f++) b->rx_of_frame[f] = b->chan_of[f];
         kg_rxbank_step_info &s = b->last;
-        s.step = b->step; s.nframes = nframes; s.nrec = nrec; s.nfir = nfir; s.fir_pos = kg_fir_pos(b->fir, 0);
-        s.snd_seq = b->snd_seq; s.table_bytes = (int32_t) b->arena.used; s.nmoves = (int32_t) b->moves.size();
-        b->snd_seq += (uint32_t) (nfir / KG_FIR_OUT);
+        const int first = NA > 0 ? act[0] : 0;             // the step's scalar audio fields: the lowest-numbered active receiver's
+        s.step = b->step; s.nframes = nframes; s.nrec = NA > 0 ? b->h_nrec[0] : 0; s.nfir = NA > 0 ? b->h_nfir[0] : 0;
+        s.fir_pos = kg_fir_pos(b->fir, first);
+        s.snd_seq = b->snd_seq[first]; s.table_bytes = (int32_t) b->arena.used; s.nmoves = (int32_t) b->moves.size();
+        for (int i = 0; i < NA; i++) {
+            b->last_nrec[act[i]] = b->h_nrec[i]; b->last_nfir[act[i]] = b->h_nfir[i];
+            b->snd_seq[act[i]] += (uint32_t) (b->h_nfir[i] / KG_FIR_OUT);
+        }
     }
     return KG_OK;
 }
@@ -357,14 +384,18 @@ int kg_rxbank_create(int device, int nrx, size_t adc_samples_per_step, int rx_mo
     BANK_HIP(hipHostMalloc((void **) &b->h_slots, b->slot_bytes * BANK_SLOTS, hipHostMallocDefault));
     BANK_HIP(hipMalloc((void **) &b->d_slots, b->slot_bytes * BANK_SLOTS));
     for (int i = 0; i < BANK_SLOTS; i++) {
-        for (int j = 0; j < 3; j++) BANK_HIP(hipEventCreateWithFlags(&b->ev_end[i][j], hipEventDisableTiming));
+        // hipEventBlockingSync: a host that has run BANK_SLOTS steps ahead SLEEPS in kg_rxbank_step's slot wait instead of spinning
+        // (the reference's server is one cooperative thread: it asks kg_rxbank_ready first and yields instead)
+        for (int j = 0; j < 3; j++) BANK_HIP(hipEventCreateWithFlags(&b->ev_end[i][j], hipEventDisableTiming | hipEventBlockingSync));
         b->ev_end_rec[i] = false;
     }
     for (hipEvent_t *e : {&b->ev_tab, &b->ev_fir, &b->ev_tail, &b->ev_frames, &b->ev_pk})
         BANK_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     // rescale = MPOW(2, -RXOUT_SCALE + CUTESDR_SCALE) * MPOW(10, CICF_GAIN_dB / 20), rx/data_pump.cpp:73-74 (kg_rxbank_set_unpack overrides)
     b->rescale = powf(2.f, -23 + 15) * powf(10.f, 4.5f / 20.f); b->dc_i = b->dc_q = 0.f; b->spectral_inversion = 0;
-    b->tail_pending = b->pk_pending = false; b->step = 0; b->snd_seq = 0;
+    b->tail_pending = b->pk_pending = false; b->step = 0;
+    b->active.assign(nrx, 1); b->snd_seq.assign(nrx, 0); b->last_nrec.assign(nrx, 0); b->last_nfir.assign(nrx, 0);
+    b->c_main->rows_by_chan = b->c_side->rows_by_chan = b->c_tail->rows_by_chan = 1;      // buffers hold one row per RECEIVER
     b->decim.assign(nrx, 0); b->wf_set.assign(nrx, 0); b->overlapped.assign(nrx, 0);
     b->ring_w.assign(nrx, 0); b->ring_total.assign(nrx, 0); b->ring_w2.assign(nrx, 0); b->ring_total2.assign(nrx, 0);
     b->pkt.assign(nrx, kg_wf_pkt_info{0, 0, 0, 1});
@@ -409,6 +440,57 @@ int kg_rxbank_set_wf(kg_rxbank *b, int rx, uint64_t phase_inc, int decim, int ov
     if (rc) return rc;
     b->decim[rx] = decim; b->overlapped[rx] = overlapped ? 1 : 0; b->wf_set[rx] = 1;
     b->ring_w[rx] = 0; b->ring_total[rx] = 0;             // CmdWFReset: the sampler starts empty ("fill pipe")
+    return KG_OK;
+}
+
+// A connection ends: the receiver is left out of every stage from the next step on (its state stays where it is).
+int kg_rxbank_leave(kg_rxbank *b, int rx)
+{
+    KG_REQUIRE(b && rx >= 0 && rx < b->nrx, KG_ERR_INVALID, "kg_rxbank_leave: receiver %d", rx);
+    b->active[rx] = 0;
+    return KG_OK;
+}
+
+// A connection starts on receiver rx (rx/rx_sound.cpp:236-269, rx/rx_waterfall.cpp:205-330): its audio DDC, CFastFIR position,
+// S-meter / detector state, ADPCM state and sound sequence number start from zero, its waterfall sampler is empty and waits for
+// kg_rxbank_set_wf; no other receiver is touched (their DDC counters, FIR positions and sequence numbers run on -- from here
+// on this receiver's sound blocks complete on its OWN steps).  The host then configures it through the per-seam objects
+// (kg_rxddc_set_freq, kg_fir_setup, kg_post_*) as for a fresh bank.  Drains the bank's streams.
+int kg_rxbank_join(kg_rxbank *b, int rx)
+{
+    KG_REQUIRE(b && rx >= 0 && rx < b->nrx, KG_ERR_INVALID, "kg_rxbank_join: receiver %d", rx);
+    KG_HIP(hipSetDevice(b->device));
+    for (hipStream_t s : {b->s_up, b->s_main, b->s_side, b->s_tail}) KG_HIP(hipStreamSynchronize(s));
+    int rc;
+    if ((rc = kg_rxddc_reset(b->rx, rx))) return rc;
+    if ((rc = kg_fir_reset(b->fir, rx))) return rc;
+    if ((rc = kg_post_reset(b->post, rx))) return rc;
+    if ((rc = kg_adpcm_set_state(b->adpcm, rx, 0, 0))) return rc;
+    for (hipStream_t s : {b->s_side, b->s_tail}) KG_HIP(hipStreamSynchronize(s));
+    b->snd_seq[rx] = 0; b->last_nrec[rx] = 0; b->last_nfir[rx] = 0;
+    b->wf_set[rx] = 0; b->ring_w[rx] = 0; b->ring_total[rx] = 0;
+    b->active[rx] = 1;
+    return KG_OK;
+}
+
+int kg_rxbank_is_active(kg_rxbank *b, int rx)
+{
+    KG_REQUIRE(b && rx >= 0 && rx < b->nrx, KG_ERR_INVALID, "kg_rxbank_is_active: receiver %d", rx);
+    return b->active[rx] ? 1 : 0;
+}
+
+// Per receiver, after the last step (arrays of nrx entries, any may be NULL): rx_iq_t records and CFastFIR outputs the step gave
+// it (0 for a receiver that is not active), FirPos() now, sound blocks it has emitted since it joined (= the seq its next
+// packets carry).
+int kg_rxbank_audio_map(kg_rxbank *b, int32_t *nrec, int32_t *nfir, int32_t *fir_pos, uint32_t *snd_seq)
+{
+    KG_REQUIRE(b != nullptr, KG_ERR_INVALID, "kg_rxbank_audio_map: null argument");
+    for (int k = 0; k < b->nrx; k++) {
+        if (nrec) nrec[k] = b->last_nrec[k];
+        if (nfir) nfir[k] = b->last_nfir[k];
+        if (fir_pos) fir_pos[k] = kg_fir_pos(b->fir, k);
+        if (snd_seq) snd_seq[k] = b->snd_seq[k];
+    }
     return KG_OK;
 }
 
@@ -487,6 +569,22 @@ int kg_rxbank_adc_done(kg_rxbank *b, void *stream, int steps_back)
     KG_HIP(hipStreamWaitEvent((hipStream_t) stream, b->ev_end[slot][0], 0));
     KG_HIP(hipStreamWaitEvent((hipStream_t) stream, b->ev_end[slot][1], 0));
     return KG_OK;
+}
+
+// 1: the next kg_rxbank_step will not wait (the step that last used its table slot, BANK_SLOTS steps ago, has run); 0: it would
+// block until then -- a cooperative host (the reference's coroutine server) yields and asks again (NextTask in the data pump).
+int kg_rxbank_ready(kg_rxbank *b)
+{
+    KG_REQUIRE(b != nullptr, KG_ERR_INVALID, "kg_rxbank_ready: null argument");
+    KG_HIP(hipSetDevice(b->device));
+    const int slot = (int) (b->step % BANK_SLOTS);
+    if (!b->ev_end_rec[slot]) return 1;
+    for (int j = 0; j < 3; j++) {
+        const hipError_t e = hipEventQuery(b->ev_end[slot][j]);
+        if (e == hipErrorNotReady) return 0;
+        if (e != hipSuccess) { kg_set_error("kg_rxbank_ready: %s", hipGetErrorString(e)); return KG_ERR_HIP; }
+    }
+    return 1;
 }
 
 int kg_rxbank_poll(kg_rxbank *b)

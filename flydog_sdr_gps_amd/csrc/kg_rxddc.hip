@@ -462,7 +462,7 @@ __global__ __launch_bounds__(RX2_WG) void rx2_fir_kernel(
     const int *__restrict__ c1buf, long c1_stride, const int *__restrict__ chan_list,
     const long *__restrict__ n1_before,       // rx1 outputs produced before this call
     const long *__restrict__ q_first, const int *__restrict__ nfinal,
-    unsigned short *__restrict__ out, long out_stride /* records */, rx_mode md)
+    unsigned short *__restrict__ out, long out_stride /* records */, rx_mode md, int by_chan /* rows of out by channel */)
 {
     __shared__ int v2s[2][2 * RX2_WG + 65];
     const int li = blockIdx.y, ch = chan_list[li], t = threadIdx.x;
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(RX2_WG) void rx2_fir_kernel(
         }
         y[comp] = sx((int) (acc >> 18), 24);
     }
-    unsigned short *o = out + ((long) li * out_stride + qi) * 3;
+    unsigned short *o = out + ((long) (by_chan ? ch : li) * out_stride + qi) * 3;
     o[0] = (unsigned short) y[0];
     o[1] = (unsigned short) y[1];
     o[2] = (unsigned short) (((y[1] >> 16) & 0xff) | (((y[0] >> 16) & 0xff) << 8));    // q3 | i3 << 8
@@ -758,7 +758,7 @@ int kg_rxddc_push_dev(kg_rxddc *d, const void *d_adc, size_t n, const int32_t *c
     if (max_final > 0) {
         hipLaunchKernelGGL(rx2_fir_kernel, dim3((max_final + RX2_WG - 1) / RX2_WG, nlist), dim3(RX2_WG), 0, st,
                            (const int *) d->d_c1buf, d->c1_stride, s_list, s_n1b,
-                           s_qfirst, s_nfinal, (unsigned short *) d_out, (long) out_stride, d->md);
+                           s_qfirst, s_nfinal, (unsigned short *) d_out, (long) out_stride, d->md, d->ctx->rows_by_chan);
         KG_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(rx_finish_kernel, dim3(nlist), dim3(RX_HIST), 0, st, d->d_chans, s_list, (long) n,

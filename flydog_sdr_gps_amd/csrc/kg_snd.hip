@@ -134,7 +134,7 @@ __global__ __launch_bounds__(64 * FIR_WAVES) void fir_block_kernel(
     const int *__restrict__ nblk, const float2 *__restrict__ coef,     // [nchan][1024]
     const float2 *__restrict__ tab4096, float2 *__restrict__ out, long out_stride, int max_blk,
     const float *__restrict__ cic, const int *__restrict__ cic_on,     // m_CIC = the table where do_CIC_comp, else 1.0 (:156)
-    float2 *__restrict__ tap_pre, float2 *__restrict__ tap_post, long tap_stride)
+    float2 *__restrict__ tap_pre, float2 *__restrict__ tap_post, long tap_stride, int by_chan /* rows of out by channel */)
 {
     (void) max_blk;                           // the grid is sized from it; rows check their own nblk
     __shared__ __attribute__((aligned(16))) float2 tiles[FIR_WAVES][FIR_FFT];
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(64 * FIR_WAVES) void fir_block_kernel(
         for (int j = 0; j < 16; j++) kg_st(&p[t + 64 * j], x[j]);
     }
     fir_fft1024<+1, true>(x, tile, tw, t);                             // :304
-    float2 *dst = out + (long) li * out_stride + (long) FIR_OUT * blk;
+    float2 *dst = out + (long) (by_chan ? ch : li) * out_stride + (long) FIR_OUT * blk;
 #pragma unroll
     for (int u = 0; u < 4; u++) {                                      // keep outputs 512..1023 (:307-310)
         kg_st(&dst[t + 64 * u], x[u + 8]);
@@ -224,13 +224,14 @@ __global__ __launch_bounds__(64) void fir_coef_fft_kernel(const float2 *__restri
     }
 }
 
-// append n new samples of every listed channel behind its pending ones
+// append the new samples of every listed channel (n_each[li] of them, or n where n_each is null) behind its pending ones
 __global__ void fir_append_kernel(const float2 *__restrict__ in, long in_stride, const int *__restrict__ chan_list,
-                                  const int *__restrict__ fill, int n, float2 *__restrict__ hist, long hist_stride)
+                                  const int *__restrict__ fill, int n, const int *__restrict__ n_each, float2 *__restrict__ hist,
+                                  long hist_stride, int by_chan /* rows of in by channel */)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, li = blockIdx.y;
-    if (i >= n) return;
-    hist[(long) chan_list[li] * hist_stride + FIR_OUT + fill[li] + i] = in[(long) li * in_stride + i];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, li = blockIdx.y, ch = chan_list[li];
+    if (i >= (n_each ? n_each[li] : n)) return;
+    hist[(long) ch * hist_stride + FIR_OUT + fill[li] + i] = in[(long) (by_chan ? ch : li) * in_stride + i];
 }
 
 // after nblk blocks: the last 512 consumed samples plus the leftover move to the front.
@@ -451,12 +452,22 @@ int kg_fir_pos(kg_fir *f, int ch)                 // FirPos(), fastfir.h:33
 }
 
 static int fir_process_impl(kg_fir *f, const int32_t *chans, int nch, const void *d_in, size_t in_stride, int n,
-                            void *d_out, size_t out_stride, int32_t *nout, void *d_pre, void *d_post, size_t tap_stride);
+                            void *d_out, size_t out_stride, int32_t *nout, void *d_pre, void *d_post, size_t tap_stride,
+                            const int32_t *n_each = nullptr);
 
 int kg_fir_process_dev(kg_fir *f, const int32_t *chans, int nch, const void *d_in, size_t in_stride, int n,
                        void *d_out, size_t out_stride, int32_t *nout)
 {
     return fir_process_impl(f, chans, nch, d_in, in_stride, n, d_out, out_stride, nout, nullptr, nullptr, 0);
+}
+
+// Every listed channel with its own InLength (n_each[i] >= 0 samples at row i of d_in): the connections of a bank whose audio
+// DDCs were started at different times deliver different record counts in one step (rx/rx_sound.cpp:503-601 runs per connection).
+int kg_fir_process_each_dev(kg_fir *f, const int32_t *chans, int nch, const void *d_in, size_t in_stride, const int32_t *n_each,
+                            void *d_out, size_t out_stride, int32_t *nout)
+{
+    KG_REQUIRE(n_each != nullptr, KG_ERR_INVALID, "kg_fir_process_each_dev: null argument");
+    return fir_process_impl(f, chans, nch, d_in, in_stride, 0, d_out, out_stride, nout, nullptr, nullptr, 0, n_each);
 }
 
 int kg_fir_process_taps_dev(kg_fir *f, const int32_t *chans, int nch, const void *d_in, size_t in_stride, int n,
@@ -497,12 +508,20 @@ int kg_fir_refilter_dev(kg_fir *f, const int32_t *chans, int nch, const int32_t 
 }  // extern "C"
 
 static int fir_process_impl(kg_fir *f, const int32_t *chans, int nch, const void *d_in, size_t in_stride, int n,
-                            void *d_out, size_t out_stride, int32_t *nout, void *d_pre, void *d_post, size_t tap_stride)
+                            void *d_out, size_t out_stride, int32_t *nout, void *d_pre, void *d_post, size_t tap_stride,
+                            const int32_t *n_each)
 {
     KG_REQUIRE(f && chans && d_in && d_out, KG_ERR_INVALID, "kg_fir_process_dev: null argument");
     int rc = kg_ctx_use(f->ctx);
     if (rc) return rc;
     KG_REQUIRE(nch >= 1 && nch <= f->nchan, KG_ERR_INVALID, "kg_fir_process_dev: nch %d", nch);
+    if (n_each) {                                 // every entry its own InLength: n = the largest
+        n = 0;
+        for (int i = 0; i < nch; i++) {
+            KG_REQUIRE(n_each[i] >= 0, KG_ERR_INVALID, "kg_fir_process_each_dev: n[%d] = %d", i, n_each[i]);
+            if (n_each[i] > n) n = n_each[i];
+        }
+    }
     KG_REQUIRE(n >= 0 && n <= f->max_in, KG_ERR_INVALID, "kg_fir_process_dev: n %d (max %d)", n, f->max_in);
     std::vector<int> h_fill(nch), h_nblk(nch), h_rem(nch);
     int max_blk = 0;
@@ -514,7 +533,7 @@ static int fir_process_impl(kg_fir *f, const int32_t *chans, int nch, const void
         KG_REQUIRE(!f->seen[ch], KG_ERR_INVALID, "kg_fir_process_dev: channel %d listed twice", ch);
         f->seen[ch] = 1;
         h_fill[i] = f->fill[ch];
-        const int tot = f->fill[ch] + n;
+        const int tot = f->fill[ch] + (n_each ? n_each[i] : n);
         h_nblk[i] = tot / FIR_OUT;
         h_rem[i] = tot % FIR_OUT;
         KG_REQUIRE((size_t) h_nblk[i] * FIR_OUT <= out_stride || h_nblk[i] == 0, KG_ERR_INVALID,
@@ -527,20 +546,23 @@ static int fir_process_impl(kg_fir *f, const int32_t *chans, int nch, const void
     if (n == 0) return KG_OK;
     hipStream_t st = f->ctx->stream;
     // per-call tables through the context's staging ring (no stream synchronisation)
-    const int *s_list, *s_fill, *s_nblk, *s_rem;
+    const int *s_list, *s_fill, *s_nblk, *s_rem, *s_each = nullptr;
     {
-        std::vector<int> pack(4 * (size_t) nch);
+        std::vector<int> pack((n_each ? 5 : 4) * (size_t) nch);
         memcpy(pack.data(), chans, sizeof(int) * nch);
         memcpy(pack.data() + nch, h_fill.data(), sizeof(int) * nch);
         memcpy(pack.data() + 2 * nch, h_nblk.data(), sizeof(int) * nch);
         memcpy(pack.data() + 3 * nch, h_rem.data(), sizeof(int) * nch);
+        if (n_each) memcpy(pack.data() + 4 * nch, n_each, sizeof(int) * nch);
         void *base = nullptr;
         if ((rc = kg_ctx_stage(f->ctx, pack.data(), sizeof(int) * pack.size(), &base))) return rc;
         s_list = (const int *) base; s_fill = s_list + nch; s_nblk = s_list + 2 * nch; s_rem = s_list + 3 * nch;
+        if (n_each) s_each = s_list + 4 * nch;
     }
+    const int by_chan = f->ctx->rows_by_chan;
     KG_PLAN_ONLY(f->ctx);
     hipLaunchKernelGGL(fir_append_kernel, dim3((n + 255) / 256, nch), dim3(256), 0, st, (const float2 *) d_in,
-                       (long) in_stride, s_list, s_fill, n, f->d_hist, f->hist_stride);
+                       (long) in_stride, s_list, s_fill, n, s_each, f->d_hist, f->hist_stride, by_chan);
     KG_HIP(hipGetLastError());
     if (max_blk > 0) {
         const dim3 grid((max_blk + FIR_WAVES - 1) / FIR_WAVES, nch);
@@ -549,12 +571,12 @@ static int fir_process_impl(kg_fir *f, const int32_t *chans, int nch, const void
                                (const float2 *) f->d_hist, f->hist_stride, s_list, s_nblk,
                                (const float2 *) f->d_coef, (const float2 *) f->ctx->d_tab4096, (float2 *) d_out,
                                (long) out_stride, max_blk, (const float *) f->d_cic, (const int *) f->d_cic_on, (float2 *) d_pre, (float2 *) d_post,
-                               (long) tap_stride);
+                               (long) tap_stride, by_chan);
         else
             hipLaunchKernelGGL(fir_block_kernel<false>, grid, dim3(64 * FIR_WAVES), 0, st,
                                (const float2 *) f->d_hist, f->hist_stride, s_list, s_nblk,
                                (const float2 *) f->d_coef, (const float2 *) f->ctx->d_tab4096, (float2 *) d_out,
-                               (long) out_stride, max_blk, (const float *) nullptr, (const int *) nullptr, (float2 *) nullptr, (float2 *) nullptr, 0L);
+                               (long) out_stride, max_blk, (const float *) nullptr, (const int *) nullptr, (float2 *) nullptr, (float2 *) nullptr, 0L, by_chan);
         KG_HIP(hipGetLastError());
         hipLaunchKernelGGL(fir_shift_kernel, dim3(nch), dim3(1024), 0, st, f->d_hist, f->hist_stride,
                            s_list, s_nblk, s_rem);
@@ -573,6 +595,8 @@ int kg_fir_process(kg_fir *f, int ch, const float *in, int n, float *out)
     int rc = fir_chan_ok(f, ch, "kg_fir_process");
     if (rc) return rc;
     KG_REQUIRE(in && out, KG_ERR_INVALID, "kg_fir_process: null argument");
+    KG_REQUIRE(!f->ctx->rows_by_chan, KG_ERR_STATE, "kg_fir_process: this object belongs to a receiver bank (its rows go by receiver "
+               "number): step the bank");
     KG_REQUIRE(n >= 0 && n <= f->max_in, KG_ERR_INVALID, "kg_fir_process: n %d (max %d)", n, f->max_in);
     if (n == 0) return 0;
     hipStream_t st = f->ctx->stream;

@@ -50,7 +50,8 @@ __device__ __forceinline__ unsigned adpcm_step(int sample, int &index, int &prev
 // encode_ima_adpcm_i16_e8 for many channels: lane = channel.
 __global__ __launch_bounds__(64) void adpcm_snd_kernel(adpcm_state *__restrict__ states, const int *__restrict__ chans,
                                                        int nch, const short *__restrict__ in, size_t in_stride,
-                                                       int nsamps, unsigned char *__restrict__ out, size_t out_stride)
+                                                       int nsamps, unsigned char *__restrict__ out, size_t out_stride,
+                                                       int by_chan /* rows of in / out by channel (kg_ctx::rows_by_chan) */)
 {
     __shared__ int tab[89];
     // a single wave's recurrence among workgroups that fill the vector units: it takes the issue priority (the coder is
@@ -61,9 +62,9 @@ __global__ __launch_bounds__(64) void adpcm_snd_kernel(adpcm_state *__restrict__
     __builtin_amdgcn_s_setprio(3);
     for (int i = threadIdx.x; i < 89; i += 64) tab[i] = c_step_size[i];
     __syncthreads();
-    const int row = blockIdx.x * 64 + threadIdx.x;
-    if (row >= nch) return;
-    const int ch = chans[row];
+    const int li = blockIdx.x * 64 + threadIdx.x;
+    if (li >= nch) return;
+    const int ch = chans[li], row = by_chan ? ch : li;
     int index = states[ch].index, previous = states[ch].previous;
     const short *p = in + (size_t) row * in_stride;
     unsigned char *q = out + (size_t) row * out_stride;
@@ -226,7 +227,7 @@ int kg_adpcm_encode_dev(kg_adpcm *a, const int32_t *chans, int nch, const void *
     if ((rc = kg_ctx_stage_cached(a->ctx, &a->list_cache, chans, sizeof(int) * nch, &d_list))) return rc;
     KG_PLAN_ONLY(a->ctx);
     hipLaunchKernelGGL(adpcm_snd_kernel, dim3((nch + 63) / 64), dim3(64), 0, st, a->d_state, (const int *) d_list,
-                       nch, (const short *) d_s16, in_stride, nsamps, (unsigned char *) d_out, out_stride);
+                       nch, (const short *) d_s16, in_stride, nsamps, (unsigned char *) d_out, out_stride, a->ctx->rows_by_chan);
     KG_HIP(hipGetLastError());
     return KG_OK;
 }

@@ -12,7 +12,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import Context, check, ptr
+from ._lib import Context, check, ptr, own_rows
 
 
 class Ddc:
@@ -86,6 +86,7 @@ class Ddc:
 
     def capture(self, adc, chans, max_out=8192):
         """Convenience for tests: host int16 array in, list of [<= max_out, 2] int16 arrays out."""
+        own_rows(self, "capture()")
         adc = np.ascontiguousarray(adc, np.int16)
         d_adc = self.ctx.alloc(adc.nbytes)
         d_out = self.ctx.alloc(len(chans) * max_out * 4)
@@ -103,6 +104,7 @@ class Ddc:
 
     def push(self, adc, chans):
         """Convenience for tests: host int16 array in, list of [nout, 2] int16 arrays out."""
+        own_rows(self, "push()")
         adc = np.ascontiguousarray(adc, np.int16)
         stride = max(int(self.outputs(c, adc.size)) for c in chans) + 1
         d_adc = self.ctx.alloc(adc.nbytes)
@@ -177,6 +179,7 @@ class RxDdc:
 
     def push(self, adc, chans):
         """Host int16 array in; per channel the rx_iq_t bytes (uint8[nout*6]) out."""
+        own_rows(self, "push()")
         adc = np.ascontiguousarray(adc, np.int16)
         stride = max(int(self.outputs(c, adc.size)) for c in chans) + 1
         d_adc = self.ctx.alloc(adc.nbytes)

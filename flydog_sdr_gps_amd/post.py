@@ -20,7 +20,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import Context, check, ptr
+from ._lib import Context, check, ptr, own_rows
 
 MODE_IQ, MODE_SSB, MODE_AM, MODE_NBFM = range(4)      # KG_POST_* of include/kiwigpu.h
 MAX_SAMPLES = 1024                                    # KG_POST_MAX_SAMPLES
@@ -87,6 +87,7 @@ class Post:
 
     def cfir_process(self, chans, which, kind, x):
         """m_*_FIR[ch].ProcessFilter on host rows x [len(chans), n] (float32, or int16 for CFIR_MONO16_MONO16)."""
+        own_rows(self, "cfir_process()")
         chans = np.ascontiguousarray(chans, np.int32)
         x = np.ascontiguousarray(x, np.int16 if kind == CFIR_MONO16_MONO16 else np.float32).reshape(chans.size, -1)
         n = x.shape[1]
@@ -106,6 +107,7 @@ class Post:
 
     def squelch_perform(self, chans, x):
         """m_Squelch[ch].PerformFMSquelch on host rows x float32 [len(chans), n] -> (mono16 [len(chans), n], nsq_nc_sq int32[len(chans)])"""
+        own_rows(self, "squelch_perform()")
         chans = np.ascontiguousarray(chans, np.int32)
         x = np.ascontiguousarray(x, np.float32).reshape(chans.size, -1)
         n = x.shape[1]
@@ -170,6 +172,7 @@ class Post:
     def process(self, chans, x):
         """x: complex64 [len(chans), n] FIR output (host).  -> (s16 int16, demod float32, agc complex64),
         each [len(chans), n]; a row is meaningful where the channel's mode produces it."""
+        own_rows(self, "process()")
         chans = np.ascontiguousarray(chans, np.int32)
         x = np.ascontiguousarray(x, np.complex64).reshape(chans.size, -1)
         n = x.shape[1]

@@ -154,6 +154,33 @@ class RxBank:
             self.set_wf(rx, p, ov)
             self.set_audio(rx, inc)
 
+    # ---- connections come and go (kg_rxbank_join / _leave)
+    def join(self, rx, wf_setting=None, phase_inc=None, **audio):
+        """A connection starts on receiver rx: its state starts from zero, nobody else's is touched.  wf_setting = (WfParams,
+        overlapped) and phase_inc / **audio (set_audio's arguments) configure it as its first commands would."""
+        check(self.lib.kg_rxbank_join(self.h, int(rx)), "kg_rxbank_join")
+        if wf_setting is not None:
+            self.set_wf(rx, wf_setting[0], wf_setting[1])
+        if phase_inc is not None:
+            self.set_audio(rx, phase_inc, **audio)
+
+    def leave(self, rx):
+        check(self.lib.kg_rxbank_leave(self.h, int(rx)), "kg_rxbank_leave")
+
+    def is_active(self, rx):
+        return check(self.lib.kg_rxbank_is_active(self.h, int(rx)), "kg_rxbank_is_active") == 1
+
+    def audio_map(self):
+        """-> (nrec, nfir, fir_pos, snd_seq) per receiver after the last step"""
+        nrec, nfir, pos = (np.zeros(self.nrx, np.int32) for _ in range(3))
+        seq = np.zeros(self.nrx, np.uint32)
+        check(self.lib.kg_rxbank_audio_map(self.h, ptr(nrec), ptr(nfir), ptr(pos), ptr(seq)), "kg_rxbank_audio_map")
+        return nrec, nfir, pos, seq
+
+    def ready(self):
+        """False: the next step() would wait for its table slot (the host is KG_RXBANK_SLOTS steps ahead of the GPU)."""
+        return check(self.lib.kg_rxbank_ready(self.h), "kg_rxbank_ready") == 1
+
     # ---- the step
     def step(self, d_adc, adc_ready_event=None):
         """One step over n ADC samples at d_adc (device pointer, int).  Enqueue only.  -> StepInfoC"""

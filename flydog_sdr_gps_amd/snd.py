@@ -11,7 +11,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import Context, check, ptr
+from ._lib import Context, check, ptr, own_rows
 
 # rescale = MPOW(2, -RXOUT_SCALE + CUTESDR_SCALE) * MPOW(10, CICF_GAIN_dB/20)  (float arithmetic)
 RESCALE = float(np.float32(2.0 ** -8) * np.float32(np.power(np.float32(10.0), np.float32(4.5 / 20.0))))
@@ -110,6 +110,7 @@ class FastFir:
 
     def process(self, ch, x):
         """ProcessData: -> the 0 or 512*k output samples."""
+        own_rows(self, "process()")
         x = np.ascontiguousarray(x, np.complex64)
         out = np.empty(x.size + 512, np.complex64)
         n = check(self.lib.kg_fir_process(self.h, int(ch), ptr(x), x.size, ptr(out)), "kg_fir_process")
@@ -126,6 +127,7 @@ class FastFir:
     def process_taps(self, ch, x):
         """ProcessData with its extension taps (fastfir.cpp:278-302), host arrays:
         -> (out, pre [nblk, 1024], post [nblk, 1024])"""
+        own_rows(self, "process_taps()")
         x = np.ascontiguousarray(x, np.complex64)
         maxblk = x.size // 512 + 2
         ctx = self.ctx
@@ -155,6 +157,7 @@ class FastFir:
         """ProcessData when a PRE_FILTERED extension rewrites the spectrum it is handed (`buf_modified`,
         fastfir.cpp:286-290): process with taps, apply edit(pre) -> edited blocks (host callable standing in
         for the extension's device code), filter the edited blocks again.  -> (out, pre, edited)"""
+        own_rows(self, "process_taps_edit()")
         x = np.ascontiguousarray(x, np.complex64)
         maxblk = x.size // 512 + 2
         ctx = self.ctx

@@ -13,7 +13,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import Context, check, ptr
+from ._lib import Context, check, ptr, own_rows
 
 WF_PKT_HDR, WF_ADPCM_PAD, WF_PKT_MAX = 16, 10, 16 + 10 + 1024
 WF_FLAGS_COMPRESSION = 0x00010000                      # rx_waterfall.h:77
@@ -64,6 +64,7 @@ class Adpcm:
 
     def encode(self, chans, x):
         """x: int16 [len(chans), n] (host) -> uint8 [len(chans), n/2]"""
+        own_rows(self, "encode()")
         chans = np.ascontiguousarray(chans, np.int32)
         x = np.ascontiguousarray(x, np.int16).reshape(chans.size, -1)
         n = x.shape[1]

@@ -398,6 +398,10 @@ int kg_fir_process(kg_fir *fir, int ch, const float *in, int n, float *out);
  * (strides in complex samples).  Enqueue only. */
 int kg_fir_process_dev(kg_fir *fir, const int32_t *chans, int nch, const void *d_in,
                        size_t in_stride, int n, void *d_out, size_t out_stride, int32_t *nout);
+/* The same with an InLength of its own for every listed channel (n_each[i] >= 0 samples at row i of d_in): connections whose
+ * audio DDCs were started at different times deliver different record counts in one data-pump interval. */
+int kg_fir_process_each_dev(kg_fir *fir, const int32_t *chans, int nch, const void *d_in, size_t in_stride,
+                            const int32_t *n_each, void *d_out, size_t out_stride, int32_t *nout);
 
 /* ---------------------------------------------------------------------------
  * What consumes the CFastFIR output in c2s_sound(), per receiver channel
@@ -667,6 +671,18 @@ kg_adpcm *kg_rxbank_adpcm(kg_rxbank *bank);
  *                     ("fill pipe", :978).  Set kg_wf_chan_cfg.overlapped accordingly (it switches the CIC compensation off).
  * Resets the receiver's sampler.  Synchronises the bank. */
 int kg_rxbank_set_wf(kg_rxbank *bank, int rx, uint64_t phase_inc, int decim, int overlapped);
+/* Connections come and go one at a time (every c2s_sound() / c2s_waterfall() of the reference is its own loop with its own
+ * CFastFIR position and sequence numbers, rx/rx_sound.cpp:264-269, 503-613).  A fresh bank has every receiver active.
+ * kg_rxbank_leave: the receiver is skipped by every stage from the next step on.  kg_rxbank_join: its audio DDC, CFastFIR,
+ * S-meter / detector, ADPCM state and sound sequence number start from zero and its waterfall sampler waits for
+ * kg_rxbank_set_wf; the OTHER receivers are not touched -- from here on this receiver's records per step and the steps on
+ * which its 512-sample sound blocks complete are its own (kg_rxbank_audio_map).  Between steps; join drains the bank. */
+int kg_rxbank_join(kg_rxbank *bank, int rx);
+int kg_rxbank_leave(kg_rxbank *bank, int rx);
+int kg_rxbank_is_active(kg_rxbank *bank, int rx);
+/* Per receiver after the last step (arrays of nrx entries, any may be NULL): records and CFastFIR outputs (0 or k * 512) the
+ * step gave it, FirPos() now, sound blocks emitted since it joined (the seq of its next wf_pkt_t, rx_waterfall.cpp:1635). */
+int kg_rxbank_audio_map(kg_rxbank *bank, int32_t *nrec, int32_t *nfir, int32_t *fir_pos, uint32_t *snd_seq);
 /* wf_pkt_t header fields of receiver rx (x_bin_server, zoom, compression); seq is the bank's sound sequence number. */
 int kg_rxbank_set_wf_pkt(kg_rxbank *bank, int rx, uint32_t x_bin_server, uint32_t zoom, int use_compression);
 /* snd_service() unpack parameters (default: rescale of rx/data_pump.cpp:73-74, no DC offset, no inversion) */
@@ -675,8 +691,10 @@ int kg_rxbank_set_unpack(kg_rxbank *bank, float rescale, float dc_i, float dc_q,
 typedef struct {
     uint64_t step;         /* steps taken before this one */
     int32_t nframes;       /* waterfall frames (= rows = packets) of this step: kg_rxbank_frame_map says whose */
-    int32_t nrec;          /* rx_iq_t records per receiver */
-    int32_t nfir;          /* CFastFIR outputs per receiver: 0 or k * 512 (k sound blocks: s16 / adpcm rows hold k * 512 / k * 256) */
+    /* the next four: of the lowest-numbered ACTIVE receiver (all receivers of a bank that was never joined into agree);
+     * per receiver: kg_rxbank_audio_map */
+    int32_t nrec;          /* rx_iq_t records */
+    int32_t nfir;          /* CFastFIR outputs: 0 or k * 512 (k sound blocks: s16 / adpcm rows hold k * 512 / k * 256) */
     int32_t fir_pos;       /* FirPos() after the step */
     uint32_t snd_seq;      /* sound blocks emitted before this step = the seq of this step's wf_pkt_t (rx_waterfall.cpp:1635) */
     int32_t table_bytes;   /* what the step's one upload carried */
@@ -699,6 +717,9 @@ int kg_rxbank_step(kg_rxbank *bank, const void *d_adc, void *adc_ready_event, kg
 #define KG_RXBANK_SLOTS 8
 int kg_rxbank_adc_done(kg_rxbank *bank, void *stream, int steps_back);
 int kg_rxbank_poll(kg_rxbank *bank);          /* 1 = all streams idle, 0 = busy, <0 error */
+/* 1: the next kg_rxbank_step will not wait for its table slot; 0: it would sleep until the step KG_RXBANK_SLOTS back has run --
+ * a cooperative host (the reference's coroutine server, NextTask) yields and asks again. */
+int kg_rxbank_ready(kg_rxbank *bank);
 int kg_rxbank_sync(kg_rxbank *bank);
 /* Frame f of the last step belongs to receiver rx_of_frame[f], was read at wf_iq + frame_off[f] pairs, and its packet has
  * pkt_bytes[f] bytes on the wire (arrays of nrx entries, any may be NULL).  Returns nframes. */

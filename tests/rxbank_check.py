@@ -60,9 +60,13 @@ class AudioTail:
 def check_bank(bank, adc_of_step, d_adc_of_step, rxs, steps=3, threads=8, events=None):
     """Steps a FRESHLY CONFIGURED RxBank `steps` times (step k over adc_of_step(k), a host int16 array of bank.n samples whose
     device copy is d_adc_of_step(k)) and checks every stage of the receivers `rxs`.
-    events: {step: [("wf", rx, WfParams, overlapped) | ("freq", rx, phase_inc)]} -- the connection's `SET zoom= start=` /
-    `SET freq=` commands, applied to the bank and to the oracle's state before that step: a new waterfall setting resets
-    the receiver's sampler (CmdWFReset, fill pipe), a new audio frequency leaves the filters running (rx_sound_cmd.cpp:41-51).
+    events: {step: [("wf", rx, WfParams, overlapped) | ("freq", rx, phase_inc) | ("leave", rx) |
+    ("join", rx, WfParams, overlapped, phase_inc, {set_audio keywords}) | ("audio", rx, {set_audio keywords})]} -- the
+    connection's `SET zoom= start=` / `SET freq=` / `SET mod=` commands and connections that end and start, applied to the bank
+    and to the oracle's state before that step: a new waterfall setting resets the receiver's sampler (CmdWFReset, fill pipe), a
+    new audio frequency leaves the filters running (rx_sound_cmd.cpp:41-51), a joining receiver starts from zero -- its audio
+    DDC, CFastFIR position, detector state, ADPCM state and sequence number; m_Agc[] persists (rx/rx_sound.cpp:152, 236-269) --
+    while every other receiver's state runs on: from then on its sound blocks complete on steps of its own.
     -> {"receivers", "steps", "frames", "audio_blocks", "overlapped_frames", "ring_moves"}"""
     from flydog_sdr_gps_amd import wf
     from oracle import kiwi_oracle as ko
@@ -82,7 +86,9 @@ def check_bank(bank, adc_of_step, d_adc_of_step, rxs, steps=3, threads=8, events
     ad_st = {rx: None for rx in rxs}
     coef = {rx: bank.fir.get_coef(rx) for rx in rxs}
     frames = audio_blocks = ov_frames = moves = 0
-    snd_seq = 0
+    snd_seq = {rx: 0 for rx in rxs}
+    active = {rx: bank.is_active(rx) for rx in rxs}
+    blocks_of = {rx: [] for rx in rxs}                     # the steps on which a receiver's sound blocks completed
     nco0 = {rx: 0 for rx in rxs}                           # one-shot receivers: ADC samples since the waterfall NCO was last set
     total_n = 0
     with ThreadPoolExecutor(threads) as pool:              # the oracle's C calls release the GIL
@@ -97,14 +103,37 @@ def check_bank(bank, adc_of_step, d_adc_of_step, rxs, steps=3, threads=8, events
                     _, rx, inc = ev
                     bank.rxddc.set_freq(rx, inc)
                     bank.rx_inc[rx] = int(inc)
+                elif ev[0] == "leave":
+                    bank.leave(ev[1])
+                    if ev[1] in active:
+                        active[ev[1]] = False
+                elif ev[0] == "join":
+                    _, rx, p, ov, inc, kw = ev
+                    bank.join(rx, (p, ov), inc, **kw)
+                    if rx in active:
+                        active[rx] = True
+                        wf_st[rx], hist[rx], nco0[rx] = None, np.zeros((0, 2), np.int16), total_n
+                        rx_st[rx], fir_st[rx], ad_st[rx], snd_seq[rx] = None, ko.fir_new_state(), None, 0
+                        tails[rx] = AudioTail(ko, bank.audio[rx])
+                        coef[rx] = bank.fir.get_coef(rx)
+                elif ev[0] == "audio":
+                    _, rx, kw = ev
+                    bank.set_audio(rx, bank.rx_inc[rx], **kw)          # `SET mod= low_cut= high_cut=`: new filters, the AGC runs on
+                    if rx in active:
+                        tails[rx] = AudioTail(ko, bank.audio[rx])
+                        coef[rx] = bank.fir.get_coef(rx)
             adc = adc_of_step(step)
             info = bank.step(d_adc_of_step(step))
             bank.sync()
-            assert info.step == step and info.snd_seq == snd_seq, (step, info.step, info.snd_seq, snd_seq)
+            assert info.step == step, (step, info.step)
             moves += info.nmoves
             rx_of, f_off, pkt_bytes = bank.frame_map()
             frame_of = {int(r): f for f, r in enumerate(rx_of)}
-            nrec, nfir = info.nrec, info.nfir
+            m_nrec, m_nfir, m_pos, m_seq = bank.audio_map()
+            live = [rx for rx in rxs if active[rx]]
+            for rx in rxs:
+                if not active[rx]:
+                    assert m_nrec[rx] == 0 and m_nfir[rx] == 0 and rx not in frame_of, (step, rx, "an inactive receiver was stepped")
 
             def wf_ref(rx):
                 p = bank.params[rx]
@@ -115,15 +144,17 @@ def check_bank(bank, adc_of_step, d_adc_of_step, rxs, steps=3, threads=8, events
                 st.phase = ((total_n - nco0[rx]) * p.i_offset) & ((1 << 48) - 1)
                 return ko.ddc_wf(adc[:8192 * p.decim], p.i_offset, l2, st)
 
-            wf_out = list(pool.map(wf_ref, rxs))
-            rx_out = list(pool.map(lambda rx: ko.ddc_rx(adc, bank.rx_inc[rx], rx_st[rx], bank.rx_mode), rxs))
-            with_frame = [rx for rx in rxs if rx in frame_of]
+            wf_out = list(pool.map(wf_ref, live))
+            rx_out = list(pool.map(lambda rx: ko.ddc_rx(adc, bank.rx_inc[rx], rx_st[rx], bank.rx_mode), live))
+            with_frame = [rx for rx in live if rx in frame_of]
             g_rows = dict(zip(with_frame, bank.fetch("rows", [frame_of[rx] for rx in with_frame])))
             g_pkts = dict(zip(with_frame, bank.fetch("pkts", [frame_of[rx] for rx in with_frame])))
-            g = {k: bank.fetch(k, rxs) for k in ("wf_iq", "raw", "xin", "firo", "s16", "pay")}
+            g = {k: bank.fetch(k, live) for k in ("wf_iq", "raw", "xin", "firo", "s16", "pay")} if live else {}
             stride = bank.bufs.wf_iq_stride
-            for i, rx in enumerate(rxs):
+            for i, rx in enumerate(live):
                 p = bank.params[rx]
+                nrec, nfir = int(m_nrec[rx]), int(m_nfir[rx])
+                assert int(m_seq[rx]) == snd_seq[rx] + nfir // 512, (step, rx, m_seq[rx], snd_seq[rx], nfir)
                 iq, st_new = wf_out[i]
                 if bank.overlapped[rx]:
                     wf_st[rx] = st_new
@@ -142,7 +173,7 @@ def check_bank(bank, adc_of_step, d_adc_of_step, rxs, steps=3, threads=8, events
                     w_out, _, w_pwr_out, w_dB = oracle_frame(ko, tables, want_frame, p, wf.WF_MAX, wf.WINF_HANNING, True,
                                                              bank.overlapped[rx], False)
                     check_row(g_rows[rx], w_out, w_dB, db_bound(w_pwr_out))
-                    want_pkt = ko.wf_packet(g_rows[rx], int(p.start), p.zoom, snd_seq, True)
+                    want_pkt = ko.wf_packet(g_rows[rx], int(p.start), p.zoom, snd_seq[rx], True)
                     assert int(pkt_bytes[f]) == want_pkt.size, (step, rx, pkt_bytes[f], want_pkt.size)
                     assert np.array_equal(g_pkts[rx][:want_pkt.size], want_pkt), (step, rx, "wf_pkt_t")
                     frames += 1
@@ -171,7 +202,10 @@ def check_bank(bank, adc_of_step, d_adc_of_step, rxs, steps=3, threads=8, events
                     want_enc, ad_st[rx] = ko.adpcm_encode_i16(g["s16"][i, sl], ad_st[rx])
                     assert np.array_equal(g["pay"][i, 256 * blk:256 * (blk + 1)], want_enc), (step, rx, "ADPCM")
                     audio_blocks += 1
-            snd_seq += nfir // 512
+                    blocks_of[rx].append(step)
+                assert int(m_pos[rx]) == fir_st[rx].in_pos - 512, (step, rx, "FirPos", m_pos[rx], fir_st[rx].in_pos)
+                snd_seq[rx] += nfir // 512
             total_n += n
+    check_bank.blocks_of = blocks_of                        # (for the caller that asks when each receiver's blocks completed)
     return {"receivers": len(rxs), "steps": steps, "frames": frames, "audio_blocks": audio_blocks,
             "overlapped_frames": ov_frames, "ring_moves": moves}

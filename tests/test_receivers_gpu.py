@@ -409,3 +409,58 @@ def test_bank_of_mixed_demodulators_reaches_the_sound_payload(oracle):
         bank.ctx.free(d_adc)
     finally:
         bank.close()
+
+
+def test_connections_join_and_leave_at_different_times(oracle):
+    """Receivers of ONE bank whose connections start, end, start again and change mode on different steps (the reference gives
+    every connection its own c2s_sound() / c2s_waterfall() loop, CFastFIR position and sequence numbers: rx/rx_sound.cpp:264-269,
+    503-613): fourteen steps, every stage of every active receiver against an oracle that saw the same events.  A receiver that
+    joined mid-block completes its 512-sample sound blocks on steps of its OWN; nobody else's state is touched by a join, a leave
+    or a `SET mod=` (rounds 4-5: the bank demanded one record count and one FIR position of all its receivers)."""
+    from flydog_sdr_gps_amd import post, synth
+    from flydog_sdr_gps_amd.ddc import rx_phase_inc
+    from flydog_sdr_gps_amd.rxbank import ADC_CLOCK, UI_SRATE
+    from flydog_sdr_gps_amd.wf import WfParams
+    from tests.rxbank_check import check_bank
+    n, steps, NR = 1 << 21, 14, 8
+    hz = UI_SRATE / (1024 << 14)
+    mix = []
+    for k, zoom in enumerate([8, 9, 10, 8, 9, 10, 8, 9]):          # R = 128 one-shot (8192 R = 2^20 <= n), R = 256: one-shot, R = 512: overlapped
+        span = UI_SRATE / (1 << zoom)
+        p = WfParams.for_zoom(zoom, (0.0123 * ADC_CLOCK - span * (0.2 + 0.07 * k)) / hz, adc_clock=ADC_CLOCK, ui_srate=UI_SRATE)
+        mix.append((p, 8192 * p.decim > n, rx_phase_inc(0.0123 * ADC_CLOCK - 900.0 - 35.0 * k, ADC_CLOCK)))
+    assert [ov for _, ov, _ in mix] == [False, False, True, False, False, True, False, False]
+    ssb = dict(lo=300.0, hi=2700.0, mode=post.MODE_SSB)
+    am = dict(lo=-2500.0, hi=2500.0, mode=post.MODE_AM, de_emp=1)
+    nbfm = dict(lo=-3000.0, hi=3000.0, mode=post.MODE_NBFM, squelch=80)
+
+    def join(rx, kw):
+        return ("join", rx, mix[rx][0], mix[rx][1], mix[rx][2], kw)
+    events = {
+        0: [("leave", 4), ("leave", 5), ("leave", 6), ("leave", 7)],     # four connections at first
+        2: [join(4, am)],
+        3: [join(5, nbfm), ("leave", 1)],
+        5: [join(6, ssb), ("audio", 2, am)],                            # receiver 2: SET mod=am on a running connection
+        7: [join(1, nbfm)],                                             # receiver 1 comes back
+        8: [join(7, am), ("wf", 3, mix[0][0], False)],                  # and a retune of receiver 3's waterfall among it all
+        9: [("leave", 0)],
+        11: [("audio", 5, ssb)],
+    }
+    adc = synth.adc_stream(n * 2, 0x5EED0061)
+    bank = _bank(NR, n, mix)
+    try:
+        d_adc = bank.ctx.alloc(adc.nbytes)
+        bank.ctx.upload(d_adc, adc)
+        got = check_bank(bank, lambda k: adc[(k % 2) * n:(k % 2 + 1) * n], lambda k: d_adc + 2 * (k % 2) * n, range(NR), steps, events=events)
+        blocks = check_bank.blocks_of
+        # 201.3 records a step: the four first connections complete their blocks on the same steps; the later ones on their own
+        assert blocks[2] == blocks[3] and len(blocks[2]) == 5, blocks
+        assert blocks[0] == [s for s in blocks[2] if s < 9], blocks
+        for rx, at in ((4, 2), (5, 3), (6, 5), (1, 7), (7, 8)):
+            assert blocks[rx] and blocks[rx][0] == at + 2 and all(s >= at for s in blocks[rx]), (rx, blocks[rx])
+        assert len({tuple(blocks[rx]) for rx in (2, 4, 5, 6, 1, 7)}) >= 4, blocks     # really different cadences
+        assert got["audio_blocks"] == sum(len(v) for v in blocks.values()), got
+        rc, sq, _ = bank.post.squelch_state([1, 5])
+        bank.ctx.free(d_adc)
+    finally:
+        bank.close()
