@@ -380,7 +380,18 @@ int kg_rxbank_create(int device, int nrx, size_t adc_samples_per_step, int rx_mo
     BANK_HIP(hipMemset(b->d_pkts, 0, (size_t) BANK_PKT_STRIDE * nrx));
     BANK_HIP(hipMemset(b->d_s16, 0, sizeof(short) * b->firo_stride * nrx));
     BANK_HIP(hipMemset(b->d_pay, 0, b->firo_stride / 2 * nrx));
-    b->slot_bytes = (8192 + (size_t) 512 * nrx + 63) & ~(size_t) 63;
+    {   // what a step's tables can take: <= 12 of them + a channel list for S-meter / AGC / detector and one for the coder per sound
+        // block (a receiver can complete nrec_max / 512 + 1 blocks in a step) -- checked HERE, not found out by every later step
+        const size_t blocks_max = b->nrec_max / KG_FIR_OUT + 1;
+        if (12 + 2 * blocks_max > KG_ARENA_MAX_ENTRIES) {
+            kg_set_error("kg_rxbank_create: %zu ADC samples per step are up to %zu sound blocks per receiver and step; the step table holds %d "
+                         "(a step of at most %zu samples)", b->n, blocks_max, (KG_ARENA_MAX_ENTRIES - 12) / 2,
+                         (size_t) ((KG_ARENA_MAX_ENTRIES - 12) / 2 - 1) * KG_FIR_OUT * (size_t) b->decim_rx);
+            kg_rxbank_destroy(b);
+            return KG_ERR_INVALID;
+        }
+        b->slot_bytes = (8192 + (size_t) (384 + 8 * blocks_max) * nrx + 63) & ~(size_t) 63;
+    }
     BANK_HIP(hipHostMalloc((void **) &b->h_slots, b->slot_bytes * BANK_SLOTS, hipHostMallocDefault));
     BANK_HIP(hipMalloc((void **) &b->d_slots, b->slot_bytes * BANK_SLOTS));
     for (int i = 0; i < BANK_SLOTS; i++) {
@@ -427,8 +438,9 @@ int kg_rxbank_set_wf(kg_rxbank *b, int rx, uint64_t phase_inc, int decim, int ov
     KG_REQUIRE(decim >= 1 && (decim & (decim - 1)) == 0 && decim <= 8192, KG_ERR_INVALID, "kg_rxbank_set_wf: decimation %d", decim);
     if (overlapped) {
         const size_t m = b->n / (size_t) decim;
-        KG_REQUIRE(b->n % (size_t) decim == 0 && m >= 1 && m <= KG_WF_NFFT && KG_WF_NFFT % m == 0, KG_ERR_INVALID,
-                   "kg_rxbank_set_wf: overlapped sampling needs a step (%zu samples) that yields a divisor of 8192 outputs at R = %d "
+        // (m even: a frame is read at ring offset w + m - 8192, and kg_wf_frames_at_dev takes 8-byte aligned frames)
+        KG_REQUIRE(b->n % (size_t) decim == 0 && m >= 2 && m <= KG_WF_NFFT && KG_WF_NFFT % m == 0, KG_ERR_INVALID,
+                   "kg_rxbank_set_wf: overlapped sampling needs a step (%zu samples) that yields an even divisor of 8192 outputs at R = %d "
                    "(a faster sampler fills a frame per step: use the one-shot mode)", b->n, decim);
     } else {
         KG_REQUIRE((size_t) KG_WF_NFFT * (size_t) decim <= b->n, KG_ERR_INVALID,

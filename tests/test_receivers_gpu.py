@@ -114,6 +114,33 @@ def test_bank_error_paths():
         with pytest.raises(KiwiGpuError):
             bank.step(d)                                     # receiver 1 has no waterfall set
         bank.ctx.free(d)
+        # a bank-owned object's host-buffer conveniences refuse (its rows go by receiver number), in C as in Python
+        with pytest.raises(KiwiGpuError, match="receiver bank"):
+            bank.fir.process(0, np.zeros(16, np.complex64))
+        # an inactive receiver needs no waterfall setting; a joined one needs a new one
+        bank.leave(1)
+        assert not bank.is_active(1) and bank.is_active(0) and bank.ready()
+        d = bank.ctx.alloc(2 << 17)
+        from flydog_sdr_gps_amd.ddc import rx_phase_inc
+        bank.set_audio(0, rx_phase_inc(1.0e6, ADC_CLOCK))
+        bank.step(d)
+        bank.join(0)
+        with pytest.raises(KiwiGpuError, match="since it joined"):
+            bank.step(d)
+        bank.sync()
+        bank.ctx.free(d)
+    finally:
+        bank.close()
+    # settings that could only fail later, on every step, fail when they are made (the advisor's round-5 finding): a step whose
+    # sound blocks do not fit the step table; an overlapped sampler that yields an odd number of outputs per step
+    from flydog_sdr_gps_amd.ddc import RX_WIDE
+    with pytest.raises(KiwiGpuError, match="sound blocks"):
+        RxBank(1, 1 << 27, rx_mode=RX_WIDE)
+    bank = RxBank(1, 8192)
+    try:
+        p14 = WfParams.for_zoom(14, 1.0e6 / hz, adc_clock=ADC_CLOCK, ui_srate=UI_SRATE)     # R = 8192: one output per step
+        with pytest.raises(KiwiGpuError, match="even divisor"):
+            bank.set_wf(0, p14, overlapped=True)
     finally:
         bank.close()
 
