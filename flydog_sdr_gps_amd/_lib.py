@@ -7,7 +7,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class KiwiGpuError(RuntimeError):
@@ -261,8 +261,8 @@ def borrow(cls, ctx, handle, **attrs):
 def own_rows(obj, what):
     """Guard of the host-buffer conveniences: see borrow()."""
     if getattr(obj, "_borrowed", False):
-        raise KiwiGpuError("%s on an object a receiver bank owns: its rows are addressed by receiver number -- step the bank and read "
-                           "its buffers (RxBank.fetch)" % what)
+        raise KiwiGpuError(-5, what, "the object belongs to a receiver bank, whose rows are addressed by receiver number: step the bank "
+                           "and read its buffers (RxBank.fetch)")
 
 
 def ptr(a):

@@ -34,7 +34,8 @@
 extern "C" {
 #endif
 
-#define KG_ABI_VERSION 3     /* 3 (round 5): kg_rxbank_*, kg_ddc_wf_step_dev; 2 (round 4): kg_wf_frames_at_dev takes the extent of d_iq; kg_ctx_mark */
+#define KG_ABI_VERSION 4     /* 4 (round 6): kg_post_cfir_* / _squelch_* / _set_deemp (AM, NBFM reach d_s16), kg_rxbank_join / _leave /
+                              * _audio_map / _ready, kg_fir_process_each_dev; 3 (round 5): kg_rxbank_*, kg_ddc_wf_step_dev; 2 (round 4): kg_wf_frames_at_dev takes the extent of d_iq; kg_ctx_mark */
 
 typedef enum {
     KG_OK = 0,

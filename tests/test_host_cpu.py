@@ -148,7 +148,7 @@ def test_library_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(kg_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     lib = _lib.load_library()                      # raises if the .so is missing a symbol
-    assert lib.kg_abi_version() == _lib.ABI_VERSION == 3          # bumped with every change of an existing signature or layout
+    assert lib.kg_abi_version() == _lib.ABI_VERSION == 4          # bumped with every change of an existing signature or layout
     assert lib.kg_strerror(-1).decode().startswith("no usable")
 
 
