@@ -120,6 +120,20 @@ static inline int kg_ctx_use(kg_ctx *ctx)
     return KG_OK;
 }
 
+// The DDCs' NCO reads: ph holds the 48-bit accumulator in its top bits, the table index is its top 13 (KG_NCO_* below).
+// KG_EXP_NCO selects a timing experiment (WRONG values; bench.py marks such builds): 1 = no table reads at all (what a
+// conflict-free NCO could gain at most), 2 = the hardware's v_sin_f32 / v_cos_f32 + scale + round (what replacing the table costs).
+#if !defined(KG_EXP_NCO)
+#define KG_NCO_COS(tab_, ph_) ((int) (tab_)[((ph_) >> 51) + 2048])
+#define KG_NCO_SIN(tab_, ph_) ((int) (tab_)[(ph_) >> 51])
+#elif KG_EXP_NCO == 1
+#define KG_NCO_COS(tab_, ph_) ((int) ((ph_) >> 50) - 8192)
+#define KG_NCO_SIN(tab_, ph_) ((int) (((ph_) >> 49) & 0x3fff) - 8192)
+#else
+#define KG_NCO_COS(tab_, ph_) ((int) __builtin_rintf(16383.0f * __builtin_amdgcn_cosf((float) (unsigned) ((ph_) >> 51) * (1.0f / 8192.0f))))
+#define KG_NCO_SIN(tab_, ph_) ((int) __builtin_rintf(16383.0f * __builtin_amdgcn_sinf((float) (unsigned) ((ph_) >> 51) * (1.0f / 8192.0f))))
+#endif
+
 // The DDCs' NCO table (frozen by us: the Xilinx DDS core of verilog/rx/iq_mixer.v is closed IP), as ONE 16-bit sine
 // table of KG_NCO_TAB = 10240 entries: T[j] = round(16383 sin(2 pi j / 8192)) for j < 8192 and, BY CONSTRUCTION,
 // T[j] = T[j - 8192] beyond.  sin(a) = T[a], cos(a) = T[a + 2048] for a < 8192: two sign-extending 16-bit LDS reads

@@ -408,7 +408,7 @@ DDC_DEV void ddc_wf_run_body(
         //  -- 2^24 x C(len + k - 1, k) -- is taken off once per run (everything is modulo 2^64 either way);
         //  pass B lets integrator 5 run on in 32 bits and masks it to 28 where it is stored (2^28 divides 2^32).
         auto step = [&](int a) {
-            const int ec = tab[(ph >> 51) + 2048], es = tab[ph >> 51];
+            const int ec = KG_NCO_COS(tab, ph), es = KG_NCO_SIN(tab, ph);
             ph += inc16;
             if (!PASS_B) {
                 const u32 ui = ((u32) (a * ec) + 0x40000020u) >> 6, uq = ((u32) (a * es) + 0x40000020u) >> 6;
@@ -479,7 +479,7 @@ DDC_DEV void ddc_wf_run_body(
                         samples8(t, buf);
                         int ec[8], es[8];
 #pragma unroll
-                        for (int w = 0; w < 8; w++) { ec[w] = tab[(ph >> 51) + 2048]; es[w] = tab[ph >> 51]; ph += inc16; }
+                        for (int w = 0; w < 8; w++) { ec[w] = KG_NCO_COS(tab, ph); es[w] = KG_NCO_SIN(tab, ph); ph += inc16; }
 #pragma unroll
                         for (int w = 0; w < 8; w++) {
                             const long long mi = mix24(buf[w], ec[w]), mq = mix24(buf[w], es[w]);
@@ -504,7 +504,7 @@ DDC_DEV void ddc_wf_run_body(
         }
         if (MODE == DDC_ALL && PASS_B && log2r <= 2 && c == 0 && (o & 3) == 0 && ((uintptr_t) c0i & 15) == 0 && ((uintptr_t) c0q & 15) == 0) {
             auto quiet = [&](int a) {                     // step() without the strobe store
-                const int ec = tab[(ph >> 51) + 2048], es = tab[ph >> 51];
+                const int ec = KG_NCO_COS(tab, ph), es = KG_NCO_SIN(tab, ph);
                 const long long mi = mix24(a, ec), mq = mix24(a, es);
                 ph += inc16;
                 I[0] += (u64) mi; I[1] += I[0]; I[2] += I[1]; I[3] += I[2];
@@ -546,7 +546,7 @@ DDC_DEV void ddc_wf_run_body(
                 // reads go out together (with the strobe test between them each was waited for where it was issued)
                 int ec[8], es[8];
 #pragma unroll
-                for (int w = 0; w < 8; w++) { ec[w] = tab[(ph >> 51) + 2048]; es[w] = tab[ph >> 51]; ph += inc16; }
+                for (int w = 0; w < 8; w++) { ec[w] = KG_NCO_COS(tab, ph); es[w] = KG_NCO_SIN(tab, ph); ph += inc16; }
 #pragma unroll
                 for (int w = 0; w < 8; w++) {
                     const long long mi = mix24(buf[w], ec[w]), mq = mix24(buf[w], es[w]);
@@ -614,7 +614,7 @@ DDC_DEV void ddc_wf_run_body(
             }
         }
         auto step = [&](int a) {
-            const int ec = tab[(ph >> 51) + 2048], es = tab[ph >> 51];
+            const int ec = KG_NCO_COS(tab, ph), es = KG_NCO_SIN(tab, ph);
             const long long mi = mix24(a, ec), mq = mix24(a, es);
             ph += inc16;
             // in = sign-extended m << shift (shift = 65 - 5 log2 R is 0 .. 20 here), 96 bits
@@ -637,7 +637,7 @@ DDC_DEV void ddc_wf_run_body(
             if (c + 8 <= (u32) Rm1) {                         // no strobe inside this group: see the narrow path
                 int ec[8], es[8];
 #pragma unroll
-                for (int w = 0; w < 8; w++) { ec[w] = tab[(ph >> 51) + 2048]; es[w] = tab[ph >> 51]; ph += inc16; }
+                for (int w = 0; w < 8; w++) { ec[w] = KG_NCO_COS(tab, ph); es[w] = KG_NCO_SIN(tab, ph); ph += inc16; }
 #pragma unroll
                 for (int w = 0; w < 8; w++) {
                     const long long mi = mix24(buf[w], ec[w]), mq = mix24(buf[w], es[w]);
@@ -673,7 +673,7 @@ DDC_DEV void ddc_wf_run_body(
         for (int k = 0; k < 4; k++) { SI.i[k] = mk128(0, 0); SQ.i[k] = mk128(0, 0); }
     }
     auto step = [&](int a) {
-        const int ec = tab[(ph >> 51) + 2048], es = tab[ph >> 51];
+        const int ec = KG_NCO_COS(tab, ph), es = KG_NCO_SIN(tab, ph);
         const long long mi = mix24(a, ec), mq = mix24(a, es);
         ph += inc16;
         // in = sign-extended m << shift, 128 bits
@@ -824,7 +824,7 @@ DDC_DEV void ddc_bypass_block(const int2 (&cur)[BYP_G], long blk, const short *t
             int *w = (int *) &w0;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const int ec = tab[(ph >> 51) + 2048], es = tab[ph >> 51];
+                const int ec = KG_NCO_COS(tab, ph), es = KG_NCO_SIN(tab, ph);
                 const int mi = mix24(a[q], ec), mq = mix24(a[q], es);
                 w[q] = (int) (((u32) (mi >> 8) & 0xffffu) | ((u32) (mq >> 8) << 16));      // short2 {i, q}
                 ph += inc16[b];
@@ -892,7 +892,7 @@ DDC_DEV long ddc_bypass_whole_t(const short *__restrict__ adc, long blk, long nf
                 int *o = (int *) (orow[b] + t0);
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const int ec = tab[(ph >> 51) + 2048], es = tab[ph >> 51];
+                    const int ec = KG_NCO_COS(tab, ph), es = KG_NCO_SIN(tab, ph);
                     const int mi = mix24(cur[g][q], ec), mq = mix24(cur[g][q], es);
                     o[64 * q] = (int) (((u32) (mi >> 8) & 0xffffu) | ((u32) (mq >> 8) << 16));      // short2 {i, q}
                     ph += step;
@@ -988,7 +988,7 @@ __global__ __launch_bounds__(256, 4) void ddc_wf_bypass_kernel(
                     short2 r[4];
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        const int ec = tab[(ph >> 51) + 2048], es = tab[ph >> 51];
+                        const int ec = KG_NCO_COS(tab, ph), es = KG_NCO_SIN(tab, ph);
                         const int mi = mix24(a[q], ec), mq = mix24(a[q], es);
                         r[q] = make_short2((short) (mi >> 8), (short) (mq >> 8));
                         ph += inc16[b];

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(RX_THREADS) void rx1_run_kernel(
     // the two integrators, taken off once per run (modulo 2^64).  Pass B lets integrator 3 run on in 32 bits and masks it to
     // 26 where it is stored (2^26 divides 2^32).
     auto step = [&](int a) {
-        const int ec = tab[(ph >> 51) + 2048], es = tab[ph >> 51];
+        const int ec = KG_NCO_COS(tab, ph), es = KG_NCO_SIN(tab, ph);
         ph += inc16;
         if (!PASS_B) {
             const u32 ui = ((u32) (a * ec) + 0x40000080u) >> 8, uq = ((u32) (a * es) + 0x40000080u) >> 8;
