@@ -891,8 +891,11 @@ def cpu_acq_pocketfft(iq, codes, nsamples, fft_len, dop_lo, dop_hi, budget_s):
         t_block += count / rate
         notes.append("%s: %.4f s per SV x %d bins on all cores" % ("E1B" if which else "C/A", 1.0 / rate, ndop))
     got = one_sv(0, ko.L1_LIMIT)
-    want, _ = ko.correlate(ko.code_fft(codes[i_ca][0], prec=0, fft_len=fft_len),
-                           ko.sample_iq16(iq, prec=0, nsamples=nsamples, fft_len=fft_len), dop_lo=dop_lo, dop_hi=dop_hi, prec=0)
+    # (this leg indexes the code spectrum modulo N; the reference reads the NEXT row behind a satellite's own for a negative bin --
+    # the oracle is told to put the same spectrum there, which IS modulo N: the flag compares like with like)
+    c_ca = ko.code_fft(codes[i_ca][0], prec=0, fft_len=fft_len)
+    want, _ = ko.correlate(c_ca, ko.sample_iq16(iq, prec=0, nsamples=nsamples, fft_len=fft_len), dop_lo=dop_lo, dop_hi=dop_hi, prec=0,
+                           code_next=c_ca)
     return {"value": round(nsamples / t_block / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "independent tuned FFT",
             "sample": "scipy.fft (pocketfft) complex64 + numpy, one SV per process, %d processes, 8 Doppler bins per batched call; "
                       "%s; block time = sum of count x per-SV time; Sample()'s mix + decimation left out (0.2 %% of the work)"

@@ -53,6 +53,9 @@ class Searcher:
                                                self.nsamples, self.fft_len, C.byref(h)), "kg_acq_create_shape")
         self.h = h
         self._last = (0, 0)
+        # what the host has written into each row of the code table (the reference's code[sat][]): Correlate() reads the row BEHIND
+        # a satellite's own for a negative Doppler bin (kg_acq.hip, acq_code_overrun_kernel), so what row sat + 1 holds matters
+        self.rows = {}
 
     def close(self):
         if getattr(self, "h", None):
@@ -73,6 +76,7 @@ class Searcher:
             limit = _sats.E1B_LIMIT if boc else _sats.L1_LIMIT
         check(self.lib.kg_acq_set_code(self.h, int(sat), ptr(chips), chips.size, int(bool(boc)),
                                        int(limit)), "kg_acq_set_code")
+        self.rows[int(sat)] = ("chips", chips.copy(), bool(boc))
 
     def set_code_fft(self, sat, code_fft, limit=_sats.L1_LIMIT):
         code_fft = np.ascontiguousarray(code_fft, np.complex64)
@@ -80,6 +84,7 @@ class Searcher:
             raise ValueError("code_fft must hold %d bins" % self.fft_len)
         check(self.lib.kg_acq_set_code_fft(self.h, int(sat), ptr(code_fft), int(limit)),
               "kg_acq_set_code_fft")
+        self.rows[int(sat)] = ("fft", code_fft.copy(), False)
 
     def get_code_fft(self, sat):
         out = np.empty(self.fft_len, np.complex64)

@@ -1266,7 +1266,7 @@ struct kg_acq {
 };
 
 // Host mirror of the plane layouts (see the head of this file): A = 256 threads x 16 legs, B = 512 x 8.
-static inline size_t plane_pos(int k1, int halo_col, int H, int layout)
+static inline __host__ __device__ size_t plane_pos(int k1, int halo_col, int H, int layout)
 {
     if (layout == 0) {
         const int t = k1 & 255, j = k1 >> 8, row = 2 * (256 + 2 * H);
@@ -1277,7 +1277,24 @@ static inline size_t plane_pos(int k1, int halo_col, int H, int layout)
 }
 // float2 per spectrum: layout A's size (the larger: 32 H against 16 H halo elements per plane) is the stride of both
 static inline size_t spec_len(int P, int H) { return (size_t) P * 8 * 2 * (256 + 2 * H); }
-static inline size_t plane_len(int H, int layout) { return layout == 0 ? (size_t) 8 * 2 * (256 + 2 * H) : (size_t) 4 * 2 * (512 + 2 * H); }
+static inline __host__ __device__ size_t plane_len(int H, int layout) { return layout == 0 ? (size_t) 8 * 2 * (256 + 2 * H) : (size_t) 4 * 2 * (512 + 2 * H); }
+
+// What the reference reads PAST THE END of a code row.  Correlate() forms conj(data[i]) code[sat][N - dop + i] over a row that
+// holds the spectrum twice (2 N entries, gps/search.cpp:54, :471): for a negative Doppler bin the last |dop| products index
+// 2 N .. 2 N + |dop| - 1 -- the first |dop| bins of the NEXT satellite's row, code[sat + 1][0 .. |dop|) (rows are contiguous in
+// the static array; a row nobody wrote is zero) -- not bins 0 .. |dop| - 1 of the satellite's own spectrum, which is what the
+// index "(i - dop) mod N" would give.  Found in round 6 by running the reference's own search.cpp:
+// 0.3 % of snr at dop = -13, and another noise peak wins for an absent SV.  The wrapped bins N, N + 1, ... of a row are the
+// right halo of its last leg in the plane layout, and only a negative bin reads them: that halo is filled from row sat + 1.
+__global__ void acq_code_overrun_kernel(float2 *__restrict__ dst, int layout_dst, const float2 *__restrict__ src, int layout_src, int P, int H)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;           // bin t of the next row = "bin N + t" of this one
+    if (t >= P * H) return;
+    const int k2 = t % P, k1 = t / P;
+    const float2 v = src ? src[(size_t) k2 * plane_len(H, layout_src) + plane_pos(k1, 0, H, layout_src)] : make_float2(0.f, 0.f);
+    const int T = layout_dst == 0 ? 256 : 512, J = SUB / T;
+    dst[(size_t) k2 * plane_len(H, layout_dst) + plane_pos(k1 + T * (J - 1), T, H, layout_dst)] = v;
+}
 
 static void to_planes(const float *nat, std::vector<float2> &pl, int P, int H, int layout)
 {
@@ -1575,6 +1592,21 @@ static int set_limit(kg_acq *a, int sat, int limit)
     return KG_OK;
 }
 
+// Row `sat` was just written (or row sat + 1 was): its beyond-the-end bins are row sat + 1's first ones (zero when that row was
+// never set, as in the reference's static array).  On the context's stream.
+static int acq_patch_overrun(kg_acq *a, int sat)
+{
+    if (sat < 0 || sat >= a->max_sats || !a->code_set[sat]) return KG_OK;
+    const bool have_next = sat + 1 < a->max_sats && a->code_set[sat + 1];
+    const int n = a->P * a->halo;
+    hipLaunchKernelGGL(acq_code_overrun_kernel, dim3((n + 63) / 64), dim3(64), 0, a->ctx->stream,
+                       a->d_code + (size_t) sat * a->code_len, a->code_layout[sat],
+                       have_next ? (const float2 *) (a->d_code + (size_t) (sat + 1) * a->code_len) : (const float2 *) nullptr,
+                       have_next ? a->code_layout[sat + 1] : 0, a->P, a->halo);
+    KG_HIP(hipGetLastError());
+    return KG_OK;
+}
+
 int kg_acq_set_code(kg_acq *a, int sat, const uint8_t *chips, int nchips, int boc, int limit)
 {
     KG_REQUIRE(a && chips, KG_ERR_INVALID, "kg_acq_set_code: null argument");
@@ -1591,6 +1623,7 @@ int kg_acq_set_code(kg_acq *a, int sat, const uint8_t *chips, int nchips, int bo
                                     a->d_td_code, a->d_fsub_code, a->code_layout[sat] ? nullptr : d_sv,
                                     a->code_layout[sat] ? d_sv : nullptr, a->code_len, a->halo);
     if (rc) return rc;
+    if ((rc = acq_patch_overrun(a, sat)) || (rc = acq_patch_overrun(a, sat - 1))) return rc;
     KG_HIP(hipStreamSynchronize(a->ctx->stream));       // chips buffer is reused per call
     return KG_OK;
 }
@@ -1605,6 +1638,7 @@ int kg_acq_set_code_fft(kg_acq *a, int sat, const float *code_fft, int limit)
     to_planes(code_fft, pl, a->P, a->halo, a->code_layout[sat]);
     KG_HIP(hipMemcpyAsync(a->d_code + (size_t) sat * a->code_len, pl.data(), sizeof(float2) * a->code_len,
                           hipMemcpyHostToDevice, a->ctx->stream));
+    if ((rc = acq_patch_overrun(a, sat)) || (rc = acq_patch_overrun(a, sat - 1))) return rc;
     KG_HIP(hipStreamSynchronize(a->ctx->stream));
     return KG_OK;
 }

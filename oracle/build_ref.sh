@@ -73,6 +73,34 @@ UNRES="-Wl,--unresolved-symbols=ignore-all"
 $CXX $OPT $DEF $INC -o "$OUT/fir_ref" "$HERE/ref/ref_fir_main.cpp" "$R/rx/CuteSDR/fir.cpp" -lm $UNRES
 $CXX $OPT $DEF $INC -o "$OUT/squelch_ref" "$HERE/ref/ref_squelch_main.cpp" "$R/rx/CuteSDR/squelch.cpp" \
     "$R/rx/CuteSDR/fir.cpp" -lm $UNRES
+# ---- 3. the FFT-dependent files, against the FFTW3 API the image ships.
+# The reference takes FFTW3 from the distribution (`apt-get install libfftw3-dev`, Makefile:365-366); this image has no
+# libfftw3f, but ROCm ships hipFFTW: AMD's implementation of the fftw3.h interface (fftwf_plan_dft_1d, fftwf_execute, ...) over
+# hipFFT -- /opt/rocm/include/hipfft/hipfftw.h, /opt/rocm/lib/libhipfftw.so.  The reference includes the interface as <fftw3.h>:
+# a directory holding ONE symlink of that name to the image's header is put on the include path (under _ref/, not in the
+# repository; no header text is written).  hipFFTW runs its transforms on the GPU, so these binaries are built HERE and RUN ON
+# THE GPU BOX (tools/make_ref_fft_golden.py; they need nothing of $REFERENCE at run time).
+HIPFFTW_H=${HIPFFTW_H:-/opt/rocm/include/hipfft/hipfftw.h}
+if [ -f "$HIPFFTW_H" ] && [ -f /opt/rocm/lib/libhipfftw.so ]; then
+    mkdir -p "$OUT/fftw3_api"
+    ln -sf "$HIPFFTW_H" "$OUT/fftw3_api/fftw3.h"
+    EXT=$(for d in "$R"/extensions/*/; do printf -- "-I%s " "$d"; done)
+    PKG=$(for d in "$R"/pkgs/*/; do printf -- "-I%s " "$d"; done)
+    FINC="-I$OUT/fftw3_api -I$(dirname "$HIPFFTW_H") -I/opt/rocm/include $INC $EXT $PKG"
+    FLIB="-L/opt/rocm/lib -lhipfftw -Wl,-rpath,/opt/rocm/lib -lm $UNRES"
+    # CFastFIR (rows A3, A4): fastfir.cpp + the reference's simd.cpp; the driver supplies the three globals fastfir.cpp reads
+    $CXX $OPT $DEF $FINC -o "$OUT/fastfir_ref" "$HERE/ref/ref_fastfir_main.cpp" "$R/rx/CuteSDR/fastfir.cpp" "$R/support/simd.cpp" $FLIB
+    # acquisition (rows G3-G7, G9): the driver TU includes gps/search.cpp itself (Sample(), Correlate() and the decimators are
+    # static there) and defines the server-runtime entry points that file calls -- scheduler yields, log printer, SPI packet
+    # read, task start: no arithmetic (oracle/ref/ref_search_main.cpp says which and why); gps/sats.cpp and support/simd.cpp
+    # are the reference's
+    $CXX $OPT $DEF $FINC -no-pie -DREF_SEARCH_CPP="\"$R/gps/search.cpp\"" -o "$OUT/search_ref" "$HERE/ref/ref_search_main.cpp" \
+        "$R/gps/sats.cpp" "$R/support/simd.cpp" $FLIB
+    FFT_BUILT=" fastfir_ref search_ref"
+else
+    echo "hipFFTW absent: the FFT-dependent reference files are not built"
+    FFT_BUILT=""
+fi
 $CC -O1 -w -DKIWISDR -I"$OUT/gen" "$R/verilog/rx/cic_gen.c" -lm -o "$OUT/cic_gen_ref"
 (cd "$OUT/cic" && "$OUT/cic_gen_ref" > cic_gen.log 2>&1)
-echo "built oracle/_ref: cacode_ref e1b_ref gpsconst_ref agc_ref adpcm_ref fir_ref squelch_ref cic_gen_ref (+ gen/kiwi.gen.h, cic/*.vh) from $REFERENCE"
+echo "built oracle/_ref: cacode_ref e1b_ref gpsconst_ref agc_ref adpcm_ref fir_ref squelch_ref cic_gen_ref$FFT_BUILT (+ gen/kiwi.gen.h, cic/*.vh) from $REFERENCE"

@@ -346,16 +346,26 @@ void ko_sample_iq16(const int16_t *iq, ko_cpx *out, ko_cpx *td, int prec)
     ko_sample_iq16_n(iq, out, td, prec, KO_NSAMPLES, KO_FFT_LEN);
 }
 
-/* one (SV, Doppler) cell of the search.cpp:465-496 loop body */
-static ko_acq_cell correlate_cell(const ko_cpx *code, const ko_cpx *data, int limit, int dop,
+/* one (SV, Doppler) cell of the search.cpp:465-496 loop body.
+ * The reference multiplies by code[sat] + FFT_LEN - dop (:471), a pointer into a row that holds the spectrum TWICE (:54,
+ * :281-282): entry N - dop + i.  For dop >= 0 that is bin (i - dop) mod N.  For dop < 0 the last |dop| products run past the
+ * row's 2 N entries into the NEXT satellite's row, code[sat + 1][0 .. |dop|) -- the rows of the static array are contiguous,
+ * a row nobody wrote is zero -- and NOT into bins 0 .. |dop| - 1 of the satellite's own spectrum.  `next` is that row (NULL:
+ * never written).  Pinned by the reference's own Correlate() (oracle/_ref/search_ref, tests/golden/acq_fftref.npz): until
+ * round 6 this function wrapped modulo N, 0.3 % off in snr at dop = -13 and another winner among noise peaks. */
+static ko_acq_cell correlate_cell(const ko_cpx *code, const ko_cpx *next, const ko_cpx *data, int limit, int dop,
                                   ko_cpx *prod, ko_cpx *rev, int prec, int N)
 {
     float max_pwr = 0, tot_pwr = 0;                       /* :466 */
     int max_pwr_i = 0, i;
     for (i = 0; i < N; i++) {                             /* :471 = :473-477, simd.cpp:39-67 */
-        int j = ((i - dop) % N + N) % N;
-        prod[i].re = data[i].re * code[j].re + data[i].im * code[j].im;
-        prod[i].im = data[i].re * code[j].im - data[i].im * code[j].re;
+        const long e = (long) N - dop + i;                /* entry of the doubled row; dop in [-N, N] */
+        ko_cpx c;
+        if (e < 2L * N) c = code[e % N];
+        else if (next) c = next[e - 2L * N];
+        else { c.re = 0.0f; c.im = 0.0f; }
+        prod[i].re = data[i].re * c.re + data[i].im * c.im;
+        prod[i].im = data[i].re * c.im - data[i].im * c.re;
     }
     ko_fft(N, +1, prod, rev, prec);                       /* :481 */
     for (i = 0; i < limit; i++) {                         /* :486-490 */
@@ -370,8 +380,8 @@ static ko_acq_cell correlate_cell(const ko_cpx *code, const ko_cpx *data, int li
 }
 
 /* gps/search.cpp:453-499 */
-ko_acq_result ko_correlate_n(const ko_cpx *code, const ko_cpx *data, int limit,
-                             int dop_lo, int dop_hi, ko_acq_cell *cells, int prec, int fft_len)
+ko_acq_result ko_correlate_next_n(const ko_cpx *code, const ko_cpx *next, const ko_cpx *data, int limit,
+                                  int dop_lo, int dop_hi, ko_acq_cell *cells, int prec, int fft_len)
 {
     ko_cpx *prod = (ko_cpx *) malloc(sizeof(ko_cpx) * fft_len);       /* rev_buf, :58,:454 */
     ko_cpx *rev = (ko_cpx *) malloc(sizeof(ko_cpx) * fft_len);
@@ -379,7 +389,7 @@ ko_acq_result ko_correlate_n(const ko_cpx *code, const ko_cpx *data, int limit,
     float max_snr = 0;                                    /* :455 */
     int dop;
     for (dop = dop_lo; dop <= dop_hi; dop++) {            /* :465 */
-        const ko_acq_cell c = correlate_cell(code, data, limit, dop, prod, rev, prec, fft_len);
+        const ko_acq_cell c = correlate_cell(code, next, data, limit, dop, prod, rev, prec, fft_len);
         if (cells) cells[dop - dop_lo] = c;
         if (c.snr > max_snr) {                            /* :495 */
             max_snr = c.snr; r.dop = dop; r.idx = c.idx; r.valid = 1;
@@ -388,6 +398,13 @@ ko_acq_result ko_correlate_n(const ko_cpx *code, const ko_cpx *data, int limit,
     r.snr = max_snr;                                      /* :498 */
     free(prod); free(rev);
     return r;
+}
+
+/* the next row never written (zeros) */
+ko_acq_result ko_correlate_n(const ko_cpx *code, const ko_cpx *data, int limit,
+                             int dop_lo, int dop_hi, ko_acq_cell *cells, int prec, int fft_len)
+{
+    return ko_correlate_next_n(code, NULL, data, limit, dop_lo, dop_hi, cells, prec, fft_len);
 }
 
 ko_acq_result ko_correlate(const ko_cpx *code, const ko_cpx *data, int limit,
@@ -399,6 +416,7 @@ ko_acq_result ko_correlate(const ko_cpx *code, const ko_cpx *data, int limit,
 typedef struct {
     const ko_cpx *codes, *data; const int *limits; int nsv, dop_lo, dop_hi, prec;
     ko_acq_cell *cells; int tid, nthreads, fft_len;
+    const ko_cpx *nexts; const unsigned char *has_next;   /* [nsv][fft_len], [nsv]: the row behind each SV's (see correlate_cell) */
 } many_arg;
 
 /* threads take (SV, Doppler) cells round-robin: all host cores stay busy even
@@ -412,17 +430,18 @@ static void *many_worker(void *p)
     int c;
     for (c = a->tid; c < ncell; c += a->nthreads) {
         const int s = c / nd, di = c - s * nd;
-        a->cells[c] = correlate_cell(a->codes + (size_t) s * a->fft_len, a->data, a->limits[s],
+        const ko_cpx *next = (a->nexts && a->has_next && a->has_next[s]) ? a->nexts + (size_t) s * a->fft_len : NULL;
+        a->cells[c] = correlate_cell(a->codes + (size_t) s * a->fft_len, next, a->data, a->limits[s],
                                      a->dop_lo + di, prod, rev, a->prec, a->fft_len);
     }
     free(prod); free(rev);
     return NULL;
 }
 
-void ko_correlate_many_n(const ko_cpx *codes, int nsv, const ko_cpx *data,
-                         const int *limits, int dop_lo, int dop_hi,
-                         ko_acq_result *out, ko_acq_cell *cells, int prec,
-                         int nthreads, int fft_len)
+void ko_correlate_many_next_n(const ko_cpx *codes, const ko_cpx *nexts, const unsigned char *has_next, int nsv, const ko_cpx *data,
+                              const int *limits, int dop_lo, int dop_hi,
+                              ko_acq_result *out, ko_acq_cell *cells, int prec,
+                              int nthreads, int fft_len)
 {
     const int nd = dop_hi - dop_lo + 1;
     if (nthreads < 1) nthreads = 1;
@@ -434,7 +453,7 @@ void ko_correlate_many_n(const ko_cpx *codes, int nsv, const ko_cpx *data,
     many_arg *args = (many_arg *) malloc(sizeof(many_arg) * nthreads);
     int t, s, di;
     for (t = 0; t < nthreads; t++) {
-        many_arg a = { codes, data, limits, nsv, dop_lo, dop_hi, prec, cl, t, nthreads, fft_len };
+        many_arg a = { codes, data, limits, nsv, dop_lo, dop_hi, prec, cl, t, nthreads, fft_len, nexts, has_next };
         args[t] = a;
         if (t > 0) pthread_create(&th[t], NULL, many_worker, &args[t]);
     }
@@ -452,6 +471,14 @@ void ko_correlate_many_n(const ko_cpx *codes, int nsv, const ko_cpx *data,
     }
     if (!cells) free(cl);
     free(th); free(args);
+}
+
+void ko_correlate_many_n(const ko_cpx *codes, int nsv, const ko_cpx *data,
+                         const int *limits, int dop_lo, int dop_hi,
+                         ko_acq_result *out, ko_acq_cell *cells, int prec,
+                         int nthreads, int fft_len)
+{
+    ko_correlate_many_next_n(codes, NULL, NULL, nsv, data, limits, dop_lo, dop_hi, out, cells, prec, nthreads, fft_len);
 }
 
 void ko_correlate_many(const ko_cpx *codes, int nsv, const ko_cpx *data,

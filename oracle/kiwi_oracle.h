@@ -129,6 +129,14 @@ void ko_sample_bits_n(const uint8_t *packed, ko_cpx *out, ko_cpx *td, int prec, 
 void ko_sample_iq16_n(const int16_t *iq, ko_cpx *out, ko_cpx *td, int prec, int nsamples, int fft_len);
 ko_acq_result ko_correlate_n(const ko_cpx *code, const ko_cpx *data, int limit, int dop_lo, int dop_hi,
                              ko_acq_cell *cells, int prec, int fft_len);
+/* With the row the reference reads BEHIND the satellite's own for a negative Doppler bin (gps/search.cpp:471 over the doubled
+ * row of :54: entries 2 N .. 2 N + |dop| - 1 are code[sat + 1][0 .. |dop|)): `next` = that row's spectrum, NULL = a row never
+ * written (zeros).  The forms without it are the NULL case.  nexts: [nsv][fft_len] with has_next[nsv] flags, or NULL. */
+ko_acq_result ko_correlate_next_n(const ko_cpx *code, const ko_cpx *next, const ko_cpx *data, int limit, int dop_lo, int dop_hi,
+                                  ko_acq_cell *cells, int prec, int fft_len);
+void ko_correlate_many_next_n(const ko_cpx *codes, const ko_cpx *nexts, const unsigned char *has_next, int nsv, const ko_cpx *data,
+                              const int *limits, int dop_lo, int dop_hi, ko_acq_result *out, ko_acq_cell *cells, int prec,
+                              int nthreads, int fft_len);
 void ko_correlate_many_n(const ko_cpx *codes, int nsv, const ko_cpx *data, const int *limits, int dop_lo,
                          int dop_hi, ko_acq_result *out, ko_acq_cell *cells, int prec, int nthreads,
                          int fft_len);

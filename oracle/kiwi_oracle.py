@@ -188,19 +188,26 @@ def sample_iq16(iq, prec=1, want_td=False, nsamples=NSAMPLES, fft_len=FFT_LEN):
     return (out, td) if want_td else out
 
 
-def correlate(code, data, limit=L1_LIMIT, dop_lo=DOP_LO, dop_hi=DOP_HI, prec=1):
-    """-> (result dict, cells structured array[dop_hi-dop_lo+1]); the transform length is code.size"""
+def correlate(code, data, limit=L1_LIMIT, dop_lo=DOP_LO, dop_hi=DOP_HI, prec=1, code_next=None):
+    """-> (result dict, cells structured array[dop_hi-dop_lo+1]); the transform length is code.size.
+    code_next: the spectrum in the NEXT row of the reference's code[][] table (the satellite numbered one higher), which a
+    negative Doppler bin reads into (ko_correlate_next_n); None = a row never written (zeros)."""
     code = np.ascontiguousarray(code, cpx)
     data = np.ascontiguousarray(data, cpx)
     assert code.size == data.size
     cells = np.zeros(dop_hi - dop_lo + 1, cell_dtype)
-    r = lib().ko_correlate_n(_p(code), _p(data), int(limit), dop_lo, dop_hi, _p(cells), int(prec),
-                             int(code.size))
+    L = lib()
+    L.ko_correlate_next_n.restype = AcqResult
+    nxt = None if code_next is None else np.ascontiguousarray(code_next, cpx)
+    assert nxt is None or nxt.size == code.size
+    r = L.ko_correlate_next_n(_p(code), _p(nxt) if nxt is not None else None, _p(data), C.c_int(int(limit)), C.c_int(dop_lo),
+                              C.c_int(dop_hi), _p(cells), C.c_int(int(prec)), C.c_int(int(code.size)))
     return dict(snr=r.snr, dop=r.dop, idx=r.idx, valid=r.valid), cells
 
 
 def correlate_many(codes, data, limits, dop_lo=DOP_LO, dop_hi=DOP_HI, prec=1, nthreads=1,
-                   want_cells=True):
+                   want_cells=True, nexts=None):
+    """nexts: per SV the spectrum of the next row of the reference's table (see correlate), None entries / None = never written."""
     codes = np.ascontiguousarray(codes, cpx)
     data = np.ascontiguousarray(data, cpx)
     nsv = codes.shape[0]
@@ -209,8 +216,17 @@ def correlate_many(codes, data, limits, dop_lo=DOP_LO, dop_hi=DOP_HI, prec=1, nt
     nd = dop_hi - dop_lo + 1
     out = np.zeros(nsv, result_dtype)
     cells = np.zeros((nsv, nd), cell_dtype) if want_cells else None
-    lib().ko_correlate_many_n(_p(codes), nsv, _p(data), _p(limits), dop_lo, dop_hi, _p(out),
-                              _p(cells) if want_cells else None, int(prec), int(nthreads), int(data.size))
+    nx, has = None, None
+    if nexts is not None:
+        assert len(nexts) == nsv
+        has = np.array([0 if n is None else 1 for n in nexts], np.uint8)
+        nx = np.zeros(codes.shape, cpx)
+        for i, n in enumerate(nexts):
+            if n is not None:
+                nx[i] = n
+    lib().ko_correlate_many_next_n(_p(codes), _p(nx) if nx is not None else None, _p(has) if has is not None else None, C.c_int(nsv),
+                                   _p(data), _p(limits), C.c_int(dop_lo), C.c_int(dop_hi), _p(out), _p(cells) if want_cells else None,
+                                   C.c_int(int(prec)), C.c_int(int(nthreads)), C.c_int(int(data.size)))
     return out, cells
 
 

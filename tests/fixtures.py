@@ -71,3 +71,56 @@ def arm_audio_tail(P, ch, rate=12000.0, hbw=4900.0, squelch=0):
     P.set_am_passband(ch, -hbw, hbw, rate)
     P.squelch_setup(ch, rate)
     P.squelch_set(ch, squelch, 0)
+
+
+def run_fastfir_script(f, script, x):
+    """The script language of oracle/ref/ref_fastfir_main.cpp on an object with window(w) / cic(on) / setup(inst, lo, hi, off, fs) /
+    process(x) -> (out complex64, FirPos).  Returns the floats the reference driver would have written."""
+    import numpy as np
+    out, pos = [], 0
+    for line in script:
+        t = str(line).split()
+        if t[0] == "W":
+            f.window(int(t[1]))
+        elif t[0] == "C":
+            f.cic(int(t[1]) != 0)
+        elif t[0] == "P":
+            f.setup(int(t[1]), *[float(v) for v in t[2:6]])
+        else:
+            n = int(t[1])
+            y, fp = f.process(x[pos:pos + n])
+            pos += n
+            out.append(np.array([y.size, fp], np.float32))
+            out.append(np.ascontiguousarray(y, np.complex64).view(np.float32))
+    assert pos == x.size
+    return np.concatenate(out)
+
+
+def fastfir_blocks(script, flat):
+    """Splits the driver's float stream into [(count, FirPos, complex64 outputs)] per `D` line."""
+    import numpy as np
+    blocks, k = [], 0
+    for line in script:
+        if str(line).split()[0] != "D":
+            continue
+        cnt, fp = int(flat[k]), int(flat[k + 1])
+        k += 2
+        blocks.append((cnt, fp, flat[k:k + 2 * cnt].view(np.complex64)))
+        k += 2 * cnt
+    assert k == flat.size
+    return blocks
+
+
+def oracle_row(oracle, searcher, sat):
+    """The oracle's version of what the host wrote into row `sat` of a Searcher's code table (Searcher.rows), or None when the
+    row was never written -- the `code_next` of sat - 1 (the reference's Correlate() reads the next satellite's row behind a
+    satellite's own for a negative Doppler bin: gps/search.cpp:471 over the doubled rows of :54)."""
+    r = searcher.rows.get(int(sat))
+    if r is None or sat >= searcher.max_sats:
+        return None
+    kind, arr, boc = r
+    return oracle.code_fft(arr, boc=boc, fft_len=searcher.fft_len) if kind == "chips" else arr
+
+
+def oracle_next_rows(oracle, searcher, svs):
+    return [oracle_row(oracle, searcher, int(s) + 1) for s in svs]

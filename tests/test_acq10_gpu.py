@@ -45,6 +45,12 @@ def oracle_codes(oracle, codes):
     return np.stack([oracle.code_fft(chips, boc=boc, fft_len=FFT10) for chips, boc in codes])
 
 
+def next_rows(oracle_codes, svs):
+    """The rows behind the listed satellites' own in the searcher10 table (all 59 rows written, the 60th never): what a negative
+    Doppler bin reads into -- the reference's Correlate() over its doubled rows (gps/search.cpp:471, :54), kept at this shape."""
+    return [oracle_codes[s + 1] if s + 1 < len(oracle_codes) else None for s in svs]
+
+
 def test_shape_accessors_and_rejections(gpu_ctx, searcher10):
     from flydog_sdr_gps_amd import KiwiGpuError
     assert searcher10.lib.kg_acq_nsamples(searcher10.h) == N10
@@ -78,7 +84,8 @@ def test_sample_10ms_iq16_and_bits(searcher10, oracle, codes):
     assert np.array_equal(searcher10.get_data_td(1).view(np.uint32), td.view(np.uint32))
     assert relmax(searcher10.get_data_fft(1), want) < RTOL
     res, _ = searcher10.correlate_many([0], first_block=1)
-    w, _ = oracle.correlate(oracle.code_fft(chips, fft_len=FFT10), want, dop_lo=DOP_LO, dop_hi=DOP_HI)
+    w, _ = oracle.correlate(oracle.code_fft(chips, fft_len=FFT10), want, dop_lo=DOP_LO, dop_hi=DOP_HI,
+                            code_next=oracle.code_fft(codes[1][0], fft_len=FFT10))
     assert (int(res[0, 0]["dop"]), int(res[0, 0]["idx"])) == (w["dop"], w["idx"]) == (11, 401)
 
 
@@ -91,7 +98,7 @@ def test_config4_all_59_svs_256_bins(searcher10, oracle, codes, oracle_codes):
     data = oracle.sample_iq16(iq, nsamples=N10, fft_len=FFT10)
     limits = [sats.E1B_LIMIT if boc else sats.L1_LIMIT for _, boc in codes]
     want, wcells = oracle.correlate_many(oracle_codes, data, limits, dop_lo=DOP_LO, dop_hi=DOP_HI,
-                                         nthreads=max(1, len(os.sched_getaffinity(0))))
+                                         nthreads=max(1, len(os.sched_getaffinity(0))), nexts=next_rows(oracle_codes, svs))
     from tests.errlog import record
     for k, tol in (("max_pwr", RTOL), ("tot_pwr", RTOL), ("snr", SNR_RTOL)):
         record("configs[4] 15104 cells.%s" % k, cells[0][k], wcells[k], tol)
@@ -128,7 +135,7 @@ def test_injected_spectrum_and_shift_edges_65536(searcher10, oracle_codes, oracl
             searcher10.set_data_fft(data)
             res, cells = searcher10.correlate_many([sat])
             assert (int(res[0, 0]["dop"]), int(res[0, 0]["idx"])) == (d, delay)
-            w, wcells = oracle.correlate(code, data, limit=limit, dop_lo=d, dop_hi=d)
+            w, wcells = oracle.correlate(code, data, limit=limit, dop_lo=d, dop_hi=d, code_next=oracle_codes[sat + 1])
             assert (w["dop"], w["idx"]) == (d, delay)
             np.testing.assert_allclose(cells[0, 0]["max_pwr"][d - DOP_LO], wcells["max_pwr"][0], rtol=RTOL)
             np.testing.assert_allclose(cells[0, 0]["tot_pwr"][d - DOP_LO], wcells["tot_pwr"][0], rtol=RTOL)
@@ -146,7 +153,7 @@ def test_two_blocks_per_sv_calls_and_zero_input(searcher10, oracle, codes, oracl
     for b in range(2):
         data = oracle.sample_iq16(iqs[b], nsamples=N10, fft_len=FFT10)
         want, _ = oracle.correlate_many(oracle_codes[svs], data, limits, dop_lo=DOP_LO, dop_hi=DOP_HI,
-                                        nthreads=max(1, len(os.sched_getaffinity(0))), want_cells=False)
+                                        nthreads=max(1, len(os.sched_getaffinity(0))), want_cells=False, nexts=next_rows(oracle_codes, svs))
         assert np.array_equal(res[b]["dop"], want["dop"]) and np.array_equal(res[b]["idx"], want["idx"])
         np.testing.assert_allclose(res[b]["snr"], want["snr"], rtol=SNR_RTOL)
         if b == 0:

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from flydog_sdr_gps_amd import Searcher, prn, sats, synth
+from tests.fixtures import oracle_next_rows, oracle_row      # the row BEHIND a satellite's own, which a negative Doppler bin reads
 
 pytestmark = pytest.mark.gpu
 
@@ -98,7 +99,7 @@ def test_config0_prn1(searcher, navstar_codes, oracle):
     searcher.sample(bits)
     res, cells = searcher.correlate_many([0])
     data = oracle.sample_bits(bits)
-    want, wcells = oracle.correlate(navstar_codes[0], data)
+    want, wcells = oracle.correlate(navstar_codes[0], data, code_next=oracle_row(oracle, searcher, 1))
     r = res[0, 0]
     assert (int(r["dop"]), int(r["idx"]), int(r["valid"])) == (want["dop"], want["idx"], 1)
     assert abs(r["snr"] - want["snr"]) <= SNR_RTOL * want["snr"]
@@ -117,7 +118,7 @@ def test_config1_32sv_41bins(searcher, navstar_codes, oracle):
     res, cells = searcher.correlate_many(svs)
     data = oracle.sample_iq16(iq)           # the oracle chain end to end, from the int16 samples
     codes = np.stack([navstar_codes[s] for s in svs])
-    want, wcells = oracle.correlate_many(codes, data, [L1] * 32, nthreads=8)
+    want, wcells = oracle.correlate_many(codes, data, [L1] * 32, nthreads=8, nexts=oracle_next_rows(oracle, searcher, svs))
     assert np.array_equal(res[0]["dop"], want["dop"])
     assert np.array_equal(res[0]["idx"], want["idx"])
     assert np.array_equal(res[0]["valid"], want["valid"])
@@ -141,7 +142,7 @@ def test_injected_spectrum_and_shifts(searcher, navstar_codes, oracle):
         data = np.roll(code, d) * np.exp(2j * np.pi * n * delay / 16384)
         searcher.set_data_fft(data.astype(np.complex64))
         res, cells = searcher.correlate_many([4])
-        want, wcells = oracle.correlate(code, data.astype(np.complex64))
+        want, wcells = oracle.correlate(code, data.astype(np.complex64), code_next=oracle_row(oracle, searcher, 5))
         assert (int(res[0, 0]["dop"]), int(res[0, 0]["idx"])) == (want["dop"], want["idx"])
         assert (want["dop"], want["idx"]) == (d, delay)
         # only the matched-Doppler cell: this noise-free input makes the other
@@ -195,7 +196,7 @@ def test_multi_block_batch(searcher, navstar_codes, oracle):
     res, cells = searcher.correlate_many(svs, nblocks=3)
     codes = np.stack([navstar_codes[s] for s in svs])
     for b in range(3):
-        want, wcells = oracle.correlate_many(codes, datas[b], [L1] * len(svs), nthreads=8)
+        want, wcells = oracle.correlate_many(codes, datas[b], [L1] * len(svs), nthreads=8, nexts=oracle_next_rows(oracle, searcher, svs))
         assert np.array_equal(res[b]["dop"], want["dop"])
         assert np.array_equal(res[b]["idx"], want["idx"])
         check_cells(cells[b], wcells)
@@ -293,8 +294,8 @@ def test_mixed_l1_e1b_batch(gpu_ctx, oracle):
     s.sample(g["case5_bits"])
     res, cells = s.correlate_many([1, 0, 2, 1])
     data = s.get_data_fft()
-    w_e, c_e = oracle.correlate(oracle.code_fft(e1b, boc=True), data, limit=sats.E1B_LIMIT)
-    w_0, c_0 = oracle.correlate(oracle.code_fft(ca), data)
+    w_e, c_e = oracle.correlate(oracle.code_fft(e1b, boc=True), data, limit=sats.E1B_LIMIT, code_next=oracle_row(oracle, s, 2))
+    w_0, c_0 = oracle.correlate(oracle.code_fft(ca), data, code_next=oracle_row(oracle, s, 1))
     for pos, (w, c) in zip((0, 1, 3), ((w_e, c_e), (w_0, c_0), (w_e, c_e))):
         assert (int(res[0, pos]["dop"]), int(res[0, pos]["idx"])) == (w["dop"], w["idx"])
         check_cells(cells[0, pos], c)
@@ -310,7 +311,7 @@ def test_two_block_sets_pipelined(gpu_ctx, navstar_codes_for, oracle):
     iqs = [synth.config1_iq16(seed=200 + i, cn0_dbhz=45.0 + i) for i in range(6)]
     wants = []
     for iq in iqs:
-        w, _ = oracle.correlate_many(codes, oracle.sample_iq16(iq), [L1] * len(svs), nthreads=4)
+        w, _ = oracle.correlate_many(codes, oracle.sample_iq16(iq), [L1] * len(svs), nthreads=4, nexts=oracle_next_rows(oracle, s, svs))
         wants.append(w)
     got = []
     for step in range(3):                       # steps use blocks {0,1}, {2,3}, {0,1}

@@ -263,3 +263,101 @@ def test_deemphasis_tables_match_rx_filter_h():
         for k in range(2):
             assert np.array_equal(g["%s_%d_out" % (name, k)][:79], tab[k])
     assert int(re.search(r"#define N_DEEMP_TAPS (\d+)", text).group(1)) == deemp.N_DEEMP_TAPS
+
+
+# ---- the FFT-dependent rows, pinned by the reference's own gps/search.cpp and rx/CuteSDR/fastfir.cpp -------------------------
+# compiled in place against the FFTW3 API the image ships (hipFFTW) and run on the GPU box (oracle/build_ref.sh,
+# tools/make_ref_fft_golden.py -> tests/golden/acq_fftref.npz, fastfir_fftref.npz).  hipFFTW's transforms are not FFTW's
+# (another algorithm, GPU arithmetic): float spectra are held to north_star's 1e-5 of the spectrum's largest bin, everything
+# that is an index or a count to equality.
+FFT_TOL = 1e-5
+
+
+def _all_codes():
+    from flydog_sdr_gps_amd import synth
+    from tests.fixtures import e1b_chips
+    return synth.all_sv_codes(e1b_chips())
+
+
+def test_acquisition_oracle_matches_reference_search_cpp(oracle):
+    """SearchInit()'s code tables (C/A PRN 1, QZSS 194, Galileo E02 and E36 with BOC(1,1)), both decimators, Sample()'s data
+    spectrum of five 1-bit IF scenes and Correlate()'s (snr, Doppler bin, peak index) for eleven (scene, SV) pairs -- present
+    SVs at positive and negative Doppler, absent ones (the winner among noise peaks), a noise-only block, E1B over its 16368
+    lags -- as gps/search.cpp ITSELF computed them.  Peak bin and index: equal.  snr: 1e-5.  Decimators: bit-exact."""
+    g = np.load(os.path.join(GOLD, "acq_fftref.npz"))
+    keep = int(g["keep_every"])
+    codes = _all_codes()
+
+    def code_fft(s):
+        return oracle.code_fft(codes[s][0], boc=codes[s][1])
+    for s in g["code_sats"]:
+        mine = code_fft(int(s))
+        assert np.abs(mine[::keep] - g["code_%d_bins" % s]).max() <= FFT_TOL * g["code_%d_max" % s], s
+        l2 = np.sqrt(np.sum(np.abs(mine.astype(np.complex128)) ** 2))
+        assert abs(l2 - g["code_%d_l2" % s]) <= FFT_TOL * g["code_%d_l2" % s] and abs(np.abs(mine).max() - g["code_%d_max" % s]) <= FFT_TOL * g["code_%d_max" % s]
+    assert np.array_equal(oracle.decimate_by2(g["dec_float_in"]).view(np.uint32), g["dec_float_out"].view(np.uint32))
+    # DecimateBy2binary (search.cpp:168-179): bits[][2] -> +-1 (bit 1 -> -1.0) -> the float decimator
+    b = g["dec_binary_in"].astype(np.float32)
+    pm = (np.where(b[:, 0] > 0, -1.0, 1.0) + 1j * np.where(b[:, 1] > 0, -1.0, 1.0)).astype(np.complex64)
+    assert np.array_equal(oracle.decimate_by2(pm).view(np.uint32), g["dec_binary_out"].view(np.uint32))
+    negative = 0
+    for name in (str(n) for n in g["scene_names"]):
+        data = oracle.sample_bits(g[name + "_bits"])
+        assert np.abs(data[::keep] - g[name + "_spec_bins"]).max() <= FFT_TOL * g[name + "_spec_max"], name
+        assert abs(np.sqrt(np.sum(np.abs(data.astype(np.complex128)) ** 2)) - g[name + "_spec_l2"]) <= FFT_TOL * g[name + "_spec_l2"]
+        for k, s in enumerate(int(v) for v in g[name + "_sats"]):
+            lim = oracle.E1B_LIMIT if codes[s][1] else oracle.L1_LIMIT
+            nxt = code_fft(s + 1) if s + 1 < len(codes) else None          # the table's next row (zeros behind the last SV)
+            r, _ = oracle.correlate(code_fft(s), data, limit=lim, code_next=nxt)
+            assert (r["dop"], r["idx"]) == (int(g[name + "_dop"][k]), int(g[name + "_idx"][k])), (name, s, r)
+            assert abs(r["snr"] - g[name + "_snr"][k]) <= FFT_TOL * g[name + "_snr"][k], (name, s, r["snr"], g[name + "_snr"][k])
+            negative += r["dop"] < 0
+    assert negative >= 4          # the cases that read the next satellite's row (search.cpp:471 over the doubled row of :54)
+    # ... which the modulo-N restatement of rounds 1-5 got wrong: it must NOT reproduce the reference there
+    data = oracle.sample_bits(g["prn20_negative_doppler_bits"])
+    wrapped, _ = oracle.correlate(code_fft(19), data, code_next=code_fft(19))      # own bins 0 .. |dop| behind the row = modulo N
+    assert abs(wrapped["snr"] - g["prn20_negative_doppler_snr"][0]) > 1e-3 * wrapped["snr"]
+
+
+class OracleFastFir:
+    def __init__(self, oracle):
+        self.o, self.st = oracle, oracle.fir_new_state()
+        self.win, self.cic_on, self.coef, self.last = oracle.fir_window(-1), False, None, None
+        self.base = None
+
+    def window(self, w):
+        self.win = self.o.fir_window(w)
+
+    def cic(self, on):                         # SetupCICFilter: m_pFilterCoef_CIC from m_pFilterCoef (fastfir.cpp:148-158)
+        self.cic_on = on
+        if self.base is not None:
+            self.coef = (self.base * (self.o.fir_cic_coeffs() if on else 1.0)).astype(np.complex64)
+
+    def setup(self, inst, lo, hi, off, fs):
+        if self.last == (lo, hi, off, fs):     # :180-184
+            return
+        self.last = (lo, hi, off, fs)
+        d = self.o.fir_design(lo, hi, off, fs, window=self.win, do_cic_comp=self.cic_on, prec=0)
+        if d is not None:                      # :193-200: a rejected setting leaves the old filter
+            self.base, self.coef = d[0], d[1]
+
+    def process(self, x):
+        return self.o.fir_process(self.st, self.coef, x, prec=0)
+
+
+def test_fastfir_oracle_matches_reference_fastfir_cpp(oracle):
+    """CFastFIR::SetupParameters / SetupCICFilter / ProcessData sequences (USB in the data pump's 170-sample interrupts, LSB in
+    ragged lengths, AM, a narrow CW filter with an offset, the 20.25 kHz mode, a retune in mid-stream with a rejected and a
+    repeated setting, CIC compensation on) as rx/CuteSDR/fastfir.cpp ITSELF computed them: output counts and FirPos() equal,
+    samples to 1e-5 of the block's largest."""
+    from tests.fixtures import fastfir_blocks, run_fastfir_script
+    g = np.load(os.path.join(GOLD, "fastfir_fftref.npz"))
+    for name in (str(n) for n in g["names"]):
+        got = fastfir_blocks(g[name + "_script"], run_fastfir_script(OracleFastFir(oracle), g[name + "_script"], g[name + "_in"]))
+        want = fastfir_blocks(g[name + "_script"], g[name + "_out"])
+        assert len(got) == len(want)
+        scale = max(float(np.abs(w[2]).max()) for w in want if w[0])
+        for b, ((gc, gp, gy), (wc, wp, wy)) in enumerate(zip(got, want)):
+            assert (gc, gp) == (wc, wp), (name, b, gc, gp, wc, wp)
+            if wc:
+                assert np.abs(gy - wy).max() <= FFT_TOL * scale, (name, b, float(np.abs(gy - wy).max()), scale)

@@ -168,3 +168,91 @@ def test_squelch_on_the_gpu_matches_reference_squelch_cpp(gpu_ctx):
             assert got.shape == want.shape and np.array_equal(got, want), "%s: %d differ" % (name, np.count_nonzero(got != want))
     finally:
         P.close()
+
+
+# ---- the FFT-dependent rows against the reference's own gps/search.cpp and rx/CuteSDR/fastfir.cpp ---------------------------
+# (tests/golden/acq_fftref.npz, fastfir_fftref.npz: compiled in place against hipFFTW, run on a GPU box; the same vectors pin
+# the oracle in tests/test_ref_pins_cpu.py)
+FFT_TOL = 1e-5
+
+
+def test_acquisition_on_the_gpu_matches_reference_search_cpp(gpu_ctx):
+    """kg_acq behind the Searcher mirror, set up as SearchInit() leaves the reference (all 59 rows of Sats[]), against what
+    gps/search.cpp ITSELF computed: code tables and Sample() spectra to 1e-5 of their largest bin, Correlate()'s Doppler bin and
+    peak index EQUAL for all eleven (scene, SV) pairs -- present and absent SVs, both signs of Doppler (a negative bin reads the
+    next satellite's row behind its own: search.cpp:471 over :54's doubled rows), E1B over 16368 lags -- and snr to 1e-5."""
+    from flydog_sdr_gps_amd import synth
+    from tests.fixtures import e1b_chips
+    g = np.load(os.path.join(GOLD, "acq_fftref.npz"))
+    keep = int(g["keep_every"])
+    codes = synth.all_sv_codes(e1b_chips())
+    s = Searcher(gpu_ctx, max_blocks=1)
+    try:
+        for sat, (chips, boc) in enumerate(codes):
+            s.set_code(sat, chips, boc=boc)
+        for sat in (int(v) for v in g["code_sats"]):
+            mine = s.get_code_fft(sat)
+            assert np.abs(mine[::keep] - g["code_%d_bins" % sat]).max() <= FFT_TOL * g["code_%d_max" % sat], sat
+        negative = 0
+        for name in (str(n) for n in g["scene_names"]):
+            s.sample(g[name + "_bits"])
+            data = s.get_data_fft()
+            assert np.abs(data[::keep] - g[name + "_spec_bins"]).max() <= FFT_TOL * g[name + "_spec_max"], name
+            asked = [int(v) for v in g[name + "_sats"]]
+            res, _ = s.correlate_many(asked)
+            for k, sat in enumerate(asked):
+                r = res[0, k]
+                assert (int(r["dop"]), int(r["idx"])) == (int(g[name + "_dop"][k]), int(g[name + "_idx"][k])), (name, sat, r)
+                assert abs(float(r["snr"]) - g[name + "_snr"][k]) <= FFT_TOL * g[name + "_snr"][k], (name, sat, r["snr"], g[name + "_snr"][k])
+                negative += int(r["dop"]) < 0
+        assert negative >= 4
+        # the row behind a satellite's own is what the table holds THERE: with satellite 20's row rewritten (to PRN 1's code) the
+        # negative-Doppler result of satellite 19 changes, a positive-Doppler one does not
+        name = "prn20_negative_doppler"
+        s.sample(g[name + "_bits"])
+        before, _ = s.correlate_many([19, 7])
+        s.set_code(20, codes[0][0])
+        after, _ = s.correlate_many([19, 7])
+        assert float(after[0, 0]["snr"]) != float(before[0, 0]["snr"]) and float(after[0, 1]["snr"]) == float(before[0, 1]["snr"])
+        assert (int(after[0, 0]["dop"]), int(after[0, 0]["idx"])) == (int(before[0, 0]["dop"]), int(before[0, 0]["idx"]))
+    finally:
+        s.close()
+
+
+class GpuFastFir:
+    def __init__(self, F, ch):
+        self.F, self.ch, self.win, self.cic_on = F, ch, -1, False
+
+    def window(self, w):
+        self.win = w
+
+    def cic(self, on):
+        self.cic_on = on
+
+    def setup(self, inst, lo, hi, off, fs):
+        self.F.setup(self.ch, lo, hi, off, fs, window_func=self.win, do_cic_comp=self.cic_on)
+
+    def process(self, x):
+        y = self.F.process(self.ch, x)
+        return y, self.F.pos(self.ch)
+
+
+def test_fastfir_on_the_gpu_matches_reference_fastfir_cpp(gpu_ctx):
+    """kg_fir against what rx/CuteSDR/fastfir.cpp ITSELF computed (fastfir_fftref.npz): counts and FirPos() equal, samples to
+    1e-5 of the scenario's largest output."""
+    from flydog_sdr_gps_amd import FastFir
+    from tests.fixtures import fastfir_blocks, run_fastfir_script
+    g = np.load(os.path.join(GOLD, "fastfir_fftref.npz"))
+    names = [str(n) for n in g["names"]]
+    F = FastFir(gpu_ctx, nchan=len(names), max_in=1024)
+    try:
+        for ch, name in enumerate(names):
+            got = fastfir_blocks(g[name + "_script"], run_fastfir_script(GpuFastFir(F, ch), g[name + "_script"], g[name + "_in"]))
+            want = fastfir_blocks(g[name + "_script"], g[name + "_out"])
+            scale = max(float(np.abs(w[2]).max()) for w in want if w[0])
+            for b, ((gc, gp, gy), (wc, wp, wy)) in enumerate(zip(got, want)):
+                assert (gc, gp) == (wc, wp), (name, b, gc, gp, wc, wp)
+                if wc:
+                    assert np.abs(gy - wy).max() <= FFT_TOL * scale, (name, b, float(np.abs(gy - wy).max()), scale)
+    finally:
+        F.close()

@@ -13,7 +13,7 @@ from flydog_sdr_gps_amd import (Adpcm, Context, Ddc, FastFir, Post, RxDdc, Searc
                                 wire)
 from flydog_sdr_gps_amd.ddc import RX_DECIM   # noqa: E402
 from oracle import kiwi_oracle as ko          # noqa: E402
-from tests.fixtures import arm_audio_tail    # noqa: E402
+from tests.fixtures import arm_audio_tail, oracle_row    # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
 only = sys.argv[3] if len(sys.argv) > 3 else None
@@ -276,7 +276,7 @@ def trial_acq():
     for k, sat in enumerate(svs):
         c, b, lim = info[sat]
         g = got[0, k]
-        res = ko.correlate(ko.code_fft(c, boc=b, prec=1), data, limit=lim)
+        res = ko.correlate(ko.code_fft(c, boc=b, prec=1), data, limit=lim, code_next=oracle_row(ko, s, sat + 1))
         w_snr, w_dop, w_idx, w_valid = (res[0][x] for x in ("snr", "dop", "idx", "valid"))
         if w_snr >= 24:                                 # a detection: everything must agree
             assert (int(g["valid"]), int(g["dop"]), int(g["idx"])) == (int(w_valid), int(w_dop), int(w_idx)), ("acq", sat, lim, g, res[0])

@@ -1,0 +1,146 @@
+"""Generates tests/golden/acq_fftref.npz and fastfir_fftref.npz from the REFERENCE ITSELF -- its gps/search.cpp (SearchInit,
+Sample, Correlate, the decimators) and rx/CuteSDR/fastfir.cpp (CFastFIR), compiled in place by oracle/build_ref.sh against the
+FFTW3 API the image ships (hipFFTW) -- RUN ON THE GPU BOX, where hipFFTW's transforms execute:
+
+    gpurun -- 'python tools/make_ref_fft_golden.py gpurun_out/fftref'      (then: cp gpurun_out/fftref/*.npz tests/golden/)
+
+Needs oracle/_ref/search_ref and fastfir_ref (built in the build container, they travel with the snapshot) and nothing of
+/root/reference.  What is committed is data: inputs made here from fixed seeds, the outputs the reference's code produced.
+Spectra are kept as every 4th bin plus the full array's L2 norm and largest magnitude (a code table is 128 KiB).
+The script also prints how far the oracle's restatement is from each vector (the tests assert it).
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = os.path.join(ROOT, "oracle", "_ref")
+out_dir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "fftref")
+os.makedirs(out_dir, exist_ok=True)
+
+from flydog_sdr_gps_amd import prn, sats, synth            # noqa: E402  (pure numpy input generators)
+from tests.fixtures import e1b_chips                         # noqa: E402
+
+FFT_LEN, KEEP = 16384, 4
+
+
+def run(binary, script, data):
+    with tempfile.TemporaryDirectory() as tmp:
+        open(os.path.join(tmp, "s.txt"), "w").write("\n".join(script) + "\n")
+        np.asarray(data).tofile(os.path.join(tmp, "in.bin"))
+        p = subprocess.run([os.path.join(REF, binary), os.path.join(tmp, "s.txt"), os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        if p.returncode != 0:
+            raise SystemExit("%s failed (%d): %s" % (binary, p.returncode, p.stderr.decode()[-2000:]))
+        return np.fromfile(os.path.join(tmp, "out.bin"), np.float32)
+
+
+def keep(spec):
+    spec = np.asarray(spec, np.complex64)
+    return {"bins": spec[::KEEP].copy(), "l2": np.float64(np.sqrt(np.sum(np.abs(spec.astype(np.complex128)) ** 2))),
+            "max": np.float32(np.abs(spec).max())}
+
+
+# ---- acquisition ------------------------------------------------------------------------------------------------------------
+e1b = e1b_chips()
+codes = synth.all_sv_codes(e1b)
+E02, E05, E36 = 36, 39, 58                                   # rows of sats.SATS (E1B PRNs 2, 5, 36)
+assert sats.SATS[E02][0] == 2 and sats.SATS[E05][0] == 5 and sats.SATS[E36][0] == 36 and sats.SATS[32][0] == 194
+scenes = [
+    # name, the SVs in the 1-bit IF block [(sat, tau chips, Doppler Hz, theta, C/N0)], seed, the SVs Correlate() is asked for
+    ("config0_prn1", [(0, 300.5, 1500.0, 0.7, 45.0)], 0x5EED0001, [0, 5]),            # BASELINE configs[0]; PRN 6 is absent
+    ("noise_only", [], 0x5EED00B0, [0, E02]),
+    ("prn20_negative_doppler", [(19, 1000.25, -3200.0, 2.1, 47.0), (7, 12.0, 4900.0, 0.3, 44.0)], 0x5EED00B1, [19, 7, 32]),
+    ("e1b_e02", [(E02, 1500.25, 3900.0, 2.2, 46.0)], 0x5EED00B2, [E02, E05]),
+    ("e1b_e36_late_code_phase", [(E36, 4000.5, -1100.0, 0.9, 47.0), (2, 700.0, 250.0, 1.0, 45.0)], 0x5EED00B3, [E36, 2]),
+]
+acq = {"scene_names": np.array([s[0] for s in scenes]), "keep_every": np.int32(KEEP)}
+# code tables (row G3): C/A PRN1, QZSS 194, Galileo E02 and E36
+code_sats = [0, 32, E02, E36]
+y = run("search_ref", ["T %d" % s for s in code_sats], np.zeros(1, np.uint8)).view(np.complex64).reshape(len(code_sats), FFT_LEN)
+acq["code_sats"] = np.array(code_sats, np.int32)
+for k, s in enumerate(code_sats):
+    for key, v in keep(y[k]).items():
+        acq["code_%d_%s" % (s, key)] = v
+# decimators (rows G5, G6): 256-sample vectors, tail behaviour included (the filter reads 30 samples past the end: zero-filled)
+rng = np.random.Generator(np.random.PCG64(0x5EED00B4))
+dec_in = (rng.standard_normal(256) + 1j * rng.standard_normal(256)).astype(np.complex64)
+bits_in = rng.integers(0, 2, (256, 2)).astype(np.int8)
+y = run("search_ref", ["D 256", "B 256"], np.concatenate([dec_in.view(np.uint8), bits_in.view(np.uint8).ravel()]))
+acq["dec_float_in"], acq["dec_float_out"] = dec_in, y[:256].view(np.complex64).copy()
+acq["dec_binary_in"], acq["dec_binary_out"] = bits_in, y[256:512].view(np.complex64).copy()
+for name, present, seed, asked in scenes:
+    svs = [(codes[sat][0], tau, fd, th, cn0, codes[sat][1]) for sat, tau, fd, th, cn0 in present]
+    packed = synth.gps_scene_bits(svs, seed)
+    assert packed.size == 8192
+    y = run("search_ref", ["S"] + ["C %d" % s for s in asked], packed)
+    spec = y[:2 * FFT_LEN].view(np.complex64)
+    res = y[2 * FFT_LEN:].reshape(len(asked), 3)
+    acq[name + "_bits"] = packed
+    for key, v in keep(spec).items():
+        acq[name + "_spec_" + key] = v
+    acq[name + "_sats"] = np.array(asked, np.int32)
+    acq[name + "_snr"] = res[:, 0].copy()
+    acq[name + "_dop"] = res[:, 1].astype(np.int32)
+    acq[name + "_idx"] = res[:, 2].astype(np.int32)
+    print("acq %-26s" % name, " ".join("sat %d: snr %.2f dop %d idx %d;" % (s, r[0], r[1], r[2]) for s, r in zip(asked, res)))
+np.savez_compressed(os.path.join(out_dir, "acq_fftref.npz"), **acq)
+
+# ---- CFastFIR ---------------------------------------------------------------------------------------------------------------
+rng = np.random.Generator(np.random.PCG64(0x5EED00B5))
+
+
+def audio_iq(n, amp=3000.0):
+    t = np.arange(n)
+    x = amp * (np.exp(2j * np.pi * 0.04 * t) + 0.3 * np.exp(-2j * np.pi * 0.11 * t)) + 40.0 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    return x.astype(np.complex64)
+
+
+ff_scen = [
+    # USB 300-2700 Hz at 12 kHz in the data pump's 170-sample interrupts (4 channels, config.h:40): FirPos 0, 170, 340, 510 -> 168, ...
+    ("usb_12k_170", ["P 0 300 2700 0 12000"] + ["D 170"] * 12),
+    ("lsb_12k_ragged", ["P 0 -2700 -300 0 12000", "D 85", "D 226", "D 48", "D 512", "D 1", "D 600", "D 170", "D 170", "D 170"]),
+    ("am_12k", ["P 0 -4900 4900 0 12000"] + ["D 170"] * 7),
+    ("cw_narrow_offset", ["P 0 -250 250 500 12000"] + ["D 170"] * 7),
+    ("wide_20k", ["P 0 -6000 6000 0 20250"] + ["D 226"] * 6),
+    # a retune in mid-stream (the buffer keeps its samples, :171-232), a rejected setting (lo >= hi: the old filter stays, :193-200),
+    # the same setting again (returns at once, :180-184)
+    ("retune_and_rejected", ["P 0 300 2700 0 12000", "D 400", "P 0 -2700 -300 0 12000", "D 400", "P 0 500 400 0 12000", "D 400",
+                             "P 0 500 400 0 12000", "D 400", "P 0 300 2700 0 12000", "D 448"]),
+    ("cic_comp_on", ["C 1", "P 0 300 2700 0 12000"] + ["D 170"] * 7),
+]
+ff = {"names": np.array([s[0] for s in ff_scen])}
+for name, script in ff_scen:
+    n = sum(int(l.split()[1]) for l in script if l[0] == "D")
+    x = audio_iq(n)
+    y = run("fastfir_ref", script, x)
+    ff[name + "_script"], ff[name + "_in"], ff[name + "_out"] = np.array(script), x, y
+    print("fastfir %-22s %5d samples in, %5d floats out" % (name, n, y.size))
+np.savez_compressed(os.path.join(out_dir, "fastfir_fftref.npz"), **ff)
+
+# ---- how far is the oracle's restatement? (the tests assert these; here for the log) -----------------------------------------
+try:
+    from oracle import kiwi_oracle as ko
+    ko.lib()
+    g = np.load(os.path.join(out_dir, "acq_fftref.npz"))
+    for s in code_sats:
+        boc = codes[s][1]
+        mine = ko.code_fft(codes[s][0], boc=boc)
+        print("code table sat %2d: oracle vs reference %.2e of max; l2 %.3e vs %.3e" % (
+            s, np.abs(mine[::KEEP] - g["code_%d_bins" % s]).max() / g["code_%d_max" % s], np.sqrt(np.sum(np.abs(mine.astype(np.complex128)) ** 2)), g["code_%d_l2" % s]))
+    print("DecimateBy2float bit-exact:", np.array_equal(ko.decimate_by2(g["dec_float_in"]).view(np.uint32), g["dec_float_out"].view(np.uint32)))
+    for name, present, seed, asked in scenes:
+        data = ko.sample_bits(g[name + "_bits"])
+        d = np.abs(data[::KEEP] - g[name + "_spec_bins"]).max() / g[name + "_spec_max"]
+        line = "scene %-26s spectrum %.2e of max;" % (name, d)
+        for k, s in enumerate(asked):
+            lim = ko.E1B_LIMIT if codes[s][1] else ko.L1_LIMIT
+            r, _ = ko.correlate(ko.code_fft(codes[s][0], boc=codes[s][1]), data, limit=lim)
+            line += " sat %d: (%d, %d) vs (%d, %d) snr %.4f vs %.4f;" % (s, r["dop"], r["idx"], g[name + "_dop"][k], g[name + "_idx"][k], r["snr"], g[name + "_snr"][k])
+        print(line)
+except Exception as e:                                                          # the vectors are written either way
+    print("oracle comparison skipped:", repr(e))
