@@ -122,6 +122,54 @@ for name, script in ff_scen:
     print("fastfir %-22s %5d samples in, %5d floats out" % (name, n, y.size))
 np.savez_compressed(os.path.join(out_dir, "fastfir_fftref.npz"), **ff)
 
+# ---- waterfall frames -------------------------------------------------------------------------------------------------------
+from flydog_sdr_gps_amd import wf as wfm                    # noqa: E402  (host mirror: WfParams, maps -- the per-frame INPUTS)
+
+WF_CASES = [
+    # zoom, start, interp, window, cic_comp, overlapped, inversion, compression   (tests/test_wf_gpu.py's cases + compression)
+    (0, 0.0, wfm.WF_CMA, wfm.WINF_HANNING, True, False, False, True),            # zoom 0: never compressed (:1285)
+    (3, 2.0e6, wfm.WF_MAX, wfm.WINF_BLACKMAN_HARRIS, True, False, False, True),
+    (10, 9.0e6, wfm.WF_DROP, wfm.WINF_HANNING, True, False, True, False),
+    (0, 0.0, wfm.WF_MAX, wfm.WINF_BLACKMAN_HARRIS, False, False, False, False),  # dc = 4 bins
+    (1, 1.0e6, wfm.WF_MIN, wfm.WINF_HAMMING, True, False, False, True),          # zoom 1: never compensated
+    (5, 5.0e6, wfm.WF_LAST, wfm.WINF_NONE, True, True, False, True),             # overlapped: no compensation
+    (7, 3.0e6, wfm.WF_CMA, wfm.WINF_HANNING, True, False, True, False),
+    (14, 1.6e7, wfm.WF_MIN, wfm.WINF_HANNING, False, False, False, True),
+]
+script, blobs, meta = ["T"], [], []
+for k, (zoom, start, interp, winf, cic, ovl, inv, comp) in enumerate(WF_CASES):
+    prm = wfm.WfParams.for_zoom(zoom, start, spectral_inversion=inv)
+    m, d = wfm.build_maps(prm.fft_used, prm.plot_width, prm.plot_width_clamped, inv)
+    sc = np.full(1024, prm.fft_scale, np.float32)
+    iq = synth.wf_iq_frame(seed=1000 + zoom + 100 * k)
+    # fft2wf_map entries of -1 (inverted maps: "not plotted") are stored in the reference's u2_t table as 65535
+    m16 = np.asarray(m, np.int64).astype(np.uint16)
+    d16 = np.zeros(1024, np.uint16)
+    d16[:np.asarray(d).size] = np.asarray(d, np.int64).astype(np.uint16)
+    blobs += [m16.tobytes(), d16.tobytes(), sc.tobytes(), (sc / np.float32(2)).astype(np.float32).tobytes(), np.ascontiguousarray(iq, np.int16).tobytes()]
+    script.append("F %d %d %d %d %d %d %d %d %r %d %d %d" % (zoom, winf, interp, int(cic), int(ovl), prm.fft_used, prm.plot_width,
+                                                             prm.plot_width_clamped, float(prm.fft_offset), int(comp), int(prm.start), 4242 + k))
+    meta.append((prm, iq))
+y = run("wf_ref", script, np.frombuffer(b"".join(blobs), np.uint8))
+wfg = {"ncases": np.int32(len(WF_CASES)), "cases": np.array([[c[0], c[1], c[2], c[3], int(c[4]), int(c[5]), int(c[6]), int(c[7])] for c in WF_CASES], np.float64)}
+pos = 0
+wfg["window_function"] = y[pos:pos + 4 * 8192].reshape(4, 8192).copy(); pos += 4 * 8192
+wfg["cic_comp"] = y[pos:pos + 8192].copy(); pos += 8192
+wfg["n_chunks"] = np.int32(y[pos]); pos += 1
+for k, (prm, iq) in enumerate(meta):
+    nbytes, limit, xbin, flags, seq = (int(v) for v in y[pos:pos + 5]); pos += 5
+    spec = y[pos:pos + 2 * prm.fft_used].view(np.complex64); pos += 2 * prm.fft_used
+    payload = y[pos:pos + nbytes].astype(np.uint8); pos += nbytes
+    wfg["case%d_iq" % k] = np.ascontiguousarray(iq, np.int16)
+    wfg["case%d_hdr" % k] = np.array([nbytes, limit, xbin, flags, seq], np.int64)
+    wfg["case%d_spec" % k] = spec[::2].copy()                       # every 2nd of the fft_used bins
+    wfg["case%d_spec_max" % k] = np.float32(np.abs(spec).max())
+    wfg["case%d_payload" % k] = payload
+    print("wf case %d (z%d): %d payload bytes, fft_used_limit %d, flags 0x%x, row min/max %d/%d" % (
+        k, WF_CASES[k][0], nbytes, limit, flags, payload.min(), payload.max()))
+assert pos == y.size
+np.savez_compressed(os.path.join(out_dir, "wf_fftref.npz"), **wfg)
+
 # ---- how far is the oracle's restatement? (the tests assert these; here for the log) -----------------------------------------
 try:
     from oracle import kiwi_oracle as ko
@@ -142,5 +190,25 @@ try:
             r, _ = ko.correlate(ko.code_fft(codes[s][0], boc=codes[s][1]), data, limit=lim)
             line += " sat %d: (%d, %d) vs (%d, %d) snr %.4f vs %.4f;" % (s, r["dop"], r["idx"], g[name + "_dop"][k], g[name + "_idx"][k], r["snr"], g[name + "_snr"][k])
         print(line)
+    g = np.load(os.path.join(out_dir, "wf_fftref.npz"))
+    tables = (g["window_function"], g["cic_comp"])
+    for w in range(4):
+        print("window %d: oracle bit-exact %s" % (w, np.array_equal(ko.wf_window(w).view(np.uint32), g["window_function"][w].view(np.uint32))))
+    print("CIC_comp: oracle max rel diff %.2e" % (np.abs(ko.wf_cic_comp() - g["cic_comp"]).max() / np.abs(g["cic_comp"]).max()))
+    for k, (zoom, start, interp, winf, cic, ovl, inv, comp) in enumerate(WF_CASES):
+        prm = meta[k][0]
+        m, d = wfm.build_maps(prm.fft_used, prm.plot_width, prm.plot_width_clamped, inv)
+        sc = np.full(1024, prm.fft_scale, np.float32)
+        samps = ko.wf_window_iq(g["case%d_iq" % k], tables[0][winf])
+        row, pwr, pwr_out, dB = ko.wf_compute_frame(samps, prm.zoom, winf, interp, cic, ovl, prm.fft_used, prm.plot_width, prm.plot_width_clamped,
+                                                    m, d, sc, (sc / np.float32(2)).astype(np.float32), prm.fft_offset, tables[1])
+        use_comp = comp and zoom != 0
+        want_pkt = ko.wf_packet(row, int(prm.start), prm.zoom, 4242 + k, use_comp)[16:]
+        pay = g["case%d_payload" % k]
+        if use_comp:
+            print("wf case %d: compressed payload equal: %s (%d bytes)" % (k, np.array_equal(want_pkt, pay), pay.size))
+        else:
+            dd = np.abs(row.astype(int) - pay.astype(int))
+            print("wf case %d: row differs in %d of 1024 pixels, max %d" % (k, np.count_nonzero(dd), dd.max()))
 except Exception as e:                                                          # the vectors are written either way
     print("oracle comparison skipped:", repr(e))
