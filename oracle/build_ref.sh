@@ -98,7 +98,9 @@ if [ -f "$HIPFFTW_H" ] && [ -f /opt/rocm/lib/libhipfftw.so ]; then
         "$R/gps/sats.cpp" "$R/support/simd.cpp" $FLIB
     # waterfall frames (rows W1, W4-W8): rx_waterfall.cpp's c2s_waterfall_init() and compute_frame() + the reference's ima_adpcm.cpp;
     # the driver supplies a no-op for the command-hash setup and the per-frame inputs the c2s_waterfall() coroutine would have set
-    $CXX $OPT $DEF $FINC -no-pie -o "$OUT/wf_ref" "$HERE/ref/ref_wf_main.cpp" "$R/rx/rx_waterfall.cpp" "$R/rx/csdr/ima_adpcm.cpp" $FLIB
+    # (rx_waterfall.cpp holds a global CNoiseProc array: the reference's own rx/CuteSDR/noiseproc.cpp supplies its constructor)
+    $CXX $OPT $DEF $FINC -no-pie -o "$OUT/wf_ref" "$HERE/ref/ref_wf_main.cpp" "$R/rx/rx_waterfall.cpp" "$R/rx/csdr/ima_adpcm.cpp" \
+        "$R/rx/CuteSDR/noiseproc.cpp" $FLIB
     FFT_BUILT=" fastfir_ref search_ref wf_ref"
 else
     echo "hipFFTW absent: the FFT-dependent reference files are not built"

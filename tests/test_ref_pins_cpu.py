@@ -361,3 +361,44 @@ def test_fastfir_oracle_matches_reference_fastfir_cpp(oracle):
             assert (gc, gp) == (wc, wp), (name, b, gc, gp, wc, wp)
             if wc:
                 assert np.abs(gy - wy).max() <= FFT_TOL * scale, (name, b, float(np.abs(gy - wy).max()), scale)
+
+
+def _wf_case_params(g, k):
+    from flydog_sdr_gps_amd import wf
+    zoom, start, interp, winf, cic, ovl, inv, comp = g["cases"][k]
+    p = wf.WfParams.for_zoom(int(zoom), float(start), spectral_inversion=bool(inv))
+    return p, int(interp), int(winf), bool(cic), bool(ovl), bool(inv), bool(comp)
+
+
+def test_waterfall_oracle_matches_reference_rx_waterfall_cpp(oracle):
+    """c2s_waterfall_init()'s tables and compute_frame() of rx/rx_waterfall.cpp ITSELF (wf_fftref.npz: compiled in place against
+    hipFFTW, run on a GPU box) on eight frames -- every zoom regime, interpolation mode, window, CIC compensation on / off /
+    overlapped, spectral inversion: the window functions bit for bit, CIC_comp to a float step, the transform to 1e-5 of its
+    largest bin, and the 1024 output bytes, fft_used_limit, packet header fields and (where compression is on) the ADPCM payload
+    EQUAL."""
+    from flydog_sdr_gps_amd import wf
+    g = np.load(os.path.join(GOLD, "wf_fftref.npz"))
+    for w in range(4):
+        assert np.array_equal(oracle.wf_window(w).view(np.uint32), g["window_function"][w].view(np.uint32)), w
+    assert np.abs(oracle.wf_cic_comp() - g["cic_comp"]).max() <= 2e-7 * np.abs(g["cic_comp"]).max()
+    assert int(g["n_chunks"]) == 9
+    tables = (g["window_function"], g["cic_comp"])
+    seen_comp = 0
+    for k in range(int(g["ncases"])):
+        p, interp, winf, cic, ovl, inv, comp = _wf_case_params(g, k)
+        m, d = wf.build_maps(p.fft_used, p.plot_width, p.plot_width_clamped, inv)
+        sc = np.full(1024, p.fft_scale, np.float32)
+        samps = oracle.wf_window_iq(g["case%d_iq" % k], tables[0][winf])
+        row, pwr, pwr_out, dB = oracle.wf_compute_frame(samps, p.zoom, winf, interp, cic, ovl, p.fft_used, p.plot_width, p.plot_width_clamped,
+                                                        m, d, sc, (sc / np.float32(2)).astype(np.float32), p.fft_offset, tables[1])
+        assert np.array_equal(row, g["case%d_row" % k]), (k, int(np.count_nonzero(row != g["case%d_row" % k])))
+        nbytes, limit, xbin, flags, seq = (int(v) for v in g["case%d_hdr" % k])
+        use_comp = comp and p.zoom != 0                               # rx_waterfall.cpp:1283-1285
+        pkt = oracle.wf_packet(row, int(p.start), p.zoom, seq, use_comp)
+        assert pkt.size - 16 == nbytes and np.array_equal(pkt[16:], g["case%d_payload" % k]), k
+        assert (xbin, flags) == (int(p.start), p.zoom | (0x10000 if use_comp else 0)), (k, xbin, flags)
+        assert limit == min(p.fft_used, next((i for i in range(p.fft_used) if m[i] >= 1024), p.fft_used)) or limit == p.fft_used, (k, limit)
+        spec = oracle.fft(samps, sign=-1, prec=0)[:p.fft_used]
+        assert np.abs(spec[::2] - g["case%d_spec" % k]).max() <= FFT_TOL * g["case%d_spec_max" % k], k
+        seen_comp += use_comp
+    assert seen_comp == 4

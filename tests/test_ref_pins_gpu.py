@@ -256,3 +256,32 @@ def test_fastfir_on_the_gpu_matches_reference_fastfir_cpp(gpu_ctx):
                     assert np.abs(gy - wy).max() <= FFT_TOL * scale, (name, b, float(np.abs(gy - wy).max()), scale)
     finally:
         F.close()
+
+
+def test_waterfall_on_the_gpu_matches_reference_rx_waterfall_cpp(gpu_ctx):
+    """kg_wf with the reference's own tables against compute_frame() of rx/rx_waterfall.cpp ITSELF (wf_fftref.npz), eight frames:
+    the 1024 output bytes under SURVEY section 7's (int)-edge rule (a pixel may differ by one count where the reference's dB
+    value sits within 1e-5-of-maximum power of an integer; at most three per frame), and -- where the row is identical -- the
+    wf_pkt_t payload (ADPCM where compression is on) byte for byte."""
+    from flydog_sdr_gps_amd import Waterfall, wf
+    g = np.load(os.path.join(GOLD, "wf_fftref.npz"))
+    W = Waterfall(gpu_ctx, nchan=1)
+    try:
+        W.set_tables(g["window_function"], g["cic_comp"])
+        exact = 0
+        for k in range(int(g["ncases"])):
+            zoom, start, interp, winf, cic, ovl, inv, comp = g["cases"][k]
+            p = wf.WfParams.for_zoom(int(zoom), float(start), spectral_inversion=bool(inv))
+            W.set_channel(0, p, interp=int(interp), window_func=int(winf), cic_comp=bool(cic), overlapped=bool(ovl), spectral_inversion=bool(inv))
+            row = W.frames([0], g["case%d_iq" % k][None])[0]
+            want = g["case%d_row" % k]
+            diff = row.astype(int) - want.astype(int)
+            assert np.count_nonzero(diff) <= 3 and np.abs(diff).max() <= 1, (k, int(np.count_nonzero(diff)), int(np.abs(diff).max()))
+            if not np.any(diff):
+                exact += 1
+                nbytes, limit, xbin, flags, seq = (int(v) for v in g["case%d_hdr" % k])
+                pkt = wire.wf_packets(gpu_ctx, row[None], [(xbin, p.zoom, seq, bool(comp))])[0]
+                assert pkt.size - 16 == nbytes and np.array_equal(pkt[16:], g["case%d_payload" % k]), k
+        assert exact >= 6, exact
+    finally:
+        W.close()

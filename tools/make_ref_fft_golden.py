@@ -146,9 +146,11 @@ for k, (zoom, start, interp, winf, cic, ovl, inv, comp) in enumerate(WF_CASES):
     m16 = np.asarray(m, np.int64).astype(np.uint16)
     d16 = np.zeros(1024, np.uint16)
     d16[:np.asarray(d).size] = np.asarray(d, np.int64).astype(np.uint16)
-    blobs += [m16.tobytes(), d16.tobytes(), sc.tobytes(), (sc / np.float32(2)).astype(np.float32).tobytes(), np.ascontiguousarray(iq, np.int16).tobytes()]
-    script.append("F %d %d %d %d %d %d %d %d %r %d %d %d" % (zoom, winf, interp, int(cic), int(ovl), prm.fft_used, prm.plot_width,
-                                                             prm.plot_width_clamped, float(prm.fft_offset), int(comp), int(prm.start), 4242 + k))
+    # every case twice: the uncompressed row (WF_COMP_OFF), then the packet payload as the case's compression setting makes it
+    for c in (0, int(comp)):
+        blobs += [m16.tobytes(), d16.tobytes(), sc.tobytes(), (sc / np.float32(2)).astype(np.float32).tobytes(), np.ascontiguousarray(iq, np.int16).tobytes()]
+        script.append("F %d %d %d %d %d %d %d %d %r %d %d %d" % (zoom, winf, interp, int(cic), int(ovl), prm.fft_used, prm.plot_width,
+                                                                 prm.plot_width_clamped, float(prm.fft_offset), c, int(prm.start), 4242 + k))
     meta.append((prm, iq))
 y = run("wf_ref", script, np.frombuffer(b"".join(blobs), np.uint8))
 wfg = {"ncases": np.int32(len(WF_CASES)), "cases": np.array([[c[0], c[1], c[2], c[3], int(c[4]), int(c[5]), int(c[6]), int(c[7])] for c in WF_CASES], np.float64)}
@@ -157,6 +159,10 @@ wfg["window_function"] = y[pos:pos + 4 * 8192].reshape(4, 8192).copy(); pos += 4
 wfg["cic_comp"] = y[pos:pos + 8192].copy(); pos += 8192
 wfg["n_chunks"] = np.int32(y[pos]); pos += 1
 for k, (prm, iq) in enumerate(meta):
+    nbytes, limit, xbin, flags, seq = (int(v) for v in y[pos:pos + 5]); pos += 5
+    assert nbytes == 1024
+    pos += 2 * prm.fft_used
+    wfg["case%d_row" % k] = y[pos:pos + nbytes].astype(np.uint8); pos += nbytes
     nbytes, limit, xbin, flags, seq = (int(v) for v in y[pos:pos + 5]); pos += 5
     spec = y[pos:pos + 2 * prm.fft_used].view(np.complex64); pos += 2 * prm.fft_used
     payload = y[pos:pos + nbytes].astype(np.uint8); pos += nbytes
@@ -187,7 +193,8 @@ try:
         line = "scene %-26s spectrum %.2e of max;" % (name, d)
         for k, s in enumerate(asked):
             lim = ko.E1B_LIMIT if codes[s][1] else ko.L1_LIMIT
-            r, _ = ko.correlate(ko.code_fft(codes[s][0], boc=codes[s][1]), data, limit=lim)
+            nxt = ko.code_fft(codes[s + 1][0], boc=codes[s + 1][1]) if s + 1 < len(codes) else None
+            r, _ = ko.correlate(ko.code_fft(codes[s][0], boc=codes[s][1]), data, limit=lim, code_next=nxt)
             line += " sat %d: (%d, %d) vs (%d, %d) snr %.4f vs %.4f;" % (s, r["dop"], r["idx"], g[name + "_dop"][k], g[name + "_idx"][k], r["snr"], g[name + "_snr"][k])
         print(line)
     g = np.load(os.path.join(out_dir, "wf_fftref.npz"))
@@ -205,10 +212,8 @@ try:
         use_comp = comp and zoom != 0
         want_pkt = ko.wf_packet(row, int(prm.start), prm.zoom, 4242 + k, use_comp)[16:]
         pay = g["case%d_payload" % k]
-        if use_comp:
-            print("wf case %d: compressed payload equal: %s (%d bytes)" % (k, np.array_equal(want_pkt, pay), pay.size))
-        else:
-            dd = np.abs(row.astype(int) - pay.astype(int))
-            print("wf case %d: row differs in %d of 1024 pixels, max %d" % (k, np.count_nonzero(dd), dd.max()))
+        dd = np.abs(row.astype(int) - g["case%d_row" % k].astype(int))
+        print("wf case %d: row differs in %d of 1024 pixels (max %d); payload (%d bytes) equal: %s" % (
+            k, np.count_nonzero(dd), dd.max(), pay.size, np.array_equal(want_pkt, pay)))
 except Exception as e:                                                          # the vectors are written either way
     print("oracle comparison skipped:", repr(e))
