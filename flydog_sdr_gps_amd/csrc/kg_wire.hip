@@ -297,10 +297,13 @@ int kg_wf_packets_dev(kg_ctx *ctx, const void *d_rows, size_t row_stride, int nr
     std::vector<wf_pkt_dev_info> h(nrows);
     for (int i = 0; i < nrows; i++) {
         h[i].x_bin_server = info[i].x_bin_server;
-        h[i].flags_x_zoom_server = info[i].zoom | (info[i].use_compression ? 0x00010000u : 0u);   // WF_FLAGS_COMPRESSION
+        // "don't use compression for zoom level zero because of bad interaction of narrow strong carriers with compression
+        // algorithm" (rx_waterfall.cpp:1283-1285): use_compression = wf->compression && wf->zoom != 0
+        const bool comp = info[i].use_compression != 0 && info[i].zoom != 0;
+        h[i].flags_x_zoom_server = info[i].zoom | (comp ? 0x00010000u : 0u);   // WF_FLAGS_COMPRESSION
         h[i].seq = info[i].seq;
-        h[i].use_compression = info[i].use_compression != 0;
-        pkt_bytes[i] = KG_WF_PKT_HDR + (info[i].use_compression ? (KG_WF_ADPCM_PAD + 1024) / 2 : 1024);
+        h[i].use_compression = comp;
+        pkt_bytes[i] = KG_WF_PKT_HDR + (comp ? (KG_WF_ADPCM_PAD + 1024) / 2 : 1024);
     }
     void *d_info = nullptr;
     if ((rc = kg_ctx_stage(ctx, h.data(), sizeof(wf_pkt_dev_info) * nrows, &d_info))) return rc;

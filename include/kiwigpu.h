@@ -549,7 +549,7 @@ typedef struct {
     uint32_t x_bin_server;          /* wf->start or wf->prev_start (rx_waterfall.cpp:1603-1616) */
     uint32_t zoom;                  /* wf->zoom or wf->prev_zoom; WF_FLAGS_COMPRESSION is added here */
     uint32_t seq;                   /* wf->snd_seq (:1635) */
-    int32_t use_compression;
+    int32_t use_compression;        /* wf->compression, the connection's setting; a row at zoom 0 is never compressed (:1283-1285) */
 } kg_wf_pkt_info;
 /* wf_pkt_t for nrows waterfall rows (1024 u8 each, row_stride bytes apart, as
  * kg_wf_frames_dev leaves them): header + either the row or, compressed, the 10 pad bytes

@@ -113,6 +113,7 @@ static void put_le32(uint8_t *p, uint32_t v) { p[0] = v; p[1] = v >> 8; p[2] = v
 int ko_wf_packet(const uint8_t *row, uint32_t x_bin_server, uint32_t zoom, uint32_t seq, int use_compression,
                  uint8_t *pkt)
 {
+    use_compression = use_compression && zoom != 0;           /* :1283-1285: wf->compression && wf->zoom != 0 */
     memcpy(pkt, "W/F ", 4);                                   /* :284 */
     put_le32(pkt + 4, x_bin_server);                          /* :1615 */
     uint32_t fz = zoom;                                       /* :1616 */

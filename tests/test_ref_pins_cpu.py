@@ -394,7 +394,7 @@ def test_waterfall_oracle_matches_reference_rx_waterfall_cpp(oracle):
         assert np.array_equal(row, g["case%d_row" % k]), (k, int(np.count_nonzero(row != g["case%d_row" % k])))
         nbytes, limit, xbin, flags, seq = (int(v) for v in g["case%d_hdr" % k])
         use_comp = comp and p.zoom != 0                               # rx_waterfall.cpp:1283-1285
-        pkt = oracle.wf_packet(row, int(p.start), p.zoom, seq, use_comp)
+        pkt = oracle.wf_packet(row, int(p.start), p.zoom, seq, comp)          # the connection's setting: the zoom rule is inside
         assert pkt.size - 16 == nbytes and np.array_equal(pkt[16:], g["case%d_payload" % k]), k
         assert (xbin, flags) == (int(p.start), p.zoom | (0x10000 if use_comp else 0)), (k, xbin, flags)
         assert limit == min(p.fft_used, next((i for i in range(p.fft_used) if m[i] >= 1024), p.fft_used)) or limit == p.fft_used, (k, limit)
