@@ -93,10 +93,11 @@ def test_waterfall_packets_bit_exact(gpu_ctx, oracle):
     pk = wire.wf_packets(gpu_ctx, rows, infos)
     for r, (info, p) in enumerate(zip(infos, pk)):
         want = oracle.wf_packet(rows[r], *info)
-        assert p.size == want.size == 16 + (517 if info[3] else 1024)
+        comp = bool(info[3]) and info[1] != 0            # rx_waterfall.cpp:1283-1285: a row at zoom 0 is never compressed (z = 0 is in the list)
+        assert p.size == want.size == 16 + (517 if comp else 1024)
         assert np.array_equal(p, want), r
-        assert bytes(p[:4]) == b"W/F " and int.from_bytes(bytes(p[8:12]), "little") == info[1] | (0x10000 if info[3] else 0)
-        if info[3]:                                                     # the client's decoder gets the row back, roughly
+        assert bytes(p[:4]) == b"W/F " and int.from_bytes(bytes(p[8:12]), "little") == info[1] | (0x10000 if comp else 0)
+        if comp:                                                        # the client's decoder gets the row back, roughly
             dec, _ = oracle.adpcm_decode_u8(p[16:])
             assert dec.size == 1034
 
