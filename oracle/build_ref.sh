@@ -18,11 +18,14 @@
 #        cic_gen_ref   verilog/rx/cic_gen.c              (Hogenauer pruning generator; its .vh
 #                                                         output for every CIC instance -> _ref/cic/)
 #
-# NOT built, and why (no stand-ins are written for missing headers or libraries):
-#   gps/search.cpp, rx/rx_waterfall.cpp, rx/CuteSDR/fastfir.cpp, support/simd.cpp  need <fftw3.h>
-#     (FFTW3f is un-vendored and absent from this image);
-#   gps/channel.cpp (CHANNEL::Start), rx/rx_sound.cpp, rx/data_pump.cpp  do not link without the
-#     SPI / task / timer runtime (spi_set, timer_us, TaskSleepMsec, ...).
+#   3. (round 6) the FFT-dependent files, against the FFTW3 API the image ships (hipFFTW) -- built here, run on the GPU box:
+#        fastfir_ref   rx/CuteSDR/fastfir.cpp + support/simd.cpp                (CFastFIR)
+#        search_ref    gps/search.cpp (included by the driver: its functions are static) + sats.cpp + simd.cpp
+#                                                                                (SearchInit, Sample, Correlate, decimators)
+#        wf_ref        rx/rx_waterfall.cpp + ima_adpcm.cpp + CuteSDR/noiseproc.cpp (c2s_waterfall_init, compute_frame)
+#
+# NOT built, and why: gps/channel.cpp (CHANNEL::Start), rx/rx_sound.cpp (c2s_sound's inline S-meter / detector loops),
+#   rx/data_pump.cpp (snd_service) -- bodies of server coroutines with no function of their own to call.
 set -e
 REFERENCE=${REFERENCE:-/root/reference}
 HERE=$(cd "$(dirname "$0")" && pwd)

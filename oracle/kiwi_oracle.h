@@ -16,14 +16,16 @@
  *     against the IS-GPS-200 first-10-chip known answers.
  *   - E1B memory-code unpack (ko_e1b_from_hex): PINNED against the reference's
  *     known answers at gps/search.cpp:295,302 (E01 0xf5d71, E02 0x96b85).
- *   - Everything that goes through an FFT (code tables, Sample, Correlate,
- *     waterfall, CFastFIR): PARITY UNPINNED.  The reference computes these with
- *     FFTW3f, an un-vendored, un-pinned apt dependency (Makefile:365-366) that
- *     is absent from this image, and its sources need the generated kiwi.gen.h;
- *     the reference's path is therefore unbuildable here and the reference
- *     holds no golden vectors for it.  The oracle FFT is
- *     a double-precision radix-2 rounded to fp32 on store, cross-checked
- *     against numpy.fft in tests/test_oracle.py.
+ *   - Everything that goes through an FFT (SearchInit code tables, Sample, the decimators, Correlate; the waterfall's
+ *     tables and compute_frame; CFastFIR): PINNED since round 6 by the reference's own gps/search.cpp, rx/rx_waterfall.cpp and
+ *     rx/CuteSDR/fastfir.cpp, compiled in place (oracle/build_ref.sh) against the FFTW3 API the image ships -- hipFFTW, in
+ *     the seat libfftw3f has in the reference's own build (Makefile:365-366) -- and run on the GPU box
+ *     (tools/make_ref_fft_golden.py -> tests/golden/acq_fftref.npz, wf_fftref.npz, fastfir_fftref.npz;
+ *     tests/test_ref_pins_cpu.py).  hipFFTW's transform is not FFTW's: spectra are held to 1e-5 of their largest bin (achieved
+ *     2e-7), every index / count / byte to equality.  The oracle FFT is a double-precision radix-2 rounded to fp32 on store.
+ *   - CAgc, IMA ADPCM, CFir, CSquelch, the CIC shapes, constants: PINNED by the reference's sources built in place.
+ *   - Restatement only: the data-pump unpack, the S-meter / AM / NBFM loops of c2s_sound(), CHANNEL::Start, the c2s_waterfall()
+ *     parameter formulas; the DDC (FPGA fabric, closed DDS core).
  */
 #ifndef KIWI_ORACLE_H
 #define KIWI_ORACLE_H

@@ -2,8 +2,8 @@
  * kiwi_oracle_snd.c -- CPU ORACLE (test infrastructure, NOT product code).
  * Part 4: audio front -- rx/data_pump.cpp snd_service() unpack and
  * rx/CuteSDR/fastfir.cpp CFastFIR.  See kiwi_oracle.h.
- * The unpack is integer/float-exact restatement; CFastFIR goes through the FFT
- * and is therefore PARITY UNPINNED (FFTW3f absent).
+ * The unpack is an integer/float-exact restatement (snd_service() does not link without the SPI runtime); CFastFIR is PINNED
+ * by rx/CuteSDR/fastfir.cpp itself, built in place against hipFFTW and run on the GPU box (tests/golden/fastfir_fftref.npz).
  * TYPEREAL is float and MSIN/MCOS/MPOW are sinf/cosf/powf (datatypes.h:69-82).
  */
 #include "kiwi_oracle.h"

@@ -1,8 +1,9 @@
 /*
  * kiwi_oracle_wf.c -- CPU ORACLE (test infrastructure, NOT product code).
  * Part 2: waterfall (rx/rx_waterfall.cpp).  See kiwi_oracle.h.
- * PARITY UNPINNED for everything downstream of the FFT (FFTW3f absent, the
- * reference holds no vectors for this path).
+ * c2s_waterfall_init()'s tables and compute_frame() are PINNED by rx/rx_waterfall.cpp itself, built in place against hipFFTW and
+ * run on the GPU box (tests/golden/wf_fftref.npz: every output byte and ADPCM payload of eight frames equal); the zoom / start
+ * parameter formulas and the map construction sit inside the c2s_waterfall() coroutine and stay a restatement.
  */
 #include "kiwi_oracle.h"
 

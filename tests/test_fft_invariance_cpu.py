@@ -1,9 +1,10 @@
 """The reference's INTEGER outputs on this path do not depend on which correct FFT computes them.
 
 Why this file exists: gps/search.cpp, rx/rx_waterfall.cpp and rx/CuteSDR/fastfir.cpp transform with FFTW3f
-(gps/search.cpp:240-241,447,481; rx/rx_waterfall.cpp:133,1291), which is absent from this image, so the oracle's
-FFT-dependent rows are PARITY UNPINNED and stay labelled so.  What can be bounded here is the
-risk that label carries: the same restated reference loops (oracle/kiwi_oracle*.c) are run over THREE independent
+(gps/search.cpp:240-241,447,481; rx/rx_waterfall.cpp:133,1291), which is absent from this image.  (Round 6 pins those rows
+with the reference's own files built against hipFFTW, the FFTW3 API the image does ship: DESIGN.md section 3.  hipFFTW is one
+more transform that is not FFTW3f's, which is what this file is about.)  What can be bounded here is the risk a transform's
+identity carries: the same restated reference loops (oracle/kiwi_oracle*.c) are run over THREE independent
 transforms --
 
     prec=1  the oracle's double-precision radix-2, rounded to fp32 on store,

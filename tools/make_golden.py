@@ -3,10 +3,10 @@
   acq_golden.npz  acquisition cases: packed 1-bit IF input + the CPU oracle's
                   (snr, dop, idx, valid) and per-Doppler peak indices.
 
-The reference holds no golden vectors for this path and its FFT-dependent code is
-unbuildable here, so the expected values come from the oracle
-(oracle/kiwi_oracle.c, prec=1) -- they pin the oracle against regressions and
-travel to the GPU box; they are not reference outputs.
+The expected values here come from the oracle (oracle/kiwi_oracle.c, prec=1): they pin the oracle against regressions
+and travel to the GPU box; they are not reference outputs.  (What the reference itself computed -- its gps/search.cpp,
+rx/rx_waterfall.cpp, rx/CuteSDR/fastfir.cpp built in place against hipFFTW -- is tests/golden/*_fftref.npz,
+tools/make_ref_fft_golden.py; the reference holds no golden vectors of its own for this path.)
 """
 import os
 import sys
