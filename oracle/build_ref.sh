@@ -23,9 +23,10 @@
 #        search_ref    gps/search.cpp (included by the driver: its functions are static) + sats.cpp + simd.cpp
 #                                                                                (SearchInit, Sample, Correlate, decimators)
 #        wf_ref        rx/rx_waterfall.cpp + ima_adpcm.cpp + CuteSDR/noiseproc.cpp (c2s_waterfall_init, compute_frame)
+#        dpump_ref     rx/data_pump.cpp (included by the driver)                  (snd_service: runs here, no transform)
 #
 # NOT built, and why: gps/channel.cpp (CHANNEL::Start), rx/rx_sound.cpp (c2s_sound's inline S-meter / detector loops),
-#   rx/data_pump.cpp (snd_service) -- bodies of server coroutines with no function of their own to call.
+#   -- bodies of server coroutines with no function of their own to call.
 set -e
 REFERENCE=${REFERENCE:-/root/reference}
 HERE=$(cd "$(dirname "$0")" && pwd)
@@ -104,7 +105,10 @@ if [ -f "$HIPFFTW_H" ] && [ -f /opt/rocm/lib/libhipfftw.so ]; then
     # (rx_waterfall.cpp holds a global CNoiseProc array: the reference's own rx/CuteSDR/noiseproc.cpp supplies its constructor)
     $CXX $OPT $DEF $FINC -no-pie -o "$OUT/wf_ref" "$HERE/ref/ref_wf_main.cpp" "$R/rx/rx_waterfall.cpp" "$R/rx/csdr/ima_adpcm.cpp" \
         "$R/rx/CuteSDR/noiseproc.cpp" $FLIB
-    FFT_BUILT=" fastfir_ref search_ref wf_ref"
+    # the data pump's unpack (rows A1, A2): no FFT is called, but data_pump.cpp's headers need the FFTW3 API header; the driver TU
+    # includes rx/data_pump.cpp itself (snd_service() is static) and defines the SPI / scheduler entry points it calls.  Runs HERE.
+    $CXX $OPT $DEF $FINC -no-pie -DREF_DATA_PUMP_CPP="\"$R/rx/data_pump.cpp\"" -o "$OUT/dpump_ref" "$HERE/ref/ref_dpump_main.cpp" -lm $UNRES
+    FFT_BUILT=" fastfir_ref search_ref wf_ref dpump_ref"
 else
     echo "hipFFTW absent: the FFT-dependent reference files are not built"
     FFT_BUILT=""

@@ -124,3 +124,29 @@ def oracle_row(oracle, searcher, sat):
 
 def oracle_next_rows(oracle, searcher, svs):
     return [oracle_row(oracle, searcher, int(s) + 1) for s in svs]
+
+
+def dpump_ref_cases(g):
+    """tests/golden/dpump_ref.npz -> [(name, nch, ns, inversion, dc_i, dc_q, enabled list, bufs uint8[nbuf, bytes], rescale,
+    [per buffer: {ch: (wr_pos after, ticks48, complex64[ns])}])] as the reference's own snd_service() produced them."""
+    import numpy as np
+    out = []
+    for name in (str(n) for n in g["names"]):
+        nch, ns, inv, dci, dcq, mask, nbuf = g[name + "_cfg"]
+        nch, ns, inv, mask, nbuf = int(nch), int(ns), int(inv), int(mask), int(nbuf)
+        en = [(mask >> ch) & 1 for ch in range(nch)]
+        y, k = g[name + "_out"], 1
+        per = []
+        for b in range(nbuf):
+            d = {}
+            for ch in range(nch):
+                if not en[ch]:
+                    continue
+                wr, hi, lo = (int(v) for v in y[k:k + 3])
+                k += 3
+                d[ch] = (wr, (hi << 24) | lo, y[k:k + 2 * ns].view(np.complex64))
+                k += 2 * ns
+            per.append(d)
+        assert k == y.size
+        out.append((name, nch, ns, bool(inv), float(dci), float(dcq), en, g[name + "_bufs"], float(y[0]), per))
+    return out

@@ -402,3 +402,21 @@ def test_waterfall_oracle_matches_reference_rx_waterfall_cpp(oracle):
         assert np.abs(spec[::2] - g["case%d_spec" % k]).max() <= FFT_TOL * g["case%d_spec_max" % k], k
         seen_comp += use_comp
     assert seen_comp == 4
+
+
+def test_dpump_oracle_matches_reference_data_pump_cpp(oracle):
+    """snd_service() of rx/data_pump.cpp ITSELF (the driver includes the file; dpump_ref.npz): `rescale` as its static initialiser
+    evaluates MPOW(2, -RXOUT_SCALE + CUTESDR_SCALE) * MPOW(10, CICF_GAIN_dB / 20), the 24-bit sign extension, the re / im swap and
+    its spectral-inversion variant, DC offsets, disabled channels skipped, sample-major channel-minor records for 4 / 8 / 14 / 3
+    channels: the oracle's unpack BIT-EXACT; the 32-deep ring position and the 48-bit tick assembly as the reference left them."""
+    from tests.fixtures import dpump_ref_cases
+    g = np.load(os.path.join(GOLD, "dpump_ref.npz"))
+    for name, nch, ns, inv, dci, dcq, en, bufs, rescale, per in dpump_ref_cases(g):
+        assert np.float32(rescale) == np.float32(oracle.dpump_rescale()), name
+        for b, d in enumerate(per):
+            raw = bufs[b, :6 * ns * nch]
+            want = oracle.dpump_unpack(raw, ns, nch, enabled=en, dc_i=dci, dc_q=dcq, spectral_inversion=inv)
+            t = bufs[b, 6 * ns * nch:].view("<u2")                    # rx_trailer_t: ticks[3], write_ctr_stored, write_ctr_current
+            for ch, (wr, ticks, samps) in d.items():
+                assert np.array_equal(want[ch].view(np.uint32), samps.view(np.uint32)), (name, b, ch)
+                assert wr == (b + 1) % 32 and ticks == (int(t[2]) << 32 | int(t[1]) << 16 | int(t[0])), (name, b, ch)

@@ -285,3 +285,17 @@ def test_waterfall_on_the_gpu_matches_reference_rx_waterfall_cpp(gpu_ctx):
         assert exact >= 6, exact
     finally:
         W.close()
+
+
+def test_dpump_unpack_on_the_gpu_matches_reference_data_pump_cpp(gpu_ctx):
+    """kg_dpump_unpack_dev against snd_service() of rx/data_pump.cpp ITSELF (dpump_ref.npz): BIT-EXACT for 4 / 8 / 14 / 3 channels,
+    disabled channels, spectral inversion, DC offsets, the -2^23 edge of the sign extension."""
+    from flydog_sdr_gps_amd import snd
+    from tests.fixtures import dpump_ref_cases
+    g = np.load(os.path.join(GOLD, "dpump_ref.npz"))
+    for name, nch, ns, inv, dci, dcq, en, bufs, rescale, per in dpump_ref_cases(g):
+        assert np.float32(rescale) == np.float32(snd.RESCALE), name
+        for b, d in enumerate(per[:4]):
+            got = snd.unpack(gpu_ctx, bufs[b, :6 * ns * nch], ns, nch, enabled=en, dc_i=dci, dc_q=dcq, spectral_inversion=inv)
+            for ch, (_, _, samps) in d.items():
+                assert np.array_equal(got[ch].view(np.uint32), samps.view(np.uint32)), (name, b, ch)

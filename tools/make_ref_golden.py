@@ -13,6 +13,7 @@ the outputs the reference's code produced for them.
   fir_ref.npz     CFir (rx/CuteSDR/fir.cpp): InitLPFilter / InitHPFilter / InitConstFir + the three real-valued
                   ProcessFilter paths -- the designed taps (read back through an impulse), inputs, outputs
   squelch_ref.npz CSquelch (rx/CuteSDR/squelch.cpp): SetupParameters / SetSquelch / Reset / PerformFMSquelch scripts
+  dpump_ref.npz   snd_service() (rx/data_pump.cpp): SPI buffers of rx_iq_t records + trailer -> in_samps rings, ticks, rescale
 """
 import json
 import os
@@ -278,3 +279,28 @@ with tempfile.TemporaryDirectory() as tmp:
         print("squelch_ref.npz: %-24s %5d floats in, %5d floats out" % (name, x.size, y.size))
 sq["names"] = np.array([s[0] for s in sq_scen])
 np.savez_compressed(os.path.join(GOLD, "squelch_ref.npz"), **sq)
+
+# ---- data pump unpack -----------------------------------------------------------------------------
+rng = np.random.Generator(np.random.PCG64(0x5EED00D9))
+dp_scen = [
+    # name, rx_chans, nrx_samps ((2047 - 5) / 3 / rx_chans, config.h:40), inversion, dc_i, dc_q, enabled mask, buffers
+    ("rx4_170", 4, 170, 0, 0.0, 0.0, 0b1111, 3),
+    ("rx8_85_some_disabled", 8, 85, 0, 0.0, 0.0, 0b10110101, 2),
+    ("rx14_48", 14, 48, 0, 0.0, 0.0, (1 << 14) - 1, 2),
+    ("rx3_226_inverted_dc", 3, 226, 1, 12.5, -7.25, 0b111, 34),          # spectral inversion, DC offsets, the 32-deep ring wraps
+]
+dp = {"names": np.array([s[0] for s in dp_scen])}
+with tempfile.TemporaryDirectory() as tmp:
+    for name, nch, ns, inv, dci, dcq, mask, nbuf in dp_scen:
+        bufs = rng.integers(0, 256, (nbuf, ns * nch * 6 + 10), dtype=np.uint8)
+        bufs[0, :6 * nch] = np.tile(np.array([0x00, 0x00, 0x00, 0x80, 0x00, 0x80], np.uint8), nch)   # i = q = -2^23: the sign extension's edge
+        script = ["G %d %d %d %r %r %d" % (nch, ns, inv, dci, dcq, mask), "R"] + ["S"] * nbuf
+        open(os.path.join(tmp, "s.txt"), "w").write("\n".join(script) + "\n")
+        bufs.tofile(os.path.join(tmp, "in.bin"))
+        run([os.path.join(REF, "dpump_ref"), os.path.join(tmp, "s.txt"), os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")])
+        y = np.fromfile(os.path.join(tmp, "out.bin"), np.float32)
+        dp[name + "_cfg"] = np.array([nch, ns, inv, dci, dcq, mask, nbuf], np.float64)
+        dp[name + "_bufs"] = bufs
+        dp[name + "_out"] = y
+        print("dpump_ref.npz: %-24s %d buffers of %d bytes, %d floats out, rescale %.9g" % (name, nbuf, bufs.shape[1], y.size, y[0]))
+np.savez_compressed(os.path.join(GOLD, "dpump_ref.npz"), **dp)
