@@ -24,8 +24,9 @@
 #                                                                                (SearchInit, Sample, Correlate, decimators)
 #        wf_ref        rx/rx_waterfall.cpp + ima_adpcm.cpp + CuteSDR/noiseproc.cpp (c2s_waterfall_init, compute_frame)
 #        dpump_ref     rx/data_pump.cpp (included by the driver)                  (snd_service: runs here, no transform)
+#        chan_ref      gps/channel.cpp + ephemeris.cpp + sats.cpp                  (CHANNEL::Start: runs here)
 #
-# NOT built, and why: gps/channel.cpp (CHANNEL::Start), rx/rx_sound.cpp (c2s_sound's inline S-meter / detector loops),
+# NOT built, and why: rx/rx_sound.cpp (c2s_sound's inline S-meter / detector loops), the c2s_waterfall() parameter formulas
 #   -- bodies of server coroutines with no function of their own to call.
 set -e
 REFERENCE=${REFERENCE:-/root/reference}
@@ -108,7 +109,12 @@ if [ -f "$HIPFFTW_H" ] && [ -f /opt/rocm/lib/libhipfftw.so ]; then
     # the data pump's unpack (rows A1, A2): no FFT is called, but data_pump.cpp's headers need the FFTW3 API header; the driver TU
     # includes rx/data_pump.cpp itself (snd_service() is static) and defines the SPI / scheduler entry points it calls.  Runs HERE.
     $CXX $OPT $DEF $FINC -no-pie -DREF_DATA_PUMP_CPP="\"$R/rx/data_pump.cpp\"" -o "$OUT/dpump_ref" "$HERE/ref/ref_dpump_main.cpp" -lm $UNRES
-    FFT_BUILT=" fastfir_ref search_ref wf_ref dpump_ref"
+    # the hand-off (8(f) rank 3): CHANNEL::Start of gps/channel.cpp + ephemeris.cpp + sats.cpp; its results are the SPI commands
+    # it sends, which the driver's _spi_set records.  Runs HERE.
+    GPSD=$(for d in $(find "$R/gps" -type d); do printf -- "-I%s " "$d"; done)
+    $CXX $OPT $DEF $GPSD $FINC -no-pie -o "$OUT/chan_ref" "$HERE/ref/ref_chan_main.cpp" "$R/gps/channel.cpp" "$R/gps/ephemeris.cpp" \
+        "$R/gps/sats.cpp" -lm $UNRES
+    FFT_BUILT=" fastfir_ref search_ref wf_ref dpump_ref chan_ref"
 else
     echo "hipFFTW absent: the FFT-dependent reference files are not built"
     FFT_BUILT=""

@@ -420,3 +420,30 @@ def test_dpump_oracle_matches_reference_data_pump_cpp(oracle):
             for ch, (wr, ticks, samps) in d.items():
                 assert np.array_equal(want[ch].view(np.uint32), samps.view(np.uint32)), (name, b, ch)
                 assert wr == (b + 1) % 32 and ticks == (int(t[2]) << 32 | int(t[1]) << 16 | int(t[0])), (name, b, ch)
+
+
+def chan_ref_expect(g):
+    """chan_ref.npz -> [(is_e1b, lo_shift, ca_shift, secs, lo_rate, ca_rate, ca_pause)] from the SPI commands CHANNEL::Start sent:
+    CmdSetRateLO (ch, lo_rate), CmdSetRateCG (ch, ca_rate), CmdPause (ch, ca_pause - 1) when ca_pause != 0, CmdSetMask."""
+    c = json.load(open(os.path.join(GOLD, "consts_ref.json")))
+    out, k = [], 0
+    for call, n in zip(g["calls"], g["ncmds"]):
+        ch, sat, t_sample, now, lo_shift, ca_shift, snr = (int(v) for v in call)
+        cmds = g["cmds"][k:k + n]
+        k += n
+        secs = ((now - t_sample) & 0xffffffff) / 1e6                # (timer_us() - t_sample) / 1e6 in u4_t arithmetic, channel.cpp:293
+        assert n in (3, 4) and cmds[0][0] != cmds[1][0]
+        pause = int(cmds[2][2]) + 1 if n == 4 else 0
+        out.append((sat >= 36, lo_shift, ca_shift, secs, int(cmds[0][2]), int(cmds[1][2]), pause))
+    return out
+
+
+def test_chan_start_oracle_matches_reference_channel_cpp(oracle):
+    """CHANNEL::Start of gps/channel.cpp ITSELF (chan_ref.npz: 205 calls over every Doppler bin, code phases of both code periods,
+    delays from 0 to a minute): the NCO rates and the code-generator pause it sent over SPI, equal."""
+    g = np.load(os.path.join(GOLD, "chan_ref.npz"))
+    exp = chan_ref_expect(g)
+    assert len(exp) == 205 and sum(e[0] for e in exp) > 50
+    for is_e1b, lo_shift, ca_shift, secs, lo_rate, ca_rate, pause in exp:
+        o = oracle.chan_start(is_e1b, lo_shift, ca_shift, secs)
+        assert (o.lo_rate, o.ca_rate, o.ca_pause) == (lo_rate, ca_rate, pause), (is_e1b, lo_shift, ca_shift, secs)

@@ -299,3 +299,14 @@ def test_dpump_unpack_on_the_gpu_matches_reference_data_pump_cpp(gpu_ctx):
             got = snd.unpack(gpu_ctx, bufs[b, :6 * ns * nch], ns, nch, enabled=en, dc_i=dci, dc_q=dcq, spectral_inversion=inv)
             for ch, (_, _, samps) in d.items():
                 assert np.array_equal(got[ch].view(np.uint32), samps.view(np.uint32)), (name, b, ch)
+
+
+def test_chan_start_matches_reference_channel_cpp():
+    """kg_acq_chan_start (host arithmetic of the library) against the SPI commands CHANNEL::Start of gps/channel.cpp ITSELF sent
+    (chan_ref.npz, 205 calls): lo_rate, ca_rate, ca_pause equal."""
+    from flydog_sdr_gps_amd import handoff
+    from tests.test_ref_pins_cpu import chan_ref_expect
+    g = np.load(os.path.join(GOLD, "chan_ref.npz"))
+    for is_e1b, lo_shift, ca_shift, secs, lo_rate, ca_rate, pause in chan_ref_expect(g):
+        o = handoff.chan_start(is_e1b, lo_shift, ca_shift, secs)
+        assert (o.lo_rate, o.ca_rate, o.ca_pause) == (lo_rate, ca_rate, pause), (is_e1b, lo_shift, ca_shift, secs)

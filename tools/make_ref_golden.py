@@ -14,6 +14,7 @@ the outputs the reference's code produced for them.
                   ProcessFilter paths -- the designed taps (read back through an impulse), inputs, outputs
   squelch_ref.npz CSquelch (rx/CuteSDR/squelch.cpp): SetupParameters / SetSquelch / Reset / PerformFMSquelch scripts
   dpump_ref.npz   snd_service() (rx/data_pump.cpp): SPI buffers of rx_iq_t records + trailer -> in_samps rings, ticks, rescale
+  chan_ref.npz    CHANNEL::Start (gps/channel.cpp): acquisition results -> the SPI commands that program a tracking channel
 """
 import json
 import os
@@ -304,3 +305,27 @@ with tempfile.TemporaryDirectory() as tmp:
         dp[name + "_out"] = y
         print("dpump_ref.npz: %-24s %d buffers of %d bytes, %d floats out, rescale %.9g" % (name, nbuf, bufs.shape[1], y.size, y[0]))
 np.savez_compressed(os.path.join(GOLD, "dpump_ref.npz"), **dp)
+
+# ---- CHANNEL::Start ---------------------------------------------------------------------------------
+rng = np.random.Generator(np.random.PCG64(0x5EED00C5))
+calls = [(0, 0, 1000, 501000, 6, 4808, 55)]                       # BASELINE configs[0]'s result, half a second after the samples
+for k in range(200):
+    e1b = k % 3 == 2
+    sat = int(rng.integers(36, 59)) if e1b else int(rng.integers(0, 36))
+    t0 = int(rng.integers(0, 1 << 30))
+    dt = int(rng.choice([0, 1, 999, 20000, 500000, 3000000, 60000000]) + rng.integers(0, 1000))
+    calls.append((int(rng.integers(0, 12)), sat, t0, (t0 + dt) & 0xffffffff, int(rng.integers(-20, 21)),
+                  4 * int(rng.integers(0, 16368 if e1b else 4092)), int(rng.integers(16, 200))))
+calls += [(1, 5, 0, 0, 0, 0, 20), (2, 40, 0, 0, 0, 0, 20), (3, 7, 0, 1000000, 20, 16364, 30), (4, 50, 0, 1000000, -20, 65468, 30)]
+with tempfile.TemporaryDirectory() as tmp:
+    open(os.path.join(tmp, "s.txt"), "w").write("".join("S %d %d %d %d %d %d %d\n" % c for c in calls))
+    run([os.path.join(REF, "chan_ref"), os.path.join(tmp, "s.txt"), os.path.join(tmp, "out.bin")])
+    y = np.fromfile(os.path.join(tmp, "out.bin"), np.float64)
+cmds, k = [], 0
+for c in calls:
+    n = int(y[k]); k += 1
+    cmds.append(y[k:k + 3 * n].reshape(n, 3).astype(np.int64)); k += 3 * n
+assert k == y.size
+np.savez_compressed(os.path.join(GOLD, "chan_ref.npz"), calls=np.array(calls, np.int64), ncmds=np.array([c.shape[0] for c in cmds], np.int32),
+                    cmds=np.concatenate(cmds))
+print("chan_ref.npz: %d ChanStart calls, %d SPI commands; first: %s" % (len(calls), sum(c.shape[0] for c in cmds), cmds[0].tolist()))
