@@ -41,7 +41,7 @@ table = ("| Config | CPU T₁ (Msamples/s) | CPU T_all (Msamples/s) | 1 GPU | 2 
          "|---|---|---|---|---|---|---|---|---|---|\n" + "\n".join(rows))
 src = open("BASELINE.md").read()
 start = src.index("Results table")
-out = src[:start] + ("Results table, filled from the default `python bench.py` line of round 5 (`%s`; one MI355X; CPU legs: the oracle port\n"
+out = src[:start] + ("Results table, filled from the default `python bench.py` line of round 6 (`%s`; one MI355X; CPU legs: the oracle port\n"
                      "and, where the work goes through an FFT, scipy.fft / pocketfft, on the GPU box's host cores in the same run):\n\n" % sys.argv[1]
                      ) + table + "\n" + NOTES if (NOTES := """
 Notes recorded beside the configs:
