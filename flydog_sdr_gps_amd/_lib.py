@@ -177,6 +177,9 @@ SYMBOLS = {
     "kg_rxbank_set_unpack": (_i, [_vp, C.c_float, C.c_float, C.c_float, _i]),
     "kg_rxbank_step": (_i, [_vp, _vp, _vp, _vp]),
     "kg_rxbank_adc_done": (_i, [_vp, _vp, _i]),
+    "kg_snd_iq_payload_dev": (_i, [_vp, _vp, _i, _vp, _sz, _i, _i, _vp, _sz]),
+    "kg_rxbank_set_little_endian": (_i, [_vp, _i, _i]),
+    "kg_post_get_mode": (_i, [_vp, _i]),
     "kg_rxbank_poll": (_i, [_vp]),
     "kg_rxbank_ready": (_i, [_vp]),
     "kg_rxbank_join": (_i, [_vp, _i]),

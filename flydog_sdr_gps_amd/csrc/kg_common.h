@@ -36,7 +36,7 @@ void kg_set_error(const char *fmt, ...);
 // REPLAY pass -- the same calls with the same arguments, after the block's one upload was enqueued -- they answer the same
 // addresses again, checking that the table is the one planned.
 enum { KG_ARENA_OFF = 0, KG_ARENA_PLAN = 1, KG_ARENA_REPLAY = 2 };
-#define KG_ARENA_MAX_ENTRIES 128     /* <= 12 tables per step + 2 per sound block of the step (kg_rxbank_create checks its step against it) */
+#define KG_ARENA_MAX_ENTRIES 192     /* <= 12 tables per step + 4 per sound block of the step (kg_rxbank_create checks its step against it) */
 struct kg_arena {
     int mode;
     unsigned char *h_base, *d_base;           // the current slot of the owner's ring (pinned host / device)

@@ -672,6 +672,13 @@ int kg_post_set_mode(kg_post *p, int ch, int mode)
     return KG_OK;
 }
 
+int kg_post_get_mode(kg_post *p, int ch)
+{
+    int rc = post_check(p, ch, "kg_post_get_mode");
+    if (rc) return rc;
+    return p->h_chan[ch].mode;
+}
+
 int kg_post_reset(kg_post *p, int ch)
 {
     int rc = post_check(p, ch, "kg_post_reset");

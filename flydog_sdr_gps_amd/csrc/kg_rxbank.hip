@@ -57,6 +57,9 @@ struct kg_rxbank {
     unsigned char *d_raw; size_t nrec_max;      // [nrx][nrec_max] rx_iq_t (6 bytes)
     float2 *d_xin, *d_firo; size_t firo_stride; // [nrx][nrec_max], [nrx][firo_stride]
     short *d_s16; unsigned char *d_pay;         // [nrx][firo_stride], [nrx][firo_stride / 2]
+    float2 *d_agc; unsigned char *d_iqpay;      // [nrx][firo_stride] the AGC's complex output, [nrx][4 firo_stride] the IQ mode's payload
+    std::vector<char> little_endian;            // per receiver: s->little_endian
+    std::vector<int32_t> real_list, iq_le_list, iq_be_list;
     // step tables: BANK_SLOTS pinned host / device slots
     kg_arena arena; unsigned char *h_slots, *d_slots; size_t slot_bytes;
     hipEvent_t ev_end[BANK_SLOTS][3];           // behind a step's last enqueue on main / side / tail
@@ -164,12 +167,27 @@ static int bank_pass(kg_rxbank *b, const void *d_adc, bool plan)
             for (int i = 0; i < NA; i++) if (b->h_nfir[i] >= (int) (o + KG_FIR_OUT)) b->blk_list.push_back(act[i]);
             const int NB = (int) b->blk_list.size();
             if ((rc = kg_post_process_dev(b->post, b->blk_list.data(), NB, b->d_firo + o, b->firo_stride, KG_FIR_OUT, b->d_s16 + o, nullptr,
-                                          nullptr, b->firo_stride)))
+                                          b->d_agc + o, b->firo_stride)))
                 return rc;
             tk.lap(b, PF_POST, pf);
-            if ((rc = kg_adpcm_encode_dev(b->adpcm, b->blk_list.data(), NB, b->d_s16 + o, b->firo_stride, KG_FIR_OUT, b->d_pay + o / 2,
-                                          b->firo_stride / 2)))
+            // the real modes' blocks go through the ADPCM coder, the IQ mode's out as (s2_t) pairs (rx_sound.cpp:1076-1140)
+            b->real_list.clear(); b->iq_le_list.clear(); b->iq_be_list.clear();
+            for (int i = 0; i < NB; i++) {
+                const int k = b->blk_list[i];
+                if (kg_post_get_mode(b->post, k) != KG_POST_IQ) b->real_list.push_back(k);
+                else (b->little_endian[k] ? b->iq_le_list : b->iq_be_list).push_back(k);
+            }
+            if (!b->real_list.empty() &&
+                (rc = kg_adpcm_encode_dev(b->adpcm, b->real_list.data(), (int) b->real_list.size(), b->d_s16 + o, b->firo_stride, KG_FIR_OUT,
+                                          b->d_pay + o / 2, b->firo_stride / 2)))
                 return rc;
+            for (int le = 0; le < 2; le++) {
+                std::vector<int32_t> &l = le ? b->iq_le_list : b->iq_be_list;
+                if (!l.empty() &&
+                    (rc = kg_snd_iq_payload_dev(b->c_tail, l.data(), (int) l.size(), b->d_agc + o, b->firo_stride, KG_FIR_OUT, le,
+                                                b->d_iqpay + 4 * o, 4 * b->firo_stride)))
+                    return rc;
+            }
             tk.lap(b, PF_ADPCM, pf);
         }
         if (!plan) {
@@ -281,6 +299,7 @@ void kg_rxbank_destroy(kg_rxbank *b)
     kg_ctx_destroy(b->c_tail); kg_ctx_destroy(b->c_side); kg_ctx_destroy(b->c_main);
     (void) hipFree(b->d_wfiq); (void) hipFree(b->d_rows); (void) hipFree(b->d_pkts); (void) hipFree(b->d_raw);
     (void) hipFree(b->d_xin); (void) hipFree(b->d_firo); (void) hipFree(b->d_s16); (void) hipFree(b->d_pay);
+    (void) hipFree(b->d_agc); (void) hipFree(b->d_iqpay);
     if (b->h_slots) (void) hipHostFree(b->h_slots);
     (void) hipFree(b->d_slots);
     for (int i = 0; i < BANK_SLOTS; i++) for (int j = 0; j < 3; j++) if (b->ev_end[i][j]) (void) hipEventDestroy(b->ev_end[i][j]);
@@ -380,17 +399,22 @@ int kg_rxbank_create(int device, int nrx, size_t adc_samples_per_step, int rx_mo
     BANK_HIP(hipMemset(b->d_pkts, 0, (size_t) BANK_PKT_STRIDE * nrx));
     BANK_HIP(hipMemset(b->d_s16, 0, sizeof(short) * b->firo_stride * nrx));
     BANK_HIP(hipMemset(b->d_pay, 0, b->firo_stride / 2 * nrx));
+    BANK_HIP(hipMalloc((void **) &b->d_agc, sizeof(float2) * b->firo_stride * nrx));
+    BANK_HIP(hipMalloc((void **) &b->d_iqpay, 4 * b->firo_stride * nrx));
+    BANK_HIP(hipMemset(b->d_agc, 0, sizeof(float2) * b->firo_stride * nrx));
+    BANK_HIP(hipMemset(b->d_iqpay, 0, 4 * b->firo_stride * nrx));
+    b->little_endian.assign(nrx, 0);
     {   // what a step's tables can take: <= 12 of them + a channel list for S-meter / AGC / detector and one for the coder per sound
         // block (a receiver can complete nrec_max / 512 + 1 blocks in a step) -- checked HERE, not found out by every later step
         const size_t blocks_max = b->nrec_max / KG_FIR_OUT + 1;
-        if (12 + 2 * blocks_max > KG_ARENA_MAX_ENTRIES) {
+        if (12 + 4 * blocks_max > KG_ARENA_MAX_ENTRIES) {
             kg_set_error("kg_rxbank_create: %zu ADC samples per step are up to %zu sound blocks per receiver and step; the step table holds %d "
-                         "(a step of at most %zu samples)", b->n, blocks_max, (KG_ARENA_MAX_ENTRIES - 12) / 2,
-                         (size_t) ((KG_ARENA_MAX_ENTRIES - 12) / 2 - 1) * KG_FIR_OUT * (size_t) b->decim_rx);
+                         "(a step of at most %zu samples)", b->n, blocks_max, (KG_ARENA_MAX_ENTRIES - 12) / 4,
+                         (size_t) ((KG_ARENA_MAX_ENTRIES - 12) / 4 - 1) * KG_FIR_OUT * (size_t) b->decim_rx);
             kg_rxbank_destroy(b);
             return KG_ERR_INVALID;
         }
-        b->slot_bytes = (8192 + (size_t) (384 + 8 * blocks_max) * nrx + 63) & ~(size_t) 63;
+        b->slot_bytes = (8192 + (size_t) (384 + 12 * blocks_max) * nrx + 63) & ~(size_t) 63;
     }
     BANK_HIP(hipHostMalloc((void **) &b->h_slots, b->slot_bytes * BANK_SLOTS, hipHostMallocDefault));
     BANK_HIP(hipMalloc((void **) &b->d_slots, b->slot_bytes * BANK_SLOTS));
@@ -503,6 +527,13 @@ int kg_rxbank_audio_map(kg_rxbank *b, int32_t *nrec, int32_t *nfir, int32_t *fir
         if (fir_pos) fir_pos[k] = kg_fir_pos(b->fir, k);
         if (snd_seq) snd_seq[k] = b->snd_seq[k];
     }
+    return KG_OK;
+}
+
+int kg_rxbank_set_little_endian(kg_rxbank *b, int rx, int little_endian)
+{
+    KG_REQUIRE(b && rx >= 0 && rx < b->nrx, KG_ERR_INVALID, "kg_rxbank_set_little_endian: receiver %d", rx);
+    b->little_endian[rx] = little_endian ? 1 : 0;
     return KG_OK;
 }
 
@@ -643,7 +674,7 @@ int kg_rxbank_buffers(kg_rxbank *b, kg_rxbank_bufs *out)
     out->rx_raw = b->d_raw; out->rx_stride = b->nrec_max;
     out->rx_in = b->d_xin;
     out->fir_out = b->d_firo; out->fir_stride = b->firo_stride;
-    out->s16 = b->d_s16; out->adpcm = b->d_pay;
+    out->s16 = b->d_s16; out->adpcm = b->d_pay; out->agc = b->d_agc; out->iq_pay = b->d_iqpay;
     return KG_OK;
 }
 

@@ -232,6 +232,47 @@ int kg_adpcm_encode_dev(kg_adpcm *a, const int32_t *chans, int nch, const void *
     return KG_OK;
 }
 
+// The IQ modes' payload (rx/rx_sound.cpp:1076-1096): out_samps_c -> (s2_t) re, (s2_t) im per sample, as they are (little_endian) or in
+// network order.  (s2_t) of a float: truncation; outside the int16 range the low 16 bits of the int32 conversion (kg_post.hip).
+__global__ void snd_iq_payload_kernel(const float2 *__restrict__ in, size_t in_stride, const int *__restrict__ chans, int nch, int nsamps,
+                                      int little_endian, unsigned short *__restrict__ out, size_t out_stride_words, int by_chan)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, li = blockIdx.y;
+    if (j >= nsamps || li >= nch) return;
+    const int row = (by_chan && chans) ? chans[li] : li;
+    const float2 v = in[(size_t) row * in_stride + j];
+    auto s2 = [](float f) -> unsigned short {
+        int w;
+        if (!(f > -2147483648.0f && f < 2147483648.0f)) w = (int) 0x80000000u;
+        else w = (int) f;
+        return (unsigned short) (unsigned) w;
+    };
+    unsigned short re = s2(v.x), im = s2(v.y);
+    if (!little_endian) { re = (unsigned short) ((re >> 8) | (re << 8)); im = (unsigned short) ((im >> 8) | (im << 8)); }
+    out[(size_t) row * out_stride_words + 2 * j] = re;
+    out[(size_t) row * out_stride_words + 2 * j + 1] = im;
+}
+
+int kg_snd_iq_payload_dev(kg_ctx *ctx, const int32_t *chans, int nch, const void *d_cpx, size_t in_stride, int nsamps, int little_endian,
+                          void *d_out, size_t out_stride)
+{
+    int rc = kg_ctx_use(ctx);
+    if (rc) return rc;
+    KG_REQUIRE(d_cpx && d_out && nch >= 1 && nsamps >= 1, KG_ERR_INVALID, "kg_snd_iq_payload_dev: bad argument");
+    KG_REQUIRE(in_stride >= (size_t) nsamps && out_stride >= 4 * (size_t) nsamps && (out_stride & 1) == 0 &&
+               ((uintptr_t) d_out & 1) == 0 && ((uintptr_t) d_cpx & 7) == 0, KG_ERR_INVALID,
+               "kg_snd_iq_payload_dev: strides/alignments (out_stride in bytes, >= 4 nsamps, even)");
+    KG_REQUIRE(chans || !ctx->rows_by_chan, KG_ERR_INVALID, "kg_snd_iq_payload_dev: a receiver bank's rows go by channel: pass the list");
+    void *d_list = nullptr;
+    if (chans && (rc = kg_ctx_stage(ctx, chans, sizeof(int) * (size_t) nch, &d_list))) return rc;
+    KG_PLAN_ONLY(ctx);
+    hipLaunchKernelGGL(snd_iq_payload_kernel, dim3((nsamps + 255) / 256, nch), dim3(256), 0, ctx->stream,
+                       (const float2 *) d_cpx, in_stride, (const int *) d_list, nch, nsamps, little_endian,
+                       (unsigned short *) d_out, out_stride / 2, ctx->rows_by_chan);
+    KG_HIP(hipGetLastError());
+    return KG_OK;
+}
+
 int kg_snd_payload_dev(kg_ctx *ctx, const void *d_s16, size_t in_stride, int nch, int nsamps, int little_endian,
                        void *d_out, size_t out_stride)
 {

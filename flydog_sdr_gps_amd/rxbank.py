@@ -32,7 +32,7 @@ class BufsC(C.Structure):
     _fields_ = [("wf_iq", C.c_void_p), ("wf_iq_stride", C.c_size_t), ("wf_rows", C.c_void_p),
                 ("wf_pkts", C.c_void_p), ("wf_pkt_stride", C.c_size_t), ("rx_raw", C.c_void_p), ("rx_stride", C.c_size_t),
                 ("rx_in", C.c_void_p), ("fir_out", C.c_void_p), ("fir_stride", C.c_size_t), ("s16", C.c_void_p),
-                ("adpcm", C.c_void_p)]
+                ("adpcm", C.c_void_p), ("agc", C.c_void_p), ("iq_pay", C.c_void_p)]
 
 
 ADC_CLOCK, UI_SRATE = 66.6666e6, 30.0e6
@@ -95,6 +95,7 @@ class RxBank:
         self.params = [None] * nrx
         self.overlapped = [False] * nrx
         self.rx_inc = [0] * nrx
+        self.little_endian = [False] * nrx
         self.audio = [None] * nrx                       # (mode, lo, hi, fs, de_emp, squelch) as set_audio configured it
         self.fs = ADC_CLOCK / self.rxddc.decim          # RX_DECIM (rx4 / rx8, rx14) or RX_DECIM_WIDE (rx3)
 
@@ -163,6 +164,10 @@ class RxBank:
             self.set_wf(rx, wf_setting[0], wf_setting[1])
         if phase_inc is not None:
             self.set_audio(rx, phase_inc, **audio)
+
+    def set_little_endian(self, rx, little_endian):
+        check(self.lib.kg_rxbank_set_little_endian(self.h, int(rx), int(bool(little_endian))), "kg_rxbank_set_little_endian")
+        self.little_endian[rx] = bool(little_endian)
 
     def leave(self, rx):
         check(self.lib.kg_rxbank_leave(self.h, int(rx)), "kg_rxbank_leave")
@@ -244,4 +249,8 @@ class RxBank:
             return self._rows(b.s16, b.fir_stride * 2, rows, np.int16, (b.fir_stride,))
         if what == "pay":
             return self._rows(b.adpcm, b.fir_stride // 2, rows, np.uint8, (b.fir_stride // 2,))
+        if what == "agc":
+            return self._rows(b.agc, b.fir_stride * 8, rows, np.float32, (b.fir_stride, 2))
+        if what == "iq_pay":
+            return self._rows(b.iq_pay, b.fir_stride * 4, rows, np.uint8, (b.fir_stride * 4,))
         raise KeyError(what)

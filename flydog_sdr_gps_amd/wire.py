@@ -88,6 +88,24 @@ def snd_header(ctx, flags, seq, smeter_dBm):
     return h
 
 
+def snd_iq_payload(ctx, x, little_endian):
+    """x: complex64 [nch, n] (host: out_samps_c of the IQ modes, rx_sound.cpp:1076-1096) -> uint8 [nch, 4n]"""
+    x = np.ascontiguousarray(x, np.complex64)
+    x = x.reshape(1, -1) if x.ndim == 1 else x
+    out = np.zeros((x.shape[0], 4 * x.shape[1]), np.uint8)
+    d_in, d_out = ctx.alloc(x.nbytes), ctx.alloc(out.nbytes)
+    try:
+        ctx.upload(d_in, x)
+        check(ctx.lib.kg_snd_iq_payload_dev(ctx.h, None, x.shape[0], C.c_void_p(d_in), x.shape[1], x.shape[1],
+                                            int(bool(little_endian)), C.c_void_p(d_out), 4 * x.shape[1]), "kg_snd_iq_payload_dev")
+        ctx.sync()
+        ctx.download(d_out, out)
+    finally:
+        ctx.free(d_in)
+        ctx.free(d_out)
+    return out
+
+
 def snd_payload(ctx, x, little_endian):
     """x: int16 [nch, n] (host) -> uint8 [nch, 2n]"""
     x = np.ascontiguousarray(x, np.int16)

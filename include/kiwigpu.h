@@ -437,6 +437,7 @@ int kg_post_agc_delay(kg_post *post, int chan);           /* CAgc::GetDelaySampl
 /* sMeterAlpha = 1 - expf(-1 / (frate * ATTACK_TIMECONST)) (rx_sound.cpp:248-249) */
 int kg_post_set_smeter(kg_post *post, int chan, float frate);
 int kg_post_set_mode(kg_post *post, int chan, int mode);
+int kg_post_get_mode(kg_post *post, int chan);              /* -> KG_POST_*, or < 0 */
 /* A new connection on the channel: sMeterAvg_dB = 0, z1 = 0 (rx_sound.cpp:244,250),
  * conn->last_sample = 0.  The AGC object persists across connections, as m_Agc[] does. */
 int kg_post_reset(kg_post *post, int chan);
@@ -519,6 +520,12 @@ int kg_adpcm_encode_dev(kg_adpcm *a, const int32_t *chans, int nch, const void *
  * (little_endian != 0) or byte-swapped to network order.  Enqueue only. */
 int kg_snd_payload_dev(kg_ctx *ctx, const void *d_s16, size_t in_stride, int nch, int nsamps,
                        int little_endian, void *d_out, size_t out_stride);
+/* The IQ modes' payload (rx/rx_sound.cpp:1076-1096; MODE_IQ, and SAS / QAM / DRM monitor with their own sources): row i of d_cpx
+ * (complex float: the AGC's output, d_agc of kg_post_process_dev) -> nsamps x {(s2_t) re, (s2_t) im}, 4 nsamps bytes at
+ * d_out + i*out_stride, little-endian as they are or in network order.  chans: NULL (rows 0 .. nch-1), or the channel list
+ * (a receiver bank's rows go by channel).  Enqueue only. */
+int kg_snd_iq_payload_dev(kg_ctx *ctx, const int32_t *chans, int nch, const void *d_cpx, size_t in_stride, int nsamps,
+                          int little_endian, void *d_out, size_t out_stride);
 /* The 10 header bytes of snd_pkt_real_t (rx/rx_sound.h:42-48; rx/rx_sound.cpp:252,
  * 1219-1254): "SND", flags, seq little-endian, S-meter clamped to -127 .. 3.4 dBm and sent
  * big-endian in 0.1 dB steps above -127.  Host only. */
@@ -687,6 +694,10 @@ int kg_rxbank_audio_map(kg_rxbank *bank, int32_t *nrec, int32_t *nfir, int32_t *
 /* wf_pkt_t header fields of receiver rx (x_bin_server, zoom, compression); seq is the bank's sound sequence number. */
 int kg_rxbank_set_wf_pkt(kg_rxbank *bank, int rx, uint32_t x_bin_server, uint32_t zoom, int use_compression);
 /* snd_service() unpack parameters (default: rescale of rx/data_pump.cpp:73-74, no DC offset, no inversion) */
+/* "SET little-endian" of a connection (rx/rx_sound.cpp:1076-1096): the byte order of receiver rx's IQ-mode payload (default:
+ * network order).  A receiver whose kg_post mode is KG_POST_IQ gets its sound blocks as IQ payload rows (bufs.iq_pay), the
+ * others as ADPCM rows (bufs.adpcm); the mode is read at every step. */
+int kg_rxbank_set_little_endian(kg_rxbank *bank, int rx, int little_endian);
 int kg_rxbank_set_unpack(kg_rxbank *bank, float rescale, float dc_i, float dc_q, int spectral_inversion);
 
 typedef struct {
@@ -734,7 +745,9 @@ typedef struct {
     void *rx_in;                          /* [nrx][rx_stride] TYPECPX: what CFastFIR was fed */
     void *fir_out; size_t fir_stride;     /* [nrx][fir_stride] TYPECPX */
     void *s16;                            /* [nrx][fir_stride] int16: CAgc / detector output */
-    void *adpcm;                          /* [nrx][fir_stride / 2] bytes */
+    void *adpcm;                          /* [nrx][fir_stride / 2] bytes: the real modes' ADPCM payload */
+    void *agc;                            /* [nrx][fir_stride] TYPECPX: the AGC's output (rx->agc_samples_c; every mode but SSB) */
+    void *iq_pay;                         /* [nrx][4 fir_stride] bytes: the IQ mode's payload, (s2_t) re, (s2_t) im per sample */
 } kg_rxbank_bufs;
 int kg_rxbank_buffers(kg_rxbank *bank, kg_rxbank_bufs *out);
 /* Where the host's share of the steps since the last call went, by phase (microseconds per step, text). */

@@ -303,6 +303,7 @@ float ko_squelch_ave(const ko_squelch_state *s);
 int ko_squelch_perform_fm(ko_squelch_state *s, int n, const float *in, int16_t *out);
 
 /* ---- part 7: wire formats (kiwi_oracle_wire.c) ---- */
+void ko_snd_iq_payload(const ko_cpx *in, int n, int little_endian, uint8_t *out);      /* rx_sound.cpp:1076-1096 */
 #define KO_WF_WIDTH 1024                 /* rx_waterfall.h:64 */
 #define KO_WF_ADPCM_PAD 10               /* rx_waterfall.h:83 */
 typedef struct { int index, previous; } ko_adpcm_state;      /* ima_adpcm.h: index, previousValue */

@@ -598,6 +598,14 @@ def wf_packet(row, x_bin_server, zoom, seq, use_compression):
     return pkt[:n].copy()
 
 
+def snd_iq_payload(x, little_endian):
+    """complex64[n] -> uint8[4n]: the IQ modes' sound payload (rx_sound.cpp:1076-1096)"""
+    x = np.ascontiguousarray(x, cpx)
+    out = np.zeros(4 * x.size, np.uint8)
+    lib().ko_snd_iq_payload(_p(x), C.c_int(x.size), C.c_int(int(bool(little_endian))), _p(out))
+    return out
+
+
 def snd_header(flags, seq, smeter_dBm):
     L = lib()
     L.ko_snd_header.argtypes = [C.c_uint8, C.c_uint32, C.c_float, C.c_void_p]

@@ -138,6 +138,23 @@ int ko_wf_packet(const uint8_t *row, uint32_t x_bin_server, uint32_t zoom, uint3
 
 /* The 10 header bytes of snd_pkt_real_t (rx_sound.h:42-48) as rx_sound.cpp:252, 1219-1254
  * fills them: id "SND", flags, seq little-endian, S-meter big-endian in 0.1 dB above -127 dBm. */
+/* rx/rx_sound.cpp:1076-1096: the IQ modes' payload.  (s2_t) of a TYPEREAL: truncation; out of range as x86 converts (low 16 bits
+ * of the int32 conversion), the same definition as kiwi_oracle_post.c's to_mono16. */
+void ko_snd_iq_payload(const ko_cpx *in, int n, int little_endian, uint8_t *out)
+{
+    for (int j = 0; j < n; j++) {
+        const float f[2] = {in[j].re, in[j].im};
+        for (int c = 0; c < 2; c++) {
+            int32_t w;
+            if (!(f[c] > -2147483648.0f && f[c] < 2147483648.0f)) w = (int32_t) 0x80000000u;
+            else w = (int32_t) f[c];
+            const uint16_t v = (uint16_t) (uint32_t) w;
+            if (little_endian) { *out++ = (uint8_t) v; *out++ = (uint8_t) (v >> 8); }      /* :1079-1081 */
+            else { *out++ = (uint8_t) (v >> 8); *out++ = (uint8_t) v; }                     /* :1088-1091 */
+        }
+    }
+}
+
 void ko_snd_header(uint8_t flags, uint32_t seq, float smeter_dBm, uint8_t *h)
 {
     if (smeter_dBm < -127.0) smeter_dBm = -127.0; else         /* :1223-1224 */

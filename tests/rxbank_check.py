@@ -41,6 +41,8 @@ class AudioTail:
     def block(self, agc, y):
         post, ko = self.post, self.ko
         bar = 1
+        if self.mode == post.MODE_IQ:
+            return agc.process_cpx(y), 0          # the AGC's complex output: compared as floats, its payload byte for byte
         if self.mode == post.MODE_SSB:
             s = agc.process_s16(y)
         elif self.mode == post.MODE_AM:
@@ -149,7 +151,7 @@ def check_bank(bank, adc_of_step, d_adc_of_step, rxs, steps=3, threads=8, events
             with_frame = [rx for rx in live if rx in frame_of]
             g_rows = dict(zip(with_frame, bank.fetch("rows", [frame_of[rx] for rx in with_frame])))
             g_pkts = dict(zip(with_frame, bank.fetch("pkts", [frame_of[rx] for rx in with_frame])))
-            g = {k: bank.fetch(k, live) for k in ("wf_iq", "raw", "xin", "firo", "s16", "pay")} if live else {}
+            g = {k: bank.fetch(k, live) for k in ("wf_iq", "raw", "xin", "firo", "s16", "pay", "agc", "iq_pay")} if live else {}
             stride = bank.bufs.wf_iq_stride
             for i, rx in enumerate(live):
                 p = bank.params[rx]
@@ -195,6 +197,14 @@ def check_bank(bank, adc_of_step, d_adc_of_step, rxs, steps=3, threads=8, events
                     got_y = np.ascontiguousarray(g["firo"][i, sl]).view(np.complex64).ravel()
                     assert np.abs(got_y - want_y[sl]).max() <= 1e-5 * np.abs(want_y[sl]).max(), (step, rx, "CFastFIR")
                     want_s, bar = tails[rx].block(agcs[rx], got_y)
+                    if bar == 0:                                          # MODE_IQ (rx_sound.cpp:1040-1096)
+                        got_a = np.ascontiguousarray(g["agc"][i, sl]).view(np.complex64).ravel()
+                        assert np.abs(got_a - want_s).max() <= 1e-5 * 32767.0, (step, rx, "IQ-mode AGC")
+                        want_p = ko.snd_iq_payload(got_a, bank.little_endian[rx])
+                        assert np.array_equal(g["iq_pay"][i, 2048 * blk:2048 * (blk + 1)], want_p), (step, rx, "IQ payload")
+                        audio_blocks += 1
+                        blocks_of[rx].append(step)
+                        continue
                     dlt = np.abs(g["s16"][i, sl].astype(int) - want_s.astype(int))
                     assert dlt.max() <= bar and (dlt <= 1).mean() > (0.99 if bar == 1 else 0.9), (step, rx, dlt.max(), bar)
                     if bar == 1:

@@ -415,6 +415,8 @@ def test_bank_of_mixed_demodulators_reaches_the_sound_payload(oracle):
         (post.MODE_NBFM, -3000.0, 3000.0, 1, 99),
         (post.MODE_SSB, 300.0, 2700.0, 0, 0),
         (post.MODE_NBFM, -3000.0, 3000.0, 0, 99),
+        (post.MODE_IQ, -3000.0, 3000.0, 0, 0),                 # the IQ mode: the AGC's complex output as (s2_t) pairs, network order
+        (post.MODE_IQ, -2500.0, 2500.0, 0, 0),                 # ... and little-endian
     ]
     NR, steps = len(modes), 6
     mix = MIXES["survey"](NR, 123, N)
@@ -423,6 +425,7 @@ def test_bank_of_mixed_demodulators_reaches_the_sound_payload(oracle):
     try:
         for rx, (mode, lo, hi, de, sq) in enumerate(modes):
             bank.set_audio(rx, mix[rx][2], lo, hi, mode=mode, de_emp=de, squelch=sq)
+        bank.set_little_endian(11, True)
         d_adc = bank.ctx.alloc(adc.nbytes)
         bank.ctx.upload(d_adc, adc)
         got = check_bank(bank, lambda k: adc, lambda k: d_adc, range(NR), steps)

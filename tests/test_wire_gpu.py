@@ -116,6 +116,21 @@ def test_sound_payload_and_header(gpu_ctx, oracle):
     assert bytes(h[:3]) == b"SND" and list(h[4:8]) == [4, 3, 2, 1] and (int(h[8]) << 8 | int(h[9])) == 537
 
 
+def test_iq_mode_sound_payload(gpu_ctx, oracle):
+    """The IQ modes' payload (rx/rx_sound.cpp:1076-1096): (s2_t) re, (s2_t) im per sample, little-endian or network order; values on
+    and beyond the int16 range, negative fractions (truncation toward zero), NaN / infinity (the x86 conversion's indefinite value)."""
+    rng = np.random.default_rng(4)
+    x = (rng.normal(0, 9000, (4, 512)) + 1j * rng.normal(0, 9000, (4, 512))).astype(np.complex64)
+    x[0, :8] = [32767.9, -32768.9, 32768.0, -32769.0, -0.9, 0.9, 70000.5 - 70000.5j, -1e12 + 1e12j]
+    x[1, 0] = complex(np.nan, np.inf)
+    for le in (True, False):
+        got = wire.snd_iq_payload(gpu_ctx, x, le)
+        for r in range(4):
+            assert np.array_equal(got[r], oracle.snd_iq_payload(x[r], le)), (le, r)
+    le = wire.snd_iq_payload(gpu_ctx, x[2:3], True)[0].view("<i2").reshape(-1, 2)
+    assert np.array_equal(le[:, 0], np.trunc(x[2].real).astype(np.int16)) and np.array_equal(le[:, 1], np.trunc(x[2].imag).astype(np.int16))
+
+
 def test_argument_errors(gpu_ctx):
     A = Adpcm(gpu_ctx, nchan=2)
     try:
