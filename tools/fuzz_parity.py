@@ -215,6 +215,74 @@ def trial_post():
     P.close()
 
 
+def trial_tail():
+    """What follows the detectors (round 6): a CFir with a random Kaiser design, forced tap count or caller's coefficients driven in
+    ragged blocks through its three ProcessFilter paths, and a CSquelch with random thresholds over noise / quiet stretches, both
+    through their standalone C-ABI entry points -- BIT-EXACT against the oracle (which rx/CuteSDR/fir.cpp and squelch.cpp, built
+    in place, pin bit for bit)."""
+    P = Post(ctx, nchan=2)
+    try:
+        f = ko.CFir()
+        rate = float(rng.choice([12000.0, 20250.0]))
+        kind = int(rng.integers(0, 3))
+        if kind == 0:                                              # the AM filter of a passband change, any half bandwidth
+            lo = -float(rng.uniform(50, rate / 2 + 500))
+            hi = float(rng.uniform(50, rate / 2 + 500))
+            n1 = P.set_am_passband(0, lo, hi, rate)
+            hbw = np.float32(min(float(np.float32(max(abs(hi), abs(lo)))), rate / 2))
+            stop = np.float32(min(float(np.float32(float(hbw) * 1.8)), rate / 2))
+            assert n1 == f.init_lp(0, 1.0, 50.0, hbw, stop, rate), "am fir taps"
+        elif kind == 1:                                            # any low-pass the interface takes
+            a = (int(rng.choice([0, 0, 5, 33, 96, 97])), float(rng.uniform(0.2, 2.0)), float(rng.uniform(10, 80)),
+                 float(rng.uniform(100, 3000)), float(rng.uniform(3100, 5900)), rate)
+            assert P.cfir_init_lp(0, post.CFIR_AM, *a) == f.init_lp(*a), "lp taps"
+        else:
+            taps = rng.normal(0, 0.2, int(rng.integers(1, 98))).astype(np.float32)
+            P.cfir_init_const(0, post.CFIR_AM, taps, rate)
+            f.init_const(taps, rate)
+        assert np.array_equal(P.cfir_taps(0, post.CFIR_AM).view(np.uint32), f.taps().view(np.uint32)), "taps"
+        for _ in range(int(rng.integers(1, 7))):
+            n = int(rng.integers(1, 1025))
+            k = int(rng.integers(0, 3))
+            if k == 2:
+                x = rng.integers(-32768, 32768, n).astype(np.int16)
+                got, want = P.cfir_process([0], post.CFIR_AM, post.CFIR_MONO16_MONO16, x[None])[0], f.process_mm(x)
+            else:
+                x = (rng.normal(0, 10.0 ** rng.uniform(0, 4.6), n)).astype(np.float32)
+                if k == 0:
+                    got, want = P.cfir_process([0], post.CFIR_AM, post.CFIR_REAL_REAL, x[None])[0], f.process_rr(x)
+                    got, want = got.view(np.uint32), want.view(np.uint32)
+                else:
+                    got, want = P.cfir_process([0], post.CFIR_AM, post.CFIR_REAL_MONO16, x[None])[0], f.process_rm(x)
+            assert np.array_equal(got, want), ("cfir", kind, k, n)
+        q = ko.Squelch()
+        P.squelch_setup(1, rate)
+        q.setup(rate)
+        for _ in range(int(rng.integers(2, 10))):
+            if rng.random() < 0.4:
+                v, m = int(rng.integers(0, 100)), int(rng.choice([0, 0, 3000, 8192, 20000]))
+                P.squelch_set(1, v, m)
+                q.set_squelch(v, m)
+            elif rng.random() < 0.1:
+                P.squelch_reset(1)
+                q.reset()
+            n = int(rng.integers(1, 1025))
+            x = np.clip(rng.normal(0, rng.uniform(10, 7000), n), -8192, 8192).astype(np.float32)
+            try:
+                got, rc = P.squelch_perform([1], x[None])
+            except Exception as e:                                  # before the first SetSquelch the library refuses; the oracle's
+                if "squelch" in str(e):                             # state then has indeterminate value / threshold in the reference
+                    P.squelch_set(1, 0, 0)
+                    q.set_squelch(0, 0)
+                    got, rc = P.squelch_perform([1], x[None])
+                else:
+                    raise
+            want, wrc = q.perform_fm(x)
+            assert np.array_equal(got[0], want) and int(rc[0]) == wrc, ("squelch", n, int(rc[0]), wrc)
+    finally:
+        P.close()
+
+
 def trial_wire():
     nch = int(rng.integers(1, 6))
     A = Adpcm(ctx, nchan=nch)
@@ -340,16 +408,38 @@ def trial_rxbank():
         span = UI_SRATE / (1 << zoom)
         # (a span that holds the stream's strong carrier: the rows' tolerance is relative to the largest bin)
         p = WfParams.for_zoom(zoom, max(0.0123 * ADC_CLOCK - span * rng.uniform(0.1, 0.6), 0.0) / hz, adc_clock=ADC_CLOCK, ui_srate=UI_SRATE)
-        can_shot, can_ov = 8192 * decim <= n, n // decim <= 8192 and n // decim >= 1
+        can_shot, can_ov = 8192 * decim <= n, n // decim <= 8192 and n // decim >= 2
         ov = bool(rng.integers(0, 2)) if (can_shot and can_ov) else can_ov
         return p, ov, rx_phase_inc(0.0123 * ADC_CLOCK - rng.uniform(400.0, 2500.0), ADC_CLOCK)
     mix = [receiver() for _ in range(nrx)]
     events = {}
-    for st in range(1, steps):
-        if rng.random() < 0.3:
-            rx = int(rng.integers(0, nrx))
+    modes = [dict(lo=300.0, hi=2700.0, mode=post.MODE_SSB), dict(lo=-2500.0, hi=2500.0, mode=post.MODE_AM, de_emp=int(rng.integers(0, 3))),
+             dict(lo=-3000.0, hi=3000.0, mode=post.MODE_NBFM, squelch=int(rng.choice([0, 60, 85, 99])), de_emp=int(rng.integers(0, 3))),
+             dict(lo=-3000.0, hi=3000.0, mode=post.MODE_IQ)]
+    gone = set()
+    for st in range(0, steps):
+        if st == 0:
+            for rx in range(nrx):                                     # some connections are not there at first
+                if nrx > 1 and rng.random() < 0.25:
+                    events.setdefault(0, []).append(("leave", rx))
+                    gone.add(rx)
+            continue
+        r = rng.random()
+        rx = int(rng.integers(0, nrx))
+        if r < 0.25 and rx not in gone:
             p, ov, inc = receiver()
-            events[st] = [("wf", rx, p, ov)] if rng.random() < 0.6 else [("freq", rx, inc)]
+            events.setdefault(st, []).append(("wf", rx, p, ov) if rng.random() < 0.6 else ("freq", rx, inc))
+        elif r < 0.45 and gone:
+            rx = int(rng.choice(sorted(gone)))
+            p, ov, inc = receiver()
+            mix[rx] = (p, ov, inc)
+            events.setdefault(st, []).append(("join", rx, p, ov, inc, dict(modes[int(rng.integers(0, 4))])))
+            gone.discard(rx)
+        elif r < 0.55 and rx not in gone and len(gone) < nrx - 1:
+            events.setdefault(st, []).append(("leave", rx))
+            gone.add(rx)
+        elif r < 0.7 and rx not in gone:
+            events.setdefault(st, []).append(("audio", rx, dict(modes[int(rng.integers(0, 4))])))
     t = np.arange(n * steps)
     x = rng.normal(0, 10.0, n * steps) + 3000.0 * np.cos(2 * np.pi * 0.0123 * t) + rng.uniform(0, 2000) * np.cos(2 * np.pi * rng.uniform(0, 0.5) * t)
     adc = np.clip(np.rint(x), -32768, 32767).astype(np.int16)
@@ -368,7 +458,7 @@ def trial_rxbank():
         bank.close()
 
 
-for name, fn in (("rxbank", trial_rxbank), ("acq", trial_acq), ("wf ddc", trial_wfddc), ("rx ddc", trial_rxddc), ("fastfir", trial_fir), ("post", trial_post), ("wire", trial_wire), ("wf frames", trial_wf)):
+for name, fn in (("rxbank", trial_rxbank), ("tail", trial_tail), ("acq", trial_acq), ("wf ddc", trial_wfddc), ("rx ddc", trial_rxddc), ("fastfir", trial_fir), ("post", trial_post), ("wire", trial_wire), ("wf frames", trial_wf)):
     soak(name, fn)
 if flips:
     print("branch flips let through (a gain step, see trial_post):", flips)
