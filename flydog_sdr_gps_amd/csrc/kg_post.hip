@@ -5,8 +5,9 @@
 // rx/rx_sound.cpp:766-787 (AM + m_AM_FIR), :845-877 (NBFM + m_Squelch), :898-907 (de-emphasis); rx/CuteSDR/fir.cpp (CFir),
 // rx/CuteSDR/squelch.cpp (CSquelch).  TYPEREAL is float there and the
 // literals are double, so the expressions below keep the reference's operand types
-// (the library is built with -ffp-contract=off): the only operations that can differ
-// from the CPU path are log10f and powf (device libm vs the host's).
+// (the library is built with -ffp-contract=off): the only operation that can differ
+// from the CPU path is powf (device libm vs the host's) -- log10f, which CAgc BRANCHES on, is the
+// host libm's algorithm restated on the device (kg_libm.h: bit-identical on every float, round 6).
 //
 // One wavefront per channel.  What the reference does with circular buffers is
 // restated so that most of it runs in parallel over the samples of the call:
@@ -24,6 +25,7 @@
 //     output sample, that is a sum every lane can do for its own sample -- in that order, over a linear history in LDS;
 //   * the squelch's noise average is one more sequential recursion (lane 0); its verdict applies to the whole block.
 #include "kg_common.h"
+#include "kg_libm.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(64) void post_kernel(
     for (int j = lane; j < n; j += 64) {
         const float2 x = in[j];
         const float pwr = x.x * x.x + x.y * x.y;
-        s_db[j] = 10.0 * log10f((pwr / snd_max_pwr) + 1e-30);
+        s_db[j] = 10.0 * kg_libm::log10f_glibc((float) ((pwr / snd_max_pwr) + 1e-30));      // the host libm's log10f, bit for bit (kg_libm.h)
     }
 
     float *P = bufA;                    // window maxima end up here, index W + j
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(64) void post_kernel(
         for (int j = lane; j < n; j += 64) {
             const float2 x = in[j];
             float mag = x.x * x.x + x.y * x.y;
-            mag = 0.5 * log10f(mag / (MAX_AMPLITUDE * MAX_AMPLITUDE) + 1e-16);
+            mag = 0.5 * kg_libm::log10f_glibc((float) (mag / (MAX_AMPLITUDE * MAX_AMPLITUDE) + 1e-16));
             bufA[W + j] = mag;
             rmag[(cnt + j) & (POST_CIRC - 1)] = mag;
             rin[(cnt + j) & (POST_CIRC - 1)] = x;
@@ -669,6 +671,25 @@ int kg_post_set_mode(kg_post *p, int ch, int mode)
     KG_REQUIRE(mode >= KG_POST_IQ && mode <= KG_POST_NBFM, KG_ERR_INVALID, "kg_post_set_mode: mode %d", mode);
     if ((rc = post_put(p, ch, &post_chan::mode, mode))) return rc;
     KG_HIP(hipStreamSynchronize(p->ctx->stream));
+    return KG_OK;
+}
+
+// ---- the log10f of the S-meter and CAgc over an array: what tests/test_libm_gpu.py compares with the image's libm
+__global__ void math_log10f_kernel(const float *__restrict__ x, unsigned first, size_t n, float *__restrict__ y)
+{
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x)
+        y[i] = kg_libm::log10f_glibc(x ? x[i] : __uint_as_float(first + (unsigned) i));
+}
+
+int kg_math_log10f_dev(kg_ctx *ctx, const void *d_x, uint32_t first_bits, size_t n, void *d_y)
+{
+    int rc = kg_ctx_use(ctx);
+    if (rc) return rc;
+    KG_REQUIRE(d_y && n >= 1 && ((uintptr_t) d_y & 3) == 0 && ((uintptr_t) d_x & 3) == 0, KG_ERR_INVALID, "kg_math_log10f_dev: bad argument");
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(math_log10f_kernel, dim3((unsigned) (blocks < 16384 ? blocks : 16384)), dim3(256), 0, ctx->stream,
+                       (const float *) d_x, first_bits, n, (float *) d_y);
+    KG_HIP(hipGetLastError());
     return KG_OK;
 }
 

@@ -201,3 +201,27 @@ class Post:
         taps = np.zeros((chans.size, 2), np.float32)
         check(self.lib.kg_post_smeter(self.h, ptr(chans), chans.size, ptr(avg), ptr(taps)), "kg_post_smeter")
         return avg, taps
+
+
+def log10f(ctx, x=None, first_bits=0, n=None):
+    """kg_math_log10f_dev: the S-meter's / CAgc's log10f over an array (x), or over the n floats whose bit patterns start at
+    first_bits.  -> float32[n]"""
+    if x is not None:
+        x = np.ascontiguousarray(x, np.float32)
+        n = x.size
+    n = int(n)
+    out = np.empty(n, np.float32)
+    d_y = ctx.alloc(4 * n)
+    d_x = ctx.alloc(4 * n) if x is not None else 0
+    try:
+        if x is not None:
+            ctx.upload(d_x, x)
+        check(ctx.lib.kg_math_log10f_dev(ctx.h, C.c_void_p(d_x) if d_x else None, int(first_bits) & 0xFFFFFFFF, n, C.c_void_p(d_y)),
+              "kg_math_log10f_dev")
+        ctx.sync()
+        ctx.download(d_y, out)
+    finally:
+        ctx.free(d_y)
+        if d_x:
+            ctx.free(d_x)
+    return out

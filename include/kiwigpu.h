@@ -438,6 +438,11 @@ int kg_post_agc_delay(kg_post *post, int chan);           /* CAgc::GetDelaySampl
 int kg_post_set_smeter(kg_post *post, int chan, float frate);
 int kg_post_set_mode(kg_post *post, int chan, int mode);
 int kg_post_get_mode(kg_post *post, int chan);              /* -> KG_POST_*, or < 0 */
+/* The log10f the S-meter and CAgc take of every sample (rx/rx_sound.cpp:687, rx/CuteSDR/agc.cpp:191) over an array: y[i] =
+ * log10f(x[i]), or, with d_x NULL, of the float whose bit pattern is first_bits + i.  The reference calls the platform's libm;
+ * the device function restates the GNU C Library 2.35 algorithm of this image (csrc/kg_libm.h) and equals it bit for bit, which
+ * is what makes CAgc's branches (agc.cpp:215-240) the reference's own.  Enqueue only. */
+int kg_math_log10f_dev(kg_ctx *ctx, const void *d_x, uint32_t first_bits, size_t n, void *d_y);
 /* A new connection on the channel: sMeterAvg_dB = 0, z1 = 0 (rx_sound.cpp:244,250),
  * conn->last_sample = 0.  The AGC object persists across connections, as m_Agc[] does. */
 int kg_post_reset(kg_post *post, int chan);

@@ -22,7 +22,8 @@
 #        fastfir_ref   rx/CuteSDR/fastfir.cpp + support/simd.cpp                (CFastFIR)
 #        search_ref    gps/search.cpp (included by the driver: its functions are static) + sats.cpp + simd.cpp
 #                                                                                (SearchInit, Sample, Correlate, decimators)
-#        wf_ref        rx/rx_waterfall.cpp + ima_adpcm.cpp + CuteSDR/noiseproc.cpp (c2s_waterfall_init, compute_frame)
+#        wf_ref        rx/rx_waterfall.cpp + ima_adpcm.cpp + CuteSDR/noiseproc.cpp + rx_util.cpp + support/misc.cpp
+#                                                         (c2s_waterfall_init, compute_frame, aperture_auto)
 #        dpump_ref     rx/data_pump.cpp (included by the driver)                  (snd_service: runs here, no transform)
 #        chan_ref      gps/channel.cpp + ephemeris.cpp + sats.cpp                  (CHANNEL::Start: runs here)
 #
@@ -104,8 +105,11 @@ if [ -f "$HIPFFTW_H" ] && [ -f /opt/rocm/lib/libhipfftw.so ]; then
     # waterfall frames (rows W1, W4-W8): rx_waterfall.cpp's c2s_waterfall_init() and compute_frame() + the reference's ima_adpcm.cpp;
     # the driver supplies a no-op for the command-hash setup and the per-frame inputs the c2s_waterfall() coroutine would have set
     # (rx_waterfall.cpp holds a global CNoiseProc array: the reference's own rx/CuteSDR/noiseproc.cpp supplies its constructor)
-    $CXX $OPT $DEF $FINC -no-pie -o "$OUT/wf_ref" "$HERE/ref/ref_wf_main.cpp" "$R/rx/rx_waterfall.cpp" "$R/rx/csdr/ima_adpcm.cpp" \
-        "$R/rx/CuteSDR/noiseproc.cpp" $FLIB
+    # aperture_auto() (static, called by compute_frame() when wf->aper == AUTO) uses dB_wire_to_dBm() of rx/rx_util.cpp and
+    # qsort_intcomp() of support/misc.cpp: both files linked in place; misc.cpp names DIR_CFG, which the reference's Makefile
+    # passes (Makefile:278, :496)
+    $CXX $OPT $DEF $FINC '-DDIR_CFG=STRINGIFY(/root/kiwi.config)' -no-pie -o "$OUT/wf_ref" "$HERE/ref/ref_wf_main.cpp" \
+        "$R/rx/rx_waterfall.cpp" "$R/rx/csdr/ima_adpcm.cpp" "$R/rx/CuteSDR/noiseproc.cpp" "$R/rx/rx_util.cpp" "$R/support/misc.cpp" $FLIB
     # the data pump's unpack (rows A1, A2): no FFT is called, but data_pump.cpp's headers need the FFTW3 API header; the driver TU
     # includes rx/data_pump.cpp itself (snd_service() is static) and defines the SPI / scheduler entry points it calls.  Runs HERE.
     $CXX $OPT $DEF $FINC -no-pie -DREF_DATA_PUMP_CPP="\"$R/rx/data_pump.cpp\"" -o "$OUT/dpump_ref" "$HERE/ref/ref_dpump_main.cpp" -lm $UNRES

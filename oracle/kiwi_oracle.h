@@ -335,6 +335,14 @@ void ko_snd_gps_stamp(ko_gps_state *s, int norm_nrx_samps, int fir_pos, int agc_
                       double adc_clock_base, double clk_gps_secs, uint64_t clk_ticks, uint32_t *gpssec,
                       uint32_t *gpsnsec, uint8_t *last_gps_solution);
 
+/* ---- part 11: the platform's log10f restated, and the check of the restatement against libm (kiwi_oracle_libm.c) ---- */
+float ko_logf_restated(float x, int fused);
+float ko_log10f_restated(float x, int fused);
+void ko_libm_log10f(const float *x, float *y, size_t n);
+void ko_libm_log10f_bits(uint32_t first, size_t n, float *y);
+uint64_t ko_libm_check_range(uint32_t first, uint64_t n, uint64_t step, int fused, int threads, uint64_t *bad_logf,
+                             uint64_t *bad_log10f, uint32_t *first_bad);
+
 #ifdef __cplusplus
 }
 #endif

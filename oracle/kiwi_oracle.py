@@ -751,3 +751,37 @@ def ref_cacode(t0, t1):
         return None
     s = subprocess.check_output([exe, str(t0), str(t1)]).decode().strip()
     return np.frombuffer(s.encode(), np.uint8) - ord("0")
+
+
+# ---- the platform's log10f (kiwi_oracle_libm.c) ------------------------------------------
+def libm_log10f(x):
+    """log10f of the libm this oracle is linked against (the reference's S-meter / CAgc call it), elementwise."""
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.empty_like(x)
+    lib().ko_libm_log10f(_p(x), _p(y), C.c_size_t(x.size))
+    return y
+
+
+def libm_log10f_bits(first, n):
+    """log10f of the floats whose bit patterns are first .. first + n - 1"""
+    y = np.empty(int(n), np.float32)
+    lib().ko_libm_log10f_bits(C.c_uint32(int(first)), C.c_size_t(int(n)), _p(y))
+    return y
+
+
+def log10f_restated(x, fused=True):
+    L = lib()
+    L.ko_log10f_restated.argtypes = [C.c_float, C.c_int]
+    L.ko_log10f_restated.restype = C.c_float
+    return np.array([L.ko_log10f_restated(float(v), int(fused)) for v in np.atleast_1d(np.asarray(x, np.float32))], np.float32)
+
+
+def libm_check_range(first, n, step=1, fused=True, threads=8):
+    """The restated logf / log10f (csrc/kg_libm.h carries the same) against libm over bit patterns first, first + step, ...
+    -> (values compared, logf differences, log10f differences, a differing pattern or 0)"""
+    L = lib()
+    L.ko_libm_check_range.argtypes = [C.c_uint32, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ko_libm_check_range.restype = C.c_uint64
+    a, b, u = C.c_uint64(), C.c_uint64(), C.c_uint32()
+    done = L.ko_libm_check_range(int(first), int(n), int(step), int(bool(fused)), int(threads), C.byref(a), C.byref(b), C.byref(u))
+    return int(done), int(a.value), int(b.value), int(u.value)

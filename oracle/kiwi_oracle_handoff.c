@@ -4,9 +4,11 @@
  *   CHANNEL::Start() NCO rates, code creep, ca_pause       gps/channel.cpp:267-311
  *   aperture_auto() waterfall autoscale                    rx/rx_waterfall.cpp:1173-1273,
  *                                                          dB_wire_to_dBm rx/rx_util.cpp:905-912
- * PARITY UNPINNED for the aperture averages that go through expf (IIR); everything else is
- * integer or + - * / arithmetic.  No reference vectors exist for these functions and neither
- * file builds from its own sources (both include kiwi.h -> kiwi.gen.h).
+ * PINNED BY THE REFERENCE ITSELF (round 6): CHANNEL::Start by gps/channel.cpp built in place (tests/golden/chan_ref.npz, 205
+ * calls: the SPI words equal); aperture_auto() by the reference's compute_frame() -> aperture_auto() run on the GPU box with
+ * rx_util.cpp's dB_wire_to_dBm and misc.cpp's qsort_intcomp linked in place (tests/golden/aper_fftref.npz, 36 frames: avg_pwr[]
+ * after every frame bit-exact -- the IIR's expf included, same libm -- signal / noise / counters equal).
+ * tests/test_ref_pins_cpu.py holds both.
  */
 #include "kiwi_oracle.h"
 

@@ -150,3 +150,37 @@ def dpump_ref_cases(g):
         assert k == y.size
         out.append((name, nch, ns, bool(inv), float(dci), float(dcq), en, g[name + "_bufs"], float(y[0]), per))
     return out
+
+
+def aper_ref_replay(g, update, report):
+    """Walks tests/golden/aper_fftref.npz -- one wf_inst_t's aperture fields over the frames the reference's compute_frame() ->
+    aperture_auto() (rx/rx_waterfall.cpp:1173-1272) was given -- with the caller's two halves:
+        update(avg, row, algo, param, clear, start, stop, waterfall_cal) -> avg      (:1183-1222)
+        report(avg, start, stop) -> (signal, noise)                                   (:1233-1271)
+    and the control flow between them restated here (need / done counters :1176, the audio FFT's pixel range :1180-1181, the
+    single-shot rule :1177, :1192-1195, the report clock :1224-1229).  Yields (frame index, avg, (signal, noise, done,
+    report_sec, avg_clear), expected avg, expected state) after every frame."""
+    import numpy as np
+    IIR, MMA, EMA, OFF = 0, 1, 2, 3
+    avg = np.zeros(1024, np.float32)
+    st = dict(done=0, clear=0, signal=0, noise=0, report_sec=0)
+    for k, (run, f, algo, param, cal, nwf, now, need) in enumerate(g["frames"]):
+        algo, cal, nwf, now, need, f = int(algo), int(cal), int(nwf), int(now), int(need), int(f)
+        if f == 0:
+            st["clear"] = 1
+        row = g["rows"][k]
+        if need > st["done"]:
+            single = algo == OFF
+            start, stop = (256, 768) if 0 >= nwf else (0, 1024)
+            if st["clear"]:
+                avg = update(avg, row, MMA, 8.0, True, start, stop, cal)
+                st["report_sec"], st["clear"] = now, 0
+            else:
+                a, p = (MMA, 8.0) if single else (algo, float(param))
+                avg = update(avg, row, a, p, False, start, stop, cal)
+            if now >= st["report_sec"] + (1 if single else 3):
+                st["report_sec"] = now
+                st["done"] += 1
+                st["signal"], st["noise"] = report(avg, start, stop)
+        yield k, avg, (st["signal"], st["noise"], st["done"], st["report_sec"], st["clear"]), g["avg_pwr"][k], \
+            tuple(int(v) for v in g["states"][k])

@@ -447,3 +447,44 @@ def test_chan_start_oracle_matches_reference_channel_cpp(oracle):
     for is_e1b, lo_shift, ca_shift, secs, lo_rate, ca_rate, pause in exp:
         o = oracle.chan_start(is_e1b, lo_shift, ca_shift, secs)
         assert (o.lo_rate, o.ca_rate, o.ca_pause) == (lo_rate, ca_rate, pause), (is_e1b, lo_shift, ca_shift, secs)
+
+
+def test_aperture_oracle_matches_reference_aperture_auto(oracle):
+    """aperture_auto() of rx/rx_waterfall.cpp ITSELF, run inside the reference's compute_frame() on the GPU box with the rows it had
+    just produced (aper_fftref.npz; dB_wire_to_dBm of rx_util.cpp and qsort_intcomp of support/misc.cpp linked in place): the IIR,
+    MMA and EMA averages, the single-shot mode, the audio FFT's pixel range, two calibrations, an all-masked run -- avg_pwr[]
+    after every frame BIT-EXACT, signal / noise / done_autoscale / report_sec / avg_clear equal."""
+    from tests.fixtures import aper_ref_replay
+    g = np.load(os.path.join(GOLD, "aper_fftref.npz"))
+    n, reports, algos = 0, set(), set()
+    for k, avg, st, want_avg, want_st in aper_ref_replay(g, oracle.aper_update, oracle.aper_report):
+        assert np.array_equal(np.asarray(avg, np.float32).view(np.uint32), want_avg.view(np.uint32)), (k, g["frames"][k])
+        assert st == want_st, (k, st, want_st)
+        n += 1
+        reports.add((st[0], st[1]))
+        algos.add(int(g["frames"][k][2]))
+    assert n == len(g["frames"]) >= 30 and algos == {0, 1, 2, 3}
+    assert (-110, -120) not in reports and (-80, -120) in reports      # the all-masked run reports -110 -> floor -80 / -120
+    assert len(reports) >= 5
+
+
+def test_log10f_restatement_equals_the_images_libm(oracle):
+    """The platform's log10f (GNU C Library 2.35: e_log10f.c over e_logf.c) restated in oracle/kiwi_oracle_libm.c against logf() and
+    log10f() of the libm the oracle is linked with: every 64th non-negative float, every float of [0.5, 2), subnormals, negatives;
+    fused and unfused multiply-adds.  0 differences (all 2 139 095 041 patterns: tools/check_log10f.py --exhaustive).  The DEVICE
+    copy (csrc/kg_libm.h) carries the same 16 x 2 table and constants: compared here as text."""
+    import re
+    for fused in (True, False):
+        for first, n, step in ((0, 0x7f800001, 64), (0x3f000000, 1 << 24, 1), (0, 0x00800000, 3), (0x80000000, 0x7fffffff, 4099)):
+            done, bad_ln, bad_l10, where = oracle.libm_check_range(first, n, step, fused)
+            assert done >= n // step and (bad_ln, bad_l10) == (0, 0), (fused, hex(first), bad_ln, bad_l10, hex(where))
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hexf = re.compile(r"-?0x[0-9a-f.]+p[-+]?\d+")
+    dev = hexf.findall(open(os.path.join(here, "flydog_sdr_gps_amd", "csrc", "kg_libm.h")).read())
+    cpu = hexf.findall(open(os.path.join(here, "oracle", "kiwi_oracle_libm.c")).read())
+    tab_dev, tab_cpu = [float.fromhex(v) for v in dev[:32]], [float.fromhex(v) for v in cpu[:32]]
+    assert len(tab_dev) == 32 and tab_dev == tab_cpu and tab_cpu[18:20] == [1.0, 0.0]
+    assert sorted(float.fromhex(v) for v in dev[32:]) == sorted(float.fromhex(v) for v in cpu[32:] if "p23" not in v)
+    for lit in ("3.3554432000e+07f", "7.9034151668e-07f", "4.3429449201e-01f", "3.0102920532e-01f"):
+        assert lit in open(os.path.join(here, "flydog_sdr_gps_amd", "csrc", "kg_libm.h")).read()
+        assert lit in open(os.path.join(here, "oracle", "kiwi_oracle_libm.c")).read()

@@ -310,3 +310,33 @@ def test_chan_start_matches_reference_channel_cpp():
     for is_e1b, lo_shift, ca_shift, secs, lo_rate, ca_rate, pause in chan_ref_expect(g):
         o = handoff.chan_start(is_e1b, lo_shift, ca_shift, secs)
         assert (o.lo_rate, o.ca_rate, o.ca_pause) == (lo_rate, ca_rate, pause), (is_e1b, lo_shift, ca_shift, secs)
+
+
+def test_aperture_on_the_gpu_matches_reference_aperture_auto(gpu_ctx):
+    """kg_aper_update_dev / kg_aper_report against aperture_auto() of rx/rx_waterfall.cpp ITSELF (aper_fftref.npz, made by the
+    reference's compute_frame() on the GPU box): the MMA / EMA averages and the loads BIT-EXACT, the IIR average (expf) within
+    1e-5 of the largest average as in tests/test_handoff_gpu.py, and every report -- signal, noise, when -- equal."""
+    from flydog_sdr_gps_amd import Aperture
+    from tests.fixtures import aper_ref_replay
+    g = np.load(os.path.join(GOLD, "aper_fftref.npz"))
+    A = Aperture(gpu_ctx, nchan=1)
+    try:
+        def update(avg, row, algo, param, clear, start, stop, cal):
+            A.update([0], row, [(algo, param, clear, start == 256)], waterfall_cal=cal)
+            return A.get(0)
+
+        def report(avg, start, stop):
+            sig, noise = A.report([0], [start == 256])
+            return int(sig[0]), int(noise[0])
+
+        n = 0
+        for k, avg, st, want_avg, want_st in aper_ref_replay(g, update, report):
+            if int(g["frames"][k][2]) == 0:
+                assert np.abs(avg - want_avg).max() <= 1e-5 * np.abs(want_avg).max(), k
+            else:
+                assert np.array_equal(avg.view(np.uint32), want_avg.view(np.uint32)), (k, g["frames"][k])
+            assert st == want_st, (k, st, want_st)
+            n += 1
+        assert n == len(g["frames"])
+    finally:
+        A.close()

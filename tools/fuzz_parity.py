@@ -18,7 +18,6 @@ from tests.fixtures import arm_audio_tail, oracle_row    # noqa: E402
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
 only = sys.argv[3] if len(sys.argv) > 3 else None
 last_story = {}
-flips = {}
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 ctx = Context(0)
 fails = 0
@@ -191,20 +190,10 @@ def trial_post():
             want = a.process_cpx(x)
             scale = max(np.abs(want).max(), 1e-20)
             err = np.abs(agc[0] - want)
-            if err.max() > 2e-5 * scale:
-                # CAgc's averagers and hang timer branch on log10f() values: a one-ulp difference between the device's libm
-                # and the host's at a threshold takes the other branch, and from that sample on the two outputs differ by a
-                # GAIN STEP (measured: 1.7e-4; tests/golden/post_branch_case.npz).  That, and only that, is let through and
-                # counted; the trial ends there (the two states have parted).
-                bad = err > 2e-5 * scale
-                with np.errstate(divide="ignore", invalid="ignore"):
-                    ratio = (agc[0][bad] / want[bad])
-                med = np.median(ratio.real)
-                assert (np.abs(ratio - med).max() <= 5e-5 and abs(med - 1.0) <= 2e-3
-                        and bad[np.argmax(bad):].all()), "post cpx"
-                flips["post"] = flips.get("post", 0) + 1
-                P.close()
-                return
+            # (rounds 4-5 let a constant gain step through here: CAgc branches on log10f() values and the device's libm differed
+            # from the host's by an ulp once in ~10^6 trials.  The device now takes log10f by the host libm's own algorithm --
+            # csrc/kg_libm.h, bit-identical on every float -- so a step is a failure like anything else.)
+            assert err.max() <= 2e-5 * scale, ("post cpx", err.max() / scale)
             if mode == post.MODE_AM:
                 wd, z1 = ko.am_detect(z1, want)
             elif mode == post.MODE_NBFM:
@@ -460,8 +449,6 @@ def trial_rxbank():
 
 for name, fn in (("rxbank", trial_rxbank), ("tail", trial_tail), ("acq", trial_acq), ("wf ddc", trial_wfddc), ("rx ddc", trial_rxddc), ("fastfir", trial_fir), ("post", trial_post), ("wire", trial_wire), ("wf frames", trial_wf)):
     soak(name, fn)
-if flips:
-    print("branch flips let through (a gain step, see trial_post):", flips)
 print("failures:", fails)
 if _acq:
     _acq["s"].close()

@@ -1,4 +1,4 @@
-"""Generates tests/golden/acq_fftref.npz and fastfir_fftref.npz from the REFERENCE ITSELF -- its gps/search.cpp (SearchInit,
+"""Generates tests/golden/acq_fftref.npz, fastfir_fftref.npz, wf_fftref.npz and aper_fftref.npz from the REFERENCE ITSELF -- its gps/search.cpp (SearchInit,
 Sample, Correlate, the decimators) and rx/CuteSDR/fastfir.cpp (CFastFIR), compiled in place by oracle/build_ref.sh against the
 FFTW3 API the image ships (hipFFTW) -- RUN ON THE GPU BOX, where hipFFTW's transforms execute:
 
@@ -175,6 +175,56 @@ for k, (prm, iq) in enumerate(meta):
         k, WF_CASES[k][0], nbytes, limit, flags, payload.min(), payload.max()))
 assert pos == y.size
 np.savez_compressed(os.path.join(out_dir, "wf_fftref.npz"), **wfg)
+
+# ---- aperture_auto(): the static function compute_frame() calls when wf->aper == AUTO (rx_waterfall.cpp:1173-1272, :1619) --------
+# One connection's life per run: the averages are loaded from the first row (avg_clear), every later row is averaged in with the
+# run's algorithm, and the 5 dB histogram is reported when the script's clock has advanced far enough (3 s; 1 s single-shot).
+# Every frame is an uncompressed row of case 1's setting (zoom 3) over its own seeded samples; a run of all-zero samples gives
+# the masked-everywhere report.  Per frame the golden keeps the row the reference produced (aperture_auto's input) and the
+# state it left: signal, noise, done_autoscale, report_sec, avg_clear, avg_pwr[1024].
+IIR, MMA, EMA, OFF = 0, 1, 2, 3
+APER_RUNS = [
+    # algo, param, waterfall_cal, wf_chans, [clock of each frame], [need_autoscale of each frame], zero input?
+    (IIR, 0.35, -13, 4, [100, 101, 102, 103, 104, 105, 107, 108], [1, 1, 1, 1, 2, 2, 2, 2], False),
+    (MMA, 4.0, -13, 4, [200, 201, 203, 204, 206, 209], [3, 3, 3, 4, 4, 4], False),
+    (EMA, 6.0, -20, 4, [300, 302, 303, 306, 307], [5, 5, 5, 6, 6], False),
+    (OFF, 0.0, -13, 4, [400, 400, 401, 401, 402], [7, 7, 7, 8, 8], False),         # single shot: MMA 8, one second
+    (MMA, 2.0, 0, 0, [500, 501, 503, 504], [9, 9, 9, 9], False),                    # rx14.wf0: the audio FFT's pixels 256 .. 767
+    (EMA, 3.0, -13, 4, [600, 601, 603], [10, 10, 10], True),                         # nothing but masked bands: -110 / -120
+    (IIR, 4.0, -13, 4, [700, 703, 704, 707, 710], [11, 11, 12, 12, 13], False),     # a fast IIR, reports every 3 s
+]
+zoom, start_hz, interp, winf, cic, ovl, inv, _ = WF_CASES[1]
+prm = wfm.WfParams.for_zoom(zoom, start_hz, spectral_inversion=inv)
+m, d = wfm.build_maps(prm.fft_used, prm.plot_width, prm.plot_width_clamped, inv)
+sc = np.full(1024, prm.fft_scale, np.float32)
+m16 = np.asarray(m, np.int64).astype(np.uint16)
+d16 = np.zeros(1024, np.uint16)
+d16[:np.asarray(d).size] = np.asarray(d, np.int64).astype(np.uint16)
+script, blobs, frames = [], [], []
+for r, (algo, param, cal, nwf, clocks, needs, zero) in enumerate(APER_RUNS):
+    for f, (now, need) in enumerate(zip(clocks, needs)):
+        script.append("P 1 %d %r %d %d %d %d %d" % (algo, float(param), 1 if f == 0 else -1, need, now, cal, nwf))
+        iq = np.zeros((8192, 2), np.int16) if zero else synth.wf_iq_frame(seed=7000 + 37 * r + f)
+        if not zero and f % 3 == 2:
+            iq = (np.asarray(iq, np.int32) // 8).astype(np.int16)       # a quieter frame: the averages move
+        blobs += [m16.tobytes(), d16.tobytes(), sc.tobytes(), (sc / np.float32(2)).astype(np.float32).tobytes(), np.ascontiguousarray(iq, np.int16).tobytes()]
+        script.append("F %d %d %d %d %d %d %d %d %r %d %d %d" % (zoom, winf, interp, int(cic), int(ovl), prm.fft_used, prm.plot_width,
+                                                                 prm.plot_width_clamped, float(prm.fft_offset), 0, int(prm.start), 9000 + f))
+        frames.append((r, f, algo, param, cal, nwf, now, need))
+y = run("wf_ref", script, np.frombuffer(b"".join(blobs), np.uint8))
+pos, rows, states, avgs = 0, [], [], []
+for _ in frames:
+    nbytes = int(y[pos]); pos += 5
+    assert nbytes == 1024
+    pos += 2 * prm.fft_used
+    rows.append(y[pos:pos + 1024].astype(np.uint8)); pos += 1024
+    states.append(y[pos:pos + 5].astype(np.int64)); pos += 5
+    avgs.append(y[pos:pos + 1024].copy()); pos += 1024
+assert pos == y.size
+aper = {"frames": np.array(frames, np.float64), "rows": np.array(rows), "states": np.array(states), "avg_pwr": np.array(avgs)}
+np.savez_compressed(os.path.join(out_dir, "aper_fftref.npz"), **aper)
+for (r, f, algo, param, cal, nwf, now, need), st in zip(frames, states):
+    print("aper run %d frame %d (algo %d, t = %d, need %d): signal %d noise %d done %d report_sec %d" % (r, f, algo, now, need, *st[:4]))
 
 # ---- how far is the oracle's restatement? (the tests assert these; here for the log) -----------------------------------------
 try:
