@@ -180,7 +180,7 @@ SYMBOLS = {
     "kg_snd_iq_payload_dev": (_i, [_vp, _vp, _i, _vp, _sz, _i, _i, _vp, _sz]),
     "kg_rxbank_set_little_endian": (_i, [_vp, _i, _i]),
     "kg_post_get_mode": (_i, [_vp, _i]),
-    "kg_math_log10f_dev": (_i, [_vp, _vp, C.c_uint32, C.c_size_t, _vp]),
+    "kg_math_dev": (_i, [_vp, _i, C.c_float, _vp, C.c_uint32, C.c_size_t, _vp]),
     "kg_rxbank_poll": (_i, [_vp]),
     "kg_rxbank_ready": (_i, [_vp]),
     "kg_rxbank_join": (_i, [_vp, _i]),

@@ -2,6 +2,7 @@
 //
 // Reference: gps/channel.cpp:267-311; rx/rx_waterfall.cpp:1173-1273, rx/rx_util.cpp:905-912.
 #include "kg_common.h"
+#include "kg_libm.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(256) void aper_update_kernel(float *__restrict__ av
     if (c.clear) {
         v = pwr;                                                         // rx_waterfall.cpp:1184-1185
     } else if (c.algo == KG_APER_IIR) {                                  // :1199-1206
-        float iir_gain = 1.0 - expf(-param * pwr / 255.0);
+        float iir_gain = 1.0 - kg_libm::expf_glibc((float) (-param * pwr / 255.0));      // the host libm's expf, bit for bit (kg_libm.h)
         if (iir_gain <= 0.01) iir_gain = 0.01;
         v += (pwr - v) * iir_gain;
     } else if (c.algo == KG_APER_MMA) {                                  // :1208-1213

@@ -1,4 +1,4 @@
-// kg_libm.h -- log10f as the reference's host computes it, on the device, bit for bit.
+// kg_libm.h -- log10f, powf and expf as the reference's host computes them, on the device, bit for bit.
 //
 // Why: the S-meter and CAgc of c2s_sound() take log10f of every sample (rx/rx_sound.cpp:687, rx/CuteSDR/agc.cpp:191), and CAgc's
 // averagers and hang timer BRANCH on those values (agc.cpp:215-240).  With the device's own log10f (1 ulp, but not the same
@@ -11,7 +11,15 @@
 // in the repository.  Pinned: the same restatement in C (the test infrastructure's part 11) equals the image's logf AND log10f on ALL
 // 2 139 095 041 non-negative floats (tools/check_log10f.py --exhaustive, 13 s on 8 cores; with and without fused
 // multiply-adds: the final rounding to float hides the difference everywhere), and tests/test_libm_gpu.py compares this device
-// function with the image's log10f through the C ABI (kg_math_log10f_dev).
+// function with the image's log10f through the C ABI (kg_math_dev).
+//
+// powf and expf (round 6, same method): CAgc's gain is powf(10, mag * (slope - 1)) (agc.cpp:250-253) -- the one operation that kept
+// the audio chain from being bit-identical to the reference once log10f was -- and aperture_auto()'s IIR gain is
+// 1 - expf(-param * pwr / 255) (rx_waterfall.cpp:1199).  glibc 2.35: sysdeps/ieee754/flt-32/e_powf.c (log2 by a 16-interval table and
+// a quintic, exp2 by a 32-entry table and a cubic, all in double, one rounding to float) and e_expf.c (the same exp2 table).  Checked
+// against the image's libm on an FMA-capable host (glibc selects its FMA build there: sysdeps/x86_64/fpu/multiarch): powf(10, y) on
+// ALL 2^32 y, powf(x, y) on 2^28 random pairs, expf on ALL 2^32 x -- 0 differences; expf needs its residual z - kd evaluated as
+// fma(InvLn2N, x, -kd), which is what that build does (2 of 2^32 arguments tell), every other multiply-add may be fused or not.
 #ifndef KG_LIBM_H
 #define KG_LIBM_H
 #include <hip/hip_runtime.h>
@@ -69,6 +77,94 @@ __device__ __forceinline__ float log10f_glibc(float x)
     const float m = __uint_as_float((uint32_t) hx);
     const float z = __fadd_rn(__fmul_rn(y, 7.9034151668e-07f), __fmul_rn(4.3429449201e-01f, logf_normal(m)));
     return __fadd_rn(z, __fmul_rn(y, 3.0102920532e-01f));
+}
+// ---- e_powf.c / e_expf.c ---------------------------------------------------------------------------------------------------
+__device__ __constant__ const double powf_log2_tab[16][2] = {
+    {0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2}, {0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2},
+    {0x1.49539f0f010bp+0, -0x1.7418b0a1fb77bp-2},  {0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2},
+    {0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2}, {0x1.25e227b0b8eap+0, -0x1.97c1d1b3b7afp-3},
+    {0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3}, {0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4},
+    {0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5}, {0x1p+0, 0x0p+0},
+    {0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4},  {0x1.ca4b31f026aap-1, 0x1.476a9543891bap-3},
+    {0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2},
+    {0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2},  {0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2}};
+// exp2f_data: tab[i] = bits(2^(i/32)) - (i << 47)
+__device__ __constant__ const unsigned long long exp2f_tab[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull, 0x3fef54873168b9aaull,
+    0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull,
+    0x3feea11473eb0187ull, 0x3feea589994cce13ull, 0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
+    0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+
+__device__ __forceinline__ double powf_log2(uint32_t ix)        // log2 of a positive normal float, in double
+{
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = (int) ((tmp >> 19) & 15u);
+    const uint32_t top = tmp & 0xff800000u;
+    const int k = (int32_t) top >> 23;
+    const double invc = powf_log2_tab[i][0], logc = powf_log2_tab[i][1];
+    const double z = (double) __uint_as_float(ix - top);
+    const double r = __fma_rn(z, invc, -1.0), y0 = __dadd_rn(logc, (double) k);
+    const double r2 = __dmul_rn(r, r);
+    double y = __fma_rn(0x1.27616c9496e0bp-2, r, -0x1.71969a075c67ap-2);
+    const double p = __fma_rn(0x1.ec70a6ca7baddp-2, r, -0x1.7154748bef6c8p-1);
+    const double r4 = __dmul_rn(r2, r2);
+    double q = __fma_rn(0x1.71547652ab82bp0, r, y0);
+    q = __fma_rn(p, r2, q);
+    return __fma_rn(y, r4, q);
+}
+
+__device__ __forceinline__ float exp2_tail(double r, unsigned long long ki, double c0, double c1, double c2)
+{
+    unsigned long long t = exp2f_tab[ki & 31u];
+    t += ki << 47;
+    const double s = __longlong_as_double((long long) t);
+    const double z = __fma_rn(c0, r, c1), r2 = __dmul_rn(r, r);
+    double y = __fma_rn(c2, r, 1.0);
+    y = __fma_rn(z, r2, y);
+    return __double2float_rn(__dmul_rn(y, s));
+}
+
+// powf(x, y) for a positive, finite, normal x (CAgc: x = 10); any y
+__device__ __forceinline__ float powf_glibc_pos(float x, float y)
+{
+    const uint32_t ix = __float_as_uint(x), iy = __float_as_uint(y);
+    if (2u * iy - 1u >= 2u * 0x7f800000u - 1u) {                       // y is 0, inf or nan
+        if (2u * iy == 0u) return 1.0f;
+        if (ix == 0x3f800000u) return 1.0f;
+        if (2u * iy > 2u * 0x7f800000u) return __fadd_rn(x, y);
+        if ((2u * ix < 2u * 0x3f800000u) == !(iy & 0x80000000u)) return 0.0f;     // |x| < 1 && y == inf or |x| > 1 && y == -inf
+        return __fmul_rn(y, y);
+    }
+    const double ylogx = __dmul_rn((double) y, powf_log2(ix));
+    if ((((unsigned long long) __double_as_longlong(ylogx) >> 47) & 0xffffull) >= ((unsigned long long) __double_as_longlong(126.0) >> 47)) {
+        if (ylogx > 0x1.fffffffd1d571p+6) return __builtin_huge_valf();           // overflow
+        if (ylogx <= -150.0) return 0.0f;                                          // underflow
+    }
+    const double SHIFT = 0x1.8p+52 / 32;
+    double kd = __dadd_rn(ylogx, SHIFT);
+    const unsigned long long ki = (unsigned long long) __double_as_longlong(kd);
+    kd = __dsub_rn(kd, SHIFT);
+    return exp2_tail(__dsub_rn(ylogx, kd), ki, 0x1.c6af84b912394p-5, 0x1.ebfce50fac4f3p-3, 0x1.62e42ff0c52d6p-1);
+}
+
+__device__ __forceinline__ float expf_glibc(float x)
+{
+    const uint32_t ux = __float_as_uint(x), abstop = (ux >> 20) & 0x7ffu;
+    if (abstop >= (0x42b00000u >> 20)) {                               // |x| >= 88 or nan
+        if (ux == 0xff800000u) return 0.0f;
+        if (abstop >= (0x7f800000u >> 20)) return __fadd_rn(x, x);
+        if (x > 0x1.62e42ep6f) return __builtin_huge_valf();
+        if (x < -0x1.9fe368p6f) return 0.0f;
+    }
+    const double xd = (double) x, InvLn2N = 0x1.71547652b82fep+0 * 32, SHIFT = 0x1.8p+52;
+    const double z = __dmul_rn(InvLn2N, xd);
+    double kd = __dadd_rn(z, SHIFT);
+    const unsigned long long ki = (unsigned long long) __double_as_longlong(kd);
+    kd = __dsub_rn(kd, SHIFT);
+    const double r = __fma_rn(InvLn2N, xd, -kd);                       // the FMA build's residual (see the head of this file)
+    return exp2_tail(r, ki, 0x1.c6af84b912394p-5 / 32 / 32 / 32, 0x1.ebfce50fac4f3p-3 / 32 / 32, 0x1.62e42ff0c52d6p-1 / 32);
 }
 }  // namespace kg_libm
 #endif

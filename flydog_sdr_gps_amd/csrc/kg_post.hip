@@ -5,9 +5,9 @@
 // rx/rx_sound.cpp:766-787 (AM + m_AM_FIR), :845-877 (NBFM + m_Squelch), :898-907 (de-emphasis); rx/CuteSDR/fir.cpp (CFir),
 // rx/CuteSDR/squelch.cpp (CSquelch).  TYPEREAL is float there and the
 // literals are double, so the expressions below keep the reference's operand types
-// (the library is built with -ffp-contract=off): the only operation that can differ
-// from the CPU path is powf (device libm vs the host's) -- log10f, which CAgc BRANCHES on, is the
-// host libm's algorithm restated on the device (kg_libm.h: bit-identical on every float, round 6).
+// (the library is built with -ffp-contract=off), and log10f (which CAgc BRANCHES on) and powf are the
+// host libm's algorithms restated on the device (kg_libm.h: bit-identical on every argument, round 6):
+// nothing in this file computes differently from the reference built on this image.
 //
 // One wavefront per channel.  What the reference does with circular buffers is
 // restated so that most of it runs in parallel over the samples of the call:
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(64) void post_kernel(
             const float mag = magsel[j];
             float gain;
             if (mag <= c.knee) gain = c.fixed_gain;
-            else gain = AGC_OUTSCALE * powf(10.0, mag * (c.gain_slope - 1.0));
+            else gain = AGC_OUTSCALE * kg_libm::powf_glibc_pos(10.0f, (float) (mag * (c.gain_slope - 1.0)));    // the host libm's powf (kg_libm.h)
             // written in this launch for j >= D, by an earlier one otherwise
             const float2 d = j >= D ? in[j - D] : rin[(cnt + j - D) & (POST_CIRC - 1)];
             y.x = d.x * gain; y.y = d.y * gain;
@@ -674,20 +674,25 @@ int kg_post_set_mode(kg_post *p, int ch, int mode)
     return KG_OK;
 }
 
-// ---- the log10f of the S-meter and CAgc over an array: what tests/test_libm_gpu.py compares with the image's libm
-__global__ void math_log10f_kernel(const float *__restrict__ x, unsigned first, size_t n, float *__restrict__ y)
+// ---- the three libm functions the device code calls, over an array: what tests/test_libm_gpu.py compares with the image's libm
+__global__ void math_kernel(int fn, float base, const float *__restrict__ x, unsigned first, size_t n, float *__restrict__ y)
 {
-    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x)
-        y[i] = kg_libm::log10f_glibc(x ? x[i] : __uint_as_float(first + (unsigned) i));
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) {
+        const float v = x ? x[i] : __uint_as_float(first + (unsigned) i);
+        y[i] = fn == KG_MATH_LOG10F ? kg_libm::log10f_glibc(v) : fn == KG_MATH_POWF ? kg_libm::powf_glibc_pos(base, v) : kg_libm::expf_glibc(v);
+    }
 }
 
-int kg_math_log10f_dev(kg_ctx *ctx, const void *d_x, uint32_t first_bits, size_t n, void *d_y)
+int kg_math_dev(kg_ctx *ctx, int fn, float base, const void *d_x, uint32_t first_bits, size_t n, void *d_y)
 {
     int rc = kg_ctx_use(ctx);
     if (rc) return rc;
-    KG_REQUIRE(d_y && n >= 1 && ((uintptr_t) d_y & 3) == 0 && ((uintptr_t) d_x & 3) == 0, KG_ERR_INVALID, "kg_math_log10f_dev: bad argument");
+    KG_REQUIRE(d_y && n >= 1 && ((uintptr_t) d_y & 3) == 0 && ((uintptr_t) d_x & 3) == 0, KG_ERR_INVALID, "kg_math_dev: bad argument");
+    KG_REQUIRE(fn == KG_MATH_LOG10F || fn == KG_MATH_POWF || fn == KG_MATH_EXPF, KG_ERR_INVALID, "kg_math_dev: unknown function");
+    KG_REQUIRE(fn != KG_MATH_POWF || (base >= 1.17549435e-38f && base < __builtin_huge_valf()), KG_ERR_INVALID,
+               "kg_math_dev: powf's base must be positive, finite and normal (CAgc's is 10)");
     const size_t blocks = (n + 255) / 256;
-    hipLaunchKernelGGL(math_log10f_kernel, dim3((unsigned) (blocks < 16384 ? blocks : 16384)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(math_kernel, dim3((unsigned) (blocks < 16384 ? blocks : 16384)), dim3(256), 0, ctx->stream, fn, base,
                        (const float *) d_x, first_bits, n, (float *) d_y);
     KG_HIP(hipGetLastError());
     return KG_OK;

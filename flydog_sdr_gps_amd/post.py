@@ -203,9 +203,12 @@ class Post:
         return avg, taps
 
 
-def log10f(ctx, x=None, first_bits=0, n=None):
-    """kg_math_log10f_dev: the S-meter's / CAgc's log10f over an array (x), or over the n floats whose bit patterns start at
-    first_bits.  -> float32[n]"""
+MATH_LOG10F, MATH_POWF, MATH_EXPF = 0, 1, 2          # KG_MATH_*
+
+
+def math_dev(ctx, fn, x=None, first_bits=0, n=None, base=10.0):
+    """kg_math_dev: the device's log10f / powf(base, .) / expf -- the host libm's algorithms, csrc/kg_libm.h -- over an array (x), or
+    over the n floats whose bit patterns start at first_bits.  -> float32[n]"""
     if x is not None:
         x = np.ascontiguousarray(x, np.float32)
         n = x.size
@@ -216,8 +219,8 @@ def log10f(ctx, x=None, first_bits=0, n=None):
     try:
         if x is not None:
             ctx.upload(d_x, x)
-        check(ctx.lib.kg_math_log10f_dev(ctx.h, C.c_void_p(d_x) if d_x else None, int(first_bits) & 0xFFFFFFFF, n, C.c_void_p(d_y)),
-              "kg_math_log10f_dev")
+        check(ctx.lib.kg_math_dev(ctx.h, int(fn), float(base), C.c_void_p(d_x) if d_x else None, int(first_bits) & 0xFFFFFFFF, n,
+                                  C.c_void_p(d_y)), "kg_math_dev")
         ctx.sync()
         ctx.download(d_y, out)
     finally:
@@ -225,3 +228,7 @@ def log10f(ctx, x=None, first_bits=0, n=None):
         if d_x:
             ctx.free(d_x)
     return out
+
+
+def log10f(ctx, x=None, first_bits=0, n=None):
+    return math_dev(ctx, MATH_LOG10F, x, first_bits, n)

@@ -438,11 +438,15 @@ int kg_post_agc_delay(kg_post *post, int chan);           /* CAgc::GetDelaySampl
 int kg_post_set_smeter(kg_post *post, int chan, float frate);
 int kg_post_set_mode(kg_post *post, int chan, int mode);
 int kg_post_get_mode(kg_post *post, int chan);              /* -> KG_POST_*, or < 0 */
-/* The log10f the S-meter and CAgc take of every sample (rx/rx_sound.cpp:687, rx/CuteSDR/agc.cpp:191) over an array: y[i] =
- * log10f(x[i]), or, with d_x NULL, of the float whose bit pattern is first_bits + i.  The reference calls the platform's libm;
- * the device function restates the GNU C Library 2.35 algorithm of this image (csrc/kg_libm.h) and equals it bit for bit, which
- * is what makes CAgc's branches (agc.cpp:215-240) the reference's own.  Enqueue only. */
-int kg_math_log10f_dev(kg_ctx *ctx, const void *d_x, uint32_t first_bits, size_t n, void *d_y);
+/* The three libm functions the device code of this path calls, over an array: y[i] = f(x[i]), or, with d_x NULL, f of the float
+ * whose bit pattern is first_bits + i.  KG_MATH_LOG10F: the S-meter's and CAgc's log10f (rx/rx_sound.cpp:687, rx/CuteSDR/agc.cpp:191;
+ * CAgc BRANCHES on it, :215-240); KG_MATH_POWF: powf(base, x), CAgc's gain with base 10 (agc.cpp:250-253; base positive, finite,
+ * normal); KG_MATH_EXPF: aperture_auto()'s IIR gain (rx/rx_waterfall.cpp:1199).  The reference calls the platform's libm; the device
+ * functions restate the GNU C Library 2.35 algorithms of this image (csrc/kg_libm.h) and equal them bit for bit on every argument
+ * (tests/test_libm_gpu.py, tools/check_libm.py --exhaustive), which is what makes the audio chain's outputs the reference's own bits.
+ * Enqueue only. */
+enum { KG_MATH_LOG10F = 0, KG_MATH_POWF = 1, KG_MATH_EXPF = 2 };
+int kg_math_dev(kg_ctx *ctx, int fn, float base, const void *d_x, uint32_t first_bits, size_t n, void *d_y);
 /* A new connection on the channel: sMeterAvg_dB = 0, z1 = 0 (rx_sound.cpp:244,250),
  * conn->last_sample = 0.  The AGC object persists across connections, as m_Agc[] does. */
 int kg_post_reset(kg_post *post, int chan);

@@ -342,6 +342,14 @@ void ko_libm_log10f(const float *x, float *y, size_t n);
 void ko_libm_log10f_bits(uint32_t first, size_t n, float *y);
 uint64_t ko_libm_check_range(uint32_t first, uint64_t n, uint64_t step, int fused, int threads, uint64_t *bad_logf,
                              uint64_t *bad_log10f, uint32_t *first_bad);
+float ko_powf_restated(float x, float y, int fused);
+float ko_expf_restated(float x, int fused, int fused_residual);
+void ko_libm_powf_bits(float base, uint32_t first, size_t n, float *y);
+void ko_libm_expf_bits(uint32_t first, size_t n, float *y);
+void ko_libm_powf(float base, const float *x, float *y, size_t n);
+void ko_libm_expf(const float *x, float *y, size_t n);
+uint64_t ko_libm_check_pow_exp(uint32_t first, uint64_t n, uint64_t step, int fused, int fused_residual, int threads,
+                               uint64_t *bad_pow10, uint64_t *bad_exp, uint64_t *bad_rand, uint64_t *nrand);
 
 #ifdef __cplusplus
 }

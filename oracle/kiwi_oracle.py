@@ -785,3 +785,41 @@ def libm_check_range(first, n, step=1, fused=True, threads=8):
     a, b, u = C.c_uint64(), C.c_uint64(), C.c_uint32()
     done = L.ko_libm_check_range(int(first), int(n), int(step), int(bool(fused)), int(threads), C.byref(a), C.byref(b), C.byref(u))
     return int(done), int(a.value), int(b.value), int(u.value)
+
+
+def libm_powf_bits(base, first, n):
+    y = np.empty(int(n), np.float32)
+    lib().ko_libm_powf_bits(C.c_float(float(base)), C.c_uint32(int(first)), C.c_size_t(int(n)), _p(y))
+    return y
+
+
+def libm_expf_bits(first, n):
+    y = np.empty(int(n), np.float32)
+    lib().ko_libm_expf_bits(C.c_uint32(int(first)), C.c_size_t(int(n)), _p(y))
+    return y
+
+
+def libm_powf(base, x):
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.empty_like(x)
+    lib().ko_libm_powf(C.c_float(float(base)), _p(x), _p(y), C.c_size_t(x.size))
+    return y
+
+
+def libm_expf(x):
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.empty_like(x)
+    lib().ko_libm_expf(_p(x), _p(y), C.c_size_t(x.size))
+    return y
+
+
+def libm_check_pow_exp(first, n, step=1, fused=True, fused_residual=True, threads=8):
+    """The restated powf(10, .) / expf / powf(random pairs) against libm over bit patterns first, first + step, ...
+    -> (values compared, powf(10, .) differences, expf differences, random-pair differences, random pairs)"""
+    L = lib()
+    L.ko_libm_check_pow_exp.argtypes = [C.c_uint32, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4
+    L.ko_libm_check_pow_exp.restype = C.c_uint64
+    a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+    done = L.ko_libm_check_pow_exp(int(first), int(n), int(step), int(bool(fused)), int(bool(fused_residual)), int(threads),
+                                   C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+    return int(done), int(a.value), int(b.value), int(c.value), int(d.value)

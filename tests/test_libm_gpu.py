@@ -1,7 +1,8 @@
-"""The device's log10f (csrc/kg_libm.h: the GNU C Library 2.35 algorithm restated) against the log10f of the image's libm -- the
-one the reference's S-meter and CAgc call and CAgc branches on -- through the C ABI (kg_math_log10f_dev): BIT-EXACT, NaNs as
-NaNs.  Every mantissa of two binades either side of 1 (the only place the mantissa enters), every exponent strided, the
-subnormals, the special values; tools/check_log10f.py --exhaustive walks all 2^31 + patterns (profiles/r06_log10f_exhaustive.txt)."""
+"""The device's log10f, powf and expf (csrc/kg_libm.h: the GNU C Library 2.35 algorithms restated) against the image's libm -- what
+the reference's S-meter, CAgc and aperture_auto() call, and CAgc branches on -- through the C ABI (kg_math_dev): BIT-EXACT, NaNs as
+NaNs.  log10f: every mantissa of two binades either side of 1 (the only place the mantissa enters), every exponent strided, the
+subnormals, the special values; powf(10, y) and expf: strided over all 2^32 arguments, dense where the receivers use them, the
+overflow / underflow edges.  tools/check_libm.py --exhaustive walks every argument (profiles/r06_libm_exhaustive.txt)."""
 import numpy as np
 import pytest
 
@@ -46,3 +47,34 @@ def test_the_values_the_receivers_take_it_of(gpu_ctx, oracle):
     for arg in ((pwr / smax).astype(np.float64) + 1e-30, pwr.astype(np.float64) / (32767.0 * 32767.0) + 1e-16):
         x = arg.astype(np.float32)
         assert np.all(same(post.log10f(gpu_ctx, x), oracle.libm_log10f(x)))
+
+
+def test_powf_and_expf_strided_over_every_argument(gpu_ctx, oracle):
+    bits = np.concatenate([np.arange(0, 1 << 32, 509, dtype=np.uint64).astype(np.uint32),                 # 8.4 M patterns, both signs, NaNs
+                           np.array([0, 0x80000000, 0x7f800000, 0xff800000, 0x7fc00000, 0x4202422f, 0xc27c65d9, 0x42b17218, 0x42b17219,
+                                     0xc2cff1b4, 0xc2cff1b5, 0x421a209a, 0x421a209b, 0xc23369f4, 0x3f800000, 0xbf800000, 1, 0x80000001], np.uint32)])
+    x = bits.view(np.float32)
+    for name, got, want in (("powf", post.math_dev(gpu_ctx, post.MATH_POWF, x, base=10.0), oracle.libm_powf(10.0, x)),
+                            ("expf", post.math_dev(gpu_ctx, post.MATH_EXPF, x), oracle.libm_expf(x)),
+                            ("powf 2.5", post.math_dev(gpu_ctx, post.MATH_POWF, x, base=2.5), oracle.libm_powf(2.5, x)),
+                            ("powf 0.3", post.math_dev(gpu_ctx, post.MATH_POWF, x, base=0.3), oracle.libm_powf(0.3, x))):
+        bad = np.flatnonzero(~same(got, want))
+        assert bad.size == 0, (name, [hex(int(b)) for b in bits[bad[:6]]], got[bad[:6]], want[bad[:6]])
+
+
+def test_powf_and_expf_where_the_receivers_use_them(gpu_ctx, oracle):
+    """CAgc's exponent mag * (slope - 1) for mag in (-8, 0] and slopes of 0 .. 10 dB (agc.cpp:250-253): all floats of [-8, -2^-20]; the
+    aperture IIR's -param * pwr / 255 for pwr in -213 .. 0 dBm."""
+    for first, n in ((0xb5800000, 0xc1000000 - 0xb5800000),):                  # -2^-20 .. -8: every float
+        for lo in range(0, n, 1 << 25):
+            m = min(1 << 25, n - lo)
+            got, want = post.math_dev(gpu_ctx, post.MATH_POWF, first_bits=first + lo, n=m, base=10.0), oracle.libm_powf_bits(10.0, first + lo, m)
+            assert np.all(same(got, want)), hex(first + lo)
+    rng = np.random.default_rng(12)
+    arg = (-rng.uniform(0.01, 20.0, 1 << 20).astype(np.float32) * rng.integers(-213, 1, 1 << 20).astype(np.float32) / 255.0).astype(np.float32)
+    assert np.all(same(post.math_dev(gpu_ctx, post.MATH_EXPF, arg), oracle.libm_expf(arg)))
+    assert np.all(same(post.math_dev(gpu_ctx, post.MATH_EXPF, -arg), oracle.libm_expf(-arg)))
+    with pytest.raises(Exception):
+        post.math_dev(gpu_ctx, post.MATH_POWF, arg[:4], base=-2.0)
+    with pytest.raises(Exception):
+        post.math_dev(gpu_ctx, 7, arg[:4])

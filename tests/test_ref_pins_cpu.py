@@ -468,23 +468,31 @@ def test_aperture_oracle_matches_reference_aperture_auto(oracle):
     assert len(reports) >= 5
 
 
-def test_log10f_restatement_equals_the_images_libm(oracle):
-    """The platform's log10f (GNU C Library 2.35: e_log10f.c over e_logf.c) restated in oracle/kiwi_oracle_libm.c against logf() and
-    log10f() of the libm the oracle is linked with: every 64th non-negative float, every float of [0.5, 2), subnormals, negatives;
-    fused and unfused multiply-adds.  0 differences (all 2 139 095 041 patterns: tools/check_log10f.py --exhaustive).  The DEVICE
-    copy (csrc/kg_libm.h) carries the same 16 x 2 table and constants: compared here as text."""
+def test_libm_restatements_equal_the_images_libm(oracle):
+    """The platform's log10f, powf and expf (GNU C Library 2.35: e_log10f.c over e_logf.c, e_powf.c, e_expf.c) restated in
+    oracle/kiwi_oracle_libm.c against the libm the oracle is linked with: every 64th float, every float of [0.5, 2), subnormals,
+    negatives; fused and unfused multiply-adds.  0 differences (every argument: tools/check_libm.py --exhaustive).  expf's residual
+    is the FMA build's on an FMA host (2 of 2^32 arguments tell: both are in the sample).  The DEVICE copy (csrc/kg_libm.h)
+    carries the same tables and constants: compared here as text."""
     import re
+    fma_host = "fma" in open("/proc/cpuinfo").read().split("flags", 1)[-1].split("\n", 1)[0].split()
     for fused in (True, False):
         for first, n, step in ((0, 0x7f800001, 64), (0x3f000000, 1 << 24, 1), (0, 0x00800000, 3), (0x80000000, 0x7fffffff, 4099)):
             done, bad_ln, bad_l10, where = oracle.libm_check_range(first, n, step, fused)
             assert done >= n // step and (bad_ln, bad_l10) == (0, 0), (fused, hex(first), bad_ln, bad_l10, hex(where))
+        for first, n, step in ((0, 1 << 32, 64), (0x42024200, 0x100, 1), (0xc27c6500, 0x100, 1), (0xb5800000, 1 << 23, 1)):
+            done, bad_p, bad_e, bad_r, nr = oracle.libm_check_pow_exp(first, n, step, fused, fma_host)
+            assert done >= n // step and (bad_p, bad_e, bad_r) == (0, 0, 0), (fused, hex(first), bad_p, bad_e, bad_r)
+    assert oracle.libm_check_pow_exp(0x42024200, 0x100, 1, True, not fma_host)[2] == 1          # the other residual: one argument tells
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dev_text = open(os.path.join(here, "flydog_sdr_gps_amd", "csrc", "kg_libm.h")).read()
+    cpu_text = open(os.path.join(here, "oracle", "kiwi_oracle_libm.c")).read()
+    dev_text, cpu_text = dev_text[dev_text.index("#ifndef KG_LIBM_H"):], cpu_text[cpu_text.index("#include"):]
     hexf = re.compile(r"-?0x[0-9a-f.]+p[-+]?\d+")
-    dev = hexf.findall(open(os.path.join(here, "flydog_sdr_gps_amd", "csrc", "kg_libm.h")).read())
-    cpu = hexf.findall(open(os.path.join(here, "oracle", "kiwi_oracle_libm.c")).read())
-    tab_dev, tab_cpu = [float.fromhex(v) for v in dev[:32]], [float.fromhex(v) for v in cpu[:32]]
-    assert len(tab_dev) == 32 and tab_dev == tab_cpu and tab_cpu[18:20] == [1.0, 0.0]
-    assert sorted(float.fromhex(v) for v in dev[32:]) == sorted(float.fromhex(v) for v in cpu[32:] if "p23" not in v)
-    for lit in ("3.3554432000e+07f", "7.9034151668e-07f", "4.3429449201e-01f", "3.0102920532e-01f"):
-        assert lit in open(os.path.join(here, "flydog_sdr_gps_amd", "csrc", "kg_libm.h")).read()
-        assert lit in open(os.path.join(here, "oracle", "kiwi_oracle_libm.c")).read()
+    dev, cpu = [float.fromhex(v) for v in hexf.findall(dev_text)], [float.fromhex(v) for v in hexf.findall(cpu_text)]
+    assert dev[:32] == cpu[:32] and cpu[18:20] == [1.0, 0.0] and len(dev) >= 80
+    assert sorted(set(dev)) == sorted(set(v for v in cpu if v != 2.0 ** 23))      # (the host's subnormal scaling 0x1p23f is log10f's two25 on the device)
+    hexi = re.compile(r"0x3f[ef][0-9a-f]{13}ull")
+    assert hexi.findall(dev_text) == hexi.findall(cpu_text) and len(hexi.findall(dev_text)) == 32
+    for lit in ("3.3554432000e+07f", "7.9034151668e-07f", "4.3429449201e-01f", "3.0102920532e-01f", "0x1.62e42ep6f", "-0x1.9fe368p6f"):
+        assert lit in dev_text and lit in cpu_text, lit

@@ -182,25 +182,22 @@ def trial_post():
         last_story["x%d" % seg] = x
         s16, demod, agc = P.process([0], x[None, :])
         avg, _ = ko.smeter_process(avg, alpha, x)
+        # BIT-EXACT (round 6): log10f (which CAgc branches on) and powf are the host libm's own algorithms on the device
+        # (csrc/kg_libm.h).  Rounds 4-5 held 1 LSB / 2e-5 / 2e-4 dB here and let a once-in-10^6 gain step through.
         if mode == post.MODE_SSB:
             want = a.process_s16(x)
-            dl = np.abs(s16[0].astype(int) - want.astype(int))
-            assert dl.max() <= 1 or np.abs(want).max() > 30000, ("post s16", dl.max())
+            assert np.array_equal(s16[0].astype(int), want.astype(int)), ("post s16", np.abs(s16[0].astype(int) - want.astype(int)).max())
         else:
             want = a.process_cpx(x)
-            scale = max(np.abs(want).max(), 1e-20)
-            err = np.abs(agc[0] - want)
-            # (rounds 4-5 let a constant gain step through here: CAgc branches on log10f() values and the device's libm differed
-            # from the host's by an ulp once in ~10^6 trials.  The device now takes log10f by the host libm's own algorithm --
-            # csrc/kg_libm.h, bit-identical on every float -- so a step is a failure like anything else.)
-            assert err.max() <= 2e-5 * scale, ("post cpx", err.max() / scale)
+            assert np.array_equal(np.ascontiguousarray(agc[0]).view(np.uint64), np.ascontiguousarray(want, np.complex64).view(np.uint64)), "post cpx"
             if mode == post.MODE_AM:
                 wd, z1 = ko.am_detect(z1, want)
+                assert np.array_equal(np.ascontiguousarray(demod[0]).view(np.uint32), np.asarray(wd, np.float32).view(np.uint32)), "post am"
             elif mode == post.MODE_NBFM:
                 wd, last = ko.nbfm_detect(last, want)
-                assert np.abs(demod[0] - wd).max() <= 2e-5 * 8192 + 2e-5 * np.abs(wd).max() + 1e-3, "post nbfm"
+                assert np.array_equal(np.ascontiguousarray(demod[0]).view(np.uint32), np.asarray(wd, np.float32).view(np.uint32)), "post nbfm"
         got_avg, _ = P.smeter([0])
-        assert abs(float(got_avg[0]) - avg) <= 2e-4, ("smeter", got_avg[0], avg)
+        assert np.float32(got_avg[0]).view(np.uint32) == np.float32(avg).view(np.uint32), ("smeter", got_avg[0], avg)
     P.close()
 
 
