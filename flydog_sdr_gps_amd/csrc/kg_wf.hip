@@ -25,6 +25,7 @@
 // order, so MAX/MIN/LAST/CMA reproduce the serial loop's result bit for bit.
 #include "kg_common.h"
 #include "kg_fft.h"
+#include "kg_libm.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -317,7 +318,11 @@ __global__ __launch_bounds__(256, 2) void wf_frame_kernel(
             // is never below 1e-30 (no denormal path), NaN stays NaN; the difference from log10f is a few 1e-6
             // in l, i.e. some 1e-5 dB, inside the bound the parity tests allow for the last ulp of log10f
             const float arg = p * scale + 1e-30f;
+#ifdef KG_EXP_WF_LOG10F
+            const float l = kg_libm::log10f_glibc(arg);
+#else
             const float l = __builtin_amdgcn_logf(arg) * 0.30102999566398120f;
+#endif
             float dB = (float) (10.0 * (double) l + (double) fft_offset);
             if (TAPS) { tap_pwr_out[(size_t) f * WF_WIDTH + px] = p; tap_db[(size_t) f * WF_WIDTH + px] = dB; }
             unsigned b;
