@@ -27,8 +27,10 @@
 #        dpump_ref     rx/data_pump.cpp (included by the driver)                  (snd_service: runs here, no transform)
 #        chan_ref      gps/channel.cpp + ephemeris.cpp + sats.cpp                  (CHANNEL::Start: runs here)
 #
-# NOT built, and why: rx/rx_sound.cpp (c2s_sound's inline S-meter / detector loops), the c2s_waterfall() parameter formulas
-#   -- bodies of server coroutines with no function of their own to call.
+#        sndpath_ref   rx/rx_sound.cpp:676-908 (a LINE RANGE of c2s_sound(): S-meter, detectors, SSB AGC, de-emphasis; cut at build
+#                                                         time, see below) + agc.cpp, fir.cpp, squelch.cpp      (runs here)
+# NOT built, and why: the rest of rx/rx_sound.cpp and the c2s_waterfall() parameter formulas -- bodies of server coroutines with no
+#   function of their own to call (and, unlike the range above, entangled with the connection's state).
 set -e
 REFERENCE=${REFERENCE:-/root/reference}
 HERE=$(cd "$(dirname "$0")" && pwd)
@@ -118,7 +120,30 @@ if [ -f "$HIPFFTW_H" ] && [ -f /opt/rocm/lib/libhipfftw.so ]; then
     GPSD=$(for d in $(find "$R/gps" -type d); do printf -- "-I%s " "$d"; done)
     $CXX $OPT $DEF $GPSD $FINC -no-pie -o "$OUT/chan_ref" "$HERE/ref/ref_chan_main.cpp" "$R/gps/channel.cpp" "$R/gps/ephemeris.cpp" \
         "$R/gps/sats.cpp" -lm $UNRES
-    FFT_BUILT=" fastfir_ref search_ref wf_ref dpump_ref chan_ref"
+    # c2s_sound()'s signal path between CFastFIR and the sound packet -- the S-meter loop, the AM and NBFM detectors with what follows
+    # them, the SSB AGC, the de-emphasis filters (rx/rx_sound.cpp:676-908) -- is the body of a server coroutine: no function to call,
+    # and the file as a whole needs the web server.  The STATEMENTS are compiled instead: the line ranges are cut out of the file where
+    # it lies into the temporary directory (deleted on exit; nothing of the text enters the repository or oracle/_ref/) and
+    # oracle/ref/ref_sndpath_main.cpp #includes them inside a function that declares c2s_sound()'s locals (by cuts of its own
+    # declaration lines where they are declarations).  Each cut is checked to begin and end where this recipe expects.  Linked with
+    # the reference's agc.cpp, fir.cpp, squelch.cpp in place.  No transform: runs HERE.
+    SND="$R/rx/rx_sound.cpp"
+    cut_lines() {   # file first last out 'text the first line must contain' 'text the last line must contain'
+        sed -n "${2}p" "$1" | grep -qF -- "$5" || { echo "build_ref.sh: $1:$2 is not '$5'"; exit 1; }
+        sed -n "${3}p" "$1" | grep -qF -- "$6" || { echo "build_ref.sh: $1:$3 is not '$6'"; exit 1; }
+        sed -n "${2},${3}p" "$1" > "$4"
+    }
+    mkdir -p "$W/sndcut"
+    cut_lines "$SND" 244 250 "$W/sndcut/snd_decls.inc" 'double z1 = 0;' 'float sMeterAvg_dB = 0, sMeter_dBm;'
+    cut_lines "$SND" 470 472 "$W/sndcut/snd_flags.inc" 'bool isNBFM = (mode_flags[s->mode] & IS_NBFM);' 'bool IQ_or_DRM_or_stereo = (mode_flags[s->mode] & IS_STEREO);'
+    cut_lines "$SND" 482 482 "$W/sndcut/snd_deemp.inc" 'bool do_de_emp = ' 'bool do_de_emp = '
+    cut_lines "$SND" 676 908 "$W/sndcut/snd_path.inc" 'TYPECPX *s_samps_c = fir_samps_c;' '}'
+    sed -n '907p' "$SND" | grep -qF '}' && sed -n '898p' "$SND" | grep -qF 'if (do_de_emp) {' || { echo "build_ref.sh: the de-emphasis block is not at rx_sound.cpp:898-908"; exit 1; }
+    ALLD=$(find "$R/rx" "$R/extensions" "$R/pkgs" -maxdepth 2 -type d | sed 's/^/-I/' | tr '\n' ' ')
+    $CXX $OPT $DEF $FINC $ALLD -I"$W/sndcut" '-DSND_CUT_DECLS="snd_decls.inc"' '-DSND_CUT_FLAGS="snd_flags.inc"' \
+        '-DSND_CUT_DEEMP="snd_deemp.inc"' '-DSND_CUT_PATH="snd_path.inc"' -no-pie -o "$OUT/sndpath_ref" "$HERE/ref/ref_sndpath_main.cpp" \
+        "$R/rx/CuteSDR/agc.cpp" "$R/rx/CuteSDR/fir.cpp" "$R/rx/CuteSDR/squelch.cpp" -lm $UNRES
+    FFT_BUILT=" fastfir_ref search_ref wf_ref dpump_ref chan_ref sndpath_ref"
 else
     echo "hipFFTW absent: the FFT-dependent reference files are not built"
     FFT_BUILT=""

@@ -1,0 +1,155 @@
+// Harness around the reference's OWN STATEMENTS for the signal path of c2s_sound() between CFastFIR and the sound packet:
+// /root/reference/rx/rx_sound.cpp lines 676-908 -- the S-meter loop, the out_samps_s2 bookkeeping, `switch (s->mode)` with the AM
+// detector + m_AM_FIR, the NBFM detector + clipper + m_Squelch, the SSB / CW AGC, and the de-emphasis filters.  Those statements are
+// the body of a server coroutine (no function to call), so oracle/build_ref.sh cuts the line range out of the file WHERE IT LIES at
+// build time (sed into a temporary directory that is deleted; nothing of it enters the repository) and this harness #includes the
+// cut in the middle of a function that declares the locals c2s_sound() declares -- most of them by cuts of the reference's own
+// declaration lines too:
+//     SND_CUT_DECLS   rx_sound.cpp:244-250   double z1; double frate = ext_update_get_sample_rateHz(); sMeterAlpha; sMeterAvg_dB, sMeter_dBm
+//     SND_CUT_FLAGS   rx_sound.cpp:470-472   isNBFM, isDRM, IQ_or_DRM_or_stereo        (per block, from mode_flags[])
+//     SND_CUT_DEEMP   rx_sound.cpp:482       do_de_emp
+//     SND_CUT_PATH    rx_sound.cpp:676-908   the path
+// CAgc, CFir, CSquelch are the reference's own (rx/CuteSDR/agc.cpp, fir.cpp, squelch.cpp linked in place), the de-emphasis tables
+// its rx_filter.h, mode_flags[] its mode.h.  Test infrastructure only.
+//
+// What the harness supplies (no arithmetic): the objects rx_sound.cpp:148-160 defines (m_Agc, m_Squelch, m_AM_FIR, m_nfm_deemp_FIR,
+// m_am_ssb_deemp_FIR; the two CFastFIR arrays are only DECLARED -- their constructors plan transforms, and the SAM case that names
+// one is never selected); snd_inst[] / one rx_dpump_t / one conn_t as zeroed storage; ext_update_get_sample_rateHz() returning the
+// script's rate; S_meter_cal (kiwi.json, default -13); a receive_S_meter hook that records the two taps; the configuration calls
+// rx_sound_cmd.cpp makes on `SET mod= / agc= / squelch= / de_emp=` as script lines.
+//
+//   sndpath_ref script.txt in.bin out.bin
+// script lines (the first must be R):
+//   R rate                                         -> the cut declarations run (z1 = 0, sMeterAlpha from rate, sMeterAvg_dB = 0); squelch SetupParameters
+//   A on hang thresh manGain slope decay           -> m_Agc[0].SetParameters(..., rate)                 (rx_sound_cmd.cpp:351)
+//   L hbw stop                                     -> m_AM_FIR[0].InitLPFilter(0, 1.0, 50.0, hbw, stop, rate)   (rx_sound_cmd.cpp:282)
+//   Q value max                                    -> m_Squelch[0].SetSquelch(value, max)                (rx_sound_cmd.cpp:430)
+//   E deemp deemp_nfm                              -> s->deemp / s->deemp_nfm and the InitConstFir calls of rx_sound_cmd.cpp:586-640
+//   M mode                                         -> s->mode (mode.h numbering)
+//   B n                                            -> n complex floats of in.bin = one CFastFIR output block; runs the cut; appends:
+//                                                     sMeterAvg_dB, sMeter_dBm, tap0, tap1, s->squelched, then n outputs as floats:
+//                                                     out_samps_s2 (mono modes) or nothing (IQ: the path leaves fir_samps_c alone)
+#include "types.h"           // rx_sound.cpp:20-64 in its own order (rsid.h, the RSID decoder's DRM resampler headers, left out)
+#include "options.h"
+#include "config.h"
+#include "kiwi.h"
+#include "mode.h"
+#include "printf.h"
+#include "rx.h"
+#include "rx_util.h"
+#include "clk.h"
+#include "mem.h"
+#include "misc.h"
+#include "str.h"
+#include "timer.h"
+#include "nbuf.h"
+#include "web.h"
+#include "spi.h"
+#include "gps.h"
+#include "coroutines.h"
+#include "cuteSDR.h"
+#include "rx_noise.h"
+#include "teensy.h"
+#include "agc.h"
+#include "fir.h"
+#include "iir.h"
+#include "squelch.h"
+#include "debug.h"
+#include "data_pump.h"
+#include "cfg.h"
+#include "mongoose.h"
+#include "ima_adpcm.h"
+#include "ext_int.h"
+#include "fastfir.h"
+#include "noiseproc.h"
+#include "lms.h"
+#include "dx.h"
+#include "noise_blank.h"
+#include "rx_sound.h"
+#include "rx_sound_cmd.h"
+#include "rx_waterfall.h"
+#include "rx_filter.h"
+#include "wdsp.h"
+#include "fpga.h"
+#include "rf_attn.h"
+#undef printf
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+snd_t snd_inst[MAX_RX_CHANS];                    // rx_sound.cpp:87
+CAgc m_Agc[MAX_RX_CHANS];                        // :148-160
+CSquelch m_Squelch[MAX_RX_CHANS];
+extern CFastFIR m_chan_null_FIR[MAX_RX_CHANS];   // (declared only: see the head of this file)
+CFir m_AM_FIR[MAX_RX_CHANS];
+CFir m_nfm_deemp_FIR[MAX_RX_CHANS];
+CFir m_am_ssb_deemp_FIR[MAX_RX_CHANS];
+int S_meter_cal = -13;                           // rx/rx_init.cpp:127, :140, :314
+static double g_rate;
+double ext_update_get_sample_rateHz(int) { return g_rate; }
+static float g_tap[2]; static int g_ntap;
+static void smeter_hook(int, float v) { if (g_ntap < 2) g_tap[g_ntap] = v; g_ntap++; }
+
+int main(int argc, char **argv)
+{
+    if (argc != 4) { fprintf(stderr, "usage: %s script in.bin out.bin\n", argv[0]); return 2; }
+    FILE *sf = fopen(argv[1], "r"), *inf = fopen(argv[2], "rb"), *outf = fopen(argv[3], "wb");
+    if (!sf || !inf || !outf) { fprintf(stderr, "cannot open files\n"); return 2; }
+    const int rx_chan = 0;
+    snd_t *s = &snd_inst[rx_chan];
+    rx_dpump_t *rx = (rx_dpump_t *) calloc(1, sizeof(rx_dpump_t));
+    conn_t *conn = (conn_t *) calloc(1, sizeof(conn_t));
+    int j, ns_out;
+    static TYPECPX fir_buf[FASTFIR_OUTBUF_SIZE];
+    char op;
+    if (fscanf(sf, " %c %lf", &op, &g_rate) != 2 || op != 'R') return 3;
+#include SND_CUT_DECLS
+    m_Squelch[rx_chan].SetupParameters(rx_chan, frate);          // rx_sound.cpp:261-262
+    m_Squelch[rx_chan].SetSquelch(0, 0);
+    s->mode = MODE_USB;
+    while (fscanf(sf, " %c", &op) == 1) {
+        if (op == 'A') {
+            int on, hang, thr, man, slope, decay;
+            if (fscanf(sf, "%d %d %d %d %d %d", &on, &hang, &thr, &man, &slope, &decay) != 6) return 3;
+            m_Agc[rx_chan].SetParameters(on, hang, thr, man, slope, decay, frate);
+        } else if (op == 'L') {
+            float hbw, stop;
+            if (fscanf(sf, "%f %f", &hbw, &stop) != 2) return 3;
+            m_AM_FIR[rx_chan].InitLPFilter(0, 1.0, 50.0, hbw, stop, frate);
+        } else if (op == 'Q') {
+            int v, mx;
+            if (fscanf(sf, "%d %d", &v, &mx) != 2) return 3;
+            m_Squelch[rx_chan].SetSquelch(v, mx);
+        } else if (op == 'E') {
+            int de, de_nfm;
+            if (fscanf(sf, "%d %d", &de, &de_nfm) != 2) return 3;
+            s->deemp = de; s->deemp_nfm = de_nfm;
+            const bool r12k = fabs(frate - 12000.0) < fabs(frate - 20250.0);         // snd_rate == SND_RATE_4CH
+            if (de)     m_am_ssb_deemp_FIR[rx_chan].InitConstFir(N_DEEMP_TAPS, r12k ? am_ssb_deemp_12000[de - 1] : am_ssb_deemp_20250[de - 1], frate);
+            if (de_nfm) m_nfm_deemp_FIR[rx_chan].InitConstFir(N_DEEMP_TAPS, r12k ? nfm_deemp_12000[de_nfm - 1] : nfm_deemp_20250[de_nfm - 1], frate);
+        } else if (op == 'M') {
+            int mode;
+            if (fscanf(sf, "%d", &mode) != 1) return 3;
+            s->mode = mode;
+        } else if (op == 'B') {
+            if (fscanf(sf, "%d", &ns_out) != 1 || ns_out < 1 || ns_out > FASTFIR_OUTBUF_SIZE) return 3;
+            if (fread(fir_buf, sizeof(TYPECPX), ns_out, inf) != (size_t) ns_out) return 4;
+            TYPECPX *fir_samps_c = fir_buf;
+            ext_receive_S_meter_t receive_S_meter = smeter_hook;
+            g_ntap = 0; g_tap[0] = g_tap[1] = 0;
+            rx->real_wr_pos = 0;
+#include SND_CUT_FLAGS
+#include SND_CUT_DEEMP
+            (void) isDRM;
+#include SND_CUT_PATH
+            const float hdr[5] = {sMeterAvg_dB, sMeter_dBm, g_tap[0], g_tap[1], (float) s->squelched};
+            fwrite(hdr, sizeof(float), 5, outf);
+            if (!IQ_or_DRM_or_stereo)
+                for (int i = 0; i < ns_out; i++) { const float v = (float) out_samps_s2[i]; fwrite(&v, sizeof v, 1, outf); }
+        } else return 3;
+    }
+    fclose(outf);
+    return 0;
+}

@@ -184,3 +184,165 @@ def aper_ref_replay(g, update, report):
                 st["signal"], st["noise"] = report(avg, start, stop)
         yield k, avg, (st["signal"], st["noise"], st["done"], st["report_sec"], st["clear"]), g["avg_pwr"][k], \
             tuple(int(v) for v in g["states"][k])
+
+
+# ---- c2s_sound()'s signal path as the reference's own statements ran it (tests/golden/sndpath_ref.npz) -------------------------
+SND_AM_MODES, SND_FM_MODES, SND_SSB_MODES, SND_IQ_MODES = (0, 1), (6, 16), (2, 3, 4, 5, 9, 10), (7, 8)      # rx/mode.h:69-70
+S_METER_CAL = -13
+
+
+class OracleSoundPath:
+    """One connection's path from the CFastFIR output to out_samps_s2, oracle side, driven by sndpath_ref's script lines."""
+
+    def __init__(self, ko, rate):
+        import numpy as np
+        self.ko, self.rate, self.np = ko, rate, np
+        self.a, self.am, self.sq, self.de_am, self.de_nfm = ko.Agc(), ko.CFir(), ko.Squelch(), ko.CFir(), ko.CFir()
+        self.sq.setup(rate)
+        self.sq.set_squelch(0, 0)
+        self.alpha, self.avg, self.z1, self.last = ko.smeter_alpha(rate), 0.0, 0.0, (0.0, 0.0)
+        self.mode, self.de, self.de_fm, self.squelched = 2, 0, 0, False
+
+    def agc(self, *prm):
+        self.a.set_parameters(*prm, self.rate)
+
+    def passband(self, lo, hi, hbw, stop):
+        self.am.init_lp(0, 1.0, 50.0, self.np.float32(hbw), self.np.float32(stop), self.rate)
+
+    def squelch(self, v, mx):
+        self.sq.set_squelch(v, mx)
+
+    def de_emp(self, de, de_fm):
+        from flydog_sdr_gps_amd import deemp
+        r12k = abs(self.rate - 12000.0) < abs(self.rate - 20250.0)
+        self.de, self.de_fm = de, de_fm
+        if de:
+            self.de_am.init_const(deemp.table(False, r12k)[de - 1], self.rate)
+        if de_fm:
+            self.de_nfm.init_const(deemp.table(True, r12k)[de_fm - 1], self.rate)
+
+    def set_mode(self, m):
+        self.mode = m
+
+    def block(self, x):
+        ko, np = self.ko, self.np
+        self.avg, taps = ko.smeter_process(self.avg, self.alpha, x)
+        out = None
+        if self.mode in SND_AM_MODES:
+            d, self.z1 = ko.am_detect(self.z1, self.a.process_cpx(x))
+            out = self.am.process_rm(d)
+        elif self.mode in SND_FM_MODES:
+            d, self.last = ko.nbfm_detect(self.last, self.a.process_cpx(x))
+            out, rc = self.sq.perform_fm(d)
+            if rc != 0:
+                self.squelched = rc == 1
+        elif self.mode in SND_SSB_MODES:
+            out = self.a.process_s16(x)
+        if out is not None:
+            fm = self.mode in SND_FM_MODES
+            if fm and self.de_fm:
+                out = self.de_nfm.process_mm(out)
+            elif not fm and self.de:
+                out = self.de_am.process_mm(out)
+        return np.float32(self.avg), np.float32(taps[0]), np.float32(taps[1]), self.squelched, out
+
+
+class GpuSoundPath:
+    """The same script through kg_post (one channel)."""
+
+    def __init__(self, P, rate):
+        import numpy as np
+        from flydog_sdr_gps_amd import post
+        self.P, self.rate, self.np, self.post = P, rate, np, post
+        self.r12k = abs(rate - 12000.0) < abs(rate - 20250.0)
+        P.set_smeter(0, rate); P.set_mode(0, post.MODE_SSB); P.reset(0)
+        P.squelch_setup(0, rate); P.squelch_set(0, 0, 0)
+        self.mode = 2
+
+    def agc(self, *prm):
+        self.P.set_agc(0, *prm, self.rate)
+
+    def passband(self, lo, hi, hbw, stop):
+        self.P.set_am_passband(0, lo, hi, self.rate)
+
+    def squelch(self, v, mx):
+        self.P.squelch_set(0, v, mx)
+
+    def de_emp(self, de, de_fm):
+        self.P.set_de_emp(0, de, 0, snd_rate_12k=self.r12k, frate=self.rate)
+        self.P.set_de_emp(0, de_fm, 1, snd_rate_12k=self.r12k, frate=self.rate)
+
+    def set_mode(self, m):
+        post = self.post
+        self.mode = m
+        self.P.set_mode(0, post.MODE_AM if m in SND_AM_MODES else post.MODE_NBFM if m in SND_FM_MODES else post.MODE_SSB if m in SND_SSB_MODES
+                        else post.MODE_IQ)
+
+    def block(self, x):
+        s16 = self.P.process([0], x[None, :])[0]
+        avg, taps = self.P.smeter([0])
+        _, sq, _ = self.P.squelch_state([0])
+        out = None if self.mode in SND_IQ_MODES else s16[0]
+        return self.np.float32(avg[0]), self.np.float32(taps[0, 0]), self.np.float32(taps[0, 1]), bool(sq[0]), out
+
+
+def sndpath_replay(g, name, make_chain):
+    """Runs scenario `name` of sndpath_ref.npz through make_chain(rate) and yields, per block,
+    (block index, mode, n, got = (avg, tap0, tap1, squelched, out), want = the same as the reference's statements produced them;
+    taps and sMeter_dBm without the S_meter_cal the reference adds)."""
+    import numpy as np
+    rate, lo, hi = (float(v) for v in g[name + "_band"])
+    x, y = g[name + "_in"], g[name + "_out"]
+    chain = make_chain(rate)
+    pos = ypos = blk = 0
+    mode = 2
+    for line in (str(l) for l in g[name + "_script"]):
+        f = line.split()
+        if f[0] == "R":
+            assert float(f[1]) == rate
+        elif f[0] == "A":
+            chain.agc(*[int(v) for v in f[1:7]])
+        elif f[0] == "L":
+            chain.passband(lo, hi, float(f[1]), float(f[2]))
+        elif f[0] == "Q":
+            chain.squelch(int(f[1]), int(f[2]))
+        elif f[0] == "E":
+            chain.de_emp(int(f[1]), int(f[2]))
+        elif f[0] == "M":
+            mode = int(f[1])
+            chain.set_mode(mode)
+        else:
+            n = int(f[1])
+            got = chain.block(x[pos:pos + n])
+            pos += n
+            avg, dbm, t0, t1, sq = y[ypos:ypos + 5]
+            ypos += 5
+            assert np.float32(avg) + np.float32(S_METER_CAL) == dbm                         # rx_sound.cpp:696
+            out = None
+            if mode not in SND_IQ_MODES:
+                out = y[ypos:ypos + n].astype(np.int32)
+                ypos += n
+            cal = np.float32(S_METER_CAL)
+            want = (np.float32(avg), np.float32(t0), np.float32(t1) if n >= 2 else None, bool(sq), out)
+            got = (got[0], np.float32(got[1]) + cal, (np.float32(got[2]) + cal) if n >= 2 else None, got[3], got[4])
+            yield blk, mode, n, got, want
+            blk += 1
+    assert pos == x.size and ypos == y.size
+
+
+def sndpath_check(g, name, make_chain, squelch_too=True):
+    """-> (blocks, samples compared); asserts equality of everything the reference's statements produced"""
+    import numpy as np
+    blocks = samples = 0
+    for blk, mode, n, got, want in sndpath_replay(g, name, make_chain):
+        for k, what in ((0, "sMeterAvg_dB"), (1, "S-meter tap j = 0"), (2, "S-meter tap j = n / 2")):
+            if want[k] is not None:
+                assert np.float32(got[k]).view(np.uint32) == np.float32(want[k]).view(np.uint32), (name, blk, mode, what, got[k], want[k])
+        if mode in SND_FM_MODES and squelch_too:
+            assert got[3] == want[3], (name, blk, "s->squelched", got[3], want[3])
+        if want[4] is not None:
+            assert np.array_equal(np.asarray(got[4]).astype(np.int32), want[4]), (
+                name, blk, mode, "out_samps_s2", int(np.abs(np.asarray(got[4]).astype(np.int32) - want[4]).max()))
+            samples += n
+        blocks += 1
+    return blocks, samples

@@ -496,3 +496,20 @@ def test_libm_restatements_equal_the_images_libm(oracle):
     assert hexi.findall(dev_text) == hexi.findall(cpu_text) and len(hexi.findall(dev_text)) == 32
     for lit in ("3.3554432000e+07f", "7.9034151668e-07f", "4.3429449201e-01f", "3.0102920532e-01f", "0x1.62e42ep6f", "-0x1.9fe368p6f"):
         assert lit in dev_text and lit in cpu_text, lit
+
+
+def test_sound_path_oracle_matches_the_references_own_statements(oracle):
+    """c2s_sound()'s signal path between CFastFIR and the sound packet -- rx/rx_sound.cpp:676-908, the reference's OWN STATEMENTS
+    cut out of the file at build time and compiled around its agc.cpp / fir.cpp / squelch.cpp (oracle/build_ref.sh,
+    oracle/ref/ref_sndpath_main.cpp; sndpath_ref.npz): S-meter average and taps, AM detector + m_AM_FIR, NBFM detector + clipper +
+    m_Squelch, the SSB / CW AGC, both de-emphasis filters, `s->squelched`; every mode family, both rates, ragged and one-sample
+    blocks, mode hops with state carried, silence and full scale.  The oracle's restatement: EQUAL, every value."""
+    from tests.fixtures import OracleSoundPath, sndpath_check
+    g = np.load(os.path.join(GOLD, "sndpath_ref.npz"))
+    names = [str(n) for n in g["names"]]
+    assert len(names) == 11
+    blocks = samples = 0
+    for name in names:
+        b, s = sndpath_check(g, name, lambda rate: OracleSoundPath(oracle, rate))
+        blocks, samples = blocks + b, samples + s
+    assert blocks >= 80 and samples >= 35000, (blocks, samples)

@@ -13,6 +13,8 @@ the outputs the reference's code produced for them.
   fir_ref.npz     CFir (rx/CuteSDR/fir.cpp): InitLPFilter / InitHPFilter / InitConstFir + the three real-valued
                   ProcessFilter paths -- the designed taps (read back through an impulse), inputs, outputs
   squelch_ref.npz CSquelch (rx/CuteSDR/squelch.cpp): SetupParameters / SetSquelch / Reset / PerformFMSquelch scripts
+  sndpath_ref.npz c2s_sound()'s own statements between CFastFIR and the sound packet (rx/rx_sound.cpp:676-908, cut at build time):
+                  S-meter, AM / NBFM detectors with m_AM_FIR / m_Squelch, SSB AGC, de-emphasis -- every mode family, both rates
   dpump_ref.npz   snd_service() (rx/data_pump.cpp): SPI buffers of rx_iq_t records + trailer -> in_samps rings, ticks, rescale
   chan_ref.npz    CHANNEL::Start (gps/channel.cpp): acquisition results -> the SPI commands that program a tracking channel
 """
@@ -280,6 +282,92 @@ with tempfile.TemporaryDirectory() as tmp:
         print("squelch_ref.npz: %-24s %5d floats in, %5d floats out" % (name, x.size, y.size))
 sq["names"] = np.array([s[0] for s in sq_scen])
 np.savez_compressed(os.path.join(GOLD, "squelch_ref.npz"), **sq)
+
+# ---- c2s_sound()'s signal path, the reference's own statements (rx/rx_sound.cpp:676-908 cut at build time) ---------------------
+# mode numbers: rx/mode.h:69-70
+M_AM, M_AMN, M_USB, M_LSB, M_CW, M_CWN, M_NBFM, M_IQ, M_DRM, M_USN, M_LSN, M_SAM, M_SAU, M_SAL, M_SAS, M_QAM, M_NNFM = range(17)
+rng = np.random.Generator(np.random.PCG64(0x5EED0061))
+
+
+def cpx_noise(n, level):
+    return (level * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+
+
+def am_sig(n, amp=4000.0, depth=0.6):
+    t = np.arange(n)
+    env = amp * (1 + depth * np.sin(2 * np.pi * t / 37.0) + 0.2 * np.sin(2 * np.pi * t / 11.0))
+    return (env * np.exp(2j * np.pi * 0.07 * t) + cpx_noise(n, 20.0)).astype(np.complex64)
+
+
+def fm_sig(n, quiet=True):
+    t = np.arange(n)
+    ph = 2 * np.pi * np.cumsum(0.02 * np.sin(2 * np.pi * t / 40.0))
+    return (5000.0 * np.exp(1j * ph) + cpx_noise(n, 6.0)).astype(np.complex64) if quiet else cpx_noise(n, 3000.0)
+
+
+def ssb_sig(n, amp=2500.0):
+    t = np.arange(n)
+    env = amp * np.where((t // 700) % 2 == 0, 0.1, 1.0) * np.exp(-t / 3000.0)
+    return (env * (np.exp(2j * np.pi * 0.031 * t) + 0.4 * np.exp(2j * np.pi * 0.113 * t)) + cpx_noise(n, 8.0)).astype(np.complex64)
+
+
+def passband(lo, hi, rate):
+    """hbw / stop of m_AM_FIR as rx_sound_cmd.cpp:268-282 derives them from the passband (float hbw, double frate)"""
+    hbw = np.float32(min(float(np.float32(max(abs(hi), abs(lo)))), rate / 2))
+    stop = np.float32(min(float(np.float32(float(hbw) * 1.8)), rate / 2))
+    return "L %r %r" % (float(hbw), float(stop))
+
+
+def blocks_of(sig, lens):
+    out, pos = [], 0
+    for n in lens:
+        out.append(sig[pos:pos + n]); pos += n
+    return out
+
+
+B6 = [512] * 6
+RAG = [512, 300, 212, 170, 342, 512, 1, 511, 512]
+sp_scen = [
+    # name, rate, (lo, hi) of the passband, script (without R / L), input blocks in B order
+    ("am_default", 12000.0, (-4900.0, 4900.0), ["A 1 0 -100 50 6 1000", "M %d" % M_AM] + ["B 512"] * 6, blocks_of(am_sig(3072), B6)),
+    ("amn_deemp", 12000.0, (-2500.0, 2500.0), ["A 1 0 -100 50 6 1000", "E 1 0", "M %d" % M_AMN] + ["B 512"] * 4 + ["E 2 0"] + ["B 512"] * 2,
+     blocks_of(am_sig(3072, 9000.0, 0.9), B6)),
+    ("usb_hang_ragged", 12000.0, (300.0, 2700.0), ["A 1 1 -90 50 3 500", "M %d" % M_USB] + ["B %d" % n for n in RAG], blocks_of(ssb_sig(sum(RAG)), RAG)),
+    ("lsb_cw_manual", 12000.0, (-2700.0, -300.0), ["A 0 0 -100 70 6 1000", "M %d" % M_LSB, "B 512", "B 512", "M %d" % M_CW, "B 512", "A 1 0 -130 50 0 100",
+                                                  "M %d" % M_CWN, "B 512", "B 512", "M %d" % M_USN, "B 512", "M %d" % M_LSN, "B 512"], blocks_of(ssb_sig(3584, 6000.0), [512] * 7)),
+    ("ssb_deemp", 12000.0, (300.0, 2700.0), ["A 1 0 -100 50 6 1000", "E 2 0", "M %d" % M_USB] + ["B 512"] * 4, blocks_of(ssb_sig(2048, 12000.0), [512] * 4)),
+    ("nbfm_squelch_80", 12000.0, (-6000.0, 6000.0), ["A 1 0 -100 50 6 1000", "Q 80 0", "M %d" % M_NBFM] + ["B 512"] * 12,
+     [fm_sig(512, False) for _ in range(3)] + [fm_sig(512) for _ in range(5)] + [fm_sig(512, False) for _ in range(4)]),
+    ("nnfm_deemp_forced_shut", 12000.0, (-3000.0, 3000.0), ["A 1 0 -100 50 6 1000", "E 0 1", "Q 0 0", "M %d" % M_NNFM, "B 512", "B 512", "Q 99 0", "B 512", "B 512",
+                                                           "Q 0 0", "B 512", "E 0 2", "B 512"], [fm_sig(512) for _ in range(6)]),
+    ("iq_smeter_only", 12000.0, (-5000.0, 5000.0), ["A 1 0 -100 50 6 1000", "M %d" % M_IQ] + ["B 512"] * 3, blocks_of(am_sig(1536, 300.0), [512] * 3)),
+    ("rate_20250_every_family", 20250.0, (-6000.0, 6000.0), ["A 1 1 -60 50 10 2000", "E 1 1", "M %d" % M_AM] + ["B 512"] * 3 + ["M %d" % M_NBFM, "Q 75 0"] + ["B 512"] * 3
+     + ["M %d" % M_USB] + ["B 512"] * 3, blocks_of(am_sig(1536), [512] * 3) + [fm_sig(512, False), fm_sig(512), fm_sig(512)] + blocks_of(ssb_sig(1536), [512] * 3)),
+    ("mode_hops_state_carried", 12000.0, (-4000.0, 4000.0), ["A 1 0 -100 50 6 1000", "E 1 2", "Q 70 0"] + sum([["M %d" % m, "B 400", "B 112"] for m in
+     (M_AM, M_NBFM, M_USB, M_AM, M_NNFM, M_CW, M_AMN, M_IQ)], []), sum([blocks_of(sg, [400, 112]) for sg in
+     (am_sig(512), fm_sig(512), ssb_sig(512), am_sig(512, 800.0), fm_sig(512, False), ssb_sig(512), am_sig(512), am_sig(512))], [])),
+    # (the IQ mode last: its AGC runs behind line 908, in the packet section -- a cut that ends at 908 leaves m_Agc untouched in that
+    #  mode, the server does not; nothing after an IQ block is compared)
+    ("silence_and_full_scale", 12000.0, (-4900.0, 4900.0), ["A 1 0 -100 50 6 1000", "M %d" % M_AM, "B 512", "B 512", "M %d" % M_NBFM, "B 512", "B 512", "M %d" % M_USB, "B 512", "B 512"],
+     [np.zeros(512, np.complex64), (30000.0 * np.exp(2j * np.pi * 0.05 * np.arange(512))).astype(np.complex64)] * 3),
+]
+sp = {}
+with tempfile.TemporaryDirectory() as tmp:
+    for name, rate, (lo, hi), script, blocks in sp_scen:
+        script = ["R %r" % rate, passband(lo, hi, rate)] + script
+        x = np.concatenate(blocks).astype(np.complex64)
+        assert x.size == sum(int(l.split()[1]) for l in script if l[0] == "B"), name
+        open(os.path.join(tmp, "s.txt"), "w").write("\n".join(script) + "\n")
+        x.tofile(os.path.join(tmp, "in.bin"))
+        run([os.path.join(REF, "sndpath_ref"), os.path.join(tmp, "s.txt"), os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")])
+        y = np.fromfile(os.path.join(tmp, "out.bin"), np.float32)
+        sp[name + "_script"] = np.array(script)
+        sp[name + "_band"] = np.array([rate, lo, hi], np.float64)
+        sp[name + "_in"] = x
+        sp[name + "_out"] = y
+        print("sndpath_ref.npz: %-26s %5d samples in, %5d floats out" % (name, x.size, y.size))
+sp["names"] = np.array([s_[0] for s_ in sp_scen])
+np.savez_compressed(os.path.join(GOLD, "sndpath_ref.npz"), **sp)
 
 # ---- data pump unpack -----------------------------------------------------------------------------
 rng = np.random.Generator(np.random.PCG64(0x5EED00D9))
