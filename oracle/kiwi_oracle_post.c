@@ -13,8 +13,11 @@
  * reference's assembler generates (oracle/build_ref.sh) and tests/golden/agc_ref.npz holds its
  * outputs; tests/test_ref_pins_cpu.py requires this restatement to reproduce them bit for bit.
  * S-meter and the AM / NBFM detectors live inside c2s_sound() (rx/rx_sound.cpp), which does not
- * link without the task / SPI runtime: PARITY UNPINNED.  Transcendentals are this host's libm
- * (log10f, powf, expf).
+ * link without the task / SPI runtime; PINNED (round 6) by the coroutine's OWN STATEMENTS -- lines 676-908, cut out of the file at
+ * build time and compiled around the reference's agc.cpp / fir.cpp / squelch.cpp (oracle/build_ref.sh, oracle/ref/ref_sndpath_main.cpp;
+ * tests/golden/sndpath_ref.npz, 11 scenarios over every mode family): tests/test_ref_pins_cpu.py requires this restatement to
+ * reproduce sMeterAvg_dB, its taps and every out_samps_s2 sample bit for bit.  Transcendentals are this host's libm
+ * (log10f, powf, expf; kiwi_oracle_libm.c restates them for the device's sake).
  */
 #include "kiwi_oracle.h"
 
