@@ -88,6 +88,29 @@ class WfParams:
                         fft_scale, fft_offset)
 
 
+def start_of_cf(zoom, cf_khz, ui_srate=32.0e6):
+    """`SET zoom=<z> cf=<kHz>` -> the start the `start=` form would carry (rx/rx_waterfall.cpp:379-383), float arithmetic."""
+    hz_per_start = _f32(ui_srate / (WF_WIDTH << MAX_ZOOM))
+    zoom = min(max(int(zoom), 0), MAX_ZOOM)
+    half_span = _f32((ui_srate / (1 << zoom)) / 2)
+    cf = _f32(_f32(cf_khz) * _f32(1000.0))
+    return float(_f32(_f32(cf - half_span) / hz_per_start))
+
+
+def scale_arrays(params, ui_srate=32.0e6, masked=()):
+    """wf_inst_t.fft_scale[] / .fft_scale_div2[] of the first plot_width_clamped pixels (rx/rx_waterfall.cpp:888-925): the zoom's
+    scale, 0 where the pixel's frequency lies inside one of the admin's masked ranges [(lo_Hz, hi_Hz), ...]."""
+    hz_per_start = _f32(ui_srate / (WF_WIDTH << MAX_ZOOM))
+    n = params.plot_width_clamped
+    scale = np.full(n, params.fft_scale, np.float32)
+    if len(masked):
+        i = np.arange(n, dtype=np.int64)
+        f = np.rint((int(params.start) + (i << (MAX_ZOOM - params.zoom))).astype(np.float32) * hz_per_start).astype(np.int64)   # :907
+        for lo, hi in masked:
+            scale[(f >= int(lo)) & (f <= int(hi))] = 0
+    return scale, (scale / np.float32(2)).astype(np.float32)
+
+
 def build_maps(fft_used, plot_width, plot_width_clamped, spectral_inversion=False):
     """wf_inst_t.fft2wf_map[] and .drop_sample[] for the "FFT >= plot" case (:798-830)."""
     i = np.arange(fft_used, dtype=np.int64)

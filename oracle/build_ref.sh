@@ -29,8 +29,9 @@
 #
 #        sndpath_ref   rx/rx_sound.cpp:676-908 (a LINE RANGE of c2s_sound(): S-meter, detectors, SSB AGC, de-emphasis; cut at build
 #                                                         time, see below) + agc.cpp, fir.cpp, squelch.cpp      (runs here)
-# NOT built, and why: the rest of rx/rx_sound.cpp and the c2s_waterfall() parameter formulas -- bodies of server coroutines with no
-#   function of their own to call (and, unlike the range above, entangled with the connection's state).
+#        wfcmd_ref     rx/rx_waterfall.cpp:365-529, 756-928 (LINE RANGES of c2s_waterfall(): the `SET zoom=` case, the map / scale /
+#                                                         mask construction; cut at build time) + support/str.cpp   (runs here)
+# NOT built: the rest of the two coroutines (connection handling, packet assembly, the noise blankers: outside SURVEY 8).
 set -e
 REFERENCE=${REFERENCE:-/root/reference}
 HERE=$(cd "$(dirname "$0")" && pwd)
@@ -143,7 +144,24 @@ if [ -f "$HIPFFTW_H" ] && [ -f /opt/rocm/lib/libhipfftw.so ]; then
     $CXX $OPT $DEF $FINC $ALLD -I"$W/sndcut" '-DSND_CUT_DECLS="snd_decls.inc"' '-DSND_CUT_FLAGS="snd_flags.inc"' \
         '-DSND_CUT_DEEMP="snd_deemp.inc"' '-DSND_CUT_PATH="snd_path.inc"' -no-pie -o "$OUT/sndpath_ref" "$HERE/ref/ref_sndpath_main.cpp" \
         "$R/rx/CuteSDR/agc.cpp" "$R/rx/CuteSDR/fir.cpp" "$R/rx/CuteSDR/squelch.cpp" -lm $UNRES
-    FFT_BUILT=" fastfir_ref search_ref wf_ref dpump_ref chan_ref sndpath_ref"
+    # the same for what c2s_waterfall() derives from `SET zoom= start=` / `cf=` (rows W2, W6's map): the command's case block with the
+    # decimation / NCO words it hands to spi_set / spi_set3, and the fft_used / plot_width / map / scale / mask construction -- line ranges of
+    # rx/rx_waterfall.cpp cut into the temporary directory, #included by oracle/ref/ref_wfcmd_main.cpp in the coroutine's own order;
+    # kiwi_str_begins_with is the reference's (support/str.cpp in place).  Runs HERE.
+    WFC="$R/rx/rx_waterfall.cpp"
+    mkdir -p "$W/wfcut"
+    cut_lines "$WFC" 67 69 "$W/wfcut/wf_macros.inc" '#define MAX_FFT_USED' '#define	MAX_START(z)'
+    cut_lines "$WFC" 217 221 "$W/wfcut/wf_bits.inc" '#define	CMD_ZOOM	0x01' '#define	CMD_ALL'
+    cut_lines "$WFC" 253 269 "$W/wfcut/wf_locals.inc" 'int i, j, k, n;' 'int wf_cal = waterfall_cal;'
+    cut_lines "$WFC" 271 283 "$W/wfcut/wf_init.inc" 'wf = &WF_SHMEM->wf_inst[rx_chan];' 'int n_chunks = WF_SHMEM->n_chunks;'
+    cut_lines "$WFC" 365 529 "$W/wfcut/wf_zoom.inc" 'case CMD_SET_ZOOM: {' '}'
+    sed -n '528p' "$WFC" | grep -qF 'break;' && sed -n '531p' "$WFC" | grep -qF 'case CMD_SET_MAX_MIN_DB:' || { echo "build_ref.sh: the CMD_SET_ZOOM case does not end at rx_waterfall.cpp:529"; exit 1; }
+    cut_lines "$WFC" 756 928 "$W/wfcut/wf_maps.inc" 'wf->fft_used = WF_C_NFFT / WF_USING_HALF_FFT;' '}'
+    sed -n '927p' "$WFC" | grep -qF 'new_scale_mask = false;' || { echo "build_ref.sh: the scale / mask block does not end at rx_waterfall.cpp:928"; exit 1; }
+    $CXX $OPT $DEF $FINC $ALLD -I"$W/wfcut" '-DWF_CUT_MACROS="wf_macros.inc"' '-DWF_CUT_BITS="wf_bits.inc"' '-DWF_CUT_LOCALS="wf_locals.inc"' \
+        '-DWF_CUT_INIT="wf_init.inc"' '-DWF_CUT_ZOOM="wf_zoom.inc"' '-DWF_CUT_MAPS="wf_maps.inc"' -no-pie -o "$OUT/wfcmd_ref" \
+        "$HERE/ref/ref_wfcmd_main.cpp" "$R/support/str.cpp" -lm $UNRES
+    FFT_BUILT=" fastfir_ref search_ref wf_ref dpump_ref chan_ref sndpath_ref wfcmd_ref"
 else
     echo "hipFFTW absent: the FFT-dependent reference files are not built"
     FFT_BUILT=""

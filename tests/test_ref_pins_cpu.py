@@ -513,3 +513,57 @@ def test_sound_path_oracle_matches_the_references_own_statements(oracle):
         b, s = sndpath_check(g, name, lambda rate: OracleSoundPath(oracle, rate))
         blocks, samples = blocks + b, samples + s
     assert blocks >= 80 and samples >= 35000, (blocks, samples)
+
+
+def test_waterfall_commands_match_the_references_own_statements(oracle):
+    """What a waterfall connection derives from `SET zoom= start=` / `SET zoom= cf=` -- rows W2 and W6's map -- against
+    c2s_waterfall()'s OWN STATEMENTS (rx/rx_waterfall.cpp:365-529, 756-928, cut out of the file at build time: oracle/build_ref.sh,
+    oracle/ref/ref_wfcmd_main.cpp; wfcmd_ref.npz): 5 configurations (30 / 32 MHz displays, spectral inversion, the admin's masked
+    ranges) x 110 commands in sequence (every zoom at its edges and beyond them, the cf form with out-of-range zooms, pans).
+    The decimation word and the 48-bit NCO offset it hands to the SPI driver, the clamped start, fft_used, plot_width(_clamped),
+    fft_offset, fft2wf_map[], drop_sample[], fft_scale[], fft_scale_div2[]: the host mirror (flydog_sdr_gps_amd/wf.py) AND the
+    oracle (ko_wf_params_for / ko_wf_build_maps) EQUAL, every value."""
+    import re
+    from flydog_sdr_gps_amd import wf
+    g = np.load(os.path.join(GOLD, "wfcmd_ref.npz"))
+    CmdSetWFDecim, CmdSetWFFreq = 1, 2                        # the harness's tags for the reference's enum values
+    ncmd = rebuilt = masked = 0
+    for name in (str(n) for n in g["names"]):
+        adc, srate, inv = g[name + "_cfg"]
+        inv = bool(inv)
+        masks = [tuple(int(v) for v in m) for m in g[name + "_masks"]]
+        mpos = dpos = 0
+        last_zoom = -1
+        for k, cmd in enumerate(str(c) for c in g[name + "_cmds"]):
+            nspi, zoom, start, wait_ms, wait_us, fft_used, pw, pwc, limit, had = (int(v) for v in g[name + "_hdr"][k])
+            m = re.match(r"SET zoom=(-?\d+) (start|cf)=(\S+)", cmd)
+            z = min(max(int(m.group(1)), 0), 14)
+            st = float(m.group(3)) if m.group(2) == "start" else wf.start_of_cf(z, float(m.group(3)), ui_srate=srate)
+            prm = wf.WfParams.for_zoom(z, st, adc_clock=adc, ui_srate=srate, spectral_inversion=inv)
+            o = oracle.wf_params(z, st, adc_clock=adc, ui_srate=srate, spectral_inversion=inv)
+            for who, p in (("mirror", prm), ("oracle", o)):
+                assert (zoom, start, fft_used, pw, pwc) == (p.zoom, int(p.start), p.fft_used, p.plot_width, p.plot_width_clamped), (name, cmd, who)
+                assert np.float32(p.fft_offset) == g[name + "_fft_offset"][k], (name, cmd, who)
+                spi = g[name + "_spi"][k]
+                freq = spi[nspi - 1]
+                assert freq[0] == CmdSetWFFreq and ((int(freq[2]) << 16) | int(freq[3])) == int(p.i_offset) & 0xFFFFFFFFFFFF, (name, cmd, who)
+                assert (nspi == 2) == (z != last_zoom), (name, cmd)
+                if nspi == 2:
+                    assert spi[0][0] == CmdSetWFDecim and int(spi[0][2]) == int(p.decim), (name, cmd, who, spi[0], p.decim)
+            sc, d2 = wf.scale_arrays(prm, ui_srate=srate, masked=masks)
+            assert np.array_equal(sc.view(np.uint32), g[name + "_scale"][k][:pwc].view(np.uint32)), (name, cmd, "fft_scale")
+            assert np.array_equal(d2.view(np.uint32), g[name + "_div2"][k][:pwc].view(np.uint32)), (name, cmd, "fft_scale_div2")
+            assert np.float32(o.fft_scale) == np.float32(prm.fft_scale)
+            masked += int((sc == 0).sum())
+            assert had == (z != last_zoom) and limit == 0
+            if had:
+                want_map, want_drop = g[name + "_maps"][mpos:mpos + fft_used], g[name + "_drops"][dpos:dpos + pwc]
+                mpos, dpos = mpos + fft_used, dpos + pwc
+                for who, (fm, dr) in (("mirror", wf.build_maps(fft_used, pw, pwc, inv)), ("oracle", oracle.wf_build_maps(fft_used, pw, pwc, inv))):
+                    assert np.array_equal(np.asarray(fm, np.int64).astype(np.uint16), want_map), (name, cmd, who, "fft2wf_map")
+                    assert np.array_equal(np.asarray(dr, np.int64).astype(np.uint16)[:pwc], want_drop), (name, cmd, who, "drop_sample")
+                rebuilt += 1
+            last_zoom = z
+            ncmd += 1
+        assert mpos == g[name + "_maps"].size and dpos == g[name + "_drops"].size
+    assert ncmd == 550 and rebuilt > 200 and masked > 10000, (ncmd, rebuilt, masked)

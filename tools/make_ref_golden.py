@@ -15,6 +15,8 @@ the outputs the reference's code produced for them.
   squelch_ref.npz CSquelch (rx/CuteSDR/squelch.cpp): SetupParameters / SetSquelch / Reset / PerformFMSquelch scripts
   sndpath_ref.npz c2s_sound()'s own statements between CFastFIR and the sound packet (rx/rx_sound.cpp:676-908, cut at build time):
                   S-meter, AM / NBFM detectors with m_AM_FIR / m_Squelch, SSB AGC, de-emphasis -- every mode family, both rates
+  wfcmd_ref.npz   c2s_waterfall()'s own statements for `SET zoom= start= / cf=` (rx/rx_waterfall.cpp:365-529, 756-928, cut at build time):
+                  the SPI words (decimation, 48-bit NCO offset), fft_used / plot_width, fft2wf_map[], drop_sample[], fft_scale[] with masks
   dpump_ref.npz   snd_service() (rx/data_pump.cpp): SPI buffers of rx_iq_t records + trailer -> in_samps rings, ticks, rescale
   chan_ref.npz    CHANNEL::Start (gps/channel.cpp): acquisition results -> the SPI commands that program a tracking channel
 """
@@ -368,6 +370,65 @@ with tempfile.TemporaryDirectory() as tmp:
         print("sndpath_ref.npz: %-26s %5d samples in, %5d floats out" % (name, x.size, y.size))
 sp["names"] = np.array([s_[0] for s_ in sp_scen])
 np.savez_compressed(os.path.join(GOLD, "sndpath_ref.npz"), **sp)
+
+# ---- c2s_waterfall()'s `SET zoom=` case and its map / scale / mask construction, the reference's own statements -------------------
+# (rx/rx_waterfall.cpp:365-529, 756-928 cut at build time).  One connection per configuration; commands in sequence, as a client zooms
+# and pans (the case block sends the decimation word only when the zoom changes).
+rng = np.random.Generator(np.random.PCG64(0x5EED0062))
+MAXZ, WIDTH = 14, 1024
+wc_scen = []
+for cname, adc, srate, inv, masks in (("kiwi_30MHz", 66.6666e6, 30.0e6, 0, []), ("kiwi_32MHz", 66.672e6, 32.0e6, 0, []),
+                                       ("inverted_30MHz", 66.6660e6, 30.0e6, 1, []),
+                                       ("masked_30MHz", 66.6666e6, 30.0e6, 0, [(7000000, 7100000), (14250000, 14250500), (0, 30000)]),
+                                       ("masked_inverted_32MHz", 66.670e6, 32.0e6, 1, [(3500000, 3600000), (28000000, 29700000)])):
+    cmds = []
+    for z in range(MAXZ + 1):                                        # every zoom: the left edge, a random start, the right edge and beyond
+        maxstart = (WIDTH << MAXZ) - (WIDTH << (MAXZ - z))
+        for st in (0.0, float(rng.integers(0, maxstart + 1)), float(maxstart), float(maxstart) + 4096.0, float(rng.integers(0, maxstart + 1)) + 0.5):
+            cmds.append("SET zoom=%d start=%r" % (z, st))
+    for _ in range(30):                                              # the cf= form, zoom out of range clamped
+        cmds.append("SET zoom=%d cf=%r" % (int(rng.integers(-1, MAXZ + 3)), float(np.round(rng.uniform(0.0, srate / 1000.0), 3))))
+    for z, st in ((5, 1234567.0), (5, 1234567.0), (5, 1234999.0), (6, 1234999.0), (0, 0.0)):     # pans without a zoom change, a repeat
+        cmds.append("SET zoom=%d start=%r" % (z, st))
+    wc_scen.append((cname, adc, srate, inv, masks, cmds))
+wc = {}
+with tempfile.TemporaryDirectory() as tmp:
+    for cname, adc, srate, inv, masks, cmds in wc_scen:
+        script = ["C %r %r %d 9" % (adc, srate, inv)] + ["X %d %d" % m for m in masks] + ["K " + c for c in cmds]
+        open(os.path.join(tmp, "s.txt"), "w").write("\n".join(script) + "\n")
+        run([os.path.join(REF, "wfcmd_ref"), os.path.join(tmp, "s.txt"), os.path.join(tmp, "out.bin")])
+        y = np.fromfile(os.path.join(tmp, "out.bin"), np.float64)
+        # typed and compact: one header row per command, the maps only where the reference rebuilt them
+        hdr, spi, offs, maps, drops, scales, div2s, pos = [], [], [], [], [], [], [], 0
+        for _ in cmds:
+            nspi = int(y[pos]); pos += 1
+            calls = y[pos:pos + 4 * nspi].reshape(nspi, 4).astype(np.int64); pos += 4 * nspi
+            zoom, start, wait_ms, wait_us, fft_used, pw, pwc = (int(v) for v in y[pos:pos + 7])
+            off, limit, had = np.float32(y[pos + 7]), int(y[pos + 8]), int(y[pos + 9]); pos += 10
+            assert fft_used >= pw, "FFT < plot does not occur at these clocks"
+            if had:
+                maps.append(y[pos:pos + fft_used].astype(np.int64).astype(np.uint16)); pos += fft_used     # u2_t table: -1 is 65535
+                drops.append(y[pos:pos + pwc].astype(np.uint16)); pos += pwc
+            sc = np.zeros(WIDTH, np.float32); sc[:pwc] = y[pos:pos + pwc]; pos += pwc
+            d2 = np.zeros(WIDTH, np.float32); d2[:pwc] = y[pos:pos + pwc]; pos += pwc
+            hdr.append([nspi, zoom, start, wait_ms, wait_us, fft_used, pw, pwc, limit, had])
+            spi.append(np.vstack([calls, np.full((2 - nspi, 4), -2, np.int64)]) if nspi < 2 else calls)
+            offs.append(off); scales.append(sc); div2s.append(d2)
+        assert pos == y.size
+        wc[cname + "_cfg"] = np.array([adc, srate, inv], np.float64)
+        wc[cname + "_masks"] = np.array(masks, np.int64).reshape(-1, 2)
+        wc[cname + "_cmds"] = np.array(cmds)
+        wc[cname + "_hdr"] = np.array(hdr, np.int64)
+        wc[cname + "_spi"] = np.array(spi, np.int64)                  # [ncmd, 2, (cmd, wparam, lparam, w2param)]; -2 rows: no call
+        wc[cname + "_fft_offset"] = np.array(offs, np.float32)
+        wc[cname + "_maps"] = np.concatenate(maps)
+        wc[cname + "_drops"] = np.concatenate(drops)
+        wc[cname + "_scale"] = np.array(scales)
+        wc[cname + "_div2"] = np.array(div2s)
+        print("wfcmd_ref.npz: %-24s %3d commands, %d map rebuilds, %d masked pixels" % (
+            cname, len(cmds), len(maps), int(sum((s_[:h[7]] == 0).sum() for s_, h in zip(scales, hdr)))))
+wc["names"] = np.array([c[0] for c in wc_scen])
+np.savez_compressed(os.path.join(GOLD, "wfcmd_ref.npz"), **wc)
 
 # ---- data pump unpack -----------------------------------------------------------------------------
 rng = np.random.Generator(np.random.PCG64(0x5EED00D9))
