@@ -111,7 +111,21 @@ if [ -f "$HIPFFTW_H" ] && [ -f /opt/rocm/lib/libhipfftw.so ]; then
     # aperture_auto() (static, called by compute_frame() when wf->aper == AUTO) uses dB_wire_to_dBm() of rx/rx_util.cpp and
     # qsort_intcomp() of support/misc.cpp: both files linked in place; misc.cpp names DIR_CFG, which the reference's Makefile
     # passes (Makefile:278, :496)
-    $CXX $OPT $DEF $FINC '-DDIR_CFG=STRINGIFY(/root/kiwi.config)' -no-pie -o "$OUT/wf_ref" "$HERE/ref/ref_wf_main.cpp" \
+    cut_lines() {   # file first last out 'text the first line must contain' 'text the last line must contain'
+        sed -n "${2}p" "$1" | grep -qF -- "$5" || { echo "build_ref.sh: $1:$2 is not '$5'"; exit 1; }
+        sed -n "${3}p" "$1" | grep -qF -- "$6" || { echo "build_ref.sh: $1:$3 is not '$6'"; exit 1; }
+        sed -n "${2},${3}p" "$1" > "$4"
+    }
+    # sample_wf()'s unpack + window of the samples of one SPI chunk (row W3: rx_waterfall.cpp:1046-1066, with the declarations of
+    # :1011-1012) is a line range of a function that pulls its chunks over SPI between coroutine sleeps: cut at build time into the
+    # temporary directory and #included by the driver once per chunk of the test's frame (the ninth pass of the reference's own chunk
+    # loop re-windows a stale buffer, SURVEY 8 W3: the driver hands over every chunk fresh)
+    mkdir -p "$W/wfcut"
+    cut_lines "$R/rx/rx_waterfall.cpp" 1011 1012 "$W/wfcut/wf_window_decls.inc" 's4_t ii, qq;' 'iq_t *iqp;'
+    cut_lines "$R/rx/rx_waterfall.cpp" 1046 1066 "$W/wfcut/wf_window.inc" 'iqp = (iq_t*) &(miso->word[0]);' '}'
+    sed -n '1065p' "$R/rx/rx_waterfall.cpp" | grep -qF 'sn++;' || { echo "build_ref.sh: the window loop does not end at rx_waterfall.cpp:1066"; exit 1; }
+    $CXX $OPT $DEF $FINC -I"$W/wfcut" '-DWF_CUT_WINDOW_DECLS="wf_window_decls.inc"' '-DWF_CUT_WINDOW="wf_window.inc"' \
+        '-DDIR_CFG=STRINGIFY(/root/kiwi.config)' -no-pie -o "$OUT/wf_ref" "$HERE/ref/ref_wf_main.cpp" \
         "$R/rx/rx_waterfall.cpp" "$R/rx/csdr/ima_adpcm.cpp" "$R/rx/CuteSDR/noiseproc.cpp" "$R/rx/rx_util.cpp" "$R/support/misc.cpp" $FLIB
     # the data pump's unpack (rows A1, A2): no FFT is called, but data_pump.cpp's headers need the FFTW3 API header; the driver TU
     # includes rx/data_pump.cpp itself (snd_service() is static) and defines the SPI / scheduler entry points it calls.  Runs HERE.
@@ -129,11 +143,6 @@ if [ -f "$HIPFFTW_H" ] && [ -f /opt/rocm/lib/libhipfftw.so ]; then
     # declaration lines where they are declarations).  Each cut is checked to begin and end where this recipe expects.  Linked with
     # the reference's agc.cpp, fir.cpp, squelch.cpp in place.  No transform: runs HERE.
     SND="$R/rx/rx_sound.cpp"
-    cut_lines() {   # file first last out 'text the first line must contain' 'text the last line must contain'
-        sed -n "${2}p" "$1" | grep -qF -- "$5" || { echo "build_ref.sh: $1:$2 is not '$5'"; exit 1; }
-        sed -n "${3}p" "$1" | grep -qF -- "$6" || { echo "build_ref.sh: $1:$3 is not '$6'"; exit 1; }
-        sed -n "${2},${3}p" "$1" > "$4"
-    }
     mkdir -p "$W/sndcut"
     cut_lines "$SND" 244 250 "$W/sndcut/snd_decls.inc" 'double z1 = 0;' 'float sMeterAvg_dB = 0, sMeter_dBm;'
     cut_lines "$SND" 470 472 "$W/sndcut/snd_flags.inc" 'bool isNBFM = (mode_flags[s->mode] & IS_NBFM);' 'bool IQ_or_DRM_or_stereo = (mode_flags[s->mode] & IS_STEREO);'

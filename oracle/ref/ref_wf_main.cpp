@@ -14,9 +14,11 @@
 //     binary; here the script says what time it is (an input) -- and the configuration value waterfall_cal that rx_init.cpp reads
 //     from kiwi.json (default -13, rx_init.cpp:139, :315; the script gives it).  dB_wire_to_dBm() and qsort_intcomp() are the
 //     reference's own (rx/rx_util.cpp, support/misc.cpp, linked in place);
-//   * sample_wf()'s unpack + window of ONE frame (rx_waterfall.cpp:1046-1061: fi = (float)(s4_t)(s2_t) iq.i * window[sn]) with
-//     the reference's own window table, without the SPI chunk loop around it (whose 9th pass re-windows a stale buffer: SURVEY
-//     8(a) W3) -- two lines, restated here.
+//   * sample_wf()'s unpack + window (row W3) is the reference's own text too: its statements for the samples of one SPI chunk
+//     (rx_waterfall.cpp:1046-1066: iqp = miso's words; fi = (float)(s4_t)(s2_t) iqp->i * window[sn]; hw_c_samps[sn] = ...) are cut out of
+//     the file at build time (oracle/build_ref.sh, WF_CUT_WINDOW; declarations :1011-1012) and #included below once per chunk of
+//     NWF_SAMPS pairs, each chunk copied fresh from the test's frame into a SPI_MISO -- without sample_wf()'s SPI pulls and
+//     coroutine sleeps around them, whose ninth pass re-windows a stale buffer.
 //
 //   wf_ref script.txt in.bin out.bin
 // script lines:
@@ -118,11 +120,17 @@ int main(int argc, char **argv)
             if (fread(wf->fft_scale_div2, sizeof(float), WF_WIDTH, inf) != WF_WIDTH) return 4;
             static s2_t iq[WF_C_NSAMPS][2];
             if (fread(iq, sizeof iq, 1, inf) != 1) return 4;
-            const float *window = S->window_function[winf];
-            for (int sn = 0; sn < WF_C_NSAMPS; sn++) {                       // rx_waterfall.cpp:1049-1060
-                const s4_t ii = (s4_t) (s2_t) iq[sn][0], qq = (s4_t) (s2_t) iq[sn][1];
-                fft->hw_c_samps[sn][0] = ((float) ii) * window[sn];
-                fft->hw_c_samps[sn][1] = ((float) qq) * window[sn];
+            {   // sample_wf()'s own statements, one SPI chunk at a time
+                static SPI_MISO miso_storage;
+                SPI_MISO *miso = &miso_storage;
+                struct iq_t { u2_t i, q; } __attribute__((packed));       // rx_waterfall.cpp:95-97 (file-local there)
+                int k, sn = 0;
+#include WF_CUT_WINDOW_DECLS
+                for (int chunk = 0; sn < WF_C_NSAMPS; chunk++) {
+                    const int left = WF_C_NSAMPS - chunk * NWF_SAMPS, m = left < NWF_SAMPS ? left : NWF_SAMPS;
+                    memcpy(&miso->word[0], &iq[chunk * NWF_SAMPS][0], (size_t) m * 4);
+#include WF_CUT_WINDOW
+                }
             }
             compute_frame(0);
             const float hdr[5] = {(float) wf->out_bytes, (float) wf->fft_used_limit, (float) wf->out.x_bin_server,
