@@ -27,8 +27,9 @@
 #        dpump_ref     rx/data_pump.cpp (included by the driver)                  (snd_service: runs here, no transform)
 #        chan_ref      gps/channel.cpp + ephemeris.cpp + sats.cpp                  (CHANNEL::Start: runs here)
 #
-#        sndpath_ref   rx/rx_sound.cpp:676-908 (a LINE RANGE of c2s_sound(): S-meter, detectors, SSB AGC, de-emphasis; cut at build
-#                                                         time, see below) + agc.cpp, fir.cpp, squelch.cpp      (runs here)
+#        sndpath_ref   rx/rx_sound.cpp:676-908, 1035-1140, 1222-1253 (LINE RANGES of c2s_sound(): S-meter, detectors, SSB AGC, de-emphasis,
+#                                                         payload, header; cut at build time, see below) + agc.cpp, fir.cpp, squelch.cpp,
+#                                                         ima_adpcm.cpp      (runs here)
 #        wfcmd_ref     rx/rx_waterfall.cpp:365-529, 756-928 (LINE RANGES of c2s_waterfall(): the `SET zoom=` case, the map / scale /
 #                                                         mask construction; cut at build time) + support/str.cpp   (runs here)
 # NOT built: the rest of the two coroutines (connection handling, packet assembly, the noise blankers: outside SURVEY 8).
@@ -135,8 +136,9 @@ if [ -f "$HIPFFTW_H" ] && [ -f /opt/rocm/lib/libhipfftw.so ]; then
     GPSD=$(for d in $(find "$R/gps" -type d); do printf -- "-I%s " "$d"; done)
     $CXX $OPT $DEF $GPSD $FINC -no-pie -o "$OUT/chan_ref" "$HERE/ref/ref_chan_main.cpp" "$R/gps/channel.cpp" "$R/gps/ephemeris.cpp" \
         "$R/gps/sats.cpp" -lm $UNRES
-    # c2s_sound()'s signal path between CFastFIR and the sound packet -- the S-meter loop, the AM and NBFM detectors with what follows
-    # them, the SSB AGC, the de-emphasis filters (rx/rx_sound.cpp:676-908) -- is the body of a server coroutine: no function to call,
+    # c2s_sound()'s signal path between CFastFIR and the bytes of the sound packet -- the S-meter loop, the AM and NBFM detectors with what
+    # follows them, the SSB AGC, the de-emphasis filters (rx/rx_sound.cpp:676-908), the payload section (IQ AGC + (s2_t) pairs, ADPCM / raw,
+    # either byte order: 1035-1140), the header's S-meter field, flags and sequence number (1222-1253) -- is the body of a server coroutine: no function to call,
     # and the file as a whole needs the web server.  The STATEMENTS are compiled instead: the line ranges are cut out of the file where
     # it lies into the temporary directory (deleted on exit; nothing of the text enters the repository or oracle/_ref/) and
     # oracle/ref/ref_sndpath_main.cpp #includes them inside a function that declares c2s_sound()'s locals (by cuts of its own
@@ -145,14 +147,21 @@ if [ -f "$HIPFFTW_H" ] && [ -f /opt/rocm/lib/libhipfftw.so ]; then
     SND="$R/rx/rx_sound.cpp"
     mkdir -p "$W/sndcut"
     cut_lines "$SND" 244 250 "$W/sndcut/snd_decls.inc" 'double z1 = 0;' 'float sMeterAvg_dB = 0, sMeter_dBm;'
-    cut_lines "$SND" 470 472 "$W/sndcut/snd_flags.inc" 'bool isNBFM = (mode_flags[s->mode] & IS_NBFM);' 'bool IQ_or_DRM_or_stereo = (mode_flags[s->mode] & IS_STEREO);'
-    cut_lines "$SND" 482 482 "$W/sndcut/snd_deemp.inc" 'bool do_de_emp = ' 'bool do_de_emp = '
+    cut_lines "$SND" 252 255 "$W/sndcut/snd_pktinit.inc" 'strncpy(s->out_pkt_real.h.id, "SND", 3);' 's->seq = 0;'
+    cut_lines "$SND" 285 285 "$W/sndcut/snd_masked.inc" 'bool masked = false, masked_area = false, check_masked = false;' 'bool masked = false'
+    cut_lines "$SND" 295 295 "$W/sndcut/snd_overload.inc" 'bool squelched_overload = false;' 'bool squelched_overload = false;'
+    cut_lines "$SND" 461 482 "$W/sndcut/snd_flags.inc" '#define	SND_FLAG_LPF' 'bool do_de_emp = '
+    cut_lines "$SND" 488 497 "$W/sndcut/snd_hooks.inc" 'u2_t bc = 0;' 'tid_t receive_real_tid'
     cut_lines "$SND" 676 908 "$W/sndcut/snd_path.inc" 'TYPECPX *s_samps_c = fir_samps_c;' '}'
     sed -n '907p' "$SND" | grep -qF '}' && sed -n '898p' "$SND" | grep -qF 'if (do_de_emp) {' || { echo "build_ref.sh: the de-emphasis block is not at rx_sound.cpp:898-908"; exit 1; }
+    cut_lines "$SND" 1035 1140 "$W/sndcut/snd_packet.inc" '#define SILENCE_VALUE 1' '}'
+    sed -n '1100p' "$SND" | grep -qF 'if (!isDRM) {' && sed -n '1142p' "$SND" | grep -qF '#ifdef DRM' || { echo "build_ref.sh: the packet section is not at rx_sound.cpp:1035-1140"; exit 1; }
+    cut_lines "$SND" 1222 1253 "$W/sndcut/snd_header.inc" '#define SMETER_BIAS 127.0' 'wf->snd_seq = s->seq;'
     ALLD=$(find "$R/rx" "$R/extensions" "$R/pkgs" -maxdepth 2 -type d | sed 's/^/-I/' | tr '\n' ' ')
-    $CXX $OPT $DEF $FINC $ALLD -I"$W/sndcut" '-DSND_CUT_DECLS="snd_decls.inc"' '-DSND_CUT_FLAGS="snd_flags.inc"' \
-        '-DSND_CUT_DEEMP="snd_deemp.inc"' '-DSND_CUT_PATH="snd_path.inc"' -no-pie -o "$OUT/sndpath_ref" "$HERE/ref/ref_sndpath_main.cpp" \
-        "$R/rx/CuteSDR/agc.cpp" "$R/rx/CuteSDR/fir.cpp" "$R/rx/CuteSDR/squelch.cpp" -lm $UNRES
+    $CXX $OPT $DEF $FINC $ALLD -I"$W/sndcut" '-DSND_CUT_DECLS="snd_decls.inc"' '-DSND_CUT_PKTINIT="snd_pktinit.inc"' '-DSND_CUT_MASKED="snd_masked.inc"' \
+        '-DSND_CUT_OVERLOAD="snd_overload.inc"' '-DSND_CUT_FLAGS="snd_flags.inc"' '-DSND_CUT_HOOKS="snd_hooks.inc"' '-DSND_CUT_PATH="snd_path.inc"' \
+        '-DSND_CUT_PACKET="snd_packet.inc"' '-DSND_CUT_HEADER="snd_header.inc"' -no-pie -o "$OUT/sndpath_ref" "$HERE/ref/ref_sndpath_main.cpp" \
+        "$R/rx/CuteSDR/agc.cpp" "$R/rx/CuteSDR/fir.cpp" "$R/rx/CuteSDR/squelch.cpp" "$R/rx/csdr/ima_adpcm.cpp" -lm $UNRES
     # the same for what c2s_waterfall() derives from `SET zoom= start=` / `cf=` (rows W2, W6's map): the command's case block with the
     # decimation / NCO words it hands to spi_set / spi_set3, and the fft_used / plot_width / map / scale / mask construction -- line ranges of
     # rx/rx_waterfall.cpp cut into the temporary directory, #included by oracle/ref/ref_wfcmd_main.cpp in the coroutine's own order;

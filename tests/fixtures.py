@@ -189,10 +189,11 @@ def aper_ref_replay(g, update, report):
 # ---- c2s_sound()'s signal path as the reference's own statements ran it (tests/golden/sndpath_ref.npz) -------------------------
 SND_AM_MODES, SND_FM_MODES, SND_SSB_MODES, SND_IQ_MODES = (0, 1), (6, 16), (2, 3, 4, 5, 9, 10), (7, 8)      # rx/mode.h:69-70
 S_METER_CAL = -13
+SND_FLAG_ADC_OVFL, SND_FLAG_MODE_IQ, SND_FLAG_COMPRESSED, SND_FLAG_SQUELCH_UI, SND_FLAG_LITTLE_ENDIAN = 0x02, 0x08, 0x10, 0x40, 0x80   # rx_sound.cpp:461-468
 
 
 class OracleSoundPath:
-    """One connection's path from the CFastFIR output to out_samps_s2, oracle side, driven by sndpath_ref's script lines."""
+    """One connection's path from the CFastFIR output to the bytes of the sound packet, oracle side, driven by sndpath_ref's script."""
 
     def __init__(self, ko, rate):
         import numpy as np
@@ -202,6 +203,7 @@ class OracleSoundPath:
         self.sq.set_squelch(0, 0)
         self.alpha, self.avg, self.z1, self.last = ko.smeter_alpha(rate), 0.0, 0.0, (0.0, 0.0)
         self.mode, self.de, self.de_fm, self.squelched = 2, 0, 0, False
+        self.comp, self.le, self.ad = 1, False, None
 
     def agc(self, *prm):
         self.a.set_parameters(*prm, self.rate)
@@ -224,6 +226,9 @@ class OracleSoundPath:
     def set_mode(self, m):
         self.mode = m
 
+    def wire(self, comp, le):
+        self.comp, self.le = comp, bool(le)
+
     def block(self, x):
         ko, np = self.ko, self.np
         self.avg, taps = ko.smeter_process(self.avg, self.alpha, x)
@@ -238,7 +243,9 @@ class OracleSoundPath:
                 self.squelched = rc == 1
         elif self.mode in SND_SSB_MODES:
             out = self.a.process_s16(x)
-        if out is not None:
+        else:
+            out = self.a.process_cpx(x)                                              # the IQ modes' AGC, in the packet section (:1052)
+        if self.mode not in SND_IQ_MODES:
             fm = self.mode in SND_FM_MODES
             if fm and self.de_fm:
                 out = self.de_nfm.process_mm(out)
@@ -246,18 +253,35 @@ class OracleSoundPath:
                 out = self.de_am.process_mm(out)
         return np.float32(self.avg), np.float32(taps[0]), np.float32(taps[1]), self.squelched, out
 
+    def payload(self, out):
+        ko, np = self.ko, self.np
+        if self.mode in SND_IQ_MODES:
+            return ko.snd_iq_payload(out, self.le)
+        s16 = np.asarray(out).astype(np.int16)
+        if self.comp:
+            enc, self.ad = ko.adpcm_encode_i16(s16, self.ad)
+            return enc
+        return s16.astype("<i2" if self.le else ">i2").view(np.uint8)
+
+    def header(self, flags, seq, smeter_dbm):
+        return self.ko.snd_header(flags, seq, smeter_dbm)
+
 
 class GpuSoundPath:
-    """The same script through kg_post (one channel)."""
+    """The same script through kg_post, kg_adpcm / kg_snd_payload / kg_snd_iq_payload and kg_snd_header (one channel)."""
 
     def __init__(self, P, rate):
         import numpy as np
-        from flydog_sdr_gps_amd import post
-        self.P, self.rate, self.np, self.post = P, rate, np, post
+        from flydog_sdr_gps_amd import post, wire
+        self.P, self.rate, self.np, self.post, self.wire_mod = P, rate, np, post, wire
         self.r12k = abs(rate - 12000.0) < abs(rate - 20250.0)
         P.set_smeter(0, rate); P.set_mode(0, post.MODE_SSB); P.reset(0)
         P.squelch_setup(0, rate); P.squelch_set(0, 0, 0)
-        self.mode = 2
+        self.mode, self.comp, self.le = 2, 1, False
+        self.ad = wire.Adpcm(P.ctx, nchan=1)
+
+    def close(self):
+        self.ad.close()
 
     def agc(self, *prm):
         self.P.set_agc(0, *prm, self.rate)
@@ -278,24 +302,42 @@ class GpuSoundPath:
         self.P.set_mode(0, post.MODE_AM if m in SND_AM_MODES else post.MODE_NBFM if m in SND_FM_MODES else post.MODE_SSB if m in SND_SSB_MODES
                         else post.MODE_IQ)
 
+    def wire(self, comp, le):
+        self.comp, self.le = comp, bool(le)
+
     def block(self, x):
-        s16 = self.P.process([0], x[None, :])[0]
+        s16, _, agc = self.P.process([0], x[None, :])
         avg, taps = self.P.smeter([0])
         _, sq, _ = self.P.squelch_state([0])
-        out = None if self.mode in SND_IQ_MODES else s16[0]
+        out = agc[0] if self.mode in SND_IQ_MODES else s16[0]
         return self.np.float32(avg[0]), self.np.float32(taps[0, 0]), self.np.float32(taps[0, 1]), bool(sq[0]), out
 
+    def payload(self, out):
+        np, wire, ctx = self.np, self.wire_mod, self.P.ctx
+        if self.mode in SND_IQ_MODES:
+            return np.asarray(wire.snd_iq_payload(ctx, np.asarray(out, np.complex64)[None, :], self.le)).reshape(-1)
+        s16 = np.asarray(out, np.int16)
+        if self.comp:
+            return np.asarray(self.ad.encode([0], s16[None, :])).reshape(-1)
+        return np.asarray(wire.snd_payload(ctx, s16[None, :], self.le)).reshape(-1)
 
-def sndpath_replay(g, name, make_chain):
-    """Runs scenario `name` of sndpath_ref.npz through make_chain(rate) and yields, per block,
-    (block index, mode, n, got = (avg, tap0, tap1, squelched, out), want = the same as the reference's statements produced them;
-    taps and sMeter_dBm without the S_meter_cal the reference adds)."""
+    def header(self, flags, seq, smeter_dbm):
+        return self.np.asarray(self.wire_mod.snd_header(self.P.ctx, flags, seq, smeter_dbm))
+
+
+def sndpath_check(g, name, make_chain):
+    """Runs scenario `name` of sndpath_ref.npz through make_chain(rate) and asserts EQUALITY with what the reference's statements
+    produced: per CFastFIR block sMeterAvg_dB, the two S-meter taps (the reference adds S_meter_cal on the way to the hook),
+    s->squelched, out_samps_s2 resp. the IQ modes' AGC output; per packet the payload bytes and the header (flags, sequence number,
+    S-meter field).  The flag rules of rx_sound.cpp:1228-1233 and the packet's block grouping are the host's and restated here.
+    -> (packets, blocks, samples compared)"""
     import numpy as np
     rate, lo, hi = (float(v) for v in g[name + "_band"])
     x, y = g[name + "_in"], g[name + "_out"]
     chain = make_chain(rate)
-    pos = ypos = blk = 0
-    mode = 2
+    pos = ypos = npkt = nblk = samples = seq = 0
+    mode, comp, le, ovfl, sq = 2, 1, False, 0, False
+    cal = np.float32(S_METER_CAL)
     for line in (str(l) for l in g[name + "_script"]):
         f = line.split()
         if f[0] == "R":
@@ -311,38 +353,53 @@ def sndpath_replay(g, name, make_chain):
         elif f[0] == "M":
             mode = int(f[1])
             chain.set_mode(mode)
+        elif f[0] == "W":
+            comp, le = int(f[1]), bool(int(f[2]))
+            chain.wire(comp, le)
+        elif f[0] == "V":
+            ovfl = int(f[1])
         else:
-            n = int(f[1])
-            got = chain.block(x[pos:pos + n])
-            pos += n
-            avg, dbm, t0, t1, sq = y[ypos:ypos + 5]
-            ypos += 5
-            assert np.float32(avg) + np.float32(S_METER_CAL) == dbm                         # rx_sound.cpp:696
-            out = None
-            if mode not in SND_IQ_MODES:
-                out = y[ypos:ypos + n].astype(np.int32)
-                ypos += n
-            cal = np.float32(S_METER_CAL)
-            want = (np.float32(avg), np.float32(t0), np.float32(t1) if n >= 2 else None, bool(sq), out)
-            got = (got[0], np.float32(got[1]) + cal, (np.float32(got[2]) + cal) if n >= 2 else None, got[3], got[4])
-            yield blk, mode, n, got, want
-            blk += 1
+            iq = mode in SND_IQ_MODES
+            payload, dbm = [], None
+            for n in (int(v) for v in f[1:]):
+                avg, t0, t1, sq, out = chain.block(x[pos:pos + n])
+                pos += n
+                w_avg, w_dbm, w_t0, w_t1, w_sq = y[ypos:ypos + 5]
+                ypos += 5
+                where = (name, npkt, nblk, mode, n)
+                assert np.float32(avg).view(np.uint32) == np.float32(w_avg).view(np.uint32), (where, "sMeterAvg_dB", avg, w_avg)
+                assert np.float32(w_avg) + cal == w_dbm                                           # rx_sound.cpp:696
+                assert np.float32(t0) + cal == w_t0, (where, "S-meter tap j = 0")
+                if n >= 2:
+                    assert np.float32(t1) + cal == w_t1, (where, "S-meter tap j = n / 2")
+                if mode in SND_FM_MODES:
+                    assert sq == bool(w_sq), (where, "s->squelched", sq, w_sq)
+                if iq:
+                    want = y[ypos:ypos + 2 * n].view(np.complex64)
+                    ypos += 2 * n
+                    assert np.array_equal(np.ascontiguousarray(out, np.complex64).view(np.uint64), np.ascontiguousarray(want).view(np.uint64)), (where, "IQ AGC")
+                else:
+                    want = y[ypos:ypos + n].astype(np.int32)
+                    ypos += n
+                    assert np.array_equal(np.asarray(out).astype(np.int32), want), (where, "out_samps_s2", int(np.abs(np.asarray(out).astype(np.int32) - want).max()))
+                payload.append(np.asarray(chain.payload(out), np.uint8))
+                dbm = np.float32(w_dbm)
+                samples += n
+                nblk += 1
+            hsize, bc = int(y[ypos]), int(y[ypos + 1])
+            ypos += 2
+            pkt = y[ypos:ypos + hsize + bc].astype(np.uint8)
+            ypos += hsize + bc
+            payload = np.concatenate(payload)
+            assert payload.size == bc and np.array_equal(payload, pkt[hsize:]), (name, npkt, mode, "payload", payload.size, bc)
+            seq += 1
+            flags = (SND_FLAG_ADC_OVFL if ovfl else 0) | (SND_FLAG_MODE_IQ if iq else 0) | (SND_FLAG_COMPRESSED if comp and not iq else 0) \
+                | (SND_FLAG_SQUELCH_UI if sq else 0) | (SND_FLAG_LITTLE_ENDIAN if le else 0)
+            hdr = np.asarray(chain.header(flags, seq, float(dbm)), np.uint8)
+            assert hsize == (20 if iq else 10) and np.array_equal(hdr[:10], pkt[:10]), (name, npkt, mode, "header", hdr[:10], pkt[:10])
+            assert not pkt[10:hsize].any()                                                        # the IQ header's GPS stamp: set outside the cuts
+            npkt += 1
     assert pos == x.size and ypos == y.size
-
-
-def sndpath_check(g, name, make_chain, squelch_too=True):
-    """-> (blocks, samples compared); asserts equality of everything the reference's statements produced"""
-    import numpy as np
-    blocks = samples = 0
-    for blk, mode, n, got, want in sndpath_replay(g, name, make_chain):
-        for k, what in ((0, "sMeterAvg_dB"), (1, "S-meter tap j = 0"), (2, "S-meter tap j = n / 2")):
-            if want[k] is not None:
-                assert np.float32(got[k]).view(np.uint32) == np.float32(want[k]).view(np.uint32), (name, blk, mode, what, got[k], want[k])
-        if mode in SND_FM_MODES and squelch_too:
-            assert got[3] == want[3], (name, blk, "s->squelched", got[3], want[3])
-        if want[4] is not None:
-            assert np.array_equal(np.asarray(got[4]).astype(np.int32), want[4]), (
-                name, blk, mode, "out_samps_s2", int(np.abs(np.asarray(got[4]).astype(np.int32) - want[4]).max()))
-            samples += n
-        blocks += 1
-    return blocks, samples
+    if hasattr(chain, "close"):
+        chain.close()
+    return npkt, nblk, samples

@@ -499,20 +499,22 @@ def test_libm_restatements_equal_the_images_libm(oracle):
 
 
 def test_sound_path_oracle_matches_the_references_own_statements(oracle):
-    """c2s_sound()'s signal path between CFastFIR and the sound packet -- rx/rx_sound.cpp:676-908, the reference's OWN STATEMENTS
-    cut out of the file at build time and compiled around its agc.cpp / fir.cpp / squelch.cpp (oracle/build_ref.sh,
-    oracle/ref/ref_sndpath_main.cpp; sndpath_ref.npz): S-meter average and taps, AM detector + m_AM_FIR, NBFM detector + clipper +
-    m_Squelch, the SSB / CW AGC, both de-emphasis filters, `s->squelched`; every mode family, both rates, ragged and one-sample
-    blocks, mode hops with state carried, silence and full scale.  The oracle's restatement: EQUAL, every value."""
+    """c2s_sound()'s signal path between CFastFIR and the bytes of the sound packet -- rx/rx_sound.cpp:676-908, 1035-1140, 1222-1253, the
+    reference's OWN STATEMENTS cut out of the file at build time and compiled around its agc.cpp / fir.cpp / squelch.cpp /
+    ima_adpcm.cpp (oracle/build_ref.sh, oracle/ref/ref_sndpath_main.cpp; sndpath_ref.npz): S-meter average and taps, AM detector +
+    m_AM_FIR, NBFM detector + clipper + m_Squelch, the SSB / CW AGC, both de-emphasis filters, `s->squelched`, the IQ modes' AGC; the
+    payload (ADPCM with its state carried over packets, raw mono and (s2_t) IQ pairs in either byte order) and the header (flags, sequence
+    number, the clamped S-meter field); every mode family, both rates, ragged and one-sample blocks, mode hops with state carried,
+    silence, full scale, ADC overflow.  The oracle's restatement: EQUAL, every value and every byte."""
     from tests.fixtures import OracleSoundPath, sndpath_check
     g = np.load(os.path.join(GOLD, "sndpath_ref.npz"))
     names = [str(n) for n in g["names"]]
     assert len(names) == 11
-    blocks = samples = 0
+    packets = blocks = samples = 0
     for name in names:
-        b, s = sndpath_check(g, name, lambda rate: OracleSoundPath(oracle, rate))
-        blocks, samples = blocks + b, samples + s
-    assert blocks >= 80 and samples >= 35000, (blocks, samples)
+        p, b, s = sndpath_check(g, name, lambda rate: OracleSoundPath(oracle, rate))
+        packets, blocks, samples = packets + p, blocks + b, samples + s
+    assert packets >= 60 and blocks >= 100 and samples >= 50000, (packets, blocks, samples)
 
 
 def test_waterfall_commands_match_the_references_own_statements(oracle):

@@ -339,17 +339,19 @@ def test_aperture_on_the_gpu_matches_reference_aperture_auto(gpu_ctx):
 
 
 def test_sound_path_on_the_gpu_matches_the_references_own_statements(gpu_ctx):
-    """kg_post against rx/rx_sound.cpp:676-908 ITSELF (sndpath_ref.npz: the reference's statements, cut at build time, around its own
-    CAgc / CFir / CSquelch): sMeterAvg_dB and its taps, out_samps_s2 of every mode family with and without de-emphasis, the squelch
-    verdict -- BIT-EXACT on the GPU (log10f / powf are the host libm's algorithms on the device, csrc/kg_libm.h)."""
+    """kg_post, the payload kernels and kg_snd_header against rx/rx_sound.cpp:676-908, 1035-1140, 1222-1253 ITSELF (sndpath_ref.npz: the
+    reference's statements, cut at build time, around its own CAgc / CFir / CSquelch / ADPCM coder): sMeterAvg_dB and its taps,
+    out_samps_s2 of every mode family with and without de-emphasis, the IQ modes' AGC output, the squelch verdict, every payload byte
+    (ADPCM with carried state, raw and IQ pairs in either byte order) and every header -- BIT-EXACT on the GPU (log10f / powf are the
+    host libm's algorithms on the device, csrc/kg_libm.h)."""
     from tests.fixtures import GpuSoundPath, sndpath_check
     g = np.load(os.path.join(GOLD, "sndpath_ref.npz"))
-    blocks = samples = 0
+    packets = blocks = samples = 0
     for name in (str(n) for n in g["names"]):
         P = Post(gpu_ctx, nchan=1)
         try:
-            b, s = sndpath_check(g, name, lambda rate: GpuSoundPath(P, rate))
+            p, b, s = sndpath_check(g, name, lambda rate: GpuSoundPath(P, rate))
         finally:
             P.close()
-        blocks, samples = blocks + b, samples + s
-    assert blocks >= 80 and samples >= 35000, (blocks, samples)
+        packets, blocks, samples = packets + p, blocks + b, samples + s
+    assert packets >= 60 and blocks >= 100 and samples >= 50000, (packets, blocks, samples)

@@ -329,36 +329,59 @@ def blocks_of(sig, lens):
 
 B6 = [512] * 6
 RAG = [512, 300, 212, 170, 342, 512, 1, 511, 512]
+
+
+def B(n=512, k=1):
+    return ["B %d" % n] * k
+
+
 sp_scen = [
-    # name, rate, (lo, hi) of the passband, script (without R / L), input blocks in B order
-    ("am_default", 12000.0, (-4900.0, 4900.0), ["A 1 0 -100 50 6 1000", "M %d" % M_AM] + ["B 512"] * 6, blocks_of(am_sig(3072), B6)),
-    ("amn_deemp", 12000.0, (-2500.0, 2500.0), ["A 1 0 -100 50 6 1000", "E 1 0", "M %d" % M_AMN] + ["B 512"] * 4 + ["E 2 0"] + ["B 512"] * 2,
-     blocks_of(am_sig(3072, 9000.0, 0.9), B6)),
-    ("usb_hang_ragged", 12000.0, (300.0, 2700.0), ["A 1 1 -90 50 3 500", "M %d" % M_USB] + ["B %d" % n for n in RAG], blocks_of(ssb_sig(sum(RAG)), RAG)),
-    ("lsb_cw_manual", 12000.0, (-2700.0, -300.0), ["A 0 0 -100 70 6 1000", "M %d" % M_LSB, "B 512", "B 512", "M %d" % M_CW, "B 512", "A 1 0 -130 50 0 100",
-                                                  "M %d" % M_CWN, "B 512", "B 512", "M %d" % M_USN, "B 512", "M %d" % M_LSN, "B 512"], blocks_of(ssb_sig(3584, 6000.0), [512] * 7)),
-    ("ssb_deemp", 12000.0, (300.0, 2700.0), ["A 1 0 -100 50 6 1000", "E 2 0", "M %d" % M_USB] + ["B 512"] * 4, blocks_of(ssb_sig(2048, 12000.0), [512] * 4)),
-    ("nbfm_squelch_80", 12000.0, (-6000.0, 6000.0), ["A 1 0 -100 50 6 1000", "Q 80 0", "M %d" % M_NBFM] + ["B 512"] * 12,
+    # name, rate, (lo, hi) of the passband, script (without R / L; "B n" = a CFastFIR block, grouped into packets below), input blocks in B order
+    ("am_default", 12000.0, (-4900.0, 4900.0), ["A 1 0 -100 50 6 1000", "M %d" % M_AM] + B(512, 8), blocks_of(am_sig(4096), [512] * 8)),
+    ("amn_deemp", 12000.0, (-2500.0, 2500.0), ["A 1 0 -100 50 6 1000", "E 1 0", "M %d" % M_AMN] + B(512, 4) + ["E 2 0"] + B(512, 4),
+     blocks_of(am_sig(4096, 9000.0, 0.9), [512] * 8)),
+    ("usb_hang_ragged_raw_le", 12000.0, (300.0, 2700.0), ["W 0 1", "A 1 1 -90 50 3 500", "M %d" % M_USB] + ["B %d" % n for n in RAG], blocks_of(ssb_sig(sum(RAG)), RAG)),
+    ("lsb_cw_manual_raw_be", 12000.0, (-2700.0, -300.0), ["W 0 0", "A 0 0 -100 70 6 1000", "M %d" % M_LSB, "B 512", "B 512", "M %d" % M_CW, "B 512", "A 1 0 -130 50 0 100",
+                                                         "M %d" % M_CWN, "B 512", "B 512", "M %d" % M_USN, "B 512", "M %d" % M_LSN, "B 512"], blocks_of(ssb_sig(3584, 6000.0), [512] * 7)),
+    ("ssb_deemp", 12000.0, (300.0, 2700.0), ["A 1 0 -100 50 6 1000", "E 2 0", "M %d" % M_USB] + B(512, 8), blocks_of(ssb_sig(4096, 12000.0), [512] * 8)),
+    ("nbfm_squelch_80", 12000.0, (-6000.0, 6000.0), ["A 1 0 -100 50 6 1000", "Q 80 0", "M %d" % M_NBFM] + B(512, 12),
      [fm_sig(512, False) for _ in range(3)] + [fm_sig(512) for _ in range(5)] + [fm_sig(512, False) for _ in range(4)]),
-    ("nnfm_deemp_forced_shut", 12000.0, (-3000.0, 3000.0), ["A 1 0 -100 50 6 1000", "E 0 1", "Q 0 0", "M %d" % M_NNFM, "B 512", "B 512", "Q 99 0", "B 512", "B 512",
-                                                           "Q 0 0", "B 512", "E 0 2", "B 512"], [fm_sig(512) for _ in range(6)]),
-    ("iq_smeter_only", 12000.0, (-5000.0, 5000.0), ["A 1 0 -100 50 6 1000", "M %d" % M_IQ] + ["B 512"] * 3, blocks_of(am_sig(1536, 300.0), [512] * 3)),
-    ("rate_20250_every_family", 20250.0, (-6000.0, 6000.0), ["A 1 1 -60 50 10 2000", "E 1 1", "M %d" % M_AM] + ["B 512"] * 3 + ["M %d" % M_NBFM, "Q 75 0"] + ["B 512"] * 3
-     + ["M %d" % M_USB] + ["B 512"] * 3, blocks_of(am_sig(1536), [512] * 3) + [fm_sig(512, False), fm_sig(512), fm_sig(512)] + blocks_of(ssb_sig(1536), [512] * 3)),
-    ("mode_hops_state_carried", 12000.0, (-4000.0, 4000.0), ["A 1 0 -100 50 6 1000", "E 1 2", "Q 70 0"] + sum([["M %d" % m, "B 400", "B 112"] for m in
-     (M_AM, M_NBFM, M_USB, M_AM, M_NNFM, M_CW, M_AMN, M_IQ)], []), sum([blocks_of(sg, [400, 112]) for sg in
-     (am_sig(512), fm_sig(512), ssb_sig(512), am_sig(512, 800.0), fm_sig(512, False), ssb_sig(512), am_sig(512), am_sig(512))], [])),
-    # (the IQ mode last: its AGC runs behind line 908, in the packet section -- a cut that ends at 908 leaves m_Agc untouched in that
-    #  mode, the server does not; nothing after an IQ block is compared)
-    ("silence_and_full_scale", 12000.0, (-4900.0, 4900.0), ["A 1 0 -100 50 6 1000", "M %d" % M_AM, "B 512", "B 512", "M %d" % M_NBFM, "B 512", "B 512", "M %d" % M_USB, "B 512", "B 512"],
-     [np.zeros(512, np.complex64), (30000.0 * np.exp(2j * np.pi * 0.05 * np.arange(512))).astype(np.complex64)] * 3),
+    ("nnfm_deemp_forced_shut", 12000.0, (-3000.0, 3000.0), ["A 1 0 -100 50 6 1000", "E 0 1", "Q 0 0", "M %d" % M_NNFM] + B(512, 4) + ["Q 99 0"] + B(512, 4)
+     + ["Q 0 0"] + B(512, 4) + ["E 0 2"] + B(512, 4), [fm_sig(512) for _ in range(16)]),
+    ("iq_le_then_be", 12000.0, (-5000.0, 5000.0), ["A 1 0 -100 50 6 1000", "W 1 1", "M %d" % M_IQ] + B(512, 3) + ["W 1 0"] + B(512, 3) + ["A 0 0 -100 90 6 1000"] + B(512, 2),
+     blocks_of(am_sig(4096, 300.0), [512] * 8)),
+    ("rate_20250_every_family", 20250.0, (-6000.0, 6000.0), ["A 1 1 -60 50 10 2000", "E 1 1", "M %d" % M_AM] + B(512, 4) + ["M %d" % M_NBFM, "Q 75 0"] + B(512, 4)
+     + ["M %d" % M_USB] + B(512, 4) + ["M %d" % M_IQ] + B(512, 2),
+     blocks_of(am_sig(2048), [512] * 4) + [fm_sig(512, False), fm_sig(512), fm_sig(512), fm_sig(512)] + blocks_of(ssb_sig(2048), [512] * 4) + blocks_of(am_sig(1024), [512] * 2)),
+    ("mode_hops_state_carried", 12000.0, (-4000.0, 4000.0), ["W 0 1", "A 1 0 -100 50 6 1000", "E 1 2", "Q 70 0"] + sum([["M %d" % m, "B 400", "B 112"] for m in
+     (M_AM, M_NBFM, M_USB, M_AM, M_IQ, M_NNFM, M_CW, M_AMN, M_IQ)], []), sum([blocks_of(sg, [400, 112]) for sg in
+     (am_sig(512), fm_sig(512), ssb_sig(512), am_sig(512, 800.0), am_sig(512), fm_sig(512, False), ssb_sig(512), am_sig(512), am_sig(512))], [])),
+    ("silence_full_scale_overflow", 12000.0, (-4900.0, 4900.0), ["A 1 0 -100 50 6 1000", "W 0 0", "M %d" % M_AM, "B 512", "V 1", "B 512", "M %d" % M_NBFM, "B 512", "V 0", "B 512",
+                                                                "M %d" % M_USB, "B 512", "B 512", "M %d" % M_IQ, "B 512", "B 512"],
+     [np.zeros(512, np.complex64), (30000.0 * np.exp(2j * np.pi * 0.05 * np.arange(512))).astype(np.complex64)] * 4),
 ]
 sp = {}
 with tempfile.TemporaryDirectory() as tmp:
-    for name, rate, (lo, hi), script, blocks in sp_scen:
-        script = ["R %r" % rate, passband(lo, hi, rate)] + script
+    for name, rate, (lo, hi), lines, blocks in sp_scen:
+        # group the blocks into packets as the server's `do { ... } while (bc < LOOP_BC)` does: 4 x 512 samples of compressed mono audio,
+        # one block otherwise (1024 bytes of raw mono, 2048 of IQ); a command between blocks ends the packet (the scenarios place them there)
+        script, pend, comp, mode = ["R %r" % rate, passband(lo, hi, rate)], [], 1, M_USB
+        for ln in lines + ["#end"]:
+            if ln[0] == "B":
+                pend.append(int(ln.split()[1]))
+                if len(pend) == (4 if comp and mode not in (M_IQ, M_DRM) else 1):
+                    script.append("P " + " ".join(str(v) for v in pend)); pend = []
+                continue
+            if pend:
+                script.append("P " + " ".join(str(v) for v in pend)); pend = []
+            if ln[0] == "W":
+                comp = int(ln.split()[1])
+            if ln[0] == "M":
+                mode = int(ln.split()[1])
+            if ln[0] != "#":
+                script.append(ln)
         x = np.concatenate(blocks).astype(np.complex64)
-        assert x.size == sum(int(l.split()[1]) for l in script if l[0] == "B"), name
+        assert x.size == sum(sum(int(v) for v in l.split()[1:]) for l in script if l[0] == "P"), name
         open(os.path.join(tmp, "s.txt"), "w").write("\n".join(script) + "\n")
         x.tofile(os.path.join(tmp, "in.bin"))
         run([os.path.join(REF, "sndpath_ref"), os.path.join(tmp, "s.txt"), os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")])
@@ -367,7 +390,7 @@ with tempfile.TemporaryDirectory() as tmp:
         sp[name + "_band"] = np.array([rate, lo, hi], np.float64)
         sp[name + "_in"] = x
         sp[name + "_out"] = y
-        print("sndpath_ref.npz: %-26s %5d samples in, %5d floats out" % (name, x.size, y.size))
+        print("sndpath_ref.npz: %-28s %5d samples in, %2d packets, %5d floats out" % (name, x.size, sum(l[0] == "P" for l in script), y.size))
 sp["names"] = np.array([s_[0] for s_ in sp_scen])
 np.savez_compressed(os.path.join(GOLD, "sndpath_ref.npz"), **sp)
 
