@@ -138,7 +138,7 @@ if [ -f "$HIPFFTW_H" ] && [ -f /opt/rocm/lib/libhipfftw.so ]; then
         "$R/gps/sats.cpp" -lm $UNRES
     # c2s_sound()'s signal path between CFastFIR and the bytes of the sound packet -- the S-meter loop, the AM and NBFM detectors with what
     # follows them, the SSB AGC, the de-emphasis filters (rx/rx_sound.cpp:676-908), the payload section (IQ AGC + (s2_t) pairs, ADPCM / raw,
-    # either byte order: 1035-1140), the header's S-meter field, flags and sequence number (1222-1253) -- is the body of a server coroutine: no function to call,
+    # either byte order: 1035-1140), the header's S-meter field, flags and sequence number (1222-1253), the IQ header's GPS stamp (536-537, 557, 638-661) -- is the body of a server coroutine: no function to call,
     # and the file as a whole needs the web server.  The STATEMENTS are compiled instead: the line ranges are cut out of the file where
     # it lies into the temporary directory (deleted on exit; nothing of the text enters the repository or oracle/_ref/) and
     # oracle/ref/ref_sndpath_main.cpp #includes them inside a function that declares c2s_sound()'s locals (by cuts of its own
@@ -146,7 +146,12 @@ if [ -f "$HIPFFTW_H" ] && [ -f /opt/rocm/lib/libhipfftw.so ]; then
     # the reference's agc.cpp, fir.cpp, squelch.cpp in place.  No transform: runs HERE.
     SND="$R/rx/rx_sound.cpp"
     mkdir -p "$W/sndcut"
+    cut_lines "$SND" 92 93 "$W/sndcut/snd_gpsconst.inc" 'const double gps_delay    = ' 'const double gps_week_sec = '
     cut_lines "$SND" 244 250 "$W/sndcut/snd_decls.inc" 'double z1 = 0;' 'float sMeterAvg_dB = 0, sMeter_dBm;'
+    cut_lines "$SND" 306 319 "$W/sndcut/snd_norm.inc" 'int ref_nrx_samps = NRX_SAMPS_CHANS(8);' '}'
+    cut_lines "$SND" 536 537 "$W/sndcut/snd_ticks.inc" 'const u64_t ticks   = rx->ticks[rx->rd_pos];' 'const u64_t dticks  = time_diff48(ticks, clk.ticks);'
+    cut_lines "$SND" 557 557 "$W/sndcut/snd_gpssec.inc" 's->gpssec = fmod(gps_week_sec + clk.gps_secs + (dticks/clk.adc_clock_base) - gps_delay + gps_delay2, gps_week_sec);' 's->gpssec = fmod('
+    cut_lines "$SND" 638 661 "$W/sndcut/snd_gpsstamp.inc" 'int sample_filter_delays = norm_nrx_samps - fir_pos;' 's->last_gpssec = s->gpssec;'
     cut_lines "$SND" 252 255 "$W/sndcut/snd_pktinit.inc" 'strncpy(s->out_pkt_real.h.id, "SND", 3);' 's->seq = 0;'
     cut_lines "$SND" 285 285 "$W/sndcut/snd_masked.inc" 'bool masked = false, masked_area = false, check_masked = false;' 'bool masked = false'
     cut_lines "$SND" 295 295 "$W/sndcut/snd_overload.inc" 'bool squelched_overload = false;' 'bool squelched_overload = false;'
@@ -158,10 +163,11 @@ if [ -f "$HIPFFTW_H" ] && [ -f /opt/rocm/lib/libhipfftw.so ]; then
     sed -n '1100p' "$SND" | grep -qF 'if (!isDRM) {' && sed -n '1142p' "$SND" | grep -qF '#ifdef DRM' || { echo "build_ref.sh: the packet section is not at rx_sound.cpp:1035-1140"; exit 1; }
     cut_lines "$SND" 1222 1253 "$W/sndcut/snd_header.inc" '#define SMETER_BIAS 127.0' 'wf->snd_seq = s->seq;'
     ALLD=$(find "$R/rx" "$R/extensions" "$R/pkgs" -maxdepth 2 -type d | sed 's/^/-I/' | tr '\n' ' ')
-    $CXX $OPT $DEF $FINC $ALLD -I"$W/sndcut" '-DSND_CUT_DECLS="snd_decls.inc"' '-DSND_CUT_PKTINIT="snd_pktinit.inc"' '-DSND_CUT_MASKED="snd_masked.inc"' \
+    $CXX $OPT $DEF $FINC $ALLD -I"$W/sndcut" '-DSND_CUT_GPSCONST="snd_gpsconst.inc"' '-DSND_CUT_NORM="snd_norm.inc"' '-DSND_CUT_TICKS="snd_ticks.inc"' \
+        '-DSND_CUT_GPSSEC="snd_gpssec.inc"' '-DSND_CUT_GPSSTAMP="snd_gpsstamp.inc"' '-DSND_CUT_DECLS="snd_decls.inc"' '-DSND_CUT_PKTINIT="snd_pktinit.inc"' '-DSND_CUT_MASKED="snd_masked.inc"' \
         '-DSND_CUT_OVERLOAD="snd_overload.inc"' '-DSND_CUT_FLAGS="snd_flags.inc"' '-DSND_CUT_HOOKS="snd_hooks.inc"' '-DSND_CUT_PATH="snd_path.inc"' \
         '-DSND_CUT_PACKET="snd_packet.inc"' '-DSND_CUT_HEADER="snd_header.inc"' -no-pie -o "$OUT/sndpath_ref" "$HERE/ref/ref_sndpath_main.cpp" \
-        "$R/rx/CuteSDR/agc.cpp" "$R/rx/CuteSDR/fir.cpp" "$R/rx/CuteSDR/squelch.cpp" "$R/rx/csdr/ima_adpcm.cpp" -lm $UNRES
+        "$R/rx/CuteSDR/agc.cpp" "$R/rx/CuteSDR/fir.cpp" "$R/rx/CuteSDR/squelch.cpp" "$R/rx/csdr/ima_adpcm.cpp" "$R/support/timing.cpp" -lm $UNRES
     # the same for what c2s_waterfall() derives from `SET zoom= start=` / `cf=` (rows W2, W6's map): the command's case block with the
     # decimation / NCO words it hands to spi_set / spi_set3, and the fft_used / plot_width / map / scale / mask construction -- line ranges of
     # rx/rx_waterfall.cpp cut into the temporary directory, #included by oracle/ref/ref_wfcmd_main.cpp in the coroutine's own order;

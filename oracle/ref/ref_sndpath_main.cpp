@@ -6,18 +6,23 @@
 // (no function to call), so oracle/build_ref.sh cuts the line ranges out of the file WHERE IT LIES at build time (sed into a
 // temporary directory that is deleted; nothing of the text enters the repository) and this harness #includes the cuts inside a
 // function, in the coroutine's own order, with the locals c2s_sound() declares -- by cuts of its own declaration lines:
+//     SND_CUT_GPSCONST rx_sound.cpp:92-93      const double gps_delay, gps_week_sec                      (file scope)
 //     SND_CUT_DECLS    rx_sound.cpp:244-250    double z1; double frate = ext_update_get_sample_rateHz(); sMeterAlpha; sMeterAvg_dB, sMeter_dBm
 //     SND_CUT_PKTINIT  rx_sound.cpp:252-255    "SND" into both headers, s->seq = 0
 //     SND_CUT_MASKED   rx_sound.cpp:285        bool masked = false, ...
 //     SND_CUT_OVERLOAD rx_sound.cpp:295        bool squelched_overload = false
+//     SND_CUT_NORM     rx_sound.cpp:306-319    ref_nrx_samps, norm_nrx_samps, gps_delay2 by firmware mode
 //     SND_CUT_FLAGS    rx_sound.cpp:461-482    the SND_FLAG_* bits; per packet: isNBFM, isDRM, IQ_or_DRM_or_stereo, the packet write
 //                                              pointers, flags / seq / smeter pointers, do_de_emp
 //     SND_CUT_HOOKS    rx_sound.cpp:488-497    u2_t bc = 0; the extension hooks of ext_users[rx_chan]
+//     SND_CUT_TICKS    rx_sound.cpp:536-537    the data-pump buffer's 48-bit tick count, its distance to the last GPS solution
+//     SND_CUT_GPSSEC   rx_sound.cpp:557        s->gpssec of the buffer
+//     SND_CUT_GPSSTAMP rx_sound.cpp:638-661    the FIR / AGC delay correction and the IQ header's GPS stamp (per CFastFIR block)
 //     SND_CUT_PATH     rx_sound.cpp:676-908    the path (per CFastFIR block)
 //     SND_CUT_PACKET   rx_sound.cpp:1035-1140  the payload (per CFastFIR block)
 //     SND_CUT_HEADER   rx_sound.cpp:1222-1253  the header (per packet)
 // CAgc, CFir, CSquelch, the ADPCM coder are the reference's own (rx/CuteSDR/agc.cpp, fir.cpp, squelch.cpp, rx/csdr/ima_adpcm.cpp linked
-// in place), the de-emphasis tables its rx_filter.h, mode_flags[] its mode.h, the packet structs its rx_sound.h.  Test infrastructure.
+// in place), time_diff48() its support/timing.cpp, the de-emphasis tables its rx_filter.h, mode_flags[] its mode.h, the packet structs its rx_sound.h.  Test infrastructure.
 //
 // What the harness supplies (no arithmetic): the objects rx_sound.cpp:148-160 defines (m_Agc, m_Squelch, m_AM_FIR, m_nfm_deemp_FIR,
 // m_am_ssb_deemp_FIR; the two CFastFIR arrays are only DECLARED -- their constructors plan transforms, and the SAM case that names
@@ -29,7 +34,8 @@
 //
 //   sndpath_ref script.txt in.bin out.bin
 // script lines (the first must be R):
-//   R rate                                         -> the cut declarations run (z1 = 0, sMeterAlpha from rate, sMeterAvg_dB = 0); squelch SetupParameters
+//   R rate fw_sel nrx_samps rx_decim adc_clock_base -> configuration (the firmware mode, its buffer size, the audio decimation, the ADC clock);
+//                                                     the cut declarations run; appends norm_nrx_samps and gps_delay2 (three floats that sum to it) (z1 = 0, sMeterAlpha from rate, sMeterAvg_dB = 0); squelch SetupParameters
 //   A on hang thresh manGain slope decay           -> m_Agc[0].SetParameters(..., rate)                 (rx_sound_cmd.cpp:351)
 //   L hbw stop                                     -> m_AM_FIR[0].InitLPFilter(0, 1.0, 50.0, hbw, stop, rate)   (rx_sound_cmd.cpp:282)
 //   Q value max                                    -> m_Squelch[0].SetSquelch(value, max)                (rx_sound_cmd.cpp:430)
@@ -37,6 +43,8 @@
 //   M mode                                         -> s->mode (mode.h numbering)
 //   W compression little_endian                    -> s->compression, s->little_endian (`SET compression=`, `SET little-endian`)
 //   V overflow                                     -> dpump.rx_adc_ovfl (the ADC overflow the data pump saw)
+//   C clk_ticks clk_gps_secs                       -> clk.ticks, clk.gps_secs: the last GPS solution (clk_ticks 0: none yet)
+//   T ticks fir_pos  (one per block of the next P) -> the data-pump buffer's tick count and CFastFIR's FirPos() for that block
 //   P n1 [n2 ...]                                  -> ONE PACKET of CFastFIR blocks of n1, n2, ... complex floats from in.bin.  Appends, per
 //                                                     block: sMeterAvg_dB, sMeter_dBm, tap0, tap1, s->squelched, then n outputs as floats:
 //                                                     out_samps_s2 (mono modes) or re, im pairs after the IQ modes' AGC (2 n floats);
@@ -84,6 +92,7 @@
 #include "wdsp.h"
 #include "fpga.h"
 #include "rf_attn.h"
+#include "timing.h"
 #undef printf
 #include <math.h>
 #include <stdio.h>
@@ -91,7 +100,10 @@
 #include <string.h>
 #include <vector>
 
+#include SND_CUT_GPSCONST
 snd_t snd_inst[MAX_RX_CHANS];                    // rx_sound.cpp:87
+clk_t clk;                                       // init/clk.cpp:40
+int fw_sel, nrx_samps, rx_decim;                 // main.cpp:65, config.h:51-52
 CAgc m_Agc[MAX_RX_CHANS];                        // :148-160
 CSquelch m_Squelch[MAX_RX_CHANS];
 extern CFastFIR m_chan_null_FIR[MAX_RX_CHANS];   // (declared only: see the head of this file)
@@ -124,13 +136,23 @@ int main(int argc, char **argv)
     int j;
     static TYPECPX fir_buf[FASTFIR_OUTBUF_SIZE];
     char line[1024];
-    if (!fgets(line, sizeof line, sf) || sscanf(line, "R %lf", &g_rate) != 1) return 3;
+    double adc_base;
+    if (!fgets(line, sizeof line, sf) || sscanf(line, "R %lf %d %d %d %lf", &g_rate, &fw_sel, &nrx_samps, &rx_decim, &adc_base) != 5) return 3;
+    clk.adc_clock_base = adc_base;
+    std::vector<std::pair<unsigned long long, int> > tq;        // the T lines waiting for their blocks
     ext_users[rx_chan].receive_S_meter = smeter_hook;
-    s->compression = 1;                                          // rx_sound.cpp:238
+    s->compression = 1; s->agc = 1;                              // rx_sound.cpp:237-238
 #include SND_CUT_DECLS
 #include SND_CUT_PKTINIT
 #include SND_CUT_MASKED
 #include SND_CUT_OVERLOAD
+#include SND_CUT_NORM
+    (void) ref_nrx_samps;
+    {   // what the firmware-mode switch gave: norm_nrx_samps, and gps_delay2 (a double) as three floats that sum to it
+        const float a = (float) gps_delay2, b = (float) (gps_delay2 - (double) a), c = (float) (gps_delay2 - (double) a - (double) b);
+        const float cfg[4] = {(float) norm_nrx_samps, a, b, c};
+        fwrite(cfg, sizeof(float), 4, outf);
+    }
     (void) masked_area; (void) check_masked;
     m_Squelch[rx_chan].SetupParameters(rx_chan, frate);          // rx_sound.cpp:261-262
     m_Squelch[rx_chan].SetSquelch(0, 0);
@@ -140,6 +162,7 @@ int main(int argc, char **argv)
         if (op == 'A') {
             int on, hang, thr, man, slope, decay;
             if (sscanf(line + 1, "%d %d %d %d %d %d", &on, &hang, &thr, &man, &slope, &decay) != 6) return 3;
+            s->agc = on;                                         // rx_sound_cmd.cpp:343
             m_Agc[rx_chan].SetParameters(on, hang, thr, man, slope, decay, frate);
         } else if (op == 'L') {
             float hbw, stop;
@@ -168,6 +191,14 @@ int main(int argc, char **argv)
             int ov;
             if (sscanf(line + 1, "%d", &ov) != 1) return 3;
             dpump.rx_adc_ovfl = ov;
+        } else if (op == 'C') {
+            unsigned long long t; double secs;
+            if (sscanf(line + 1, "%llu %lf", &t, &secs) != 2) return 3;
+            clk.ticks = t; clk.gps_secs = secs;
+        } else if (op == 'T') {
+            unsigned long long t; int fp;
+            if (sscanf(line + 1, "%llu %d", &t, &fp) != 2) return 3;
+            tq.push_back(std::make_pair(t, fp));
         } else if (op == 'P') {
             // one pass of the `while (TRUE)` loop of c2s_sound() from :459 on: one packet
 #include SND_CUT_FLAGS
@@ -184,7 +215,14 @@ int main(int argc, char **argv)
                 if (fread(fir_buf, sizeof(TYPECPX), ns_out, inf) != (size_t) ns_out) return 4;
                 TYPECPX *fir_samps_c = fir_buf;
                 g_ntap = 0; g_tap[0] = g_tap[1] = 0;
+                int fir_pos = 0;
+                rx->rd_pos = 0; rx->ticks[0] = 0;
+                if (!tq.empty()) { rx->ticks[0] = tq.front().first; fir_pos = tq.front().second; tq.erase(tq.begin()); }
                 {
+#include SND_CUT_TICKS
+#include SND_CUT_GPSSEC
+#include SND_CUT_GPSSTAMP
+                    (void) dt_to_pos_sol;
 #include SND_CUT_PATH
                     const float hdr[5] = {sMeterAvg_dB, sMeter_dBm, g_tap[0], g_tap[1], (float) s->squelched};
                     fwrite(hdr, sizeof(float), 5, outf);

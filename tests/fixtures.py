@@ -189,6 +189,12 @@ def aper_ref_replay(g, update, report):
 # ---- c2s_sound()'s signal path as the reference's own statements ran it (tests/golden/sndpath_ref.npz) -------------------------
 SND_AM_MODES, SND_FM_MODES, SND_SSB_MODES, SND_IQ_MODES = (0, 1), (6, 16), (2, 3, 4, 5, 9, 10), (7, 8)      # rx/mode.h:69-70
 S_METER_CAL = -13
+GPS_DELAY = 28926.838e-6                                  # rx_sound.cpp:92 (tests/test_ref_text_pins_cpu.py compares it by text)
+
+
+def time_diff48(nxt, prev):
+    """support/timing.cpp:90-100 (the host's; the library takes dticks as an argument)"""
+    return nxt - prev if nxt >= prev else (0x0000FFFFFFFFFFFF - prev) + nxt
 SND_FLAG_ADC_OVFL, SND_FLAG_MODE_IQ, SND_FLAG_COMPRESSED, SND_FLAG_SQUELCH_UI, SND_FLAG_LITTLE_ENDIAN = 0x02, 0x08, 0x10, 0x40, 0x80   # rx_sound.cpp:461-468
 
 
@@ -266,6 +272,14 @@ class OracleSoundPath:
     def header(self, flags, seq, smeter_dbm):
         return self.ko.snd_header(flags, seq, smeter_dbm)
 
+    def gps(self, dticks, fir_pos, agc_on, cfg, clk_ticks, clk_secs):
+        ko = self.ko
+        if not hasattr(self, "gst"):
+            self.gst = ko.GpsState()
+        norm, delay2, decim, adc = cfg
+        ko.gps_begin(self.gst, clk_secs, float(dticks), adc, GPS_DELAY, delay2)
+        return ko.gps_stamp(self.gst, norm, fir_pos, agc_on, self.a.delay(), decim, adc, clk_secs, clk_ticks)
+
 
 class GpuSoundPath:
     """The same script through kg_post, kg_adpcm / kg_snd_payload / kg_snd_iq_payload and kg_snd_header (one channel)."""
@@ -324,6 +338,14 @@ class GpuSoundPath:
     def header(self, flags, seq, smeter_dbm):
         return self.np.asarray(self.wire_mod.snd_header(self.P.ctx, flags, seq, smeter_dbm))
 
+    def gps(self, dticks, fir_pos, agc_on, cfg, clk_ticks, clk_secs):
+        wire, lib = self.wire_mod, self.P.ctx.lib
+        if not hasattr(self, "gst"):
+            self.gst = wire.GpsState()
+        norm, delay2, decim, adc = cfg
+        wire.gps_begin(lib, self.gst, clk_secs, float(dticks), adc, GPS_DELAY, delay2)
+        return wire.gps_stamp(lib, self.gst, norm, fir_pos, agc_on, self.P.agc_delay(0), decim, adc, clk_secs, clk_ticks)
+
 
 def sndpath_check(g, name, make_chain):
     """Runs scenario `name` of sndpath_ref.npz through make_chain(rate) and asserts EQUALITY with what the reference's statements
@@ -335,15 +357,26 @@ def sndpath_check(g, name, make_chain):
     rate, lo, hi = (float(v) for v in g[name + "_band"])
     x, y = g[name + "_in"], g[name + "_out"]
     chain = make_chain(rate)
-    pos = ypos = npkt = nblk = samples = seq = 0
-    mode, comp, le, ovfl, sq = 2, 1, False, 0, False
+    import struct
+    pos = npkt = nblk = samples = seq = 0
+    mode, comp, le, ovfl, sq, agc_on = 2, 1, False, 0, False, 1
     cal = np.float32(S_METER_CAL)
+    # what the reference's firmware-mode switch (rx_sound.cpp:306-319) gave: inputs of the library's stamp functions
+    gps_cfg, clk_ticks, clk_secs, tq, stamp = None, 0, 0.0, [], None
+    norm, delay2 = int(y[0]), float(np.float64(y[1]) + np.float64(y[2]) + np.float64(y[3]))
+    ypos = 4
     for line in (str(l) for l in g[name + "_script"]):
         f = line.split()
         if f[0] == "R":
             assert float(f[1]) == rate
+            gps_cfg = (norm, delay2, int(f[4]), float(f[5]))
+        elif f[0] == "C":
+            clk_ticks, clk_secs = int(f[1]), float(f[2])
+        elif f[0] == "T":
+            tq.append((int(f[1]), int(f[2])))
         elif f[0] == "A":
             chain.agc(*[int(v) for v in f[1:7]])
+            agc_on = int(f[1])
         elif f[0] == "L":
             chain.passband(lo, hi, float(f[1]), float(f[2]))
         elif f[0] == "Q":
@@ -362,6 +395,8 @@ def sndpath_check(g, name, make_chain):
             iq = mode in SND_IQ_MODES
             payload, dbm = [], None
             for n in (int(v) for v in f[1:]):
+                ticks, fir_pos = tq.pop(0) if tq else (0, 0)
+                stamp = chain.gps(time_diff48(ticks, clk_ticks), fir_pos, agc_on, gps_cfg, clk_ticks, clk_secs)     # before the AGC runs, as :636-661
                 avg, t0, t1, sq, out = chain.block(x[pos:pos + n])
                 pos += n
                 w_avg, w_dbm, w_t0, w_t1, w_sq = y[ypos:ypos + 5]
@@ -397,7 +432,9 @@ def sndpath_check(g, name, make_chain):
                 | (SND_FLAG_SQUELCH_UI if sq else 0) | (SND_FLAG_LITTLE_ENDIAN if le else 0)
             hdr = np.asarray(chain.header(flags, seq, float(dbm)), np.uint8)
             assert hsize == (20 if iq else 10) and np.array_equal(hdr[:10], pkt[:10]), (name, npkt, mode, "header", hdr[:10], pkt[:10])
-            assert not pkt[10:hsize].any()                                                        # the IQ header's GPS stamp: set outside the cuts
+            if iq:                                                                                # snd_pkt_iq_t's GPS stamp (rx_sound.h:61-64): the last block's
+                want_stamp = struct.pack("<BBII", stamp[2], 0, stamp[0], stamp[1])
+                assert bytes(pkt[10:20]) == want_stamp, (name, npkt, "GPS stamp", stamp, struct.unpack("<BBII", bytes(pkt[10:20])))
             npkt += 1
     assert pos == x.size and ypos == y.size
     if hasattr(chain, "close"):

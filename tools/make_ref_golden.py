@@ -365,15 +365,33 @@ with tempfile.TemporaryDirectory() as tmp:
     for name, rate, (lo, hi), lines, blocks in sp_scen:
         # group the blocks into packets as the server's `do { ... } while (bc < LOOP_BC)` does: 4 x 512 samples of compressed mono audio,
         # one block otherwise (1024 bytes of raw mono, 2048 of IQ); a command between blocks ends the packet (the scenarios place them there)
-        script, pend, comp, mode = ["R %r" % rate, passband(lo, hi, rate)], [], 1, M_USB
+        # the firmware mode of the scenario (config.h:31-34; nrx_samps = 680 / channels), the audio decimation, the ADC clock
+        fw_sel, nrx, adc_base = {"am_default": (0, 170, 66.6666e6), "amn_deemp": (1, 85, 66.6666e6), "iq_le_then_be": (3, 48, 66.6672e6),
+                                 "mode_hops_state_carried": (1, 85, 66.6660e6)}.get(name, (2, 226, 66.6666e6) if rate > 15000 else (0, 170, 66.6666e6))
+        decim = int(round(adc_base / rate))
+        script, pend, comp, mode = ["R %r %d %d %d %r" % (rate, fw_sel, nrx, decim, adc_base), passband(lo, hi, rate)], [], 1, M_USB
+        tick, nblk_seen = [(1 << 48) - 40 * decim * nrx], [0]       # the 48-bit tick counter wraps inside every scenario
+
+        def flush():
+            for _ in pend:                                         # one T line per block: the buffer's ticks, CFastFIR's position
+                tick[0] = (tick[0] + 3 * decim * nrx) & ((1 << 48) - 1)
+                script.append("T %d %d" % (tick[0], (nblk_seen[0] * 166) % nrx))
+                nblk_seen[0] += 1
+                if nblk_seen[0] == 3:                              # the first GPS solution arrives after three blocks, a later one after nine
+                    script.insert(len(script) - 1, "C %d %r" % ((tick[0] - 7 * decim * nrx) & ((1 << 48) - 1), 345600.25))
+                if nblk_seen[0] == 9:
+                    script.insert(len(script) - 1, "C %d %r" % ((tick[0] - 2 * decim * nrx) & ((1 << 48) - 1), 604799.9995))
+            script.append("P " + " ".join(str(v) for v in pend))
+            del pend[:]
+
         for ln in lines + ["#end"]:
             if ln[0] == "B":
                 pend.append(int(ln.split()[1]))
                 if len(pend) == (4 if comp and mode not in (M_IQ, M_DRM) else 1):
-                    script.append("P " + " ".join(str(v) for v in pend)); pend = []
+                    flush()
                 continue
             if pend:
-                script.append("P " + " ".join(str(v) for v in pend)); pend = []
+                flush()
             if ln[0] == "W":
                 comp = int(ln.split()[1])
             if ln[0] == "M":
