@@ -440,3 +440,31 @@ def sndpath_check(g, name, make_chain):
     if hasattr(chain, "close"):
         chain.close()
     return npkt, nblk, samples
+
+
+def fastfir_taps_cases(g):
+    """tests/golden/fastfir_taps_fftref.npz -> [(name, script lines, x, [per D line: (n, count, FirPos, [(flag, bins complex64[1024])...],
+    out complex64[count])])]: what the reference's CFastFIR::ProcessData handed a registered extension hook and returned."""
+    import numpy as np
+    cases = []
+    for name in (str(n) for n in g["names"]):
+        script, x, y = [str(l) for l in g[name + "_script"]], g[name + "_in"], g[name + "_out"]
+        pos, hooked, per = 0, False, []
+        for line in script:
+            f = line.split()
+            if f[0] == "H":
+                hooked = int(f[1]) != 0
+            elif f[0] == "D":
+                count, firpos = int(y[pos]), int(y[pos + 1])
+                pos += 2
+                taps = []
+                if hooked:
+                    nt = int(y[pos]); pos += 1
+                    for _ in range(nt):
+                        flag = int(y[pos]); pos += 1
+                        taps.append((flag, y[pos:pos + 2048].view(np.complex64).copy())); pos += 2048
+                out = y[pos:pos + 2 * count].view(np.complex64).copy(); pos += 2 * count
+                per.append((int(f[1]), count, firpos, taps, out))
+        assert pos == y.size
+        cases.append((name, script, x, per))
+    return cases

@@ -569,3 +569,50 @@ def test_waterfall_commands_match_the_references_own_statements(oracle):
             ncmd += 1
         assert mpos == g[name + "_maps"].size and dpos == g[name + "_drops"].size
     assert ncmd == 550 and rebuilt > 200 and masked > 10000, (ncmd, rebuilt, masked)
+
+
+def _notch(pre):
+    e = np.array(pre, np.complex64, copy=True)
+    e[..., 256:768] = 0                         # what the driver's editing hook does (oracle/ref/ref_fastfir_main.cpp)
+    return e
+
+
+def test_fastfir_extension_taps_oracle_matches_reference_fastfir_cpp(oracle):
+    """SURVEY 8(f) rank 4: what CFastFIR::ProcessData of rx/CuteSDR/fastfir.cpp ITSELF hands a registered extension hook
+    (fastfir_taps_fftref.npz; the driver registers one through ext_users[] as extensions do): the PRE_FILTERED buffer (forward
+    spectrum x m_CIC), the POST_FILTERED buffer (x m_pFilterCoef_CIC), and -- when the PRE hook edits its buffer and answers true --
+    the output filtered from the EDITED buffer with m_pFilterCoef (`buf_modified`, :286-290).  Hook calls and their order equal;
+    bins and samples to 1e-5 of the largest."""
+    from tests.fixtures import fastfir_taps_cases
+    g = np.load(os.path.join(GOLD, "fastfir_taps_fftref.npz"))
+    ncalls = 0
+    for name, script, x, per in fastfir_taps_cases(g):
+        f, pos, flags, edit, k = OracleFastFir(oracle), 0, 0, 0, 0
+        for line in script:
+            t = line.split()
+            if t[0] == "C":
+                f.cic(int(t[1]) != 0)
+            elif t[0] == "P":
+                f.setup(int(t[1]), *[float(v) for v in t[2:6]])
+            elif t[0] == "H":
+                flags, edit = int(t[1]), int(t[2])
+            else:
+                n, count, firpos, taps, want = per[k]
+                k += 1
+                cic = oracle.fir_cic_coeffs() if f.cic_on else np.ones(1024, np.float32)
+                out, fp, pre, post = oracle.fir_process_taps(f.st, f.coef, cic, x[pos:pos + n], prec=0)
+                pos += n
+                assert (out.size, fp) == (count, firpos), (name, k)
+                nblk = count // 512
+                order = [fl for fl in (1, 2) if flags & fl] * nblk if flags else []
+                assert [fl for fl, _ in taps] == order, (name, k, [fl for fl, _ in taps])
+                for i, (fl, bins) in enumerate(taps):
+                    b = i // len([1 for fl_ in (1, 2) if flags & fl_])
+                    got = pre[b] if fl == 1 else post[b]
+                    assert np.abs(got - bins).max() <= FFT_TOL * np.abs(bins).max(), (name, k, b, fl)
+                    ncalls += 1
+                if flags & 1 and edit and nblk:
+                    out = np.concatenate([oracle.fft(f.base * _notch(pre[b]), sign=+1, prec=1)[512:] for b in range(nblk)])
+                if count:
+                    assert np.abs(out - want).max() <= FFT_TOL * np.abs(want).max(), (name, k, float(np.abs(out - want).max()))
+    assert ncalls == 20

@@ -355,3 +355,47 @@ def test_sound_path_on_the_gpu_matches_the_references_own_statements(gpu_ctx):
             P.close()
         packets, blocks, samples = packets + p, blocks + b, samples + s
     assert packets >= 60 and blocks >= 100 and samples >= 50000, (packets, blocks, samples)
+
+
+def test_fastfir_extension_taps_on_the_gpu_match_reference_fastfir_cpp(gpu_ctx):
+    """kg_fir_process_taps_dev / kg_fir_refilter_dev against what CFastFIR::ProcessData of rx/CuteSDR/fastfir.cpp ITSELF handed a
+    registered extension hook and returned (fastfir_taps_fftref.npz): PRE_FILTERED and POST_FILTERED buffers, and the output
+    filtered from the buffer the PRE hook edited (`buf_modified`): counts, FirPos(), the hook calls equal; bins and samples to 1e-5
+    of the largest."""
+    from flydog_sdr_gps_amd import FastFir
+    from tests.fixtures import fastfir_taps_cases
+    from tests.test_ref_pins_cpu import _notch
+    g = np.load(os.path.join(GOLD, "fastfir_taps_fftref.npz"))
+    cases = fastfir_taps_cases(g)
+    F = FastFir(gpu_ctx, nchan=len(cases), max_in=2048)
+    try:
+        for ch, (name, script, x, per) in enumerate(cases):
+            pos = flags = edit = k = 0
+            cic_on = False
+            for line in script:
+                t = line.split()
+                if t[0] == "C":
+                    cic_on = int(t[1]) != 0
+                elif t[0] == "P":
+                    F.setup(ch, *[float(v) for v in t[2:6]], do_cic_comp=cic_on)
+                elif t[0] == "H":
+                    flags, edit = int(t[1]), int(t[2])
+                else:
+                    n, count, firpos, taps, want = per[k]
+                    k += 1
+                    blk = x[pos:pos + n]
+                    pos += n
+                    if flags & 1 and edit:
+                        out, pre, _ = F.process_taps_edit(ch, blk, _notch)
+                        post = None
+                    else:
+                        out, pre, post = F.process_taps(ch, blk)
+                    assert (out.size, F.pos(ch)) == (count, firpos), (name, k)
+                    per_blk = len([1 for fl in (1, 2) if flags & fl])
+                    for i, (fl, bins) in enumerate(taps):
+                        got = pre[i // per_blk] if fl == 1 else post[i // per_blk]
+                        assert np.abs(got - bins).max() <= FFT_TOL * np.abs(bins).max(), (name, k, i, fl)
+                    if count:
+                        assert np.abs(out - want).max() <= FFT_TOL * np.abs(want).max(), (name, k, float(np.abs(out - want).max()))
+    finally:
+        F.close()

@@ -122,6 +122,24 @@ for name, script in ff_scen:
     print("fastfir %-22s %5d samples in, %5d floats out" % (name, n, y.size))
 np.savez_compressed(os.path.join(out_dir, "fastfir_fftref.npz"), **ff)
 
+# ---- CFastFIR's extension taps (fastfir.cpp:278-302) ------------------------------------------------------------
+# the driver's H line registers an extension hook through ext_users[]: PRE_FILTERED gets the forward spectrum times m_CIC, POST_FILTERED the
+# filtered spectrum; an editing PRE hook (zeroes bins 256 .. 767, answers true) makes ProcessData filter the edited buffer with m_pFilterCoef
+tp_scen = [
+    ("pre_post_cic_on", ["C 1", "P 0 300 2700 0 12000", "H 3 0"] + ["D 512"] * 4),
+    ("post_only_cic_off_ragged", ["P 0 -2700 -300 0 12000", "H 2 0", "D 300", "D 724", "D 1024", "D 170", "D 342"]),
+    ("pre_edit_cic_on", ["C 1", "P 0 -4900 4900 0 12000", "H 1 1"] + ["D 512"] * 4),
+    ("pre_edit_cic_off", ["P 0 -4900 4900 0 12000", "H 1 1"] + ["D 512"] * 3 + ["H 0 0", "D 512"]),
+]
+tp = {"names": np.array([s_[0] for s_ in tp_scen])}
+for name, script in tp_scen:
+    n = sum(int(l.split()[1]) for l in script if l[0] == "D")
+    x = audio_iq(n)
+    y = run("fastfir_ref", script, x)
+    tp[name + "_script"], tp[name + "_in"], tp[name + "_out"] = np.array(script), x, y
+    print("fastfir taps %-26s %5d samples in, %6d floats out" % (name, n, y.size))
+np.savez_compressed(os.path.join(out_dir, "fastfir_taps_fftref.npz"), **tp)
+
 # ---- waterfall frames -------------------------------------------------------------------------------------------------------
 from flydog_sdr_gps_amd import wf as wfm                    # noqa: E402  (host mirror: WfParams, maps -- the per-frame INPUTS)
 
