@@ -128,9 +128,13 @@ RX_DECIM_WIDE = 1543 * 2 * 2   # RX_DECIM_3CH (kiwi.config:140): the rx3 / 20.25
 RX_STD, RX_WIDE, RX_14 = 0, 1, 2
 
 
-def rx_phase_inc(freq_hz, adc_clock=125.0e6):
-    """rx_sound_set_freq (rx/rx_sound_cmd.cpp:41-51): i_phase = (u64) round(f / adc_clk * 2^48)."""
-    return int(round(freq_hz / adc_clock * 2.0 ** 48)) & ((1 << 48) - 1)
+def rx_phase_inc(freq_hz, adc_clock=125.0e6, spectral_inversion=False, ui_srate=32.0e6):
+    """rx_sound_set_freq (rx/rx_sound_cmd.cpp:80-90): i_phase = (u64) round(f / adc_clk * 2^48), f mirrored about the displayed
+    bandwidth (ui_srate - f) when the admin's spectral inversion is on; C's round() (half away from zero), 48 bits to the FPGA."""
+    import math
+    f = (ui_srate - freq_hz) if spectral_inversion else freq_hz
+    v = f / adc_clock * 2.0 ** 48
+    return int(math.floor(abs(v) + 0.5) * (1 if v >= 0 else -1)) & ((1 << 48) - 1)
 
 
 class RxDdc:

@@ -32,6 +32,7 @@
 #                                                         ima_adpcm.cpp      (runs here)
 #        wfcmd_ref     rx/rx_waterfall.cpp:365-529, 756-928 (LINE RANGES of c2s_waterfall(): the `SET zoom=` case, the map / scale /
 #                                                         mask construction; cut at build time) + support/str.cpp   (runs here)
+#        sndcmd_ref    rx/rx_sound_cmd.cpp                (rx_sound_set_freq: the audio NCO's phase increment; runs here)
 # NOT built: the rest of the two coroutines (connection handling, packet assembly, the noise blankers: outside SURVEY 8).
 set -e
 REFERENCE=${REFERENCE:-/root/reference}
@@ -185,7 +186,10 @@ if [ -f "$HIPFFTW_H" ] && [ -f /opt/rocm/lib/libhipfftw.so ]; then
     $CXX $OPT $DEF $FINC $ALLD -I"$W/wfcut" '-DWF_CUT_MACROS="wf_macros.inc"' '-DWF_CUT_BITS="wf_bits.inc"' '-DWF_CUT_LOCALS="wf_locals.inc"' \
         '-DWF_CUT_INIT="wf_init.inc"' '-DWF_CUT_ZOOM="wf_zoom.inc"' '-DWF_CUT_MAPS="wf_maps.inc"' -no-pie -o "$OUT/wfcmd_ref" \
         "$HERE/ref/ref_wfcmd_main.cpp" "$R/support/str.cpp" -lm $UNRES
-    FFT_BUILT=" fastfir_ref search_ref wf_ref dpump_ref chan_ref sndpath_ref wfcmd_ref"
+    # the audio NCO's phase increment (row D6): rx_sound_set_freq() of rx/rx_sound_cmd.cpp, the file linked in place; the driver records
+    # the words it hands to spi_set3.  Runs HERE.
+    $CXX $OPT $DEF $FINC $ALLD -no-pie -o "$OUT/sndcmd_ref" "$HERE/ref/ref_sndcmd_main.cpp" "$R/rx/rx_sound_cmd.cpp" -lm $UNRES
+    FFT_BUILT=" fastfir_ref search_ref wf_ref dpump_ref chan_ref sndpath_ref wfcmd_ref sndcmd_ref"
 else
     echo "hipFFTW absent: the FFT-dependent reference files are not built"
     FFT_BUILT=""

@@ -616,3 +616,15 @@ def test_fastfir_extension_taps_oracle_matches_reference_fastfir_cpp(oracle):
                 if count:
                     assert np.abs(out - want).max() <= FFT_TOL * np.abs(want).max(), (name, k, float(np.abs(out - want).max()))
     assert ncalls == 20
+
+
+def test_audio_nco_phase_increment_matches_reference_rx_sound_cmd_cpp():
+    """Row D6: rx_sound_set_freq() of rx/rx_sound_cmd.cpp ITSELF (built in place; sndcmd_ref.npz: 396 frequencies over three ADC clocks,
+    both display bandwidths, spectral inversion on and off, the band edges): the 48-bit word it hands to spi_set3(CmdSetRXFreq) equals
+    the host mirror's (ddc.rx_phase_inc), which is what kg_rxddc_set_freq is given."""
+    from flydog_sdr_gps_amd import ddc
+    g = np.load(os.path.join(GOLD, "sndcmd_ref.npz"))
+    assert len(g["calls"]) == 396
+    for (f_khz, adc, srate, inv), want in zip(g["calls"], g["i_phase"]):
+        got = ddc.rx_phase_inc(f_khz * 1000.0, adc_clock=adc, spectral_inversion=bool(inv), ui_srate=srate)
+        assert got == int(want), (f_khz, adc, srate, inv, hex(got), hex(int(want)))

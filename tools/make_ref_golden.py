@@ -17,6 +17,7 @@ the outputs the reference's code produced for them.
                   S-meter, AM / NBFM detectors with m_AM_FIR / m_Squelch, SSB AGC, de-emphasis -- every mode family, both rates
   wfcmd_ref.npz   c2s_waterfall()'s own statements for `SET zoom= start= / cf=` (rx/rx_waterfall.cpp:365-529, 756-928, cut at build time):
                   the SPI words (decimation, 48-bit NCO offset), fft_used / plot_width, fft2wf_map[], drop_sample[], fft_scale[] with masks
+  sndcmd_ref.npz  rx_sound_set_freq() (rx/rx_sound_cmd.cpp): frequency -> the 48-bit phase increment it hands to spi_set3(CmdSetRXFreq)
   dpump_ref.npz   snd_service() (rx/data_pump.cpp): SPI buffers of rx_iq_t records + trailer -> in_samps rings, ticks, rescale
   chan_ref.npz    CHANNEL::Start (gps/channel.cpp): acquisition results -> the SPI commands that program a tracking channel
 """
@@ -470,6 +471,22 @@ with tempfile.TemporaryDirectory() as tmp:
             cname, len(cmds), len(maps), int(sum((s_[:h[7]] == 0).sum() for s_, h in zip(scales, hdr)))))
 wc["names"] = np.array([c[0] for c in wc_scen])
 np.savez_compressed(os.path.join(GOLD, "wfcmd_ref.npz"), **wc)
+
+# ---- rx_sound_set_freq(): the audio NCO's phase increment (row D6) -------------------------------------------------------------
+rng = np.random.Generator(np.random.PCG64(0x5EED0063))
+fq = []
+for adc, srate in ((66.6666e6, 30.0e6), (66.672e6, 32.0e6), (66.66599e6, 30.0e6)):
+    for inv in (0, 1):
+        for f in [0.0, 0.001, 7020.0, 14250.5, 29999.999, srate / 1000.0] + [float(np.round(rng.uniform(0.0, srate / 1000.0), 3)) for _ in range(60)]:
+            fq.append((f, adc, srate, inv))
+with tempfile.TemporaryDirectory() as tmp:
+    open(os.path.join(tmp, "s.txt"), "w").write("".join("F %r %r %r %d\n" % q for q in fq))
+    run([os.path.join(REF, "sndcmd_ref"), os.path.join(tmp, "s.txt"), os.path.join(tmp, "out.bin")])
+    y = np.fromfile(os.path.join(tmp, "out.bin"), np.float64).reshape(-1, 4)
+assert y.shape[0] == len(fq) and np.all(y[:, 0] == 1) and np.all(y[:, 1] == 3)
+np.savez_compressed(os.path.join(GOLD, "sndcmd_ref.npz"), calls=np.array(fq, np.float64),
+                    i_phase=(y[:, 2].astype(np.uint64) << np.uint64(16)) | y[:, 3].astype(np.uint64))
+print("sndcmd_ref.npz: %d rx_sound_set_freq calls" % len(fq))
 
 # ---- data pump unpack -----------------------------------------------------------------------------
 rng = np.random.Generator(np.random.PCG64(0x5EED00D9))
