@@ -835,7 +835,11 @@ int kg_post_squelch_perform_dev(kg_post *p, const int32_t *chans, int nch, const
 
 int kg_post_set_am_passband(kg_post *p, int ch, double locut, double hicut, double frate)
 {
-    // rx_sound_cmd.cpp:268-282: "hbw for post AM det is max of hi/lo filter cuts"
+    // rx_sound_cmd.cpp:248-250: the handler first clamps the client's cuts to the Nyquist limit less one (idempotent for a caller that
+    // passes the clamped s->locut / s->hicut); :268-282: "hbw for post AM det is max of hi/lo filter cuts"
+    const int fmax = frate / 2 - 1;
+    if (hicut > fmax) hicut = fmax;
+    if (locut < -fmax) locut = -fmax;
     float hbw = fmaxf(fabs(hicut), fabs(locut));
     if (hbw > frate / 2) hbw = frate / 2;
     float stop = hbw * 1.8;

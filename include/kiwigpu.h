@@ -481,7 +481,8 @@ int kg_post_cfir_process_dev(kg_post *post, const int32_t *chans, int nch, int w
  * squelched); the return values through kg_post_squelch_state.  Enqueue only. */
 int kg_post_squelch_perform_dev(kg_post *post, const int32_t *chans, int nch, const void *d_in, size_t in_stride, int nsamps,
                                 void *d_out, size_t out_stride);
-/* The post-AM-detector filter as a passband change designs it (rx/rx_sound_cmd.cpp:268-282): hbw = max(|hicut|, |locut|)
+/* The post-AM-detector filter as a passband change designs it (rx/rx_sound_cmd.cpp:248-250, 268-282): the cuts clamped to
+ * +-(frate / 2 - 1) as the handler clamps s->locut / s->hicut (a no-op for a caller that passes those), hbw = max(|hicut|, |locut|)
  * capped at frate / 2, stop = 1.8 hbw capped at frate / 2, m_AM_FIR.InitLPFilter(0, 1.0, 50.0, hbw, stop, frate).  Returns the
  * tap count.  A channel in KG_POST_AM mode without it is refused (the reference's undesigned CFir holds garbage). */
 int kg_post_set_am_passband(kg_post *post, int chan, double locut, double hicut, double frate);

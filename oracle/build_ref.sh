@@ -188,7 +188,17 @@ if [ -f "$HIPFFTW_H" ] && [ -f /opt/rocm/lib/libhipfftw.so ]; then
         "$HERE/ref/ref_wfcmd_main.cpp" "$R/support/str.cpp" -lm $UNRES
     # the audio NCO's phase increment (row D6): rx_sound_set_freq() of rx/rx_sound_cmd.cpp, the file linked in place; the driver records
     # the words it hands to spi_set3.  Runs HERE.
-    $CXX $OPT $DEF $FINC $ALLD -no-pie -o "$OUT/sndcmd_ref" "$HERE/ref/ref_sndcmd_main.cpp" "$R/rx/rx_sound_cmd.cpp" -lm $UNRES
+    # ... and the passband statements of its `SET mod= low_cut= high_cut=` handler (:243-272, 276-286: clamp, normalised passband, hbw / stop,
+    # m_AM_FIR's design), cut at build time like the ranges above; the lines between the cuts are the two CFastFIR::SetupParameters calls
+    SCMD="$R/rx/rx_sound_cmd.cpp"
+    mkdir -p "$W/sndcmdcut"
+    cut_lines "$SCMD" 243 272 "$W/sndcmdcut/pb_a.inc" 'bool no_pb_change = (_hicut == 0 && _locut == 0);' ''
+    sed -n '269p' "$SCMD" | grep -qF 'float hbw = fmaxf(fabs(s->hicut), fabs(s->locut));' && sed -n '274p' "$SCMD" | grep -qF 'm_PassbandFIR[rx_chan].SetupParameters' \
+        && sed -n '275p' "$SCMD" | grep -qF 'm_chan_null_FIR[rx_chan].SetupParameters' || { echo "build_ref.sh: the passband statements are not at rx_sound_cmd.cpp:243-286"; exit 1; }
+    cut_lines "$SCMD" 276 286 "$W/sndcmdcut/pb_b.inc" 'conn->half_bw = hbw;' '}'
+    sed -n '282p' "$SCMD" | grep -qF 'm_AM_FIR[rx_chan].InitLPFilter(0, 1.0, 50.0, hbw, stop, frate);' || { echo "build_ref.sh: m_AM_FIR's design is not at rx_sound_cmd.cpp:282"; exit 1; }
+    $CXX $OPT $DEF $FINC $ALLD -I"$W/sndcmdcut" '-DSNDCMD_CUT_PB_A="pb_a.inc"' '-DSNDCMD_CUT_PB_B="pb_b.inc"' -no-pie -o "$OUT/sndcmd_ref" \
+        "$HERE/ref/ref_sndcmd_main.cpp" "$R/rx/rx_sound_cmd.cpp" "$R/rx/CuteSDR/fir.cpp" -lm $UNRES
     FFT_BUILT=" fastfir_ref search_ref wf_ref dpump_ref chan_ref sndpath_ref wfcmd_ref sndcmd_ref"
 else
     echo "hipFFTW absent: the FFT-dependent reference files are not built"

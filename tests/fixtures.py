@@ -65,6 +65,21 @@ def run_squelch_script(sq, script, x):
     return np.concatenate(out)
 
 
+def am_passband(lo, hi, rate):
+    """The passband statements of the `SET mod= low_cut= high_cut=` handler (rx/rx_sound_cmd.cpp:248-250, 268-282; pinned by the
+    reference's own statements: tests/golden/sndcmd_ref.npz): -> (locut, hicut as clamped to +-(int)(rate / 2 - 1), hbw, stop of m_AM_FIR)"""
+    import numpy as np
+    fmax = int(rate / 2 - 1)
+    hi, lo = min(float(hi), float(fmax)), max(float(lo), float(-fmax))
+    hbw = np.float32(max(np.float32(abs(hi)), np.float32(abs(lo))))
+    if float(hbw) > rate / 2:
+        hbw = np.float32(rate / 2)
+    stop = np.float32(float(hbw) * 1.8)
+    if float(stop) > rate / 2:
+        stop = np.float32(rate / 2)
+    return lo, hi, hbw, stop
+
+
 def arm_audio_tail(P, ch, rate=12000.0, hbw=4900.0, squelch=0):
     """What the reference has always done before a channel can demodulate AM / NBFM: the post-detector filter of the passband
     command (rx/rx_sound_cmd.cpp:268-282) and the squelch of a new connection (rx/rx_sound.cpp:261-262)."""

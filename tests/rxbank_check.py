@@ -25,8 +25,8 @@ class AudioTail:
         self.mode, lo, hi, fs, self.de_emp, squelch = audio if audio is not None else (post.MODE_SSB, 300.0, 2700.0, 12000.0, 0, 0)
         self.z1, self.last = 0.0, (0.0, 0.0)
         self.am = ko.CFir()
-        hbw = np.float32(min(float(np.float32(max(abs(hi), abs(lo)))), fs / 2))        # rx_sound_cmd.cpp:268-282
-        stop = np.float32(min(float(np.float32(float(hbw) * 1.8)), fs / 2))
+        from tests.fixtures import am_passband
+        _, _, hbw, stop = am_passband(lo, hi, fs)                                       # rx_sound_cmd.cpp:248-250, 268-282
         self.am.init_lp(0, 1.0, 50.0, hbw, stop, fs)
         self.sq = ko.Squelch()
         self.sq.setup(fs)

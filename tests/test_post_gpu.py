@@ -295,9 +295,8 @@ def oracle_chain(oracle, prm, mode, blocks, rate, hbw, squelch, de_emp, nfm_flag
     a.set_parameters(*prm)
     z1, last = 0.0, (0.0, 0.0)
     am = oracle.CFir()
-    hb = np.float32(min(float(np.float32(hbw)), rate / 2))                         # rx_sound_cmd.cpp:268-281: float hbw, double frate
-    stop = np.float32(float(hb) * 1.8)
-    stop = np.float32(min(float(stop), rate / 2))
+    from tests.fixtures import am_passband
+    _, _, hb, stop = am_passband(-hbw, hbw * 0.5, rate)                             # rx_sound_cmd.cpp:248-250, 268-282 (the cuts the test sets)
     am.init_lp(0, 1.0, 50.0, hb, stop, rate)
     sq = oracle.Squelch()
     sq.setup(rate)

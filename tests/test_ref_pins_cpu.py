@@ -628,3 +628,27 @@ def test_audio_nco_phase_increment_matches_reference_rx_sound_cmd_cpp():
     for (f_khz, adc, srate, inv), want in zip(g["calls"], g["i_phase"]):
         got = ddc.rx_phase_inc(f_khz * 1000.0, adc_clock=adc, spectral_inversion=bool(inv), ui_srate=srate)
         assert got == int(want), (f_khz, adc, srate, inv, hex(got), hex(int(want)))
+
+
+def test_passband_statements_match_reference_rx_sound_cmd_cpp(oracle):
+    """The passband part of the `SET mod= low_cut= high_cut=` handler -- rx/rx_sound_cmd.cpp:243-272, 276-286, the reference's own
+    statements cut out of the file at build time around its own CFir (sndcmd_ref.npz, 37 passbands: both rates, cuts beyond the
+    Nyquist limit, one-sided and narrow passbands, the all-zero "no change" command): the clamped cuts CFastFIR::SetupParameters is
+    given, the half bandwidth, and m_AM_FIR's taps read back through an impulse -- the helper every AM test uses
+    (tests/fixtures.am_passband) and the oracle's CFir design: EQUAL, taps bit for bit."""
+    from tests.fixtures import am_passband
+    g = np.load(os.path.join(GOLD, "sndcmd_ref.npz"))
+    assert len(g["bands"]) == 37
+    clamped = 0
+    for (lo, hi, rate), (w_lo, w_hi, _, _, _, w_hbw), w_taps in zip(g["bands"], g["band_out"], g["am_fir"]):
+        if lo == 0 and hi == 0:                                   # no_pb_change: nothing is touched
+            assert (w_lo, w_hi) == (0, 0) and not w_taps.any()
+            continue
+        c_lo, c_hi, hbw, stop = am_passband(lo, hi, rate)
+        assert (c_lo, c_hi, float(hbw)) == (w_lo, w_hi, w_hbw), (lo, hi, rate, c_lo, c_hi, hbw, w_lo, w_hi, w_hbw)
+        clamped += (c_lo, c_hi) != (lo, hi)
+        f = oracle.CFir()
+        n = f.init_lp(0, 1.0, 50.0, hbw, stop, rate)
+        taps = np.asarray(f.taps(), np.float32)
+        assert n == taps.size <= 97 and np.array_equal(taps.view(np.uint32), w_taps[:n].view(np.uint32)) and not w_taps[n:].any(), (lo, hi, rate, n)
+    assert clamped >= 7

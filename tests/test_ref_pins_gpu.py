@@ -399,3 +399,20 @@ def test_fastfir_extension_taps_on_the_gpu_match_reference_fastfir_cpp(gpu_ctx):
                         assert np.abs(out - want).max() <= FFT_TOL * np.abs(want).max(), (name, k, float(np.abs(out - want).max()))
     finally:
         F.close()
+
+
+def test_am_passband_on_the_gpu_matches_reference_rx_sound_cmd_cpp(gpu_ctx):
+    """kg_post_set_am_passband against the reference's own passband statements (rx/rx_sound_cmd.cpp:243-286 cut at build time around
+    its own CFir; sndcmd_ref.npz): the taps the library designs for the client's cuts -- beyond the Nyquist limit included, where the
+    handler clamps them first -- equal m_AM_FIR's, bit for bit."""
+    g = np.load(os.path.join(GOLD, "sndcmd_ref.npz"))
+    P = Post(gpu_ctx, nchan=1)
+    try:
+        for (lo, hi, rate), w_taps in zip(g["bands"], g["am_fir"]):
+            if lo == 0 and hi == 0:
+                continue
+            n = P.set_am_passband(0, lo, hi, rate)
+            taps = P.cfir_taps(0, post.CFIR_AM)
+            assert n == taps.size and np.array_equal(taps.view(np.uint32), w_taps[:n].view(np.uint32)) and not w_taps[n:].any(), (lo, hi, rate, n)
+    finally:
+        P.close()

@@ -13,7 +13,7 @@ from flydog_sdr_gps_amd import (Adpcm, Context, Ddc, FastFir, Post, RxDdc, Searc
                                 wire)
 from flydog_sdr_gps_amd.ddc import RX_DECIM   # noqa: E402
 from oracle import kiwi_oracle as ko          # noqa: E402
-from tests.fixtures import arm_audio_tail, oracle_row    # noqa: E402
+from tests.fixtures import am_passband, arm_audio_tail, oracle_row    # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
 only = sys.argv[3] if len(sys.argv) > 3 else None
@@ -215,8 +215,7 @@ def trial_tail():
             lo = -float(rng.uniform(50, rate / 2 + 500))
             hi = float(rng.uniform(50, rate / 2 + 500))
             n1 = P.set_am_passband(0, lo, hi, rate)
-            hbw = np.float32(min(float(np.float32(max(abs(hi), abs(lo)))), rate / 2))
-            stop = np.float32(min(float(np.float32(float(hbw) * 1.8)), rate / 2))
+            _, _, hbw, stop = am_passband(lo, hi, rate)
             assert n1 == f.init_lp(0, 1.0, 50.0, hbw, stop, rate), "am fir taps"
         elif kind == 1:                                            # any low-pass the interface takes
             a = (int(rng.choice([0, 0, 5, 33, 96, 97])), float(rng.uniform(0.2, 2.0)), float(rng.uniform(10, 80)),

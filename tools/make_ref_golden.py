@@ -484,9 +484,20 @@ with tempfile.TemporaryDirectory() as tmp:
     run([os.path.join(REF, "sndcmd_ref"), os.path.join(tmp, "s.txt"), os.path.join(tmp, "out.bin")])
     y = np.fromfile(os.path.join(tmp, "out.bin"), np.float64).reshape(-1, 4)
 assert y.shape[0] == len(fq) and np.all(y[:, 0] == 1) and np.all(y[:, 1] == 3)
+# ... and the passband statements of the `SET mod= low_cut= high_cut=` handler (rx_sound_cmd.cpp:243-272, 276-286, cut at build time)
+bands = [(-4900.0, 4900.0, 12000.0), (-6000.0, 6000.0, 12000.0), (300.0, 2700.0, 12000.0), (-2700.0, -300.0, 12000.0), (-2500.0, 2500.0, 12000.0),
+         (-1200.0, 1250.0, 12000.0), (450.0, 550.0, 12000.0), (-5999.0, 5999.0, 12000.0), (-9000.0, 2000.0, 12000.0), (100.0, 8000.0, 12000.0),
+         (0.0, 0.0, 12000.0), (-6000.0, 6000.0, 20250.0), (-10124.0, 10124.0, 20250.0), (-12000.0, 12000.0, 20250.0), (300.0, 3600.0, 20250.0),
+         (-5623.0, 5629.5, 20250.0), (0.0, 40.0, 12000.0)]
+bands += [(float(-np.round(rng.uniform(0, 7000), 1)), float(np.round(rng.uniform(0, 7000), 1)), 12000.0) for _ in range(20)]
+with tempfile.TemporaryDirectory() as tmp:
+    open(os.path.join(tmp, "s.txt"), "w").write("".join("B %r %r %r\n" % b for b in bands))
+    run([os.path.join(REF, "sndcmd_ref"), os.path.join(tmp, "s.txt"), os.path.join(tmp, "out.bin")])
+    yb = np.fromfile(os.path.join(tmp, "out.bin"), np.float64).reshape(len(bands), 134)
 np.savez_compressed(os.path.join(GOLD, "sndcmd_ref.npz"), calls=np.array(fq, np.float64),
-                    i_phase=(y[:, 2].astype(np.uint64) << np.uint64(16)) | y[:, 3].astype(np.uint64))
-print("sndcmd_ref.npz: %d rx_sound_set_freq calls" % len(fq))
+                    i_phase=(y[:, 2].astype(np.uint64) << np.uint64(16)) | y[:, 3].astype(np.uint64),
+                    bands=np.array(bands, np.float64), band_out=yb[:, :6], am_fir=yb[:, 6:].astype(np.float32))
+print("sndcmd_ref.npz: %d rx_sound_set_freq calls, %d passbands" % (len(fq), len(bands)))
 
 # ---- data pump unpack -----------------------------------------------------------------------------
 rng = np.random.Generator(np.random.PCG64(0x5EED00D9))
