@@ -53,6 +53,9 @@ def test_powf_and_expf_strided_over_every_argument(gpu_ctx, oracle):
     bits = np.concatenate([np.arange(0, 1 << 32, 509, dtype=np.uint64).astype(np.uint32),                 # 8.4 M patterns, both signs, NaNs
                            np.array([0, 0x80000000, 0x7f800000, 0xff800000, 0x7fc00000, 0x4202422f, 0xc27c65d9, 0x42b17218, 0x42b17219,
                                      0xc2cff1b4, 0xc2cff1b5, 0x421a209a, 0x421a209b, 0xc23369f4, 0x3f800000, 0xbf800000, 1, 0x80000001], np.uint32)])
+    fma_host = "fma" in open("/proc/cpuinfo").read().split("flags", 1)[-1].split("\n", 1)[0].split()
+    if not fma_host:        # glibc's baseline expf evaluates its residual unfused: 0x4202422f and 0xc27c65d9 then differ from the FMA build's (and the device's)
+        bits = bits[~np.isin(bits, np.array([0x4202422f, 0xc27c65d9], np.uint32))]
     x = bits.view(np.float32)
     for name, got, want in (("powf", post.math_dev(gpu_ctx, post.MATH_POWF, x, base=10.0), oracle.libm_powf(10.0, x)),
                             ("expf", post.math_dev(gpu_ctx, post.MATH_EXPF, x), oracle.libm_expf(x)),
