@@ -219,3 +219,96 @@ def test_cpp_bank_caller_equals_the_python_mirror(tmp_path):
         bank.ctx.free(d_adc)
     finally:
         bank.close()
+
+
+# ---- the audio chain from C++ ------------------------------------------------------------------------------------------
+SND_EXE = os.path.join(ROOT, "examples", "sound_dropin")
+
+
+def test_cpp_sound_caller_equals_the_python_mirror(gpu_ctx, tmp_path):
+    """examples/sound_dropin.cpp -- snd_service()'s unpack, CFastFIR, the S-meter / AGC / detector / filter stage, the payload coders
+    and the packet header through include/kiwigpu.h from plain C++, on 40 SPI buffers of 170 records for six connections (USB and AM
+    with ADPCM, NBFM behind a squelch as raw little-endian audio, IQ in both byte orders, LSB with de-emphasis in network order):
+    every packet it writes -- header, sequence number, S-meter field, flags, payload -- equals the Python mirror's, made with the
+    same entry points.  (What those entry points compute is held to the reference elsewhere: tests/test_ref_pins_gpu.py.)"""
+    import struct
+    from flydog_sdr_gps_amd import FastFir, Post, deemp, post, snd, wire
+    assert os.path.exists(SND_EXE), "examples/sound_dropin is not built (run __graft_entry__.build())"
+    rate, nsamps, nbuf, cal = 12000.0, 170, 40, np.float32(-13)
+    chans = [   # mode, agc (on, hang, thresh, manGain, slope, decay), de_emp, nfm, squelch, compression, little_endian, lo, hi
+        (post.MODE_SSB, (1, 0, -100, 50, 6, 1000), 0, 0, 0, 1, 0, 300.0, 2700.0),
+        (post.MODE_AM, (1, 0, -100, 50, 6, 1000), 1, 0, 0, 1, 0, -4900.0, 4900.0),
+        (post.MODE_NBFM, (1, 0, -100, 50, 6, 1000), 0, 0, 80, 0, 1, -6000.0, 6000.0),
+        (post.MODE_IQ, (1, 1, -90, 50, 3, 500), 0, 0, 0, 1, 0, -5000.0, 5000.0),
+        (post.MODE_IQ, (0, 0, -100, 70, 6, 1000), 0, 0, 0, 1, 1, -5000.0, 5000.0),
+        (post.MODE_SSB, (1, 0, -100, 50, 6, 1000), 2, 0, 0, 0, 0, -2700.0, -300.0),
+    ]
+    nch = len(chans)
+    rng = np.random.default_rng(2024)
+    t = np.arange(nsamps * nbuf)
+    i24, q24 = np.zeros((t.size, nch), np.int64), np.zeros((t.size, nch), np.int64)
+    for ch in range(nch):
+        z = 2.0e5 * (1 + 0.5 * np.sin(2 * np.pi * t / (40.0 + ch))) * np.exp(2j * np.pi * (0.05 + 0.013 * ch) * t) + rng.normal(0, 2000, t.size) \
+            + 1j * rng.normal(0, 2000, t.size)
+        i24[:, ch], q24[:, ch] = np.rint(z.real).astype(np.int64), np.rint(z.imag).astype(np.int64)
+    raw = snd.pack_rx_iq(i24, q24)
+    cfg = struct.pack("<iiiff", nch, nsamps, nbuf, rate, snd.RESCALE)
+    for mode, agc, de, nfm, sqv, comp, le, lo, hi in chans:
+        taps = np.zeros(79, np.float32)
+        if de:
+            taps[:] = deemp.table(bool(nfm), True)[de - 1]
+        cfg += struct.pack("<12iff", mode, *agc, de, nfm, sqv, comp, le, lo, hi) + taps.tobytes()
+    cb, rb, ob = tmp_path / "cfg.bin", tmp_path / "raw.bin", tmp_path / "out.bin"
+    cb.write_bytes(cfg); rb.write_bytes(raw.tobytes())
+    r = subprocess.run([SND_EXE, str(cb), str(rb), str(ob)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    data, got, pos = ob.read_bytes(), [], 0
+    while pos < len(data):
+        ch, nb = struct.unpack_from("<ii", data, pos)
+        got.append((ch, np.frombuffer(data, np.uint8, nb, pos + 8)))
+        pos += 8 + nb
+
+    # the same calls from Python
+    F, P, A = FastFir(gpu_ctx, nchan=nch, max_in=nsamps), Post(gpu_ctx, nchan=nch), wire.Adpcm(gpu_ctx, nchan=nch)
+    try:
+        for ch, (mode, agc, de, nfm, sqv, comp, le, lo, hi) in enumerate(chans):
+            lo, hi = max(lo, -(rate / 2 - 1)), min(hi, rate / 2 - 1)            # rx_sound_cmd.cpp:248-250
+            assert F.setup(ch, lo, hi, 0.0, rate)
+            P.set_smeter(ch, rate); P.set_agc(ch, *agc, rate); P.set_am_passband(ch, lo, hi, rate)
+            P.squelch_setup(ch, rate); P.squelch_set(ch, sqv, 0)
+            P.set_de_emp(ch, de, nfm, snd_rate_12k=True, frate=rate)
+            P.set_mode(ch, mode); P.reset(ch)
+        want, pend, seq = [], [np.zeros(0, np.uint8) for _ in chans], [0] * nch
+        for b in range(nbuf):
+            x = snd.unpack(gpu_ctx, raw[b * nsamps * nch * 6:(b + 1) * nsamps * nch * 6], nsamps, nch)
+            for ch, (mode, agc, de, nfm, sqv, comp, le, lo, hi) in enumerate(chans):
+                y = F.process(ch, x[ch])
+                if y.size == 0:
+                    continue
+                assert y.size == 512
+                s16, _, agc_out = P.process([ch], y[None, :])
+                if mode == post.MODE_IQ:
+                    pay = wire.snd_iq_payload(gpu_ctx, agc_out[0][None, :], le).reshape(-1)
+                elif comp:
+                    pay = A.encode([ch], s16[0][None, :]).reshape(-1)
+                else:
+                    pay = wire.snd_payload(gpu_ctx, s16[0][None, :], le).reshape(-1)
+                pend[ch] = np.concatenate([pend[ch], pay])
+                if pend[ch].size < 1024:
+                    continue
+                avg, _ = P.smeter([ch])
+                _, sq, _ = P.squelch_state([ch])
+                iq = mode == post.MODE_IQ
+                flags = (0x08 if iq else 0) | (0x10 if comp and not iq else 0) | (0x40 if sq[0] else 0) | (0x80 if le else 0)
+                seq[ch] += 1
+                want.append((ch, np.concatenate([wire.snd_header(gpu_ctx, flags, seq[ch], float(np.float32(avg[0]) + cal)), pend[ch]])))
+                pend[ch] = np.zeros(0, np.uint8)
+    finally:
+        A.close(); P.close(); F.close()
+    assert len(got) == len(want) >= 40, (len(got), len(want))
+    sizes = {ch: set() for ch in range(nch)}
+    for k, ((gc, gp), (wc, wp)) in enumerate(zip(got, want)):
+        assert gc == wc and gp.size == wp.size and np.array_equal(gp, wp), (k, gc, wc, gp.size, wp.size, int(np.argmax(gp[:min(gp.size, wp.size)] != wp[:min(gp.size, wp.size)])))
+        assert bytes(gp[:3]) == b"SND"
+        sizes[gc].add(gp.size)
+    assert sizes == {0: {1034}, 1: {1034}, 2: {1034}, 3: {2058}, 4: {2058}, 5: {1034}}, sizes
