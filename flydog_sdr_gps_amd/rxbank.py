@@ -129,8 +129,11 @@ class RxBank:
         filter and the post-AM-detector filter designed with it (rx/rx_sound_cmd.cpp:268-282), AGC / S-meter / detector, the
         squelch of a new connection (rx/rx_sound.cpp:261-262) then the command's value, the mode's de-emphasis filter."""
         fs = self.fs if fs is None else fs
+        fmax = int(fs / 2 - 1)                          # the handler clamps the client's cuts first (rx_sound_cmd.cpp:248-250)
+        lo, hi = max(float(lo), float(-fmax)), min(float(hi), float(fmax))
         self.rxddc.set_freq(rx, phase_inc)
-        self.fir.setup(rx, lo, hi, 0.0, fs)
+        if not self.fir.setup(rx, lo, hi, 0.0, fs):
+            raise ValueError("set_audio: CFastFIR::SetupParameters rejects the passband %g .. %g Hz at %g Hz (fastfir.cpp:193-200)" % (lo, hi, fs))
         self.post.set_am_passband(rx, lo, hi, fs)
         self.post.set_agc(rx, True, False, -100, 50, 6, 1000, fs)
         self.post.set_smeter(rx, fs)
